@@ -1,0 +1,178 @@
+/*
+ * bowtie_amd.h -- C ABI of the MI355X-native FM-index search hot path.
+ *
+ * This is the drop-in boundary for the one data-parallel path of BenLangmead/bowtie v1.3.1 that
+ * this project accelerates: everything a reference worker thread does for a read between
+ * GET_READ and FINISH_READ (ebwt_search.cpp:923-961) in the default (non --best, unpaired)
+ * search modes:
+ *
+ *     exactSearchWorker                    ebwt_search.cpp:1130   (-v 0)
+ *     mismatchSearchWorkerFull             ebwt_search.cpp:1606   (-v 1)
+ *     twoOrThreeMismatchSearchWorkerFull   ebwt_search.cpp:2056   (-v 2)
+ *     seededQualSearchWorkerFull           ebwt_search.cpp:2378   (-n 0..3 -l -e)
+ *
+ * i.e. GreedyDFSRangeSource::backtrack (ebwt_search_backtrack.h:237-1091), the Ebwt rank/LF
+ * primitives (ebwt.h:1418-1523, 1696-2560), Ebwt::reportChaseOne/joinedToTextOff
+ * (ebwt.h:2569-2755), the phase scripts search_*.c and the per-read stop/continue policy of
+ * NGoodHitSinkPerThread / AllHitSinkPerThread (hit.h:969-985, 1201-1209).
+ *
+ * The reference has no FFI for this path (it is one C++ process); the seams this ABI replaces
+ * are cited per entry point.  Plain pointers and sizes only; no exceptions cross the boundary
+ * (the reference signals errors with `throw 1`, ebwt_search.cpp:3449-3461; here: int codes).
+ *
+ * All arithmetic on the path is integer (u8/u32/u64 + popcount).  Results are bit-identical to
+ * the reference's for the same reads, index and policy.
+ */
+#ifndef BOWTIE_AMD_H_
+#define BOWTIE_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------ */
+#define BT_OK              0
+#define BT_ERR_IO          1   /* index file missing / short read                             */
+#define BT_ERR_FORMAT      2   /* not a small little-endian lineRate-6 .ebwt index            */
+#define BT_ERR_ARG         3   /* bad policy / batch                                          */
+#define BT_ERR_DEVICE      4   /* HIP runtime error (no GPU, OOM, launch failure)             */
+#define BT_ERR_READ_SHORT  5   /* read shorter than the mode allows (reference: throw 1,
+                                  search_1mm_phase1.c:12-15, search_23mm_phase1.c:13-20)      */
+
+/* ---- policy: exactly the knobs the reference workers read -------------------------------- */
+#define BT_MODE_V 0            /* end-to-end, -v <mms>   (ebwt_search.cpp:3249-3268)          */
+#define BT_MODE_N 1            /* seeded/quality-aware, -n <mms> -l -e (ebwt_search.cpp:3243) */
+
+typedef struct bt_policy {
+	int32_t  mode;         /* BT_MODE_V | BT_MODE_N                                           */
+	int32_t  mms;          /* -v 0..2  or  -n 0..3 (seedMms)                                  */
+	int32_t  seed_len;     /* -l (default 28)                     ebwt_search.cpp:162         */
+	int32_t  qual_thresh;  /* -e (default 70)                     ebwt_search.cpp:163         */
+	int32_t  max_bts;      /* --maxbts (default 125; half-and-half searchers only enforce it,
+	                          ebwt_search_backtrack.h:428-434)                                */
+	int32_t  nofw;         /* --nofw                                                          */
+	int32_t  norc;         /* --norc                                                          */
+	int32_t  maq_round;    /* 1 unless --nomaqround               qual.cpp:4                  */
+	uint32_t khits;        /* -k (default 1)                      hit.h:969-985               */
+	uint32_t mhits;        /* -m (0xffffffff = unlimited)                                     */
+	int32_t  all_hits;     /* -a                                  hit.h:1201-1209             */
+	int32_t  reserved;
+} bt_policy;
+
+void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 -k 1          */
+
+/* ---- reads in: what PatternSourcePerThread hands the worker (read.h:42-273) -------------- */
+typedef struct bt_read_batch {
+	uint32_t        n_reads;
+	uint32_t        stride;   /* bytes per read row in seq[] and qual[] (>= max len)          */
+	const uint8_t*  seq;      /* [n_reads][stride]  A=0 C=1 G=2 T=3 N=4 (patFw)               */
+	const uint8_t*  qual;     /* [n_reads][stride]  Phred+33 ASCII (Read::qual)               */
+	const uint16_t* len;      /* [n_reads]          1..1024                                   */
+	const uint32_t* seed;     /* [n_reads]          Read::seed = genRandSeed (pat.cpp:21-57)  */
+} bt_read_batch;
+
+/* ---- hits out: the fields of Hit the search computes (hit.h:56-112, ebwt.h:1288-1405) ---- */
+typedef struct bt_hit {
+	uint32_t tidx;            /* Hit::h.first   reference sequence index                      */
+	uint32_t toff;            /* Hit::h.second  0-based offset of leftmost base               */
+	uint32_t oms;             /* Hit::oms       bot-top-1                                     */
+	uint32_t mm_off;          /* first entry of this hit's mismatches in mm_pool              */
+	uint16_t cost;            /* Hit::cost      ham | stratum<<14                             */
+	uint16_t nmm;             /* # mismatches                                                 */
+	uint8_t  stratum;         /* Hit::stratum                                                 */
+	uint8_t  fw;              /* Hit::fw                                                      */
+	uint8_t  pad[2];
+} bt_hit;                         /* 24 bytes */
+
+/* mm_pool entry: bits 0-9 = offset from the read's 5' end (Hit::mms), bits 12-13 = reference
+ * base at that offset in the orientation reported by the reference (Hit::refcs).            */
+#define BT_MM_POS(e)  ((uint32_t)(e) & 0x3ffu)
+#define BT_MM_REFC(e) (((uint32_t)(e) >> 12) & 3u)
+
+/* per-read status bits */
+#define BT_ST_SKIPPED   1u   /* -n mode: len<4 or too many Ns in seed (search_seeded_phase1.c:17-44) */
+#define BT_ST_HITCAP    2u   /* more reportable hits than hit_cap slots (slots hold the first ones)  */
+
+typedef struct bt_hit_batch {
+	uint32_t  hit_cap;        /* hit slots per read                                           */
+	bt_hit*   hits;           /* [n_reads][hit_cap]                                           */
+	uint32_t* n_hits;         /* [n_reads] HitSinkPerThread::hitsForThisRead_ at finishRead   */
+	uint8_t*  status;         /* [n_reads] BT_ST_*                                            */
+	uint16_t* mm_pool;        /* [mm_pool_cap]                                                */
+	uint32_t  mm_pool_cap;
+	uint32_t  mm_pool_used;   /* out                                                          */
+} bt_hit_batch;
+
+/* operation counters of one batch (what the reference counts under -DEBWT_STATS,
+ * ebwt.h:2343-2345, 2424-2426, 2462-2464, 2498-2500): feed the algorithmic-bytes model.     */
+typedef struct bt_op_counts {
+	uint64_t lfex;            /* two-locus all-char rank steps (mapLFEx)                      */
+	uint64_t lf2;             /* two-locus single-char steps (mapLF(ltop,c)+mapLF(lbot,c))    */
+	uint64_t lf1;             /* single-locus steps (mapLF1)                                  */
+	uint64_t chase;           /* SA-walk steps (mapLF(l) in reportChaseOne)                   */
+	uint64_t ftab;            /* ftab lookups (pairs)                                         */
+	uint64_t offs;            /* offs[] lookups                                               */
+	uint64_t rstarts;         /* rstarts probes                                               */
+	uint64_t frames;          /* backtrack frames entered                                     */
+} bt_op_counts;
+
+/* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */
+typedef struct bt_index_info {
+	uint32_t len, n_pat, n_frag, ftab_chars, off_rate, z_off;
+	uint64_t ebwt_bytes, offs_bytes;
+	int32_t  has_mirror;
+} bt_index_info;
+
+typedef struct bt_index bt_index;   /* device-resident fw (+ mirror) index image              */
+typedef struct bt_ctx   bt_ctx;     /* per-GPU stream, scratch, queues                        */
+
+/* Replaces: Ebwt ctor + Ebwt::loadIntoMemory for <base>.{1,2}.ebwt and, if need_mirror,
+ * <base>.rev.{1,2}.ebwt (ebwt.h:402-448, 2835-3445; ebwt_search.cpp:3120-3155); then uploads
+ * the arrays to the HBM of `device`.  offrate_override = -1 keeps the index's offRate (-o). */
+int  bt_index_load(const char* ebwt_base, int need_mirror, int offrate_override, int device,
+                   bt_index** out);
+void bt_index_info_get(const bt_index* idx, bt_index_info* info);
+const char* bt_index_refname(const bt_index* idx, uint32_t tidx);   /* Ebwt::refnames()      */
+uint32_t    bt_index_reflen (const bt_index* idx, uint32_t tidx);   /* Ebwt::plen()          */
+void bt_index_free(bt_index* idx);
+
+/* Replaces: the per-thread set-up at the top of each worker (sink, params, 1..9
+ * GreedyDFSRangeSource objects; ebwt_search.cpp:1155, 2082-2134, 2413-2539).  One ctx per GPU,
+ * driven by one host thread.  `stream` = a hipStream_t to launch on (NULL = own stream).   */
+int  bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* stream, bt_ctx** out);
+void bt_ctx_destroy(bt_ctx* ctx);
+
+/* Replaces: the body of the worker loop for a batch of reads (FINISH_READ/GET_READ/#include
+ * "search_*.c"; ebwt_search.cpp:1183-1199, 1660-1682, 2151-2176, 2557-2585).
+ *   bt_align_batch         : host pointers in `in`/`out`; copies H2D, runs, copies D2H.
+ *   bt_align_batch_device  : every pointer in `in`/`out` is a device pointer (reads already in
+ *                            HBM, hits stay in HBM); asynchronous on the ctx stream.  `counts`
+ *                            (optional, device pointer to bt_op_counts) is accumulated into. */
+int  bt_align_batch(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, bt_op_counts* counts);
+int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out,
+                           bt_op_counts* counts_dev);
+int  bt_ctx_sync(bt_ctx* ctx);
+/* milliseconds the search kernel(s) of the last bt_align_batch[_device] call took, measured with
+ * HIP events on the ctx stream (valid after bt_ctx_sync). */
+float bt_ctx_last_kernel_ms(bt_ctx* ctx);
+
+const char* bt_strerror(int code);
+const char* bt_version(void);
+
+/* ---- kernel-level probes (known-answer tests against the reference's Ebwt methods) -------- */
+/* rows[n] -> lf[n][4] = mapLFEx (ebwt.h:2334), L[n] = rowL (ebwt.h:1696); mirror=1 probes the
+ * .rev index.  Host pointers. */
+int bt_probe_rank(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L);
+/* rows[n] -> joined-text offset via the SA walk of reportChaseOne (ebwt.h:2727-2746) and
+ * (tidx,toff) via joinedToTextOff (ebwt.h:2569) for a query of length qlen; tidx=0xffffffff when
+ * the hit straddles a fragment boundary. */
+int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t qlen,
+                   uint32_t* joined_off, uint32_t* tidx, uint32_t* toff);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOWTIE_AMD_H_ */

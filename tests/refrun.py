@@ -1,0 +1,60 @@
+"""Helpers shared by tests and oracle/gen_golden.py: run a search through a backend and render the
+reference's output formats; run the unmodified reference binary (oracle/_ref) when present."""
+from __future__ import annotations
+
+import os
+import subprocess
+from typing import List, Optional
+
+from bowtie_amd import output as O
+from bowtie_amd.reads import ReadBatch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
+
+
+def have_ref_binary() -> bool:
+    return os.path.exists(REF_BIN)
+
+
+def run_reference(args: List[str], index_base: str, reads_path: str) -> bytes:
+    """stdout of the unmodified reference, -p 1 (deterministic order)."""
+    cmd = [REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", index_base, reads_path]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    return p.stdout
+
+
+def render(batch: ReadBatch, per_read, refnames, sam: bool, mhits: int = 0xFFFFFFFF) -> bytes:
+    """per_read[i] = (hits(list of output.Hit), n_hits_total, status) -> reference-format text.
+
+    Verbose mode prints nothing for unaligned/maxed reads (hit.h:494-500); SAM prints a flag-4
+    record (sam.cpp:57-124)."""
+    out = []
+    for i in range(batch.n):
+        hits, total, status = per_read[i]
+        L = int(batch.len[i])
+        seq = batch.seq[i, :L]
+        qual = batch.qual[i, :L].tobytes()
+        name = batch.names[i]
+        maxed = total > mhits
+        if hits and not maxed:
+            for h in hits:
+                if sam:
+                    out.append(O.format_sam(name, seq, qual, h, refnames, xms=len(hits)))
+                else:
+                    out.append(O.format_verbose(name, seq, qual, h, refnames))
+        elif sam:
+            out.append(O.format_sam_unaligned(name, seq, qual, total if maxed else 0))
+    return b"".join(out)
+
+
+def oracle_search(oidx, pol, batch: ReadBatch, cap: Optional[int] = None, counts=None):
+    cap = cap or (64 if pol.all_hits else max(1, min(int(pol.khits), 64)))
+    res = []
+    for i in range(batch.n):
+        L = int(batch.len[i])
+        hits, total, st = oidx.align(pol, batch.seq[i, :L], batch.qual[i, :L].tobytes(),
+                                     int(batch.seed[i]), cap=cap, counts=counts)
+        res.append(([O.Hit(h["tidx"], h["toff"], h["oms"], h["cost"], h["stratum"], h["fw"], h["mms"])
+                     for h in hits], total, st))
+    return res
