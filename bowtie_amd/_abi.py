@@ -1,0 +1,57 @@
+"""ctypes mirror of include/bowtie_amd.h (plain-data structs only)."""
+from __future__ import annotations
+
+import ctypes as C
+
+BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, BT_ERR_OVERFLOW = range(7)
+BT_MODE_V, BT_MODE_N = 0, 1
+BT_ST_SKIPPED, BT_ST_HITCAP, BT_ST_TOOSHORT, BT_ST_OVERFLOW, BT_ST_MMPOOL = 1, 2, 4, 8, 16
+
+
+class Policy(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("mms", C.c_int32), ("seed_len", C.c_int32),
+                ("qual_thresh", C.c_int32), ("max_bts", C.c_int32), ("nofw", C.c_int32),
+                ("norc", C.c_int32), ("maq_round", C.c_int32), ("khits", C.c_uint32),
+                ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ReadBatchC(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("stride", C.c_uint32), ("seq", C.c_void_p),
+                ("qual", C.c_void_p), ("len", C.c_void_p), ("seed", C.c_void_p)]
+
+
+class HitC(C.Structure):
+    _fields_ = [("tidx", C.c_uint32), ("toff", C.c_uint32), ("oms", C.c_uint32), ("mm_off", C.c_uint32),
+                ("cost", C.c_uint16), ("nmm", C.c_uint16), ("stratum", C.c_uint8), ("fw", C.c_uint8),
+                ("pad", C.c_uint8 * 2)]
+
+
+class HitBatchC(C.Structure):
+    _fields_ = [("hit_cap", C.c_uint32), ("hits", C.c_void_p), ("n_hits", C.c_void_p),
+                ("status", C.c_void_p), ("mm_pool", C.c_void_p), ("mm_pool_cap", C.c_uint32),
+                ("mm_pool_used", C.c_uint32)]
+
+
+class OpCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("len", C.c_uint32), ("n_pat", C.c_uint32), ("n_frag", C.c_uint32),
+                ("ftab_chars", C.c_uint32), ("off_rate", C.c_uint32), ("z_off", C.c_uint32),
+                ("ebwt_bytes", C.c_uint64), ("offs_bytes", C.c_uint64), ("has_mirror", C.c_int32)]
+
+
+HIT_DTYPE = [("tidx", "<u4"), ("toff", "<u4"), ("oms", "<u4"), ("mm_off", "<u4"), ("cost", "<u2"),
+             ("nmm", "<u2"), ("stratum", "u1"), ("fw", "u1"), ("pad", "u1", (2,))]
+
+
+def make_policy(mode="n", mms=2, seed_len=28, qual_thresh=70, max_bts=125, nofw=False, norc=False,
+                maq_round=True, khits=1, mhits=0xFFFFFFFF, all_hits=False) -> Policy:
+    """Reference defaults: -n 2 -l 28 -e 70 --maxbts 125 -k 1 (ebwt_search.cpp:153-253)."""
+    return Policy(BT_MODE_V if mode == "v" else BT_MODE_N, mms, seed_len, qual_thresh, max_bts,
+                  int(nofw), int(norc), int(maq_round), khits, mhits, int(all_hits), 0)

@@ -1,0 +1,195 @@
+"""Host-side binding of the C ABI (include/bowtie_amd.h) -- the drop-in boundary.
+
+`Index` mirrors the reference's `Ebwt` objects (ebwt_search.cpp:3120-3155) and `Aligner` the
+per-thread worker loop (ebwt_search.cpp:1130/1606/2056/2378): reads in, `Hit` records out.
+There is no fallback: if bowtie_amd/libbowtie_amd.so (HIP, gfx950) is missing or no GPU is
+present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi as A
+from .output import Hit
+from .reads import ReadBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbowtie_amd.so")
+EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_refname",
+           "bt_index_reflen", "bt_index_free", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
+           "bt_align_batch_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used",
+           "bt_ctx_counts", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase"]
+_lib = None
+
+
+class BowtieAmdError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        self.code = code
+        super().__init__("%s: %s (code %d)" % (what, strerror(code), code))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("bowtie_amd: %s is missing -- build it with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.bt_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bt_index_info_get.argtypes = [C.c_void_p, C.POINTER(A.IndexInfo)]
+        L.bt_index_info_get.restype = None
+        L.bt_index_refname.argtypes = [C.c_void_p, C.c_uint32]
+        L.bt_index_refname.restype = C.c_char_p
+        L.bt_index_reflen.argtypes = [C.c_void_p, C.c_uint32]
+        L.bt_index_reflen.restype = C.c_uint32
+        L.bt_index_free.argtypes = [C.c_void_p]
+        L.bt_index_free.restype = None
+        L.bt_ctx_create.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.c_void_p, C.POINTER(C.c_void_p)]
+        L.bt_ctx_destroy.argtypes = [C.c_void_p]
+        L.bt_ctx_destroy.restype = None
+        L.bt_align_batch.argtypes = [C.c_void_p, C.POINTER(A.ReadBatchC), C.POINTER(A.HitBatchC),
+                                     C.POINTER(A.OpCounts)]
+        L.bt_align_batch_device.argtypes = [C.c_void_p, C.POINTER(A.ReadBatchC), C.POINTER(A.HitBatchC),
+                                            C.c_void_p]
+        L.bt_ctx_sync.argtypes = [C.c_void_p]
+        L.bt_ctx_last_kernel_ms.argtypes = [C.c_void_p]
+        L.bt_ctx_last_kernel_ms.restype = C.c_float
+        L.bt_ctx_last_mm_used.argtypes = [C.c_void_p]
+        L.bt_ctx_last_mm_used.restype = C.c_uint32
+        L.bt_ctx_counts.argtypes = [C.c_void_p, C.POINTER(A.OpCounts), C.c_int]
+        L.bt_strerror.argtypes = [C.c_int]
+        L.bt_strerror.restype = C.c_char_p
+        L.bt_version.restype = C.c_char_p
+        L.bt_probe_rank.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.bt_probe_chase.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bt_policy_default.argtypes = [C.POINTER(A.Policy)]
+        L.bt_policy_default.restype = None
+        _lib = L
+    return _lib
+
+
+def strerror(code: int) -> str:
+    return lib().bt_strerror(code).decode()
+
+
+class Index:
+    """Device-resident fw (+ mirror) index image: Ebwt ctor + loadIntoMemory + H2D upload."""
+
+    def __init__(self, base: str, need_mirror: bool = True, offrate: int = -1, device: int = 0):
+        self._h = C.c_void_p()
+        rc = lib().bt_index_load(base.encode(), int(need_mirror), offrate, device, C.byref(self._h))
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_index_load(%s)" % base)
+        info = A.IndexInfo()
+        lib().bt_index_info_get(self._h, C.byref(info))
+        self.info = info
+        self.refnames = [lib().bt_index_refname(self._h, i).decode() for i in range(info.n_pat)]
+        self.reflens = [int(lib().bt_index_reflen(self._h, i)) for i in range(info.n_pat)]
+
+    def close(self):
+        if self._h:
+            lib().bt_index_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unpack_hits(n: int, hit_cap: int, hits: np.ndarray, n_hits: np.ndarray, status: np.ndarray,
+                mm_pool: np.ndarray, khits: int, mhits: int, all_hits: bool):
+    """-> per read (hits: List[Hit], hitsForThisRead, status), applying finishRead's rules
+    (hit.h:741-786): a read over the -m ceiling reports nothing; otherwise the first -k hits."""
+    out = []
+    lim = hit_cap if all_hits else min(hit_cap, khits)
+    for i in range(n):
+        tot = int(n_hits[i])
+        hs: List[Hit] = []
+        if tot <= mhits:
+            for k in range(min(tot, lim)):
+                h = hits[i * hit_cap + k]
+                off, nmm = int(h["mm_off"]), int(h["nmm"])
+                mms = [(int(e) & 0x3FF, (int(e) >> 12) & 3) for e in mm_pool[off:off + nmm]]
+                hs.append(Hit(int(h["tidx"]), int(h["toff"]), int(h["oms"]), int(h["cost"]),
+                              int(h["stratum"]), bool(h["fw"]), mms))
+        out.append((hs, tot, int(status[i])))
+    return out
+
+
+class Aligner:
+    """One per GPU; `align(batch)` = the worker loop body over a batch of reads."""
+
+    def __init__(self, index: Index, policy: A.Policy, stream: Optional[int] = None):
+        self.index = index
+        self.policy = policy
+        self._h = C.c_void_p()
+        rc = lib().bt_ctx_create(index._h, C.byref(policy), C.c_void_p(stream) if stream else None,
+                                 C.byref(self._h))
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_ctx_create")
+
+    def close(self):
+        if self._h:
+            lib().bt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def default_hit_cap(self) -> int:
+        return 64 if self.policy.all_hits else max(1, min(int(self.policy.khits), 64))
+
+    def align(self, batch: ReadBatch, hit_cap: Optional[int] = None, mm_per_hit: int = 8,
+              counts: Optional[A.OpCounts] = None):
+        """Host arrays in, host arrays out (bt_align_batch).  Returns unpack_hits()'s list."""
+        n = batch.n
+        hit_cap = hit_cap or self.default_hit_cap()
+        seq = np.ascontiguousarray(batch.seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(batch.qual, dtype=np.uint8)
+        ln = np.ascontiguousarray(batch.len, dtype=np.uint16)
+        seed = np.ascontiguousarray(batch.seed, dtype=np.uint32)
+        hits = np.zeros(n * hit_cap, dtype=A.HIT_DTYPE)
+        n_hits = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint8)
+        pool = np.zeros(max(1, n * hit_cap * mm_per_hit), dtype=np.uint16)
+        rb = A.ReadBatchC(n, batch.stride, seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, seed.ctypes.data)
+        hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data,
+                         pool.ctypes.data, len(pool), 0)
+        rc = lib().bt_align_batch(self._h, C.byref(rb), C.byref(hb),
+                                  C.byref(counts) if counts is not None else None)
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_align_batch")
+        self.last_kernel_ms = float(lib().bt_ctx_last_kernel_ms(self._h))
+        return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(self.policy.khits),
+                           int(self.policy.mhits), bool(self.policy.all_hits))
+
+    def probe_rank(self, rows: np.ndarray, mirror: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        lf = np.zeros((len(rows), 4), dtype=np.uint32)
+        L = np.zeros(len(rows), dtype=np.uint8)
+        rc = lib().bt_probe_rank(self._h, int(mirror), rows.ctypes.data, len(rows), lf.ctypes.data, L.ctypes.data)
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_probe_rank")
+        return lf, L
+
+    def probe_chase(self, rows: np.ndarray, qlen: int, mirror: bool = False):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        j = np.zeros(len(rows), dtype=np.uint32)
+        t = np.zeros(len(rows), dtype=np.uint32)
+        o = np.zeros(len(rows), dtype=np.uint32)
+        rc = lib().bt_probe_chase(self._h, int(mirror), rows.ctypes.data, len(rows), qlen,
+                                  j.ctypes.data, t.ctypes.data, o.ctypes.data)
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_probe_chase")
+        return j, t, o

@@ -1,0 +1,380 @@
+/*
+ * bt_api.cpp -- the C ABI of include/bowtie_amd.h: index upload, per-GPU context, batch search.
+ * Host C++ only; the kernels live in bt_kernels.hip.  No CPU search path exists here: without a
+ * HIP device every entry point that computes returns BT_ERR_DEVICE.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/bowtie_amd.h"
+#include "bt_host.h"
+#include "bt_kernels.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+	fprintf(stderr, "bowtie_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+	return BT_ERR_DEVICE; } } while (0)
+
+struct bt_index {
+	int device = 0;
+	bool has_mirror = false;
+	BtIndexHost host[2];           /* big arrays are released after upload; names/plen stay */
+	BtIndexDev  dev[2];
+	std::vector<void*> allocs;
+	uint64_t ebwt_bytes = 0, offs_bytes = 0;
+};
+
+struct bt_ctx {
+	const bt_index* idx = nullptr;
+	bt_policy pol;
+	BtProgram prog;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool timed = false;
+	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
+	uint32_t *frames = nullptr, *pairs = nullptr; uint8_t* elims = nullptr; uint64_t* pals = nullptr;
+	uint32_t* d_cursor = nullptr;      /* [0] nextRead, [1] mm_pool_used */
+	unsigned long long* d_counts = nullptr;
+	/* staging for the host-pointer entry point */
+	void* stage = nullptr; size_t stage_bytes = 0;
+	uint32_t last_mm_used = 0;
+};
+
+template <class T> static int upload(bt_index* ix, const std::vector<T>& v, const T** out, size_t pad_elems = 0)
+{
+	void* p = nullptr;
+	size_t bytes = (v.size() + pad_elems) * sizeof(T);
+	if (bytes == 0) bytes = sizeof(T);
+	HIPCHK(hipMalloc(&p, bytes));
+	ix->allocs.push_back(p);
+	HIPCHK(hipMemset(p, 0, bytes));
+	if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+	*out = (const T*)p;
+	return BT_OK;
+}
+
+extern "C" void bt_policy_default(bt_policy* p)
+{
+	memset(p, 0, sizeof(*p));
+	p->mode = BT_MODE_N; p->mms = 2; p->seed_len = 28; p->qual_thresh = 70; p->max_bts = 125;
+	p->maq_round = 1; p->khits = 1; p->mhits = 0xffffffffu;
+}
+
+extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate_override, int device,
+                             bt_index** out)
+{
+	if (!ebwt_base || !out) return BT_ERR_ARG;
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return BT_ERR_DEVICE;
+	HIPCHK(hipSetDevice(device));
+	bt_index* ix = new bt_index();
+	ix->device = device;
+	ix->has_mirror = need_mirror != 0;
+	for (int m = 0; m < (need_mirror ? 2 : 1); m++) {
+		std::string base = std::string(ebwt_base) + (m ? ".rev" : "");
+		int rc = bt_host_index_load(base, m == 0, offrate_override, &ix->host[m]);
+		if (rc != BT_OK) { bt_index_free(ix); return rc; }
+		BtIndexHost& h = ix->host[m];
+		BtIndexDev& d = ix->dev[m];
+		bt_host_index_describe(h, &d);
+		int r2;
+		/* pad the ebwt image by one side pair so that the partner-counter load of the last side
+		 * never leaves the allocation */
+		if ((r2 = upload(ix, h.ebwt, &d.ebwt, 128)) || (r2 = upload(ix, h.ftab, &d.ftab)) ||
+		    (r2 = upload(ix, h.eftab, &d.eftab)) || (r2 = upload(ix, h.offs, &d.offs)) ||
+		    (r2 = upload(ix, h.rstarts, &d.rstarts)) || (r2 = upload(ix, h.plen, &d.plen))) {
+			bt_index_free(ix); return r2;
+		}
+		ix->ebwt_bytes += h.ebwt.size(); ix->offs_bytes += h.offs.size() * 4ull;
+		std::vector<uint8_t>().swap(h.ebwt);
+		std::vector<uint32_t>().swap(h.offs);
+		std::vector<uint32_t>().swap(h.ftab);
+	}
+	if (!need_mirror) ix->dev[1] = ix->dev[0];
+	*out = ix;
+	return BT_OK;
+}
+
+extern "C" void bt_index_info_get(const bt_index* idx, bt_index_info* info)
+{
+	memset(info, 0, sizeof(*info));
+	const BtIndexHost& h = idx->host[0];
+	info->len = h.len; info->n_pat = h.nPat; info->n_frag = h.nFrag; info->ftab_chars = (uint32_t)h.ftabChars;
+	info->off_rate = (uint32_t)h.offRate; info->z_off = h.zOff;
+	info->ebwt_bytes = idx->ebwt_bytes; info->offs_bytes = idx->offs_bytes;
+	info->has_mirror = idx->has_mirror ? 1 : 0;
+}
+extern "C" const char* bt_index_refname(const bt_index* idx, uint32_t tidx)
+{
+	return tidx < idx->host[0].refnames.size() ? idx->host[0].refnames[tidx].c_str() : nullptr;
+}
+extern "C" uint32_t bt_index_reflen(const bt_index* idx, uint32_t tidx)
+{
+	return tidx < idx->host[0].plen.size() ? idx->host[0].plen[tidx] : 0;
+}
+extern "C" void bt_index_free(bt_index* idx)
+{
+	if (!idx) return;
+	for (void* p : idx->allocs) (void)hipFree(p);
+	delete idx;
+}
+
+static uint32_t env_u32(const char* name, uint32_t dflt)
+{
+	const char* v = getenv(name);
+	return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
+static void ctx_free_scratch(bt_ctx* c)
+{
+	if (c->frames) (void)hipFree(c->frames);
+	if (c->pairs) (void)hipFree(c->pairs);
+	if (c->elims) (void)hipFree(c->elims);
+	if (c->pals) (void)hipFree(c->pals);
+	c->frames = c->pairs = nullptr; c->elims = nullptr; c->pals = nullptr;
+}
+
+/* (re)size the per-lane arenas for reads up to maxLen */
+static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen)
+{
+	if (c->frames && maxLen <= c->maxLen) return BT_OK;
+	ctx_free_scratch(c);
+	c->maxLen = maxLen < 64 ? 64 : maxLen;
+	const bool seeded = c->pol.mode == BT_MODE_N;
+	/* range-stack entries per lane: every frame may span the whole read.  -v k has k+1 frames;
+	 * -n: frames are bounded by -e / min penalty (10) unless the read has Phred<5 bases. */
+	uint32_t frames = seeded ? 12u : (uint32_t)c->pol.mms + 2u;
+	c->frCap = env_u32("BT_FRAME_CAP", seeded ? 64u : 8u);
+	c->entCap = env_u32("BT_ENTRY_CAP", frames * c->maxLen);
+	c->palCap = env_u32("BT_PARTIAL_CAP", seeded ? (c->pol.mms >= 3 ? 8192u : 1024u) : 1u);
+	HIPCHK(hipMalloc((void**)&c->frames, (size_t)c->nLanes * c->frCap * BT_FR_WORDS * 4u));
+	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nLanes * c->entCap * 32u));
+	HIPCHK(hipMalloc((void**)&c->elims, (size_t)c->nLanes * c->entCap));
+	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nLanes * c->palCap * 8u));
+	return BT_OK;
+}
+
+extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* stream, bt_ctx** out)
+{
+	if (!idx || !pol || !out) return BT_ERR_ARG;
+	*out = nullptr;
+	bt_ctx* c = new bt_ctx();
+	c->idx = idx; c->pol = *pol;
+	int rc = bt_host_compile_program(*pol, &c->prog);
+	if (rc != BT_OK) { delete c; return rc; }
+	bool need_mirror = false;
+	for (int i = 0; i < c->prog.nsteps; i++) need_mirror |= c->prog.steps[i].mirror != 0;
+	if (need_mirror && !idx->has_mirror) { delete c; return BT_ERR_ARG; }
+	HIPCHK(hipSetDevice(idx->device));
+	if (stream) c->stream = (hipStream_t)stream;
+	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+	HIPCHK(hipEventCreate(&c->ev0));
+	HIPCHK(hipEventCreate(&c->ev1));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, idx->device));
+	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", 2);
+	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
+	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
+	HIPCHK(hipMalloc((void**)&c->d_counts, 9 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(c->d_counts, 0, 9 * sizeof(unsigned long long)));
+	*out = c;
+	return BT_OK;
+}
+
+extern "C" void bt_ctx_destroy(bt_ctx* c)
+{
+	if (!c) return;
+	(void)hipStreamSynchronize(c->stream);
+	ctx_free_scratch(c);
+	if (c->d_cursor) (void)hipFree(c->d_cursor);
+	if (c->d_counts) (void)hipFree(c->d_counts);
+	if (c->stage) (void)hipFree(c->stage);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->own_stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uint32_t maxLen,
+                      unsigned long long* counts_dev)
+{
+	if (in->n_reads == 0) { c->timed = false; return BT_OK; }
+	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
+	    out->hit_cap == 0 || in->stride == 0) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(c->idx->device));
+	int rc = ctx_ensure_scratch(c, maxLen);
+	if (rc != BT_OK) return rc;
+	BtKernelArgs A;
+	memset(&A, 0, sizeof(A));
+	A.P = c->prog;
+	A.ix[0] = c->idx->dev[0]; A.ix[1] = c->idx->dev[1];
+	A.B.seq = in->seq; A.B.qual = in->qual; A.B.len = in->len; A.B.seed = in->seed;
+	A.B.n_reads = in->n_reads; A.B.stride = in->stride;
+	A.B.hits = (BtHitRec*)out->hits; A.B.hit_cap = out->hit_cap;
+	A.B.n_hits = out->n_hits; A.B.status = out->status;
+	A.B.mm_pool = out->mm_pool; A.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
+	A.B.mm_pool_used = c->d_cursor + 1;
+	A.frames = c->frames; A.pairs = c->pairs; A.elims = c->elims; A.pals = c->pals;
+	A.nLanes = c->nLanes; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
+	A.nextRead = c->d_cursor;
+	A.counts = counts_dev ? counts_dev : c->d_counts;
+	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
+	const uint32_t maxBlocks = c->nLanes / BT_BLOCK;
+	if (nBlocks > maxBlocks) nBlocks = maxBlocks;
+	HIPCHK(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	if (bt_launch_search(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	c->timed = true;
+	return BT_OK;
+}
+
+extern "C" int bt_align_batch_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out,
+                                     bt_op_counts* counts_dev)
+{
+	if (!c || !in || !out) return BT_ERR_ARG;
+	/* lengths live in HBM: size the scratch for the row stride (>= every length) */
+	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev);
+}
+
+extern "C" int bt_ctx_sync(bt_ctx* c)
+{
+	if (!c) return BT_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(&c->last_mm_used, c->d_cursor + 1, 4, hipMemcpyDeviceToHost));
+	return BT_OK;
+}
+
+extern "C" float bt_ctx_last_kernel_ms(bt_ctx* c)
+{
+	float ms = 0.f;
+	if (!c || !c->timed) return 0.f;
+	if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+	return ms;
+}
+
+extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
+
+extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
+{
+	if (!c || !out) return BT_ERR_ARG;
+	unsigned long long h[9];
+	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
+	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
+	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
+	out->lane_iters = h[8];
+	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
+	return BT_OK;
+}
+
+extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, bt_op_counts* counts)
+{
+	if (!c || !in || !out) return BT_ERR_ARG;
+	const uint32_t n = in->n_reads;
+	out->mm_pool_used = 0;
+	if (n == 0) return BT_OK;
+	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
+	    out->hit_cap == 0) return BT_ERR_ARG;
+	uint32_t maxLen = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		if (in->len[i] == 0 || in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;
+		if (in->len[i] > maxLen) maxLen = in->len[i];
+	}
+	HIPCHK(hipSetDevice(c->idx->device));
+	/* one staging allocation: seq | qual | len | seed | hits | n_hits | status | mm_pool */
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t o_seq = 0, o_qual = o_seq + al((size_t)n * in->stride), o_len = o_qual + al((size_t)n * in->stride),
+	             o_seed = o_len + al(2ull * n), o_hits = o_seed + al(4ull * n),
+	             o_nh = o_hits + al((size_t)n * out->hit_cap * sizeof(bt_hit)), o_st = o_nh + al(4ull * n),
+	             o_mm = o_st + al(n), total = o_mm + al(2ull * out->mm_pool_cap);
+	if (total > c->stage_bytes) {
+		if (c->stage) (void)hipFree(c->stage);
+		c->stage = nullptr; c->stage_bytes = 0;
+		HIPCHK(hipMalloc(&c->stage, total));
+		c->stage_bytes = total;
+	}
+	uint8_t* d = (uint8_t*)c->stage;
+	HIPCHK(hipMemcpyAsync(d + o_seq, in->seq, (size_t)n * in->stride, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d + o_qual, in->qual, (size_t)n * in->stride, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d + o_len, in->len, 2ull * n, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(d + o_seed, in->seed, 4ull * n, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_mm - o_hits, c->stream));
+	bt_read_batch din = *in;
+	din.seq = d + o_seq; din.qual = d + o_qual; din.len = (const uint16_t*)(d + o_len); din.seed = (const uint32_t*)(d + o_seed);
+	bt_hit_batch dout = *out;
+	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
+	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
+	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, 9 * sizeof(unsigned long long), c->stream));
+	int rc = run_device(c, &din, &dout, maxLen, nullptr);
+	if (rc != BT_OK) return rc;
+	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out->n_hits, d + o_nh, 4ull * n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out->status, d + o_st, n, hipMemcpyDeviceToHost, c->stream));
+	if (out->mm_pool_cap)
+		HIPCHK(hipMemcpyAsync(out->mm_pool, d + o_mm, 2ull * out->mm_pool_cap, hipMemcpyDeviceToHost, c->stream));
+	rc = bt_ctx_sync(c);
+	if (rc != BT_OK) return rc;
+	out->mm_pool_used = c->last_mm_used < out->mm_pool_cap ? c->last_mm_used : out->mm_pool_cap;
+	if (counts) { rc = bt_ctx_counts(c, counts, 0); if (rc != BT_OK) return rc; }
+	int worst = BT_OK;
+	for (uint32_t i = 0; i < n; i++) {
+		if (out->status[i] & BT_STF_TOOSHORT) worst = BT_ERR_READ_SHORT;
+		else if ((out->status[i] & (BT_STF_OVERFLOW | BT_STF_MMPOOL)) && worst == BT_OK) worst = BT_ERR_OVERFLOW;
+	}
+	return worst;
+}
+
+/* ---- probes ---------------------------------------------------------------------------------- */
+extern "C" int bt_probe_rank(bt_ctx* c, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L)
+{
+	if (!c || !rows || !lf || !L || (mirror && !c->idx->has_mirror)) return BT_ERR_ARG;
+	if (n == 0) return BT_OK;
+	HIPCHK(hipSetDevice(c->idx->device));
+	uint32_t *d_rows = nullptr, *d_lf = nullptr; uint8_t* d_L = nullptr;
+	HIPCHK(hipMalloc((void**)&d_rows, 4ull * n)); HIPCHK(hipMalloc((void**)&d_lf, 16ull * n)); HIPCHK(hipMalloc((void**)&d_L, n));
+	HIPCHK(hipMemcpy(d_rows, rows, 4ull * n, hipMemcpyHostToDevice));
+	int rc = bt_launch_probe_rank(&c->idx->dev[mirror ? 1 : 0], d_rows, n, d_lf, d_L, c->stream);
+	if (rc == 0) rc = (int)hipStreamSynchronize(c->stream);
+	if (rc == 0) { (void)hipMemcpy(lf, d_lf, 16ull * n, hipMemcpyDeviceToHost); (void)hipMemcpy(L, d_L, n, hipMemcpyDeviceToHost); }
+	(void)hipFree(d_rows); (void)hipFree(d_lf); (void)hipFree(d_L);
+	return rc == 0 ? BT_OK : BT_ERR_DEVICE;
+}
+
+extern "C" int bt_probe_chase(bt_ctx* c, int mirror, const uint32_t* rows, uint32_t n, uint32_t qlen,
+                              uint32_t* joined_off, uint32_t* tidx, uint32_t* toff)
+{
+	if (!c || !rows || !joined_off || !tidx || !toff || (mirror && !c->idx->has_mirror)) return BT_ERR_ARG;
+	if (n == 0) return BT_OK;
+	HIPCHK(hipSetDevice(c->idx->device));
+	uint32_t* d = nullptr;
+	HIPCHK(hipMalloc((void**)&d, 16ull * n));
+	HIPCHK(hipMemcpy(d, rows, 4ull * n, hipMemcpyHostToDevice));
+	int rc = bt_launch_probe_chase(&c->idx->dev[mirror ? 1 : 0], d, n, qlen, d + n, d + 2ull * n, d + 3ull * n, c->stream);
+	if (rc == 0) rc = (int)hipStreamSynchronize(c->stream);
+	if (rc == 0) {
+		(void)hipMemcpy(joined_off, d + n, 4ull * n, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(tidx, d + 2ull * n, 4ull * n, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(toff, d + 3ull * n, 4ull * n, hipMemcpyDeviceToHost);
+	}
+	(void)hipFree(d);
+	return rc == 0 ? BT_OK : BT_ERR_DEVICE;
+}
+
+extern "C" const char* bt_strerror(int code)
+{
+	switch (code) {
+	case BT_OK: return "ok";
+	case BT_ERR_IO: return "index file missing or truncated";
+	case BT_ERR_FORMAT: return "not a small little-endian lineRate-6 .ebwt index";
+	case BT_ERR_ARG: return "bad argument";
+	case BT_ERR_DEVICE: return "HIP device error";
+	case BT_ERR_READ_SHORT: return "read shorter than the alignment mode allows";
+	case BT_ERR_OVERFLOW: return "per-read scratch capacity exceeded";
+	default: return "unknown error";
+	}
+}
+extern "C" const char* bt_version(void) { return "bowtie_amd 0.1.0 (gfx950)"; }

@@ -1,0 +1,40 @@
+/*
+ * bt_host.h -- host-side pieces behind the C ABI that need no GPU: the .ebwt loader and the
+ * policy -> phase-program compiler.  Pure C++ (shared by libbowtie_amd.so and the unit tests).
+ */
+#ifndef BT_HOST_H_
+#define BT_HOST_H_
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/bowtie_amd.h"
+#include "bt_core.h"
+
+/* One index (text or mirror) parsed into host memory.  Field order and geometry follow
+ * Ebwt::readIntoMemory (ebwt.h:2926-3421) and EbwtParams::init (ebwt.h:138-184). */
+struct BtIndexHost {
+	uint32_t len = 0, nPat = 0, nFrag = 0, zOff = 0;
+	int32_t  lineRate = 0, linesPerSide = 0, offRate = 0, ftabChars = 0, flags = 0;
+	uint32_t fchr[5] = {0, 0, 0, 0, 0};
+	bool     fw = true;
+	std::vector<uint8_t>  ebwt;
+	std::vector<uint32_t> plen, rstarts, ftab, eftab, offs;
+	std::vector<std::string> refnames;
+	uint64_t ebwtTotLen() const { return ebwt.size(); }
+};
+
+/* Returns BT_OK or BT_ERR_*.  offrate_override (>= index offRate) subsamples offs[] the way
+ * -o does (ebwt.h:2988-3001, 3301-3327); -1 keeps the index's own rate. */
+int bt_host_index_load(const std::string& base, bool fw, int offrate_override, BtIndexHost* out);
+
+/* Fill the device-visible descriptor from host-side geometry (pointers are left to the caller). */
+void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d);
+
+/* Compile a bt_policy into the linear list of searcher invocations the reference's phase scripts
+ * perform (search_exact.c, search_1mm_phase{1,2}.c, search_23mm_phase{1,2,3}.c,
+ * search_seeded_phase{1..4}.c) with every policy-uniform condition (--nofw/--norc, seedMms)
+ * resolved.  Returns BT_OK or BT_ERR_ARG. */
+int bt_host_compile_program(const bt_policy& pol, BtProgram* prog);
+
+#endif

@@ -1,0 +1,169 @@
+/*
+ * bt_kernels.hip -- gfx950 kernels of the FM-index search path.
+ *
+ *   bt_search_kernel : one lane = one read automaton (bt_core.h).  The 64 reads of a wavefront
+ *                      advance in lock step from LF-mapping to LF-mapping; the rank gathers of
+ *                      all lanes (one 64-byte side + the partner side's 8 counter bytes per BWT
+ *                      row, i.e. one 128-byte side pair) are issued together at one program
+ *                      point, whatever phase / backtrack frame / SA walk each read is in.
+ *                      Lanes that finish a read pull the next one from a global counter
+ *                      (wave-aggregated atomic), so wavefronts stay full until the batch drains.
+ *   bt_probe_*       : known-answer probes of rank/LF and the SA walk.
+ *
+ * Replaces (reference, CPU): the worker loops of ebwt_search.cpp:1130/1606/2056/2378 and
+ * everything they call for a read.
+ */
+#include <hip/hip_runtime.h>
+#include "bt_core.h"
+#include "bt_kernels.h"
+
+struct BtRankSel { const uint8_t* ebwt; uint32_t zSide, zSym, f0, f1, f2, f3; };
+
+/* rank at `row`: 4 x 16-byte loads of the row's side + one 8-byte load of the partner counters */
+__device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint32_t lf[4], uint32_t* L)
+{
+	const uint32_t sideNum = row / BT_SIDE_SYMS;
+	const uint32_t charOff = row - sideNum * BT_SIDE_SYMS;
+	const uint8_t* side = s.ebwt + (uint64_t)sideNum * 64u;
+	const uint4* s4 = (const uint4*)side;
+	uint4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3];
+	const bool fw = (sideNum & 1u) != 0;
+	const uint2 oth = *(const uint2*)(fw ? side - 8 : side + 120);
+	uint64_t w[7];
+	w[0] = ((uint64_t)q0.y << 32) | q0.x; w[1] = ((uint64_t)q0.w << 32) | q0.z;
+	w[2] = ((uint64_t)q1.y << 32) | q1.x; w[3] = ((uint64_t)q1.w << 32) | q1.z;
+	w[4] = ((uint64_t)q2.y << 32) | q2.x; w[5] = ((uint64_t)q2.w << 32) | q2.z;
+	w[6] = ((uint64_t)q3.y << 32) | q3.x;
+	uint32_t occ[4];
+	occ[0] = fw ? oth.x : q3.z; occ[1] = fw ? oth.y : q3.w;
+	occ[2] = fw ? q3.z : oth.x; occ[3] = fw ? q3.w : oth.y;
+	BtIndexDev ix;
+	ix.zSide = s.zSide; ix.zSym = s.zSym;
+	ix.fchr[0] = s.f0; ix.fchr[1] = s.f1; ix.fchr[2] = s.f2; ix.fchr[3] = s.f3;
+	bt_rank4_words(ix, sideNum, charOff, w, occ, lf, L);
+}
+
+__global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	BtScratch S;
+	S.frStride = A.nLanes;
+	S.frames = A.frames + g;
+	S.pairs = A.pairs + (uint64_t)g * A.entCap * 8u;
+	S.elims = A.elims + (uint64_t)g * A.entCap;
+	S.pals = A.pals + (uint64_t)g * A.palCap;
+	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
+
+	BtLane L;
+	L.state = ST_IDLE; L.mirror = 0;
+	L.cnt.lfex = L.cnt.lf2 = L.cnt.lf1 = L.cnt.chase = L.cnt.ftab = L.cnt.offs = L.cnt.rstarts = L.cnt.frames = 0;
+	BtRes res;
+	BtReq req;
+	res.LA = 0;
+	for (int k = 0; k < 4; k++) { res.a[k] = 0; res.b[k] = 0; }
+	bool drained = false;
+	uint32_t iters = 0;
+
+	for (;;) {
+		/* advance to the next LF request, pulling new reads as old ones finish */
+		for (;;) {
+			if (L.state == ST_IDLE) {
+				if (drained) break;
+				const uint32_t rd = atomicAdd(A.nextRead, 1u);
+				if (rd >= A.B.n_reads) { drained = true; break; }
+				bt_lane_start(L, A.P, A.B, rd);
+			}
+			bt_lane_run(L, A.P, A.ix, S, A.B, res, req);
+			if (L.state != ST_IDLE) break;
+		}
+		if (L.state == ST_IDLE) break;
+		iters++;
+		/* the rank gathers of the whole wavefront */
+		BtRankSel sel;
+		const bool m = L.mirror != 0;
+		sel.ebwt = m ? A.ix[1].ebwt : A.ix[0].ebwt;
+		sel.zSide = m ? A.ix[1].zSide : A.ix[0].zSide;
+		sel.zSym = m ? A.ix[1].zSym : A.ix[0].zSym;
+		sel.f0 = m ? A.ix[1].fchr[0] : A.ix[0].fchr[0];
+		sel.f1 = m ? A.ix[1].fchr[1] : A.ix[0].fchr[1];
+		sel.f2 = m ? A.ix[1].fchr[2] : A.ix[0].fchr[2];
+		sel.f3 = m ? A.ix[1].fchr[3] : A.ix[0].fchr[3];
+		dev_rank4(sel, req.rowA, res.a, &res.LA);
+		if (req.op & 2u) {
+			uint32_t dummy;
+			dev_rank4(sel, req.rowB, res.b, &dummy);
+		}
+	}
+
+	/* op counters: block-reduce, then one atomic per counter per block */
+	__shared__ unsigned long long sh[9];
+	if (threadIdx.x < 9) sh[threadIdx.x] = 0;
+	__syncthreads();
+	atomicAdd(&sh[0], (unsigned long long)L.cnt.lfex);
+	atomicAdd(&sh[1], (unsigned long long)L.cnt.lf2);
+	atomicAdd(&sh[2], (unsigned long long)L.cnt.lf1);
+	atomicAdd(&sh[3], (unsigned long long)L.cnt.chase);
+	atomicAdd(&sh[4], (unsigned long long)L.cnt.ftab);
+	atomicAdd(&sh[5], (unsigned long long)L.cnt.offs);
+	atomicAdd(&sh[6], (unsigned long long)L.cnt.rstarts);
+	atomicAdd(&sh[7], (unsigned long long)L.cnt.frames);
+	atomicAdd(&sh[8], (unsigned long long)iters);
+	__syncthreads();
+	if (threadIdx.x < 9 && A.counts) atomicAdd(&A.counts[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	BtRankSel sel;
+	sel.ebwt = ix.ebwt; sel.zSide = ix.zSide; sel.zSym = ix.zSym;
+	sel.f0 = ix.fchr[0]; sel.f1 = ix.fchr[1]; sel.f2 = ix.fchr[2]; sel.f3 = ix.fchr[3];
+	uint32_t r[4], L;
+	dev_rank4(sel, rows[i], r, &L);
+	lf[i * 4 + 0] = r[0]; lf[i * 4 + 1] = r[1]; lf[i * 4 + 2] = r[2]; lf[i * 4 + 3] = r[3];
+	Lout[i] = (uint8_t)L;
+}
+
+__global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
+                                      uint32_t* joined, uint32_t* tidx, uint32_t* toff)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	BtRankSel sel;
+	sel.ebwt = ix.ebwt; sel.zSide = ix.zSide; sel.zSym = ix.zSym;
+	sel.f0 = ix.fchr[0]; sel.f1 = ix.fchr[1]; sel.f2 = ix.fchr[2]; sel.f3 = ix.fchr[3];
+	uint32_t row = rows[i], jumps = 0;
+	while ((row & ix.offMask) != row && row != ix.zOff) {
+		uint32_t r[4], L;
+		dev_rank4(sel, row, r, &L);
+		row = r[L];
+		jumps++;
+	}
+	const uint32_t off = (row == ix.zOff) ? jumps : ix.offs[row >> ix.offRate] + jumps;
+	joined[i] = off;
+	uint32_t t = 0xffffffffu, o = 0, probes = 0;
+	if (!bt_joined_to_text(ix, qlen, off, &t, &o, &probes)) { t = 0xffffffffu; o = 0; }
+	tidx[i] = t; toff[i] = o;
+}
+
+/* ---- launchers (called from bt_api.cpp, which is plain C++) ------------------------------- */
+extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, void* stream)
+{
+	hipLaunchKernelGGL(bt_search_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
+	return (int)hipGetLastError();
+}
+extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
+                                    uint8_t* L, void* stream)
+{
+	hipLaunchKernelGGL(bt_probe_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   *ix, rows, n, lf, L);
+	return (int)hipGetLastError();
+}
+extern "C" int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
+                                     uint32_t* joined, uint32_t* tidx, uint32_t* toff, void* stream)
+{
+	hipLaunchKernelGGL(bt_probe_chase_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   *ix, rows, n, qlen, joined, tidx, toff);
+	return (int)hipGetLastError();
+}

@@ -41,6 +41,9 @@ extern "C" {
 #define BT_ERR_DEVICE      4   /* HIP runtime error (no GPU, OOM, launch failure)             */
 #define BT_ERR_READ_SHORT  5   /* read shorter than the mode allows (reference: throw 1,
                                   search_1mm_phase1.c:12-15, search_23mm_phase1.c:13-20)      */
+#define BT_ERR_OVERFLOW    6   /* a read exceeded a per-read scratch capacity (status bit
+                                  BT_ST_OVERFLOW / BT_ST_MMPOOL says which reads); the other
+                                  reads of the batch are valid                                */
 
 /* ---- policy: exactly the knobs the reference workers read -------------------------------- */
 #define BT_MODE_V 0            /* end-to-end, -v <mms>   (ebwt_search.cpp:3249-3268)          */
@@ -95,6 +98,9 @@ typedef struct bt_hit {
 /* per-read status bits */
 #define BT_ST_SKIPPED   1u   /* -n mode: len<4 or too many Ns in seed (search_seeded_phase1.c:17-44) */
 #define BT_ST_HITCAP    2u   /* more reportable hits than hit_cap slots (slots hold the first ones)  */
+#define BT_ST_TOOSHORT  4u   /* -v 1: len<2, -v 2: len<4 (the reference aborts the whole run)        */
+#define BT_ST_OVERFLOW  8u   /* backtrack-frame / range-stack / seedling capacity exceeded           */
+#define BT_ST_MMPOOL    16u  /* mm_pool exhausted: hit stored with nmm = 0                           */
 
 typedef struct bt_hit_batch {
 	uint32_t  hit_cap;        /* hit slots per read                                           */
@@ -117,6 +123,7 @@ typedef struct bt_op_counts {
 	uint64_t offs;            /* offs[] lookups                                               */
 	uint64_t rstarts;         /* rstarts probes                                               */
 	uint64_t frames;          /* backtrack frames entered                                     */
+	uint64_t lane_iters;      /* sum over lanes of lock-step iterations (GPU only)            */
 } bt_op_counts;
 
 /* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */
@@ -155,6 +162,11 @@ int  bt_align_batch(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, bt_
 int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out,
                            bt_op_counts* counts_dev);
 int  bt_ctx_sync(bt_ctx* ctx);
+/* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */
+uint32_t bt_ctx_last_mm_used(bt_ctx* ctx);
+/* read (and optionally reset) the ctx-owned op counters that bt_align_batch_device accumulates
+ * into when counts_dev == NULL */
+int  bt_ctx_counts(bt_ctx* ctx, bt_op_counts* out, int reset);
 /* milliseconds the search kernel(s) of the last bt_align_batch[_device] call took, measured with
  * HIP events on the ctx stream (valid after bt_ctx_sync). */
 float bt_ctx_last_kernel_ms(bt_ctx* ctx);

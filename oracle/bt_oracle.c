@@ -190,6 +190,21 @@ uint32_t bto_chase(const bto_index* ix, uint32_t row, uint32_t* jumps_out)
 	return (i == ix->zOff) ? jumps : ix->offs[i >> ix->offRate] + jumps;
 }
 
+/* Ebwt::restore (ebwt.h:2793-2824): invert the BWT into the joined text (codes 0..3).  For the
+ * mirror index this yields the reversed joined text. */
+void bto_restore_text(const bto_index* ix, uint8_t* out)
+{
+	uint32_t i = ix->len, jumps = 0;     /* the row of the suffix "$" (sorts last) */
+	while (i != ix->zOff) {
+		uint32_t lf[4];
+		int c = bto_rowL(ix, i);
+		bto_rank4(ix, i, lf);
+		out[ix->len - 1 - jumps] = (uint8_t)c;
+		i = lf[c];
+		jumps++;
+	}
+}
+
 /* joinedToTextOff, ebwt.h:2569-2629 */
 int bto_joined_to_text(const bto_index* ix, uint32_t qlen, uint32_t off,
                        uint32_t* tidx, uint32_t* toff, uint32_t* tlen)

@@ -1,0 +1,109 @@
+/*
+ * bt_emu.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Host build of the per-read automaton in bowtie_amd/csrc/bt_core.h, driven the way the HIP
+ * kernel drives it (lock-step lanes, LF requests answered between steps), so the automaton's
+ * logic can be checked against the oracle in a container that has no GPU.  It is not part of
+ * libbowtie_amd.so and nothing in the product loads it; GPU parity is tested separately
+ * (tests/test_gpu_*.py) through the C ABI.
+ */
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../bowtie_amd/csrc/bt_host.h"
+
+struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; bool mirror; };
+
+static void bind(EmuIndex* e, int m)
+{
+	bt_host_index_describe(e->h[m], &e->d[m]);
+	e->d[m].ebwt = e->h[m].ebwt.data(); e->d[m].ftab = e->h[m].ftab.data(); e->d[m].eftab = e->h[m].eftab.data();
+	e->d[m].offs = e->h[m].offs.data(); e->d[m].rstarts = e->h[m].rstarts.data(); e->d[m].plen = e->h[m].plen.data();
+}
+
+extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
+{
+	EmuIndex* e = new EmuIndex();
+	e->mirror = need_mirror != 0;
+	if (bt_host_index_load(base, true, offrate, &e->h[0]) != BT_OK) { delete e; return nullptr; }
+	e->h[0].ebwt.resize(e->h[0].ebwt.size() + 128);
+	bind(e, 0);
+	if (need_mirror) {
+		if (bt_host_index_load(std::string(base) + ".rev", false, offrate, &e->h[1]) != BT_OK) { delete e; return nullptr; }
+		e->h[1].ebwt.resize(e->h[1].ebwt.size() + 128);
+		bind(e, 1);
+	} else e->d[1] = e->d[0];
+	return e;
+}
+extern "C" void emu_index_free(void* p) { delete (EmuIndex*)p; }
+
+extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint32_t* L)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	bt_rank4(e->d[mirror ? 1 : 0], row, lf, L);
+}
+
+/* Same contract as bt_align_batch (host pointers); nLanes lock-step lanes. */
+extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
+                               bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	BtProgram P;
+	int rc = bt_host_compile_program(*pol, &P);
+	if (rc != BT_OK) return rc;
+	BtBatchDev B;
+	memset(&B, 0, sizeof(B));
+	B.seq = in->seq; B.qual = in->qual; B.len = in->len; B.seed = in->seed; B.n_reads = in->n_reads; B.stride = in->stride;
+	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
+	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
+	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
+	std::vector<uint32_t> frames((size_t)nLanes * frCap * BT_FR_WORDS), pairs((size_t)nLanes * entCap * 8);
+	std::vector<uint8_t> elims((size_t)nLanes * entCap);
+	std::vector<uint64_t> pals((size_t)nLanes * palCap);
+	std::vector<BtLane> lanes(nLanes);
+	std::vector<BtScratch> scr(nLanes);
+	std::vector<BtRes> res(nLanes);
+	std::vector<char> drained(nLanes, 0);
+	for (uint32_t g = 0; g < nLanes; g++) {
+		memset(&lanes[g], 0, sizeof(BtLane));
+		memset(&res[g], 0, sizeof(BtRes));
+		lanes[g].state = ST_IDLE;
+		scr[g].frames = frames.data() + g; scr[g].frStride = nLanes;
+		scr[g].pairs = pairs.data() + (size_t)g * entCap * 8; scr[g].elims = elims.data() + (size_t)g * entCap;
+		scr[g].pals = pals.data() + (size_t)g * palCap;
+		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
+	}
+	uint32_t next = 0, live = nLanes;
+	uint64_t iters = 0;
+	while (live > 0) {
+		for (uint32_t g = 0; g < nLanes; g++) {
+			if (drained[g]) continue;
+			BtLane& L = lanes[g];
+			BtReq req;
+			for (;;) {
+				if (L.state == ST_IDLE) {
+					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
+					bt_lane_start(L, P, B, next++);
+				}
+				bt_lane_run(L, P, e->d, scr[g], B, res[g], req);
+				if (L.state != ST_IDLE) break;
+			}
+			if (drained[g]) continue;
+			iters++;
+			const BtIndexDev& ix = e->d[L.mirror];
+			bt_rank4(ix, req.rowA, res[g].a, &res[g].LA);
+			if (req.op & 2u) { uint32_t dummy; bt_rank4(ix, req.rowB, res[g].b, &dummy); }
+		}
+	}
+	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
+	if (counts) {
+		memset(counts, 0, sizeof(*counts));
+		for (uint32_t g = 0; g < nLanes; g++) {
+			counts->lfex += lanes[g].cnt.lfex; counts->lf2 += lanes[g].cnt.lf2; counts->lf1 += lanes[g].cnt.lf1;
+			counts->chase += lanes[g].cnt.chase; counts->ftab += lanes[g].cnt.ftab; counts->offs += lanes[g].cnt.offs;
+			counts->rstarts += lanes[g].cnt.rstarts; counts->frames += lanes[g].cnt.frames;
+		}
+		counts->lane_iters = iters;
+	}
+	return BT_OK;
+}

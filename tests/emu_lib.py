@@ -1,0 +1,79 @@
+"""ctypes driver of tests/emu/libbt_emu.so -- TEST INFRASTRUCTURE ONLY: the host build of the
+per-read automaton (bowtie_amd/csrc/bt_core.h), used to check its logic against the oracle where
+no GPU exists.  Not a product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from bowtie_amd import _abi as A
+from bowtie_amd.aligner import unpack_hits
+from bowtie_amd.reads import ReadBatch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+LIB_PATH = os.path.join(EMU_DIR, "libbt_emu.so")
+SRCS = [os.path.join(EMU_DIR, "bt_emu.cpp")] + [os.path.join(ROOT, "bowtie_amd", "csrc", f) for f in
+                                                ("bt_host.cpp", "bt_host.h", "bt_core.h", "bt_rank.h")]
+_lib = None
+
+
+def build():
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", LIB_PATH,
+                           SRCS[0], SRCS[1]])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in SRCS):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.emu_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.emu_index_load.restype = C.c_void_p
+        L.emu_index_free.argtypes = [C.c_void_p]
+        L.emu_rank4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
+                                      C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 4
+        _lib = L
+    return _lib
+
+
+class EmuAligner:
+    def __init__(self, base: str, need_mirror=True, offrate=-1):
+        self.h = lib().emu_index_load(base.encode(), int(need_mirror), offrate)
+        if not self.h:
+            raise IOError("emu: cannot load " + base)
+
+    def rank4(self, row, mirror=False):
+        lf = (C.c_uint32 * 4)()
+        L = C.c_uint32()
+        lib().emu_rank4(self.h, int(mirror), row, lf, C.byref(L))
+        return list(lf), int(L.value)
+
+    def align(self, pol: A.Policy, batch: ReadBatch, hit_cap=None, mm_per_hit=8, counts=None,
+              n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024):
+        n = batch.n
+        hit_cap = hit_cap or (64 if pol.all_hits else max(1, min(int(pol.khits), 64)))
+        ent_cap = ent_cap or 12 * max(64, batch.stride)
+        seq = np.ascontiguousarray(batch.seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(batch.qual, dtype=np.uint8)
+        ln = np.ascontiguousarray(batch.len, dtype=np.uint16)
+        seed = np.ascontiguousarray(batch.seed, dtype=np.uint32)
+        hits = np.zeros(n * hit_cap, dtype=A.HIT_DTYPE)
+        n_hits = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint8)
+        pool = np.zeros(max(1, n * hit_cap * mm_per_hit), dtype=np.uint16)
+        rb = A.ReadBatchC(n, batch.stride, seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, seed.ctypes.data)
+        hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data,
+                         pool.ctypes.data, len(pool), 0)
+        rc = lib().emu_align_batch(self.h, C.byref(pol), C.byref(rb), C.byref(hb),
+                                   C.byref(counts) if counts is not None else None,
+                                   n_lanes, fr_cap, ent_cap, pal_cap)
+        if rc != 0:
+            raise RuntimeError("emu_align_batch rc=%d" % rc)
+        return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(pol.khits), int(pol.mhits),
+                           bool(pol.all_hits))

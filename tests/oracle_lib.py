@@ -27,7 +27,7 @@ class Policy(C.Structure):
 
 class OpCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames")]
+                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters")]
 
 
 class OHit(C.Structure):
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
         L.bto_chase.restype = C.c_uint32
         L.bto_joined_to_text.argtypes = [C.POINTER(OIndex), C.c_uint32, C.c_uint32] + \
             [C.POINTER(C.c_uint32)] * 3
+        L.bto_restore_text.argtypes = [C.POINTER(OIndex), C.c_void_p]
+        L.bto_restore_text.restype = None
         L.bto_rand_seed.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint32]
         L.bto_rand_seed.restype = C.c_uint32
         L.bto_align_read.argtypes = [C.POINTER(OIndex), C.POINTER(OIndex), C.POINTER(Policy),
@@ -108,6 +110,12 @@ class OracleIndex:
                 raise IOError("oracle: cannot load %s.rev (rc=%d)" % (base, rc))
         self.refnames = [self.fw.refnames[i].decode() for i in range(self.fw.nPat)]
         self.reflens = [int(self.fw.plen[i]) for i in range(self.fw.nPat)]
+
+    def joined_text(self) -> np.ndarray:
+        """The joined reference text (codes 0..3) recovered from the fw index."""
+        out = np.zeros(self.fw.len, dtype=np.uint8)
+        lib().bto_restore_text(C.byref(self.fw), out.ctypes.data)
+        return out
 
     def ix(self, mirror: bool) -> OIndex:
         return self.bw if mirror else self.fw

@@ -43,8 +43,9 @@ def render(batch: ReadBatch, per_read, refnames, sam: bool, mhits: int = 0xFFFFF
                     out.append(O.format_sam(name, seq, qual, h, refnames, xms=len(hits)))
                 else:
                     out.append(O.format_verbose(name, seq, qual, h, refnames))
-        elif sam:
-            out.append(O.format_sam_unaligned(name, seq, qual, total if maxed else 0))
+        elif sam and not maxed:
+            # -m-suppressed reads print nothing unless -M (hit.h:494-500, sam.cpp:263-269)
+            out.append(O.format_sam_unaligned(name, seq, qual, 0))
     return b"".join(out)
 
 
