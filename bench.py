@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned reads/s of the FM-index search hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--reads R]
+
+A "step" is one pass of the hot path (bt_align_batch_device: one persistent-lane search kernel)
+over one batch of synthetic reads that already sits in HBM.  One process per GPU (torchrun);
+reads are sharded by rank, the index is replicated in every GPU's HBM, and the only collective
+is the final all-reduce of the hit counters (RCCL over xGMI).  Rank 0 prints one JSON line.
+
+Workloads (BASELINE.json configs):
+    ecoli_v0_36    e_coli index, 36-bp reads, -v 0              (config 1)
+    ecoli_v2_76    e_coli index, 76-bp reads, -v 2
+    ecoli_n2_100   e_coli index, 100-bp reads, -n 2 -l 28 -e 70
+    big_v2_76      hg19-scale synthetic genome, 76-bp, -v 2     (config 2)
+    big_n2_100     hg19-scale synthetic genome, 100-bp, -n 2    (config 3; the headline metric)
+The hg19-scale index is synthesised on the GPU at start-up (bowtie_amd/ebwt_build.py): neither
+hg19 nor any network exists on the bench box.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+from bowtie_amd import _abi as A            # noqa: E402
+from bowtie_amd import aligner as AL        # noqa: E402
+from bowtie_amd.synth import synth_reads_torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
+    "ecoli_v2_76": dict(index="ecoli", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=2_000_000),
+    "ecoli_n2_100": dict(index="ecoli", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=2_000_000),
+    "big_v2_76": dict(index="big", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=20_000_000),
+    "big_n2_100": dict(index="big", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=20_000_000),
+}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(c: dict, n_reads: int, length: int, hits: int) -> float:
+    """128 B per rank locus (one side pair), 4 B per ftab/offs word, 12 B per
+    rstarts probe, read in (len x (seq+qual) + 16 B meta), hit out (32 B + 2 B/mm ~ 36 B)."""
+    loci = 2 * (c["lfex"] + c["lf2"]) - c["same_pair"] + c["lf1"] + c["chase"]
+    return 128.0 * loci + 4.0 * (2 * c["ftab"] + c["offs"]) + 12.0 * c["rstarts"] + \
+        n_reads * (2.0 * length + 16.0) + hits * 36.0
+
+
+def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0):
+    """Reference bowtie (oracle/_ref, unmodified, all host cores) on a bounded FASTQ sample of the
+    same workload; falls back to the single-core C restatement if the binary is not on the box."""
+    import subprocess
+    import tempfile
+    from bowtie_amd.synth import synth_reads, write_fastq
+    pol = wl["pol"]
+    args = ["-v", str(pol["mms"])] if pol["mode"] == "v" else ["-n", str(pol["mms"]), "-l", "28", "-e", "70"]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
+    cores = os.cpu_count() or 1
+    if os.path.exists(ref_bin):
+        # calibrate: 20k reads first, then size the sample for ~`seconds`
+        n = 20000
+        out = None
+        with tempfile.TemporaryDirectory() as td:
+            for attempt in range(2):
+                batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
+                fq = os.path.join(td, "s.fq")
+                write_fastq(batch, fq)
+                t0 = time.perf_counter()
+                p = subprocess.run([ref_bin, "--wrapper", "basic-0", "-p", str(cores), "-t"] + args +
+                                   ["-x", base, fq, os.devnull], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                wall = time.perf_counter() - t0
+                if p.returncode != 0:
+                    break
+                err = p.stderr.decode()
+                ts = None
+                for line in err.split("\n"):
+                    if line.startswith("Time searching:"):
+                        hh, mm, ss = line.split(":", 1)[1].strip().split(":")
+                        ts = int(hh) * 3600 + int(mm) * 60 + int(ss)
+                rate = n / max(wall, 1e-3)
+                out = {"value": rate, "unit": "reads/s", "cores": cores, "kind": "reference",
+                       "sample": "%d synthetic %d-bp reads, bowtie-align-s -p %d %s, wall %.2fs incl. index load "
+                                 "(reference's own 'Time searching' %ss)" %
+                                 (n, wl["length"], cores, " ".join(args), wall, ts)}
+                if attempt == 0:
+                    n = int(min(5_000_000, max(20000, rate * seconds)))
+        if out:
+            return out
+    # port: the C restatement, one core
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as OL
+    import refrun as R
+    oi = OL.OracleIndex(base)
+    opol = OL.make_policy(**pol)
+    n = 2000
+    batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321)
+    t0 = time.perf_counter()
+    R.oracle_search(oi, opol, batch)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic %d-bp reads through oracle/bt_oracle.c via ctypes, %.2fs" % (n, wl["length"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("BT_WORKLOAD", "big_n2_100"))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = workload default)")
+    ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
+                    help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    wl = WORKLOADS[args.workload]
+    n = args.reads or wl["reads"]
+    L = wl["length"]
+
+    # ---- index: in HBM before anything is timed ------------------------------------------------
+    t0 = time.perf_counter()
+    if wl["index"] == "ecoli":
+        base = os.path.join(ROOT, "tests", "golden", "e_coli")
+        text_np = AL.restore_text(base)
+        index_note = "e_coli (bundled reference index, 4.9 Mbp)"
+    else:
+        from bowtie_amd import ebwt_build as EB
+        base, text_np, index_note = EB.ensure_big_index(args.genome, dev, rank, world)
+    idx = AL.Index(base, need_mirror=True, device=local)
+    text_t = torch.from_numpy(text_np).to(dev)
+    log("[bench] index %s loaded in %.1fs" % (index_note, time.perf_counter() - t0))
+
+    # ---- reads: synthetic, generated straight into HBM, sharded by rank -------------------------
+    t0 = time.perf_counter()
+    rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
+    del text_t
+    hit_cap = 1
+    hits = torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev)
+    n_hits = torch.zeros(n, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mm_cap = n * 8
+    mm_pool = torch.zeros(mm_cap, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
+
+    pol = A.make_policy(**wl["pol"])
+    stream = torch.cuda.current_stream().cuda_stream
+    al = AL.Aligner(idx, pol, stream=stream)
+    rbc = A.ReadBatchC(n, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(),
+                       rb["seed"].data_ptr())
+    hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), mm_pool.data_ptr(), mm_cap, 0)
+    lib = AL.lib()
+
+    def step():
+        rc = lib.bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None)
+        if rc != 0:
+            raise RuntimeError("bt_align_batch_device: " + AL.strerror(rc))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    cnt = A.OpCounts()
+    lib.bt_ctx_counts(al._h, C.byref(cnt), 1)        # reset: count the timed steps only
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if lib.bt_ctx_sync(al._h) != 0:
+            raise RuntimeError("bt_ctx_sync failed")
+        kernel_ms.append(float(lib.bt_ctx_last_kernel_ms(al._h)))   # HIP events on the kernel's stream
+    barrier()
+    wall = time.perf_counter() - t0
+    lib.bt_ctx_counts(al._h, C.byref(cnt), 0)
+    c = cnt.as_dict()
+
+    aligned = int((n_hits > 0).sum().item())
+    bad = int(((status & (A.BT_ST_OVERFLOW | A.BT_ST_MMPOOL)) != 0).sum().item())
+    tot = torch.tensor([wall, float(aligned), float(n), float(bad)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # the hit-count reduce over xGMI
+        wall = float(mx[0].item())
+    aligned_all, reads_all, bad_all = float(tot[1].item()), float(tot[2].item()), float(tot[3].item())
+
+    if rank == 0:
+        per_launch = {k: v / max(1, args.steps) for k, v in c.items()}
+        kavg = sum(kernel_ms) / len(kernel_ms)
+        abytes = algorithmic_bytes(per_launch, n, L, aligned)
+        achieved = abytes / (kavg * 1e-3) / 1e9
+        out = {
+            "metric": "aligned reads/sec (whole node)", "value": reads_all * args.steps / wall,
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": args.workload, "index": index_note, "read_len": L,
+                       "policy": wl["pol"], "reads_per_gpu_per_step": n,
+                       "reads_with_alignment_per_s": aligned_all * args.steps / wall,
+                       "pct_aligned": 100.0 * aligned_all / reads_all, "reads_overflowed": bad_all,
+                       "parallelism": "reads sharded x%d, index replicated" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "bt_search_kernel", "kernel_ms_avg": kavg,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames")},
+                         "lane_iters_per_read": per_launch["lane_iters"] / n},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(base, wl, text_np)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

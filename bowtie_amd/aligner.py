@@ -20,7 +20,7 @@ from .reads import ReadBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbowtie_amd.so")
 EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_refname",
-           "bt_index_reflen", "bt_index_free", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
+           "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
            "bt_align_batch_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used",
            "bt_ctx_counts", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase"]
 _lib = None
@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         L.bt_index_refname.restype = C.c_char_p
         L.bt_index_reflen.argtypes = [C.c_void_p, C.c_uint32]
         L.bt_index_reflen.restype = C.c_uint32
+        L.bt_index_restore_text.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
         L.bt_index_free.argtypes = [C.c_void_p]
         L.bt_index_free.restype = None
         L.bt_ctx_create.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.c_void_p, C.POINTER(C.c_void_p)]
@@ -76,6 +77,17 @@ def lib() -> C.CDLL:
 
 def strerror(code: int) -> str:
     return lib().bt_strerror(code).decode()
+
+
+def restore_text(base: str) -> np.ndarray:
+    """Joined reference text (codes 0..3) of an index, recovered on the host (bowtie-inspect's job)."""
+    with open(base + ".1.ebwt", "rb") as f:
+        hdr = np.frombuffer(f.read(8), dtype="<u4")
+    out = np.zeros(int(hdr[1]), dtype=np.uint8)
+    rc = lib().bt_index_restore_text(base.encode(), out.ctypes.data, len(out))
+    if rc != A.BT_OK:
+        raise BowtieAmdError(rc, "bt_index_restore_text(%s)" % base)
+    return out
 
 
 class Index:

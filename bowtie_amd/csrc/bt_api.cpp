@@ -179,8 +179,8 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", 2);
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
-	HIPCHK(hipMalloc((void**)&c->d_counts, 9 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(c->d_counts, 0, 9 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&c->d_counts, 10 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(c->d_counts, 0, 10 * sizeof(unsigned long long)));
 	*out = c;
 	return BT_OK;
 }
@@ -262,11 +262,11 @@ extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used 
 extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 {
 	if (!c || !out) return BT_ERR_ARG;
-	unsigned long long h[9];
+	unsigned long long h[10];
 	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
 	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
 	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
-	out->lane_iters = h[8];
+	out->lane_iters = h[8]; out->same_pair = h[9];
 	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
 	return BT_OK;
 }
@@ -308,7 +308,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	bt_hit_batch dout = *out;
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
-	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, 9 * sizeof(unsigned long long), c->stream));
+	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, 10 * sizeof(unsigned long long), c->stream));
 	int rc = run_device(c, &din, &dout, maxLen, nullptr);
 	if (rc != BT_OK) return rc;
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
@@ -362,6 +362,17 @@ extern "C" int bt_probe_chase(bt_ctx* c, int mirror, const uint32_t* rows, uint3
 	}
 	(void)hipFree(d);
 	return rc == 0 ? BT_OK : BT_ERR_DEVICE;
+}
+
+extern "C" int bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64_t cap)
+{
+	if (!ebwt_base || !out) return BT_ERR_ARG;
+	BtIndexHost h;
+	int rc = bt_host_index_load(ebwt_base, true, -1, &h);
+	if (rc != BT_OK) return rc;
+	if (cap < h.len) return BT_ERR_ARG;
+	bt_host_restore_text(h, out);
+	return BT_OK;
 }
 
 extern "C" const char* bt_strerror(int code)

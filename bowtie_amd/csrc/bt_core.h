@@ -109,7 +109,7 @@ enum {
 enum { RC_STEP = 0, RC_CHILD, RC_FELL, RC_ENTRY };
 enum { LFK_EX2 = 0, LFK_C2, LFK_LF1 };
 
-struct BtOpCnt { uint32_t lfex, lf2, lf1, chase, ftab, offs, rstarts, frames; };
+struct BtOpCnt { uint32_t lfex, lf2, lf1, chase, ftab, offs, rstarts, frames, samePair; };
 
 struct BtLane {
 	/* read */
@@ -441,12 +441,14 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 				L.state = ST_STEP_POST;
 			} else if (alt) {
 				req.rowA = rtop; req.rowB = rbot; req.op = 3; L.lfk = LFK_EX2; L.cnt.lfex++;
+				if (rtop / 448u == rbot / 448u) L.cnt.samePair++;
 				L.state = ST_STEP_LFDONE; return;
 			} else if (c < 4u) {
 				if (L.top + 1u == L.bot) {
 					req.rowA = L.top; req.op = 1; L.lfk = LFK_LF1; L.cnt.lf1++;
 				} else {
 					req.rowA = L.top; req.rowB = L.bot; req.op = 3; L.lfk = LFK_C2; L.cnt.lf2++;
+					if (L.top / 448u == L.bot / 448u) L.cnt.samePair++;
 				}
 				L.state = ST_STEP_LFDONE; return;
 			} else {

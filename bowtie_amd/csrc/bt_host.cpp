@@ -91,6 +91,23 @@ void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d)
 	d->zSym = (d->zSide & 1u) ? co : (223u - co);
 }
 
+void bt_host_restore_text(const BtIndexHost& h, uint8_t* out)
+{
+	BtIndexDev d;
+	bt_host_index_describe(h, &d);
+	std::vector<uint8_t> padded(h.ebwt);
+	padded.resize(padded.size() + 128);
+	d.ebwt = padded.data();
+	uint32_t i = h.len, jumps = 0;            /* the row of the suffix "$" (sorts last) */
+	while (i != h.zOff && jumps < h.len) {
+		uint32_t lf[4], L;
+		bt_rank4(d, i, lf, &L);
+		out[h.len - 1u - jumps] = (uint8_t)L;
+		i = lf[L];
+		jumps++;
+	}
+}
+
 /* ---- phase programs ------------------------------------------------------------------------ */
 static BtStep mk(bool mirror, bool readFw, int kind, bool re, bool cq, bool hh, bool maq, int rp,
                  int o0, int o1, int o2, int o3, int o4, int o5, uint32_t qt, uint32_t mb)

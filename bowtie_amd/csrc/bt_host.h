@@ -31,6 +31,10 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 /* Fill the device-visible descriptor from host-side geometry (pointers are left to the caller). */
 void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d);
 
+/* Ebwt::restore (ebwt.h:2793-2824): invert the BWT of a loaded index into the joined reference
+ * text (codes 0..3, `len` bytes).  Host-side utility (bowtie-inspect's job), not on the hot path. */
+void bt_host_restore_text(const BtIndexHost& h, uint8_t* out);
+
 /* Compile a bt_policy into the linear list of searcher invocations the reference's phase scripts
  * perform (search_exact.c, search_1mm_phase{1,2}.c, search_23mm_phase{1,2,3}.c,
  * search_seeded_phase{1..4}.c) with every policy-uniform condition (--nofw/--norc, seedMms)

@@ -17,7 +17,7 @@ struct BtKernelArgs {
 	uint64_t*  pals;             /* [nLanes][palCap]                                             */
 	uint32_t   nLanes, frCap, entCap, palCap;
 	uint32_t*  nextRead;         /* global read cursor                                           */
-	unsigned long long* counts;  /* 9 x u64: bt_op_counts fields + wavefront-iterations (lane sum) */
+	unsigned long long* counts;  /* 10 x u64 = bt_op_counts */
 };
 
 extern "C" {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
 
 	BtLane L;
 	L.state = ST_IDLE; L.mirror = 0;
-	L.cnt.lfex = L.cnt.lf2 = L.cnt.lf1 = L.cnt.chase = L.cnt.ftab = L.cnt.offs = L.cnt.rstarts = L.cnt.frames = 0;
+	L.cnt.lfex = L.cnt.lf2 = L.cnt.lf1 = L.cnt.chase = L.cnt.ftab = L.cnt.offs = L.cnt.rstarts = L.cnt.frames = L.cnt.samePair = 0;
 	BtRes res;
 	BtReq req;
 	res.LA = 0;
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
 	}
 
 	/* op counters: block-reduce, then one atomic per counter per block */
-	__shared__ unsigned long long sh[9];
-	if (threadIdx.x < 9) sh[threadIdx.x] = 0;
+	__shared__ unsigned long long sh[10];
+	if (threadIdx.x < 10) sh[threadIdx.x] = 0;
 	__syncthreads();
 	atomicAdd(&sh[0], (unsigned long long)L.cnt.lfex);
 	atomicAdd(&sh[1], (unsigned long long)L.cnt.lf2);
@@ -108,8 +108,9 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
 	atomicAdd(&sh[6], (unsigned long long)L.cnt.rstarts);
 	atomicAdd(&sh[7], (unsigned long long)L.cnt.frames);
 	atomicAdd(&sh[8], (unsigned long long)iters);
+	atomicAdd(&sh[9], (unsigned long long)L.cnt.samePair);
 	__syncthreads();
-	if (threadIdx.x < 9 && A.counts) atomicAdd(&A.counts[threadIdx.x], sh[threadIdx.x]);
+	if (threadIdx.x < 10 && A.counts) atomicAdd(&A.counts[threadIdx.x], sh[threadIdx.x]);
 }
 
 __global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)

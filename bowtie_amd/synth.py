@@ -58,3 +58,69 @@ def write_fastq(batch: ReadBatch, path: str) -> None:
             L = int(batch.len[i])
             f.write(b"@" + batch.names[i] + b"\n" + asc[batch.seq[i, :L]].tobytes() + b"\n+\n" +
                     batch.qual[i, :L].tobytes() + b"\n")
+
+
+# ---- torch twin: batches generated directly in HBM (bench.py) -------------------------------
+def synth_reads_torch(text_t, n: int, length: int, mm_dist=(0, 1, 2, 2, 3, 4), seed: int = 12345,
+                      n_frac: float = 0.01, qlo: int = 10, qhi: int = 40, first_id: int = 0,
+                      global_seed: int = 0, stride: int | None = None, chunk: int = 2_000_000):
+    """text_t: uint8 torch tensor (codes 0..3) on the target device.  Returns a dict of device
+    tensors {seq [n,stride] u8, qual [n,stride] u8, len [n] i16 (bit pattern of u16), seed [n] i32
+    (bit pattern of u32)} laid out as bt_read_batch wants.  Same distribution as synth_reads()
+    (not the same stream: torch's generator); per-read seeds follow genRandSeed (pat.cpp:21-57)
+    with names r<first_id + i>."""
+    import torch
+    dev = text_t.device
+    stride = stride or max(4, (length + 3) & ~3)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    T = text_t.numel()
+    seq = torch.full((n, stride), 4, dtype=torch.uint8, device=dev)
+    qual = torch.full((n, stride), 33, dtype=torch.uint8, device=dev)
+    seeds = torch.empty(n, dtype=torch.int32, device=dev)
+    ar = torch.arange(length, device=dev)
+    mmd = torch.tensor(list(mm_dist), device=dev)
+    base = ((global_seed + 101) * 59 * 61 * 67 * 71 * 73 * 79 * 83) & 0xFFFFFFFF
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        start = torch.randint(0, T - length + 1, (m,), generator=g, device=dev)
+        s = text_t[(start[:, None] + ar[None, :])]
+        rc = torch.rand(m, generator=g, device=dev) < 0.5
+        s = torch.where(rc[:, None], 3 - s.flip(1), s)
+        nmm = mmd[torch.randint(0, len(mm_dist), (m,), generator=g, device=dev)]
+        rows = torch.arange(m, device=dev)
+        for k in range(int(max(mm_dist)) if len(mm_dist) else 0):
+            pos = torch.randint(0, length, (m,), generator=g, device=dev)
+            add = torch.randint(1, 4, (m,), generator=g, device=dev).to(torch.uint8)
+            cur = s[rows, pos]
+            s[rows, pos] = torch.where(nmm > k, (cur + add) & 3, cur)
+        if n_frac > 0:
+            hasn = torch.rand(m, generator=g, device=dev) < n_frac
+            pos = torch.randint(0, length, (m,), generator=g, device=dev)
+            cur = s[rows, pos]
+            s[rows, pos] = torch.where(hasn, torch.full_like(cur, 4), cur)
+        q = (torch.randint(qlo, qhi + 1, (m, length), generator=g, device=dev) + 33).to(torch.uint8)
+        seq[lo:lo + m, :length] = s
+        qual[lo:lo + m, :length] = q
+        # genRandSeed
+        acc = torch.full((m,), base, dtype=torch.int64, device=dev)
+        for i in range(length):
+            acc ^= s[:, i].to(torch.int64) << ((i & 15) << 1)
+            acc ^= q[:, i].to(torch.int64) << ((i & 3) << 3)
+        ids = torch.arange(first_id + lo, first_id + lo + m, dtype=torch.int64, device=dev)
+        acc ^= ord("r")
+        ndig = torch.ones_like(ids)
+        p = 10
+        for _ in range(11):
+            ndig += (ids >= p).to(torch.int64)
+            p *= 10
+        for k in range(12):                       # digit k from the left sits at name index k+1
+            e = ndig - 1 - k
+            valid = e >= 0
+            div = torch.pow(torch.tensor(10, dtype=torch.int64, device=dev), e.clamp(min=0))
+            dig = (ids // div) % 10 + ord("0")
+            acc ^= torch.where(valid, dig << (((k + 1) & 3) << 3), torch.zeros_like(dig))
+        acc &= 0xFFFFFFFF
+        seeds[lo:lo + m] = torch.where(acc >= 2 ** 31, acc - 2 ** 32, acc).to(torch.int32)
+    lens = torch.full((n,), length, dtype=torch.int16, device=dev)
+    return {"seq": seq, "qual": qual, "len": lens, "seed": seeds, "n": n, "stride": stride, "length": length}

@@ -124,6 +124,7 @@ typedef struct bt_op_counts {
 	uint64_t rstarts;         /* rstarts probes                                               */
 	uint64_t frames;          /* backtrack frames entered                                     */
 	uint64_t lane_iters;      /* sum over lanes of lock-step iterations (GPU only)            */
+	uint64_t same_pair;       /* two-locus steps whose rows share one 128-byte side pair      */
 } bt_op_counts;
 
 /* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */
@@ -145,6 +146,9 @@ void bt_index_info_get(const bt_index* idx, bt_index_info* info);
 const char* bt_index_refname(const bt_index* idx, uint32_t tidx);   /* Ebwt::refnames()      */
 uint32_t    bt_index_reflen (const bt_index* idx, uint32_t tidx);   /* Ebwt::plen()          */
 void bt_index_free(bt_index* idx);
+/* Host-side utility (no GPU): joined reference text of <base>.1.ebwt as codes 0..3, `len` bytes
+ * (Ebwt::restore, ebwt.h:2793-2824; what bowtie-inspect prints).  cap = bytes available in out. */
+int  bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64_t cap);
 
 /* Replaces: the per-thread set-up at the top of each worker (sink, params, 1..9
  * GreedyDFSRangeSource objects; ebwt_search.cpp:1155, 2082-2134, 2413-2539).  One ctx per GPU,

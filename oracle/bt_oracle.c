@@ -206,12 +206,13 @@ void bto_restore_text(const bto_index* ix, uint8_t* out)
 }
 
 /* joinedToTextOff, ebwt.h:2569-2629 */
-int bto_joined_to_text(const bto_index* ix, uint32_t qlen, uint32_t off,
-                       uint32_t* tidx, uint32_t* toff, uint32_t* tlen)
+static int joined_to_text_cnt(const bto_index* ix, uint32_t qlen, uint32_t off,
+                              uint32_t* tidx, uint32_t* toff, uint32_t* tlen, uint64_t* probes)
 {
 	uint32_t top = 0, bot = ix->nFrag;
 	for (;;) {
 		uint32_t elt = top + ((bot - top) >> 1);
+		if (probes) (*probes)++;
 		uint32_t lower = ix->rstarts[elt * 3];
 		uint32_t upper = (elt == ix->nFrag - 1) ? ix->len : ix->rstarts[(elt + 1) * 3];
 		uint32_t fraglen = upper - lower;
@@ -231,6 +232,12 @@ int bto_joined_to_text(const bto_index* ix, uint32_t qlen, uint32_t off,
 	}
 	if (tlen) *tlen = ix->plen[*tidx];
 	return 1;
+}
+
+int bto_joined_to_text(const bto_index* ix, uint32_t qlen, uint32_t off,
+                       uint32_t* tidx, uint32_t* toff, uint32_t* tlen)
+{
+	return joined_to_text_cnt(ix, qlen, off, tidx, toff, tlen, NULL);
 }
 
 /* genRandSeed, pat.cpp:21-57 */
@@ -350,7 +357,7 @@ static int dfs_report_row(dfs_t* s, uint32_t numMms, uint32_t row, uint32_t top,
 	uint32_t off = bto_chase(ix, row, &jumps);
 	if (s->cnt) { s->cnt->chase += jumps; s->cnt->offs++; }
 	uint32_t tidx, toff, tlen;
-	if (!bto_joined_to_text(ix, s->qlen, off, &tidx, &toff, &tlen)) return 0;
+	if (!joined_to_text_cnt(ix, s->qlen, off, &tidx, &toff, &tlen, s->cnt ? &s->cnt->rstarts : NULL)) return 0;
 	bto_hit h;
 	memset(&h, 0, sizeof(h));
 	h.tidx = tidx; h.toff = toff; h.oms = bot - top - 1;
@@ -450,6 +457,7 @@ static int dfs_hh_check_top(const dfs_t* s, uint32_t stackDepth, uint32_t d)
 
 static void dfs_lf_pair(dfs_t* s, uint32_t top, uint32_t bot, uint32_t tops[4], uint32_t bots[4])
 {
+	if (s->cnt && top / 448 == bot / 448) s->cnt->same_pair++;
 	bto_rank4(s->ix, top, tops);
 	bto_rank4(s->ix, bot, bots);
 }

@@ -10,6 +10,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if not hasattr(config, "workerinput"):
+        # build the checkers once, before any xdist worker can race on the .so files
+        import emu_lib
+        import oracle_lib
+        oracle_lib.lib()
+        emu_lib.lib()
 
 
 def _has_gpu() -> bool:

@@ -102,6 +102,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 			counts->lfex += lanes[g].cnt.lfex; counts->lf2 += lanes[g].cnt.lf2; counts->lf1 += lanes[g].cnt.lf1;
 			counts->chase += lanes[g].cnt.chase; counts->ftab += lanes[g].cnt.ftab; counts->offs += lanes[g].cnt.offs;
 			counts->rstarts += lanes[g].cnt.rstarts; counts->frames += lanes[g].cnt.frames;
+			counts->same_pair += lanes[g].cnt.samePair;
 		}
 		counts->lane_iters = iters;
 	}

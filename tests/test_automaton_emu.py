@@ -1,0 +1,91 @@
+"""Host build of the per-read automaton (bowtie_amd/csrc/bt_core.h, the code the HIP kernel runs
+per lane) against the oracle, where no GPU exists.  The automaton is driven exactly like the
+kernel drives it: lock-step lanes, LF requests answered between steps, lanes refilled from a
+cursor.  This checks the *logic*; GPU parity proper is tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import common as T
+import emu_lib as E
+import oracle_lib as OL
+from bowtie_amd import _abi as A
+from bowtie_amd.reads import Read, pack_reads
+from bowtie_amd.synth import synth_reads
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return {n: E.EmuAligner(T.G + "/" + n) for n in ("e_coli", "multi")}
+
+
+def test_rank_emu_vs_oracle(emu):
+    rng = np.random.default_rng(1)
+    for name in ("e_coli", "multi"):
+        oi = T.oracle_index(name)
+        rows = list(rng.integers(0, oi.fw.len + 1, size=3000)) + [0, 1, 223, 224, 447, 448, oi.fw.zOff,
+                                                                   oi.fw.zOff + 1, oi.fw.len]
+        for mirror in (False, True):
+            z = oi.ix(mirror).zOff
+            for r in rows:
+                lf, L = emu[name].rank4(int(r), mirror)
+                olf, oL = oi.rank4(int(r), mirror)
+                assert lf == olf, (name, mirror, r)
+                if r != z:
+                    assert L == oL
+
+
+@pytest.mark.parametrize("run", T.golden_runs(reads=("e_coli_1000", "syn100", "syn50lowq", "syn12")),
+                         ids=lambda r: r["file"][:-7])
+def test_emu_matches_reference_sam(run, emu):
+    batch = T.read_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = emu[run["index"]].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384,
+                                  n_lanes=37)
+    T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("mode", ["v0", "v1", "v2", "n2", "n3", "n2_k3", "n2_nomaq", "n1_a_m20"])
+def test_emu_vs_oracle_ragged(mode, emu):
+    """Ragged lengths (4..150), Ns, low qualities; results *and* op counts equal the oracle's."""
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(99)
+    reads = []
+    for i in range(300):
+        L = int(rng.integers(4, 151))
+        b = synth_reads(text, 1, L, mm_dist=(0, 1, 2, 3), seed=1000 + i, n_frac=0.2, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :L].copy(), b.qual[0, :L].tobytes()))
+    batch = pack_reads(reads)
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+    got = emu["multi"].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), counts=ec, pal_cap=16384,
+                             n_lanes=64, ent_cap=12 * 160)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(ec, f), f
+
+
+def test_emu_lane_count_independence(emu):
+    batch = T.read_set("multi", "syn76")
+    pol = A.make_policy(**T.MODES["n2"])
+    d = {n: T.result_digest(emu["multi"].align(pol, batch, n_lanes=n)) for n in (1, 7, 64, 1000)}
+    assert len(set(d.values())) == 1
+
+
+def test_emu_too_short_and_skipped(emu):
+    reads = [Read(b"a", np.array([0, 1, 2], dtype=np.uint8), b"III"),
+             Read(b"b", np.array([0, 1, 2, 3, 0, 1, 2, 3, 1], dtype=np.uint8), b"IIIIIIIII"),
+             Read(b"c", np.array([4, 4, 4, 1, 2, 3, 0, 1, 2], dtype=np.uint8), b"IIIIIIIII")]
+    batch = pack_reads(reads)
+    res = emu["multi"].align(A.make_policy(**T.MODES["v2"]), batch)
+    assert res[0][2] & A.BT_ST_TOOSHORT and not (res[1][2] & A.BT_ST_TOOSHORT)
+    res = emu["multi"].align(A.make_policy(**T.MODES["n2"]), batch)
+    assert res[0][2] & A.BT_ST_SKIPPED and res[2][2] & A.BT_ST_SKIPPED and not res[1][2]
+    want = T.oracle_results("multi", batch, T.MODES["n2"])
+    T.compare_results(res, want)
+
+
+def test_emu_overflow_is_flagged(emu):
+    batch = T.read_set("multi", "syn100")
+    res = emu["multi"].align(A.make_policy(**T.MODES["n2"]), batch, ent_cap=64)
+    assert any(st & A.BT_ST_OVERFLOW for _, _, st in res)

@@ -1,0 +1,158 @@
+"""GPU parity (run on the MI355X box: pytest -m gpu).  Everything goes through the C ABI
+(libbowtie_amd.so -> HIP kernels); the oracle and the reference's golden outputs are the checkers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import common as T
+from bowtie_amd import _abi as A
+from bowtie_amd import aligner as AL
+from bowtie_amd.reads import Read, pack_reads
+from bowtie_amd.synth import synth_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gidx():
+    return {n: AL.Index(os.path.join(T.G, n)) for n in ("e_coli", "multi")}
+
+
+def aligner(gidx, name, kw):
+    return AL.Aligner(gidx[name], A.make_policy(**kw))
+
+
+def test_probe_rank_known_answers(gidx):
+    with open(os.path.join(T.G, "rank_vectors.json")) as f:
+        v = json.load(f)
+    al = aligner(gidx, "e_coli", T.MODES["v0"])
+    rows = np.array([int(r) for r in v["rows"]], dtype=np.uint32)
+    lf, L = al.probe_rank(rows)
+    for i, r in enumerate(rows):
+        e = v["rows"][str(int(r))]
+        assert list(lf[i]) == e["lf"], r
+        if int(r) != v["zOff"]:
+            assert int(L[i]) == e["L"], r
+    j, t, o = al.probe_chase(np.array([v["chase"]["row"]], dtype=np.uint32), 36)
+    assert (int(j[0]), int(t[0]), int(o[0])) == (v["chase"]["joined"], v["chase"]["tidx"], v["chase"]["toff"])
+
+
+@pytest.mark.parametrize("name", ["e_coli", "multi"])
+def test_probe_rank_and_chase_vs_oracle(gidx, name):
+    oi = T.oracle_index(name)
+    rng = np.random.default_rng(5)
+    rows = np.concatenate([rng.integers(0, oi.fw.len + 1, size=20000),
+                           [0, 1, 223, 224, 447, 448, oi.fw.zOff, oi.fw.zOff + 1, oi.fw.len]]).astype(np.uint32)
+    al = aligner(gidx, name, T.MODES["n2"])
+    for mirror in (False, True):
+        lf, L = al.probe_rank(rows, mirror)
+        z = oi.ix(mirror).zOff
+        for i in range(0, len(rows), 7):
+            olf, oL = oi.rank4(int(rows[i]), mirror)
+            assert list(lf[i]) == olf
+            if rows[i] != z:
+                assert int(L[i]) == oL
+        sub = rows[:3000]
+        j, t, o = al.probe_chase(sub, 30, mirror)
+        for i in range(0, len(sub), 3):
+            off, _ = oi.chase(int(sub[i]), mirror)
+            assert int(j[i]) == off
+            assert (int(t[i]), int(o[i])) == oi.joined_to_text(30, off, mirror)
+
+
+@pytest.mark.parametrize("run", T.golden_runs(), ids=lambda r: r["file"][:-7])
+def test_gpu_matches_reference_sam(run, gidx):
+    """HIP path -> SAM == the unmodified reference's SAM, byte for byte."""
+    batch = T.read_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    al = aligner(gidx, run["index"], kw)
+    res = al.align(batch, hit_cap=T.hit_cap_for(kw))
+    T.check_against_golden(run, res, batch, gidx[run["index"]].refnames)
+
+
+@pytest.mark.parametrize("mode", ["v0", "v1", "v2", "n0", "n1", "n2", "n3", "n2_k3", "n2_nomaq", "n1_a_m20"])
+def test_gpu_vs_oracle_ragged(mode, gidx):
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(99)
+    reads = []
+    for i in range(1500):
+        L = int(rng.integers(4, 151))
+        b = synth_reads(text, 1, L, mm_dist=(0, 1, 2, 3), seed=1000 + i, n_frac=0.2, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :L].copy(), b.qual[0, :L].tobytes()))
+    batch = pack_reads(reads)
+    import oracle_lib as OL
+    oc, gc = OL.OpCounts(), A.OpCounts()
+    want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+    got = aligner(gidx, "multi", kw).align(batch, hit_cap=T.hit_cap_for(kw), counts=gc)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(gc, f), f
+
+
+@pytest.mark.parametrize("mode,length,n", [("v0", 36, 20000), ("v2", 76, 20000), ("n2", 100, 20000)])
+def test_gpu_vs_oracle_e_coli_synthetic(mode, length, n, gidx):
+    kw = T.MODES[mode]
+    batch = synth_reads(T.joined_text("e_coli"), n, length, seed=4242 + length)
+    want = T.oracle_results("e_coli", batch, kw)
+    got = aligner(gidx, "e_coli", kw).align(batch)
+    T.compare_results(got, want, mode)
+
+
+def test_gpu_large_batch_properties(gidx):
+    """BASELINE config-2 size (1M x 36 bp, -v 0): properties that need no oracle run --
+    idempotence, batch-split invariance, permutation equivariance, and every reported hit
+    re-verified against the reference text."""
+    text = T.joined_text("e_coli")
+    n = 1_000_000
+    batch = synth_reads(text, n, 36, mm_dist=(0,), seed=777, n_frac=0.0)
+    al = aligner(gidx, "e_coli", T.MODES["v0"])
+    r1 = al.align(batch)
+    assert T.result_digest(r1) == T.result_digest(al.align(batch))
+    aligned = sum(1 for h, _, _ in r1 if h)
+    assert aligned == n                                   # exact reads drawn from the text
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    for i in range(0, n, 997):
+        h = r1[i][0][0]
+        s = batch.seq[i, :36]
+        if not h.fw:
+            s = comp[s[::-1]]
+        assert (text[h.toff:h.toff + 36] == s).all()
+    # permutation equivariance on a slice
+    from bowtie_amd.reads import ReadBatch
+    sl = slice(0, 50000)
+    perm = np.random.default_rng(3).permutation(50000)
+    pb = ReadBatch(batch.seq[sl][perm], batch.qual[sl][perm], batch.len[sl][perm], batch.seed[sl][perm],
+                   [batch.names[i] for i in perm])
+    rp = al.align(pb)
+    for k in range(0, 50000, 101):
+        assert rp[k] == r1[perm[k]]
+
+
+def test_gpu_empty_and_edge_batches(gidx):
+    al = aligner(gidx, "multi", T.MODES["n2"])
+    from bowtie_amd.reads import ReadBatch
+    empty = ReadBatch(np.zeros((0, 4), np.uint8), np.zeros((0, 4), np.uint8), np.zeros(0, np.uint16),
+                      np.zeros(0, np.uint32), [])
+    assert al.align(empty) == []
+    reads = [Read(b"a", np.array([0, 1, 2], dtype=np.uint8), b"III"),
+             Read(b"c", np.array([4, 4, 4, 1, 2, 3, 0, 1, 2], dtype=np.uint8), b"IIIIIIIII"),
+             Read(b"one", np.array([2] * 9, dtype=np.uint8), b"I" * 9)]
+    batch = pack_reads(reads)
+    got = al.align(batch)
+    T.compare_results(got, T.oracle_results("multi", batch, T.MODES["n2"]))
+    assert got[0][2] & A.BT_ST_SKIPPED and got[1][2] & A.BT_ST_SKIPPED
+    with pytest.raises(AL.BowtieAmdError) as e:
+        aligner(gidx, "multi", T.MODES["v2"]).align(batch)
+    assert e.value.code == A.BT_ERR_READ_SHORT
+
+
+def test_gpu_max_length_reads(gidx):
+    """1024-bp reads (the reference's FixedBitset<1024> ceiling, hit.h:66)."""
+    text = T.joined_text("e_coli")
+    batch = synth_reads(text, 64, 1024, mm_dist=(0, 1, 2), seed=31, n_frac=0.0)
+    for mode in ("v2", "n2"):
+        kw = T.MODES[mode]
+        T.compare_results(aligner(gidx, "e_coli", kw).align(batch), T.oracle_results("e_coli", batch, kw), mode)
