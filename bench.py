@@ -71,35 +71,30 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
     cores = os.cpu_count() or 1
     if os.path.exists(ref_bin):
-        # calibrate: 20k reads first, then size the sample for ~`seconds`
-        n = 20000
-        out = None
+        # two runs of different size: the difference cancels the fixed cost (index load from the
+        # page cache, spawning `cores` threads), leaving the reference's search throughput
+        runs = []
         with tempfile.TemporaryDirectory() as td:
+            n = 200_000
             for attempt in range(2):
                 batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
                 fq = os.path.join(td, "s.fq")
                 write_fastq(batch, fq)
                 t0 = time.perf_counter()
-                p = subprocess.run([ref_bin, "--wrapper", "basic-0", "-p", str(cores), "-t"] + args +
+                p = subprocess.run([ref_bin, "--wrapper", "basic-0", "-p", str(cores)] + args +
                                    ["-x", base, fq, os.devnull], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 wall = time.perf_counter() - t0
                 if p.returncode != 0:
                     break
-                err = p.stderr.decode()
-                ts = None
-                for line in err.split("\n"):
-                    if line.startswith("Time searching:"):
-                        hh, mm, ss = line.split(":", 1)[1].strip().split(":")
-                        ts = int(hh) * 3600 + int(mm) * 60 + int(ss)
-                rate = n / max(wall, 1e-3)
-                out = {"value": rate, "unit": "reads/s", "cores": cores, "kind": "reference",
-                       "sample": "%d synthetic %d-bp reads, bowtie-align-s -p %d %s, wall %.2fs incl. index load "
-                                 "(reference's own 'Time searching' %ss)" %
-                                 (n, wl["length"], cores, " ".join(args), wall, ts)}
-                if attempt == 0:
-                    n = int(min(5_000_000, max(20000, rate * seconds)))
-        if out:
-            return out
+                runs.append((n, wall))
+                n = int(min(8_000_000, max(600_000, 2.0 * seconds * n / wall)))
+        if len(runs) == 2:
+            (n1, t1), (n2, t2) = runs
+            rate = (n2 - n1) / (t2 - t1) if t2 > 1.2 * t1 else n2 / t2
+            return {"value": rate, "unit": "reads/s", "cores": cores, "kind": "reference",
+                    "sample": "unmodified bowtie-align-s -p %d %s on the same index: %d reads in %.2fs and %d reads "
+                              "in %.2fs wall (incl. index load); value = (n2-n1)/(t2-t1)" %
+                              (cores, " ".join(args), n1, t1, n2, t2)}
     # port: the C restatement, one core
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as OL

@@ -1,0 +1,430 @@
+"""GPU construction of Bowtie `.ebwt` indexes (torch; runs on the MI355X or, for small genomes,
+on the CPU).
+
+Why this exists: the headline benchmark is quoted on an hg19-scale index, and neither hg19 nor a
+network exists on the bench box, while reference `bowtie-build` needs hours for 2.9 Gbp.  This
+module synthesises a genome of that scale and indexes it in HBM in about a minute, writing files
+that are *byte-identical* to what reference `bowtie-build` writes for the same sequences
+(tests/test_ebwt_build.py checks that against the reference binary), so that both this project's
+loader and the unmodified reference aligner (the CPU baseline) read the very same index.
+
+It is bench/test infrastructure for the search hot path, not a re-implementation of the
+reference's indexer (blockwise difference-cover SA, ebwt_build.cpp/blockwise_sa.h): the suffix
+array here comes from one radix sort of 32-mer keys plus prefix-doubling on the non-unique rest,
+which is the natural thing to do with 288 GB of HBM.
+
+On-disk format follows Ebwt::writeFromMemory / joinToDisk / szsToDisk / buildToDisk
+(ebwt.h:3602-3672, 3825-3960, 1645-1675, 3986-4388): see `write_index`.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import time
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+SIDE_SYMS = 224
+_MAX_SORT = 1 << 30          # keep every device sort well below INT_MAX elements
+
+
+def _log(msg):
+    if os.environ.get("BT_BUILD_VERBOSE"):
+        print("[ebwt_build] " + msg, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# suffix array of text+'$' with '$' sorting LAST (bowtie's convention: row len is the suffix "$")
+# ---------------------------------------------------------------------------------------------
+def _kmer32_keys(s: torch.Tensor) -> torch.Tensor:
+    """key[i] = the 32-mer at i (text padded with T), as an order-preserving signed int64."""
+    n = s.numel()
+    k = torch.full((n + 1 + 32,), 3, dtype=torch.int64, device=s.device)
+    k[:n] = s
+    w = 1
+    while w < 32:                       # k_{2w}[i] = k_w[i] << 2w | k_w[i+w]
+        nk = k.clone()
+        nk[:-w] = (k[:-w] << (2 * w)) | k[w:]
+        k = nk
+        w *= 2
+    k = k[:n + 1]
+    return k ^ (-(1 << 63))             # unsigned order -> signed order
+
+
+def _chunks_at_group_starts(is_start: torch.Tensor, max_chunk: int) -> List[Tuple[int, int]]:
+    """Split [0,n) into ranges of about max_chunk elements that begin at group starts."""
+    n = is_start.numel()
+    if n <= max_chunk:
+        return [(0, n)]
+    cuts = [0]
+    while cuts[-1] + max_chunk < n:
+        lo = cuts[-1] + max_chunk
+        nxt = torch.nonzero(is_start[lo:lo + (1 << 24)])[:1]
+        if nxt.numel() == 0:
+            nxt = torch.nonzero(is_start[lo:])[:1]
+            if nxt.numel() == 0:
+                break
+        cuts.append(lo + int(nxt[0].item()))
+    cuts.append(n)
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+_CH = 1 << 29              # element chunk for the "giant array" passes (every kernel sees < 2^31)
+
+
+def _nonzero(mask: torch.Tensor) -> torch.Tensor:
+    """torch.nonzero on a 1-D mask of any length (chunked: < 2^31 elements per kernel)."""
+    n = mask.numel()
+    if n <= _CH:
+        return torch.nonzero(mask).squeeze(1)
+    out = [torch.nonzero(mask[lo:lo + _CH]).squeeze(1) + lo for lo in range(0, n, _CH)]
+    return torch.cat(out)
+
+
+def _group_start_rank(is_start: torch.Tensor) -> torch.Tensor:
+    """rank of the first slot of each slot's group (chunked cummax with carry)."""
+    n = is_start.numel()
+    out = torch.empty(n, dtype=torch.int64, device=is_start.device)
+    carry = 0
+    for lo in range(0, n, _CH):
+        hi = min(n, lo + _CH)
+        ar = torch.arange(lo, hi, dtype=torch.int64, device=is_start.device)
+        g = torch.cummax(torch.where(is_start[lo:hi], ar, torch.zeros_like(ar)), 0).values
+        g = torch.clamp(g, min=carry)
+        out[lo:hi] = g
+        carry = int(g[-1].item())
+    return out
+
+
+def _sort_into(key, idx, sa, is_start, pos):
+    ks, perm = torch.sort(key[idx])
+    m = idx.numel()
+    sa[pos:pos + m] = idx[perm]
+    st = torch.ones(m, dtype=torch.bool, device=key.device)
+    st[1:] = ks[1:] != ks[:-1]
+    is_start[pos:pos + m] = st
+    return pos + m
+
+
+def suffix_array(s: torch.Tensor) -> torch.Tensor:
+    """s: uint8 codes 0..3 -> SA (int64, length n+1) of s+'$' with '$' greater than ACGT."""
+    dev = s.device
+    n = s.numel()
+    key = _kmer32_keys(s)
+    # 1) radix sort of the 32-mer keys, bucketed by the first two (or four) characters
+    sa = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    is_start = torch.empty(n + 1, dtype=torch.bool, device=dev)
+    pos = 0
+    for b in range(16):
+        idx = _nonzero((((key >> 60) & 15) ^ 8) == b)       # first two characters (undo the sign flip)
+        m = idx.numel()
+        if m == 0:
+            continue
+        if m > _MAX_SORT:
+            sub = (key[idx] >> 56) & 15
+            for b2 in range(16):
+                idx2 = idx[sub == b2]
+                if idx2.numel():
+                    pos = _sort_into(key, idx2, sa, is_start, pos)
+            del sub
+        else:
+            pos = _sort_into(key, idx, sa, is_start, pos)
+        del idx
+    del key
+    assert pos == n + 1
+    # 2) prefix doubling on the suffixes whose 32-mer is not unique
+    rank = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    grp = _group_start_rank(is_start)
+    for lo in range(0, n + 1, _CH):
+        rank[sa[lo:lo + _CH]] = grp[lo:lo + _CH]
+    del grp
+    h = 32
+    while True:
+        nxt_start = torch.ones(n + 1, dtype=torch.bool, device=dev)
+        nxt_start[:-1] = is_start[1:]
+        upos = _nonzero(~(is_start & nxt_start))              # SA slots in groups of size > 1
+        del nxt_start
+        if upos.numel() == 0:
+            break
+        _log("doubling h=%d: %d suffixes in non-unique groups" % (h, upos.numel()))
+        ust = is_start[upos]
+        staged = []
+        for lo, hi in _chunks_at_group_starts(ust, _MAX_SORT):
+            p = upos[lo:hi]
+            el = sa[p]
+            j = el + h
+            # beyond the end: larger than every real rank, and larger for the shorter suffix
+            r2 = torch.where(j <= n, rank[j.clamp(max=n)], (1 << 32) - 1 - (n - el))
+            k2 = (rank[el] << 32) | r2
+            ks, perm = torch.sort(k2)
+            el = el[perm]
+            sa[p] = el
+            st = torch.ones(p.numel(), dtype=torch.bool, device=dev)
+            st[1:] = ks[1:] != ks[:-1]
+            is_start[p] = st
+            g = torch.cummax(torch.where(st, p, torch.zeros_like(p)), 0).values
+            staged.append((el, g))      # every chunk of a round must read the *old* ranks
+        for el, g in staged:
+            rank[el] = g
+        del staged
+        h *= 2
+        if h > 4 * (n + 1):
+            raise RuntimeError("suffix_array: doubling did not converge")
+    return sa
+
+
+# ---------------------------------------------------------------------------------------------
+# index arrays from (text, SA)
+# ---------------------------------------------------------------------------------------------
+def build_arrays(s: torch.Tensor, off_rate: int = 5, ftab_chars: int = 10):
+    """-> dict(ebwt u8 [numSides*64], zOff, fchr[5], ftab, eftab, offs) as CPU numpy arrays."""
+    dev = s.device
+    n = s.numel()
+    sa = suffix_array(s)
+    # BWT (the '$' row stores an A, uncounted); pad to whole side pairs with A (counted)
+    bwt_sz = n // 4 + 1
+    num_pairs = (bwt_sz + 2 * 56 - 1) // (2 * 56)
+    num_sides = 2 * num_pairs
+    tot = num_sides * SIDE_SYMS
+    bwt = torch.zeros(tot, dtype=torch.uint8, device=dev)
+    zoff = -1
+    ftab_len = (1 << (2 * ftab_chars)) + 1
+    nb = ftab_len - 1
+    count = torch.zeros(nb, dtype=torch.int64, device=dev)
+    first = torch.full((nb,), n + 2, dtype=torch.int64, device=dev)
+    last = torch.full((nb,), -1, dtype=torch.int64, device=dev)
+    zero8 = torch.zeros(1, dtype=torch.uint8, device=dev)
+    for lo in range(0, n + 1, _CH):
+        hi = min(n + 1, lo + _CH)
+        el = sa[lo:hi]
+        bwt[lo:hi] = torch.where(el > 0, s[(el - 1).clamp(min=0)], zero8)
+        z = torch.nonzero(el == 0)
+        if z.numel():
+            zoff = lo + int(z[0].item())
+        # ftab buckets of the rows whose suffix has >= ftabChars characters (ebwt.h:4150-4180)
+        rows = torch.nonzero((n - el) >= ftab_chars).squeeze(1)
+        e2 = el[rows]
+        suf = torch.zeros(e2.numel(), dtype=torch.int64, device=dev)
+        for i in range(ftab_chars):
+            suf = (suf << 2) | s[e2 + i].to(torch.int64)
+        rows = rows + lo
+        count += torch.bincount(suf, minlength=nb)
+        first.scatter_reduce_(0, suf, rows, reduce="amin", include_self=True)
+        last.scatter_reduce_(0, suf, rows, reduce="amax", include_self=True)
+        del el, rows, e2, suf
+    # offs sample: rows that are multiples of 2^offRate
+    offs = sa[:: (1 << off_rate)].cpu().numpy().astype(np.uint32)
+    del sa
+    # fchr
+    cnt = np.zeros(4, dtype=np.int64)
+    for lo in range(0, n, _CH):
+        cnt += torch.bincount(s[lo:lo + _CH].to(torch.int64), minlength=4)[:4].cpu().numpy()
+    fchr = np.zeros(5, dtype=np.uint32)
+    fchr[1:] = np.cumsum(cnt)
+    # ftab / eftab (ebwt.h:4325-4370): lo(i) = end of the last non-empty bucket < i (short suffixes
+    # excluded), hi(i) = first row of bucket i; where they differ the pair goes to eftab
+    nonempty = count > 0
+    end_excl = torch.where(nonempty, last + 1, torch.zeros_like(last))
+    run_end = torch.cummax(end_excl, 0).values
+    lo_t = torch.zeros(ftab_len, dtype=torch.int64, device=dev)
+    lo_t[1:] = run_end
+    hi_t = lo_t.clone()
+    hi_t[:nb] = torch.where(nonempty, first, lo_t[:nb])
+    hi_t[nb] = n + 1
+    lo_a, hi_a = lo_t.cpu().numpy(), hi_t.cpu().numpy()
+    ftab = lo_a.astype(np.uint32).copy()
+    eftab = np.zeros(2 * ftab_chars, dtype=np.uint32)
+    absorbed = np.nonzero(hi_a[1:] != lo_a[1:])[0] + 1
+    if len(absorbed) > ftab_chars:
+        raise RuntimeError("eftab overflow")
+    for k, i in enumerate(absorbed):
+        eftab[2 * k] = lo_a[i]
+        eftab[2 * k + 1] = hi_a[i]
+        ftab[i] = np.uint32(k ^ 0xFFFFFFFF)
+    ftab[0] = 0
+    # sides: 56 BWT bytes + two counters; counters = counts over BWT rows [0, 224*(2p+1)), '$' uncounted
+    sides = bwt.view(num_sides, SIDE_SYMS)
+    ebwt = torch.zeros(num_sides, 64, dtype=torch.uint8, device=dev)
+    SCH = (1 << 22)                                            # sides per chunk (even)
+    carry = torch.zeros(4, dtype=torch.int64, device=dev)
+    zside = zoff // SIDE_SYMS
+    first_mid_after = (zside // 2) if (zside % 2 == 0) else (zside // 2 + 1)
+    for lo in range(0, num_sides, SCH):
+        hi = min(num_sides, lo + SCH)
+        sd = sides[lo:hi]
+        occ_side = torch.stack([(sd == c).sum(1) for c in range(4)], 1).to(torch.int64)
+        cum = torch.cumsum(occ_side, 0) + carry[None, :]
+        carry = cum[-1].clone()
+        mid = cum[0::2].clone()                                  # after each backward (even) side
+        pidx = torch.arange(lo // 2, hi // 2, device=dev)
+        mid[:, 0] -= (pidx >= first_mid_after).to(torch.int64)
+        sym = sd.clone()
+        sym[0::2] = sd[0::2].flip(1)                             # backward sides store reversed
+        q = sym.view(hi - lo, 56, 4).to(torch.int32)
+        ebwt[lo:hi, :56] = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).to(torch.uint8)
+        m32 = mid.to(torch.int32)
+        ebwt[lo:hi:2, 56:] = m32[:, 0:2].contiguous().view(torch.uint8).view(-1, 8)
+        ebwt[lo + 1:hi:2, 56:] = m32[:, 2:4].contiguous().view(torch.uint8).view(-1, 8)
+        del sd, occ_side, cum, mid, sym, q, m32
+    return dict(ebwt=ebwt.view(-1).cpu().numpy(), zOff=zoff, fchr=fchr, ftab=ftab, eftab=eftab, offs=offs,
+                len=n, off_rate=off_rate, ftab_chars=ftab_chars)
+
+
+# ---------------------------------------------------------------------------------------------
+# sequences -> joined text + fragment table (fastaRefReadSizes / szsToDisk semantics)
+# ---------------------------------------------------------------------------------------------
+def fragments_of(seqs: Sequence[np.ndarray]):
+    """seqs: per reference sequence, codes 0..4 (4 = N).  -> (plen, rstarts[nFrag,3], frag slices)."""
+    plen, rst, frs = [], [], []
+    tot = 0
+    seq_id = 0
+    for s in seqs:
+        isn = np.concatenate([[True], s == 4, [True]])
+        d = np.diff(isn.astype(np.int8))
+        starts = np.nonzero(d == -1)[0]
+        ends = np.nonzero(d == 1)[0]
+        if len(starts) == 0:
+            continue                                    # all-N sequence: not indexed
+        for a, b in zip(starts, ends):
+            rst.append((tot, seq_id, int(a)))
+            frs.append((seq_id, int(a), int(b)))
+            tot += int(b - a)
+        plen.append(len(s))
+        seq_id += 1
+    return np.array(plen, dtype=np.uint32), np.array(rst, dtype=np.uint32).reshape(-1, 3), frs
+
+
+def write_index(base: str, arrays: dict, plen: np.ndarray, rstarts: np.ndarray, names: Sequence[str]):
+    """`.1.ebwt`: i32 1, len, lineRate 6, linesPerSide 1, offRate, ftabChars, flags -1, nPat, plen[],
+    nFrag, rstarts[3*nFrag], ebwt[], zOff, fchr[5], ftab[], eftab[], names '\\n'-separated + '\\0'.
+    `.2.ebwt`: i32 1, offs[]."""
+    a = arrays
+    with open(base + ".1.ebwt", "wb") as f:
+        f.write(struct.pack("<iIiiiii", 1, a["len"], 6, 1, a["off_rate"], a["ftab_chars"], -1))
+        f.write(struct.pack("<I", len(plen)))
+        f.write(np.asarray(plen, dtype="<u4").tobytes())
+        f.write(struct.pack("<I", len(rstarts)))
+        f.write(np.asarray(rstarts, dtype="<u4").tobytes())
+        f.write(np.ascontiguousarray(a["ebwt"]).tobytes())
+        f.write(struct.pack("<I", a["zOff"]))
+        f.write(np.asarray(a["fchr"], dtype="<u4").tobytes())
+        f.write(np.asarray(a["ftab"], dtype="<u4").tobytes())
+        f.write(np.asarray(a["eftab"], dtype="<u4").tobytes())
+        for nm in names:
+            f.write(nm.encode() + b"\n")
+        f.write(b"\0")
+    with open(base + ".2.ebwt", "wb") as f:
+        f.write(struct.pack("<i", 1))
+        f.write(np.asarray(a["offs"], dtype="<u4").tobytes())
+
+
+def build_index(seqs: Sequence[np.ndarray], names: Sequence[str], base: str, device="cpu",
+                off_rate: int = 5, ftab_chars: int = 10) -> np.ndarray:
+    """Index `seqs` (codes 0..4) into base.{1,2}.ebwt and base.rev.{1,2}.ebwt; returns the joined
+    text (codes 0..3).  The mirror index is over the text with every unambiguous stretch reversed
+    in place (REF_READ_REVERSE_EACH, ebwt_build.cpp:77)."""
+    plen, rstarts, frs = fragments_of(seqs)
+    pieces = [seqs[k][a:b] for k, a, b in _orig_ids(seqs, frs)]
+    fw = np.concatenate(pieces).astype(np.uint8)
+    rv = np.concatenate([p[::-1] for p in pieces]).astype(np.uint8)
+    used = [i for i, s in enumerate(seqs) if (s != 4).any()]
+    nm = [names[i] for i in used]
+    for text, suffix in ((fw, ""), (rv, ".rev")):
+        t = torch.from_numpy(text).to(device)
+        arr = build_arrays(t, off_rate, ftab_chars)
+        del t
+        write_index(base + suffix, arr, plen, rstarts, nm)
+    return fw
+
+
+def _orig_ids(seqs, frs):
+    """fragments_of numbers only the sequences that have unambiguous characters; map back."""
+    used = [i for i, s in enumerate(seqs) if (s != 4).any()]
+    return [(used[k], a, b) for k, a, b in frs]
+
+
+# ---------------------------------------------------------------------------------------------
+# the hg19-scale synthetic genome of the benchmark
+# ---------------------------------------------------------------------------------------------
+HG19_LIKE_BP = 2_860_000_000
+
+
+def synth_genome(total_bp: int, device, seed: int = 20240926):
+    """24 'chromosomes' with hg19-like relative sizes, an N gap inside each (two fragments per
+    chromosome) and interspersed repeat families (SINE-like 300 bp x many copies at 5-18 %
+    divergence, LINE-like 3 kbp at 2-10 %, covering ~20 % of the text) so that a realistic share of
+    reads multi-map.  Returns (joined text u8 tensor on device, plen, rstarts, names)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rel = np.array([249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103, 90, 81, 78,
+                    59, 63, 48, 51, 155, 59], dtype=np.float64)
+    sizes = np.maximum(2000, (rel / rel.sum() * total_bp).astype(np.int64))
+    T = int(sizes.sum())
+    text = torch.randint(0, 4, (T,), generator=g, device=device, dtype=torch.uint8)
+    for fam_len, cover, dlo, dhi, nfam in ((300, 0.12, 0.05, 0.18, 8), (3000, 0.08, 0.02, 0.10, 4)):
+        for _ in range(nfam):
+            ncopy = int(T * cover / nfam / fam_len)
+            if ncopy < 2 or T < 50 * fam_len:
+                continue
+            cons = torch.randint(0, 4, (fam_len,), generator=g, device=device, dtype=torch.uint8)
+            CH = max(1, (1 << 26) // fam_len)
+            for lo in range(0, ncopy, CH):
+                m = min(CH, ncopy - lo)
+                div = dlo + (dhi - dlo) * torch.rand(m, 1, generator=g, device=device)
+                mut = torch.rand(m, fam_len, generator=g, device=device) < div
+                add = torch.randint(1, 4, (m, fam_len), generator=g, device=device, dtype=torch.uint8)
+                cp = torch.where(mut, (cons[None, :] + add) & 3, cons[None, :].expand(m, fam_len))
+                st = torch.randint(0, T - fam_len, (m,), generator=g, device=device)
+                text[(st[:, None] + torch.arange(fam_len, device=device)[None, :]).reshape(-1)] = cp.reshape(-1)
+    # fragment table: each chromosome = [frag A][gap of Ns][frag B]
+    plen, rst, names = [], [], []
+    tot = 0
+    for k, sz in enumerate(sizes):
+        a = int(sz * 0.4)
+        gap = int(min(3_000_000, max(50, sz // 50)))
+        lead = int(min(10_000, sz // 200))
+        rst.append((tot, k, lead))
+        rst.append((tot + a, k, lead + a + gap))
+        plen.append(lead + int(sz) + gap + lead)
+        tot += int(sz)
+        names.append("chrS%d synthetic" % (k + 1))
+    return text, np.array(plen, dtype=np.uint32), np.array(rst, dtype=np.uint32), names
+
+
+def ensure_big_index(total_bp: int, device, rank: int = 0, world: int = 1, cache_dir: str | None = None):
+    """Build (rank 0) or wait for (other ranks) the synthetic hg19-scale index; returns
+    (base path, joined text as numpy u8, description)."""
+    total_bp = total_bp or HG19_LIKE_BP
+    cache_dir = cache_dir or os.environ.get("BT_INDEX_CACHE", "/tmp/bowtie_amd_idx")
+    os.makedirs(cache_dir, exist_ok=True)
+    base = os.path.join(cache_dir, "synth_%d" % total_bp)
+    done = base + ".done"
+    if rank == 0 and not os.path.exists(done):
+        t0 = time.perf_counter()
+        text, plen, rstarts, names = synth_genome(total_bp, device)
+        np.save(base + ".text.npy", text.cpu().numpy())
+        for suffix in ("", ".rev"):
+            t = text
+            if suffix:
+                # reverse every fragment in place
+                t = text.clone()
+                bounds = list(rstarts[:, 0]) + [text.numel()]
+                for a, b in zip(bounds[:-1], bounds[1:]):
+                    t[int(a):int(b)] = text[int(a):int(b)].flip(0)
+            arr = build_arrays(t, 5, 10)
+            write_index(base + suffix, arr, plen, rstarts, names)
+            del arr, t
+            torch.cuda.empty_cache() if torch.cuda.is_available() else None
+        with open(done, "w") as f:
+            f.write("%.1f\n" % (time.perf_counter() - t0))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    text_np = np.load(base + ".text.npy", mmap_mode="r")
+    with open(done) as f:
+        secs = f.read().strip()
+    note = ("synthetic hg19-scale genome: %d bp, 24 sequences / 48 fragments, ~20%% interspersed repeats, "
+            "indexed on the GPU in %ss (bowtie-build format: offRate 5, ftabChars 10)" % (len(text_np), secs))
+    return base, np.asarray(text_np), note

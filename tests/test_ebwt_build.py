@@ -1,0 +1,90 @@
+"""bowtie_amd/ebwt_build.py (the GPU index synthesiser that feeds the hg19-scale benchmark) must
+write exactly what reference bowtie-build writes.  The committed fixtures tests/golden/e_coli.* and
+multi.* ARE reference bowtie-build outputs, so byte equality with them pins the builder without
+needing the reference binary; when the binary is present a fresh random genome is checked too."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import common as T
+import refrun as R
+from bowtie_amd import ebwt_build as EB
+
+EXTS = ("1.ebwt", "2.ebwt", "rev.1.ebwt", "rev.2.ebwt")
+
+
+def read_fa(path):
+    names, seqs, cur = [], [], []
+    for line in open(path):
+        line = line.rstrip()
+        if line.startswith(">"):
+            if names:
+                seqs.append("".join(cur))
+            names.append(line[1:])
+            cur = []
+        else:
+            cur.append(line)
+    seqs.append("".join(cur))
+    lut = np.full(256, 4, np.uint8)
+    for i, c in enumerate("ACGT"):
+        lut[ord(c)] = i
+    return names, [lut[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs]
+
+
+def same(a, b):
+    return all(open(a + "." + e, "rb").read() == open(b + "." + e, "rb").read() for e in EXTS)
+
+
+def test_rebuild_multi_fixture(tmp_path):
+    names, seqs = read_fa(os.path.join(T.G, "multi.fa"))
+    EB.build_index(seqs, names, str(tmp_path / "m"), off_rate=3, ftab_chars=6)
+    assert same(str(tmp_path / "m"), os.path.join(T.G, "multi"))
+
+
+def test_rebuild_e_coli_fixture_chunked(tmp_path, monkeypatch):
+    """Also drives the chunked giant-array passes and the sub-bucket sort split."""
+    monkeypatch.setattr(EB, "_CH", 1_000_003)
+    monkeypatch.setattr(EB, "_MAX_SORT", 200_000)
+    text = T.joined_text("e_coli")
+    EB.build_index([text], [T.oracle_index("e_coli").refnames[0]], str(tmp_path / "e"), off_rate=5, ftab_chars=7)
+    assert same(str(tmp_path / "e"), os.path.join(T.G, "e_coli"))
+
+
+@pytest.mark.skipif(not R.have_ref_binary(), reason="needs oracle/_ref/bowtie-build-s")
+def test_random_genome_vs_reference_build(tmp_path):
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 4, size=150000)
+    rep = rng.integers(0, 4, size=700)
+    for p in (1000, 50000, 120000, 149000):
+        base[p:p + 700] = rep
+    base[60000:60300] = 3
+    base[-40:] = 3
+    base[30000:30010] = 4
+    fa = tmp_path / "r.fa"
+    with open(fa, "w") as f:
+        f.write(">a desc\n" + "".join("ACGTN"[c] for c in base) + "\n")
+        f.write(">b\n" + "ACGTTTTTTTTTTTTTTTT" * 3 + "\n")
+        f.write(">c\nNNNNACGTACGTACGTNNNN" + "T" * 43 + "NN\n")
+        f.write(">d\n" + "T" * 64 + "\n")
+    for offrate, ftab in ((5, 10), (2, 4)):
+        subprocess.run([os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-s"), "--offrate", str(offrate),
+                        "--ftabchars", str(ftab), "-q", str(fa), str(tmp_path / "ref")], check=True)
+        names, seqs = read_fa(str(fa))
+        EB.build_index(seqs, names, str(tmp_path / "mine"), off_rate=offrate, ftab_chars=ftab)
+        assert same(str(tmp_path / "mine"), str(tmp_path / "ref"))
+
+
+def test_synthetic_genome_index_is_searchable(tmp_path):
+    """ensure_big_index at toy scale: the oracle finds planted reads where they came from."""
+    import oracle_lib as OL
+    from bowtie_amd.synth import synth_reads
+    base, text, note = EB.ensure_big_index(400_000, torch.device("cpu"), cache_dir=str(tmp_path))
+    oi = OL.OracleIndex(base)
+    assert (oi.joined_text() == text).all()
+    assert oi.fw.nFrag == 48 and oi.fw.nPat == 24
+    batch = synth_reads(text, 200, 50, mm_dist=(0,), seed=3, n_frac=0.0)
+    res = R.oracle_search(oi, OL.make_policy("v", 0), batch)
+    assert sum(1 for h, _, _ in res if h) >= 190         # reads straddling a fragment boundary are rejected
