@@ -37,6 +37,7 @@ struct bt_ctx {
 	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint8_t* elims = nullptr; uint64_t* pals = nullptr;
 	uint32_t* d_cursor = nullptr;      /* [0] nextRead, [1] mm_pool_used */
+	BtCold* d_cold = nullptr;
 	unsigned long long* d_counts = nullptr;
 	/* staging for the host-pointer entry point */
 	void* stage = nullptr; size_t stage_bytes = 0;
@@ -179,6 +180,7 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", 2);
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
+	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, 10 * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(c->d_counts, 0, 10 * sizeof(unsigned long long)));
 	*out = c;
@@ -191,6 +193,7 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	(void)hipStreamSynchronize(c->stream);
 	ctx_free_scratch(c);
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
+	if (c->d_cold) (void)hipFree(c->d_cold);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->stage) (void)hipFree(c->stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -204,20 +207,32 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 {
 	if (in->n_reads == 0) { c->timed = false; return BT_OK; }
 	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
-	    out->hit_cap == 0 || in->stride == 0) return BT_ERR_ARG;
+	    out->hit_cap == 0 || in->stride == 0 || (in->stride & 15u) != 0 ||
+	    ((uintptr_t)in->seq & 15u) != 0 || ((uintptr_t)in->qual & 15u) != 0) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
 	int rc = ctx_ensure_scratch(c, maxLen);
 	if (rc != BT_OK) return rc;
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
-	A.P = c->prog;
-	A.ix[0] = c->idx->dev[0]; A.ix[1] = c->idx->dev[1];
-	A.B.seq = in->seq; A.B.qual = in->qual; A.B.len = in->len; A.B.seed = in->seed;
-	A.B.n_reads = in->n_reads; A.B.stride = in->stride;
-	A.B.hits = (BtHitRec*)out->hits; A.B.hit_cap = out->hit_cap;
-	A.B.n_hits = out->n_hits; A.B.status = out->status;
-	A.B.mm_pool = out->mm_pool; A.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
-	A.B.mm_pool_used = c->d_cursor + 1;
+	BtCold cold;
+	memset(&cold, 0, sizeof(cold));
+	cold.P = c->prog;
+	cold.ix[0] = c->idx->dev[0]; cold.ix[1] = c->idx->dev[1];
+	cold.B.seq = in->seq; cold.B.qual = in->qual; cold.B.len = in->len; cold.B.seed = in->seed;
+	cold.B.n_reads = in->n_reads; cold.B.stride = in->stride;
+	cold.B.hits = (BtHitRec*)out->hits; cold.B.hit_cap = out->hit_cap;
+	cold.B.n_hits = out->n_hits; cold.B.status = out->status;
+	cold.B.mm_pool = out->mm_pool; cold.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
+	cold.B.mm_pool_used = c->d_cursor + 1;
+	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+	for (int m = 0; m < 2; m++) {
+		const BtIndexDev& d = c->idx->dev[m];
+		A.H.ebwt[m] = d.ebwt; A.H.zSide[m] = d.zSide; A.H.zSym[m] = d.zSym; A.H.zOff[m] = d.zOff;
+		A.H.offMask[m] = d.offMask;
+		for (int k = 0; k < 5; k++) A.H.fchr[m][k] = d.fchr[k];
+	}
+	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
+	A.cold = c->d_cold;
 	A.frames = c->frames; A.pairs = c->pairs; A.elims = c->elims; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
 	A.nextRead = c->d_cursor;
@@ -278,7 +293,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	out->mm_pool_used = 0;
 	if (n == 0) return BT_OK;
 	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
-	    out->hit_cap == 0) return BT_ERR_ARG;
+	    out->hit_cap == 0 || (in->stride & 15u) != 0) return BT_ERR_ARG;
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < n; i++) {
 		if (in->len[i] == 0 || in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;

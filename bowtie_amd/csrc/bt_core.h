@@ -15,11 +15,18 @@
  * in lock step, so that all rank gathers of a wavefront are issued together, independent of
  * which phase / frame / SA walk each individual read is in.
  *
- *   lane state   : BtLane (registers)
- *   frame stack  : one record per backtrack level, in HBM scratch        (BT_FR_*)
+ *   lane state   : BtLane -- bit-packed so the whole automaton lives in ~50 VGPRs
+ *   read window  : 16 bases + 16 qualities of the read, cached in registers (the query is
+ *                  consumed one position per LF step, so one 2x16-byte fetch serves 16 steps)
+ *   frame stack  : one record per backtrack level, HBM scratch, lane-interleaved  (FR_*)
  *   range stack  : per visited query position, the 4x(top,bot) ranges and the eliminated-
  *                  alternatives mask; compact (a child frame starts where its parent stopped)
  *   seedlings    : packed partial alignments of the -n seed phases (ebwt_search_util.h:37-88)
+ *
+ * Control flow is arranged so that the common transitions (query step -> LF -> query step, and
+ * SA-walk step -> LF -> SA-walk step) take one pass through bt_lane_run; everything else
+ * (backtrack-target choice, frame push/pop, reporting, phase changes) runs in the "slow" inner
+ * loop of the same pass.
  *
  * This header is plain C++ that compiles for gfx950 (hipcc) and for the host; the host build
  * exists only so the automaton can be unit-tested against the oracle without a GPU
@@ -61,15 +68,22 @@ struct BtProgram {
 };
 
 /* ---- per-lane scratch in HBM ------------------------------------------------------------- */
-#define BT_FR_WORDS 24
+#define BT_FR_WORDS 16
 enum {
-	FR_DEPTH = 0, FR_D, FR_HAM, FR_U, FR_R1, FR_R2, FR_R3, FR_ALTNUM, FR_ELIGNUM, FR_ELIGSZ,
-	FR_ELI, FR_ELTOP, FR_ELBOT, FR_ELHAM, FR_ELC, FR_LOWQ, FR_PI, FR_PJ, FR_PTOP, FR_PBOT,
-	FR_EBASE, FR_MM, FR_TOP, FR_BOT
+	FR_W0 = 0,   /* depth | d<<11                                   */
+	FR_W1,       /* ham | lowAltQual<<16 | elham<<24                */
+	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25 */
+	FR_W3,       /* f2 | f3<<11                                     */
+	FR_W4,       /* altNum | eligibleNum<<12                        */
+	FR_ELIGSZ, FR_ELTOP, FR_ELBOT,
+	FR_W8,       /* eli | cand<<11                                  */
+	FR_W9,       /* pi | pj<<11                                     */
+	FR_PTOP, FR_PBOT, FR_EBASE,
+	FR_MM        /* mismatch chosen at this level: query offset | refc<<16                        */
 };
 
 struct BtScratch {
-	uint32_t* frames;   uint32_t frStride;   /* word w of frame f at frames[(f*24+w)*frStride]   */
+	uint32_t* frames;   uint32_t frStride;   /* word w of frame f at frames[(f*16+w)*frStride]   */
 	uint32_t* pairs;                         /* [entry][8]: tops ACGT, bots ACGT                 */
 	uint8_t*  elims;                         /* [entry]                                           */
 	uint64_t* pals;                          /* [palCap] seedlings                                */
@@ -85,10 +99,27 @@ struct BtHitRec {            /* == bt_hit (include/bowtie_amd.h) */
 
 struct BtBatchDev {
 	const uint8_t*  seq;  const uint8_t* qual;  const uint16_t* len;  const uint32_t* seed;
-	uint32_t n_reads, stride;
+	uint32_t n_reads, stride;               /* stride: multiple of 16 (rows are 16-byte aligned) */
 	BtHitRec* hits; uint32_t hit_cap;
 	uint32_t* n_hits; uint8_t* status;
 	uint16_t* mm_pool; uint32_t mm_pool_cap; uint32_t* mm_pool_used;
+};
+
+/* Arguments split by temperature.  BtHot is passed by value (kernarg -> SGPRs) and holds only what
+ * the per-position / per-SA-step code touches; BtCold lives in device memory and is read where
+ * it is used (phase changes, frame pushes, reporting), so that the 1 KB of program + index
+ * descriptors does not sit in scalar registers across the lock-step loop. */
+struct BtHot {
+	const uint8_t* ebwt[2];
+	uint32_t zSide[2], zSym[2], zOff[2], offMask[2];
+	uint32_t fchr[2][5];
+	const uint8_t* seq; const uint8_t* qual;
+	uint32_t stride, n_reads;
+};
+struct BtCold {
+	BtProgram  P;
+	BtIndexDev ix[2];            /* [0] index of the text, [1] mirror index */
+	BtBatchDev B;
 };
 
 #define BT_STF_SKIPPED   1u
@@ -102,45 +133,67 @@ struct BtReq { uint32_t rowA, rowB; uint32_t op; };     /* op bit0: rank at rowA
 struct BtRes { uint32_t a[4], b[4], LA; };
 
 enum {
-	ST_IDLE = 0, ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FRAME_ENTER, ST_STEP_BEGIN, ST_STEP_LFDONE,
-	ST_STEP_POST, ST_BT_LOOP, ST_CHILD_RET, ST_FRAME_RETURN, ST_FELL_OFF, ST_RA_BEGIN,
-	ST_ROW_BEGIN, ST_CHASE_CHECK, ST_CHASE_LFDONE, ST_RESOLVE, ST_RA_END, ST_SEARCH_END
+	ST_IDLE = 0,
+	/* fast states */
+	ST_STEP_BEGIN, ST_STEP_LFDONE, ST_STEP_POST, ST_CHASE_CHECK, ST_CHASE_LFDONE,
+	/* slow states */
+	ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FRAME_ENTER, ST_BT_LOOP, ST_CHILD_RET, ST_FRAME_RETURN,
+	ST_FELL_OFF, ST_RA_BEGIN, ST_ROW_BEGIN, ST_RESOLVE, ST_RA_END, ST_SEARCH_END
 };
+#define BT_IS_SLOW(st) ((st) >= ST_PHASE_NEXT)
 enum { RC_STEP = 0, RC_CHILD, RC_FELL, RC_ENTRY };
 enum { LFK_EX2 = 0, LFK_C2, LFK_LF1 };
 
-struct BtOpCnt { uint32_t lfex, lf2, lf1, chase, ftab, offs, rstarts, frames, samePair; };
+/* op counters (bt_op_counts order) */
+enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_N };
+#if defined(__HIP_DEVICE_COMPILE__)
+/* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
+#define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)
+#define BT_COUNT_N(k, n) atomicAdd(&CNT[k], (unsigned long long)(n))
+#else
+#define BT_COUNT(k) (CNT[k]++)
+#define BT_COUNT_N(k, n) (CNT[k] += (n))
+#endif
 
 struct BtLane {
 	/* read */
-	uint32_t rd, plen, seed;
-	const uint8_t *seq, *qual;
-	uint32_t S, S3, S5;
-	/* sink (hit.h:969-985) */
-	uint32_t nhits, stored, status;
-	/* phase */
-	int32_t  step;
-	uint32_t npals, palIdx;
+	uint32_t rd;
+	uint64_t roff;                   /* rd * stride */
+	uint32_t plen : 11, status : 8, step : 5, kind : 2, nmuts : 2, palIdxBefore : 1;
+	uint32_t nhits;
+	uint32_t stored : 16, npals : 16;
+	uint32_t palIdx : 16, iham : 8, mutnew0 : 2, mutnew1 : 2, mutnew2 : 2;
+	uint32_t mutpos0 : 10, mutpos1 : 10, mutpos2 : 10;
 	/* searcher (GreedyDFSRangeSource members) */
-	uint32_t qlen;
-	uint32_t mirror, readFw, rev, reportExacts, considerQuals, halfAndHalf, maq, reportPartials, kind;
-	uint32_t d5, d3, unrev, r1, r2, r3, qualThresh, maxBts;
-	uint32_t rnd, numBts, bailed, nsFtab0;
-	uint32_t nmuts, mutpos[3], mutnew[3];
-	uint32_t iham;
+	uint32_t qlen : 11, mirror : 1, readFw : 1, rev : 1, reportExacts : 1, considerQuals : 1, halfAndHalf : 1,
+	         maq : 1, reportPartials : 2, bailed : 1, nsFtab0 : 1;
+	uint32_t d5 : 11, d3 : 11;
+	uint32_t unrev : 11, r1 : 11;
+	uint32_t r2 : 11, r3 : 11;
+	uint32_t qualThresh;
+	uint32_t rnd, numBts;
 	/* current frame (locals of backtrack(), ebwt_search_backtrack.h:363-455) */
-	uint32_t sd, depth, d, top, bot, ham, fu, f1, f2, f3;
-	uint32_t altNum, eligibleNum, eligibleSz, eli, eltop, elbot, elham, elcint, elignore, lowAltQual, ebase;
-	/* per-position temporaries that live across the LF wait */
-	uint32_t c, q, lfk, fl_alt, fl_elig, fl_over;
-	uint32_t btDespite;
+	uint32_t sd : 7, depth : 11, d : 11;
+	uint32_t top, bot;
+	uint32_t ham : 16, lowAltQual : 8, elham : 8;
+	uint32_t fu : 11, f1 : 11, elcint : 2, elignore : 1, candValid : 1;
+	uint32_t f2 : 11, f3 : 11;
+	uint32_t altNum : 12, eligibleNum : 12;
+	uint32_t eligibleSz, eltop, elbot;
+	uint32_t eli : 11, cand : 11;
+	uint32_t ebase;
+	/* per-position temporaries that live across the LF wait + control */
+	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, state : 5, ra_cont : 2;
 	/* pending backtrack target */
-	uint32_t pi, pj, pbttop, pbtbot;
+	uint32_t pi : 11, pj : 2, btham : 16;
+	uint32_t pbttop, pbtbot;
 	/* report */
-	uint32_t ra_sd, ra_top, ra_bot, ra_cost, ra_stratum, ra_cont, ra_r, ra_i, ra_nmm;
+	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
+	uint32_t ra_top, ra_bot, ra_r, ra_i;
 	uint32_t crow, cjumps;
-	uint32_t ret, state;
-	BtOpCnt cnt;
+	/* register window over the read: 16 bases + 16 quals around the current position */
+	uint32_t cchunk;                 /* index of the cached 16-byte chunk, 0xff = none */
+	uint32_t cs0, cs1, cs2, cs3, cq0, cq1, cq2, cq3;
 };
 
 /* ---- small helpers ----------------------------------------------------------------------- */
@@ -161,35 +214,65 @@ BT_HD uint32_t bt_mm_penalty(uint32_t maq, uint32_t q)     /* qual.h:61-67, qual
 	if (q < 25) return 20;
 	return 30;
 }
-/* query char / quality at index i of the string setQuery selected (ebwt_search_backtrack.h:90-140),
- * with the seedling mutations applied (:1368-1382) */
-BT_HD uint32_t bt_qry(const BtLane& L, uint32_t i)
+BT_HD uint32_t bt_apply_muts(const BtLane& L, uint32_t i, uint32_t c)
 {
-	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t c = L.seq[j];
-	if (!L.readFw && c < 4u) c ^= 3u;
 	if (L.nmuts > 0) {
-		if (i == L.mutpos[0]) c = L.mutnew[0];
-		if (L.nmuts > 1 && i == L.mutpos[1]) c = L.mutnew[1];
-		if (L.nmuts > 2 && i == L.mutpos[2]) c = L.mutnew[2];
+		if (i == L.mutpos0) c = L.mutnew0;
+		if (L.nmuts > 1 && i == L.mutpos1) c = L.mutnew1;
+		if (L.nmuts > 2 && i == L.mutpos2) c = L.mutnew2;
 	}
 	return c;
 }
-BT_HD uint32_t bt_qual(const BtLane& L, uint32_t i)
+/* query char / quality at index i of the string setQuery selected (ebwt_search_backtrack.h:90-140),
+ * with the seedling mutations applied (:1368-1382).  Direct (uncached) form. */
+BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t v = L.qual[j];
+	uint32_t c = H.seq[L.roff + j];
+	if (!L.readFw && c < 4u) c ^= 3u;
+	return bt_apply_muts(L, i, c);
+}
+BT_HD uint32_t bt_qual(const BtLane& L, const BtHot& H, uint32_t i)
+{
+	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
+	uint32_t v = H.qual[L.roff + j];
 	return v >= 33u ? v - 33u : 0u;
+}
+BT_HD uint32_t bt_sel4(uint32_t k, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+	uint32_t lo = (k & 1u) ? w1 : w0, hi = (k & 1u) ? w3 : w2;
+	return (k & 2u) ? hi : lo;
+}
+/* Windowed form used by the per-position step: one 2 x 16-byte fetch per 16 positions. */
+BT_HD void bt_qq_cached(BtLane& L, const BtHot& H, uint32_t i, uint32_t* c_out, uint32_t* q_out)
+{
+	const uint32_t j = L.rev ? (L.plen - 1u - i) : i;
+	const uint32_t chunk = j >> 4;
+	if (chunk != L.cchunk) {
+		const uint32_t* ps = (const uint32_t*)(H.seq + L.roff + (uint64_t)chunk * 16u);
+		const uint32_t* pq = (const uint32_t*)(H.qual + L.roff + (uint64_t)chunk * 16u);
+		L.cs0 = ps[0]; L.cs1 = ps[1]; L.cs2 = ps[2]; L.cs3 = ps[3];
+		L.cq0 = pq[0]; L.cq1 = pq[1]; L.cq2 = pq[2]; L.cq3 = pq[3];
+		L.cchunk = chunk;
+	}
+	const uint32_t k = (j >> 2) & 3u, sh = (j & 3u) * 8u;
+	uint32_t c = (bt_sel4(k, L.cs0, L.cs1, L.cs2, L.cs3) >> sh) & 0xffu;
+	uint32_t v = (bt_sel4(k, L.cq0, L.cq1, L.cq2, L.cq3) >> sh) & 0xffu;
+	if (!L.readFw && c < 4u) c ^= 3u;
+	*c_out = bt_apply_muts(L, i, c);
+	*q_out = v >= 33u ? v - 33u : 0u;
 }
 
 #define FRW(f, w) S.frames[((f) * BT_FR_WORDS + (w)) * S.frStride]
 #define PT(e, c) S.pairs[(e) * 8u + (c)]
 #define PB(e, c) S.pairs[(e) * 8u + 4u + (c)]
+#define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
+#define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
 
-BT_HD uint32_t bt_off_code(const BtLane& L, uint32_t code)
+BT_HD uint32_t bt_off_code(uint32_t plen, uint32_t qs, uint32_t code)
 {
-	return code == BT_OC_ZERO ? 0u : code == BT_OC_PLEN ? L.plen : code == BT_OC_S ? L.S :
-	       code == BT_OC_S3 ? L.S3 : L.S5;
+	return code == BT_OC_ZERO ? 0u : code == BT_OC_PLEN ? plen : code == BT_OC_S ? qs :
+	       code == BT_OC_S3 ? (qs >> 1) : ((qs >> 1) + (qs & 1u));
 }
 
 /* hhCheckTop (ebwt_search_backtrack.h:1200-1275) */
@@ -202,6 +285,7 @@ BT_HD bool bt_hh_check_top(const BtLane& L, const BtScratch& S, uint32_t d)
 			if (L.sd < 2) return false;
 		} else {
 			uint32_t lo = 0;
+			BT_NOUNROLL
 			for (uint32_t i = 0; i < L.sd; i++) {
 				uint32_t dd = L.qlen - (FRW(i, FR_MM) & 0xffffu) - 1u;
 				if (dd >= L.d5 && dd < L.d3) lo++;
@@ -215,40 +299,40 @@ BT_HD bool bt_hh_check_top(const BtLane& L, const BtScratch& S, uint32_t d)
 /* reportPartial (ebwt_search_backtrack.h:1571-1655) */
 BT_HD void bt_report_partial(BtLane& L, const BtScratch& S, uint32_t sd)
 {
-	uint64_t pos[3] = {0xffff, 0xffff, 0xffff}, chr[3] = {3, 3, 3};
-	for (uint32_t k = 0; k < sd && k < 3; k++) {
-		uint32_t mm = FRW(k, FR_MM);
-		pos[k] = mm & 0xffffu; chr[k] = (mm >> 16) & 3u;
-	}
-	uint64_t al = (pos[0]) | (pos[1] << 16) | (pos[2] << 32) | (chr[0] << 48) | (chr[1] << 50) | (chr[2] << 52)
-	            | (0xffull << 54) | (3ull << 62);
-	if (L.npals < S.palCap) S.pals[L.npals++] = al;
-	else L.status |= BT_STF_OVERFLOW;
+	uint64_t p0 = 0xffff, p1 = 0xffff, p2 = 0xffff, c0 = 3, c1 = 3, c2 = 3;
+	if (sd > 0) { uint32_t mm = FRW(0, FR_MM); p0 = mm & 0xffffu; c0 = (mm >> 16) & 3u; }
+	if (sd > 1) { uint32_t mm = FRW(1, FR_MM); p1 = mm & 0xffffu; c1 = (mm >> 16) & 3u; }
+	if (sd > 2) { uint32_t mm = FRW(2, FR_MM); p2 = mm & 0xffffu; c2 = (mm >> 16) & 3u; }
+	uint64_t al = p0 | (p1 << 16) | (p2 << 32) | (c0 << 48) | (c1 << 50) | (c2 << 52) | (0xffull << 54) | (3ull << 62);
+	if (L.npals < S.palCap) { S.pals[L.npals] = al; L.npals = L.npals + 1u; }
+	else L.status = L.status | BT_STF_OVERFLOW;
 }
 
 /* Start read `rd`: the worker-loop prologue (ebwt_search.cpp:1675-1683, 2167-2175, 2572-2584;
  * search_seeded_phase1.c:17-44). */
-BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtBatchDev& B, uint32_t rd)
+BT_HD void bt_lane_start(BtLane& L, const BtHot& H, const BtCold& C, uint32_t rd)
 {
+	const BtProgram& P = C.P;
 	L.rd = rd;
-	L.plen = B.len[rd];
-	L.seed = B.seed[rd];
-	L.seq = B.seq + (uint64_t)rd * B.stride;
-	L.qual = B.qual + (uint64_t)rd * B.stride;
-	uint32_t qs = L.plen < P.seedLen ? L.plen : P.seedLen;
-	L.S = qs; L.S3 = qs >> 1; L.S5 = (qs >> 1) + (qs & 1u);
+	L.roff = (uint64_t)rd * H.stride;
+	L.plen = C.B.len[rd];
 	L.nhits = 0; L.stored = 0; L.status = 0;
-	L.step = -1; L.npals = 0; L.palIdx = 0; L.nmuts = 0;
+	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
+	L.mirror = 0; L.readFw = 1; L.rev = 0;
+	L.cchunk = 0xffu;
 	L.state = ST_PHASE_NEXT;
+	const uint32_t plen = L.plen;
+	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
 	if (P.seeded) {
-		bool skip = L.plen < 4u;
+		bool skip = plen < 4u;
 		if (!skip) {
 			uint32_t ns = 0;
-			for (uint32_t i = 0; i < qs; i++) if (L.seq[i] == 4u && ++ns > P.seedMms) { skip = true; break; }
+			BT_NOUNROLL
+			for (uint32_t i = 0; i < qs; i++) if (H.seq[L.roff + i] == 4u && ++ns > P.seedMms) { skip = true; break; }
 		}
-		if (skip) { L.status |= BT_STF_SKIPPED; L.step = P.nsteps; }
-	} else if (L.plen < P.minLen) {
-		L.status |= BT_STF_TOOSHORT; L.step = P.nsteps;
+		if (skip) { L.status = L.status | BT_STF_SKIPPED; L.step = (uint32_t)P.nsteps - 1u; }
+	} else if (plen < P.minLen) {
+		L.status = L.status | BT_STF_TOOSHORT; L.step = (uint32_t)P.nsteps - 1u;
 	}
 }
 
@@ -262,7 +346,7 @@ BT_HD void bt_lane_finish(BtLane& L, const BtBatchDev& B)
 
 /* Ebwt::report + EbwtSearchParams::reportHit + sink (ebwt.h:2635-2682, 1288-1405; hit.h:969-985).
  * Returns true iff the sink says stop. */
-BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, const BtIndexDev& ix, const BtScratch& S,
+BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtScratch& S,
                          const BtBatchDev& B, uint32_t tidx, uint32_t toff)
 {
 	L.nhits++;
@@ -272,7 +356,7 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, const BtIndexDev& ix, co
 		h.tidx = tidx; h.toff = toff; h.oms = L.ra_bot - L.ra_top - 1u;
 		h.cost = (uint16_t)L.ra_cost; h.stratum = (uint8_t)L.ra_stratum; h.fw = (uint8_t)L.readFw;
 		h.pad[0] = h.pad[1] = 0;
-		uint32_t nmm = L.ra_nmm;
+		const uint32_t nmm = L.ra_sd + L.nmuts;
 		h.nmm = (uint16_t)nmm; h.mm_off = 0;
 		if (nmm > 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -282,12 +366,17 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, const BtIndexDev& ix, co
 #endif
 			if (off + nmm <= B.mm_pool_cap) {
 				h.mm_off = off;
-				const bool flip = (ix.fw != 0) != (L.readFw != 0);
+				const bool flip = (ixfw != 0) != (L.readFw != 0);
 				uint16_t* mm = B.mm_pool + off;
+				BT_NOUNROLL
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t pos, refc;
 					if (i < L.ra_sd) { uint32_t v = FRW(i, FR_MM); pos = v & 0xffffu; refc = (v >> 16) & 3u; }
-					else { pos = L.mutpos[i - L.ra_sd]; refc = L.mutnew[i - L.ra_sd] & 3u; }
+					else {
+						const uint32_t k = i - L.ra_sd;
+						pos = k == 0 ? L.mutpos0 : k == 1 ? L.mutpos1 : L.mutpos2;
+						refc = k == 0 ? L.mutnew0 : k == 1 ? L.mutnew1 : L.mutnew2;
+					}
 					if (flip) pos = L.qlen - pos - 1u;
 					uint16_t e = (uint16_t)(pos | (refc << 12));
 					/* Hit::mms is a bitset: keep the list ordered by position */
@@ -296,13 +385,13 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, const BtIndexDev& ix, co
 					mm[j + 1] = e;
 				}
 			} else {
-				h.nmm = 0; L.status |= BT_STF_MMPOOL;
+				h.nmm = 0; L.status = L.status | BT_STF_MMPOOL;
 			}
 		}
 		B.hits[(uint64_t)L.rd * B.hit_cap + L.stored] = h;
-		L.stored++;
+		L.stored = L.stored + 1u;
 	} else if (L.stored < P.sinkN) {
-		L.status |= BT_STF_HITCAP;
+		L.status = L.status | BT_STF_HITCAP;
 	}
 	if (P.sinkAll) return false;
 	if (L.nhits == P.sinkN && (P.sinkMax == 0xffffffffu || P.sinkMax < P.sinkN)) return true;
@@ -314,41 +403,50 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, const BtIndexDev& ix, co
 	do { L.ra_sd = (SD); L.ra_top = (TOP); L.ra_bot = (BOT); L.ra_cost = (COST); L.ra_cont = (CONT); \
 	     L.state = ST_RA_BEGIN; } while (0)
 
-/*
- * Advance one lane until it needs an LF-mapping (returns with req.op != 0 and the lane in a
- * *_LFDONE state) or has finished its read (state ST_IDLE, req.op == 0).
- * `res` is consumed iff the lane was waiting for it.
- */
-BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, const BtScratch& S,
-                       const BtBatchDev& B, const BtRes& res, BtReq& req)
+/* Scan the frame for the deepest position that still has a backtrack target of the current
+ * eligible quality (the `for(; i >= depth; i--)` walk of :767-812). */
+BT_HD bool bt_find_cand(BtLane& L, const BtScratch& S, const BtHot& H, uint32_t from)
 {
-	req.op = 0; req.rowA = 0; req.rowB = 0;
-	for (;;) {
-		const BtIndexDev& ix = IX[L.mirror];
-		switch (L.state) {
-		case ST_IDLE:
-			return;
+	BT_NOUNROLL
+	for (uint32_t i = from;; i--) {
+		const uint32_t qi = bt_qual(L, H, L.qlen - i - 1u);
+		const uint32_t el = S.elims[L.ebase + (i - L.depth)];
+		if ((qi == L.lowAltQual || !L.considerQuals) && el != 15u) { L.cand = i; L.candValid = 1; return true; }
+		if (i == L.depth) break;
+	}
+	return false;
+}
 
+/* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
+BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScratch& S, unsigned long long* CNT)
+{
+	const BtProgram& P = C.P;
+	const BtIndexDev* IX = C.ix;
+	const BtBatchDev& B = C.B;
+	while (BT_IS_SLOW(L.state)) {
+		switch (L.state) {
 		/* ---- phase script ------------------------------------------------------------- */
 		case ST_PHASE_NEXT: {
-			L.step++;
-			if (L.step >= P.nsteps || (L.status & BT_STF_OVERFLOW)) { bt_lane_finish(L, B); return; }
+			L.step = L.step + 1u;        /* 5-bit wrap: 31 -> 0 */
+			if ((int32_t)L.step >= P.nsteps || (L.status & BT_STF_OVERFLOW)) { bt_lane_finish(L, B); break; }
 			const BtStep& st = P.steps[L.step];
 			/* setQuery + setOffs + ctor flags */
-			L.mirror = st.mirror; L.readFw = st.readFw; L.rev = (st.mirror != 0) == (st.readFw != 0) ? 1u : 0u;
+			L.mirror = st.mirror; L.readFw = st.readFw; L.rev = ((st.mirror != 0) == (st.readFw != 0)) ? 1u : 0u;
 			L.kind = st.kind; L.reportExacts = st.reportExacts; L.considerQuals = st.considerQuals;
 			L.halfAndHalf = st.halfAndHalf; L.maq = st.maq; L.reportPartials = st.reportPartials;
-			L.qualThresh = st.qualThresh; L.maxBts = st.maxBts;
-			L.d5 = bt_off_code(L, st.oc[0]); L.d3 = bt_off_code(L, st.oc[1]); L.unrev = bt_off_code(L, st.oc[2]);
-			L.r1 = bt_off_code(L, st.oc[3]); L.r2 = bt_off_code(L, st.oc[4]); L.r3 = bt_off_code(L, st.oc[5]);
-			L.qlen = (st.kind == BT_KIND_GEN) ? L.S : L.plen;           /* setQlen(seed) */
-			L.rnd = L.seed; L.numBts = 0; L.nmuts = 0; L.iham = 0;
+			L.qualThresh = st.qualThresh;
+			const uint32_t plen = L.plen, qs = plen < P.seedLen ? plen : P.seedLen;
+			L.d5 = bt_off_code(plen, qs, st.oc[0]); L.d3 = bt_off_code(plen, qs, st.oc[1]);
+			L.unrev = bt_off_code(plen, qs, st.oc[2]); L.r1 = bt_off_code(plen, qs, st.oc[3]);
+			L.r2 = bt_off_code(plen, qs, st.oc[4]); L.r3 = bt_off_code(plen, qs, st.oc[5]);
+			L.qlen = (st.kind == BT_KIND_GEN) ? qs : plen;               /* setQlen(seed) */
+			L.rnd = B.seed[L.rd]; L.numBts = 0; L.nmuts = 0; L.iham = 0;
+			L.cchunk = 0xffu;
 			if (st.kind == BT_KIND_GEN) L.npals = 0;
 			if (st.kind == BT_KIND_EXTEND) {
-				L.palIdx = 0;
 				if (L.npals == 0) { L.state = ST_PHASE_NEXT; break; }
-				/* fallthrough into the first seedling below */
-				L.state = ST_SEARCH_END; L.ret = 0; L.palIdx = 0xffffffffu;   /* "before first" */
+				L.palIdxBefore = 1; L.palIdx = 0; L.ret = 0;
+				L.state = ST_SEARCH_END;
 				break;
 			}
 			L.state = ST_SEARCH_BEGIN;
@@ -358,10 +456,10 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
 		case ST_SEARCH_BEGIN: {
 			L.bailed = 0; L.sd = 0;
-			/* tallyNs */
 			uint32_t nsInSeed = 0; bool ok = true;
+			BT_NOUNROLL
 			for (uint32_t i = 0; i < L.r3 && ok; i++) {
-				if (bt_qry(L, L.qlen - i - 1u) == 4u) {
+				if (bt_qry(L, H, L.qlen - i - 1u) == 4u) {
 					nsInSeed++;
 					if (nsInSeed == 1) { if (i < L.unrev) ok = false; }
 					else if (nsInSeed == 2) { if (i < L.r1) ok = false; }
@@ -371,21 +469,25 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 			}
 			if (!ok) { L.ret = 0; L.state = ST_SEARCH_END; break; }
 			uint32_t nsInFtab = 0;
-			const uint32_t ftabChars = ix.ftabChars;
+			const uint32_t ftabChars = IXSEL(ftabChars);
+			BT_NOUNROLL
 			for (uint32_t i = 0; i < ftabChars && i < L.qlen; i++)
-				if (bt_qry(L, L.qlen - i - 1u) == 4u) nsInFtab++;
+				if (bt_qry(L, H, L.qlen - i - 1u) == 4u) nsInFtab++;
 			L.nsFtab0 = nsInFtab > 0 ? 1u : 0u;
 			const uint32_t m = L.unrev < L.qlen ? L.unrev : L.qlen;
-			/* frame 0 parameters */
 			L.fu = L.unrev; L.f1 = L.r1; L.f2 = L.r2; L.f3 = L.r3; L.ham = L.iham; L.ebase = 0;
 			if (nsInFtab == 0 && m >= ftabChars) {
-				uint32_t ftabOff = bt_qry(L, L.qlen - ftabChars);
-				for (uint32_t i = ftabChars - 1u; i > 0; i--) { ftabOff <<= 2; ftabOff |= bt_qry(L, L.qlen - i); }
-				uint32_t top = bt_ftab_hi(ix, ftabOff), bot = bt_ftab_lo(ix, ftabOff + 1u);
-				L.cnt.ftab++;
+				uint32_t ftabOff = bt_qry(L, H, L.qlen - ftabChars);
+				BT_NOUNROLL
+				for (uint32_t i = ftabChars - 1u; i > 0; i--) { ftabOff <<= 2; ftabOff |= bt_qry(L, H, L.qlen - i); }
+				const uint32_t* ftab = IXSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = IXSEL(len);
+				uint32_t top = ftab[ftabOff], bot = ftab[ftabOff + 1u];
+				if (top > len) top = eftab[(top ^ BT_OFF_MASK) * 2u + 1u];
+				if (bot > len) bot = eftab[(bot ^ BT_OFF_MASK) * 2u];
+				BT_COUNT(CN_FTAB);
 				if (L.qlen == ftabChars && bot > top) {
 					if (L.reportPartials > 0) { L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER; }
-					else BT_GOTO_RA(0, top, bot, L.iham, RC_ENTRY);
+					else { L.top = top; L.bot = bot; BT_GOTO_RA(0, top, bot, L.iham, RC_ENTRY); }
 				} else if (bot > top) {
 					L.depth = ftabChars; L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER;
 				} else { L.ret = 0; L.state = ST_SEARCH_END; }
@@ -397,176 +499,53 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 
 		/* ---- frame prologue (:363-455) -------------------------------------------------- */
 		case ST_FRAME_ENTER: {
-			L.cnt.frames++;
+			BT_COUNT(CN_FRAMES);
 			if (L.halfAndHalf) {
-				if (L.maxBts > 0 && L.numBts == L.maxBts) { L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break; }
+				const uint32_t maxBts = P.steps[L.step].maxBts;
+				if (maxBts > 0 && L.numBts == maxBts) { L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break; }
 				L.numBts++;
 			}
 			L.altNum = 0; L.eligibleNum = 0; L.eligibleSz = 0;
 			L.eli = 0; L.eltop = 0; L.elbot = 0; L.elham = L.ham; L.elcint = 0; L.elignore = 1;
-			L.lowAltQual = 0xff;
+			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0;
 			L.d = L.depth;
-			L.state = ST_STEP_BEGIN;
-			break;
-		}
-
-		/* ---- one query position (:456-568) ---------------------------------------------- */
-		case ST_STEP_BEGIN: {
-			if (L.d >= L.qlen) { L.state = ST_FELL_OFF; break; }
-			const uint32_t d = L.d, cur = L.qlen - d - 1u;
-			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-			if (L.ebase + (d - L.depth) >= S.entCap) { L.status |= BT_STF_OVERFLOW; bt_lane_finish(L, B); return; }
-			const uint32_t c = bt_qry(L, cur), q = bt_qual(L, cur);
-			L.c = c; L.q = q;
-			const bool alt = (d >= L.fu) && (!L.considerQuals || (L.ham + bt_mm_penalty(L.maq, q) <= L.qualThresh));
-			bool elig = false, over = false;
-			if (alt) {
-				if (L.considerQuals) {
-					if (q < L.lowAltQual) { elig = true; over = true; }
-					else if (q == L.lowAltQual) elig = true;
-				} else elig = true;
-			}
-			L.fl_alt = alt; L.fl_elig = elig; L.fl_over = over;
-			const uint32_t rtop = L.top, rbot = L.bot;
-			if (c == 4u && d > 0) { L.top = 1; L.bot = 1; }
-			if (rtop == 0 && rbot == 0) {
-				/* depth 0: the fchr quartet (:531-543) */
-				const uint32_t e = L.ebase + (d - L.depth);
-				PT(e, 0) = ix.fchr[0];
-				PB(e, 0) = PT(e, 1) = ix.fchr[1];
-				PB(e, 1) = PT(e, 2) = ix.fchr[2];
-				PB(e, 2) = PT(e, 3) = ix.fchr[3];
-				PB(e, 3) = ix.fchr[4];
-				if (c < 4u) { L.top = ix.fchr[c]; L.bot = ix.fchr[c + 1u]; }
-				L.state = ST_STEP_POST;
-			} else if (alt) {
-				req.rowA = rtop; req.rowB = rbot; req.op = 3; L.lfk = LFK_EX2; L.cnt.lfex++;
-				if (rtop / 448u == rbot / 448u) L.cnt.samePair++;
-				L.state = ST_STEP_LFDONE; return;
-			} else if (c < 4u) {
-				if (L.top + 1u == L.bot) {
-					req.rowA = L.top; req.op = 1; L.lfk = LFK_LF1; L.cnt.lf1++;
-				} else {
-					req.rowA = L.top; req.rowB = L.bot; req.op = 3; L.lfk = LFK_C2; L.cnt.lf2++;
-					if (L.top / 448u == L.bot / 448u) L.cnt.samePair++;
-				}
-				L.state = ST_STEP_LFDONE; return;
-			} else {
-				L.state = ST_STEP_POST;
-			}
-			break;
-		}
-
-		case ST_STEP_LFDONE: {
-			const uint32_t c = L.c;
-			if (L.lfk == LFK_EX2) {
-				const uint32_t e = L.ebase + (L.d - L.depth);
-				PT(e, 0) = res.a[0]; PT(e, 1) = res.a[1]; PT(e, 2) = res.a[2]; PT(e, 3) = res.a[3];
-				PB(e, 0) = res.b[0]; PB(e, 1) = res.b[1]; PB(e, 2) = res.b[2]; PB(e, 3) = res.b[3];
-				if (c < 4u) { L.top = res.a[c]; L.bot = res.b[c]; }
-			} else if (L.lfk == LFK_C2) {
-				L.top = res.a[c]; L.bot = res.b[c];
-			} else {
-				/* mapLF1 (ebwt.h:2494-2512) */
-				if (res.LA != c || L.top == ix.zOff) { L.top = L.bot = BT_OFF_MASK; }
-				else { L.top = res.a[c]; L.bot = L.top + 1u; }
-			}
-			L.state = ST_STEP_POST;
-			/* fallthrough */
-		}
-		// fallthrough
-		case ST_STEP_POST: {
-			const uint32_t d = L.d, cur = L.qlen - d - 1u, c = L.c, q = L.q;
-			const uint32_t e = L.ebase + (d - L.depth);
-			uint32_t el = (c < 4u) ? (1u << c) : 0u;
-			if (L.fl_alt) {
-				bool over = L.fl_over != 0;
-				for (uint32_t i = 0; i < 4u; i++) {
-					if (i == c) continue;
-					uint32_t spread = PB(e, i) - PT(e, i);
-					if (spread == 0) el |= (1u << i);
-					else {
-						if (L.fl_elig) {
-							if (over) {
-								L.lowAltQual = q; L.eligibleNum = 0; L.eligibleSz = 0; over = false;
-								L.eli = d; L.eltop = PT(e, i); L.elbot = PB(e, i);
-								L.elham = bt_mm_penalty(L.maq, q); L.elcint = i; L.elignore = 0;
-							}
-							L.eligibleSz += spread; L.eligibleNum++;
-						}
-						L.altNum++;
-					}
-				}
-			}
-			S.elims[e] = (uint8_t)el;
-			bool btDespite = false, reportedPartial = false;
-			if (cur == 0 && L.top < L.bot && L.sd < L.reportPartials && L.reportPartials > 0) {
-				if (L.altNum > 0) btDespite = true;
-				if (L.sd > 0) { bt_report_partial(L, S, L.sd); reportedPartial = true; }
-			}
-			bool invalidExact = false;
-			if (cur == 0 && L.sd == 0 && L.bot > L.top && !L.reportExacts) { invalidExact = true; btDespite = true; }
-			bool mustBacktrack = false, invalidHH = false;
-			if (L.halfAndHalf) {
-				if (d == L.d5 - 1u && L.top < L.bot) {
-					invalidHH = (L.sd == 0);
-					if (L.sd == 0 && L.altNum > 0) { btDespite = true; mustBacktrack = true; }
-					else if (L.sd == 0) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-				} else if (d == L.d3 - 1u && L.top < L.bot) {
-					uint32_t lo = 0, hi = 0;
-					for (uint32_t i = 0; i < L.sd; i++) {
-						uint32_t dd = L.qlen - (FRW(i, FR_MM) & 0xffffu) - 1u;
-						if (dd < L.d5) hi++; else if (dd < L.d3) lo++;
-					}
-					invalidHH = (lo == 0 || hi == 0);
-					if ((L.sd < 2 || invalidHH) && L.altNum > 0) { mustBacktrack = true; btDespite = true; }
-					else if (L.sd < 2) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-				}
-			}
-			L.btDespite = btDespite;
-			if (cur == 0 && L.bot > L.top && !invalidHH && !invalidExact && !reportedPartial) {
-				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP);
-				break;
-			}
-			if ((L.top == L.bot || btDespite) && L.altNum > 0) { L.state = ST_BT_LOOP; break; }
-			if (mustBacktrack || invalidHH || invalidExact) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-			if (L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-			L.d = d + 1u;
 			L.state = ST_STEP_BEGIN;
 			break;
 		}
 
 		/* ---- choose a backtrack target and descend (:743-971) --------------------------- */
 		case ST_BT_LOOP: {
-			uint32_t i = L.d, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
+			uint32_t i, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
-				bool found = false;
-				for (;; i--) {
-					const uint32_t icur = L.qlen - i - 1u;
-					const uint32_t qi = bt_qual(L, icur);
+				bool found = L.candValid || bt_find_cand(L, S, H, L.d);
+				if (found) {
+					found = false;
+					i = L.cand;
 					const uint32_t e = L.ebase + (i - L.depth);
 					const uint32_t el = S.elims[e];
-					if ((qi == L.lowAltQual || !L.considerQuals) && el != 15u) {
-						uint32_t posSz = 0;
-						for (j = 0; j < 4u; j++) if ((el & (1u << j)) == 0) posSz += PB(e, j) - PT(e, j);
-						uint32_t r = (posSz > 0) ? (bt_rnd_u32(L) % posSz) : 0u;
-						for (j = 0; j < 4u; j++) {
-							if ((el & (1u << j)) == 0) {
-								uint32_t spread = PB(e, j) - PT(e, j);
-								if (r < spread) {
-									bttop = PT(e, j); btbot = PB(e, j);
-									btham += bt_mm_penalty(L.maq, qi);
-									btcint = j; found = true;
-									break;
-								}
-								r -= spread;
+					const uint32_t qi = bt_qual(L, H, L.qlen - i - 1u);
+					uint32_t sp[4], tp[4];
+					BT_UNROLL
+					for (j = 0; j < 4u; j++) { tp[j] = PT(e, j); sp[j] = PB(e, j) - tp[j]; }
+					uint32_t posSz = 0;
+					BT_UNROLL
+					for (j = 0; j < 4u; j++) if ((el & (1u << j)) == 0) posSz += sp[j];
+					uint32_t r = (posSz > 0) ? (bt_rnd_u32(L) % posSz) : 0u;
+					BT_UNROLL
+					for (j = 0; j < 4u; j++) {
+						if ((el & (1u << j)) == 0) {
+							if (r < sp[j]) {
+								bttop = tp[j]; btbot = tp[j] + sp[j];
+								btham += bt_mm_penalty(L.maq, qi);
+								btcint = j; found = true;
+								break;
 							}
+							r -= sp[j];
 						}
-						break;
 					}
-					if (i == L.depth) break;
 				}
-				if (!found) { L.status |= BT_STF_OVERFLOW; bt_lane_finish(L, B); return; }   /* cannot happen */
+				if (!found) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); break; }   /* cannot happen */
+				i = L.cand;
 			} else {
 				i = L.eli; bttop = L.eltop; btbot = L.elbot; btham += L.elham; j = btcint = L.elcint;
 			}
@@ -576,38 +555,44 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 			else if (i < L.f2) { n1 = L.f2; n2 = L.f3; }
 			else if (i < L.f3) { n2 = L.f3; }
 			FRW(L.sd, FR_MM) = icur | (btcint << 16);
-			L.pi = i; L.pj = j; L.pbttop = bttop; L.pbtbot = btbot;
+			L.pi = i; L.pj = j; L.pbttop = bttop; L.pbtbot = btbot; L.btham = btham;
 			if (i + 1u == L.qlen) {
 				BT_GOTO_RA(L.sd + 1u, bttop, btbot, btham, RC_CHILD);
 				break;
 			}
 			uint32_t newDepth = i + 1u, ntop = bttop, nbot = btbot;
 			const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
-			if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < ix.ftabChars && ix.ftabChars <= L.d5) {
+			const uint32_t ftabChars = IXSEL(ftabChars);
+			if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < ftabChars && ftabChars <= L.d5) {
 				/* re-jump through the ftab with the substituted character (:908-952) */
-				const uint32_t ftabChars = ix.ftabChars;
-				uint32_t ftabOff = bt_qry(L, L.qlen - ftabChars);
+				uint32_t ftabOff = bt_qry(L, H, L.qlen - ftabChars);
+				BT_NOUNROLL
 				for (uint32_t jj = ftabChars - 1u; jj > 0; jj--) {
 					ftabOff <<= 2;
 					if (L.qlen - jj == icur) ftabOff |= btcint;
-					else ftabOff |= bt_qry(L, L.qlen - jj);
+					else ftabOff |= bt_qry(L, H, L.qlen - jj);
 				}
-				ntop = bt_ftab_hi(ix, ftabOff); nbot = bt_ftab_lo(ix, ftabOff + 1u);
-				L.cnt.ftab++;
+				const uint32_t* ftab = IXSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = IXSEL(len);
+				ntop = ftab[ftabOff]; nbot = ftab[ftabOff + 1u];
+				if (ntop > len) ntop = eftab[(ntop ^ BT_OFF_MASK) * 2u + 1u];
+				if (nbot > len) nbot = eftab[(nbot ^ BT_OFF_MASK) * 2u];
+				BT_COUNT(CN_FTAB);
 				if (ntop == nbot) { L.ret = 0; L.state = ST_CHILD_RET; break; }
 				newDepth = ftabChars;
 			}
 			/* push: save the parent, enter the child */
-			if (L.sd + 1u >= S.frCap) { L.status |= BT_STF_OVERFLOW; bt_lane_finish(L, B); return; }
+			if (L.sd + 1u >= S.frCap) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); break; }
 			{
 				const uint32_t f = L.sd;
-				FRW(f, FR_DEPTH) = L.depth; FRW(f, FR_D) = L.d; FRW(f, FR_HAM) = L.ham;
-				FRW(f, FR_U) = L.fu; FRW(f, FR_R1) = L.f1; FRW(f, FR_R2) = L.f2; FRW(f, FR_R3) = L.f3;
-				FRW(f, FR_ALTNUM) = L.altNum; FRW(f, FR_ELIGNUM) = L.eligibleNum; FRW(f, FR_ELIGSZ) = L.eligibleSz;
-				FRW(f, FR_ELI) = L.eli; FRW(f, FR_ELTOP) = L.eltop; FRW(f, FR_ELBOT) = L.elbot;
-				FRW(f, FR_ELHAM) = L.elham; FRW(f, FR_ELC) = L.elcint | (L.elignore << 8);
-				FRW(f, FR_LOWQ) = L.lowAltQual;
-				FRW(f, FR_PI) = L.pi; FRW(f, FR_PJ) = L.pj; FRW(f, FR_PTOP) = L.pbttop; FRW(f, FR_PBOT) = L.pbtbot;
+				FRW(f, FR_W0) = L.depth | (L.d << 11);
+				FRW(f, FR_W1) = L.ham | (L.lowAltQual << 16) | (L.elham << 24);
+				FRW(f, FR_W2) = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
+				FRW(f, FR_W3) = L.f2 | (L.f3 << 11);
+				FRW(f, FR_W4) = L.altNum | (L.eligibleNum << 12);
+				FRW(f, FR_ELIGSZ) = L.eligibleSz; FRW(f, FR_ELTOP) = L.eltop; FRW(f, FR_ELBOT) = L.elbot;
+				FRW(f, FR_W8) = L.eli | (L.cand << 11);
+				FRW(f, FR_W9) = L.pi | (L.pj << 11);
+				FRW(f, FR_PTOP) = L.pbttop; FRW(f, FR_PBOT) = L.pbtbot;
 				FRW(f, FR_EBASE) = L.ebase;
 			}
 			L.ebase = L.ebase + (L.d - L.depth + 1u);
@@ -620,24 +605,26 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 		/* ---- a child frame (or a leaf report) came back (:972-1064) ---------------------- */
 		case ST_CHILD_RET: {
 			if (L.ret) { L.state = ST_FRAME_RETURN; break; }
-			if (L.bailed || (L.halfAndHalf && L.maxBts > 0 && L.numBts >= L.maxBts)) {
+			if (L.bailed || (L.halfAndHalf && P.steps[L.step].maxBts > 0 && L.numBts >= P.steps[L.step].maxBts)) {
 				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
 			}
 			{
 				const uint32_t e = L.ebase + (L.pi - L.depth);
-				S.elims[e] = (uint8_t)(S.elims[e] | (1u << L.pj));
+				const uint32_t el = S.elims[e] | (1u << L.pj);
+				S.elims[e] = (uint8_t)el;
+				if (el == 15u) L.candValid = 0;      /* that position is exhausted: re-scan next time */
 			}
 			L.eligibleSz -= (L.pbtbot - L.pbttop);
-			L.eligibleNum--;
+			L.eligibleNum = L.eligibleNum - 1u;
 			L.elignore = 1;
-			L.altNum--;
+			L.altNum = L.altNum - 1u;
 			if (L.altNum == 0) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
 			if (L.eligibleNum == 0 && L.considerQuals) {
 				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058) */
-				L.lowAltQual = 0xff;
+				L.lowAltQual = 0xff; L.candValid = 0;
+				BT_NOUNROLL
 				for (uint32_t k = L.d; k >= L.depth && k <= L.qlen; k--) {
-					const uint32_t kcur = L.qlen - k - 1u;
-					const uint32_t kq = bt_qual(L, kcur);
+					const uint32_t kq = bt_qual(L, H, L.qlen - k - 1u);
 					if (k < L.fu) break;
 					const bool kAlt = (L.ham + bt_mm_penalty(L.maq, kq) <= L.qualThresh);
 					bool kOver = false;
@@ -646,15 +633,17 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 						if (kq <= L.lowAltQual) {
 							const uint32_t e = L.ebase + (k - L.depth);
 							const uint32_t el = S.elims[e];
+							BT_UNROLL
 							for (uint32_t l = 0; l < 4u; l++) {
 								if ((el & (1u << l)) == 0) {
-									uint32_t spread = PB(e, l) - PT(e, l);
+									const uint32_t t = PT(e, l), spread = PB(e, l) - t;
 									if (kOver) {
 										L.lowAltQual = kq; kOver = false; L.eligibleNum = 0; L.eligibleSz = 0;
-										L.eli = k; L.eltop = PT(e, l); L.elbot = PB(e, l);
+										L.eli = k; L.eltop = t; L.elbot = t + spread;
 										L.elham = bt_mm_penalty(L.maq, kq); L.elcint = l; L.elignore = 0;
+										L.cand = k; L.candValid = 1;     /* deepest position of the new quality */
 									}
-									L.eligibleNum++; L.eligibleSz += spread;
+									L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += spread;
 								}
 							}
 						}
@@ -671,15 +660,19 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - 1u;
 			L.sd = f;
-			L.depth = FRW(f, FR_DEPTH); L.d = FRW(f, FR_D); L.ham = FRW(f, FR_HAM);
-			L.fu = FRW(f, FR_U); L.f1 = FRW(f, FR_R1); L.f2 = FRW(f, FR_R2); L.f3 = FRW(f, FR_R3);
-			L.altNum = FRW(f, FR_ALTNUM); L.eligibleNum = FRW(f, FR_ELIGNUM); L.eligibleSz = FRW(f, FR_ELIGSZ);
-			L.eli = FRW(f, FR_ELI); L.eltop = FRW(f, FR_ELTOP); L.elbot = FRW(f, FR_ELBOT);
-			L.elham = FRW(f, FR_ELHAM);
-			{ uint32_t v = FRW(f, FR_ELC); L.elcint = v & 0xffu; L.elignore = (v >> 8) & 1u; }
-			L.lowAltQual = FRW(f, FR_LOWQ);
-			L.pi = FRW(f, FR_PI); L.pj = FRW(f, FR_PJ); L.pbttop = FRW(f, FR_PTOP); L.pbtbot = FRW(f, FR_PBOT);
+			uint32_t v;
+			v = FRW(f, FR_W0); L.depth = v & 0x7ffu; L.d = (v >> 11) & 0x7ffu;
+			v = FRW(f, FR_W1); L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu; L.elham = (v >> 24) & 0xffu;
+			v = FRW(f, FR_W2); L.fu = v & 0x7ffu; L.f1 = (v >> 11) & 0x7ffu; L.elcint = (v >> 22) & 3u;
+			L.elignore = (v >> 24) & 1u; L.candValid = (v >> 25) & 1u;
+			v = FRW(f, FR_W3); L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
+			v = FRW(f, FR_W4); L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
+			L.eligibleSz = FRW(f, FR_ELIGSZ); L.eltop = FRW(f, FR_ELTOP); L.elbot = FRW(f, FR_ELBOT);
+			v = FRW(f, FR_W8); L.eli = v & 0x7ffu; L.cand = (v >> 11) & 0x7ffu;
+			v = FRW(f, FR_W9); L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u;
+			L.pbttop = FRW(f, FR_PTOP); L.pbtbot = FRW(f, FR_PBOT);
 			L.ebase = FRW(f, FR_EBASE);
+			L.cchunk = 0xffu;
 			L.state = ST_CHILD_RET;
 			break;
 		}
@@ -698,13 +691,13 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 				L.ret = 0; L.state = ST_RA_END; break;
 			}
 			uint32_t stratum = 0;
+			BT_NOUNROLL
 			for (uint32_t i = 0; i < L.ra_sd; i++)                      /* calcStratum (:1164-1177) */
 				if ((FRW(i, FR_MM) & 0xffffu) >= (L.qlen - L.r3)) stratum++;
 			stratum += L.nmuts;
-			L.ra_nmm = L.ra_sd + L.nmuts;
 			L.ra_stratum = stratum;
 			L.ra_cost = (L.ra_cost | (stratum << 14)) & 0xffffu;
-			if (L.ra_nmm == 0 && !L.reportExacts) { L.ret = 0; L.state = ST_RA_END; break; }
+			if (L.ra_sd + L.nmuts == 0 && !L.reportExacts) { L.ret = 0; L.state = ST_RA_END; break; }
 			{
 				const uint32_t spread = L.ra_bot - L.ra_top;
 				L.ra_r = L.ra_top + (bt_rnd_u32(L) % spread);
@@ -720,33 +713,41 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 			if (ri >= L.ra_bot) ri -= spread;
 			L.crow = ri; L.cjumps = 0;
 			L.state = ST_CHASE_CHECK;
-			/* fallthrough */
-		}
-		// fallthrough
-		case ST_CHASE_CHECK: {
-			/* reportChaseOne's walk (ebwt.h:2727-2746) */
-			if ((L.crow & ix.offMask) != L.crow && L.crow != ix.zOff) {
-				req.rowA = L.crow; req.op = 1; L.cnt.chase++;
-				L.state = ST_CHASE_LFDONE; return;
-			}
-			L.state = ST_RESOLVE;
-			break;
-		}
-		case ST_CHASE_LFDONE: {
-			L.crow = res.a[res.LA];                 /* mapLF(l), ebwt.h:2420 */
-			L.cjumps++;
-			L.state = ST_CHASE_CHECK;
 			break;
 		}
 		case ST_RESOLVE: {
+			const uint32_t zOff = IXSEL(zOff);
 			uint32_t off;
-			if (L.crow == ix.zOff) off = L.cjumps;
-			else { off = ix.offs[L.crow >> ix.offRate] + L.cjumps; }
-			L.cnt.offs++;
-			uint32_t tidx = 0, toff = 0;
-			if (bt_joined_to_text(ix, L.qlen, off, &tidx, &toff, &L.cnt.rstarts)) {
-				if (bt_report_hit(L, P, ix, S, B, tidx, toff)) { L.ret = 1; L.state = ST_RA_END; break; }
+			if (L.crow == zOff) off = L.cjumps;
+			else { const uint32_t* offs = IXSEL(offs); off = offs[L.crow >> IXSEL(offRate)] + L.cjumps; }
+			BT_COUNT(CN_OFFS);
+			/* joinedToTextOff (ebwt.h:2569-2629) */
+			const uint32_t* rstarts = IXSEL(rstarts);
+			const uint32_t nFrag = IXSEL(nFrag), len = IXSEL(len), ixfw = IXSEL(fw);
+			uint32_t lo = 0, hi = nFrag, tidx = 0, toff = 0, probes = 0;
+			bool hit = false;
+			BT_NOUNROLL
+			for (;;) {
+				const uint32_t elt = lo + ((hi - lo) >> 1);
+				const uint32_t lower = rstarts[elt * 3u];
+				const uint32_t upper = (elt == nFrag - 1u) ? len : rstarts[(elt + 1u) * 3u];
+				probes++;
+				if (lower <= off) {
+					if (upper > off) {
+						if (off + L.qlen <= upper) {
+							uint32_t fragoff = off - lower;
+							if (!ixfw) { fragoff = (upper - lower) - fragoff - 1u; fragoff -= (L.qlen - 1u); }
+							tidx = rstarts[elt * 3u + 1u];
+							toff = fragoff + rstarts[elt * 3u + 2u];
+							hit = true;
+						}
+						break;
+					}
+					lo = elt;
+				} else hi = elt;
 			}
+			BT_COUNT_N(CN_RSTARTS, probes);
+			if (hit && bt_report_hit(L, P, ixfw, S, B, tidx, toff)) { L.ret = 1; L.state = ST_RA_END; break; }
 			L.ra_i++;
 			L.state = ST_ROW_BEGIN;
 			break;
@@ -772,38 +773,203 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtIndexDev* IX, cons
 			if (L.kind == BT_KIND_EXTEND) {
 				/* search_seeded_phase3.c:9-59 / phase4.c:9-55: for each seedling, setMuts +
 				 * backtrack(oldQuals); the RNG runs on across seedlings */
-				if (L.palIdx != 0xffffffffu && L.ret) { bt_lane_finish(L, B); return; }
-				L.palIdx = (L.palIdx == 0xffffffffu) ? 0u : L.palIdx + 1u;
-				if (L.palIdx >= L.npals) { L.nmuts = 0; L.state = ST_PHASE_NEXT; break; }
+				if (!L.palIdxBefore && L.ret) { bt_lane_finish(L, B); break; }
+				if (L.palIdxBefore) { L.palIdxBefore = 0; L.palIdx = 0; } else L.palIdx = L.palIdx + 1u;
+				L.nmuts = 0;
+				if (L.palIdx >= L.npals) { L.state = ST_PHASE_NEXT; break; }
 				/* PartialAlignmentManager::toMutsString (ebwt_search_util.h:310-362) */
 				const uint64_t pal = S.pals[L.palIdx];
-				uint32_t pos[3] = { (uint32_t)(pal & 0xffffu), (uint32_t)((pal >> 16) & 0xffffu), (uint32_t)((pal >> 32) & 0xffffu) };
-				uint32_t chr[3] = { (uint32_t)((pal >> 48) & 3u), (uint32_t)((pal >> 50) & 3u), (uint32_t)((pal >> 52) & 3u) };
-				L.nmuts = 0;
-				uint32_t oldQuals = 0;
-				for (int k = 0; k < 3; k++) {
-					if (k > 0 && pos[k] == 0xffffu) break;
-					uint32_t tpos = L.plen - 1u - pos[k];
-					oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, tpos))) & 0xffu;
-					L.mutpos[k] = tpos; L.mutnew[k] = chr[k];
-					L.nmuts = (uint32_t)k + 1u;
+				const uint32_t p0 = (uint32_t)(pal & 0xffffu), p1 = (uint32_t)((pal >> 16) & 0xffffu), p2 = (uint32_t)((pal >> 32) & 0xffffu);
+				uint32_t oldQuals = 0, nm = 1;
+				const uint32_t t0 = L.plen - 1u - p0;
+				oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t0))) & 0xffu;
+				L.mutpos0 = t0; L.mutnew0 = (uint32_t)((pal >> 48) & 3u);
+				if (p1 != 0xffffu) {
+					const uint32_t t1 = L.plen - 1u - p1;
+					oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t1))) & 0xffu;
+					L.mutpos1 = t1; L.mutnew1 = (uint32_t)((pal >> 50) & 3u); nm = 2;
+					if (p2 != 0xffffu) {
+						const uint32_t t2 = L.plen - 1u - p2;
+						oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t2))) & 0xffu;
+						L.mutpos2 = t2; L.mutnew2 = (uint32_t)((pal >> 52) & 3u); nm = 3;
+					}
 				}
+				L.nmuts = nm;
 				L.iham = oldQuals;
 				L.state = ST_SEARCH_BEGIN;
 				break;
 			}
 			if (L.kind == BT_KIND_GEN) { L.state = ST_PHASE_NEXT; break; }
-			if (L.ret) { bt_lane_finish(L, B); return; }
+			if (L.ret) { bt_lane_finish(L, B); break; }
 			L.state = ST_PHASE_NEXT;
 			break;
 		}
 		default:
-			return;
+			L.state = ST_IDLE;
+			break;
 		}
+	}
+}
+
+/*
+ * Advance one lane until it needs an LF-mapping (returns with req.op != 0 and the lane in a
+ * *_LFDONE state) or has finished its read (state ST_IDLE, req.op == 0).
+ * `res` is consumed iff the lane was waiting for it.
+ */
+BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScratch& S,
+                       const BtRes& res, BtReq& req, unsigned long long* CNT)
+{
+	req.op = 0; req.rowA = 0; req.rowB = 0;
+	BT_NOUNROLL
+	for (;;) {
+		/* ---- resume: SA walk (reportChaseOne, ebwt.h:2727-2746) --------------------------- */
+		if (L.state == ST_CHASE_LFDONE) {
+			L.crow = res.LA == 0 ? res.a[0] : res.LA == 1 ? res.a[1] : res.LA == 2 ? res.a[2] : res.a[3];   /* mapLF(l) */
+			L.cjumps++;
+			L.state = ST_CHASE_CHECK;
+		}
+		/* ---- resume: one query position (:456-739) ---------------------------------------- */
+		if (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST) {
+			const uint32_t c = L.c, q = L.q, d = L.d, cur = L.qlen - d - 1u;
+			const uint32_t e = L.ebase + (d - L.depth);
+			uint32_t ta[4], tb[4];
+			if (L.state == ST_STEP_LFDONE) {
+				const uint32_t ac = c == 0 ? res.a[0] : c == 1 ? res.a[1] : c == 2 ? res.a[2] : res.a[3];
+				const uint32_t bc = c == 0 ? res.b[0] : c == 1 ? res.b[1] : c == 2 ? res.b[2] : res.b[3];
+				if (L.lfk == LFK_EX2) {
+					BT_UNROLL
+					for (int k = 0; k < 4; k++) { ta[k] = res.a[k]; tb[k] = res.b[k]; PT(e, k) = ta[k]; PB(e, k) = tb[k]; }
+					if (c < 4u) { L.top = ac; L.bot = bc; }
+				} else if (L.lfk == LFK_C2) {
+					L.top = ac; L.bot = bc;
+				} else {
+					/* mapLF1 (ebwt.h:2494-2512) */
+					if (res.LA != c || L.top == HSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
+					else { L.top = ac; L.bot = ac + 1u; }
+				}
+			} else {
+				/* no LF was needed: depth-0 fchr quartet (:531-543) or a non-alternative N */
+				BT_UNROLL
+				for (int k = 0; k < 4; k++) { ta[k] = (L.mirror ? H.fchr[1][k] : H.fchr[0][k]); tb[k] = (L.mirror ? H.fchr[1][k + 1] : H.fchr[0][k + 1]); }
+			}
+			uint32_t el = (c < 4u) ? (1u << c) : 0u;
+			if (L.fl_alt) {
+				bool over = L.fl_over != 0;
+				BT_UNROLL
+				for (uint32_t i = 0; i < 4u; i++) {
+					if (i == c) continue;
+					const uint32_t spread = tb[i] - ta[i];
+					if (spread == 0) el |= (1u << i);
+					else {
+						if (L.fl_elig) {
+							if (over) {
+								L.lowAltQual = q; L.eligibleNum = 0; L.eligibleSz = 0; over = false;
+								L.eli = d; L.eltop = ta[i]; L.elbot = tb[i];
+								L.elham = bt_mm_penalty(L.maq, q); L.elcint = i; L.elignore = 0;
+							}
+							L.eligibleSz += spread; L.eligibleNum = L.eligibleNum + 1u;
+						}
+						L.altNum = L.altNum + 1u;
+					}
+				}
+				if (L.fl_elig && el != 15u) { L.cand = d; L.candValid = 1; }     /* deepest eligible target so far */
+			}
+			S.elims[e] = (uint8_t)el;
+			bool btDespite = false, reportedPartial = false;
+			if (cur == 0 && L.top < L.bot && L.sd < L.reportPartials && L.reportPartials > 0) {
+				if (L.altNum > 0) btDespite = true;
+				if (L.sd > 0) { bt_report_partial(L, S, L.sd); reportedPartial = true; }
+			}
+			bool invalidExact = false;
+			if (cur == 0 && L.sd == 0 && L.bot > L.top && !L.reportExacts) { invalidExact = true; btDespite = true; }
+			bool mustBacktrack = false, invalidHH = false, frameFail = false;
+			if (L.halfAndHalf) {
+				if (d + 1u == L.d5 && L.top < L.bot) {
+					invalidHH = (L.sd == 0);
+					if (L.sd == 0 && L.altNum > 0) { btDespite = true; mustBacktrack = true; }
+					else if (L.sd == 0) frameFail = true;
+				} else if (d + 1u == L.d3 && L.top < L.bot) {
+					uint32_t lo = 0, hi = 0;
+					BT_NOUNROLL
+					for (uint32_t i = 0; i < L.sd; i++) {
+						uint32_t dd = L.qlen - (FRW(i, FR_MM) & 0xffffu) - 1u;
+						if (dd < L.d5) hi++; else if (dd < L.d3) lo++;
+					}
+					invalidHH = (lo == 0 || hi == 0);
+					if ((L.sd < 2 || invalidHH) && L.altNum > 0) { mustBacktrack = true; btDespite = true; }
+					else if (L.sd < 2) frameFail = true;
+				}
+			}
+			if (frameFail) { L.ret = 0; L.state = ST_FRAME_RETURN; }
+			else if (cur == 0 && L.bot > L.top && !invalidHH && !invalidExact && !reportedPartial)
+				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP);
+			else if ((L.top == L.bot || btDespite) && L.altNum > 0) L.state = ST_BT_LOOP;
+			else if (mustBacktrack || invalidHH || invalidExact || L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; }
+			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
+		}
+
+		/* ---- everything else ---------------------------------------------------------------- */
+		if (BT_IS_SLOW(L.state)) bt_lane_slow(L, H, C, S, CNT);
+
+		/* ---- emit: next query position (:456-568) -------------------------------------------- */
+		if (L.state == ST_STEP_BEGIN) {
+			const uint32_t d = L.d;
+			if (d >= L.qlen) { L.state = ST_FELL_OFF; continue; }
+			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; continue; }
+			if (L.ebase + (d - L.depth) >= S.entCap) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, C.B); return; }
+			uint32_t c, q;
+			bt_qq_cached(L, H, L.qlen - d - 1u, &c, &q);
+			L.c = c; L.q = q;
+			const bool alt = (d >= L.fu) && (!L.considerQuals || (L.ham + bt_mm_penalty(L.maq, q) <= L.qualThresh));
+			bool elig = false, over = false;
+			if (alt) {
+				if (L.considerQuals) {
+					if (q < L.lowAltQual) { elig = true; over = true; }
+					else if (q == L.lowAltQual) elig = true;
+				} else elig = true;
+			}
+			L.fl_alt = alt; L.fl_elig = elig; L.fl_over = over;
+			const uint32_t rtop = L.top, rbot = L.bot;
+			if (c == 4u && d > 0) { L.top = 1; L.bot = 1; }
+			if (rtop == 0 && rbot == 0) {
+				/* depth 0: the fchr quartet (:531-543) */
+				const uint32_t e = L.ebase + (d - L.depth);
+				BT_UNROLL
+				for (int k = 0; k < 4; k++) { PT(e, k) = (L.mirror ? H.fchr[1][k] : H.fchr[0][k]); PB(e, k) = (L.mirror ? H.fchr[1][k + 1] : H.fchr[0][k + 1]); }
+				if (c < 4u) { L.top = c == 0 ? (L.mirror ? H.fchr[1][0] : H.fchr[0][0]) : c == 1 ? (L.mirror ? H.fchr[1][1] : H.fchr[0][1]) : c == 2 ? (L.mirror ? H.fchr[1][2] : H.fchr[0][2]) : (L.mirror ? H.fchr[1][3] : H.fchr[0][3]);
+				              L.bot = c == 0 ? (L.mirror ? H.fchr[1][1] : H.fchr[0][1]) : c == 1 ? (L.mirror ? H.fchr[1][2] : H.fchr[0][2]) : c == 2 ? (L.mirror ? H.fchr[1][3] : H.fchr[0][3]) : (L.mirror ? H.fchr[1][4] : H.fchr[0][4]); }
+				L.state = ST_STEP_POST;
+				continue;
+			} else if (alt) {
+				req.rowA = rtop; req.rowB = rbot; req.op = 3; L.lfk = LFK_EX2;
+				L.state = ST_STEP_LFDONE; return;
+			} else if (c < 4u) {
+				if (L.top + 1u == L.bot) { req.rowA = L.top; req.op = 1; L.lfk = LFK_LF1; }
+				else { req.rowA = L.top; req.rowB = L.bot; req.op = 3; L.lfk = LFK_C2; }
+				L.state = ST_STEP_LFDONE; return;
+			} else {
+				/* non-alternative N: the range is already (1,1); only the bookkeeping remains.
+				 * ta/tb are unused on that path because fl_alt is false. */
+				L.state = ST_STEP_POST;
+				continue;
+			}
+		}
+		/* ---- emit: next SA-walk step ---------------------------------------------------------- */
+		if (L.state == ST_CHASE_CHECK) {
+			if ((L.crow & HSEL(offMask)) != L.crow && L.crow != HSEL(zOff)) {
+				req.rowA = L.crow; req.op = 1; L.lfk = 3;
+				L.state = ST_CHASE_LFDONE; return;
+			}
+			L.state = ST_RESOLVE;
+			continue;
+		}
+		if (L.state == ST_IDLE) return;
 	}
 }
 
 #undef FRW
 #undef PT
 #undef PB
+#undef IXSEL
+#undef HSEL
 #endif /* BT_CORE_H_ */

@@ -7,17 +7,16 @@
 #define BT_BLOCK 256
 
 struct BtKernelArgs {
-	BtProgram  P;
-	BtIndexDev ix[2];            /* [0] index of the text, [1] mirror index                      */
-	BtBatchDev B;
+	BtHot      H;                /* by value: scalar registers                                   */
+	const BtCold* cold;          /* device memory: program, full index descriptors, batch        */
 	/* per-lane scratch arenas (see BtScratch) */
-	uint32_t*  frames;           /* [frCap*24][nLanes]                                           */
+	uint32_t*  frames;           /* [frCap*16][nLanes]                                           */
 	uint32_t*  pairs;            /* [nLanes][entCap][8]                                          */
 	uint8_t*   elims;            /* [nLanes][entCap]                                             */
 	uint64_t*  pals;             /* [nLanes][palCap]                                             */
 	uint32_t   nLanes, frCap, entCap, palCap;
 	uint32_t*  nextRead;         /* global read cursor                                           */
-	unsigned long long* counts;  /* 10 x u64 = bt_op_counts */
+	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
 };
 
 extern "C" {

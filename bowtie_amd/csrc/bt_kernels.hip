@@ -45,6 +45,10 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 
 __global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
 {
+	__shared__ unsigned long long CNT[CN_N];
+	if (threadIdx.x < CN_N) CNT[threadIdx.x] = 0;
+	__syncthreads();
+
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BtScratch S;
 	S.frStride = A.nLanes;
@@ -55,39 +59,48 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
 	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
 
 	BtLane L;
-	L.state = ST_IDLE; L.mirror = 0;
-	L.cnt.lfex = L.cnt.lf2 = L.cnt.lf1 = L.cnt.chase = L.cnt.ftab = L.cnt.offs = L.cnt.rstarts = L.cnt.frames = L.cnt.samePair = 0;
+	memset(&L, 0, sizeof(L));
+	L.state = ST_IDLE;
 	BtRes res;
 	BtReq req;
 	res.LA = 0;
 	for (int k = 0; k < 4; k++) { res.a[k] = 0; res.b[k] = 0; }
 	bool drained = false;
-	uint32_t iters = 0;
+	const BtCold* cold = A.cold;
 
 	for (;;) {
+		/* keep the compiler from hoisting the cold descriptor's fields into scalar registers for
+		 * the whole loop: they are read where they are used */
+		asm volatile("" : "+s"(cold));
 		/* advance to the next LF request, pulling new reads as old ones finish */
 		for (;;) {
 			if (L.state == ST_IDLE) {
 				if (drained) break;
 				const uint32_t rd = atomicAdd(A.nextRead, 1u);
-				if (rd >= A.B.n_reads) { drained = true; break; }
-				bt_lane_start(L, A.P, A.B, rd);
+				if (rd >= A.H.n_reads) { drained = true; break; }
+				bt_lane_start(L, A.H, *cold, rd);
 			}
-			bt_lane_run(L, A.P, A.ix, S, A.B, res, req);
+			bt_lane_run(L, A.H, *cold, S, res, req, CNT);
 			if (L.state != ST_IDLE) break;
 		}
 		if (L.state == ST_IDLE) break;
-		iters++;
+		/* op counters: one LDS atomic per wavefront per kind */
+		BT_COUNT(CN_ITERS);
+		if (L.state == ST_CHASE_LFDONE) BT_COUNT(CN_CHASE);
+		else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
+		else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
+		else BT_COUNT(CN_LF1);
+		if ((req.op & 2u) && req.rowA / 448u == req.rowB / 448u) BT_COUNT(CN_SAMEPAIR);
 		/* the rank gathers of the whole wavefront */
 		BtRankSel sel;
 		const bool m = L.mirror != 0;
-		sel.ebwt = m ? A.ix[1].ebwt : A.ix[0].ebwt;
-		sel.zSide = m ? A.ix[1].zSide : A.ix[0].zSide;
-		sel.zSym = m ? A.ix[1].zSym : A.ix[0].zSym;
-		sel.f0 = m ? A.ix[1].fchr[0] : A.ix[0].fchr[0];
-		sel.f1 = m ? A.ix[1].fchr[1] : A.ix[0].fchr[1];
-		sel.f2 = m ? A.ix[1].fchr[2] : A.ix[0].fchr[2];
-		sel.f3 = m ? A.ix[1].fchr[3] : A.ix[0].fchr[3];
+		sel.ebwt = m ? A.H.ebwt[1] : A.H.ebwt[0];
+		sel.zSide = m ? A.H.zSide[1] : A.H.zSide[0];
+		sel.zSym = m ? A.H.zSym[1] : A.H.zSym[0];
+		sel.f0 = m ? A.H.fchr[1][0] : A.H.fchr[0][0];
+		sel.f1 = m ? A.H.fchr[1][1] : A.H.fchr[0][1];
+		sel.f2 = m ? A.H.fchr[1][2] : A.H.fchr[0][2];
+		sel.f3 = m ? A.H.fchr[1][3] : A.H.fchr[0][3];
 		dev_rank4(sel, req.rowA, res.a, &res.LA);
 		if (req.op & 2u) {
 			uint32_t dummy;
@@ -95,22 +108,8 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
 		}
 	}
 
-	/* op counters: block-reduce, then one atomic per counter per block */
-	__shared__ unsigned long long sh[10];
-	if (threadIdx.x < 10) sh[threadIdx.x] = 0;
 	__syncthreads();
-	atomicAdd(&sh[0], (unsigned long long)L.cnt.lfex);
-	atomicAdd(&sh[1], (unsigned long long)L.cnt.lf2);
-	atomicAdd(&sh[2], (unsigned long long)L.cnt.lf1);
-	atomicAdd(&sh[3], (unsigned long long)L.cnt.chase);
-	atomicAdd(&sh[4], (unsigned long long)L.cnt.ftab);
-	atomicAdd(&sh[5], (unsigned long long)L.cnt.offs);
-	atomicAdd(&sh[6], (unsigned long long)L.cnt.rstarts);
-	atomicAdd(&sh[7], (unsigned long long)L.cnt.frames);
-	atomicAdd(&sh[8], (unsigned long long)iters);
-	atomicAdd(&sh[9], (unsigned long long)L.cnt.samePair);
-	__syncthreads();
-	if (threadIdx.x < 10 && A.counts) atomicAdd(&A.counts[threadIdx.x], sh[threadIdx.x]);
+	if (threadIdx.x < CN_N && A.counts) atomicAdd(&A.counts[threadIdx.x], CNT[threadIdx.x]);
 }
 
 __global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)

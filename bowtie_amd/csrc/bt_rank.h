@@ -30,8 +30,10 @@
 #endif
 #if defined(__clang__)
 #define BT_UNROLL _Pragma("unroll")
+#define BT_NOUNROLL _Pragma("nounroll")
 #else
 #define BT_UNROLL
+#define BT_NOUNROLL
 #endif
 
 #define BT_OFF_MASK 0xffffffffu

@@ -108,6 +108,26 @@ def _sort_into(key, idx, sa, is_start, pos):
     return pos + m
 
 
+def check_sa_sample(s: torch.Tensor, sa: torch.Tensor, nsample: int = 1_000_000, depth: int = 256) -> int:
+    """Number of sampled adjacent SA pairs that are out of order (0 for a correct SA); compares up to
+    `depth` characters with '$' (end of text) greater than ACGT."""
+    n = s.numel()
+    g = torch.Generator(device=s.device)
+    g.manual_seed(1)
+    i = torch.randint(0, n, (nsample,), generator=g, device=s.device)
+    a, b = sa[i], sa[i + 1]
+    undecided = torch.ones(nsample, dtype=torch.bool, device=s.device)
+    bad = torch.zeros(nsample, dtype=torch.bool, device=s.device)
+    for k in range(depth):
+        ca = torch.where(a + k < n, s[(a + k).clamp(max=n - 1)].to(torch.int16), torch.full_like(a, 4, dtype=torch.int16))
+        cb = torch.where(b + k < n, s[(b + k).clamp(max=n - 1)].to(torch.int16), torch.full_like(b, 4, dtype=torch.int16))
+        bad |= undecided & (ca > cb)
+        undecided &= (ca == cb) & (ca < 4)
+        if not bool(undecided.any()):
+            break
+    return int(bad.sum().item())
+
+
 def suffix_array(s: torch.Tensor) -> torch.Tensor:
     """s: uint8 codes 0..3 -> SA (int64, length n+1) of s+'$' with '$' greater than ACGT."""
     dev = s.device
@@ -157,7 +177,7 @@ def suffix_array(s: torch.Tensor) -> torch.Tensor:
             j = el + h
             # beyond the end: larger than every real rank, and larger for the shorter suffix
             r2 = torch.where(j <= n, rank[j.clamp(max=n)], (1 << 32) - 1 - (n - el))
-            k2 = (rank[el] << 32) | r2
+            k2 = ((rank[el] - (1 << 31)) << 32) | r2      # biased so that ranks >= 2^31 keep signed order
             ks, perm = torch.sort(k2)
             el = el[perm]
             sa[p] = el
@@ -183,6 +203,8 @@ def build_arrays(s: torch.Tensor, off_rate: int = 5, ftab_chars: int = 10):
     dev = s.device
     n = s.numel()
     sa = suffix_array(s)
+    if os.environ.get("BT_BUILD_VERBOSE"):
+        _log("SA check: %d of 1M sampled adjacent pairs out of order" % check_sa_sample(s, sa))
     # BWT (the '$' row stores an A, uncounted); pad to whole side pairs with A (counted)
     bwt_sz = n // 4 + 1
     num_pairs = (bwt_sz + 2 * 56 - 1) // (2 * 56)
@@ -210,10 +232,16 @@ def build_arrays(s: torch.Tensor, off_rate: int = 5, ftab_chars: int = 10):
         for i in range(ftab_chars):
             suf = (suf << 2) | s[e2 + i].to(torch.int64)
         rows = rows + lo
-        count += torch.bincount(suf, minlength=nb)
-        first.scatter_reduce_(0, suf, rows, reduce="amin", include_self=True)
-        last.scatter_reduce_(0, suf, rows, reduce="amax", include_self=True)
-        del el, rows, e2, suf
+        # rows are in SA order, so bucket ids are non-decreasing along them: run-length encode
+        # (no atomics: scatter_reduce amin/amax on int64 proved unreliable on this stack)
+        vals, cnts = torch.unique_consecutive(suf, return_counts=True)
+        ends = torch.cumsum(cnts, 0)
+        f_in = rows[ends - cnts]
+        l_in = rows[ends - 1]
+        count[vals] += cnts
+        first[vals] = torch.minimum(first[vals], f_in)
+        last[vals] = torch.maximum(last[vals], l_in)
+        del el, rows, e2, suf, vals, cnts, ends, f_in, l_in
     # offs sample: rows that are multiples of 2^offRate
     offs = sa[:: (1 << off_rate)].cpu().numpy().astype(np.uint32)
     del sa
@@ -238,7 +266,8 @@ def build_arrays(s: torch.Tensor, off_rate: int = 5, ftab_chars: int = 10):
     eftab = np.zeros(2 * ftab_chars, dtype=np.uint32)
     absorbed = np.nonzero(hi_a[1:] != lo_a[1:])[0] + 1
     if len(absorbed) > ftab_chars:
-        raise RuntimeError("eftab overflow")
+        raise RuntimeError("eftab overflow: %d absorbed entries, first at %s (lo %s hi %s)" %
+                           (len(absorbed), absorbed[:8], lo_a[absorbed[:8]], hi_a[absorbed[:8]]))
     for k, i in enumerate(absorbed):
         eftab[2 * k] = lo_a[i]
         eftab[2 * k + 1] = hi_a[i]

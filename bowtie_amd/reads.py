@@ -164,7 +164,7 @@ def pack_reads(reads: Iterable[Read], global_seed: int = 0, stride: int | None =
     n = len(reads)
     maxlen = max((len(r) for r in reads), default=1)
     if stride is None:
-        stride = max(4, (maxlen + 3) & ~3)
+        stride = max(16, (maxlen + 15) & ~15)     # rows 16-byte aligned (the kernel fetches 16-byte windows)
     seq = np.full((n, stride), 4, dtype=np.uint8)
     qual = np.full((n, stride), 33, dtype=np.uint8)
     lens = np.zeros(n, dtype=np.uint16)

@@ -40,7 +40,7 @@ def synth_reads(text: np.ndarray, n: int, length: int, mm_dist: Sequence[int] = 
         low = rng.random((n, length)) < lowq_frac
         qual[low] = rng.integers(0, 5, size=int(low.sum()))
     qual = (qual + 33).astype(np.uint8)
-    stride = stride or max(4, (length + 3) & ~3)
+    stride = stride or max(16, (length + 15) & ~15)
     pseq = np.full((n, stride), 4, dtype=np.uint8)
     pqual = np.full((n, stride), 33, dtype=np.uint8)
     pseq[:, :length] = seq
@@ -90,7 +90,7 @@ def synth_reads_torch(text_t, n: int, length: int, mm_dist=(0, 1, 2, 2, 3, 4), s
     with names r<first_id + i>."""
     import torch
     dev = text_t.device
-    stride = stride or max(4, (length + 3) & ~3)
+    stride = stride or max(16, (length + 15) & ~15)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     T = text_t.numel()

@@ -70,7 +70,8 @@ void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 
 /* ---- reads in: what PatternSourcePerThread hands the worker (read.h:42-273) -------------- */
 typedef struct bt_read_batch {
 	uint32_t        n_reads;
-	uint32_t        stride;   /* bytes per read row in seq[] and qual[] (>= max len)          */
+	uint32_t        stride;   /* bytes per read row in seq[] and qual[]: >= max len, a multiple
+	                             of 16; seq and qual themselves 16-byte aligned               */
 	const uint8_t*  seq;      /* [n_reads][stride]  A=0 C=1 G=2 T=3 N=4 (patFw)               */
 	const uint8_t*  qual;     /* [n_reads][stride]  Phred+33 ASCII (Read::qual)               */
 	const uint16_t* len;      /* [n_reads]          1..1024                                   */

@@ -48,15 +48,25 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
                                bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap)
 {
 	EmuIndex* e = (EmuIndex*)p;
-	BtProgram P;
+	BtCold cold;
+	memset(&cold, 0, sizeof(cold));
+	BtProgram& P = cold.P;
 	int rc = bt_host_compile_program(*pol, &P);
 	if (rc != BT_OK) return rc;
-	BtBatchDev B;
-	memset(&B, 0, sizeof(B));
+	BtBatchDev& B = cold.B;
 	B.seq = in->seq; B.qual = in->qual; B.len = in->len; B.seed = in->seed; B.n_reads = in->n_reads; B.stride = in->stride;
 	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
+	cold.ix[0] = e->d[0]; cold.ix[1] = e->d[1];
+	BtHot H;
+	memset(&H, 0, sizeof(H));
+	for (int m = 0; m < 2; m++) {
+		H.ebwt[m] = e->d[m].ebwt; H.zSide[m] = e->d[m].zSide; H.zSym[m] = e->d[m].zSym; H.zOff[m] = e->d[m].zOff;
+		H.offMask[m] = e->d[m].offMask;
+		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
+	}
+	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
 	std::vector<uint32_t> frames((size_t)nLanes * frCap * BT_FR_WORDS), pairs((size_t)nLanes * entCap * 8);
 	std::vector<uint8_t> elims((size_t)nLanes * entCap);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
@@ -64,6 +74,8 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	std::vector<BtScratch> scr(nLanes);
 	std::vector<BtRes> res(nLanes);
 	std::vector<char> drained(nLanes, 0);
+	unsigned long long CNT[CN_N];
+	memset(CNT, 0, sizeof(CNT));
 	for (uint32_t g = 0; g < nLanes; g++) {
 		memset(&lanes[g], 0, sizeof(BtLane));
 		memset(&res[g], 0, sizeof(BtRes));
@@ -74,7 +86,6 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
 	}
 	uint32_t next = 0, live = nLanes;
-	uint64_t iters = 0;
 	while (live > 0) {
 		for (uint32_t g = 0; g < nLanes; g++) {
 			if (drained[g]) continue;
@@ -83,13 +94,18 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 			for (;;) {
 				if (L.state == ST_IDLE) {
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
-					bt_lane_start(L, P, B, next++);
+					bt_lane_start(L, H, cold, next++);
 				}
-				bt_lane_run(L, P, e->d, scr[g], B, res[g], req);
+				bt_lane_run(L, H, cold, scr[g], res[g], req, CNT);
 				if (L.state != ST_IDLE) break;
 			}
 			if (drained[g]) continue;
-			iters++;
+			BT_COUNT(CN_ITERS);
+			if (L.state == ST_CHASE_LFDONE) BT_COUNT(CN_CHASE);
+			else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
+			else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
+			else BT_COUNT(CN_LF1);
+			if ((req.op & 2u) && req.rowA / 448u == req.rowB / 448u) BT_COUNT(CN_SAMEPAIR);
 			const BtIndexDev& ix = e->d[L.mirror];
 			bt_rank4(ix, req.rowA, res[g].a, &res[g].LA);
 			if (req.op & 2u) { uint32_t dummy; bt_rank4(ix, req.rowB, res[g].b, &dummy); }
@@ -97,14 +113,9 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	}
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
-		memset(counts, 0, sizeof(*counts));
-		for (uint32_t g = 0; g < nLanes; g++) {
-			counts->lfex += lanes[g].cnt.lfex; counts->lf2 += lanes[g].cnt.lf2; counts->lf1 += lanes[g].cnt.lf1;
-			counts->chase += lanes[g].cnt.chase; counts->ftab += lanes[g].cnt.ftab; counts->offs += lanes[g].cnt.offs;
-			counts->rstarts += lanes[g].cnt.rstarts; counts->frames += lanes[g].cnt.frames;
-			counts->same_pair += lanes[g].cnt.samePair;
-		}
-		counts->lane_iters = iters;
+		counts->lfex = CNT[CN_LFEX]; counts->lf2 = CNT[CN_LF2]; counts->lf1 = CNT[CN_LF1]; counts->chase = CNT[CN_CHASE];
+		counts->ftab = CNT[CN_FTAB]; counts->offs = CNT[CN_OFFS]; counts->rstarts = CNT[CN_RSTARTS];
+		counts->frames = CNT[CN_FRAMES]; counts->lane_iters = CNT[CN_ITERS]; counts->same_pair = CNT[CN_SAMEPAIR];
 	}
 	return BT_OK;
 }
