@@ -35,6 +35,7 @@ struct bt_ctx {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
 	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
+	int occ = 2;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint8_t* elims = nullptr; uint64_t* pals = nullptr;
 	uint32_t* d_cursor = nullptr;      /* [0] nextRead, [1] mm_pool_used */
 	BtCold* d_cold = nullptr;
@@ -177,7 +178,10 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	HIPCHK(hipEventCreate(&c->ev1));
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, idx->device));
-	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", 2);
+	c->occ = (int)env_u32("BT_OCC", 2);               /* waves/SIMD the kernel variant is built for */
+	if (c->occ < 1) c->occ = 1;
+	if (c->occ > 4) c->occ = 4;
+	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", (uint32_t)c->occ);
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
@@ -242,7 +246,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	if (nBlocks > maxBlocks) nBlocks = maxBlocks;
 	HIPCHK(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
-	if (bt_launch_search(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
+	if (bt_launch_search(&A, nBlocks, c->occ, c->stream) != 0) return BT_ERR_DEVICE;
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
 	return BT_OK;

@@ -20,7 +20,7 @@ struct BtKernelArgs {
 };
 
 extern "C" {
-int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, void* stream);
+int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, void* stream);
 int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
                          uint8_t* L, void* stream);
 int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,

@@ -43,7 +43,8 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 	bt_rank4_words(ix, sideNum, charOff, w, occ, lf, L);
 }
 
-__global__ __launch_bounds__(BT_BLOCK) void bt_search_kernel(BtKernelArgs A)
+template <int OCC>
+__global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
 	__shared__ unsigned long long CNT[CN_N];
 	if (threadIdx.x < CN_N) CNT[threadIdx.x] = 0;
@@ -148,9 +149,17 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 }
 
 /* ---- launchers (called from bt_api.cpp, which is plain C++) ------------------------------- */
-extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, void* stream)
+/* occ = waves per SIMD the register allocator was told to fit (1..4): the same source compiled for
+ * different register budgets; which is fastest is a measured choice (bt_api.cpp, BT_OCC). */
+extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, void* stream)
 {
-	hipLaunchKernelGGL(bt_search_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
+	hipStream_t st = (hipStream_t)stream;
+	switch (occ) {
+	case 1:  hipLaunchKernelGGL(bt_search_kernel<1>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
+	case 2:  hipLaunchKernelGGL(bt_search_kernel<2>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
+	case 3:  hipLaunchKernelGGL(bt_search_kernel<3>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
+	default: hipLaunchKernelGGL(bt_search_kernel<4>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
+	}
 	return (int)hipGetLastError();
 }
 extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
