@@ -36,7 +36,7 @@ struct bt_ctx {
 	bool timed = false;
 	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
 	int occ = 2;
-	uint32_t *frames = nullptr, *pairs = nullptr; uint8_t* elims = nullptr; uint64_t* pals = nullptr;
+	uint32_t *frames = nullptr, *pairs = nullptr; uint16_t* meta = nullptr; uint64_t* pals = nullptr;
 	uint32_t* d_cursor = nullptr;      /* [0] nextRead, [1] mm_pool_used */
 	BtCold* d_cold = nullptr;
 	unsigned long long* d_counts = nullptr;
@@ -135,9 +135,9 @@ static void ctx_free_scratch(bt_ctx* c)
 {
 	if (c->frames) (void)hipFree(c->frames);
 	if (c->pairs) (void)hipFree(c->pairs);
-	if (c->elims) (void)hipFree(c->elims);
+	if (c->meta) (void)hipFree(c->meta);
 	if (c->pals) (void)hipFree(c->pals);
-	c->frames = c->pairs = nullptr; c->elims = nullptr; c->pals = nullptr;
+	c->frames = c->pairs = nullptr; c->meta = nullptr; c->pals = nullptr;
 }
 
 /* (re)size the per-lane arenas for reads up to maxLen */
@@ -151,11 +151,11 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen)
 	 * -n: frames are bounded by -e / min penalty (10) unless the read has Phred<5 bases. */
 	uint32_t frames = seeded ? 12u : (uint32_t)c->pol.mms + 2u;
 	c->frCap = env_u32("BT_FRAME_CAP", seeded ? 64u : 8u);
-	c->entCap = env_u32("BT_ENTRY_CAP", frames * c->maxLen);
+	c->entCap = (env_u32("BT_ENTRY_CAP", frames * c->maxLen) + 7u) & ~7u;      /* lane regions stay 16-byte aligned */
 	c->palCap = env_u32("BT_PARTIAL_CAP", seeded ? (c->pol.mms >= 3 ? 8192u : 1024u) : 1u);
 	HIPCHK(hipMalloc((void**)&c->frames, (size_t)c->nLanes * c->frCap * BT_FR_WORDS * 4u));
 	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nLanes * c->entCap * 32u));
-	HIPCHK(hipMalloc((void**)&c->elims, (size_t)c->nLanes * c->entCap));
+	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nLanes * c->entCap * 2u));
 	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nLanes * c->palCap * 8u));
 	return BT_OK;
 }
@@ -237,7 +237,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	}
 	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
 	A.cold = c->d_cold;
-	A.frames = c->frames; A.pairs = c->pairs; A.elims = c->elims; A.pals = c->pals;
+	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
 	A.nextRead = c->d_cursor;
 	A.counts = counts_dev ? counts_dev : c->d_counts;

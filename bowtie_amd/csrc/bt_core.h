@@ -19,8 +19,8 @@
  *   read window  : 16 bases + 16 qualities of the read, cached in registers (the query is
  *                  consumed one position per LF step, so one 2x16-byte fetch serves 16 steps)
  *   frame stack  : one record per backtrack level, HBM scratch, lane-interleaved  (FR_*)
- *   range stack  : per visited query position, the 4x(top,bot) ranges and the eliminated-
- *                  alternatives mask; compact (a child frame starts where its parent stopped)
+  *   range stack  : per visited query position, the 4x(top,bot) ranges plus (eliminated-
+ *                  alternatives mask, quality); compact (a child frame starts where its parent stopped)
  *   seedlings    : packed partial alignments of the -n seed phases (ebwt_search_util.h:37-88)
  *
  * Control flow is arranged so that the common transitions (query step -> LF -> query step, and
@@ -85,7 +85,7 @@ enum {
 struct BtScratch {
 	uint32_t* frames;   uint32_t frStride;   /* word w of frame f at frames[(f*16+w)*frStride]   */
 	uint32_t* pairs;                         /* [entry][8]: tops ACGT, bots ACGT                 */
-	uint8_t*  elims;                         /* [entry]                                           */
+	uint16_t* meta;                          /* [entry] eliminated-chars mask | Phred<<8          */
 	uint64_t* pals;                          /* [palCap] seedlings                                */
 	uint32_t  frCap, entCap, palCap;
 };
@@ -159,7 +159,7 @@ struct BtLane {
 	/* read */
 	uint32_t rd;
 	uint64_t roff;                   /* rd * stride */
-	uint32_t plen : 11, status : 8, step : 5, kind : 2, nmuts : 2, palIdxBefore : 1;
+	uint32_t plen : 11, status : 8, step : 5, kind : 2, nmuts : 2, palIdxBefore : 1, hasN : 1;
 	uint32_t nhits;
 	uint32_t stored : 16, npals : 16;
 	uint32_t palIdx : 16, iham : 8, mutnew0 : 2, mutnew1 : 2, mutnew2 : 2;
@@ -323,14 +323,31 @@ BT_HD void bt_lane_start(BtLane& L, const BtHot& H, const BtCold& C, uint32_t rd
 	L.state = ST_PHASE_NEXT;
 	const uint32_t plen = L.plen;
 	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
-	if (P.seeded) {
-		bool skip = plen < 4u;
-		if (!skip) {
-			uint32_t ns = 0;
-			BT_NOUNROLL
-			for (uint32_t i = 0; i < qs; i++) if (H.seq[L.roff + i] == 4u && ++ns > P.seedMms) { skip = true; break; }
+	/* one pass of 16-byte loads over the read: does it contain an N at all (almost never), and
+	 * how many in the seed (search_seeded_phase1.c:24-44) */
+	uint32_t nsAll = 0, nsSeed = 0;
+	BT_NOUNROLL
+	for (uint32_t base = 0; base < plen; base += 16u) {
+		const BtU4 v = *(const BtU4*)(H.seq + L.roff + base);
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		BT_UNROLL
+		for (int k = 0; k < 4; k++) {
+			const uint32_t t = w[k] ^ 0x04040404u;
+			uint32_t z = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;      /* bytes equal to 4 */
+			const uint32_t p0 = base + 4u * (uint32_t)k;
+			uint32_t inRead = 0, inSeed = 0;
+			BT_UNROLL
+			for (uint32_t b = 0; b < 4u; b++) {
+				if (p0 + b < plen) inRead |= 0x80u << (8u * b);
+				if (p0 + b < qs) inSeed |= 0x80u << (8u * b);
+			}
+			nsAll += (uint32_t)__builtin_popcount(z & inRead);
+			nsSeed += (uint32_t)__builtin_popcount(z & inSeed);
 		}
-		if (skip) { L.status = L.status | BT_STF_SKIPPED; L.step = (uint32_t)P.nsteps - 1u; }
+	}
+	L.hasN = nsAll > 0 ? 1u : 0u;
+	if (P.seeded) {
+		if (plen < 4u || nsSeed > P.seedMms) { L.status = L.status | BT_STF_SKIPPED; L.step = (uint32_t)P.nsteps - 1u; }
 	} else if (plen < P.minLen) {
 		L.status = L.status | BT_STF_TOOSHORT; L.step = (uint32_t)P.nsteps - 1u;
 	}
@@ -403,16 +420,40 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 	do { L.ra_sd = (SD); L.ra_top = (TOP); L.ra_bot = (BOT); L.ra_cost = (COST); L.ra_cont = (CONT); \
 	     L.state = ST_RA_BEGIN; } while (0)
 
-/* Scan the frame for the deepest position that still has a backtrack target of the current
- * eligible quality (the `for(; i >= depth; i--)` walk of :767-812). */
-BT_HD bool bt_find_cand(BtLane& L, const BtScratch& S, const BtHot& H, uint32_t from)
+/* The (mask, quality) records of a frame are scanned 8 at a time (one 16-byte load per 8 query
+ * positions) so that a scan costs a handful of independent loads instead of one dependent load per
+ * position. */
+struct BtMeta8 { uint32_t w[4]; };
+BT_HD BtMeta8 bt_meta_load8(const BtScratch& S, uint32_t chunk)
 {
+	const uint32_t* p = (const uint32_t*)(S.meta + (uint64_t)chunk * 8u);
+	BtMeta8 m; m.w[0] = p[0]; m.w[1] = p[1]; m.w[2] = p[2]; m.w[3] = p[3];
+	return m;
+}
+BT_HD uint32_t bt_meta_get(const BtMeta8& m, uint32_t k)       /* k in 0..7 */
+{
+	const uint32_t w = bt_sel4(k >> 1, m.w[0], m.w[1], m.w[2], m.w[3]);
+	return (k & 1u) ? (w >> 16) : (w & 0xffffu);
+}
+
+/* Deepest position in [depth, from] that still has a backtrack target of the current eligible
+ * quality (the `for(; i >= depth; i--)` walk of ebwt_search_backtrack.h:767-812). */
+BT_HD bool bt_find_cand(BtLane& L, const BtScratch& S, uint32_t from)
+{
+	const uint32_t e_lo = L.ebase, e_hi = L.ebase + (from - L.depth);
 	BT_NOUNROLL
-	for (uint32_t i = from;; i--) {
-		const uint32_t qi = bt_qual(L, H, L.qlen - i - 1u);
-		const uint32_t el = S.elims[L.ebase + (i - L.depth)];
-		if ((qi == L.lowAltQual || !L.considerQuals) && el != 15u) { L.cand = i; L.candValid = 1; return true; }
-		if (i == L.depth) break;
+	for (uint32_t chunk = e_hi >> 3;; chunk--) {
+		const BtMeta8 m = bt_meta_load8(S, chunk);
+		BT_UNROLL
+		for (int k = 7; k >= 0; k--) {
+			const uint32_t e = chunk * 8u + (uint32_t)k;
+			const uint32_t v = bt_meta_get(m, (uint32_t)k);
+			if (e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u) {
+				L.cand = L.depth + (e - L.ebase); L.candValid = 1;
+				return true;
+			}
+		}
+		if (chunk * 8u <= e_lo) break;
 	}
 	return false;
 }
@@ -456,30 +497,39 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
 		case ST_SEARCH_BEGIN: {
 			L.bailed = 0; L.sd = 0;
-			uint32_t nsInSeed = 0; bool ok = true;
-			BT_NOUNROLL
-			for (uint32_t i = 0; i < L.r3 && ok; i++) {
-				if (bt_qry(L, H, L.qlen - i - 1u) == 4u) {
-					nsInSeed++;
-					if (nsInSeed == 1) { if (i < L.unrev) ok = false; }
-					else if (nsInSeed == 2) { if (i < L.r1) ok = false; }
-					else if (nsInSeed == 3) { if (i < L.r2) ok = false; }
-					else ok = false;
-				}
-			}
-			if (!ok) { L.ret = 0; L.state = ST_SEARCH_END; break; }
 			uint32_t nsInFtab = 0;
 			const uint32_t ftabChars = IXSEL(ftabChars);
-			BT_NOUNROLL
-			for (uint32_t i = 0; i < ftabChars && i < L.qlen; i++)
-				if (bt_qry(L, H, L.qlen - i - 1u) == 4u) nsInFtab++;
+			if (L.hasN) {
+				/* tallyNs (:1308-1341); reads without any N (nearly all) skip both walks */
+				uint32_t nsInSeed = 0; bool ok = true;
+				BT_NOUNROLL
+				for (uint32_t i = 0; i < L.r3 && ok; i++) {
+					if (bt_qry(L, H, L.qlen - i - 1u) == 4u) {
+						nsInSeed++;
+						if (nsInSeed == 1) { if (i < L.unrev) ok = false; }
+						else if (nsInSeed == 2) { if (i < L.r1) ok = false; }
+						else if (nsInSeed == 3) { if (i < L.r2) ok = false; }
+						else ok = false;
+					}
+				}
+				if (!ok) { L.ret = 0; L.state = ST_SEARCH_END; break; }
+				BT_NOUNROLL
+				for (uint32_t i = 0; i < ftabChars && i < L.qlen; i++)
+					if (bt_qry(L, H, L.qlen - i - 1u) == 4u) nsInFtab++;
+			}
 			L.nsFtab0 = nsInFtab > 0 ? 1u : 0u;
 			const uint32_t m = L.unrev < L.qlen ? L.unrev : L.qlen;
 			L.fu = L.unrev; L.f1 = L.r1; L.f2 = L.r2; L.f3 = L.r3; L.ham = L.iham; L.ebase = 0;
 			if (nsInFtab == 0 && m >= ftabChars) {
-				uint32_t ftabOff = bt_qry(L, H, L.qlen - ftabChars);
+				/* calcFtabOff (:1348-1362) through the register window: the step loop continues from
+				 * the same 16-byte window */
+				uint32_t ftabOff = 0;
 				BT_NOUNROLL
-				for (uint32_t i = ftabChars - 1u; i > 0; i--) { ftabOff <<= 2; ftabOff |= bt_qry(L, H, L.qlen - i); }
+				for (uint32_t i = 0; i < ftabChars; i++) {
+					uint32_t c, q;
+					bt_qq_cached(L, H, L.qlen - 1u - i, &c, &q);
+					ftabOff |= c << (2u * i);
+				}
 				const uint32_t* ftab = IXSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = IXSEL(len);
 				uint32_t top = ftab[ftabOff], bot = ftab[ftabOff + 1u];
 				if (top > len) top = eftab[(top ^ BT_OFF_MASK) * 2u + 1u];
@@ -517,16 +567,19 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 		case ST_BT_LOOP: {
 			uint32_t i, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
-				bool found = L.candValid || bt_find_cand(L, S, H, L.d);
+				bool found = L.candValid || bt_find_cand(L, S, L.d);
 				if (found) {
 					found = false;
 					i = L.cand;
 					const uint32_t e = L.ebase + (i - L.depth);
-					const uint32_t el = S.elims[e];
-					const uint32_t qi = bt_qual(L, H, L.qlen - i - 1u);
+					const uint32_t mv = S.meta[e];
+					const uint32_t el = mv & 15u, qi = mv >> 8;
 					uint32_t sp[4], tp[4];
-					BT_UNROLL
-					for (j = 0; j < 4u; j++) { tp[j] = PT(e, j); sp[j] = PB(e, j) - tp[j]; }
+					{
+						const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
+						tp[0] = t4.x; tp[1] = t4.y; tp[2] = t4.z; tp[3] = t4.w;
+						sp[0] = b4.x - t4.x; sp[1] = b4.y - t4.y; sp[2] = b4.z - t4.z; sp[3] = b4.w - t4.w;
+					}
 					uint32_t posSz = 0;
 					BT_UNROLL
 					for (j = 0; j < 4u; j++) if ((el & (1u << j)) == 0) posSz += sp[j];
@@ -565,12 +618,13 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			const uint32_t ftabChars = IXSEL(ftabChars);
 			if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < ftabChars && ftabChars <= L.d5) {
 				/* re-jump through the ftab with the substituted character (:908-952) */
-				uint32_t ftabOff = bt_qry(L, H, L.qlen - ftabChars);
+				uint32_t ftabOff = 0;
 				BT_NOUNROLL
-				for (uint32_t jj = ftabChars - 1u; jj > 0; jj--) {
-					ftabOff <<= 2;
-					if (L.qlen - jj == icur) ftabOff |= btcint;
-					else ftabOff |= bt_qry(L, H, L.qlen - jj);
+				for (uint32_t jj = 0; jj < ftabChars; jj++) {
+					uint32_t c, q;
+					bt_qq_cached(L, H, L.qlen - 1u - jj, &c, &q);
+					if (L.qlen - 1u - jj == icur) c = btcint;
+					ftabOff |= c << (2u * jj);
 				}
 				const uint32_t* ftab = IXSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = IXSEL(len);
 				ntop = ftab[ftabOff]; nbot = ftab[ftabOff + 1u];
@@ -610,9 +664,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			{
 				const uint32_t e = L.ebase + (L.pi - L.depth);
-				const uint32_t el = S.elims[e] | (1u << L.pj);
-				S.elims[e] = (uint8_t)el;
-				if (el == 15u) L.candValid = 0;      /* that position is exhausted: re-scan next time */
+				const uint32_t mv = S.meta[e] | (1u << L.pj);
+				S.meta[e] = (uint16_t)mv;
+				if ((mv & 15u) == 15u) L.candValid = 0;      /* that position is exhausted: re-scan next time */
 			}
 			L.eligibleSz -= (L.pbtbot - L.pbttop);
 			L.eligibleNum = L.eligibleNum - 1u;
@@ -620,35 +674,55 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.altNum = L.altNum - 1u;
 			if (L.altNum == 0) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
 			if (L.eligibleNum == 0 && L.considerQuals) {
-				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058) */
+				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058): the
+				 * reference walks k = d..max(depth,unrev) once, restarting its tallies whenever it
+				 * meets a strictly lower quality.  Same result in two batched passes: (1) the lowest
+				 * quality among positions that still have a target, (2) the tallies over the positions
+				 * of exactly that quality, deepest first. */
 				L.lowAltQual = 0xff; L.candValid = 0;
-				BT_NOUNROLL
-				for (uint32_t k = L.d; k >= L.depth && k <= L.qlen; k--) {
-					const uint32_t kq = bt_qual(L, H, L.qlen - k - 1u);
-					if (k < L.fu) break;
-					const bool kAlt = (L.ham + bt_mm_penalty(L.maq, kq) <= L.qualThresh);
-					bool kOver = false;
-					if (kAlt) {
-						if (kq < L.lowAltQual) kOver = true;
-						if (kq <= L.lowAltQual) {
-							const uint32_t e = L.ebase + (k - L.depth);
-							const uint32_t el = S.elims[e];
-							BT_UNROLL
-							for (uint32_t l = 0; l < 4u; l++) {
-								if ((el & (1u << l)) == 0) {
-									const uint32_t t = PT(e, l), spread = PB(e, l) - t;
-									if (kOver) {
-										L.lowAltQual = kq; kOver = false; L.eligibleNum = 0; L.eligibleSz = 0;
-										L.eli = k; L.eltop = t; L.elbot = t + spread;
-										L.elham = bt_mm_penalty(L.maq, kq); L.elcint = l; L.elignore = 0;
-										L.cand = k; L.candValid = 1;     /* deepest position of the new quality */
+				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
+				if (L.d >= kmin) {
+					const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
+					uint32_t qmin = 0xffu;
+					BT_NOUNROLL
+					for (uint32_t chunk = e_hi >> 3;; chunk--) {
+						const BtMeta8 m = bt_meta_load8(S, chunk);
+						BT_UNROLL
+						for (int k = 7; k >= 0; k--) {
+							const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
+							if (e <= e_hi && e >= e_lo && (v & 15u) != 15u && (v >> 8) < qmin) qmin = v >> 8;
+						}
+						if (chunk * 8u <= e_lo) break;
+					}
+					if (qmin != 0xffu && L.ham + bt_mm_penalty(L.maq, qmin) <= L.qualThresh) {
+						bool first = true;
+						BT_NOUNROLL
+						for (uint32_t chunk = e_hi >> 3;; chunk--) {
+							const BtMeta8 m = bt_meta_load8(S, chunk);
+							BT_NOUNROLL
+							for (int k = 7; k >= 0; k--) {
+								const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
+								if (e > e_hi || e < e_lo || (v & 15u) == 15u || (v >> 8) != qmin) continue;
+								const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
+								const uint32_t tp[4] = {t4.x, t4.y, t4.z, t4.w};
+								const uint32_t sp[4] = {b4.x - t4.x, b4.y - t4.y, b4.z - t4.z, b4.w - t4.w};
+								BT_UNROLL
+								for (uint32_t l = 0; l < 4u; l++) {
+									if ((v & (1u << l)) == 0) {
+										if (first) {
+											first = false;
+											L.lowAltQual = qmin; L.eligibleNum = 0; L.eligibleSz = 0;
+											L.eli = L.depth + (e - L.ebase); L.eltop = tp[l]; L.elbot = tp[l] + sp[l];
+											L.elham = bt_mm_penalty(L.maq, qmin); L.elcint = l; L.elignore = 0;
+											L.cand = L.eli; L.candValid = 1;
+										}
+										L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += sp[l];
 									}
-									L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += spread;
 								}
 							}
+							if (chunk * 8u <= e_lo) break;
 						}
 					}
-					if (k == 0) break;
 				}
 			}
 			L.state = ST_BT_LOOP;
@@ -838,7 +912,9 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 				const uint32_t bc = c == 0 ? res.b[0] : c == 1 ? res.b[1] : c == 2 ? res.b[2] : res.b[3];
 				if (L.lfk == LFK_EX2) {
 					BT_UNROLL
-					for (int k = 0; k < 4; k++) { ta[k] = res.a[k]; tb[k] = res.b[k]; PT(e, k) = ta[k]; PB(e, k) = tb[k]; }
+					for (int k = 0; k < 4; k++) { ta[k] = res.a[k]; tb[k] = res.b[k]; }
+					{ BtU4 v; v.x = ta[0]; v.y = ta[1]; v.z = ta[2]; v.w = ta[3]; *(BtU4*)&PT(e, 0) = v; }
+					{ BtU4 v; v.x = tb[0]; v.y = tb[1]; v.z = tb[2]; v.w = tb[3]; *(BtU4*)&PB(e, 0) = v; }
 					if (c < 4u) { L.top = ac; L.bot = bc; }
 				} else if (L.lfk == LFK_C2) {
 					L.top = ac; L.bot = bc;
@@ -874,7 +950,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 				}
 				if (L.fl_elig && el != 15u) { L.cand = d; L.candValid = 1; }     /* deepest eligible target so far */
 			}
-			S.elims[e] = (uint8_t)el;
+			S.meta[e] = (uint16_t)(el | (q << 8));
 			bool btDespite = false, reportedPartial = false;
 			if (cur == 0 && L.top < L.bot && L.sd < L.reportPartials && L.reportPartials > 0) {
 				if (L.altNum > 0) btDespite = true;

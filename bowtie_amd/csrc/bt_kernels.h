@@ -12,7 +12,7 @@ struct BtKernelArgs {
 	/* per-lane scratch arenas (see BtScratch) */
 	uint32_t*  frames;           /* [frCap*16][nLanes]                                           */
 	uint32_t*  pairs;            /* [nLanes][entCap][8]                                          */
-	uint8_t*   elims;            /* [nLanes][entCap]                                             */
+	uint16_t*  meta;             /* [nLanes][entCap] mask | Phred<<8                             */
 	uint64_t*  pals;             /* [nLanes][palCap]                                             */
 	uint32_t   nLanes, frCap, entCap, palCap;
 	uint32_t*  nextRead;         /* global read cursor                                           */

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	S.frStride = A.nLanes;
 	S.frames = A.frames + g;
 	S.pairs = A.pairs + (uint64_t)g * A.entCap * 8u;
-	S.elims = A.elims + (uint64_t)g * A.entCap;
+	S.meta = A.meta + (uint64_t)g * A.entCap;
 	S.pals = A.pals + (uint64_t)g * A.palCap;
 	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
 

@@ -36,6 +36,8 @@
 #define BT_NOUNROLL
 #endif
 
+struct alignas(16) BtU4 { uint32_t x, y, z, w; };
+
 #define BT_OFF_MASK 0xffffffffu
 #define BT_SIDE_SYMS 224u
 

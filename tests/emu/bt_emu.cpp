@@ -67,8 +67,10 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
 	}
 	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
-	std::vector<uint32_t> frames((size_t)nLanes * frCap * BT_FR_WORDS), pairs((size_t)nLanes * entCap * 8);
-	std::vector<uint8_t> elims((size_t)nLanes * entCap);
+	entCap = (entCap + 7u) & ~7u;
+	std::vector<uint32_t> frames((size_t)nLanes * frCap * BT_FR_WORDS);
+	std::vector<BtU4> pairs4((size_t)nLanes * entCap * 2);
+	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
 	std::vector<BtLane> lanes(nLanes);
 	std::vector<BtScratch> scr(nLanes);
@@ -81,7 +83,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		memset(&res[g], 0, sizeof(BtRes));
 		lanes[g].state = ST_IDLE;
 		scr[g].frames = frames.data() + g; scr[g].frStride = nLanes;
-		scr[g].pairs = pairs.data() + (size_t)g * entCap * 8; scr[g].elims = elims.data() + (size_t)g * entCap;
+		scr[g].pairs = (uint32_t*)(pairs4.data() + (size_t)g * entCap * 2); scr[g].meta = meta.data() + (size_t)g * entCap;
 		scr[g].pals = pals.data() + (size_t)g * palCap;
 		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
 	}

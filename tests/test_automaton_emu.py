@@ -89,3 +89,14 @@ def test_emu_overflow_is_flagged(emu):
     batch = T.read_set("multi", "syn100")
     res = emu["multi"].align(A.make_policy(**T.MODES["n2"]), batch, ent_cap=64)
     assert any(st & A.BT_ST_OVERFLOW for _, _, st in res)
+
+
+def test_emu_max_length_reads(emu):
+    """1024-bp reads: exercises the widths of the bit-packed lane state."""
+    text = T.joined_text("e_coli")
+    e = E.EmuAligner(T.G + "/e_coli")
+    batch = synth_reads(text, 24, 1024, mm_dist=(0, 1, 2), seed=31, n_frac=0.0)
+    for mode in ("v2", "n2"):
+        kw = T.MODES[mode]
+        got = e.align(A.make_policy(**kw), batch, ent_cap=12 * 1024)
+        T.compare_results(got, T.oracle_results("e_coli", batch, kw), mode)
