@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,6 +170,10 @@ def main():
                        rb["seed"].data_ptr())
     hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), mm_pool.data_ptr(), mm_cap, 0)
     lib = AL.lib()
+    iters_t = None
+    if args.iters_hist:
+        iters_t = torch.zeros(n, dtype=torch.int32, device=dev)
+        lib.bt_ctx_set_iters_buffer(al._h, iters_t.data_ptr())
 
     def step():
         rc = lib.bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None)
@@ -197,6 +202,12 @@ def main():
     lib.bt_ctx_counts(al._h, C.byref(cnt), 0)
     c = cnt.as_dict()
 
+    if iters_t is not None and rank == 0:
+        it = iters_t.to(torch.float64)
+        qs = torch.quantile(it[:min(n, 4_000_000)], torch.tensor([0.5, 0.9, 0.99, 0.999, 0.9999, 1.0], dtype=torch.float64, device=dev))
+        log("[bench] LF rounds per read: mean %.1f  p50/p90/p99/p99.9/p99.99/max = %s  (reads > 20k rounds: %d, their share of all rounds %.1f%%)" %
+            (it.mean().item(), [int(x) for x in qs.tolist()], int((it > 20000).sum().item()),
+             100.0 * it[it > 20000].sum().item() / max(1.0, it.sum().item())))
     aligned = int((n_hits > 0).sum().item())
     bad = int(((status & (A.BT_ST_OVERFLOW | A.BT_ST_MMPOOL)) != 0).sum().item())
     tot = torch.tensor([wall, float(aligned), float(n), float(bad)], dtype=torch.float64, device=dev)

@@ -43,6 +43,7 @@ struct bt_ctx {
 	/* staging for the host-pointer entry point */
 	void* stage = nullptr; size_t stage_bytes = 0;
 	uint32_t last_mm_used = 0;
+	uint32_t* iters_dev = nullptr;     /* optional per-read iteration counts (diagnostics) */
 };
 
 template <class T> static int upload(bt_index* ix, const std::vector<T>& v, const T** out, size_t pad_elems = 0)
@@ -228,6 +229,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	cold.B.n_hits = out->n_hits; cold.B.status = out->status;
 	cold.B.mm_pool = out->mm_pool; cold.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
 	cold.B.mm_pool_used = c->d_cursor + 1;
+	cold.B.iters = c->iters_dev;
 	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
 	for (int m = 0; m < 2; m++) {
 		const BtIndexDev& d = c->idx->dev[m];
@@ -275,6 +277,8 @@ extern "C" float bt_ctx_last_kernel_ms(bt_ctx* c)
 	if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
 	return ms;
 }
+
+extern "C" void bt_ctx_set_iters_buffer(bt_ctx* c, uint32_t* dev_ptr) { if (c) c->iters_dev = dev_ptr; }
 
 extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
 

@@ -18,7 +18,7 @@
  *   lane state   : BtLane -- bit-packed so the whole automaton lives in ~50 VGPRs
  *   read window  : 16 bases + 16 qualities of the read, cached in registers (the query is
  *                  consumed one position per LF step, so one 2x16-byte fetch serves 16 steps)
- *   frame stack  : one record per backtrack level, HBM scratch, lane-interleaved  (FR_*)
+ *   frame stack  : one 64-byte record per backtrack level, HBM scratch              (FR_*)
   *   range stack  : per visited query position, the 4x(top,bot) ranges plus (eliminated-
  *                  alternatives mask, quality); compact (a child frame starts where its parent stopped)
  *   seedlings    : packed partial alignments of the -n seed phases (ebwt_search_util.h:37-88)
@@ -83,7 +83,7 @@ enum {
 };
 
 struct BtScratch {
-	uint32_t* frames;   uint32_t frStride;   /* word w of frame f at frames[(f*16+w)*frStride]   */
+	uint32_t* frames;                        /* [frame][16]: one 64-byte record per backtrack level */
 	uint32_t* pairs;                         /* [entry][8]: tops ACGT, bots ACGT                 */
 	uint16_t* meta;                          /* [entry] eliminated-chars mask | Phred<<8          */
 	uint64_t* pals;                          /* [palCap] seedlings                                */
@@ -103,6 +103,7 @@ struct BtBatchDev {
 	BtHitRec* hits; uint32_t hit_cap;
 	uint32_t* n_hits; uint8_t* status;
 	uint16_t* mm_pool; uint32_t mm_pool_cap; uint32_t* mm_pool_used;
+	uint32_t* iters;                        /* optional [n_reads]: lock-step iterations the read took   */
 };
 
 /* Arguments split by temperature.  BtHot is passed by value (kernarg -> SGPRs) and holds only what
@@ -191,6 +192,7 @@ struct BtLane {
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
 	uint32_t ra_top, ra_bot, ra_r, ra_i;
 	uint32_t crow, cjumps;
+	uint32_t iters;
 	/* register window over the read: 16 bases + 16 quals around the current position */
 	uint32_t cchunk;                 /* index of the cached 16-byte chunk, 0xff = none */
 	uint32_t cs0, cs1, cs2, cs3, cq0, cq1, cq2, cq3;
@@ -263,7 +265,7 @@ BT_HD void bt_qq_cached(BtLane& L, const BtHot& H, uint32_t i, uint32_t* c_out, 
 	*q_out = v >= 33u ? v - 33u : 0u;
 }
 
-#define FRW(f, w) S.frames[((f) * BT_FR_WORDS + (w)) * S.frStride]
+#define FRW(f, w) S.frames[(f) * BT_FR_WORDS + (w)]
 #define PT(e, c) S.pairs[(e) * 8u + (c)]
 #define PB(e, c) S.pairs[(e) * 8u + 4u + (c)]
 #define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
@@ -320,6 +322,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtHot& H, const BtCold& C, uint32_t rd
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
 	L.cchunk = 0xffu;
+	L.iters = 0;
 	L.state = ST_PHASE_NEXT;
 	const uint32_t plen = L.plen;
 	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
@@ -358,6 +361,7 @@ BT_HD void bt_lane_finish(BtLane& L, const BtBatchDev& B)
 {
 	B.n_hits[L.rd] = L.nhits;
 	B.status[L.rd] = (uint8_t)L.status;
+	if (B.iters) B.iters[L.rd] = L.iters;
 	L.state = ST_IDLE;
 }
 
@@ -464,10 +468,209 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 	const BtProgram& P = C.P;
 	const BtIndexDev* IX = C.ix;
 	const BtBatchDev& B = C.B;
+	/* The states are visited in an order that lets the usual chains finish in one sweep
+	 * (child failed: FRAME_RETURN -> CHILD_RET -> BT_LOOP -> FRAME_ENTER; phase change: FRAME_RETURN ->
+	 * SEARCH_END -> PHASE_NEXT -> SEARCH_BEGIN -> FRAME_ENTER; report: RA_BEGIN -> ROW_BEGIN).  Within a
+	 * block `break` leaves the block. */
 	while (BT_IS_SLOW(L.state)) {
-		switch (L.state) {
+		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */
+		if (L.state == ST_FELL_OFF) do {
+			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL);
+			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
+			break;
+		} while (0);
+
+		if (L.state == ST_RESOLVE) do {
+			const uint32_t zOff = IXSEL(zOff);
+			uint32_t off;
+			if (L.crow == zOff) off = L.cjumps;
+			else { const uint32_t* offs = IXSEL(offs); off = offs[L.crow >> IXSEL(offRate)] + L.cjumps; }
+			BT_COUNT(CN_OFFS);
+			/* joinedToTextOff (ebwt.h:2569-2629) */
+			const uint32_t* rstarts = IXSEL(rstarts);
+			const uint32_t nFrag = IXSEL(nFrag), len = IXSEL(len), ixfw = IXSEL(fw);
+			uint32_t lo = 0, hi = nFrag, tidx = 0, toff = 0, probes = 0;
+			bool hit = false;
+			BT_NOUNROLL
+			for (;;) {
+				const uint32_t elt = lo + ((hi - lo) >> 1);
+				const uint32_t lower = rstarts[elt * 3u];
+				const uint32_t upper = (elt == nFrag - 1u) ? len : rstarts[(elt + 1u) * 3u];
+				probes++;
+				if (lower <= off) {
+					if (upper > off) {
+						if (off + L.qlen <= upper) {
+							uint32_t fragoff = off - lower;
+							if (!ixfw) { fragoff = (upper - lower) - fragoff - 1u; fragoff -= (L.qlen - 1u); }
+							tidx = rstarts[elt * 3u + 1u];
+							toff = fragoff + rstarts[elt * 3u + 2u];
+							hit = true;
+						}
+						break;
+					}
+					lo = elt;
+				} else hi = elt;
+			}
+			BT_COUNT_N(CN_RSTARTS, probes);
+			if (hit && bt_report_hit(L, P, ixfw, S, B, tidx, toff)) { L.ret = 1; L.state = ST_RA_END; break; }
+			L.ra_i++;
+			L.state = ST_ROW_BEGIN;
+			break;
+		} while (0);
+
+		if (L.state == ST_RA_END) do {
+			switch (L.ra_cont) {
+			case RC_STEP:
+				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
+				L.top = L.bot;                                   /* keep looking (:730-735) */
+				if (L.altNum > 0) L.state = ST_BT_LOOP;
+				else { L.ret = 0; L.state = ST_FRAME_RETURN; }
+				break;
+			case RC_CHILD: L.state = ST_CHILD_RET; break;
+			case RC_FELL:  L.state = ST_FRAME_RETURN; break;
+			default:       L.state = ST_SEARCH_END; break;
+			}
+			break;
+		} while (0);
+
+		/* ---- return from a frame -------------------------------------------------------- */
+		if (L.state == ST_FRAME_RETURN) do {
+			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
+			const uint32_t f = L.sd - 1u;
+			L.sd = f;
+			const BtU4* fr = (const BtU4*)&FRW(f, 0);
+			const BtU4 q0 = fr[0], q1 = fr[1], q2 = fr[2];
+			const uint32_t eb = FRW(f, FR_EBASE);
+			uint32_t v;
+			v = q0.x; L.depth = v & 0x7ffu; L.d = (v >> 11) & 0x7ffu;
+			v = q0.y; L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu; L.elham = (v >> 24) & 0xffu;
+			v = q0.z; L.fu = v & 0x7ffu; L.f1 = (v >> 11) & 0x7ffu; L.elcint = (v >> 22) & 3u;
+			L.elignore = (v >> 24) & 1u; L.candValid = (v >> 25) & 1u;
+			v = q0.w; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
+			v = q1.x; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
+			L.eligibleSz = q1.y; L.eltop = q1.z; L.elbot = q1.w;
+			v = q2.x; L.eli = v & 0x7ffu; L.cand = (v >> 11) & 0x7ffu;
+			v = q2.y; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u;
+			L.pbttop = q2.z; L.pbtbot = q2.w;
+			L.ebase = eb;
+			L.cchunk = 0xffu;
+			L.state = ST_CHILD_RET;
+			break;
+		} while (0);
+
+		/* ---- a child frame (or a leaf report) came back (:972-1064) ---------------------- */
+		if (L.state == ST_CHILD_RET) do {
+			if (L.ret) { L.state = ST_FRAME_RETURN; break; }
+			if (L.bailed || (L.halfAndHalf && P.steps[L.step].maxBts > 0 && L.numBts >= P.steps[L.step].maxBts)) {
+				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
+			}
+			{
+				const uint32_t e = L.ebase + (L.pi - L.depth);
+				const uint32_t mv = S.meta[e] | (1u << L.pj);
+				S.meta[e] = (uint16_t)mv;
+				if ((mv & 15u) == 15u) L.candValid = 0;      /* that position is exhausted: re-scan next time */
+			}
+			L.eligibleSz -= (L.pbtbot - L.pbttop);
+			L.eligibleNum = L.eligibleNum - 1u;
+			L.elignore = 1;
+			L.altNum = L.altNum - 1u;
+			if (L.altNum == 0) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
+			if (L.eligibleNum == 0 && L.considerQuals) {
+				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058): the
+				 * reference walks k = d..max(depth,unrev) once, restarting its tallies whenever it
+				 * meets a strictly lower quality.  Same result in two batched passes: (1) the lowest
+				 * quality among positions that still have a target, (2) the tallies over the positions
+				 * of exactly that quality, deepest first. */
+				L.lowAltQual = 0xff; L.candValid = 0;
+				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
+				if (L.d >= kmin) {
+					const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
+					uint32_t qmin = 0xffu;
+					BT_NOUNROLL
+					for (uint32_t chunk = e_hi >> 3;; chunk--) {
+						const BtMeta8 m = bt_meta_load8(S, chunk);
+						BT_UNROLL
+						for (int k = 7; k >= 0; k--) {
+							const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
+							if (e <= e_hi && e >= e_lo && (v & 15u) != 15u && (v >> 8) < qmin) qmin = v >> 8;
+						}
+						if (chunk * 8u <= e_lo) break;
+					}
+					if (qmin != 0xffu && L.ham + bt_mm_penalty(L.maq, qmin) <= L.qualThresh) {
+						bool first = true;
+						BT_NOUNROLL
+						for (uint32_t chunk = e_hi >> 3;; chunk--) {
+							const BtMeta8 m = bt_meta_load8(S, chunk);
+							BT_NOUNROLL
+							for (int k = 7; k >= 0; k--) {
+								const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
+								if (e > e_hi || e < e_lo || (v & 15u) == 15u || (v >> 8) != qmin) continue;
+								const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
+								const uint32_t tp[4] = {t4.x, t4.y, t4.z, t4.w};
+								const uint32_t sp[4] = {b4.x - t4.x, b4.y - t4.y, b4.z - t4.z, b4.w - t4.w};
+								BT_UNROLL
+								for (uint32_t l = 0; l < 4u; l++) {
+									if ((v & (1u << l)) == 0) {
+										if (first) {
+											first = false;
+											L.lowAltQual = qmin; L.eligibleNum = 0; L.eligibleSz = 0;
+											L.eli = L.depth + (e - L.ebase); L.eltop = tp[l]; L.elbot = tp[l] + sp[l];
+											L.elham = bt_mm_penalty(L.maq, qmin); L.elcint = l; L.elignore = 0;
+											L.cand = L.eli; L.candValid = 1;
+										}
+										L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += sp[l];
+									}
+								}
+							}
+							if (chunk * 8u <= e_lo) break;
+						}
+					}
+				}
+			}
+			L.state = ST_BT_LOOP;
+			break;
+		} while (0);
+
+		/* ---- backtrack() exit (:333-353, 303-324) + the seedling-extension loop ---------- */
+		if (L.state == ST_SEARCH_END) do {
+			L.numBts = 0;
+			if (L.kind == BT_KIND_EXTEND) {
+				/* search_seeded_phase3.c:9-59 / phase4.c:9-55: for each seedling, setMuts +
+				 * backtrack(oldQuals); the RNG runs on across seedlings */
+				if (!L.palIdxBefore && L.ret) { bt_lane_finish(L, B); break; }
+				if (L.palIdxBefore) { L.palIdxBefore = 0; L.palIdx = 0; } else L.palIdx = L.palIdx + 1u;
+				L.nmuts = 0;
+				if (L.palIdx >= L.npals) { L.state = ST_PHASE_NEXT; break; }
+				/* PartialAlignmentManager::toMutsString (ebwt_search_util.h:310-362) */
+				const uint64_t pal = S.pals[L.palIdx];
+				const uint32_t p0 = (uint32_t)(pal & 0xffffu), p1 = (uint32_t)((pal >> 16) & 0xffffu), p2 = (uint32_t)((pal >> 32) & 0xffffu);
+				uint32_t oldQuals = 0, nm = 1;
+				const uint32_t t0 = L.plen - 1u - p0;
+				oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t0))) & 0xffu;
+				L.mutpos0 = t0; L.mutnew0 = (uint32_t)((pal >> 48) & 3u);
+				if (p1 != 0xffffu) {
+					const uint32_t t1 = L.plen - 1u - p1;
+					oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t1))) & 0xffu;
+					L.mutpos1 = t1; L.mutnew1 = (uint32_t)((pal >> 50) & 3u); nm = 2;
+					if (p2 != 0xffffu) {
+						const uint32_t t2 = L.plen - 1u - p2;
+						oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t2))) & 0xffu;
+						L.mutpos2 = t2; L.mutnew2 = (uint32_t)((pal >> 52) & 3u); nm = 3;
+					}
+				}
+				L.nmuts = nm;
+				L.iham = oldQuals;
+				L.state = ST_SEARCH_BEGIN;
+				break;
+			}
+			if (L.kind == BT_KIND_GEN) { L.state = ST_PHASE_NEXT; break; }
+			if (L.ret) { bt_lane_finish(L, B); break; }
+			L.state = ST_PHASE_NEXT;
+			break;
+		} while (0);
+
 		/* ---- phase script ------------------------------------------------------------- */
-		case ST_PHASE_NEXT: {
+		if (L.state == ST_PHASE_NEXT) do {
 			L.step = L.step + 1u;        /* 5-bit wrap: 31 -> 0 */
 			if ((int32_t)L.step >= P.nsteps || (L.status & BT_STF_OVERFLOW)) { bt_lane_finish(L, B); break; }
 			const BtStep& st = P.steps[L.step];
@@ -492,10 +695,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			L.state = ST_SEARCH_BEGIN;
 			break;
-		}
+		} while (0);
 
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
-		case ST_SEARCH_BEGIN: {
+		if (L.state == ST_SEARCH_BEGIN) do {
 			L.bailed = 0; L.sd = 0;
 			uint32_t nsInFtab = 0;
 			const uint32_t ftabChars = IXSEL(ftabChars);
@@ -545,26 +748,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER;
 			}
 			break;
-		}
-
-		/* ---- frame prologue (:363-455) -------------------------------------------------- */
-		case ST_FRAME_ENTER: {
-			BT_COUNT(CN_FRAMES);
-			if (L.halfAndHalf) {
-				const uint32_t maxBts = P.steps[L.step].maxBts;
-				if (maxBts > 0 && L.numBts == maxBts) { L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-				L.numBts++;
-			}
-			L.altNum = 0; L.eligibleNum = 0; L.eligibleSz = 0;
-			L.eli = 0; L.eltop = 0; L.elbot = 0; L.elham = L.ham; L.elcint = 0; L.elignore = 1;
-			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0;
-			L.d = L.depth;
-			L.state = ST_STEP_BEGIN;
-			break;
-		}
+		} while (0);
 
 		/* ---- choose a backtrack target and descend (:743-971) --------------------------- */
-		case ST_BT_LOOP: {
+		if (L.state == ST_BT_LOOP) do {
 			uint32_t i, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
 				bool found = L.candValid || bt_find_cand(L, S, L.d);
@@ -637,129 +824,27 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			/* push: save the parent, enter the child */
 			if (L.sd + 1u >= S.frCap) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); break; }
 			{
-				const uint32_t f = L.sd;
-				FRW(f, FR_W0) = L.depth | (L.d << 11);
-				FRW(f, FR_W1) = L.ham | (L.lowAltQual << 16) | (L.elham << 24);
-				FRW(f, FR_W2) = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
-				FRW(f, FR_W3) = L.f2 | (L.f3 << 11);
-				FRW(f, FR_W4) = L.altNum | (L.eligibleNum << 12);
-				FRW(f, FR_ELIGSZ) = L.eligibleSz; FRW(f, FR_ELTOP) = L.eltop; FRW(f, FR_ELBOT) = L.elbot;
-				FRW(f, FR_W8) = L.eli | (L.cand << 11);
-				FRW(f, FR_W9) = L.pi | (L.pj << 11);
-				FRW(f, FR_PTOP) = L.pbttop; FRW(f, FR_PBOT) = L.pbtbot;
-				FRW(f, FR_EBASE) = L.ebase;
+				/* one 64-byte record, written as four 16-byte stores (FR_MM was stored above) */
+				BtU4* fr = (BtU4*)&FRW(L.sd, 0);
+				BtU4 q0, q1, q2;
+				q0.x = L.depth | (L.d << 11);
+				q0.y = L.ham | (L.lowAltQual << 16) | (L.elham << 24);
+				q0.z = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
+				q0.w = L.f2 | (L.f3 << 11);
+				q1.x = L.altNum | (L.eligibleNum << 12); q1.y = L.eligibleSz; q1.z = L.eltop; q1.w = L.elbot;
+				q2.x = L.eli | (L.cand << 11); q2.y = L.pi | (L.pj << 11); q2.z = L.pbttop; q2.w = L.pbtbot;
+				fr[0] = q0; fr[1] = q1; fr[2] = q2;
+				FRW(L.sd, FR_EBASE) = L.ebase;
 			}
 			L.ebase = L.ebase + (L.d - L.depth + 1u);
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
 			break;
-		}
-
-		/* ---- a child frame (or a leaf report) came back (:972-1064) ---------------------- */
-		case ST_CHILD_RET: {
-			if (L.ret) { L.state = ST_FRAME_RETURN; break; }
-			if (L.bailed || (L.halfAndHalf && P.steps[L.step].maxBts > 0 && L.numBts >= P.steps[L.step].maxBts)) {
-				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
-			}
-			{
-				const uint32_t e = L.ebase + (L.pi - L.depth);
-				const uint32_t mv = S.meta[e] | (1u << L.pj);
-				S.meta[e] = (uint16_t)mv;
-				if ((mv & 15u) == 15u) L.candValid = 0;      /* that position is exhausted: re-scan next time */
-			}
-			L.eligibleSz -= (L.pbtbot - L.pbttop);
-			L.eligibleNum = L.eligibleNum - 1u;
-			L.elignore = 1;
-			L.altNum = L.altNum - 1u;
-			if (L.altNum == 0) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
-			if (L.eligibleNum == 0 && L.considerQuals) {
-				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058): the
-				 * reference walks k = d..max(depth,unrev) once, restarting its tallies whenever it
-				 * meets a strictly lower quality.  Same result in two batched passes: (1) the lowest
-				 * quality among positions that still have a target, (2) the tallies over the positions
-				 * of exactly that quality, deepest first. */
-				L.lowAltQual = 0xff; L.candValid = 0;
-				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
-				if (L.d >= kmin) {
-					const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
-					uint32_t qmin = 0xffu;
-					BT_NOUNROLL
-					for (uint32_t chunk = e_hi >> 3;; chunk--) {
-						const BtMeta8 m = bt_meta_load8(S, chunk);
-						BT_UNROLL
-						for (int k = 7; k >= 0; k--) {
-							const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
-							if (e <= e_hi && e >= e_lo && (v & 15u) != 15u && (v >> 8) < qmin) qmin = v >> 8;
-						}
-						if (chunk * 8u <= e_lo) break;
-					}
-					if (qmin != 0xffu && L.ham + bt_mm_penalty(L.maq, qmin) <= L.qualThresh) {
-						bool first = true;
-						BT_NOUNROLL
-						for (uint32_t chunk = e_hi >> 3;; chunk--) {
-							const BtMeta8 m = bt_meta_load8(S, chunk);
-							BT_NOUNROLL
-							for (int k = 7; k >= 0; k--) {
-								const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
-								if (e > e_hi || e < e_lo || (v & 15u) == 15u || (v >> 8) != qmin) continue;
-								const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
-								const uint32_t tp[4] = {t4.x, t4.y, t4.z, t4.w};
-								const uint32_t sp[4] = {b4.x - t4.x, b4.y - t4.y, b4.z - t4.z, b4.w - t4.w};
-								BT_UNROLL
-								for (uint32_t l = 0; l < 4u; l++) {
-									if ((v & (1u << l)) == 0) {
-										if (first) {
-											first = false;
-											L.lowAltQual = qmin; L.eligibleNum = 0; L.eligibleSz = 0;
-											L.eli = L.depth + (e - L.ebase); L.eltop = tp[l]; L.elbot = tp[l] + sp[l];
-											L.elham = bt_mm_penalty(L.maq, qmin); L.elcint = l; L.elignore = 0;
-											L.cand = L.eli; L.candValid = 1;
-										}
-										L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += sp[l];
-									}
-								}
-							}
-							if (chunk * 8u <= e_lo) break;
-						}
-					}
-				}
-			}
-			L.state = ST_BT_LOOP;
-			break;
-		}
-
-		/* ---- return from a frame -------------------------------------------------------- */
-		case ST_FRAME_RETURN: {
-			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
-			const uint32_t f = L.sd - 1u;
-			L.sd = f;
-			uint32_t v;
-			v = FRW(f, FR_W0); L.depth = v & 0x7ffu; L.d = (v >> 11) & 0x7ffu;
-			v = FRW(f, FR_W1); L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu; L.elham = (v >> 24) & 0xffu;
-			v = FRW(f, FR_W2); L.fu = v & 0x7ffu; L.f1 = (v >> 11) & 0x7ffu; L.elcint = (v >> 22) & 3u;
-			L.elignore = (v >> 24) & 1u; L.candValid = (v >> 25) & 1u;
-			v = FRW(f, FR_W3); L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
-			v = FRW(f, FR_W4); L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
-			L.eligibleSz = FRW(f, FR_ELIGSZ); L.eltop = FRW(f, FR_ELTOP); L.elbot = FRW(f, FR_ELBOT);
-			v = FRW(f, FR_W8); L.eli = v & 0x7ffu; L.cand = (v >> 11) & 0x7ffu;
-			v = FRW(f, FR_W9); L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u;
-			L.pbttop = FRW(f, FR_PTOP); L.pbtbot = FRW(f, FR_PBOT);
-			L.ebase = FRW(f, FR_EBASE);
-			L.cchunk = 0xffu;
-			L.state = ST_CHILD_RET;
-			break;
-		}
-
-		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */
-		case ST_FELL_OFF: {
-			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL);
-			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
-			break;
-		}
+		} while (0);
 
 		/* ---- reportAlignment / reportFullAlignment (:1455-1565) -------------------------- */
-		case ST_RA_BEGIN: {
+		if (L.state == ST_RA_BEGIN) do {
 			if (L.reportPartials) {
 				if (L.ra_sd > 0) bt_report_partial(L, S, L.ra_sd);
 				L.ret = 0; L.state = ST_RA_END; break;
@@ -779,8 +864,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			L.state = ST_ROW_BEGIN;
 			break;
-		}
-		case ST_ROW_BEGIN: {
+		} while (0);
+
+		if (L.state == ST_ROW_BEGIN) do {
 			const uint32_t spread = L.ra_bot - L.ra_top;
 			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
 			uint32_t ri = L.ra_r + L.ra_i;
@@ -788,100 +874,24 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.crow = ri; L.cjumps = 0;
 			L.state = ST_CHASE_CHECK;
 			break;
-		}
-		case ST_RESOLVE: {
-			const uint32_t zOff = IXSEL(zOff);
-			uint32_t off;
-			if (L.crow == zOff) off = L.cjumps;
-			else { const uint32_t* offs = IXSEL(offs); off = offs[L.crow >> IXSEL(offRate)] + L.cjumps; }
-			BT_COUNT(CN_OFFS);
-			/* joinedToTextOff (ebwt.h:2569-2629) */
-			const uint32_t* rstarts = IXSEL(rstarts);
-			const uint32_t nFrag = IXSEL(nFrag), len = IXSEL(len), ixfw = IXSEL(fw);
-			uint32_t lo = 0, hi = nFrag, tidx = 0, toff = 0, probes = 0;
-			bool hit = false;
-			BT_NOUNROLL
-			for (;;) {
-				const uint32_t elt = lo + ((hi - lo) >> 1);
-				const uint32_t lower = rstarts[elt * 3u];
-				const uint32_t upper = (elt == nFrag - 1u) ? len : rstarts[(elt + 1u) * 3u];
-				probes++;
-				if (lower <= off) {
-					if (upper > off) {
-						if (off + L.qlen <= upper) {
-							uint32_t fragoff = off - lower;
-							if (!ixfw) { fragoff = (upper - lower) - fragoff - 1u; fragoff -= (L.qlen - 1u); }
-							tidx = rstarts[elt * 3u + 1u];
-							toff = fragoff + rstarts[elt * 3u + 2u];
-							hit = true;
-						}
-						break;
-					}
-					lo = elt;
-				} else hi = elt;
-			}
-			BT_COUNT_N(CN_RSTARTS, probes);
-			if (hit && bt_report_hit(L, P, ixfw, S, B, tidx, toff)) { L.ret = 1; L.state = ST_RA_END; break; }
-			L.ra_i++;
-			L.state = ST_ROW_BEGIN;
-			break;
-		}
-		case ST_RA_END: {
-			switch (L.ra_cont) {
-			case RC_STEP:
-				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
-				L.top = L.bot;                                   /* keep looking (:730-735) */
-				if (L.altNum > 0) L.state = ST_BT_LOOP;
-				else { L.ret = 0; L.state = ST_FRAME_RETURN; }
-				break;
-			case RC_CHILD: L.state = ST_CHILD_RET; break;
-			case RC_FELL:  L.state = ST_FRAME_RETURN; break;
-			default:       L.state = ST_SEARCH_END; break;
-			}
-			break;
-		}
+		} while (0);
 
-		/* ---- backtrack() exit (:333-353, 303-324) + the seedling-extension loop ---------- */
-		case ST_SEARCH_END: {
-			L.numBts = 0;
-			if (L.kind == BT_KIND_EXTEND) {
-				/* search_seeded_phase3.c:9-59 / phase4.c:9-55: for each seedling, setMuts +
-				 * backtrack(oldQuals); the RNG runs on across seedlings */
-				if (!L.palIdxBefore && L.ret) { bt_lane_finish(L, B); break; }
-				if (L.palIdxBefore) { L.palIdxBefore = 0; L.palIdx = 0; } else L.palIdx = L.palIdx + 1u;
-				L.nmuts = 0;
-				if (L.palIdx >= L.npals) { L.state = ST_PHASE_NEXT; break; }
-				/* PartialAlignmentManager::toMutsString (ebwt_search_util.h:310-362) */
-				const uint64_t pal = S.pals[L.palIdx];
-				const uint32_t p0 = (uint32_t)(pal & 0xffffu), p1 = (uint32_t)((pal >> 16) & 0xffffu), p2 = (uint32_t)((pal >> 32) & 0xffffu);
-				uint32_t oldQuals = 0, nm = 1;
-				const uint32_t t0 = L.plen - 1u - p0;
-				oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t0))) & 0xffu;
-				L.mutpos0 = t0; L.mutnew0 = (uint32_t)((pal >> 48) & 3u);
-				if (p1 != 0xffffu) {
-					const uint32_t t1 = L.plen - 1u - p1;
-					oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t1))) & 0xffu;
-					L.mutpos1 = t1; L.mutnew1 = (uint32_t)((pal >> 50) & 3u); nm = 2;
-					if (p2 != 0xffffu) {
-						const uint32_t t2 = L.plen - 1u - p2;
-						oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t2))) & 0xffu;
-						L.mutpos2 = t2; L.mutnew2 = (uint32_t)((pal >> 52) & 3u); nm = 3;
-					}
-				}
-				L.nmuts = nm;
-				L.iham = oldQuals;
-				L.state = ST_SEARCH_BEGIN;
-				break;
+		/* ---- frame prologue (:363-455) -------------------------------------------------- */
+		if (L.state == ST_FRAME_ENTER) do {
+			BT_COUNT(CN_FRAMES);
+			if (L.halfAndHalf) {
+				const uint32_t maxBts = P.steps[L.step].maxBts;
+				if (maxBts > 0 && L.numBts == maxBts) { L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break; }
+				L.numBts++;
 			}
-			if (L.kind == BT_KIND_GEN) { L.state = ST_PHASE_NEXT; break; }
-			if (L.ret) { bt_lane_finish(L, B); break; }
-			L.state = ST_PHASE_NEXT;
+			L.altNum = 0; L.eligibleNum = 0; L.eligibleSz = 0;
+			L.eli = 0; L.eltop = 0; L.elbot = 0; L.elham = L.ham; L.elcint = 0; L.elignore = 1;
+			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0;
+			L.d = L.depth;
+			L.state = ST_STEP_BEGIN;
 			break;
-		}
-		default:
-			L.state = ST_IDLE;
-			break;
-		}
+		} while (0);
+
 	}
 }
 

@@ -10,7 +10,7 @@ struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */
 	const BtCold* cold;          /* device memory: program, full index descriptors, batch        */
 	/* per-lane scratch arenas (see BtScratch) */
-	uint32_t*  frames;           /* [frCap*16][nLanes]                                           */
+	uint32_t*  frames;           /* [nLanes][frCap][16]                                           */
 	uint32_t*  pairs;            /* [nLanes][entCap][8]                                          */
 	uint16_t*  meta;             /* [nLanes][entCap] mask | Phred<<8                             */
 	uint64_t*  pals;             /* [nLanes][palCap]                                             */

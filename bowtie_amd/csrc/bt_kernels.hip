@@ -52,8 +52,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BtScratch S;
-	S.frStride = A.nLanes;
-	S.frames = A.frames + g;
+	S.frames = A.frames + (uint64_t)g * A.frCap * BT_FR_WORDS;
 	S.pairs = A.pairs + (uint64_t)g * A.entCap * 8u;
 	S.meta = A.meta + (uint64_t)g * A.entCap;
 	S.pals = A.pals + (uint64_t)g * A.palCap;
@@ -87,6 +86,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		if (L.state == ST_IDLE) break;
 		/* op counters: one LDS atomic per wavefront per kind */
 		BT_COUNT(CN_ITERS);
+		L.iters++;
 		if (L.state == ST_CHASE_LFDONE) BT_COUNT(CN_CHASE);
 		else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
 		else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);

@@ -169,6 +169,9 @@ int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* o
 int  bt_ctx_sync(bt_ctx* ctx);
 /* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */
 uint32_t bt_ctx_last_mm_used(bt_ctx* ctx);
+/* diagnostics: device buffer [n_reads] that receives, per read, the number of lock-step LF rounds it
+ * took (NULL = off; stays set for later batches) */
+void bt_ctx_set_iters_buffer(bt_ctx* ctx, uint32_t* dev_ptr);
 /* read (and optionally reset) the ctx-owned op counters that bt_align_batch_device accumulates
  * into when counts_dev == NULL */
 int  bt_ctx_counts(bt_ctx* ctx, bt_op_counts* out, int reset);

@@ -68,7 +68,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	}
 	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
 	entCap = (entCap + 7u) & ~7u;
-	std::vector<uint32_t> frames((size_t)nLanes * frCap * BT_FR_WORDS);
+	std::vector<BtU4> frames4((size_t)nLanes * frCap * 4);
 	std::vector<BtU4> pairs4((size_t)nLanes * entCap * 2);
 	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
@@ -82,7 +82,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		memset(&lanes[g], 0, sizeof(BtLane));
 		memset(&res[g], 0, sizeof(BtRes));
 		lanes[g].state = ST_IDLE;
-		scr[g].frames = frames.data() + g; scr[g].frStride = nLanes;
+		scr[g].frames = (uint32_t*)(frames4.data() + (size_t)g * frCap * 4);
 		scr[g].pairs = (uint32_t*)(pairs4.data() + (size_t)g * entCap * 2); scr[g].meta = meta.data() + (size_t)g * entCap;
 		scr[g].pals = pals.data() + (size_t)g * palCap;
 		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
