@@ -237,7 +237,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "bt_search_kernel", "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": abytes,
-                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames")},
+                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n},
         }
         if not args.no_cpu:

@@ -186,8 +186,8 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
-	HIPCHK(hipMalloc((void**)&c->d_counts, 10 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(c->d_counts, 0, 10 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&c->d_counts, CN_N * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(c->d_counts, 0, CN_N * sizeof(unsigned long long)));
 	*out = c;
 	return BT_OK;
 }
@@ -285,11 +285,11 @@ extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used 
 extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 {
 	if (!c || !out) return BT_ERR_ARG;
-	unsigned long long h[10];
+	unsigned long long h[CN_N];
 	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
 	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
 	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
-	out->lane_iters = h[8]; out->same_pair = h[9];
+	out->lane_iters = h[8]; out->same_pair = h[9]; out->rescans = h[10]; out->cand_scans = h[11];
 	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
 	return BT_OK;
 }
@@ -331,7 +331,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	bt_hit_batch dout = *out;
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
-	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, 10 * sizeof(unsigned long long), c->stream));
+	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, CN_N * sizeof(unsigned long long), c->stream));
 	int rc = run_device(c, &din, &dout, maxLen, nullptr);
 	if (rc != BT_OK) return rc;
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));

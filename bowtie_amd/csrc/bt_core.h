@@ -76,8 +76,8 @@ enum {
 	FR_W3,       /* f2 | f3<<11                                     */
 	FR_W4,       /* altNum | eligibleNum<<12                        */
 	FR_ELIGSZ, FR_ELTOP, FR_ELBOT,
-	FR_W8,       /* eli | cand<<11                                  */
-	FR_W9,       /* pi | pj<<11                                     */
+	FR_W8,       /* eli | cand<<11 | elel<<22                       */
+	FR_W9,       /* pi | pj<<11 | pel<<13                           */
 	FR_PTOP, FR_PBOT, FR_EBASE,
 	FR_MM        /* mismatch chosen at this level: query offset | refc<<16                        */
 };
@@ -87,6 +87,9 @@ struct BtScratch {
 	uint32_t* pairs;                         /* [entry][8]: tops ACGT, bots ACGT                 */
 	uint16_t* meta;                          /* [entry] eliminated-chars mask | Phred<<8          */
 	uint64_t* pals;                          /* [palCap] seedlings                                */
+	uint32_t* tos;      uint32_t tosStride;  /* LDS copy of the most recently pushed frame record:
+	                                            word w at tos[w*tosStride] (a failed child pops it
+	                                            back without a trip to HBM)                         */
 	uint32_t  frCap, entCap, palCap;
 };
 
@@ -146,7 +149,7 @@ enum { RC_STEP = 0, RC_CHILD, RC_FELL, RC_ENTRY };
 enum { LFK_EX2 = 0, LFK_C2, LFK_LF1 };
 
 /* op counters (bt_op_counts order) */
-enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_N };
+enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_RESCAN, CN_CANDSCAN, CN_N };
 #if defined(__HIP_DEVICE_COMPILE__)
 /* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
 #define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)
@@ -187,6 +190,7 @@ struct BtLane {
 	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, state : 5, ra_cont : 2;
 	/* pending backtrack target */
 	uint32_t pi : 11, pj : 2, btham : 16;
+	uint32_t pel : 4, elel : 4, tosFrame : 7, tosValid : 1;
 	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
@@ -322,7 +326,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtHot& H, const BtCold& C, uint32_t rd
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
 	L.cchunk = 0xffu;
-	L.iters = 0;
+	L.iters = 0; L.tosValid = 0;
 	L.state = ST_PHASE_NEXT;
 	const uint32_t plen = L.plen;
 	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
@@ -442,8 +446,9 @@ BT_HD uint32_t bt_meta_get(const BtMeta8& m, uint32_t k)       /* k in 0..7 */
 
 /* Deepest position in [depth, from] that still has a backtrack target of the current eligible
  * quality (the `for(; i >= depth; i--)` walk of ebwt_search_backtrack.h:767-812). */
-BT_HD bool bt_find_cand(BtLane& L, const BtScratch& S, uint32_t from)
+BT_HD bool bt_find_cand(BtLane& L, const BtScratch& S, uint32_t from, unsigned long long* CNT)
 {
+	BT_COUNT(CN_CANDSCAN);
 	const uint32_t e_lo = L.ebase, e_hi = L.ebase + (from - L.depth);
 	BT_NOUNROLL
 	for (uint32_t chunk = e_hi >> 3;; chunk--) {
@@ -538,9 +543,19 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - 1u;
 			L.sd = f;
-			const BtU4* fr = (const BtU4*)&FRW(f, 0);
-			const BtU4 q0 = fr[0], q1 = fr[1], q2 = fr[2];
-			const uint32_t eb = FRW(f, FR_EBASE);
+			BtU4 q0, q1, q2; uint32_t eb;
+			if (L.tosValid && L.tosFrame == f) {
+				const uint32_t ts = S.tosStride;
+				q0.x = S.tos[0]; q0.y = S.tos[ts]; q0.z = S.tos[2u * ts]; q0.w = S.tos[3u * ts];
+				q1.x = S.tos[4u * ts]; q1.y = S.tos[5u * ts]; q1.z = S.tos[6u * ts]; q1.w = S.tos[7u * ts];
+				q2.x = S.tos[8u * ts]; q2.y = S.tos[9u * ts]; q2.z = S.tos[10u * ts]; q2.w = S.tos[11u * ts];
+				eb = S.tos[12u * ts];
+				L.tosValid = 0;
+			} else {
+				const BtU4* fr = (const BtU4*)&FRW(f, 0);
+				q0 = fr[0]; q1 = fr[1]; q2 = fr[2];
+				eb = FRW(f, FR_EBASE);
+			}
 			uint32_t v;
 			v = q0.x; L.depth = v & 0x7ffu; L.d = (v >> 11) & 0x7ffu;
 			v = q0.y; L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu; L.elham = (v >> 24) & 0xffu;
@@ -549,8 +564,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			v = q0.w; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
 			v = q1.x; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
 			L.eligibleSz = q1.y; L.eltop = q1.z; L.elbot = q1.w;
-			v = q2.x; L.eli = v & 0x7ffu; L.cand = (v >> 11) & 0x7ffu;
-			v = q2.y; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u;
+			v = q2.x; L.eli = v & 0x7ffu; L.cand = (v >> 11) & 0x7ffu; L.elel = (v >> 22) & 15u;
+			v = q2.y; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
 			L.pbttop = q2.z; L.pbtbot = q2.w;
 			L.ebase = eb;
 			L.cchunk = 0xffu;
@@ -566,9 +581,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			{
 				const uint32_t e = L.ebase + (L.pi - L.depth);
-				const uint32_t mv = S.meta[e] | (1u << L.pj);
-				S.meta[e] = (uint16_t)mv;
-				if ((mv & 15u) == 15u) L.candValid = 0;      /* that position is exhausted: re-scan next time */
+				const uint32_t el = L.pel | (1u << L.pj);           /* the mask travelled with the frame record */
+				((uint8_t*)S.meta)[2u * e] = (uint8_t)el;
+				if (el == 15u) L.candValid = 0;             /* that position is exhausted: re-scan next time */
+				if (L.eli == L.pi) L.elel = el;
 			}
 			L.eligibleSz -= (L.pbtbot - L.pbttop);
 			L.eligibleNum = L.eligibleNum - 1u;
@@ -581,48 +597,65 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				 * meets a strictly lower quality.  Same result in two batched passes: (1) the lowest
 				 * quality among positions that still have a target, (2) the tallies over the positions
 				 * of exactly that quality, deepest first. */
+				BT_COUNT(CN_RESCAN);
 				L.lowAltQual = 0xff; L.candValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
 				if (L.d >= kmin) {
 					const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
+					/* both passes walk the frame's records 4 chunks (32 positions) per batch, the four
+					 * 16-byte loads of a batch issued back to back */
+					const uint32_t c_hi = e_hi >> 3, c_lo = e_lo >> 3;
 					uint32_t qmin = 0xffu;
 					BT_NOUNROLL
-					for (uint32_t chunk = e_hi >> 3;; chunk--) {
-						const BtMeta8 m = bt_meta_load8(S, chunk);
+					for (uint32_t cb = c_hi;; cb -= 4u) {
+						BtMeta8 m[4];
 						BT_UNROLL
-						for (int k = 7; k >= 0; k--) {
-							const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
-							if (e <= e_hi && e >= e_lo && (v & 15u) != 15u && (v >> 8) < qmin) qmin = v >> 8;
+						for (uint32_t t = 0; t < 4u; t++) m[t] = bt_meta_load8(S, cb >= t + c_lo ? cb - t : c_lo);
+						BT_UNROLL
+						for (uint32_t t = 0; t < 4u; t++) {
+							if (cb < t + c_lo) continue;
+							BT_UNROLL
+							for (int k = 7; k >= 0; k--) {
+								const uint32_t e = (cb - t) * 8u + (uint32_t)k, v = bt_meta_get(m[t], (uint32_t)k);
+								if (e <= e_hi && e >= e_lo && (v & 15u) != 15u && (v >> 8) < qmin) qmin = v >> 8;
+							}
 						}
-						if (chunk * 8u <= e_lo) break;
+						if (cb < c_lo + 4u) break;
 					}
 					if (qmin != 0xffu && L.ham + bt_mm_penalty(L.maq, qmin) <= L.qualThresh) {
 						bool first = true;
 						BT_NOUNROLL
-						for (uint32_t chunk = e_hi >> 3;; chunk--) {
-							const BtMeta8 m = bt_meta_load8(S, chunk);
-							BT_NOUNROLL
-							for (int k = 7; k >= 0; k--) {
-								const uint32_t e = chunk * 8u + (uint32_t)k, v = bt_meta_get(m, (uint32_t)k);
-								if (e > e_hi || e < e_lo || (v & 15u) == 15u || (v >> 8) != qmin) continue;
-								const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
-								const uint32_t tp[4] = {t4.x, t4.y, t4.z, t4.w};
-								const uint32_t sp[4] = {b4.x - t4.x, b4.y - t4.y, b4.z - t4.z, b4.w - t4.w};
-								BT_UNROLL
-								for (uint32_t l = 0; l < 4u; l++) {
-									if ((v & (1u << l)) == 0) {
-										if (first) {
-											first = false;
-											L.lowAltQual = qmin; L.eligibleNum = 0; L.eligibleSz = 0;
-											L.eli = L.depth + (e - L.ebase); L.eltop = tp[l]; L.elbot = tp[l] + sp[l];
-											L.elham = bt_mm_penalty(L.maq, qmin); L.elcint = l; L.elignore = 0;
-											L.cand = L.eli; L.candValid = 1;
+						for (uint32_t cb = c_hi;; cb -= 4u) {
+							BtMeta8 m[4];
+							BT_UNROLL
+							for (uint32_t t = 0; t < 4u; t++) m[t] = bt_meta_load8(S, cb >= t + c_lo ? cb - t : c_lo);
+							BT_UNROLL
+							for (uint32_t t = 0; t < 4u; t++) {
+								if (cb < t + c_lo) continue;
+								BT_NOUNROLL
+								for (int k = 7; k >= 0; k--) {
+									const uint32_t e = (cb - t) * 8u + (uint32_t)k, v = bt_meta_get(m[t], (uint32_t)k);
+									if (e > e_hi || e < e_lo || (v & 15u) == 15u || (v >> 8) != qmin) continue;
+									const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
+									const uint32_t tp[4] = {t4.x, t4.y, t4.z, t4.w};
+									const uint32_t sp[4] = {b4.x - t4.x, b4.y - t4.y, b4.z - t4.z, b4.w - t4.w};
+									BT_UNROLL
+									for (uint32_t l = 0; l < 4u; l++) {
+										if ((v & (1u << l)) == 0) {
+											if (first) {
+												first = false;
+												L.lowAltQual = qmin; L.eligibleNum = 0; L.eligibleSz = 0;
+												L.eli = L.depth + (e - L.ebase); L.eltop = tp[l]; L.elbot = tp[l] + sp[l];
+												L.elham = bt_mm_penalty(L.maq, qmin); L.elcint = l; L.elignore = 0;
+												L.elel = v & 15u;
+												L.cand = L.eli; L.candValid = 1;
+											}
+											L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += sp[l];
 										}
-										L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += sp[l];
 									}
 								}
 							}
-							if (chunk * 8u <= e_lo) break;
+							if (cb < c_lo + 4u) break;
 						}
 					}
 				}
@@ -754,13 +787,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 		if (L.state == ST_BT_LOOP) do {
 			uint32_t i, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
-				bool found = L.candValid || bt_find_cand(L, S, L.d);
+				bool found = L.candValid || bt_find_cand(L, S, L.d, CNT);
 				if (found) {
 					found = false;
 					i = L.cand;
 					const uint32_t e = L.ebase + (i - L.depth);
 					const uint32_t mv = S.meta[e];
 					const uint32_t el = mv & 15u, qi = mv >> 8;
+					L.pel = el;
 					uint32_t sp[4], tp[4];
 					{
 						const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
@@ -788,6 +822,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				i = L.cand;
 			} else {
 				i = L.eli; bttop = L.eltop; btbot = L.elbot; btham += L.elham; j = btcint = L.elcint;
+				L.pel = L.elel;
 			}
 			const uint32_t icur = L.qlen - i - 1u;
 			uint32_t nu = L.fu, n1 = L.f1, n2 = L.f2, n3 = L.f3;
@@ -832,9 +867,16 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				q0.z = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
 				q0.w = L.f2 | (L.f3 << 11);
 				q1.x = L.altNum | (L.eligibleNum << 12); q1.y = L.eligibleSz; q1.z = L.eltop; q1.w = L.elbot;
-				q2.x = L.eli | (L.cand << 11); q2.y = L.pi | (L.pj << 11); q2.z = L.pbttop; q2.w = L.pbtbot;
+				q2.x = L.eli | (L.cand << 11) | (L.elel << 22); q2.y = L.pi | (L.pj << 11) | (L.pel << 13); q2.z = L.pbttop; q2.w = L.pbtbot;
 				fr[0] = q0; fr[1] = q1; fr[2] = q2;
 				FRW(L.sd, FR_EBASE) = L.ebase;
+				/* top-of-stack copy in LDS */
+				const uint32_t ts = S.tosStride;
+				S.tos[0] = q0.x; S.tos[ts] = q0.y; S.tos[2u * ts] = q0.z; S.tos[3u * ts] = q0.w;
+				S.tos[4u * ts] = q1.x; S.tos[5u * ts] = q1.y; S.tos[6u * ts] = q1.z; S.tos[7u * ts] = q1.w;
+				S.tos[8u * ts] = q2.x; S.tos[9u * ts] = q2.y; S.tos[10u * ts] = q2.z; S.tos[11u * ts] = q2.w;
+				S.tos[12u * ts] = L.ebase;
+				L.tosFrame = L.sd; L.tosValid = 1;
 			}
 			L.ebase = L.ebase + (L.d - L.depth + 1u);
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
@@ -959,6 +1001,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 					}
 				}
 				if (L.fl_elig && el != 15u) { L.cand = d; L.candValid = 1; }     /* deepest eligible target so far */
+				if (L.eli == d && !L.elignore) L.elel = el;
 			}
 			S.meta[e] = (uint16_t)(el | (q << 8));
 			bool btDespite = false, reportedPartial = false;

@@ -47,6 +47,7 @@ template <int OCC>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
 	__shared__ unsigned long long CNT[CN_N];
+	__shared__ uint32_t TOS[13 * BT_BLOCK];          /* top-of-stack frame record per lane */
 	if (threadIdx.x < CN_N) CNT[threadIdx.x] = 0;
 	__syncthreads();
 
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	S.meta = A.meta + (uint64_t)g * A.entCap;
 	S.pals = A.pals + (uint64_t)g * A.palCap;
 	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
+	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 
-	BtLane L;
-	memset(&L, 0, sizeof(L));
+	BtLane L = {};
 	L.state = ST_IDLE;
 	BtRes res;
 	BtReq req;

@@ -126,6 +126,8 @@ typedef struct bt_op_counts {
 	uint64_t frames;          /* backtrack frames entered                                     */
 	uint64_t lane_iters;      /* sum over lanes of lock-step iterations (GPU only)            */
 	uint64_t same_pair;       /* two-locus steps whose rows share one 128-byte side pair      */
+	uint64_t rescans;         /* frame re-scans for the next-lowest-quality target set        */
+	uint64_t cand_scans;      /* frame scans for the deepest remaining target                 */
 } bt_op_counts;
 
 /* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */

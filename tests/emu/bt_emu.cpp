@@ -72,6 +72,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	std::vector<BtU4> pairs4((size_t)nLanes * entCap * 2);
 	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
+	std::vector<uint32_t> tos((size_t)nLanes * 13);
 	std::vector<BtLane> lanes(nLanes);
 	std::vector<BtScratch> scr(nLanes);
 	std::vector<BtRes> res(nLanes);
@@ -86,6 +87,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		scr[g].pairs = (uint32_t*)(pairs4.data() + (size_t)g * entCap * 2); scr[g].meta = meta.data() + (size_t)g * entCap;
 		scr[g].pals = pals.data() + (size_t)g * palCap;
 		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
+		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
 	}
 	uint32_t next = 0, live = nLanes;
 	while (live > 0) {
@@ -118,6 +120,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		counts->lfex = CNT[CN_LFEX]; counts->lf2 = CNT[CN_LF2]; counts->lf1 = CNT[CN_LF1]; counts->chase = CNT[CN_CHASE];
 		counts->ftab = CNT[CN_FTAB]; counts->offs = CNT[CN_OFFS]; counts->rstarts = CNT[CN_RSTARTS];
 		counts->frames = CNT[CN_FRAMES]; counts->lane_iters = CNT[CN_ITERS]; counts->same_pair = CNT[CN_SAMEPAIR];
+		counts->rescans = CNT[CN_RESCAN]; counts->cand_scans = CNT[CN_CANDSCAN];
 	}
 	return BT_OK;
 }
