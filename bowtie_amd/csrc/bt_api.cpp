@@ -289,7 +289,7 @@ extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
 	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
 	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
-	out->lane_iters = h[8]; out->same_pair = h[9]; out->rescans = h[10]; out->cand_scans = h[11];
+	out->lane_iters = h[8]; out->same_pair = h[9]; out->rescans = h[10]; out->cand_scans = h[11]; out->wave_rounds = h[12];
 	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
 	return BT_OK;
 }

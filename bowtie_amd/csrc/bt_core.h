@@ -149,7 +149,7 @@ enum { RC_STEP = 0, RC_CHILD, RC_FELL, RC_ENTRY };
 enum { LFK_EX2 = 0, LFK_C2, LFK_LF1 };
 
 /* op counters (bt_op_counts order) */
-enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_RESCAN, CN_CANDSCAN, CN_N };
+enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_RESCAN, CN_CANDSCAN, CN_WROUNDS, CN_N };
 #if defined(__HIP_DEVICE_COMPILE__)
 /* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
 #define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)

@@ -88,6 +88,10 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		/* op counters: one LDS atomic per wavefront per kind */
 		BT_COUNT(CN_ITERS);
 		L.iters++;
+		{
+			const unsigned long long act = __ballot(1);
+			if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) BT_COUNT(CN_WROUNDS);
+		}
 		if (L.state == ST_CHASE_LFDONE) BT_COUNT(CN_CHASE);
 		else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
 		else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);

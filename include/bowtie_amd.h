@@ -128,6 +128,8 @@ typedef struct bt_op_counts {
 	uint64_t same_pair;       /* two-locus steps whose rows share one 128-byte side pair      */
 	uint64_t rescans;         /* frame re-scans for the next-lowest-quality target set        */
 	uint64_t cand_scans;      /* frame scans for the deepest remaining target                 */
+	uint64_t wave_rounds;     /* lock-step rounds summed over wavefronts (GPU only);
+	                             lane_iters / wave_rounds = mean active lanes per round        */
 } bt_op_counts;
 
 /* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */
