@@ -186,8 +186,8 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
-	HIPCHK(hipMalloc((void**)&c->d_counts, CN_N * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(c->d_counts, 0, CN_N * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long)));
 	*out = c;
 	return BT_OK;
 }
@@ -278,6 +278,16 @@ extern "C" float bt_ctx_last_kernel_ms(bt_ctx* c)
 	return ms;
 }
 
+/* profiling build only (-DBT_PROFILE): wavefront cycles per automaton section, PS_N values */
+extern "C" int bt_ctx_prof_sections(bt_ctx* c, uint64_t* out, int n)
+{
+	if (!c || !out) return BT_ERR_ARG;
+	unsigned long long h[CN_N + PS_N];
+	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
+	for (int i = 0; i < n && i < PS_N; i++) out[i] = h[CN_N + i];
+	return BT_OK;
+}
+
 extern "C" void bt_ctx_set_iters_buffer(bt_ctx* c, uint32_t* dev_ptr) { if (c) c->iters_dev = dev_ptr; }
 
 extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
@@ -285,7 +295,7 @@ extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used 
 extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 {
 	if (!c || !out) return BT_ERR_ARG;
-	unsigned long long h[CN_N];
+	unsigned long long h[CN_N + PS_N];
 	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
 	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
 	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
@@ -331,7 +341,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	bt_hit_batch dout = *out;
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
-	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, CN_N * sizeof(unsigned long long), c->stream));
+	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long), c->stream));
 	int rc = run_device(c, &din, &dout, maxLen, nullptr);
 	if (rc != BT_OK) return rc;
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));

@@ -148,6 +148,21 @@ enum {
 enum { RC_STEP = 0, RC_CHILD, RC_FELL, RC_ENTRY };
 enum { LFK_EX2 = 0, LFK_C2, LFK_LF1 };
 
+/* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
+ * cycles (s_memtime) spent in each block of the automaton, accumulated per block in LDS.  No-ops in
+ * the product build. */
+enum { PS_RESUME = 0, PS_SLOW, PS_EMIT, PS_RANK, PS_REFILL, PS_LOOP,
+       PS_FELL_OFF, PS_RESOLVE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_SEARCH_END, PS_PHASE_NEXT,
+       PS_SEARCH_BEGIN, PS_BT_LOOP, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_RESCAN, PS_N };
+#if defined(BT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define BT_PROF_T0(v) const unsigned long long v = __builtin_readcyclecounter()
+#define BT_PROF_ADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
+	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + (k)], __builtin_readcyclecounter() - (v)); } while (0)
+#else
+#define BT_PROF_T0(v)
+#define BT_PROF_ADD(k, v)
+#endif
+
 /* op counters (bt_op_counts order) */
 enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_RESCAN, CN_CANDSCAN, CN_WROUNDS, CN_N };
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -479,13 +494,13 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 	 * block `break` leaves the block. */
 	while (BT_IS_SLOW(L.state)) {
 		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */
-		if (L.state == ST_FELL_OFF) do {
+		if (L.state == ST_FELL_OFF) { BT_PROF_T0(t_fell_off); do {
 			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL);
 			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FELL_OFF, t_fell_off); }
 
-		if (L.state == ST_RESOLVE) do {
+		if (L.state == ST_RESOLVE) { BT_PROF_T0(t_resolve); do {
 			const uint32_t zOff = IXSEL(zOff);
 			uint32_t off;
 			if (L.crow == zOff) off = L.cjumps;
@@ -521,9 +536,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.ra_i++;
 			L.state = ST_ROW_BEGIN;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RESOLVE, t_resolve); }
 
-		if (L.state == ST_RA_END) do {
+		if (L.state == ST_RA_END) { BT_PROF_T0(t_ra_end); do {
 			switch (L.ra_cont) {
 			case RC_STEP:
 				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
@@ -536,10 +551,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			default:       L.state = ST_SEARCH_END; break;
 			}
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RA_END, t_ra_end); }
 
 		/* ---- return from a frame -------------------------------------------------------- */
-		if (L.state == ST_FRAME_RETURN) do {
+		if (L.state == ST_FRAME_RETURN) { BT_PROF_T0(t_frame_return); do {
 			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - 1u;
 			L.sd = f;
@@ -571,10 +586,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.cchunk = 0xffu;
 			L.state = ST_CHILD_RET;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FRAME_RETURN, t_frame_return); }
 
 		/* ---- a child frame (or a leaf report) came back (:972-1064) ---------------------- */
-		if (L.state == ST_CHILD_RET) do {
+		if (L.state == ST_CHILD_RET) { BT_PROF_T0(t_child_ret); do {
 			if (L.ret) { L.state = ST_FRAME_RETURN; break; }
 			if (L.bailed || (L.halfAndHalf && P.steps[L.step].maxBts > 0 && L.numBts >= P.steps[L.step].maxBts)) {
 				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
@@ -598,6 +613,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				 * quality among positions that still have a target, (2) the tallies over the positions
 				 * of exactly that quality, deepest first. */
 				BT_COUNT(CN_RESCAN);
+				BT_PROF_T0(t_rescan);
 				L.lowAltQual = 0xff; L.candValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
 				if (L.d >= kmin) {
@@ -659,13 +675,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 						}
 					}
 				}
+				BT_PROF_ADD(PS_RESCAN, t_rescan);
 			}
 			L.state = ST_BT_LOOP;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_CHILD_RET, t_child_ret); }
 
 		/* ---- backtrack() exit (:333-353, 303-324) + the seedling-extension loop ---------- */
-		if (L.state == ST_SEARCH_END) do {
+		if (L.state == ST_SEARCH_END) { BT_PROF_T0(t_search_end); do {
 			L.numBts = 0;
 			if (L.kind == BT_KIND_EXTEND) {
 				/* search_seeded_phase3.c:9-59 / phase4.c:9-55: for each seedling, setMuts +
@@ -700,10 +717,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			if (L.ret) { bt_lane_finish(L, B); break; }
 			L.state = ST_PHASE_NEXT;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_SEARCH_END, t_search_end); }
 
 		/* ---- phase script ------------------------------------------------------------- */
-		if (L.state == ST_PHASE_NEXT) do {
+		if (L.state == ST_PHASE_NEXT) { BT_PROF_T0(t_phase_next); do {
 			L.step = L.step + 1u;        /* 5-bit wrap: 31 -> 0 */
 			if ((int32_t)L.step >= P.nsteps || (L.status & BT_STF_OVERFLOW)) { bt_lane_finish(L, B); break; }
 			const BtStep& st = P.steps[L.step];
@@ -728,10 +745,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			L.state = ST_SEARCH_BEGIN;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_PHASE_NEXT, t_phase_next); }
 
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
-		if (L.state == ST_SEARCH_BEGIN) do {
+		if (L.state == ST_SEARCH_BEGIN) { BT_PROF_T0(t_search_begin); do {
 			L.bailed = 0; L.sd = 0;
 			uint32_t nsInFtab = 0;
 			const uint32_t ftabChars = IXSEL(ftabChars);
@@ -781,10 +798,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER;
 			}
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_SEARCH_BEGIN, t_search_begin); }
 
 		/* ---- choose a backtrack target and descend (:743-971) --------------------------- */
-		if (L.state == ST_BT_LOOP) do {
+		if (L.state == ST_BT_LOOP) { BT_PROF_T0(t_bt_loop); do {
 			uint32_t i, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
 				bool found = L.candValid || bt_find_cand(L, S, L.d, CNT);
@@ -883,10 +900,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_BT_LOOP, t_bt_loop); }
 
 		/* ---- reportAlignment / reportFullAlignment (:1455-1565) -------------------------- */
-		if (L.state == ST_RA_BEGIN) do {
+		if (L.state == ST_RA_BEGIN) { BT_PROF_T0(t_ra_begin); do {
 			if (L.reportPartials) {
 				if (L.ra_sd > 0) bt_report_partial(L, S, L.ra_sd);
 				L.ret = 0; L.state = ST_RA_END; break;
@@ -906,9 +923,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			L.state = ST_ROW_BEGIN;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RA_BEGIN, t_ra_begin); }
 
-		if (L.state == ST_ROW_BEGIN) do {
+		if (L.state == ST_ROW_BEGIN) { BT_PROF_T0(t_row_begin); do {
 			const uint32_t spread = L.ra_bot - L.ra_top;
 			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
 			uint32_t ri = L.ra_r + L.ra_i;
@@ -916,10 +933,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.crow = ri; L.cjumps = 0;
 			L.state = ST_CHASE_CHECK;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
 
 		/* ---- frame prologue (:363-455) -------------------------------------------------- */
-		if (L.state == ST_FRAME_ENTER) do {
+		if (L.state == ST_FRAME_ENTER) { BT_PROF_T0(t_frame_enter); do {
 			BT_COUNT(CN_FRAMES);
 			if (L.halfAndHalf) {
 				const uint32_t maxBts = P.steps[L.step].maxBts;
@@ -932,7 +949,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.d = L.depth;
 			L.state = ST_STEP_BEGIN;
 			break;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FRAME_ENTER, t_frame_enter); }
 
 	}
 }
@@ -948,6 +965,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 	req.op = 0; req.rowA = 0; req.rowB = 0;
 	BT_NOUNROLL
 	for (;;) {
+		BT_PROF_T0(t_resume);
 		/* ---- resume: SA walk (reportChaseOne, ebwt.h:2727-2746) --------------------------- */
 		if (L.state == ST_CHASE_LFDONE) {
 			L.crow = res.LA == 0 ? res.a[0] : res.LA == 1 ? res.a[1] : res.LA == 2 ? res.a[2] : res.a[3];   /* mapLF(l) */
@@ -1037,8 +1055,9 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
 		}
 
+		BT_PROF_ADD(PS_RESUME, t_resume);
 		/* ---- everything else ---------------------------------------------------------------- */
-		if (BT_IS_SLOW(L.state)) bt_lane_slow(L, H, C, S, CNT);
+		{ BT_PROF_T0(t_slow); if (BT_IS_SLOW(L.state)) bt_lane_slow(L, H, C, S, CNT); BT_PROF_ADD(PS_SLOW, t_slow); }
 
 		/* ---- emit: next query position (:456-568) -------------------------------------------- */
 		if (L.state == ST_STEP_BEGIN) {

@@ -46,9 +46,9 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 template <int OCC>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
-	__shared__ unsigned long long CNT[CN_N];
+	__shared__ unsigned long long CNT[CN_N + PS_N];
 	__shared__ uint32_t TOS[13 * BT_BLOCK];          /* top-of-stack frame record per lane */
-	if (threadIdx.x < CN_N) CNT[threadIdx.x] = 0;
+	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
 	__syncthreads();
 
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,9 +79,13 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				if (drained) break;
 				const uint32_t rd = atomicAdd(A.nextRead, 1u);
 				if (rd >= A.H.n_reads) { drained = true; break; }
+				BT_PROF_T0(t_refill);
 				bt_lane_start(L, A.H, *cold, rd);
+				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
+			BT_PROF_T0(t_loop);
 			bt_lane_run(L, A.H, *cold, S, res, req, CNT);
+			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state != ST_IDLE) break;
 		}
 		if (L.state == ST_IDLE) break;
@@ -107,15 +111,17 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		sel.f1 = m ? A.H.fchr[1][1] : A.H.fchr[0][1];
 		sel.f2 = m ? A.H.fchr[1][2] : A.H.fchr[0][2];
 		sel.f3 = m ? A.H.fchr[1][3] : A.H.fchr[0][3];
+		BT_PROF_T0(t_rank);
 		dev_rank4(sel, req.rowA, res.a, &res.LA);
 		if (req.op & 2u) {
 			uint32_t dummy;
 			dev_rank4(sel, req.rowB, res.b, &dummy);
 		}
+		BT_PROF_ADD(PS_RANK, t_rank);
 	}
 
 	__syncthreads();
-	if (threadIdx.x < CN_N && A.counts) atomicAdd(&A.counts[threadIdx.x], CNT[threadIdx.x]);
+	if (threadIdx.x < CN_N + PS_N && A.counts) atomicAdd(&A.counts[threadIdx.x], CNT[threadIdx.x]);
 }
 
 __global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)

@@ -173,6 +173,9 @@ int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* o
 int  bt_ctx_sync(bt_ctx* ctx);
 /* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */
 uint32_t bt_ctx_last_mm_used(bt_ctx* ctx);
+/* diagnostics (profiling build of the library only; zeros otherwise): wavefront cycles spent per
+ * section of the automaton since the counters were last reset */
+int  bt_ctx_prof_sections(bt_ctx* ctx, uint64_t* out, int n);
 /* diagnostics: device buffer [n_reads] that receives, per read, the number of lock-step LF rounds it
  * took (NULL = off; stays set for later batches) */
 void bt_ctx_set_iters_buffer(bt_ctx* ctx, uint32_t* dev_ptr);
