@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = workload default)")
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
+    ap.add_argument("--pipes", type=int, default=2, help="contexts/streams the steps are pipelined over")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
     args = ap.parse_args()
@@ -155,52 +156,75 @@ def main():
     rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
     del text_t
     hit_cap = 1
-    hits = torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev)
-    n_hits = torch.zeros(n, dtype=torch.int32, device=dev)
-    status = torch.zeros(n, dtype=torch.uint8, device=dev)
     mm_cap = n * 8
-    mm_pool = torch.zeros(mm_cap, dtype=torch.int16, device=dev)
+    pol = A.make_policy(**wl["pol"])
+    lib = AL.lib()
+    # Software pipelining across steps: `--pipes` contexts, each with its own HIP stream, scratch and
+    # output buffers, take the steps round-robin.  A step's last few long-running reads (the
+    # backtracking tail) then drain while the next step's wavefronts already fill the machine --
+    # what a host driver double-buffering read batches does.
+    pipes = []
+    for pi in range(max(1, args.pipes)):
+        st = torch.cuda.current_stream() if pi == 0 else torch.cuda.Stream()
+        o = dict(stream=st,
+                 hits=torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev),
+                 n_hits=torch.zeros(n, dtype=torch.int32, device=dev),
+                 status=torch.zeros(n, dtype=torch.uint8, device=dev),
+                 mm_pool=torch.zeros(mm_cap, dtype=torch.int16, device=dev), busy=False)
+        o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
+        o["hbc"] = A.HitBatchC(hit_cap, o["hits"].data_ptr(), o["n_hits"].data_ptr(), o["status"].data_ptr(),
+                               o["mm_pool"].data_ptr(), mm_cap, 0)
+        pipes.append(o)
     torch.cuda.synchronize()
     log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
-
-    pol = A.make_policy(**wl["pol"])
-    stream = torch.cuda.current_stream().cuda_stream
-    al = AL.Aligner(idx, pol, stream=stream)
     rbc = A.ReadBatchC(n, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(),
                        rb["seed"].data_ptr())
-    hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), mm_pool.data_ptr(), mm_cap, 0)
-    lib = AL.lib()
+    n_hits, status = pipes[0]["n_hits"], pipes[0]["status"]
     iters_t = None
     if args.iters_hist:
         iters_t = torch.zeros(n, dtype=torch.int32, device=dev)
-        lib.bt_ctx_set_iters_buffer(al._h, iters_t.data_ptr())
+        lib.bt_ctx_set_iters_buffer(pipes[0]["al"]._h, iters_t.data_ptr())
+    kernel_ms = []
 
-    def step():
-        rc = lib.bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None)
+    def retire(o):
+        if o["busy"]:
+            if lib.bt_ctx_sync(o["al"]._h) != 0:
+                raise RuntimeError("bt_ctx_sync failed")
+            kernel_ms.append(float(lib.bt_ctx_last_kernel_ms(o["al"]._h)))   # HIP events on the kernel's stream
+            o["busy"] = False
+
+    def step(k):
+        o = pipes[k % len(pipes)]
+        retire(o)
+        rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(o["hbc"]), None)
         if rc != 0:
             raise RuntimeError("bt_align_batch_device: " + AL.strerror(rc))
+        o["busy"] = True
 
     def barrier():
+        for o in pipes:
+            retire(o)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     barrier()
     cnt = A.OpCounts()
-    lib.bt_ctx_counts(al._h, C.byref(cnt), 1)        # reset: count the timed steps only
-    kernel_ms = []
+    for o in pipes:
+        lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 1)        # reset: count the timed steps only
+    kernel_ms.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if lib.bt_ctx_sync(al._h) != 0:
-            raise RuntimeError("bt_ctx_sync failed")
-        kernel_ms.append(float(lib.bt_ctx_last_kernel_ms(al._h)))   # HIP events on the kernel's stream
+    for k in range(args.steps):
+        step(k)
     barrier()
     wall = time.perf_counter() - t0
-    lib.bt_ctx_counts(al._h, C.byref(cnt), 0)
-    c = cnt.as_dict()
+    c = {}
+    for o in pipes:
+        lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 0)
+        for kk, v in cnt.as_dict().items():
+            c[kk] = c.get(kk, 0) + v
 
     if iters_t is not None and rank == 0:
         it = iters_t.to(torch.float64)
@@ -232,6 +256,7 @@ def main():
                        "policy": wl["pol"], "reads_per_gpu_per_step": n,
                        "reads_with_alignment_per_s": aligned_all * args.steps / wall,
                        "pct_aligned": 100.0 * aligned_all / reads_all, "reads_overflowed": bad_all,
+                       "pipelined_contexts": len(pipes),
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

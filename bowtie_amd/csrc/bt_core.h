@@ -83,14 +83,16 @@ enum {
 };
 
 struct BtScratch {
-	uint32_t* frames;                        /* [frame][16]: one 64-byte record per backtrack level */
-	uint32_t* pairs;                         /* [entry][8]: tops ACGT, bots ACGT                 */
-	uint16_t* meta;                          /* [entry] eliminated-chars mask | Phred<<8          */
-	uint64_t* pals;                          /* [palCap] seedlings                                */
+	/* arena bases (wave-uniform) + this lane's slot; addresses are formed where they are used so
+	 * that no per-lane 64-bit pointers have to live in registers across the lock-step loop */
+	uint32_t* frames;   /* [slot][frame][16]: one 64-byte record per backtrack level              */
+	uint32_t* pairs;    /* [slot][entry][8]: tops ACGT, bots ACGT                                  */
+	uint16_t* meta;     /* [slot][entry] eliminated-chars mask | Phred<<8                          */
+	uint64_t* pals;     /* [slot][palCap] seedlings                                                */
 	uint32_t* tos;      uint32_t tosStride;  /* LDS copy of the most recently pushed frame record:
 	                                            word w at tos[w*tosStride] (a failed child pops it
 	                                            back without a trip to HBM)                         */
-	uint32_t  frCap, entCap, palCap;
+	uint32_t  slot, frCap, entCap, palCap;
 };
 
 /* ---- batch-level arguments --------------------------------------------------------------- */
@@ -284,9 +286,11 @@ BT_HD void bt_qq_cached(BtLane& L, const BtHot& H, uint32_t i, uint32_t* c_out, 
 	*q_out = v >= 33u ? v - 33u : 0u;
 }
 
-#define FRW(f, w) S.frames[(f) * BT_FR_WORDS + (w)]
-#define PT(e, c) S.pairs[(e) * 8u + (c)]
-#define PB(e, c) S.pairs[(e) * 8u + 4u + (c)]
+#define FRW(f, w) S.frames[((uint64_t)S.slot * S.frCap + (f)) * BT_FR_WORDS + (w)]
+#define PT(e, c) S.pairs[((uint64_t)S.slot * S.entCap + (e)) * 8u + (c)]
+#define PB(e, c) S.pairs[((uint64_t)S.slot * S.entCap + (e)) * 8u + 4u + (c)]
+#define META(e) S.meta[(uint64_t)S.slot * S.entCap + (e)]
+#define PALS(k) S.pals[(uint64_t)S.slot * S.palCap + (k)]
 #define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
 #define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
 
@@ -325,7 +329,7 @@ BT_HD void bt_report_partial(BtLane& L, const BtScratch& S, uint32_t sd)
 	if (sd > 1) { uint32_t mm = FRW(1, FR_MM); p1 = mm & 0xffffu; c1 = (mm >> 16) & 3u; }
 	if (sd > 2) { uint32_t mm = FRW(2, FR_MM); p2 = mm & 0xffffu; c2 = (mm >> 16) & 3u; }
 	uint64_t al = p0 | (p1 << 16) | (p2 << 32) | (c0 << 48) | (c1 << 50) | (c2 << 52) | (0xffull << 54) | (3ull << 62);
-	if (L.npals < S.palCap) { S.pals[L.npals] = al; L.npals = L.npals + 1u; }
+	if (L.npals < S.palCap) { PALS(L.npals) = al; L.npals = L.npals + 1u; }
 	else L.status = L.status | BT_STF_OVERFLOW;
 }
 
@@ -449,7 +453,7 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 struct BtMeta8 { uint32_t w[4]; };
 BT_HD BtMeta8 bt_meta_load8(const BtScratch& S, uint32_t chunk)
 {
-	const uint32_t* p = (const uint32_t*)(S.meta + (uint64_t)chunk * 8u);
+	const uint32_t* p = (const uint32_t*)(&META(0) + (uint64_t)chunk * 8u);
 	BtMeta8 m; m.w[0] = p[0]; m.w[1] = p[1]; m.w[2] = p[2]; m.w[3] = p[3];
 	return m;
 }
@@ -597,7 +601,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			{
 				const uint32_t e = L.ebase + (L.pi - L.depth);
 				const uint32_t el = L.pel | (1u << L.pj);           /* the mask travelled with the frame record */
-				((uint8_t*)S.meta)[2u * e] = (uint8_t)el;
+				((uint8_t*)&META(e))[0] = (uint8_t)el;
 				if (el == 15u) L.candValid = 0;             /* that position is exhausted: re-scan next time */
 				if (L.eli == L.pi) L.elel = el;
 			}
@@ -692,7 +696,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				L.nmuts = 0;
 				if (L.palIdx >= L.npals) { L.state = ST_PHASE_NEXT; break; }
 				/* PartialAlignmentManager::toMutsString (ebwt_search_util.h:310-362) */
-				const uint64_t pal = S.pals[L.palIdx];
+				const uint64_t pal = PALS(L.palIdx);
 				const uint32_t p0 = (uint32_t)(pal & 0xffffu), p1 = (uint32_t)((pal >> 16) & 0xffffu), p2 = (uint32_t)((pal >> 32) & 0xffffu);
 				uint32_t oldQuals = 0, nm = 1;
 				const uint32_t t0 = L.plen - 1u - p0;
@@ -809,7 +813,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 					found = false;
 					i = L.cand;
 					const uint32_t e = L.ebase + (i - L.depth);
-					const uint32_t mv = S.meta[e];
+					const uint32_t mv = META(e);
 					const uint32_t el = mv & 15u, qi = mv >> 8;
 					L.pel = el;
 					uint32_t sp[4], tp[4];
@@ -1021,7 +1025,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 				if (L.fl_elig && el != 15u) { L.cand = d; L.candValid = 1; }     /* deepest eligible target so far */
 				if (L.eli == d && !L.elignore) L.elel = el;
 			}
-			S.meta[e] = (uint16_t)(el | (q << 8));
+			META(e) = (uint16_t)(el | (q << 8));
 			bool btDespite = false, reportedPartial = false;
 			if (cur == 0 && L.top < L.bot && L.sd < L.reportPartials && L.reportPartials > 0) {
 				if (L.altNum > 0) btDespite = true;
@@ -1118,6 +1122,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 #undef FRW
 #undef PT
 #undef PB
+#undef META
+#undef PALS
 #undef IXSEL
 #undef HSEL
 #endif /* BT_CORE_H_ */

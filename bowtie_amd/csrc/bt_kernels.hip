@@ -53,10 +53,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BtScratch S;
-	S.frames = A.frames + (uint64_t)g * A.frCap * BT_FR_WORDS;
-	S.pairs = A.pairs + (uint64_t)g * A.entCap * 8u;
-	S.meta = A.meta + (uint64_t)g * A.entCap;
-	S.pals = A.pals + (uint64_t)g * A.palCap;
+	S.frames = A.frames; S.pairs = A.pairs; S.meta = A.meta; S.pals = A.pals; S.slot = g;
 	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 

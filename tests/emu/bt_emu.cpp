@@ -83,9 +83,9 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		memset(&lanes[g], 0, sizeof(BtLane));
 		memset(&res[g], 0, sizeof(BtRes));
 		lanes[g].state = ST_IDLE;
-		scr[g].frames = (uint32_t*)(frames4.data() + (size_t)g * frCap * 4);
-		scr[g].pairs = (uint32_t*)(pairs4.data() + (size_t)g * entCap * 2); scr[g].meta = meta.data() + (size_t)g * entCap;
-		scr[g].pals = pals.data() + (size_t)g * palCap;
+		scr[g].frames = (uint32_t*)frames4.data(); scr[g].slot = g;
+		scr[g].pairs = (uint32_t*)pairs4.data(); scr[g].meta = meta.data();
+		scr[g].pals = pals.data();
 		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
 		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
 	}
