@@ -262,7 +262,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "bt_search_kernel", "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": abytes,
-                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans")},
+                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n,
                          "mean_active_lanes_per_round": per_launch["lane_iters"] / max(1.0, per_launch["wave_rounds"]),
                          "wave_rounds_per_launch": per_launch["wave_rounds"]},

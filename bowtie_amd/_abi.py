@@ -34,7 +34,7 @@ class HitBatchC(C.Structure):
 
 class OpCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters", "same_pair", "rescans", "cand_scans", "wave_rounds")]
+                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters", "same_pair", "rescans", "cand_scans", "wave_rounds", "fetches")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -86,9 +86,10 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 		bt_host_index_describe(h, &d);
 		int r2;
 		/* pad the ebwt image by one side pair so that the partner-counter load of the last side
-		 * never leaves the allocation */
-		if ((r2 = upload(ix, h.ebwt, &d.ebwt, 128)) || (r2 = upload(ix, h.ftab, &d.ftab)) ||
-		    (r2 = upload(ix, h.eftab, &d.eftab)) || (r2 = upload(ix, h.offs, &d.offs)) ||
+		 * never leaves the allocation; ftab / offs by one 16-byte piece (they are fetched in aligned
+		 * 16-byte pieces) */
+		if ((r2 = upload(ix, h.ebwt, &d.ebwt, 128)) || (r2 = upload(ix, h.ftab, &d.ftab, 4)) ||
+		    (r2 = upload(ix, h.eftab, &d.eftab)) || (r2 = upload(ix, h.offs, &d.offs, 4)) ||
 		    (r2 = upload(ix, h.rstarts, &d.rstarts)) || (r2 = upload(ix, h.plen, &d.plen))) {
 			bt_index_free(ix); return r2;
 		}
@@ -234,7 +235,8 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	for (int m = 0; m < 2; m++) {
 		const BtIndexDev& d = c->idx->dev[m];
 		A.H.ebwt[m] = d.ebwt; A.H.zSide[m] = d.zSide; A.H.zSym[m] = d.zSym; A.H.zOff[m] = d.zOff;
-		A.H.offMask[m] = d.offMask;
+		A.H.offMask[m] = d.offMask; A.H.ftab[m] = d.ftab; A.H.offs[m] = d.offs; A.H.offRate[m] = d.offRate;
+		A.H.ftabChars[m] = d.ftabChars; A.H.len[m] = d.len;
 		for (int k = 0; k < 5; k++) A.H.fchr[m][k] = d.fchr[k];
 	}
 	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
@@ -299,7 +301,7 @@ extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 	HIPCHK(hipMemcpy(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost));
 	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
 	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
-	out->lane_iters = h[8]; out->same_pair = h[9]; out->rescans = h[10]; out->cand_scans = h[11]; out->wave_rounds = h[12];
+	out->lane_iters = h[8]; out->same_pair = h[9]; out->rescans = h[10]; out->cand_scans = h[11]; out->wave_rounds = h[12]; out->fetches = h[13];
 	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
 	return BT_OK;
 }

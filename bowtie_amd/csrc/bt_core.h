@@ -8,25 +8,25 @@
  * 1118-1655), the SA walk + offset resolution (Ebwt::reportChaseOne / joinedToTextOff,
  * ebwt.h:2569-2755) and the per-read hit-sink policy (hit.h:969-985, 1201-1209).
  *
- * How it computes it is not the reference's way.  The reference recurses and performs each
- * rank query inline.  Here every read is an explicit-stack automaton that runs until it needs
- * the next LF-mapping, hands a BtReq (one or two BWT rows) to its caller and is resumed with the
- * BtRes.  The caller -- the HIP kernel in bt_kernels.hip -- advances the 64 reads of a wavefront
- * in lock step, so that all rank gathers of a wavefront are issued together, independent of
- * which phase / frame / SA walk each individual read is in.
+ * How it computes it is not the reference's way.  The reference recurses and touches memory
+ * wherever the algorithm happens to need it.  Here every read is an explicit-stack automaton with
+ * ONE rule: *a lane issues at most one memory request per round and never waits inside a round*.
+ * Whenever the automaton needs data that is not in registers or LDS -- the next LF-mapping (rank
+ * over one or two BWT rows), the next 16 bases of the read, the (top,bot) ranges of a backtrack
+ * target, a popped frame record, a batch of (mask,quality) records to re-scan, an ftab entry, an
+ * SA sample -- it describes the request (BtReq), returns, and is resumed in the next round with
+ * the data (BtRes).  The caller -- the HIP kernel in bt_kernels.hip -- advances the 64 reads of a
+ * wavefront in lock step, issues the requests of all lanes back to back and waits once; which
+ * phase / frame / SA walk each individual read is in does not matter.  Stores are fire-and-forget.
  *
- *   lane state   : BtLane -- bit-packed so the whole automaton lives in ~50 VGPRs
- *   read window  : 16 bases + 16 qualities of the read, cached in registers (the query is
- *                  consumed one position per LF step, so one 2x16-byte fetch serves 16 steps)
- *   frame stack  : one 64-byte record per backtrack level, HBM scratch              (FR_*)
-  *   range stack  : per visited query position, the 4x(top,bot) ranges plus (eliminated-
- *                  alternatives mask, quality); compact (a child frame starts where its parent stopped)
+ *   lane state   : BtLane -- bit-packed, lives in VGPRs
+ *   read window  : 16 bases + 16 qualities of the read around the current position (registers)
+ *   frame stack  : one 48-byte record per backtrack level in HBM scratch, the most recently
+ *                  pushed one also in LDS (a failed child pops it back without a fetch)
+ *   range stack  : per visited query position the 4x(top,bot) ranges (32 B) and a 16-bit
+ *                  (eliminated-chars mask | Phred<<8) record; compact -- a child frame starts
+ *                  where its parent stopped
  *   seedlings    : packed partial alignments of the -n seed phases (ebwt_search_util.h:37-88)
- *
- * Control flow is arranged so that the common transitions (query step -> LF -> query step, and
- * SA-walk step -> LF -> SA-walk step) take one pass through bt_lane_run; everything else
- * (backtrack-target choice, frame push/pop, reporting, phase changes) runs in the "slow" inner
- * loop of the same pass.
  *
  * This header is plain C++ that compiles for gfx950 (hipcc) and for the host; the host build
  * exists only so the automaton can be unit-tested against the oracle without a GPU
@@ -68,30 +68,28 @@ struct BtProgram {
 };
 
 /* ---- per-lane scratch in HBM ------------------------------------------------------------- */
-#define BT_FR_WORDS 16
+#define BT_FR_WORDS 12       /* 48-byte frame record = three 16-byte pieces                     */
 enum {
-	FR_W0 = 0,   /* depth | d<<11                                   */
-	FR_W1,       /* ham | lowAltQual<<16 | elham<<24                */
-	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25 */
-	FR_W3,       /* f2 | f3<<11                                     */
-	FR_W4,       /* altNum | eligibleNum<<12                        */
-	FR_ELIGSZ, FR_ELTOP, FR_ELBOT,
-	FR_W8,       /* eli | cand<<11 | elel<<22                       */
-	FR_W9,       /* pi | pj<<11 | pel<<13                           */
+	FR_W0 = 0,   /* depth | d<<11                                                                */
+	FR_W1,       /* ham | lowAltQual<<16                                                         */
+	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25                      */
+	FR_W3,       /* f2 | f3<<11                                                                  */
+	FR_W4,       /* altNum | eligibleNum<<12                                                     */
+	FR_W5,       /* cand                                                                         */
+	FR_W6,       /* pi | pj<<11 | pel<<13                                                        */
 	FR_PTOP, FR_PBOT, FR_EBASE,
-	FR_MM        /* mismatch chosen at this level: query offset | refc<<16                        */
+	FR_MM,       /* mismatch chosen at this level: query offset | refc<<16                       */
+	FR_PAD
 };
+#define BT_TOS_WORDS 10      /* FR_W0..FR_EBASE travel to the LDS top-of-stack copy              */
 
 struct BtScratch {
-	/* arena bases (wave-uniform) + this lane's slot; addresses are formed where they are used so
-	 * that no per-lane 64-bit pointers have to live in registers across the lock-step loop */
-	uint32_t* frames;   /* [slot][frame][16]: one 64-byte record per backtrack level              */
-	uint32_t* pairs;    /* [slot][entry][8]: tops ACGT, bots ACGT                                  */
-	uint16_t* meta;     /* [slot][entry] eliminated-chars mask | Phred<<8                          */
-	uint64_t* pals;     /* [slot][palCap] seedlings                                                */
-	uint32_t* tos;      uint32_t tosStride;  /* LDS copy of the most recently pushed frame record:
-	                                            word w at tos[w*tosStride] (a failed child pops it
-	                                            back without a trip to HBM)                         */
+	/* arena bases (wave-uniform) + this lane's slot; addresses are formed where they are used */
+	uint32_t* frames;   /* [slot][frame][12]                                                     */
+	uint32_t* pairs;    /* [slot][entry][8]: tops ACGT, bots ACGT                                */
+	uint16_t* meta;     /* [slot][entry] eliminated-chars mask | Phred<<8                        */
+	uint64_t* pals;     /* [slot][palCap] seedlings                                              */
+	uint32_t* tos;      uint32_t tosStride;  /* LDS: word w of the top-of-stack record at tos[w*tosStride] */
 	uint32_t  slot, frCap, entCap, palCap;
 };
 
@@ -108,16 +106,17 @@ struct BtBatchDev {
 	BtHitRec* hits; uint32_t hit_cap;
 	uint32_t* n_hits; uint8_t* status;
 	uint16_t* mm_pool; uint32_t mm_pool_cap; uint32_t* mm_pool_used;
-	uint32_t* iters;                        /* optional [n_reads]: lock-step iterations the read took   */
+	uint32_t* iters;                        /* optional [n_reads]: lock-step rounds the read took       */
 };
 
 /* Arguments split by temperature.  BtHot is passed by value (kernarg -> SGPRs) and holds only what
  * the per-position / per-SA-step code touches; BtCold lives in device memory and is read where
- * it is used (phase changes, frame pushes, reporting), so that the 1 KB of program + index
- * descriptors does not sit in scalar registers across the lock-step loop. */
+ * it is used (phase changes, reporting). */
 struct BtHot {
 	const uint8_t* ebwt[2];
-	uint32_t zSide[2], zSym[2], zOff[2], offMask[2];
+	const uint32_t* ftab[2];
+	const uint32_t* offs[2];
+	uint32_t zSide[2], zSym[2], zOff[2], offMask[2], offRate[2], ftabChars[2], len[2];
 	uint32_t fchr[2][5];
 	const uint8_t* seq; const uint8_t* qual;
 	uint32_t stride, n_reads;
@@ -134,39 +133,38 @@ struct BtCold {
 #define BT_STF_OVERFLOW  8u     /* a per-read scratch capacity was exceeded; results invalid      */
 #define BT_STF_MMPOOL    16u    /* mm_pool exhausted; hit stored without its mismatch list        */
 
-/* ---- LF request / response --------------------------------------------------------------- */
-struct BtReq { uint32_t rowA, rowB; uint32_t op; };     /* op bit0: rank at rowA, bit1: at rowB    */
-struct BtRes { uint32_t a[4], b[4], LA; };
+/* ---- the one memory request of a round, and its answer -------------------------------------- */
+enum { RQ_NONE = 0, RQ_RANK = 1, RQ_FETCH = 2 };
+struct BtReq {
+	uint32_t kind;          /* RQ_*                                                               */
+	uint32_t n;             /* RANK: 1 or 2 rows; FETCH: 16-byte pieces at a (1..4)               */
+	/* RANK : a = rowA, x = rowB
+	 * FETCH: a = address of n contiguous 16-byte pieces -> res.q[0..n)
+	 *        x = address of an optional extra 16-byte piece -> res.x (0 = none) */
+	uint64_t a, x;
+};
+struct BtRes {
+	BtU4 q[4];              /* RANK: q[0] = LF(rowA, ACGT), q[1] = LF(rowB, ACGT), q[2].x = BWT char at rowA */
+	BtU4 x;
+};
 
 enum {
 	ST_IDLE = 0,
 	/* fast states */
-	ST_STEP_BEGIN, ST_STEP_LFDONE, ST_STEP_POST, ST_CHASE_CHECK, ST_CHASE_LFDONE,
+	ST_STEP_BEGIN, ST_STEP_LFDONE, ST_STEP_POST, ST_CHASE_CHECK, ST_CHASE_LFDONE, ST_WIN_DONE,
 	/* slow states */
-	ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FRAME_ENTER, ST_BT_LOOP, ST_CHILD_RET, ST_FRAME_RETURN,
-	ST_FELL_OFF, ST_RA_BEGIN, ST_ROW_BEGIN, ST_RESOLVE, ST_RA_END, ST_SEARCH_END
+	ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FTABSEQ_DONE, ST_FTAB_DONE, ST_FRAME_ENTER, ST_BT_LOOP, ST_BT_PICK,
+	ST_CANDSCAN, ST_CANDSCAN_DONE, ST_CHILD_RET, ST_RESCAN, ST_RESCAN_DONE, ST_FRAME_RETURN,
+	ST_FRAME_FETCHED, ST_FELL_OFF, ST_RA_BEGIN, ST_ROW_BEGIN, ST_RESOLVE_DONE, ST_RA_END, ST_SEARCH_END,
+	ST_ABORT
 };
 #define BT_IS_SLOW(st) ((st) >= ST_PHASE_NEXT)
 enum { RC_STEP = 0, RC_CHILD, RC_FELL, RC_ENTRY };
-enum { LFK_EX2 = 0, LFK_C2, LFK_LF1 };
-
-/* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
- * cycles (s_memtime) spent in each block of the automaton, accumulated per block in LDS.  No-ops in
- * the product build. */
-enum { PS_RESUME = 0, PS_SLOW, PS_EMIT, PS_RANK, PS_REFILL, PS_LOOP,
-       PS_FELL_OFF, PS_RESOLVE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_SEARCH_END, PS_PHASE_NEXT,
-       PS_SEARCH_BEGIN, PS_BT_LOOP, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_RESCAN, PS_N };
-#if defined(BT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-#define BT_PROF_T0(v) const unsigned long long v = __builtin_readcyclecounter()
-#define BT_PROF_ADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
-	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + (k)], __builtin_readcyclecounter() - (v)); } while (0)
-#else
-#define BT_PROF_T0(v)
-#define BT_PROF_ADD(k, v)
-#endif
+enum { LFK_EX2 = 0, LFK_C2, LFK_LF1, LFK_CHASE };
 
 /* op counters (bt_op_counts order) */
-enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR, CN_RESCAN, CN_CANDSCAN, CN_WROUNDS, CN_N };
+enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR,
+       CN_RESCAN, CN_CANDSCAN, CN_WROUNDS, CN_FETCH, CN_N };
 #if defined(__HIP_DEVICE_COMPILE__)
 /* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
 #define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)
@@ -176,9 +174,21 @@ enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_F
 #define BT_COUNT_N(k, n) (CNT[k] += (n))
 #endif
 
+/* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
+ * cycles (s_memtime) per section, accumulated in LDS.  No-ops in the product build. */
+enum { PS_RESUME = 0, PS_SLOW, PS_WAIT, PS_RANK, PS_REFILL, PS_LOOP, PS_N };
+#if defined(BT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define BT_PROF_T0(v) const unsigned long long v = __builtin_readcyclecounter()
+#define BT_PROF_ADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
+	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + (k)], __builtin_readcyclecounter() - (v)); } while (0)
+#else
+#define BT_PROF_T0(v)
+#define BT_PROF_ADD(k, v)
+#endif
+
 struct BtLane {
 	/* read */
-	uint32_t rd;
+	uint32_t rd, seed;
 	uint64_t roff;                   /* rd * stride */
 	uint32_t plen : 11, status : 8, step : 5, kind : 2, nmuts : 2, palIdxBefore : 1, hasN : 1;
 	uint32_t nhits;
@@ -196,18 +206,17 @@ struct BtLane {
 	/* current frame (locals of backtrack(), ebwt_search_backtrack.h:363-455) */
 	uint32_t sd : 7, depth : 11, d : 11;
 	uint32_t top, bot;
-	uint32_t ham : 16, lowAltQual : 8, elham : 8;
+	uint32_t ham : 16, lowAltQual : 8;
 	uint32_t fu : 11, f1 : 11, elcint : 2, elignore : 1, candValid : 1;
 	uint32_t f2 : 11, f3 : 11;
 	uint32_t altNum : 12, eligibleNum : 12;
-	uint32_t eligibleSz, eltop, elbot;
-	uint32_t eli : 11, cand : 11;
+	uint32_t cand : 11, scanCb : 16;         /* scanCb: next chunk (8 records) of a running frame scan */
 	uint32_t ebase;
-	/* per-position temporaries that live across the LF wait + control */
+	/* per-position temporaries that live across the wait + control */
 	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, state : 5, ra_cont : 2;
 	/* pending backtrack target */
 	uint32_t pi : 11, pj : 2, btham : 16;
-	uint32_t pel : 4, elel : 4, tosFrame : 7, tosValid : 1;
+	uint32_t pel : 4, tosFrame : 7, tosValid : 1;
 	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
@@ -247,7 +256,7 @@ BT_HD uint32_t bt_apply_muts(const BtLane& L, uint32_t i, uint32_t c)
 	return c;
 }
 /* query char / quality at index i of the string setQuery selected (ebwt_search_backtrack.h:90-140),
- * with the seedling mutations applied (:1368-1382).  Direct (uncached) form. */
+ * with the seedling mutations applied (:1368-1382).  Direct (synchronous) form: rare paths only. */
 BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
@@ -266,24 +275,13 @@ BT_HD uint32_t bt_sel4(uint32_t k, uint32_t w0, uint32_t w1, uint32_t w2, uint32
 	uint32_t lo = (k & 1u) ? w1 : w0, hi = (k & 1u) ? w3 : w2;
 	return (k & 2u) ? hi : lo;
 }
-/* Windowed form used by the per-position step: one 2 x 16-byte fetch per 16 positions. */
-BT_HD void bt_qq_cached(BtLane& L, const BtHot& H, uint32_t i, uint32_t* c_out, uint32_t* q_out)
+BT_HD uint32_t bt_u4_word(const BtU4& v, uint32_t k) { return bt_sel4(k, v.x, v.y, v.z, v.w); }
+BT_HD uint32_t bt_u4_byte(const BtU4& v, uint32_t b) { return (bt_u4_word(v, (b >> 2) & 3u) >> ((b & 3u) * 8u)) & 0xffu; }
+/* the 16-bit record k (0..7) of a fetched chunk of the (mask,quality) array */
+BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 {
-	const uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	const uint32_t chunk = j >> 4;
-	if (chunk != L.cchunk) {
-		const uint32_t* ps = (const uint32_t*)(H.seq + L.roff + (uint64_t)chunk * 16u);
-		const uint32_t* pq = (const uint32_t*)(H.qual + L.roff + (uint64_t)chunk * 16u);
-		L.cs0 = ps[0]; L.cs1 = ps[1]; L.cs2 = ps[2]; L.cs3 = ps[3];
-		L.cq0 = pq[0]; L.cq1 = pq[1]; L.cq2 = pq[2]; L.cq3 = pq[3];
-		L.cchunk = chunk;
-	}
-	const uint32_t k = (j >> 2) & 3u, sh = (j & 3u) * 8u;
-	uint32_t c = (bt_sel4(k, L.cs0, L.cs1, L.cs2, L.cs3) >> sh) & 0xffu;
-	uint32_t v = (bt_sel4(k, L.cq0, L.cq1, L.cq2, L.cq3) >> sh) & 0xffu;
-	if (!L.readFw && c < 4u) c ^= 3u;
-	*c_out = bt_apply_muts(L, i, c);
-	*q_out = v >= 33u ? v - 33u : 0u;
+	const uint32_t w = bt_u4_word(v, (k >> 1) & 3u);
+	return (k & 1u) ? (w >> 16) : (w & 0xffffu);
 }
 
 #define FRW(f, w) S.frames[((uint64_t)S.slot * S.frCap + (f)) * BT_FR_WORDS + (w)]
@@ -293,11 +291,31 @@ BT_HD void bt_qq_cached(BtLane& L, const BtHot& H, uint32_t i, uint32_t* c_out, 
 #define PALS(k) S.pals[(uint64_t)S.slot * S.palCap + (k)]
 #define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
 #define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
+#define HFCHR(k) (L.mirror ? H.fchr[1][k] : H.fchr[0][k])
+#define ST_IS(x) (L.state == (x) && req.kind == RQ_NONE)
+
+#define BT_REQ_RANK1(R) do { req.kind = RQ_RANK; req.n = 1; req.a = (R); } while (0)
+#define BT_REQ_RANK2(RA, RB) do { req.kind = RQ_RANK; req.n = 2; req.a = (RA); req.x = (RB); } while (0)
+#define BT_REQ_FETCH(PA, N, PX) do { req.kind = RQ_FETCH; req.n = (N); req.a = (uint64_t)(uintptr_t)(const void*)(PA); req.x = (uint64_t)(uintptr_t)(const void*)(PX); } while (0)
 
 BT_HD uint32_t bt_off_code(uint32_t plen, uint32_t qs, uint32_t code)
 {
 	return code == BT_OC_ZERO ? 0u : code == BT_OC_PLEN ? plen : code == BT_OC_S ? qs :
 	       code == BT_OC_S3 ? (qs >> 1) : ((qs >> 1) + (qs & 1u));
+}
+
+/* current position through the register window; false if the window has to be fetched first */
+BT_HD bool bt_window_get(const BtLane& L, uint32_t i, uint32_t* c_out, uint32_t* q_out)
+{
+	const uint32_t j = L.rev ? (L.plen - 1u - i) : i;
+	if ((j >> 4) != L.cchunk) return false;
+	const uint32_t k = (j >> 2) & 3u, sh = (j & 3u) * 8u;
+	uint32_t c = (bt_sel4(k, L.cs0, L.cs1, L.cs2, L.cs3) >> sh) & 0xffu;
+	uint32_t v = (bt_sel4(k, L.cq0, L.cq1, L.cq2, L.cq3) >> sh) & 0xffu;
+	if (!L.readFw && c < 4u) c ^= 3u;
+	*c_out = bt_apply_muts(L, i, c);
+	*q_out = v >= 33u ? v - 33u : 0u;
+	return true;
 }
 
 /* hhCheckTop (ebwt_search_backtrack.h:1200-1275) */
@@ -335,12 +353,12 @@ BT_HD void bt_report_partial(BtLane& L, const BtScratch& S, uint32_t sd)
 
 /* Start read `rd`: the worker-loop prologue (ebwt_search.cpp:1675-1683, 2167-2175, 2572-2584;
  * search_seeded_phase1.c:17-44). */
-BT_HD void bt_lane_start(BtLane& L, const BtHot& H, const BtCold& C, uint32_t rd)
+BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, uint32_t rd)
 {
-	const BtProgram& P = C.P;
 	L.rd = rd;
 	L.roff = (uint64_t)rd * H.stride;
 	L.plen = C.B.len[rd];
+	L.seed = C.B.seed[rd];
 	L.nhits = 0; L.stored = 0; L.status = 0;
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
@@ -447,72 +465,42 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 	do { L.ra_sd = (SD); L.ra_top = (TOP); L.ra_bot = (BOT); L.ra_cost = (COST); L.ra_cont = (CONT); \
 	     L.state = ST_RA_BEGIN; } while (0)
 
-/* The (mask, quality) records of a frame are scanned 8 at a time (one 16-byte load per 8 query
- * positions) so that a scan costs a handful of independent loads instead of one dependent load per
- * position. */
-struct BtMeta8 { uint32_t w[4]; };
-BT_HD BtMeta8 bt_meta_load8(const BtScratch& S, uint32_t chunk)
+/* A frame scan (re-scan for the next eligible quality, or search for the deepest remaining target)
+ * walks the frame's (mask,quality) records from the deepest position down, 32 records = four
+ * 16-byte chunks = one fetch per round.  Request the next batch: chunks lo..scanCb. */
+BT_HD void bt_scan_request(const BtLane& L, const BtScratch& S, uint32_t c_lo, BtReq& req)
 {
-	const uint32_t* p = (const uint32_t*)(&META(0) + (uint64_t)chunk * 8u);
-	BtMeta8 m; m.w[0] = p[0]; m.w[1] = p[1]; m.w[2] = p[2]; m.w[3] = p[3];
-	return m;
-}
-BT_HD uint32_t bt_meta_get(const BtMeta8& m, uint32_t k)       /* k in 0..7 */
-{
-	const uint32_t w = bt_sel4(k >> 1, m.w[0], m.w[1], m.w[2], m.w[3]);
-	return (k & 1u) ? (w >> 16) : (w & 0xffffu);
-}
-
-/* Deepest position in [depth, from] that still has a backtrack target of the current eligible
- * quality (the `for(; i >= depth; i--)` walk of ebwt_search_backtrack.h:767-812). */
-BT_HD bool bt_find_cand(BtLane& L, const BtScratch& S, uint32_t from, unsigned long long* CNT)
-{
-	BT_COUNT(CN_CANDSCAN);
-	const uint32_t e_lo = L.ebase, e_hi = L.ebase + (from - L.depth);
-	BT_NOUNROLL
-	for (uint32_t chunk = e_hi >> 3;; chunk--) {
-		const BtMeta8 m = bt_meta_load8(S, chunk);
-		BT_UNROLL
-		for (int k = 7; k >= 0; k--) {
-			const uint32_t e = chunk * 8u + (uint32_t)k;
-			const uint32_t v = bt_meta_get(m, (uint32_t)k);
-			if (e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u) {
-				L.cand = L.depth + (e - L.ebase); L.candValid = 1;
-				return true;
-			}
-		}
-		if (chunk * 8u <= e_lo) break;
-	}
-	return false;
+	const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
+	BT_REQ_FETCH(&META((uint64_t)lo * 8u), hi - lo + 1u, nullptr);
 }
 
 /* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
-BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScratch& S, unsigned long long* CNT)
+BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, const BtScratch& S,
+                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
-	const BtProgram& P = C.P;
 	const BtIndexDev* IX = C.ix;
 	const BtBatchDev& B = C.B;
-	/* The states are visited in an order that lets the usual chains finish in one sweep
-	 * (child failed: FRAME_RETURN -> CHILD_RET -> BT_LOOP -> FRAME_ENTER; phase change: FRAME_RETURN ->
-	 * SEARCH_END -> PHASE_NEXT -> SEARCH_BEGIN -> FRAME_ENTER; report: RA_BEGIN -> ROW_BEGIN).  Within a
-	 * block `break` leaves the block. */
-	while (BT_IS_SLOW(L.state)) {
+	/* The states are visited in an order that lets the usual chains finish in one sweep (child
+	 * failed: FRAME_RETURN -> CHILD_RET -> BT_LOOP; phase change: FRAME_RETURN -> SEARCH_END ->
+	 * PHASE_NEXT -> SEARCH_BEGIN).  Within a block `break` leaves the block; a block that sets `req`
+	 * ends the lane's round (no later block runs: ST_IS tests req). */
+	while (BT_IS_SLOW(L.state) && req.kind == RQ_NONE) {
 		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */
-		if (L.state == ST_FELL_OFF) { BT_PROF_T0(t_fell_off); do {
+		if (ST_IS(ST_FELL_OFF)) do {
 			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL);
 			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
-			break;
-		} while (0); BT_PROF_ADD(PS_FELL_OFF, t_fell_off); }
+		} while (0);
 
-		if (L.state == ST_RESOLVE) { BT_PROF_T0(t_resolve); do {
-			const uint32_t zOff = IXSEL(zOff);
+		/* ---- an SA walk reached a sampled row: offset -> (tidx,toff) -> sink (ebwt.h:2569-2746) ---- */
+		if (ST_IS(ST_RESOLVE_DONE)) do {
+			const uint32_t zOff = HSEL(zOff);
 			uint32_t off;
 			if (L.crow == zOff) off = L.cjumps;
-			else { const uint32_t* offs = IXSEL(offs); off = offs[L.crow >> IXSEL(offRate)] + L.cjumps; }
+			else off = bt_u4_word(res.q[0], (L.crow >> HSEL(offRate)) & 3u) + L.cjumps;
 			BT_COUNT(CN_OFFS);
 			/* joinedToTextOff (ebwt.h:2569-2629) */
 			const uint32_t* rstarts = IXSEL(rstarts);
-			const uint32_t nFrag = IXSEL(nFrag), len = IXSEL(len), ixfw = IXSEL(fw);
+			const uint32_t nFrag = IXSEL(nFrag), len = HSEL(len), ixfw = L.mirror ? 0u : 1u;
 			uint32_t lo = 0, hi = nFrag, tidx = 0, toff = 0, probes = 0;
 			bool hit = false;
 			BT_NOUNROLL
@@ -539,10 +527,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			if (hit && bt_report_hit(L, P, ixfw, S, B, tidx, toff)) { L.ret = 1; L.state = ST_RA_END; break; }
 			L.ra_i++;
 			L.state = ST_ROW_BEGIN;
-			break;
-		} while (0); BT_PROF_ADD(PS_RESOLVE, t_resolve); }
+		} while (0);
 
-		if (L.state == ST_RA_END) { BT_PROF_T0(t_ra_end); do {
+		if (ST_IS(ST_RA_END)) do {
 			switch (L.ra_cont) {
 			case RC_STEP:
 				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
@@ -554,46 +541,44 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			case RC_FELL:  L.state = ST_FRAME_RETURN; break;
 			default:       L.state = ST_SEARCH_END; break;
 			}
-			break;
-		} while (0); BT_PROF_ADD(PS_RA_END, t_ra_end); }
+		} while (0);
 
-		/* ---- return from a frame -------------------------------------------------------- */
-		if (L.state == ST_FRAME_RETURN) { BT_PROF_T0(t_frame_return); do {
+		/* ---- return from a frame: pop the parent's record (LDS copy, else one fetch) ---------- */
+		if (ST_IS(ST_FRAME_RETURN) || ST_IS(ST_FRAME_FETCHED)) do {
 			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - 1u;
-			L.sd = f;
-			BtU4 q0, q1, q2; uint32_t eb;
-			if (L.tosValid && L.tosFrame == f) {
+			uint32_t w[BT_TOS_WORDS];
+			if (L.state == ST_FRAME_FETCHED) {
+				w[0] = res.q[0].x; w[1] = res.q[0].y; w[2] = res.q[0].z; w[3] = res.q[0].w;
+				w[4] = res.q[1].x; w[5] = res.q[1].y; w[6] = res.q[1].z; w[7] = res.q[1].w;
+				w[8] = res.q[2].x; w[9] = res.q[2].y;
+			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
-				q0.x = S.tos[0]; q0.y = S.tos[ts]; q0.z = S.tos[2u * ts]; q0.w = S.tos[3u * ts];
-				q1.x = S.tos[4u * ts]; q1.y = S.tos[5u * ts]; q1.z = S.tos[6u * ts]; q1.w = S.tos[7u * ts];
-				q2.x = S.tos[8u * ts]; q2.y = S.tos[9u * ts]; q2.z = S.tos[10u * ts]; q2.w = S.tos[11u * ts];
-				eb = S.tos[12u * ts];
+				BT_UNROLL
+				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) w[k] = S.tos[k * ts];
 				L.tosValid = 0;
 			} else {
-				const BtU4* fr = (const BtU4*)&FRW(f, 0);
-				q0 = fr[0]; q1 = fr[1]; q2 = fr[2];
-				eb = FRW(f, FR_EBASE);
+				BT_REQ_FETCH(&FRW(f, 0), 3, nullptr);
+				L.state = ST_FRAME_FETCHED;
+				break;
 			}
+			L.sd = f;
 			uint32_t v;
-			v = q0.x; L.depth = v & 0x7ffu; L.d = (v >> 11) & 0x7ffu;
-			v = q0.y; L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu; L.elham = (v >> 24) & 0xffu;
-			v = q0.z; L.fu = v & 0x7ffu; L.f1 = (v >> 11) & 0x7ffu; L.elcint = (v >> 22) & 3u;
+			v = w[FR_W0]; L.depth = v & 0x7ffu; L.d = (v >> 11) & 0x7ffu;
+			v = w[FR_W1]; L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu;
+			v = w[FR_W2]; L.fu = v & 0x7ffu; L.f1 = (v >> 11) & 0x7ffu; L.elcint = (v >> 22) & 3u;
 			L.elignore = (v >> 24) & 1u; L.candValid = (v >> 25) & 1u;
-			v = q0.w; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
-			v = q1.x; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
-			L.eligibleSz = q1.y; L.eltop = q1.z; L.elbot = q1.w;
-			v = q2.x; L.eli = v & 0x7ffu; L.cand = (v >> 11) & 0x7ffu; L.elel = (v >> 22) & 15u;
-			v = q2.y; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
-			L.pbttop = q2.z; L.pbtbot = q2.w;
-			L.ebase = eb;
-			L.cchunk = 0xffu;
+			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
+			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
+			L.cand = w[FR_W5] & 0x7ffu;
+			v = w[FR_W6]; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
+			L.pbttop = w[FR_PTOP]; L.pbtbot = w[FR_PBOT];
+			L.ebase = w[FR_EBASE];
 			L.state = ST_CHILD_RET;
-			break;
-		} while (0); BT_PROF_ADD(PS_FRAME_RETURN, t_frame_return); }
+		} while (0);
 
 		/* ---- a child frame (or a leaf report) came back (:972-1064) ---------------------- */
-		if (L.state == ST_CHILD_RET) { BT_PROF_T0(t_child_ret); do {
+		if (ST_IS(ST_CHILD_RET)) do {
 			if (L.ret) { L.state = ST_FRAME_RETURN; break; }
 			if (L.bailed || (L.halfAndHalf && P.steps[L.step].maxBts > 0 && L.numBts >= P.steps[L.step].maxBts)) {
 				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
@@ -602,91 +587,56 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				const uint32_t e = L.ebase + (L.pi - L.depth);
 				const uint32_t el = L.pel | (1u << L.pj);           /* the mask travelled with the frame record */
 				((uint8_t*)&META(e))[0] = (uint8_t)el;
-				if (el == 15u) L.candValid = 0;             /* that position is exhausted: re-scan next time */
-				if (L.eli == L.pi) L.elel = el;
+				L.pel = el;
+				if (el == 15u) L.candValid = 0;             /* that position is exhausted: scan next time */
 			}
-			L.eligibleSz -= (L.pbtbot - L.pbttop);
 			L.eligibleNum = L.eligibleNum - 1u;
 			L.elignore = 1;
 			L.altNum = L.altNum - 1u;
 			if (L.altNum == 0) { L.ret = 0; L.state = ST_FRAME_RETURN; break; }
 			if (L.eligibleNum == 0 && L.considerQuals) {
-				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058): the
-				 * reference walks k = d..max(depth,unrev) once, restarting its tallies whenever it
-				 * meets a strictly lower quality.  Same result in two batched passes: (1) the lowest
-				 * quality among positions that still have a target, (2) the tallies over the positions
-				 * of exactly that quality, deepest first. */
+				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058), one
+				 * fetched batch of records per round, deepest position first */
 				BT_COUNT(CN_RESCAN);
-				BT_PROF_T0(t_rescan);
 				L.lowAltQual = 0xff; L.candValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
-				if (L.d >= kmin) {
-					const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
-					/* both passes walk the frame's records 4 chunks (32 positions) per batch, the four
-					 * 16-byte loads of a batch issued back to back */
-					const uint32_t c_hi = e_hi >> 3, c_lo = e_lo >> 3;
-					uint32_t qmin = 0xffu;
-					BT_NOUNROLL
-					for (uint32_t cb = c_hi;; cb -= 4u) {
-						BtMeta8 m[4];
-						BT_UNROLL
-						for (uint32_t t = 0; t < 4u; t++) m[t] = bt_meta_load8(S, cb >= t + c_lo ? cb - t : c_lo);
-						BT_UNROLL
-						for (uint32_t t = 0; t < 4u; t++) {
-							if (cb < t + c_lo) continue;
-							BT_UNROLL
-							for (int k = 7; k >= 0; k--) {
-								const uint32_t e = (cb - t) * 8u + (uint32_t)k, v = bt_meta_get(m[t], (uint32_t)k);
-								if (e <= e_hi && e >= e_lo && (v & 15u) != 15u && (v >> 8) < qmin) qmin = v >> 8;
-							}
-						}
-						if (cb < c_lo + 4u) break;
-					}
-					if (qmin != 0xffu && L.ham + bt_mm_penalty(L.maq, qmin) <= L.qualThresh) {
-						bool first = true;
-						BT_NOUNROLL
-						for (uint32_t cb = c_hi;; cb -= 4u) {
-							BtMeta8 m[4];
-							BT_UNROLL
-							for (uint32_t t = 0; t < 4u; t++) m[t] = bt_meta_load8(S, cb >= t + c_lo ? cb - t : c_lo);
-							BT_UNROLL
-							for (uint32_t t = 0; t < 4u; t++) {
-								if (cb < t + c_lo) continue;
-								BT_NOUNROLL
-								for (int k = 7; k >= 0; k--) {
-									const uint32_t e = (cb - t) * 8u + (uint32_t)k, v = bt_meta_get(m[t], (uint32_t)k);
-									if (e > e_hi || e < e_lo || (v & 15u) == 15u || (v >> 8) != qmin) continue;
-									const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
-									const uint32_t tp[4] = {t4.x, t4.y, t4.z, t4.w};
-									const uint32_t sp[4] = {b4.x - t4.x, b4.y - t4.y, b4.z - t4.z, b4.w - t4.w};
-									BT_UNROLL
-									for (uint32_t l = 0; l < 4u; l++) {
-										if ((v & (1u << l)) == 0) {
-											if (first) {
-												first = false;
-												L.lowAltQual = qmin; L.eligibleNum = 0; L.eligibleSz = 0;
-												L.eli = L.depth + (e - L.ebase); L.eltop = tp[l]; L.elbot = tp[l] + sp[l];
-												L.elham = bt_mm_penalty(L.maq, qmin); L.elcint = l; L.elignore = 0;
-												L.elel = v & 15u;
-												L.cand = L.eli; L.candValid = 1;
-											}
-											L.eligibleNum = L.eligibleNum + 1u; L.eligibleSz += sp[l];
-										}
-									}
-								}
-							}
-							if (cb < c_lo + 4u) break;
-						}
-					}
-				}
-				BT_PROF_ADD(PS_RESCAN, t_rescan);
+				if (L.d >= kmin) { L.scanCb = (L.ebase + (L.d - L.depth)) >> 3; L.state = ST_RESCAN; break; }
 			}
 			L.state = ST_BT_LOOP;
-			break;
-		} while (0); BT_PROF_ADD(PS_CHILD_RET, t_child_ret); }
+		} while (0);
+
+		if (ST_IS(ST_RESCAN) || ST_IS(ST_RESCAN_DONE)) do {
+			const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
+			const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
+			const uint32_t c_lo = e_lo >> 3;
+			if (L.state == ST_RESCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_RESCAN_DONE; break; }
+			/* the batch (chunks lo..hi) arrived in res.q[0..]; same walk as the reference: deepest
+			 * record first, restart the tallies whenever a strictly lower quality shows up */
+			const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
+			BT_UNROLL
+			for (int t = 3; t >= 0; t--) {
+				if ((uint32_t)t > hi - lo) continue;
+				BT_NOUNROLL
+				for (int k = 7; k >= 0; k--) {
+					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k, v = bt_u4_meta(res.q[t], (uint32_t)k);
+					const uint32_t el = v & 15u, kq = v >> 8;
+					if (e > e_hi || e < e_lo || el == 15u) continue;
+					if (L.ham + bt_mm_penalty(L.maq, kq) > L.qualThresh) continue;
+					if (kq < L.lowAltQual) {
+						L.lowAltQual = kq; L.eligibleNum = 0;
+						L.cand = L.depth + (e - L.ebase); L.candValid = 1;
+						L.elcint = (el & 1u) == 0 ? 0u : (el & 2u) == 0 ? 1u : (el & 4u) == 0 ? 2u : 3u;
+						L.elignore = 0;
+					}
+					if (kq == L.lowAltQual) L.eligibleNum = L.eligibleNum + (4u - (uint32_t)__builtin_popcount(el));
+				}
+			}
+			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_RESCAN; break; }
+			L.state = ST_BT_LOOP;
+		} while (0);
 
 		/* ---- backtrack() exit (:333-353, 303-324) + the seedling-extension loop ---------- */
-		if (L.state == ST_SEARCH_END) { BT_PROF_T0(t_search_end); do {
+		if (ST_IS(ST_SEARCH_END)) do {
 			L.numBts = 0;
 			if (L.kind == BT_KIND_EXTEND) {
 				/* search_seeded_phase3.c:9-59 / phase4.c:9-55: for each seedling, setMuts +
@@ -720,11 +670,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			if (L.kind == BT_KIND_GEN) { L.state = ST_PHASE_NEXT; break; }
 			if (L.ret) { bt_lane_finish(L, B); break; }
 			L.state = ST_PHASE_NEXT;
-			break;
-		} while (0); BT_PROF_ADD(PS_SEARCH_END, t_search_end); }
+		} while (0);
 
 		/* ---- phase script ------------------------------------------------------------- */
-		if (L.state == ST_PHASE_NEXT) { BT_PROF_T0(t_phase_next); do {
+		if (ST_IS(ST_PHASE_NEXT)) do {
 			L.step = L.step + 1u;        /* 5-bit wrap: 31 -> 0 */
 			if ((int32_t)L.step >= P.nsteps || (L.status & BT_STF_OVERFLOW)) { bt_lane_finish(L, B); break; }
 			const BtStep& st = P.steps[L.step];
@@ -738,8 +687,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			L.unrev = bt_off_code(plen, qs, st.oc[2]); L.r1 = bt_off_code(plen, qs, st.oc[3]);
 			L.r2 = bt_off_code(plen, qs, st.oc[4]); L.r3 = bt_off_code(plen, qs, st.oc[5]);
 			L.qlen = (st.kind == BT_KIND_GEN) ? qs : plen;               /* setQlen(seed) */
-			L.rnd = B.seed[L.rd]; L.numBts = 0; L.nmuts = 0; L.iham = 0;
-			L.cchunk = 0xffu;
+			L.rnd = L.seed; L.numBts = 0; L.nmuts = 0; L.iham = 0;
 			if (st.kind == BT_KIND_GEN) L.npals = 0;
 			if (st.kind == BT_KIND_EXTEND) {
 				if (L.npals == 0) { L.state = ST_PHASE_NEXT; break; }
@@ -748,14 +696,13 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				break;
 			}
 			L.state = ST_SEARCH_BEGIN;
-			break;
-		} while (0); BT_PROF_ADD(PS_PHASE_NEXT, t_phase_next); }
+		} while (0);
 
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
-		if (L.state == ST_SEARCH_BEGIN) { BT_PROF_T0(t_search_begin); do {
+		if (ST_IS(ST_SEARCH_BEGIN)) do {
 			L.bailed = 0; L.sd = 0;
 			uint32_t nsInFtab = 0;
-			const uint32_t ftabChars = IXSEL(ftabChars);
+			const uint32_t ftabChars = HSEL(ftabChars);
 			if (L.hasN) {
 				/* tallyNs (:1308-1341); reads without any N (nearly all) skip both walks */
 				uint32_t nsInSeed = 0; bool ok = true;
@@ -778,73 +725,123 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			const uint32_t m = L.unrev < L.qlen ? L.unrev : L.qlen;
 			L.fu = L.unrev; L.f1 = L.r1; L.f2 = L.r2; L.f3 = L.r3; L.ham = L.iham; L.ebase = 0;
 			if (nsInFtab == 0 && m >= ftabChars) {
-				/* calcFtabOff (:1348-1362) through the register window: the step loop continues from
-				 * the same 16-byte window */
-				uint32_t ftabOff = 0;
-				BT_NOUNROLL
-				for (uint32_t i = 0; i < ftabChars; i++) {
-					uint32_t c, q;
-					bt_qq_cached(L, H, L.qlen - 1u - i, &c, &q);
-					ftabOff |= c << (2u * i);
-				}
-				const uint32_t* ftab = IXSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = IXSEL(len);
-				uint32_t top = ftab[ftabOff], bot = ftab[ftabOff + 1u];
-				if (top > len) top = eftab[(top ^ BT_OFF_MASK) * 2u + 1u];
-				if (bot > len) bot = eftab[(bot ^ BT_OFF_MASK) * 2u];
-				BT_COUNT(CN_FTAB);
-				if (L.qlen == ftabChars && bot > top) {
-					if (L.reportPartials > 0) { L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER; }
-					else { L.top = top; L.bot = bot; BT_GOTO_RA(0, top, bot, L.iham, RC_ENTRY); }
-				} else if (bot > top) {
-					L.depth = ftabChars; L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER;
-				} else { L.ret = 0; L.state = ST_SEARCH_END; }
+				/* calcFtabOff (:1348-1362) needs the last ftabChars characters of the query: fetch the
+				 * (at most two) 16-byte chunks of the read that hold them */
+				const uint32_t i0 = L.qlen - ftabChars, i1 = L.qlen - 1u;
+				const uint32_t j0 = L.rev ? (L.plen - 1u - i1) : i0, j1 = L.rev ? (L.plen - 1u - i0) : i1;
+				const uint8_t* base = H.seq + L.roff;
+				BT_REQ_FETCH(base + (uint64_t)(j0 >> 4) * 16u, 1, base + (uint64_t)(j1 >> 4) * 16u);
+				L.state = ST_FTABSEQ_DONE;
 			} else {
 				L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER;
 			}
-			break;
-		} while (0); BT_PROF_ADD(PS_SEARCH_BEGIN, t_search_begin); }
+		} while (0);
+
+		if (ST_IS(ST_FTABSEQ_DONE)) do {
+			const uint32_t ftabChars = HSEL(ftabChars);
+			const uint32_t i0 = L.qlen - ftabChars, i1 = L.qlen - 1u;
+			const uint32_t j0 = L.rev ? (L.plen - 1u - i1) : i0;
+			uint32_t ftabOff = 0;
+			BT_NOUNROLL
+			for (uint32_t t = 0; t < ftabChars; t++) {
+				const uint32_t i = L.qlen - 1u - t;
+				const uint32_t j = L.rev ? (L.plen - 1u - i) : i;
+				uint32_t c = ((j >> 4) == (j0 >> 4)) ? bt_u4_byte(res.q[0], j & 15u) : bt_u4_byte(res.x, j & 15u);
+				if (!L.readFw && c < 4u) c ^= 3u;
+				c = bt_apply_muts(L, i, c);
+				ftabOff |= c << (2u * t);
+			}
+			const uint32_t* ftab = HSEL(ftab);
+			L.ra_r = ftabOff;           /* parked until the table entry arrives */
+			BT_REQ_FETCH(ftab + (ftabOff & ~3u), 1, ftab + ((ftabOff + 1u) & ~3u));
+			L.state = ST_FTAB_DONE;
+		} while (0);
+
+		if (ST_IS(ST_FTAB_DONE)) do {
+			const uint32_t ftabChars = HSEL(ftabChars), len = HSEL(len);
+			const uint32_t ftabOff = L.ra_r;
+			uint32_t top = bt_u4_word(res.q[0], ftabOff & 3u);
+			uint32_t bot = (((ftabOff + 1u) & ~3u) == (ftabOff & ~3u)) ? bt_u4_word(res.q[0], (ftabOff + 1u) & 3u)
+			                                                          : bt_u4_word(res.x, (ftabOff + 1u) & 3u);
+			if (top > len) { const uint32_t* eftab = IXSEL(eftab); top = eftab[(top ^ BT_OFF_MASK) * 2u + 1u]; }
+			if (bot > len) { const uint32_t* eftab = IXSEL(eftab); bot = eftab[(bot ^ BT_OFF_MASK) * 2u]; }
+			BT_COUNT(CN_FTAB);
+			if (L.qlen == ftabChars && bot > top) {
+				if (L.reportPartials > 0) { L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER; }
+				else { L.top = top; L.bot = bot; BT_GOTO_RA(0, top, bot, L.iham, RC_ENTRY); }
+			} else if (bot > top) {
+				L.depth = ftabChars; L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER;
+			} else { L.ret = 0; L.state = ST_SEARCH_END; }
+		} while (0);
 
 		/* ---- choose a backtrack target and descend (:743-971) --------------------------- */
-		if (L.state == ST_BT_LOOP) { BT_PROF_T0(t_bt_loop); do {
-			uint32_t i, j = 0, bttop = 0, btbot = 0, btham = L.ham, btcint = 0;
-			if (L.eligibleNum > 1 || L.elignore) {
-				bool found = L.candValid || bt_find_cand(L, S, L.d, CNT);
-				if (found) {
-					found = false;
-					i = L.cand;
-					const uint32_t e = L.ebase + (i - L.depth);
-					const uint32_t mv = META(e);
-					const uint32_t el = mv & 15u, qi = mv >> 8;
-					L.pel = el;
-					uint32_t sp[4], tp[4];
-					{
-						const BtU4 t4 = *(const BtU4*)&PT(e, 0), b4 = *(const BtU4*)&PB(e, 0);
-						tp[0] = t4.x; tp[1] = t4.y; tp[2] = t4.z; tp[3] = t4.w;
-						sp[0] = b4.x - t4.x; sp[1] = b4.y - t4.y; sp[2] = b4.z - t4.z; sp[3] = b4.w - t4.w;
-					}
-					uint32_t posSz = 0;
-					BT_UNROLL
-					for (j = 0; j < 4u; j++) if ((el & (1u << j)) == 0) posSz += sp[j];
-					uint32_t r = (posSz > 0) ? (bt_rnd_u32(L) % posSz) : 0u;
-					BT_UNROLL
-					for (j = 0; j < 4u; j++) {
-						if ((el & (1u << j)) == 0) {
-							if (r < sp[j]) {
-								bttop = tp[j]; btbot = tp[j] + sp[j];
-								btham += bt_mm_penalty(L.maq, qi);
-								btcint = j; found = true;
-								break;
-							}
-							r -= sp[j];
-						}
+		if (ST_IS(ST_BT_LOOP)) do {
+			if (!L.candValid) {
+				/* the deepest position that still has a target of the eligible quality (the
+				 * `for(; i >= depth; i--)` walk of :767-812), batch by batch */
+				BT_COUNT(CN_CANDSCAN);
+				L.scanCb = (L.ebase + (L.d - L.depth)) >> 3;
+				L.state = ST_CANDSCAN;
+				break;
+			}
+			/* fetch the target position's four (top,bot) ranges and its (mask,quality) record */
+			const uint32_t e = L.ebase + (L.cand - L.depth);
+			BT_REQ_FETCH(&PT(e, 0), 2, &META(e & ~7u));
+			L.state = ST_BT_PICK;
+		} while (0);
+
+		if (ST_IS(ST_CANDSCAN) || ST_IS(ST_CANDSCAN_DONE)) do {
+			const uint32_t e_lo = L.ebase, e_hi = L.ebase + (L.d - L.depth);
+			const uint32_t c_lo = e_lo >> 3;
+			if (L.state == ST_CANDSCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_CANDSCAN_DONE; break; }
+			const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
+			bool found = false;
+			BT_UNROLL
+			for (int t = 3; t >= 0; t--) {
+				if ((uint32_t)t > hi - lo) continue;
+				BT_NOUNROLL
+				for (int k = 7; k >= 0; k--) {
+					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k, v = bt_u4_meta(res.q[t], (uint32_t)k);
+					if (!found && e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u) {
+						L.cand = L.depth + (e - L.ebase); L.candValid = 1; found = true;
 					}
 				}
-				if (!found) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); break; }   /* cannot happen */
-				i = L.cand;
-			} else {
-				i = L.eli; bttop = L.eltop; btbot = L.elbot; btham += L.elham; j = btcint = L.elcint;
-				L.pel = L.elel;
 			}
+			if (found) { L.state = ST_BT_LOOP; break; }
+			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_CANDSCAN; break; }
+			L.state = ST_ABORT;                                   /* cannot happen: altNum > 0 */
+		} while (0);
+
+		if (ST_IS(ST_BT_PICK)) do {
+			const uint32_t i = L.cand;
+			const uint32_t e = L.ebase + (i - L.depth);
+			const uint32_t mv = bt_u4_meta(res.x, e & 7u);
+			const uint32_t el = mv & 15u, qi = mv >> 8;
+			const uint32_t tp[4] = {res.q[0].x, res.q[0].y, res.q[0].z, res.q[0].w};
+			const uint32_t sp[4] = {res.q[1].x - tp[0], res.q[1].y - tp[1], res.q[1].z - tp[2], res.q[1].w - tp[3]};
+			uint32_t j = 0;
+			if (L.eligibleNum > 1 || L.elignore) {
+				uint32_t posSz = 0;
+				BT_UNROLL
+				for (uint32_t l = 0; l < 4u; l++) if ((el & (1u << l)) == 0) posSz += sp[l];
+				if (posSz == 0) { L.state = ST_ABORT; break; }
+				uint32_t r = bt_rnd_u32(L) % posSz;
+				bool found = false;
+				BT_UNROLL
+				for (uint32_t l = 0; l < 4u; l++) {
+					if (!found && (el & (1u << l)) == 0) {
+						if (r < sp[l]) { j = l; found = true; }
+						else r -= sp[l];
+					}
+				}
+			} else {
+				j = L.elcint;                                     /* the only eligible target: no draw (:820-834) */
+			}
+			const uint32_t bttop = bt_sel4(j, tp[0], tp[1], tp[2], tp[3]);
+			const uint32_t btbot = bttop + bt_sel4(j, sp[0], sp[1], sp[2], sp[3]);
+			const uint32_t btham = L.ham + bt_mm_penalty(L.maq, qi);
+			const uint32_t btcint = j;
+			L.pel = el;
 			const uint32_t icur = L.qlen - i - 1u;
 			uint32_t nu = L.fu, n1 = L.f1, n2 = L.f2, n3 = L.f3;
 			if (i < L.f1)      { nu = L.f1; n1 = L.f2; n2 = L.f3; }
@@ -858,18 +855,17 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 			}
 			uint32_t newDepth = i + 1u, ntop = bttop, nbot = btbot;
 			const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
-			const uint32_t ftabChars = IXSEL(ftabChars);
+			const uint32_t ftabChars = HSEL(ftabChars);
 			if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < ftabChars && ftabChars <= L.d5) {
-				/* re-jump through the ftab with the substituted character (:908-952) */
+				/* re-jump through the ftab with the substituted character (:908-952); rare, synchronous */
 				uint32_t ftabOff = 0;
 				BT_NOUNROLL
 				for (uint32_t jj = 0; jj < ftabChars; jj++) {
-					uint32_t c, q;
-					bt_qq_cached(L, H, L.qlen - 1u - jj, &c, &q);
+					uint32_t c = bt_qry(L, H, L.qlen - 1u - jj);
 					if (L.qlen - 1u - jj == icur) c = btcint;
 					ftabOff |= c << (2u * jj);
 				}
-				const uint32_t* ftab = IXSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = IXSEL(len);
+				const uint32_t* ftab = HSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = HSEL(len);
 				ntop = ftab[ftabOff]; nbot = ftab[ftabOff + 1u];
 				if (ntop > len) ntop = eftab[(ntop ^ BT_OFF_MASK) * 2u + 1u];
 				if (nbot > len) nbot = eftab[(nbot ^ BT_OFF_MASK) * 2u];
@@ -877,37 +873,35 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				if (ntop == nbot) { L.ret = 0; L.state = ST_CHILD_RET; break; }
 				newDepth = ftabChars;
 			}
-			/* push: save the parent, enter the child */
-			if (L.sd + 1u >= S.frCap) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); break; }
+			/* push: save the parent (HBM record + LDS top-of-stack copy), enter the child */
+			if (L.sd + 1u >= S.frCap) { L.state = ST_ABORT; break; }
 			{
-				/* one 64-byte record, written as four 16-byte stores (FR_MM was stored above) */
+				uint32_t w[BT_TOS_WORDS];
+				w[FR_W0] = L.depth | (L.d << 11);
+				w[FR_W1] = L.ham | (L.lowAltQual << 16);
+				w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
+				w[FR_W3] = L.f2 | (L.f3 << 11);
+				w[FR_W4] = L.altNum | (L.eligibleNum << 12);
+				w[FR_W5] = L.cand;
+				w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
+				w[FR_PTOP] = L.pbttop; w[FR_PBOT] = L.pbtbot; w[FR_EBASE] = L.ebase;
 				BtU4* fr = (BtU4*)&FRW(L.sd, 0);
-				BtU4 q0, q1, q2;
-				q0.x = L.depth | (L.d << 11);
-				q0.y = L.ham | (L.lowAltQual << 16) | (L.elham << 24);
-				q0.z = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
-				q0.w = L.f2 | (L.f3 << 11);
-				q1.x = L.altNum | (L.eligibleNum << 12); q1.y = L.eligibleSz; q1.z = L.eltop; q1.w = L.elbot;
-				q2.x = L.eli | (L.cand << 11) | (L.elel << 22); q2.y = L.pi | (L.pj << 11) | (L.pel << 13); q2.z = L.pbttop; q2.w = L.pbtbot;
-				fr[0] = q0; fr[1] = q1; fr[2] = q2;
-				FRW(L.sd, FR_EBASE) = L.ebase;
-				/* top-of-stack copy in LDS */
+				BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
+				fr[0] = q0; fr[1] = q1;
+				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE];
 				const uint32_t ts = S.tosStride;
-				S.tos[0] = q0.x; S.tos[ts] = q0.y; S.tos[2u * ts] = q0.z; S.tos[3u * ts] = q0.w;
-				S.tos[4u * ts] = q1.x; S.tos[5u * ts] = q1.y; S.tos[6u * ts] = q1.z; S.tos[7u * ts] = q1.w;
-				S.tos[8u * ts] = q2.x; S.tos[9u * ts] = q2.y; S.tos[10u * ts] = q2.z; S.tos[11u * ts] = q2.w;
-				S.tos[12u * ts] = L.ebase;
+				BT_UNROLL
+				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tos[k * ts] = w[k];
 				L.tosFrame = L.sd; L.tosValid = 1;
 			}
 			L.ebase = L.ebase + (L.d - L.depth + 1u);
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
-			break;
-		} while (0); BT_PROF_ADD(PS_BT_LOOP, t_bt_loop); }
+		} while (0);
 
 		/* ---- reportAlignment / reportFullAlignment (:1455-1565) -------------------------- */
-		if (L.state == ST_RA_BEGIN) { BT_PROF_T0(t_ra_begin); do {
+		if (ST_IS(ST_RA_BEGIN)) do {
 			if (L.reportPartials) {
 				if (L.ra_sd > 0) bt_report_partial(L, S, L.ra_sd);
 				L.ret = 0; L.state = ST_RA_END; break;
@@ -926,53 +920,56 @@ BT_HD void bt_lane_slow(BtLane& L, const BtHot& H, const BtCold& C, const BtScra
 				L.ra_i = 0;
 			}
 			L.state = ST_ROW_BEGIN;
-			break;
-		} while (0); BT_PROF_ADD(PS_RA_BEGIN, t_ra_begin); }
+		} while (0);
 
-		if (L.state == ST_ROW_BEGIN) { BT_PROF_T0(t_row_begin); do {
+		if (ST_IS(ST_ROW_BEGIN)) do {
 			const uint32_t spread = L.ra_bot - L.ra_top;
 			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
 			uint32_t ri = L.ra_r + L.ra_i;
 			if (ri >= L.ra_bot) ri -= spread;
 			L.crow = ri; L.cjumps = 0;
 			L.state = ST_CHASE_CHECK;
-			break;
-		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
+		} while (0);
 
 		/* ---- frame prologue (:363-455) -------------------------------------------------- */
-		if (L.state == ST_FRAME_ENTER) { BT_PROF_T0(t_frame_enter); do {
+		if (ST_IS(ST_FRAME_ENTER)) do {
 			BT_COUNT(CN_FRAMES);
 			if (L.halfAndHalf) {
 				const uint32_t maxBts = P.steps[L.step].maxBts;
 				if (maxBts > 0 && L.numBts == maxBts) { L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break; }
 				L.numBts++;
 			}
-			L.altNum = 0; L.eligibleNum = 0; L.eligibleSz = 0;
-			L.eli = 0; L.eltop = 0; L.elbot = 0; L.elham = L.ham; L.elcint = 0; L.elignore = 1;
+			L.altNum = 0; L.eligibleNum = 0;
+			L.elcint = 0; L.elignore = 1;
 			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0;
 			L.d = L.depth;
 			L.state = ST_STEP_BEGIN;
-			break;
-		} while (0); BT_PROF_ADD(PS_FRAME_ENTER, t_frame_enter); }
+		} while (0);
 
+		if (ST_IS(ST_ABORT)) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); }
 	}
 }
 
 /*
- * Advance one lane until it needs an LF-mapping (returns with req.op != 0 and the lane in a
- * *_LFDONE state) or has finished its read (state ST_IDLE, req.op == 0).
- * `res` is consumed iff the lane was waiting for it.
+ * Advance one lane until it has a memory request for this round (req.kind != RQ_NONE) or has
+ * finished its read (state ST_IDLE).  `res` is the answer to the lane's previous request.
  */
-BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScratch& S,
+BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, const BtScratch& S,
                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
-	req.op = 0; req.rowA = 0; req.rowB = 0;
-	BT_NOUNROLL
+	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0;
 	for (;;) {
 		BT_PROF_T0(t_resume);
+		/* ---- resume: the read window arrived ------------------------------------------------- */
+		if (L.state == ST_WIN_DONE) {
+			L.cs0 = res.q[0].x; L.cs1 = res.q[0].y; L.cs2 = res.q[0].z; L.cs3 = res.q[0].w;
+			L.cq0 = res.x.x; L.cq1 = res.x.y; L.cq2 = res.x.z; L.cq3 = res.x.w;
+			L.cchunk = L.scanCb;
+			L.state = ST_STEP_BEGIN;
+		}
 		/* ---- resume: SA walk (reportChaseOne, ebwt.h:2727-2746) --------------------------- */
 		if (L.state == ST_CHASE_LFDONE) {
-			L.crow = res.LA == 0 ? res.a[0] : res.LA == 1 ? res.a[1] : res.LA == 2 ? res.a[2] : res.a[3];   /* mapLF(l) */
+			L.crow = bt_u4_word(res.q[0], res.q[2].x);                  /* mapLF(l) */
 			L.cjumps++;
 			L.state = ST_CHASE_CHECK;
 		}
@@ -982,25 +979,25 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 			const uint32_t e = L.ebase + (d - L.depth);
 			uint32_t ta[4], tb[4];
 			if (L.state == ST_STEP_LFDONE) {
-				const uint32_t ac = c == 0 ? res.a[0] : c == 1 ? res.a[1] : c == 2 ? res.a[2] : res.a[3];
-				const uint32_t bc = c == 0 ? res.b[0] : c == 1 ? res.b[1] : c == 2 ? res.b[2] : res.b[3];
+				ta[0] = res.q[0].x; ta[1] = res.q[0].y; ta[2] = res.q[0].z; ta[3] = res.q[0].w;
+				tb[0] = res.q[1].x; tb[1] = res.q[1].y; tb[2] = res.q[1].z; tb[3] = res.q[1].w;
+				const uint32_t ac = bt_sel4(c & 3u, ta[0], ta[1], ta[2], ta[3]);
+				const uint32_t bc = bt_sel4(c & 3u, tb[0], tb[1], tb[2], tb[3]);
 				if (L.lfk == LFK_EX2) {
-					BT_UNROLL
-					for (int k = 0; k < 4; k++) { ta[k] = res.a[k]; tb[k] = res.b[k]; }
-					{ BtU4 v; v.x = ta[0]; v.y = ta[1]; v.z = ta[2]; v.w = ta[3]; *(BtU4*)&PT(e, 0) = v; }
-					{ BtU4 v; v.x = tb[0]; v.y = tb[1]; v.z = tb[2]; v.w = tb[3]; *(BtU4*)&PB(e, 0) = v; }
+					*(BtU4*)&PT(e, 0) = res.q[0];
+					*(BtU4*)&PB(e, 0) = res.q[1];
 					if (c < 4u) { L.top = ac; L.bot = bc; }
 				} else if (L.lfk == LFK_C2) {
 					L.top = ac; L.bot = bc;
 				} else {
 					/* mapLF1 (ebwt.h:2494-2512) */
-					if (res.LA != c || L.top == HSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
+					if (res.q[2].x != c || L.top == HSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
 					else { L.top = ac; L.bot = ac + 1u; }
 				}
 			} else {
 				/* no LF was needed: depth-0 fchr quartet (:531-543) or a non-alternative N */
 				BT_UNROLL
-				for (int k = 0; k < 4; k++) { ta[k] = (L.mirror ? H.fchr[1][k] : H.fchr[0][k]); tb[k] = (L.mirror ? H.fchr[1][k + 1] : H.fchr[0][k + 1]); }
+				for (int k = 0; k < 4; k++) { ta[k] = HFCHR(k); tb[k] = HFCHR(k + 1); }
 			}
 			uint32_t el = (c < 4u) ? (1u << c) : 0u;
 			if (L.fl_alt) {
@@ -1013,17 +1010,15 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 					else {
 						if (L.fl_elig) {
 							if (over) {
-								L.lowAltQual = q; L.eligibleNum = 0; L.eligibleSz = 0; over = false;
-								L.eli = d; L.eltop = ta[i]; L.elbot = tb[i];
-								L.elham = bt_mm_penalty(L.maq, q); L.elcint = i; L.elignore = 0;
+								L.lowAltQual = q; L.eligibleNum = 0; over = false;
+								L.elcint = i; L.elignore = 0;
 							}
-							L.eligibleSz += spread; L.eligibleNum = L.eligibleNum + 1u;
+							L.eligibleNum = L.eligibleNum + 1u;
 						}
 						L.altNum = L.altNum + 1u;
 					}
 				}
 				if (L.fl_elig && el != 15u) { L.cand = d; L.candValid = 1; }     /* deepest eligible target so far */
-				if (L.eli == d && !L.elignore) L.elel = el;
 			}
 			META(e) = (uint16_t)(el | (q << 8));
 			bool btDespite = false, reportedPartial = false;
@@ -1058,19 +1053,31 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 			else if (mustBacktrack || invalidHH || invalidExact || L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
 		}
-
 		BT_PROF_ADD(PS_RESUME, t_resume);
+
 		/* ---- everything else ---------------------------------------------------------------- */
-		{ BT_PROF_T0(t_slow); if (BT_IS_SLOW(L.state)) bt_lane_slow(L, H, C, S, CNT); BT_PROF_ADD(PS_SLOW, t_slow); }
+		{
+			BT_PROF_T0(t_slow);
+			if (BT_IS_SLOW(L.state)) bt_lane_slow(L, P, H, C, S, res, req, CNT);
+			BT_PROF_ADD(PS_SLOW, t_slow);
+		}
+		if (req.kind != RQ_NONE) { BT_COUNT(CN_FETCH); return; }
 
 		/* ---- emit: next query position (:456-568) -------------------------------------------- */
 		if (L.state == ST_STEP_BEGIN) {
 			const uint32_t d = L.d;
 			if (d >= L.qlen) { L.state = ST_FELL_OFF; continue; }
 			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; continue; }
-			if (L.ebase + (d - L.depth) >= S.entCap) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, C.B); return; }
+			if (L.ebase + (d - L.depth) >= S.entCap) { L.state = ST_ABORT; continue; }
 			uint32_t c, q;
-			bt_qq_cached(L, H, L.qlen - d - 1u, &c, &q);
+			if (!bt_window_get(L, L.qlen - d - 1u, &c, &q)) {
+				const uint32_t i = L.qlen - d - 1u, j = L.rev ? (L.plen - 1u - i) : i;
+				L.scanCb = j >> 4;       /* chunk id, parked until the window arrives */
+				BT_REQ_FETCH(H.seq + L.roff + (uint64_t)(j >> 4) * 16u, 1, H.qual + L.roff + (uint64_t)(j >> 4) * 16u);
+				L.state = ST_WIN_DONE;
+				BT_COUNT(CN_FETCH);
+				return;
+			}
 			L.c = c; L.q = q;
 			const bool alt = (d >= L.fu) && (!L.considerQuals || (L.ham + bt_mm_penalty(L.maq, q) <= L.qualThresh));
 			bool elig = false, over = false;
@@ -1086,33 +1093,38 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 			if (rtop == 0 && rbot == 0) {
 				/* depth 0: the fchr quartet (:531-543) */
 				const uint32_t e = L.ebase + (d - L.depth);
-				BT_UNROLL
-				for (int k = 0; k < 4; k++) { PT(e, k) = (L.mirror ? H.fchr[1][k] : H.fchr[0][k]); PB(e, k) = (L.mirror ? H.fchr[1][k + 1] : H.fchr[0][k + 1]); }
-				if (c < 4u) { L.top = c == 0 ? (L.mirror ? H.fchr[1][0] : H.fchr[0][0]) : c == 1 ? (L.mirror ? H.fchr[1][1] : H.fchr[0][1]) : c == 2 ? (L.mirror ? H.fchr[1][2] : H.fchr[0][2]) : (L.mirror ? H.fchr[1][3] : H.fchr[0][3]);
-				              L.bot = c == 0 ? (L.mirror ? H.fchr[1][1] : H.fchr[0][1]) : c == 1 ? (L.mirror ? H.fchr[1][2] : H.fchr[0][2]) : c == 2 ? (L.mirror ? H.fchr[1][3] : H.fchr[0][3]) : (L.mirror ? H.fchr[1][4] : H.fchr[0][4]); }
+				const uint32_t f0 = HFCHR(0), f1 = HFCHR(1), f2 = HFCHR(2), f3 = HFCHR(3), f4 = HFCHR(4);
+				{ BtU4 v; v.x = f0; v.y = f1; v.z = f2; v.w = f3; *(BtU4*)&PT(e, 0) = v; }
+				{ BtU4 v; v.x = f1; v.y = f2; v.z = f3; v.w = f4; *(BtU4*)&PB(e, 0) = v; }
+				if (c < 4u) { L.top = bt_sel4(c, f0, f1, f2, f3); L.bot = bt_sel4(c, f1, f2, f3, f4); }
 				L.state = ST_STEP_POST;
 				continue;
 			} else if (alt) {
-				req.rowA = rtop; req.rowB = rbot; req.op = 3; L.lfk = LFK_EX2;
+				BT_REQ_RANK2(rtop, rbot); L.lfk = LFK_EX2;
 				L.state = ST_STEP_LFDONE; return;
 			} else if (c < 4u) {
-				if (L.top + 1u == L.bot) { req.rowA = L.top; req.op = 1; L.lfk = LFK_LF1; }
-				else { req.rowA = L.top; req.rowB = L.bot; req.op = 3; L.lfk = LFK_C2; }
+				if (L.top + 1u == L.bot) { BT_REQ_RANK1(L.top); L.lfk = LFK_LF1; }
+				else { BT_REQ_RANK2(L.top, L.bot); L.lfk = LFK_C2; }
 				L.state = ST_STEP_LFDONE; return;
 			} else {
-				/* non-alternative N: the range is already (1,1); only the bookkeeping remains.
-				 * ta/tb are unused on that path because fl_alt is false. */
+				/* non-alternative N: the range is already (1,1); only the bookkeeping remains */
 				L.state = ST_STEP_POST;
 				continue;
 			}
 		}
-		/* ---- emit: next SA-walk step ---------------------------------------------------------- */
+		/* ---- emit: next SA-walk step, or the SA sample once the walk has arrived ---------------- */
 		if (L.state == ST_CHASE_CHECK) {
 			if ((L.crow & HSEL(offMask)) != L.crow && L.crow != HSEL(zOff)) {
-				req.rowA = L.crow; req.op = 1; L.lfk = 3;
+				BT_REQ_RANK1(L.crow); L.lfk = LFK_CHASE;
 				L.state = ST_CHASE_LFDONE; return;
 			}
-			L.state = ST_RESOLVE;
+			L.state = ST_RESOLVE_DONE;
+			if (L.crow != HSEL(zOff)) {
+				const uint32_t* offs = HSEL(offs);
+				BT_REQ_FETCH(offs + ((L.crow >> HSEL(offRate)) & ~3u), 1, nullptr);
+				BT_COUNT(CN_FETCH);
+				return;
+			}
 			continue;
 		}
 		if (L.state == ST_IDLE) return;
@@ -1126,4 +1138,6 @@ BT_HD void bt_lane_run(BtLane& L, const BtHot& H, const BtCold& C, const BtScrat
 #undef PALS
 #undef IXSEL
 #undef HSEL
+#undef HFCHR
+#undef ST_IS
 #endif /* BT_CORE_H_ */

@@ -19,16 +19,14 @@
 
 struct BtRankSel { const uint8_t* ebwt; uint32_t zSide, zSym, f0, f1, f2, f3; };
 
-/* rank at `row`: 4 x 16-byte loads of the row's side + one 8-byte load of the partner counters */
-__device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint32_t lf[4], uint32_t* L)
+/* rank from the row's side already in registers (q0..q3 = its 64 bytes) + the partner side's
+ * 8 counter bytes */
+__device__ __forceinline__ void dev_rank4_loaded(const BtRankSel& s, uint32_t row, const BtU4& q0, const BtU4& q1,
+                                                 const BtU4& q2, const BtU4& q3, const uint2& oth, uint32_t lf[4], uint32_t* L)
 {
 	const uint32_t sideNum = row / BT_SIDE_SYMS;
 	const uint32_t charOff = row - sideNum * BT_SIDE_SYMS;
-	const uint8_t* side = s.ebwt + (uint64_t)sideNum * 64u;
-	const uint4* s4 = (const uint4*)side;
-	uint4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3];
 	const bool fw = (sideNum & 1u) != 0;
-	const uint2 oth = *(const uint2*)(fw ? side - 8 : side + 120);
 	uint64_t w[7];
 	w[0] = ((uint64_t)q0.y << 32) | q0.x; w[1] = ((uint64_t)q0.w << 32) | q0.z;
 	w[2] = ((uint64_t)q1.y << 32) | q1.x; w[3] = ((uint64_t)q1.w << 32) | q1.z;
@@ -43,12 +41,26 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 	bt_rank4_words(ix, sideNum, charOff, w, occ, lf, L);
 }
 
+/* rank at `row` (probe kernels): 4 x 16-byte loads of the row's side + one 8-byte load of the partner counters */
+__device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint32_t lf[4], uint32_t* L)
+{
+	const uint32_t sideNum = row / BT_SIDE_SYMS;
+	const uint8_t* side = s.ebwt + (uint64_t)sideNum * 64u;
+	const BtU4* s4 = (const BtU4*)side;
+	const BtU4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3];
+	const uint2 oth = *(const uint2*)((sideNum & 1u) ? side - 8 : side + 120);
+	dev_rank4_loaded(s, row, q0, q1, q2, q3, oth, lf, L);
+}
+
 template <int OCC>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
 	__shared__ unsigned long long CNT[CN_N + PS_N];
-	__shared__ uint32_t TOS[13 * BT_BLOCK];          /* top-of-stack frame record per lane */
+	__shared__ uint32_t TOS[BT_TOS_WORDS * BT_BLOCK];          /* top-of-stack frame record per lane */
+	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
+	for (uint32_t i = threadIdx.x; i < sizeof(BtProgram) / 4; i += blockDim.x)
+		((uint32_t*)&PROG)[i] = ((const uint32_t*)&A.cold->P)[i];
 	__syncthreads();
 
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,10 +71,8 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 
 	BtLane L = {};
 	L.state = ST_IDLE;
-	BtRes res;
 	BtReq req;
-	res.LA = 0;
-	for (int k = 0; k < 4; k++) { res.a[k] = 0; res.b[k] = 0; }
+	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0;
 	bool drained = false;
 	const BtCold* cold = A.cold;
 
@@ -70,18 +80,68 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		/* keep the compiler from hoisting the cold descriptor's fields into scalar registers for
 		 * the whole loop: they are read where they are used */
 		asm volatile("" : "+s"(cold));
-		/* advance to the next LF request, pulling new reads as old ones finish */
+
+		/* ---- the round's memory requests: every lane's loads are issued, then one wait ---------- */
+		BT_PROF_T0(t_rank);
+		BtRes res;
+		{
+			const bool isRank = req.kind == RQ_RANK;
+			const bool isFetch = req.kind == RQ_FETCH;
+			BtRankSel sel;
+			const bool m = L.mirror != 0;
+			sel.ebwt = m ? A.H.ebwt[1] : A.H.ebwt[0];
+			sel.zSide = m ? A.H.zSide[1] : A.H.zSide[0];
+			sel.zSym = m ? A.H.zSym[1] : A.H.zSym[0];
+			sel.f0 = m ? A.H.fchr[1][0] : A.H.fchr[0][0];
+			sel.f1 = m ? A.H.fchr[1][1] : A.H.fchr[0][1];
+			sel.f2 = m ? A.H.fchr[1][2] : A.H.fchr[0][2];
+			sel.f3 = m ? A.H.fchr[1][3] : A.H.fchr[0][3];
+			const uint32_t rowA = (uint32_t)req.a, rowB = (uint32_t)req.x;
+			const uint32_t sideA = rowA / BT_SIDE_SYMS, sideB = rowB / BT_SIDE_SYMS;
+			const uint8_t* pA = isRank ? sel.ebwt + (uint64_t)sideA * 64u : (const uint8_t*)(uintptr_t)req.a;
+			const uint8_t* pB = sel.ebwt + (uint64_t)sideB * 64u;
+			const uint32_t nA = isRank ? 4u : (isFetch ? req.n : 0u);
+			const bool hasB = isRank && req.n == 2;
+			const bool hasX = isFetch && req.x != 0;
+			BtU4 qa[4] = {}, qb[4] = {}, qx = {};
+			uint2 oa = make_uint2(0, 0), ob = make_uint2(0, 0);
+			BT_UNROLL
+			for (uint32_t k = 0; k < 4u; k++) if (k < nA) qa[k] = ((const BtU4*)pA)[k];
+			if (isRank) oa = *(const uint2*)((sideA & 1u) ? pA - 8 : pA + 120);
+			if (hasB) {
+				BT_UNROLL
+				for (uint32_t k = 0; k < 4u; k++) qb[k] = ((const BtU4*)pB)[k];
+				ob = *(const uint2*)((sideB & 1u) ? pB - 8 : pB + 120);
+			}
+			if (hasX) qx = *(const BtU4*)(uintptr_t)req.x;
+			if (isRank) {
+				uint32_t lf[4], la;
+				dev_rank4_loaded(sel, rowA, qa[0], qa[1], qa[2], qa[3], oa, lf, &la);
+				res.q[0].x = lf[0]; res.q[0].y = lf[1]; res.q[0].z = lf[2]; res.q[0].w = lf[3];
+				res.q[2].x = la;
+				if (hasB) {
+					uint32_t dummy;
+					dev_rank4_loaded(sel, rowB, qb[0], qb[1], qb[2], qb[3], ob, lf, &dummy);
+					res.q[1].x = lf[0]; res.q[1].y = lf[1]; res.q[1].z = lf[2]; res.q[1].w = lf[3];
+				}
+			} else {
+				res.q[0] = qa[0]; res.q[1] = qa[1]; res.q[2] = qa[2]; res.q[3] = qa[3]; res.x = qx;
+			}
+		}
+		BT_PROF_ADD(PS_RANK, t_rank);
+
+		/* ---- advance every lane to its next request, pulling new reads as old ones finish ------- */
 		for (;;) {
 			if (L.state == ST_IDLE) {
 				if (drained) break;
 				const uint32_t rd = atomicAdd(A.nextRead, 1u);
 				if (rd >= A.H.n_reads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
-				bt_lane_start(L, A.H, *cold, rd);
+				bt_lane_start(L, PROG, A.H, *cold, rd);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
-			bt_lane_run(L, A.H, *cold, S, res, req, CNT);
+			bt_lane_run(L, PROG, A.H, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state != ST_IDLE) break;
 		}
@@ -93,28 +153,13 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			const unsigned long long act = __ballot(1);
 			if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) BT_COUNT(CN_WROUNDS);
 		}
-		if (L.state == ST_CHASE_LFDONE) BT_COUNT(CN_CHASE);
-		else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
-		else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
-		else BT_COUNT(CN_LF1);
-		if ((req.op & 2u) && req.rowA / 448u == req.rowB / 448u) BT_COUNT(CN_SAMEPAIR);
-		/* the rank gathers of the whole wavefront */
-		BtRankSel sel;
-		const bool m = L.mirror != 0;
-		sel.ebwt = m ? A.H.ebwt[1] : A.H.ebwt[0];
-		sel.zSide = m ? A.H.zSide[1] : A.H.zSide[0];
-		sel.zSym = m ? A.H.zSym[1] : A.H.zSym[0];
-		sel.f0 = m ? A.H.fchr[1][0] : A.H.fchr[0][0];
-		sel.f1 = m ? A.H.fchr[1][1] : A.H.fchr[0][1];
-		sel.f2 = m ? A.H.fchr[1][2] : A.H.fchr[0][2];
-		sel.f3 = m ? A.H.fchr[1][3] : A.H.fchr[0][3];
-		BT_PROF_T0(t_rank);
-		dev_rank4(sel, req.rowA, res.a, &res.LA);
-		if (req.op & 2u) {
-			uint32_t dummy;
-			dev_rank4(sel, req.rowB, res.b, &dummy);
+		if (req.kind == RQ_RANK) {
+			if (L.lfk == LFK_CHASE) BT_COUNT(CN_CHASE);
+			else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
+			else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
+			else BT_COUNT(CN_LF1);
+			if (req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u) BT_COUNT(CN_SAMEPAIR);
 		}
-		BT_PROF_ADD(PS_RANK, t_rank);
 	}
 
 	__syncthreads();

@@ -130,6 +130,8 @@ typedef struct bt_op_counts {
 	uint64_t cand_scans;      /* frame scans for the deepest remaining target                 */
 	uint64_t wave_rounds;     /* lock-step rounds summed over wavefronts (GPU only);
 	                             lane_iters / wave_rounds = mean active lanes per round        */
+	uint64_t fetches;         /* rounds a lane spent on a non-rank request (read window, backtrack
+	                             target, frame record, record scan, ftab, SA sample)           */
 } bt_op_counts;
 
 /* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */

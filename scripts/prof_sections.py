@@ -6,8 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("BT_LIB", "libbowtie_amd_prof.so")
 import bench  # noqa
 from bowtie_amd import aligner as AL
-NAMES = ["RESUME", "SLOW", "EMIT(unused)", "RANK", "REFILL", "LANE_RUN", "FELL_OFF", "RESOLVE", "RA_END", "FRAME_RETURN",
-         "CHILD_RET", "SEARCH_END", "PHASE_NEXT", "SEARCH_BEGIN", "BT_LOOP", "RA_BEGIN", "ROW_BEGIN", "FRAME_ENTER", "RESCAN"]
+NAMES = ["RESUME", "SLOW", "WAIT(unused)", "FETCH+RANK", "REFILL", "LANE_RUN"]
 orig_counts = AL.lib().bt_ctx_counts
 def hook(h, cnt, reset):
     rc = orig_counts(h, cnt, reset)

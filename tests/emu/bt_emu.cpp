@@ -26,11 +26,11 @@ extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
 	EmuIndex* e = new EmuIndex();
 	e->mirror = need_mirror != 0;
 	if (bt_host_index_load(base, true, offrate, &e->h[0]) != BT_OK) { delete e; return nullptr; }
-	e->h[0].ebwt.resize(e->h[0].ebwt.size() + 128);
+	e->h[0].ebwt.resize(e->h[0].ebwt.size() + 128); e->h[0].ftab.resize(e->h[0].ftab.size() + 4); e->h[0].offs.resize(e->h[0].offs.size() + 4);
 	bind(e, 0);
 	if (need_mirror) {
 		if (bt_host_index_load(std::string(base) + ".rev", false, offrate, &e->h[1]) != BT_OK) { delete e; return nullptr; }
-		e->h[1].ebwt.resize(e->h[1].ebwt.size() + 128);
+		e->h[1].ebwt.resize(e->h[1].ebwt.size() + 128); e->h[1].ftab.resize(e->h[1].ftab.size() + 4); e->h[1].offs.resize(e->h[1].offs.size() + 4);
 		bind(e, 1);
 	} else e->d[1] = e->d[0];
 	return e;
@@ -63,7 +63,8 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	memset(&H, 0, sizeof(H));
 	for (int m = 0; m < 2; m++) {
 		H.ebwt[m] = e->d[m].ebwt; H.zSide[m] = e->d[m].zSide; H.zSym[m] = e->d[m].zSym; H.zOff[m] = e->d[m].zOff;
-		H.offMask[m] = e->d[m].offMask;
+		H.offMask[m] = e->d[m].offMask; H.ftab[m] = e->d[m].ftab; H.offs[m] = e->d[m].offs; H.offRate[m] = e->d[m].offRate;
+		H.ftabChars[m] = e->d[m].ftabChars; H.len[m] = e->d[m].len;
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
 	}
 	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
@@ -72,7 +73,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	std::vector<BtU4> pairs4((size_t)nLanes * entCap * 2);
 	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
-	std::vector<uint32_t> tos((size_t)nLanes * 13);
+	std::vector<uint32_t> tos((size_t)nLanes * BT_TOS_WORDS);
 	std::vector<BtLane> lanes(nLanes);
 	std::vector<BtScratch> scr(nLanes);
 	std::vector<BtRes> res(nLanes);
@@ -98,21 +99,33 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 			for (;;) {
 				if (L.state == ST_IDLE) {
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
-					bt_lane_start(L, H, cold, next++);
+					bt_lane_start(L, P, H, cold, next++);
 				}
-				bt_lane_run(L, H, cold, scr[g], res[g], req, CNT);
+				bt_lane_run(L, P, H, cold, scr[g], res[g], req, CNT);
 				if (L.state != ST_IDLE) break;
 			}
 			if (drained[g]) continue;
 			BT_COUNT(CN_ITERS);
-			if (L.state == ST_CHASE_LFDONE) BT_COUNT(CN_CHASE);
-			else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
-			else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
-			else BT_COUNT(CN_LF1);
-			if ((req.op & 2u) && req.rowA / 448u == req.rowB / 448u) BT_COUNT(CN_SAMEPAIR);
-			const BtIndexDev& ix = e->d[L.mirror];
-			bt_rank4(ix, req.rowA, res[g].a, &res[g].LA);
-			if (req.op & 2u) { uint32_t dummy; bt_rank4(ix, req.rowB, res[g].b, &dummy); }
+			L.iters++;
+			if (req.kind == RQ_RANK) {
+				if (L.lfk == LFK_CHASE) BT_COUNT(CN_CHASE);
+				else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
+				else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
+				else BT_COUNT(CN_LF1);
+				if (req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u) BT_COUNT(CN_SAMEPAIR);
+				const BtIndexDev& ix = e->d[L.mirror];
+				uint32_t lf[4], la, dummy;
+				bt_rank4(ix, (uint32_t)req.a, lf, &la);
+				res[g].q[0].x = lf[0]; res[g].q[0].y = lf[1]; res[g].q[0].z = lf[2]; res[g].q[0].w = lf[3];
+				res[g].q[2].x = la;
+				if (req.n == 2) {
+					bt_rank4(ix, (uint32_t)req.x, lf, &dummy);
+					res[g].q[1].x = lf[0]; res[g].q[1].y = lf[1]; res[g].q[1].z = lf[2]; res[g].q[1].w = lf[3];
+				}
+			} else {
+				for (uint32_t k = 0; k < req.n; k++) memcpy(&res[g].q[k], (const uint8_t*)(uintptr_t)req.a + 16 * k, 16);
+				if (req.x) memcpy(&res[g].x, (const void*)(uintptr_t)req.x, 16);
+			}
 		}
 	}
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
@@ -120,7 +133,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		counts->lfex = CNT[CN_LFEX]; counts->lf2 = CNT[CN_LF2]; counts->lf1 = CNT[CN_LF1]; counts->chase = CNT[CN_CHASE];
 		counts->ftab = CNT[CN_FTAB]; counts->offs = CNT[CN_OFFS]; counts->rstarts = CNT[CN_RSTARTS];
 		counts->frames = CNT[CN_FRAMES]; counts->lane_iters = CNT[CN_ITERS]; counts->same_pair = CNT[CN_SAMEPAIR];
-		counts->rescans = CNT[CN_RESCAN]; counts->cand_scans = CNT[CN_CANDSCAN];
+		counts->rescans = CNT[CN_RESCAN]; counts->cand_scans = CNT[CN_CANDSCAN]; counts->fetches = CNT[CN_FETCH];
 	}
 	return BT_OK;
 }
