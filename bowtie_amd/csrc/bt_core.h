@@ -176,14 +176,17 @@ enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_F
 
 /* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
  * cycles (s_memtime) per section, accumulated in LDS.  No-ops in the product build. */
-enum { PS_RESUME = 0, PS_SLOW, PS_WAIT, PS_RANK, PS_REFILL, PS_LOOP, PS_N };
+enum { PS_RESUME = 0, PS_SLOW, PS_WAIT, PS_RANK, PS_REFILL, PS_LOOP,
+       PS_FELL_OFF, PS_RESOLVE_DONE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_RESCAN, PS_SEARCH_END, PS_PHASE_NEXT, PS_SEARCH_BEGIN, PS_FTABSEQ_DONE, PS_FTAB_DONE, PS_BT_LOOP, PS_CANDSCAN, PS_BT_PICK, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_PASSES, PS_N };
 #if defined(BT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define BT_PROF_T0(v) const unsigned long long v = __builtin_readcyclecounter()
+#define BT_PROF_PASS() do { const unsigned long long ex_ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + PS_PASSES], 1ull); } while (0)
 #define BT_PROF_ADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
 	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + (k)], __builtin_readcyclecounter() - (v)); } while (0)
 #else
 #define BT_PROF_T0(v)
 #define BT_PROF_ADD(k, v)
+#define BT_PROF_PASS()
 #endif
 
 struct BtLane {
@@ -485,14 +488,15 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 	 * PHASE_NEXT -> SEARCH_BEGIN).  Within a block `break` leaves the block; a block that sets `req`
 	 * ends the lane's round (no later block runs: ST_IS tests req). */
 	while (BT_IS_SLOW(L.state) && req.kind == RQ_NONE) {
+		BT_PROF_PASS();
 		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */
-		if (ST_IS(ST_FELL_OFF)) do {
+		if (ST_IS(ST_FELL_OFF)) { BT_PROF_T0(t_fell_off); do {
 			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL);
 			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FELL_OFF, t_fell_off); }
 
 		/* ---- an SA walk reached a sampled row: offset -> (tidx,toff) -> sink (ebwt.h:2569-2746) ---- */
-		if (ST_IS(ST_RESOLVE_DONE)) do {
+		if (ST_IS(ST_RESOLVE_DONE)) { BT_PROF_T0(t_resolve_done); do {
 			const uint32_t zOff = HSEL(zOff);
 			uint32_t off;
 			if (L.crow == zOff) off = L.cjumps;
@@ -527,9 +531,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			if (hit && bt_report_hit(L, P, ixfw, S, B, tidx, toff)) { L.ret = 1; L.state = ST_RA_END; break; }
 			L.ra_i++;
 			L.state = ST_ROW_BEGIN;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RESOLVE_DONE, t_resolve_done); }
 
-		if (ST_IS(ST_RA_END)) do {
+		if (ST_IS(ST_RA_END)) { BT_PROF_T0(t_ra_end); do {
 			switch (L.ra_cont) {
 			case RC_STEP:
 				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
@@ -541,10 +545,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			case RC_FELL:  L.state = ST_FRAME_RETURN; break;
 			default:       L.state = ST_SEARCH_END; break;
 			}
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RA_END, t_ra_end); }
 
 		/* ---- return from a frame: pop the parent's record (LDS copy, else one fetch) ---------- */
-		if (ST_IS(ST_FRAME_RETURN) || ST_IS(ST_FRAME_FETCHED)) do {
+		if (ST_IS(ST_FRAME_RETURN) || ST_IS(ST_FRAME_FETCHED)) { BT_PROF_T0(t_frame_return); do {
 			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - 1u;
 			uint32_t w[BT_TOS_WORDS];
@@ -575,10 +579,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			L.pbttop = w[FR_PTOP]; L.pbtbot = w[FR_PBOT];
 			L.ebase = w[FR_EBASE];
 			L.state = ST_CHILD_RET;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FRAME_RETURN, t_frame_return); }
 
 		/* ---- a child frame (or a leaf report) came back (:972-1064) ---------------------- */
-		if (ST_IS(ST_CHILD_RET)) do {
+		if (ST_IS(ST_CHILD_RET)) { BT_PROF_T0(t_child_ret); do {
 			if (L.ret) { L.state = ST_FRAME_RETURN; break; }
 			if (L.bailed || (L.halfAndHalf && P.steps[L.step].maxBts > 0 && L.numBts >= P.steps[L.step].maxBts)) {
 				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
@@ -603,9 +607,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				if (L.d >= kmin) { L.scanCb = (L.ebase + (L.d - L.depth)) >> 3; L.state = ST_RESCAN; break; }
 			}
 			L.state = ST_BT_LOOP;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_CHILD_RET, t_child_ret); }
 
-		if (ST_IS(ST_RESCAN) || ST_IS(ST_RESCAN_DONE)) do {
+		if (ST_IS(ST_RESCAN) || ST_IS(ST_RESCAN_DONE)) { BT_PROF_T0(t_rescan); do {
 			const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
 			const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
 			const uint32_t c_lo = e_lo >> 3;
@@ -633,10 +637,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			}
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_RESCAN; break; }
 			L.state = ST_BT_LOOP;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RESCAN, t_rescan); }
 
 		/* ---- backtrack() exit (:333-353, 303-324) + the seedling-extension loop ---------- */
-		if (ST_IS(ST_SEARCH_END)) do {
+		if (ST_IS(ST_SEARCH_END)) { BT_PROF_T0(t_search_end); do {
 			L.numBts = 0;
 			if (L.kind == BT_KIND_EXTEND) {
 				/* search_seeded_phase3.c:9-59 / phase4.c:9-55: for each seedling, setMuts +
@@ -670,10 +674,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			if (L.kind == BT_KIND_GEN) { L.state = ST_PHASE_NEXT; break; }
 			if (L.ret) { bt_lane_finish(L, B); break; }
 			L.state = ST_PHASE_NEXT;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_SEARCH_END, t_search_end); }
 
 		/* ---- phase script ------------------------------------------------------------- */
-		if (ST_IS(ST_PHASE_NEXT)) do {
+		if (ST_IS(ST_PHASE_NEXT)) { BT_PROF_T0(t_phase_next); do {
 			L.step = L.step + 1u;        /* 5-bit wrap: 31 -> 0 */
 			if ((int32_t)L.step >= P.nsteps || (L.status & BT_STF_OVERFLOW)) { bt_lane_finish(L, B); break; }
 			const BtStep& st = P.steps[L.step];
@@ -696,10 +700,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				break;
 			}
 			L.state = ST_SEARCH_BEGIN;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_PHASE_NEXT, t_phase_next); }
 
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
-		if (ST_IS(ST_SEARCH_BEGIN)) do {
+		if (ST_IS(ST_SEARCH_BEGIN)) { BT_PROF_T0(t_search_begin); do {
 			L.bailed = 0; L.sd = 0;
 			uint32_t nsInFtab = 0;
 			const uint32_t ftabChars = HSEL(ftabChars);
@@ -735,9 +739,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			} else {
 				L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER;
 			}
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_SEARCH_BEGIN, t_search_begin); }
 
-		if (ST_IS(ST_FTABSEQ_DONE)) do {
+		if (ST_IS(ST_FTABSEQ_DONE)) { BT_PROF_T0(t_ftabseq_done); do {
 			const uint32_t ftabChars = HSEL(ftabChars);
 			const uint32_t i0 = L.qlen - ftabChars, i1 = L.qlen - 1u;
 			const uint32_t j0 = L.rev ? (L.plen - 1u - i1) : i0;
@@ -755,9 +759,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			L.ra_r = ftabOff;           /* parked until the table entry arrives */
 			BT_REQ_FETCH(ftab + (ftabOff & ~3u), 1, ftab + ((ftabOff + 1u) & ~3u));
 			L.state = ST_FTAB_DONE;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FTABSEQ_DONE, t_ftabseq_done); }
 
-		if (ST_IS(ST_FTAB_DONE)) do {
+		if (ST_IS(ST_FTAB_DONE)) { BT_PROF_T0(t_ftab_done); do {
 			const uint32_t ftabChars = HSEL(ftabChars), len = HSEL(len);
 			const uint32_t ftabOff = L.ra_r;
 			uint32_t top = bt_u4_word(res.q[0], ftabOff & 3u);
@@ -772,10 +776,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			} else if (bot > top) {
 				L.depth = ftabChars; L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER;
 			} else { L.ret = 0; L.state = ST_SEARCH_END; }
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FTAB_DONE, t_ftab_done); }
 
 		/* ---- choose a backtrack target and descend (:743-971) --------------------------- */
-		if (ST_IS(ST_BT_LOOP)) do {
+		if (ST_IS(ST_BT_LOOP)) { BT_PROF_T0(t_bt_loop); do {
 			if (!L.candValid) {
 				/* the deepest position that still has a target of the eligible quality (the
 				 * `for(; i >= depth; i--)` walk of :767-812), batch by batch */
@@ -788,9 +792,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			const uint32_t e = L.ebase + (L.cand - L.depth);
 			BT_REQ_FETCH(&PT(e, 0), 2, &META(e & ~7u));
 			L.state = ST_BT_PICK;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_BT_LOOP, t_bt_loop); }
 
-		if (ST_IS(ST_CANDSCAN) || ST_IS(ST_CANDSCAN_DONE)) do {
+		if (ST_IS(ST_CANDSCAN) || ST_IS(ST_CANDSCAN_DONE)) { BT_PROF_T0(t_candscan); do {
 			const uint32_t e_lo = L.ebase, e_hi = L.ebase + (L.d - L.depth);
 			const uint32_t c_lo = e_lo >> 3;
 			if (L.state == ST_CANDSCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_CANDSCAN_DONE; break; }
@@ -810,9 +814,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			if (found) { L.state = ST_BT_LOOP; break; }
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_CANDSCAN; break; }
 			L.state = ST_ABORT;                                   /* cannot happen: altNum > 0 */
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_CANDSCAN, t_candscan); }
 
-		if (ST_IS(ST_BT_PICK)) do {
+		if (ST_IS(ST_BT_PICK)) { BT_PROF_T0(t_bt_pick); do {
 			const uint32_t i = L.cand;
 			const uint32_t e = L.ebase + (i - L.depth);
 			const uint32_t mv = bt_u4_meta(res.x, e & 7u);
@@ -898,10 +902,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_BT_PICK, t_bt_pick); }
 
 		/* ---- reportAlignment / reportFullAlignment (:1455-1565) -------------------------- */
-		if (ST_IS(ST_RA_BEGIN)) do {
+		if (ST_IS(ST_RA_BEGIN)) { BT_PROF_T0(t_ra_begin); do {
 			if (L.reportPartials) {
 				if (L.ra_sd > 0) bt_report_partial(L, S, L.ra_sd);
 				L.ret = 0; L.state = ST_RA_END; break;
@@ -920,19 +924,19 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				L.ra_i = 0;
 			}
 			L.state = ST_ROW_BEGIN;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_RA_BEGIN, t_ra_begin); }
 
-		if (ST_IS(ST_ROW_BEGIN)) do {
+		if (ST_IS(ST_ROW_BEGIN)) { BT_PROF_T0(t_row_begin); do {
 			const uint32_t spread = L.ra_bot - L.ra_top;
 			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
 			uint32_t ri = L.ra_r + L.ra_i;
 			if (ri >= L.ra_bot) ri -= spread;
 			L.crow = ri; L.cjumps = 0;
 			L.state = ST_CHASE_CHECK;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
 
 		/* ---- frame prologue (:363-455) -------------------------------------------------- */
-		if (ST_IS(ST_FRAME_ENTER)) do {
+		if (ST_IS(ST_FRAME_ENTER)) { BT_PROF_T0(t_frame_enter); do {
 			BT_COUNT(CN_FRAMES);
 			if (L.halfAndHalf) {
 				const uint32_t maxBts = P.steps[L.step].maxBts;
@@ -944,7 +948,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0;
 			L.d = L.depth;
 			L.state = ST_STEP_BEGIN;
-		} while (0);
+		} while (0); BT_PROF_ADD(PS_FRAME_ENTER, t_frame_enter); }
 
 		if (ST_IS(ST_ABORT)) { L.status = L.status | BT_STF_OVERFLOW; bt_lane_finish(L, B); }
 	}
