@@ -37,7 +37,11 @@ struct bt_ctx {
 	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
 	int occ = 2;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint16_t* meta = nullptr; uint64_t* pals = nullptr;
-	uint32_t* d_cursor = nullptr;      /* [0] nextRead, [1] mm_pool_used */
+	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [2] spare-slot cursor,
+	                                      [3] pool1 count, [4] pool1 cursor, [5] pool2 count, [6] pool2 cursor */
+	BtPoolRec *pool1 = nullptr, *pool2 = nullptr;
+	uint32_t pool1Cap = 0, pool2Cap = 0, nSlots = 0;
+	uint32_t heavy0 = 0, heavy1 = 0;
 	BtCold* d_cold = nullptr;
 	unsigned long long* d_counts = nullptr;
 	/* staging for the host-pointer entry point */
@@ -142,23 +146,39 @@ static void ctx_free_scratch(bt_ctx* c)
 	c->frames = c->pairs = nullptr; c->meta = nullptr; c->pals = nullptr;
 }
 
-/* (re)size the per-lane arenas for reads up to maxLen */
-static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen)
+/* (re)size the per-slot arenas for reads up to maxLen and batches of n_reads.  Slots beyond the
+ * nLanes resident lanes back the reads that get parked as "heavy" (see BtPoolRec). */
+static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
 {
-	if (c->frames && maxLen <= c->maxLen) return BT_OK;
+	/* heavy-read offload only pays (and only has anything to offload) on batches that keep the
+	 * lanes refilling for a while */
+	uint32_t want1 = 0, want2 = 0;
+	if (c->heavy0 > 0 && n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes)) {
+		want1 = n_reads / 64u + 4096u;
+		want2 = n_reads / 512u + 1024u;
+	}
+	if (c->frames && maxLen <= c->maxLen && want1 <= c->pool1Cap && want2 <= c->pool2Cap) return BT_OK;
 	ctx_free_scratch(c);
-	c->maxLen = maxLen < 64 ? 64 : maxLen;
+	if (c->pool1) (void)hipFree(c->pool1);
+	if (c->pool2) (void)hipFree(c->pool2);
+	c->pool1 = c->pool2 = nullptr;
+	c->maxLen = maxLen < 64 ? 64 : (maxLen > c->maxLen ? maxLen : c->maxLen);
+	c->pool1Cap = want1 > c->pool1Cap ? want1 : c->pool1Cap;
+	c->pool2Cap = want2 > c->pool2Cap ? want2 : c->pool2Cap;
+	c->nSlots = c->nLanes + c->pool1Cap + c->pool2Cap;
 	const bool seeded = c->pol.mode == BT_MODE_N;
-	/* range-stack entries per lane: every frame may span the whole read.  -v k has k+1 frames;
+	/* range-stack entries per slot: every frame may span the whole read.  -v k has k+1 frames;
 	 * -n: frames are bounded by -e / min penalty (10) unless the read has Phred<5 bases. */
 	uint32_t frames = seeded ? 12u : (uint32_t)c->pol.mms + 2u;
 	c->frCap = env_u32("BT_FRAME_CAP", seeded ? 64u : 8u);
-	c->entCap = (env_u32("BT_ENTRY_CAP", frames * c->maxLen) + 7u) & ~7u;      /* lane regions stay 16-byte aligned */
+	c->entCap = (env_u32("BT_ENTRY_CAP", frames * c->maxLen) + 7u) & ~7u;      /* slot regions stay 16-byte aligned */
 	c->palCap = env_u32("BT_PARTIAL_CAP", seeded ? (c->pol.mms >= 3 ? 8192u : 1024u) : 1u);
-	HIPCHK(hipMalloc((void**)&c->frames, (size_t)c->nLanes * c->frCap * BT_FR_WORDS * 4u));
-	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nLanes * c->entCap * 32u));
-	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nLanes * c->entCap * 2u));
-	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nLanes * c->palCap * 8u));
+	HIPCHK(hipMalloc((void**)&c->frames, (size_t)c->nSlots * c->frCap * BT_FR_WORDS * 4u));
+	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nSlots * c->entCap * 32u));
+	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nSlots * c->entCap * 2u));
+	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nSlots * c->palCap * 8u));
+	if (c->pool1Cap) HIPCHK(hipMalloc((void**)&c->pool1, (size_t)c->pool1Cap * sizeof(BtPoolRec)));
+	if (c->pool2Cap) HIPCHK(hipMalloc((void**)&c->pool2, (size_t)c->pool2Cap * sizeof(BtPoolRec)));
 	return BT_OK;
 }
 
@@ -185,7 +205,9 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	if (c->occ > 4) c->occ = 4;
 	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", (uint32_t)c->occ);
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
-	HIPCHK(hipMalloc((void**)&c->d_cursor, 8));
+	HIPCHK(hipMalloc((void**)&c->d_cursor, 32));
+	c->heavy0 = env_u32("BT_HEAVY0", 16384);
+	c->heavy1 = env_u32("BT_HEAVY1", 65536);
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long)));
@@ -200,6 +222,8 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	ctx_free_scratch(c);
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_cold) (void)hipFree(c->d_cold);
+	if (c->pool1) (void)hipFree(c->pool1);
+	if (c->pool2) (void)hipFree(c->pool2);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->stage) (void)hipFree(c->stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -216,7 +240,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	    out->hit_cap == 0 || in->stride == 0 || (in->stride & 15u) != 0 ||
 	    ((uintptr_t)in->seq & 15u) != 0 || ((uintptr_t)in->qual & 15u) != 0) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
-	int rc = ctx_ensure_scratch(c, maxLen);
+	int rc = ctx_ensure_scratch(c, maxLen, in->n_reads);
 	if (rc != BT_OK) return rc;
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
@@ -242,15 +266,37 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
 	A.cold = c->d_cold;
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
-	A.nLanes = c->nLanes; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
-	A.nextRead = c->d_cursor;
+	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
 	A.counts = counts_dev ? counts_dev : c->d_counts;
+	A.nextSlot = c->d_cursor + 2;
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	const uint32_t maxBlocks = c->nLanes / BT_BLOCK;
 	if (nBlocks > maxBlocks) nBlocks = maxBlocks;
-	HIPCHK(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+	const bool offload = c->pool1 != nullptr && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
+	const uint32_t init[8] = {0, 0, c->nLanes, 0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	/* level 0: all reads; reads that reach heavy0 rounds are parked in pool 1 */
+	A.nextRead = c->d_cursor;
+	A.poolIn = nullptr; A.poolInCount = nullptr;
+	A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
+	A.heavyRounds = c->heavy0;
 	if (bt_launch_search(&A, nBlocks, c->occ, c->stream) != 0) return BT_ERR_DEVICE;
+	if (offload) {
+		/* level 1: the parked reads, one per lane; those that reach heavy1 rounds move on to pool 2 */
+		auto blocksFor = [&](uint32_t cap) { uint32_t b = (cap + BT_BLOCK - 1) / BT_BLOCK; return b > maxBlocks ? maxBlocks : (b ? b : 1u); };
+		A.nextRead = c->d_cursor + 4;
+		A.poolIn = c->pool1; A.poolInCount = c->d_cursor + 3;
+		A.poolOut = c->pool2; A.poolOutCount = c->d_cursor + 5; A.poolOutCap = c->pool2Cap;
+		A.heavyRounds = c->heavy1;
+		if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, c->stream) != 0) return BT_ERR_DEVICE;
+		/* level 2: run whatever is left to completion */
+		A.nextRead = c->d_cursor + 6;
+		A.poolIn = c->pool2; A.poolInCount = c->d_cursor + 5;
+		A.poolOut = nullptr; A.poolOutCount = nullptr; A.poolOutCap = 0;
+		A.heavyRounds = 0xffffffffu;
+		if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, c->stream) != 0) return BT_ERR_DEVICE;
+	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
 	return BT_OK;

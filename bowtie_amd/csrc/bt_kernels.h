@@ -6,16 +6,29 @@
 
 #define BT_BLOCK 256
 
+/* A read that has run for more than `heavyRounds` rounds is taken out of its lane: the lane's whole
+ * state (automaton + pending request + scratch slot) is parked in a pool record and the lane pulls
+ * the next read.  A follow-up launch of the same kernel adopts the parked reads, one per lane, so
+ * the few reads that backtrack for 10^5 rounds neither hold 63 idle lanes hostage nor keep the
+ * batch's other wavefronts from retiring. */
+#define BT_POOL_WORDS 64
+struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot, [50..55] BtReq */
+
 struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */
 	const BtCold* cold;          /* device memory: program, full index descriptors, batch        */
-	/* per-lane scratch arenas (see BtScratch) */
-	uint32_t*  frames;           /* [nLanes][frCap][16]                                           */
-	uint32_t*  pairs;            /* [nLanes][entCap][8]                                          */
-	uint16_t*  meta;             /* [nLanes][entCap] mask | Phred<<8                             */
-	uint64_t*  pals;             /* [nLanes][palCap]                                             */
-	uint32_t   nLanes, frCap, entCap, palCap;
-	uint32_t*  nextRead;         /* global read cursor                                           */
+	/* per-slot scratch arenas (see BtScratch); slots 0..nLanes-1 belong to the lanes of the first
+	 * launch, the rest are handed out when a lane parks a heavy read and needs a fresh slot      */
+	uint32_t*  frames;           /* [nSlots][frCap][12]                                          */
+	uint32_t*  pairs;            /* [nSlots][entCap][8]                                          */
+	uint16_t*  meta;             /* [nSlots][entCap] mask | Phred<<8                             */
+	uint64_t*  pals;             /* [nSlots][palCap]                                             */
+	uint32_t   nLanes, nSlots, frCap, entCap, palCap;
+	uint32_t*  nextRead;         /* work cursor: read ids (level 0) or pool records (level > 0)  */
+	uint32_t*  nextSlot;         /* spare-slot cursor (starts at nLanes)                         */
+	const BtPoolRec* poolIn;  const uint32_t* poolInCount;      /* NULL at level 0               */
+	BtPoolRec* poolOut;       uint32_t* poolOutCount;  uint32_t poolOutCap;   /* NULL at the last level */
+	uint32_t   heavyRounds;      /* park reads that reach this many rounds                       */
 	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
 };
 

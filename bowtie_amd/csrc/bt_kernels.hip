@@ -66,6 +66,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BtScratch S;
 	S.frames = A.frames; S.pairs = A.pairs; S.meta = A.meta; S.pals = A.pals; S.slot = g;
+	static_assert(sizeof(BtLane) <= 48 * 4 && sizeof(BtReq) <= 6 * 4, "pool record layout");
 	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 
@@ -134,16 +135,51 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		for (;;) {
 			if (L.state == ST_IDLE) {
 				if (drained) break;
-				const uint32_t rd = atomicAdd(A.nextRead, 1u);
-				if (rd >= A.H.n_reads) { drained = true; break; }
+				const uint32_t w = atomicAdd(A.nextRead, 1u);
+				if (A.poolIn) {
+					/* adopt a parked read: state, scratch slot and its pending request */
+					if (w >= *A.poolInCount) { drained = true; break; }
+					const BtPoolRec* r = A.poolIn + w;
+					uint32_t t[56];
+					BT_UNROLL
+					for (int k = 0; k < 14; k++) { const BtU4 v = ((const BtU4*)r->w)[k]; t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w; }
+					__builtin_memcpy(&L, t, sizeof(BtLane));
+					S.slot = t[48];
+					__builtin_memcpy(&req, t + 50, sizeof(BtReq));
+					L.tosValid = 0;
+					break;                                   /* its request is served at the top of the next round */
+				}
+				if (w >= A.H.n_reads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
-				bt_lane_start(L, PROG, A.H, *cold, rd);
+				bt_lane_start(L, PROG, A.H, *cold, w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
 			bt_lane_run(L, PROG, A.H, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
-			if (L.state != ST_IDLE) break;
+			if (L.state == ST_IDLE) continue;
+			if (A.poolOut && L.iters >= A.heavyRounds) {
+				/* park this read (it resumes, bit for bit, in the next launch) and free the lane */
+				const uint32_t slot = atomicAdd(A.poolOutCount, 1u);
+				const uint32_t fresh = atomicAdd(A.nextSlot, 1u);
+				if (slot < A.poolOutCap && fresh < A.nSlots) {
+					uint32_t t[56];
+					BT_UNROLL
+					for (int k = 0; k < 56; k++) t[k] = 0;
+					__builtin_memcpy(t, &L, sizeof(BtLane));
+					t[48] = S.slot;
+					__builtin_memcpy(t + 50, &req, sizeof(BtReq));
+					BtPoolRec* r = A.poolOut + slot;
+					BT_UNROLL
+					for (int k = 0; k < 14; k++) { BtU4 v; v.x = t[4 * k]; v.y = t[4 * k + 1]; v.z = t[4 * k + 2]; v.w = t[4 * k + 3]; ((BtU4*)r->w)[k] = v; }
+					S.slot = fresh;
+					L.state = ST_IDLE;
+					req.kind = RQ_NONE;
+					continue;
+				}
+				/* pool or slot arena full: the read simply stays in its lane */
+			}
+			break;
 		}
 		if (L.state == ST_IDLE) break;
 		/* op counters: one LDS atomic per wavefront per kind */
