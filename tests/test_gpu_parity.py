@@ -156,3 +156,17 @@ def test_gpu_max_length_reads(gidx):
     for mode in ("v2", "n2"):
         kw = T.MODES[mode]
         T.compare_results(aligner(gidx, "e_coli", kw).align(batch), T.oracle_results("e_coli", batch, kw), mode)
+
+
+def test_gpu_heavy_read_offload_is_transparent(gidx, monkeypatch):
+    """Reads that run long are parked mid-search and resumed by follow-up launches (two levels);
+    with tiny thresholds nearly every read takes that path -- results must not change."""
+    monkeypatch.setenv("BT_HEAVY0", "25")
+    monkeypatch.setenv("BT_HEAVY1", "90")
+    monkeypatch.setenv("BT_HEAVY_MIN_BATCH", "1")
+    for index, rname, mode in (("multi", "syn100", "n2"), ("multi", "syn50lowq", "n3"), ("e_coli", "syn76", "v2"),
+                               ("multi", "syn76", "n1_a_m20")):
+        batch = T.read_set(index, rname)
+        kw = T.MODES[mode]
+        got = aligner(gidx, index, kw).align(batch, hit_cap=T.hit_cap_for(kw))
+        T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "offload " + mode)
