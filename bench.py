@@ -42,8 +42,8 @@ WORKLOADS = {
     "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
     "ecoli_v2_76": dict(index="ecoli", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=2_000_000),
     "ecoli_n2_100": dict(index="ecoli", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=2_000_000),
-    "big_v2_76": dict(index="big", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=20_000_000),
-    "big_n2_100": dict(index="big", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=20_000_000),
+    "big_v2_76": dict(index="big", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=48_000_000),
+    "big_n2_100": dict(index="big", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=48_000_000),
 }
 
 
@@ -113,7 +113,7 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("BT_WORKLOAD", "big_n2_100"))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = workload default)")

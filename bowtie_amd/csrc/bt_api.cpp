@@ -206,7 +206,9 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", (uint32_t)c->occ);
 	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 32));
-	c->heavy0 = env_u32("BT_HEAVY0", 16384);
+	/* heavy-read offload is off by default: measured on MI355X (profiles/README.md) it raises lane
+	 * utilisation but lengthens the batch tail; BT_HEAVY0=<rounds> turns it on */
+	c->heavy0 = env_u32("BT_HEAVY0", 0);
 	c->heavy1 = env_u32("BT_HEAVY1", 65536);
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
