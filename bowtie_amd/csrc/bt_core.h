@@ -72,7 +72,7 @@ struct BtProgram {
 enum {
 	FR_W0 = 0,   /* depth | d<<11                                                                */
 	FR_W1,       /* ham | lowAltQual<<16                                                         */
-	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25                      */
+	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25 | ccValid<<26 (LDS copy only) */
 	FR_W3,       /* f2 | f3<<11                                                                  */
 	FR_W4,       /* altNum | eligibleNum<<12                                                     */
 	FR_W5,       /* cand                                                                         */
@@ -82,6 +82,8 @@ enum {
 	FR_PAD
 };
 #define BT_TOS_WORDS 10      /* FR_W0..FR_EBASE travel to the LDS top-of-stack copy              */
+#define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
+#define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
 
 struct BtScratch {
 	/* arena bases (wave-uniform) + this lane's slot; addresses are formed where they are used */
@@ -89,7 +91,9 @@ struct BtScratch {
 	uint32_t* pairs;    /* [slot][entry][8]: tops ACGT, bots ACGT                                */
 	uint16_t* meta;     /* [slot][entry] eliminated-chars mask | Phred<<8                        */
 	uint64_t* pals;     /* [slot][palCap] seedlings                                              */
-	uint32_t* tos;      uint32_t tosStride;  /* LDS: word w of the top-of-stack record at tos[w*tosStride] */
+	uint32_t* tos;      uint32_t tosStride;  /* LDS, word w at tos[w*tosStride]: [0,9) the candidate's ranges +
+	                                            record, [9,19) top-of-stack frame record, [19,28) that
+	                                            frame's candidate */
 	uint32_t  slot, frCap, entCap, palCap;
 };
 
@@ -219,7 +223,7 @@ struct BtLane {
 	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, state : 5, ra_cont : 2;
 	/* pending backtrack target */
 	uint32_t pi : 11, pj : 2, btham : 16;
-	uint32_t pel : 4, tosFrame : 7, tosValid : 1;
+	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1;
 	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
@@ -366,7 +370,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
 	L.cchunk = 0xffu;
-	L.iters = 0; L.tosValid = 0;
+	L.iters = 0; L.tosValid = 0; L.ccValid = 0;
 	L.state = ST_PHASE_NEXT;
 	const uint32_t plen = L.plen;
 	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
@@ -552,6 +556,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - 1u;
 			uint32_t w[BT_TOS_WORDS];
+			bool fromTos = false;
 			if (L.state == ST_FRAME_FETCHED) {
 				w[0] = res.q[0].x; w[1] = res.q[0].y; w[2] = res.q[0].z; w[3] = res.q[0].w;
 				w[4] = res.q[1].x; w[5] = res.q[1].y; w[6] = res.q[1].z; w[7] = res.q[1].w;
@@ -559,8 +564,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
 				BT_UNROLL
-				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) w[k] = S.tos[k * ts];
+				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) w[k] = S.tos[(BT_CC_WORDS + k) * ts];
 				L.tosValid = 0;
+				fromTos = true;
 			} else {
 				BT_REQ_FETCH(&FRW(f, 0), 3, nullptr);
 				L.state = ST_FRAME_FETCHED;
@@ -572,6 +578,12 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			v = w[FR_W1]; L.ham = v & 0xffffu; L.lowAltQual = (v >> 16) & 0xffu;
 			v = w[FR_W2]; L.fu = v & 0x7ffu; L.f1 = (v >> 11) & 0x7ffu; L.elcint = (v >> 22) & 3u;
 			L.elignore = (v >> 24) & 1u; L.candValid = (v >> 25) & 1u;
+			L.ccValid = fromTos ? ((v >> 26) & 1u) : 0u;
+			if (L.ccValid) {
+				const uint32_t ts = S.tosStride;
+				BT_UNROLL
+				for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[k * ts] = S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts];
+			}
 			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
 			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
 			L.cand = w[FR_W5] & 0x7ffu;
@@ -592,7 +604,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				const uint32_t el = L.pel | (1u << L.pj);           /* the mask travelled with the frame record */
 				((uint8_t*)&META(e))[0] = (uint8_t)el;
 				L.pel = el;
-				if (el == 15u) L.candValid = 0;             /* that position is exhausted: scan next time */
+				if (L.ccValid && L.pi == L.cand) S.tos[8u * S.tosStride] = (S.tos[8u * S.tosStride] & ~15u) | el;
+				if (el == 15u) { L.candValid = 0; L.ccValid = 0; }      /* that position is exhausted: scan next time */
 			}
 			L.eligibleNum = L.eligibleNum - 1u;
 			L.elignore = 1;
@@ -602,7 +615,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				/* re-scan the frame for the next-lowest-quality set of targets (:1004-1058), one
 				 * fetched batch of records per round, deepest position first */
 				BT_COUNT(CN_RESCAN);
-				L.lowAltQual = 0xff; L.candValid = 0;
+				L.lowAltQual = 0xff; L.candValid = 0; L.ccValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
 				if (L.d >= kmin) { L.scanCb = (L.ebase + (L.d - L.depth)) >> 3; L.state = ST_RESCAN; break; }
 			}
@@ -628,7 +641,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 					if (L.ham + bt_mm_penalty(L.maq, kq) > L.qualThresh) continue;
 					if (kq < L.lowAltQual) {
 						L.lowAltQual = kq; L.eligibleNum = 0;
-						L.cand = L.depth + (e - L.ebase); L.candValid = 1;
+						L.cand = L.depth + (e - L.ebase); L.candValid = 1; L.ccValid = 0;
 						L.elcint = (el & 1u) == 0 ? 0u : (el & 2u) == 0 ? 1u : (el & 4u) == 0 ? 2u : 3u;
 						L.elignore = 0;
 					}
@@ -788,10 +801,11 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				L.state = ST_CANDSCAN;
 				break;
 			}
+			L.state = ST_BT_PICK;
+			if (L.ccValid) break;                        /* its ranges are in LDS: pick right away */
 			/* fetch the target position's four (top,bot) ranges and its (mask,quality) record */
 			const uint32_t e = L.ebase + (L.cand - L.depth);
 			BT_REQ_FETCH(&PT(e, 0), 2, &META(e & ~7u));
-			L.state = ST_BT_PICK;
 		} while (0); BT_PROF_ADD(PS_BT_LOOP, t_bt_loop); }
 
 		if (ST_IS(ST_CANDSCAN) || ST_IS(ST_CANDSCAN_DONE)) { BT_PROF_T0(t_candscan); do {
@@ -807,7 +821,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				for (int k = 7; k >= 0; k--) {
 					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k, v = bt_u4_meta(res.q[t], (uint32_t)k);
 					if (!found && e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u) {
-						L.cand = L.depth + (e - L.ebase); L.candValid = 1; found = true;
+						L.cand = L.depth + (e - L.ebase); L.candValid = 1; L.ccValid = 0; found = true;
 					}
 				}
 			}
@@ -819,10 +833,23 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 		if (ST_IS(ST_BT_PICK)) { BT_PROF_T0(t_bt_pick); do {
 			const uint32_t i = L.cand;
 			const uint32_t e = L.ebase + (i - L.depth);
-			const uint32_t mv = bt_u4_meta(res.x, e & 7u);
+			const uint32_t ts = S.tosStride;
+			uint32_t mv, tp[4], bp[4];
+			if (L.ccValid) {
+				BT_UNROLL
+				for (uint32_t k = 0; k < 4u; k++) { tp[k] = S.tos[k * ts]; bp[k] = S.tos[(4u + k) * ts]; }
+				mv = S.tos[8u * ts];
+			} else {
+				tp[0] = res.q[0].x; tp[1] = res.q[0].y; tp[2] = res.q[0].z; tp[3] = res.q[0].w;
+				bp[0] = res.q[1].x; bp[1] = res.q[1].y; bp[2] = res.q[1].z; bp[3] = res.q[1].w;
+				mv = bt_u4_meta(res.x, e & 7u);
+				BT_UNROLL
+				for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = tp[k]; S.tos[(4u + k) * ts] = bp[k]; }
+				S.tos[8u * ts] = mv;
+				L.ccValid = 1;
+			}
 			const uint32_t el = mv & 15u, qi = mv >> 8;
-			const uint32_t tp[4] = {res.q[0].x, res.q[0].y, res.q[0].z, res.q[0].w};
-			const uint32_t sp[4] = {res.q[1].x - tp[0], res.q[1].y - tp[1], res.q[1].z - tp[2], res.q[1].w - tp[3]};
+			const uint32_t sp[4] = {bp[0] - tp[0], bp[1] - tp[1], bp[2] - tp[2], bp[3] - tp[3]};
 			uint32_t j = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
 				uint32_t posSz = 0;
@@ -883,7 +910,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				uint32_t w[BT_TOS_WORDS];
 				w[FR_W0] = L.depth | (L.d << 11);
 				w[FR_W1] = L.ham | (L.lowAltQual << 16);
-				w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25);
+				w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (L.ccValid << 26);
 				w[FR_W3] = L.f2 | (L.f3 << 11);
 				w[FR_W4] = L.altNum | (L.eligibleNum << 12);
 				w[FR_W5] = L.cand;
@@ -893,9 +920,12 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
 				fr[0] = q0; fr[1] = q1;
 				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE];
-				const uint32_t ts = S.tosStride;
 				BT_UNROLL
-				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tos[k * ts] = w[k];
+				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tos[(BT_CC_WORDS + k) * ts] = w[k];
+				if (L.ccValid) {
+					BT_UNROLL
+					for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts] = S.tos[k * ts];
+				}
 				L.tosFrame = L.sd; L.tosValid = 1;
 			}
 			L.ebase = L.ebase + (L.d - L.depth + 1u);
@@ -945,7 +975,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			}
 			L.altNum = 0; L.eligibleNum = 0;
 			L.elcint = 0; L.elignore = 1;
-			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0;
+			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0;
 			L.d = L.depth;
 			L.state = ST_STEP_BEGIN;
 		} while (0); BT_PROF_ADD(PS_FRAME_ENTER, t_frame_enter); }
@@ -1022,7 +1052,15 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 						L.altNum = L.altNum + 1u;
 					}
 				}
-				if (L.fl_elig && el != 15u) { L.cand = d; L.candValid = 1; }     /* deepest eligible target so far */
+				if (L.fl_elig && el != 15u) {
+					/* deepest eligible target so far; its ranges go to the LDS candidate slot so that
+					 * choosing it later costs no fetch */
+					L.cand = d; L.candValid = 1; L.ccValid = 1;
+					const uint32_t ts = S.tosStride;
+					BT_UNROLL
+					for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = ta[k]; S.tos[(4u + k) * ts] = tb[k]; }
+					S.tos[8u * ts] = el | (q << 8);
+				}
 			}
 			META(e) = (uint16_t)(el | (q << 8));
 			bool btDespite = false, reportedPartial = false;

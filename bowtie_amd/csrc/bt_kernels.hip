@@ -56,7 +56,7 @@ template <int OCC>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
 	__shared__ unsigned long long CNT[CN_N + PS_N];
-	__shared__ uint32_t TOS[BT_TOS_WORDS * BT_BLOCK];          /* top-of-stack frame record per lane */
+	__shared__ uint32_t TOS[BT_LDS_WORDS * BT_BLOCK];          /* per lane: candidate, top-of-stack record, its candidate */
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
 	for (uint32_t i = threadIdx.x; i < sizeof(BtProgram) / 4; i += blockDim.x)
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 					__builtin_memcpy(&L, t, sizeof(BtLane));
 					S.slot = t[48];
 					__builtin_memcpy(&req, t + 50, sizeof(BtReq));
-					L.tosValid = 0;
+					L.tosValid = 0; L.ccValid = 0;
 					break;                                   /* its request is served at the top of the next round */
 				}
 				if (w >= A.H.n_reads) { drained = true; break; }

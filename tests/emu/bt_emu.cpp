@@ -73,7 +73,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	std::vector<BtU4> pairs4((size_t)nLanes * entCap * 2);
 	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
-	std::vector<uint32_t> tos((size_t)nLanes * BT_TOS_WORDS);
+	std::vector<uint32_t> tos((size_t)nLanes * BT_LDS_WORDS);
 	std::vector<BtLane> lanes(nLanes);
 	std::vector<BtScratch> scr(nLanes);
 	std::vector<BtRes> res(nLanes);
