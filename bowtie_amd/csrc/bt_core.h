@@ -142,10 +142,12 @@ enum { RQ_NONE = 0, RQ_RANK = 1, RQ_FETCH = 2 };
 struct BtReq {
 	uint32_t kind;          /* RQ_*                                                               */
 	uint32_t n;             /* RANK: 1 or 2 rows; FETCH: 16-byte pieces at a (1..4)               */
-	/* RANK : a = rowA, x = rowB
+	/* RANK : a = rowA, x = rowB; wchunk != 0xffff: also fetch 16-byte chunk `wchunk` of the lane's
+	 *        read (bases -> res.q[3], qualities -> res.x): the next read window, one step ahead
 	 * FETCH: a = address of n contiguous 16-byte pieces -> res.q[0..n)
 	 *        x = address of an optional extra 16-byte piece -> res.x (0 = none) */
 	uint64_t a, x;
+	uint32_t wchunk;
 };
 struct BtRes {
 	BtU4 q[4];              /* RANK: q[0] = LF(rowA, ACGT), q[1] = LF(rowB, ACGT), q[2].x = BWT char at rowA */
@@ -223,7 +225,7 @@ struct BtLane {
 	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, state : 5, ra_cont : 2;
 	/* pending backtrack target */
 	uint32_t pi : 11, pj : 2, btham : 16;
-	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1;
+	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1, wpf : 1;
 	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
@@ -991,7 +993,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, const BtScratch& S,
                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
-	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0;
+	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
 	for (;;) {
 		BT_PROF_T0(t_resume);
 		/* ---- resume: the read window arrived ------------------------------------------------- */
@@ -1013,6 +1015,11 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 			const uint32_t e = L.ebase + (d - L.depth);
 			uint32_t ta[4], tb[4];
 			if (L.state == ST_STEP_LFDONE) {
+				if (L.wpf) {
+					L.cs0 = res.q[3].x; L.cs1 = res.q[3].y; L.cs2 = res.q[3].z; L.cs3 = res.q[3].w;
+					L.cq0 = res.x.x; L.cq1 = res.x.y; L.cq2 = res.x.z; L.cq3 = res.x.w;
+					L.cchunk = L.scanCb; L.wpf = 0;
+				}
 				ta[0] = res.q[0].x; ta[1] = res.q[0].y; ta[2] = res.q[0].z; ta[3] = res.q[0].w;
 				tb[0] = res.q[1].x; tb[1] = res.q[1].y; tb[2] = res.q[1].z; tb[3] = res.q[1].w;
 				const uint32_t ac = bt_sel4(c & 3u, ta[0], ta[1], ta[2], ta[3]);
@@ -1141,12 +1148,17 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 				if (c < 4u) { L.top = bt_sel4(c, f0, f1, f2, f3); L.bot = bt_sel4(c, f1, f2, f3, f4); }
 				L.state = ST_STEP_POST;
 				continue;
-			} else if (alt) {
-				BT_REQ_RANK2(rtop, rbot); L.lfk = LFK_EX2;
-				L.state = ST_STEP_LFDONE; return;
-			} else if (c < 4u) {
-				if (L.top + 1u == L.bot) { BT_REQ_RANK1(L.top); L.lfk = LFK_LF1; }
+			} else if (alt || c < 4u) {
+				if (alt) { BT_REQ_RANK2(rtop, rbot); L.lfk = LFK_EX2; }
+				else if (L.top + 1u == L.bot) { BT_REQ_RANK1(L.top); L.lfk = LFK_LF1; }
 				else { BT_REQ_RANK2(L.top, L.bot); L.lfk = LFK_C2; }
+				/* the next position (d+1) leaves the 16-base window: fetch the neighbouring chunk with
+				 * this round's rank request instead of spending a round on it */
+				L.wpf = 0;
+				if (d + 1u < L.qlen) {
+					const uint32_t i2 = L.qlen - d - 2u, j2 = L.rev ? (L.plen - 1u - i2) : i2;
+					if ((j2 >> 4) != L.cchunk) { req.wchunk = j2 >> 4; L.scanCb = j2 >> 4; L.wpf = 1; }
+				}
 				L.state = ST_STEP_LFDONE; return;
 			} else {
 				/* non-alternative N: the range is already (1,1); only the bookkeeping remains */

@@ -12,7 +12,7 @@
  * the few reads that backtrack for 10^5 rounds neither hold 63 idle lanes hostage nor keep the
  * batch's other wavefronts from retiring. */
 #define BT_POOL_WORDS 64
-struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot, [50..55] BtReq */
+struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot, [52..53] request kind/n, [56..59] request a/x */
 
 struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */

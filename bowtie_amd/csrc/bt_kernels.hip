@@ -66,14 +66,14 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BtScratch S;
 	S.frames = A.frames; S.pairs = A.pairs; S.meta = A.meta; S.pals = A.pals; S.slot = g;
-	static_assert(sizeof(BtLane) <= 48 * 4 && sizeof(BtReq) <= 6 * 4, "pool record layout");
+	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
 	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 
 	BtLane L = {};
 	L.state = ST_IDLE;
 	BtReq req;
-	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0;
+	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
 	bool drained = false;
 	const BtCold* cold = A.cold;
 
@@ -103,8 +103,11 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			const uint8_t* pB = sel.ebwt + (uint64_t)sideB * 64u;
 			const uint32_t nA = isRank ? 4u : (isFetch ? req.n : 0u);
 			const bool hasB = isRank && req.n == 2;
-			const bool hasX = isFetch && req.x != 0;
-			BtU4 qa[4] = {}, qb[4] = {}, qx = {};
+			const bool hasW = isRank && req.wchunk != 0xffffu;          /* next read window rides along */
+			const bool hasX = (isFetch && req.x != 0) || hasW;
+			const uint8_t* pX = hasW ? A.H.qual + L.roff + (uint64_t)req.wchunk * 16u : (const uint8_t*)(uintptr_t)req.x;
+			const uint8_t* pW = A.H.seq + L.roff + (uint64_t)req.wchunk * 16u;
+			BtU4 qa[4] = {}, qb[4] = {}, qx = {}, qw = {};
 			uint2 oa = make_uint2(0, 0), ob = make_uint2(0, 0);
 			BT_UNROLL
 			for (uint32_t k = 0; k < 4u; k++) if (k < nA) qa[k] = ((const BtU4*)pA)[k];
@@ -114,12 +117,14 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				for (uint32_t k = 0; k < 4u; k++) qb[k] = ((const BtU4*)pB)[k];
 				ob = *(const uint2*)((sideB & 1u) ? pB - 8 : pB + 120);
 			}
-			if (hasX) qx = *(const BtU4*)(uintptr_t)req.x;
+			if (hasX) qx = *(const BtU4*)pX;
+			if (hasW) qw = *(const BtU4*)pW;
 			if (isRank) {
 				uint32_t lf[4], la;
 				dev_rank4_loaded(sel, rowA, qa[0], qa[1], qa[2], qa[3], oa, lf, &la);
 				res.q[0].x = lf[0]; res.q[0].y = lf[1]; res.q[0].z = lf[2]; res.q[0].w = lf[3];
 				res.q[2].x = la;
+				res.q[3] = qw; res.x = qx;
 				if (hasB) {
 					uint32_t dummy;
 					dev_rank4_loaded(sel, rowB, qb[0], qb[1], qb[2], qb[3], ob, lf, &dummy);
@@ -140,12 +145,11 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 					/* adopt a parked read: state, scratch slot and its pending request */
 					if (w >= *A.poolInCount) { drained = true; break; }
 					const BtPoolRec* r = A.poolIn + w;
-					uint32_t t[56];
 					BT_UNROLL
-					for (int k = 0; k < 14; k++) { const BtU4 v = ((const BtU4*)r->w)[k]; t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w; }
-					__builtin_memcpy(&L, t, sizeof(BtLane));
-					S.slot = t[48];
-					__builtin_memcpy(&req, t + 50, sizeof(BtReq));
+					for (int k = 0; k < 12; k++) { const BtU4 v = ((const BtU4*)r->w)[k]; __builtin_memcpy((char*)&L + 16 * k, &v, 16); }
+					{ const BtU4 v = ((const BtU4*)r->w)[12]; S.slot = v.x; }
+					{ const BtU4 v = ((const BtU4*)r->w)[13]; req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
+					{ const BtU4 v = ((const BtU4*)r->w)[14]; req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
 					L.tosValid = 0; L.ccValid = 0;
 					break;                                   /* its request is served at the top of the next round */
 				}
@@ -163,18 +167,15 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				const uint32_t slot = atomicAdd(A.poolOutCount, 1u);
 				const uint32_t fresh = atomicAdd(A.nextSlot, 1u);
 				if (slot < A.poolOutCap && fresh < A.nSlots) {
-					uint32_t t[56];
-					BT_UNROLL
-					for (int k = 0; k < 56; k++) t[k] = 0;
-					__builtin_memcpy(t, &L, sizeof(BtLane));
-					t[48] = S.slot;
-					__builtin_memcpy(t + 50, &req, sizeof(BtReq));
 					BtPoolRec* r = A.poolOut + slot;
 					BT_UNROLL
-					for (int k = 0; k < 14; k++) { BtU4 v; v.x = t[4 * k]; v.y = t[4 * k + 1]; v.z = t[4 * k + 2]; v.w = t[4 * k + 3]; ((BtU4*)r->w)[k] = v; }
+					for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); ((BtU4*)r->w)[k] = v; }
+					{ BtU4 v; v.x = S.slot; v.y = 0; v.z = 0; v.w = 0; ((BtU4*)r->w)[12] = v; }
+					{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; ((BtU4*)r->w)[13] = v; }
+					{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); ((BtU4*)r->w)[14] = v; }
 					S.slot = fresh;
 					L.state = ST_IDLE;
-					req.kind = RQ_NONE;
+					req.kind = RQ_NONE; req.wchunk = 0xffffu;
 					continue;
 				}
 				/* pool or slot arena full: the read simply stays in its lane */

@@ -118,6 +118,10 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 				bt_rank4(ix, (uint32_t)req.a, lf, &la);
 				res[g].q[0].x = lf[0]; res[g].q[0].y = lf[1]; res[g].q[0].z = lf[2]; res[g].q[0].w = lf[3];
 				res[g].q[2].x = la;
+				if (req.wchunk != 0xffffu) {
+					memcpy(&res[g].q[3], in->seq + L.roff + (size_t)req.wchunk * 16, 16);
+					memcpy(&res[g].x, in->qual + L.roff + (size_t)req.wchunk * 16, 16);
+				}
 				if (req.n == 2) {
 					bt_rank4(ix, (uint32_t)req.x, lf, &dummy);
 					res[g].q[1].x = lf[0]; res[g].q[1].y = lf[1]; res[g].q[1].z = lf[2]; res[g].q[1].w = lf[3];
