@@ -37,6 +37,11 @@ from bowtie_amd import aligner as AL        # noqa: E402
 from bowtie_amd.synth import synth_reads_torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# HBM bytes per read of bt_search_kernel measured with rocprofv3 PMC (separate --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE passes, (FETCH_SIZE + WRITE_SIZE) x 1024, uncorrected) on the same workload:
+# profiles/r1_final/pmc_big_n2_100_16M.txt.  bench.py cannot run the profiler on itself, so `traffic`
+# is that measured per-read figure times the reads of one launch; null for workloads not profiled.
+MEASURED_HBM_BYTES_PER_READ = {"big_n2_100": (1.408e9 + 7.315e8) * 1024.0 / 16_000_000}
 
 WORKLOADS = {
     "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
@@ -259,7 +264,11 @@ def main():
                        "pipelined_contexts": len(pipes),
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (MEASURED_HBM_BYTES_PER_READ[args.workload] * n
+                                     if args.workload in MEASURED_HBM_BYTES_PER_READ and not args.genome else None),
+                         "traffic_note": "rocprofv3 FETCH_SIZE+WRITE_SIZE per read (profiles/r1_final) x reads per launch",
+                         "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": "bt_search_kernel", "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": abytes,
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
