@@ -43,6 +43,7 @@ struct bt_ctx {
 	uint32_t pool1Cap = 0, pool2Cap = 0, nSlots = 0;
 	uint32_t heavy0 = 0, heavy1 = 0;
 	BtCold* d_cold = nullptr;
+	BtWarm* d_warm = nullptr;
 	unsigned long long* d_counts = nullptr;
 	/* staging for the host-pointer entry point */
 	void* stage = nullptr; size_t stage_bytes = 0;
@@ -211,6 +212,7 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	c->heavy0 = env_u32("BT_HEAVY0", 0);
 	c->heavy1 = env_u32("BT_HEAVY1", 65536);
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
+	HIPCHK(hipMalloc((void**)&c->d_warm, sizeof(BtWarm)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long)));
 	*out = c;
@@ -224,6 +226,7 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	ctx_free_scratch(c);
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_cold) (void)hipFree(c->d_cold);
+	if (c->d_warm) (void)hipFree(c->d_warm);
 	if (c->pool1) (void)hipFree(c->pool1);
 	if (c->pool2) (void)hipFree(c->pool2);
 	if (c->d_counts) (void)hipFree(c->d_counts);
@@ -258,15 +261,18 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	cold.B.mm_pool_used = c->d_cursor + 1;
 	cold.B.iters = c->iters_dev;
 	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+	BtWarm warm;
+	memset(&warm, 0, sizeof(warm));
 	for (int m = 0; m < 2; m++) {
 		const BtIndexDev& d = c->idx->dev[m];
-		A.H.ebwt[m] = d.ebwt; A.H.zSide[m] = d.zSide; A.H.zSym[m] = d.zSym; A.H.zOff[m] = d.zOff;
-		A.H.offMask[m] = d.offMask; A.H.ftab[m] = d.ftab; A.H.offs[m] = d.offs; A.H.offRate[m] = d.offRate;
-		A.H.ftabChars[m] = d.ftabChars; A.H.len[m] = d.len;
+		A.H.ebwt[m] = d.ebwt; A.H.zSide[m] = d.zSide; A.H.zSym[m] = d.zSym;
+		warm.zOff[m] = d.zOff; warm.offMask[m] = d.offMask; warm.ftab[m] = d.ftab; warm.offs[m] = d.offs;
+		warm.offRate[m] = d.offRate; warm.ftabChars[m] = d.ftabChars; warm.len[m] = d.len;
 		for (int k = 0; k < 5; k++) A.H.fchr[m][k] = d.fchr[k];
 	}
 	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
-	A.cold = c->d_cold;
+	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	A.cold = c->d_cold; A.warm = c->d_warm;
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
 	A.counts = counts_dev ? counts_dev : c->d_counts;

@@ -118,12 +118,17 @@ struct BtBatchDev {
  * it is used (phase changes, reporting). */
 struct BtHot {
 	const uint8_t* ebwt[2];
-	const uint32_t* ftab[2];
-	const uint32_t* offs[2];
-	uint32_t zSide[2], zSym[2], zOff[2], offMask[2], offRate[2], ftabChars[2], len[2];
+	uint32_t zSide[2], zSym[2];
 	uint32_t fchr[2][5];
 	const uint8_t* seq; const uint8_t* qual;
 	uint32_t stride, n_reads;
+};
+/* BtWarm: index geometry the automaton reads a few times per frame / SA walk.  On the GPU it sits
+ * in LDS (one copy per workgroup) so that it occupies no scalar registers across the round loop. */
+struct BtWarm {
+	const uint32_t* ftab[2];
+	const uint32_t* offs[2];
+	uint32_t zOff[2], offMask[2], offRate[2], ftabChars[2], len[2];
 };
 struct BtCold {
 	BtProgram  P;
@@ -300,6 +305,7 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 #define PALS(k) S.pals[(uint64_t)S.slot * S.palCap + (k)]
 #define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
 #define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
+#define WSEL(f) (L.mirror ? W.f[1] : W.f[0])          /* warm: LDS */
 #define HFCHR(k) (L.mirror ? H.fchr[1][k] : H.fchr[0][k])
 #define ST_IS(x) (L.state == (x) && req.kind == RQ_NONE)
 
@@ -484,7 +490,7 @@ BT_HD void bt_scan_request(const BtLane& L, const BtScratch& S, uint32_t c_lo, B
 }
 
 /* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
-BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, const BtScratch& S,
+BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
                         const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
 	const BtIndexDev* IX = C.ix;
@@ -503,14 +509,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 
 		/* ---- an SA walk reached a sampled row: offset -> (tidx,toff) -> sink (ebwt.h:2569-2746) ---- */
 		if (ST_IS(ST_RESOLVE_DONE)) { BT_PROF_T0(t_resolve_done); do {
-			const uint32_t zOff = HSEL(zOff);
+			const uint32_t zOff = WSEL(zOff);
 			uint32_t off;
 			if (L.crow == zOff) off = L.cjumps;
-			else off = bt_u4_word(res.q[0], (L.crow >> HSEL(offRate)) & 3u) + L.cjumps;
+			else off = bt_u4_word(res.q[0], (L.crow >> WSEL(offRate)) & 3u) + L.cjumps;
 			BT_COUNT(CN_OFFS);
 			/* joinedToTextOff (ebwt.h:2569-2629) */
 			const uint32_t* rstarts = IXSEL(rstarts);
-			const uint32_t nFrag = IXSEL(nFrag), len = HSEL(len), ixfw = L.mirror ? 0u : 1u;
+			const uint32_t nFrag = IXSEL(nFrag), len = WSEL(len), ixfw = L.mirror ? 0u : 1u;
 			uint32_t lo = 0, hi = nFrag, tidx = 0, toff = 0, probes = 0;
 			bool hit = false;
 			BT_NOUNROLL
@@ -721,7 +727,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 		if (ST_IS(ST_SEARCH_BEGIN)) { BT_PROF_T0(t_search_begin); do {
 			L.bailed = 0; L.sd = 0;
 			uint32_t nsInFtab = 0;
-			const uint32_t ftabChars = HSEL(ftabChars);
+			const uint32_t ftabChars = WSEL(ftabChars);
 			if (L.hasN) {
 				/* tallyNs (:1308-1341); reads without any N (nearly all) skip both walks */
 				uint32_t nsInSeed = 0; bool ok = true;
@@ -757,7 +763,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 		} while (0); BT_PROF_ADD(PS_SEARCH_BEGIN, t_search_begin); }
 
 		if (ST_IS(ST_FTABSEQ_DONE)) { BT_PROF_T0(t_ftabseq_done); do {
-			const uint32_t ftabChars = HSEL(ftabChars);
+			const uint32_t ftabChars = WSEL(ftabChars);
 			const uint32_t i0 = L.qlen - ftabChars, i1 = L.qlen - 1u;
 			const uint32_t j0 = L.rev ? (L.plen - 1u - i1) : i0;
 			uint32_t ftabOff = 0;
@@ -770,14 +776,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 				c = bt_apply_muts(L, i, c);
 				ftabOff |= c << (2u * t);
 			}
-			const uint32_t* ftab = HSEL(ftab);
+			const uint32_t* ftab = WSEL(ftab);
 			L.ra_r = ftabOff;           /* parked until the table entry arrives */
 			BT_REQ_FETCH(ftab + (ftabOff & ~3u), 1, ftab + ((ftabOff + 1u) & ~3u));
 			L.state = ST_FTAB_DONE;
 		} while (0); BT_PROF_ADD(PS_FTABSEQ_DONE, t_ftabseq_done); }
 
 		if (ST_IS(ST_FTAB_DONE)) { BT_PROF_T0(t_ftab_done); do {
-			const uint32_t ftabChars = HSEL(ftabChars), len = HSEL(len);
+			const uint32_t ftabChars = WSEL(ftabChars), len = WSEL(len);
 			const uint32_t ftabOff = L.ra_r;
 			uint32_t top = bt_u4_word(res.q[0], ftabOff & 3u);
 			uint32_t bot = (((ftabOff + 1u) & ~3u) == (ftabOff & ~3u)) ? bt_u4_word(res.q[0], (ftabOff + 1u) & 3u)
@@ -888,7 +894,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 			}
 			uint32_t newDepth = i + 1u, ntop = bttop, nbot = btbot;
 			const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
-			const uint32_t ftabChars = HSEL(ftabChars);
+			const uint32_t ftabChars = WSEL(ftabChars);
 			if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < ftabChars && ftabChars <= L.d5) {
 				/* re-jump through the ftab with the substituted character (:908-952); rare, synchronous */
 				uint32_t ftabOff = 0;
@@ -898,7 +904,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
 					if (L.qlen - 1u - jj == icur) c = btcint;
 					ftabOff |= c << (2u * jj);
 				}
-				const uint32_t* ftab = HSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = HSEL(len);
+				const uint32_t* ftab = WSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = WSEL(len);
 				ntop = ftab[ftabOff]; nbot = ftab[ftabOff + 1u];
 				if (ntop > len) ntop = eftab[(ntop ^ BT_OFF_MASK) * 2u + 1u];
 				if (nbot > len) nbot = eftab[(nbot ^ BT_OFF_MASK) * 2u];
@@ -990,7 +996,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtC
  * Advance one lane until it has a memory request for this round (req.kind != RQ_NONE) or has
  * finished its read (state ST_IDLE).  `res` is the answer to the lane's previous request.
  */
-BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, const BtScratch& S,
+BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
@@ -1032,7 +1038,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 					L.top = ac; L.bot = bc;
 				} else {
 					/* mapLF1 (ebwt.h:2494-2512) */
-					if (res.q[2].x != c || L.top == HSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
+					if (res.q[2].x != c || L.top == WSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
 					else { L.top = ac; L.bot = ac + 1u; }
 				}
 			} else {
@@ -1107,7 +1113,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 		/* ---- everything else ---------------------------------------------------------------- */
 		{
 			BT_PROF_T0(t_slow);
-			if (BT_IS_SLOW(L.state)) bt_lane_slow(L, P, H, C, S, res, req, CNT);
+			if (BT_IS_SLOW(L.state)) bt_lane_slow(L, P, H, W, C, S, res, req, CNT);
 			BT_PROF_ADD(PS_SLOW, t_slow);
 		}
 		if (req.kind != RQ_NONE) { BT_COUNT(CN_FETCH); return; }
@@ -1168,14 +1174,14 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 		}
 		/* ---- emit: next SA-walk step, or the SA sample once the walk has arrived ---------------- */
 		if (L.state == ST_CHASE_CHECK) {
-			if ((L.crow & HSEL(offMask)) != L.crow && L.crow != HSEL(zOff)) {
+			if ((L.crow & WSEL(offMask)) != L.crow && L.crow != WSEL(zOff)) {
 				BT_REQ_RANK1(L.crow); L.lfk = LFK_CHASE;
 				L.state = ST_CHASE_LFDONE; return;
 			}
 			L.state = ST_RESOLVE_DONE;
-			if (L.crow != HSEL(zOff)) {
-				const uint32_t* offs = HSEL(offs);
-				BT_REQ_FETCH(offs + ((L.crow >> HSEL(offRate)) & ~3u), 1, nullptr);
+			if (L.crow != WSEL(zOff)) {
+				const uint32_t* offs = WSEL(offs);
+				BT_REQ_FETCH(offs + ((L.crow >> WSEL(offRate)) & ~3u), 1, nullptr);
 				BT_COUNT(CN_FETCH);
 				return;
 			}
@@ -1192,6 +1198,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtCo
 #undef PALS
 #undef IXSEL
 #undef HSEL
+#undef WSEL
 #undef HFCHR
 #undef ST_IS
 #endif /* BT_CORE_H_ */

@@ -17,6 +17,7 @@ struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot,
 struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */
 	const BtCold* cold;          /* device memory: program, full index descriptors, batch        */
+	const BtWarm* warm;          /* device memory; each workgroup copies it to LDS               */
 	/* per-slot scratch arenas (see BtScratch); slots 0..nLanes-1 belong to the lanes of the first
 	 * launch, the rest are handed out when a lane parks a heavy read and needs a fresh slot      */
 	uint32_t*  frames;           /* [nSlots][frCap][12]                                          */

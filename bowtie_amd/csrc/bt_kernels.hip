@@ -58,9 +58,12 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	__shared__ unsigned long long CNT[CN_N + PS_N];
 	__shared__ uint32_t TOS[BT_LDS_WORDS * BT_BLOCK];          /* per lane: candidate, top-of-stack record, its candidate */
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
+	__shared__ BtWarm WARM;                                    /* index geometry (see BtWarm) */
 	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
 	for (uint32_t i = threadIdx.x; i < sizeof(BtProgram) / 4; i += blockDim.x)
 		((uint32_t*)&PROG)[i] = ((const uint32_t*)&A.cold->P)[i];
+	for (uint32_t i = threadIdx.x; i < sizeof(BtWarm) / 4; i += blockDim.x)
+		((uint32_t*)&WARM)[i] = ((const uint32_t*)A.warm)[i];
 	__syncthreads();
 
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
-			bt_lane_run(L, PROG, A.H, *cold, S, res, req, CNT);
+			bt_lane_run(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state == ST_IDLE) continue;
 			if (A.poolOut && L.iters >= A.heavyRounds) {

@@ -61,10 +61,12 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	cold.ix[0] = e->d[0]; cold.ix[1] = e->d[1];
 	BtHot H;
 	memset(&H, 0, sizeof(H));
+	BtWarm W;
+	memset(&W, 0, sizeof(W));
 	for (int m = 0; m < 2; m++) {
-		H.ebwt[m] = e->d[m].ebwt; H.zSide[m] = e->d[m].zSide; H.zSym[m] = e->d[m].zSym; H.zOff[m] = e->d[m].zOff;
-		H.offMask[m] = e->d[m].offMask; H.ftab[m] = e->d[m].ftab; H.offs[m] = e->d[m].offs; H.offRate[m] = e->d[m].offRate;
-		H.ftabChars[m] = e->d[m].ftabChars; H.len[m] = e->d[m].len;
+		H.ebwt[m] = e->d[m].ebwt; H.zSide[m] = e->d[m].zSide; H.zSym[m] = e->d[m].zSym; W.zOff[m] = e->d[m].zOff;
+		W.offMask[m] = e->d[m].offMask; W.ftab[m] = e->d[m].ftab; W.offs[m] = e->d[m].offs; W.offRate[m] = e->d[m].offRate;
+		W.ftabChars[m] = e->d[m].ftabChars; W.len[m] = e->d[m].len;
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
 	}
 	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
@@ -101,7 +103,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
 					bt_lane_start(L, P, H, cold, next++);
 				}
-				bt_lane_run(L, P, H, cold, scr[g], res[g], req, CNT);
+				bt_lane_run(L, P, H, W, cold, scr[g], res[g], req, CNT);
 				if (L.state != ST_IDLE) break;
 			}
 			if (drained[g]) continue;
