@@ -44,6 +44,7 @@ struct bt_ctx {
 	uint32_t heavy0 = 0, heavy1 = 0;
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
+	uint32_t *d_order = nullptr, *d_hist = nullptr; uint8_t* d_bucket = nullptr; uint32_t orderCap = 0;
 	unsigned long long* d_counts = nullptr;
 	/* staging for the host-pointer entry point */
 	void* stage = nullptr; size_t stage_bytes = 0;
@@ -227,6 +228,9 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_cold) (void)hipFree(c->d_cold);
 	if (c->d_warm) (void)hipFree(c->d_warm);
+	if (c->d_order) (void)hipFree(c->d_order);
+	if (c->d_hist) (void)hipFree(c->d_hist);
+	if (c->d_bucket) (void)hipFree(c->d_bucket);
 	if (c->pool1) (void)hipFree(c->pool1);
 	if (c->pool2) (void)hipFree(c->pool2);
 	if (c->d_counts) (void)hipFree(c->d_counts);
@@ -283,7 +287,24 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	const bool offload = c->pool1 != nullptr && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
 	const uint32_t init[8] = {0, 0, c->nLanes, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	/* heavy-first schedule (see bt_weight_kernel); timed with the search since it is part of a step */
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	A.order = nullptr;
+	if (in->n_reads >= env_u32("BT_SCHEDULE_MIN_BATCH", 4u * c->nLanes) && env_u32("BT_SCHEDULE", 1)) {
+		if (c->orderCap < in->n_reads) {
+			if (c->d_order) (void)hipFree(c->d_order);
+			if (c->d_bucket) (void)hipFree(c->d_bucket);
+			c->d_order = nullptr; c->d_bucket = nullptr; c->orderCap = 0;
+			HIPCHK(hipMalloc((void**)&c->d_order, (size_t)in->n_reads * 4u));
+			HIPCHK(hipMalloc((void**)&c->d_bucket, (size_t)in->n_reads));
+			if (!c->d_hist) HIPCHK(hipMalloc((void**)&c->d_hist, 64 * 4));
+			c->orderCap = in->n_reads;
+		}
+		const BtIndexDev& d0 = c->idx->dev[0];
+		if (bt_launch_schedule(in->seq, in->len, in->stride, in->n_reads, d0.ftab, d0.ftabChars, d0.len,
+		                       c->d_bucket, c->d_hist, c->d_order, c->stream) != 0) return BT_ERR_DEVICE;
+		A.order = c->d_order;
+	}
 	/* level 0: all reads; reads that reach heavy0 rounds are parked in pool 1 */
 	A.nextRead = c->d_cursor;
 	A.poolIn = nullptr; A.poolInCount = nullptr;

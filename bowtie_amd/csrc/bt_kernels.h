@@ -26,6 +26,7 @@ struct BtKernelArgs {
 	uint64_t*  pals;             /* [nSlots][palCap]                                             */
 	uint32_t   nLanes, nSlots, frCap, entCap, palCap;
 	uint32_t*  nextRead;         /* work cursor: read ids (level 0) or pool records (level > 0)  */
+	const uint32_t* order;       /* optional: read id for each cursor value (heavy-first schedule) */
 	uint32_t*  nextSlot;         /* spare-slot cursor (starts at nLanes)                         */
 	const BtPoolRec* poolIn;  const uint32_t* poolInCount;      /* NULL at level 0               */
 	BtPoolRec* poolOut;       uint32_t* poolOutCount;  uint32_t poolOutCap;   /* NULL at the last level */
@@ -35,6 +36,9 @@ struct BtKernelArgs {
 
 extern "C" {
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, void* stream);
+int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
+                       const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
+                       uint8_t* bucket, uint32_t* hist, uint32_t* order, void* stream);
 int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
                          uint8_t* L, void* stream);
 int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				}
 				if (w >= A.H.n_reads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
-				bt_lane_start(L, PROG, A.H, *cold, w);
+				bt_lane_start(L, PROG, A.H, *cold, A.order ? A.order[w] : w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
@@ -204,6 +204,81 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 
 	__syncthreads();
 	if (threadIdx.x < CN_N + PS_N && A.counts) atomicAdd(&A.counts[threadIdx.x], CNT[threadIdx.x]);
+}
+
+/* ---- heavy-first scheduling ------------------------------------------------------------------
+ * The time a read takes is dominated by how repetitive its sequence is (a read from a high-copy
+ * repeat family backtracks for 10^4..10^5 rounds; the median read needs ~200).  Reads are therefore
+ * handed to the lanes longest-expected-first: a cheap proxy for the expected work -- the number of
+ * occurrences in the text of a few 10-mers of the read, i.e. ftab range sizes -- is bucketed by
+ * magnitude and the read ids are counting-sorted by bucket, heaviest bucket first.  Only the order
+ * in which lanes pick up reads changes; results are indexed by read id. */
+__global__ void bt_weight_kernel(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
+                                 const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
+                                 uint8_t* bucket, uint32_t* hist)
+{
+	__shared__ uint32_t h[32];
+	if (threadIdx.x < 32) h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rd < n) {
+		const uint8_t* s = seq + (uint64_t)rd * stride;
+		const uint32_t L = len[rd];
+		uint32_t weight = 0;
+		if (L >= ftabChars) {
+			const uint32_t nwin = 6, span = L - ftabChars;
+			for (uint32_t w = 0; w < nwin; w++) {
+				const uint32_t p0 = (uint32_t)(((uint64_t)span * w) / (nwin - 1));
+				uint32_t k = 0; bool ok = true;
+				for (uint32_t i = 0; i < ftabChars; i++) {
+					const uint32_t c = s[p0 + i];
+					if (c > 3u) ok = false;
+					k = (k << 2) | (c & 3u);
+				}
+				if (!ok) continue;
+				/* suffixes starting with this k-mer: [ftab[k], ftab[k+1]) up to the handful of
+				 * end-of-text entries, which are ignored for a weight */
+				const uint32_t a = ftab[k], b = ftab[k + 1];
+				if (a <= textLen && b <= textLen && b > a) weight += (b - a);
+			}
+		}
+		const uint32_t bk = weight == 0 ? 0u : 32u - (uint32_t)__builtin_clz(weight);   /* 0..32 */
+		const uint32_t bb = bk > 31u ? 31u : bk;
+		bucket[rd] = (uint8_t)bb;
+		atomicAdd(&h[bb], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+/* hist[0..32) -> start offsets with the heaviest bucket first; cursors[32..64) */
+__global__ void bt_schedule_offsets_kernel(uint32_t* hist)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		uint32_t acc = 0;
+		for (int b = 31; b >= 0; b--) { const uint32_t c = hist[b]; hist[32 + b] = acc; acc += c; }
+	}
+}
+
+__global__ void bt_schedule_scatter_kernel(const uint8_t* bucket, uint32_t n, uint32_t* hist, uint32_t* order)
+{
+	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rd >= n) return;
+	const uint32_t pos = atomicAdd(&hist[32 + bucket[rd]], 1u);
+	order[pos] = rd;
+}
+
+extern "C" int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
+                                  const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
+                                  uint8_t* bucket, uint32_t* hist, uint32_t* order, void* stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	if (hipMemsetAsync(hist, 0, 64 * sizeof(uint32_t), st) != hipSuccess) return 1;
+	const uint32_t nb = (n + 255) / 256;
+	hipLaunchKernelGGL(bt_weight_kernel, dim3(nb), dim3(256), 0, st, seq, len, stride, n, ftab, ftabChars, textLen, bucket, hist);
+	hipLaunchKernelGGL(bt_schedule_offsets_kernel, dim3(1), dim3(64), 0, st, hist);
+	hipLaunchKernelGGL(bt_schedule_scatter_kernel, dim3(nb), dim3(256), 0, st, bucket, n, hist, order);
+	return (int)hipGetLastError();
 }
 
 __global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)
