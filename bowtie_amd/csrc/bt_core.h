@@ -180,9 +180,11 @@ enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_F
 /* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
 #define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)
 #define BT_COUNT_N(k, n) atomicAdd(&CNT[k], (unsigned long long)(n))
+#define BT_COUNT_HOST(k)            /* tallied by the kernel with wave-uniform counters */
 #else
 #define BT_COUNT(k) (CNT[k]++)
 #define BT_COUNT_N(k, n) (CNT[k] += (n))
+#define BT_COUNT_HOST(k) (CNT[k]++)
 #endif
 
 /* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
@@ -388,21 +390,20 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	BT_NOUNROLL
 	for (uint32_t base = 0; base < plen; base += 16u) {
 		const BtU4 v = *(const BtU4*)(H.seq + L.roff + base);
+		/* bit i of nb = byte i of the chunk is an N (code 4): exact zero-byte test on v ^ 0x04.., then
+		 * the four flag bits of each word are gathered with one multiply */
+		uint32_t nb = 0;
 		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 		BT_UNROLL
 		for (int k = 0; k < 4; k++) {
 			const uint32_t t = w[k] ^ 0x04040404u;
-			uint32_t z = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;      /* bytes equal to 4 */
-			const uint32_t p0 = base + 4u * (uint32_t)k;
-			uint32_t inRead = 0, inSeed = 0;
-			BT_UNROLL
-			for (uint32_t b = 0; b < 4u; b++) {
-				if (p0 + b < plen) inRead |= 0x80u << (8u * b);
-				if (p0 + b < qs) inSeed |= 0x80u << (8u * b);
-			}
-			nsAll += (uint32_t)__builtin_popcount(z & inRead);
-			nsSeed += (uint32_t)__builtin_popcount(z & inSeed);
+			const uint32_t z = (~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u) >> 7;   /* 0x01 per N byte */
+			nb |= ((z * 0x00204081u) >> 21 & 0xfu) << (4 * k);
 		}
+		const uint32_t inRead = plen - base >= 16u ? 0xffffu : ((1u << (plen - base)) - 1u);
+		const uint32_t inSeed = qs <= base ? 0u : (qs - base >= 16u ? 0xffffu : ((1u << (qs - base)) - 1u));
+		nsAll += (uint32_t)__builtin_popcount(nb & inRead);
+		nsSeed += (uint32_t)__builtin_popcount(nb & inSeed);
 	}
 	L.hasN = nsAll > 0 ? 1u : 0u;
 	if (P.seeded) {
@@ -1116,7 +1117,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			if (BT_IS_SLOW(L.state)) bt_lane_slow(L, P, H, W, C, S, res, req, CNT);
 			BT_PROF_ADD(PS_SLOW, t_slow);
 		}
-		if (req.kind != RQ_NONE) { BT_COUNT(CN_FETCH); return; }
+		if (req.kind != RQ_NONE) { BT_COUNT_HOST(CN_FETCH); return; }
 
 		/* ---- emit: next query position (:456-568) -------------------------------------------- */
 		if (L.state == ST_STEP_BEGIN) {
@@ -1130,7 +1131,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				L.scanCb = j >> 4;       /* chunk id, parked until the window arrives */
 				BT_REQ_FETCH(H.seq + L.roff + (uint64_t)(j >> 4) * 16u, 1, H.qual + L.roff + (uint64_t)(j >> 4) * 16u);
 				L.state = ST_WIN_DONE;
-				BT_COUNT(CN_FETCH);
+				BT_COUNT_HOST(CN_FETCH);
 				return;
 			}
 			L.c = c; L.q = q;
@@ -1182,7 +1183,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			if (L.crow != WSEL(zOff)) {
 				const uint32_t* offs = WSEL(offs);
 				BT_REQ_FETCH(offs + ((L.crow >> WSEL(offRate)) & ~3u), 1, nullptr);
-				BT_COUNT(CN_FETCH);
+				BT_COUNT_HOST(CN_FETCH);
 				return;
 			}
 			continue;

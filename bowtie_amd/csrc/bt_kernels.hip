@@ -79,6 +79,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
 	bool drained = false;
 	const BtCold* cold = A.cold;
+	uint32_t sc_iters = 0, sc_rounds = 0, sc_fetch = 0, sc_chase = 0, sc_lfex = 0, sc_lf2 = 0, sc_lf1 = 0, sc_same = 0;
 
 	for (;;) {
 		/* keep the compiler from hoisting the cold descriptor's fields into scalar registers for
@@ -185,21 +186,31 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			}
 			break;
 		}
-		if (L.state == ST_IDLE) break;
-		/* op counters: one LDS atomic per wavefront per kind */
-		BT_COUNT(CN_ITERS);
-		L.iters++;
+		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
+		 * have run out of work simply carry an empty request */
+		const bool live = L.state != ST_IDLE;
+		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
+		if (__ballot(live) == 0) break;
+		/* op counters: wave-uniform tallies in scalar registers (ballot + popcount), flushed once
+		 * per wavefront at the end */
 		{
-			const unsigned long long act = __ballot(1);
-			if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) BT_COUNT(CN_WROUNDS);
+			const bool isR = req.kind == RQ_RANK;
+			sc_iters += (uint32_t)__builtin_popcountll(__ballot(live));
+			sc_rounds += 1u;
+			sc_fetch += (uint32_t)__builtin_popcountll(__ballot(req.kind == RQ_FETCH));
+			sc_chase += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_CHASE));
+			sc_lfex += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_EX2));
+			sc_lf2 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_C2));
+			sc_lf1 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_LF1));
+			sc_same += (uint32_t)__builtin_popcountll(__ballot(isR && req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u));
 		}
-		if (req.kind == RQ_RANK) {
-			if (L.lfk == LFK_CHASE) BT_COUNT(CN_CHASE);
-			else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
-			else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
-			else BT_COUNT(CN_LF1);
-			if (req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u) BT_COUNT(CN_SAMEPAIR);
-		}
+		if (live) L.iters++;
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		atomicAdd(&CNT[CN_ITERS], (unsigned long long)sc_iters); atomicAdd(&CNT[CN_WROUNDS], (unsigned long long)sc_rounds);
+		atomicAdd(&CNT[CN_FETCH], (unsigned long long)sc_fetch); atomicAdd(&CNT[CN_CHASE], (unsigned long long)sc_chase);
+		atomicAdd(&CNT[CN_LFEX], (unsigned long long)sc_lfex); atomicAdd(&CNT[CN_LF2], (unsigned long long)sc_lf2);
+		atomicAdd(&CNT[CN_LF1], (unsigned long long)sc_lf1); atomicAdd(&CNT[CN_SAMEPAIR], (unsigned long long)sc_same);
 	}
 
 	__syncthreads();
