@@ -287,10 +287,12 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	const bool offload = c->pool1 != nullptr && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
 	const uint32_t init[8] = {0, 0, c->nLanes, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	/* heavy-first schedule (see bt_weight_kernel); timed with the search since it is part of a step */
+	/* heavy-first schedule (see bt_weight_kernel); timed with the search since it is part of a step.
+	 * Off by default (BT_SCHEDULE=1 enables): measured on MI355X it does not shorten the batch tail --
+	 * the tail is set by the longest single read, not by when it starts (profiles/README.md). */
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	A.order = nullptr;
-	if (in->n_reads >= env_u32("BT_SCHEDULE_MIN_BATCH", 4u * c->nLanes) && env_u32("BT_SCHEDULE", 1)) {
+	if (in->n_reads >= env_u32("BT_SCHEDULE_MIN_BATCH", 4u * c->nLanes) && env_u32("BT_SCHEDULE", 0)) {
 		if (c->orderCap < in->n_reads) {
 			if (c->d_order) (void)hipFree(c->d_order);
 			if (c->d_bucket) (void)hipFree(c->d_bucket);

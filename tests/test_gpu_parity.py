@@ -175,6 +175,7 @@ def test_gpu_heavy_read_offload_is_transparent(gidx, monkeypatch):
 def test_gpu_heavy_first_schedule_is_transparent(gidx, monkeypatch):
     """The lanes pick reads up heaviest-expected-first (ftab-count proxy, counting sort on the GPU);
     only the pick-up order changes, never a result."""
+    monkeypatch.setenv("BT_SCHEDULE", "1")
     monkeypatch.setenv("BT_SCHEDULE_MIN_BATCH", "1")
     for index, rname, mode in (("multi", "syn100", "n2"), ("e_coli", "syn36", "v0"), ("multi", "syn12", "n2"),
                                ("multi", "syn50lowq", "v2_a")):
