@@ -85,16 +85,21 @@ enum {
 #define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
 #define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
 
-struct BtScratch {
-	/* arena bases (wave-uniform) + this lane's slot; addresses are formed where they are used */
+struct BtArena {
+	/* arena bases and capacities (wave-uniform).  On the GPU this lives in LDS, one copy per
+	 * workgroup: addresses are formed where they are used and nothing stays in registers. */
 	uint32_t* frames;   /* [slot][frame][12]                                                     */
 	uint32_t* pairs;    /* [slot][entry][8]: tops ACGT, bots ACGT                                */
 	uint16_t* meta;     /* [slot][entry] eliminated-chars mask | Phred<<8                        */
 	uint64_t* pals;     /* [slot][palCap] seedlings                                              */
+	uint32_t  frCap, entCap, palCap, pad;
+};
+struct BtScratch {
+	const BtArena* a;
 	uint32_t* tos;      uint32_t tosStride;  /* LDS, word w at tos[w*tosStride]: [0,9) the candidate's ranges +
 	                                            record, [9,19) top-of-stack frame record, [19,28) that
 	                                            frame's candidate */
-	uint32_t  slot, frCap, entCap, palCap;
+	uint32_t  slot;
 };
 
 /* ---- batch-level arguments --------------------------------------------------------------- */
@@ -300,11 +305,11 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 	return (k & 1u) ? (w >> 16) : (w & 0xffffu);
 }
 
-#define FRW(f, w) S.frames[((uint64_t)S.slot * S.frCap + (f)) * BT_FR_WORDS + (w)]
-#define PT(e, c) S.pairs[((uint64_t)S.slot * S.entCap + (e)) * 8u + (c)]
-#define PB(e, c) S.pairs[((uint64_t)S.slot * S.entCap + (e)) * 8u + 4u + (c)]
-#define META(e) S.meta[(uint64_t)S.slot * S.entCap + (e)]
-#define PALS(k) S.pals[(uint64_t)S.slot * S.palCap + (k)]
+#define FRW(f, w) S.a->frames[((uint64_t)S.slot * S.a->frCap + (f)) * BT_FR_WORDS + (w)]
+#define PT(e, c) S.a->pairs[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + (c)]
+#define PB(e, c) S.a->pairs[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u + (c)]
+#define META(e) S.a->meta[(uint64_t)S.slot * S.a->entCap + (e)]
+#define PALS(k) S.a->pals[(uint64_t)S.slot * S.a->palCap + (k)]
 #define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
 #define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
 #define WSEL(f) (L.mirror ? W.f[1] : W.f[0])          /* warm: LDS */
@@ -364,7 +369,7 @@ BT_HD void bt_report_partial(BtLane& L, const BtScratch& S, uint32_t sd)
 	if (sd > 1) { uint32_t mm = FRW(1, FR_MM); p1 = mm & 0xffffu; c1 = (mm >> 16) & 3u; }
 	if (sd > 2) { uint32_t mm = FRW(2, FR_MM); p2 = mm & 0xffffu; c2 = (mm >> 16) & 3u; }
 	uint64_t al = p0 | (p1 << 16) | (p2 << 32) | (c0 << 48) | (c1 << 50) | (c2 << 52) | (0xffull << 54) | (3ull << 62);
-	if (L.npals < S.palCap) { PALS(L.npals) = al; L.npals = L.npals + 1u; }
+	if (L.npals < S.a->palCap) { PALS(L.npals) = al; L.npals = L.npals + 1u; }
 	else L.status = L.status | BT_STF_OVERFLOW;
 }
 
@@ -914,7 +919,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				newDepth = ftabChars;
 			}
 			/* push: save the parent (HBM record + LDS top-of-stack copy), enter the child */
-			if (L.sd + 1u >= S.frCap) { L.state = ST_ABORT; break; }
+			if (L.sd + 1u >= S.a->frCap) { L.state = ST_ABORT; break; }
 			{
 				uint32_t w[BT_TOS_WORDS];
 				w[FR_W0] = L.depth | (L.d << 11);
@@ -1124,7 +1129,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			const uint32_t d = L.d;
 			if (d >= L.qlen) { L.state = ST_FELL_OFF; continue; }
 			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; continue; }
-			if (L.ebase + (d - L.depth) >= S.entCap) { L.state = ST_ABORT; continue; }
+			if (L.ebase + (d - L.depth) >= S.a->entCap) { L.state = ST_ABORT; continue; }
 			uint32_t c, q;
 			if (!bt_window_get(L, L.qlen - d - 1u, &c, &q)) {
 				const uint32_t i = L.qlen - d - 1u, j = L.rev ? (L.plen - 1u - i) : i;

@@ -52,13 +52,16 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 	dev_rank4_loaded(s, row, q0, q1, q2, q3, oth, lf, L);
 }
 
-template <int OCC>
+/* EXT = true compiles in the optional machinery (heavy-read parking/adoption, heavy-first pick-up
+ * order); the default launch uses the leaner EXT = false build of the same source. */
+template <int OCC, bool EXT>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
 	__shared__ unsigned long long CNT[CN_N + PS_N];
 	__shared__ uint32_t TOS[BT_LDS_WORDS * BT_BLOCK];          /* per lane: candidate, top-of-stack record, its candidate */
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	__shared__ BtWarm WARM;                                    /* index geometry (see BtWarm) */
+	__shared__ BtArena ARENA;                                  /* scratch arena bases + capacities */
 	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
 	for (uint32_t i = threadIdx.x; i < sizeof(BtProgram) / 4; i += blockDim.x)
 		((uint32_t*)&PROG)[i] = ((const uint32_t*)&A.cold->P)[i];
@@ -68,9 +71,13 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BtScratch S;
-	S.frames = A.frames; S.pairs = A.pairs; S.meta = A.meta; S.pals = A.pals; S.slot = g;
+	if (threadIdx.x == 0) {
+		ARENA.frames = A.frames; ARENA.pairs = A.pairs; ARENA.meta = A.meta; ARENA.pals = A.pals;
+		ARENA.frCap = A.frCap; ARENA.entCap = A.entCap; ARENA.palCap = A.palCap; ARENA.pad = 0;
+	}
+	__syncthreads();
+	S.a = &ARENA; S.slot = g;
 	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
-	S.frCap = A.frCap; S.entCap = A.entCap; S.palCap = A.palCap;
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 
 	BtLane L = {};
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			if (L.state == ST_IDLE) {
 				if (drained) break;
 				const uint32_t w = atomicAdd(A.nextRead, 1u);
-				if (A.poolIn) {
+				if (EXT && A.poolIn) {
 					/* adopt a parked read: state, scratch slot and its pending request */
 					if (w >= *A.poolInCount) { drained = true; break; }
 					const BtPoolRec* r = A.poolIn + w;
@@ -159,14 +166,14 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				}
 				if (w >= A.H.n_reads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
-				bt_lane_start(L, PROG, A.H, *cold, A.order ? A.order[w] : w);
+				bt_lane_start(L, PROG, A.H, *cold, (EXT && A.order) ? A.order[w] : w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
 			bt_lane_run(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state == ST_IDLE) continue;
-			if (A.poolOut && L.iters >= A.heavyRounds) {
+			if (EXT && A.poolOut && L.iters >= A.heavyRounds) {
 				/* park this read (it resumes, bit for bit, in the next launch) and free the lane */
 				const uint32_t slot = atomicAdd(A.poolOutCount, 1u);
 				const uint32_t fresh = atomicAdd(A.nextSlot, 1u);
@@ -333,12 +340,16 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
+	const bool ext = a->poolIn || a->poolOut || a->order;
+#define BT_LAUNCH(O) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
+                          else hipLaunchKernelGGL((bt_search_kernel<O, false>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
 	switch (occ) {
-	case 1:  hipLaunchKernelGGL(bt_search_kernel<1>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
-	case 2:  hipLaunchKernelGGL(bt_search_kernel<2>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
-	case 3:  hipLaunchKernelGGL(bt_search_kernel<3>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
-	default: hipLaunchKernelGGL(bt_search_kernel<4>, dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); break;
+	case 1:  BT_LAUNCH(1); break;
+	case 2:  BT_LAUNCH(2); break;
+	case 3:  BT_LAUNCH(3); break;
+	default: BT_LAUNCH(4); break;
 	}
+#undef BT_LAUNCH
 	return (int)hipGetLastError();
 }
 extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,

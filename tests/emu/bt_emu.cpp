@@ -82,14 +82,15 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	std::vector<char> drained(nLanes, 0);
 	unsigned long long CNT[CN_N];
 	memset(CNT, 0, sizeof(CNT));
+	BtArena arena;
+	arena.frames = (uint32_t*)frames4.data(); arena.pairs = (uint32_t*)pairs4.data(); arena.meta = meta.data(); arena.pals = pals.data();
+	arena.frCap = frCap; arena.entCap = entCap; arena.palCap = palCap; arena.pad = 0;
 	for (uint32_t g = 0; g < nLanes; g++) {
 		memset(&lanes[g], 0, sizeof(BtLane));
 		memset(&res[g], 0, sizeof(BtRes));
 		lanes[g].state = ST_IDLE;
-		scr[g].frames = (uint32_t*)frames4.data(); scr[g].slot = g;
-		scr[g].pairs = (uint32_t*)pairs4.data(); scr[g].meta = meta.data();
-		scr[g].pals = pals.data();
-		scr[g].frCap = frCap; scr[g].entCap = entCap; scr[g].palCap = palCap;
+		scr[g].a = &arena; scr[g].slot = g;
+		
 		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
 	}
 	uint32_t next = 0, live = nLanes;
