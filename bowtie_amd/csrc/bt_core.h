@@ -642,25 +642,44 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			const uint32_t c_lo = e_lo >> 3;
 			if (L.state == ST_RESCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_RESCAN_DONE; break; }
 			/* the batch (chunks lo..hi) arrived in res.q[0..]; same walk as the reference: deepest
-			 * record first, restart the tallies whenever a strictly lower quality shows up */
+			 * record first, restart the tallies whenever a strictly lower quality shows up.  The
+			 * affordability test ham + penalty(q) <= qualThresh is folded into one bound on q, and
+			 * the running tallies stay in plain registers until the batch is done. */
 			const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
-			BT_UNROLL
+			uint32_t qlim;                                     /* records with q > qlim cannot be afforded */
+			{
+				const uint32_t P = L.qualThresh >= L.ham ? L.qualThresh - L.ham : 0xffffffffu;
+				if (P == 0xffffffffu) qlim = 0xffffffffu;         /* nothing affordable: marks "none" below */
+				else if (!L.maq) qlim = P;
+				else qlim = P >= 30u ? 0xffu : P >= 20u ? 24u : P >= 10u ? 14u : 4u;
+			}
+			const bool none = qlim == 0xffffffffu;
+			uint32_t low = L.lowAltQual, num = L.eligibleNum, cnd = 0xffffffffu, elc = 0;
+			BT_NOUNROLL
 			for (int t = 3; t >= 0; t--) {
 				if ((uint32_t)t > hi - lo) continue;
-				BT_NOUNROLL
+				const uint32_t wv[4] = {bt_sel4((uint32_t)t, res.q[0].x, res.q[1].x, res.q[2].x, res.q[3].x),
+				                        bt_sel4((uint32_t)t, res.q[0].y, res.q[1].y, res.q[2].y, res.q[3].y),
+				                        bt_sel4((uint32_t)t, res.q[0].z, res.q[1].z, res.q[2].z, res.q[3].z),
+				                        bt_sel4((uint32_t)t, res.q[0].w, res.q[1].w, res.q[2].w, res.q[3].w)};
+				BT_UNROLL
 				for (int k = 7; k >= 0; k--) {
-					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k, v = bt_u4_meta(res.q[t], (uint32_t)k);
+					const uint32_t v = (k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu);
+					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k;
 					const uint32_t el = v & 15u, kq = v >> 8;
-					if (e > e_hi || e < e_lo || el == 15u) continue;
-					if (L.ham + bt_mm_penalty(L.maq, kq) > L.qualThresh) continue;
-					if (kq < L.lowAltQual) {
-						L.lowAltQual = kq; L.eligibleNum = 0;
-						L.cand = L.depth + (e - L.ebase); L.candValid = 1; L.ccValid = 0;
-						L.elcint = (el & 1u) == 0 ? 0u : (el & 2u) == 0 ? 1u : (el & 4u) == 0 ? 2u : 3u;
-						L.elignore = 0;
+					const bool ok = !none && e <= e_hi && e >= e_lo && el != 15u && kq <= qlim;
+					const uint32_t live = 4u - (uint32_t)__builtin_popcount(el);
+					if (ok && kq < low) {
+						low = kq; num = 0; cnd = e;
+						elc = (el & 1u) == 0 ? 0u : (el & 2u) == 0 ? 1u : (el & 4u) == 0 ? 2u : 3u;
 					}
-					if (kq == L.lowAltQual) L.eligibleNum = L.eligibleNum + (4u - (uint32_t)__builtin_popcount(el));
+					num += (ok && kq == low) ? live : 0u;
 				}
+			}
+			L.lowAltQual = low; L.eligibleNum = num;
+			if (cnd != 0xffffffffu) {
+				L.cand = L.depth + (cnd - L.ebase); L.candValid = 1; L.ccValid = 0;
+				L.elcint = elc; L.elignore = 0;
 			}
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_RESCAN; break; }
 			L.state = ST_BT_LOOP;
@@ -828,17 +847,24 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.state == ST_CANDSCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_CANDSCAN_DONE; break; }
 			const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
 			bool found = false;
-			BT_UNROLL
+			uint32_t cnd = 0;
+			BT_NOUNROLL
 			for (int t = 3; t >= 0; t--) {
 				if ((uint32_t)t > hi - lo) continue;
-				BT_NOUNROLL
+				const uint32_t wv[4] = {bt_sel4((uint32_t)t, res.q[0].x, res.q[1].x, res.q[2].x, res.q[3].x),
+				                        bt_sel4((uint32_t)t, res.q[0].y, res.q[1].y, res.q[2].y, res.q[3].y),
+				                        bt_sel4((uint32_t)t, res.q[0].z, res.q[1].z, res.q[2].z, res.q[3].z),
+				                        bt_sel4((uint32_t)t, res.q[0].w, res.q[1].w, res.q[2].w, res.q[3].w)};
+				BT_UNROLL
 				for (int k = 7; k >= 0; k--) {
-					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k, v = bt_u4_meta(res.q[t], (uint32_t)k);
-					if (!found && e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u) {
-						L.cand = L.depth + (e - L.ebase); L.candValid = 1; L.ccValid = 0; found = true;
-					}
+					const uint32_t v = (k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu);
+					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k;
+					const bool hit = !found && e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u;
+					cnd = hit ? e : cnd;
+					found = found || hit;
 				}
 			}
+			if (found) { L.cand = L.depth + (cnd - L.ebase); L.candValid = 1; L.ccValid = 0; }
 			if (found) { L.state = ST_BT_LOOP; break; }
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_CANDSCAN; break; }
 			L.state = ST_ABORT;                                   /* cannot happen: altNum > 0 */
@@ -1052,26 +1078,23 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				BT_UNROLL
 				for (int k = 0; k < 4; k++) { ta[k] = HFCHR(k); tb[k] = HFCHR(k + 1); }
 			}
+			/* alternatives at this position (:578-624): the characters other than the read's own whose
+			 * range is not empty.  The eliminated-set is the complement of that mask. */
 			uint32_t el = (c < 4u) ? (1u << c) : 0u;
 			if (L.fl_alt) {
-				bool over = L.fl_over != 0;
+				uint32_t nz = 0;
 				BT_UNROLL
-				for (uint32_t i = 0; i < 4u; i++) {
-					if (i == c) continue;
-					const uint32_t spread = tb[i] - ta[i];
-					if (spread == 0) el |= (1u << i);
-					else {
-						if (L.fl_elig) {
-							if (over) {
-								L.lowAltQual = q; L.eligibleNum = 0; over = false;
-								L.elcint = i; L.elignore = 0;
-							}
-							L.eligibleNum = L.eligibleNum + 1u;
-						}
-						L.altNum = L.altNum + 1u;
+				for (uint32_t i = 0; i < 4u; i++) nz |= (tb[i] != ta[i] && i != c) ? (1u << i) : 0u;
+				el = ~nz & 15u;
+				const uint32_t na = (uint32_t)__builtin_popcount(nz);
+				L.altNum = L.altNum + na;
+				if (L.fl_elig && nz != 0) {
+					if (L.fl_over) {
+						L.lowAltQual = q; L.eligibleNum = 0;
+						L.elcint = (nz & 1u) ? 0u : (nz & 2u) ? 1u : (nz & 4u) ? 2u : 3u;
+						L.elignore = 0;
 					}
-				}
-				if (L.fl_elig && el != 15u) {
+					L.eligibleNum = L.eligibleNum + na;
 					/* deepest eligible target so far; its ranges go to the LDS candidate slot so that
 					 * choosing it later costs no fetch */
 					L.cand = d; L.candValid = 1; L.ccValid = 1;
