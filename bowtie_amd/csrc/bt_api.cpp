@@ -42,6 +42,8 @@ struct bt_ctx {
 	BtPoolRec *pool1 = nullptr, *pool2 = nullptr;
 	uint32_t pool1Cap = 0, pool2Cap = 0, nSlots = 0;
 	uint32_t heavy0 = 0, heavy1 = 0;
+	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
+	bool is_big = false;
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
 	uint32_t *d_order = nullptr, *d_hist = nullptr; uint8_t* d_bucket = nullptr; uint32_t orderCap = 0;
@@ -175,6 +177,18 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
 	c->frCap = env_u32("BT_FRAME_CAP", seeded ? 64u : 8u);
 	c->entCap = (env_u32("BT_ENTRY_CAP", frames * c->maxLen) + 7u) & ~7u;      /* slot regions stay 16-byte aligned */
 	c->palCap = env_u32("BT_PARTIAL_CAP", seeded ? (c->pol.mms >= 3 ? 8192u : 1024u) : 1u);
+	if (c->is_big) {
+		/* worst case: one frame per query position, frame f spanning the remaining len-f positions;
+		 * every (position, character) combination of up to seedMms seed mismatches as a seedling */
+		const uint64_t L = c->maxLen, S = seeded ? (uint64_t)c->pol.seed_len : 0, n = seeded ? (uint64_t)c->pol.mms : 0;
+		c->frCap = (uint32_t)L + 8u;
+		c->entCap = (uint32_t)((L * (L + 3u) / 2u + 64u + 7u) & ~7ull);
+		uint64_t pals = 16;
+		if (n >= 1) pals += 3 * S;
+		if (n >= 2) pals += 9 * S * (S - 1) / 2;
+		if (n >= 3) pals += 27 * S * (S - 1) * (S - 2) / 6;
+		c->palCap = (uint32_t)(pals > (1u << 22) ? (1u << 22) : pals);
+	}
 	HIPCHK(hipMalloc((void**)&c->frames, (size_t)c->nSlots * c->frCap * BT_FR_WORDS * 4u));
 	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nSlots * c->entCap * 32u));
 	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nSlots * c->entCap * 2u));
@@ -224,6 +238,7 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 {
 	if (!c) return;
 	(void)hipStreamSynchronize(c->stream);
+	if (c->big) bt_ctx_destroy(c->big);
 	ctx_free_scratch(c);
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_cold) (void)hipFree(c->d_cold);
@@ -432,6 +447,48 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	if (rc != BT_OK) return rc;
 	out->mm_pool_used = c->last_mm_used < out->mm_pool_cap ? c->last_mm_used : out->mm_pool_cap;
 	if (counts) { rc = bt_ctx_counts(c, counts, 0); if (rc != BT_OK) return rc; }
+	/* reads whose search outgrew the per-read scratch are run again, on the GPU, through a twin
+	 * context sized for the worst case (few lanes, huge per-lane arenas) */
+	std::vector<uint32_t> redo;
+	if (!c->is_big)
+		for (uint32_t i = 0; i < n; i++) if (out->status[i] & BT_STF_OVERFLOW) redo.push_back(i);
+	if (!redo.empty()) {
+		if (!c->big) {
+			bt_ctx* b = nullptr;
+			rc = bt_ctx_create(c->idx, &c->pol, nullptr, &b);
+			if (rc != BT_OK) return rc;
+			b->is_big = true; b->heavy0 = 0;
+			b->nLanes = BT_BLOCK * (maxLen > 256 ? 1u : 16u);
+			c->big = b;
+		}
+		const uint32_t m = (uint32_t)redo.size();
+		std::vector<uint8_t> sseq((size_t)m * in->stride), squal((size_t)m * in->stride), sst(m);
+		std::vector<uint16_t> slen(m); std::vector<uint32_t> sseed(m), snh(m);
+		std::vector<bt_hit> shits((size_t)m * out->hit_cap);
+		const uint32_t spare = out->mm_pool_cap > out->mm_pool_used ? out->mm_pool_cap - out->mm_pool_used : 0;
+		std::vector<uint16_t> spool(spare ? spare : 1);
+		for (uint32_t k = 0; k < m; k++) {
+			const uint32_t i = redo[k];
+			memcpy(&sseq[(size_t)k * in->stride], in->seq + (size_t)i * in->stride, in->stride);
+			memcpy(&squal[(size_t)k * in->stride], in->qual + (size_t)i * in->stride, in->stride);
+			slen[k] = in->len[i]; sseed[k] = in->seed[i];
+		}
+		bt_read_batch sin = { m, in->stride, sseq.data(), squal.data(), slen.data(), sseed.data() };
+		bt_hit_batch sout = { out->hit_cap, shits.data(), snh.data(), sst.data(), spool.data(), spare, 0 };
+		rc = bt_align_batch(c->big, &sin, &sout, nullptr);
+		if (rc != BT_OK && rc != BT_ERR_OVERFLOW && rc != BT_ERR_READ_SHORT) return rc;
+		for (uint32_t k = 0; k < m; k++) {
+			const uint32_t i = redo[k];
+			out->n_hits[i] = snh[k]; out->status[i] = sst[k];
+			for (uint32_t h = 0; h < out->hit_cap; h++) {
+				bt_hit hit = shits[(size_t)k * out->hit_cap + h];
+				if (hit.nmm) hit.mm_off += out->mm_pool_used;
+				out->hits[(size_t)i * out->hit_cap + h] = hit;
+			}
+		}
+		if (sout.mm_pool_used) memcpy(out->mm_pool + out->mm_pool_used, spool.data(), 2ull * sout.mm_pool_used);
+		out->mm_pool_used += sout.mm_pool_used;
+	}
 	int worst = BT_OK;
 	for (uint32_t i = 0; i < n; i++) {
 		if (out->status[i] & BT_STF_TOOSHORT) worst = BT_ERR_READ_SHORT;

@@ -183,3 +183,18 @@ def test_gpu_heavy_first_schedule_is_transparent(gidx, monkeypatch):
         kw = T.MODES[mode]
         got = aligner(gidx, index, kw).align(batch, hit_cap=T.hit_cap_for(kw))
         T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "schedule " + mode)
+
+
+def test_gpu_scratch_overflow_is_retried(gidx, monkeypatch):
+    """A read whose backtracking outgrows its per-lane arenas is flagged by the kernel and re-run by
+    bt_align_batch through a worst-case-sized context; with absurdly small arenas most reads take
+    that road and the results must still equal the oracle's."""
+    monkeypatch.setenv("BT_ENTRY_CAP", "24")
+    monkeypatch.setenv("BT_FRAME_CAP", "3")
+    monkeypatch.setenv("BT_PARTIAL_CAP", "4")
+    for index, rname, mode in (("multi", "syn100", "n2"), ("multi", "syn50lowq", "n3"), ("e_coli", "syn76", "v2"),
+                               ("multi", "syn76", "n1_a_m20"), ("multi", "syn12", "n2_k3")):
+        batch = T.read_set(index, rname)
+        kw = T.MODES[mode]
+        got = aligner(gidx, index, kw).align(batch, hit_cap=T.hit_cap_for(kw))
+        T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "overflow-retry " + mode)
