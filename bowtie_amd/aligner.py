@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("BT_LIB", "libbowtie_amd.so"))
 EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_refname",
            "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
-           "bt_align_batch_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used",
+           "bt_align_batch_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used", "bt_ctx_last_retried",
            "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase"]
 _lib = None
 
@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
         L.bt_ctx_last_kernel_ms.restype = C.c_float
         L.bt_ctx_last_mm_used.argtypes = [C.c_void_p]
         L.bt_ctx_last_mm_used.restype = C.c_uint32
+        L.bt_ctx_last_retried.argtypes = [C.c_void_p]
+        L.bt_ctx_last_retried.restype = C.c_uint32
         L.bt_ctx_set_iters_buffer.argtypes = [C.c_void_p, C.c_void_p]
         L.bt_ctx_set_iters_buffer.restype = None
         L.bt_ctx_counts.argtypes = [C.c_void_p, C.POINTER(A.OpCounts), C.c_int]
@@ -185,6 +187,7 @@ class Aligner:
         if rc != A.BT_OK:
             raise BowtieAmdError(rc, "bt_align_batch")
         self.last_kernel_ms = float(lib().bt_ctx_last_kernel_ms(self._h))
+        self.last_retried = int(lib().bt_ctx_last_retried(self._h))
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(self.policy.khits),
                            int(self.policy.mhits), bool(self.policy.all_hits))
 

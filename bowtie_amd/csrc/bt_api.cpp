@@ -44,6 +44,7 @@ struct bt_ctx {
 	uint32_t heavy0 = 0, heavy1 = 0;
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
+	uint32_t last_retried = 0;
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
 	uint32_t *d_order = nullptr, *d_hist = nullptr; uint8_t* d_bucket = nullptr; uint32_t orderCap = 0;
@@ -385,6 +386,7 @@ extern "C" int bt_ctx_prof_sections(bt_ctx* c, uint64_t* out, int n)
 extern "C" void bt_ctx_set_iters_buffer(bt_ctx* c, uint32_t* dev_ptr) { if (c) c->iters_dev = dev_ptr; }
 
 extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
+extern "C" uint32_t bt_ctx_last_retried(bt_ctx* c) { return c ? c->last_retried : 0; }
 
 extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 {
@@ -452,6 +454,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	std::vector<uint32_t> redo;
 	if (!c->is_big)
 		for (uint32_t i = 0; i < n; i++) if (out->status[i] & BT_STF_OVERFLOW) redo.push_back(i);
+	c->last_retried = (uint32_t)redo.size();
 	if (!redo.empty()) {
 		if (!c->big) {
 			bt_ctx* b = nullptr;

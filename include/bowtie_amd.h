@@ -175,6 +175,9 @@ int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* o
 int  bt_ctx_sync(bt_ctx* ctx);
 /* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */
 uint32_t bt_ctx_last_mm_used(bt_ctx* ctx);
+/* reads of the last bt_align_batch that outgrew their search arenas and were re-run with worst-case
+ * arenas (the reference sizes every backtrack frame for the whole read instead, ebwt_search_backtrack.h:107) */
+uint32_t bt_ctx_last_retried(bt_ctx* ctx);
 /* diagnostics (profiling build of the library only; zeros otherwise): wavefront cycles spent per
  * section of the automaton since the counters were last reset */
 int  bt_ctx_prof_sections(bt_ctx* ctx, uint64_t* out, int n);

@@ -196,5 +196,7 @@ def test_gpu_scratch_overflow_is_retried(gidx, monkeypatch):
                                ("multi", "syn76", "n1_a_m20"), ("multi", "syn12", "n2_k3")):
         batch = T.read_set(index, rname)
         kw = T.MODES[mode]
-        got = aligner(gidx, index, kw).align(batch, hit_cap=T.hit_cap_for(kw))
+        al = aligner(gidx, index, kw)
+        got = al.align(batch, hit_cap=T.hit_cap_for(kw))
+        assert al.last_retried > batch.n // 20, (mode, al.last_retried)
         T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "overflow-retry " + mode)
