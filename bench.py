@@ -9,11 +9,12 @@ reads are sharded by rank, the index is replicated in every GPU's HBM, and the o
 is the final all-reduce of the hit counters (RCCL over xGMI).  Rank 0 prints one JSON line.
 
 Workloads (BASELINE.json configs):
-    ecoli_v0_36    e_coli index, 36-bp reads, -v 0              (config 1)
+    ecoli_v0_36    e_coli index, 36-bp reads, -v 0              (config 2)
     ecoli_v2_76    e_coli index, 76-bp reads, -v 2
     ecoli_n2_100   e_coli index, 100-bp reads, -n 2 -l 28 -e 70
-    big_v2_76      hg19-scale synthetic genome, 76-bp, -v 2     (config 2)
-    big_n2_100     hg19-scale synthetic genome, 100-bp, -n 2    (config 3; the headline metric)
+    big_v2_76      hg19-scale synthetic genome, 50 M x 76-bp, -v 2      (config 3)
+    big_n2_100     hg19-scale synthetic genome, 200 M x 100-bp, -n 2 -l 28 per GPU per step
+                   (config 4; the headline metric, default)
 The hg19-scale index is synthesised on the GPU at start-up (bowtie_amd/ebwt_build.py): neither
 hg19 nor any network exists on the bench box.
 """
@@ -47,8 +48,8 @@ WORKLOADS = {
     "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
     "ecoli_v2_76": dict(index="ecoli", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=2_000_000),
     "ecoli_n2_100": dict(index="ecoli", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=2_000_000),
-    "big_v2_76": dict(index="big", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=48_000_000),
-    "big_n2_100": dict(index="big", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=48_000_000),
+    "big_v2_76": dict(index="big", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=50_000_000),
+    "big_n2_100": dict(index="big", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=200_000_000),
 }
 
 
@@ -124,7 +125,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = workload default)")
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
-    ap.add_argument("--pipes", type=int, default=2, help="contexts/streams the steps are pipelined over")
+    ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
     args = ap.parse_args()

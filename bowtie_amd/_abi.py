@@ -3,7 +3,9 @@ from __future__ import annotations
 
 import ctypes as C
 
-BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, BT_ERR_OVERFLOW = range(7)
+BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, BT_ERR_OVERFLOW, BT_ERR_READS = range(8)
+BT_FMT_FASTQ, BT_FMT_FASTA, BT_FMT_RAW, BT_FMT_CMDLINE = range(4)
+BT_QUAL_PHRED33, BT_QUAL_PHRED64, BT_QUAL_SOLEXA64 = range(3)
 BT_MODE_V, BT_MODE_N = 0, 1
 BT_ST_SKIPPED, BT_ST_HITCAP, BT_ST_TOOSHORT, BT_ST_OVERFLOW, BT_ST_MMPOOL = 1, 2, 4, 8, 16
 
@@ -44,6 +46,23 @@ class IndexInfo(C.Structure):
     _fields_ = [("len", C.c_uint32), ("n_pat", C.c_uint32), ("n_frag", C.c_uint32),
                 ("ftab_chars", C.c_uint32), ("off_rate", C.c_uint32), ("z_off", C.c_uint32),
                 ("ebwt_bytes", C.c_uint64), ("offs_bytes", C.c_uint64), ("has_mirror", C.c_int32)]
+
+
+class ReadOpts(C.Structure):
+    _fields_ = [("format", C.c_int32), ("trim5", C.c_int32), ("trim3", C.c_int32), ("qual_enc", C.c_int32),
+                ("seed", C.c_uint32), ("reserved", C.c_uint32), ("skip", C.c_uint64), ("upto", C.c_uint64)]
+
+
+class OutOpts(C.Structure):
+    _fields_ = [("sam", C.c_int32), ("full_ref", C.c_int32), ("ref_idx", C.c_int32), ("off_base", C.c_int32),
+                ("print_cost", C.c_int32), ("show_seed", C.c_int32), ("mapq", C.c_int32),
+                ("no_qname_trunc", C.c_int32), ("no_unal", C.c_int32), ("sam_nosq", C.c_int32),
+                ("khits", C.c_uint32), ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("reserved", C.c_int32),
+                ("suppress", C.c_uint64)]
+
+
+class OutTally(C.Structure):
+    _fields_ = [("aligned", C.c_uint64), ("unaligned", C.c_uint64), ("maxed", C.c_uint64), ("reported", C.c_uint64)]
 
 
 HIT_DTYPE = [("tidx", "<u4"), ("toff", "<u4"), ("oms", "<u4"), ("mm_off", "<u4"), ("cost", "<u2"),

@@ -557,6 +557,7 @@ extern "C" const char* bt_strerror(int code)
 	case BT_ERR_DEVICE: return "HIP device error";
 	case BT_ERR_READ_SHORT: return "read shorter than the alignment mode allows";
 	case BT_ERR_OVERFLOW: return "per-read scratch capacity exceeded";
+	case BT_ERR_READS: return "malformed read input";
 	default: return "unknown error";
 	}
 }

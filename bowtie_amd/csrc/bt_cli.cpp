@@ -1,0 +1,617 @@
+/*
+ * bowtie-amd -- command-line front end over the C ABI (include/bowtie_amd.h): the reference's
+ * `bowtie [options]* -x <ebwt> <reads> [<hits>]` surface for unpaired, non---best alignment.
+ *
+ *   option table, defaults, validation   ebwt_search.cpp:144-254, 256-430, 590-925
+ *   driver (index load, search, finish)  ebwt_search.cpp:2886-3290
+ *   usage text                           ebwt_search.cpp:433-540
+ *
+ * Three host stages run concurrently over batches of reads: parse (bt_reads_next) -> search on the
+ * GPU (bt_align_batch) -> format + write (bt_io_format), each batch in read order, so the output is
+ * that of the reference run with -p 1.  Everything the search does happens behind the C ABI; this
+ * file holds no alignment logic and has no CPU search path.
+ */
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <errno.h>
+#include <limits.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include "bt_io.h"
+
+namespace {
+
+struct Options {
+	bt_policy pol;
+	bt_read_opts rd;
+	bt_out_opts out;
+	std::string index, reads, hits_file, rg_id;
+	std::vector<std::string> rg_fields;
+	int threads = 1, offrate = -1, device = 0;
+	bool quiet = false, timing = false, sam_nohead = false, tryhard = false;
+	bool suppress_set = false;
+	uint32_t batch_reads = 8u << 20;
+	std::string cmdline;
+};
+
+[[noreturn]] void die(const char* fmt, ...)
+{
+	va_list ap; va_start(ap, fmt);
+	vfprintf(stderr, fmt, ap);
+	va_end(ap);
+	fputc('\n', stderr);
+	exit(1);
+}
+
+void usage(FILE* o)
+{
+	fputs(
+	    "Usage: \n"
+	    "bowtie-amd [options]* -x <ebwt> <s> [<hit>]\n\n"
+	    "  <ebwt>  Index filename prefix (minus trailing .X.ebwt).\n"
+	    "  <s>     Comma-separated list of files containing unpaired reads, or the\n"
+	    "          sequences themselves, if -c is set.  Specify \"-\" for stdin.\n"
+	    "  <hit>   File to write hits to (default: stdout)\n"
+	    "Input:\n"
+	    "  -q                 query input files are FASTQ .fq/.fastq (default)\n"
+	    "  -f                 query input files are (multi-)FASTA .fa/.mfa\n"
+	    "  -r                 query input files are raw one-sequence-per-line\n"
+	    "  -c                 query sequences given on cmd line (as <s>)\n"
+	    "  -s/--skip <int>    skip the first <int> reads in the input\n"
+	    "  -u/--qupto <int>   stop after first <int> reads (excl. skipped reads)\n"
+	    "  -5/--trim5 <int>   trim <int> bases from 5' (left) end of reads\n"
+	    "  -3/--trim3 <int>   trim <int> bases from 3' (right) end of reads\n"
+	    "  --phred33-quals    input quals are Phred+33 (default)\n"
+	    "  --phred64-quals    input quals are Phred+64 (same as --solexa1.3-quals)\n"
+	    "  --solexa-quals     input quals are from GA Pipeline ver. < 1.3\n"
+	    "  --solexa1.3-quals  input quals are from GA Pipeline ver. >= 1.3\n"
+	    "Alignment:\n"
+	    "  -v <int>           report end-to-end hits w/ <=v mismatches; ignore qualities (0-2)\n"
+	    "    or\n"
+	    "  -n/--seedmms <int> max mismatches in seed (can be 0-3, default: -n 2)\n"
+	    "  -e/--maqerr <int>  max sum of mismatch quals across alignment for -n (def: 70)\n"
+	    "  -l/--seedlen <int> seed length for -n (default: 28)\n"
+	    "  --nomaqround       disable Maq-like quality rounding for -n (nearest 10 <= 30)\n"
+	    "  --nofw/--norc      do not align to forward/reverse-complement reference strand\n"
+	    "  --maxbts <int>     max # backtracks for -n 2/3 (default: 125)\n"
+	    "  -y/--tryhard       try hard to find valid alignments, at the expense of speed\n"
+	    "Reporting:\n"
+	    "  -k <int>           report up to <int> good alignments per read (default: 1)\n"
+	    "  -a/--all           report all alignments per read (much slower than low -k)\n"
+	    "  -m <int>           suppress all alignments if > <int> exist (def: no limit)\n"
+	    "Output:\n"
+	    "  -t/--time          print wall-clock time taken by search phases\n"
+	    "  -B/--offbase <int> leftmost ref offset = <int> in bowtie output (default: 0)\n"
+	    "  --quiet            print nothing but the alignments\n"
+	    "  --refidx           refer to ref. seqs by 0-based index rather than name\n"
+	    "  --fullref          write entire ref name (default: only up to 1st space)\n"
+	    "  --suppress <cols>  suppresses given columns (comma-delim'ed) in default output\n"
+	    "  --cost / --showseed  extra columns in default output\n"
+	    "SAM:\n"
+	    "  -S/--sam           write hits in SAM format\n"
+	    "  --mapq <int>       default mapping quality (MAPQ) to print for SAM alignments\n"
+	    "  --sam-nohead       supppress header lines (starting with @) for SAM output\n"
+	    "  --sam-nosq         supppress @SQ header lines for SAM output\n"
+	    "  --sam-RG <text>    add <text> (usually \"lab=value\") to @RG line of SAM header\n"
+	    "  --sam-no-qname-trunc  do not cut read names at the first whitespace\n"
+	    "  --no-unal          suppress SAM records for unaligned reads\n"
+	    "Performance:\n"
+	    "  -o/--offrate <int> override offrate of index; must be >= index's offrate\n"
+	    "  -p/--threads <int> number of host threads for parsing and formatting (default: 1)\n"
+	    "  --device <int>     GPU to run on (default: 0)\n"
+	    "  --batch <int>      reads per GPU batch (default: 8388608)\n"
+	    "Other:\n"
+	    "  --seed <int>       seed for random number generator\n"
+	    "  --version          print version information and quit\n"
+	    "  -h/--help          print this usage message\n"
+	    "Not in this build (best-first engine, SURVEY.md 8f-1): --best --strata -M -v 3 -1/-2 --12\n"
+	    "  --interleaved -I/-X --ff/--fr/--rf -F -Q --integer-quals --al/--un/--max -z --mm --shmem\n",
+	    o);
+}
+
+long parse_int(const char* s, long lo, const char* msg)
+{
+	char* e = nullptr; errno = 0;
+	const long v = strtol(s ? s : "", &e, 10);
+	if (!s || e == s || *e || errno || v < lo || v > INT_MAX) { fprintf(stderr, "%s\n", msg); usage(stderr); exit(1); }
+	return v;
+}
+
+struct LongOpt { const char* name; int has_arg; int id; };
+enum {
+	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
+	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
+	O_USAGE, O_DEVICE, O_BATCH, O_WRAPPER, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+};
+const LongOpt LONGS[] = {
+	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
+	{"qupto", 1, 'u'}, {"offrate", 1, 'o'}, {"version", 0, O_VERSION}, {"maqerr", 1, 'e'}, {"seedlen", 1, 'l'}, {"seedmms", 1, 'n'},
+	{"help", 0, 'h'}, {"threads", 1, 'p'}, {"khits", 1, 'k'}, {"mhits", 1, 'm'}, {"nomaqround", 0, O_NOMAQ}, {"refidx", 0, O_REFIDX},
+	{"maxbts", 1, O_MAXBTS}, {"nofw", 0, O_NOFW}, {"norc", 0, O_NORC}, {"offbase", 1, 'B'}, {"tryhard", 0, 'y'}, {"skip", 1, 's'},
+	{"phred33-quals", 0, O_PHRED33}, {"phred64-quals", 0, O_PHRED64}, {"solexa1.3-quals", 0, O_PHRED64}, {"fullref", 0, O_FULLREF},
+	{"usage", 0, O_USAGE}, {"sam", 0, 'S'}, {"sam-no-qname-trunc", 0, O_SAM_NOTRUNC}, {"sam-nohead", 0, O_SAM_NOHEAD},
+	{"sam-nosq", 0, O_SAM_NOSQ}, {"sam-noSQ", 0, O_SAM_NOSQ}, {"sam-RG", 1, O_SAM_RG}, {"suppress", 1, O_SUPPRESS}, {"mapq", 1, O_MAPQ},
+	{"cost", 0, O_COST}, {"showseed", 0, O_SHOWSEED}, {"no-unal", 0, O_NO_UNAL}, {"quiet", 0, O_QUIET}, {"device", 1, O_DEVICE},
+	{"batch", 1, O_BATCH}, {"wrapper", 1, O_WRAPPER},
+	/* accepted and without effect here (host-memory / CPU-threading knobs of the reference) */
+	{"reads-per-batch", 1, O_IGNORED_ARG}, {"chunkmbs", 1, O_IGNORED_ARG}, {"chunksz", 1, O_IGNORED_ARG}, {"chunkverbose", 0, O_IGNORED},
+	{"verbose", 0, O_IGNORED}, {"startverbose", 0, O_IGNORED}, {"sanity", 0, O_IGNORED}, {"reorder", 0, O_IGNORED},
+	{"thread-ceiling", 1, O_IGNORED_ARG}, {"thread-piddir", 1, O_IGNORED_ARG}, {"mm", 0, O_IGNORED}, {"shmem", 0, O_IGNORED},
+	{"mmsweep", 0, O_IGNORED}, {"prewidth", 1, O_IGNORED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_UNSUPPORTED},
+	/* the best-first engine and everything that needs it */
+	{"best", 0, O_UNSUPPORTED}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_UNSUPPORTED},
+	{"minins", 1, O_UNSUPPORTED_ARG}, {"maxins", 1, O_UNSUPPORTED_ARG}, {"ff", 0, O_UNSUPPORTED}, {"fr", 0, O_UNSUPPORTED},
+	{"rf", 0, O_UNSUPPORTED}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_UNSUPPORTED_ARG},
+	{"integer-quals", 0, O_UNSUPPORTED}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
+	{"al", 1, O_UNSUPPORTED_ARG}, {"un", 1, O_UNSUPPORTED_ARG}, {"max", 1, O_UNSUPPORTED_ARG}, {"phased", 0, O_UNSUPPORTED},
+	{"strandfix", 0, O_UNSUPPORTED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
+	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_UNSUPPORTED},
+	{"orig", 1, O_UNSUPPORTED_ARG}, {"filepar", 0, O_UNSUPPORTED}, {"noreconcile", 0, O_UNSUPPORTED},
+	{nullptr, 0, 0}
+};
+/* short options taking an argument */
+const char* SHORT_ARG = "us35oenlpkmBxv";
+const char* SHORT_UNSUPPORTED_ARG = "FM12IXQw";
+const char* SHORT_UNSUPPORTED = "bz";
+
+void parse_args(int argc, char** argv, Options* O)
+{
+	bt_policy_default(&O->pol);
+	memset(&O->rd, 0, sizeof(O->rd));
+	memset(&O->out, 0, sizeof(O->out));
+	O->rd.format = BT_FMT_FASTQ;
+	O->out.mapq = 255;
+	bool v_mode = false, n_set = false;
+	std::vector<std::string> pos;
+	for (int i = 0; i < argc; i++) { if (i) O->cmdline.push_back(' '); O->cmdline.append(argv[i]); }
+	for (int i = 1; i < argc; i++) {
+		const char* a = argv[i];
+		if (a[0] != '-' || a[1] == 0) { pos.emplace_back(a); continue; }
+		int id = 0; const char* val = nullptr;
+		if (a[1] == '-') {
+			if (a[2] == 0) { for (i++; i < argc; i++) pos.emplace_back(argv[i]); break; }
+			std::string name(a + 2); std::string inl; bool has_inl = false;
+			const size_t eq = name.find('=');
+			if (eq != std::string::npos) { inl = name.substr(eq + 1); name.resize(eq); has_inl = true; }
+			const LongOpt* lo = nullptr;
+			for (const LongOpt* p = LONGS; p->name; p++) if (name == p->name) { lo = p; break; }
+			if (!lo) { fprintf(stderr, "bowtie-amd: unrecognized option '--%s'\n", name.c_str()); usage(stderr); exit(1); }
+			id = lo->id;
+			if (lo->has_arg) {
+				static std::string keep;
+				if (has_inl) { keep = inl; val = keep.c_str(); }
+				else { if (i + 1 >= argc) die("bowtie-amd: option '--%s' requires an argument", name.c_str()); val = argv[++i]; }
+			}
+			if (id == O_UNSUPPORTED || id == O_UNSUPPORTED_ARG)
+				die("Error: --%s needs the reference's best-first / paired-end engine, which this build does not have (SURVEY.md 8f-1)", name.c_str());
+			if (id == O_IGNORED || id == O_IGNORED_ARG) continue;
+		} else {
+			/* a short option with its value (attached or next argument), or a bundle of flags */
+			const char c = a[1];
+			if (strchr(SHORT_UNSUPPORTED_ARG, c) || strchr(SHORT_UNSUPPORTED, c))
+				die("Error: -%c needs a part of the reference this build does not have (SURVEY.md 8f-1)", c);
+			if (strchr(SHORT_ARG, c)) {
+				if (a[2]) val = a + 2;
+				else { if (i + 1 >= argc) die("bowtie-amd: option requires an argument -- '%c'", c); val = argv[++i]; }
+				id = c;
+			} else {
+				for (const char* p = a + 1; *p; p++) {
+					switch (*p) {
+					case 'f': O->rd.format = BT_FMT_FASTA; break;
+					case 'q': O->rd.format = BT_FMT_FASTQ; break;
+					case 'r': O->rd.format = BT_FMT_RAW; break;
+					case 'c': O->rd.format = BT_FMT_CMDLINE; break;
+					case 'a': O->pol.all_hits = 1; break;
+					case 't': O->timing = true; break;
+					case 'y': O->tryhard = true; break;
+					case 'S': O->out.sam = 1; break;
+					case 'h': usage(stdout); exit(0);
+					case 'C': die("Error: -C specified but Bowtie no longer supports colorspace.");
+					default: fprintf(stderr, "bowtie-amd: invalid option -- '%c'\n", *p); usage(stderr); exit(1);
+					}
+				}
+				continue;
+			}
+		}
+		switch (id) {
+		case 'a': O->pol.all_hits = 1; break;
+		case 't': O->timing = true; break;
+		case 'y': O->tryhard = true; break;
+		case 'S': O->out.sam = 1; break;
+		case 'h': case O_USAGE: usage(stdout); exit(0);
+		case 'u': O->rd.upto = (uint64_t)parse_int(val, 1, "-u/--qupto arg must be at least 1"); break;
+		case 's': O->rd.skip = (uint64_t)parse_int(val, 0, "-s arg must be positive"); break;
+		case '3': O->rd.trim3 = (int32_t)parse_int(val, 0, "-3/--trim3 arg must be at least 0"); break;
+		case '5': O->rd.trim5 = (int32_t)parse_int(val, 0, "-5/--trim5 arg must be at least 0"); break;
+		case 'o': O->offrate = (int)parse_int(val, 1, "-o/--offrate arg must be at least 1"); break;
+		case 'e': O->pol.qual_thresh = (int32_t)parse_int(val, 1, "-e/--err arg must be at least 1"); break;
+		case 'n': O->pol.mode = BT_MODE_N; O->pol.mms = (int32_t)parse_int(val, 0, "-n/--seedmms arg must be at least 0"); n_set = true; break;
+		case 'l': O->pol.seed_len = (int32_t)parse_int(val, 5, "-l/--seedlen arg must be at least 5"); break;
+		case 'v': break;
+		case 'p': O->threads = (int)parse_int(val, 1, "-p/--threads arg must be at least 1"); break;
+		case 'k': O->pol.khits = (uint32_t)parse_int(val, 1, "-k arg must be at least 1"); break;
+		case 'm': O->pol.mhits = (uint32_t)parse_int(val, 1, "-m arg must be at least 1"); break;
+		case 'B': O->out.off_base = (int32_t)parse_int(val, -999999, "-B/--offbase arg must be at least -999999"); break;
+		case 'x': O->index = val; break;
+		case O_SOLEXA: O->rd.qual_enc = BT_QUAL_SOLEXA64; break;
+		case O_PHRED64: O->rd.qual_enc = BT_QUAL_PHRED64; break;
+		case O_PHRED33: O->rd.qual_enc = BT_QUAL_PHRED33; break;
+		case O_SEED: O->rd.seed = (uint32_t)parse_int(val, 0, "--seed arg must be at least 0"); break;
+		case O_MAXBTS: O->pol.max_bts = (int32_t)parse_int(val, 0, "--maxbts must be positive"); break;
+		case O_QUIET: O->quiet = true; break;
+		case O_REFIDX: O->out.ref_idx = 1; break;
+		case O_FULLREF: O->out.full_ref = 1; break;
+		case O_NOMAQ: O->pol.maq_round = 0; break;
+		case O_NOFW: O->pol.nofw = 1; break;
+		case O_NORC: O->pol.norc = 1; break;
+		case O_SAM_NOHEAD: O->sam_nohead = true; break;
+		case O_SAM_NOSQ: O->out.sam_nosq = 1; break;
+		case O_SAM_NOTRUNC: O->out.no_qname_trunc = 1; break;
+		case O_NO_UNAL: O->out.no_unal = 1; break;
+		case O_MAPQ: O->out.mapq = (int32_t)parse_int(val, 0, "--mapq must be positive"); break;
+		case O_COST: O->out.print_cost = 1; break;
+		case O_SHOWSEED: O->out.show_seed = 1; break;
+		case O_DEVICE: O->device = (int)parse_int(val, 0, "--device arg must be at least 0"); break;
+		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
+		case O_WRAPPER: break;
+		case O_VERSION: printf("bowtie-amd (%s), output-compatible with bowtie-align-s version 1.3.1\n", bt_version()); exit(0);
+		case O_SAM_RG: {
+			/* "ID:x" opens the @RG line, later fields are tab-appended (ebwt_search.cpp ARG_SAM_RG) */
+			O->rg_fields.emplace_back(val);
+			break;
+		}
+		case O_SUPPRESS: {
+			const char* p = val;
+			while (*p) {
+				char* e = nullptr;
+				const long f = strtol(p, &e, 10);
+				if (e == p || f < 1 || f > 64) die("Error: bad --suppress field: %s", val);
+				O->out.suppress |= 1ull << (f - 1);
+				O->suppress_set = true;
+				p = (*e == ',') ? e + 1 : e;
+				if (*e && *e != ',') die("Error: bad --suppress field: %s", val);
+			}
+			break;
+		}
+		default: break;
+		}
+		if (id == 'v') {
+			O->pol.mode = BT_MODE_V; O->pol.mms = (int32_t)parse_int(val, 0, "-v arg must be at least 0"); v_mode = true;
+			if (O->pol.mms > 3) die("-v arg must be at most 3");
+		}
+	}
+	(void)n_set;
+	if (v_mode && O->pol.mms == 3)
+		die("Error: -v 3 runs the reference's best-first engine, which this build does not have (SURVEY.md 8f-1)");
+	if (O->pol.mode == BT_MODE_N && O->pol.mms > 3) die("-n/--seedmms arg must be at most 3");
+	/* positionals: [<ebwt>] <reads> [<hits>] (ebwt_search.cpp:2930-2975) */
+	size_t pi = 0;
+	if (O->index.empty()) {
+		if (pi >= pos.size()) { fprintf(stderr, "No index, query, or output file specified!\n"); usage(stderr); exit(1); }
+		O->index = pos[pi++];
+	}
+	if (pi >= pos.size()) { fprintf(stderr, "No query or output file specified!\n"); usage(stderr); exit(1); }
+	O->reads = pos[pi++];
+	if (pi < pos.size()) O->hits_file = pos[pi++];
+	if (pi < pos.size()) { fprintf(stderr, "Extra parameter(s) specified: "); for (; pi < pos.size(); pi++) fprintf(stderr, "\"%s\"%s", pos[pi].c_str(), pi + 1 < pos.size() ? ", " : "\n"); exit(1); }
+	if (O->tryhard) O->pol.max_bts = INT_MAX;
+	if (O->out.sam && O->suppress_set) {
+		if (!O->quiet) fprintf(stderr, "Warning: Ignoring --suppress because output type is not default.\n"
+		                               "         --suppress is only available for the default output type.\n");
+		O->out.suppress = 0;
+	}
+	if (O->out.sam && O->out.ref_idx) { /* SAMHitSink gets no names: indexes are printed */ }
+	O->out.khits = O->pol.khits; O->out.mhits = O->pol.mhits; O->out.all_hits = O->pol.all_hits;
+}
+
+bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+/* adjustEbwtBase (ebwt.h): the prefix as given, else under $BOWTIE_INDEXES */
+std::string find_index(const std::string& base)
+{
+	if (file_exists(base + ".1.ebwt")) return base;
+	const char* dir = getenv("BOWTIE_INDEXES");
+	if (dir && *dir) {
+		std::string p = std::string(dir) + (dir[strlen(dir) - 1] == '/' ? "" : "/") + base;
+		if (file_exists(p + ".1.ebwt")) return p;
+	}
+	return base;
+}
+
+double now_s() { struct timeval tv; gettimeofday(&tv, nullptr); return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec; }
+void print_timer(const char* msg, double secs)
+{
+	/* Timer::write (timer.h): hh:mm:ss */
+	const long s = (long)secs;
+	fprintf(stderr, "%s%02ld:%02ld:%02ld\n", msg, s / 3600, (s / 60) % 60, s % 60);
+}
+
+/* ---- one batch travelling through the stages ------------------------------------------------ */
+struct Job {
+	bt_read_batch rb;                        /* view into `store` */
+	std::unique_ptr<BtHostBatch> store;
+	uint32_t hit_cap = 1;
+	std::vector<bt_hit> hits;
+	std::vector<uint32_t> n_hits;
+	std::vector<uint8_t> status;
+	std::vector<uint16_t> mm_pool;
+	uint32_t mm_used = 0;
+	/* reads whose hits did not fit the uniform slots: searched again alone with room for all */
+	struct Wide { uint32_t read; uint32_t hit_cap; std::vector<bt_hit> hits; std::vector<uint16_t> pool; uint32_t n_hits; uint8_t status; };
+	std::vector<Wide> wide;
+	bool last = false;
+	std::string error;
+};
+
+template <class T> class Chan {
+public:
+	explicit Chan(size_t cap) : cap_(cap) {}
+	void put(T v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
+	T take() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); T v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return v; }
+private:
+	std::mutex m_; std::condition_variable cv_; std::deque<T> q_; size_t cap_;
+};
+
+
+/* one read of a batch as a batch of its own */
+bt_read_batch one_read(const bt_read_batch& rb, uint32_t i)
+{
+	bt_read_batch one = rb;
+	one.n_reads = 1;
+	one.seq = rb.seq + (size_t)i * rb.stride; one.qual = rb.qual + (size_t)i * rb.stride;
+	one.len = rb.len + i; one.seed = rb.seed + i;
+	return one;
+}
+
+/* Search one batch.  Hit slots are uniform per read (bt_hit_batch); reads that report more than the
+ * first pass had slots for (-a, large -k) or whose mismatch lists outgrew the pool are searched
+ * again, together, with as many slots as the hungriest of them needs.  "" = ok. */
+std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
+{
+	const uint32_t n = j->rb.n_reads;
+	const bool all = O.pol.all_hits != 0;
+	j->hit_cap = all ? 16u : (O.pol.khits > 64u ? 64u : O.pol.khits);
+	j->hits.resize((size_t)n * j->hit_cap);
+	j->n_hits.assign(n, 0); j->status.assign(n, 0);
+	j->mm_pool.resize((size_t)n * j->hit_cap * 6u + 1024u);
+	bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
+	int rc = bt_align_batch(ctx, &j->rb, &hb, nullptr);
+	j->mm_used = hb.mm_pool_used;
+	if (rc == BT_ERR_READ_SHORT) {
+		/* the reference stops at the first such read (search_1mm_phase1.c:12-15, search_23mm_phase1.c:13-20) */
+		for (uint32_t i = 0; i < n; i++) if (j->status[i] & BT_ST_TOOSHORT) {
+			if (O.pol.mms == 1) return "Error: Reads must be at least 2 characters long in 1-mismatch mode";
+			const std::string nm(j->store->names.data() + j->store->name_off[i], (size_t)(j->store->name_off[i + 1] - j->store->name_off[i]));
+			return "Error: Read (" + nm + ") is less than " + (j->rb.len[i] < 3 ? "3" : "4") + " characters long";
+		}
+		return "Error: read too short for the alignment mode";
+	}
+	if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
+
+	std::vector<uint32_t> redo, need;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t tot = j->n_hits[i];
+		if (j->status[i] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
+		if (tot > O.pol.mhits) continue;                              /* nothing of it is printed */
+		const uint32_t want = all ? tot : (tot < O.pol.khits ? tot : O.pol.khits);
+		if (want > j->hit_cap || (j->status[i] & BT_ST_MMPOOL)) { redo.push_back(i); need.push_back(want > j->hit_cap ? want : j->hit_cap); }
+	}
+	size_t at = 0;
+	while (at < redo.size()) {
+		/* a group whose slot matrix stays under 16 M hits */
+		size_t end = at; uint32_t cap = 0; uint32_t maxlen = 1;
+		while (end < redo.size()) {
+			const uint32_t c2 = need[end] > cap ? need[end] : cap;
+			if (end > at && (uint64_t)c2 * (end - at + 1) > (16ull << 20)) break;
+			cap = c2;
+			if (j->rb.len[redo[end]] > maxlen) maxlen = j->rb.len[redo[end]];
+			end++;
+		}
+		const uint32_t m = (uint32_t)(end - at);
+		BtHostBatch sub;
+		sub.reset(m, j->rb.stride);
+		for (uint32_t k = 0; k < m; k++) {
+			const uint32_t i = redo[at + k];
+			memcpy(sub.seq + (size_t)k * sub.stride, j->rb.seq + (size_t)i * j->rb.stride, j->rb.stride);
+			memcpy(sub.qual + (size_t)k * sub.stride, j->rb.qual + (size_t)i * j->rb.stride, j->rb.stride);
+			sub.len[k] = j->rb.len[i]; sub.seed[k] = j->rb.seed[i];
+		}
+		const bt_read_batch srb = sub.view();
+		std::vector<bt_hit> sh((size_t)m * cap);
+		std::vector<uint32_t> snh(m); std::vector<uint8_t> sst(m);
+		uint64_t pool_n = (uint64_t)m * cap * (maxlen < 12u ? maxlen : 12u) + 1024u;
+		if (pool_n > 0xfffffff0ull) pool_n = 0xfffffff0ull;
+		std::vector<uint16_t> sp((size_t)pool_n);
+		bt_hit_batch shb = { cap, sh.data(), snh.data(), sst.data(), sp.data(), (uint32_t)sp.size(), 0 };
+		rc = bt_align_batch(ctx, &srb, &shb, nullptr);
+		if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
+		for (uint32_t k = 0; k < m; k++) {
+			Job::Wide w;
+			w.read = redo[at + k]; w.n_hits = snh[k]; w.status = sst[k];
+			if (sst[k] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
+			const uint32_t tot = snh[k];
+			uint32_t keep = all ? tot : (tot < O.pol.khits ? tot : O.pol.khits);
+			if (keep > cap) keep = cap;
+			if (sst[k] & BT_ST_MMPOOL) {
+				/* still short of mismatch slots: this read alone, a full-length list per hit */
+				w.hit_cap = keep ? keep : 1u;
+				w.hits.assign(w.hit_cap, bt_hit());
+				w.pool.assign((size_t)w.hit_cap * j->rb.len[w.read] + 16u, 0);
+				const bt_read_batch one = one_read(j->rb, w.read);
+				bt_hit_batch hw = { w.hit_cap, w.hits.data(), &w.n_hits, &w.status, w.pool.data(), (uint32_t)w.pool.size(), 0 };
+				rc = bt_align_batch(ctx, &one, &hw, nullptr);
+				if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
+				if (w.status & (BT_ST_MMPOOL | BT_ST_OVERFLOW)) return "Error: a read exceeded the search scratch space";
+			} else {
+				w.hit_cap = keep ? keep : 1u;
+				w.hits.assign(sh.begin() + (size_t)k * cap, sh.begin() + (size_t)k * cap + w.hit_cap);
+				for (uint32_t h = 0; h < keep; h++) {          /* the read's mismatch lists, re-based */
+					bt_hit& x = w.hits[h];
+					const uint32_t off = (uint32_t)w.pool.size();
+					w.pool.insert(w.pool.end(), sp.begin() + x.mm_off, sp.begin() + x.mm_off + x.nmm);
+					x.mm_off = off;
+				}
+				if (w.pool.empty()) w.pool.push_back(0);
+			}
+			j->wide.push_back(std::move(w));
+		}
+		at = end;
+	}
+	return "";
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+	Options O;
+	parse_args(argc, argv, &O);
+	const double t_all = now_s();
+
+	/* ---- index into HBM ---- */
+	const std::string base = find_index(O.index);
+	bt_index* idx = nullptr;
+	double t0 = now_s();
+	int rc = bt_index_load(base.c_str(), 1, O.offrate, O.device, &idx);
+	if (rc != BT_OK) {
+		if (rc == BT_ERR_IO) die("Could not locate a Bowtie index corresponding to basename \"%s\"", O.index.c_str());
+		die("Error: could not load index \"%s\": %s", O.index.c_str(), bt_strerror(rc));
+	}
+	if (O.timing) print_timer("Time loading forward and mirror index: ", now_s() - t0);
+	bt_index_info info;
+	bt_index_info_get(idx, &info);
+	BtRefNames refs;
+	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
+	bt_ctx* ctx = nullptr;
+	rc = bt_ctx_create(idx, &O.pol, nullptr, &ctx);
+	if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+
+	/* ---- output ---- */
+	FILE* fout = stdout;
+	if (!O.hits_file.empty()) { fout = fopen(O.hits_file.c_str(), "wb"); if (!fout) die("Error: Could not open alignment output file %s", O.hits_file.c_str()); }
+	static char obuf[1 << 22];
+	setvbuf(fout, obuf, _IOFBF, sizeof(obuf));
+	if (O.out.sam && !O.sam_nohead) {
+		std::string rg;
+		for (size_t i = 0; i < O.rg_fields.size(); i++) { if (i) rg.push_back('\t'); rg.append(O.rg_fields[i]); }
+		std::string h;
+		bt_io_sam_header(refs, O.out, O.cmdline.c_str(), rg.empty() ? nullptr : rg.c_str(), &h);
+		fwrite(h.data(), 1, h.size(), fout);
+	}
+
+	/* ---- stage 1: reader ---- */
+	std::string open_err;
+	BtReadStream* rs = bt_io_open(O.reads.c_str(), O.rd, &open_err);
+	Chan<std::unique_ptr<Job>> to_gpu(2), to_out(2);
+	const int T = O.threads;
+	std::thread reader([&] {
+		for (;;) {
+			std::unique_ptr<Job> j(new Job());
+			j->store.reset(new BtHostBatch());
+			std::string err;
+			const int r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
+			if (r != BT_OK) { j->error = err; j->last = true; to_gpu.put(std::move(j)); return; }
+			j->rb = j->store->view();
+			if (j->rb.n_reads == 0) { j->last = true; to_gpu.put(std::move(j)); return; }
+			to_gpu.put(std::move(j));
+		}
+	});
+
+	/* ---- stage 3: writer ---- */
+	bt_out_tally tally = {0, 0, 0, 0};
+	std::string fatal;
+	std::thread writer([&] {
+		for (;;) {
+			std::unique_ptr<Job> j = to_out.take();
+			if (!j->error.empty()) { fatal = j->error; return; }
+			if (j->last) return;
+			const uint32_t n = j->rb.n_reads;
+			bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), j->mm_used };
+			const char* names = j->store->names.data();
+			const uint64_t* noff = j->store->name_off.data();
+			/* segments between the reads that were searched again with wider slots */
+			std::vector<uint32_t> cuts; cuts.push_back(0);
+			for (auto& w : j->wide) { cuts.push_back(w.read); cuts.push_back(w.read + 1); }
+			cuts.push_back(n);
+			std::vector<std::string> parts;
+			std::vector<bt_out_tally> tl;
+			struct Seg { uint32_t lo, hi; int wide; };
+			std::vector<Seg> segs;
+			for (size_t c = 0; c + 1 < cuts.size(); c++) {
+				const bool is_wide = (c & 1u) != 0;
+				uint32_t lo = cuts[c], hi = cuts[c + 1];
+				if (lo >= hi) continue;
+				if (is_wide) { segs.push_back({lo, hi, (int)(c / 2)}); continue; }
+				/* split plain segments across the threads */
+				const uint32_t pieces = (hi - lo) >= 8192 ? (uint32_t)T : 1u;
+				for (uint32_t p = 0; p < pieces; p++)
+					segs.push_back({lo + (uint32_t)((uint64_t)(hi - lo) * p / pieces), lo + (uint32_t)((uint64_t)(hi - lo) * (p + 1) / pieces), -1});
+			}
+			parts.resize(segs.size()); tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0});
+			auto run = [&](size_t si) {
+				const Seg& sg = segs[si];
+				if (sg.wide < 0) { bt_io_format(j->rb, names, noff, hb, refs, O.out, sg.lo, sg.hi, &parts[si], &tl[si]); return; }
+				Job::Wide& w = j->wide[(size_t)sg.wide];
+				/* a one-read view whose slot count holds every hit of that read */
+				bt_read_batch one = j->rb;
+				one.n_reads = 1;
+				one.seq = j->rb.seq + (size_t)w.read * j->rb.stride; one.qual = j->rb.qual + (size_t)w.read * j->rb.stride;
+				one.len = j->rb.len + w.read; one.seed = j->rb.seed + w.read;
+				bt_hit_batch hw = { w.hit_cap, w.hits.data(), &w.n_hits, &w.status, w.pool.data(), (uint32_t)w.pool.size(), 0 };
+				const uint64_t off[2] = { noff[w.read], noff[w.read + 1] };
+				bt_io_format(one, names, off, hw, refs, O.out, 0, 1, &parts[si], &tl[si]);
+			};
+			if (T > 1 && segs.size() > 1) {
+				std::vector<std::thread> th;
+				std::mutex m; size_t next = 0;
+				for (int t = 0; t < T; t++) th.emplace_back([&] { for (;;) { size_t si; { std::lock_guard<std::mutex> l(m); si = next++; } if (si >= segs.size()) return; run(si); } });
+				for (auto& x : th) x.join();
+			} else for (size_t si = 0; si < segs.size(); si++) run(si);
+			for (size_t si = 0; si < segs.size(); si++) {
+				fwrite(parts[si].data(), 1, parts[si].size(), fout);
+				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
+			}
+		}
+	});
+
+	/* ---- stage 2: the GPU ---- */
+	const double t_search = now_s();
+	std::string stop_msg;
+	for (;;) {
+		std::unique_ptr<Job> j = to_gpu.take();
+		if (j->last) { to_out.put(std::move(j)); break; }
+		stop_msg = search_job(ctx, O, j.get());
+		if (!stop_msg.empty()) {
+			j->error = stop_msg; j->last = true;
+			to_out.put(std::move(j));
+			/* let the reader run to its end so that it can be joined */
+			for (;;) { std::unique_ptr<Job> r = to_gpu.take(); if (r->last) break; }
+			break;
+		}
+		to_out.put(std::move(j));
+	}
+	reader.join();
+	writer.join();
+	if (O.timing) print_timer("Time searching: ", now_s() - t_search);
+	fflush(fout);
+	if (fout != stdout) fclose(fout);
+	bt_io_close(rs);
+	bt_ctx_destroy(ctx);
+	bt_index_free(idx);
+	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
+	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }
+	if (O.timing) print_timer("Overall time: ", now_s() - t_all);
+	return 0;
+}

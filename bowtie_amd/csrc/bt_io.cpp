@@ -1,0 +1,813 @@
+/*
+ * bt_io.cpp -- read input and hit output around the search path (host only).
+ *
+ * Input follows the reference's two-stage pattern sources: a cheap sequential "light parse" that
+ * only finds record boundaries (done here on the reading thread), and the per-record parse that
+ * the worker threads do (done here by `threads` host threads over the batch):
+ *   FASTQ    pat.cpp:797-975      FASTA   pat.cpp:531-640
+ *   raw      pat.cpp:1129-1213    -c      pat.cpp:359-528
+ *   qualities qual.h:89-153, qual.cpp:38-50      seeds  pat.cpp:21-57
+ * Output follows VerboseHitSink::append (hit.cpp:73-301), SAMHitSink::append / reportUnOrMax /
+ * appendHeaders (sam.cpp:20-257) and HitSink::finish (hit.h:270-346).
+ */
+#include "bt_io.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <thread>
+
+/* ---- batch storage ----------------------------------------------------------------------- */
+BtHostBatch::~BtHostBatch() { free(seq); free(qual); }
+
+void BtHostBatch::reset(uint32_t n_reads, uint32_t stride_bytes)
+{
+	n = n_reads; stride = stride_bytes;
+	const size_t need = ((size_t)n_reads * stride_bytes + 63u) & ~(size_t)63u;
+	if (need > cap_bytes) {
+		free(seq); free(qual);
+		cap_bytes = need + need / 4 + 64;
+		cap_bytes = (cap_bytes + 63u) & ~(size_t)63u;
+		seq = (uint8_t*)aligned_alloc(64, cap_bytes);
+		qual = (uint8_t*)aligned_alloc(64, cap_bytes);
+	}
+	len.assign(n_reads, 0); seed.assign(n_reads, 0);
+}
+
+bt_read_batch BtHostBatch::view() const
+{
+	bt_read_batch b;
+	b.n_reads = n; b.stride = stride; b.seq = seq; b.qual = qual; b.len = len.data(); b.seed = seed.data();
+	return b;
+}
+
+/* ---- the stream -------------------------------------------------------------------------- */
+struct BtRec { size_t off; uint32_t len; uint64_t rdid; };
+
+struct BtReadStream {
+	bt_read_opts o;
+	std::vector<std::string> items;       /* file names, or the -c sequences                     */
+	size_t item = 0;
+	gzFile f = nullptr;
+	bool file_first = true;               /* nothing of the current file consumed yet            */
+	std::vector<char> buf;                /* file window                                         */
+	size_t pos = 0, end = 0;
+	bool feof = false;
+	uint64_t rdid = 0;                    /* next read id (counts skipped reads too)             */
+	uint64_t limit = ~0ull;               /* first read id that is not processed                 */
+	bool done = false;
+	std::string raw;                      /* the batch's record texts                            */
+	std::vector<BtRec> recs;
+};
+
+static int st_fill(BtReadStream* s)
+{
+	/* keep the unread tail, top the window up */
+	if (s->pos > 0) {
+		memmove(s->buf.data(), s->buf.data() + s->pos, s->end - s->pos);
+		s->end -= s->pos; s->pos = 0;
+	}
+	if (s->feof || !s->f) return 0;
+	const size_t room = s->buf.size() - s->end;
+	const int got = gzread(s->f, s->buf.data() + s->end, (unsigned)room);
+	if (got <= 0) { s->feof = true; return 0; }
+	s->end += (size_t)got;
+	return got;
+}
+static inline int st_getc(BtReadStream* s)
+{
+	if (s->pos == s->end) { if (st_fill(s) == 0) return -1; }
+	return (unsigned char)s->buf[s->pos++];
+}
+static inline int st_peek(BtReadStream* s)
+{
+	if (s->pos == s->end) { if (st_fill(s) == 0) return -1; }
+	return (unsigned char)s->buf[s->pos];
+}
+
+static bool st_open_next(BtReadStream* s, std::string* err)
+{
+	if (s->f) { gzclose(s->f); s->f = nullptr; }
+	if (s->item >= s->items.size()) return false;
+	const std::string& fn = s->items[s->item++];
+	s->f = (fn == "-") ? gzdopen(0, "rb") : gzopen(fn.c_str(), "rb");
+	if (!s->f) {
+		/* the reference warns and moves on to the next file (pat.cpp:301-305); with none left the
+		 * run simply has no reads */
+		*err = "Warning: Could not open read file \"" + fn + "\" for reading; skipping...";
+		fprintf(stderr, "%s\n", err->c_str());
+		err->clear();
+		return st_open_next(s, err);
+	}
+	gzbuffer(s->f, 1u << 20);
+	s->file_first = true; s->feof = false; s->pos = s->end = 0;
+	return true;
+}
+
+BtReadStream* bt_io_open(const char* spec, const bt_read_opts& opts, std::string* err)
+{
+	BtReadStream* s = new BtReadStream();
+	s->o = opts;
+	const char* p = spec ? spec : "";
+	while (*p) {                               /* tokenize(..., ",") : empty tokens vanish */
+		const char* q = strchr(p, ',');
+		const size_t n = q ? (size_t)(q - p) : strlen(p);
+		if (n) s->items.emplace_back(p, n);
+		p += n + (q ? 1 : 0);
+	}
+	s->buf.resize(8u << 20);
+	if (opts.upto != 0 && opts.skip + opts.upto > opts.skip) s->limit = opts.skip + opts.upto;
+	(void)err;
+	return s;
+}
+
+void bt_io_close(BtReadStream* s)
+{
+	if (!s) return;
+	if (s->f) gzclose(s->f);
+	delete s;
+}
+
+/* ---- light parse: one record's text appended to s->raw ------------------------------------- */
+/* Each returns 1 = a record was appended, 0 = the current file is finished, -1 = error. */
+
+static int light_fastq(BtReadStream* s, std::string* err)
+{
+	std::string& raw = s->raw;
+	const size_t start = raw.size();
+	if (s->file_first) {
+		int c = st_getc(s);
+		while (c == '\r' || c == '\n') c = st_getc(s);
+		if (c != '@') {
+			/* the reference checks the first character only (an empty file fails the same way) */
+			*err = "Error: reads file does not look like a FASTQ file";
+			return -1;
+		}
+		s->file_first = false;
+		raw.push_back('@');
+	}
+	int newlines = 4;
+	while (newlines) {
+		/* bulk path: copy up to the next '\n' in the window */
+		if (s->pos < s->end) {
+			const char* b = s->buf.data() + s->pos;
+			const char* nl = (const char*)memchr(b, '\n', s->end - s->pos);
+			const size_t take = nl ? (size_t)(nl - b) + 1 : s->end - s->pos;
+			raw.append(b, take);
+			s->pos += take;
+			if (nl) newlines--;
+			continue;
+		}
+		const int c = st_getc(s);
+		if (c < 0) {
+			if (newlines == 1) { raw.push_back('\n'); newlines = 0; break; }   /* EOF stands in for the last newline */
+			/* clean end of file, or EOF inside a record: the partial record is dropped (the
+			 * reference's light parser additionally loses the record before a truncated one) */
+			raw.resize(start);
+			return 0;
+		}
+		s->pos--;            /* window refilled: take the bulk path */
+	}
+	return 1;
+}
+
+static int light_fasta(BtReadStream* s, std::string* err)
+{
+	std::string& raw = s->raw;
+	if (s->file_first) {
+		int c = st_getc(s);
+		if (c < 0) return 0;
+		while (c == '\r' || c == '\n') c = st_getc(s);
+		if (c != '>') { *err = "Error: reads file does not look like a FASTA file"; return -1; }
+		s->file_first = false;
+	} else if (s->feof && s->pos == s->end) return 0;
+	const size_t start = raw.size();
+	raw.push_back('>');
+	for (;;) {
+		if (s->pos == s->end && st_fill(s) == 0) break;
+		const char* b = s->buf.data() + s->pos;
+		const char* gt = (const char*)memchr(b, '>', s->end - s->pos);
+		const size_t take = gt ? (size_t)(gt - b) : s->end - s->pos;
+		raw.append(b, take);
+		s->pos += take;
+		if (gt) { s->pos++; return 1; }          /* the next record's '>' is consumed here */
+	}
+	/* EOF: a lone '>' is no record */
+	if (raw.size() == start + 1) { raw.resize(start); return 0; }
+	return 1;
+}
+
+static int light_raw(BtReadStream* s, std::string* err)
+{
+	(void)err;
+	std::string& raw = s->raw;
+	s->file_first = false;
+	int c = st_getc(s);
+	while (c == '\n' || c == '\r') c = st_getc(s);
+	if (c < 0) return 0;
+	while (c >= 0 && c != '\n' && c != '\r') { raw.push_back((char)c); c = st_getc(s); }
+	if (c == '\n') {
+		raw.push_back('\n');
+		if (st_peek(s) == '\r') { raw.push_back('\r'); s->pos++; }
+	}
+	return 1;
+}
+
+/* ---- per-record parse ---------------------------------------------------------------------- */
+struct BtParsed {
+	std::string seq, qual;      /* codes 0..4, Phred+33 */
+	size_t name_b = 0, name_n = 0;   /* name = rec[name_b, name_b + name_n), or the read id when empty */
+	bool ok = true;             /* false: the record ended prematurely -- the reference skips it */
+};
+
+static const uint8_t* asc2dna_table()
+{
+	static uint8_t t[256];
+	static bool init = false;
+	if (!init) {
+		memset(t, 4, sizeof(t));
+		t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
+		init = true;
+	}
+	return t;
+}
+
+/* solexaToPhred (qual.h:29-33): round(10 log10(10^(sol/10) + 1)) */
+static int solexa_to_phred(int sol)
+{
+	if (sol < -10) return 0;
+	return (int)(10.0 * log(1.0 + pow(10.0, sol / 10.0)) / log(10.0) + 0.5);
+}
+
+static bool qual_to_phred33(int c, int enc, char* out, std::string* err)
+{
+	char tmp[256];
+	if (c == ' ') {
+		*err = "Saw a space but expected an ASCII-encoded quality value.\n"
+		       "Are quality values formatted as integers?  If so, try --integer-quals.";
+		return false;
+	}
+	if (enc == BT_QUAL_SOLEXA64) {
+		const int cc = (int)(char)(solexa_to_phred(c - 64) + 33);
+		if (cc < 33) {
+			snprintf(tmp, sizeof(tmp), "Saw ASCII character %d but expected 64-based Solexa qual (converts to %d).\n"
+			         "Try not specifying --solexa-quals.", c, cc);
+			*err = tmp; return false;
+		}
+		c = cc;
+	} else if (enc == BT_QUAL_PHRED64) {
+		if (c < 64) {
+			snprintf(tmp, sizeof(tmp), "Saw ASCII character %d but expected 64-based Phred qual.\n"
+			         "Try not specifying --solexa1.3-quals/--phred64-quals.", c);
+			*err = tmp; return false;
+		}
+		c -= (64 - 33);
+	} else if (c < 33) {
+		snprintf(tmp, sizeof(tmp), "Saw ASCII character %d but expected 33-based Phred qual.", c);
+		*err = tmp; return false;
+	}
+	*out = (char)c;
+	return true;
+}
+
+static void trim_end(std::string& s, size_t n) { s.resize(n >= s.size() ? 0 : s.size() - n); }
+
+static std::string name_of(const char* rec, const BtParsed& p, uint64_t rdid)
+{
+	if (p.name_n) return std::string(rec + p.name_b, p.name_n);
+	char b[24]; snprintf(b, sizeof(b), "%llu", (unsigned long long)rdid);
+	return b;
+}
+
+static bool parse_fastq(const char* r, size_t n, const bt_read_opts& o, uint64_t rdid, BtParsed* p, std::string* err)
+{
+	const uint8_t* a2d = asc2dna_table();
+	size_t cur = 1;
+	int c = '\n';
+#define NEXT() ((cur < n) ? (unsigned char)r[cur++] : (cur++, '\n'))
+	p->name_b = 1;
+	for (;;) {
+		c = NEXT();
+		if (c == '\n' || c == '\r') {
+			do { c = NEXT(); } while ((c == '\n' || c == '\r') && cur < n);
+			break;
+		}
+		p->name_n++;
+	}
+	int nchar = 0;
+	while (c != '+' && cur < n) {
+		if (c == '.') c = 'N';
+		if (isalpha(c)) { if (nchar++ >= o.trim5) p->seq.push_back((char)a2d[c]); }
+		c = NEXT();
+	}
+	const size_t trimmed5 = (size_t)nchar - p->seq.size();
+	const size_t before = p->seq.size();
+	trim_end(p->seq, (size_t)o.trim3);
+	const size_t trimmed3 = before - p->seq.size();
+	if (c != '+') { *err = "Error: reads file does not look like a FASTQ file"; return false; }
+	do { c = NEXT(); } while (c != '\n' && c != '\r' && cur <= n);
+	while (cur < n && (c == '\n' || c == '\r')) c = NEXT();
+	size_t nqual = 0;
+	char q;
+	if (!qual_to_phred33(c, o.qual_enc, &q, err)) return false;
+	if (nqual++ >= trimmed5) p->qual.push_back(q);
+	while (cur < n) {
+		c = NEXT();
+		if (c == ' ') {
+			*err = "Encountered a space parsing the quality string for read " + name_of(r, *p, rdid) + "\n"
+			       "If this is a FASTQ file with integer (non-ASCII-encoded) qualities, please\n"
+			       "re-run Bowtie with the --integer-quals option.";
+			return false;
+		}
+		if (c == '\r' || c == '\n') break;
+		if (!qual_to_phred33(c, o.qual_enc, &q, err)) return false;
+		if (nqual++ >= trimmed5) p->qual.push_back(q);
+	}
+	trim_end(p->qual, trimmed3);
+	if (p->qual.size() < p->seq.size()) {
+		*err = "Too few quality values for read: " + name_of(r, *p, rdid) + "\n\tare you sure this is a FASTQ-int file?";
+		return false;
+	}
+	if (p->qual.size() > p->seq.size()) {
+		*err = "Reads file contained a pattern with more than 1024 quality values.\n"
+		       "Please truncate reads and quality values and and re-run Bowtie";
+		return false;
+	}
+#undef NEXT
+	return true;
+}
+
+static bool parse_fasta(const char* r, size_t n, const bt_read_opts& o, BtParsed* p)
+{
+	const uint8_t* a2d = asc2dna_table();
+	size_t cur = 1;
+	int c = -1;
+	p->name_b = 1;
+	while (cur < n) {
+		c = (unsigned char)r[cur++];
+		if (c == '\n' || c == '\r') {
+			do { c = (cur < n) ? (unsigned char)r[cur] : '\n'; cur++; } while ((c == '\n' || c == '\r') && cur < n);
+			break;
+		}
+		p->name_n++;
+	}
+	if (cur >= n) { p->ok = false; return true; }          /* "FASTA ended prematurely": the read is skipped */
+	int nchar = 0;
+	/* the first sequence line only; a final character that sits at the very end of the record
+	 * (no newline before EOF) is not consumed -- as in the reference */
+	while (c != '\n' && cur < n) {
+		if (c == '.') c = 'N';
+		if (isalpha(c)) { if (nchar++ >= o.trim5) p->seq.push_back((char)a2d[c]); }
+		c = (unsigned char)r[cur++];
+	}
+	trim_end(p->seq, (size_t)o.trim3);
+	p->qual.assign(p->seq.size(), 'I');
+	return true;
+}
+
+static bool parse_raw(const char* r, size_t n, const bt_read_opts& o, BtParsed* p)
+{
+	const uint8_t* a2d = asc2dna_table();
+	int nchar = 0;
+	for (size_t cur = 0; cur < n; cur++) {
+		const int c = (unsigned char)r[cur];
+		if (isalpha(c)) { if (nchar++ >= o.trim5) p->seq.push_back((char)a2d[c]); }
+	}
+	trim_end(p->seq, (size_t)o.trim3);
+	p->qual.assign(p->seq.size(), 'I');
+	p->name_n = 0;                                        /* name = read id */
+	return true;
+}
+
+/* -c: "SEQ" or "SEQ:QUALS"; qualities are always Phred+33 here (pat.cpp:502) */
+static bool parse_cmdline(const char* r, size_t n, const bt_read_opts& o, uint64_t rdid, BtParsed* p, std::string* err)
+{
+	const uint8_t* a2d = asc2dna_table();
+	const char* colon = (const char*)memchr(r, ':', n);
+	const size_t sl = colon ? (size_t)(colon - r) : n;
+	if (sl == 0) { p->ok = false; return true; }
+	int nchar = 0;
+	/* the token is walked up to, not including, its last character's successor; the reference's
+	 * buffer always has a tab after the sequence, so every character is seen */
+	for (size_t i = 0; i < sl; i++) {
+		const int c = (unsigned char)r[i];
+		if (isalpha(c)) { if (nchar++ >= o.trim5) p->seq.push_back((char)a2d[c]); }
+	}
+	trim_end(p->seq, (size_t)o.trim3);
+	int nqual = 0;
+	if (colon) {
+		for (size_t i = sl + 1; i < n; i++) {
+			const int c = (unsigned char)r[i];
+			if (c == '\t' || c == '\n' || c == '\r') break;
+			char q;
+			if (c == ' ') { *err = "Encountered a space parsing the quality string for read " + name_of(r, *p, rdid); return false; }
+			if (!qual_to_phred33(c, BT_QUAL_PHRED33, &q, err)) return false;
+			if (++nqual > o.trim5) p->qual.push_back(q);
+		}
+	} else {
+		/* default qualities are one 'I' per character of the token */
+		for (size_t i = 0; i < sl; i++) { if (++nqual > o.trim5) p->qual.push_back('I'); }
+	}
+	if (nchar > nqual) { *err = "Too few quality values for read: " + name_of(r, *p, rdid) + "\n\tare you sure this is a FASTQ-int file?"; return false; }
+	if (nqual > nchar) {
+		*err = "Reads file contained a pattern with more than 1024 quality values.\n"
+		       "Please truncate reads and quality values and and re-run Bowtie";
+		return false;
+	}
+	trim_end(p->qual, (size_t)o.trim3);
+	p->name_n = 0;
+	return true;
+}
+
+/* genRandSeed (pat.cpp:21-57) */
+static uint32_t rand_seed(const uint8_t* seq, const uint8_t* qual, size_t len, const char* name, size_t name_n, uint32_t seed)
+{
+	uint32_t r = (seed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+	for (size_t i = 0; i < len; i++) r ^= (uint32_t)seq[i] << ((i & 15u) << 1);
+	for (size_t i = 0; i < len; i++) r ^= (uint32_t)qual[i] << ((i & 3u) << 3);
+	for (size_t i = 0; i < name_n; i++) r ^= (uint32_t)(int)(signed char)name[i] << ((i & 3u) << 3);
+	return r;
+}
+
+int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
+{
+	s->raw.clear(); s->recs.clear();
+	batch->n = 0;
+	/* ---- light parse (sequential) ---- */
+	while (!s->done && s->recs.size() < max_reads) {
+		if (s->rdid >= s->limit) { s->done = true; break; }
+		if (s->o.format == BT_FMT_CMDLINE) {
+			if (s->item >= s->items.size()) { s->done = true; break; }
+			const std::string& it = s->items[s->item++];
+			const size_t off = s->raw.size();
+			s->raw.append(it);
+			if (s->rdid >= s->o.skip) s->recs.push_back({off, (uint32_t)it.size(), s->rdid});
+			else s->raw.resize(off);
+			s->rdid++;
+			continue;
+		}
+		if (!s->f && !st_open_next(s, err)) { s->done = true; break; }
+		const size_t off = s->raw.size();
+		int rc;
+		if (s->o.format == BT_FMT_FASTQ) rc = light_fastq(s, err);
+		else if (s->o.format == BT_FMT_FASTA) rc = light_fasta(s, err);
+		else rc = light_raw(s, err);
+		if (rc < 0) return BT_ERR_READS;
+		if (rc == 0) { gzclose(s->f); s->f = nullptr; continue; }
+		if (s->rdid >= s->o.skip) s->recs.push_back({off, (uint32_t)(s->raw.size() - off), s->rdid});
+		else s->raw.resize(off);                    /* skipped reads are never parsed */
+		s->rdid++;
+	}
+	const size_t nrec = s->recs.size();
+	if (nrec == 0) return BT_OK;
+
+	/* ---- per-record parse (parallel) ---- */
+	std::vector<BtParsed> parsed(nrec);
+	const int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+	std::vector<std::string> errs((size_t)T);
+	std::vector<size_t> err_at((size_t)T, (size_t)-1);
+	auto work = [&](int t) {
+		const size_t lo = nrec * (size_t)t / (size_t)T, hi = nrec * (size_t)(t + 1) / (size_t)T;
+		for (size_t i = lo; i < hi; i++) {
+			const BtRec& rc = s->recs[i];
+			const char* r = s->raw.data() + rc.off;
+			bool ok = true;
+			switch (s->o.format) {
+			case BT_FMT_FASTQ: ok = parse_fastq(r, rc.len, s->o, rc.rdid, &parsed[i], &errs[(size_t)t]); break;
+			case BT_FMT_FASTA: ok = parse_fasta(r, rc.len, s->o, &parsed[i]); break;
+			case BT_FMT_RAW: ok = parse_raw(r, rc.len, s->o, &parsed[i]); break;
+			default: ok = parse_cmdline(r, rc.len, s->o, rc.rdid, &parsed[i], &errs[(size_t)t]); break;
+			}
+			if (ok && parsed[i].seq.size() > 1024) {
+				errs[(size_t)t] = "Reads file contained a pattern with more than 1024 sequence characters.\n"
+				                  "Please truncate reads and quality values and and re-run Bowtie.\n"
+				                  "Offending read: " + name_of(r, parsed[i], rc.rdid);
+				ok = false;
+			}
+			if (!ok) { err_at[(size_t)t] = i; return; }
+		}
+	};
+	if (T == 1 || nrec < 4096) { for (int t = 0; t < T; t++) work(t); }
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(work, t);
+		for (auto& x : th) x.join();
+	}
+	size_t first_err = (size_t)-1; int et = -1;
+	for (int t = 0; t < T; t++) if (err_at[(size_t)t] < first_err) { first_err = err_at[(size_t)t]; et = t; }
+	if (et >= 0) { *err = errs[(size_t)et]; return BT_ERR_READS; }
+
+	/* ---- pack ---- */
+	std::vector<uint32_t> keep; keep.reserve(nrec);
+	size_t maxlen = 1;
+	for (size_t i = 0; i < nrec; i++) {
+		if (!parsed[i].ok) continue;
+		keep.push_back((uint32_t)i);
+		if (parsed[i].seq.size() > maxlen) maxlen = parsed[i].seq.size();
+	}
+	const uint32_t n = (uint32_t)keep.size();
+	const uint32_t stride = (uint32_t)((maxlen + 15u) & ~(size_t)15u);
+	batch->reset(n, stride);
+	batch->rdid.resize(n);
+	batch->name_off.assign((size_t)n + 1, 0);
+	batch->names.clear();
+	for (uint32_t k = 0; k < n; k++) {
+		const BtParsed& p = parsed[keep[k]];
+		const BtRec& rc = s->recs[keep[k]];
+		batch->name_off[k] = batch->names.size();
+		if (p.name_n) batch->names.append(s->raw.data() + rc.off + p.name_b, p.name_n);
+		else { char b[24]; snprintf(b, sizeof(b), "%llu", (unsigned long long)rc.rdid); batch->names.append(b); }
+		batch->rdid[k] = rc.rdid;
+	}
+	batch->name_off[n] = batch->names.size();
+	auto pack = [&](int t) {
+		const size_t lo = (size_t)n * (size_t)t / (size_t)T, hi = (size_t)n * (size_t)(t + 1) / (size_t)T;
+		for (size_t k = lo; k < hi; k++) {
+			const BtParsed& p = parsed[keep[k]];
+			uint8_t* sq = batch->seq + k * stride;
+			uint8_t* ql = batch->qual + k * stride;
+			const size_t L = p.seq.size();
+			memcpy(sq, p.seq.data(), L); memset(sq + L, 4, stride - L);
+			memcpy(ql, p.qual.data(), L); memset(ql + L, 33, stride - L);
+			batch->len[k] = (uint16_t)L;
+			batch->seed[k] = rand_seed(sq, ql, L, batch->names.data() + batch->name_off[k],
+			                           (size_t)(batch->name_off[k + 1] - batch->name_off[k]), s->o.seed);
+		}
+	};
+	if (T == 1 || n < 4096) { for (int t = 0; t < T; t++) pack(t); }
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(pack, t);
+		for (auto& x : th) x.join();
+	}
+	batch->first_rdid = n ? batch->rdid[0] : 0;
+	return BT_OK;
+}
+
+/* ---- output ---------------------------------------------------------------------------------- */
+static inline void put_u(std::string* o, uint64_t v)
+{
+	char b[24]; int n = 0;
+	do { b[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+	while (n) o->push_back(b[--n]);
+}
+static inline void put_ref(std::string* o, const BtRefNames& refs, uint32_t tidx, const bt_out_opts& op)
+{
+	if (!op.ref_idx && tidx < refs.names.size()) {
+		const std::string& nm = refs.names[tidx];
+		if (op.full_ref) o->append(nm);
+		else { size_t i = 0; while (i < nm.size() && !isspace((unsigned char)nm[i])) i++; o->append(nm, 0, i); }
+	} else put_u(o, tidx);
+}
+static inline void put_qname(std::string* o, const char* nm, size_t n, bool trunc)
+{
+	size_t i = 0;
+	if (trunc) { while (i < n && !isspace((unsigned char)nm[i])) i++; } else i = n;
+	o->append(nm, i);
+}
+/* the read as aligned: reverse-complemented / reversed for '-' hits (Hit::patSeq, Hit::quals) */
+static inline void put_seq(std::string* o, const uint8_t* seq, uint32_t L, bool fw)
+{
+	static const char fwc[] = "ACGTN", rcc[] = "TGCAN";
+	if (fw) for (uint32_t i = 0; i < L; i++) o->push_back(fwc[seq[i] > 4 ? 4 : seq[i]]);
+	else for (uint32_t i = L; i-- > 0;) o->push_back(rcc[seq[i] > 4 ? 4 : seq[i]]);
+}
+static inline void put_qual(std::string* o, const uint8_t* q, uint32_t L, bool fw)
+{
+	if (fw) o->append((const char*)q, L);
+	else for (uint32_t i = L; i-- > 0;) o->push_back((char)q[i]);
+}
+
+struct MmList { uint32_t n; uint16_t e[64]; };
+
+static void verbose_hit(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
+                        const bt_hit& h, const uint16_t* mm, uint32_t seed, const BtRefNames& refs, const bt_out_opts& op)
+{
+	uint32_t field = 0; bool first = true;
+#define FIELD(body) do { if (!((op.suppress >> field++) & 1ull)) { if (first) first = false; else o->push_back('\t'); body; } } while (0)
+	const bool fw = h.fw != 0;
+	FIELD(o->append(nm, nn));
+	FIELD(o->push_back(fw ? '+' : '-'));
+	FIELD(put_ref(o, refs, h.tidx, op));
+	FIELD(put_u(o, (uint64_t)((int64_t)h.toff + op.off_base)));
+	FIELD(put_seq(o, seq, L, fw));
+	FIELD(put_qual(o, qual, L, fw));
+	FIELD(put_u(o, h.oms));
+	auto put_mms = [&]() {
+		/* mismatches by ascending 5'-relative offset: pos:ref>read */
+		static const char dna[] = "ACGTN", rc[] = "TGCAN";
+		bool firstmm = true;
+		uint16_t sorted[64]; uint32_t n = h.nmm > 64 ? 64 : h.nmm;
+		for (uint32_t i = 0; i < n; i++) sorted[i] = mm[i];
+		for (uint32_t i = 1; i < n; i++) { uint16_t v = sorted[i]; uint32_t j = i; while (j > 0 && BT_MM_POS(sorted[j - 1]) > BT_MM_POS(v)) { sorted[j] = sorted[j - 1]; j--; } sorted[j] = v; }
+		for (uint32_t i = 0; i < n; i++) {
+			const uint32_t pos = BT_MM_POS(sorted[i]), refc = BT_MM_REFC(sorted[i]);
+			if (!firstmm) o->push_back(',');
+			put_u(o, pos);
+			o->push_back(':'); o->push_back(dna[refc]); o->push_back('>');
+			/* the read character as printed in the sequence column */
+			const uint8_t c = seq[pos] > 4 ? 4 : seq[pos];
+			o->push_back(fw ? dna[c] : rc[c]);
+			firstmm = false;
+		}
+	};
+	FIELD(put_mms());
+	if (op.print_cost) {
+		FIELD(put_u(o, h.stratum));
+		FIELD(put_u(o, h.cost));
+	}
+	if (op.show_seed) FIELD(put_u(o, seed));
+#undef FIELD
+	o->push_back('\n');
+}
+
+static void sam_hit(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
+                    const bt_hit& h, const uint16_t* mm, uint32_t xms, const BtRefNames& refs, const bt_out_opts& op)
+{
+	static const char dna[] = "ACGT";
+	const bool fw = h.fw != 0;
+	put_qname(o, nm, nn, !op.no_qname_trunc);
+	o->push_back('\t'); put_u(o, fw ? 0u : 16u);
+	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
+	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
+	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", op.mapq); o->append(b); }
+	o->push_back('\t'); put_u(o, L); o->append("M\t*\t0\t0\t");
+	put_seq(o, seq, L, fw);
+	o->push_back('\t');
+	put_qual(o, qual, L, fw);
+	o->append("\tXA:i:"); put_u(o, h.stratum);
+	o->append("\tMD:Z:");
+	/* MD walks the alignment left to right on the reference: by 5' offset for '+', by descending
+	 * offset for '-' */
+	uint16_t sorted[64]; uint32_t n = h.nmm > 64 ? 64 : h.nmm;
+	for (uint32_t i = 0; i < n; i++) sorted[i] = mm[i];
+	for (uint32_t i = 1; i < n; i++) { uint16_t v = sorted[i]; uint32_t j = i; while (j > 0 && BT_MM_POS(sorted[j - 1]) > BT_MM_POS(v)) { sorted[j] = sorted[j - 1]; j--; } sorted[j] = v; }
+	uint32_t run_from = 0;     /* alignment columns consumed so far */
+	for (uint32_t k = 0; k < n; k++) {
+		const uint16_t e = fw ? sorted[k] : sorted[n - 1 - k];
+		const uint32_t col = fw ? BT_MM_POS(e) : (L - 1u - BT_MM_POS(e));
+		put_u(o, col - run_from);
+		o->push_back(dna[BT_MM_REFC(e)]);
+		run_from = col + 1u;
+	}
+	put_u(o, L - run_from);
+	o->append("\tNM:i:"); put_u(o, n);
+	if (xms > 0) { o->append("\tXM:i:"); put_u(o, xms); }
+	o->push_back('\n');
+}
+
+static void sam_unaligned(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
+                          uint32_t xm, const bt_out_opts& op)
+{
+	put_qname(o, nm, nn, !op.no_qname_trunc);
+	o->append("\t4\t*\t0\t0\t*\t*\t0\t0\t");
+	put_seq(o, seq, L, true);
+	o->push_back('\t');
+	put_qual(o, qual, L, true);
+	o->append("\tXM:i:"); put_u(o, xm);
+	o->push_back('\n');
+}
+
+void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* name_off, const bt_hit_batch& hb,
+                  const BtRefNames& refs, const bt_out_opts& op, uint32_t lo, uint32_t hi, std::string* out,
+                  bt_out_tally* tally)
+{
+	const uint32_t lim = op.all_hits ? hb.hit_cap : (hb.hit_cap < op.khits ? hb.hit_cap : op.khits);
+	for (uint32_t i = lo; i < hi; i++) {
+		const uint32_t tot = hb.n_hits[i];
+		const uint8_t* seq = rb.seq + (size_t)i * rb.stride;
+		const uint8_t* qual = rb.qual + (size_t)i * rb.stride;
+		const uint32_t L = rb.len[i];
+		const char* nm = names + name_off[i];
+		const size_t nn = (size_t)(name_off[i + 1] - name_off[i]);
+		if (tot == 0) {
+			if (tally) tally->unaligned++;
+			if (op.sam && !op.no_unal) sam_unaligned(out, nm, nn, seq, qual, L, 0, op);
+			continue;
+		}
+		if (tot > op.mhits) {           /* over the -m ceiling: counted, nothing printed (hit.h:494-500) */
+			if (tally) tally->maxed++;
+			continue;
+		}
+		const uint32_t np = tot < lim ? tot : lim;
+		if (tally) { tally->aligned++; tally->reported += np; }
+		for (uint32_t k = 0; k < np; k++) {
+			const bt_hit& h = hb.hits[(size_t)i * hb.hit_cap + k];
+			const uint16_t* mm = hb.mm_pool ? hb.mm_pool + h.mm_off : nullptr;
+			if (op.sam) sam_hit(out, nm, nn, seq, qual, L, h, mm, np, refs, op);
+			else verbose_hit(out, nm, nn, seq, qual, L, h, mm, rb.seed[i], refs, op);
+		}
+	}
+}
+
+void bt_io_sam_header(const BtRefNames& refs, const bt_out_opts& op, const char* cmdline, const char* rgline,
+                      std::string* o)
+{
+	o->append("@HD\tVN:1.0\tSO:unsorted\n");
+	if (!op.sam_nosq) {
+		for (size_t i = 0; i < refs.lens.size(); i++) {
+			o->append("@SQ\tSN:");
+			put_ref(o, refs, (uint32_t)i, op);
+			o->append("\tLN:"); put_u(o, refs.lens[i]); o->push_back('\n');
+		}
+	}
+	if (rgline && *rgline) { o->append("@RG\t"); o->append(rgline); o->push_back('\n'); }
+	o->append("@PG\tID:Bowtie\tVN:1.3.1\tCL:\""); o->append(cmdline ? cmdline : ""); o->append("\"\n");
+}
+
+void bt_io_summary(const bt_out_tally& t, std::string* o)
+{
+	const uint64_t tot = t.aligned + t.unaligned + t.maxed;
+	double al = 0, un = 0, mx = 0;
+	if (tot) { al = 100.0 * (double)(t.aligned + t.maxed) / (double)tot; un = 100.0 * (double)t.unaligned / (double)tot; mx = 100.0 * (double)t.maxed / (double)tot; }
+	char b[256];
+	snprintf(b, sizeof(b), "# reads processed: %llu\n", (unsigned long long)tot); o->append(b);
+	snprintf(b, sizeof(b), "# reads with at least one alignment: %llu (%.2f%%)\n", (unsigned long long)(t.aligned + t.maxed), al); o->append(b);
+	snprintf(b, sizeof(b), "# reads that failed to align: %llu (%.2f%%)\n", (unsigned long long)t.unaligned, un); o->append(b);
+	if (t.maxed) { snprintf(b, sizeof(b), "# reads with alignments suppressed due to -m: %llu (%.2f%%)\n", (unsigned long long)t.maxed, mx); o->append(b); }
+	if (t.reported == 0) o->append("No alignments\n");
+	else { snprintf(b, sizeof(b), "Reported %llu alignments\n", (unsigned long long)t.reported); o->append(b); }
+}
+
+/* ---- C entry points (include/bowtie_amd.h) ---------------------------------------------------- */
+struct bt_reads {
+	BtReadStream* s = nullptr;
+	BtHostBatch batch;
+	std::string err;
+};
+
+extern "C" int bt_reads_open(const char* spec, const bt_read_opts* opts, bt_reads** out)
+{
+	if (!spec || !opts || !out) return BT_ERR_ARG;
+	if (opts->format < BT_FMT_FASTQ || opts->format > BT_FMT_CMDLINE || opts->trim5 < 0 || opts->trim3 < 0) return BT_ERR_ARG;
+	bt_reads* r = new bt_reads();
+	r->s = bt_io_open(spec, *opts, &r->err);
+	*out = r;
+	return BT_OK;
+}
+extern "C" int bt_reads_next(bt_reads* r, uint32_t max_reads, int threads, bt_read_batch* batch,
+                             const char** names, const uint64_t** name_off)
+{
+	if (!r || !batch || max_reads == 0) return BT_ERR_ARG;
+	r->err.clear();
+	const int rc = bt_io_next(r->s, max_reads, threads, &r->batch, &r->err);
+	if (rc != BT_OK) return rc;
+	*batch = r->batch.view();
+	if (names) *names = r->batch.names.data();
+	if (name_off) *name_off = r->batch.name_off.data();
+	return BT_OK;
+}
+extern "C" const char* bt_reads_error(const bt_reads* r) { return r ? r->err.c_str() : ""; }
+extern "C" void bt_reads_close(bt_reads* r)
+{
+	if (!r) return;
+	bt_io_close(r->s);
+	delete r;
+}
+
+static char* text_out(const std::string& s, size_t* len)
+{
+	char* t = (char*)malloc(s.size() + 1);
+	if (!t) return nullptr;
+	memcpy(t, s.data(), s.size()); t[s.size()] = 0;
+	if (len) *len = s.size();
+	return t;
+}
+static void refs_from(const char* const* refnames, const uint32_t* reflens, uint32_t n, BtRefNames* r)
+{
+	for (uint32_t i = 0; i < n; i++) { r->names.emplace_back(refnames && refnames[i] ? refnames[i] : ""); r->lens.push_back(reflens ? reflens[i] : 0); }
+}
+extern "C" int bt_format_hits(const bt_read_batch* reads, const char* names, const uint64_t* name_off,
+                              const bt_hit_batch* hits, const char* const* refnames, const uint32_t* reflens,
+                              uint32_t n_refs, const bt_out_opts* o, char** text, size_t* text_len, bt_out_tally* tally)
+{
+	if (!reads || !names || !name_off || !hits || !o || !text) return BT_ERR_ARG;
+	BtRefNames refs; refs_from(refnames, reflens, n_refs, &refs);
+	std::string s;
+	bt_io_format(*reads, names, name_off, *hits, refs, *o, 0, reads->n_reads, &s, tally);
+	*text = text_out(s, text_len);
+	return *text ? BT_OK : BT_ERR_IO;
+}
+extern "C" int bt_format_sam_header(const char* const* refnames, const uint32_t* reflens, uint32_t n_refs,
+                                    const bt_out_opts* o, const char* cmdline, const char* rgline,
+                                    char** text, size_t* text_len)
+{
+	if (!o || !text) return BT_ERR_ARG;
+	BtRefNames refs; refs_from(refnames, reflens, n_refs, &refs);
+	std::string s;
+	bt_io_sam_header(refs, *o, cmdline, rgline, &s);
+	*text = text_out(s, text_len);
+	return *text ? BT_OK : BT_ERR_IO;
+}
+extern "C" int bt_format_summary(const bt_out_tally* tally, char** text, size_t* text_len)
+{
+	if (!tally || !text) return BT_ERR_ARG;
+	std::string s;
+	bt_io_summary(*tally, &s);
+	*text = text_out(s, text_len);
+	return *text ? BT_OK : BT_ERR_IO;
+}
+extern "C" void bt_text_free(char* t) { free(t); }

@@ -1,0 +1,58 @@
+/*
+ * bt_io.h -- host I/O either side of the search path: read files in,
+ * SAM / default-format hit text out.  Plain host C++ (no HIP); the C entry points are declared in
+ * include/bowtie_amd.h.  Behaviour follows the reference's pattern sources and hit sinks; the
+ * citations are next to each function in bt_io.cpp.
+ */
+#ifndef BT_IO_H_
+#define BT_IO_H_
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bowtie_amd.h"
+
+/* one batch of parsed reads, laid out as bt_read_batch wants it (rows 16-byte aligned) */
+struct BtHostBatch {
+	uint32_t n = 0, stride = 16;
+	uint64_t first_rdid = 0;              /* rdid[0]                                             */
+	uint8_t* seq = nullptr;               /* [cap][stride] codes 0..4, rows padded with 4        */
+	uint8_t* qual = nullptr;              /* [cap][stride] Phred+33, rows padded with '!'        */
+	std::vector<uint16_t> len;
+	std::vector<uint32_t> seed;
+	std::vector<uint64_t> rdid;           /* TReadId of each read (names default to it)          */
+	std::vector<uint64_t> name_off;       /* n + 1 offsets into names                            */
+	std::string names;
+	size_t cap_bytes = 0;
+
+	BtHostBatch() {}
+	~BtHostBatch();
+	BtHostBatch(const BtHostBatch&) = delete;
+	BtHostBatch& operator=(const BtHostBatch&) = delete;
+	void reset(uint32_t n_reads, uint32_t stride_bytes);
+	bt_read_batch view() const;
+};
+
+/* a stream of reads over one or more files (or the -c sequences) */
+struct BtReadStream;
+BtReadStream* bt_io_open(const char* spec, const bt_read_opts& opts, std::string* err);
+/* next <= max_reads reads; returns BT_OK (batch.n == 0 at the end) or an error code with *err set */
+int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err);
+void bt_io_close(BtReadStream* s);
+
+struct BtRefNames {
+	std::vector<std::string> names;
+	std::vector<uint32_t> lens;
+};
+
+/* appends the text for reads [lo, hi) of the batch to `out` and adds to the tally */
+void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* name_off, const bt_hit_batch& hb,
+                  const BtRefNames& refs, const bt_out_opts& o, uint32_t lo, uint32_t hi, std::string* out,
+                  bt_out_tally* tally);
+void bt_io_sam_header(const BtRefNames& refs, const bt_out_opts& o, const char* cmdline, const char* rgline,
+                      std::string* out);
+void bt_io_summary(const bt_out_tally& t, std::string* out);
+
+#endif /* BT_IO_H_ */

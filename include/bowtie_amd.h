@@ -44,6 +44,8 @@ extern "C" {
 #define BT_ERR_OVERFLOW    6   /* a read exceeded a per-read scratch capacity (status bit
                                   BT_ST_OVERFLOW / BT_ST_MMPOOL says which reads); the other
                                   reads of the batch are valid                                */
+#define BT_ERR_READS       7   /* malformed read input (the reference prints a message and
+                                  exits 1; the message is in bt_reads_error())                */
 
 /* ---- policy: exactly the knobs the reference workers read -------------------------------- */
 #define BT_MODE_V 0            /* end-to-end, -v <mms>   (ebwt_search.cpp:3249-3268)          */
@@ -203,6 +205,76 @@ int bt_probe_rank(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uin
  * the hit straddles a fragment boundary. */
 int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t qlen,
                    uint32_t* joined_off, uint32_t* tidx, uint32_t* toff);
+
+
+/* ---- host I/O either side of the path --------------------------------
+ * Read files -> bt_read_batch, bt_hit_batch -> the reference's output text.  Host-only code in
+ * the same library; no GPU is needed to call these. */
+#define BT_FMT_FASTQ    0   /* -q (default)  FastqPatternSource        pat.cpp:797-975          */
+#define BT_FMT_FASTA    1   /* -f            FastaPatternSource        pat.cpp:531-640          */
+#define BT_FMT_RAW      2   /* -r            RawPatternSource          pat.cpp:1129-1213        */
+#define BT_FMT_CMDLINE  3   /* -c            VectorPatternSource       pat.cpp:359-528          */
+#define BT_QUAL_PHRED33  0  /* charToPhred33, qual.h:89-127                                      */
+#define BT_QUAL_PHRED64  1  /* --phred64-quals / --solexa1.3-quals                               */
+#define BT_QUAL_SOLEXA64 2  /* --solexa-quals                                                    */
+
+typedef struct bt_read_opts {
+	int32_t  format;       /* BT_FMT_*                                                        */
+	int32_t  trim5, trim3; /* -5 / -3                         pat.h TrimmingPatternSource      */
+	int32_t  qual_enc;     /* BT_QUAL_*                                                       */
+	uint32_t seed;         /* --seed: mixed into every read's seed (pat.cpp:21-57)            */
+	uint32_t reserved;
+	uint64_t skip;         /* -s: first reads to skip         pat.cpp:113-115                 */
+	uint64_t upto;         /* -u: reads to process after the skipped ones (0 = all)
+	                          ebwt_search.cpp:891-896, 937                                    */
+} bt_read_opts;
+
+typedef struct bt_reads bt_reads;
+/* spec: comma-separated file names ("-" = stdin, .gz read through zlib, pat.cpp:278-330), or the
+ * comma-separated sequences themselves for BT_FMT_CMDLINE ("SEQ" or "SEQ:QUALS") */
+int  bt_reads_open(const char* spec, const bt_read_opts* opts, bt_reads** out);
+/* parses the next <= max_reads reads with `threads` host threads; the batch (and the name
+ * table: names + name_off[n+1]) stays valid until the next call.  n_reads == 0 at the end.  On
+ * an input error returns BT_ERR_READS; bt_reads_error() then holds the reference's message. */
+int  bt_reads_next(bt_reads* r, uint32_t max_reads, int threads, bt_read_batch* batch,
+                   const char** names, const uint64_t** name_off);
+const char* bt_reads_error(const bt_reads* r);
+void bt_reads_close(bt_reads* r);
+
+typedef struct bt_out_opts {
+	int32_t  sam;            /* -S: SAMHitSink (sam.cpp) instead of VerboseHitSink (hit.cpp)   */
+	int32_t  full_ref;       /* --fullref: reference names not cut at the first whitespace     */
+	int32_t  ref_idx;        /* --refidx: print the reference's index, not its name            */
+	int32_t  off_base;       /* -B: added to offsets in the default format                     */
+	int32_t  print_cost;     /* --cost: stratum and cost columns (default format)              */
+	int32_t  show_seed;      /* --showseed: the read's seed column (default format)            */
+	int32_t  mapq;           /* --mapq (255)                                                   */
+	int32_t  no_qname_trunc; /* --sam-no-qname-trunc                                           */
+	int32_t  no_unal;        /* --no-unal                                                      */
+	int32_t  sam_nosq;       /* --sam-nosq (header only)                                       */
+	uint32_t khits, mhits;   /* -k / -m: finishRead's rules (hit.h:741-786)                    */
+	int32_t  all_hits;       /* -a                                                             */
+	int32_t  reserved;
+	uint64_t suppress;       /* --suppress: bit f set = 1-based column f+1 of the default
+	                            format is left out (hit.cpp:94-297)                            */
+} bt_out_opts;
+
+/* HitSink::finish's counters (hit.h:270-346) */
+typedef struct bt_out_tally { uint64_t aligned, unaligned, maxed, reported; } bt_out_tally;
+
+/* text of all reads of the batch, in read order; *text is malloc'ed (bt_text_free).  tally
+ * (optional) is added to. */
+int  bt_format_hits(const bt_read_batch* reads, const char* names, const uint64_t* name_off,
+                    const bt_hit_batch* hits, const char* const* refnames, const uint32_t* reflens,
+                    uint32_t n_refs, const bt_out_opts* o, char** text, size_t* text_len,
+                    bt_out_tally* tally);
+/* SAMHitSink::appendHeaders (sam.cpp:20-49) */
+int  bt_format_sam_header(const char* const* refnames, const uint32_t* reflens, uint32_t n_refs,
+                          const bt_out_opts* o, const char* cmdline, const char* rgline,
+                          char** text, size_t* text_len);
+/* HitSink::finish's stderr summary (hit.h:270-346), unpaired, no -M */
+int  bt_format_summary(const bt_out_tally* tally, char** text, size_t* text_len);
+void bt_text_free(char* text);
 
 #ifdef __cplusplus
 }

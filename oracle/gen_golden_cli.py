@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/cli/ -- TEST INFRASTRUCTURE, run in the build container (needs
+/root/reference and `make -C oracle ref`).  Pins the host I/O surface either side of the search
+path: read-file parsing (FASTQ / FASTA / raw / -c, trimming, -s/-u, quality
+encodings, gz, several files) and the reference's two output formats with their options.
+
+Every expected output here is the stdout/stderr of the *unmodified* reference binary
+(oracle/_ref/bowtie-align-s -p 1); the repo keeps the small input files made below, the outputs
+(gzip) and MANIFEST.json.  Paths in the commands are relative to tests/golden/.
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bowtie_amd.synth import synth_reads, write_fastq   # noqa: E402
+import oracle_lib as OL                                   # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+D = os.path.join(G, "cli")
+BIN = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
+
+
+def fastq_records(path, n):
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    return [lines[4 * i:4 * i + 4] for i in range(n)]
+
+
+def make_inputs():
+    os.makedirs(D, exist_ok=True)
+    recs = fastq_records(os.path.join(G, "e_coli_1000.fq"), 120)
+    # edge cases of the FASTQ parser, each on a read that still aligns somewhere
+    recs[3][0] = b"@r3 extra words\tand a tab"
+    recs[5][0] = b"@"                                             # empty name -> the read id
+    recs[7][1] = recs[7][1][:10].lower() + b"." + recs[7][1][11:]   # lower case, '.' -> N
+    recs[9][1] = recs[9][1][:5] + b"-*" + recs[9][1][5:]          # non-alphabetic characters are dropped
+    recs[11][1] = recs[11][1][:20] + b"RYK" + recs[11][1][23:]    # IUPAC codes -> N
+    recs[13] = [x + b"\r" for x in recs[13]]                      # CRLF record
+    recs[14][2] = b"+" + recs[14][0][1:]                          # '+' line repeats the name
+    body = b"\n\n" + b"\n".join(b"\n".join(r) for r in recs)       # leading blank lines; no final newline
+    with open(os.path.join(D, "io.fq"), "wb") as f:
+        f.write(body)
+    with gzip.GzipFile(os.path.join(D, "io.fq.gz"), "wb", mtime=0) as f:
+        f.write(b"\n".join(b"\n".join(r) for r in recs[:40]) + b"\n")
+    # phred+64 and solexa-scaled copies of the first 50 reads
+    plain = fastq_records(os.path.join(G, "e_coli_1000.fq"), 50)
+    with open(os.path.join(D, "io64.fq"), "wb") as f:
+        for r in plain:
+            f.write(b"\n".join([r[0], r[1], r[2], bytes(q + 31 for q in r[3])]) + b"\n")
+    rng = np.random.default_rng(64)
+    with open(os.path.join(D, "iosol.fq"), "wb") as f:
+        for r in plain:
+            sol = rng.integers(-5, 41, size=len(r[1]))
+            f.write(b"\n".join([r[0], r[1], r[2], bytes(int(64 + s) for s in sol)]) + b"\n")
+    # FASTA: one-line records, a two-line record (only its first line is read), an empty name,
+    # blank lines after a name, and a last record without a final newline (loses its last base)
+    with open(os.path.join(D, "io.fa"), "wb") as f:
+        f.write(b"\n")
+        for i, r in enumerate(plain[:40]):
+            name = b"" if i == 4 else r[0][1:] + (b" desc" if i == 2 else b"")
+            seq = r[1]
+            if i == 6:
+                seq = seq[:18] + b"\n" + seq[18:]
+            if i == 8:
+                f.write(b">" + name + b"\n\n" + seq + b"\n")
+                continue
+            f.write(b">" + name + b"\n" + seq + (b"" if i == 39 else b"\n"))
+    # raw: one sequence per line, blank lines, a CRLF line
+    with open(os.path.join(D, "io.raw"), "wb") as f:
+        f.write(b"\n")
+        for i, r in enumerate(plain[:40]):
+            f.write(r[1] + (b"\r\n" if i == 3 else b"\n") + (b"\n" if i == 5 else b""))
+    # reads for the multi-sequence index (names with a space; repeats -> many hits)
+    oi = OL.OracleIndex(os.path.join(G, "multi"))
+    text = oi.joined_text()
+    b = synth_reads(text, 150, 50, mm_dist=(0, 0, 1, 2), seed=515)
+    b.names = [nm + (b" lane 3" if i % 7 == 0 else b"") for i, nm in enumerate(b.names)]
+    write_fastq(b, os.path.join(D, "multi.fq"))
+    return plain
+
+
+def cases(plain):
+    cseq = ",".join([plain[0][1].decode(), plain[1][1].decode() + ":" + plain[1][3].decode(),
+                     plain[2][1][:30].decode(), "ACGTTGCANNACGT" + plain[3][1][:20].decode()])
+    E, M = "e_coli", "multi"
+    return [
+        ("fq_default", E, ["-n", "2"], "cli/io.fq"),
+        ("fq_sam_head", E, ["-S", "-n", "2"], "cli/io.fq"),
+        ("fq_v2_a_suppress", E, ["-v", "2", "-a", "--suppress", "1,5,6"], "cli/io.fq"),
+        ("fq_refidx_B1_k3", E, ["-v", "1", "-k", "3", "--refidx", "-B", "1"], "cli/io.fq"),
+        ("fq_cost_showseed_seed", E, ["-n", "1", "--cost", "--showseed", "--seed", "7"], "cli/io.fq"),
+        ("fq_trim", E, ["-5", "3", "-3", "2", "-v", "2"], "cli/io.fq"),
+        ("fq_trim_sam", E, ["-5", "1", "-3", "4", "-n", "2", "-S", "--sam-nohead"], "cli/io.fq"),
+        ("fq_skip_upto", E, ["-s", "10", "-u", "50", "-S", "--sam-nohead"], "cli/io.fq"),
+        ("fq_gz_two_files", E, ["-v", "0", "-S", "--sam-nohead"], "cli/io.fq.gz,cli/io.fq"),
+        ("fq_sam_opts", E, ["-S", "--sam-RG", "ID:grp1", "--sam-RG", "SM:x", "--mapq", "30", "--no-unal"], "cli/io.fq"),
+        ("fq_sam_nosq_refidx", E, ["-S", "--sam-nosq", "--refidx", "-v", "1"], "cli/io.fq"),
+        ("fq_tryhard_nofw", E, ["-y", "--nofw", "-n", "3", "-e", "120"], "cli/io.fq"),
+        ("fq_maxbts_norc_offrate", E, ["--maxbts", "20", "--norc", "-o", "7", "-n", "2", "-l", "20"], "cli/io.fq"),
+        ("fa_default", E, ["-f", "-v", "2"], "cli/io.fa"),
+        ("fa_sam", E, ["-f", "-S", "--sam-nohead", "-n", "3"], "cli/io.fa"),
+        ("fa_trim", E, ["-f", "-5", "2", "-3", "3", "-v", "1", "-S", "--sam-nohead"], "cli/io.fa"),
+        ("raw_default", E, ["-r", "-v", "1"], "cli/io.raw"),
+        ("raw_sam", E, ["-r", "-S", "--sam-nohead", "-s", "2"], "cli/io.raw"),
+        ("cmdline", E, ["-c", "-v", "2"], cseq),
+        ("cmdline_sam_trim", E, ["-c", "-S", "--sam-nohead", "-5", "2", "-n", "2"], cseq),
+        ("phred64", E, ["--phred64-quals", "-n", "2", "-S", "--sam-nohead"], "cli/io64.fq"),
+        ("solexa", E, ["--solexa-quals", "-n", "2", "-S", "--sam-nohead"], "cli/iosol.fq"),
+        ("multi_default_fullref", M, ["--fullref", "-v", "2", "-k", "4"], "cli/multi.fq"),
+        ("multi_sam_notrunc", M, ["-S", "--sam-no-qname-trunc", "-n", "2", "-k", "2"], "cli/multi.fq"),
+        ("multi_sam_fullref", M, ["-S", "--fullref", "-v", "1"], "cli/multi.fq"),
+        ("multi_all_m3", M, ["-a", "-m", "3", "-v", "2", "-S", "--sam-nohead"], "cli/multi.fq"),
+        ("multi_all", M, ["-a", "-v", "2"], "cli/multi.fq"),
+        ("multi_k2_m5", M, ["-k", "2", "-m", "5", "-n", "1"], "cli/multi.fq"),
+    ]
+
+
+def main():
+    plain = make_inputs()
+    manifest = {"reference": "BenLangmead/bowtie v1.3.1", "cwd": "tests/golden", "cases": []}
+    for name, idx, args, reads in cases(plain):
+        cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", idx, reads]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=G)
+        entry = {"name": name, "index": idx, "args": args, "reads": reads, "returncode": p.returncode,
+                 "stderr": p.stderr.decode(errors="replace").strip().split("\n"),
+                 "md5": hashlib.md5(p.stdout).hexdigest(), "file": "cli/%s.out.gz" % name}
+        with gzip.GzipFile(os.path.join(G, entry["file"]), "wb", mtime=0) as f:
+            f.write(p.stdout)
+        manifest["cases"].append(entry)
+        print(name, p.returncode, len(p.stdout), entry["stderr"][-1])
+    with open(os.path.join(D, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""The bowtie-amd binary (bowtie_amd/csrc/bt_cli.cpp: C++ host over the C ABI, search on the GPU) end
+to end against the unmodified reference's stdout/stderr on the host-I/O cases of tests/golden/cli:
+same command lines, byte-identical output."""
+import os
+import subprocess
+
+import pytest
+
+import cli_cases as CC
+import common as T
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
+
+
+def run(args, index, reads, extra=()):
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + list(extra) + list(args) + ["-x", index, reads]
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
+
+
+def split_pg(text: bytes):
+    lines = text.split(b"\n")
+    pg = [l for l in lines if l.startswith(b"@PG")]
+    return [l for l in lines if not l.startswith(b"@PG")], pg
+
+
+def summary_lines(stderr: bytes):
+    return [l for l in stderr.decode(errors="replace").strip().split("\n")
+            if l.startswith("#") or l.startswith("Reported") or l.startswith("No align")]
+
+
+@pytest.mark.parametrize("case", CC.cases(), ids=lambda c: c["name"])
+def test_cli_matches_reference(case):
+    assert os.path.exists(BIN), "bowtie-amd is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    p = run(case["args"], case["index"], case["reads"])
+    assert p.returncode == 0, p.stderr.decode(errors="replace")
+    want = CC.expected(case)
+    got_body, got_pg = split_pg(p.stdout)
+    want_body, want_pg = split_pg(want)
+    assert got_body == want_body
+    assert len(got_pg) == len(want_pg)
+    for l in got_pg:
+        assert l.startswith(b'@PG\tID:Bowtie\tVN:1.3.1\tCL:"')
+    assert summary_lines(p.stderr) == summary_lines("\n".join(case["stderr"]).encode())
+
+
+@pytest.mark.parametrize("name", ["fq_default", "multi_all", "multi_sam_notrunc", "fq_gz_two_files", "multi_all_m3"])
+def test_cli_small_batches_and_threads_do_not_change_output(name):
+    """Many tiny GPU batches, several host threads: same bytes (batches concatenate in read order;
+    -a reads with more hits than the first pass had slots for take the second pass)."""
+    case = [c for c in CC.cases() if c["name"] == name][0]
+    p = run(case["args"], case["index"], case["reads"], extra=["--batch", "37", "-p", "3"])
+    assert p.returncode == 0, p.stderr.decode(errors="replace")
+    assert split_pg(p.stdout)[0] == split_pg(CC.expected(case))[0]
+    assert summary_lines(p.stderr) == summary_lines("\n".join(case["stderr"]).encode())
+
+
+def test_cli_output_file_and_quiet(tmp_path):
+    case = [c for c in CC.cases() if c["name"] == "fq_default"][0]
+    out = tmp_path / "hits.txt"
+    cmd = [BIN, "--quiet"] + case["args"] + ["-x", case["index"], case["reads"], str(out)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
+    assert p.returncode == 0 and p.stdout == b"" and p.stderr == b""
+    assert out.read_bytes() == CC.expected(case)
+
+
+@pytest.mark.parametrize("args,reads,msg", [
+    (["-c", "-v", "2"], "ACGTACGTACGTACGTACGT,ACG", "Error: Read (1) is less than 4 characters long"),
+    (["-c", "-v", "1"], "A", "Error: Reads must be at least 2 characters long in 1-mismatch mode"),
+    (["--best"], "cli/io.fq", "best-first"),
+    (["-v", "3"], "cli/io.fq", "best-first"),
+    (["-1", "a.fq", "-2", "b.fq"], "cli/io.fq", "does not have"),
+])
+def test_cli_errors(args, reads, msg):
+    p = run(args, "e_coli", reads)
+    assert p.returncode == 1
+    assert msg in p.stderr.decode(errors="replace")
+
+
+def test_cli_missing_index():
+    p = run(["-v", "0"], "no_such_index", "cli/io.fq")
+    assert p.returncode == 1 and "Could not locate a Bowtie index" in p.stderr.decode()

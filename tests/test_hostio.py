@@ -1,0 +1,92 @@
+"""Host I/O either side of the search path (bowtie_amd/csrc/bt_io.cpp through the C ABI): the C++
+read parsers and output formatters against the unmodified reference's own outputs
+(tests/golden/cli).  The search in the middle is done by the oracle here -- no GPU needed; the GPU
+twin of these tests (test_gpu_cli.py) runs the bowtie-amd binary on the same cases."""
+import os
+
+import numpy as np
+import pytest
+
+import cli_cases as CC
+import common as T
+from bowtie_amd import hostio as H
+from bowtie_amd.reads import pack_reads, parse_fastq
+
+
+def run_case(case):
+    rd, pol, out, ex = CC.interpret(case["args"])
+    batch = H.read_all(CC.reads_spec(case), **rd)
+    oi = T.oracle_index(case["index"])
+    cap = 1024 if pol.get("all_hits") else pol.get("khits", 1)
+    per = T.oracle_results(case["index"], batch, pol, cap=cap)
+    hits, nh, st, pool = H.pack_hits(per, cap)
+    opts = H.out_opts(**out)
+    text, tally = H.format_hits(batch, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    return batch, text, tally, opts, ex, oi
+
+
+@pytest.mark.parametrize("case", CC.cases(), ids=lambda c: c["name"])
+def test_parse_and_format_match_reference(case):
+    want = CC.expected(case)
+    batch, text, tally, opts, ex, oi = run_case(case)
+    if opts.sam and not ex["sam_nohead"]:
+        # the @PG line quotes the command line: take the reference's own
+        head = [l for l in want.split(b"\n") if l.startswith(b"@")]
+        cl = head[-1].split(b'CL:"', 1)[1][:-1].decode()
+        text = H.sam_header(oi.refnames, oi.reflens, opts, cl, "\t".join(ex["rg"]) or None) + text
+    if text != want:
+        g, w = text.split(b"\n"), want.split(b"\n")
+        for i, (a, b) in enumerate(zip(g, w)):
+            assert a == b, "%s: line %d" % (case["name"], i)
+        assert len(g) == len(w), case["name"]
+    got_summary = H.summary(tally).strip().split("\n")
+    assert got_summary == [l for l in case["stderr"] if l.startswith("#") or l.startswith("Reported") or l.startswith("No align")]
+
+
+def test_fastq_parser_equals_python_reference_reader():
+    b = H.read_all(os.path.join(T.G, "e_coli_1000.fq"), threads=3)
+    p = pack_reads(parse_fastq(os.path.join(T.G, "e_coli_1000.fq")))
+    assert b.n == p.n == 1000 and b.stride == p.stride
+    assert (b.seq == p.seq).all() and (b.qual == p.qual).all() and (b.len == p.len).all()
+    assert (b.seed == p.seed).all() and b.names == p.names
+
+
+def test_batches_concatenate_and_ids_continue(tmp_path):
+    """Small batches give the same reads as one large one; default names keep counting across batches and files."""
+    spec = os.path.join(CC.D, "io.raw") + "," + os.path.join(CC.D, "io.raw")
+    whole = H.read_all(spec, fmt="raw")
+    parts = list(H.read_batches(spec, fmt="raw", max_reads=7))
+    assert sum(x.n for x in parts) == whole.n == 80
+    names = [nm for x in parts for nm in x.names]
+    assert names == whole.names == [str(i).encode() for i in range(80)]
+    assert np.concatenate([x.seed for x in parts]).tolist() == whole.seed.tolist()
+
+
+@pytest.mark.parametrize("body,fmt,kw,msg", [
+    (b"ACGT\n", "fastq", {}, "does not look like a FASTQ file"),
+    (b"ACGT\n", "fasta", {}, "does not look like a FASTA file"),
+    (b"@r\nACGT\n+\nII I\n", "fastq", {}, "Encountered a space"),
+    (b"@r\nACGT\n+\nIII\n", "fastq", {}, "Too few quality values"),
+    (b"@r\nACGT\n+\nIIIII\n", "fastq", {}, "more than 1024 quality values"),
+    (b"@r\nACGT\n+\nII#\x1f\n", "fastq", {}, "expected 33-based Phred qual"),
+    (b"@r\nACGT\n+\nII5I\n", "fastq", dict(quals="phred64"), "expected 64-based Phred qual"),
+])
+def test_malformed_input_reports_the_reference_message(tmp_path, body, fmt, kw, msg):
+    p = tmp_path / "bad.txt"
+    p.write_bytes(body)
+    with pytest.raises(H.ReadInputError, match=msg):
+        H.read_all(str(p), fmt=fmt, **kw)
+
+
+def test_truncated_fastq_record_is_dropped(tmp_path):
+    p = tmp_path / "t.fq"
+    p.write_bytes(b"@a\nACGT\n+\nIIII\n@b\nACG")
+    b = H.read_all(str(p))
+    assert b.n == 1 and b.names == [b"a"]
+
+
+def test_empty_inputs(tmp_path):
+    p = tmp_path / "e.fa"
+    p.write_bytes(b"")
+    assert H.read_all(str(p), fmt="fasta") is None
+    assert H.read_all(str(p), fmt="raw") is None
