@@ -11,6 +11,7 @@
  * that of the reference run with -p 1.  Everything the search does happens behind the C ABI; this
  * file holds no alignment logic and has no CPU search path.
  */
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -39,10 +40,10 @@ struct Options {
 	bt_out_opts out;
 	std::string index, reads, hits_file, rg_id;
 	std::vector<std::string> rg_fields;
-	int threads = 1, offrate = -1, device = 0;
+	int threads = 1, offrate = -1, device = 0, inflight = 2;
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false;
 	bool suppress_set = false;
-	uint32_t batch_reads = 8u << 20;
+	uint32_t batch_reads = 4u << 20;
 	std::string cmdline;
 };
 
@@ -111,7 +112,8 @@ void usage(FILE* o)
 	    "  -o/--offrate <int> override offrate of index; must be >= index's offrate\n"
 	    "  -p/--threads <int> number of host threads for parsing and formatting (default: 1)\n"
 	    "  --device <int>     GPU to run on (default: 0)\n"
-	    "  --batch <int>      reads per GPU batch (default: 8388608)\n"
+	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
+	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
 	    "Other:\n"
 	    "  --seed <int>       seed for random number generator\n"
 	    "  --version          print version information and quit\n"
@@ -133,7 +135,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_DEVICE, O_BATCH, O_WRAPPER, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -144,7 +146,7 @@ const LongOpt LONGS[] = {
 	{"usage", 0, O_USAGE}, {"sam", 0, 'S'}, {"sam-no-qname-trunc", 0, O_SAM_NOTRUNC}, {"sam-nohead", 0, O_SAM_NOHEAD},
 	{"sam-nosq", 0, O_SAM_NOSQ}, {"sam-noSQ", 0, O_SAM_NOSQ}, {"sam-RG", 1, O_SAM_RG}, {"suppress", 1, O_SUPPRESS}, {"mapq", 1, O_MAPQ},
 	{"cost", 0, O_COST}, {"showseed", 0, O_SHOWSEED}, {"no-unal", 0, O_NO_UNAL}, {"quiet", 0, O_QUIET}, {"device", 1, O_DEVICE},
-	{"batch", 1, O_BATCH}, {"wrapper", 1, O_WRAPPER},
+	{"batch", 1, O_BATCH}, {"inflight", 1, O_INFLIGHT}, {"wrapper", 1, O_WRAPPER},
 	/* accepted and without effect here (host-memory / CPU-threading knobs of the reference) */
 	{"reads-per-batch", 1, O_IGNORED_ARG}, {"chunkmbs", 1, O_IGNORED_ARG}, {"chunksz", 1, O_IGNORED_ARG}, {"chunkverbose", 0, O_IGNORED},
 	{"verbose", 0, O_IGNORED}, {"startverbose", 0, O_IGNORED}, {"sanity", 0, O_IGNORED}, {"reorder", 0, O_IGNORED},
@@ -265,6 +267,7 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_SHOWSEED: O->out.show_seed = 1; break;
 		case O_DEVICE: O->device = (int)parse_int(val, 0, "--device arg must be at least 0"); break;
 		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
+		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
 		case O_VERSION: printf("bowtie-amd (%s), output-compatible with bowtie-align-s version 1.3.1\n", bt_version()); exit(0);
 		case O_SAM_RG: {
@@ -352,6 +355,7 @@ struct Job {
 	struct Wide { uint32_t read; uint32_t hit_cap; std::vector<bt_hit> hits; std::vector<uint16_t> pool; uint32_t n_hits; uint8_t status; };
 	std::vector<Wide> wide;
 	bool last = false;
+	uint64_t seq = 0;                        /* position in the input: the writer restores this order */
 	std::string error;
 };
 
@@ -360,6 +364,8 @@ public:
 	explicit Chan(size_t cap) : cap_(cap) {}
 	void put(T v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
 	T take() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); T v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return v; }
+	bool try_take(T* v) { std::unique_lock<std::mutex> l(m_); if (q_.empty()) return false; *v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return true; }
+	bool try_put(T& v) { std::unique_lock<std::mutex> l(m_); if (q_.size() >= cap_) return false; q_.push_back(std::move(v)); cv_.notify_all(); return true; }
 private:
 	std::mutex m_; std::condition_variable cv_; std::deque<T> q_; size_t cap_;
 };
@@ -494,9 +500,11 @@ int main(int argc, char** argv)
 	bt_index_info_get(idx, &info);
 	BtRefNames refs;
 	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
-	bt_ctx* ctx = nullptr;
-	rc = bt_ctx_create(idx, &O.pol, nullptr, &ctx);
-	if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+	std::vector<bt_ctx*> ctxs((size_t)O.inflight, nullptr);
+	for (auto& c : ctxs) {
+		rc = bt_ctx_create(idx, &O.pol, nullptr, &c);
+		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+	}
 
 	/* ---- output ---- */
 	FILE* fout = stdout;
@@ -514,17 +522,35 @@ int main(int argc, char** argv)
 	/* ---- stage 1: reader ---- */
 	std::string open_err;
 	BtReadStream* rs = bt_io_open(O.reads.c_str(), O.rd, &open_err);
-	Chan<std::unique_ptr<Job>> to_gpu(2), to_out(2);
+	const int G = O.inflight;
+	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
+	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
 	const int T = O.threads;
+	double busy_read = 0, busy_write = 0;
+	std::vector<double> busy_gpu((size_t)G, 0.0);
+	std::atomic<bool> abort_run(false);
 	std::thread reader([&] {
+		uint64_t seq = 0;
 		for (;;) {
 			std::unique_ptr<Job> j(new Job());
-			j->store.reset(new BtHostBatch());
+			j->seq = seq++;
+			if (!spare.try_take(&j->store)) j->store.reset(new BtHostBatch());
 			std::string err;
-			const int r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
-			if (r != BT_OK) { j->error = err; j->last = true; to_gpu.put(std::move(j)); return; }
+			const double tb = now_s();
+			int r = BT_OK;
+			if (abort_run.load()) j->store->n = 0;
+			else r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
+			busy_read += now_s() - tb;
+			if (r != BT_OK) j->error = err;
 			j->rb = j->store->view();
-			if (j->rb.n_reads == 0) { j->last = true; to_gpu.put(std::move(j)); return; }
+			if (r != BT_OK || j->rb.n_reads == 0) {
+				/* the end (or an input error, reported in its place in the order): one marker per searcher */
+				j->last = true;
+				const uint64_t sq = j->seq;
+				to_gpu.put(std::move(j));
+				for (int g = 1; g < G; g++) { std::unique_ptr<Job> e(new Job()); e->last = true; e->seq = sq + (uint64_t)g; to_gpu.put(std::move(e)); }
+				return;
+			}
 			to_gpu.put(std::move(j));
 		}
 	});
@@ -533,10 +559,22 @@ int main(int argc, char** argv)
 	bt_out_tally tally = {0, 0, 0, 0};
 	std::string fatal;
 	std::thread writer([&] {
+		std::vector<std::unique_ptr<Job>> held;              /* finished out of turn */
+		uint64_t next_seq = 0; int lasts = 0;
 		for (;;) {
-			std::unique_ptr<Job> j = to_out.take();
-			if (!j->error.empty()) { fatal = j->error; return; }
-			if (j->last) return;
+			std::unique_ptr<Job> j;
+			for (size_t h = 0; h < held.size(); h++) if (held[h]->seq == next_seq) { j = std::move(held[h]); held.erase(held.begin() + (long)h); break; }
+			if (!j) {
+				if (lasts == G && held.empty()) return;
+				std::unique_ptr<Job> in = to_out.take();
+				if (in->seq != next_seq) { held.push_back(std::move(in)); continue; }
+				j = std::move(in);
+			}
+			next_seq++;
+			if (!j->error.empty() && fatal.empty()) { fatal = j->error; abort_run.store(true); }
+			if (j->last) { if (++lasts == G && held.empty()) return; continue; }
+			if (!fatal.empty()) continue;
+			const double tb = now_s();
 			const uint32_t n = j->rb.n_reads;
 			bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), j->mm_used };
 			const char* names = j->store->names.data();
@@ -583,32 +621,40 @@ int main(int argc, char** argv)
 				fwrite(parts[si].data(), 1, parts[si].size(), fout);
 				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
 			}
+			busy_write += now_s() - tb;
+			j->wide.clear();
+			spare.try_put(j->store);
 		}
 	});
 
-	/* ---- stage 2: the GPU ---- */
+	/* ---- stage 2: the GPU.  Each searcher owns a context (its own stream and scratch); with two, one
+	 * batch's long-running stragglers finish while the next batch already fills the machine ---- */
 	const double t_search = now_s();
-	std::string stop_msg;
-	for (;;) {
-		std::unique_ptr<Job> j = to_gpu.take();
-		if (j->last) { to_out.put(std::move(j)); break; }
-		stop_msg = search_job(ctx, O, j.get());
-		if (!stop_msg.empty()) {
-			j->error = stop_msg; j->last = true;
+	std::vector<std::thread> searchers;
+	for (int g = 0; g < G; g++) searchers.emplace_back([&, g] {
+		for (;;) {
+			std::unique_ptr<Job> j = to_gpu.take();
+			if (j->last) { to_out.put(std::move(j)); return; }
+			if (!abort_run.load()) {
+				const double tb = now_s();
+				j->error = search_job(ctxs[(size_t)g], O, j.get());
+				busy_gpu[(size_t)g] += now_s() - tb;
+			}
 			to_out.put(std::move(j));
-			/* let the reader run to its end so that it can be joined */
-			for (;;) { std::unique_ptr<Job> r = to_gpu.take(); if (r->last) break; }
-			break;
 		}
-		to_out.put(std::move(j));
-	}
+	});
+	for (auto& x : searchers) x.join();
 	reader.join();
 	writer.join();
-	if (O.timing) print_timer("Time searching: ", now_s() - t_search);
+	if (O.timing) {
+		print_timer("Time searching: ", now_s() - t_search);
+		double bg = 0; for (double v : busy_gpu) bg += v;
+		fprintf(stderr, "Stage busy time (s): read+parse %.2f, search (GPU, incl. PCIe; %d in flight) %.2f, format+write %.2f\n", busy_read, G, bg, busy_write);
+	}
 	fflush(fout);
 	if (fout != stdout) fclose(fout);
 	bt_io_close(rs);
-	bt_ctx_destroy(ctx);
+	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
 	bt_index_free(idx);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }

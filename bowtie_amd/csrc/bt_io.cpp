@@ -88,7 +88,7 @@ static inline int st_peek(BtReadStream* s)
 	return (unsigned char)s->buf[s->pos];
 }
 
-static bool st_open_next(BtReadStream* s, std::string* err)
+static bool st_open_next(BtReadStream* s, std::string* err, bool keep_window = false)
 {
 	if (s->f) { gzclose(s->f); s->f = nullptr; }
 	if (s->item >= s->items.size()) return false;
@@ -100,10 +100,11 @@ static bool st_open_next(BtReadStream* s, std::string* err)
 		*err = "Warning: Could not open read file \"" + fn + "\" for reading; skipping...";
 		fprintf(stderr, "%s\n", err->c_str());
 		err->clear();
-		return st_open_next(s, err);
+		return st_open_next(s, err, keep_window);
 	}
 	gzbuffer(s->f, 1u << 20);
-	s->file_first = true; s->feof = false; s->pos = s->end = 0;
+	s->file_first = true; s->feof = false;
+	if (!keep_window) s->pos = s->end = 0;
 	return true;
 }
 
@@ -432,10 +433,183 @@ static uint32_t rand_seed(const uint8_t* seq, const uint8_t* qual, size_t len, c
 	return r;
 }
 
+/* ---- FASTQ, the format that matters for throughput -------------------------------------------
+ * The file is read in large pieces into one window; a batch's records are spans of that window
+ * (found by counting newlines, the reference's light parse), and the host threads turn them
+ * straight into rows of the batch.  A record of the everyday shape -- no '\r', a name, only
+ * letters or '.' on the sequence line, a '+' line, as many quality characters as bases, all of
+ * them valid for the encoding -- takes a short loop; anything else goes through parse_fastq
+ * above, which follows the reference's parser step by step (and produces its error messages). */
+struct FqRec { size_t off; uint32_t e[4]; uint64_t rdid; };   /* e[k]: offset of line k's '\n' from off */
+
+static bool fq_more(BtReadStream* s)
+{
+	if (s->feof || !s->f) return false;
+	if (s->buf.size() - s->end < (16u << 20)) s->buf.resize(s->buf.size() + s->buf.size() / 2 + (32u << 20));
+	size_t room = s->buf.size() - s->end;
+	if (room > (1u << 30)) room = 1u << 30;
+	const int got = gzread(s->f, s->buf.data() + s->end, (unsigned)room);
+	if (got <= 0) { s->feof = true; return false; }
+	s->end += (size_t)got;
+	return true;
+}
+
+static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
+{
+	/* the window keeps only what the previous batch did not use */
+	if (s->pos > 0) { memmove(s->buf.data(), s->buf.data() + s->pos, s->end - s->pos); s->end -= s->pos; s->pos = 0; }
+	std::vector<FqRec> recs;
+	recs.reserve(max_reads < (1u << 22) ? max_reads : (1u << 22));
+	uint32_t maxline = 1;
+	while (!s->done && recs.size() < max_reads) {
+		if (s->rdid >= s->limit) { s->done = true; break; }
+		if (!s->f) {
+			/* the next file continues the same window: this batch's records stay where they are */
+			if (!st_open_next(s, err, true)) { s->done = true; break; }
+		}
+		if (s->file_first) {
+			for (;;) {
+				while (s->pos < s->end && (s->buf[s->pos] == '\r' || s->buf[s->pos] == '\n')) s->pos++;
+				if (s->pos < s->end || !fq_more(s)) break;
+			}
+			if (s->pos >= s->end || s->buf[s->pos] != '@') { *err = "Error: reads file does not look like a FASTQ file"; return BT_ERR_READS; }
+			s->file_first = false;
+		}
+		FqRec r; r.off = s->pos; r.rdid = s->rdid;
+		size_t p = s->pos; int k = 0; bool partial = false;
+		while (k < 4) {
+			const char* b = s->buf.data();
+			const char* nl = p < s->end ? (const char*)memchr(b + p, '\n', s->end - p) : nullptr;
+			if (nl) { r.e[k++] = (uint32_t)((size_t)(nl - b) - r.off); p = (size_t)(nl - b) + 1; continue; }
+			if (fq_more(s)) continue;
+			/* end of file: it stands in for the fourth newline only */
+			if (k == 3) { r.e[3] = (uint32_t)(s->end - r.off); k = 4; p = s->end; }
+			else partial = true;
+			break;
+		}
+		if (partial) { s->pos = s->end; gzclose(s->f); s->f = nullptr; continue; }
+		s->pos = p;
+		if (s->rdid >= s->o.skip) {
+			recs.push_back(r);
+			const uint32_t l2 = r.e[1] - r.e[0] - 1u;
+			if (l2 > maxline) maxline = l2;
+		}
+		s->rdid++;
+		if (s->pos >= s->end && s->feof) { gzclose(s->f); s->f = nullptr; }
+	}
+	const size_t n = recs.size();
+	if (n == 0) { batch->n = 0; return BT_OK; }
+	if (maxline > 1040u) maxline = 1040u;
+	const uint32_t stride = (maxline + 15u) & ~15u;
+	batch->reset((uint32_t)n, stride);
+	batch->rdid.resize(n);
+	std::vector<uint32_t> name_b(n), name_n(n);
+	std::vector<std::string> alt_name;                 /* default names (read id): rare */
+	std::vector<size_t> alt_at;
+	const int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+	std::vector<std::string> errs((size_t)T);
+	std::vector<size_t> err_at((size_t)T, (size_t)-1);
+	const uint8_t* a2d = asc2dna_table();
+	uint8_t seqcode[256];
+	for (int c = 0; c < 256; c++) seqcode[c] = (isalpha(c) || c == '.') ? a2d[c == '.' ? 'N' : c] : 0xff;
+	const bt_read_opts o = s->o;
+	const char* W = s->buf.data();
+	auto work = [&](int t) {
+		const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+		for (size_t i = lo; i < hi; i++) {
+			const FqRec& r = recs[i];
+			const char* rec = W + r.off;
+			const uint32_t len = r.e[3] + 1u > (uint32_t)(s->end - r.off) ? r.e[3] : r.e[3] + 1u;   /* with its last '\n' if present */
+			uint8_t* sq = batch->seq + i * stride;
+			uint8_t* ql = batch->qual + i * stride;
+			const uint32_t L = r.e[1] - r.e[0] - 1u, LQ = r.e[3] - r.e[2] - 1u;
+			const uint8_t* sl = (const uint8_t*)rec + r.e[0] + 1;
+			const uint8_t* qlin = (const uint8_t*)rec + r.e[2] + 1;
+			bool fast = r.e[0] > 1 && L == LQ && L <= 1024u && rec[r.e[1] + 1] == '+' && memchr(rec, '\r', r.e[3]) == nullptr;
+			uint32_t out_len = 0;
+			if (fast) {
+				const uint32_t t5 = (uint32_t)o.trim5 < L ? (uint32_t)o.trim5 : L;
+				const uint32_t kept = L - t5;
+				const uint32_t t3 = (uint32_t)o.trim3 < kept ? (uint32_t)o.trim3 : kept;
+				out_len = kept - t3;
+				uint8_t bad = 0;
+				for (uint32_t j = 0; j < L; j++) bad |= seqcode[sl[j]];          /* 0xff marks a character the parser drops */
+				if (bad == 0xff) fast = false;
+				else {
+					for (uint32_t j = 0; j < out_len; j++) sq[j] = seqcode[sl[t5 + j]];
+					if (o.qual_enc == BT_QUAL_PHRED33) {
+						uint8_t mn = 255;
+						for (uint32_t j = 0; j < L; j++) mn = qlin[j] < mn ? qlin[j] : mn;
+						if (L && mn < 33) fast = false;
+						else memcpy(ql, qlin + t5, out_len);
+					} else if (o.qual_enc == BT_QUAL_PHRED64) {
+						uint8_t mn = 255;
+						for (uint32_t j = 0; j < L; j++) mn = qlin[j] < mn ? qlin[j] : mn;
+						if (L && mn < 64) fast = false;
+						else for (uint32_t j = 0; j < out_len; j++) ql[j] = (uint8_t)(qlin[t5 + j] - 31);
+					} else fast = false;
+					if (L == 0) fast = false;           /* an empty read has its own story in the reference parser */
+				}
+			}
+			if (fast) {
+				name_b[i] = 1; name_n[i] = r.e[0] - 1u;
+			} else {
+				BtParsed p;
+				if (!parse_fastq(rec, len, o, r.rdid, &p, &errs[(size_t)t])) { err_at[(size_t)t] = i; return; }
+				if (p.seq.size() > 1024 || p.seq.size() > stride) {
+					errs[(size_t)t] = "Reads file contained a pattern with more than 1024 sequence characters.\n"
+					                  "Please truncate reads and quality values and and re-run Bowtie.\n"
+					                  "Offending read: " + name_of(rec, p, r.rdid);
+					err_at[(size_t)t] = i; return;
+				}
+				out_len = (uint32_t)p.seq.size();
+				memcpy(sq, p.seq.data(), out_len); memcpy(ql, p.qual.data(), out_len);
+				name_b[i] = (uint32_t)p.name_b; name_n[i] = (uint32_t)p.name_n;
+			}
+			memset(sq + out_len, 4, stride - out_len);
+			memset(ql + out_len, 33, stride - out_len);
+			batch->len[i] = (uint16_t)out_len;
+			batch->rdid[i] = r.rdid;
+			if (name_n[i]) batch->seed[i] = rand_seed(sq, ql, out_len, rec + name_b[i], name_n[i], o.seed);
+		}
+	};
+	if (T == 1 || n < 4096) { for (int t = 0; t < T; t++) { work(t); if (err_at[(size_t)t] != (size_t)-1) break; } }
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(work, t);
+		for (auto& x : th) x.join();
+	}
+	size_t first_err = (size_t)-1; int et = -1;
+	for (int t = 0; t < T; t++) if (err_at[(size_t)t] < first_err) { first_err = err_at[(size_t)t]; et = t; }
+	if (et >= 0) { *err = errs[(size_t)et]; batch->n = 0; return BT_ERR_READS; }
+	/* names: offsets are a running sum, so this part is sequential (and short) */
+	batch->name_off.resize(n + 1);
+	uint64_t tot = 0;
+	for (size_t i = 0; i < n; i++) { batch->name_off[i] = tot; tot += name_n[i] ? name_n[i] : 20u; }
+	batch->names.resize((size_t)tot);
+	tot = 0;
+	for (size_t i = 0; i < n; i++) {
+		batch->name_off[i] = tot;
+		if (name_n[i]) { memcpy(&batch->names[(size_t)tot], W + recs[i].off + name_b[i], name_n[i]); tot += name_n[i]; }
+		else {
+			char b[24]; const int k = snprintf(b, sizeof(b), "%llu", (unsigned long long)recs[i].rdid);
+			memcpy(&batch->names[(size_t)tot], b, (size_t)k);
+			batch->seed[i] = rand_seed(batch->seq + i * stride, batch->qual + i * stride, batch->len[i], b, (size_t)k, o.seed);
+			tot += (uint64_t)k;
+		}
+	}
+	batch->name_off[n] = tot;
+	batch->names.resize((size_t)tot);
+	batch->first_rdid = batch->rdid[0];
+	return BT_OK;
+}
+
+
 int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
 {
 	s->raw.clear(); s->recs.clear();
 	batch->n = 0;
+	if (s->o.format == BT_FMT_FASTQ && !(s->o.reserved & 1u)) return next_fastq(s, max_reads, threads, batch, err);
 	/* ---- light parse (sequential) ---- */
 	while (!s->done && s->recs.size() < max_reads) {
 		if (s->rdid >= s->limit) { s->done = true; break; }

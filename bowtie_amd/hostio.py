@@ -22,10 +22,10 @@ class ReadInputError(ValueError):
 
 def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, quals: str = "phred33",
                  seed: int = 0, skip: int = 0, upto: int = 0, max_reads: int = 1 << 20,
-                 threads: int = 1) -> Iterator[ReadBatch]:
+                 threads: int = 1, careful: bool = False) -> Iterator[ReadBatch]:
     """Yield ReadBatch objects (copies) of up to max_reads reads each."""
     L = lib()
-    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, 0, skip, upto)
+    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful), skip, upto)
     h = C.c_void_p()
     rc = L.bt_reads_open(spec.encode(), C.byref(o), C.byref(h))
     if rc != A.BT_OK:

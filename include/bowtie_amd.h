@@ -223,7 +223,7 @@ typedef struct bt_read_opts {
 	int32_t  trim5, trim3; /* -5 / -3                         pat.h TrimmingPatternSource      */
 	int32_t  qual_enc;     /* BT_QUAL_*                                                       */
 	uint32_t seed;         /* --seed: mixed into every read's seed (pat.cpp:21-57)            */
-	uint32_t reserved;
+	uint32_t reserved;     /* bit 0: every record through the step-by-step parser (testing)   */
 	uint64_t skip;         /* -s: first reads to skip         pat.cpp:113-115                 */
 	uint64_t upto;         /* -u: reads to process after the skipped ones (0 = all)
 	                          ebwt_search.cpp:891-896, 937                                    */

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 1))
     ap.add_argument("--mode", default="-n 2")
+    ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--extra", default="", help="extra bowtie-amd options")
     a = ap.parse_args()
     if a.index == "ecoli":
         base = os.path.join(ROOT, "tests", "golden", "e_coli")
@@ -37,14 +39,14 @@ def main():
         write_fastq(synth_reads(text, a.reads, a.len, mm_dist=(0, 1, 2, 2, 3, 4), seed=99), fq)
     mode = a.mode.split()
     out = {"index": a.index, "reads": a.reads, "len": a.len, "mode": a.mode, "fastq_bytes": os.path.getsize(fq)}
-    ours = [os.path.join(ROOT, "bowtie_amd", "bowtie-amd"), "-p", str(a.threads), "-t", "-S"] + mode + ["-x", base, fq, "/tmp/cli_ours.sam"]
+    ours = [os.path.join(ROOT, "bowtie_amd", "bowtie-amd"), "-p", str(a.threads), "-t", "-S"] + a.extra.split() + mode + ["-x", base, fq, "/tmp/cli_ours.sam"]
     t0 = time.perf_counter()
     p = subprocess.run(ours, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     out["bowtie_amd_s"] = time.perf_counter() - t0
     out["bowtie_amd_reads_per_s"] = a.reads / out["bowtie_amd_s"]
     out["bowtie_amd_stderr"] = p.stderr.decode(errors="replace").strip().split("\n")[-8:]
     ref = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
-    if os.path.exists(ref):
+    if os.path.exists(ref) and not a.no_ref:
         cores = os.cpu_count() or 1
         t0 = time.perf_counter()
         p = subprocess.run([ref, "--wrapper", "basic-0", "-p", str(cores), "-t", "-S"] + mode + ["-x", base, fq, "/tmp/cli_ref.sam"],

@@ -193,7 +193,7 @@ def test_gpu_scratch_overflow_is_retried(gidx, monkeypatch):
     monkeypatch.setenv("BT_FRAME_CAP", "3")
     monkeypatch.setenv("BT_PARTIAL_CAP", "4")
     for index, rname, mode in (("multi", "syn100", "n2"), ("multi", "syn50lowq", "n3"), ("e_coli", "syn76", "v2"),
-                               ("multi", "syn76", "n1_a_m20"), ("multi", "syn12", "n2_k3")):
+                               ("multi", "syn76", "n1_a_m20"), ("multi", "syn36", "n2_k3")):
         batch = T.read_set(index, rname)
         kw = T.MODES[mode]
         al = aligner(gidx, index, kw)

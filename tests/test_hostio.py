@@ -90,3 +90,51 @@ def test_empty_inputs(tmp_path):
     p.write_bytes(b"")
     assert H.read_all(str(p), fmt="fasta") is None
     assert H.read_all(str(p), fmt="raw") is None
+
+
+def _messy_fastq(rng, n):
+    """FASTQ text with the things real files contain and a few they should not."""
+    out = []
+    for i in range(n):
+        L = int(rng.integers(1, 60))
+        seq = bytes(rng.choice(list(b"ACGTNacgtn"), size=L).tolist())
+        qual = bytes(rng.integers(33, 74, size=L).tolist())
+        name = b"rd%d" % i
+        k = rng.integers(0, 14)
+        if k == 0: name = b""
+        elif k == 1: name += b" with words\tand tab"
+        elif k == 2: seq = seq[:L // 2] + b"." + seq[L // 2 + 1:]
+        elif k == 3: seq = seq[:L // 2] + b"-" + seq[L // 2:]          # dropped character: one quality too many -> error
+        elif k == 4: seq = seq[:L // 2] + b"RYK"[:1] + seq[L // 2 + 1:]
+        eol = b"\r\n" if k == 5 else b"\n"
+        plus = b"+" + (name if k == 6 else b"")
+        out.append(b"@" + name + eol + seq + eol + plus + eol + qual + eol)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fast_fastq_path_equals_step_by_step_parser(tmp_path, seed):
+    """The bulk FASTQ path and the record-by-record parser that follows the reference must agree on
+    every file: same reads, or the same error."""
+    rng = np.random.default_rng(seed)
+    recs = _messy_fastq(rng, 400)
+    if seed % 2 == 0:
+        recs = [r for r in recs if b"-" not in r.split(b"\n")[1]]       # an error-free file
+    body = (b"\n\r\n" if seed % 3 == 0 else b"") + b"".join(recs)
+    if seed % 3 == 1:
+        body = body.rstrip(b"\r\n")                                        # no final newline
+    p = tmp_path / "m.fq"
+    p.write_bytes(body)
+    kw = dict(trim5=int(seed % 3), trim3=int(seed % 2) * 2, seed=seed, skip=seed, upto=0 if seed < 3 else 300)
+
+    def load(**extra):
+        try:
+            bs = list(H.read_batches(str(p), max_reads=97, threads=3, **kw, **extra))
+        except H.ReadInputError as e:
+            return ("error", str(e))
+        return [(b.seq[i, :b.len[i]].tobytes(), b.qual[i, :b.len[i]].tobytes(), int(b.seed[i]), b.names[i])
+                for b in bs for i in range(b.n)]
+    fast, slow = load(), load(careful=True)
+    assert fast == slow
+    if seed % 2 == 0:
+        assert isinstance(fast, list) and len(fast) > 50
