@@ -40,7 +40,7 @@ struct Options {
 	bt_out_opts out;
 	std::string index, reads, hits_file, rg_id;
 	std::vector<std::string> rg_fields;
-	int threads = 1, offrate = -1, device = 0, inflight = 2;
+	int threads = 0, offrate = -1, device = 0, inflight = 2;      /* threads 0 = pick from the host */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false;
 	bool suppress_set = false;
 	uint32_t batch_reads = 4u << 20;
@@ -110,7 +110,8 @@ void usage(FILE* o)
 	    "  --no-unal          suppress SAM records for unaligned reads\n"
 	    "Performance:\n"
 	    "  -o/--offrate <int> override offrate of index; must be >= index's offrate\n"
-	    "  -p/--threads <int> number of host threads for parsing and formatting (default: 1)\n"
+	    "  -p/--threads <int> number of host threads for parsing and formatting (default: all, up to 32);\n"
+	    "                     the output order is that of the input whatever the value\n"
 	    "  --device <int>     GPU to run on (default: 0)\n"
 	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
@@ -316,6 +317,7 @@ void parse_args(int argc, char** argv, Options* O)
 		O->out.suppress = 0;
 	}
 	if (O->out.sam && O->out.ref_idx) { /* SAMHitSink gets no names: indexes are printed */ }
+	if (O->threads <= 0) { const unsigned hc = std::thread::hardware_concurrency(); O->threads = hc == 0 ? 1 : (hc > 32 ? 32 : (int)hc); }
 	O->out.khits = O->pol.khits; O->out.mhits = O->pol.mhits; O->out.all_hits = O->pol.all_hits;
 }
 
