@@ -38,11 +38,15 @@ from bowtie_amd import aligner as AL        # noqa: E402
 from bowtie_amd.synth import synth_reads_torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
-# HBM bytes per read of bt_search_kernel measured with rocprofv3 PMC (separate --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE passes, (FETCH_SIZE + WRITE_SIZE) x 1024, uncorrected) on the same workload:
-# profiles/r1_final/pmc_big_n2_100_16M.txt.  bench.py cannot run the profiler on itself, so `traffic`
-# is that measured per-read figure times the reads of one launch; null for workloads not profiled.
-MEASURED_HBM_BYTES_PER_READ = {"big_n2_100": (1.408e9 + 7.315e8) * 1024.0 / 16_000_000}
+# HBM-side bytes per read of bt_search_kernel, measured with rocprofv3 PMC (separate --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE passes over a 16 M-read launch of the same workload, profiles/r1_final/pmc_big_n2_100_16M.txt)
+# and corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies this kernel's 128-byte
+# side-pair fetches at 64 B (calibrated on the probe kernel, whose bytes are known:
+# profiles/r1_final/calib_fetch_size.txt), so it is doubled; WRITE_SIZE calibrates exact.
+#   (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / reads = (2 x 1.408e9 + 7.325e8) x 1024 / 16e6 = 227 KB/read
+# bench.py cannot run the profiler on itself, so `traffic` is that per-read figure times the reads of one
+# launch; null for workloads not profiled.
+MEASURED_HBM_BYTES_PER_READ = {"big_n2_100": (2 * 1.408e9 + 7.325e8) * 1024.0 / 16_000_000}
 
 WORKLOADS = {
     "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
@@ -268,7 +272,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (MEASURED_HBM_BYTES_PER_READ[args.workload] * n
                                      if args.workload in MEASURED_HBM_BYTES_PER_READ and not args.genome else None),
-                         "traffic_note": "rocprofv3 FETCH_SIZE+WRITE_SIZE per read (profiles/r1_final) x reads per launch",
+                         "traffic_note": "rocprofv3 (2 x FETCH_SIZE + WRITE_SIZE) per read, gfx950-calibrated (profiles/r1_final/calib_fetch_size.txt), x reads per launch",
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": "bt_search_kernel", "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": abytes,
