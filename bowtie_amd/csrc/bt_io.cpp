@@ -56,6 +56,7 @@ struct BtReadStream {
 	std::vector<char> buf;                /* file window                                         */
 	size_t pos = 0, end = 0;
 	bool feof = false;
+	uint64_t file_recs = 0;               /* complete records seen in the current file           */
 	uint64_t rdid = 0;                    /* next read id (counts skipped reads too)             */
 	uint64_t limit = ~0ull;               /* first read id that is not processed                 */
 	bool done = false;
@@ -103,7 +104,7 @@ static bool st_open_next(BtReadStream* s, std::string* err, bool keep_window = f
 		return st_open_next(s, err, keep_window);
 	}
 	gzbuffer(s->f, 1u << 20);
-	s->file_first = true; s->feof = false;
+	s->file_first = true; s->feof = false; s->file_recs = 0;
 	if (!keep_window) s->pos = s->end = 0;
 	return true;
 }
@@ -487,15 +488,41 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 			else partial = true;
 			break;
 		}
-		if (partial) { s->pos = s->end; gzclose(s->f); s->f = nullptr; continue; }
+		if (partial) {
+			/* A file that ends inside a record.  The reference's light parser (pat.cpp:822-858) then
+			 * also gives up the record before it, unless that one closed a 16-read batch
+			 * (--reads-per-batch); its read id is handed to the next file's first read. */
+			if (k > 0 && s->file_recs % 16u != 0) {      /* k == 0: the file ended before the first newline of a record -- a clean end */
+				s->rdid--;
+				if (s->rdid >= s->o.skip && !recs.empty() && recs.back().rdid == s->rdid) recs.pop_back();
+			}
+			s->pos = s->end; gzclose(s->f); s->f = nullptr; continue;
+		}
 		s->pos = p;
 		if (s->rdid >= s->o.skip) {
 			recs.push_back(r);
 			const uint32_t l2 = r.e[1] - r.e[0] - 1u;
 			if (l2 > maxline) maxline = l2;
 		}
-		s->rdid++;
+		s->rdid++; s->file_recs++;
 		if (s->pos >= s->end && s->feof) { gzclose(s->f); s->f = nullptr; }
+	}
+	if (recs.size() == max_reads && s->f && !s->done && s->file_recs % 16u != 0) {
+		/* the batch is full: look (without consuming) whether the file ends inside the next record,
+		 * because that would take this batch's last record with it */
+		size_t p = s->pos; int k = 0;
+		while (k < 3) {
+			const char* b = s->buf.data();
+			const char* nl = p < s->end ? (const char*)memchr(b + p, '\n', s->end - p) : nullptr;
+			if (nl) { k++; p = (size_t)(nl - b) + 1; continue; }
+			if (fq_more(s)) continue;
+			break;
+		}
+		if (k > 0 && k < 3 && s->feof) {
+			s->rdid--;
+			if (!recs.empty() && recs.back().rdid == s->rdid) recs.pop_back();
+			s->pos = s->end; gzclose(s->f); s->f = nullptr;
+		}
 	}
 	const size_t n = recs.size();
 	if (n == 0) { batch->n = 0; return BT_OK; }

@@ -78,13 +78,6 @@ def test_malformed_input_reports_the_reference_message(tmp_path, body, fmt, kw, 
         H.read_all(str(p), fmt=fmt, **kw)
 
 
-def test_truncated_fastq_record_is_dropped(tmp_path):
-    p = tmp_path / "t.fq"
-    p.write_bytes(b"@a\nACGT\n+\nIIII\n@b\nACG")
-    b = H.read_all(str(p))
-    assert b.n == 1 and b.names == [b"a"]
-
-
 def test_empty_inputs(tmp_path):
     p = tmp_path / "e.fa"
     p.write_bytes(b"")
@@ -138,3 +131,29 @@ def test_fast_fastq_path_equals_step_by_step_parser(tmp_path, seed):
     assert fast == slow
     if seed % 2 == 0:
         assert isinstance(fast, list) and len(fast) > 50
+
+
+def test_file_ending_inside_a_record_follows_the_reference(tmp_path):
+    """Checked against the unmodified binary: with reads a, b and a cut-off third record the reference
+    aligns only `a` -- its light parser gives up the record before a truncated one unless that record
+    closed a 16-read batch (pat.cpp:822-858) -- and a stray blank line at the end counts as a cut-off record."""
+    rec = lambda nm: b"@" + nm + b"\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    p = tmp_path / "t.fq"
+    p.write_bytes(rec(b"a") + rec(b"b") + b"@c\nACG")
+    assert H.read_all(str(p)).names == [b"a"]
+    p.write_bytes(rec(b"a") + b"@c\nACG")
+    assert H.read_all(str(p)) is None
+    p.write_bytes(b"".join(rec(b"r%d" % i) for i in range(16)) + b"@c\nACG\n+")
+    assert H.read_all(str(p)).n == 16                       # the 16th closed its batch (there the reference itself fails)
+    p.write_bytes(b"".join(rec(b"r%d" % i) for i in range(5)) + b"\n")
+    assert H.read_all(str(p)).n == 4
+    p.write_bytes(b"".join(rec(b"r%d" % i) for i in range(5)) + b"@partial first line")
+    assert H.read_all(str(p)).n == 5                        # EOF before the first newline: a clean end
+    # the same when the cut falls exactly on our own batch boundary
+    p.write_bytes(b"".join(rec(b"r%d" % i) for i in range(7)) + b"@c\nACG")
+    assert [b.n for b in H.read_batches(str(p), max_reads=7)] == [6]
+    # the dropped record's id goes to the next file's first read
+    q = tmp_path / "u.raw"
+    p.write_bytes(rec(b"") + rec(b"") + b"@c\nACG")
+    names = [nm for b in H.read_batches(str(p) + "," + str(p)) for nm in b.names]
+    assert names == [b"0", b"1"]
