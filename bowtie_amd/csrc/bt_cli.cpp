@@ -40,7 +40,8 @@ struct Options {
 	bt_out_opts out;
 	std::string index, reads, hits_file, rg_id;
 	std::vector<std::string> rg_fields;
-	int threads = 0, offrate = -1, device = 0, inflight = 2;      /* threads 0 = pick from the host */
+	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
+	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false;
 	bool suppress_set = false;
 	uint32_t batch_reads = 4u << 20;
@@ -112,7 +113,7 @@ void usage(FILE* o)
 	    "  -o/--offrate <int> override offrate of index; must be >= index's offrate\n"
 	    "  -p/--threads <int> number of host threads for parsing and formatting (default: all, up to 32);\n"
 	    "                     the output order is that of the input whatever the value\n"
-	    "  --device <int>     GPU to run on (default: 0)\n"
+	    "  --device <list>    GPU(s) to run on, e.g. 0,1,2,3: index replicated, batches dealt out (default: 0)\n"
 	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
 	    "Other:\n"
@@ -266,7 +267,21 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_MAPQ: O->out.mapq = (int32_t)parse_int(val, 0, "--mapq must be positive"); break;
 		case O_COST: O->out.print_cost = 1; break;
 		case O_SHOWSEED: O->out.show_seed = 1; break;
-		case O_DEVICE: O->device = (int)parse_int(val, 0, "--device arg must be at least 0"); break;
+		case O_DEVICE: {
+			/* "--device 2" or "--device 0,1,2,3": the index is replicated on every listed GPU and the
+			 * batches are dealt to them; the output order does not depend on the list */
+			O->devices.clear();
+			const char* p = val;
+			while (*p) {
+				char* e = nullptr;
+				const long d = strtol(p, &e, 10);
+				if (e == p || d < 0 || d > 1023 || (*e && *e != ',')) die("Error: bad --device list: %s", val);
+				O->devices.push_back((int)d);
+				p = (*e == ',') ? e + 1 : e;
+			}
+			if (O->devices.empty()) die("Error: bad --device list: %s", val);
+			break;
+		}
 		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
@@ -490,21 +505,32 @@ int main(int argc, char** argv)
 
 	/* ---- index into HBM ---- */
 	const std::string base = find_index(O.index);
-	bt_index* idx = nullptr;
+	if (O.devices.empty()) O.devices.push_back(0);
+	const size_t ND = O.devices.size();
+	std::vector<bt_index*> idxs(ND, nullptr);
 	double t0 = now_s();
-	int rc = bt_index_load(base.c_str(), 1, O.offrate, O.device, &idx);
+	int rc = BT_OK;
+	{
+		/* one replica per GPU, loaded side by side */
+		std::vector<int> rcs(ND, BT_OK);
+		std::vector<std::thread> th;
+		for (size_t d = 0; d < ND; d++) th.emplace_back([&, d] { rcs[d] = bt_index_load(base.c_str(), 1, O.offrate, O.devices[d], &idxs[d]); });
+		for (auto& x : th) x.join();
+		for (size_t d = 0; d < ND; d++) if (rcs[d] != BT_OK) { rc = rcs[d]; break; }
+	}
 	if (rc != BT_OK) {
 		if (rc == BT_ERR_IO) die("Could not locate a Bowtie index corresponding to basename \"%s\"", O.index.c_str());
 		die("Error: could not load index \"%s\": %s", O.index.c_str(), bt_strerror(rc));
 	}
+	bt_index* idx = idxs[0];
 	if (O.timing) print_timer("Time loading forward and mirror index: ", now_s() - t0);
 	bt_index_info info;
 	bt_index_info_get(idx, &info);
 	BtRefNames refs;
 	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
-	std::vector<bt_ctx*> ctxs((size_t)O.inflight, nullptr);
-	for (auto& c : ctxs) {
-		rc = bt_ctx_create(idx, &O.pol, nullptr, &c);
+	std::vector<bt_ctx*> ctxs((size_t)O.inflight * ND, nullptr);          /* searcher g works on GPU g % ND */
+	for (size_t g = 0; g < ctxs.size(); g++) {
+		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 	}
 
@@ -524,7 +550,7 @@ int main(int argc, char** argv)
 	/* ---- stage 1: reader ---- */
 	std::string open_err;
 	BtReadStream* rs = bt_io_open(O.reads.c_str(), O.rd, &open_err);
-	const int G = O.inflight;
+	const int G = (int)ctxs.size();
 	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
 	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
 	const int T = O.threads;
@@ -657,7 +683,7 @@ int main(int argc, char** argv)
 	if (fout != stdout) fclose(fout);
 	bt_io_close(rs);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
-	bt_index_free(idx);
+	for (bt_index* x : idxs) bt_index_free(x);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }
 	if (O.timing) print_timer("Overall time: ", now_s() - t_all);

@@ -81,3 +81,12 @@ def test_cli_errors(args, reads, msg):
 def test_cli_missing_index():
     p = run(["-v", "0"], "no_such_index", "cli/io.fq")
     assert p.returncode == 1 and "Could not locate a Bowtie index" in p.stderr.decode()
+
+
+def test_cli_batches_dealt_to_several_devices_keep_the_order():
+    """--device takes a list: one index replica per entry, batches dealt round-robin, output in input
+    order.  One GPU is all a test box has, so it is listed twice."""
+    case = [c for c in CC.cases() if c["name"] == "multi_all"][0]
+    p = run(case["args"], case["index"], case["reads"], extra=["--device", "0,0", "--batch", "11", "--inflight", "2"])
+    assert p.returncode == 0, p.stderr.decode(errors="replace")
+    assert p.stdout == CC.expected(case)
