@@ -131,6 +131,8 @@ def main():
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps, re-check every reported hit of the last step against the genome (bowtie_amd/verify.py)")
     ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
     args = ap.parse_args()
 
@@ -164,7 +166,8 @@ def main():
     # ---- reads: synthetic, generated straight into HBM, sharded by rank -------------------------
     t0 = time.perf_counter()
     rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
-    del text_t
+    if not args.verify:
+        del text_t
     hit_cap = 1
     mm_cap = n * 8
     pol = A.make_policy(**wl["pol"])
@@ -236,6 +239,18 @@ def main():
         for kk, v in cnt.as_dict().items():
             c[kk] = c.get(kk, 0) + v
 
+    verified = None
+    if args.verify:
+        # size-independent parity property at full size: every hit is re-derived from the text
+        from bowtie_amd import verify as V
+        tl, plen, rstarts = V.read_fragments(base)
+        o = pipes[(args.steps - 1) % len(pipes)] if args.steps > 0 else pipes[0]
+        t1 = time.perf_counter()
+        verified = V.verify_hits(text_t, tl, rstarts, rb["seq"], rb["qual"], L, o["hits"], o["n_hits"], o["mm_pool"],
+                                 dict(wl["pol"], seed_len=28, qual_thresh=70))
+        log("[bench] verify: %s in %.1fs" % (verified, time.perf_counter() - t1))
+        if any(v for k, v in verified.items() if k != "checked"):
+            raise SystemExit("bench.py --verify: reported hits fail the re-check: %s" % verified)
     if iters_t is not None and rank == 0:
         it = iters_t.to(torch.float64)
         qs = torch.quantile(it[:min(n, 4_000_000)], torch.tensor([0.5, 0.9, 0.99, 0.999, 0.9999, 1.0], dtype=torch.float64, device=dev))
@@ -267,6 +282,7 @@ def main():
                        "reads_with_alignment_per_s": aligned_all * args.steps / wall,
                        "pct_aligned": 100.0 * aligned_all / reads_all, "reads_overflowed": bad_all,
                        "pipelined_contexts": len(pipes),
+                       "hits_verified_against_text": verified["checked"] if verified else None,
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -200,3 +200,31 @@ def test_gpu_scratch_overflow_is_retried(gidx, monkeypatch):
         got = al.align(batch, hit_cap=T.hit_cap_for(kw))
         assert al.last_retried > batch.n // 20, (mode, al.last_retried)
         T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "overflow-retry " + mode)
+
+
+def test_gpu_hits_verify_against_text_large(gidx):
+    """2 M reads through the device-pointer path (what bench.py times), then every reported hit
+    re-derived from the text on the GPU (bowtie_amd/verify.py): windows, mismatch lists, policy, cost."""
+    import ctypes as C
+    import torch
+    from bowtie_amd import verify as V
+    from bowtie_amd.synth import synth_reads_torch
+    dev = torch.device("cuda", 0)
+    ln, plen, rstarts = V.read_fragments(os.path.join(T.G, "e_coli"))
+    text_t = torch.from_numpy(T.joined_text("e_coli").copy()).to(dev)
+    for mode, L in (("n2", 100), ("v2", 76)):
+        kw = T.MODES[mode]
+        n = 2_000_000
+        rb = synth_reads_torch(text_t, n, L, seed=31 + L)
+        hits = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+        n_hits = torch.zeros(n, dtype=torch.int32, device=dev)
+        status = torch.zeros(n, dtype=torch.uint8, device=dev)
+        pool = torch.zeros(n * 8, dtype=torch.int16, device=dev)
+        al = aligner(gidx, "e_coli", kw)
+        rbc = A.ReadBatchC(n, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(), rb["seed"].data_ptr())
+        hbc = A.HitBatchC(1, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), pool.data_ptr(), n * 8, 0)
+        assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
+        assert AL.lib().bt_ctx_sync(al._h) == 0
+        r = V.verify_hits(text_t, ln, rstarts, rb["seq"], rb["qual"], L, hits, n_hits, pool, kw)
+        assert r["checked"] > 0.7 * n
+        assert {k: v for k, v in r.items() if k != "checked"} == dict(bad_window=0, bad_mm_count=0, bad_mm_list=0, bad_policy=0, bad_cost=0)
