@@ -226,5 +226,5 @@ def test_gpu_hits_verify_against_text_large(gidx):
         assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
         assert AL.lib().bt_ctx_sync(al._h) == 0
         r = V.verify_hits(text_t, ln, rstarts, rb["seq"], rb["qual"], L, hits, n_hits, pool, kw)
-        assert r["checked"] > 0.7 * n
+        assert r["checked"] > 0.5 * n
         assert {k: v for k, v in r.items() if k != "checked"} == dict(bad_window=0, bad_mm_count=0, bad_mm_list=0, bad_policy=0, bad_cost=0)
