@@ -269,6 +269,8 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	if (rc != BT_OK) return rc;
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
+	/* short reads (all of today's sequencers' single-end lengths up to 112) keep the whole read in LDS */
+	const int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
 	BtCold cold;
 	memset(&cold, 0, sizeof(cold));
 	cold.P = c->prog;
@@ -328,7 +330,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.poolIn = nullptr; A.poolInCount = nullptr;
 	A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
 	A.heavyRounds = c->heavy0;
-	if (bt_launch_search(&A, nBlocks, c->occ, c->stream) != 0) return BT_ERR_DEVICE;
+	if (bt_launch_search(&A, nBlocks, c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
 	if (offload) {
 		/* level 1: the parked reads, one per lane; those that reach heavy1 rounds move on to pool 2 */
 		auto blocksFor = [&](uint32_t cap) { uint32_t b = (cap + BT_BLOCK - 1) / BT_BLOCK; return b > maxBlocks ? maxBlocks : (b ? b : 1u); };
@@ -336,13 +338,13 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		A.poolIn = c->pool1; A.poolInCount = c->d_cursor + 3;
 		A.poolOut = c->pool2; A.poolOutCount = c->d_cursor + 5; A.poolOutCap = c->pool2Cap;
 		A.heavyRounds = c->heavy1;
-		if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, c->stream) != 0) return BT_ERR_DEVICE;
+		if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
 		/* level 2: run whatever is left to completion */
 		A.nextRead = c->d_cursor + 6;
 		A.poolIn = c->pool2; A.poolInCount = c->d_cursor + 5;
 		A.poolOut = nullptr; A.poolOutCount = nullptr; A.poolOutCap = 0;
 		A.heavyRounds = 0xffffffffu;
-		if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, c->stream) != 0) return BT_ERR_DEVICE;
+		if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
 	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;

@@ -100,7 +100,13 @@ struct BtScratch {
 	                                            record, [9,19) top-of-stack frame record, [19,28) that
 	                                            frame's candidate */
 	uint32_t  slot;
+	uint32_t* rl;       /* LDS copy of the lane's whole read (reads of <= BT_RL_MAXLEN bases; RL builds of the
+	                       automaton): word w at rl[w*tosStride]; [0,14) the bases, 4 bits each,
+	                       [14,42) the qualities, one byte each */
 };
+#define BT_RL_MAXLEN 112u
+#define BT_RL_SEQ_WORDS 14u
+#define BT_RL_WORDS 42u
 
 /* ---- batch-level arguments --------------------------------------------------------------- */
 struct BtHitRec {            /* == bt_hit (include/bowtie_amd.h) */
@@ -277,19 +283,50 @@ BT_HD uint32_t bt_apply_muts(const BtLane& L, uint32_t i, uint32_t c)
 	return c;
 }
 /* query char / quality at index i of the string setQuery selected (ebwt_search_backtrack.h:90-140),
- * with the seedling mutations applied (:1368-1382).  Direct (synchronous) form: rare paths only. */
-BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, uint32_t i)
+ * with the seedling mutations applied (:1368-1382).  RL: from the lane's LDS copy of the read;
+ * otherwise a direct (synchronous) global load, used on rare paths only. */
+BT_HD uint32_t bt_rl_base(const BtScratch& S, uint32_t j)
+{
+	return (S.rl[(j >> 3) * S.tosStride] >> ((j & 7u) * 4u)) & 0xfu;
+}
+BT_HD uint32_t bt_rl_qual(const BtScratch& S, uint32_t j)
+{
+	return (S.rl[(BT_RL_SEQ_WORDS + (j >> 2)) * S.tosStride] >> ((j & 3u) * 8u)) & 0xffu;
+}
+template <bool RL>
+BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t c = H.seq[L.roff + j];
+	uint32_t c = RL ? bt_rl_base(S, j) : (uint32_t)H.seq[L.roff + j];
 	if (!L.readFw && c < 4u) c ^= 3u;
 	return bt_apply_muts(L, i, c);
 }
-BT_HD uint32_t bt_qual(const BtLane& L, const BtHot& H, uint32_t i)
+template <bool RL>
+BT_HD uint32_t bt_qual(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t v = H.qual[L.roff + j];
+	uint32_t v = RL ? bt_rl_qual(S, j) : (uint32_t)H.qual[L.roff + j];
 	return v >= 33u ? v - 33u : 0u;
+}
+/* copy the lane's read into its LDS slot (RL): 16 bases + 16 qualities per step */
+BT_HD void bt_rl_store_chunk(const BtScratch& S, uint32_t base, const BtU4& sv, const BtU4& qv)
+{
+	const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+	uint32_t p[4];
+	BT_UNROLL
+	for (int k = 0; k < 4; k++)
+		p[k] = (w[k] & 0xfu) | ((w[k] >> 4) & 0xf0u) | ((w[k] >> 8) & 0xf00u) | ((w[k] >> 12) & 0xf000u);
+	const uint32_t ts = S.tosStride;
+	S.rl[((base >> 3) + 0u) * ts] = p[0] | (p[1] << 16);
+	S.rl[((base >> 3) + 1u) * ts] = p[2] | (p[3] << 16);
+	const uint32_t qb = BT_RL_SEQ_WORDS + (base >> 2);
+	S.rl[(qb + 0u) * ts] = qv.x; S.rl[(qb + 1u) * ts] = qv.y; S.rl[(qb + 2u) * ts] = qv.z; S.rl[(qb + 3u) * ts] = qv.w;
+}
+BT_HD void bt_rl_load(const BtLane& L, const BtHot& H, const BtScratch& S)
+{
+	BT_NOUNROLL
+	for (uint32_t base = 0; base < L.plen; base += 16u)
+		bt_rl_store_chunk(S, base, *(const BtU4*)(H.seq + L.roff + base), *(const BtU4*)(H.qual + L.roff + base));
 }
 BT_HD uint32_t bt_sel4(uint32_t k, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
@@ -340,6 +377,17 @@ BT_HD bool bt_window_get(const BtLane& L, uint32_t i, uint32_t* c_out, uint32_t*
 	return true;
 }
 
+/* the same from the LDS copy of the read (RL): always there */
+BT_HD void bt_read_get(const BtLane& L, const BtScratch& S, uint32_t i, uint32_t* c_out, uint32_t* q_out)
+{
+	const uint32_t j = L.rev ? (L.plen - 1u - i) : i;
+	uint32_t c = bt_rl_base(S, j);
+	const uint32_t v = bt_rl_qual(S, j);
+	if (!L.readFw && c < 4u) c ^= 3u;
+	*c_out = bt_apply_muts(L, i, c);
+	*q_out = v >= 33u ? v - 33u : 0u;
+}
+
 /* hhCheckTop (ebwt_search_backtrack.h:1200-1275) */
 BT_HD bool bt_hh_check_top(const BtLane& L, const BtScratch& S, uint32_t d)
 {
@@ -375,7 +423,8 @@ BT_HD void bt_report_partial(BtLane& L, const BtScratch& S, uint32_t sd)
 
 /* Start read `rd`: the worker-loop prologue (ebwt_search.cpp:1675-1683, 2167-2175, 2572-2584;
  * search_seeded_phase1.c:17-44). */
-BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, uint32_t rd)
+template <bool RL>
+BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const BtCold& C, const BtScratch& S, uint32_t rd)
 {
 	L.rd = rd;
 	L.roff = (uint64_t)rd * H.stride;
@@ -395,6 +444,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	BT_NOUNROLL
 	for (uint32_t base = 0; base < plen; base += 16u) {
 		const BtU4 v = *(const BtU4*)(H.seq + L.roff + base);
+		if (RL) bt_rl_store_chunk(S, base, v, *(const BtU4*)(H.qual + L.roff + base));
 		/* bit i of nb = byte i of the chunk is an N (code 4): exact zero-byte test on v ^ 0x04.., then
 		 * the four flag bits of each word are gathered with one multiply */
 		uint32_t nb = 0;
@@ -496,6 +546,7 @@ BT_HD void bt_scan_request(const BtLane& L, const BtScratch& S, uint32_t c_lo, B
 }
 
 /* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
+template <bool RL>
 BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
                         const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
@@ -700,15 +751,15 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				const uint32_t p0 = (uint32_t)(pal & 0xffffu), p1 = (uint32_t)((pal >> 16) & 0xffffu), p2 = (uint32_t)((pal >> 32) & 0xffffu);
 				uint32_t oldQuals = 0, nm = 1;
 				const uint32_t t0 = L.plen - 1u - p0;
-				oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t0))) & 0xffu;
+				oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual<RL>(L, H, S, t0))) & 0xffu;
 				L.mutpos0 = t0; L.mutnew0 = (uint32_t)((pal >> 48) & 3u);
 				if (p1 != 0xffffu) {
 					const uint32_t t1 = L.plen - 1u - p1;
-					oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t1))) & 0xffu;
+					oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual<RL>(L, H, S, t1))) & 0xffu;
 					L.mutpos1 = t1; L.mutnew1 = (uint32_t)((pal >> 50) & 3u); nm = 2;
 					if (p2 != 0xffffu) {
 						const uint32_t t2 = L.plen - 1u - p2;
-						oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual(L, H, t2))) & 0xffu;
+						oldQuals = (oldQuals + bt_mm_penalty(L.maq, bt_qual<RL>(L, H, S, t2))) & 0xffu;
 						L.mutpos2 = t2; L.mutnew2 = (uint32_t)((pal >> 52) & 3u); nm = 3;
 					}
 				}
@@ -758,7 +809,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				uint32_t nsInSeed = 0; bool ok = true;
 				BT_NOUNROLL
 				for (uint32_t i = 0; i < L.r3 && ok; i++) {
-					if (bt_qry(L, H, L.qlen - i - 1u) == 4u) {
+					if (bt_qry<RL>(L, H, S, L.qlen - i - 1u) == 4u) {
 						nsInSeed++;
 						if (nsInSeed == 1) { if (i < L.unrev) ok = false; }
 						else if (nsInSeed == 2) { if (i < L.r1) ok = false; }
@@ -769,12 +820,21 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				if (!ok) { L.ret = 0; L.state = ST_SEARCH_END; break; }
 				BT_NOUNROLL
 				for (uint32_t i = 0; i < ftabChars && i < L.qlen; i++)
-					if (bt_qry(L, H, L.qlen - i - 1u) == 4u) nsInFtab++;
+					if (bt_qry<RL>(L, H, S, L.qlen - i - 1u) == 4u) nsInFtab++;
 			}
 			L.nsFtab0 = nsInFtab > 0 ? 1u : 0u;
 			const uint32_t m = L.unrev < L.qlen ? L.unrev : L.qlen;
 			L.fu = L.unrev; L.f1 = L.r1; L.f2 = L.r2; L.f3 = L.r3; L.ham = L.iham; L.ebase = 0;
-			if (nsInFtab == 0 && m >= ftabChars) {
+			if (RL && nsInFtab == 0 && m >= ftabChars) {
+				/* calcFtabOff (:1348-1362) straight from the LDS copy of the read */
+				uint32_t ftabOff = 0;
+				BT_NOUNROLL
+				for (uint32_t t = 0; t < ftabChars; t++) ftabOff |= bt_qry<RL>(L, H, S, L.qlen - 1u - t) << (2u * t);
+				const uint32_t* ftab = WSEL(ftab);
+				L.ra_r = ftabOff;           /* parked until the table entry arrives */
+				BT_REQ_FETCH(ftab + (ftabOff & ~3u), 1, ftab + ((ftabOff + 1u) & ~3u));
+				L.state = ST_FTAB_DONE;
+			} else if (nsInFtab == 0 && m >= ftabChars) {
 				/* calcFtabOff (:1348-1362) needs the last ftabChars characters of the query: fetch the
 				 * (at most two) 16-byte chunks of the read that hold them */
 				const uint32_t i0 = L.qlen - ftabChars, i1 = L.qlen - 1u;
@@ -932,7 +992,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				uint32_t ftabOff = 0;
 				BT_NOUNROLL
 				for (uint32_t jj = 0; jj < ftabChars; jj++) {
-					uint32_t c = bt_qry(L, H, L.qlen - 1u - jj);
+					uint32_t c = bt_qry<RL>(L, H, S, L.qlen - 1u - jj);
 					if (L.qlen - 1u - jj == icur) c = btcint;
 					ftabOff |= c << (2u * jj);
 				}
@@ -1028,6 +1088,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
  * Advance one lane until it has a memory request for this round (req.kind != RQ_NONE) or has
  * finished its read (state ST_IDLE).  `res` is the answer to the lane's previous request.
  */
+template <bool RL>
 BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
@@ -1035,7 +1096,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 	for (;;) {
 		BT_PROF_T0(t_resume);
 		/* ---- resume: the read window arrived ------------------------------------------------- */
-		if (L.state == ST_WIN_DONE) {
+		if (!RL && L.state == ST_WIN_DONE) {
 			L.cs0 = res.q[0].x; L.cs1 = res.q[0].y; L.cs2 = res.q[0].z; L.cs3 = res.q[0].w;
 			L.cq0 = res.x.x; L.cq1 = res.x.y; L.cq2 = res.x.z; L.cq3 = res.x.w;
 			L.cchunk = L.scanCb;
@@ -1053,7 +1114,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			const uint32_t e = L.ebase + (d - L.depth);
 			uint32_t ta[4], tb[4];
 			if (L.state == ST_STEP_LFDONE) {
-				if (L.wpf) {
+				if (!RL && L.wpf) {
 					L.cs0 = res.q[3].x; L.cs1 = res.q[3].y; L.cs2 = res.q[3].z; L.cs3 = res.q[3].w;
 					L.cq0 = res.x.x; L.cq1 = res.x.y; L.cq2 = res.x.z; L.cq3 = res.x.w;
 					L.cchunk = L.scanCb; L.wpf = 0;
@@ -1142,7 +1203,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 		/* ---- everything else ---------------------------------------------------------------- */
 		{
 			BT_PROF_T0(t_slow);
-			if (BT_IS_SLOW(L.state)) bt_lane_slow(L, P, H, W, C, S, res, req, CNT);
+			if (BT_IS_SLOW(L.state)) bt_lane_slow<RL>(L, P, H, W, C, S, res, req, CNT);
 			BT_PROF_ADD(PS_SLOW, t_slow);
 		}
 		if (req.kind != RQ_NONE) { BT_COUNT_HOST(CN_FETCH); return; }
@@ -1154,7 +1215,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; continue; }
 			if (L.ebase + (d - L.depth) >= S.a->entCap) { L.state = ST_ABORT; continue; }
 			uint32_t c, q;
-			if (!bt_window_get(L, L.qlen - d - 1u, &c, &q)) {
+			if (RL) bt_read_get(L, S, L.qlen - d - 1u, &c, &q);
+			else if (!bt_window_get(L, L.qlen - d - 1u, &c, &q)) {
 				const uint32_t i = L.qlen - d - 1u, j = L.rev ? (L.plen - 1u - i) : i;
 				L.scanCb = j >> 4;       /* chunk id, parked until the window arrives */
 				BT_REQ_FETCH(H.seq + L.roff + (uint64_t)(j >> 4) * 16u, 1, H.qual + L.roff + (uint64_t)(j >> 4) * 16u);
@@ -1190,7 +1252,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				/* the next position (d+1) leaves the 16-base window: fetch the neighbouring chunk with
 				 * this round's rank request instead of spending a round on it */
 				L.wpf = 0;
-				if (d + 1u < L.qlen) {
+				if (!RL && d + 1u < L.qlen) {
 					const uint32_t i2 = L.qlen - d - 2u, j2 = L.rev ? (L.plen - 1u - i2) : i2;
 					if ((j2 >> 4) != L.cchunk) { req.wchunk = j2 >> 4; L.scanCb = j2 >> 4; L.wpf = 1; }
 				}

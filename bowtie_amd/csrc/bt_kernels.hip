@@ -54,9 +54,10 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 
 /* EXT = true compiles in the optional machinery (heavy-read parking/adoption, heavy-first pick-up
  * order); the default launch uses the leaner EXT = false build of the same source. */
-template <int OCC, bool EXT>
+template <int OCC, bool EXT, bool RL>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
+	__shared__ uint32_t RLB[RL ? BT_RL_WORDS * BT_BLOCK : 1];  /* RL: every lane's whole read (<= BT_RL_MAXLEN bases) */
 	__shared__ unsigned long long CNT[CN_N + PS_N];
 	__shared__ uint32_t TOS[BT_LDS_WORDS * BT_BLOCK];          /* per lane: candidate, top-of-stack record, its candidate */
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	S.a = &ARENA; S.slot = g;
 	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
+	S.rl = RLB + (RL ? threadIdx.x : 0u);
 
 	BtLane L = {};
 	L.state = ST_IDLE;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			const uint8_t* pB = sel.ebwt + (uint64_t)sideB * 64u;
 			const uint32_t nA = isRank ? 4u : (isFetch ? req.n : 0u);
 			const bool hasB = isRank && req.n == 2;
-			const bool hasW = isRank && req.wchunk != 0xffffu;          /* next read window rides along */
+			const bool hasW = !RL && isRank && req.wchunk != 0xffffu;   /* next read window rides along (register-window build) */
 			const bool hasX = (isFetch && req.x != 0) || hasW;
 			const uint8_t* pX = hasW ? A.H.qual + L.roff + (uint64_t)req.wchunk * 16u : (const uint8_t*)(uintptr_t)req.x;
 			const uint8_t* pW = A.H.seq + L.roff + (uint64_t)req.wchunk * 16u;
@@ -162,15 +164,16 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 					{ const BtU4 v = ((const BtU4*)r->w)[13]; req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
 					{ const BtU4 v = ((const BtU4*)r->w)[14]; req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
 					L.tosValid = 0; L.ccValid = 0;
+					if (RL) bt_rl_load(L, A.H, S);
 					break;                                   /* its request is served at the top of the next round */
 				}
 				if (w >= A.H.n_reads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
-				bt_lane_start(L, PROG, A.H, *cold, (EXT && A.order) ? A.order[w] : w);
+				bt_lane_start<RL>(L, PROG, A.H, *cold, S, (EXT && A.order) ? A.order[w] : w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
-			bt_lane_run(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
+			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state == ST_IDLE) continue;
 			if (EXT && A.poolOut && L.iters >= A.heavyRounds) {
@@ -337,17 +340,24 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 /* ---- launchers (called from bt_api.cpp, which is plain C++) ------------------------------- */
 /* occ = waves per SIMD the register allocator was told to fit (1..4): the same source compiled for
  * different register budgets; which is fastest is a measured choice (bt_api.cpp, BT_OCC). */
-extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, void* stream)
+/* rl = every read of the batch has <= BT_RL_MAXLEN bases: the build that keeps each lane's whole read
+ * in LDS (no read-window fetches); otherwise the register-window build. */
+extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
 	const bool ext = a->poolIn || a->poolOut || a->order;
-#define BT_LAUNCH(O) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
-                          else hipLaunchKernelGGL((bt_search_kernel<O, false>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
-	switch (occ) {
-	case 1:  BT_LAUNCH(1); break;
-	case 2:  BT_LAUNCH(2); break;
-	case 3:  BT_LAUNCH(3); break;
-	default: BT_LAUNCH(4); break;
+#define BT_LAUNCH(O, R) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
+                             else hipLaunchKernelGGL((bt_search_kernel<O, false, R>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
+	if (rl) {
+		/* the read copies take 42 KB of LDS per block: two blocks per CU at most */
+		if (occ == 1) BT_LAUNCH(1, true); else BT_LAUNCH(2, true);
+	} else {
+		switch (occ) {
+		case 1:  BT_LAUNCH(1, false); break;
+		case 2:  BT_LAUNCH(2, false); break;
+		case 3:  BT_LAUNCH(3, false); break;
+		default: BT_LAUNCH(4, false); break;
+		}
 	}
 #undef BT_LAUNCH
 	return (int)hipGetLastError();

@@ -44,8 +44,9 @@ extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint3
 }
 
 /* Same contract as bt_align_batch (host pointers); nLanes lock-step lanes. */
-extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
-                               bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap)
+template <bool RL>
+static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
+                   bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap)
 {
 	EmuIndex* e = (EmuIndex*)p;
 	BtCold cold;
@@ -76,6 +77,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
 	std::vector<uint32_t> tos((size_t)nLanes * BT_LDS_WORDS);
+	std::vector<uint32_t> rlbuf((size_t)nLanes * BT_RL_WORDS);       /* the "LDS" copies of the reads (RL) */
 	std::vector<BtLane> lanes(nLanes);
 	std::vector<BtScratch> scr(nLanes);
 	std::vector<BtRes> res(nLanes);
@@ -92,6 +94,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		scr[g].a = &arena; scr[g].slot = g;
 		
 		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
+		scr[g].rl = rlbuf.data() + g;
 	}
 	uint32_t next = 0, live = nLanes;
 	while (live > 0) {
@@ -102,9 +105,9 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 			for (;;) {
 				if (L.state == ST_IDLE) {
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
-					bt_lane_start(L, P, H, cold, next++);
+					bt_lane_start<RL>(L, P, H, cold, scr[g], next++);
 				}
-				bt_lane_run(L, P, H, W, cold, scr[g], res[g], req, CNT);
+				bt_lane_run<RL>(L, P, H, W, cold, scr[g], res[g], req, CNT);
 				if (L.state != ST_IDLE) break;
 			}
 			if (drained[g]) continue;
@@ -143,4 +146,16 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 		counts->rescans = CNT[CN_RESCAN]; counts->cand_scans = CNT[CN_CANDSCAN]; counts->fetches = CNT[CN_FETCH];
 	}
 	return BT_OK;
+}
+
+/* rl_mode: 0 = as the kernel launcher decides (reads of <= BT_RL_MAXLEN bases keep their read in "LDS"),
+ * 1 = force the register-window build of the automaton */
+extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
+                               bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap,
+                               uint32_t rl_mode)
+{
+	uint32_t maxLen = 0;
+	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
+	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap);
+	return emu_run<false>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap);
 }

@@ -37,7 +37,7 @@ def lib():
         L.emu_index_free.argtypes = [C.c_void_p]
         L.emu_rank4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
-                                      C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 4
+                                      C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 5
         _lib = L
     return _lib
 
@@ -55,7 +55,7 @@ class EmuAligner:
         return list(lf), int(L.value)
 
     def align(self, pol: A.Policy, batch: ReadBatch, hit_cap=None, mm_per_hit=8, counts=None,
-              n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024):
+              n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024, no_rl=False):
         n = batch.n
         hit_cap = hit_cap or (64 if pol.all_hits else max(1, min(int(pol.khits), 64)))
         ent_cap = ent_cap or 12 * max(64, batch.stride)
@@ -72,7 +72,7 @@ class EmuAligner:
                          pool.ctypes.data, len(pool), 0)
         rc = lib().emu_align_batch(self.h, C.byref(pol), C.byref(rb), C.byref(hb),
                                    C.byref(counts) if counts is not None else None,
-                                   n_lanes, fr_cap, ent_cap, pal_cap)
+                                   n_lanes, fr_cap, ent_cap, pal_cap, int(no_rl))
         if rc != 0:
             raise RuntimeError("emu_align_batch rc=%d" % rc)
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(pol.khits), int(pol.mhits),

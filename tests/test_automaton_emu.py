@@ -100,3 +100,38 @@ def test_emu_max_length_reads(emu):
         kw = T.MODES[mode]
         got = e.align(A.make_policy(**kw), batch, ent_cap=12 * 1024)
         T.compare_results(got, T.oracle_results("e_coli", batch, kw), mode)
+
+
+@pytest.mark.parametrize("run", T.golden_runs(reads=("syn100", "syn50lowq"), modes=("n2", "v2_a", "n3", "n2_nofw", "n1_a_m20", "v1")),
+                         ids=lambda r: r["file"][:-7])
+def test_emu_register_window_build_matches_reference_sam(run, emu):
+    """Reads of <= 112 bases normally run the build of the automaton that keeps the whole read in
+    LDS; the register-window build (longer reads) must give the same on them."""
+    batch = T.read_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = emu[run["index"]].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384,
+                                  n_lanes=37, no_rl=True)
+    T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("mode", ["v2", "n2", "n3", "n1_a_m20"])
+def test_emu_vs_oracle_ragged_read_in_lds(mode, emu):
+    """Ragged 4..112-base reads with Ns and low qualities through the read-in-LDS build: results and
+    op counts equal the oracle's, and equal the register-window build's."""
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(7)
+    reads = []
+    for i in range(300):
+        L = int(rng.integers(4, 113))
+        b = synth_reads(text, 1, L, mm_dist=(0, 1, 2, 3), seed=5000 + i, n_frac=0.2, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :L].copy(), b.qual[0, :L].tobytes()))
+    batch = pack_reads(reads)
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+    pol = A.make_policy(**kw)
+    got = emu["multi"].align(pol, batch, hit_cap=T.hit_cap_for(kw), counts=ec, pal_cap=16384, n_lanes=64, ent_cap=12 * 128)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(ec, f), f
+    T.compare_results(emu["multi"].align(pol, batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, ent_cap=12 * 128, no_rl=True), want, mode)
