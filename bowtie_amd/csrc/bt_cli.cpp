@@ -177,7 +177,6 @@ void parse_args(int argc, char** argv, Options* O)
 	memset(&O->out, 0, sizeof(O->out));
 	O->rd.format = BT_FMT_FASTQ;
 	O->out.mapq = 255;
-	bool v_mode = false, n_set = false;
 	std::vector<std::string> pos;
 	for (int i = 0; i < argc; i++) { if (i) O->cmdline.push_back(' '); O->cmdline.append(argv[i]); }
 	for (int i = 1; i < argc; i++) {
@@ -241,7 +240,7 @@ void parse_args(int argc, char** argv, Options* O)
 		case '5': O->rd.trim5 = (int32_t)parse_int(val, 0, "-5/--trim5 arg must be at least 0"); break;
 		case 'o': O->offrate = (int)parse_int(val, 1, "-o/--offrate arg must be at least 1"); break;
 		case 'e': O->pol.qual_thresh = (int32_t)parse_int(val, 1, "-e/--err arg must be at least 1"); break;
-		case 'n': O->pol.mode = BT_MODE_N; O->pol.mms = (int32_t)parse_int(val, 0, "-n/--seedmms arg must be at least 0"); n_set = true; break;
+		case 'n': O->pol.mode = BT_MODE_N; O->pol.mms = (int32_t)parse_int(val, 0, "-n/--seedmms arg must be at least 0"); break;
 		case 'l': O->pol.seed_len = (int32_t)parse_int(val, 5, "-l/--seedlen arg must be at least 5"); break;
 		case 'v': break;
 		case 'p': O->threads = (int)parse_int(val, 1, "-p/--threads arg must be at least 1"); break;
@@ -307,12 +306,11 @@ void parse_args(int argc, char** argv, Options* O)
 		default: break;
 		}
 		if (id == 'v') {
-			O->pol.mode = BT_MODE_V; O->pol.mms = (int32_t)parse_int(val, 0, "-v arg must be at least 0"); v_mode = true;
+			O->pol.mode = BT_MODE_V; O->pol.mms = (int32_t)parse_int(val, 0, "-v arg must be at least 0");
 			if (O->pol.mms > 3) die("-v arg must be at most 3");
 		}
 	}
-	(void)n_set;
-	if (v_mode && O->pol.mms == 3)
+	if (O->pol.mode == BT_MODE_V && O->pol.mms == 3)
 		die("Error: -v 3 runs the reference's best-first engine, which this build does not have (SURVEY.md 8f-1)");
 	if (O->pol.mode == BT_MODE_N && O->pol.mms > 3) die("-n/--seedmms arg must be at most 3");
 	/* positionals: [<ebwt>] <reads> [<hits>] (ebwt_search.cpp:2930-2975) */
@@ -331,7 +329,6 @@ void parse_args(int argc, char** argv, Options* O)
 		                               "         --suppress is only available for the default output type.\n");
 		O->out.suppress = 0;
 	}
-	if (O->out.sam && O->out.ref_idx) { /* SAMHitSink gets no names: indexes are printed */ }
 	if (O->threads <= 0) { const unsigned hc = std::thread::hardware_concurrency(); O->threads = hc == 0 ? 1 : (hc > 32 ? 32 : (int)hc); }
 	O->out.khits = O->pol.khits; O->out.mhits = O->pol.mhits; O->out.all_hits = O->pol.all_hits;
 }
