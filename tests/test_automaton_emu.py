@@ -114,7 +114,7 @@ def test_emu_register_window_build_matches_reference_sam(run, emu):
     T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
 
 
-@pytest.mark.parametrize("mode", ["v2", "n2", "n3", "n1_a_m20"])
+@pytest.mark.parametrize("mode", ["v0", "v2", "n2", "n3", "n1_a_m20"])
 def test_emu_vs_oracle_ragged_read_in_lds(mode, emu):
     """Ragged 4..112-base reads with Ns and low qualities through the read-in-LDS build: results and
     op counts equal the oracle's, and equal the register-window build's."""
