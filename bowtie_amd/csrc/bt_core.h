@@ -297,7 +297,7 @@ template <bool RL>
 BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t c = RL ? bt_rl_base(S, j) : (uint32_t)H.seq[L.roff + j];
+	uint32_t c = RL ? bt_rl_base(S, j) : (uint32_t)BT_GP(const uint8_t, H.seq)[L.roff + j];
 	if (!L.readFw && c < 4u) c ^= 3u;
 	return bt_apply_muts(L, i, c);
 }
@@ -305,7 +305,7 @@ template <bool RL>
 BT_HD uint32_t bt_qual(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t v = RL ? bt_rl_qual(S, j) : (uint32_t)H.qual[L.roff + j];
+	uint32_t v = RL ? bt_rl_qual(S, j) : (uint32_t)BT_GP(const uint8_t, H.qual)[L.roff + j];
 	return v >= 33u ? v - 33u : 0u;
 }
 /* copy the lane's read into its LDS slot (RL): 16 bases + 16 qualities per step */
@@ -326,7 +326,7 @@ BT_HD void bt_rl_load(const BtLane& L, const BtHot& H, const BtScratch& S)
 {
 	BT_NOUNROLL
 	for (uint32_t base = 0; base < L.plen; base += 16u)
-		bt_rl_store_chunk(S, base, *(const BtU4*)(H.seq + L.roff + base), *(const BtU4*)(H.qual + L.roff + base));
+		bt_rl_store_chunk(S, base, bt_ld4(H.seq + L.roff + base), bt_ld4(H.qual + L.roff + base));
 }
 BT_HD uint32_t bt_sel4(uint32_t k, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
@@ -342,11 +342,14 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 	return (k & 1u) ? (w >> 16) : (w & 0xffffu);
 }
 
-#define FRW(f, w) S.a->frames[((uint64_t)S.slot * S.a->frCap + (f)) * BT_FR_WORDS + (w)]
-#define PT(e, c) S.a->pairs[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + (c)]
-#define PB(e, c) S.a->pairs[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u + (c)]
-#define META(e) S.a->meta[(uint64_t)S.slot * S.a->entCap + (e)]
-#define PALS(k) S.a->pals[(uint64_t)S.slot * S.a->palCap + (k)]
+#define FRW(f, w) BT_GP(uint32_t, S.a->frames)[((uint64_t)S.slot * S.a->frCap + (f)) * BT_FR_WORDS + (w)]
+#define PT(e, c) BT_GP(uint32_t, S.a->pairs)[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + (c)]
+#define PT4(e) (S.a->pairs + ((uint64_t)S.slot * S.a->entCap + (e)) * 8u)          /* address of tops[4] */
+#define PB4(e) (S.a->pairs + ((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u)     /* address of bots[4] */
+#define PB(e, c) BT_GP(uint32_t, S.a->pairs)[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u + (c)]
+#define META(e) BT_GP(uint16_t, S.a->meta)[(uint64_t)S.slot * S.a->entCap + (e)]
+#define META_MASK(e) BT_GP(uint8_t, S.a->meta + (uint64_t)S.slot * S.a->entCap + (e))[0]   /* low byte: the eliminated-set */
+#define PALS(k) BT_GP(uint64_t, S.a->pals)[(uint64_t)S.slot * S.a->palCap + (k)]
 #define IXSEL(f) (L.mirror ? IX[1].f : IX[0].f)      /* cold: device memory */
 #define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
 #define WSEL(f) (L.mirror ? W.f[1] : W.f[0])          /* warm: LDS */
@@ -428,8 +431,8 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 {
 	L.rd = rd;
 	L.roff = (uint64_t)rd * H.stride;
-	L.plen = C.B.len[rd];
-	L.seed = C.B.seed[rd];
+	L.plen = BT_GP(const uint16_t, C.B.len)[rd];
+	L.seed = BT_GP(const uint32_t, C.B.seed)[rd];
 	L.nhits = 0; L.stored = 0; L.status = 0;
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
@@ -443,8 +446,8 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	uint32_t nsAll = 0, nsSeed = 0;
 	BT_NOUNROLL
 	for (uint32_t base = 0; base < plen; base += 16u) {
-		const BtU4 v = *(const BtU4*)(H.seq + L.roff + base);
-		if (RL) bt_rl_store_chunk(S, base, v, *(const BtU4*)(H.qual + L.roff + base));
+		const BtU4 v = bt_ld4(H.seq + L.roff + base);
+		if (RL) bt_rl_store_chunk(S, base, v, bt_ld4(H.qual + L.roff + base));
 		/* bit i of nb = byte i of the chunk is an N (code 4): exact zero-byte test on v ^ 0x04.., then
 		 * the four flag bits of each word are gathered with one multiply */
 		uint32_t nb = 0;
@@ -471,8 +474,8 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 /* FINISH_READ: publish the sink counters (hit.h:741-786); the hit slots were written as found. */
 BT_HD void bt_lane_finish(BtLane& L, const BtBatchDev& B)
 {
-	B.n_hits[L.rd] = L.nhits;
-	B.status[L.rd] = (uint8_t)L.status;
+	BT_GP(uint32_t, B.n_hits)[L.rd] = L.nhits;
+	BT_GP(uint8_t, B.status)[L.rd] = (uint8_t)L.status;
 	if (B.iters) B.iters[L.rd] = L.iters;
 	L.state = ST_IDLE;
 }
@@ -500,7 +503,7 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 			if (off + nmm <= B.mm_pool_cap) {
 				h.mm_off = off;
 				const bool flip = (ixfw != 0) != (L.readFw != 0);
-				uint16_t* mm = B.mm_pool + off;
+				auto mm = BT_GP(uint16_t, B.mm_pool + off);
 				BT_NOUNROLL
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t pos, refc;
@@ -521,7 +524,16 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 				h.nmm = 0; L.status = L.status | BT_STF_MMPOOL;
 			}
 		}
-		B.hits[(uint64_t)L.rd * B.hit_cap + L.stored] = h;
+		{
+			/* 24-byte record: one 16-byte and two 4-byte global stores */
+			static_assert(sizeof(BtHitRec) == 24, "bt_hit layout");
+			uint32_t hw[6];
+			__builtin_memcpy(hw, &h, 24);
+			uint32_t* dst = (uint32_t*)(B.hits + ((uint64_t)L.rd * B.hit_cap + L.stored));
+			BtU4 q; q.x = hw[0]; q.y = hw[1]; q.z = hw[2]; q.w = hw[3];
+			bt_st4(dst, q);
+			BT_GP(uint32_t, dst)[4] = hw[4]; BT_GP(uint32_t, dst)[5] = hw[5];
+		}
 		L.stored = L.stored + 1u;
 	} else if (L.stored < P.sinkN) {
 		L.status = L.status | BT_STF_HITCAP;
@@ -579,16 +591,16 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			BT_NOUNROLL
 			for (;;) {
 				const uint32_t elt = lo + ((hi - lo) >> 1);
-				const uint32_t lower = rstarts[elt * 3u];
-				const uint32_t upper = (elt == nFrag - 1u) ? len : rstarts[(elt + 1u) * 3u];
+				const uint32_t lower = BT_GP(const uint32_t, rstarts)[elt * 3u];
+				const uint32_t upper = (elt == nFrag - 1u) ? len : BT_GP(const uint32_t, rstarts)[(elt + 1u) * 3u];
 				probes++;
 				if (lower <= off) {
 					if (upper > off) {
 						if (off + L.qlen <= upper) {
 							uint32_t fragoff = off - lower;
 							if (!ixfw) { fragoff = (upper - lower) - fragoff - 1u; fragoff -= (L.qlen - 1u); }
-							tidx = rstarts[elt * 3u + 1u];
-							toff = fragoff + rstarts[elt * 3u + 2u];
+							tidx = BT_GP(const uint32_t, rstarts)[elt * 3u + 1u];
+							toff = fragoff + BT_GP(const uint32_t, rstarts)[elt * 3u + 2u];
 							hit = true;
 						}
 						break;
@@ -667,7 +679,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			{
 				const uint32_t e = L.ebase + (L.pi - L.depth);
 				const uint32_t el = L.pel | (1u << L.pj);           /* the mask travelled with the frame record */
-				((uint8_t*)&META(e))[0] = (uint8_t)el;
+				META_MASK(e) = (uint8_t)el;
 				L.pel = el;
 				if (L.ccValid && L.pi == L.cand) S.tos[8u * S.tosStride] = (S.tos[8u * S.tosStride] & ~15u) | el;
 				if (el == 15u) { L.candValid = 0; L.ccValid = 0; }      /* that position is exhausted: scan next time */
@@ -873,8 +885,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			uint32_t top = bt_u4_word(res.q[0], ftabOff & 3u);
 			uint32_t bot = (((ftabOff + 1u) & ~3u) == (ftabOff & ~3u)) ? bt_u4_word(res.q[0], (ftabOff + 1u) & 3u)
 			                                                          : bt_u4_word(res.x, (ftabOff + 1u) & 3u);
-			if (top > len) { const uint32_t* eftab = IXSEL(eftab); top = eftab[(top ^ BT_OFF_MASK) * 2u + 1u]; }
-			if (bot > len) { const uint32_t* eftab = IXSEL(eftab); bot = eftab[(bot ^ BT_OFF_MASK) * 2u]; }
+			if (top > len) { const uint32_t* eftab = IXSEL(eftab); top = BT_GP(const uint32_t, eftab)[(top ^ BT_OFF_MASK) * 2u + 1u]; }
+			if (bot > len) { const uint32_t* eftab = IXSEL(eftab); bot = BT_GP(const uint32_t, eftab)[(bot ^ BT_OFF_MASK) * 2u]; }
 			BT_COUNT(CN_FTAB);
 			if (L.qlen == ftabChars && bot > top) {
 				if (L.reportPartials > 0) { L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER; }
@@ -997,9 +1009,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 					ftabOff |= c << (2u * jj);
 				}
 				const uint32_t* ftab = WSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = WSEL(len);
-				ntop = ftab[ftabOff]; nbot = ftab[ftabOff + 1u];
-				if (ntop > len) ntop = eftab[(ntop ^ BT_OFF_MASK) * 2u + 1u];
-				if (nbot > len) nbot = eftab[(nbot ^ BT_OFF_MASK) * 2u];
+				ntop = BT_GP(const uint32_t, ftab)[ftabOff]; nbot = BT_GP(const uint32_t, ftab)[ftabOff + 1u];
+				if (ntop > len) ntop = BT_GP(const uint32_t, eftab)[(ntop ^ BT_OFF_MASK) * 2u + 1u];
+				if (nbot > len) nbot = BT_GP(const uint32_t, eftab)[(nbot ^ BT_OFF_MASK) * 2u];
 				BT_COUNT(CN_FTAB);
 				if (ntop == nbot) { L.ret = 0; L.state = ST_CHILD_RET; break; }
 				newDepth = ftabChars;
@@ -1016,9 +1028,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				w[FR_W5] = L.cand;
 				w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
 				w[FR_PTOP] = L.pbttop; w[FR_PBOT] = L.pbtbot; w[FR_EBASE] = L.ebase;
-				BtU4* fr = (BtU4*)&FRW(L.sd, 0);
+				uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
 				BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
-				fr[0] = q0; fr[1] = q1;
+				bt_st4(fr, q0); bt_st4(fr + 4, q1);
 				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE];
 				BT_UNROLL
 				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tos[(BT_CC_WORDS + k) * ts] = w[k];
@@ -1124,8 +1136,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				const uint32_t ac = bt_sel4(c & 3u, ta[0], ta[1], ta[2], ta[3]);
 				const uint32_t bc = bt_sel4(c & 3u, tb[0], tb[1], tb[2], tb[3]);
 				if (L.lfk == LFK_EX2) {
-					*(BtU4*)&PT(e, 0) = res.q[0];
-					*(BtU4*)&PB(e, 0) = res.q[1];
+					bt_st4(PT4(e), res.q[0]);
+					bt_st4(PB4(e), res.q[1]);
 					if (c < 4u) { L.top = ac; L.bot = bc; }
 				} else if (L.lfk == LFK_C2) {
 					L.top = ac; L.bot = bc;
@@ -1240,8 +1252,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				/* depth 0: the fchr quartet (:531-543) */
 				const uint32_t e = L.ebase + (d - L.depth);
 				const uint32_t f0 = HFCHR(0), f1 = HFCHR(1), f2 = HFCHR(2), f3 = HFCHR(3), f4 = HFCHR(4);
-				{ BtU4 v; v.x = f0; v.y = f1; v.z = f2; v.w = f3; *(BtU4*)&PT(e, 0) = v; }
-				{ BtU4 v; v.x = f1; v.y = f2; v.z = f3; v.w = f4; *(BtU4*)&PB(e, 0) = v; }
+				{ BtU4 v; v.x = f0; v.y = f1; v.z = f2; v.w = f3; bt_st4(PT4(e), v); }
+				{ BtU4 v; v.x = f1; v.y = f2; v.z = f3; v.w = f4; bt_st4(PB4(e), v); }
 				if (c < 4u) { L.top = bt_sel4(c, f0, f1, f2, f3); L.bot = bt_sel4(c, f1, f2, f3, f4); }
 				L.state = ST_STEP_POST;
 				continue;

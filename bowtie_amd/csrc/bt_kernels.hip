@@ -46,9 +46,9 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 {
 	const uint32_t sideNum = row / BT_SIDE_SYMS;
 	const uint8_t* side = s.ebwt + (uint64_t)sideNum * 64u;
-	const BtU4* s4 = (const BtU4*)side;
-	const BtU4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3];
-	const uint2 oth = *(const uint2*)((sideNum & 1u) ? side - 8 : side + 120);
+	const BtU4 q0 = bt_ld4(side), q1 = bt_ld4(side + 16), q2 = bt_ld4(side + 32), q3 = bt_ld4(side + 48);
+	const bt_vec2 ot = *BT_GP(const bt_vec2, (sideNum & 1u) ? side - 8 : side + 120);
+	const uint2 oth = make_uint2(ot.x, ot.y);
 	dev_rank4_loaded(s, row, q0, q1, q2, q3, oth, lf, L);
 }
 
@@ -122,16 +122,18 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			const uint8_t* pW = A.H.seq + L.roff + (uint64_t)req.wchunk * 16u;
 			BtU4 qa[4] = {}, qb[4] = {}, qx = {}, qw = {};
 			uint2 oa = make_uint2(0, 0), ob = make_uint2(0, 0);
+			/* every address a lane can ask for is global memory (index, scratch arenas, ftab, SA sample,
+			 * reads): plain global loads, not FLAT ones (see BT_GP) */
 			BT_UNROLL
-			for (uint32_t k = 0; k < 4u; k++) if (k < nA) qa[k] = ((const BtU4*)pA)[k];
-			if (isRank) oa = *(const uint2*)((sideA & 1u) ? pA - 8 : pA + 120);
+			for (uint32_t k = 0; k < 4u; k++) if (k < nA) qa[k] = bt_ld4(pA + 16u * k);
+			if (isRank) { const bt_vec2 t = *BT_GP(const bt_vec2, (sideA & 1u) ? pA - 8 : pA + 120); oa = make_uint2(t.x, t.y); }
 			if (hasB) {
 				BT_UNROLL
-				for (uint32_t k = 0; k < 4u; k++) qb[k] = ((const BtU4*)pB)[k];
-				ob = *(const uint2*)((sideB & 1u) ? pB - 8 : pB + 120);
+				for (uint32_t k = 0; k < 4u; k++) qb[k] = bt_ld4(pB + 16u * k);
+				const bt_vec2 t = *BT_GP(const bt_vec2, (sideB & 1u) ? pB - 8 : pB + 120); ob = make_uint2(t.x, t.y);
 			}
-			if (hasX) qx = *(const BtU4*)pX;
-			if (hasW) qw = *(const BtU4*)pW;
+			if (hasX) qx = bt_ld4(pX);
+			if (hasW) qw = bt_ld4(pW);
 			if (isRank) {
 				uint32_t lf[4], la;
 				dev_rank4_loaded(sel, rowA, qa[0], qa[1], qa[2], qa[3], oa, lf, &la);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				}
 				if (w >= A.H.n_reads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
-				bt_lane_start<RL>(L, PROG, A.H, *cold, S, (EXT && A.order) ? A.order[w] : w);
+				bt_lane_start<RL>(L, PROG, A.H, *cold, S, (EXT && A.order) ? BT_GP(const uint32_t, A.order)[w] : w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);

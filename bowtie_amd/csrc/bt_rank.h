@@ -21,6 +21,7 @@
 #define BT_RANK_H_
 
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -53,6 +54,42 @@ struct BtIndexDev {
 	uint32_t len, zOff, zSide, zSym, ftabChars, offRate, offMask, nFrag, fw, nPat;
 	uint32_t fchr[5];
 };
+
+/* ---- global-memory accessors ---------------------------------------------------------------
+ * Pointers that reach the device code through LDS or through structures in memory are generic,
+ * and a load or store through a generic pointer is a FLAT instruction: it counts on the LDS
+ * counter as well, so the next wait for an LDS read also waits for the HBM round trip of every
+ * such access still in flight.  Everything the search kernel touches outside LDS is global
+ * memory; BT_GP says so (no-op on the host build). */
+#if defined(__HIPCC__)
+typedef uint32_t bt_vec4 __attribute__((ext_vector_type(4)));
+typedef uint32_t bt_vec2 __attribute__((ext_vector_type(2)));
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BT_GP(T, p) ((__attribute__((address_space(1))) T*)(p))
+#else
+#define BT_GP(T, p) ((T*)(p))
+#endif
+BT_HD BtU4 bt_ld4(const void* p)
+{
+	BtU4 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const bt_vec4 v = *BT_GP(const bt_vec4, p);
+	r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+#else
+	memcpy(&r, p, 16);
+#endif
+	return r;
+}
+BT_HD void bt_st4(void* p, const BtU4& v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	bt_vec4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+	*BT_GP(bt_vec4, p) = t;
+#else
+	memcpy(p, &v, 16);
+#endif
+}
 
 /* counts of C,G,T among the first `bits` (0..32) symbols of w; A = bits - (C+G+T) */
 BT_HD void bt_count_word(uint64_t w, uint32_t bits, uint32_t& cC, uint32_t& cG, uint32_t& cT)
@@ -125,15 +162,15 @@ BT_UNROLL
 /* ftabHi / ftabLo (ebwt.h:985-1034) */
 BT_HD uint32_t bt_ftab_hi(const BtIndexDev& ix, uint32_t i)
 {
-	uint32_t v = ix.ftab[i];
+	uint32_t v = BT_GP(const uint32_t, ix.ftab)[i];
 	if (v <= ix.len) return v;
-	return ix.eftab[(v ^ BT_OFF_MASK) * 2u + 1u];
+	return BT_GP(const uint32_t, ix.eftab)[(v ^ BT_OFF_MASK) * 2u + 1u];
 }
 BT_HD uint32_t bt_ftab_lo(const BtIndexDev& ix, uint32_t i)
 {
-	uint32_t v = ix.ftab[i];
+	uint32_t v = BT_GP(const uint32_t, ix.ftab)[i];
 	if (v <= ix.len) return v;
-	return ix.eftab[(v ^ BT_OFF_MASK) * 2u];
+	return BT_GP(const uint32_t, ix.eftab)[(v ^ BT_OFF_MASK) * 2u];
 }
 
 /* joinedToTextOff (ebwt.h:2569-2629): joined offset -> (tidx,toff); false if [off,off+qlen)
@@ -144,8 +181,8 @@ BT_HD bool bt_joined_to_text(const BtIndexDev& ix, uint32_t qlen, uint32_t off,
 	uint32_t top = 0, bot = ix.nFrag;
 	for (;;) {
 		uint32_t elt = top + ((bot - top) >> 1);
-		uint32_t lower = ix.rstarts[elt * 3u];
-		uint32_t upper = (elt == ix.nFrag - 1u) ? ix.len : ix.rstarts[(elt + 1u) * 3u];
+		uint32_t lower = BT_GP(const uint32_t, ix.rstarts)[elt * 3u];
+		uint32_t upper = (elt == ix.nFrag - 1u) ? ix.len : BT_GP(const uint32_t, ix.rstarts)[(elt + 1u) * 3u];
 		(*probes)++;
 		if (lower <= off) {
 			if (upper > off) {
@@ -153,8 +190,8 @@ BT_HD bool bt_joined_to_text(const BtIndexDev& ix, uint32_t qlen, uint32_t off,
 				uint32_t fraglen = upper - lower;
 				uint32_t fragoff = off - lower;
 				if (!ix.fw) { fragoff = fraglen - fragoff - 1u; fragoff -= (qlen - 1u); }
-				*tidx = ix.rstarts[elt * 3u + 1u];
-				*toff = fragoff + ix.rstarts[elt * 3u + 2u];
+				*tidx = BT_GP(const uint32_t, ix.rstarts)[elt * 3u + 1u];
+				*toff = fragoff + BT_GP(const uint32_t, ix.rstarts)[elt * 3u + 2u];
 				return true;
 			}
 			top = elt;
