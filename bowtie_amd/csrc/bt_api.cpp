@@ -35,6 +35,8 @@ struct bt_ctx {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
 	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
+	uint32_t cus = 0, blocksPerCU = 2;      /* nLanes covers the widest launch (3 blocks per CU) */
+	bool rl3 = true;                        /* the three-blocks-per-CU build may be used */
 	int occ = 2;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint16_t* meta = nullptr; uint64_t* pals = nullptr;
 	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [2] spare-slot cursor,
@@ -220,8 +222,12 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	c->occ = (int)env_u32("BT_OCC", 2);               /* waves/SIMD the kernel variant is built for */
 	if (c->occ < 1) c->occ = 1;
 	if (c->occ > 4) c->occ = 4;
-	const uint32_t blocksPerCU = env_u32("BT_BLOCKS_PER_CU", (uint32_t)c->occ);
-	c->nLanes = (uint32_t)prop.multiProcessorCount * blocksPerCU * BT_BLOCK;
+	c->cus = (uint32_t)prop.multiProcessorCount;
+	c->blocksPerCU = env_u32("BT_BLOCKS_PER_CU", (uint32_t)c->occ);
+	/* reads of <= 104 bases run three blocks per CU (the LDS diet of the read-in-LDS build: measured
+	 * +15..23 % over two blocks, profiles/README.md); BT_NO_RL3=1 keeps every launch at blocksPerCU */
+	c->rl3 = env_u32("BT_NO_RL3", 0) == 0 && c->occ == 2;
+	c->nLanes = c->cus * (c->rl3 && c->blocksPerCU < 3u ? 3u : c->blocksPerCU) * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 32));
 	/* heavy-read offload is off by default: measured on MI355X (profiles/README.md) it raises lane
 	 * utilisation but lengthens the batch tail; BT_HEAVY0=<rounds> turns it on */
@@ -258,7 +264,7 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 }
 
 static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uint32_t maxLen,
-                      unsigned long long* counts_dev)
+                      unsigned long long* counts_dev, bool lens_on_device)
 {
 	if (in->n_reads == 0) { c->timed = false; return BT_OK; }
 	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
@@ -270,7 +276,20 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
 	/* short reads (all of today's sequencers' single-end lengths up to 112) keep the whole read in LDS */
-	const int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
+	int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
+	if (rl && c->rl3 && c->heavy0 == 0 && !env_u32("BT_SCHEDULE", 0)) {
+		uint32_t longest = maxLen;
+		if (lens_on_device && maxLen > BT_RL3_MAXLEN) {
+			/* only the row stride is known here: one small reduction over len[] settles it */
+			uint32_t* d_max = c->d_cursor + 7;
+			HIPCHK(hipMemsetAsync(d_max, 0, 4, c->stream));
+			if (bt_launch_maxlen(in->len, in->n_reads, d_max, c->stream) != 0) return BT_ERR_DEVICE;
+			HIPCHK(hipMemcpyAsync(&longest, d_max, 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+		}
+		if (longest <= BT_RL3_MAXLEN) rl = 2;                 /* three blocks per CU: the LDS diet */
+	}
+	const uint32_t launchLanes = c->cus * (rl == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
 	BtCold cold;
 	memset(&cold, 0, sizeof(cold));
 	cold.P = c->prog;
@@ -300,7 +319,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	A.nextSlot = c->d_cursor + 2;
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
-	const uint32_t maxBlocks = c->nLanes / BT_BLOCK;
+	const uint32_t maxBlocks = launchLanes / BT_BLOCK;
 	if (nBlocks > maxBlocks) nBlocks = maxBlocks;
 	const bool offload = c->pool1 != nullptr && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
 	const uint32_t init[8] = {0, 0, c->nLanes, 0, 0, 0, 0, 0};
@@ -356,7 +375,7 @@ extern "C" int bt_align_batch_device(bt_ctx* c, const bt_read_batch* in, bt_hit_
 {
 	if (!c || !in || !out) return BT_ERR_ARG;
 	/* lengths live in HBM: size the scratch for the row stride (>= every length) */
-	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev);
+	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev, true);
 }
 
 extern "C" int bt_ctx_sync(bt_ctx* c)
@@ -440,7 +459,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
 	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long), c->stream));
-	int rc = run_device(c, &din, &dout, maxLen, nullptr);
+	int rc = run_device(c, &din, &dout, maxLen, nullptr, false);
 	if (rc != BT_OK) return rc;
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out->n_hits, d + o_nh, 4ull * n, hipMemcpyDeviceToHost, c->stream));
@@ -464,6 +483,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 			if (rc != BT_OK) return rc;
 			b->is_big = true; b->heavy0 = 0;
 			b->nLanes = BT_BLOCK * (maxLen > 256 ? 1u : 16u);
+			b->cus = 1; b->blocksPerCU = b->nLanes / BT_BLOCK; b->rl3 = false;
 			c->big = b;
 		}
 		const uint32_t m = (uint32_t)redo.size();

@@ -100,6 +100,11 @@ struct BtScratch {
 	                                            record, [9,19) top-of-stack frame record, [19,28) that
 	                                            frame's candidate */
 	uint32_t  slot;
+	uint32_t* tosRec;   /* the top-of-stack record region of `tos` (tos + 9*tosStride, or the whole of a
+	                       smaller LDS allocation when the candidate caches are off) */
+	uint32_t  noCC;     /* 1: no LDS candidate caches (the 3-waves-per-SIMD build: LDS holds the read and
+	                       the top-of-stack record only); choosing a target then always fetches its ranges */
+	uint32_t  rlQual;   /* first quality word of `rl` = number of base words (14, or 13 for <= 104 bases) */
 	uint32_t* rl;       /* LDS copy of the lane's whole read (reads of <= BT_RL_MAXLEN bases; RL builds of the
 	                       automaton): word w at rl[w*tosStride]; [0,14) the bases, 4 bits each,
 	                       [14,42) the qualities, one byte each */
@@ -107,6 +112,9 @@ struct BtScratch {
 #define BT_RL_MAXLEN 112u
 #define BT_RL_SEQ_WORDS 14u
 #define BT_RL_WORDS 42u
+#define BT_RL3_MAXLEN 104u       /* the 3-waves-per-SIMD build: 13 base words + 26 quality words */
+#define BT_RL3_SEQ_WORDS 13u
+#define BT_RL3_WORDS 39u
 
 /* ---- batch-level arguments --------------------------------------------------------------- */
 struct BtHitRec {            /* == bt_hit (include/bowtie_amd.h) */
@@ -291,7 +299,7 @@ BT_HD uint32_t bt_rl_base(const BtScratch& S, uint32_t j)
 }
 BT_HD uint32_t bt_rl_qual(const BtScratch& S, uint32_t j)
 {
-	return (S.rl[(BT_RL_SEQ_WORDS + (j >> 2)) * S.tosStride] >> ((j & 3u) * 8u)) & 0xffu;
+	return (S.rl[(S.rlQual + (j >> 2)) * S.tosStride] >> ((j & 3u) * 8u)) & 0xffu;
 }
 template <bool RL>
 BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
@@ -317,10 +325,13 @@ BT_HD void bt_rl_store_chunk(const BtScratch& S, uint32_t base, const BtU4& sv, 
 	for (int k = 0; k < 4; k++)
 		p[k] = (w[k] & 0xfu) | ((w[k] >> 4) & 0xf0u) | ((w[k] >> 8) & 0xf00u) | ((w[k] >> 12) & 0xf000u);
 	const uint32_t ts = S.tosStride;
+	/* the last chunk of a 104-base layout (13 + 26 words) is half a chunk: its upper half is padding */
+	const bool full = (base >> 3) + 1u < S.rlQual;
 	S.rl[((base >> 3) + 0u) * ts] = p[0] | (p[1] << 16);
-	S.rl[((base >> 3) + 1u) * ts] = p[2] | (p[3] << 16);
-	const uint32_t qb = BT_RL_SEQ_WORDS + (base >> 2);
-	S.rl[(qb + 0u) * ts] = qv.x; S.rl[(qb + 1u) * ts] = qv.y; S.rl[(qb + 2u) * ts] = qv.z; S.rl[(qb + 3u) * ts] = qv.w;
+	if (full) S.rl[((base >> 3) + 1u) * ts] = p[2] | (p[3] << 16);
+	const uint32_t qb = S.rlQual + (base >> 2);
+	S.rl[(qb + 0u) * ts] = qv.x; S.rl[(qb + 1u) * ts] = qv.y;
+	if (full) { S.rl[(qb + 2u) * ts] = qv.z; S.rl[(qb + 3u) * ts] = qv.w; }
 }
 BT_HD void bt_rl_load(const BtLane& L, const BtHot& H, const BtScratch& S)
 {
@@ -641,7 +652,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
 				BT_UNROLL
-				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) w[k] = S.tos[(BT_CC_WORDS + k) * ts];
+				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) w[k] = S.tosRec[k * ts];
 				L.tosValid = 0;
 				fromTos = true;
 			} else {
@@ -955,10 +966,12 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				tp[0] = res.q[0].x; tp[1] = res.q[0].y; tp[2] = res.q[0].z; tp[3] = res.q[0].w;
 				bp[0] = res.q[1].x; bp[1] = res.q[1].y; bp[2] = res.q[1].z; bp[3] = res.q[1].w;
 				mv = bt_u4_meta(res.x, e & 7u);
-				BT_UNROLL
-				for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = tp[k]; S.tos[(4u + k) * ts] = bp[k]; }
-				S.tos[8u * ts] = mv;
-				L.ccValid = 1;
+				if (!S.noCC) {
+					BT_UNROLL
+					for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = tp[k]; S.tos[(4u + k) * ts] = bp[k]; }
+					S.tos[8u * ts] = mv;
+					L.ccValid = 1;
+				}
 			}
 			const uint32_t el = mv & 15u, qi = mv >> 8;
 			const uint32_t sp[4] = {bp[0] - tp[0], bp[1] - tp[1], bp[2] - tp[2], bp[3] - tp[3]};
@@ -1033,7 +1046,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				bt_st4(fr, q0); bt_st4(fr + 4, q1);
 				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE];
 				BT_UNROLL
-				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tos[(BT_CC_WORDS + k) * ts] = w[k];
+				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
 				if (L.ccValid) {
 					BT_UNROLL
 					for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts] = S.tos[k * ts];
@@ -1170,11 +1183,14 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 					L.eligibleNum = L.eligibleNum + na;
 					/* deepest eligible target so far; its ranges go to the LDS candidate slot so that
 					 * choosing it later costs no fetch */
-					L.cand = d; L.candValid = 1; L.ccValid = 1;
-					const uint32_t ts = S.tosStride;
-					BT_UNROLL
-					for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = ta[k]; S.tos[(4u + k) * ts] = tb[k]; }
-					S.tos[8u * ts] = el | (q << 8);
+					L.cand = d; L.candValid = 1;
+					if (!S.noCC) {
+						L.ccValid = 1;
+						const uint32_t ts = S.tosStride;
+						BT_UNROLL
+						for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = ta[k]; S.tos[(4u + k) * ts] = tb[k]; }
+						S.tos[8u * ts] = el | (q << 8);
+					}
 				}
 			}
 			META(e) = (uint16_t)(el | (q << 8));

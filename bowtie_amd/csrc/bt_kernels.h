@@ -36,6 +36,7 @@ struct BtKernelArgs {
 
 extern "C" {
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
+int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */
 int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
                        const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
                        uint8_t* bucket, uint32_t* hist, uint32_t* order, void* stream);

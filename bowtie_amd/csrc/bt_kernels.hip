@@ -54,12 +54,14 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 
 /* EXT = true compiles in the optional machinery (heavy-read parking/adoption, heavy-first pick-up
  * order); the default launch uses the leaner EXT = false build of the same source. */
-template <int OCC, bool EXT, bool RL>
+/* LITE (with RL): the LDS diet that lets three blocks share a CU -- the read in 39 words (<= 104 bases) and
+ * the top-of-stack record only, no candidate caches (51 KB per block instead of 72). */
+template <int OCC, bool EXT, bool RL, bool LITE>
 __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A)
 {
-	__shared__ uint32_t RLB[RL ? BT_RL_WORDS * BT_BLOCK : 1];  /* RL: every lane's whole read (<= BT_RL_MAXLEN bases) */
+	__shared__ uint32_t RLB[RL ? (LITE ? BT_RL3_WORDS : BT_RL_WORDS) * BT_BLOCK : 1];  /* RL: every lane's whole read */
 	__shared__ unsigned long long CNT[CN_N + PS_N];
-	__shared__ uint32_t TOS[BT_LDS_WORDS * BT_BLOCK];          /* per lane: candidate, top-of-stack record, its candidate */
+	__shared__ uint32_t TOS[(LITE ? BT_TOS_WORDS : BT_LDS_WORDS) * BT_BLOCK];   /* per lane: candidate, top-of-stack record, its candidate */
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	__shared__ BtWarm WARM;                                    /* index geometry (see BtWarm) */
 	__shared__ BtArena ARENA;                                  /* scratch arena bases + capacities */
@@ -80,6 +82,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	S.a = &ARENA; S.slot = g;
 	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
+	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
+	S.noCC = LITE ? 1u : 0u;
+	S.rlQual = LITE ? BT_RL3_SEQ_WORDS : BT_RL_SEQ_WORDS;
 	S.rl = RLB + (RL ? threadIdx.x : 0u);
 
 	BtLane L = {};
@@ -343,25 +348,41 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 /* occ = waves per SIMD the register allocator was told to fit (1..4): the same source compiled for
  * different register budgets; which is fastest is a measured choice (bt_api.cpp, BT_OCC). */
 /* rl = every read of the batch has <= BT_RL_MAXLEN bases: the build that keeps each lane's whole read
- * in LDS (no read-window fetches); otherwise the register-window build. */
+ * in LDS (no read-window fetches); otherwise the register-window build.  rl == 2 (reads of <= BT_RL3_MAXLEN
+ * bases, occ 3): the three-blocks-per-CU diet of the same. */
 extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
 	const bool ext = a->poolIn || a->poolOut || a->order;
-#define BT_LAUNCH(O, R) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
-                             else hipLaunchKernelGGL((bt_search_kernel<O, false, R>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
-	if (rl) {
+#define BT_LAUNCH(O, R, T) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
+                                else hipLaunchKernelGGL((bt_search_kernel<O, false, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
+	if (rl == 2) {
+		BT_LAUNCH(3, true, true);
+	} else if (rl) {
 		/* the read copies take 42 KB of LDS per block: two blocks per CU at most */
-		if (occ == 1) BT_LAUNCH(1, true); else BT_LAUNCH(2, true);
+		if (occ == 1) BT_LAUNCH(1, true, false); else BT_LAUNCH(2, true, false);
 	} else {
 		switch (occ) {
-		case 1:  BT_LAUNCH(1, false); break;
-		case 2:  BT_LAUNCH(2, false); break;
-		case 3:  BT_LAUNCH(3, false); break;
-		default: BT_LAUNCH(4, false); break;
+		case 1:  BT_LAUNCH(1, false, false); break;
+		case 2:  BT_LAUNCH(2, false, false); break;
+		case 3:  BT_LAUNCH(3, false, false); break;
+		default: BT_LAUNCH(4, false, false); break;
 		}
 	}
 #undef BT_LAUNCH
+	return (int)hipGetLastError();
+}
+__global__ void bt_maxlen_kernel(const uint16_t* len, uint32_t n, uint32_t* out)
+{
+	uint32_t m = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t v = len[i]; m = v > m ? v : m; }
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, o); m = t > m ? t : m; }
+	if ((threadIdx.x & 63u) == 0) atomicMax(out, m);
+}
+extern "C" int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream)
+{
+	uint32_t nb = (n + 255u) / 256u; if (nb > 2048u) nb = 2048u;
+	hipLaunchKernelGGL(bt_maxlen_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, len, n, out);
 	return (int)hipGetLastError();
 }
 extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,

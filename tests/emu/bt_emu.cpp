@@ -46,7 +46,7 @@ extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint3
 /* Same contract as bt_align_batch (host pointers); nLanes lock-step lanes. */
 template <bool RL>
 static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
-                   bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap)
+                   bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap, bool lite)
 {
 	EmuIndex* e = (EmuIndex*)p;
 	BtCold cold;
@@ -95,6 +95,9 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		
 		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
 		scr[g].rl = rlbuf.data() + g;
+		scr[g].tosRec = scr[g].tos + (size_t)BT_CC_WORDS * nLanes;
+		scr[g].noCC = lite ? 1u : 0u;
+		scr[g].rlQual = lite ? BT_RL3_SEQ_WORDS : BT_RL_SEQ_WORDS;
 	}
 	uint32_t next = 0, live = nLanes;
 	while (live > 0) {
@@ -149,13 +152,15 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 }
 
 /* rl_mode: 0 = as the kernel launcher decides (reads of <= BT_RL_MAXLEN bases keep their read in "LDS"),
- * 1 = force the register-window build of the automaton */
+ * 1 = force the register-window build of the automaton, 2 = the lite layout of the 3-waves build */
 extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
                                bt_op_counts* counts, uint32_t nLanes, uint32_t frCap, uint32_t entCap, uint32_t palCap,
                                uint32_t rl_mode)
 {
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
-	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap);
-	return emu_run<false>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap);
+	/* rl_mode 2 = the 3-waves-per-SIMD layout: read in LDS (<= 104 bases), no candidate caches */
+	if (rl_mode == 2 && maxLen <= BT_RL3_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, true);
+	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, false);
+	return emu_run<false>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, false);
 }

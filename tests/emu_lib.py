@@ -55,7 +55,7 @@ class EmuAligner:
         return list(lf), int(L.value)
 
     def align(self, pol: A.Policy, batch: ReadBatch, hit_cap=None, mm_per_hit=8, counts=None,
-              n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024, no_rl=False):
+              n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024, no_rl=False, lite=False):
         n = batch.n
         hit_cap = hit_cap or (64 if pol.all_hits else max(1, min(int(pol.khits), 64)))
         ent_cap = ent_cap or 12 * max(64, batch.stride)
@@ -72,7 +72,7 @@ class EmuAligner:
                          pool.ctypes.data, len(pool), 0)
         rc = lib().emu_align_batch(self.h, C.byref(pol), C.byref(rb), C.byref(hb),
                                    C.byref(counts) if counts is not None else None,
-                                   n_lanes, fr_cap, ent_cap, pal_cap, int(no_rl))
+                                   n_lanes, fr_cap, ent_cap, pal_cap, 2 if lite else int(no_rl))
         if rc != 0:
             raise RuntimeError("emu_align_batch rc=%d" % rc)
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(pol.khits), int(pol.mhits),

@@ -135,3 +135,15 @@ def test_emu_vs_oracle_ragged_read_in_lds(mode, emu):
     for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
         assert getattr(oc, f) == getattr(ec, f), f
     T.compare_results(emu["multi"].align(pol, batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, ent_cap=12 * 128, no_rl=True), want, mode)
+
+
+@pytest.mark.parametrize("run", T.golden_runs(reads=("syn100", "syn50lowq", "e_coli_1000"), modes=("n2", "v2_a", "n3", "n2_k3", "n1_a_m20", "v0")),
+                         ids=lambda r: r["file"][:-7])
+def test_emu_three_wave_layout_matches_reference_sam(run, emu):
+    """The layout of the 3-waves-per-SIMD build (reads of <= 104 bases: 13 base words + 26 quality words in
+    LDS, no candidate caches, so every chosen target's ranges are fetched) gives the same alignments."""
+    batch = T.read_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = emu[run["index"]].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384,
+                                  n_lanes=37, lite=True)
+    T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
