@@ -43,10 +43,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # and corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies this kernel's 128-byte
 # side-pair fetches at 64 B (calibrated on the probe kernel, whose bytes are known:
 # profiles/r1_final/calib_fetch_size.txt), so it is doubled; WRITE_SIZE calibrates exact.
-#   (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / reads = (2 x 1.122e9 + 7.43e8) x 1024 / 16e6 = 191 KB/read
+#   (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / reads = (2 x 1.297e9 + 7.11e8) x 1024 / 16e6 = 212 KB/read
 # bench.py cannot run the profiler on itself, so `traffic` is that per-read figure times the reads of one
 # launch; null for workloads not profiled.
-MEASURED_HBM_BYTES_PER_READ = {"big_n2_100": (2 * 1.122e9 + 7.43e8) * 1024.0 / 16_000_000}
+MEASURED_HBM_BYTES_PER_READ = {"big_n2_100": (2 * 1.297e9 + 7.11e8) * 1024.0 / 16_000_000}
 
 WORKLOADS = {
     "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
