@@ -50,7 +50,7 @@ class IndexInfo(C.Structure):
 
 class ReadOpts(C.Structure):
     _fields_ = [("format", C.c_int32), ("trim5", C.c_int32), ("trim3", C.c_int32), ("qual_enc", C.c_int32),
-                ("seed", C.c_uint32), ("reserved", C.c_uint32), ("skip", C.c_uint64), ("upto", C.c_uint64)]
+                ("seed", C.c_uint32), ("flags", C.c_uint32), ("skip", C.c_uint64), ("upto", C.c_uint64)]
 
 
 class OutOpts(C.Structure):

@@ -39,6 +39,7 @@ struct Options {
 	bt_read_opts rd;
 	bt_out_opts out;
 	std::string index, reads, hits_file, rg_id;
+	std::string dump_al, dump_un, dump_max;   /* --al / --un / --max */
 	std::vector<std::string> rg_fields;
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
@@ -98,6 +99,9 @@ void usage(FILE* o)
 	    "  -B/--offbase <int> leftmost ref offset = <int> in bowtie output (default: 0)\n"
 	    "  --quiet            print nothing but the alignments\n"
 	    "  --refidx           refer to ref. seqs by 0-based index rather than name\n"
+	    "  --al <fname>       write aligned reads to file <fname>\n"
+	    "  --un <fname>       write unaligned reads to file <fname>\n"
+	    "  --max <fname>      write reads exceeding -m limit to file <fname>\n"
 	    "  --fullref          write entire ref name (default: only up to 1st space)\n"
 	    "  --suppress <cols>  suppresses given columns (comma-delim'ed) in default output\n"
 	    "  --cost / --showseed  extra columns in default output\n"
@@ -121,7 +125,7 @@ void usage(FILE* o)
 	    "  --version          print version information and quit\n"
 	    "  -h/--help          print this usage message\n"
 	    "Not in this build (best-first engine, SURVEY.md 8f-1): --best --strata -M -v 3 -1/-2 --12\n"
-	    "  --interleaved -I/-X --ff/--fr/--rf -F -Q --integer-quals --al/--un/--max -z --mm --shmem\n",
+	    "  --interleaved -I/-X --ff/--fr/--rf -F -Q --integer-quals -z\n",
 	    o);
 }
 
@@ -137,7 +141,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -159,7 +163,7 @@ const LongOpt LONGS[] = {
 	{"minins", 1, O_UNSUPPORTED_ARG}, {"maxins", 1, O_UNSUPPORTED_ARG}, {"ff", 0, O_UNSUPPORTED}, {"fr", 0, O_UNSUPPORTED},
 	{"rf", 0, O_UNSUPPORTED}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_UNSUPPORTED_ARG},
 	{"integer-quals", 0, O_UNSUPPORTED}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
-	{"al", 1, O_UNSUPPORTED_ARG}, {"un", 1, O_UNSUPPORTED_ARG}, {"max", 1, O_UNSUPPORTED_ARG}, {"phased", 0, O_UNSUPPORTED},
+	{"al", 1, O_AL}, {"un", 1, O_UN}, {"max", 1, O_MAX}, {"phased", 0, O_UNSUPPORTED},
 	{"strandfix", 0, O_UNSUPPORTED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
 	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_UNSUPPORTED},
 	{"orig", 1, O_UNSUPPORTED_ARG}, {"filepar", 0, O_UNSUPPORTED}, {"noreconcile", 0, O_UNSUPPORTED},
@@ -284,6 +288,9 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
+		case O_AL: O->dump_al = val; break;
+		case O_UN: O->dump_un = val; break;
+		case O_MAX: O->dump_max = val; break;
 		case O_VERSION: printf("bowtie-amd (%s), output-compatible with bowtie-align-s version 1.3.1\n", bt_version()); exit(0);
 		case O_SAM_RG: {
 			/* "ID:x" opens the @RG line, later fields are tab-appended (ebwt_search.cpp ARG_SAM_RG) */
@@ -546,6 +553,8 @@ int main(int argc, char** argv)
 
 	/* ---- stage 1: reader ---- */
 	std::string open_err;
+	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
+	if (dumping) O.rd.flags |= BT_READ_KEEP_RAW;
 	BtReadStream* rs = bt_io_open(O.reads.c_str(), O.rd, &open_err);
 	const int G = (int)ctxs.size();
 	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
@@ -583,6 +592,7 @@ int main(int argc, char** argv)
 	/* ---- stage 3: writer ---- */
 	bt_out_tally tally = {0, 0, 0, 0};
 	std::string fatal;
+	FILE *f_al = nullptr, *f_un = nullptr, *f_max = nullptr;
 	std::thread writer([&] {
 		std::vector<std::unique_ptr<Job>> held;              /* finished out of turn */
 		uint64_t next_seq = 0; int lasts = 0;
@@ -646,6 +656,25 @@ int main(int argc, char** argv)
 				fwrite(parts[si].data(), 1, parts[si].size(), fout);
 				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
 			}
+			if (dumping) {
+				/* HitSink::dumpAlign / dumpUnal / dumpMaxed (hit.h:385-488): the read's record as it stood in
+				 * the input; files are created when the first read goes to them; without --max, reads over
+				 * the -m ceiling go to --un */
+				const BtHostBatch& sb = *j->store;
+				size_t wi = 0;
+				for (uint32_t i = 0; i < n; i++) {
+					uint32_t tot = j->n_hits[i];
+					while (wi < j->wide.size() && j->wide[wi].read < i) wi++;
+					if (wi < j->wide.size() && j->wide[wi].read == i) tot = j->wide[wi].n_hits;
+					FILE** f; const std::string* nm;
+					if (tot == 0) { f = &f_un; nm = &O.dump_un; }
+					else if (tot > O.pol.mhits) { if (!O.dump_max.empty()) { f = &f_max; nm = &O.dump_max; } else { f = &f_un; nm = &O.dump_un; } }
+					else { f = &f_al; nm = &O.dump_al; }
+					if (nm->empty()) continue;
+					if (!*f) { *f = fopen(nm->c_str(), "wb"); if (!*f) { if (fatal.empty()) fatal = "Error: could not open read dump file " + *nm; abort_run.store(true); break; } }
+					fwrite(sb.raw.data() + sb.raw_off[i], 1, (size_t)(sb.raw_off[i + 1] - sb.raw_off[i]), *f);
+				}
+			}
 			busy_write += now_s() - tb;
 			j->wide.clear();
 			spare.try_put(j->store);
@@ -678,6 +707,9 @@ int main(int argc, char** argv)
 	}
 	fflush(fout);
 	if (fout != stdout) fclose(fout);
+	if (f_al) fclose(f_al);
+	if (f_un) fclose(f_un);
+	if (f_max) fclose(f_max);
 	bt_io_close(rs);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
 	for (bt_index* x : idxs) bt_index_free(x);

@@ -627,6 +627,21 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 	}
 	batch->name_off[n] = tot;
 	batch->names.resize((size_t)tot);
+	batch->raw_off.clear(); batch->raw.clear();
+	if (o.flags & BT_READ_KEEP_RAW) {
+		/* the records themselves, for --al/--un/--max: what the reference keeps as readOrigBuf (a final
+		 * record that the end of the file closed gets its newline) */
+		batch->raw_off.resize(n + 1);
+		uint64_t rt = 0;
+		for (size_t i = 0; i < n; i++) { batch->raw_off[i] = rt; rt += recs[i].e[3] + 1u; }
+		batch->raw_off[n] = rt;
+		batch->raw.resize((size_t)rt);
+		for (size_t i = 0; i < n; i++) {
+			const size_t have = recs[i].off + recs[i].e[3] < s->end ? recs[i].e[3] + 1u : recs[i].e[3];
+			memcpy(&batch->raw[(size_t)batch->raw_off[i]], W + recs[i].off, have);
+			if (have == recs[i].e[3]) batch->raw[(size_t)batch->raw_off[i] + have] = '\n';
+		}
+	}
 	batch->first_rdid = batch->rdid[0];
 	return BT_OK;
 }
@@ -636,7 +651,7 @@ int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* ba
 {
 	s->raw.clear(); s->recs.clear();
 	batch->n = 0;
-	if (s->o.format == BT_FMT_FASTQ && !(s->o.reserved & 1u)) return next_fastq(s, max_reads, threads, batch, err);
+	if (s->o.format == BT_FMT_FASTQ && !(s->o.flags & BT_READ_CAREFUL)) return next_fastq(s, max_reads, threads, batch, err);
 	/* ---- light parse (sequential) ---- */
 	while (!s->done && s->recs.size() < max_reads) {
 		if (s->rdid >= s->limit) { s->done = true; break; }
@@ -724,6 +739,24 @@ int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* ba
 		batch->rdid[k] = rc.rdid;
 	}
 	batch->name_off[n] = batch->names.size();
+	batch->raw_off.clear(); batch->raw.clear();
+	if (s->o.flags & BT_READ_KEEP_RAW) {
+		batch->raw_off.resize((size_t)n + 1);
+		for (uint32_t k = 0; k < n; k++) {
+			const BtRec& rc = s->recs[keep[k]];
+			batch->raw_off[k] = batch->raw.size();
+			if (s->o.format == BT_FMT_CMDLINE) {
+				/* VectorPatternSource keeps "<id>\t<seq>\t<quals>" (pat.cpp:372-392) */
+				char b[24]; snprintf(b, sizeof(b), "%llu", (unsigned long long)rc.rdid);
+				const char* r = s->raw.data() + rc.off;
+				const char* colon = (const char*)memchr(r, ':', rc.len);
+				const size_t sl = colon ? (size_t)(colon - r) : rc.len;
+				batch->raw.append(b); batch->raw.push_back('\t'); batch->raw.append(r, sl); batch->raw.push_back('\t');
+				if (colon) batch->raw.append(colon + 1, rc.len - sl - 1); else batch->raw.append(sl, 'I');
+			} else batch->raw.append(s->raw.data() + rc.off, rc.len);
+		}
+		batch->raw_off[n] = batch->raw.size();
+	}
 	auto pack = [&](int t) {
 		const size_t lo = (size_t)n * (size_t)t / (size_t)T, hi = (size_t)n * (size_t)(t + 1) / (size_t)T;
 		for (size_t k = lo; k < hi; k++) {
@@ -959,6 +992,12 @@ extern "C" int bt_reads_next(bt_reads* r, uint32_t max_reads, int threads, bt_re
 	*batch = r->batch.view();
 	if (names) *names = r->batch.names.data();
 	if (name_off) *name_off = r->batch.name_off.data();
+	return BT_OK;
+}
+extern "C" int bt_reads_raw(const bt_reads* r, const char** raw, const uint64_t** raw_off)
+{
+	if (!r || !raw || !raw_off || r->batch.raw_off.empty()) return BT_ERR_ARG;
+	*raw = r->batch.raw.data(); *raw_off = r->batch.raw_off.data();
 	return BT_OK;
 }
 extern "C" const char* bt_reads_error(const bt_reads* r) { return r ? r->err.c_str() : ""; }

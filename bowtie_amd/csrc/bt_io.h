@@ -25,6 +25,8 @@ struct BtHostBatch {
 	std::vector<uint64_t> rdid;           /* TReadId of each read (names default to it)          */
 	std::vector<uint64_t> name_off;       /* n + 1 offsets into names                            */
 	std::string names;
+	std::vector<uint64_t> raw_off;        /* bt_read_opts.reserved bit 1: n + 1 offsets into raw   */
+	std::string raw;                      /* each read's record as it stood in the input (Read::readOrigBuf) */
 	size_t cap_bytes = 0;
 
 	BtHostBatch() {}

@@ -22,10 +22,11 @@ class ReadInputError(ValueError):
 
 def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, quals: str = "phred33",
                  seed: int = 0, skip: int = 0, upto: int = 0, max_reads: int = 1 << 20,
-                 threads: int = 1, careful: bool = False) -> Iterator[ReadBatch]:
-    """Yield ReadBatch objects (copies) of up to max_reads reads each."""
+                 threads: int = 1, careful: bool = False, keep_raw: bool = False) -> Iterator[ReadBatch]:
+    """Yield ReadBatch objects (copies) of up to max_reads reads each; keep_raw adds `.raw`, the list of
+    the reads' records as they stood in the input."""
     L = lib()
-    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful), skip, upto)
+    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0), skip, upto)
     h = C.c_void_p()
     rc = L.bt_reads_open(spec.encode(), C.byref(o), C.byref(h))
     if rc != A.BT_OK:
@@ -50,7 +51,15 @@ def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, 
             off = np.ctypeslib.as_array(C.cast(noff, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
             blob = C.string_at(names, int(off[n]))
             nm = [blob[int(off[i]):int(off[i + 1])] for i in range(n)]
-            yield ReadBatch(seq, qual, ln, sd, nm)
+            rbatch = ReadBatch(seq, qual, ln, sd, nm)
+            if keep_raw:
+                rp, ro = C.c_void_p(), C.c_void_p()
+                if L.bt_reads_raw(h, C.byref(rp), C.byref(ro)) != A.BT_OK:
+                    raise BowtieAmdError(A.BT_ERR_ARG, "bt_reads_raw")
+                roff = np.ctypeslib.as_array(C.cast(ro, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+                rblob = C.string_at(rp, int(roff[n]))
+                rbatch.raw = [rblob[int(roff[i]):int(roff[i + 1])] for i in range(n)]
+            yield rbatch
     finally:
         L.bt_reads_close(h)
 

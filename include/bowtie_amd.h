@@ -217,13 +217,15 @@ int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, ui
 #define BT_QUAL_PHRED33  0  /* charToPhred33, qual.h:89-127                                      */
 #define BT_QUAL_PHRED64  1  /* --phred64-quals / --solexa1.3-quals                               */
 #define BT_QUAL_SOLEXA64 2  /* --solexa-quals                                                    */
+#define BT_READ_CAREFUL  1u /* every record through the step-by-step parser (testing)            */
+#define BT_READ_KEEP_RAW 2u /* keep each read's record text (Read::readOrigBuf) for --al/--un/--max */
 
 typedef struct bt_read_opts {
 	int32_t  format;       /* BT_FMT_*                                                        */
 	int32_t  trim5, trim3; /* -5 / -3                         pat.h TrimmingPatternSource      */
 	int32_t  qual_enc;     /* BT_QUAL_*                                                       */
 	uint32_t seed;         /* --seed: mixed into every read's seed (pat.cpp:21-57)            */
-	uint32_t reserved;     /* bit 0: every record through the step-by-step parser (testing)   */
+	uint32_t flags;        /* BT_READ_* bits                                                  */
 	uint64_t skip;         /* -s: first reads to skip         pat.cpp:113-115                 */
 	uint64_t upto;         /* -u: reads to process after the skipped ones (0 = all)
 	                          ebwt_search.cpp:891-896, 937                                    */
@@ -238,6 +240,9 @@ int  bt_reads_open(const char* spec, const bt_read_opts* opts, bt_reads** out);
  * an input error returns BT_ERR_READS; bt_reads_error() then holds the reference's message. */
 int  bt_reads_next(bt_reads* r, uint32_t max_reads, int threads, bt_read_batch* batch,
                    const char** names, const uint64_t** name_off);
+/* with BT_READ_KEEP_RAW: the records of the batch last returned, raw_off[n+1] offsets into raw --
+ * what the reference dumps for --al / --un / --max (hit.h:385-488) */
+int  bt_reads_raw(const bt_reads* r, const char** raw, const uint64_t** raw_off);
 const char* bt_reads_error(const bt_reads* r);
 void bt_reads_close(bt_reads* r);
 

@@ -120,6 +120,14 @@ def cases(plain):
         ("multi_all_m3", M, ["-a", "-m", "3", "-v", "2", "-S", "--sam-nohead"], "cli/multi.fq"),
         ("multi_all", M, ["-a", "-v", "2"], "cli/multi.fq"),
         ("multi_k2_m5", M, ["-k", "2", "-m", "5", "-n", "1"], "cli/multi.fq"),
+        # --al / --un / --max: AL, UN, MAX stand for the dump files (their contents are stored too)
+        ("dump_multi_m3", M, ["-a", "-m", "3", "-v", "2", "--al", "AL", "--un", "UN", "--max", "MAX"], "cli/multi.fq"),
+        ("dump_multi_nomax", M, ["-k", "2", "-m", "5", "-n", "1", "--al", "AL", "--un", "UN"], "cli/multi.fq"),
+        ("dump_fq", E, ["-n", "2", "--un", "UN", "--al", "AL"], "cli/io.fq"),
+        ("dump_fq_trim_skip", E, ["-5", "3", "-3", "2", "-s", "5", "-u", "40", "--al", "AL", "--un", "UN"], "cli/io.fq"),
+        ("dump_fa", E, ["-f", "-v", "2", "--al", "AL", "--un", "UN"], "cli/io.fa"),
+        ("dump_raw", E, ["-r", "-v", "1", "--un", "UN"], "cli/io.raw"),
+        ("dump_cmdline", E, ["-c", "-v", "2", "--al", "AL", "--un", "UN"], cseq),
     ]
 
 
@@ -127,9 +135,21 @@ def main():
     plain = make_inputs()
     manifest = {"reference": "BenLangmead/bowtie v1.3.1", "cwd": "tests/golden", "cases": []}
     for name, idx, args, reads in cases(plain):
-        cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", idx, reads]
+        dump_paths = {k: os.path.join(D, "_dump_%s.txt" % k) for k in ("AL", "UN", "MAX") if k in args}
+        cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + [dump_paths.get(a, a) for a in args] + ["-x", idx, reads]
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=G)
-        entry = {"name": name, "index": idx, "args": args, "reads": reads, "returncode": p.returncode,
+        dumps = {}
+        for k, path in dump_paths.items():
+            data = b""
+            if os.path.exists(path):
+                with open(path, "rb") as f:
+                    data = f.read()
+                os.remove(path)
+            fn = "cli/%s.%s.gz" % (name, k.lower())
+            with gzip.GzipFile(os.path.join(G, fn), "wb", mtime=0) as f:
+                f.write(data)
+            dumps[k] = fn
+        entry = {"name": name, "index": idx, "args": args, "reads": reads, "returncode": p.returncode, "dumps": dumps,
                  "stderr": p.stderr.decode(errors="replace").strip().split("\n"),
                  "md5": hashlib.md5(p.stdout).hexdigest(), "file": "cli/%s.out.gz" % name}
         with gzip.GzipFile(os.path.join(G, entry["file"]), "wb", mtime=0) as f:

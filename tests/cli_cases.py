@@ -67,6 +67,7 @@ def interpret(args):
         elif a == "--cost": out["print_cost"] = True
         elif a == "--showseed": out["show_seed"] = True
         elif a == "--suppress": out["suppress"] = [int(x) for x in next(it).split(",")]
+        elif a in ("--al", "--un", "--max"): ex.setdefault("dumps", {})[next(it)] = a
         else: raise ValueError("unhandled option " + a)
     for k in ("khits", "mhits", "all_hits"):
         if k in pol:
@@ -79,3 +80,8 @@ def reads_spec(case) -> str:
     if "-c" in case["args"]:
         return case["reads"]
     return ",".join(os.path.join(T.G, x) for x in case["reads"].split(","))
+
+
+def expected_dump(case, key) -> bytes:
+    with gzip.open(os.path.join(T.G, case["dumps"][key]), "rb") as f:
+        return f.read()

@@ -19,6 +19,12 @@ def run(args, index, reads, extra=()):
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
 
 
+def with_dump_paths(case, tmp_path):
+    """AL / UN / MAX in a case's arguments stand for dump files: real paths for this run."""
+    paths = {k: str(tmp_path / (k + ".txt")) for k in case.get("dumps", {})}
+    return [paths.get(a, a) for a in case["args"]], paths
+
+
 def split_pg(text: bytes):
     lines = text.split(b"\n")
     pg = [l for l in lines if l.startswith(b"@PG")]
@@ -31,9 +37,10 @@ def summary_lines(stderr: bytes):
 
 
 @pytest.mark.parametrize("case", CC.cases(), ids=lambda c: c["name"])
-def test_cli_matches_reference(case):
+def test_cli_matches_reference(case, tmp_path):
     assert os.path.exists(BIN), "bowtie-amd is not built (python -c 'import __graft_entry__ as g; g.build()')"
-    p = run(case["args"], case["index"], case["reads"])
+    args, dumps = with_dump_paths(case, tmp_path)
+    p = run(args, case["index"], case["reads"])
     assert p.returncode == 0, p.stderr.decode(errors="replace")
     want = CC.expected(case)
     got_body, got_pg = split_pg(p.stdout)
@@ -43,17 +50,24 @@ def test_cli_matches_reference(case):
     for l in got_pg:
         assert l.startswith(b'@PG\tID:Bowtie\tVN:1.3.1\tCL:"')
     assert summary_lines(p.stderr) == summary_lines("\n".join(case["stderr"]).encode())
+    for k, path in dumps.items():
+        got = open(path, "rb").read() if os.path.exists(path) else b""
+        assert got == CC.expected_dump(case, k), k
 
 
-@pytest.mark.parametrize("name", ["fq_default", "multi_all", "multi_sam_notrunc", "fq_gz_two_files", "multi_all_m3"])
-def test_cli_small_batches_and_threads_do_not_change_output(name):
+@pytest.mark.parametrize("name", ["fq_default", "multi_all", "multi_sam_notrunc", "fq_gz_two_files", "multi_all_m3", "dump_multi_m3", "dump_fq"])
+def test_cli_small_batches_and_threads_do_not_change_output(name, tmp_path):
     """Many tiny GPU batches, several host threads: same bytes (batches concatenate in read order;
     -a reads with more hits than the first pass had slots for take the second pass)."""
     case = [c for c in CC.cases() if c["name"] == name][0]
-    p = run(case["args"], case["index"], case["reads"], extra=["--batch", "37", "-p", "3"])
+    args, dumps = with_dump_paths(case, tmp_path)
+    p = run(args, case["index"], case["reads"], extra=["--batch", "37", "-p", "3"])
     assert p.returncode == 0, p.stderr.decode(errors="replace")
     assert split_pg(p.stdout)[0] == split_pg(CC.expected(case))[0]
     assert summary_lines(p.stderr) == summary_lines("\n".join(case["stderr"]).encode())
+    for k, path in dumps.items():
+        got = open(path, "rb").read() if os.path.exists(path) else b""
+        assert got == CC.expected_dump(case, k), k
 
 
 def test_cli_output_file_and_quiet(tmp_path):

@@ -15,13 +15,14 @@ from bowtie_amd.reads import pack_reads, parse_fastq
 
 def run_case(case):
     rd, pol, out, ex = CC.interpret(case["args"])
-    batch = H.read_all(CC.reads_spec(case), **rd)
+    batch = H.read_all(CC.reads_spec(case), keep_raw=bool(case.get("dumps")), **rd)
     oi = T.oracle_index(case["index"])
     cap = 1024 if pol.get("all_hits") else pol.get("khits", 1)
     per = T.oracle_results(case["index"], batch, pol, cap=cap)
     hits, nh, st, pool = H.pack_hits(per, cap)
     opts = H.out_opts(**out)
     text, tally = H.format_hits(batch, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    ex["per_read"] = per
     return batch, text, tally, opts, ex, oi
 
 
@@ -39,6 +40,15 @@ def test_parse_and_format_match_reference(case):
         for i, (a, b) in enumerate(zip(g, w)):
             assert a == b, "%s: line %d" % (case["name"], i)
         assert len(g) == len(w), case["name"]
+    if case.get("dumps"):
+        # --al / --un / --max: each read's record text goes to the file of its class (hit.h:385-488)
+        mhits = opts.mhits
+        got = {"AL": b"", "UN": b"", "MAX": b""}
+        for raw, (hs, tot, st) in zip(batch.raw, ex["per_read"]):
+            k = "UN" if tot == 0 else ("AL" if tot <= mhits else ("MAX" if "MAX" in case["dumps"] else "UN"))
+            got[k] += raw
+        for k in case["dumps"]:
+            assert got[k] == CC.expected_dump(case, k), (case["name"], k)
     got_summary = H.summary(tally).strip().split("\n")
     assert got_summary == [l for l in case["stderr"] if l.startswith("#") or l.startswith("Reported") or l.startswith("No align")]
 
