@@ -44,7 +44,7 @@ struct Options {
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false;
-	bool suppress_set = false;
+	bool suppress_set = false, int_quals = false;
 	uint32_t batch_reads = 4u << 20;
 	std::string cmdline;
 };
@@ -80,6 +80,7 @@ void usage(FILE* o)
 	    "  --phred64-quals    input quals are Phred+64 (same as --solexa1.3-quals)\n"
 	    "  --solexa-quals     input quals are from GA Pipeline ver. < 1.3\n"
 	    "  --solexa1.3-quals  input quals are from GA Pipeline ver. >= 1.3\n"
+	    "  --integer-quals    qualities are given as space-separated integers (not ASCII)\n"
 	    "Alignment:\n"
 	    "  -v <int>           report end-to-end hits w/ <=v mismatches; ignore qualities (0-2)\n"
 	    "    or\n"
@@ -125,7 +126,7 @@ void usage(FILE* o)
 	    "  --version          print version information and quit\n"
 	    "  -h/--help          print this usage message\n"
 	    "Not in this build (best-first engine, SURVEY.md 8f-1): --best --strata -M -v 3 -1/-2 --12\n"
-	    "  --interleaved -I/-X --ff/--fr/--rf -F -Q --integer-quals -z\n",
+	    "  --interleaved -I/-X --ff/--fr/--rf -F -Q -z\n",
 	    o);
 }
 
@@ -141,7 +142,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -162,7 +163,7 @@ const LongOpt LONGS[] = {
 	{"best", 0, O_UNSUPPORTED}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_UNSUPPORTED},
 	{"minins", 1, O_UNSUPPORTED_ARG}, {"maxins", 1, O_UNSUPPORTED_ARG}, {"ff", 0, O_UNSUPPORTED}, {"fr", 0, O_UNSUPPORTED},
 	{"rf", 0, O_UNSUPPORTED}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_UNSUPPORTED_ARG},
-	{"integer-quals", 0, O_UNSUPPORTED}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
+	{"integer-quals", 0, O_INTQUALS}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
 	{"al", 1, O_AL}, {"un", 1, O_UN}, {"max", 1, O_MAX}, {"phased", 0, O_UNSUPPORTED},
 	{"strandfix", 0, O_UNSUPPORTED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
 	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_UNSUPPORTED},
@@ -288,6 +289,7 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
+		case O_INTQUALS: O->int_quals = true; break;
 		case O_AL: O->dump_al = val; break;
 		case O_UN: O->dump_un = val; break;
 		case O_MAX: O->dump_max = val; break;
@@ -330,6 +332,11 @@ void parse_args(int argc, char** argv, Options* O)
 	O->reads = pos[pi++];
 	if (pi < pos.size()) O->hits_file = pos[pi++];
 	if (pi < pos.size()) { fprintf(stderr, "Extra parameter(s) specified: "); for (; pi < pos.size(); pi++) fprintf(stderr, "\"%s\"%s", pos[pi].c_str(), pi + 1 < pos.size() ? ", " : "\n"); exit(1); }
+	if (O->int_quals) {
+		/* intToPhred33 (qual.h:132-153) knows Phred and Solexa scales only */
+		if (O->rd.format != BT_FMT_FASTQ) die("Error: --integer-quals is for FASTQ input");
+		O->rd.qual_enc = O->rd.qual_enc == BT_QUAL_SOLEXA64 ? BT_QUAL_INT_SOLEXA : BT_QUAL_INT;
+	}
 	if (O->tryhard) O->pol.max_bts = INT_MAX;
 	if (O->out.sam && O->suppress_set) {
 		if (!O->quiet) fprintf(stderr, "Warning: Ignoring --suppress because output type is not default.\n"

@@ -314,6 +314,34 @@ static bool parse_fastq(const char* r, size_t n, const bt_read_opts& o, uint64_t
 	while (cur < n && (c == '\n' || c == '\r')) c = NEXT();
 	size_t nqual = 0;
 	char q;
+	if (o.qual_enc == BT_QUAL_INT || o.qual_enc == BT_QUAL_INT_SOLEXA) {
+		/* space-separated integers (pat.cpp:918-936); the reference neither trims these at the 3' end
+		 * nor compares their number with the bases -- here a mismatch in number is an error */
+		int cur_int = 0;
+		while (c != '\t' && c != '\n' && c != '\r') {
+			cur_int = cur_int * 10 + (c - '0');
+			c = NEXT();
+			if (c == ' ' || c == '\t' || c == '\n' || c == '\r') {
+				int pq = (o.qual_enc == BT_QUAL_INT_SOLEXA) ? solexa_to_phred(cur_int) + 33 : (cur_int <= 93 ? cur_int : 93) + 33;
+				if (pq < 33) { char b[96]; snprintf(b, sizeof(b), "Saw negative Phred quality %d.", pq - 33); *err = b; return false; }
+				cur_int = 0;
+				if (c == ' ') c = NEXT();
+				if (++nqual > (size_t)o.trim5) p->qual.push_back((char)pq);
+			}
+			if (cur > n + 1) break;
+		}
+		trim_end(p->qual, trimmed3);
+		if (p->qual.size() < p->seq.size()) {
+			*err = "Too few quality values for read: " + name_of(r, *p, rdid) + "\n\tare you sure this is a FASTQ-int file?";
+			return false;
+		}
+		if (p->qual.size() > p->seq.size()) {
+			*err = "Reads file contained a pattern with more than 1024 quality values.\n"
+			       "Please truncate reads and quality values and and re-run Bowtie";
+			return false;
+		}
+		return true;
+	}
 	if (!qual_to_phred33(c, o.qual_enc, &q, err)) return false;
 	if (nqual++ >= trimmed5) p->qual.push_back(q);
 	while (cur < n) {

@@ -13,7 +13,8 @@ from .aligner import BowtieAmdError, lib
 from .reads import ReadBatch
 
 FORMATS = {"fastq": A.BT_FMT_FASTQ, "fasta": A.BT_FMT_FASTA, "raw": A.BT_FMT_RAW, "cmdline": A.BT_FMT_CMDLINE}
-QUALS = {"phred33": A.BT_QUAL_PHRED33, "phred64": A.BT_QUAL_PHRED64, "solexa": A.BT_QUAL_SOLEXA64}
+QUALS = {"phred33": A.BT_QUAL_PHRED33, "phred64": A.BT_QUAL_PHRED64, "solexa": A.BT_QUAL_SOLEXA64,
+         "int": 3, "int-solexa": 4}
 
 
 class ReadInputError(ValueError):

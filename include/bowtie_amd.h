@@ -217,6 +217,9 @@ int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, ui
 #define BT_QUAL_PHRED33  0  /* charToPhred33, qual.h:89-127                                      */
 #define BT_QUAL_PHRED64  1  /* --phred64-quals / --solexa1.3-quals                               */
 #define BT_QUAL_SOLEXA64 2  /* --solexa-quals                                                    */
+#define BT_QUAL_INT      3  /* --integer-quals: space-separated Phred integers (FASTQ only;
+                               intToPhred33, qual.h:132-153; pat.cpp:918-936)                  */
+#define BT_QUAL_INT_SOLEXA 4 /* --integer-quals --solexa-quals                                   */
 #define BT_READ_CAREFUL  1u /* every record through the step-by-step parser (testing)            */
 #define BT_READ_KEEP_RAW 2u /* keep each read's record text (Read::readOrigBuf) for --al/--un/--max */
 

@@ -60,6 +60,14 @@ def make_inputs():
         for r in plain:
             sol = rng.integers(-5, 41, size=len(r[1]))
             f.write(b"\n".join([r[0], r[1], r[2], bytes(int(64 + s) for s in sol)]) + b"\n")
+    # integer qualities (Phred, and Solexa-scaled with negative values), space-separated
+    with open(os.path.join(D, "ioint.fq"), "wb") as f:
+        for r in plain[:40]:
+            f.write(b"\n".join([r[0], r[1], r[2], b" ".join(str(q - 33).encode() for q in r[3])]) + b"\n")
+    with open(os.path.join(D, "iointsol.fq"), "wb") as f:
+        for r in plain[:40]:
+            sol = rng.integers(-5, 41, size=len(r[1]))
+            f.write(b"\n".join([r[0], r[1], r[2], b" ".join(str(int(x)).encode() for x in sol)]) + b"\n")
     # FASTA: one-line records, a two-line record (only its first line is read), an empty name,
     # blank lines after a name, and a last record without a final newline (loses its last base)
     with open(os.path.join(D, "io.fa"), "wb") as f:
@@ -120,6 +128,9 @@ def cases(plain):
         ("multi_all_m3", M, ["-a", "-m", "3", "-v", "2", "-S", "--sam-nohead"], "cli/multi.fq"),
         ("multi_all", M, ["-a", "-v", "2"], "cli/multi.fq"),
         ("multi_k2_m5", M, ["-k", "2", "-m", "5", "-n", "1"], "cli/multi.fq"),
+        ("intquals", E, ["--integer-quals", "-n", "2", "-S", "--sam-nohead"], "cli/ioint.fq"),
+        ("intquals_solexa", E, ["--integer-quals", "--solexa-quals", "-n", "2", "-S", "--sam-nohead"], "cli/iointsol.fq"),
+        ("intquals_trim5", E, ["--integer-quals", "-5", "2", "-v", "2"], "cli/ioint.fq"),
         # --al / --un / --max: AL, UN, MAX stand for the dump files (their contents are stored too)
         ("dump_multi_m3", M, ["-a", "-m", "3", "-v", "2", "--al", "AL", "--un", "UN", "--max", "MAX"], "cli/multi.fq"),
         ("dump_multi_nomax", M, ["-k", "2", "-m", "5", "-n", "1", "--al", "AL", "--un", "UN"], "cli/multi.fq"),

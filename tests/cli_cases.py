@@ -53,7 +53,8 @@ def interpret(args):
         elif a == "-u": rd["upto"] = int(next(it))
         elif a == "--seed": rd["seed"] = int(next(it))
         elif a == "--phred64-quals": rd["quals"] = "phred64"
-        elif a == "--solexa-quals": rd["quals"] = "solexa"
+        elif a == "--solexa-quals": rd["quals"] = "int-solexa" if rd.get("quals") == "int" else "solexa"
+        elif a == "--integer-quals": rd["quals"] = "int-solexa" if rd.get("quals") == "solexa" else "int"
         elif a == "-S": out["sam"] = True
         elif a == "--sam-nohead": ex["sam_nohead"] = True
         elif a == "--sam-nosq": out["sam_nosq"] = True

@@ -33,7 +33,7 @@ def test_version_and_help():
     (["-v", "3", "-x", "e_coli", "cli/io.fq"], "best-first"),
     (["-M", "2", "-x", "e_coli", "cli/io.fq"], "does not have"),
     (["-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "does not have"),
-    (["--integer-quals", "-x", "e_coli", "cli/io.fq"], "does not have"),
+    (["--integer-quals", "-f", "-x", "e_coli", "cli/io.fa"], "is for FASTQ input"),
     (["-C", "-x", "e_coli", "cli/io.fq"], "colorspace"),
     (["-k", "0", "-x", "e_coli", "cli/io.fq"], "-k arg must be at least 1"),
     (["-n", "4", "-x", "e_coli", "cli/io.fq"], "at most 3"),
