@@ -4,7 +4,7 @@ from __future__ import annotations
 import ctypes as C
 
 BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, BT_ERR_OVERFLOW, BT_ERR_READS = range(8)
-BT_FMT_FASTQ, BT_FMT_FASTA, BT_FMT_RAW, BT_FMT_CMDLINE = range(4)
+BT_FMT_FASTQ, BT_FMT_FASTA, BT_FMT_RAW, BT_FMT_CMDLINE, BT_FMT_FASTA_CONT = range(5)
 BT_QUAL_PHRED33, BT_QUAL_PHRED64, BT_QUAL_SOLEXA64 = range(3)
 BT_MODE_V, BT_MODE_N = 0, 1
 BT_ST_SKIPPED, BT_ST_HITCAP, BT_ST_TOOSHORT, BT_ST_OVERFLOW, BT_ST_MMPOOL = 1, 2, 4, 8, 16
@@ -50,7 +50,8 @@ class IndexInfo(C.Structure):
 
 class ReadOpts(C.Structure):
     _fields_ = [("format", C.c_int32), ("trim5", C.c_int32), ("trim3", C.c_int32), ("qual_enc", C.c_int32),
-                ("seed", C.c_uint32), ("flags", C.c_uint32), ("skip", C.c_uint64), ("upto", C.c_uint64)]
+                ("seed", C.c_uint32), ("flags", C.c_uint32), ("skip", C.c_uint64), ("upto", C.c_uint64),
+                ("cont_len", C.c_uint32), ("cont_freq", C.c_uint32)]
 
 
 class OutOpts(C.Structure):

@@ -70,6 +70,8 @@ void usage(FILE* o)
 	    "Input:\n"
 	    "  -q                 query input files are FASTQ .fq/.fastq (default)\n"
 	    "  -f                 query input files are (multi-)FASTA .fa/.mfa\n"
+	    "  -F <len>,<int>     query input files are FASTA whose reads are the <len>-mers at every\n"
+	    "                     <int>-th position of each record\n"
 	    "  -r                 query input files are raw one-sequence-per-line\n"
 	    "  -c                 query sequences given on cmd line (as <s>)\n"
 	    "  -s/--skip <int>    skip the first <int> reads in the input\n"
@@ -126,7 +128,7 @@ void usage(FILE* o)
 	    "  --version          print version information and quit\n"
 	    "  -h/--help          print this usage message\n"
 	    "Not in this build (best-first engine, SURVEY.md 8f-1): --best --strata -M -v 3 -1/-2 --12\n"
-	    "  --interleaved -I/-X --ff/--fr/--rf -F -Q -z\n",
+	    "  --interleaved -I/-X --ff/--fr/--rf -Q -z\n",
 	    o);
 }
 
@@ -171,8 +173,8 @@ const LongOpt LONGS[] = {
 	{nullptr, 0, 0}
 };
 /* short options taking an argument */
-const char* SHORT_ARG = "us35oenlpkmBxv";
-const char* SHORT_UNSUPPORTED_ARG = "FM12IXQw";
+const char* SHORT_ARG = "us35oenlpkmBxvF";
+const char* SHORT_UNSUPPORTED_ARG = "M12IXQw";
 const char* SHORT_UNSUPPORTED = "bz";
 
 void parse_args(int argc, char** argv, Options* O)
@@ -253,6 +255,17 @@ void parse_args(int argc, char** argv, Options* O)
 		case 'm': O->pol.mhits = (uint32_t)parse_int(val, 1, "-m arg must be at least 1"); break;
 		case 'B': O->out.off_base = (int32_t)parse_int(val, -999999, "-B/--offbase arg must be at least -999999"); break;
 		case 'x': O->index = val; break;
+		case 'F': {
+			/* parsePair<size_t>(optarg, ','): two plain numbers, read length and interval */
+			char* e = nullptr;
+			const long k = strtol(val, &e, 10);
+			if (e == val || *e != ',' || k < 1 || k >= 1024) die("Error: -F takes <length>,<interval> (two numbers, length < 1024): %s", val);
+			const char* q = e + 1;
+			const long iv = strtol(q, &e, 10);
+			if (e == q || *e || iv < 1) die("Error: -F takes <length>,<interval> (two numbers, length < 1024): %s", val);
+			O->rd.format = BT_FMT_FASTA_CONT; O->rd.cont_len = (uint32_t)k; O->rd.cont_freq = (uint32_t)iv;
+			break;
+		}
 		case O_SOLEXA: O->rd.qual_enc = BT_QUAL_SOLEXA64; break;
 		case O_PHRED64: O->rd.qual_enc = BT_QUAL_PHRED64; break;
 		case O_PHRED33: O->rd.qual_enc = BT_QUAL_PHRED33; break;

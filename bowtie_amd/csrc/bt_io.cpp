@@ -61,6 +61,9 @@ struct BtReadStream {
 	uint64_t limit = ~0ull;               /* first read id that is not processed                 */
 	bool done = false;
 	std::string raw;                      /* the batch's record texts                            */
+	/* -F: the sliding window over the FASTA text (FastaContinuousPatternSource's members) */
+	size_t c_eat = 0, c_bufcur = 0; bool c_begin = true; uint64_t c_cur = 0, c_last = 0;
+	char c_buf[1024]; std::string c_prefix;
 	std::vector<BtRec> recs;
 };
 
@@ -216,6 +219,60 @@ static int light_raw(BtReadStream* s, std::string* err)
 		if (st_peek(s) == '\r') { raw.push_back('\r'); s->pos++; }
 	}
 	return 1;
+}
+
+/* -F <len>,<freq>: every len-mer at interval freq of each FASTA record, named <record name>_<offset>
+ * (pat.cpp:651-724).  The sequence name stops at its first whitespace; characters that are no
+ * nucleotide code are skipped, ambiguity codes and '-' become N. */
+static int dna_cat(int c)
+{
+	if (c < 0) return 0;
+	if (strchr("ACGTacgt", c) && c) return 1;
+	if (strchr("BDHKMNRSVWXYbdhkmnrsvwxy", c) && c) return 2;
+	return c == '-' ? 3 : 0;
+}
+static int light_fasta_cont(BtReadStream* s, std::string* err)
+{
+	(void)err;
+	const size_t length = s->o.cont_len, freq = s->o.cont_freq;
+	s->file_first = false;
+	for (;;) {
+		int c = st_getc(s);
+		if (c < 0) return 0;
+		if (c == '>') {
+			s->c_eat = length - 1; s->c_prefix.clear(); s->c_begin = true; s->c_bufcur = 0; s->c_last = s->c_cur;
+			c = st_getc(s);
+			bool sawSpace = false;
+			while (c >= 0 && c != '\n' && c != '\r') {
+				if (!sawSpace) sawSpace = isspace(c) != 0;
+				if (!sawSpace) s->c_prefix.push_back((char)c);
+				c = st_getc(s);
+			}
+			while (c == '\n' || c == '\r') c = st_getc(s);
+			if (c < 0) return 0;
+			s->c_prefix.push_back('_');
+		}
+		const int cat = dna_cat(c);
+		if (cat >= 2) c = 'N';
+		if (cat == 0) continue;
+		s->c_buf[s->c_bufcur++] = (char)c;
+		if (s->c_bufcur == 1024) s->c_bufcur = 0;
+		if (s->c_eat > 0) {
+			s->c_eat--;
+			if (!s->c_begin) s->c_cur++;
+			continue;
+		}
+		char nb[24]; snprintf(nb, sizeof(nb), "%llu", (unsigned long long)(s->c_cur - s->c_last));
+		s->raw.append(s->c_prefix); s->raw.append(nb); s->raw.push_back('\t');
+		for (size_t i = 0; i < length; i++) {
+			const size_t back = length - i;
+			s->raw.push_back(back <= s->c_bufcur ? s->c_buf[s->c_bufcur - back] : s->c_buf[s->c_bufcur + 1024 - back]);
+		}
+		s->c_eat = freq - 1;
+		s->c_cur++;
+		s->c_begin = false;
+		return 1;
+	}
 }
 
 /* ---- per-record parse ---------------------------------------------------------------------- */
@@ -409,6 +466,22 @@ static bool parse_raw(const char* r, size_t n, const bt_read_opts& o, BtParsed* 
 	trim_end(p->seq, (size_t)o.trim3);
 	p->qual.assign(p->seq.size(), 'I');
 	p->name_n = 0;                                        /* name = read id */
+	return true;
+}
+
+static bool parse_fasta_cont(const char* r, size_t n, const bt_read_opts& o, BtParsed* p)
+{
+	const uint8_t* a2d = asc2dna_table();
+	const char* tab = (const char*)memchr(r, '\t', n);
+	if (!tab || (size_t)(tab - r) + 1 >= n) { p->ok = false; return true; }
+	p->name_b = 0; p->name_n = (size_t)(tab - r);
+	/* -5 / -3 do not reach this source: the reference constructs it with both trims 0 (pat.h:600-604) */
+	(void)o;
+	for (size_t cur = (size_t)(tab - r) + 1; cur < n; cur++) {
+		const int c = (unsigned char)r[cur];
+		if (isalpha(c)) p->seq.push_back((char)a2d[c]);
+	}
+	p->qual.assign(p->seq.size(), 'I');
 	return true;
 }
 
@@ -698,6 +771,7 @@ int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* ba
 		int rc;
 		if (s->o.format == BT_FMT_FASTQ) rc = light_fastq(s, err);
 		else if (s->o.format == BT_FMT_FASTA) rc = light_fasta(s, err);
+		else if (s->o.format == BT_FMT_FASTA_CONT) rc = light_fasta_cont(s, err);
 		else rc = light_raw(s, err);
 		if (rc < 0) return BT_ERR_READS;
 		if (rc == 0) { gzclose(s->f); s->f = nullptr; continue; }
@@ -723,6 +797,7 @@ int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* ba
 			case BT_FMT_FASTQ: ok = parse_fastq(r, rc.len, s->o, rc.rdid, &parsed[i], &errs[(size_t)t]); break;
 			case BT_FMT_FASTA: ok = parse_fasta(r, rc.len, s->o, &parsed[i]); break;
 			case BT_FMT_RAW: ok = parse_raw(r, rc.len, s->o, &parsed[i]); break;
+			case BT_FMT_FASTA_CONT: ok = parse_fasta_cont(r, rc.len, s->o, &parsed[i]); break;
 			default: ok = parse_cmdline(r, rc.len, s->o, rc.rdid, &parsed[i], &errs[(size_t)t]); break;
 			}
 			if (ok && parsed[i].seq.size() > 1024) {
@@ -1004,7 +1079,8 @@ struct bt_reads {
 extern "C" int bt_reads_open(const char* spec, const bt_read_opts* opts, bt_reads** out)
 {
 	if (!spec || !opts || !out) return BT_ERR_ARG;
-	if (opts->format < BT_FMT_FASTQ || opts->format > BT_FMT_CMDLINE || opts->trim5 < 0 || opts->trim3 < 0) return BT_ERR_ARG;
+	if (opts->format < BT_FMT_FASTQ || opts->format > BT_FMT_FASTA_CONT || opts->trim5 < 0 || opts->trim3 < 0) return BT_ERR_ARG;
+	if (opts->format == BT_FMT_FASTA_CONT && (opts->cont_len < 1 || opts->cont_len >= 1024 || opts->cont_freq < 1)) return BT_ERR_ARG;
 	bt_reads* r = new bt_reads();
 	r->s = bt_io_open(spec, *opts, &r->err);
 	*out = r;

@@ -12,7 +12,8 @@ from . import _abi as A
 from .aligner import BowtieAmdError, lib
 from .reads import ReadBatch
 
-FORMATS = {"fastq": A.BT_FMT_FASTQ, "fasta": A.BT_FMT_FASTA, "raw": A.BT_FMT_RAW, "cmdline": A.BT_FMT_CMDLINE}
+FORMATS = {"fastq": A.BT_FMT_FASTQ, "fasta": A.BT_FMT_FASTA, "raw": A.BT_FMT_RAW, "cmdline": A.BT_FMT_CMDLINE,
+           "fasta-cont": A.BT_FMT_FASTA_CONT}
 QUALS = {"phred33": A.BT_QUAL_PHRED33, "phred64": A.BT_QUAL_PHRED64, "solexa": A.BT_QUAL_SOLEXA64,
          "int": 3, "int-solexa": 4}
 
@@ -23,11 +24,13 @@ class ReadInputError(ValueError):
 
 def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, quals: str = "phred33",
                  seed: int = 0, skip: int = 0, upto: int = 0, max_reads: int = 1 << 20,
-                 threads: int = 1, careful: bool = False, keep_raw: bool = False) -> Iterator[ReadBatch]:
+                 threads: int = 1, careful: bool = False, keep_raw: bool = False,
+                 cont: Tuple[int, int] = (0, 0)) -> Iterator[ReadBatch]:
     """Yield ReadBatch objects (copies) of up to max_reads reads each; keep_raw adds `.raw`, the list of
     the reads' records as they stood in the input."""
     L = lib()
-    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0), skip, upto)
+    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0), skip, upto,
+                   cont[0], cont[1])
     h = C.c_void_p()
     rc = L.bt_reads_open(spec.encode(), C.byref(o), C.byref(h))
     if rc != A.BT_OK:

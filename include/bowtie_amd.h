@@ -214,6 +214,7 @@ int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, ui
 #define BT_FMT_FASTA    1   /* -f            FastaPatternSource        pat.cpp:531-640          */
 #define BT_FMT_RAW      2   /* -r            RawPatternSource          pat.cpp:1129-1213        */
 #define BT_FMT_CMDLINE  3   /* -c            VectorPatternSource       pat.cpp:359-528          */
+#define BT_FMT_FASTA_CONT 4 /* -F <len>,<freq>  FastaContinuousPatternSource pat.cpp:651-793     */
 #define BT_QUAL_PHRED33  0  /* charToPhred33, qual.h:89-127                                      */
 #define BT_QUAL_PHRED64  1  /* --phred64-quals / --solexa1.3-quals                               */
 #define BT_QUAL_SOLEXA64 2  /* --solexa-quals                                                    */
@@ -232,6 +233,8 @@ typedef struct bt_read_opts {
 	uint64_t skip;         /* -s: first reads to skip         pat.cpp:113-115                 */
 	uint64_t upto;         /* -u: reads to process after the skipped ones (0 = all)
 	                          ebwt_search.cpp:891-896, 937                                    */
+	uint32_t cont_len;     /* -F: length of the reads cut from the FASTA records (< 1024)     */
+	uint32_t cont_freq;    /* -F: one read every cont_freq positions                          */
 } bt_read_opts;
 
 typedef struct bt_reads bt_reads;

@@ -68,6 +68,16 @@ def make_inputs():
         for r in plain[:40]:
             sol = rng.integers(-5, 41, size=len(r[1]))
             f.write(b"\n".join([r[0], r[1], r[2], b" ".join(str(int(x)).encode() for x in sol)]) + b"\n")
+    # a two-record FASTA for -F: multi-line sequence, ambiguity codes, '-', lower case, a description after the name
+    oi_e = OL.OracleIndex(os.path.join(G, "e_coli"))
+    et = "".join("ACGT"[c] for c in oi_e.joined_text()[100000:100900])
+    with open(os.path.join(D, "cont.fa"), "wb") as f:
+        a_ = et[:400]
+        a_ = a_[:90] + "RY-N" + a_[94:200].lower() + a_[200:]
+        f.write(b">ctgA first contig\n")
+        for i in range(0, len(a_), 60):
+            f.write(a_[i:i + 60].encode() + b"\n")
+        f.write(b">ctgB\n" + et[400:900].encode())
     # FASTA: one-line records, a two-line record (only its first line is read), an empty name,
     # blank lines after a name, and a last record without a final newline (loses its last base)
     with open(os.path.join(D, "io.fa"), "wb") as f:
@@ -128,6 +138,8 @@ def cases(plain):
         ("multi_all_m3", M, ["-a", "-m", "3", "-v", "2", "-S", "--sam-nohead"], "cli/multi.fq"),
         ("multi_all", M, ["-a", "-v", "2"], "cli/multi.fq"),
         ("multi_k2_m5", M, ["-k", "2", "-m", "5", "-n", "1"], "cli/multi.fq"),
+        ("fasta_cont", E, ["-F", "40,13", "-v", "2", "-S", "--sam-nohead"], "cli/cont.fa"),
+        ("fasta_cont_trim_dump", E, ["-F", "50,7", "-5", "3", "-3", "2", "-n", "2", "-s", "4", "--al", "AL", "--un", "UN"], "cli/cont.fa,cli/cont.fa"),
         ("intquals", E, ["--integer-quals", "-n", "2", "-S", "--sam-nohead"], "cli/ioint.fq"),
         ("intquals_solexa", E, ["--integer-quals", "--solexa-quals", "-n", "2", "-S", "--sam-nohead"], "cli/iointsol.fq"),
         ("intquals_trim5", E, ["--integer-quals", "-5", "2", "-v", "2"], "cli/ioint.fq"),

@@ -47,6 +47,9 @@ def interpret(args):
         elif a == "-f": rd["fmt"] = "fasta"
         elif a == "-r": rd["fmt"] = "raw"
         elif a == "-c": rd["fmt"] = "cmdline"
+        elif a == "-F":
+            k, iv = next(it).split(",")
+            rd["fmt"] = "fasta-cont"; rd["cont"] = (int(k), int(iv))
         elif a == "-5": rd["trim5"] = int(next(it))
         elif a == "-3": rd["trim3"] = int(next(it))
         elif a == "-s": rd["skip"] = int(next(it))
