@@ -81,6 +81,10 @@ def read_set(index: str, rname: str):
         return synth_reads(text, n, 50, mm_dist=(0, 1, 2, 3, 5), seed=50, lowq_frac=0.15, n_frac=0.05)
     if rname == "syn12":
         return synth_reads(text, n // 2, 12, mm_dist=(0, 0, 1), seed=12, n_frac=0.03)
+    if rname == "syn150":
+        return synth_reads(text, n // 2, 150, mm_dist=(0, 1, 2, 3, 5), seed=150, lowq_frac=0.05, n_frac=0.02)
+    if rname == "syn110":
+        return synth_reads(text, n // 2, 110, mm_dist=(0, 1, 2, 3), seed=110)
     raise KeyError(rname)
 
 

@@ -34,7 +34,7 @@ def test_rank_emu_vs_oracle(emu):
                     assert L == oL
 
 
-@pytest.mark.parametrize("run", T.golden_runs(reads=("e_coli_1000", "syn100", "syn50lowq", "syn12")),
+@pytest.mark.parametrize("run", T.golden_runs(reads=("e_coli_1000", "syn100", "syn50lowq", "syn12", "syn150", "syn110")),
                          ids=lambda r: r["file"][:-7])
 def test_emu_matches_reference_sam(run, emu):
     batch = T.read_set(run["index"], run["reads"])
