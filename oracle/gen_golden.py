@@ -44,6 +44,15 @@ MODES = {
     "n3_l22_e140_k2": ["-n", "3", "-l", "22", "-e", "140", "-k", "2"],
     "v1_k5": ["-v", "1", "-k", "5"], "n1_a_m20": ["-n", "1", "-a", "-m", "20"],
 }
+# further option sets, run on three read sets only (EXTRA_SETS)
+EXTRA_MODES = {
+    "n3_a": ["-n", "3", "-a"], "n2_e200_nomaq": ["-n", "2", "-e", "200", "--nomaqround"],
+    "n2_l12": ["-n", "2", "-l", "12"], "n2_maxbts10": ["-n", "2", "--maxbts", "10"], "n3_y": ["-n", "3", "-y"],
+    "v2_k100": ["-v", "2", "-k", "100"], "n0_a_m5": ["-n", "0", "-a", "-m", "5"], "n1_l36_e40": ["-n", "1", "-l", "36", "-e", "40"],
+    "v2_nofw_k3": ["-v", "2", "--nofw", "-k", "3"],
+}
+EXTRA_SETS = {("multi", "syn100"), ("multi", "syn50lowq"), ("e_coli", "syn100")}
+MODES.update(EXTRA_MODES)
 
 
 def run(cmd, **kw):
@@ -120,6 +129,8 @@ def main():
             if rname == "syn12" and "-a" in margs:
                 continue  # 12-mers with -a: tens of thousands of hits per read, fixture too big
             if rname in ("syn150", "syn110") and mname not in ("n2", "v2", "n3", "v2_a", "n2_k3", "v0", "n1_a_m20"):
+                continue
+            if mname in EXTRA_MODES and (idx, rname) not in EXTRA_SETS:
                 continue
             cmd = [os.path.join(BIN, "bowtie-align-s"), "--wrapper", "basic-0", "-p", "1", "-S", "--sam-nohead"] + \
                 margs + ["-x", os.path.join(G, idx), tmp]

@@ -30,6 +30,11 @@ MODES = {
     "n2_nomaq": dict(mode="n", mms=2, maq_round=False),
     "n3_l22_e140_k2": dict(mode="n", mms=3, seed_len=22, qual_thresh=140, khits=2),
     "v1_k5": dict(mode="v", mms=1, khits=5), "n1_a_m20": dict(mode="n", mms=1, all_hits=True, mhits=20),
+    "n3_a": dict(mode="n", mms=3, all_hits=True), "n2_e200_nomaq": dict(mode="n", mms=2, qual_thresh=200, maq_round=False),
+    "n2_l12": dict(mode="n", mms=2, seed_len=12), "n2_maxbts10": dict(mode="n", mms=2, max_bts=10),
+    "n3_y": dict(mode="n", mms=3, max_bts=0x7FFFFFFF), "v2_k100": dict(mode="v", mms=2, khits=100),
+    "n0_a_m5": dict(mode="n", mms=0, all_hits=True, mhits=5), "n1_l36_e40": dict(mode="n", mms=1, seed_len=36, qual_thresh=40),
+    "v2_nofw_k3": dict(mode="v", mms=2, nofw=True, khits=3),
 }
 
 
@@ -147,4 +152,4 @@ def result_digest(per_read) -> str:
 
 def hit_cap_for(kw) -> int:
     """Hit slots per read large enough that no golden case overflows (-a on the tandem repeat)."""
-    return 1024 if kw.get("all_hits") else 64
+    return 1024 if kw.get("all_hits") else max(64, int(kw.get("khits", 1)))
