@@ -14,7 +14,8 @@ class Policy(C.Structure):
     _fields_ = [("mode", C.c_int32), ("mms", C.c_int32), ("seed_len", C.c_int32),
                 ("qual_thresh", C.c_int32), ("max_bts", C.c_int32), ("nofw", C.c_int32),
                 ("norc", C.c_int32), ("maq_round", C.c_int32), ("khits", C.c_uint32),
-                ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("reserved", C.c_int32)]
+                ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("best", C.c_int32),
+                ("strata", C.c_int32), ("sample_max", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class ReadBatchC(C.Structure):
@@ -70,8 +71,15 @@ HIT_DTYPE = [("tidx", "<u4"), ("toff", "<u4"), ("oms", "<u4"), ("mm_off", "<u4")
              ("nmm", "<u2"), ("stratum", "u1"), ("fw", "u1"), ("pad", "u1", (2,))]
 
 
-def make_policy(mode="n", mms=2, seed_len=28, qual_thresh=70, max_bts=125, nofw=False, norc=False,
-                maq_round=True, khits=1, mhits=0xFFFFFFFF, all_hits=False) -> Policy:
-    """Reference defaults: -n 2 -l 28 -e 70 --maxbts 125 -k 1 (ebwt_search.cpp:153-253)."""
+def make_policy(mode="n", mms=2, seed_len=28, qual_thresh=70, max_bts=None, nofw=False, norc=False,
+                maq_round=True, khits=1, mhits=0xFFFFFFFF, all_hits=False, best=False, strata=False,
+                sample_max=False) -> Policy:
+    """Reference defaults: -n 2 -l 28 -e 70 -k 1, --maxbts 125 (800 for the best-first workers)
+    (ebwt_search.cpp:153-253).  --strata, -M and -v 3 imply the best-first workers
+    (ebwt_search.cpp:851-853, 877-887)."""
+    best = bool(best or strata or sample_max or (mode == "v" and mms == 3))
+    if max_bts is None:
+        max_bts = 800 if best else 125
     return Policy(BT_MODE_V if mode == "v" else BT_MODE_N, mms, seed_len, qual_thresh, max_bts,
-                  int(nofw), int(norc), int(maq_round), khits, mhits, int(all_hits), 0)
+                  int(nofw), int(norc), int(maq_round), khits, mhits, int(all_hits), int(best),
+                  int(strata), int(sample_max))

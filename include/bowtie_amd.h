@@ -64,7 +64,13 @@ typedef struct bt_policy {
 	uint32_t khits;        /* -k (default 1)                      hit.h:969-985               */
 	uint32_t mhits;        /* -m (0xffffffff = unlimited)                                     */
 	int32_t  all_hits;     /* -a                                  hit.h:1201-1209             */
-	int32_t  reserved;
+	int32_t  best;         /* 1 = the reference's stateful best-first workers (--best; implied by
+	                          --strata, -M and -v 3: ebwt_search.cpp:775-776, 851-853, 877-882);
+	                          max_bts then defaults to 800 (ebwt_search.cpp:186)                */
+	int32_t  strata;       /* --strata                            hit.h:1070-1129             */
+	int32_t  sample_max;   /* -M: reads over mhits keep their first mhits hits so that one can
+	                          be sampled (hit.cpp:16-68, sam.cpp:263-311)                      */
+	int32_t  reserved[3];
 } bt_policy;
 
 void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 -k 1          */

@@ -972,6 +972,7 @@ int bto_align_read(const bto_index* ixFw, const bto_index* ixBw, const bt_policy
                    bt_op_counts* counts)
 {
 	if (len <= 0 || len > BTO_MAXLEN) return -BT_ERR_ARG;
+	if (pol->best) return bto_align_read_best(ixFw, ixBw, pol, seq, qual, len, seed, hits, cap, n_hits_total, status, counts);
 	sink_t sink;
 	memset(&sink, 0, sizeof(sink));
 	sink.n = pol->all_hits ? 0xffffffffu : pol->khits;

@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bowtie_amd.synth import synth_reads, write_fastq   # noqa: E402
 from bowtie_amd.reads import parse_fastq, pack_reads     # noqa: E402
 import oracle_lib as OL                                   # noqa: E402
+from best_modes import BEST_CORE, BEST_EXTRA             # noqa: E402
 
 REF = "/root/reference"
 G = os.path.join(ROOT, "tests", "golden")
@@ -53,6 +54,11 @@ EXTRA_MODES = {
 }
 EXTRA_SETS = {("multi", "syn100"), ("multi", "syn50lowq"), ("e_coli", "syn100")}
 MODES.update(EXTRA_MODES)
+# the stateful best-first workers (tests/best_modes.py)
+MODES.update({k: v[0] for k, v in BEST_CORE.items()})
+MODES.update({k: v[0] for k, v in BEST_EXTRA.items()})
+BEST_EXTRA_SETS = EXTRA_SETS | {("e_coli", "e_coli_1000")}
+LONG_OK = ("n2", "v2", "n3", "v2_a", "n2_k3", "v0", "n1_a_m20", "n2_best", "v3", "n3_best", "v2_a_best_strata", "n2_M3")
 
 
 def run(cmd, **kw):
@@ -128,9 +134,11 @@ def main():
         for mname, margs in MODES.items():
             if rname == "syn12" and "-a" in margs:
                 continue  # 12-mers with -a: tens of thousands of hits per read, fixture too big
-            if rname in ("syn150", "syn110") and mname not in ("n2", "v2", "n3", "v2_a", "n2_k3", "v0", "n1_a_m20"):
+            if rname in ("syn150", "syn110") and mname not in LONG_OK:
                 continue
             if mname in EXTRA_MODES and (idx, rname) not in EXTRA_SETS:
+                continue
+            if mname in BEST_EXTRA and (idx, rname) not in BEST_EXTRA_SETS:
                 continue
             cmd = [os.path.join(BIN, "bowtie-align-s"), "--wrapper", "basic-0", "-p", "1", "-S", "--sam-nohead"] + \
                 margs + ["-x", os.path.join(G, idx), tmp]

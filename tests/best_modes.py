@@ -1,0 +1,45 @@
+"""Option sets that send the reference down its stateful best-first workers (--best, --strata, -M,
+-v 3): name -> (reference command-line arguments, make_policy keywords).  Shared by
+oracle/gen_golden.py (which runs the unmodified reference on them) and the parity tests."""
+
+# run on every read set
+BEST_CORE = {
+    "n2_best": (["-n", "2", "--best"], dict(mode="n", mms=2, best=True)),
+    "v0_best": (["-v", "0", "--best"], dict(mode="v", mms=0, best=True)),
+    "v1_best": (["-v", "1", "--best"], dict(mode="v", mms=1, best=True)),
+    "v2_best": (["-v", "2", "--best"], dict(mode="v", mms=2, best=True)),
+    "v3": (["-v", "3"], dict(mode="v", mms=3)),
+    "n0_best": (["-n", "0", "--best"], dict(mode="n", mms=0, best=True)),
+    "n1_best": (["-n", "1", "--best"], dict(mode="n", mms=1, best=True)),
+    "n3_best": (["-n", "3", "--best"], dict(mode="n", mms=3, best=True)),
+    "v2_a_best_strata": (["-v", "2", "-a", "--best", "--strata"], dict(mode="v", mms=2, all_hits=True, strata=True)),
+    "n2_k3_best": (["-n", "2", "-k", "3", "--best"], dict(mode="n", mms=2, khits=3, best=True)),
+    "n2_M3": (["-n", "2", "-M", "3"], dict(mode="n", mms=2, mhits=3, sample_max=True)),
+    "n2_k2_best_strata_m5": (["-n", "2", "-k", "2", "--best", "--strata", "-m", "5"],
+                             dict(mode="n", mms=2, khits=2, mhits=5, strata=True)),
+}
+# run on the EXTRA_SETS of oracle/gen_golden.py and on reads/e_coli_1000.fq
+BEST_EXTRA = {
+    "v3_a_best_strata": (["-v", "3", "-a", "--best", "--strata"], dict(mode="v", mms=3, all_hits=True, strata=True)),
+    "n2_best_nofw": (["-n", "2", "--best", "--nofw"], dict(mode="n", mms=2, best=True, nofw=True)),
+    "n3_best_norc_k5": (["-n", "3", "--best", "--norc", "-k", "5"], dict(mode="n", mms=3, best=True, norc=True, khits=5)),
+    "n2_best_nomaq": (["-n", "2", "--best", "--nomaqround"], dict(mode="n", mms=2, best=True, maq_round=False)),
+    "n2_best_maxbts5": (["-n", "2", "--best", "--maxbts", "5"], dict(mode="n", mms=2, best=True, max_bts=5)),
+    "n3_best_maxbts20_k4": (["-n", "3", "--best", "--maxbts", "20", "-k", "4"],
+                            dict(mode="n", mms=3, best=True, max_bts=20, khits=4)),
+    "n1_best_l20_e100": (["-n", "1", "--best", "-l", "20", "-e", "100"],
+                         dict(mode="n", mms=1, best=True, seed_len=20, qual_thresh=100)),
+    "v1_M1": (["-v", "1", "-M", "1"], dict(mode="v", mms=1, mhits=1, sample_max=True)),
+    "n2_a_best_strata_m10": (["-n", "2", "-a", "--best", "--strata", "-m", "10"],
+                             dict(mode="n", mms=2, all_hits=True, strata=True, mhits=10)),
+    "n2_best_M2_k2": (["-n", "2", "--best", "-M", "2", "-k", "2"],
+                      dict(mode="n", mms=2, best=True, mhits=2, khits=2, sample_max=True)),
+    "v2_best_a": (["-v", "2", "--best", "-a"], dict(mode="v", mms=2, best=True, all_hits=True)),
+    "n3_best_a_l12_e200": (["-n", "3", "--best", "-a", "-l", "12", "-e", "200"],
+                           dict(mode="n", mms=3, best=True, all_hits=True, seed_len=12, qual_thresh=200)),
+    "n2_best_y": (["-n", "2", "--best", "-y"], dict(mode="n", mms=2, best=True, max_bts=0x7FFFFFFF)),
+    "v3_best_k10_strata": (["-v", "3", "--best", "-k", "10", "--strata"], dict(mode="v", mms=3, khits=10, strata=True)),
+    "n0_best_a_m3": (["-n", "0", "--best", "-a", "-m", "3"], dict(mode="n", mms=0, best=True, all_hits=True, mhits=3)),
+}
+BEST_MODES = dict(BEST_CORE)
+BEST_MODES.update(BEST_EXTRA)

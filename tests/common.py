@@ -14,6 +14,7 @@ import refrun as R
 from bowtie_amd import _abi as A
 from bowtie_amd.reads import pack_reads, parse_fastq
 from bowtie_amd.synth import synth_reads
+from best_modes import BEST_MODES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
@@ -36,6 +37,7 @@ MODES = {
     "n0_a_m5": dict(mode="n", mms=0, all_hits=True, mhits=5), "n1_l36_e40": dict(mode="n", mms=1, seed_len=36, qual_thresh=40),
     "v2_nofw_k3": dict(mode="v", mms=2, nofw=True, khits=3),
 }
+MODES.update({k: v[1] for k, v in BEST_MODES.items()})
 
 
 @lru_cache(maxsize=None)
@@ -109,7 +111,8 @@ def check_against_golden(run: dict, per_read, batch, refnames):
     """per_read from any backend -> SAM text; must equal the reference's output byte for byte
     (md5 of the full text) and field for field (stripped fixture)."""
     pol = MODES[run["mode"]]
-    sam = R.render(batch, per_read, refnames, sam=True, mhits=pol.get("mhits", 0xFFFFFFFF))
+    sam = R.render(batch, per_read, refnames, sam=True, mhits=pol.get("mhits", 0xFFFFFFFF),
+                   sample_max=pol.get("sample_max", False))
     with gzip.open(os.path.join(G, run["file"]), "rb") as f:
         want = f.read()
     got = strip_sam(sam)

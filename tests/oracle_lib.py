@@ -17,12 +17,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 BTO_MAXMM = 64
 
 
-class Policy(C.Structure):
-    """bt_policy (include/bowtie_amd.h)."""
-    _fields_ = [("mode", C.c_int32), ("mms", C.c_int32), ("seed_len", C.c_int32),
-                ("qual_thresh", C.c_int32), ("max_bts", C.c_int32), ("nofw", C.c_int32),
-                ("norc", C.c_int32), ("maq_round", C.c_int32), ("khits", C.c_uint32),
-                ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("reserved", C.c_int32)]
+from bowtie_amd._abi import Policy, make_policy   # noqa: E402  (bt_policy, include/bowtie_amd.h)
 
 
 class OpCounts(C.Structure):
@@ -50,10 +45,6 @@ class OIndex(C.Structure):
                 ("refnames", C.POINTER(C.c_char_p))]
 
 
-def make_policy(mode="n", mms=2, seed_len=28, qual_thresh=70, max_bts=125, nofw=False, norc=False,
-                maq_round=True, khits=1, mhits=0xFFFFFFFF, all_hits=False) -> Policy:
-    return Policy(0 if mode == "v" else 1, mms, seed_len, qual_thresh, max_bts, int(nofw), int(norc),
-                  int(maq_round), khits, mhits, int(all_hits), 0)
 
 
 _lib = None
@@ -67,7 +58,8 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH) or \
-                os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(ORACLE_DIR, "bt_oracle.c")):
+                os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(ORACLE_DIR, f))
+                                                 for f in ("bt_oracle.c", "bt_oracle_best.c", "bt_oracle.h")):
             build()
         L = C.CDLL(LIB_PATH)
         L.bto_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(OIndex)]

@@ -24,7 +24,16 @@ def run_reference(args: List[str], index_base: str, reads_path: str) -> bytes:
     return p.stdout
 
 
-def render(batch: ReadBatch, per_read, refnames, sam: bool, mhits: int = 0xFFFFFFFF) -> bytes:
+def _rand_u32(seed: int) -> int:
+    """First RandomSource::nextU32 after init(seed) (random_source.h:45-54)."""
+    last = (1664525 * seed + 1013904223) & 0xFFFFFFFF
+    ret = last >> 16
+    last = (1664525 * last + 1013904223) & 0xFFFFFFFF
+    return ret ^ last
+
+
+def render(batch: ReadBatch, per_read, refnames, sam: bool, mhits: int = 0xFFFFFFFF,
+           sample_max: bool = False) -> bytes:
     """per_read[i] = (hits(list of output.Hit), n_hits_total, status) -> reference-format text.
 
     Verbose mode prints nothing for unaligned/maxed reads (hit.h:494-500); SAM prints a flag-4
@@ -43,6 +52,21 @@ def render(batch: ReadBatch, per_read, refnames, sam: bool, mhits: int = 0xFFFFF
                     out.append(O.format_sam(name, seq, qual, h, refnames, xms=len(hits)))
                 else:
                     out.append(O.format_verbose(name, seq, qual, h, refnames))
+        elif maxed and sample_max and hits:
+            # -M: one of the hits tied for the best stratum, picked with the read's seed
+            # (VerboseHitSink::reportMaxed hit.cpp:16-68, SAMHitSink::reportMaxed sam.cpp:263-311)
+            num = 1
+            for k in range(1, len(hits)):
+                if hits[k].stratum == hits[k - 1].stratum:
+                    num += 1
+                else:
+                    break
+            h = hits[_rand_u32(int(batch.seed[i])) % num]
+            if sam:
+                out.append(O.format_sam(name, seq, qual, h, refnames, mapq=0, xms=len(hits) + 1))
+            else:
+                import dataclasses
+                out.append(O.format_verbose(name, seq, qual, dataclasses.replace(h, oms=len(hits)), refnames))
         elif sam and not maxed:
             # -m-suppressed reads print nothing unless -M (hit.h:494-500, sam.cpp:263-269)
             out.append(O.format_sam_unaligned(name, seq, qual, 0))
