@@ -139,16 +139,17 @@ class Index:
 
 
 def unpack_hits(n: int, hit_cap: int, hits: np.ndarray, n_hits: np.ndarray, status: np.ndarray,
-                mm_pool: np.ndarray, khits: int, mhits: int, all_hits: bool):
+                mm_pool: np.ndarray, khits: int, mhits: int, all_hits: bool, sample_max: bool = False):
     """-> per read (hits: List[Hit], hitsForThisRead, status), applying finishRead's rules
-    (hit.h:741-786): a read over the -m ceiling reports nothing; otherwise the first -k hits."""
+    (hit.h:741-786): a read over the -m ceiling reports nothing (with -M: keeps the first mhits
+    hits, one of which the output stage samples); otherwise the first -k hits."""
     out = []
     lim = hit_cap if all_hits else min(hit_cap, khits)
     for i in range(n):
         tot = int(n_hits[i])
         hs: List[Hit] = []
-        if tot <= mhits:
-            for k in range(min(tot, lim)):
+        if tot <= mhits or sample_max:
+            for k in range(min(mhits, hit_cap) if tot > mhits else min(tot, lim)):
                 h = hits[i * hit_cap + k]
                 off, nmm = int(h["mm_off"]), int(h["nmm"])
                 mms = [(int(e) & 0x3FF, (int(e) >> 12) & 3) for e in mm_pool[off:off + nmm]]
@@ -182,6 +183,8 @@ class Aligner:
             pass
 
     def default_hit_cap(self) -> int:
+        if self.policy.sample_max:      # -M: the first mhits hits are kept for sampling
+            return max(1, min(max(int(self.policy.khits), int(self.policy.mhits)), 64))
         return 64 if self.policy.all_hits else max(1, min(int(self.policy.khits), 64))
 
     def align(self, batch: ReadBatch, hit_cap: Optional[int] = None, mm_per_hit: int = 8,
@@ -207,7 +210,8 @@ class Aligner:
         self.last_kernel_ms = float(lib().bt_ctx_last_kernel_ms(self._h))
         self.last_retried = int(lib().bt_ctx_last_retried(self._h))
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(self.policy.khits),
-                           int(self.policy.mhits), bool(self.policy.all_hits))
+                           int(self.policy.mhits), bool(self.policy.all_hits),
+                           sample_max=bool(self.policy.sample_max))
 
     def probe_rank(self, rows: np.ndarray, mirror: bool = False) -> Tuple[np.ndarray, np.ndarray]:
         rows = np.ascontiguousarray(rows, dtype=np.uint32)

@@ -1,0 +1,1152 @@
+/*
+ * bt_best.h -- the best-first search engine, one lane = one read (gfx950 device code; also
+ * compiles for the host, where tests/emu drives it without a GPU).
+ *
+ * What it computes is what the reference's stateful workers compute for a single-end read
+ * (`--best`, `--strata`, `-M`, `-v 3`; ebwt_search.cpp:1223, 1509, 1955, 2609): the tree of
+ * RangeSourceDrivers built by Unpaired{Exact,1mm,23mm,Seed}AlignerFactory::create()
+ * (aligner_0mm.h:69, aligner_1mm.h:73, aligner_23mm.h:73, aligner_seed_mm.h:82), advanced by
+ * UnpairedAlignerV2::advance (aligner.h:503-567), each leaf an EbwtRangeSource
+ * (ebwt_search_backtrack.h:1788-2599) doing best-first branch-and-bound over a PathManager's
+ * priority queue (range_source.h:517-1574), ranges resolved row by row by RangeChaser
+ * (range_chaser.h:52-209).  Results are bit-identical, which pins down: the order of every
+ * per-read LCG draw, libstdc++'s heap sift order (keys change while a Branch is queued), and the
+ * Branch ids the reference derives from its pool allocator (pool.h:216-322).
+ *
+ * How it is laid out here (nothing like the reference's heap-allocated object graph):
+ *
+ *   * Every read owns one bump-allocated arena of 32-bit words in HBM (slot = lane).  All
+ *     "objects" are word offsets into it; nothing is ever freed (a read's arena is recycled whole
+ *     when the lane picks up its next read).
+ *   * A driver is a fixed 32-word record (BF_DRW), whatever its kind (leaf / cost-aware list /
+ *     seeded pair); the static part of the tree is instantiated from a small table the host
+ *     compiles from the policy (BfProgram), partial-alignment extenders are appended on demand.
+ *   * A Branch is a 16-word record.  Its per-position RangeStates are not stored: only positions
+ *     that still have an untried substitution get a 10-word "alternative" record, appended
+ *     behind the branch while it grows (exactly one branch grows at a time per read: a
+ *     PathManager only yields control with a freshly split front branch), so a curtailed branch
+ *     is its record plus a dense run of alternatives.  The reference keeps qlen-rdepth
+ *     RangeStates per branch (range_source.h:567-576).
+ *   * Edit lists are parent-linked (a branch stores its own edit and its parent's offset).
+ *   * Each PathManager's heap is an array of branch offsets, doubled on demand.
+ *
+ * This first version runs each lane's automaton straight through (loads where the data is
+ * needed, divergent control flow inside the wavefront); it is the parity baseline for the
+ * --best path, not yet a tuned kernel.
+ */
+#ifndef BT_BEST_H_
+#define BT_BEST_H_
+
+#include "bt_rank.h"
+#include "bt_core.h"
+
+#if defined(__HIPCC__)
+#define BF_FN __host__ __device__
+#define BF_INL __host__ __device__ __forceinline__
+#else
+#define BF_FN static
+#define BF_INL static inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BF_G __attribute__((address_space(1)))
+#else
+#define BF_G
+#endif
+
+/* ---- the policy, compiled on the host (bt_host_compile_best) ------------------------------- */
+enum { BF_PIN_BEGIN = 1, BF_PIN_LEN = 2, BF_PIN_HI_HALF = 3, BF_PIN_SEED = 4 };   /* SearchConstraintExtent */
+enum { BF_LEAF = 0, BF_COST = 1, BF_SEEDED = 2 };
+
+struct BfSpec {                   /* EbwtRangeSource + EbwtRangeSourceDriver constructor arguments */
+	uint8_t  mirror;              /* 1: searches the mirror index (ebwtBw)                        */
+	uint8_t  fw;                  /* read orientation                                             */
+	uint8_t  reportExacts, halfAndHalf, partial;
+	uint8_t  seed;                /* EbwtRangeSourceDriver::seed_: truncate the query to the seed */
+	uint8_t  nudgeLeft, useBtCnt;
+	uint8_t  rev[4];              /* rev0Off..rev3Off as BF_PIN_*                                 */
+	uint32_t qualLim, seedLen;
+};
+struct BfNode { uint8_t kind, spec, genSpec, fw; };   /* child of the top-level cost-aware driver */
+#define BF_MAX_SPECS 24
+#define BF_MAX_NODES 8
+struct BfProgram {
+	BfSpec   specs[BF_MAX_SPECS];
+	BfNode   nodes[BF_MAX_NODES];
+	uint32_t nspecs, nnodes;
+	uint32_t maq, maxBts, btCntOn, strandFix;
+	uint32_t sinkN, sinkMax, sinkAll, sinkStrata, sampleMax;
+	uint32_t needMirror;
+};
+
+/* ---- record layouts (word indices) ---------------------------------------------------------- */
+#define BF_DRW 32u
+enum {
+	DR_KIND = 0,       /* kind | fw<<8 | spec<<16                                                  */
+	DR_FLAGS,          /* 1 done, 2 foundRange                                                     */
+	DR_COST,           /* minCost | minCostAdjustment<<16                                          */
+	/* leaf (EbwtRangeSourceDriver + its PathManager + its EbwtRangeSource) */
+	LF_HEAP, LF_HEAPSZ /* sz | cap<<16 */, LF_BP /* bpCur | bpPool<<16 */, LF_BPLAST /* lastCur[0] | lastCur[1]<<16 */,
+	LF_PMCOST, LF_RND, LF_QLEN /* qlen | len<<16 */, LF_REV01, LF_REV23, LF_D53 /* depth5 | depth3<<16 */,
+	LF_RSFLAGS         /* 1 rs.done, 2 rs.foundRange, 4 skippingThisRead, 8 seedRange valid        */,
+	LF_CURTOP, LF_CURBOT, LF_CURCOST /* cost | numMms<<16 */, LF_CURBR /* branch whose edits the range carries */,
+	LF_SEED            /* seedRange: cost | n<<16 */, LF_SEEDMM0, LF_SEEDMM1, LF_SEEDMM2 /* mms | refc<<16 */,
+	/* cost-aware (CostAwareRangeSourceDriver) */
+	CA_RSS = 3, CA_NRSS /* n | cap<<16 */, CA_ACT, CA_NACT, CA_RND, CA_LAST, CA_DELAYED, CA_OPTS /* 1 strandFix, 2 patsrc set */,
+	/* seeded (EbwtSeededRangeSourceDriver) */
+	SD_FULL = 3, SD_SEED, SD_FACT
+};
+#define BF_F_DONE 1u
+#define BF_F_FOUND 2u
+
+#define BF_BRW 16u
+enum { BR_ID = 0, BR_D01, BR_D23, BR_RDLEN /* rdepth | len<<16 */, BR_COSTHAM /* cost | ham<<16 */, BR_TOP, BR_BOT,
+       BR_FLAGS /* 1 curtailed 2 exhausted 4 delayedIncrease 8 ltop valid 16 lbot valid | delayedCost<<16 */,
+       BR_LTOP, BR_LBOT, BR_ALT, BR_NALT, BR_PARENT, BR_EDIT /* pos | refc<<10 | nedits<<16 */, BR_HILO /* hi | lo<<16 */ };
+#define BRF_CURTAILED 1u
+#define BRF_EXHAUSTED 2u
+#define BRF_DELAYED 4u
+#define BRF_LTOP 8u
+#define BRF_LBOT 16u
+
+#define BF_ALW 10u     /* tops[4] bots[4] info pad; info = i | quallo<<16 | elim mask<<24 | eliminated<<28 */
+#define BF_RESERVED 64u
+#define BF_BPOOL_LIM 1927u      /* AllocOnlyPool<Branch>: 256 KB chunk / sizeof(Branch) = 136 (pool.h:198) */
+#define BF_ADV_COST_CHANGES 2
+
+struct BfChase {                  /* RangeChaser + RowChaser state */
+	uint32_t mirror, qlen, top, bot, irow, row, tidx, toff, done, cDone, cRow, cJumps, cOff;
+};
+
+struct BfLane {                   /* per-lane registers / private memory */
+	BF_G uint32_t* A;             /* this read's arena                                            */
+	uint32_t cap, top, ovf;
+	const BtIndexDev* ix;         /* [2]: text index, mirror index                                */
+	const BfProgram* P;
+	BF_G const uint8_t* seq; BF_G const uint8_t* qual;
+	uint32_t len, seed, rd;
+	int32_t  btCnt;
+	uint32_t alRnd;
+	uint32_t nhits, stored, bestStratum, status;
+	uint32_t growing;             /* branch whose alternatives are being appended (contiguity check) */
+	uint32_t c_lfex, c_lf2, c_lf1, c_chase, c_ftab, c_offs, c_rst, c_same, c_frames;
+};
+
+#define AW(o) (X.A[(o)])
+
+BF_INL uint32_t bf_rnd(uint32_t& last)                       /* RandomSource::nextU32, random_source.h:45-54 */
+{
+	last = 1664525u * last + 1013904223u;
+	uint32_t ret = last >> 16;
+	last = 1664525u * last + 1013904223u;
+	return ret ^ last;
+}
+BF_INL uint32_t bf_rnd_at(BfLane& X, uint32_t off) { uint32_t s = AW(off); uint32_t r = bf_rnd(s); AW(off) = s; return r; }
+
+BF_INL uint32_t bf_alloc(BfLane& X, uint32_t n)
+{
+	if (X.top + n > X.cap) { X.ovf = 1; return 0; }           /* offsets [0, BF_RESERVED) are a harmless dump */
+	uint32_t o = X.top; X.top += n; return o;
+}
+
+/* Read::patFw / patRc / patFwRev / patRcRev and qual / qualRev (read.h:119-133) from the one stored copy */
+BF_INL uint32_t bf_base(const BfLane& X, uint32_t fw, uint32_t ebwtFw, uint32_t i)
+{
+	uint32_t c = X.seq[(fw == ebwtFw) ? i : X.len - 1u - i];
+	return (!fw && c < 4u) ? (c ^ 3u) : c;
+}
+BF_INL uint32_t bf_qualc(const BfLane& X, uint32_t fw, uint32_t ebwtFw, uint32_t i)
+{
+	return X.qual[(fw == ebwtFw) ? i : X.len - 1u - i];
+}
+BF_INL uint32_t bf_phred(uint32_t c) { return c >= 33u ? c - 33u : 0u; }
+
+/* ---- Branch ---------------------------------------------------------------------------------- */
+BF_INL uint32_t br_cost(BfLane& X, uint32_t b) { return AW(b + BR_COSTHAM) & 0xffffu; }
+BF_INL uint32_t br_ham(BfLane& X, uint32_t b) { return AW(b + BR_COSTHAM) >> 16; }
+BF_INL void br_set_cost(BfLane& X, uint32_t b, uint32_t c) { AW(b + BR_COSTHAM) = (AW(b + BR_COSTHAM) & 0xffff0000u) | (c & 0xffffu); }
+BF_INL uint32_t br_rdepth(BfLane& X, uint32_t b) { return AW(b + BR_RDLEN) & 0xffffu; }
+BF_INL uint32_t br_len(BfLane& X, uint32_t b) { return AW(b + BR_RDLEN) >> 16; }
+BF_INL uint32_t br_nedits(BfLane& X, uint32_t b) { return AW(b + BR_EDIT) >> 16; }
+
+/* Branch::prep and the locus part of Branch::init (range_source.h:559-566, 946-954) */
+BF_INL void br_prep(BfLane& X, uint32_t b)
+{
+	const uint32_t top = AW(b + BR_TOP), bot = AW(b + BR_BOT);
+	uint32_t f = AW(b + BR_FLAGS);
+	if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; AW(b + BR_LTOP) = top; AW(b + BR_LBOT) = bot; }
+	else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; AW(b + BR_LTOP) = top; }
+	AW(b + BR_FLAGS) = f;
+}
+
+/* Branch::init (range_source.h:527-604) */
+BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32_t rdepth, uint32_t len, uint32_t cost,
+                      uint32_t ham, uint32_t top, uint32_t bot, uint32_t parent, uint32_t edit, uint32_t hilo)
+{
+	const uint32_t b = bf_alloc(X, BF_BRW);
+	AW(b + BR_ID) = id; AW(b + BR_D01) = d01; AW(b + BR_D23) = d23;
+	AW(b + BR_RDLEN) = rdepth | (len << 16); AW(b + BR_COSTHAM) = (cost & 0xffffu) | (ham << 16);
+	AW(b + BR_TOP) = top; AW(b + BR_BOT) = bot; AW(b + BR_FLAGS) = 0;
+	AW(b + BR_LTOP) = 0; AW(b + BR_LBOT) = 0; AW(b + BR_ALT) = 0; AW(b + BR_NALT) = 0;
+	AW(b + BR_PARENT) = parent; AW(b + BR_EDIT) = edit; AW(b + BR_HILO) = hilo;
+	br_prep(X, b);
+	X.c_frames++;
+	return b;
+}
+
+/* lowest marginal cost over the untried alternatives of a branch: the scan Branch::curtail
+ * (range_source.h:885-902) and Branch::splitBranch (:669-707) both make.  A position below depth0
+ * never gets an alternative record, so the records are exactly the loop's candidates. */
+BF_INL uint32_t alt_cost(uint32_t info, uint32_t rdepth, uint32_t seedLen)
+{
+	const uint32_t i = info & 0xffffu;
+	return ((rdepth + i < seedLen) ? (1u << 14) : 0u) | ((info >> 16) & 0xffu);
+}
+
+/* Branch::curtail (range_source.h:877-939) */
+BF_FN void br_curtail(BfLane& X, uint32_t b, uint32_t seedLen)
+{
+	const uint32_t alt = AW(b + BR_ALT), n = AW(b + BR_NALT), rdepth = br_rdepth(X, b);
+	uint32_t lowest = 0xffffu;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t info = AW(alt + k * BF_ALW + 8u);
+		if (info >> 28) continue;
+		const uint32_t c = alt_cost(info, rdepth, seedLen);
+		if (c < lowest) lowest = c;
+	}
+	uint32_t f = AW(b + BR_FLAGS);
+	if (lowest > 0 && lowest != 0xffffu) br_set_cost(X, b, br_cost(X, b) + lowest);
+	else if (lowest == 0xffffu) f |= BRF_EXHAUSTED;
+	AW(b + BR_FLAGS) = f | BRF_CURTAILED;
+	if (X.growing == b) X.growing = 0;
+}
+
+/* ---- CostCompare (range_source.h:1103-1142) and the heap ----------------------------------------
+ * std::priority_queue<Branch*, vector, CostCompare> = libstdc++'s __push_heap / __adjust_heap
+ * (bits/stl_heap.h); reproduced step for step because keys change while a branch is queued. */
+BF_FN bool bf_before(BfLane& X, uint32_t a, uint32_t b)        /* CostCompare()(a, b): true -> b before a */
+{
+	const uint32_t ca = br_cost(X, a), cb = br_cost(X, b);
+	if (ca != cb) return cb < ca;
+	const bool aUn = (AW(a + BR_FLAGS) & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0;
+	const bool bUn = (AW(b + BR_FLAGS) & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0;
+	if (bUn && !aUn) return false;
+	if (aUn && !bUn) return true;
+	const uint32_t ra = AW(a + BR_RDLEN), rb = AW(b + BR_RDLEN);
+	const uint32_t ta = ((ra & 0xffffu) + (ra >> 16)) & 0xffffu, tb = ((rb & 0xffffu) + (rb >> 16)) & 0xffffu;
+	if (ta != tb) return ta < tb;
+	return AW(b + BR_ID) < AW(a + BR_ID);
+}
+
+BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)          /* PathManager::push (range_source.h:1361-1372) */
+{
+	uint32_t heap = AW(d + LF_HEAP), sz = AW(d + LF_HEAPSZ) & 0xffffu, cap = AW(d + LF_HEAPSZ) >> 16;
+	if (sz == cap) {
+		const uint32_t ncap = cap ? cap * 2u : 8u;
+		if (ncap > 0xffffu) { X.ovf = 1; return; }
+		const uint32_t nh = bf_alloc(X, ncap);
+		if (X.ovf) return;
+		for (uint32_t k = 0; k < sz; k++) AW(nh + k) = AW(heap + k);
+		heap = nh; cap = ncap; AW(d + LF_HEAP) = heap;
+	}
+	uint32_t hole = sz;
+	while (hole > 0) {
+		const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
+		if (!bf_before(X, pv, v)) break;
+		AW(heap + hole) = pv; hole = parent;
+	}
+	AW(heap + hole) = v;
+	AW(d + LF_HEAPSZ) = (sz + 1u) | (cap << 16);
+	AW(d + LF_PMCOST) = br_cost(X, AW(heap));
+}
+
+/* PathManager::pop (range_source.h:1337-1356).  minCost is read from the queue's front even when
+ * the queue has just become empty: vector::front() then still sees the element just removed. */
+BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
+{
+	const uint32_t heap = AW(d + LF_HEAP), n = AW(d + LF_HEAPSZ) & 0xffffu, cap = AW(d + LF_HEAPSZ) >> 16;
+	const uint32_t top = AW(heap);
+	if (n > 1u) {
+		const uint32_t value = AW(heap + n - 1u);
+		AW(heap + n - 1u) = top;
+		const uint32_t len = n - 1u;
+		uint32_t hole = 0, second = 0;
+		while (second < (len - 1u) / 2u) {
+			second = 2u * (second + 1u);
+			if (bf_before(X, AW(heap + second), AW(heap + second - 1u))) second--;
+			AW(heap + hole) = AW(heap + second); hole = second;
+		}
+		if ((len & 1u) == 0 && second == (len - 2u) / 2u) {
+			second = 2u * (second + 1u);
+			AW(heap + hole) = AW(heap + second - 1u); hole = second - 1u;
+		}
+		while (hole > 0) {
+			const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
+			if (!bf_before(X, pv, value)) break;
+			AW(heap + hole) = pv; hole = parent;
+		}
+		AW(heap + hole) = value;
+	}
+	AW(d + LF_HEAPSZ) = (n - 1u) | (cap << 16);
+	AW(d + LF_PMCOST) = br_cost(X, n > 1u ? AW(heap) : top);
+	return top;
+}
+
+BF_INL uint32_t pm_size(BfLane& X, uint32_t d) { return AW(d + LF_HEAPSZ) & 0xffffu; }
+BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return AW(AW(d + LF_HEAP)); }
+BF_INL void pm_reset(BfLane& X, uint32_t d)                    /* PathManager::reset (range_source.h:1386-1399) */
+{
+	AW(d + LF_HEAPSZ) &= 0xffff0000u; AW(d + LF_BP) = 0; AW(d + LF_BPLAST) = 0; AW(d + LF_PMCOST) = 0;
+}
+
+/* AllocOnlyPool<Branch>::alloc + lastId (pool.h:216-223, 320-322, 335-352) */
+BF_FN uint32_t pm_alloc_id(BfLane& X, uint32_t d)
+{
+	uint32_t cur = AW(d + LF_BP) & 0xffffu, pool = AW(d + LF_BP) >> 16;
+	if (cur + 1u >= BF_BPOOL_LIM) {
+		if (pool >= 2u) { X.ovf = 1; return 0; }
+		uint32_t last = AW(d + LF_BPLAST);
+		last = pool == 0 ? ((last & 0xffff0000u) | cur) : ((last & 0xffffu) | (cur << 16));
+		AW(d + LF_BPLAST) = last;
+		pool++; cur = 0;
+	}
+	cur++;
+	AW(d + LF_BP) = cur | (pool << 16);
+	return (pool << 16) | cur;
+}
+/* AllocOnlyPool<Branch>::free(T*) (pool.h:279-292): only the topmost element's id is given back */
+BF_FN void pm_free_id(BfLane& X, uint32_t d, uint32_t id)
+{
+	uint32_t cur = AW(d + LF_BP) & 0xffffu, pool = AW(d + LF_BP) >> 16;
+	if (cur > 0 && id == ((pool << 16) | cur)) {
+		cur--;
+		if (cur == 0 && pool > 0) { pool--; const uint32_t last = AW(d + LF_BPLAST); cur = pool == 0 ? (last & 0xffffu) : (last >> 16); }
+		AW(d + LF_BP) = cur | (pool << 16);
+	}
+}
+
+/* PathManager::curtail (range_source.h:1435-1454) */
+BF_FN void pm_curtail(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen)
+{
+	const uint32_t orig = br_cost(X, br);
+	br_curtail(X, br, seedLen);
+	if (AW(br + BR_FLAGS) & BRF_EXHAUSTED) { pm_pop(X, d); pm_free_id(X, d, AW(br + BR_ID)); }
+	else if (br_cost(X, br) != orig) { const uint32_t p = pm_pop(X, d); pm_push(X, d, p); }
+}
+
+/* Branch::splitBranch + RangeState::pickEdit (range_source.h:644-773, 321-485) */
+BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uint32_t depth5)
+{
+	const uint32_t id = pm_alloc_id(X, d);
+	const uint32_t alt = AW(b + BR_ALT), n = AW(b + BR_NALT), rdepth = br_rdepth(X, b);
+	uint32_t tied[3] = {0, 0, 0}, numTied = 0, numNotElim = 0, best = 0xffffu, next = 0xffffu;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t info = AW(alt + k * BF_ALW + 8u);
+		if (info >> 28) continue;
+		numNotElim++;
+		const uint32_t c = alt_cost(info, rdepth, seedLen);
+		if (c < best) { next = best; best = c; numTied = 1; tied[0] = k; }
+		else if (c == best) {
+			if (numTied < 3u) tied[numTied++] = k;
+			else { tied[0] = tied[1]; tied[1] = tied[2]; tied[2] = k; }
+		} else if (c < next) next = c;
+	}
+	uint32_t r = 0;
+	if (numTied > 1u) r = bf_rnd_at(X, d + LF_RND) % numTied;
+	const uint32_t rec = alt + tied[r] * BF_ALW;
+	uint32_t info = AW(rec + 8u);
+	const uint32_t pos = info & 0xffffu;
+	uint32_t mask = (info >> 24) & 0xfu;                           /* bit c set: substitution to c already tried / impossible */
+	const uint32_t num = 4u - (uint32_t)__builtin_popcount(mask);
+	uint32_t chr = 0, last = 0;
+	if (num > 1u) {
+		uint32_t tot = 0;
+		for (uint32_t c = 0; c < 4u; c++) if (!((mask >> c) & 1u)) tot += AW(rec + 4u + c) - AW(rec + c);
+		uint32_t dart = bf_rnd_at(X, d + LF_RND) % tot;
+		for (uint32_t c = 0; c < 4u; c++) {
+			if ((mask >> c) & 1u) continue;
+			const uint32_t w = AW(rec + 4u + c) - AW(rec + c);
+			chr = c;
+			if (c == 3u || dart < w) break;
+			dart -= w;
+		}
+		mask |= 1u << chr;
+		info = (info & ~(0xfu << 24)) | (mask << 24);
+	} else {
+		last = 1;
+		chr = !(mask & 1u) ? 0u : !(mask & 2u) ? 1u : !(mask & 4u) ? 2u : 3u;
+		info |= 1u << 28;
+	}
+	AW(rec + 8u) = info;
+	const uint32_t top = AW(rec + chr), bot = AW(rec + 4u + chr);
+	const uint32_t depth = pos + rdepth;
+	uint32_t d01 = AW(b + BR_D01), d23 = AW(b + BR_D23);
+	const uint32_t d0 = d01 & 0xffffu, d1 = d01 >> 16, d2 = d23 & 0xffffu, d3 = d23 >> 16;
+	const uint32_t nd0 = depth < d1 ? d1 : d0, nd1 = depth < d2 ? d2 : d1, nd2 = depth < d3 ? d3 : d2;
+	const uint32_t hamadd = best & 0x3fffu;
+	uint32_t hilo = AW(b + BR_HILO);
+	if (depth < depth5) hilo += 1u; else if (depth < seedLen) hilo += 1u << 16;
+	const uint32_t nb = br_new(X, id, nd0 | (nd1 << 16), nd2 | (d3 << 16), depth + 1u, 0, br_cost(X, b),
+	                           (br_ham(X, b) + hamadd) & 0xffffu, top, bot, b,
+	                           depth | (chr << 10) | ((br_nedits(X, b) + 1u) << 16), hilo);
+	uint32_t f = AW(b + BR_FLAGS);
+	if (numNotElim == 1u && last) f |= BRF_EXHAUSTED;
+	else if (numTied == 1u && last && best != next) {
+		f = (f & 0xffffu) | BRF_DELAYED | (((br_cost(X, b) - best + next) & 0xffffu) << 16);
+	}
+	AW(b + BR_FLAGS) = f;
+	return nb;
+}
+
+/* PathManager::splitAndPrep (range_source.h:1460-1518); false = the search of this leaf ends now */
+BF_FN bool pm_split_and_prep(BfLane& X, uint32_t d, uint32_t seedLen, uint32_t depth5, bool useBtCnt)
+{
+	if (pm_size(X, d) == 0) return true;
+	if (useBtCnt && X.btCnt == 0) return false;
+	uint32_t f = pm_front(X, d);
+	while (AW(f + BR_FLAGS) & BRF_DELAYED) {
+		pm_pop(X, d);
+		const uint32_t fl = AW(f + BR_FLAGS);
+		br_set_cost(X, f, fl >> 16);
+		AW(f + BR_FLAGS) = fl & 0xffffu & ~BRF_DELAYED;
+		pm_push(X, d, f);
+		f = pm_front(X, d);
+		if (X.ovf) return false;
+	}
+	if (AW(f + BR_FLAGS) & BRF_CURTAILED) {
+		if (useBtCnt) { if (--X.btCnt == 0) return false; }
+		const uint32_t nb = br_split(X, d, f, seedLen, depth5);
+		if (X.ovf) return false;
+		if (AW(f + BR_FLAGS) & BRF_EXHAUSTED) { pm_pop(X, d); pm_free_id(X, d, AW(f + BR_ID)); }
+		pm_push(X, d, nb);
+	}
+	if (pm_size(X, d)) br_prep(X, pm_front(X, d));
+	return true;
+}
+
+/* ---- the leaf: EbwtRangeSourceDriver + EbwtRangeSource ------------------------------------------- */
+BF_INL const BfSpec& leaf_spec(BfLane& X, uint32_t d) { return X.P->specs[(AW(d + DR_KIND) >> 16) & 0xffu]; }
+
+/* the leaf's query character at offset i of its (possibly seed-edited) query: qry_ / qryBuf_
+ * (ebwt_search_backtrack.h:1831-1861) */
+BF_FN uint32_t leaf_qry(BfLane& X, uint32_t d, const BfSpec& sp, uint32_t i)
+{
+	uint32_t c = bf_base(X, sp.fw, !sp.mirror, i);
+	if (AW(d + LF_RSFLAGS) & 8u) {
+		const uint32_t n = AW(d + LF_SEED) >> 16, full = X.len;
+		for (uint32_t k = 0; k < n; k++) {
+			const uint32_t m = AW(d + LF_SEEDMM0 + k);
+			if (full - (m & 0xffffu) - 1u == i) c = m >> 16;
+		}
+	}
+	return c;
+}
+
+BF_INL uint32_t bf_cext(uint32_t cext, uint32_t sRight, uint32_t s, uint32_t len)
+{
+	return cext == BF_PIN_SEED ? s : cext == BF_PIN_HI_HALF ? sRight : cext == BF_PIN_BEGIN ? 0u : len;
+}
+
+BF_FN void leaf_init(BfLane& X, uint32_t d, uint32_t spec)
+{
+	for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
+	AW(d + DR_KIND) = BF_LEAF | ((uint32_t)X.P->specs[spec].fw << 8) | (spec << 16);
+	AW(d + DR_FLAGS) = BF_F_DONE;
+}
+
+/* the seed range a partial-alignment extender starts from: the generator's current range, copied
+ * (EbwtRangeSource::setQuery keeps a copy, ebwt_search_backtrack.h:1841) */
+BF_FN void leaf_take_seed(BfLane& X, uint32_t d, uint32_t src)
+{
+	const uint32_t n = AW(src + LF_CURCOST) >> 16, sq = AW(src + LF_QLEN) & 0xffffu;
+	AW(d + LF_SEED) = (AW(src + LF_CURCOST) & 0xffffu) | (n << 16);
+	uint32_t b = AW(src + LF_CURBR);
+	/* the edit chain runs from the newest edit to the oldest; the list order is oldest first */
+	for (uint32_t k = n; k-- > 0 && b; ) {
+		const uint32_t e = AW(b + BR_EDIT);
+		if (k < 3u) AW(d + LF_SEEDMM0 + k) = (sq - (e & 0x3ffu) - 1u) | (((e >> 10) & 3u) << 16);
+		b = AW(b + BR_PARENT);
+	}
+	AW(d + LF_RSFLAGS) |= 8u;
+}
+
+/* SingleRangeSourceDriver::setQueryImpl (range_source.h:1750-1771) with EbwtRangeSource::setQuery
+ * (ebwt_search_backtrack.h:1831-1870), EbwtRangeSourceDriver::initRangeSource (:2721-2806) and
+ * EbwtRangeSource::initBranch (:1920-2051) */
+BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
+{
+	const BfSpec& sp = leaf_spec(X, d);
+	const BtIndexDev& ix = X.ix[sp.mirror];
+	const uint32_t maq = X.P->maq;
+	AW(d + DR_FLAGS) = 0;
+	pm_reset(X, d);
+	const uint32_t len = X.len;
+	AW(d + LF_RSFLAGS) = 0;
+	if (seedSrc) leaf_take_seed(X, d, seedSrc);
+	AW(d + LF_RND) = X.seed;
+	/* initRangeSource */
+	const uint32_t s = sp.seedLen > 0 ? (sp.seedLen < len ? sp.seedLen : len) : len;
+	uint32_t sRight = s >> 1;
+	if ((s & 1u) != 0 && !sp.nudgeLeft) sRight++;
+	const uint32_t r0 = bf_cext(sp.rev[0], sRight, s, len), r1 = bf_cext(sp.rev[1], sRight, s, len);
+	const uint32_t r2 = bf_cext(sp.rev[2], sRight, s, len), r3 = bf_cext(sp.rev[3], sRight, s, len);
+	uint32_t qlen = len;
+	if (sp.seed && len > s) qlen = s;
+	AW(d + LF_QLEN) = qlen | (len << 16);
+	/* the quality string handed to initRangeSource is qual for fw == ebwtFw, qualRev otherwise: the
+	 * same string the source reads its penalties from (ebwt_search_backtrack.h:1833-1839) */
+	const uint32_t ebwtFw = !sp.mirror;
+	uint32_t minCost = 0;
+	if (sp.reportExacts) {
+	} else if (!sp.halfAndHalf && r0 < s) {
+		minCost = 1u << 14;
+		uint32_t low = 0xffu;
+		for (uint32_t k = r0; k < s; k++) { const uint32_t c = bf_qualc(X, sp.fw, ebwtFw, qlen - k - 1u); if (c < low) low = c; }
+		minCost += bt_mm_penalty(maq, bf_phred(low));
+	} else if (sp.halfAndHalf && sRight > 0 && sRight < (s - 1u)) {
+		minCost = (sp.seed ? 3u : 2u) << 14;
+		uint32_t low1 = 0xffu;
+		for (uint32_t k = 0; k < sRight; k++) { const uint32_t c = bf_qualc(X, sp.fw, ebwtFw, qlen - k - 1u); if (c < low1) low1 = c; }
+		minCost += bt_mm_penalty(maq, bf_phred(low1));
+		uint32_t l21 = 0xffu, l22 = 0xffu;
+		for (uint32_t k = sRight; k < s; k++) {
+			const uint32_t c = bf_qualc(X, sp.fw, ebwtFw, qlen - k - 1u);
+			if (c < l21) { if (l21 != 0xffu) l22 = l21; l21 = c; }
+			else if (c < l22) l22 = c;
+		}
+		minCost += bt_mm_penalty(maq, bf_phred(l21));
+		if (sp.halfAndHalf > 2 && l22 != 0xffu) minCost += bt_mm_penalty(maq, bf_phred(l22));
+	}
+	minCost &= 0xffffu;
+	AW(d + LF_REV01) = r0 | (r1 << 16); AW(d + LF_REV23) = r2 | (r3 << 16); AW(d + LF_D53) = sRight | (s << 16);
+	/* initBranch */
+	uint32_t rsf = AW(d + LF_RSFLAGS);
+	const uint32_t valid = rsf & 8u;
+	const uint32_t icost = valid ? (AW(d + LF_SEED) & 0xffffu) : 0u;
+	const uint32_t iham = valid ? (icost & 0x3fffu) : 0u;
+	bool go = true;
+	if (qlen < 4u) {
+		uint32_t maxmms = 0;
+		if (r0 != r1) maxmms = 1;
+		if (r1 != r2) maxmms = 2;
+		if (r2 != r3) maxmms = 3;
+		if (qlen <= maxmms) { rsf |= 1u | 4u; go = false; }
+	}
+	uint32_t nsInFtab = 0;
+	if (go) {
+		/* tallyNs (ebwt_search_backtrack.h:2490-2523) */
+		uint32_t nsInSeed = 0;
+		for (uint32_t i = 0; i < r3 && go; i++) {
+			if (leaf_qry(X, d, sp, qlen - i - 1u) == 4u) {
+				nsInSeed++;
+				if (nsInSeed == 1u) { if (i < r0) go = false; }
+				else if (nsInSeed == 2u) { if (i < r1) go = false; }
+				else if (nsInSeed == 3u) { if (i < r2) go = false; }
+				else go = false;
+			}
+		}
+		if (go) for (uint32_t i = 0; i < ix.ftabChars && i < qlen; i++) if (leaf_qry(X, d, sp, qlen - i - 1u) == 4u) nsInFtab++;
+	}
+	if (go) {
+		const uint32_t ftabChars = ix.ftabChars;
+		const uint32_t m = r0 < qlen ? r0 : qlen;
+		const bool skipInvalidExact = !sp.reportExacts && qlen == ftabChars;
+		const uint32_t d01 = r0 | (r1 << 16), d23 = r2 | (r3 << 16);
+		if (nsInFtab == 0 && m >= ftabChars && !skipInvalidExact) {
+			uint32_t off = leaf_qry(X, d, sp, qlen - ftabChars);                /* calcFtabOff (:2530-2544) */
+			for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | leaf_qry(X, d, sp, qlen - i);
+			const uint32_t top = bt_ftab_hi(ix, off), bot = bt_ftab_lo(ix, off + 1u);
+			X.c_ftab++;
+			if (qlen == ftabChars && bot > top) {
+				AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
+				AW(d + LF_CURCOST) = icost | ((valid ? (AW(d + LF_SEED) >> 16) : 0u) << 16);
+				AW(d + LF_CURBR) = 0;
+				rsf |= 2u;
+			} else if (bot > top) {
+				const uint32_t b = br_new(X, pm_alloc_id(X, d), d01, d23, 0, ftabChars, icost, iham, top, bot, 0, 0, 0);
+				if (!X.ovf) pm_push(X, d, b);
+			}
+		} else {
+			const uint32_t b = br_new(X, pm_alloc_id(X, d), d01, d23, 0, 0, icost, iham, 0, 0, 0, 0, 0);
+			if (!X.ovf) pm_push(X, d, b);
+		}
+	}
+	AW(d + LF_RSFLAGS) = rsf;
+	const uint32_t mc = icost > minCost ? icost : minCost;
+	AW(d + DR_COST) = mc | (minCost << 16);
+	AW(d + DR_FLAGS) = ((rsf & 1u) ? BF_F_DONE : 0u) | ((rsf & 2u) ? BF_F_FOUND : 0u);
+}
+
+/* EbwtRangeSource::advanceBranch (ebwt_search_backtrack.h:2059-2361), until = ADV_COST_CHANGES */
+BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
+{
+	const BtIndexDev& ix = X.ix[sp.mirror];
+	const uint32_t qlen = AW(d + LF_QLEN) & 0xffffu;
+	const uint32_t depth5 = AW(d + LF_D53) & 0xffffu, depth3 = AW(d + LF_D53) >> 16;
+	const uint32_t maq = X.P->maq;
+	bool found = false;
+	do {
+		const uint32_t br = pm_front(X, d);
+		const uint32_t rdepth = br_rdepth(X, br), blen = br_len(X, br);
+		const uint32_t depth = rdepth + blen;
+		const uint32_t cost = br_cost(X, br);
+		const uint32_t nedits = br_nedits(X, br);
+		uint32_t cur = 0;
+		uint32_t top = AW(br + BR_TOP), bot = AW(br + BR_BOT);
+		bool curtail = false, hit = false;
+		/* hhCheckTop (:2444-2475) */
+		if (sp.halfAndHalf && ((depth == depth5 && nedits == 0) || (depth == depth3 && nedits < sp.halfAndHalf))) {
+			curtail = true;
+		} else {
+			cur = qlen - depth - 1u;
+			if (depth < qlen) {
+				const uint32_t c = leaf_qry(X, d, sp, cur);
+				const uint32_t q = bt_mm_penalty(maq, bf_phred(bf_qualc(X, sp.fw, !sp.mirror, cur)));
+				const uint32_t ham = br_ham(X, br);
+				const uint32_t d0 = AW(br + BR_D01) & 0xffffu;
+				const bool alt = depth >= d0 && ham + q <= sp.qualLim;
+				uint32_t otop = top;
+				if (c == 4u && depth > 0) top = bot = 1;
+				const uint32_t fl = AW(br + BR_FLAGS);
+				uint32_t tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
+				bool ranges = false;
+				if (top == 0 && bot == 0) {
+					tops[0] = ix.fchr[0]; bots[0] = tops[1] = ix.fchr[1]; bots[1] = tops[2] = ix.fchr[2];
+					bots[2] = tops[3] = ix.fchr[3]; bots[3] = ix.fchr[4];
+					ranges = true;
+					if (c < 4u) { top = tops[c]; bot = bots[c]; }
+				} else if (alt && (bot > top || c == 4u)) {
+					if (fl & BRF_LBOT) {
+						uint32_t L;
+						const uint32_t ra = AW(br + BR_LTOP), rb = AW(br + BR_LBOT);
+						bt_rank4(ix, ra, tops, &L);
+						bt_rank4(ix, rb, bots, &L);
+						X.c_lfex++; if (ra / 448u == rb / 448u) X.c_same++;
+					} else {
+						/* mapLF1(otop, ltop_) (ebwt.h:2530-2560) */
+						X.c_lf1++;
+						if (otop != ix.zOff) {
+							uint32_t lf[4], L;
+							bt_rank4(ix, AW(br + BR_LTOP), lf, &L);
+							otop = lf[L];
+							tops[L] = otop; bots[L] = otop + 1u;
+						}
+					}
+					ranges = true;
+					if (c < 4u) { top = tops[c]; bot = bots[c]; } else top = bot = 1;
+				} else if (bot > top) {
+					if (c < 4u) {
+						uint32_t lf[4], L;
+						if (top + 1u == bot) {
+							/* mapLF1(top_, ltop_, c) (ebwt.h:2494-2524) */
+							X.c_lf1++;
+							bt_rank4(ix, AW(br + BR_LTOP), lf, &L);
+							if (L != c || top == ix.zOff) top = bot = BT_OFF_MASK;
+							else { top = lf[c]; bot = top + 1u; }
+						} else {
+							const uint32_t ra = AW(br + BR_LTOP), rb = AW(br + BR_LBOT);
+							X.c_lf2++; if (ra / 448u == rb / 448u) X.c_same++;
+							bt_rank4(ix, ra, lf, &L); top = lf[c];
+							bt_rank4(ix, rb, lf, &L); bot = lf[c];
+						}
+					}
+				}
+				if (ranges) {
+					/* Branch::installRanges (range_source.h:970-1023): a record only for a position that
+					 * is a legitimate place to branch from and still has an untried substitution */
+					uint32_t mask = 0xfu;
+					if (q <= sp.qualLim - ham) {
+						for (uint32_t k = 0; k < 4u; k++) if (c != k && bots[k] > tops[k]) mask &= ~(1u << k);
+					}
+					if (mask != 0xfu && depth >= d0) {
+						const uint32_t nalt = AW(br + BR_NALT);
+						const uint32_t rec = bf_alloc(X, BF_ALW);
+						if (nalt == 0) { AW(br + BR_ALT) = rec; X.growing = br; }
+						else if (X.growing != br || rec != AW(br + BR_ALT) + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
+						if (!X.ovf) {
+							for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
+							AW(rec + 8u) = blen | (q << 16) | (mask << 24);
+							AW(br + BR_NALT) = nalt + 1u;
+						}
+					}
+				}
+			} else {
+				cur = 0;
+			}
+			AW(br + BR_TOP) = top; AW(br + BR_BOT) = bot;
+			const bool empty = top == bot;
+			hit = cur == 0 && !empty;
+			const bool invalidExact = hit && nedits == 0 && !sp.reportExacts;
+			/* hhCheck (:2397-2436) */
+			bool hhOk = true;
+			if (sp.halfAndHalf) {
+				if (depth == depth5 - 1u && !empty) hhOk = nedits > 0;
+				else if (depth == depth3 - 1u && !empty) {
+					const uint32_t hilo = AW(br + BR_HILO);
+					hhOk = nedits >= sp.halfAndHalf && (hilo & 0xffffu) != 0 && (hilo >> 16) != 0;
+				}
+			}
+			if (!hhOk) { curtail = true; hit = false; }
+			else if (hit && !invalidExact) {
+				AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
+				const uint32_t sn = (AW(d + LF_RSFLAGS) & 8u) ? (AW(d + LF_SEED) >> 16) : 0u;
+				AW(d + LF_CURCOST) = br_cost(X, br) | ((nedits + sn) << 16);
+				AW(d + LF_CURBR) = br;
+				found = true;
+				curtail = true;
+			} else if (empty || cur == 0) curtail = true;
+			else AW(br + BR_RDLEN) = rdepth | ((blen + 1u) << 16);        /* Branch::extend */
+		}
+		if (curtail) pm_curtail(X, d, br, depth3);
+		if (X.ovf) break;
+		if (!pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0)) pm_reset(X, d);
+		if (X.ovf) break;
+		if (pm_size(X, d) == 0) break;
+		if (br_cost(X, pm_front(X, d)) != cost) break;
+	} while (!found);
+	AW(d + LF_RSFLAGS) = (AW(d + LF_RSFLAGS) & ~2u) | (found ? 2u : 0u);
+}
+
+/* SingleRangeSourceDriver::advanceImpl (range_source.h:1777-1838) */
+BF_FN void leaf_advance(BfLane& X, uint32_t d)
+{
+	uint32_t fl = AW(d + DR_FLAGS);
+	if ((fl & BF_F_DONE) || pm_size(X, d) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
+	const BfSpec& sp = leaf_spec(X, d);
+	leaf_advance_branch(X, d, sp);
+	fl &= ~(BF_F_DONE | BF_F_FOUND);
+	if (pm_size(X, d) == 0) fl |= BF_F_DONE;
+	const uint32_t pmc = AW(d + LF_PMCOST), adj = AW(d + DR_COST) >> 16;
+	if (pmc != 0) AW(d + DR_COST) = (pmc > adj ? pmc : adj) | (adj << 16);
+	if (AW(d + LF_RSFLAGS) & 2u) fl |= BF_F_FOUND;
+	AW(d + DR_FLAGS) = fl;
+}
+
+/* ---- the inner drivers ------------------------------------------------------------------------ */
+BF_INL uint32_t dr_kind(BfLane& X, uint32_t d) { return AW(d + DR_KIND) & 0xffu; }
+BF_INL uint32_t dr_fw(BfLane& X, uint32_t d) { return (AW(d + DR_KIND) >> 8) & 1u; }
+BF_INL uint32_t dr_mincost(BfLane& X, uint32_t d) { return AW(d + DR_COST) & 0xffffu; }
+BF_INL void dr_set_mincost(BfLane& X, uint32_t d, uint32_t c) { AW(d + DR_COST) = (AW(d + DR_COST) & 0xffff0000u) | (c & 0xffffu); }
+BF_INL bool dr_done(BfLane& X, uint32_t d) { return (AW(d + DR_FLAGS) & BF_F_DONE) != 0; }
+BF_INL bool dr_found(BfLane& X, uint32_t d) { return (AW(d + DR_FLAGS) & BF_F_FOUND) != 0; }
+BF_INL void dr_set(BfLane& X, uint32_t d, uint32_t bit, bool v) { uint32_t f = AW(d + DR_FLAGS); AW(d + DR_FLAGS) = v ? (f | bit) : (f & ~bit); }
+
+BF_FN void cost_init(BfLane& X, uint32_t d, uint32_t strandFix, uint32_t cap)
+{
+	for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
+	AW(d + DR_KIND) = BF_COST | (1u << 8);
+	AW(d + CA_OPTS) = strandFix ? 1u : 0u;
+	if (cap) { AW(d + CA_RSS) = bf_alloc(X, cap); AW(d + CA_ACT) = bf_alloc(X, cap); AW(d + CA_NRSS) = cap << 16; }
+}
+BF_FN void cost_add_rss(BfLane& X, uint32_t d, uint32_t p)
+{
+	uint32_t n = AW(d + CA_NRSS) & 0xffffu, cap = AW(d + CA_NRSS) >> 16;
+	if (n == cap) {
+		const uint32_t ncap = cap ? cap * 2u : 4u;
+		const uint32_t nr = bf_alloc(X, ncap), na = bf_alloc(X, ncap);
+		if (X.ovf) return;
+		const uint32_t nact = AW(d + CA_NACT);
+		for (uint32_t k = 0; k < n; k++) AW(nr + k) = AW(AW(d + CA_RSS) + k);
+		for (uint32_t k = 0; k < nact; k++) AW(na + k) = AW(AW(d + CA_ACT) + k);
+		AW(d + CA_RSS) = nr; AW(d + CA_ACT) = na; cap = ncap;
+	}
+	AW(AW(d + CA_RSS) + n) = p;
+	AW(d + CA_NRSS) = (n + 1u) | (cap << 16);
+}
+
+/* CostAwareRangeSourceDriver::sortActives (range_source.h:2370-2415) */
+BF_FN void cost_sort_actives(BfLane& X, uint32_t d)
+{
+	const uint32_t vec = AW(d + CA_ACT);
+	uint32_t n = AW(d + CA_NACT), sz = n;
+	for (uint32_t i = 0; i < sz;) {
+		const uint32_t vi = AW(vec + i);
+		if (dr_done(X, vi) && !dr_found(X, vi)) {
+			for (uint32_t k = i; k + 1u < n; k++) AW(vec + k) = AW(vec + k + 1u);
+			n--; sz--;
+			continue;
+		}
+		uint32_t minCost = dr_mincost(X, vi), minOff = i;
+		for (uint32_t j = i + 1u; j < sz; j++) {
+			const uint32_t vj = AW(vec + j);
+			if (dr_done(X, vj) && !dr_found(X, vj)) continue;
+			const uint32_t cj = dr_mincost(X, vj);
+			if (cj < minCost) { minCost = cj; minOff = j; }
+			else if (cj == minCost) { if (bf_rnd_at(X, d + CA_RND) & 0x1000u) minOff = j; }
+		}
+		if (i != minOff) { const uint32_t t = AW(vec + i); AW(vec + i) = AW(vec + minOff); AW(vec + minOff) = t; }
+		i++;
+	}
+	AW(d + CA_NACT) = n;
+	if (AW(d + CA_DELAYED) == 0 && sz > 0) dr_set_mincost(X, d, dr_mincost(X, AW(vec)));
+}
+
+/* LEVEL 0 = the aligner's driver (children: leaves and seeded pairs), LEVEL 1 = a seeded pair's
+ * rsFull_ (children: leaves only).  Two instantiations instead of the reference's virtual recursion. */
+template <int LEVEL> BF_FN void child_set_query(BfLane& X, uint32_t d, uint32_t seedSrc);
+template <int LEVEL> BF_FN void child_advance(BfLane& X, uint32_t d);
+BF_FN uint32_t child_range(BfLane& X, uint32_t d);
+
+/* setQueryImpl (range_source.h:2076-2093) */
+template <int LEVEL> BF_FN void cost_set_query(BfLane& X, uint32_t d)
+{
+	AW(d + DR_FLAGS) = 0; AW(d + CA_LAST) = 0; AW(d + CA_DELAYED) = 0;
+	AW(d + CA_OPTS) |= 2u;
+	AW(d + CA_RND) = X.seed;
+	const uint32_t n = AW(d + CA_NRSS) & 0xffffu;
+	if (n == 0) return;
+	for (uint32_t i = 0; i < n; i++) child_set_query<LEVEL>(X, AW(AW(d + CA_RSS) + i), 0);
+	for (uint32_t i = 0; i < n; i++) AW(AW(d + CA_ACT) + i) = AW(AW(d + CA_RSS) + i);
+	AW(d + CA_NACT) = n;
+	dr_set_mincost(X, d, 0);
+	cost_sort_actives(X, d);
+}
+
+/* foundFirstRange (range_source.h:2311-2362); rss_[i] -- not active_[i] -- supplies mate1()/fw() */
+template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, uint32_t r, uint32_t rfw)
+{
+	dr_set(X, d, BF_F_FOUND, true);
+	AW(d + CA_LAST) = r;
+	if (AW(d + CA_OPTS) & 1u) {
+		const uint32_t sz = AW(d + CA_NACT);
+		const uint32_t rcost = AW(r + LF_CURCOST) & 0xffffu;
+		for (uint32_t i = 1; i < sz; i++) {
+			if (dr_fw(X, AW(AW(d + CA_RSS) + i)) != rfw) {
+				const uint32_t p = AW(AW(d + CA_ACT) + i);
+				const uint32_t mine = dr_mincost(X, d), theirs = dr_mincost(X, p);
+				const uint32_t minCost = mine > theirs ? mine : theirs;
+				if (minCost > rcost) break;
+				while (!dr_done(X, p) && !dr_found(X, p) && !X.ovf) {
+					child_advance<LEVEL>(X, p);
+					if (dr_mincost(X, p) > minCost) break;
+				}
+				if (dr_found(X, p)) {
+					uint32_t del = child_range(X, p), lastR = r;
+					const uint32_t wd = AW(del + LF_CURBOT) - AW(del + LF_CURTOP), wl = AW(lastR + LF_CURBOT) - AW(lastR + LF_CURTOP);
+					const uint64_t tot = (uint64_t)wd + wl;
+					const uint32_t rq = (uint32_t)((uint64_t)bf_rnd_at(X, d + CA_RND) % tot);
+					if (rq < wd) { const uint32_t t = lastR; lastR = del; del = t; }
+					AW(d + CA_LAST) = lastR; AW(d + CA_DELAYED) = del;
+					dr_set(X, p, BF_F_FOUND, false);
+				}
+				return true;
+			}
+		}
+	}
+	return false;
+}
+
+/* advanceImpl (range_source.h:2157-2210), unpaired */
+template <int LEVEL> BF_FN void cost_advance(BfLane& X, uint32_t d)
+{
+	AW(d + CA_LAST) = 0;
+	const uint32_t actSz = AW(d + CA_NACT);
+	if (AW(d + CA_DELAYED)) {
+		AW(d + CA_LAST) = AW(d + CA_DELAYED); AW(d + CA_DELAYED) = 0;
+		dr_set(X, d, BF_F_FOUND, true);
+		if (actSz > 0) { const uint32_t a0 = dr_mincost(X, AW(AW(d + CA_ACT))); if (a0 > dr_mincost(X, d)) dr_set_mincost(X, d, a0); }
+		else dr_set(X, d, BF_F_DONE, true);
+		return;
+	}
+	if (actSz == 0) { dr_set(X, d, BF_F_DONE, true); return; }
+	const uint32_t p = AW(AW(d + CA_ACT));
+	const uint32_t precost = dr_mincost(X, p);
+	if (!dr_found(X, p)) child_advance<LEVEL>(X, p);
+	bool needsSort = false;
+	if (dr_found(X, p)) {
+		const uint32_t r = child_range(X, p);
+		needsSort = cost_found_first_range<LEVEL>(X, d, r, dr_fw(X, p));
+		dr_set(X, p, BF_F_FOUND, false);
+	}
+	if (dr_done(X, p) || precost != dr_mincost(X, p) || needsSort) {
+		cost_sort_actives(X, d);
+		if (AW(d + CA_NACT) == 0) dr_set(X, d, BF_F_DONE, AW(d + CA_DELAYED) == 0);
+	}
+}
+
+/* EbwtSeededRangeSourceDriver::setQueryImpl (ebwt_search_backtrack.h:2963-2978) */
+BF_FN void seeded_set_query(BfLane& X, uint32_t d)
+{
+	const uint32_t seed = AW(d + SD_SEED), full = AW(d + SD_FULL);
+	AW(d + DR_FLAGS) = 0;
+	leaf_set_query(X, seed, 0);
+	const uint32_t sadj = AW(seed + DR_COST) >> 16, smin = dr_mincost(X, seed);
+	const uint32_t adj = sadj > smin ? sadj : smin;
+	AW(d + DR_COST) = adj | (adj << 16);
+	/* rsFull_.clearSources(); rsFull_.setQuery() */
+	AW(full + CA_NRSS) &= 0xffff0000u; AW(full + CA_NACT) = 0;
+	cost_set_query<1>(X, full);
+	dr_set_mincost(X, full, adj);
+}
+
+/* EbwtSeededRangeSourceDriver::advanceImpl (ebwt_search_backtrack.h:3011-3103) */
+BF_FN void seeded_advance(BfLane& X, uint32_t d)
+{
+	const uint32_t seed = AW(d + SD_SEED), full = AW(d + SD_FULL);
+	if (dr_done(X, seed) && dr_done(X, full) && !dr_found(X, seed) && !dr_found(X, full)) { dr_set(X, d, BF_F_DONE, true); return; }
+	if (dr_done(X, seed) && !dr_found(X, seed)) {
+		dr_set_mincost(X, seed, 0xffffu);
+		if (dr_mincost(X, full) > dr_mincost(X, d)) { dr_set_mincost(X, d, dr_mincost(X, full)); return; }
+	}
+	if (dr_done(X, full) && !dr_found(X, full)) {
+		dr_set_mincost(X, full, 0xffffu);
+		if (dr_mincost(X, seed) > dr_mincost(X, d)) { dr_set_mincost(X, d, dr_mincost(X, seed)); return; }
+	}
+	if (dr_mincost(X, full) > dr_mincost(X, seed)) {
+		if (!dr_found(X, seed)) leaf_advance(X, seed);
+		if (dr_found(X, seed)) {
+			dr_set(X, seed, BF_F_FOUND, false);
+			const uint32_t scost = AW(seed + LF_CURCOST) & 0xffffu;
+			AW(d + DR_COST) = dr_mincost(X, d) | (scost << 16);
+			/* rsFact_->create(); rsFull_.addSource(partial, seedRange_) (range_source.h:2098-2111) */
+			const uint32_t part = bf_alloc(X, BF_DRW);
+			if (X.ovf) return;
+			leaf_init(X, part, AW(d + SD_FACT));
+			AW(full + CA_LAST) = 0; AW(full + CA_DELAYED) = 0; dr_set(X, full, BF_F_DONE, false);
+			leaf_set_query(X, part, seed);
+			cost_add_rss(X, full, part);
+			if (X.ovf) return;
+			const uint32_t na = AW(full + CA_NACT);
+			AW(AW(full + CA_ACT) + na) = part; AW(full + CA_NACT) = na + 1u;
+			dr_set_mincost(X, full, 0);
+			cost_sort_actives(X, full);
+			if (dr_found(X, full)) { dr_set(X, d, BF_F_FOUND, true); dr_set(X, full, BF_F_FOUND, false); }
+		}
+		if (dr_mincost(X, seed) > dr_mincost(X, d)) {
+			uint32_t mc = dr_mincost(X, seed);
+			if (!dr_done(X, full) && dr_mincost(X, full) < mc) mc = dr_mincost(X, full);
+			dr_set_mincost(X, d, mc);
+		}
+	} else {
+		const uint32_t old = dr_mincost(X, full);
+		if (!dr_found(X, full)) cost_advance<1>(X, full);
+		if (dr_found(X, full)) { dr_set(X, d, BF_F_FOUND, true); dr_set(X, full, BF_F_FOUND, false); }
+		if (dr_mincost(X, full) > old) {
+			const uint32_t a = dr_mincost(X, full), b = dr_mincost(X, seed);
+			dr_set_mincost(X, d, a < b ? a : b);
+		}
+	}
+}
+
+template <int LEVEL> BF_FN void child_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
+{
+	if (LEVEL == 0 && dr_kind(X, d) == BF_SEEDED) seeded_set_query(X, d);
+	else leaf_set_query(X, d, seedSrc);
+}
+template <int LEVEL> BF_FN void child_advance(BfLane& X, uint32_t d)
+{
+	if (LEVEL == 0 && dr_kind(X, d) == BF_SEEDED) seeded_advance(X, d);
+	else leaf_advance(X, d);
+}
+/* RangeSourceDriver::range(): the leaf whose current range it is */
+BF_FN uint32_t child_range(BfLane& X, uint32_t d)
+{
+	if (dr_kind(X, d) == BF_SEEDED) return AW(AW(d + SD_FULL) + CA_LAST);
+	return d;
+}
+
+/* the static part of the tree (Unpaired*Factory::create()) */
+BF_FN uint32_t bf_build_tree(BfLane& X)
+{
+	const BfProgram& P = *X.P;
+	const uint32_t top = bf_alloc(X, BF_DRW);
+	cost_init(X, top, P.strandFix, P.nnodes);
+	for (uint32_t i = 0; i < P.nnodes && !X.ovf; i++) {
+		const BfNode nd = P.nodes[i];
+		const uint32_t d = bf_alloc(X, BF_DRW);
+		if (nd.kind == BF_LEAF) leaf_init(X, d, nd.spec);
+		else {
+			const uint32_t gen = bf_alloc(X, BF_DRW), full = bf_alloc(X, BF_DRW);
+			if (X.ovf) break;
+			leaf_init(X, gen, nd.genSpec);
+			cost_init(X, full, 0, 0);
+			for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
+			AW(d + DR_KIND) = BF_SEEDED | ((uint32_t)nd.fw << 8);
+			AW(d + DR_FLAGS) = BF_F_DONE;
+			AW(d + SD_FULL) = full; AW(d + SD_SEED) = gen; AW(d + SD_FACT) = nd.spec;
+		}
+		cost_add_rss(X, top, d);
+	}
+	return top;
+}
+
+/* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
+ * ebwt_search.cpp passes NULL caches) ------------------------------------------------------------- */
+BF_FN void ch_row_set(BfLane& X, BfChase& c, uint32_t row)
+{
+	const BtIndexDev& ix = X.ix[c.mirror];
+	c.cRow = row;
+	if (row == ix.zOff) { c.cOff = 0; c.cDone = 1; return; }
+	if ((row & ix.offMask) == row) { c.cOff = BT_GP(const uint32_t, ix.offs)[row >> ix.offRate]; c.cDone = 1; X.c_offs++; return; }
+	c.cDone = 0; c.cJumps = 0; c.cOff = BT_OFF_MASK;
+}
+BF_FN void ch_row_advance(BfLane& X, BfChase& c)
+{
+	const BtIndexDev& ix = X.ix[c.mirror];
+	while (!c.cDone) {
+		uint32_t lf[4], L;
+		bt_rank4(ix, c.cRow, lf, &L);
+		c.cRow = lf[L];
+		c.cJumps++; X.c_chase++;
+		if (c.cRow == ix.zOff) { c.cOff = c.cJumps; c.cDone = 1; }
+		else if ((c.cRow & ix.offMask) == c.cRow) { c.cOff = BT_GP(const uint32_t, ix.offs)[c.cRow >> ix.offRate] + c.cJumps; c.cDone = 1; X.c_offs++; }
+	}
+}
+BF_FN void ch_row_off(BfLane& X, BfChase& c)
+{
+	uint32_t tidx = BT_OFF_MASK, toff = BT_OFF_MASK;
+	if (!bt_joined_to_text(X.ix[c.mirror], c.qlen, c.cOff, &tidx, &toff, &X.c_rst)) tidx = BT_OFF_MASK;
+	c.tidx = tidx; c.toff = toff;
+}
+BF_FN void ch_set_row(BfLane& X, BfChase& c, uint32_t row)
+{
+	c.row = row;
+	for (;;) {
+		ch_row_set(X, c, c.row);
+		if (!c.cDone) break;
+		ch_row_off(X, c);
+		if (c.tidx != BT_OFF_MASK) return;
+		c.row++;
+		if (c.row == c.bot) c.row = c.top;
+		if (c.row == c.irow) { c.done = 1; return; }
+	}
+}
+BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uint32_t mirror)
+{
+	c.mirror = mirror; c.qlen = X.len; c.top = top; c.bot = bot;
+	c.irow = top + (bf_rnd(X.alRnd) % (bot - top));
+	c.done = 0; c.tidx = BT_OFF_MASK;
+	ch_set_row(X, c, c.irow);
+}
+BF_FN void ch_advance(BfLane& X, BfChase& c)
+{
+	c.tidx = BT_OFF_MASK;
+	if (c.cDone) {
+		c.row++;
+		if (c.row == c.bot) c.row = c.top;
+		if (c.row == c.irow) { c.done = 1; return; }
+		ch_set_row(X, c, c.row);
+	} else {
+		ch_row_advance(X, c);
+		if (c.cDone) ch_row_off(X, c);
+	}
+}
+
+/* ---- sink + hit record -------------------------------------------------------------------------
+ * UnpairedAlignerV2::report (aligner.h:467-497), EbwtSearchParams::reportHit (ebwt.h:1288-1405),
+ * NGood / NBestFirstStrat / All sinks (hit.h:969-985, 1070-1129, 1201-1209).  true = stop. */
+BF_FN bool bf_report(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff)
+{
+	const BfProgram& P = *X.P;
+	const BfSpec& sp = leaf_spec(X, leaf);
+	const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu, stratum = cost >> 14;
+	X.nhits++;
+	if (P.sinkStrata && stratum < X.bestStratum) X.bestStratum = stratum;
+	if (X.nhits > P.sinkMax) return true;
+	if (X.stored < B.hit_cap) {
+		BtHitRec h;
+		h.tidx = tidx; h.toff = toff; h.oms = AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u;
+		h.cost = (uint16_t)cost; h.stratum = (uint8_t)stratum; h.fw = sp.fw; h.pad[0] = h.pad[1] = 0;
+		const uint32_t nmm = AW(leaf + LF_CURCOST) >> 16;
+		h.nmm = (uint16_t)nmm; h.mm_off = 0;
+		if (nmm > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			const uint32_t off = atomicAdd(B.mm_pool_used, nmm);
+#else
+			const uint32_t off = *B.mm_pool_used; *B.mm_pool_used += nmm;
+#endif
+			if (off + nmm <= B.mm_pool_cap) {
+				h.mm_off = off;
+				auto mm = BT_GP(uint16_t, B.mm_pool + off);
+				const bool flip = (sp.mirror == 0) != (sp.fw != 0);
+				const uint32_t qlen = AW(leaf + LF_QLEN) & 0xffffu, alen = X.len;
+				const uint32_t sn = (AW(leaf + LF_RSFLAGS) & 8u) ? (AW(leaf + LF_SEED) >> 16) : 0u;
+				uint32_t b = AW(leaf + LF_CURBR);
+				for (uint32_t i = 0; i < nmm; i++) {
+					uint32_t m, refc;
+					if (i < nmm - sn) { const uint32_t e = AW(b + BR_EDIT); m = qlen - (e & 0x3ffu) - 1u; refc = (e >> 10) & 3u; b = AW(b + BR_PARENT); }
+					else { const uint32_t s = AW(leaf + LF_SEEDMM0 + (i - (nmm - sn))); m = qlen - (s & 0xffffu) - 1u; refc = s >> 16; }
+					const uint32_t pos = flip ? alen - m - 1u : m;
+					const uint16_t e16 = (uint16_t)(pos | (refc << 12));
+					int j = (int)i - 1;                              /* Hit::mms is a bitset: ordered by position */
+					while (j >= 0 && (mm[j] & 0x3ffu) > (e16 & 0x3ffu)) { mm[j + 1] = mm[j]; j--; }
+					mm[j + 1] = e16;
+				}
+			} else { h.nmm = 0; X.status |= BT_STF_MMPOOL; }
+		}
+		uint32_t hw[6];
+		__builtin_memcpy(hw, &h, 24);
+		uint32_t* dst = (uint32_t*)(B.hits + ((uint64_t)X.rd * B.hit_cap + X.stored));
+		BtU4 q; q.x = hw[0]; q.y = hw[1]; q.z = hw[2]; q.w = hw[3];
+		bt_st4(dst, q);
+		BT_GP(uint32_t, dst)[4] = hw[4]; BT_GP(uint32_t, dst)[5] = hw[5];
+		X.stored++;
+	} else if (X.stored < P.sinkN) X.status |= BT_STF_HITCAP;
+	if (P.sinkAll && !P.sinkStrata) return false;
+	return X.nhits == P.sinkN && (P.sinkMax == 0xffffffffu || P.sinkMax < P.sinkN);
+}
+BF_INL bool bf_irrelevant(const BfLane& X, uint32_t cost)       /* NBestFirstStrat::irrelevantCost (hit.h:1121-1127) */
+{
+	return X.P->sinkStrata && X.nhits && (cost >> 14) > X.bestStratum;
+}
+
+/* ---- one read: UnpairedAlignerV2::setQuery + advance() until done (aligner.h:434-567) ---------- */
+BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
+{
+	X.rd = rd;
+	X.len = BT_GP(const uint16_t, B.len)[rd];
+	X.seed = BT_GP(const uint32_t, B.seed)[rd];
+	X.seq = (BF_G const uint8_t*)(B.seq + (uint64_t)rd * B.stride);
+	X.qual = (BF_G const uint8_t*)(B.qual + (uint64_t)rd * B.stride);
+	X.top = BF_RESERVED; X.ovf = 0; X.growing = 0;
+	X.nhits = 0; X.stored = 0; X.bestStratum = 999; X.status = 0;
+	X.alRnd = X.seed;
+	X.btCnt = (int32_t)X.P->maxBts;
+	if (X.len < 4u) {
+		X.status |= BT_STF_SKIPPED;
+	} else {
+		const uint32_t drv = bf_build_tree(X);
+		BfChase ch;
+		ch.mirror = 0; ch.qlen = 0; ch.top = ch.bot = ch.irow = ch.row = 0; ch.tidx = BT_OFF_MASK; ch.toff = 0;
+		ch.done = 0; ch.cDone = 1; ch.cRow = ch.cJumps = ch.cOff = 0;
+		bool done = true, chase = false;
+		if (!X.ovf) { cost_set_query<0>(X, drv); done = dr_done(X, drv); }
+		while (!done && !X.ovf) {
+			if (chase) {
+				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
+				if (ch.tidx != BT_OFF_MASK) {
+					done = bf_report(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff);
+					ch.tidx = BT_OFF_MASK;
+				} else {
+					chase = false;
+					dr_set(X, drv, BF_F_FOUND, false);
+					done = dr_done(X, drv);
+				}
+			}
+			if (!done && !chase) {
+				if (dr_found(X, drv)) {
+					const uint32_t leaf = AW(drv + CA_LAST);
+					const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
+					ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror);
+					if (ch.tidx != BT_OFF_MASK) { done = bf_report(X, B, leaf, ch.tidx, ch.toff); ch.tidx = BT_OFF_MASK; }
+					if (!ch.done && !bf_irrelevant(X, cost)) chase = true;
+					else dr_set(X, drv, BF_F_FOUND, false);
+				} else {
+					done = bf_irrelevant(X, dr_mincost(X, drv));
+					if (!done) cost_advance<0>(X, drv);
+				}
+				if (dr_done(X, drv) && !dr_found(X, drv) && !chase) done = true;
+			}
+		}
+		if (X.ovf) X.status |= BT_STF_OVERFLOW;
+	}
+	/* NBestFirstStrat::finishReadImpl (hit.h:1098-1110): every buffered hit's oms = #buffered - 1 */
+	if (X.P->sinkStrata) {
+		for (uint32_t k = 0; k < X.stored; k++)
+			BT_GP(uint32_t, (uint32_t*)(B.hits + ((uint64_t)rd * B.hit_cap + k)))[2] = X.stored - 1u;
+	}
+	BT_GP(uint32_t, B.n_hits)[rd] = X.nhits;
+	BT_GP(uint8_t, B.status)[rd] = (uint8_t)X.status;
+}
+
+#undef AW
+#endif /* BT_BEST_H_ */

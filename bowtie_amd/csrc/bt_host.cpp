@@ -199,3 +199,122 @@ int bt_host_compile_program(const bt_policy& pol, BtProgram* prog)
 	for (size_t i = 0; i < st.size(); i++) P.steps[i] = st[i];
 	return BT_OK;
 }
+
+/* ---- best-first driver trees ------------------------------------------------------------------
+ * The tree of RangeSourceDrivers the reference's Unpaired*AlignerFactory::create() builds for a
+ * policy (aligner_0mm.h:69-115, aligner_1mm.h:73-152, aligner_23mm.h:73-236,
+ * aligner_seed_mm.h:82-516), as data for the device automaton of bt_best.h. */
+namespace {
+struct TreeBuilder {
+	BfProgram& P;
+	int add_spec(bool mirror, bool fw, uint32_t qualLim, bool reportExacts, int hh, bool partial, bool seed,
+	             uint32_t seedLen, bool nudgeLeft, int r0, int r1, int r2, int r3, bool useBtCnt)
+	{
+		if (P.nspecs >= BF_MAX_SPECS) return -1;
+		BfSpec& s = P.specs[P.nspecs];
+		memset(&s, 0, sizeof(s));
+		s.mirror = mirror; s.fw = fw; s.reportExacts = reportExacts; s.halfAndHalf = (uint8_t)hh; s.partial = partial;
+		s.seed = seed; s.nudgeLeft = nudgeLeft; s.useBtCnt = useBtCnt;
+		s.rev[0] = (uint8_t)r0; s.rev[1] = (uint8_t)r1; s.rev[2] = (uint8_t)r2; s.rev[3] = (uint8_t)r3;
+		s.qualLim = qualLim; s.seedLen = seedLen;
+		if (mirror) P.needMirror = 1;
+		return (int)P.nspecs++;
+	}
+	bool leaf(int spec)
+	{
+		if (spec < 0 || P.nnodes >= BF_MAX_NODES) return false;
+		BfNode& n = P.nodes[P.nnodes++];
+		n.kind = BF_LEAF; n.spec = (uint8_t)spec; n.genSpec = 0; n.fw = P.specs[spec].fw;
+		return true;
+	}
+	bool seeded(int factSpec, int genSpec, bool fw)
+	{
+		if (factSpec < 0 || genSpec < 0 || P.nnodes >= BF_MAX_NODES) return false;
+		BfNode& n = P.nodes[P.nnodes++];
+		n.kind = BF_SEEDED; n.spec = (uint8_t)factSpec; n.genSpec = (uint8_t)genSpec; n.fw = fw;
+		return true;
+	}
+};
+}
+
+int bt_host_compile_best(const bt_policy& pol, BfProgram* prog)
+{
+	BfProgram& P = *prog;
+	memset(&P, 0, sizeof(P));
+	if (pol.mms < 0 || pol.mms > 3) return BT_ERR_ARG;
+	if (pol.mode != BT_MODE_V && pol.mode != BT_MODE_N) return BT_ERR_ARG;
+	if (pol.mode == BT_MODE_N && pol.seed_len < 5) return BT_ERR_ARG;
+	const uint32_t INF = 0xffffffffu;
+	P.maq = pol.maq_round ? 1u : 0u;
+	P.maxBts = (uint32_t)pol.max_bts;
+	P.strandFix = 1;                                   /* ebwt_search.cpp:227 */
+	/* createSinkFactory (ebwt_search.cpp:992-1020) */
+	P.sinkStrata = pol.strata ? 1u : 0u;
+	P.sinkAll = pol.all_hits ? 1u : 0u;
+	P.sinkN = pol.all_hits ? (pol.strata ? INF / 2u : INF) : pol.khits;
+	P.sinkMax = pol.mhits;
+	P.sampleMax = pol.sample_max ? 1u : 0u;
+	if (P.sinkN == 0) return BT_ERR_ARG;
+	const bool doFw = !pol.nofw, doRc = !pol.norc;
+	const int B = BF_PIN_BEGIN, L = BF_PIN_LEN, H = BF_PIN_HI_HALF, S = BF_PIN_SEED;
+	TreeBuilder T{P};
+	bool ok = true;
+	/* leaf(mirror, fw, qualLim, reportExacts, halfAndHalf, partial, seed, seedLen, nudgeLeft, rev0..3, btCnt) */
+#define LEAF(...) ok = ok && T.leaf(T.add_spec(__VA_ARGS__))
+	if (pol.mode == BT_MODE_V) {
+		if (pol.mms == 0) {
+			if (doFw) LEAF(false, true, INF, true, 0, false, false, 0, true, L, L, L, L, false);
+			if (doRc) LEAF(false, false, INF, true, 0, false, false, 0, true, L, L, L, L, false);
+		} else if (pol.mms == 1) {
+			if (doFw) {
+				LEAF(true, true, INF, true, 0, false, false, 0, false, H, L, L, L, false);
+				LEAF(false, true, INF, false, 0, false, false, 0, true, H, L, L, L, false);
+			}
+			if (doRc) {
+				LEAF(false, false, INF, true, 0, false, false, 0, true, H, L, L, L, false);
+				LEAF(true, false, INF, false, 0, false, false, 0, false, H, L, L, L, false);
+			}
+		} else {
+			const bool two = pol.mms == 2;
+			const int r2 = two ? L : H;
+			if (doFw) {
+				LEAF(true, true, INF, true, 0, false, false, 0, true, H, H, r2, L, false);
+				LEAF(false, true, INF, false, 0, false, false, 0, false, H, H, r2, L, false);
+				LEAF(true, true, INF, false, 2, false, false, 0, true, B, H, r2, L, false);
+				if (!two) LEAF(false, true, INF, false, 3, false, false, 0, false, B, H, H, L, false);
+			}
+			if (doRc) {
+				LEAF(false, false, INF, true, 0, false, false, 0, true, H, H, r2, L, false);
+				LEAF(true, false, INF, false, 0, false, false, 0, false, H, H, r2, L, false);
+				LEAF(false, false, INF, false, 2, false, false, 0, true, B, H, r2, L, false);
+				if (!two) LEAF(true, false, INF, false, 3, false, false, 0, false, B, H, H, L, false);
+			}
+		}
+	} else {
+		const uint32_t q = (uint32_t)pol.qual_thresh, sl = (uint32_t)pol.seed_len;
+		const int n = pol.mms;
+		const bool bc = n >= 2;                      /* the backtrack budget only exists for -n 2/3 (aligner_seed_mm.h:99,134) */
+		P.btCntOn = bc ? 1u : 0u;
+		/* the extender factory of a seeded pair: all of the seed unrevisitable, exact hits allowed */
+#define FACT(mirror, fw) T.add_spec(mirror, fw, q, true, 0, false, false, sl, true, S, S, S, S, bc)
+		if (n == 0) {
+			if (doFw) LEAF(true, true, q, true, 0, false, false, sl, true, S, S, S, S, false);
+			if (doRc) LEAF(false, false, q, true, 0, false, false, sl, true, S, S, S, S, false);
+		} else {
+			const int a1 = n >= 2 ? H : S, a2 = n >= 3 ? H : S;        /* rev1, rev2 of the lo-half searchers */
+			for (int pass = 0; pass < 2; pass++) {
+				const bool fw = pass == 0;
+				if (fw ? !doFw : !doRc) continue;
+				/* fw read: exact-in-hi-half searcher on the mirror index, generator on the text index; rc: the other way round */
+				const bool m1 = fw, m2 = !fw;
+				LEAF(m1, fw, q, true, 0, false, false, sl, true, H, a1, a2, S, bc);
+				{ const int f = FACT(m1, fw); ok = ok && T.seeded(f, T.add_spec(m2, fw, q, false, 0, true, true, sl, false, H, a1, a2, S, bc), fw); }
+				if (n >= 3) { const int f = FACT(m1, fw); ok = ok && T.seeded(f, T.add_spec(m2, fw, q, false, 3, true, true, sl, false, B, H, H, S, bc), fw); }
+				if (n >= 2) LEAF(m1, fw, q, false, 2, false, false, sl, true, B, H, a2, S, bc);
+			}
+		}
+#undef FACT
+	}
+#undef LEAF
+	return ok ? BT_OK : BT_ERR_ARG;
+}

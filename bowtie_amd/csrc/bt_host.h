@@ -10,6 +10,7 @@
 #include <vector>
 #include "../../include/bowtie_amd.h"
 #include "bt_core.h"
+#include "bt_best.h"
 
 /* One index (text or mirror) parsed into host memory.  Field order and geometry follow
  * Ebwt::readIntoMemory (ebwt.h:2926-3421) and EbwtParams::init (ebwt.h:138-184). */
@@ -40,5 +41,9 @@ void bt_host_restore_text(const BtIndexHost& h, uint8_t* out);
  * search_seeded_phase{1..4}.c) with every policy-uniform condition (--nofw/--norc, seedMms)
  * resolved.  Returns BT_OK or BT_ERR_ARG. */
 int bt_host_compile_program(const bt_policy& pol, BtProgram* prog);
+
+/* The same for the stateful best-first workers (pol.best): the driver tree of
+ * Unpaired{Exact,1mm,23mm,Seed}AlignerFactory::create() as a BfProgram (bt_best.h). */
+int bt_host_compile_best(const bt_policy& pol, BfProgram* prog);
 
 #endif

@@ -155,4 +155,4 @@ def result_digest(per_read) -> str:
 
 def hit_cap_for(kw) -> int:
     """Hit slots per read large enough that no golden case overflows (-a on the tandem repeat)."""
-    return 1024 if kw.get("all_hits") else max(64, int(kw.get("khits", 1)))
+    return 1024 if kw.get("all_hits") else max(64, int(kw.get("khits", 1)))   # >= any -M value used

@@ -151,6 +151,36 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	return BT_OK;
 }
 
+/* The best-first engine (bowtie_amd/csrc/bt_best.h), one read after the other, each in an arena of
+ * arenaWords 32-bit words. */
+static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
+                        bt_op_counts* counts, uint32_t arenaWords)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	BfProgram P;
+	int rc = bt_host_compile_best(*pol, &P);
+	if (rc != BT_OK) return rc;
+	if (P.needMirror && !e->mirror) return BT_ERR_ARG;
+	BtBatchDev B;
+	memset(&B, 0, sizeof(B));
+	B.seq = in->seq; B.qual = in->qual; B.len = in->len; B.seed = in->seed; B.n_reads = in->n_reads; B.stride = in->stride;
+	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
+	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
+	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
+	std::vector<uint32_t> arena(arenaWords);
+	BfLane X;
+	memset(&X, 0, sizeof(X));
+	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
+	for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
+	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
+	if (counts) {
+		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
+		counts->ftab = X.c_ftab; counts->offs = X.c_offs; counts->rstarts = X.c_rst; counts->same_pair = X.c_same;
+		counts->frames = X.c_frames;
+	}
+	return BT_OK;
+}
+
 /* rl_mode: 0 = as the kernel launcher decides (reads of <= BT_RL_MAXLEN bases keep their read in "LDS"),
  * 1 = force the register-window build of the automaton, 2 = the lite layout of the 3-waves build */
 extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
@@ -159,6 +189,8 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 {
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
+	/* the stateful best-first workers: entCap doubles as the arena size in words (0 = 4 M words) */
+	if (pol->best) return emu_run_best(p, pol, in, out, counts, entCap >= 4096u ? entCap : (1u << 22));
 	/* rl_mode 2 = the 3-waves-per-SIMD layout: read in LDS (<= 104 bases), no candidate caches */
 	if (rl_mode == 2 && maxLen <= BT_RL3_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, true);
 	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, false);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 LIB_PATH = os.path.join(EMU_DIR, "libbt_emu.so")
 SRCS = [os.path.join(EMU_DIR, "bt_emu.cpp")] + [os.path.join(ROOT, "bowtie_amd", "csrc", f) for f in
-                                                ("bt_host.cpp", "bt_host.h", "bt_core.h", "bt_rank.h")]
+                                                ("bt_host.cpp", "bt_host.h", "bt_core.h", "bt_rank.h", "bt_best.h")]
 _lib = None
 
 
@@ -58,7 +58,7 @@ class EmuAligner:
               n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024, no_rl=False, lite=False):
         n = batch.n
         hit_cap = hit_cap or (64 if pol.all_hits else max(1, min(int(pol.khits), 64)))
-        ent_cap = ent_cap or 12 * max(64, batch.stride)
+        ent_cap = ent_cap or (0 if pol.best else 12 * max(64, batch.stride))
         seq = np.ascontiguousarray(batch.seq, dtype=np.uint8)
         qual = np.ascontiguousarray(batch.qual, dtype=np.uint8)
         ln = np.ascontiguousarray(batch.len, dtype=np.uint16)
@@ -76,4 +76,4 @@ class EmuAligner:
         if rc != 0:
             raise RuntimeError("emu_align_batch rc=%d" % rc)
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(pol.khits), int(pol.mhits),
-                           bool(pol.all_hits))
+                           bool(pol.all_hits), sample_max=bool(pol.sample_max))
