@@ -30,6 +30,10 @@ struct bt_ctx {
 	const bt_index* idx = nullptr;
 	bt_policy pol;
 	BtProgram prog;
+	bool best = false;               /* pol.best: the best-first engine (bt_best.h) instead of the phase programs */
+	BfProgram bprog;
+	BfProgram* d_bprog = nullptr; BtIndexDev* d_ix = nullptr; BtBatchDev* d_batch = nullptr;
+	uint32_t* arenas = nullptr; uint32_t arenaWords = 0; uint32_t arenaLanes = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -207,10 +211,11 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	*out = nullptr;
 	bt_ctx* c = new bt_ctx();
 	c->idx = idx; c->pol = *pol;
-	int rc = bt_host_compile_program(*pol, &c->prog);
+	c->best = pol->best != 0;
+	int rc = c->best ? bt_host_compile_best(*pol, &c->bprog) : bt_host_compile_program(*pol, &c->prog);
 	if (rc != BT_OK) { delete c; return rc; }
-	bool need_mirror = false;
-	for (int i = 0; i < c->prog.nsteps; i++) need_mirror |= c->prog.steps[i].mirror != 0;
+	bool need_mirror = c->best && c->bprog.needMirror;
+	for (int i = 0; !c->best && i < c->prog.nsteps; i++) need_mirror |= c->prog.steps[i].mirror != 0;
 	if (need_mirror && !idx->has_mirror) { delete c; return BT_ERR_ARG; }
 	HIPCHK(hipSetDevice(idx->device));
 	if (stream) c->stream = (hipStream_t)stream;
@@ -237,6 +242,15 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	HIPCHK(hipMalloc((void**)&c->d_warm, sizeof(BtWarm)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long)));
+	if (c->best) {
+		HIPCHK(hipMalloc((void**)&c->d_bprog, sizeof(BfProgram)));
+		HIPCHK(hipMalloc((void**)&c->d_ix, 2 * sizeof(BtIndexDev)));
+		HIPCHK(hipMalloc((void**)&c->d_batch, sizeof(BtBatchDev)));
+		HIPCHK(hipMemcpy(c->d_bprog, &c->bprog, sizeof(BfProgram), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(c->d_ix, idx->dev, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
+		/* the best-first kernel is built for two waves per SIMD (248 VGPRs): two 256-lane blocks per CU */
+		c->nLanes = c->cus * 2u * BT_BLOCK;
+	}
 	*out = c;
 	return BT_OK;
 }
@@ -256,11 +270,51 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->pool1) (void)hipFree(c->pool1);
 	if (c->pool2) (void)hipFree(c->pool2);
 	if (c->d_counts) (void)hipFree(c->d_counts);
+	if (c->d_bprog) (void)hipFree(c->d_bprog);
+	if (c->d_ix) (void)hipFree(c->d_ix);
+	if (c->d_batch) (void)hipFree(c->d_batch);
+	if (c->arenas) (void)hipFree(c->arenas);
 	if (c->stage) (void)hipFree(c->stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->own_stream) (void)hipStreamDestroy(c->stream);
 	delete c;
+}
+
+/* the best-first engine: one launch of bt_best_kernel, every lane with its own arena */
+static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, unsigned long long* counts_dev)
+{
+	/* arena words per lane: typical reads need a few thousand; a read that outgrows its arena is
+	 * flagged (BT_STF_OVERFLOW) and re-run by bt_align_batch through the twin context's 16 MB arenas */
+	const uint32_t words = c->is_big ? (1u << 22) : env_u32("BT_BEST_ARENA_WORDS", 16384u);
+	const uint32_t lanes = c->is_big ? (c->nLanes > 1024u ? 1024u : c->nLanes) : c->nLanes;
+	if (!c->arenas || c->arenaWords != words || c->arenaLanes < lanes) {
+		if (c->arenas) (void)hipFree(c->arenas);
+		c->arenas = nullptr;
+		HIPCHK(hipMalloc((void**)&c->arenas, (size_t)lanes * words * 4u));
+		c->arenaWords = words; c->arenaLanes = lanes;
+	}
+	BtBatchDev B;
+	memset(&B, 0, sizeof(B));
+	B.seq = in->seq; B.qual = in->qual; B.len = in->len; B.seed = in->seed;
+	B.n_reads = in->n_reads; B.stride = in->stride;
+	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
+	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
+	B.mm_pool_used = c->d_cursor + 1;
+	HIPCHK(hipMemcpyAsync(c->d_batch, &B, sizeof(B), hipMemcpyHostToDevice, c->stream));
+	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	BtBestArgs A;
+	A.prog = c->d_bprog; A.ix = c->d_ix; A.batch = c->d_batch;
+	A.arenas = c->arenas; A.arenaWords = words; A.nextRead = c->d_cursor;
+	A.counts = counts_dev ? counts_dev : c->d_counts;
+	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
+	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	c->timed = true;
+	return BT_OK;
 }
 
 static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uint32_t maxLen,
@@ -271,6 +325,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	    out->hit_cap == 0 || in->stride == 0 || (in->stride & 15u) != 0 ||
 	    ((uintptr_t)in->seq & 15u) != 0 || ((uintptr_t)in->qual & 15u) != 0) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
+	if (c->best) return run_best_device(c, in, out, counts_dev);
 	int rc = ctx_ensure_scratch(c, maxLen, in->n_reads);
 	if (rc != BT_OK) return rc;
 	BtKernelArgs A;

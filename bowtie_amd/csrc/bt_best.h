@@ -41,7 +41,7 @@
 #include "bt_core.h"
 
 #if defined(__HIPCC__)
-#define BF_FN __host__ __device__
+#define BF_FN static __host__ __device__
 #define BF_INL __host__ __device__ __forceinline__
 #else
 #define BF_FN static

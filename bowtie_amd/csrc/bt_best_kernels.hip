@@ -1,0 +1,51 @@
+/*
+ * bt_best_kernels.hip -- gfx950 kernel of the best-first search path (--best, --strata, -M, -v 3).
+ *
+ *   bt_best_kernel : one lane = one read, run start to finish by the automaton of bt_best.h; lanes
+ *                    pull reads from a global cursor until the batch drains.  Every lane owns an
+ *                    arena of `arenaWords` 32-bit words in HBM for the read's branches, heaps and
+ *                    driver records.
+ *
+ * Replaces (reference, CPU): the *Stateful worker loops of ebwt_search.cpp:1223/1509/1955/2609 for
+ * unpaired reads (MixedMultiAligner::run + UnpairedAlignerV2, aligner.h:244-360, 381-599).
+ */
+#include <hip/hip_runtime.h>
+#include "bt_best.h"
+#include "bt_kernels.h"
+
+__global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
+{
+	__shared__ BfProgram PROG;
+	__shared__ BtIndexDev IX[2];
+	__shared__ BtBatchDev BATCH;
+	for (uint32_t i = threadIdx.x; i < sizeof(BfProgram) / 4; i += blockDim.x) ((uint32_t*)&PROG)[i] = ((const uint32_t*)A.prog)[i];
+	for (uint32_t i = threadIdx.x; i < 2 * sizeof(BtIndexDev) / 4; i += blockDim.x) ((uint32_t*)IX)[i] = ((const uint32_t*)A.ix)[i];
+	for (uint32_t i = threadIdx.x; i < sizeof(BtBatchDev) / 4; i += blockDim.x) ((uint32_t*)&BATCH)[i] = ((const uint32_t*)A.batch)[i];
+	__syncthreads();
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	BfLane X;
+	__builtin_memset(&X, 0, sizeof(X));
+	X.A = (BF_G uint32_t*)(A.arenas + (uint64_t)g * A.arenaWords);
+	X.cap = A.arenaWords;
+	X.ix = IX; X.P = &PROG;
+	const uint32_t n = BATCH.n_reads;
+	for (;;) {
+		const uint32_t rd = atomicAdd(A.nextRead, 1u);
+		if (rd >= n) break;
+		bf_run_read(X, BATCH, rd);
+	}
+	if (A.counts) {
+		/* op counters (bt_op_counts order: lfex lf2 lf1 chase ftab offs rstarts frames lane_iters same_pair) */
+		atomicAdd(&A.counts[CN_LFEX], (unsigned long long)X.c_lfex); atomicAdd(&A.counts[CN_LF2], (unsigned long long)X.c_lf2);
+		atomicAdd(&A.counts[CN_LF1], (unsigned long long)X.c_lf1); atomicAdd(&A.counts[CN_CHASE], (unsigned long long)X.c_chase);
+		atomicAdd(&A.counts[CN_FTAB], (unsigned long long)X.c_ftab); atomicAdd(&A.counts[CN_OFFS], (unsigned long long)X.c_offs);
+		atomicAdd(&A.counts[CN_RSTARTS], (unsigned long long)X.c_rst); atomicAdd(&A.counts[CN_FRAMES], (unsigned long long)X.c_frames);
+		atomicAdd(&A.counts[CN_SAMEPAIR], (unsigned long long)X.c_same);
+	}
+}
+
+extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)
+{
+	hipLaunchKernelGGL(bt_best_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
+	return (int)hipGetLastError();
+}

@@ -3,6 +3,7 @@
 #define BT_KERNELS_H_
 
 #include "bt_core.h"
+#include "bt_best.h"
 
 #define BT_BLOCK 256
 
@@ -34,7 +35,19 @@ struct BtKernelArgs {
 	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
 };
 
+/* the best-first kernel (bt_best_kernels.hip) */
+struct BtBestArgs {
+	const BfProgram*  prog;      /* device memory */
+	const BtIndexDev* ix;        /* [2] */
+	const BtBatchDev* batch;
+	uint32_t*  arenas;           /* [nLanes][arenaWords] */
+	uint32_t   arenaWords;
+	uint32_t*  nextRead;
+	unsigned long long* counts;
+};
+
 extern "C" {
+int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream);
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */
 int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,

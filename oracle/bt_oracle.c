@@ -206,8 +206,8 @@ void bto_restore_text(const bto_index* ix, uint8_t* out)
 }
 
 /* joinedToTextOff, ebwt.h:2569-2629 */
-static int joined_to_text_cnt(const bto_index* ix, uint32_t qlen, uint32_t off,
-                              uint32_t* tidx, uint32_t* toff, uint32_t* tlen, uint64_t* probes)
+int bto_joined_to_text_cnt(const bto_index* ix, uint32_t qlen, uint32_t off,
+                           uint32_t* tidx, uint32_t* toff, uint32_t* tlen, uint64_t* probes)
 {
 	uint32_t top = 0, bot = ix->nFrag;
 	for (;;) {
@@ -237,7 +237,7 @@ static int joined_to_text_cnt(const bto_index* ix, uint32_t qlen, uint32_t off,
 int bto_joined_to_text(const bto_index* ix, uint32_t qlen, uint32_t off,
                        uint32_t* tidx, uint32_t* toff, uint32_t* tlen)
 {
-	return joined_to_text_cnt(ix, qlen, off, tidx, toff, tlen, NULL);
+	return bto_joined_to_text_cnt(ix, qlen, off, tidx, toff, tlen, NULL);
 }
 
 /* genRandSeed, pat.cpp:21-57 */
@@ -357,7 +357,7 @@ static int dfs_report_row(dfs_t* s, uint32_t numMms, uint32_t row, uint32_t top,
 	uint32_t off = bto_chase(ix, row, &jumps);
 	if (s->cnt) { s->cnt->chase += jumps; s->cnt->offs++; }
 	uint32_t tidx, toff, tlen;
-	if (!joined_to_text_cnt(ix, s->qlen, off, &tidx, &toff, &tlen, s->cnt ? &s->cnt->rstarts : NULL)) return 0;
+	if (!bto_joined_to_text_cnt(ix, s->qlen, off, &tidx, &toff, &tlen, s->cnt ? &s->cnt->rstarts : NULL)) return 0;
 	bto_hit h;
 	memset(&h, 0, sizeof(h));
 	h.tidx = tidx; h.toff = toff; h.oms = bot - top - 1;

@@ -136,6 +136,7 @@ static branch_t* br_new(env_t* env, uint32_t id, uint32_t qlen, uint16_t d0, uin
                         uint32_t itop, uint32_t ibot, const edit_t* edits, uint32_t nedits, int extraEdit)
 {
 	if (--(*env->budget) < 0) return NULL;
+	if (env->cnt) env->cnt->frames++;
 	branch_t* b = (branch_t*)calloc(1, sizeof(branch_t));
 	b->id = id; b->depth0 = d0; b->depth1 = d1; b->depth2 = d2; b->depth3 = d3;
 	b->rdepth = rdepth; b->len = len; b->cost = cost; b->ham = ham; b->top = itop; b->bot = ibot;
@@ -1170,6 +1171,7 @@ typedef struct {
 	int done;
 	/* RowChaser */
 	int cDone; uint32_t cRow, cJumps, cOff;
+	uint64_t* probes;
 } chaser_t;
 
 /* RowChaser::setRow, row_chaser.h:69-95 */
@@ -1199,7 +1201,7 @@ static void rowchaser_advance(chaser_t* c, env_t* env)
 static void rowchaser_off(chaser_t* c, uint32_t* tidx, uint32_t* toff)
 {
 	*toff = OFF_MASK;
-	if (!bto_joined_to_text(c->ebwt, c->qlen, c->cOff, tidx, toff, &c->tlen)) *tidx = OFF_MASK;
+	if (!bto_joined_to_text_cnt(c->ebwt, c->qlen, c->cOff, tidx, toff, &c->tlen, c->probes)) *tidx = OFF_MASK;
 }
 
 /* RangeChaser::setRow, range_chaser.h:52-121 */
@@ -1301,6 +1303,7 @@ int bto_align_read_best(const bto_index* ixFw, const bto_index* ixBw, const bt_p
 	driver_t* driver = build_tree(&env, ixFw, ixBw, pol, btCnt);
 	uint32_t alRnd = seed;                       /* Aligner::rand_ (aligner.h:65) */
 	chaser_t ch; memset(&ch, 0, sizeof(ch));
+	ch.probes = counts ? &counts->rstarts : NULL;
 	drv_set_query(driver, rd, NULL);
 	int done = driver->done;
 	if (btCnt) *btCnt = pol->max_bts;

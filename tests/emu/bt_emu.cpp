@@ -190,7 +190,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
 	/* the stateful best-first workers: entCap doubles as the arena size in words (0 = 4 M words) */
-	if (pol->best) return emu_run_best(p, pol, in, out, counts, entCap >= 4096u ? entCap : (1u << 22));
+	if (pol->best) return emu_run_best(p, pol, in, out, counts, entCap >= 256u ? entCap : (1u << 22));
 	/* rl_mode 2 = the 3-waves-per-SIMD layout: read in LDS (<= 104 bases), no candidate caches */
 	if (rl_mode == 2 && maxLen <= BT_RL3_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, true);
 	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, false);

@@ -147,3 +147,50 @@ def test_emu_three_wave_layout_matches_reference_sam(run, emu):
     res = emu[run["index"]].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384,
                                   n_lanes=37, lite=True)
     T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
+
+
+BEST_RAGGED = ["n2_best", "v3", "v2_a_best_strata", "n3_best", "n2_M3", "v1_best", "n1_best", "n0_best_a_m3",
+               "n3_best_a_l12_e200", "n2_k2_best_strata_m5"]
+
+
+def ragged_batch(n, lo, hi, seed0):
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(seed0)
+    reads = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        b = synth_reads(text, 1, L, mm_dist=(0, 1, 2, 3), seed=seed0 * 1000 + i, n_frac=0.2, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :L].copy(), b.qual[0, :L].tobytes()))
+    return pack_reads(reads)
+
+
+@pytest.mark.parametrize("mode", BEST_RAGGED)
+def test_emu_best_first_vs_oracle_ragged(mode, emu):
+    """The best-first automaton (bt_best.h) on ragged 1..150-base reads with Ns and low qualities:
+    hits and op counts equal the oracle's."""
+    kw = T.MODES[mode]
+    batch = ragged_batch(300, 1, 151, 11)
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+    got = emu["multi"].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), counts=ec)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(ec, f), f
+
+
+def test_emu_best_first_arena_overflow_is_flagged(emu):
+    batch = T.read_set("multi", "syn100")
+    res = emu["multi"].align(A.make_policy(**T.MODES["n2_best"]), batch, ent_cap=1200)
+    assert any(st & A.BT_ST_OVERFLOW for _, _, st in res)
+    # and a read that fits is unaffected by the others' overflow
+    want = T.oracle_results("multi", batch, T.MODES["n2_best"])
+    assert all(g == w for g, w in zip(res, want) if not (g[2] & A.BT_ST_OVERFLOW))
+
+
+def test_emu_best_first_max_length_reads(emu):
+    text = T.joined_text("e_coli")
+    e = E.EmuAligner(T.G + "/e_coli")
+    batch = synth_reads(text, 16, 1024, mm_dist=(0, 1, 2), seed=31, n_frac=0.0)
+    for mode in ("v2_best", "n2_best", "v3"):
+        kw = T.MODES[mode]
+        T.compare_results(e.align(A.make_policy(**kw), batch), T.oracle_results("e_coli", batch, kw), mode)

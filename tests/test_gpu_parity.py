@@ -228,3 +228,70 @@ def test_gpu_hits_verify_against_text_large(gidx):
         r = V.verify_hits(text_t, ln, rstarts, rb["seq"], rb["qual"], L, hits, n_hits, pool, kw)
         assert r["checked"] > 0.5 * n
         assert {k: v for k, v in r.items() if k != "checked"} == dict(bad_window=0, bad_mm_count=0, bad_mm_list=0, bad_policy=0, bad_cost=0)
+
+
+# ---- the best-first engine (--best, --strata, -M, -v 3): bt_best_kernel ---------------------------
+BEST_RAGGED = ["n2_best", "v3", "v2_a_best_strata", "n3_best", "n2_M3", "v1_best", "n1_best", "n0_best_a_m3",
+               "n3_best_a_l12_e200", "n2_k2_best_strata_m5"]
+
+
+@pytest.mark.parametrize("mode", BEST_RAGGED)
+def test_gpu_best_first_vs_oracle_ragged(mode, gidx):
+    """Ragged 1..150-base reads with Ns and low qualities: hits and op counts equal the oracle's."""
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(11)
+    reads = []
+    for i in range(1500):
+        L = int(rng.integers(1, 151))
+        b = synth_reads(text, 1, L, mm_dist=(0, 1, 2, 3), seed=11000 + i, n_frac=0.2, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :L].copy(), b.qual[0, :L].tobytes()))
+    batch = pack_reads(reads)
+    import oracle_lib as OL
+    oc, gc = OL.OpCounts(), A.OpCounts()
+    want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+    got = aligner(gidx, "multi", kw).align(batch, hit_cap=T.hit_cap_for(kw), counts=gc)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(gc, f), f
+
+
+@pytest.mark.parametrize("mode,length,n", [("n2_best", 100, 20000), ("v3", 76, 20000), ("v2_a_best_strata", 50, 10000)])
+def test_gpu_best_first_vs_oracle_e_coli_synthetic(mode, length, n, gidx):
+    kw = T.MODES[mode]
+    batch = synth_reads(T.joined_text("e_coli"), n, length, seed=777 + length)
+    want = T.oracle_results("e_coli", batch, kw, cap=T.hit_cap_for(kw))
+    got = aligner(gidx, "e_coli", kw).align(batch, hit_cap=T.hit_cap_for(kw))
+    T.compare_results(got, want, mode)
+
+
+def test_gpu_best_first_arena_overflow_retry(gidx, monkeypatch):
+    """Reads that outgrow a (deliberately tiny) arena are re-run through the twin context."""
+    monkeypatch.setenv("BT_BEST_ARENA_WORDS", "1200")
+    kw = T.MODES["n2_best"]
+    batch = T.read_set("multi", "syn100")
+    al = aligner(gidx, "multi", kw)
+    got = al.align(batch)
+    assert al.last_retried > 0
+    T.compare_results(got, T.oracle_results("multi", batch, kw), "n2_best tiny arenas")
+
+
+def test_gpu_best_first_large_batch_properties(gidx):
+    """300 k reads x 100 bp -n 2 --best: idempotence, permutation equivariance, and a sample
+    against the oracle."""
+    text = T.joined_text("e_coli")
+    n = 300_000
+    batch = synth_reads(text, n, 100, mm_dist=(0, 1, 2, 2, 3, 4), seed=4321)
+    kw = T.MODES["n2_best"]
+    al = aligner(gidx, "e_coli", kw)
+    r1 = al.align(batch)
+    assert T.result_digest(r1) == T.result_digest(al.align(batch))
+    from bowtie_amd.reads import ReadBatch
+    idx = np.arange(0, n, 149)
+    sub = ReadBatch(batch.seq[idx], batch.qual[idx], batch.len[idx], batch.seed[idx], [batch.names[i] for i in idx])
+    want = T.oracle_results("e_coli", sub, kw)
+    T.compare_results([r1[i] for i in idx], want, "sample of large batch")
+    perm = np.random.default_rng(3).permutation(len(idx))
+    pb = ReadBatch(sub.seq[perm], sub.qual[perm], sub.len[perm], sub.seed[perm], [sub.names[i] for i in perm])
+    rp = al.align(pb)
+    T.compare_results(rp, [want[i] for i in perm], "permuted")
