@@ -54,6 +54,9 @@ WORKLOADS = {
     "ecoli_n2_100": dict(index="ecoli", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=2_000_000),
     "big_v2_76": dict(index="big", length=76, pol=dict(mode="v", mms=2), mm_dist=(0, 0, 1, 1, 2, 3), reads=50_000_000),
     "big_n2_100": dict(index="big", length=100, pol=dict(mode="n", mms=2), mm_dist=(0, 1, 2, 2, 3, 4), reads=200_000_000),
+    # the best-first engine (--best): bt_best_kernel
+    "ecoli_n2_best_100": dict(index="ecoli", length=100, pol=dict(mode="n", mms=2, best=True), mm_dist=(0, 1, 2, 2, 3, 4), reads=2_000_000),
+    "big_n2_best_100": dict(index="big", length=100, pol=dict(mode="n", mms=2, best=True), mm_dist=(0, 1, 2, 2, 3, 4), reads=32_000_000),
 }
 
 
@@ -78,6 +81,8 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
     from bowtie_amd.synth import synth_reads, write_fastq
     pol = wl["pol"]
     args = ["-v", str(pol["mms"])] if pol["mode"] == "v" else ["-n", str(pol["mms"]), "-l", "28", "-e", "70"]
+    if pol.get("best"):
+        args.append("--best")
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
     cores = os.cpu_count() or 1
     if os.path.exists(ref_bin):
@@ -290,7 +295,7 @@ def main():
                                      if args.workload in MEASURED_HBM_BYTES_PER_READ and not args.genome else None),
                          "traffic_note": "rocprofv3 (2 x FETCH_SIZE + WRITE_SIZE) per read, gfx950-calibrated (profiles/r1_final/calib_fetch_size.txt), x reads per launch",
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
-                         "kernel": "bt_search_kernel", "kernel_ms_avg": kavg,
+                         "kernel": "bt_best_kernel" if wl["pol"].get("best") else "bt_search_kernel", "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": abytes,
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n,

@@ -555,8 +555,14 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 		}
 		bt_read_batch sin = { m, in->stride, sseq.data(), squal.data(), slen.data(), sseed.data() };
 		bt_hit_batch sout = { out->hit_cap, shits.data(), snh.data(), sst.data(), spool.data(), spare, 0 };
-		rc = bt_align_batch(c->big, &sin, &sout, nullptr);
+		bt_op_counts c2;
+		rc = bt_align_batch(c->big, &sin, &sout, counts ? &c2 : nullptr);
 		if (rc != BT_OK && rc != BT_ERR_OVERFLOW && rc != BT_ERR_READ_SHORT) return rc;
+		if (counts && c->best) {
+			counts->lfex += c2.lfex; counts->lf2 += c2.lf2; counts->lf1 += c2.lf1; counts->chase += c2.chase;
+			counts->ftab += c2.ftab; counts->offs += c2.offs; counts->rstarts += c2.rstarts; counts->frames += c2.frames;
+			counts->same_pair += c2.same_pair;
+		}
 		for (uint32_t k = 0; k < m; k++) {
 			const uint32_t i = redo[k];
 			out->n_hits[i] = snh[k]; out->status[i] = sst[k];
@@ -611,6 +617,27 @@ extern "C" int bt_probe_chase(bt_ctx* c, int mirror, const uint32_t* rows, uint3
 	}
 	(void)hipFree(d);
 	return rc == 0 ? BT_OK : BT_ERR_DEVICE;
+}
+
+/* Random-128-byte-gather ceiling: n_blocks x 256 threads, `iters` rank queries each, timed with HIP
+ * events; *gbs = queries x 128 B / time. */
+extern "C" int bt_bench_gather(bt_ctx* c, int mirror, uint32_t n_blocks, uint32_t iters, int dependent,
+                               float* ms_out, double* gbs_out)
+{
+	if (!c || !ms_out || !gbs_out || n_blocks == 0 || iters == 0 || (mirror && !c->idx->has_mirror)) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(c->idx->device));
+	uint32_t* sink = c->d_cursor + 7;
+	for (int rep = 0; rep < 2; rep++) {            /* first pass warms the TLBs */
+		HIPCHK(hipEventRecord(c->ev0, c->stream));
+		if (bt_launch_gather_bench(&c->idx->dev[mirror ? 1 : 0], n_blocks, iters, dependent ? 1u : 0u, sink, c->stream) != 0) return BT_ERR_DEVICE;
+		HIPCHK(hipEventRecord(c->ev1, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	float ms = 0.f;
+	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	*ms_out = ms;
+	*gbs_out = (double)n_blocks * 256.0 * iters * 128.0 / (ms * 1e-3) / 1e9;
+	return BT_OK;
 }
 
 extern "C" int bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64_t cap)

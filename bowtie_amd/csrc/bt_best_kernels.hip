@@ -32,7 +32,15 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 	for (;;) {
 		const uint32_t rd = atomicAdd(A.nextRead, 1u);
 		if (rd >= n) break;
+		/* a read that outgrows its arena is searched again by the host through the twin context:
+		 * its partial work is not tallied */
+		const BfLane before = X;
 		bf_run_read(X, BATCH, rd);
+		if (X.status & BT_STF_OVERFLOW) {
+			X.c_lfex = before.c_lfex; X.c_lf2 = before.c_lf2; X.c_lf1 = before.c_lf1; X.c_chase = before.c_chase;
+			X.c_ftab = before.c_ftab; X.c_offs = before.c_offs; X.c_rst = before.c_rst; X.c_same = before.c_same;
+			X.c_frames = before.c_frames;
+		}
 	}
 	if (A.counts) {
 		/* op counters (bt_op_counts order: lfex lf2 lf1 chase ftab offs rstarts frames lane_iters same_pair) */

@@ -53,6 +53,7 @@ int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* strea
 int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
                        const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
                        uint8_t* bucket, uint32_t* hist, uint32_t* order, void* stream);
+int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, uint32_t iters, uint32_t dep, uint32_t* sink, void* stream);
 int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
                          uint8_t* L, void* stream);
 int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,

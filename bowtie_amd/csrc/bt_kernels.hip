@@ -344,6 +344,33 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 	tidx[i] = t; toff[i] = o;
 }
 
+/* Random 128-byte-gather ceiling: every thread does `iters` independent rank queries at
+ * pseudo-random rows of the index -- the memory access pattern of the search kernels with all the
+ * search logic taken away.  Each query touches one aligned 128-byte side pair (4 x 16-byte loads of the
+ * row's side + 8 counter bytes of the partner side).  `dep` != 0 makes each query's row depend on the
+ * previous result (an SA walk's dependency chain) instead of being known up front. */
+__global__ __launch_bounds__(256) void bt_gather_bench_kernel(BtIndexDev ix, uint32_t iters, uint32_t dep, uint32_t* sink)
+{
+	BtRankSel sel;
+	sel.ebwt = ix.ebwt; sel.zSide = ix.zSide; sel.zSym = ix.zSym;
+	sel.f0 = ix.fchr[0]; sel.f1 = ix.fchr[1]; sel.f2 = ix.fchr[2]; sel.f3 = ix.fchr[3];
+	uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+	for (uint32_t k = 0; k < iters; k++) {
+		x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+		const uint32_t row = (uint32_t)(((uint64_t)x * ix.len) >> 32);
+		uint32_t r[4], L;
+		dev_rank4(sel, row, r, &L);
+		acc += r[L];
+		if (dep) x += r[L];
+	}
+	if (acc == 0x12345678u) sink[0] = acc;
+}
+extern "C" int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, uint32_t iters, uint32_t dep, uint32_t* sink, void* stream)
+{
+	hipLaunchKernelGGL(bt_gather_bench_kernel, dim3(nBlocks), dim3(256), 0, (hipStream_t)stream, *ix, iters, dep, sink);
+	return (int)hipGetLastError();
+}
+
 /* ---- launchers (called from bt_api.cpp, which is plain C++) ------------------------------- */
 /* occ = waves per SIMD the register allocator was told to fit (1..4): the same source compiled for
  * different register budgets; which is fastest is a measured choice (bt_api.cpp, BT_OCC). */

@@ -212,6 +212,12 @@ int bt_probe_rank(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uin
 int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t qlen,
                    uint32_t* joined_off, uint32_t* tidx, uint32_t* toff);
 
+/* Measurement aid: the random-128-byte-gather ceiling of this GPU on this index --
+ * n_blocks x 256 lanes each doing `iters` rank queries at pseudo-random rows (dependent != 0: each
+ * row derived from the previous answer, as in an SA walk), timed with HIP events.
+ * *gbs = queries x 128 B / time. */
+int bt_bench_gather(bt_ctx* ctx, int mirror, uint32_t n_blocks, uint32_t iters, int dependent,
+                    float* ms, double* gbs);
 
 /* ---- host I/O either side of the path --------------------------------
  * Read files -> bt_read_batch, bt_hit_batch -> the reference's output text.  Host-only code in
