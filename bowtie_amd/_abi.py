@@ -59,12 +59,13 @@ class OutOpts(C.Structure):
     _fields_ = [("sam", C.c_int32), ("full_ref", C.c_int32), ("ref_idx", C.c_int32), ("off_base", C.c_int32),
                 ("print_cost", C.c_int32), ("show_seed", C.c_int32), ("mapq", C.c_int32),
                 ("no_qname_trunc", C.c_int32), ("no_unal", C.c_int32), ("sam_nosq", C.c_int32),
-                ("khits", C.c_uint32), ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("reserved", C.c_int32),
+                ("khits", C.c_uint32), ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("sample_max", C.c_int32),
                 ("suppress", C.c_uint64)]
 
 
 class OutTally(C.Structure):
-    _fields_ = [("aligned", C.c_uint64), ("unaligned", C.c_uint64), ("maxed", C.c_uint64), ("reported", C.c_uint64)]
+    _fields_ = [("aligned", C.c_uint64), ("unaligned", C.c_uint64), ("maxed", C.c_uint64), ("reported", C.c_uint64),
+                ("sample_max", C.c_uint64)]
 
 
 HIT_DTYPE = [("tidx", "<u4"), ("toff", "<u4"), ("oms", "<u4"), ("mm_off", "<u4"), ("cost", "<u2"),

@@ -486,7 +486,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	    out->hit_cap == 0 || (in->stride & 15u) != 0) return BT_ERR_ARG;
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < n; i++) {
-		if (in->len[i] == 0 || in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;
+		if (in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;    /* 0 is fine: -3/-5 can trim a read away */
 		if (in->len[i] > maxLen) maxLen = in->len[i];
 	}
 	HIPCHK(hipSetDevice(c->idx->device));

@@ -43,7 +43,7 @@ struct Options {
 	std::vector<std::string> rg_fields;
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
-	bool quiet = false, timing = false, sam_nohead = false, tryhard = false;
+	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false;
 	bool suppress_set = false, int_quals = false;
 	uint32_t batch_reads = 4u << 20;
 	std::string cmdline;
@@ -127,8 +127,7 @@ void usage(FILE* o)
 	    "  --seed <int>       seed for random number generator\n"
 	    "  --version          print version information and quit\n"
 	    "  -h/--help          print this usage message\n"
-	    "Not in this build (best-first engine, SURVEY.md 8f-1): --best --strata -M -v 3 -1/-2 --12\n"
-	    "  --interleaved -I/-X --ff/--fr/--rf -Q -z\n",
+	    "Not in this build (paired-end, SURVEY.md 8f-1): -1/-2 --12 --interleaved -I/-X --ff/--fr/--rf -Q -z\n",
 	    o);
 }
 
@@ -144,7 +143,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_BEST, O_STRATA, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -162,19 +161,19 @@ const LongOpt LONGS[] = {
 	{"thread-ceiling", 1, O_IGNORED_ARG}, {"thread-piddir", 1, O_IGNORED_ARG}, {"mm", 0, O_IGNORED}, {"shmem", 0, O_IGNORED},
 	{"mmsweep", 0, O_IGNORED}, {"prewidth", 1, O_IGNORED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_UNSUPPORTED},
 	/* the best-first engine and everything that needs it */
-	{"best", 0, O_UNSUPPORTED}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_UNSUPPORTED},
+	{"best", 0, O_BEST}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_STRATA},
 	{"minins", 1, O_UNSUPPORTED_ARG}, {"maxins", 1, O_UNSUPPORTED_ARG}, {"ff", 0, O_UNSUPPORTED}, {"fr", 0, O_UNSUPPORTED},
 	{"rf", 0, O_UNSUPPORTED}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_UNSUPPORTED_ARG},
 	{"integer-quals", 0, O_INTQUALS}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
 	{"al", 1, O_AL}, {"un", 1, O_UN}, {"max", 1, O_MAX}, {"phased", 0, O_UNSUPPORTED},
-	{"strandfix", 0, O_UNSUPPORTED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
+	{"strandfix", 0, O_IGNORED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
 	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_UNSUPPORTED},
 	{"orig", 1, O_UNSUPPORTED_ARG}, {"filepar", 0, O_UNSUPPORTED}, {"noreconcile", 0, O_UNSUPPORTED},
 	{nullptr, 0, 0}
 };
 /* short options taking an argument */
-const char* SHORT_ARG = "us35oenlpkmBxvF";
-const char* SHORT_UNSUPPORTED_ARG = "M12IXQw";
+const char* SHORT_ARG = "us35oenlpkmMBxvF";
+const char* SHORT_UNSUPPORTED_ARG = "12IXQw";
 const char* SHORT_UNSUPPORTED = "bz";
 
 void parse_args(int argc, char** argv, Options* O)
@@ -252,7 +251,10 @@ void parse_args(int argc, char** argv, Options* O)
 		case 'v': break;
 		case 'p': O->threads = (int)parse_int(val, 1, "-p/--threads arg must be at least 1"); break;
 		case 'k': O->pol.khits = (uint32_t)parse_int(val, 1, "-k arg must be at least 1"); break;
+		case 'M': O->pol.sample_max = 1;    /* falls through: -M <n> is -m <n> plus sampling (ebwt_search.cpp:721-725) */
 		case 'm': O->pol.mhits = (uint32_t)parse_int(val, 1, "-m arg must be at least 1"); break;
+		case O_BEST: O->pol.best = 1; break;
+		case O_STRATA: O->pol.strata = 1; break;
 		case 'B': O->out.off_base = (int32_t)parse_int(val, -999999, "-B/--offbase arg must be at least -999999"); break;
 		case 'x': O->index = val; break;
 		case 'F': {
@@ -270,7 +272,7 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_PHRED64: O->rd.qual_enc = BT_QUAL_PHRED64; break;
 		case O_PHRED33: O->rd.qual_enc = BT_QUAL_PHRED33; break;
 		case O_SEED: O->rd.seed = (uint32_t)parse_int(val, 0, "--seed arg must be at least 0"); break;
-		case O_MAXBTS: O->pol.max_bts = (int32_t)parse_int(val, 0, "--maxbts must be positive"); break;
+		case O_MAXBTS: O->pol.max_bts = (int32_t)parse_int(val, 0, "--maxbts must be positive"); O->maxbts_set = true; break;
 		case O_QUIET: O->quiet = true; break;
 		case O_REFIDX: O->out.ref_idx = 1; break;
 		case O_FULLREF: O->out.full_ref = 1; break;
@@ -332,8 +334,17 @@ void parse_args(int argc, char** argv, Options* O)
 			if (O->pol.mms > 3) die("-v arg must be at most 3");
 		}
 	}
-	if (O->pol.mode == BT_MODE_V && O->pol.mms == 3)
-		die("Error: -v 3 runs the reference's best-first engine, which this build does not have (SURVEY.md 8f-1)");
+	/* what sends the reference to its stateful best-first workers (ebwt_search.cpp:851-853, 877-887) */
+	if (O->pol.mode == BT_MODE_V && O->pol.mms == 3) O->pol.best = 1;
+	if (!O->pol.best && O->pol.sample_max) {
+		if (!O->quiet) fprintf(stderr, "Warning: -M was specified w/o --best; automatically enabling --best\n");
+		O->pol.best = 1;
+	}
+	if (O->pol.strata && !O->pol.best) die("--strata must be combined with --best");
+	if (O->pol.strata && !O->pol.all_hits && O->pol.khits == 1 && O->pol.mhits == 0xffffffffu)
+		die("--strata has no effect unless combined with -m, -a, or -k N where N > 1");
+	/* --maxbts: 125 for the phase programs, 800 for the best-first workers (ebwt_search.cpp:185-186) */
+	if (O->pol.best && !O->maxbts_set) O->pol.max_bts = 800;
 	if (O->pol.mode == BT_MODE_N && O->pol.mms > 3) die("-n/--seedmms arg must be at most 3");
 	/* positionals: [<ebwt>] <reads> [<hits>] (ebwt_search.cpp:2930-2975) */
 	size_t pi = 0;
@@ -358,6 +369,7 @@ void parse_args(int argc, char** argv, Options* O)
 	}
 	if (O->threads <= 0) { const unsigned hc = std::thread::hardware_concurrency(); O->threads = hc == 0 ? 1 : (hc > 32 ? 32 : (int)hc); }
 	O->out.khits = O->pol.khits; O->out.mhits = O->pol.mhits; O->out.all_hits = O->pol.all_hits;
+	O->out.sample_max = O->pol.sample_max;
 }
 
 bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
@@ -430,6 +442,8 @@ std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 	const uint32_t n = j->rb.n_reads;
 	const bool all = O.pol.all_hits != 0;
 	j->hit_cap = all ? 16u : (O.pol.khits > 64u ? 64u : O.pol.khits);
+	/* -M: a read over the ceiling keeps its first mhits hits, one of which is printed */
+	if (O.pol.sample_max && !all && O.pol.mhits > j->hit_cap) j->hit_cap = O.pol.mhits > 64u ? 64u : O.pol.mhits;
 	j->hits.resize((size_t)n * j->hit_cap);
 	j->n_hits.assign(n, 0); j->status.assign(n, 0);
 	j->mm_pool.resize((size_t)n * j->hit_cap * 6u + 1024u);
@@ -451,8 +465,8 @@ std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 	for (uint32_t i = 0; i < n; i++) {
 		const uint32_t tot = j->n_hits[i];
 		if (j->status[i] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
-		if (tot > O.pol.mhits) continue;                              /* nothing of it is printed */
-		const uint32_t want = all ? tot : (tot < O.pol.khits ? tot : O.pol.khits);
+		if (tot > O.pol.mhits && !O.pol.sample_max) continue;         /* nothing of it is printed */
+		const uint32_t want = tot > O.pol.mhits ? O.pol.mhits : (all ? tot : (tot < O.pol.khits ? tot : O.pol.khits));
 		if (want > j->hit_cap || (j->status[i] & BT_ST_MMPOOL)) { redo.push_back(i); need.push_back(want > j->hit_cap ? want : j->hit_cap); }
 	}
 	size_t at = 0;
@@ -489,7 +503,7 @@ std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 			w.read = redo[at + k]; w.n_hits = snh[k]; w.status = sst[k];
 			if (sst[k] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
 			const uint32_t tot = snh[k];
-			uint32_t keep = all ? tot : (tot < O.pol.khits ? tot : O.pol.khits);
+			uint32_t keep = tot > O.pol.mhits ? O.pol.mhits : (all ? tot : (tot < O.pol.khits ? tot : O.pol.khits));
 			if (keep > cap) keep = cap;
 			if (sst[k] & BT_ST_MMPOOL) {
 				/* still short of mismatch slots: this read alone, a full-length list per hit */
@@ -610,7 +624,7 @@ int main(int argc, char** argv)
 	});
 
 	/* ---- stage 3: writer ---- */
-	bt_out_tally tally = {0, 0, 0, 0};
+	bt_out_tally tally = {0, 0, 0, 0, 0};
 	std::string fatal;
 	FILE *f_al = nullptr, *f_un = nullptr, *f_max = nullptr;
 	std::thread writer([&] {
@@ -631,6 +645,14 @@ int main(int argc, char** argv)
 			if (!fatal.empty()) continue;
 			const double tb = now_s();
 			const uint32_t n = j->rb.n_reads;
+			if (!O.quiet && (O.pol.mode == BT_MODE_N || O.pol.best)) {
+				/* search_seeded_phase1.c:17-20 / UnpairedAlignerV2::setQuery (aligner.h:440-444) */
+				for (uint32_t i = 0; i < n; i++) if (j->rb.len[i] < 4u) {
+					const std::string nm(j->store->names.data() + j->store->name_off[i], (size_t)(j->store->name_off[i + 1] - j->store->name_off[i]));
+					if (O.pol.best) fprintf(stderr, "Warning: Skipping read %s because it is less than 4 characters long\n", nm.c_str());
+					else fprintf(stderr, "Warning: Skipping read (%s) because it is less than 4 characters long\n", nm.c_str());
+				}
+			}
 			bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), j->mm_used };
 			const char* names = j->store->names.data();
 			const uint64_t* noff = j->store->name_off.data();
@@ -652,7 +674,7 @@ int main(int argc, char** argv)
 				for (uint32_t p = 0; p < pieces; p++)
 					segs.push_back({lo + (uint32_t)((uint64_t)(hi - lo) * p / pieces), lo + (uint32_t)((uint64_t)(hi - lo) * (p + 1) / pieces), -1});
 			}
-			parts.resize(segs.size()); tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0});
+			parts.resize(segs.size()); tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0, 0});
 			auto run = [&](size_t si) {
 				const Seg& sg = segs[si];
 				if (sg.wide < 0) { bt_io_format(j->rb, names, noff, hb, refs, O.out, sg.lo, sg.hi, &parts[si], &tl[si]); return; }
@@ -675,6 +697,7 @@ int main(int argc, char** argv)
 			for (size_t si = 0; si < segs.size(); si++) {
 				fwrite(parts[si].data(), 1, parts[si].size(), fout);
 				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
+				tally.sample_max |= tl[si].sample_max;
 			}
 			if (dumping) {
 				/* HitSink::dumpAlign / dumpUnal / dumpMaxed (hit.h:385-488): the read's record as it stood in

@@ -479,6 +479,8 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 		if (plen < 4u || nsSeed > P.seedMms) { L.status = L.status | BT_STF_SKIPPED; L.step = (uint32_t)P.nsteps - 1u; }
 	} else if (plen < P.minLen) {
 		L.status = L.status | BT_STF_TOOSHORT; L.step = (uint32_t)P.nsteps - 1u;
+	} else if (plen == 0) {
+		L.step = (uint32_t)P.nsteps - 1u;          /* nothing to search: unaligned */
 	}
 }
 

@@ -284,14 +284,11 @@ struct BtParsed {
 
 static const uint8_t* asc2dna_table()
 {
-	static uint8_t t[256];
-	static bool init = false;
-	if (!init) {
-		memset(t, 4, sizeof(t));
-		t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
-		init = true;
-	}
-	return t;
+	/* built once, by whichever thread gets here first (C++11 guarantees the initialisation of a
+	 * function-local static is race-free); the parse threads only ever read it */
+	struct Table { uint8_t t[256]; Table() { memset(t, 4, sizeof(t)); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; } };
+	static const Table tab;
+	return tab.t;
 }
 
 /* solexaToPhred (qual.h:29-33): round(10 log10(10^(sol/10) + 1)) */
@@ -937,9 +934,8 @@ static void verbose_hit(std::string* o, const char* nm, size_t nn, const uint8_t
 		/* mismatches by ascending 5'-relative offset: pos:ref>read */
 		static const char dna[] = "ACGTN", rc[] = "TGCAN";
 		bool firstmm = true;
-		uint16_t sorted[64]; uint32_t n = h.nmm > 64 ? 64 : h.nmm;
-		for (uint32_t i = 0; i < n; i++) sorted[i] = mm[i];
-		for (uint32_t i = 1; i < n; i++) { uint16_t v = sorted[i]; uint32_t j = i; while (j > 0 && BT_MM_POS(sorted[j - 1]) > BT_MM_POS(v)) { sorted[j] = sorted[j - 1]; j--; } sorted[j] = v; }
+		const uint16_t* sorted = mm;               /* the search stores the list ordered by position */
+		const uint32_t n = h.nmm;
 		for (uint32_t i = 0; i < n; i++) {
 			const uint32_t pos = BT_MM_POS(sorted[i]), refc = BT_MM_REFC(sorted[i]);
 			if (!firstmm) o->push_back(',');
@@ -962,7 +958,8 @@ static void verbose_hit(std::string* o, const char* nm, size_t nn, const uint8_t
 }
 
 static void sam_hit(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
-                    const bt_hit& h, const uint16_t* mm, uint32_t xms, const BtRefNames& refs, const bt_out_opts& op)
+                    const bt_hit& h, const uint16_t* mm, uint32_t xms, const BtRefNames& refs, const bt_out_opts& op,
+                    int mapq_override = -1)
 {
 	static const char dna[] = "ACGT";
 	const bool fw = h.fw != 0;
@@ -970,7 +967,7 @@ static void sam_hit(std::string* o, const char* nm, size_t nn, const uint8_t* se
 	o->push_back('\t'); put_u(o, fw ? 0u : 16u);
 	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
 	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
-	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", op.mapq); o->append(b); }
+	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", mapq_override >= 0 ? mapq_override : op.mapq); o->append(b); }
 	o->push_back('\t'); put_u(o, L); o->append("M\t*\t0\t0\t");
 	put_seq(o, seq, L, fw);
 	o->push_back('\t');
@@ -979,9 +976,8 @@ static void sam_hit(std::string* o, const char* nm, size_t nn, const uint8_t* se
 	o->append("\tMD:Z:");
 	/* MD walks the alignment left to right on the reference: by 5' offset for '+', by descending
 	 * offset for '-' */
-	uint16_t sorted[64]; uint32_t n = h.nmm > 64 ? 64 : h.nmm;
-	for (uint32_t i = 0; i < n; i++) sorted[i] = mm[i];
-	for (uint32_t i = 1; i < n; i++) { uint16_t v = sorted[i]; uint32_t j = i; while (j > 0 && BT_MM_POS(sorted[j - 1]) > BT_MM_POS(v)) { sorted[j] = sorted[j - 1]; j--; } sorted[j] = v; }
+	const uint16_t* sorted = mm;                   /* ordered by position (any length: Phred<5 mismatches cost nothing) */
+	const uint32_t n = h.nmm;
 	uint32_t run_from = 0;     /* alignment columns consumed so far */
 	for (uint32_t k = 0; k < n; k++) {
 		const uint16_t e = fw ? sorted[k] : sorted[n - 1 - k];
@@ -1027,6 +1023,25 @@ void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* na
 		}
 		if (tot > op.mhits) {           /* over the -m ceiling: counted, nothing printed (hit.h:494-500) */
 			if (tally) tally->maxed++;
+			if (op.sample_max) {
+				/* -M (VerboseHitSink::reportMaxed hit.cpp:16-68, SAMHitSink::reportMaxed sam.cpp:263-311): the
+				 * first mhits hits were buffered, best stratum first; one of those tied for the best
+				 * stratum is printed, picked with the first draw of the read's generator */
+				const uint32_t nb = op.mhits < hb.hit_cap ? op.mhits : hb.hit_cap;
+				const bt_hit* hs = hb.hits + (size_t)i * hb.hit_cap;
+				uint32_t num = 1;
+				for (uint32_t k = 1; k < nb; k++) { if (hs[k].stratum == hs[k - 1].stratum) num++; else break; }
+				uint32_t last = rb.seed[i];
+				last = 1664525u * last + 1013904223u;
+				uint32_t r = last >> 16;
+				last = 1664525u * last + 1013904223u;
+				r = (r ^ last) % num;
+				bt_hit h = hs[r];
+				const uint16_t* mm = hb.mm_pool ? hb.mm_pool + h.mm_off : nullptr;
+				if (op.sam) sam_hit(out, nm, nn, seq, qual, L, h, mm, nb + 1u, refs, op, 0);
+				else { h.oms = nb; verbose_hit(out, nm, nn, seq, qual, L, h, mm, rb.seed[i], refs, op); }
+				if (tally) { tally->aligned++; tally->reported++; tally->sample_max = 1; }
+			}
 			continue;
 		}
 		const uint32_t np = tot < lim ? tot : lim;
@@ -1057,14 +1072,21 @@ void bt_io_sam_header(const BtRefNames& refs, const bt_out_opts& op, const char*
 
 void bt_io_summary(const bt_out_tally& t, std::string* o)
 {
-	const uint64_t tot = t.aligned + t.unaligned + t.maxed;
+	/* with -M the sampled reads are already among the aligned ones (hit.h:289-319) */
+	const bool sm = t.sample_max != 0;
+	const uint64_t tot = t.aligned + t.unaligned + (sm ? 0 : t.maxed);
+	const uint64_t withAl = t.aligned + (sm ? 0 : t.maxed);
 	double al = 0, un = 0, mx = 0;
-	if (tot) { al = 100.0 * (double)(t.aligned + t.maxed) / (double)tot; un = 100.0 * (double)t.unaligned / (double)tot; mx = 100.0 * (double)t.maxed / (double)tot; }
+	if (tot) { al = 100.0 * (double)withAl / (double)tot; un = 100.0 * (double)t.unaligned / (double)tot; mx = 100.0 * (double)t.maxed / (double)tot; }
 	char b[256];
 	snprintf(b, sizeof(b), "# reads processed: %llu\n", (unsigned long long)tot); o->append(b);
-	snprintf(b, sizeof(b), "# reads with at least one alignment: %llu (%.2f%%)\n", (unsigned long long)(t.aligned + t.maxed), al); o->append(b);
+	snprintf(b, sizeof(b), "# reads with at least one alignment: %llu (%.2f%%)\n", (unsigned long long)withAl, al); o->append(b);
 	snprintf(b, sizeof(b), "# reads that failed to align: %llu (%.2f%%)\n", (unsigned long long)t.unaligned, un); o->append(b);
-	if (t.maxed) { snprintf(b, sizeof(b), "# reads with alignments suppressed due to -m: %llu (%.2f%%)\n", (unsigned long long)t.maxed, mx); o->append(b); }
+	if (t.maxed) {
+		snprintf(b, sizeof(b), sm ? "# reads with alignments sampled due to -M: %llu (%.2f%%)\n" : "# reads with alignments suppressed due to -m: %llu (%.2f%%)\n",
+		         (unsigned long long)t.maxed, mx);
+		o->append(b);
+	}
 	if (t.reported == 0) o->append("No alignments\n");
 	else { snprintf(b, sizeof(b), "Reported %llu alignments\n", (unsigned long long)t.reported); o->append(b); }
 }

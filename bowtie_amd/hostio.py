@@ -80,12 +80,12 @@ def read_all(spec: str, **kw) -> Optional[ReadBatch]:
 
 def out_opts(sam=False, full_ref=False, ref_idx=False, off_base=0, print_cost=False, show_seed=False, mapq=255,
              no_qname_trunc=False, no_unal=False, sam_nosq=False, khits=1, mhits=0xFFFFFFFF, all_hits=False,
-             suppress: Sequence[int] = ()) -> A.OutOpts:
+             suppress: Sequence[int] = (), sample_max=False) -> A.OutOpts:
     mask = 0
     for f in suppress:
         mask |= 1 << (f - 1)
     return A.OutOpts(int(sam), int(full_ref), int(ref_idx), off_base, int(print_cost), int(show_seed), mapq,
-                     int(no_qname_trunc), int(no_unal), int(sam_nosq), khits, mhits, int(all_hits), 0, mask)
+                     int(no_qname_trunc), int(no_unal), int(sam_nosq), khits, mhits, int(all_hits), int(sample_max), mask)
 
 
 def pack_hits(per_read, hit_cap: int):

@@ -277,13 +277,14 @@ typedef struct bt_out_opts {
 	int32_t  sam_nosq;       /* --sam-nosq (header only)                                       */
 	uint32_t khits, mhits;   /* -k / -m: finishRead's rules (hit.h:741-786)                    */
 	int32_t  all_hits;       /* -a                                                             */
-	int32_t  reserved;
+	int32_t  sample_max;     /* -M: a read over mhits prints one of its buffered best-stratum hits,
+	                            picked with the read's seed (hit.cpp:16-68, sam.cpp:263-311)     */
 	uint64_t suppress;       /* --suppress: bit f set = 1-based column f+1 of the default
 	                            format is left out (hit.cpp:94-297)                            */
 } bt_out_opts;
 
 /* HitSink::finish's counters (hit.h:270-346) */
-typedef struct bt_out_tally { uint64_t aligned, unaligned, maxed, reported; } bt_out_tally;
+typedef struct bt_out_tally { uint64_t aligned, unaligned, maxed, reported, sample_max; } bt_out_tally;
 
 /* text of all reads of the batch, in read order; *text is malloc'ed (bt_text_free).  tally
  * (optional) is added to. */
@@ -295,7 +296,7 @@ int  bt_format_hits(const bt_read_batch* reads, const char* names, const uint64_
 int  bt_format_sam_header(const char* const* refnames, const uint32_t* reflens, uint32_t n_refs,
                           const bt_out_opts* o, const char* cmdline, const char* rgline,
                           char** text, size_t* text_len);
-/* HitSink::finish's stderr summary (hit.h:270-346), unpaired, no -M */
+/* HitSink::finish's stderr summary (hit.h:270-346), unpaired; tally->sample_max != 0: the -M wording */
 int  bt_format_summary(const bt_out_tally* tally, char** text, size_t* text_len);
 void bt_text_free(char* text);
 

@@ -971,7 +971,14 @@ int bto_align_read(const bto_index* ixFw, const bto_index* ixBw, const bt_policy
                    bto_hit* hits, int cap, uint32_t* n_hits_total, uint32_t* status,
                    bt_op_counts* counts)
 {
-	if (len <= 0 || len > BTO_MAXLEN) return -BT_ERR_ARG;
+	if (len < 0 || len > BTO_MAXLEN) return -BT_ERR_ARG;
+	if (len == 0 && !pol->best) {
+		/* a read trimmed away (-3/-5): skipped by the seeded worker (search_seeded_phase1.c:17-44), an
+		 * error for -v 1/2 (search_1mm_phase1.c:12-15, search_23mm_phase1.c:13-20), nothing to find for -v 0 */
+		if (n_hits_total) *n_hits_total = 0;
+		if (status) *status = pol->mode == BT_MODE_N ? BT_ST_SKIPPED : (pol->mms > 0 ? BT_ST_TOOSHORT : 0);
+		return 0;
+	}
 	if (pol->best) return bto_align_read_best(ixFw, ixBw, pol, seq, qual, len, seed, hits, cap, n_hits_total, status, counts);
 	sink_t sink;
 	memset(&sink, 0, sizeof(sink));

@@ -1274,7 +1274,7 @@ int bto_align_read_best(const bto_index* ixFw, const bto_index* ixBw, const bt_p
                         bto_hit* hits, int cap, uint32_t* n_hits_total, uint32_t* status,
                         bt_op_counts* counts)
 {
-	if (len <= 0 || len > BTO_MAXLEN) return -BT_ERR_ARG;
+	if (len < 0 || len > BTO_MAXLEN) return -BT_ERR_ARG;
 	if (pol->mode == BT_MODE_V ? (pol->mms < 0 || pol->mms > 3) : (pol->mms < 0 || pol->mms > 3)) return -BT_ERR_ARG;
 	if ((pol->mode == BT_MODE_N || pol->mms > 0) && !ixBw) return -BT_ERR_ARG;
 	sink_t sink;

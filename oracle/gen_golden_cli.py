@@ -151,6 +151,21 @@ def cases(plain):
         ("dump_fa", E, ["-f", "-v", "2", "--al", "AL", "--un", "UN"], "cli/io.fa"),
         ("dump_raw", E, ["-r", "-v", "1", "--un", "UN"], "cli/io.raw"),
         ("dump_cmdline", E, ["-c", "-v", "2", "--al", "AL", "--un", "UN"], cseq),
+        # the stateful best-first workers: --best, --strata, -M, -v 3
+        ("best_default", E, ["--best"], "cli/io.fq"),
+        ("best_sam_n2", E, ["--best", "-S", "--sam-nohead", "-n", "2"], "cli/io.fq"),
+        ("v3_default", E, ["-v", "3"], "cli/io.fq"),
+        ("best_strata_a", M, ["-a", "--best", "--strata", "-v", "2"], "cli/multi.fq"),
+        ("best_strata_k3_m5_sam", M, ["-k", "3", "--best", "--strata", "-m", "5", "-S", "--sam-nohead"], "cli/multi.fq"),
+        ("bigM_verbose", M, ["-M", "2", "-v", "2"], "cli/multi.fq"),
+        ("bigM_sam_dump", M, ["-M", "3", "--best", "-n", "2", "-S", "--sam-nohead", "--max", "MAX", "--un", "UN", "--al", "AL"], "cli/multi.fq"),
+        ("bigM_k2_cost", M, ["-M", "4", "-k", "2", "--best", "--cost", "-v", "3"], "cli/multi.fq"),
+        ("best_maxbts_nofw", E, ["--best", "--maxbts", "3", "--nofw", "-n", "3", "-e", "100"], "cli/io.fq"),
+        # reads trimmed to fewer than 4 bases, or to nothing: skipped with a warning, counted as unaligned
+        ("best_trim_short", E, ["--best", "-3", "32", "-n", "2"], "cli/io.fq"),
+        ("n2_trim_short_sam", E, ["-3", "33", "-n", "2", "-S", "--sam-nohead"], "cli/io.fq"),
+        ("n2_trim_away", E, ["-3", "40", "-n", "2", "-S", "--sam-nohead"], "cli/io.fq"),
+        ("best_trim_away", E, ["-5", "20", "-3", "20", "--best", "-v", "1"], "cli/io.fq"),
     ]
 
 

@@ -38,6 +38,9 @@ def interpret(args):
         elif a == "-e": pol["qual_thresh"] = int(next(it))
         elif a == "-k": pol["khits"] = int(next(it))
         elif a == "-m": pol["mhits"] = int(next(it))
+        elif a == "-M": pol["mhits"] = int(next(it)); pol["sample_max"] = True
+        elif a == "--best": pol["best"] = True
+        elif a == "--strata": pol["strata"] = True
         elif a == "-a": pol["all_hits"] = True
         elif a == "--nofw": pol["nofw"] = True
         elif a == "--norc": pol["norc"] = True
@@ -73,7 +76,7 @@ def interpret(args):
         elif a == "--suppress": out["suppress"] = [int(x) for x in next(it).split(",")]
         elif a in ("--al", "--un", "--max"): ex.setdefault("dumps", {})[next(it)] = a
         else: raise ValueError("unhandled option " + a)
-    for k in ("khits", "mhits", "all_hits"):
+    for k in ("khits", "mhits", "all_hits", "sample_max"):
         if k in pol:
             out[k] = pol[k]
     return rd, pol, out, ex

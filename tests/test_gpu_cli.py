@@ -36,6 +36,10 @@ def summary_lines(stderr: bytes):
             if l.startswith("#") or l.startswith("Reported") or l.startswith("No align")]
 
 
+def warning_lines(stderr: bytes):
+    return [l for l in stderr.decode(errors="replace").strip().split("\n") if l.startswith("Warning:")]
+
+
 @pytest.mark.parametrize("case", CC.cases(), ids=lambda c: c["name"])
 def test_cli_matches_reference(case, tmp_path):
     assert os.path.exists(BIN), "bowtie-amd is not built (python -c 'import __graft_entry__ as g; g.build()')"
@@ -50,12 +54,14 @@ def test_cli_matches_reference(case, tmp_path):
     for l in got_pg:
         assert l.startswith(b'@PG\tID:Bowtie\tVN:1.3.1\tCL:"')
     assert summary_lines(p.stderr) == summary_lines("\n".join(case["stderr"]).encode())
+    assert warning_lines(p.stderr) == warning_lines("\n".join(case["stderr"]).encode())
     for k, path in dumps.items():
         got = open(path, "rb").read() if os.path.exists(path) else b""
         assert got == CC.expected_dump(case, k), k
 
 
-@pytest.mark.parametrize("name", ["fq_default", "multi_all", "multi_sam_notrunc", "fq_gz_two_files", "multi_all_m3", "dump_multi_m3", "dump_fq"])
+@pytest.mark.parametrize("name", ["fq_default", "multi_all", "multi_sam_notrunc", "fq_gz_two_files", "multi_all_m3", "dump_multi_m3", "dump_fq",
+                                  "best_strata_a", "bigM_sam_dump", "bigM_k2_cost", "best_trim_short"])
 def test_cli_small_batches_and_threads_do_not_change_output(name, tmp_path):
     """Many tiny GPU batches, several host threads: same bytes (batches concatenate in read order;
     -a reads with more hits than the first pass had slots for take the second pass)."""
@@ -82,8 +88,8 @@ def test_cli_output_file_and_quiet(tmp_path):
 @pytest.mark.parametrize("args,reads,msg", [
     (["-c", "-v", "2"], "ACGTACGTACGTACGTACGT,ACG", "Error: Read (1) is less than 4 characters long"),
     (["-c", "-v", "1"], "A", "Error: Reads must be at least 2 characters long in 1-mismatch mode"),
-    (["--best"], "cli/io.fq", "best-first"),
-    (["-v", "3"], "cli/io.fq", "best-first"),
+    (["--strata"], "cli/io.fq", "--strata must be combined with --best"),
+    (["--best", "--strata"], "cli/io.fq", "--strata has no effect unless combined with"),
     (["-1", "a.fq", "-2", "b.fq"], "cli/io.fq", "does not have"),
 ])
 def test_cli_errors(args, reads, msg):

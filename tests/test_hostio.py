@@ -17,7 +17,7 @@ def run_case(case):
     rd, pol, out, ex = CC.interpret(case["args"])
     batch = H.read_all(CC.reads_spec(case), keep_raw=bool(case.get("dumps")), **rd)
     oi = T.oracle_index(case["index"])
-    cap = 1024 if pol.get("all_hits") else pol.get("khits", 1)
+    cap = 1024 if pol.get("all_hits") else max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
     per = T.oracle_results(case["index"], batch, pol, cap=cap)
     hits, nh, st, pool = H.pack_hits(per, cap)
     opts = H.out_opts(**out)
