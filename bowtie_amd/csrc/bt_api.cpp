@@ -79,6 +79,7 @@ extern "C" void bt_policy_default(bt_policy* p)
 	memset(p, 0, sizeof(*p));
 	p->mode = BT_MODE_N; p->mms = 2; p->seed_len = 28; p->qual_thresh = 70; p->max_bts = 125;
 	p->maq_round = 1; p->khits = 1; p->mhits = 0xffffffffu;
+	p->max_ins = 250; p->mate1_fw = 1; p->pair_tries = 100;
 }
 
 extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate_override, int device,

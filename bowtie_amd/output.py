@@ -29,6 +29,7 @@ class Hit:
     stratum: int
     fw: bool
     mms: List[Tuple[int, int]] = field(default_factory=list)   # (5'-relative pos, refc 0..3), by pos
+    mate: int = 0              # 1 / 2: mate of a paired alignment (its partner is the adjacent hit)
 
 
 def _upto_ws(name: str) -> str:
@@ -71,13 +72,23 @@ def _qname(name: bytes, trunc: bool = True) -> bytes:
 
 
 def format_sam(name: bytes, seq: np.ndarray, qual: bytes, hit: Hit, refnames: Sequence[str],
-               mapq: int = 255, xms: int = 0, full_ref: bool = False) -> bytes:
+               mapq: int = 255, xms: int = 0, full_ref: bool = False, mate_hit: "Hit | None" = None,
+               mate_len: int = 0) -> bytes:
+    """mate_hit / mate_len: the partner alignment of a paired hit (sam.cpp:129-257: flags 1|2|64/128|32,
+    MRNM '=', MPOS, ISIZE; QNAME loses its /1 or /2)."""
     pseq, pqual = _oriented(seq, qual, hit.fw)
     L = len(seq)
     ref = refnames[hit.tidx] if hit.tidx < len(refnames) else str(hit.tidx)
     if not full_ref:
         ref = _upto_ws(ref)
     flags = 0 if hit.fw else 16
+    mrnm, mpos, isize = b"*", b"0", b"0"
+    if mate_hit is not None:
+        flags |= 1 | 2 | (64 if hit.mate == 1 else 128) | (0 if mate_hit.fw else 32)
+        mrnm, mpos = b"=", str(mate_hit.toff + 1).encode()
+        ins = -(hit.toff - mate_hit.toff + L) if hit.toff > mate_hit.toff else (mate_hit.toff - hit.toff + mate_len)
+        isize = str(ins).encode()
+        name = name[:-2] if len(name) >= 2 else b""
     # MD:Z walks the alignment left to right on the reference
     mmd = {pos: refc for pos, refc in hit.mms}
     order = range(L) if hit.fw else range(L - 1, -1, -1)
@@ -93,7 +104,7 @@ def format_sam(name: bytes, seq: np.ndarray, qual: bytes, hit: Hit, refnames: Se
             run += 1
     md.append(str(run))
     out = [_qname(name), str(flags).encode(), ref.encode(), str(hit.toff + 1).encode(),
-           str(mapq).encode(), ("%dM" % L).encode(), b"*", b"0", b"0", decode_seq(pseq), pqual,
+           str(mapq).encode(), ("%dM" % L).encode(), mrnm, mpos, isize, decode_seq(pseq), pqual,
            ("XA:i:%d" % hit.stratum).encode(), ("MD:Z:" + "".join(md)).encode(),
            ("NM:i:%d" % nm).encode()]
     if xms > 0:
@@ -101,8 +112,11 @@ def format_sam(name: bytes, seq: np.ndarray, qual: bytes, hit: Hit, refnames: Se
     return b"\t".join(out) + b"\n"
 
 
-def format_sam_unaligned(name: bytes, seq: np.ndarray, qual: bytes, n_maxed_hits: int = 0) -> bytes:
-    out = [_qname(name), b"4", b"*", b"0", b"0", b"*", b"*", b"0", b"0", decode_seq(seq), qual,
+def format_sam_unaligned(name: bytes, seq: np.ndarray, qual: bytes, n_maxed_hits: int = 0, mate: int = 0) -> bytes:
+    flag = b"4" if mate == 0 else (b"77" if mate == 1 else b"141")
+    if mate:
+        name = name[:-2] if len(name) >= 2 else b""
+    out = [_qname(name), flag, b"*", b"0", b"0", b"*", b"*", b"0", b"0", decode_seq(seq), qual,
            ("XM:i:%d" % n_maxed_hits).encode()]
     return b"\t".join(out) + b"\n"
 

@@ -143,3 +143,43 @@ def synth_reads_torch(text_t, n: int, length: int, mm_dist=(0, 1, 2, 2, 3, 4), s
         seeds[lo:lo + m] = torch.where(acc >= 2 ** 31, acc - 2 ** 32, acc).to(torch.int32)
     lens = torch.full((n,), length, dtype=torch.int16, device=dev)
     return {"seq": seq, "qual": qual, "len": lens, "seed": seeds, "n": n, "stride": stride, "length": length}
+
+
+def synth_pairs(text: np.ndarray, n: int, length: int, frag_lo: int = 200, frag_hi: int = 450,
+                mm_dist: Sequence[int] = (0, 0, 1, 1, 2), seed: int = 777, n_frac: float = 0.01,
+                qlo: int = 10, qhi: int = 40, length2: int | None = None, name_prefix: str = "p"):
+    """--fr read pairs: a fragment of frag_lo..frag_hi bases cut from the joined text on either
+    strand; mate 1 = its first `length` bases, mate 2 = the reverse complement of its last
+    `length2` bases.  Names <prefix><i>/1 and /2.  Returns (ReadBatch, ReadBatch)."""
+    rng = np.random.default_rng(seed)
+    length2 = length2 or length
+    T = len(text)
+    flen = rng.integers(max(frag_lo, length, length2), frag_hi + 1, size=n)
+    start = rng.integers(0, T - frag_hi, size=n)
+    out = []
+    strand = rng.random(n) < 0.5
+    for mate, L in ((1, length), (2, length2)):
+        seq = np.empty((n, L), dtype=np.uint8)
+        for i in range(n):
+            frag = text[start[i]:start[i] + flen[i]]
+            if strand[i]:
+                frag = _COMP[frag[::-1]]
+            seq[i] = frag[:L] if mate == 1 else _COMP[frag[-L:][::-1]]
+        nmm = np.asarray(mm_dist)[rng.integers(0, len(mm_dist), size=n)]
+        for k in range(int(max(mm_dist)) if len(mm_dist) else 0):
+            rows = np.nonzero(nmm > k)[0]
+            pos = rng.integers(0, L, size=len(rows))
+            seq[rows, pos] = (seq[rows, pos] + rng.integers(1, 4, size=len(rows))) & 3
+        if n_frac > 0:
+            rows = np.nonzero(rng.random(n) < n_frac)[0]
+            seq[rows, rng.integers(0, L, size=len(rows))] = 4
+        qual = (rng.integers(qlo, qhi + 1, size=(n, L)) + 33).astype(np.uint8)
+        stride = max(16, (L + 15) & ~15)
+        pseq = np.full((n, stride), 4, dtype=np.uint8)
+        pqual = np.full((n, stride), 33, dtype=np.uint8)
+        pseq[:, :L] = seq
+        pqual[:, :L] = qual
+        lens = np.full(n, L, dtype=np.uint16)
+        names = [("%s%d/%d" % (name_prefix, i, mate)).encode() for i in range(n)]
+        out.append(ReadBatch(pseq, pqual, lens, rand_seeds(pseq, pqual, lens, names, 0), names))
+    return out[0], out[1]

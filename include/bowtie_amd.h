@@ -70,7 +70,14 @@ typedef struct bt_policy {
 	int32_t  strata;       /* --strata                            hit.h:1070-1129             */
 	int32_t  sample_max;   /* -M: reads over mhits keep their first mhits hits so that one can
 	                          be sampled (hit.cpp:16-68, sam.cpp:263-311)                      */
-	int32_t  reserved[3];
+	/* paired-end (bt_align_pairs; PairedBWAlignerV2, aligner.h:1483-2051) */
+	int32_t  min_ins;      /* -I (0)     already reduced by the mates' 5'/3' trimming          */
+	int32_t  max_ins;      /* -X (250)   (aligner.h:1921-1935)                                 */
+	int32_t  mate1_fw;     /* --fr: 1,0  --ff: 1,1  --rf: 0,1        ebwt_search.cpp:902-906   */
+	int32_t  mate2_fw;
+	int32_t  pair_tries;   /* --pairtries (100): anchors tried per pair (aligner.h:1855)       */
+	int32_t  allow_contain;/* --allow-contain                                                  */
+	int32_t  reserved[2];
 } bt_policy;
 
 void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 -k 1          */

@@ -682,6 +682,7 @@ enum { DR_SINGLE, DR_COST, DR_SEEDED };
 typedef struct {                       /* EbwtRangeSourceDriverFactory + EbwtRangeSourceFactory */
 	const bto_index* ebwt; int fw; uint32_t qualLim; int reportExacts, halfAndHalf, partial;
 	int seed; uint32_t seedLen; int nudgeLeft; int rev[4]; int* btCnt;
+	int mate1;
 } single_spec_t;
 
 typedef struct driver {
@@ -710,7 +711,7 @@ static driver_t* single_new(env_t* env, int maq, int qualOrder, const single_spe
 {
 	driver_t* d = (driver_t*)calloc(1, sizeof(driver_t));
 	d->type = DR_SINGLE; d->done = 1; d->env = env; d->maq = maq; d->qualOrder = qualOrder;
-	d->fw = sp->fw; d->mate1 = 1;
+	d->fw = sp->fw; d->mate1 = sp->mate1;
 	d->rs = (rsrc_t*)calloc(1, sizeof(rsrc_t));
 	d->rs->ebwt = sp->ebwt; d->rs->fw = sp->fw; d->rs->qualLim = sp->qualLim; d->rs->reportExacts = sp->reportExacts;
 	d->rs->halfAndHalf = sp->halfAndHalf; d->rs->partial = sp->partial; d->rs->maqPenalty = maq; d->rs->qualOrder = qualOrder;
@@ -780,8 +781,9 @@ static void single_init_range_source(driver_t* d, const uint8_t* qual)
 }
 
 /* SingleRangeSourceDriver::setQueryImpl, range_source.h:1750-1771 */
-static void single_set_query(driver_t* d, const read_t* rd, range_t* r)
+static void single_set_query(driver_t* d, const read_t* patsrc, range_t* r)
 {
+	const read_t* rd = &patsrc[d->mate1 ? 0 : 1];      /* bufa() / bufb() */
 	d->done = 0;
 	pm_reset(&d->pm);
 	d->len = rd->len;
@@ -821,7 +823,20 @@ static void cost_add_rss(driver_t* d, driver_t* p)
 	}
 	d->rss[d->nrss++] = p;
 }
-static int cost_mate_eliminated(driver_t* d) { (void)d; return 0; }     /* unpaired: paired_ is false */
+/* calcPaired (range_source.h:2251-2261), mateEliminated (:2266-2280) */
+static void cost_calc_paired(driver_t* d)
+{
+	int saw1 = 0, saw2 = 0;
+	for (int i = 0; i < d->nrss; i++) { if (d->rss[i]->mate1) saw1 = 1; else saw2 = 1; }
+	d->paired = saw1 && saw2;
+}
+static int cost_mate_eliminated(driver_t* d)
+{
+	if (!d->paired) return 0;
+	int m1 = 0, m2 = 0;
+	for (int i = 0; i < d->nactive; i++) if (!d->active[i]->done) { if (d->active[i]->mate1) m1 = 1; else m2 = 1; }
+	return !m1 || !m2;
+}
 
 /* sortActives, :2370-2415 */
 static void cost_sort_actives(driver_t* d)
@@ -853,7 +868,7 @@ static void cost_set_query(driver_t* d, const read_t* rd, range_t* r)
 {
 	d->done = 0; d->foundRange = 0; d->lastRange = NULL; d->delayedRange = NULL;
 	d->patsrc = rd;
-	d->rnd = rd->seed;
+	d->rnd = rd[0].seed;                                 /* patsrc->bufa().seed */
 	if (d->nrss == 0) return;
 	for (int i = 0; i < d->nrss; i++) drv_set_query(d->rss[i], rd, r);
 	memcpy(d->active, d->rss, sizeof(driver_t*) * (size_t)d->nrss); d->nactive = d->nrss;
@@ -868,6 +883,7 @@ static void cost_add_source(driver_t* d, driver_t* p, range_t* r)
 	if (d->patsrc) drv_set_query(p, d->patsrc, r);
 	cost_add_rss(d, p);
 	d->active[d->nactive++] = p;
+	cost_calc_paired(d);
 	d->minCost = 0;
 	cost_sort_actives(d);
 }
@@ -887,7 +903,7 @@ static int cost_found_first_range(driver_t* d, range_t* r)
 	if (d->strandFix) {
 		int sz = d->nactive;
 		for (int i = 1; i < sz; i++) {
-			if (d->rss[i]->mate1 == r->mate1 && d->rss[i]->fw != r->fw) {
+			if ((d->rss[i]->mate1 != 0) == (r->mate1 != 0) && d->rss[i]->fw != r->fw) {
 				driver_t* p = d->active[i];
 				uint16_t minCost = d->minCost > p->minCost ? d->minCost : p->minCost;
 				if (minCost > r->cost) break;
@@ -943,7 +959,7 @@ static driver_t* seeded_new(env_t* env, int maq, int qualOrder, const single_spe
 {
 	driver_t* d = (driver_t*)calloc(1, sizeof(driver_t));
 	d->type = DR_SEEDED; d->done = 1; d->env = env; d->maq = maq; d->qualOrder = qualOrder;
-	d->rsFact = *fact; d->rsSeed = rsSeed; d->fw = fw; d->mate1 = 1;
+	d->rsFact = *fact; d->rsSeed = rsSeed; d->fw = fw; d->mate1 = fact->mate1;
 	d->rsFull = cost_new(env, 0);
 	return d;
 }
@@ -1030,6 +1046,7 @@ static range_t* drv_range(driver_t* d)
 #define H PIN_TO_HI_HALF_EDGE
 #define S PIN_TO_SEED_EDGE
 
+static int g_mate1 = 1;     /* mate the specs being built are for (tree construction only) */
 static single_spec_t spec(const bto_index* ebwt, int fw, uint32_t qualLim, int reportExacts, int hh, int partial,
                           int seed, uint32_t seedLen, int nudgeLeft, int r0, int r1, int r2, int r3, int* btCnt)
 {
@@ -1037,98 +1054,89 @@ static single_spec_t spec(const bto_index* ebwt, int fw, uint32_t qualLim, int r
 	sp.ebwt = ebwt; sp.fw = fw; sp.qualLim = qualLim; sp.reportExacts = reportExacts; sp.halfAndHalf = hh;
 	sp.partial = partial; sp.seed = seed; sp.seedLen = seedLen; sp.nudgeLeft = nudgeLeft;
 	sp.rev[0] = r0; sp.rev[1] = r1; sp.rev[2] = r2; sp.rev[3] = r3; sp.btCnt = btCnt;
+	sp.mate1 = g_mate1;
 	return sp;
 }
 
-static driver_t* build_tree(env_t* env, const bto_index* fwI, const bto_index* bwI, const bt_policy* pol, int* btCnt)
+/* the drivers of one (mate, strand) combination, in the order the factories push them */
+static void add_block(driver_t* top, env_t* env, const bto_index* fwI, const bto_index* bwI, const bt_policy* pol,
+                      int* btCnt, int fw, int paired)
 {
 	int maq = pol->maq_round, qo = 1 /* qualOrder = !better */;
-	int doFw = !pol->nofw, doRc = !pol->norc;
-	driver_t* top = cost_new(env, 1 /* strandFix default (ebwt_search.cpp:227) */);
 	single_spec_t sp, fs;
+	/* fw read: mirror index first; rc read: text index first */
+	const bto_index* i1 = fw ? bwI : fwI;
+	const bto_index* i2 = fw ? fwI : bwI;
 #define ADD1(...) do { sp = spec(__VA_ARGS__); cost_add_rss(top, single_new(env, maq, qo, &sp)); } while (0)
-#define ADDSEED(fact_args, gen_args, fwflag) do { \
+#define ADDSEED(fact_args, gen_args) do { \
 		fs = spec fact_args; sp = spec gen_args; \
-		cost_add_rss(top, seeded_new(env, maq, qo, &fs, single_new(env, maq, qo, &sp), fwflag)); } while (0)
+		cost_add_rss(top, seeded_new(env, maq, qo, &fs, single_new(env, maq, qo, &sp), fw)); } while (0)
 	if (pol->mode == BT_MODE_V) {
-		if (pol->mms == 0) {                       /* aligner_0mm.h:69-115 */
-			if (doFw) ADD1(fwI, 1, OFF_MASK, 1, 0, 0, 0, 0, 1, L, L, L, L, NULL);
-			if (doRc) ADD1(fwI, 0, OFF_MASK, 1, 0, 0, 0, 0, 1, L, L, L, L, NULL);
-		} else if (pol->mms == 1) {                /* aligner_1mm.h:73-152 */
-			if (doFw) {
-				ADD1(bwI, 1, OFF_MASK, 1, 0, 0, 0, 0, 0, H, L, L, L, NULL);
-				ADD1(fwI, 1, OFF_MASK, 0, 0, 0, 0, 0, 1, H, L, L, L, NULL);
-			}
-			if (doRc) {
-				ADD1(fwI, 0, OFF_MASK, 1, 0, 0, 0, 0, 1, H, L, L, L, NULL);
-				ADD1(bwI, 0, OFF_MASK, 0, 0, 0, 0, 0, 0, H, L, L, L, NULL);
-			}
-		} else {                                   /* aligner_23mm.h:73-236 */
+		if (pol->mms == 0) {                       /* aligner_0mm.h:69-115, 244-300 */
+			ADD1(fwI, fw, OFF_MASK, 1, 0, 0, 0, 0, 1, L, L, L, L, NULL);
+		} else if (pol->mms == 1) {                /* aligner_1mm.h:73-152, 286-415: nudgeLeft is true on the text index */
+			/* nudgeLeft: "true for Fw index" in the unpaired factory; the paired one (aligner_1mm.h:295-408)
+			 * passes true for the first and false for the second driver of every block */
+			ADD1(i1, fw, OFF_MASK, 1, 0, 0, 0, 0, paired ? 1 : i1 == fwI, H, L, L, L, NULL);
+			ADD1(i2, fw, OFF_MASK, 0, 0, 0, 0, 0, paired ? 0 : i2 == fwI, H, L, L, L, NULL);
+		} else {                                   /* aligner_23mm.h:73-236, 358-606: nudgeLeft alternates */
 			int two = (pol->mms == 2);
 			int r2 = two ? L : H;
-			if (doFw) {
-				ADD1(bwI, 1, OFF_MASK, 1, 0, 0, 0, 0, 1, H, H, r2, L, NULL);
-				ADD1(fwI, 1, OFF_MASK, 0, 0, 0, 0, 0, 0, H, H, r2, L, NULL);
-				ADD1(bwI, 1, OFF_MASK, 0, 2, 0, 0, 0, 1, B, H, r2, L, NULL);
-				if (!two) ADD1(fwI, 1, OFF_MASK, 0, 3, 0, 0, 0, 0, B, H, H, L, NULL);
-			}
-			if (doRc) {
-				ADD1(fwI, 0, OFF_MASK, 1, 0, 0, 0, 0, 1, H, H, r2, L, NULL);
-				ADD1(bwI, 0, OFF_MASK, 0, 0, 0, 0, 0, 0, H, H, r2, L, NULL);
-				ADD1(fwI, 0, OFF_MASK, 0, 2, 0, 0, 0, 1, B, H, r2, L, NULL);
-				if (!two) ADD1(bwI, 0, OFF_MASK, 0, 3, 0, 0, 0, 0, B, H, H, L, NULL);
-			}
+			ADD1(i1, fw, OFF_MASK, 1, 0, 0, 0, 0, 1, H, H, r2, L, NULL);
+			ADD1(i2, fw, OFF_MASK, 0, 0, 0, 0, 0, 0, H, H, r2, L, NULL);
+			ADD1(i1, fw, OFF_MASK, 0, 2, 0, 0, 0, 1, B, H, r2, L, NULL);
+			/* the 3-mismatch half-and-half driver: rev1Off is PIN_TO_HI_HALF_EDGE in the unpaired factory and
+			 * for mate 1's rc block of the paired one, PIN_TO_BEGINNING in the paired factory's other three
+			 * blocks (aligner_23mm.h:403-411, 469-477, 534-542, 598-606) */
+			if (!two) ADD1(i2, fw, OFF_MASK, 0, 3, 0, 0, 0, 0, B, (paired && !(g_mate1 && !fw)) ? B : H, H, L, NULL);
 		}
-	} else {                                           /* aligner_seed_mm.h:82-516 */
+	} else {                                           /* aligner_seed_mm.h:82-516, 705-1290 */
 		uint32_t q = (uint32_t)pol->qual_thresh, sl = (uint32_t)pol->seed_len;
-		if (pol->mms == 0) {
-			if (doFw) ADD1(bwI, 1, q, 1, 0, 0, 0, sl, 1, S, S, S, S, NULL);
-			if (doRc) ADD1(fwI, 0, q, 1, 0, 0, 0, sl, 1, S, S, S, S, NULL);
-		} else if (pol->mms == 1) {
-			if (doFw) {
-				ADD1(bwI, 1, q, 1, 0, 0, 0, sl, 1, H, S, S, S, NULL);
-				ADDSEED((bwI, 1, q, 1, 0, 0, 0, sl, 1, S, S, S, S, NULL),
-				        (fwI, 1, q, 0, 0, 1, 1, sl, 0, H, S, S, S, NULL), 1);
-			}
-			if (doRc) {
-				ADD1(fwI, 0, q, 1, 0, 0, 0, sl, 1, H, S, S, S, NULL);
-				ADDSEED((fwI, 0, q, 1, 0, 0, 0, sl, 1, S, S, S, S, NULL),
-				        (bwI, 0, q, 0, 0, 1, 1, sl, 0, H, S, S, S, NULL), 0);
-			}
-		} else if (pol->mms == 2) {
-			if (doFw) {
-				ADD1(bwI, 1, q, 1, 0, 0, 0, sl, 1, H, H, S, S, btCnt);
-				ADDSEED((bwI, 1, q, 1, 0, 0, 0, sl, 1, S, S, S, S, btCnt),
-				        (fwI, 1, q, 0, 0, 1, 1, sl, 0, H, H, S, S, btCnt), 1);
-				ADD1(bwI, 1, q, 0, 2, 0, 0, sl, 1, B, H, S, S, btCnt);
-			}
-			if (doRc) {
-				ADD1(fwI, 0, q, 1, 0, 0, 0, sl, 1, H, H, S, S, btCnt);
-				ADDSEED((fwI, 0, q, 1, 0, 0, 0, sl, 1, S, S, S, S, btCnt),
-				        (bwI, 0, q, 0, 0, 1, 1, sl, 0, H, H, S, S, btCnt), 0);
-				ADD1(fwI, 0, q, 0, 2, 0, 0, sl, 1, B, H, S, S, btCnt);
-			}
+		int n = pol->mms;
+		int* bc = n >= 2 ? btCnt : NULL;
+		if (n == 0) {
+			ADD1(i1, fw, q, 1, 0, 0, 0, sl, 1, S, S, S, S, NULL);
 		} else {
-			if (doFw) {
-				ADD1(bwI, 1, q, 1, 0, 0, 0, sl, 1, H, H, H, S, btCnt);
-				ADDSEED((bwI, 1, q, 1, 0, 0, 0, sl, 1, S, S, S, S, btCnt),
-				        (fwI, 1, q, 0, 0, 1, 1, sl, 0, H, H, H, S, btCnt), 1);
-				ADDSEED((bwI, 1, q, 1, 0, 0, 0, sl, 1, S, S, S, S, btCnt),
-				        (fwI, 1, q, 0, 3, 1, 1, sl, 0, B, H, H, S, btCnt), 1);
-				ADD1(bwI, 1, q, 0, 2, 0, 0, sl, 1, B, H, H, S, btCnt);
-			}
-			if (doRc) {
-				ADD1(fwI, 0, q, 1, 0, 0, 0, sl, 1, H, H, H, S, btCnt);
-				ADDSEED((fwI, 0, q, 1, 0, 0, 0, sl, 1, S, S, S, S, btCnt),
-				        (bwI, 0, q, 0, 0, 1, 1, sl, 0, H, H, H, S, btCnt), 0);
-				ADDSEED((fwI, 0, q, 1, 0, 0, 0, sl, 1, S, S, S, S, btCnt),
-				        (bwI, 0, q, 0, 3, 1, 1, sl, 0, B, H, H, S, btCnt), 0);
-				ADD1(fwI, 0, q, 0, 2, 0, 0, sl, 1, B, H, H, S, btCnt);
-			}
+			int a1 = n >= 2 ? H : S, a2 = n >= 3 ? H : S;
+			ADD1(i1, fw, q, 1, 0, 0, 0, sl, 1, H, a1, a2, S, bc);
+			ADDSEED((i1, fw, q, 1, 0, 0, 0, sl, 1, S, S, S, S, bc), (i2, fw, q, 0, 0, 1, 1, sl, 0, H, a1, a2, S, bc));
+			if (n >= 3) ADDSEED((i1, fw, q, 1, 0, 0, 0, sl, 1, S, S, S, S, bc), (i2, fw, q, 0, 3, 1, 1, sl, 0, B, H, H, S, bc));
+			if (n >= 2) ADD1(i1, fw, q, 0, 2, 0, 0, sl, 1, B, H, a2, S, bc);
 		}
 	}
 #undef ADD1
 #undef ADDSEED
+}
+
+static driver_t* build_tree(env_t* env, const bto_index* fwI, const bto_index* bwI, const bt_policy* pol, int* btCnt)
+{
+	driver_t* top = cost_new(env, 1 /* strandFix default (ebwt_search.cpp:227) */);
+	g_mate1 = 1;
+	if (!pol->nofw) add_block(top, env, fwI, bwI, pol, btCnt, 1, 0);
+	if (!pol->norc) add_block(top, env, fwI, bwI, pol, btCnt, 0, 0);
+	return top;
+}
+
+/* Paired*AlignerFactory::create() with v1_ == false (--best): every driver of both mates in one
+ * cost-aware driver; -v: 1Fw 1Rc 2Fw 2Rc (aligner_0mm.h:320-327, aligner_1mm.h:286-415,
+ * aligner_23mm.h:358-606), -n: 1Fw 2Fw 1Rc 2Rc (aligner_seed_mm.h:705-1290) */
+static driver_t* build_tree_paired(env_t* env, const bto_index* fwI, const bto_index* bwI, const bt_policy* pol, int* btCnt)
+{
+	driver_t* top = cost_new(env, 1);
+	int do1Fw = 1, do1Rc = 1, do2Fw = 1, do2Rc = 1;
+	if (pol->nofw) { if (pol->mate1_fw) do1Fw = 0; else do1Rc = 0; if (pol->mate2_fw) do2Fw = 0; else do2Rc = 0; }
+	if (pol->norc) { if (pol->mate1_fw) do1Rc = 0; else do1Fw = 0; if (pol->mate2_fw) do2Rc = 0; else do2Fw = 0; }
+	int order_v[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}}, order_n[4][2] = {{1, 1}, {0, 1}, {1, 0}, {0, 0}};
+	for (int k = 0; k < 4; k++) {
+		int mate1 = pol->mode == BT_MODE_V ? order_v[k][0] : order_n[k][0];
+		int fw = pol->mode == BT_MODE_V ? order_v[k][1] : order_n[k][1];
+		int doit = mate1 ? (fw ? do1Fw : do1Rc) : (fw ? do2Fw : do2Rc);
+		if (!doit) continue;
+		g_mate1 = mate1;
+		add_block(top, env, fwI, bwI, pol, btCnt, fw, 1);
+	}
+	g_mate1 = 1;
+	cost_calc_paired(top);
 	return top;
 }
 #undef B
@@ -1246,15 +1254,16 @@ static void chaser_advance(chaser_t* c, env_t* env)
 }
 
 /* UnpairedAlignerV2::report (aligner.h:467-497) + EbwtSearchParams::reportHit (ebwt.h:1288-1405) */
-static int al_report(sink_t* sink, const range_t* ra, uint32_t tidx, uint32_t toff, uint32_t alen)
+static int al_report_ex(sink_t* sink, const range_t* ra, uint32_t tidx, uint32_t toff, uint32_t alen,
+                        int ebwtFw, int mate, uint32_t oms)
 {
 	bto_hit h;
 	memset(&h, 0, sizeof(h));
-	h.tidx = tidx; h.toff = toff; h.oms = ra->bot - ra->top - 1;
+	h.tidx = tidx; h.toff = toff; h.oms = oms; h.mate = (uint16_t)mate;
 	h.cost = ra->cost; h.stratum = (uint8_t)ra->stratum; h.fw = (uint8_t)ra->fw;
 	uint32_t n = ra->numMms > BTO_MAXMM ? BTO_MAXMM : ra->numMms;
 	h.nmm = (uint16_t)n;
-	int flip = (ra->ebwt->fw != 0) != (ra->fw != 0);
+	int flip = (ebwtFw != 0) != (ra->fw != 0);
 	for (uint32_t i = 0; i < n; i++) {
 		uint32_t pos = flip ? alen - ra->mms[i] - 1 : ra->mms[i];
 		uint8_t rc = ra->refcs[i];
@@ -1267,6 +1276,10 @@ static int al_report(sink_t* sink, const range_t* ra, uint32_t tidx, uint32_t to
 		h.mm[j + 1] = v;
 	}
 	return sink_report(sink, &h, (int)ra->stratum);
+}
+static int al_report(sink_t* sink, const range_t* ra, uint32_t tidx, uint32_t toff, uint32_t alen)
+{
+	return al_report_ex(sink, ra, tidx, toff, alen, ra->ebwt->fw != 0, 0, ra->bot - ra->top - 1);
 }
 
 int bto_align_read_best(const bto_index* ixFw, const bto_index* ixBw, const bt_policy* pol,
@@ -1296,7 +1309,7 @@ int bto_align_read_best(const bto_index* ixFw, const bto_index* ixBw, const bt_p
 		if (status) *status = st;
 		return 0;
 	}
-	read_t* rd = (read_t*)malloc(sizeof(read_t));
+	read_t* rd = (read_t*)calloc(2, sizeof(read_t));
 	read_init(rd, seq, qual, (uint32_t)len, seed);
 	int btCntStore = pol->max_bts;
 	int* btCnt = (pol->mode == BT_MODE_N && pol->mms >= 2) ? &btCntStore : NULL;
@@ -1352,6 +1365,254 @@ int bto_align_read_best(const bto_index* ixFw, const bto_index* ixBw, const bt_p
 		 * reportMaxed samples from (hit.cpp:16-68) */
 		return pol->sample_max ? sink.stored : 0;
 	}
+	int n = sink.stored;
+	if ((uint32_t)n > sink.n) n = (int)sink.n;
+	return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Paired-end: BitPairReference (reference.h:35-120, getStretch :479), RefAligner::find
+ * (ref_aligner.h:63-101; the naiveFind of each concrete aligner is the specification its
+ * anchor64Find is asserted against: :182-262, 513-601, 2561-2752), PairedBWAlignerV2
+ * (aligner.h:1483-2051)
+ * ---------------------------------------------------------------------------------------- */
+struct bto_refs {
+	uint32_t n;
+	uint8_t** seq;           /* [tidx][plen]: 0..3, 4 = N / gap */
+	uint32_t* approxLen;     /* BitPairReference::approxLen: up to the end of the last unambiguous stretch */
+	uint32_t* plen;
+};
+
+/* The reference's BitPairReference reads <base>.3.ebwt / .4.ebwt; the oracle derives the same
+ * sequences independently from the index proper: the joined text (Ebwt::restore) cut at the
+ * fragment table rstarts[] (joined offset, tidx, offset within the reference). */
+bto_refs* bto_refs_build(const bto_index* ix)
+{
+	bto_refs* r = (bto_refs*)calloc(1, sizeof(bto_refs));
+	r->n = ix->nPat;
+	r->seq = (uint8_t**)calloc(ix->nPat, sizeof(uint8_t*));
+	r->approxLen = (uint32_t*)calloc(ix->nPat, 4);
+	r->plen = (uint32_t*)calloc(ix->nPat, 4);
+	uint8_t* text = (uint8_t*)malloc(ix->len ? ix->len : 1);
+	bto_restore_text(ix, text);
+	for (uint32_t t = 0; t < ix->nPat; t++) {
+		r->plen[t] = ix->plen[t];
+		r->seq[t] = (uint8_t*)malloc(ix->plen[t] + 16);
+		memset(r->seq[t], 4, ix->plen[t] + 16);
+	}
+	for (uint32_t f = 0; f < ix->nFrag; f++) {
+		uint32_t joff = ix->rstarts[f * 3], tidx = ix->rstarts[f * 3 + 1], foff = ix->rstarts[f * 3 + 2];
+		uint32_t jend = (f + 1 < ix->nFrag) ? ix->rstarts[(f + 1) * 3] : ix->len;
+		uint32_t flen = jend - joff;
+		memcpy(r->seq[tidx] + foff, text + joff, flen);
+		if (foff + flen > r->approxLen[tidx]) r->approxLen[tidx] = foff + flen;
+	}
+	free(text);
+	return r;
+}
+void bto_refs_free(bto_refs* r)
+{
+	if (!r) return;
+	for (uint32_t t = 0; t < r->n; t++) free(r->seq[t]);
+	free(r->seq); free(r->approxLen); free(r->plen); free(r);
+}
+
+/* the set of (upstream, downstream) coordinate pairs already reported for one pair orientation
+ * (TSetPairs; aligner.h:2049) */
+typedef struct { uint64_t* a; int n, cap; } pairset_t;
+static int pairset_has(const pairset_t* p, uint64_t first, uint64_t second)
+{
+	for (int i = 0; i < p->n; i++) if (p->a[2 * i] == first && p->a[2 * i + 1] == second) return 1;
+	return 0;
+}
+static void pairset_add(pairset_t* p, uint64_t first, uint64_t second)
+{
+	if (p->n == p->cap) { p->cap = p->cap ? p->cap * 2 : 16; p->a = (uint64_t*)realloc(p->a, 16 * (size_t)p->cap); }
+	p->a[2 * p->n] = first; p->a[2 * p->n + 1] = second; p->n++;
+}
+
+/* RefAligner::find with numToFind = 1: candidate leftmost positions radiate out from the middle of
+ * [begin, end - qlen]; the first one that (a) touches no reference N, (b) has at most `k`
+ * mismatches in the seed (the first min(qlen, seedLen) bases from the 5' end; the whole read in
+ * -v mode), (c) for the seeded aligners keeps the summed penalty of all its mismatches within
+ * qualMax, and (d) is not in `pairs` yet, is returned.  Returns 1 and fills *r / *result. */
+static int ref_find_one(const bt_policy* pol, const uint8_t* ref, const uint8_t* qry, const uint8_t* quals, uint32_t qlen,
+                        uint32_t tidx, uint32_t begin, uint32_t end, int seedOnLeft, pairset_t* pairs, uint32_t aoff,
+                        range_t* r, uint32_t* result)
+{
+	const int seeded = pol->mode == BT_MODE_N;
+	const uint32_t k = (uint32_t)pol->mms;
+	const uint32_t slen = seeded ? (qlen < (uint32_t)pol->seed_len ? qlen : (uint32_t)pol->seed_len) : qlen;
+	const uint32_t qualMax = seeded ? (uint32_t)pol->qual_thresh : 0xffffffffu;
+	const uint32_t lim = end - qlen - begin;
+	const uint32_t halfway = begin + (lim >> 1);
+	int hi = 0;
+	for (uint32_t i = 1; i <= lim + 1; i++) {
+		uint32_t ri = hi ? halfway + (i >> 1) : halfway - (i >> 1);
+		hi = !hi;
+		int match = 1;
+		uint32_t mms = 0, seedMms = 0, ham = 0;
+		r->n = 0;
+		for (uint32_t j = 0; j < qlen; j++) {
+			int rc = ref[ri + j];
+			if (rc & 4) { match = 0; break; }
+			if (qry[j] != rc) {
+				const int inSeed = seedOnLeft ? (j < slen) : (j >= qlen - slen);
+				if (inSeed && ++seedMms > k) { match = 0; break; }
+				if (seeded) {
+					ham += mm_penalty(pol->maq_round, phred_of(quals[j]));
+					if (ham > qualMax) { match = 0; break; }
+				}
+				r->mms[mms] = j; r->refcs[mms] = (uint8_t)"ACGT"[rc]; mms++;
+			}
+		}
+		if (!match) continue;
+		if (pairs) {
+			uint64_t a = ((uint64_t)tidx << 32) | ri, b = ((uint64_t)tidx << 32) | aoff;
+			uint64_t first = ri < aoff ? a : b, second = ri < aoff ? b : a;
+			if (pairset_has(pairs, first, second)) continue;
+			pairset_add(pairs, first, second);
+		}
+		r->n = mms; r->numMms = mms; r->stratum = seedMms; r->cost = 0; r->ebwt = NULL;
+		*result = ri;
+		return 1;
+	}
+	return 0;
+}
+
+int bto_align_pair_best(const bto_index* ixFw, const bto_index* ixBw, const bto_refs* refs, const bt_policy* pol,
+                        const uint8_t* seq1, const uint8_t* qual1, int len1, uint32_t seed1,
+                        const uint8_t* seq2, const uint8_t* qual2, int len2, uint32_t seed2,
+                        bto_hit* hits, int cap, uint32_t* n_hits_total, uint32_t* status, bt_op_counts* counts)
+{
+	if (len1 < 0 || len1 > BTO_MAXLEN || len2 < 0 || len2 > BTO_MAXLEN || !refs) return -BT_ERR_ARG;
+	if ((pol->mode == BT_MODE_N || pol->mms > 0) && !ixBw) return -BT_ERR_ARG;
+	sink_t sink;
+	memset(&sink, 0, sizeof(sink));
+	/* createMult(2) (hit.h:1012-1016, 1155-1159, 1246-1249): mates count separately */
+	sink.strata = pol->strata; sink.all = pol->all_hits;
+	sink.n = pol->all_hits ? (pol->strata ? (0xffffffffu / 2) * 2u : 0xffffffffu) : pol->khits * 2u;
+	sink.max = pol->mhits == 0xffffffffu ? 0xffffffffu : pol->mhits * 2u;
+	sink.bestStratum = 999;
+	sink.hits = hits; sink.cap = cap;
+	uint32_t st = 0;
+	int budget = BRANCH_BUDGET;
+	env_t env = { &budget, counts };
+	if (len1 < 4 || len2 < 4) {                 /* aligner.h:1579-1588 */
+		if (n_hits_total) *n_hits_total = 0;
+		if (status) *status = BT_ST_SKIPPED;
+		return 0;
+	}
+	read_t* rd = (read_t*)calloc(2, sizeof(read_t));
+	read_init(&rd[0], seq1, qual1, (uint32_t)len1, seed1);
+	read_init(&rd[1], seq2, qual2, (uint32_t)len2, seed2);
+	int btCntStore = pol->max_bts;
+	int* btCnt = (pol->mode == BT_MODE_N && pol->mms >= 2) ? &btCntStore : NULL;
+	driver_t* driver = build_tree_paired(&env, ixFw, ixBw, pol, btCnt);
+	uint32_t alRnd = seed1;                       /* Aligner::rand_.init(bufa_->seed) */
+	chaser_t ch; memset(&ch, 0, sizeof(ch));
+	ch.probes = counts ? &counts->rstarts : NULL;
+	drv_set_query(driver, rd, NULL);
+	if (btCnt) *btCnt = pol->max_bts;
+	const int fw1 = pol->mate1_fw, fw2 = pol->mate2_fw;
+	pairset_t pairs_fw = {0, 0, 0}, pairs_rc = {0, 0, 0};
+	range_t* found = (range_t*)malloc(sizeof(range_t));
+	uint32_t mixedAttempts = 0;
+	int done = 0, chase = 0, donePe = 0;
+	while (!done) {
+		if (chase) {
+			if (ch.offTidx == OFF_MASK && !ch.done) { chaser_advance(&ch, &env); continue; }
+			if (ch.offTidx != OFF_MASK) {
+				/* resolveOutstanding (aligner.h:1849-1871) -> resolveOutstandingInRef (:1883-1997) */
+				const range_t* range = drv_range(driver);
+				const uint32_t tidx = ch.offTidx, toff = ch.offToff, tlen = ixFw->plen[ch.offTidx];
+				(void)tlen;
+				if (!donePe) {
+					int ret = 0;
+					const int pairFw = range->mate1 ? (range->fw == fw1) : (range->fw == fw2);
+					const int matchRight = pairFw ? range->mate1 : !range->mate1;
+					int fw = range->mate1 ? fw2 : fw1;
+					if (!pairFw) fw = !fw;
+					const read_t* om = &rd[range->mate1 ? 1 : 0];             /* the outstanding mate */
+					const uint8_t* oseq = fw ? om->pat[1][1] : om->pat[0][1];   /* patFw : patRc */
+					const uint8_t* oqual = fw ? om->qual[0] : om->qual[1];
+					const uint32_t qlen = om->len, alen = range->mate1 ? rd[0].len : rd[1].len;
+					const int minins = pol->min_ins, maxins = pol->max_ins;
+					if ((uint32_t)maxins > (qlen > alen ? qlen : alen)) {
+						uint32_t begin, end;
+						const uint32_t insDiff = (uint32_t)(maxins - minins);
+						const int contain = pol->allow_contain;
+						if (matchRight) {
+							end = toff + (uint32_t)maxins;
+							begin = toff + (contain ? 0 : 1);
+							if (!contain && qlen < alen) begin += alen - qlen;
+							if (end > insDiff + qlen) { uint32_t b2 = end - insDiff - qlen; if (b2 > begin) begin = b2; }
+							if (refs->approxLen[tidx] < end) end = refs->approxLen[tidx];
+							if (refs->approxLen[tidx] < begin) begin = refs->approxLen[tidx];
+						} else {
+							begin = (toff + alen < (uint32_t)maxins) ? 0 : toff + alen - (uint32_t)maxins;
+							const uint32_t mi = alen < qlen ? alen : qlen;
+							if (contain) end = toff + alen - 1;
+							else {
+								end = toff + mi - 1;
+								const uint32_t e2 = toff + alen - (uint32_t)minins + qlen - 1;
+								if (e2 < end) end = e2;
+								if (toff + alen + qlen < (uint32_t)minins + 1) end = 0;
+							}
+						}
+						if (end - begin >= qlen) {          /* unsigned, as in the reference (aligner.h:1964) */
+							uint32_t result = 0;
+							if (ref_find_one(pol, refs->seq[tidx], oseq, oqual, qlen, tidx, begin, end, fw,
+							                 pairFw ? &pairs_fw : &pairs_rc, toff, found, &result)) {
+								range_t* r = found;
+								r->fw = fw; r->cost = (uint16_t)(r->cost | (r->stratum << 14));
+								r->mate1 = !range->mate1; r->top = range->top; r->bot = range->bot;
+								const int ebwtLFw = matchRight ? (range->ebwt->fw != 0) : 1;
+								const int ebwtRFw = matchRight ? 1 : (range->ebwt->fw != 0);
+								const range_t* rL = matchRight ? range : r;
+								const range_t* rR = matchRight ? r : range;
+								const uint32_t up = matchRight ? toff : result, dn = matchRight ? result : toff;
+								/* report (aligner.h:1720-1788): upstream mate first */
+								const uint32_t oms = (rL->bot - rL->top < rR->bot - rR->top ? rL->bot - rL->top : rR->bot - rR->top) - 1;
+								const uint32_t lenL = pairFw ? rd[0].len : rd[1].len, lenR = pairFw ? rd[1].len : rd[0].len;
+								ret = al_report_ex(&sink, rL, tidx, up, lenL, ebwtLFw, pairFw ? 1 : 2, oms);
+								if (!ret) ret = al_report_ex(&sink, rR, tidx, dn, lenR, ebwtRFw, pairFw ? 2 : 1, oms);
+							}
+						}
+					}
+					if (++mixedAttempts > (uint32_t)pol->pair_tries || ret) donePe = 1;
+					done = donePe;
+				}
+				ch.offTidx = OFF_MASK;
+			} else {
+				chase = 0;
+				done = driver->done;
+			}
+		}
+		if (!done && !chase) {
+			if (!driver->done) {
+				if (!donePe) {
+					donePe = sink_irrelevant_cost(&sink, driver->minCost);
+					if (donePe) done = 1;
+				}
+				if (!done) drv_advance(driver, ADV_COST_CHANGES);
+				if (driver->foundRange) {
+					chase = 1;
+					driver->foundRange = 0;
+					const range_t* r = drv_range(driver);
+					chaser_set_top_bot(&ch, r->top, r->bot, r->mate1 ? rd[0].len : rd[1].len, &alRnd, r->ebwt, &env);
+				}
+			} else done = 1;
+		}
+	}
+	if (budget < 0) st |= BT_ST_OVERFLOW;
+	drv_free(driver);
+	free(rd); free(found); free(pairs_fw.a); free(pairs_rc.a);
+	if (sink.dropped && sink.hitsForThisRead <= sink.max) st |= BT_ST_HITCAP;
+	if (n_hits_total) *n_hits_total = sink.hitsForThisRead;
+	if (status) *status = st;
+	if (sink.strata) for (int i = 0; i < sink.stored; i++) sink.hits[i].oms = (uint32_t)sink.stored / 2u - 1u;
+	if (sink.hitsForThisRead > sink.max) return pol->sample_max ? sink.stored : 0;
 	int n = sink.stored;
 	if ((uint32_t)n > sink.n) n = (int)sink.n;
 	return n;

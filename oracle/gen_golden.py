@@ -30,7 +30,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bowtie_amd.synth import synth_reads, write_fastq   # noqa: E402
 from bowtie_amd.reads import parse_fastq, pack_reads     # noqa: E402
 import oracle_lib as OL                                   # noqa: E402
-from best_modes import BEST_CORE, BEST_EXTRA             # noqa: E402
+from best_modes import BEST_CORE, BEST_EXTRA, PAIRED_MODES, PAIR_SETS   # noqa: E402
+from bowtie_amd.synth import synth_pairs                 # noqa: E402
 
 REF = "/root/reference"
 G = os.path.join(ROOT, "tests", "golden")
@@ -90,8 +91,7 @@ def make_multi():
                 f.write(txt[i:i + 70] + "\n")
     run([os.path.join(BIN, "bowtie-build-s"), "--offrate", "3", "--ftabchars", "6", "-q",
          os.path.join(G, "multi.fa"), os.path.join(G, "multi")])
-    for ext in ("3.ebwt", "4.ebwt"):
-        os.remove(os.path.join(G, "multi." + ext))
+    # multi.3.ebwt / .4.ebwt (the 2-bit reference, BitPairReference) stay: the paired-end path reads them
 
 
 def strip_sam(sam: bytes) -> bytes:
@@ -108,7 +108,7 @@ def strip_sam(sam: bytes) -> bytes:
 def main():
     os.makedirs(G, exist_ok=True)
     manifest = {"reference": "BenLangmead/bowtie v1.3.1", "runs": []}
-    for ext in ("1.ebwt", "2.ebwt", "rev.1.ebwt", "rev.2.ebwt"):
+    for ext in ("1.ebwt", "2.ebwt", "3.ebwt", "4.ebwt", "rev.1.ebwt", "rev.2.ebwt"):
         shutil.copyfile(os.path.join(REF, "indexes", "e_coli." + ext), os.path.join(G, "e_coli." + ext))
     shutil.copyfile(os.path.join(REF, "reads", "e_coli_1000.fq"), os.path.join(G, "e_coli_1000.fq"))
     make_multi()
@@ -153,6 +153,34 @@ def main():
                                      "md5": hashlib.md5(p.stdout).hexdigest(),
                                      "summary": p.stderr.decode().strip().split("\n")})
     os.remove(tmp)
+    # paired-end (-1/-2 --best: PairedBWAlignerV2)
+    manifest["paired_runs"] = []
+    for k in ("1", "2"):
+        shutil.copyfile(os.path.join(REF, "reads", "e_coli_1000_%s.fq" % k), os.path.join(G, "e_coli_1000_%s.fq" % k))
+    t1, t2 = os.path.join(G, "_tmp_1.fq"), os.path.join(G, "_tmp_2.fq")
+    for idx, pname in PAIR_SETS:
+        if pname == "e_coli_1000_pe":
+            b1 = pack_reads(parse_fastq(os.path.join(G, "e_coli_1000_1.fq")))
+            b2 = pack_reads(parse_fastq(os.path.join(G, "e_coli_1000_2.fq")))
+        else:
+            L = int(pname[2:])
+            b1, b2 = synth_pairs(OL.OracleIndex(os.path.join(G, idx)).joined_text(), 400, L, seed=L)
+        write_fastq(b1, t1)
+        write_fastq(b2, t2)
+        for mname, (margs, _) in PAIRED_MODES.items():
+            cmd = [os.path.join(BIN, "bowtie-align-s"), "--wrapper", "basic-0", "-p", "1", "-S", "--sam-nohead"] + \
+                margs + ["-x", os.path.join(G, idx), "-1", t1, "-2", t2]
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if p.returncode != 0:
+                raise SystemExit("reference failed: " + " ".join(cmd))
+            fn = "%s__%s__%s.sam.gz" % (idx, pname, mname)
+            with gzip.GzipFile(os.path.join(G, fn), "wb", mtime=0) as f:
+                f.write(strip_sam(p.stdout))
+            manifest["paired_runs"].append({"index": idx, "reads": pname, "mode": mname, "args": margs, "file": fn,
+                                            "md5": hashlib.md5(p.stdout).hexdigest(),
+                                            "summary": p.stderr.decode().strip().split("\n")})
+    os.remove(t1)
+    os.remove(t2)
     # kernel-level known answers from the reference's own Ebwt methods are in SURVEY.md Appendix D
     # (micro-oracle that #includes ebwt.h); restated here as data
     vec = {"index": "e_coli", "fchr": [0, 1222723, 2474304, 3717743, 4938920], "zOff": 780711,
@@ -174,7 +202,7 @@ def main():
         json.dump(vec, f, indent=1)
     with open(os.path.join(G, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
-    print("wrote", len(manifest["runs"]), "runs")
+    print("wrote", len(manifest["runs"]), "runs,", len(manifest["paired_runs"]), "paired runs")
 
 
 if __name__ == "__main__":

@@ -43,3 +43,31 @@ BEST_EXTRA = {
 }
 BEST_MODES = dict(BEST_CORE)
 BEST_MODES.update(BEST_EXTRA)
+
+# paired-end (PairedBWAlignerV2: --best with -1/-2): name -> (reference arguments, make_policy keywords)
+PAIRED_MODES = {
+    "pe_n1_best_X500": (["-n", "1", "--best", "-X", "500"], dict(mode="n", mms=1, best=True, max_ins=500)),
+    "pe_n2_best_X500": (["-n", "2", "--best", "-X", "500"], dict(mode="n", mms=2, best=True, max_ins=500)),
+    "pe_v0_best_X500": (["-v", "0", "--best", "-X", "500"], dict(mode="v", mms=0, best=True, max_ins=500)),
+    "pe_v1_best_X500": (["-v", "1", "--best", "-X", "500"], dict(mode="v", mms=1, best=True, max_ins=500)),
+    "pe_v2_best_X500": (["-v", "2", "--best", "-X", "500"], dict(mode="v", mms=2, best=True, max_ins=500)),
+    "pe_v3_best_X500": (["-v", "3", "--best", "-X", "500"], dict(mode="v", mms=3, best=True, max_ins=500)),
+    "pe_n0_best_X500": (["-n", "0", "--best", "-X", "500"], dict(mode="n", mms=0, best=True, max_ins=500)),
+    "pe_n3_best_X500": (["-n", "3", "--best", "-X", "500"], dict(mode="n", mms=3, best=True, max_ins=500)),
+    "pe_n2_best_X400_I250_k3": (["-n", "2", "--best", "-X", "400", "-I", "250", "-k", "3"],
+                                dict(mode="n", mms=2, best=True, max_ins=400, min_ins=250, khits=3)),
+    "pe_n1_a_strata_X500": (["-n", "1", "--best", "-X", "500", "-a", "--strata"],
+                            dict(mode="n", mms=1, strata=True, all_hits=True, max_ins=500)),
+    "pe_n2_best_X500_m1": (["-n", "2", "--best", "-X", "500", "-m", "1"], dict(mode="n", mms=2, best=True, max_ins=500, mhits=1)),
+    "pe_n2_best": (["-n", "2", "--best"], dict(mode="n", mms=2, best=True)),
+    "pe_v2_best_X500_nofw": (["-v", "2", "--best", "-X", "500", "--nofw"], dict(mode="v", mms=2, best=True, max_ins=500, nofw=True)),
+    "pe_n2_best_X500_norc_k2": (["-n", "2", "--best", "-X", "500", "--norc", "-k", "2"],
+                                dict(mode="n", mms=2, best=True, max_ins=500, norc=True, khits=2)),
+    "pe_n2_best_X500_ff": (["-n", "2", "--best", "-X", "500", "--ff"], dict(mode="n", mms=2, best=True, max_ins=500, mate2_fw=True)),
+    "pe_n2_best_X500_rf": (["-n", "2", "--best", "-X", "500", "--rf"],
+                           dict(mode="n", mms=2, best=True, max_ins=500, mate1_fw=False, mate2_fw=True)),
+    "pe_n2_best_X500_pairtries2_k4": (["-n", "2", "--best", "-X", "500", "--pairtries", "2", "-k", "4"],
+                                      dict(mode="n", mms=2, best=True, max_ins=500, pair_tries=2, khits=4)),
+}
+# (index, pair set name) -> how tests regenerate the pairs (tests/common.py: pair_set)
+PAIR_SETS = [("e_coli", "e_coli_1000_pe"), ("e_coli", "pe50"), ("multi", "pe50"), ("multi", "pe100"), ("multi", "pe30"), ("e_coli", "pe75")]

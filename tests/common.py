@@ -14,7 +14,7 @@ import refrun as R
 from bowtie_amd import _abi as A
 from bowtie_amd.reads import pack_reads, parse_fastq
 from bowtie_amd.synth import synth_reads
-from best_modes import BEST_MODES
+from best_modes import BEST_MODES, PAIRED_MODES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
@@ -38,12 +38,57 @@ MODES = {
     "v2_nofw_k3": dict(mode="v", mms=2, nofw=True, khits=3),
 }
 MODES.update({k: v[1] for k, v in BEST_MODES.items()})
+MODES.update({k: v[1] for k, v in PAIRED_MODES.items()})
 
 
 @lru_cache(maxsize=None)
 def manifest():
     with open(os.path.join(G, "MANIFEST.json")) as f:
         return json.load(f)
+
+
+@lru_cache(maxsize=None)
+def pair_set(index: str, name: str):
+    """The read pairs oracle/gen_golden.py fed to the reference: (mates 1, mates 2)."""
+    if name == "e_coli_1000_pe":
+        return (pack_reads(parse_fastq(os.path.join(G, "e_coli_1000_1.fq"))),
+                pack_reads(parse_fastq(os.path.join(G, "e_coli_1000_2.fq"))))
+    from bowtie_amd.synth import synth_pairs
+    L = int(name[2:])
+    return synth_pairs(joined_text(index), 400, L, seed=L)
+
+
+def paired_runs(index=None, reads=None, modes=None):
+    out = []
+    for r in manifest().get("paired_runs", []):
+        if index and r["index"] != index:
+            continue
+        if reads and r["reads"] not in reads:
+            continue
+        if modes and r["mode"] not in modes:
+            continue
+        out.append(r)
+    return out
+
+
+def check_pairs_against_golden(run: dict, per_pair, b1, b2, refnames):
+    pol = MODES[run["mode"]]
+    sam = R.render_pairs(b1, b2, per_pair, refnames, sam=True, mhits=pol.get("mhits", 0xFFFFFFFF))
+    with gzip.open(os.path.join(G, run["file"]), "rb") as f:
+        want = f.read()
+    got = strip_sam(sam)
+    if got != want:
+        gl, wl = got.split(b"\n"), want.split(b"\n")
+        for i, (a, b) in enumerate(zip(gl, wl)):
+            if a != b:
+                raise AssertionError("%s: first difference at SAM line %d:\n got  %r\n want %r" % (run["file"], i, a, b))
+        raise AssertionError("%s: %d lines vs %d" % (run["file"], len(gl), len(wl)))
+    assert hashlib.md5(sam).hexdigest() == run["md5"], run["file"] + ": full-SAM md5 differs"
+
+
+def oracle_pair_results(index: str, b1, b2, kw, cap=None, counts=None):
+    pol = OL.make_policy(**kw)
+    return R.oracle_search_pairs(oracle_index(index), pol, b1, b2, cap=cap, counts=counts)
 
 
 def golden_runs(index=None, reads=None, modes=None):

@@ -28,7 +28,7 @@ class OpCounts(C.Structure):
 class OHit(C.Structure):
     _fields_ = [("tidx", C.c_uint32), ("toff", C.c_uint32), ("oms", C.c_uint32),
                 ("cost", C.c_uint16), ("stratum", C.c_uint8), ("fw", C.c_uint8),
-                ("nmm", C.c_uint16), ("mm", C.c_uint16 * BTO_MAXMM)]
+                ("nmm", C.c_uint16), ("mate", C.c_uint16), ("mm", C.c_uint16 * BTO_MAXMM)]
 
 
 class OIndex(C.Structure):
@@ -81,6 +81,14 @@ def lib() -> C.CDLL:
                                      C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
                                      C.POINTER(OHit), C.c_int, C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint32), C.POINTER(OpCounts)]
+        L.bto_refs_build.argtypes = [C.POINTER(OIndex)]
+        L.bto_refs_build.restype = C.c_void_p
+        L.bto_refs_free.argtypes = [C.c_void_p]
+        L.bto_align_pair_best.argtypes = [C.POINTER(OIndex), C.POINTER(OIndex), C.c_void_p, C.POINTER(Policy),
+                                          C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
+                                          C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
+                                          C.POINTER(OHit), C.c_int, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32), C.POINTER(OpCounts)]
         _lib = L
     return _lib
 
@@ -137,13 +145,32 @@ class OracleIndex:
                                  C.byref(tot), C.byref(st), C.byref(counts) if counts is not None else None)
         if n < 0:
             raise ValueError("oracle error %d" % -n)
+        return self._unpack(hits, n), int(tot.value), int(st.value)
+
+    @staticmethod
+    def _unpack(hits, n):
         out = []
         for i in range(n):
             h = hits[i]
             out.append(dict(tidx=h.tidx, toff=h.toff, oms=h.oms, cost=h.cost, stratum=h.stratum,
-                            fw=bool(h.fw),
+                            fw=bool(h.fw), mate=int(h.mate),
                             mms=[(h.mm[k] & 0x3FF, (h.mm[k] >> 12) & 3) for k in range(h.nmm)]))
-        return out, int(tot.value), int(st.value)
+        return out
+
+    def align_pair(self, pol: Policy, seq1, qual1: bytes, seed1: int, seq2, qual2: bytes, seed2: int,
+                   cap: int = 16, counts: Optional[OpCounts] = None):
+        """PairedBWAlignerV2 for one pair -> (hits: upstream mate, downstream mate, ..., n_hits_total, status)"""
+        if getattr(self, "_refs", None) is None:
+            self._refs = lib().bto_refs_build(C.byref(self.fw))
+        hits = (OHit * cap)()
+        tot, st = C.c_uint32(), C.c_uint32()
+        n = lib().bto_align_pair_best(C.byref(self.fw), C.byref(self.bw) if self.bw is not None else None, self._refs,
+                                      C.byref(pol), seq1.tobytes(), bytes(qual1), len(seq1), seed1,
+                                      seq2.tobytes(), bytes(qual2), len(seq2), seed2, hits, cap,
+                                      C.byref(tot), C.byref(st), C.byref(counts) if counts is not None else None)
+        if n < 0:
+            raise ValueError("oracle error %d" % -n)
+        return self._unpack(hits, n), int(tot.value), int(st.value)
 
 
 def rand_seed(seq: np.ndarray, qual: bytes, name: bytes, global_seed: int = 0) -> int:

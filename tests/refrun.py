@@ -83,3 +83,48 @@ def oracle_search(oidx, pol, batch: ReadBatch, cap: Optional[int] = None, counts
         res.append(([O.Hit(h["tidx"], h["toff"], h["oms"], h["cost"], h["stratum"], h["fw"], h["mms"])
                      for h in hits], total, st))
     return res
+
+
+def run_reference_pairs(args: List[str], index_base: str, reads1: str, reads2: str) -> bytes:
+    cmd = [REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", index_base, "-1", reads1, "-2", reads2]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    return p.stdout
+
+
+def oracle_search_pairs(oidx, pol, b1: ReadBatch, b2: ReadBatch, cap: Optional[int] = None, counts=None):
+    cap = cap or (128 if pol.all_hits else max(2, min(2 * int(pol.khits), 128)))
+    res = []
+    for i in range(b1.n):
+        L1, L2 = int(b1.len[i]), int(b2.len[i])
+        hits, total, st = oidx.align_pair(pol, b1.seq[i, :L1], b1.qual[i, :L1].tobytes(), int(b1.seed[i]),
+                                          b2.seq[i, :L2], b2.qual[i, :L2].tobytes(), int(b2.seed[i]),
+                                          cap=cap, counts=counts)
+        res.append(([O.Hit(h["tidx"], h["toff"], h["oms"], h["cost"], h["stratum"], h["fw"], h["mms"], h["mate"])
+                     for h in hits], total, st))
+    return res
+
+
+def render_pairs(b1: ReadBatch, b2: ReadBatch, per_pair, refnames, sam: bool, mhits: int = 0xFFFFFFFF) -> bytes:
+    """per_pair[i] = (hits: upstream mate, downstream mate, ..., n_hits_total, status) -> reference text.
+    finishRead (hit.h:741-786) with the doubled -k/-m of createMult(2); XM:i = pairs reported."""
+    out = []
+    maxv = 0xFFFFFFFF if mhits == 0xFFFFFFFF else 2 * mhits
+    for i in range(b1.n):
+        hits, total, status = per_pair[i]
+        reads = {1: (b1.names[i], b1.seq[i, :int(b1.len[i])], b1.qual[i, :int(b1.len[i])].tobytes()),
+                 2: (b2.names[i], b2.seq[i, :int(b2.len[i])], b2.qual[i, :int(b2.len[i])].tobytes())}
+        maxed = total > maxv
+        if hits and not maxed:
+            for k in range(0, len(hits) - 1, 2):
+                for h, m in ((hits[k], hits[k + 1]), (hits[k + 1], hits[k])):
+                    name, seq, qual = reads[h.mate]
+                    if sam:
+                        out.append(O.format_sam(name, seq, qual, h, refnames, xms=len(hits) // 2, mate_hit=m,
+                                                mate_len=len(reads[m.mate][1])))
+                    else:
+                        out.append(O.format_verbose(name, seq, qual, h, refnames))
+        elif sam and not maxed:
+            for mate in (1, 2):
+                name, seq, qual = reads[mate]
+                out.append(O.format_sam_unaligned(name, seq, qual, 0, mate=mate))
+    return b"".join(out)
