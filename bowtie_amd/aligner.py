@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("BT_LIB", "libbowtie_amd.so"))
 EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_refname",
            "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
-           "bt_align_batch_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used", "bt_ctx_last_retried",
+           "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used", "bt_ctx_last_retried",
            "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase", "bt_bench_gather",
            "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_error", "bt_reads_close", "bt_format_hits",
            "bt_format_sam_header", "bt_format_summary", "bt_text_free"]
@@ -59,6 +59,11 @@ def lib() -> C.CDLL:
                                      C.POINTER(A.OpCounts)]
         L.bt_align_batch_device.argtypes = [C.c_void_p, C.POINTER(A.ReadBatchC), C.POINTER(A.HitBatchC),
                                             C.c_void_p]
+        L.bt_index_load_reference.argtypes = [C.c_void_p]
+        L.bt_align_pairs.argtypes = [C.c_void_p, C.POINTER(A.ReadBatchC), C.POINTER(A.ReadBatchC), C.POINTER(A.HitBatchC),
+                                     C.POINTER(A.OpCounts)]
+        L.bt_align_pairs_device.argtypes = [C.c_void_p, C.POINTER(A.ReadBatchC), C.POINTER(A.ReadBatchC),
+                                            C.POINTER(A.HitBatchC), C.c_void_p]
         L.bt_ctx_sync.argtypes = [C.c_void_p]
         L.bt_ctx_last_kernel_ms.argtypes = [C.c_void_p]
         L.bt_ctx_last_kernel_ms.restype = C.c_float
@@ -159,6 +164,37 @@ def unpack_hits(n: int, hit_cap: int, hits: np.ndarray, n_hits: np.ndarray, stat
     return out
 
 
+def pack_batch(batch: ReadBatch):
+    """ReadBatch -> (arrays kept alive, ReadBatchC over them)"""
+    seq = np.ascontiguousarray(batch.seq, dtype=np.uint8)
+    qual = np.ascontiguousarray(batch.qual, dtype=np.uint8)
+    ln = np.ascontiguousarray(batch.len, dtype=np.uint16)
+    seed = np.ascontiguousarray(batch.seed, dtype=np.uint32)
+    return (seq, qual, ln, seed), A.ReadBatchC(batch.n, batch.stride, seq.ctypes.data, qual.ctypes.data,
+                                               ln.ctypes.data, seed.ctypes.data)
+
+
+def unpack_pair_hits(n: int, hit_cap: int, hits, n_hits, status, mm_pool, pol):
+    """Paired-end results: per pair (hits: upstream mate, downstream mate, ..., hitsForThisRead, status),
+    finishRead's rules with the doubled -k / -m of createMult(2) (hit.h:741-786)."""
+    out = []
+    mhits, khits = int(pol.mhits), int(pol.khits)
+    maxv = 0xFFFFFFFF if mhits == 0xFFFFFFFF else 2 * mhits
+    lim = hit_cap if pol.all_hits else min(hit_cap, 2 * khits)
+    for i in range(n):
+        tot = int(n_hits[i])
+        hs: List[Hit] = []
+        if tot <= maxv:
+            for k in range(min(tot, lim)):
+                h = hits[i * hit_cap + k]
+                off, nmm = int(h["mm_off"]), int(h["nmm"])
+                mms = [(int(e) & 0x3FF, (int(e) >> 12) & 3) for e in mm_pool[off:off + nmm]]
+                hs.append(Hit(int(h["tidx"]), int(h["toff"]), int(h["oms"]), int(h["cost"]), int(h["stratum"]),
+                              bool(h["fw"]), mms, int(h["pad"][0])))
+        out.append((hs, tot, int(status[i])))
+    return out
+
+
 class Aligner:
     """One per GPU; `align(batch)` = the worker loop body over a batch of reads."""
 
@@ -212,6 +248,30 @@ class Aligner:
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(self.policy.khits),
                            int(self.policy.mhits), bool(self.policy.all_hits),
                            sample_max=bool(self.policy.sample_max))
+
+    def align_pairs(self, b1: ReadBatch, b2: ReadBatch, hit_cap: Optional[int] = None, mm_per_hit: int = 8,
+                    counts: Optional[A.OpCounts] = None):
+        """Paired-end (bt_align_pairs): per pair (hits: upstream mate, downstream mate, ...,
+        hitsForThisRead, status).  Loads the 2-bit reference into HBM on first use."""
+        rc = lib().bt_index_load_reference(self.index._h)
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_index_load_reference")
+        n = b1.n
+        hit_cap = hit_cap or (128 if self.policy.all_hits else max(2, min(2 * int(self.policy.khits), 128)))
+        k1, rb1 = pack_batch(b1)
+        k2, rb2 = pack_batch(b2)
+        hits = np.zeros(n * hit_cap, dtype=A.HIT_DTYPE)
+        n_hits = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint8)
+        pool = np.zeros(max(1, n * hit_cap * mm_per_hit), dtype=np.uint16)
+        hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, pool.ctypes.data, len(pool), 0)
+        rc = lib().bt_align_pairs(self._h, C.byref(rb1), C.byref(rb2), C.byref(hb),
+                                  C.byref(counts) if counts is not None else None)
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_align_pairs")
+        self.last_kernel_ms = float(lib().bt_ctx_last_kernel_ms(self._h))
+        self.last_retried = int(lib().bt_ctx_last_retried(self._h))
+        return unpack_pair_hits(n, hit_cap, hits, n_hits, status, pool, self.policy)
 
     def probe_rank(self, rows: np.ndarray, mirror: bool = False) -> Tuple[np.ndarray, np.ndarray]:
         rows = np.ascontiguousarray(rows, dtype=np.uint32)

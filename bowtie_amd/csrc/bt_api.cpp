@@ -24,6 +24,9 @@ struct bt_index {
 	BtIndexDev  dev[2];
 	std::vector<void*> allocs;
 	uint64_t ebwt_bytes = 0, offs_bytes = 0;
+	std::string base;
+	BtRefDev* d_ref = nullptr;     /* the 2-bit reference, loaded on demand (bt_index_load_reference) */
+	uint64_t ref_bytes = 0;
 };
 
 struct bt_ctx {
@@ -33,6 +36,7 @@ struct bt_ctx {
 	bool best = false;               /* pol.best: the best-first engine (bt_best.h) instead of the phase programs */
 	BfProgram bprog;
 	BfProgram* d_bprog = nullptr; BtIndexDev* d_ix = nullptr; BtBatchDev* d_batch = nullptr;
+	BfProgram* d_bprog_pe = nullptr; bool have_pe = false;      /* the paired program, compiled on first use */
 	uint32_t* arenas = nullptr; uint32_t arenaWords = 0; uint32_t arenaLanes = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
@@ -93,6 +97,7 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 	bt_index* ix = new bt_index();
 	ix->device = device;
 	ix->has_mirror = need_mirror != 0;
+	ix->base = ebwt_base;
 	for (int m = 0; m < (need_mirror ? 2 : 1); m++) {
 		std::string base = std::string(ebwt_base) + (m ? ".rev" : "");
 		int rc = bt_host_index_load(base, m == 0, offrate_override, &ix->host[m]);
@@ -272,6 +277,7 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->pool2) (void)hipFree(c->pool2);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->d_bprog) (void)hipFree(c->d_bprog);
+	if (c->d_bprog_pe) (void)hipFree(c->d_bprog_pe);
 	if (c->d_ix) (void)hipFree(c->d_ix);
 	if (c->d_batch) (void)hipFree(c->d_batch);
 	if (c->arenas) (void)hipFree(c->arenas);
@@ -283,7 +289,8 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 }
 
 /* the best-first engine: one launch of bt_best_kernel, every lane with its own arena */
-static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, unsigned long long* counts_dev)
+static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, unsigned long long* counts_dev,
+                           const bt_read_batch* in2 = nullptr)
 {
 	/* arena words per lane: typical reads need a few thousand; a read that outgrows its arena is
 	 * flagged (BT_STF_OVERFLOW) and re-run by bt_align_batch through the twin context's 16 MB arenas */
@@ -302,11 +309,13 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
 	B.mm_pool_used = c->d_cursor + 1;
+	if (in2) { B.seq2 = in2->seq; B.qual2 = in2->qual; B.len2 = in2->len; B.seed2 = in2->seed; B.stride2 = in2->stride; }
 	HIPCHK(hipMemcpyAsync(c->d_batch, &B, sizeof(B), hipMemcpyHostToDevice, c->stream));
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
 	BtBestArgs A;
-	A.prog = c->d_bprog; A.ix = c->d_ix; A.batch = c->d_batch;
+	A.prog = in2 ? c->d_bprog_pe : c->d_bprog; A.ix = c->d_ix; A.batch = c->d_batch;
+	A.ref = in2 ? c->idx->d_ref : nullptr;
 	A.arenas = c->arenas; A.arenaWords = words; A.nextRead = c->d_cursor;
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
@@ -432,6 +441,180 @@ extern "C" int bt_align_batch_device(bt_ctx* c, const bt_read_batch* in, bt_hit_
 	if (!c || !in || !out) return BT_ERR_ARG;
 	/* lengths live in HBM: size the scratch for the row stride (>= every length) */
 	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev, true);
+}
+
+/* Replaces: BitPairReference's constructor (reference.h:35-240; ebwt_search.cpp:3162-3171 loads it
+ * for paired-end runs): <base>.3.ebwt / .4.ebwt into HBM, 2 bits per base plus an N mask. */
+extern "C" int bt_index_load_reference(bt_index* ix)
+{
+	if (!ix) return BT_ERR_ARG;
+	if (ix->d_ref) return BT_OK;
+	HIPCHK(hipSetDevice(ix->device));
+	BtRefHost R;
+	int rc = bt_host_ref_load(ix->base, ix->host[0], &R);
+	if (rc != BT_OK) return rc;
+	BtRefDev d;
+	memset(&d, 0, sizeof(d));
+	int r2;
+	if ((r2 = upload(ix, R.bits, &d.bits)) || (r2 = upload(ix, R.nmask, &d.nmask)) || (r2 = upload(ix, R.start, &d.start)) ||
+	    (r2 = upload(ix, R.approxLen, &d.approxLen))) return r2;
+	d.nRefs = (uint32_t)R.start.size();
+	void* p = nullptr;
+	HIPCHK(hipMalloc(&p, sizeof(d)));
+	ix->allocs.push_back(p);
+	HIPCHK(hipMemcpy(p, &d, sizeof(d), hipMemcpyHostToDevice));
+	ix->d_ref = (BtRefDev*)p;
+	ix->ref_bytes = (R.bits.size() + R.nmask.size()) * 4ull;
+	return BT_OK;
+}
+
+static int ctx_ensure_paired(bt_ctx* c)
+{
+	if (!c->best) return BT_ERR_ARG;                 /* PairedBWAlignerV2 is the --best aligner */
+	if (c->have_pe) return BT_OK;
+	if (!c->idx->d_ref) return BT_ERR_ARG;           /* bt_index_load_reference first */
+	BfProgram P;
+	int rc = bt_host_compile_best_paired(c->pol, &P);
+	if (rc != BT_OK) return rc;
+	if (P.needMirror && !c->idx->has_mirror) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(c->idx->device));
+	HIPCHK(hipMalloc((void**)&c->d_bprog_pe, sizeof(BfProgram)));
+	HIPCHK(hipMemcpy(c->d_bprog_pe, &P, sizeof(P), hipMemcpyHostToDevice));
+	c->have_pe = true;
+	return BT_OK;
+}
+
+extern "C" int bt_align_pairs_device(bt_ctx* c, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
+                                     bt_op_counts* counts_dev)
+{
+	if (!c || !in1 || !in2 || !out || in1->n_reads != in2->n_reads) return BT_ERR_ARG;
+	int rc = ctx_ensure_paired(c);
+	if (rc != BT_OK) return rc;
+	if (in1->n_reads == 0) { c->timed = false; return BT_OK; }
+	if (!in1->seq || !in1->qual || !in1->len || !in1->seed || !in2->seq || !in2->qual || !in2->len || !in2->seed ||
+	    !out->hits || !out->n_hits || !out->status || out->hit_cap < 2 || (out->hit_cap & 1u) ||
+	    (in1->stride & 15u) || (in2->stride & 15u)) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(c->idx->device));
+	return run_best_device(c, in1, out, (unsigned long long*)counts_dev, in2);
+}
+
+extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
+                              bt_op_counts* counts)
+{
+	if (!c || !in1 || !in2 || !out || in1->n_reads != in2->n_reads) return BT_ERR_ARG;
+	int rc = ctx_ensure_paired(c);
+	if (rc != BT_OK) return rc;
+	const uint32_t n = in1->n_reads;
+	out->mm_pool_used = 0;
+	if (n == 0) return BT_OK;
+	if (!out->hits || !out->n_hits || !out->status || out->hit_cap < 2 || (out->hit_cap & 1u)) return BT_ERR_ARG;
+	for (int m = 0; m < 2; m++) {
+		const bt_read_batch* in = m ? in2 : in1;
+		if (!in->seq || !in->qual || !in->len || !in->seed || (in->stride & 15u) != 0) return BT_ERR_ARG;
+		for (uint32_t i = 0; i < n; i++) if (in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;
+	}
+	HIPCHK(hipSetDevice(c->idx->device));
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	size_t o_seq[2], o_qual[2], o_len[2], o_seed[2], cur = 0;
+	for (int m = 0; m < 2; m++) {
+		const bt_read_batch* in = m ? in2 : in1;
+		o_seq[m] = cur; cur += al((size_t)n * in->stride);
+		o_qual[m] = cur; cur += al((size_t)n * in->stride);
+		o_len[m] = cur; cur += al(2ull * n);
+		o_seed[m] = cur; cur += al(4ull * n);
+	}
+	const size_t o_hits = cur, o_nh = o_hits + al((size_t)n * out->hit_cap * sizeof(bt_hit)), o_st = o_nh + al(4ull * n),
+	             o_mm = o_st + al(n), total = o_mm + al(2ull * out->mm_pool_cap);
+	if (total > c->stage_bytes) {
+		if (c->stage) (void)hipFree(c->stage);
+		c->stage = nullptr; c->stage_bytes = 0;
+		HIPCHK(hipMalloc(&c->stage, total));
+		c->stage_bytes = total;
+	}
+	uint8_t* d = (uint8_t*)c->stage;
+	bt_read_batch din[2];
+	for (int m = 0; m < 2; m++) {
+		const bt_read_batch* in = m ? in2 : in1;
+		HIPCHK(hipMemcpyAsync(d + o_seq[m], in->seq, (size_t)n * in->stride, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d + o_qual[m], in->qual, (size_t)n * in->stride, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d + o_len[m], in->len, 2ull * n, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d + o_seed[m], in->seed, 4ull * n, hipMemcpyHostToDevice, c->stream));
+		din[m] = *in;
+		din[m].seq = d + o_seq[m]; din[m].qual = d + o_qual[m];
+		din[m].len = (const uint16_t*)(d + o_len[m]); din[m].seed = (const uint32_t*)(d + o_seed[m]);
+	}
+	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_mm - o_hits, c->stream));
+	bt_hit_batch dout = *out;
+	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
+	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
+	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long), c->stream));
+	rc = run_best_device(c, &din[0], &dout, nullptr, &din[1]);
+	if (rc != BT_OK) return rc;
+	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out->n_hits, d + o_nh, 4ull * n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out->status, d + o_st, n, hipMemcpyDeviceToHost, c->stream));
+	if (out->mm_pool_cap)
+		HIPCHK(hipMemcpyAsync(out->mm_pool, d + o_mm, 2ull * out->mm_pool_cap, hipMemcpyDeviceToHost, c->stream));
+	rc = bt_ctx_sync(c);
+	if (rc != BT_OK) return rc;
+	out->mm_pool_used = c->last_mm_used < out->mm_pool_cap ? c->last_mm_used : out->mm_pool_cap;
+	if (counts) { rc = bt_ctx_counts(c, counts, 0); if (rc != BT_OK) return rc; }
+	/* pairs that outgrew their arena: again through the twin context's 16 MB arenas */
+	std::vector<uint32_t> redo;
+	if (!c->is_big)
+		for (uint32_t i = 0; i < n; i++) if (out->status[i] & BT_STF_OVERFLOW) redo.push_back(i);
+	c->last_retried = (uint32_t)redo.size();
+	if (!redo.empty()) {
+		if (!c->big) {
+			bt_ctx* b = nullptr;
+			rc = bt_ctx_create(c->idx, &c->pol, nullptr, &b);
+			if (rc != BT_OK) return rc;
+			b->is_big = true; b->heavy0 = 0;
+			c->big = b;
+		}
+		const uint32_t m = (uint32_t)redo.size();
+		std::vector<uint8_t> sseq[2], squal[2]; std::vector<uint16_t> slen[2]; std::vector<uint32_t> sseed[2];
+		bt_read_batch sin[2];
+		for (int k2 = 0; k2 < 2; k2++) {
+			const bt_read_batch* in = k2 ? in2 : in1;
+			sseq[k2].resize((size_t)m * in->stride); squal[k2].resize((size_t)m * in->stride); slen[k2].resize(m); sseed[k2].resize(m);
+			for (uint32_t k = 0; k < m; k++) {
+				const uint32_t i = redo[k];
+				memcpy(&sseq[k2][(size_t)k * in->stride], in->seq + (size_t)i * in->stride, in->stride);
+				memcpy(&squal[k2][(size_t)k * in->stride], in->qual + (size_t)i * in->stride, in->stride);
+				slen[k2][k] = in->len[i]; sseed[k2][k] = in->seed[i];
+			}
+			sin[k2] = bt_read_batch{ m, in->stride, sseq[k2].data(), squal[k2].data(), slen[k2].data(), sseed[k2].data() };
+		}
+		std::vector<uint8_t> sst(m); std::vector<uint32_t> snh(m);
+		std::vector<bt_hit> shits((size_t)m * out->hit_cap);
+		const uint32_t spare = out->mm_pool_cap > out->mm_pool_used ? out->mm_pool_cap - out->mm_pool_used : 0;
+		std::vector<uint16_t> spool(spare ? spare : 1);
+		bt_hit_batch sout = { out->hit_cap, shits.data(), snh.data(), sst.data(), spool.data(), spare, 0 };
+		bt_op_counts c2;
+		rc = bt_align_pairs(c->big, &sin[0], &sin[1], &sout, counts ? &c2 : nullptr);
+		if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return rc;
+		if (counts) {
+			counts->lfex += c2.lfex; counts->lf2 += c2.lf2; counts->lf1 += c2.lf1; counts->chase += c2.chase;
+			counts->ftab += c2.ftab; counts->offs += c2.offs; counts->rstarts += c2.rstarts; counts->frames += c2.frames;
+			counts->same_pair += c2.same_pair;
+		}
+		for (uint32_t k = 0; k < m; k++) {
+			const uint32_t i = redo[k];
+			out->n_hits[i] = snh[k]; out->status[i] = sst[k];
+			for (uint32_t h = 0; h < out->hit_cap; h++) {
+				bt_hit hit = shits[(size_t)k * out->hit_cap + h];
+				if (hit.nmm) hit.mm_off += out->mm_pool_used;
+				out->hits[(size_t)i * out->hit_cap + h] = hit;
+			}
+		}
+		if (sout.mm_pool_used) memcpy(out->mm_pool + out->mm_pool_used, spool.data(), 2ull * sout.mm_pool_used);
+		out->mm_pool_used += sout.mm_pool_used;
+	}
+	int worst = BT_OK;
+	for (uint32_t i = 0; i < n; i++)
+		if ((out->status[i] & (BT_STF_OVERFLOW | BT_STF_MMPOOL)) && worst == BT_OK) worst = BT_ERR_OVERFLOW;
+	return worst;
 }
 
 extern "C" int bt_ctx_sync(bt_ctx* c)

@@ -63,12 +63,13 @@ struct BfSpec {                   /* EbwtRangeSource + EbwtRangeSourceDriver con
 	uint8_t  reportExacts, halfAndHalf, partial;
 	uint8_t  seed;                /* EbwtRangeSourceDriver::seed_: truncate the query to the seed */
 	uint8_t  nudgeLeft, useBtCnt;
+	uint8_t  mate;                /* 0: mate 1 / the unpaired read, 1: mate 2                     */
 	uint8_t  rev[4];              /* rev0Off..rev3Off as BF_PIN_*                                 */
 	uint32_t qualLim, seedLen;
 };
 struct BfNode { uint8_t kind, spec, genSpec, fw; };   /* child of the top-level cost-aware driver */
-#define BF_MAX_SPECS 24
-#define BF_MAX_NODES 8
+#define BF_MAX_SPECS 48
+#define BF_MAX_NODES 16
 struct BfProgram {
 	BfSpec   specs[BF_MAX_SPECS];
 	BfNode   nodes[BF_MAX_NODES];
@@ -76,12 +77,27 @@ struct BfProgram {
 	uint32_t maq, maxBts, btCntOn, strandFix;
 	uint32_t sinkN, sinkMax, sinkAll, sinkStrata, sampleMax;
 	uint32_t needMirror;
+	/* paired-end (PairedBWAlignerV2, aligner.h:1483-2051) */
+	uint32_t paired, minIns, maxIns, mate1Fw, mate2Fw, pairTries, allowContain;
+	/* the RefAligner the pair's second mate is found with (ref_aligner.h): k mismatches end to end
+	 * (-v k) or k in the seed with a quality ceiling (-n k) */
+	uint32_t refSeeded, refMms, refSeedLen, refQualMax;
+};
+
+/* the 2-bit reference with its N mask (BitPairReference, reference.h:35-120), one position space
+ * for all sequences: reference t occupies positions [start[t], start[t] + len) */
+struct BtRefDev {
+	const uint32_t* bits;        /* 16 bases per word, base i at bits 2(i%16)                    */
+	const uint32_t* nmask;       /* 32 positions per word, 1 = N / gap                           */
+	const uint64_t* start;       /* [nRefs]                                                      */
+	const uint32_t* approxLen;   /* [nRefs] up to the end of the last unambiguous stretch        */
+	uint32_t nRefs, pad;
 };
 
 /* ---- record layouts (word indices) ---------------------------------------------------------- */
 #define BF_DRW 32u
 enum {
-	DR_KIND = 0,       /* kind | fw<<8 | spec<<16                                                  */
+	DR_KIND = 0,       /* kind | fw<<8 | mate<<9 | spec<<16                                        */
 	DR_FLAGS,          /* 1 done, 2 foundRange                                                     */
 	DR_COST,           /* minCost | minCostAdjustment<<16                                          */
 	/* leaf (EbwtRangeSourceDriver + its PathManager + its EbwtRangeSource) */
@@ -117,13 +133,16 @@ struct BfChase {                  /* RangeChaser + RowChaser state */
 	uint32_t mirror, qlen, top, bot, irow, row, tidx, toff, done, cDone, cRow, cJumps, cOff;
 };
 
+struct BfRead { BF_G const uint8_t* seq; BF_G const uint8_t* qual; uint32_t len, seed; };
+
 struct BfLane {                   /* per-lane registers / private memory */
 	BF_G uint32_t* A;             /* this read's arena                                            */
 	uint32_t cap, top, ovf;
 	const BtIndexDev* ix;         /* [2]: text index, mirror index                                */
 	const BfProgram* P;
-	BF_G const uint8_t* seq; BF_G const uint8_t* qual;
-	uint32_t len, seed, rd;
+	const BtRefDev* ref;          /* paired-end only                                              */
+	BfRead R[2];                  /* the read / the two mates                                     */
+	uint32_t rd;
 	int32_t  btCnt;
 	uint32_t alRnd;
 	uint32_t nhits, stored, bestStratum, status;
@@ -149,14 +168,14 @@ BF_INL uint32_t bf_alloc(BfLane& X, uint32_t n)
 }
 
 /* Read::patFw / patRc / patFwRev / patRcRev and qual / qualRev (read.h:119-133) from the one stored copy */
-BF_INL uint32_t bf_base(const BfLane& X, uint32_t fw, uint32_t ebwtFw, uint32_t i)
+BF_INL uint32_t bf_base(const BfRead& R, uint32_t fw, uint32_t ebwtFw, uint32_t i)
 {
-	uint32_t c = X.seq[(fw == ebwtFw) ? i : X.len - 1u - i];
+	uint32_t c = R.seq[(fw == ebwtFw) ? i : R.len - 1u - i];
 	return (!fw && c < 4u) ? (c ^ 3u) : c;
 }
-BF_INL uint32_t bf_qualc(const BfLane& X, uint32_t fw, uint32_t ebwtFw, uint32_t i)
+BF_INL uint32_t bf_qualc(const BfRead& R, uint32_t fw, uint32_t ebwtFw, uint32_t i)
 {
-	return X.qual[(fw == ebwtFw) ? i : X.len - 1u - i];
+	return R.qual[(fw == ebwtFw) ? i : R.len - 1u - i];
 }
 BF_INL uint32_t bf_phred(uint32_t c) { return c >= 33u ? c - 33u : 0u; }
 
@@ -430,9 +449,10 @@ BF_INL const BfSpec& leaf_spec(BfLane& X, uint32_t d) { return X.P->specs[(AW(d 
  * (ebwt_search_backtrack.h:1831-1861) */
 BF_FN uint32_t leaf_qry(BfLane& X, uint32_t d, const BfSpec& sp, uint32_t i)
 {
-	uint32_t c = bf_base(X, sp.fw, !sp.mirror, i);
+	const BfRead& R = X.R[sp.mate];
+	uint32_t c = bf_base(R, sp.fw, !sp.mirror, i);
 	if (AW(d + LF_RSFLAGS) & 8u) {
-		const uint32_t n = AW(d + LF_SEED) >> 16, full = X.len;
+		const uint32_t n = AW(d + LF_SEED) >> 16, full = R.len;
 		for (uint32_t k = 0; k < n; k++) {
 			const uint32_t m = AW(d + LF_SEEDMM0 + k);
 			if (full - (m & 0xffffu) - 1u == i) c = m >> 16;
@@ -449,7 +469,7 @@ BF_INL uint32_t bf_cext(uint32_t cext, uint32_t sRight, uint32_t s, uint32_t len
 BF_FN void leaf_init(BfLane& X, uint32_t d, uint32_t spec)
 {
 	for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
-	AW(d + DR_KIND) = BF_LEAF | ((uint32_t)X.P->specs[spec].fw << 8) | (spec << 16);
+	AW(d + DR_KIND) = BF_LEAF | ((uint32_t)X.P->specs[spec].fw << 8) | ((uint32_t)X.P->specs[spec].mate << 9) | (spec << 16);
 	AW(d + DR_FLAGS) = BF_F_DONE;
 }
 
@@ -479,10 +499,11 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	const uint32_t maq = X.P->maq;
 	AW(d + DR_FLAGS) = 0;
 	pm_reset(X, d);
-	const uint32_t len = X.len;
+	const BfRead& R = X.R[sp.mate];
+	const uint32_t len = R.len;
 	AW(d + LF_RSFLAGS) = 0;
 	if (seedSrc) leaf_take_seed(X, d, seedSrc);
-	AW(d + LF_RND) = X.seed;
+	AW(d + LF_RND) = R.seed;
 	/* initRangeSource */
 	const uint32_t s = sp.seedLen > 0 ? (sp.seedLen < len ? sp.seedLen : len) : len;
 	uint32_t sRight = s >> 1;
@@ -500,16 +521,16 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	} else if (!sp.halfAndHalf && r0 < s) {
 		minCost = 1u << 14;
 		uint32_t low = 0xffu;
-		for (uint32_t k = r0; k < s; k++) { const uint32_t c = bf_qualc(X, sp.fw, ebwtFw, qlen - k - 1u); if (c < low) low = c; }
+		for (uint32_t k = r0; k < s; k++) { const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u); if (c < low) low = c; }
 		minCost += bt_mm_penalty(maq, bf_phred(low));
 	} else if (sp.halfAndHalf && sRight > 0 && sRight < (s - 1u)) {
 		minCost = (sp.seed ? 3u : 2u) << 14;
 		uint32_t low1 = 0xffu;
-		for (uint32_t k = 0; k < sRight; k++) { const uint32_t c = bf_qualc(X, sp.fw, ebwtFw, qlen - k - 1u); if (c < low1) low1 = c; }
+		for (uint32_t k = 0; k < sRight; k++) { const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u); if (c < low1) low1 = c; }
 		minCost += bt_mm_penalty(maq, bf_phred(low1));
 		uint32_t l21 = 0xffu, l22 = 0xffu;
 		for (uint32_t k = sRight; k < s; k++) {
-			const uint32_t c = bf_qualc(X, sp.fw, ebwtFw, qlen - k - 1u);
+			const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u);
 			if (c < l21) { if (l21 != 0xffu) l22 = l21; l21 = c; }
 			else if (c < l22) l22 = c;
 		}
@@ -600,7 +621,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			cur = qlen - depth - 1u;
 			if (depth < qlen) {
 				const uint32_t c = leaf_qry(X, d, sp, cur);
-				const uint32_t q = bt_mm_penalty(maq, bf_phred(bf_qualc(X, sp.fw, !sp.mirror, cur)));
+				const uint32_t q = bt_mm_penalty(maq, bf_phred(bf_qualc(X.R[sp.mate], sp.fw, !sp.mirror, cur)));
 				const uint32_t ham = br_ham(X, br);
 				const uint32_t d0 = AW(br + BR_D01) & 0xffffu;
 				const bool alt = depth >= d0 && ham + q <= sp.qualLim;
@@ -724,6 +745,7 @@ BF_FN void leaf_advance(BfLane& X, uint32_t d)
 /* ---- the inner drivers ------------------------------------------------------------------------ */
 BF_INL uint32_t dr_kind(BfLane& X, uint32_t d) { return AW(d + DR_KIND) & 0xffu; }
 BF_INL uint32_t dr_fw(BfLane& X, uint32_t d) { return (AW(d + DR_KIND) >> 8) & 1u; }
+BF_INL uint32_t dr_mate(BfLane& X, uint32_t d) { return (AW(d + DR_KIND) >> 9) & 1u; }
 BF_INL uint32_t dr_mincost(BfLane& X, uint32_t d) { return AW(d + DR_COST) & 0xffffu; }
 BF_INL void dr_set_mincost(BfLane& X, uint32_t d, uint32_t c) { AW(d + DR_COST) = (AW(d + DR_COST) & 0xffff0000u) | (c & 0xffffu); }
 BF_INL bool dr_done(BfLane& X, uint32_t d) { return (AW(d + DR_FLAGS) & BF_F_DONE) != 0; }
@@ -791,7 +813,7 @@ template <int LEVEL> BF_FN void cost_set_query(BfLane& X, uint32_t d)
 {
 	AW(d + DR_FLAGS) = 0; AW(d + CA_LAST) = 0; AW(d + CA_DELAYED) = 0;
 	AW(d + CA_OPTS) |= 2u;
-	AW(d + CA_RND) = X.seed;
+	AW(d + CA_RND) = X.R[0].seed;                             /* patsrc->bufa().seed */
 	const uint32_t n = AW(d + CA_NRSS) & 0xffffu;
 	if (n == 0) return;
 	for (uint32_t i = 0; i < n; i++) child_set_query<LEVEL>(X, AW(AW(d + CA_RSS) + i), 0);
@@ -802,7 +824,7 @@ template <int LEVEL> BF_FN void cost_set_query(BfLane& X, uint32_t d)
 }
 
 /* foundFirstRange (range_source.h:2311-2362); rss_[i] -- not active_[i] -- supplies mate1()/fw() */
-template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, uint32_t r, uint32_t rfw)
+template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, uint32_t r, uint32_t rfw, uint32_t rmate)
 {
 	dr_set(X, d, BF_F_FOUND, true);
 	AW(d + CA_LAST) = r;
@@ -810,7 +832,7 @@ template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, ui
 		const uint32_t sz = AW(d + CA_NACT);
 		const uint32_t rcost = AW(r + LF_CURCOST) & 0xffffu;
 		for (uint32_t i = 1; i < sz; i++) {
-			if (dr_fw(X, AW(AW(d + CA_RSS) + i)) != rfw) {
+			if (dr_mate(X, AW(AW(d + CA_RSS) + i)) == rmate && dr_fw(X, AW(AW(d + CA_RSS) + i)) != rfw) {
 				const uint32_t p = AW(AW(d + CA_ACT) + i);
 				const uint32_t mine = dr_mincost(X, d), theirs = dr_mincost(X, p);
 				const uint32_t minCost = mine > theirs ? mine : theirs;
@@ -835,7 +857,20 @@ template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, ui
 	return false;
 }
 
-/* advanceImpl (range_source.h:2157-2210), unpaired */
+/* mateEliminated (range_source.h:2266-2280): only the aligner's own driver mixes mates */
+template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
+{
+	if (LEVEL != 0 || !X.P->paired) return false;
+	const uint32_t n = AW(d + CA_NACT);
+	bool m1 = false, m2 = false;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t a = AW(AW(d + CA_ACT) + i);
+		if (!dr_done(X, a)) { if (dr_mate(X, a)) m2 = true; else m1 = true; }
+	}
+	return !m1 || !m2;
+}
+
+/* advanceImpl (range_source.h:2157-2210) */
 template <int LEVEL> BF_FN void cost_advance(BfLane& X, uint32_t d)
 {
 	AW(d + CA_LAST) = 0;
@@ -847,19 +882,19 @@ template <int LEVEL> BF_FN void cost_advance(BfLane& X, uint32_t d)
 		else dr_set(X, d, BF_F_DONE, true);
 		return;
 	}
-	if (actSz == 0) { dr_set(X, d, BF_F_DONE, true); return; }
+	if (cost_mate_eliminated<LEVEL>(X, d) || actSz == 0) { AW(d + CA_NACT) = 0; dr_set(X, d, BF_F_DONE, true); return; }
 	const uint32_t p = AW(AW(d + CA_ACT));
 	const uint32_t precost = dr_mincost(X, p);
 	if (!dr_found(X, p)) child_advance<LEVEL>(X, p);
 	bool needsSort = false;
 	if (dr_found(X, p)) {
 		const uint32_t r = child_range(X, p);
-		needsSort = cost_found_first_range<LEVEL>(X, d, r, dr_fw(X, p));
+		needsSort = cost_found_first_range<LEVEL>(X, d, r, dr_fw(X, p), dr_mate(X, p));
 		dr_set(X, p, BF_F_FOUND, false);
 	}
 	if (dr_done(X, p) || precost != dr_mincost(X, p) || needsSort) {
 		cost_sort_actives(X, d);
-		if (AW(d + CA_NACT) == 0) dr_set(X, d, BF_F_DONE, AW(d + CA_DELAYED) == 0);
+		if (cost_mate_eliminated<LEVEL>(X, d) || AW(d + CA_NACT) == 0) { AW(d + CA_NACT) = 0; dr_set(X, d, BF_F_DONE, AW(d + CA_DELAYED) == 0); }
 	}
 }
 
@@ -960,7 +995,7 @@ BF_FN uint32_t bf_build_tree(BfLane& X)
 			leaf_init(X, gen, nd.genSpec);
 			cost_init(X, full, 0, 0);
 			for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
-			AW(d + DR_KIND) = BF_SEEDED | ((uint32_t)nd.fw << 8);
+			AW(d + DR_KIND) = BF_SEEDED | ((uint32_t)nd.fw << 8) | ((uint32_t)P.specs[nd.spec].mate << 9);
 			AW(d + DR_FLAGS) = BF_F_DONE;
 			AW(d + SD_FULL) = full; AW(d + SD_SEED) = gen; AW(d + SD_FACT) = nd.spec;
 		}
@@ -1010,9 +1045,9 @@ BF_FN void ch_set_row(BfLane& X, BfChase& c, uint32_t row)
 		if (c.row == c.irow) { c.done = 1; return; }
 	}
 }
-BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uint32_t mirror)
+BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uint32_t mirror, uint32_t qlen)
 {
-	c.mirror = mirror; c.qlen = X.len; c.top = top; c.bot = bot;
+	c.mirror = mirror; c.qlen = qlen; c.top = top; c.bot = bot;
 	c.irow = top + (bf_rnd(X.alRnd) % (bot - top));
 	c.done = 0; c.tidx = BT_OFF_MASK;
 	ch_set_row(X, c, c.irow);
@@ -1032,21 +1067,24 @@ BF_FN void ch_advance(BfLane& X, BfChase& c)
 }
 
 /* ---- sink + hit record -------------------------------------------------------------------------
- * UnpairedAlignerV2::report (aligner.h:467-497), EbwtSearchParams::reportHit (ebwt.h:1288-1405),
- * NGood / NBestFirstStrat / All sinks (hit.h:969-985, 1070-1129, 1201-1209).  true = stop. */
-BF_FN bool bf_report(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff)
+ * UnpairedAlignerV2::report (aligner.h:467-497) / PairedBWAlignerV2::report (:1720-1788),
+ * EbwtSearchParams::reportHit (ebwt.h:1288-1405), NGood / NBestFirstStrat / All sinks
+ * (hit.h:969-985, 1070-1129, 1201-1209).  true = stop.
+ * getmm(i, &m, &refc): the i-th mismatch as (offset in the searched query string, reference base);
+ * `flip` says that string runs 3'->5' (ebwtFw != fw). */
+template <class F>
+BF_FN bool bf_emit_hit(BfLane& X, const BtBatchDev& B, uint32_t fw, bool flip, uint32_t alen, uint32_t cost, uint32_t oms,
+                       uint32_t mate, uint32_t nmm, uint32_t tidx, uint32_t toff, F getmm)
 {
 	const BfProgram& P = *X.P;
-	const BfSpec& sp = leaf_spec(X, leaf);
-	const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu, stratum = cost >> 14;
+	const uint32_t stratum = cost >> 14;
 	X.nhits++;
 	if (P.sinkStrata && stratum < X.bestStratum) X.bestStratum = stratum;
 	if (X.nhits > P.sinkMax) return true;
 	if (X.stored < B.hit_cap) {
 		BtHitRec h;
-		h.tidx = tidx; h.toff = toff; h.oms = AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u;
-		h.cost = (uint16_t)cost; h.stratum = (uint8_t)stratum; h.fw = sp.fw; h.pad[0] = h.pad[1] = 0;
-		const uint32_t nmm = AW(leaf + LF_CURCOST) >> 16;
+		h.tidx = tidx; h.toff = toff; h.oms = oms;
+		h.cost = (uint16_t)cost; h.stratum = (uint8_t)stratum; h.fw = (uint8_t)fw; h.pad[0] = (uint8_t)mate; h.pad[1] = 0;
 		h.nmm = (uint16_t)nmm; h.mm_off = 0;
 		if (nmm > 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1057,14 +1095,9 @@ BF_FN bool bf_report(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tid
 			if (off + nmm <= B.mm_pool_cap) {
 				h.mm_off = off;
 				auto mm = BT_GP(uint16_t, B.mm_pool + off);
-				const bool flip = (sp.mirror == 0) != (sp.fw != 0);
-				const uint32_t qlen = AW(leaf + LF_QLEN) & 0xffffu, alen = X.len;
-				const uint32_t sn = (AW(leaf + LF_RSFLAGS) & 8u) ? (AW(leaf + LF_SEED) >> 16) : 0u;
-				uint32_t b = AW(leaf + LF_CURBR);
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t m, refc;
-					if (i < nmm - sn) { const uint32_t e = AW(b + BR_EDIT); m = qlen - (e & 0x3ffu) - 1u; refc = (e >> 10) & 3u; b = AW(b + BR_PARENT); }
-					else { const uint32_t s = AW(leaf + LF_SEEDMM0 + (i - (nmm - sn))); m = qlen - (s & 0xffffu) - 1u; refc = s >> 16; }
+					getmm(i, m, refc);
 					const uint32_t pos = flip ? alen - m - 1u : m;
 					const uint16_t e16 = (uint16_t)(pos | (refc << 12));
 					int j = (int)i - 1;                              /* Hit::mms is a bitset: ordered by position */
@@ -1084,37 +1117,82 @@ BF_FN bool bf_report(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tid
 	if (P.sinkAll && !P.sinkStrata) return false;
 	return X.nhits == P.sinkN && (P.sinkMax == 0xffffffffu || P.sinkMax < P.sinkN);
 }
+
+/* a hit from a leaf's current range: its edits are the found branch's chain plus the seed range's */
+BF_FN bool bf_report_leaf(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff, uint32_t mate,
+                          uint32_t oms, bool ebwtFw)
+{
+	const BfSpec& sp = leaf_spec(X, leaf);
+	const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu, nmm = AW(leaf + LF_CURCOST) >> 16;
+	const uint32_t qlen = AW(leaf + LF_QLEN) & 0xffffu;
+	const uint32_t sn = (AW(leaf + LF_RSFLAGS) & 8u) ? (AW(leaf + LF_SEED) >> 16) : 0u;
+	uint32_t b = AW(leaf + LF_CURBR);
+	return bf_emit_hit(X, B, sp.fw, ebwtFw != (sp.fw != 0), X.R[sp.mate].len, cost, oms, mate, nmm, tidx, toff,
+		[&](uint32_t i, uint32_t& m, uint32_t& refc) {
+			if (i < nmm - sn) { const uint32_t e = AW(b + BR_EDIT); m = qlen - (e & 0x3ffu) - 1u; refc = (e >> 10) & 3u; b = AW(b + BR_PARENT); }
+			else { const uint32_t sd = AW(leaf + LF_SEEDMM0 + (i - (nmm - sn))); m = qlen - (sd & 0xffffu) - 1u; refc = sd >> 16; }
+		});
+}
 BF_INL bool bf_irrelevant(const BfLane& X, uint32_t cost)       /* NBestFirstStrat::irrelevantCost (hit.h:1121-1127) */
 {
 	return X.P->sinkStrata && X.nhits && (cost >> 14) > X.bestStratum;
 }
 
+BF_FN void bf_read_begin(BfLane& X, const BtBatchDev& B, uint32_t rd)
+{
+	X.rd = rd;
+	X.R[0].len = BT_GP(const uint16_t, B.len)[rd];
+	X.R[0].seed = BT_GP(const uint32_t, B.seed)[rd];
+	X.R[0].seq = (BF_G const uint8_t*)(B.seq + (uint64_t)rd * B.stride);
+	X.R[0].qual = (BF_G const uint8_t*)(B.qual + (uint64_t)rd * B.stride);
+	X.R[1] = X.R[0];
+	if (B.seq2) {
+		X.R[1].len = BT_GP(const uint16_t, B.len2)[rd];
+		X.R[1].seed = BT_GP(const uint32_t, B.seed2)[rd];
+		X.R[1].seq = (BF_G const uint8_t*)(B.seq2 + (uint64_t)rd * B.stride2);
+		X.R[1].qual = (BF_G const uint8_t*)(B.qual2 + (uint64_t)rd * B.stride2);
+	}
+	X.top = BF_RESERVED; X.ovf = 0; X.growing = 0;
+	X.nhits = 0; X.stored = 0; X.bestStratum = 999; X.status = 0;
+	X.alRnd = X.R[0].seed;                                      /* Aligner::rand_.init(bufa_->seed) */
+	X.btCnt = (int32_t)X.P->maxBts;
+}
+BF_FN void bf_read_end(BfLane& X, const BtBatchDev& B, uint32_t mult)
+{
+	if (X.ovf) X.status |= BT_STF_OVERFLOW;
+	/* NBestFirstStrat::finishReadImpl (hit.h:1098-1110): every buffered hit's oms = #buffered / mult - 1 */
+	if (X.P->sinkStrata) {
+		for (uint32_t k = 0; k < X.stored; k++)
+			BT_GP(uint32_t, (uint32_t*)(B.hits + ((uint64_t)X.rd * B.hit_cap + k)))[2] = X.stored / mult - 1u;
+	}
+	BT_GP(uint32_t, B.n_hits)[X.rd] = X.nhits;
+	BT_GP(uint8_t, B.status)[X.rd] = (uint8_t)X.status;
+}
+BF_INL void bf_chase_init(BfChase& ch)
+{
+	ch.mirror = 0; ch.qlen = 0; ch.top = ch.bot = ch.irow = ch.row = 0; ch.tidx = BT_OFF_MASK; ch.toff = 0;
+	ch.done = 0; ch.cDone = 1; ch.cRow = ch.cJumps = ch.cOff = 0;
+}
+
 /* ---- one read: UnpairedAlignerV2::setQuery + advance() until done (aligner.h:434-567) ---------- */
 BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 {
-	X.rd = rd;
-	X.len = BT_GP(const uint16_t, B.len)[rd];
-	X.seed = BT_GP(const uint32_t, B.seed)[rd];
-	X.seq = (BF_G const uint8_t*)(B.seq + (uint64_t)rd * B.stride);
-	X.qual = (BF_G const uint8_t*)(B.qual + (uint64_t)rd * B.stride);
-	X.top = BF_RESERVED; X.ovf = 0; X.growing = 0;
-	X.nhits = 0; X.stored = 0; X.bestStratum = 999; X.status = 0;
-	X.alRnd = X.seed;
-	X.btCnt = (int32_t)X.P->maxBts;
-	if (X.len < 4u) {
+	bf_read_begin(X, B, rd);
+	if (X.R[0].len < 4u) {
 		X.status |= BT_STF_SKIPPED;
 	} else {
 		const uint32_t drv = bf_build_tree(X);
 		BfChase ch;
-		ch.mirror = 0; ch.qlen = 0; ch.top = ch.bot = ch.irow = ch.row = 0; ch.tidx = BT_OFF_MASK; ch.toff = 0;
-		ch.done = 0; ch.cDone = 1; ch.cRow = ch.cJumps = ch.cOff = 0;
+		bf_chase_init(ch);
 		bool done = true, chase = false;
 		if (!X.ovf) { cost_set_query<0>(X, drv); done = dr_done(X, drv); }
 		while (!done && !X.ovf) {
 			if (chase) {
 				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
 				if (ch.tidx != BT_OFF_MASK) {
-					done = bf_report(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff);
+					const uint32_t leaf = AW(drv + CA_LAST);
+					done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+					                      !leaf_spec(X, leaf).mirror);
 					ch.tidx = BT_OFF_MASK;
 				} else {
 					chase = false;
@@ -1126,8 +1204,12 @@ BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				if (dr_found(X, drv)) {
 					const uint32_t leaf = AW(drv + CA_LAST);
 					const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
-					ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror);
-					if (ch.tidx != BT_OFF_MASK) { done = bf_report(X, B, leaf, ch.tidx, ch.toff); ch.tidx = BT_OFF_MASK; }
+					ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
+					if (ch.tidx != BT_OFF_MASK) {
+						done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+						                      !leaf_spec(X, leaf).mirror);
+						ch.tidx = BT_OFF_MASK;
+					}
 					if (!ch.done && !bf_irrelevant(X, cost)) chase = true;
 					else dr_set(X, drv, BF_F_FOUND, false);
 				} else {
@@ -1137,15 +1219,181 @@ BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				if (dr_done(X, drv) && !dr_found(X, drv) && !chase) done = true;
 			}
 		}
-		if (X.ovf) X.status |= BT_STF_OVERFLOW;
 	}
-	/* NBestFirstStrat::finishReadImpl (hit.h:1098-1110): every buffered hit's oms = #buffered - 1 */
-	if (X.P->sinkStrata) {
-		for (uint32_t k = 0; k < X.stored; k++)
-			BT_GP(uint32_t, (uint32_t*)(B.hits + ((uint64_t)rd * B.hit_cap + k)))[2] = X.stored - 1u;
+	bf_read_end(X, B, 1u);
+}
+
+/* ---- paired-end -------------------------------------------------------------------------------- */
+BF_INL uint32_t ref_base(const BtRefDev& rf, uint64_t p)        /* 0..3, or 4 for N / gap (BitPairReference::getStretch) */
+{
+	if ((BT_GP(const uint32_t, rf.nmask)[p >> 5] >> (p & 31u)) & 1u) return 4u;
+	return (BT_GP(const uint32_t, rf.bits)[p >> 4] >> (2u * (uint32_t)(p & 15u))) & 3u;
+}
+
+/* RefAligner::find with numToFind = 1 (ref_aligner.h:63-101; specification = the naiveFind of the
+ * concrete aligners, :182-262, 513-601, 2561-2752): candidate leftmost positions radiate out from
+ * the middle of [begin, end - qlen]; the first one that touches no reference N, keeps the seed's
+ * (or, -v, the read's) mismatches within refMms and -- seeded -- the summed penalties within
+ * refQualMax, and has not been reported yet for this pair orientation (TSetPairs), is it.
+ * Its mismatches go to AW(mmBuf ..) as m | refc<<16; returns true and sets the out-parameters. */
+BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t fw, uint32_t begin, uint32_t end,
+                           uint32_t pairsList /* arena words: [0] n, [1] cap, [2] array */, uint32_t aoff, uint32_t mmBuf,
+                           uint32_t* result, uint32_t* nmmOut, uint32_t* stratumOut)
+{
+	const BfProgram& P = *X.P;
+	const BtRefDev& rf = *X.ref;
+	const uint32_t qlen = M.len;
+	const uint32_t slen = P.refSeeded ? (qlen < P.refSeedLen ? qlen : P.refSeedLen) : qlen;
+	const uint64_t base = BT_GP(const uint64_t, rf.start)[tidx];
+	const uint32_t lim = end - qlen - begin, halfway = begin + (lim >> 1);
+	bool hi = false;
+	for (uint32_t i = 1; i <= lim + 1u; i++) {
+		const uint32_t ri = hi ? halfway + (i >> 1) : halfway - (i >> 1);
+		hi = !hi;
+		bool match = true;
+		uint32_t mms = 0, seedMms = 0, ham = 0;
+		for (uint32_t j = 0; j < qlen; j++) {
+			const uint32_t rc = ref_base(rf, base + ri + j);
+			if (rc & 4u) { match = false; break; }
+			const uint32_t q = bf_base(M, fw, 1u, j);               /* patFw / patRc */
+			if (q != rc) {
+				const bool inSeed = fw ? (j < slen) : (j >= qlen - slen);
+				if (inSeed && ++seedMms > P.refMms) { match = false; break; }
+				if (P.refSeeded) {
+					ham += bt_mm_penalty(P.maq, bf_phred(bf_qualc(M, fw, 1u, j)));
+					if (ham > P.refQualMax) { match = false; break; }
+				}
+				AW(mmBuf + mms) = j | (rc << 16); mms++;
+			}
+		}
+		if (!match) continue;
+		/* TSetPairs: (upstream, downstream) coordinates already reported for this orientation */
+		const uint32_t first = ri < aoff ? ri : aoff, second = ri < aoff ? aoff : ri;
+		uint32_t n = AW(pairsList), cap = AW(pairsList + 1u), arr = AW(pairsList + 2u);
+		bool dup = false;
+		for (uint32_t k = 0; k < n && !dup; k++) dup = AW(arr + 3u * k) == tidx && AW(arr + 3u * k + 1u) == first && AW(arr + 3u * k + 2u) == second;
+		if (dup) continue;
+		if (n == cap) {
+			const uint32_t ncap = cap ? cap * 2u : 8u;
+			const uint32_t na = bf_alloc(X, 3u * ncap);
+			if (X.ovf) return false;
+			for (uint32_t k = 0; k < 3u * n; k++) AW(na + k) = AW(arr + k);
+			arr = na; AW(pairsList + 1u) = ncap; AW(pairsList + 2u) = arr;
+		}
+		AW(arr + 3u * n) = tidx; AW(arr + 3u * n + 1u) = first; AW(arr + 3u * n + 2u) = second;
+		AW(pairsList) = n + 1u;
+		*result = ri; *nmmOut = mms; *stratumOut = seedMms;
+		return true;
 	}
-	BT_GP(uint32_t, B.n_hits)[rd] = X.nhits;
-	BT_GP(uint8_t, B.status)[rd] = (uint8_t)X.status;
+	return false;
+}
+
+/* PairedBWAlignerV2::resolveOutstandingInRef + report (aligner.h:1883-1997, 1720-1788): the anchor
+ * mate's range `leaf` resolved to (tidx, toff); look for the other mate in the window the insert
+ * constraints allow and report the pair, upstream mate first.  true = the sink says stop. */
+BF_FN bool bf_resolve_in_ref(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff,
+                             uint32_t pairsFw, uint32_t pairsRc, uint32_t mmBuf)
+{
+	const BfProgram& P = *X.P;
+	const BfSpec& sp = leaf_spec(X, leaf);
+	const bool amate1 = sp.mate == 0, afw = sp.fw != 0;
+	const bool pairFw = amate1 ? (afw == (P.mate1Fw != 0)) : (afw == (P.mate2Fw != 0));
+	const bool matchRight = pairFw ? amate1 : !amate1;
+	bool fw = amate1 ? (P.mate2Fw != 0) : (P.mate1Fw != 0);
+	if (!pairFw) fw = !fw;
+	const BfRead& M = X.R[amate1 ? 1 : 0];                       /* the outstanding mate */
+	const uint32_t qlen = M.len, alen = X.R[sp.mate].len;
+	const uint32_t minins = P.minIns, maxins = P.maxIns;
+	if (maxins <= (qlen > alen ? qlen : alen)) return false;
+	const uint32_t approx = BT_GP(const uint32_t, X.ref->approxLen)[tidx];
+	uint32_t begin, end;
+	if (matchRight) {
+		const uint32_t insDiff = maxins - minins;
+		end = toff + maxins;
+		begin = toff + (P.allowContain ? 0u : 1u);
+		if (!P.allowContain && qlen < alen) begin += alen - qlen;
+		if (end > insDiff + qlen) { const uint32_t b2 = end - insDiff - qlen; if (b2 > begin) begin = b2; }
+		if (approx < end) end = approx;
+		if (approx < begin) begin = approx;
+	} else {
+		begin = (toff + alen < maxins) ? 0u : toff + alen - maxins;
+		const uint32_t mi = alen < qlen ? alen : qlen;
+		if (P.allowContain) end = toff + alen - 1u;
+		else {
+			end = toff + mi - 1u;
+			const uint32_t e2 = toff + alen - minins + qlen - 1u;
+			if (e2 < end) end = e2;
+			if (toff + alen + qlen < minins + 1u) end = 0;
+		}
+	}
+	if (end - begin < qlen || end < begin) return false;
+	uint32_t result = 0, nmm = 0, stratum = 0;
+	if (!bf_ref_find_one(X, tidx, M, fw ? 1u : 0u, begin, end, pairFw ? pairsFw : pairsRc, toff, mmBuf, &result, &nmm, &stratum)) return false;
+	const uint32_t oms = AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u;     /* both mates carry the anchor's range */
+	const uint32_t omate = amate1 ? 1u : 0u;
+	/* the found mate: fw-index coordinates (ebwtFw = true), cost = stratum << 14 (aligner.h:1973) */
+	auto emit_found = [&](uint32_t mateNo) {
+		return bf_emit_hit(X, B, fw ? 1u : 0u, !fw, qlen, stratum << 14, oms, mateNo, nmm, tidx, result,
+			[&](uint32_t i, uint32_t& m, uint32_t& refc) { const uint32_t w = AW(mmBuf + i); m = w & 0xffffu; refc = w >> 16; });
+	};
+	(void)omate;
+	const uint32_t mateL = pairFw ? 1u : 2u, mateR = pairFw ? 2u : 1u;
+	if (matchRight) {
+		if (bf_report_leaf(X, B, leaf, tidx, toff, mateL, oms, !sp.mirror)) return true;
+		return emit_found(mateR);
+	}
+	if (emit_found(mateL)) return true;
+	return bf_report_leaf(X, B, leaf, tidx, toff, mateR, oms, !sp.mirror);
+}
+
+/* PairedBWAlignerV2::setQuery + advance() until done (aligner.h:1571-1701), reportSe off */
+BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
+{
+	bf_read_begin(X, B, rd);
+	if (X.R[0].len < 4u || X.R[1].len < 4u) {
+		X.status |= BT_STF_SKIPPED;
+	} else {
+		const uint32_t drv = bf_build_tree(X);
+		const uint32_t maxLen = X.R[0].len > X.R[1].len ? X.R[0].len : X.R[1].len;
+		const uint32_t pairsFw = bf_alloc(X, 3), pairsRc = bf_alloc(X, 3), mmBuf = bf_alloc(X, maxLen);
+		BfChase ch;
+		bf_chase_init(ch);
+		bool done = true, chase = false;
+		uint32_t attempts = 0;
+		if (!X.ovf) {
+			AW(pairsFw) = AW(pairsFw + 1u) = AW(pairsFw + 2u) = 0; AW(pairsRc) = AW(pairsRc + 1u) = AW(pairsRc + 2u) = 0;
+			cost_set_query<0>(X, drv);
+			done = false;
+		}
+		while (!done && !X.ovf) {
+			if (chase) {
+				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
+				if (ch.tidx != BT_OFF_MASK) {
+					/* resolveOutstanding (aligner.h:1849-1871) */
+					const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, pairsFw, pairsRc, mmBuf);
+					if (++attempts > X.P->pairTries || ret) done = true;
+					ch.tidx = BT_OFF_MASK;
+				} else {
+					chase = false;
+					done = dr_done(X, drv);
+				}
+			}
+			if (!done && !chase) {
+				if (!dr_done(X, drv)) {
+					done = bf_irrelevant(X, dr_mincost(X, drv));
+					if (!done) cost_advance<0>(X, drv);
+					if (dr_found(X, drv)) {
+						chase = true;
+						dr_set(X, drv, BF_F_FOUND, false);
+						const uint32_t leaf = AW(drv + CA_LAST);
+						const BfSpec& sp = leaf_spec(X, leaf);
+						ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
+					}
+				} else done = true;
+			}
+		}
+	}
+	bf_read_end(X, B, 2u);
 }
 
 #undef AW

@@ -4,7 +4,9 @@
  *   bt_best_kernel : one lane = one read, run start to finish by the automaton of bt_best.h; lanes
  *                    pull reads from a global cursor until the batch drains.  Every lane owns an
  *                    arena of `arenaWords` 32-bit words in HBM for the read's branches, heaps and
- *                    driver records.
+ *                    driver records.  With a paired program a "read" is a pair: both mates' drivers
+ *                    compete in one queue and the second mate is found by scanning the 2-bit
+ *                    reference next to the first one's hit (PairedBWAlignerV2, aligner.h:1483-2051).
  *
  * Replaces (reference, CPU): the *Stateful worker loops of ebwt_search.cpp:1223/1509/1955/2609 for
  * unpaired reads (MixedMultiAligner::run + UnpairedAlignerV2, aligner.h:244-360, 381-599).
@@ -18,16 +20,19 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 	__shared__ BfProgram PROG;
 	__shared__ BtIndexDev IX[2];
 	__shared__ BtBatchDev BATCH;
+	__shared__ BtRefDev REF;
 	for (uint32_t i = threadIdx.x; i < sizeof(BfProgram) / 4; i += blockDim.x) ((uint32_t*)&PROG)[i] = ((const uint32_t*)A.prog)[i];
 	for (uint32_t i = threadIdx.x; i < 2 * sizeof(BtIndexDev) / 4; i += blockDim.x) ((uint32_t*)IX)[i] = ((const uint32_t*)A.ix)[i];
 	for (uint32_t i = threadIdx.x; i < sizeof(BtBatchDev) / 4; i += blockDim.x) ((uint32_t*)&BATCH)[i] = ((const uint32_t*)A.batch)[i];
+	if (A.ref) for (uint32_t i = threadIdx.x; i < sizeof(BtRefDev) / 4; i += blockDim.x) ((uint32_t*)&REF)[i] = ((const uint32_t*)A.ref)[i];
 	__syncthreads();
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	BfLane X;
 	__builtin_memset(&X, 0, sizeof(X));
 	X.A = (BF_G uint32_t*)(A.arenas + (uint64_t)g * A.arenaWords);
 	X.cap = A.arenaWords;
-	X.ix = IX; X.P = &PROG;
+	X.ix = IX; X.P = &PROG; X.ref = &REF;
+	const bool paired = PROG.paired != 0;
 	const uint32_t n = BATCH.n_reads;
 	for (;;) {
 		const uint32_t rd = atomicAdd(A.nextRead, 1u);
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 		/* a read that outgrows its arena is searched again by the host through the twin context:
 		 * its partial work is not tallied */
 		const BfLane before = X;
-		bf_run_read(X, BATCH, rd);
+		if (paired) bf_run_pair(X, BATCH, rd); else bf_run_read(X, BATCH, rd);
 		if (X.status & BT_STF_OVERFLOW) {
 			X.c_lfex = before.c_lfex; X.c_lf2 = before.c_lf2; X.c_lf1 = before.c_lf1; X.c_chase = before.c_chase;
 			X.c_ftab = before.c_ftab; X.c_offs = before.c_offs; X.c_rst = before.c_rst; X.c_same = before.c_same;

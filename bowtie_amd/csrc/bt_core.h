@@ -130,6 +130,9 @@ struct BtBatchDev {
 	uint32_t* n_hits; uint8_t* status;
 	uint16_t* mm_pool; uint32_t mm_pool_cap; uint32_t* mm_pool_used;
 	uint32_t* iters;                        /* optional [n_reads]: lock-step rounds the read took       */
+	/* paired-end (bt_align_pairs): the second mates, same layout; NULL otherwise */
+	const uint8_t*  seq2; const uint8_t* qual2; const uint16_t* len2; const uint32_t* seed2;
+	uint32_t stride2, pad2;
 };
 
 /* Arguments split by temperature.  BtHot is passed by value (kernarg -> SGPRs) and holds only what

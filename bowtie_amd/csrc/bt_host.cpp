@@ -237,7 +237,61 @@ struct TreeBuilder {
 };
 }
 
-int bt_host_compile_best(const bt_policy& pol, BfProgram* prog)
+/* the drivers of one (mate, strand) block, in the order the factories push them.  `paired` selects
+ * the Paired*AlignerFactory variants, which differ from the unpaired ones in two places: the
+ * nudgeLeft flags of -v 1 (aligner_1mm.h:295-408) and rev1Off of the -v 3 half-and-half driver
+ * (aligner_23mm.h:403-411, 469-477, 534-542, 598-606). */
+static bool add_block(TreeBuilder& T, const bt_policy& pol, bool fw, int mate, bool paired)
+{
+	const uint32_t INF = 0xffffffffu;
+	const int B = BF_PIN_BEGIN, L = BF_PIN_LEN, H = BF_PIN_HI_HALF, S = BF_PIN_SEED;
+	bool ok = true;
+	/* fw read: mirror index first; rc read: text index first */
+	const bool m1 = fw, m2 = !fw;
+	auto spec = [&](bool mirror, uint32_t qualLim, bool exact, int hh, bool partial, bool seed, uint32_t sl, bool nudge,
+	                int r0, int r1, int r2, int r3, bool bc) {
+		const int id = T.add_spec(mirror, fw, qualLim, exact, hh, partial, seed, sl, nudge, r0, r1, r2, r3, bc);
+		if (id >= 0) T.P.specs[id].mate = (uint8_t)mate;
+		return id;
+	};
+	if (pol.mode == BT_MODE_V) {
+		if (pol.mms == 0) {
+			ok = ok && T.leaf(spec(false, INF, true, 0, false, false, 0, true, L, L, L, L, false));
+		} else if (pol.mms == 1) {
+			ok = ok && T.leaf(spec(m1, INF, true, 0, false, false, 0, paired ? true : !m1, H, L, L, L, false));
+			ok = ok && T.leaf(spec(m2, INF, false, 0, false, false, 0, paired ? false : !m2, H, L, L, L, false));
+		} else {
+			const bool two = pol.mms == 2;
+			const int r2 = two ? L : H;
+			ok = ok && T.leaf(spec(m1, INF, true, 0, false, false, 0, true, H, H, r2, L, false));
+			ok = ok && T.leaf(spec(m2, INF, false, 0, false, false, 0, false, H, H, r2, L, false));
+			ok = ok && T.leaf(spec(m1, INF, false, 2, false, false, 0, true, B, H, r2, L, false));
+			if (!two) ok = ok && T.leaf(spec(m2, INF, false, 3, false, false, 0, false, B, (paired && !(mate == 0 && !fw)) ? B : H, H, L, false));
+		}
+	} else {
+		const uint32_t q = (uint32_t)pol.qual_thresh, sl = (uint32_t)pol.seed_len;
+		const int n = pol.mms;
+		const bool bc = n >= 2;          /* the backtrack budget only exists for -n 2/3 (aligner_seed_mm.h:99,134) */
+		if (n == 0) {
+			ok = ok && T.leaf(spec(m1, q, true, 0, false, false, sl, true, S, S, S, S, false));
+		} else {
+			const int a1 = n >= 2 ? H : S, a2 = n >= 3 ? H : S;
+			ok = ok && T.leaf(spec(m1, q, true, 0, false, false, sl, true, H, a1, a2, S, bc));
+			{
+				const int f = spec(m1, q, true, 0, false, false, sl, true, S, S, S, S, bc);
+				ok = ok && T.seeded(f, spec(m2, q, false, 0, true, true, sl, false, H, a1, a2, S, bc), fw);
+			}
+			if (n >= 3) {
+				const int f = spec(m1, q, true, 0, false, false, sl, true, S, S, S, S, bc);
+				ok = ok && T.seeded(f, spec(m2, q, false, 3, true, true, sl, false, B, H, H, S, bc), fw);
+			}
+			if (n >= 2) ok = ok && T.leaf(spec(m1, q, false, 2, false, false, sl, true, B, H, a2, S, bc));
+		}
+	}
+	return ok;
+}
+
+static int compile_best(const bt_policy& pol, bool paired, BfProgram* prog)
 {
 	BfProgram& P = *prog;
 	memset(&P, 0, sizeof(P));
@@ -245,76 +299,106 @@ int bt_host_compile_best(const bt_policy& pol, BfProgram* prog)
 	if (pol.mode != BT_MODE_V && pol.mode != BT_MODE_N) return BT_ERR_ARG;
 	if (pol.mode == BT_MODE_N && pol.seed_len < 5) return BT_ERR_ARG;
 	const uint32_t INF = 0xffffffffu;
+	const uint32_t mult = paired ? 2u : 1u;       /* createMult(2): mates count separately (hit.h:1012-1016, 1155-1159, 1246-1249) */
 	P.maq = pol.maq_round ? 1u : 0u;
 	P.maxBts = (uint32_t)pol.max_bts;
 	P.strandFix = 1;                                   /* ebwt_search.cpp:227 */
+	P.btCntOn = (pol.mode == BT_MODE_N && pol.mms >= 2) ? 1u : 0u;
 	/* createSinkFactory (ebwt_search.cpp:992-1020) */
 	P.sinkStrata = pol.strata ? 1u : 0u;
 	P.sinkAll = pol.all_hits ? 1u : 0u;
-	P.sinkN = pol.all_hits ? (pol.strata ? INF / 2u : INF) : pol.khits;
-	P.sinkMax = pol.mhits;
+	P.sinkN = pol.all_hits ? (pol.strata ? (INF / 2u) * mult : INF) : pol.khits * mult;
+	P.sinkMax = pol.mhits == INF ? INF : pol.mhits * mult;
 	P.sampleMax = pol.sample_max ? 1u : 0u;
 	if (P.sinkN == 0) return BT_ERR_ARG;
-	const bool doFw = !pol.nofw, doRc = !pol.norc;
-	const int B = BF_PIN_BEGIN, L = BF_PIN_LEN, H = BF_PIN_HI_HALF, S = BF_PIN_SEED;
 	TreeBuilder T{P};
 	bool ok = true;
-	/* leaf(mirror, fw, qualLim, reportExacts, halfAndHalf, partial, seed, seedLen, nudgeLeft, rev0..3, btCnt) */
-#define LEAF(...) ok = ok && T.leaf(T.add_spec(__VA_ARGS__))
-	if (pol.mode == BT_MODE_V) {
-		if (pol.mms == 0) {
-			if (doFw) LEAF(false, true, INF, true, 0, false, false, 0, true, L, L, L, L, false);
-			if (doRc) LEAF(false, false, INF, true, 0, false, false, 0, true, L, L, L, L, false);
-		} else if (pol.mms == 1) {
-			if (doFw) {
-				LEAF(true, true, INF, true, 0, false, false, 0, false, H, L, L, L, false);
-				LEAF(false, true, INF, false, 0, false, false, 0, true, H, L, L, L, false);
-			}
-			if (doRc) {
-				LEAF(false, false, INF, true, 0, false, false, 0, true, H, L, L, L, false);
-				LEAF(true, false, INF, false, 0, false, false, 0, false, H, L, L, L, false);
-			}
-		} else {
-			const bool two = pol.mms == 2;
-			const int r2 = two ? L : H;
-			if (doFw) {
-				LEAF(true, true, INF, true, 0, false, false, 0, true, H, H, r2, L, false);
-				LEAF(false, true, INF, false, 0, false, false, 0, false, H, H, r2, L, false);
-				LEAF(true, true, INF, false, 2, false, false, 0, true, B, H, r2, L, false);
-				if (!two) LEAF(false, true, INF, false, 3, false, false, 0, false, B, H, H, L, false);
-			}
-			if (doRc) {
-				LEAF(false, false, INF, true, 0, false, false, 0, true, H, H, r2, L, false);
-				LEAF(true, false, INF, false, 0, false, false, 0, false, H, H, r2, L, false);
-				LEAF(false, false, INF, false, 2, false, false, 0, true, B, H, r2, L, false);
-				if (!two) LEAF(true, false, INF, false, 3, false, false, 0, false, B, H, H, L, false);
-			}
-		}
+	if (!paired) {
+		if (!pol.nofw) ok = ok && add_block(T, pol, true, 0, false);
+		if (!pol.norc) ok = ok && add_block(T, pol, false, 0, false);
 	} else {
-		const uint32_t q = (uint32_t)pol.qual_thresh, sl = (uint32_t)pol.seed_len;
-		const int n = pol.mms;
-		const bool bc = n >= 2;                      /* the backtrack budget only exists for -n 2/3 (aligner_seed_mm.h:99,134) */
-		P.btCntOn = bc ? 1u : 0u;
-		/* the extender factory of a seeded pair: all of the seed unrevisitable, exact hits allowed */
-#define FACT(mirror, fw) T.add_spec(mirror, fw, q, true, 0, false, false, sl, true, S, S, S, S, bc)
-		if (n == 0) {
-			if (doFw) LEAF(true, true, q, true, 0, false, false, sl, true, S, S, S, S, false);
-			if (doRc) LEAF(false, false, q, true, 0, false, false, sl, true, S, S, S, S, false);
-		} else {
-			const int a1 = n >= 2 ? H : S, a2 = n >= 3 ? H : S;        /* rev1, rev2 of the lo-half searchers */
-			for (int pass = 0; pass < 2; pass++) {
-				const bool fw = pass == 0;
-				if (fw ? !doFw : !doRc) continue;
-				/* fw read: exact-in-hi-half searcher on the mirror index, generator on the text index; rc: the other way round */
-				const bool m1 = fw, m2 = !fw;
-				LEAF(m1, fw, q, true, 0, false, false, sl, true, H, a1, a2, S, bc);
-				{ const int f = FACT(m1, fw); ok = ok && T.seeded(f, T.add_spec(m2, fw, q, false, 0, true, true, sl, false, H, a1, a2, S, bc), fw); }
-				if (n >= 3) { const int f = FACT(m1, fw); ok = ok && T.seeded(f, T.add_spec(m2, fw, q, false, 3, true, true, sl, false, B, H, H, S, bc), fw); }
-				if (n >= 2) LEAF(m1, fw, q, false, 2, false, false, sl, true, B, H, a2, S, bc);
-			}
+		/* Paired*AlignerFactory::create() with v1_ == false: -v: 1Fw 1Rc 2Fw 2Rc (aligner_0mm.h:320-327,
+		 * aligner_1mm.h:286-415, aligner_23mm.h:358-606); -n: 1Fw 2Fw 1Rc 2Rc (aligner_seed_mm.h:705-1290) */
+		if (pol.max_ins < 0 || pol.min_ins < 0 || pol.pair_tries < 0) return BT_ERR_ARG;
+		if (pol.sample_max) return BT_ERR_ARG;     /* -M sampling of pairs (hit.cpp:27-55) is not built */
+		bool d1f = true, d1r = true, d2f = true, d2r = true;
+		if (pol.nofw) { if (pol.mate1_fw) d1f = false; else d1r = false; if (pol.mate2_fw) d2f = false; else d2r = false; }
+		if (pol.norc) { if (pol.mate1_fw) d1r = false; else d1f = false; if (pol.mate2_fw) d2r = false; else d2f = false; }
+		const int ov[4][2] = {{0, 1}, {0, 0}, {1, 1}, {1, 0}}, on[4][2] = {{0, 1}, {1, 1}, {0, 0}, {1, 0}};
+		for (int k = 0; k < 4; k++) {
+			const int mate = pol.mode == BT_MODE_V ? ov[k][0] : on[k][0];
+			const bool fw = (pol.mode == BT_MODE_V ? ov[k][1] : on[k][1]) != 0;
+			const bool doit = mate == 0 ? (fw ? d1f : d1r) : (fw ? d2f : d2r);
+			if (doit) ok = ok && add_block(T, pol, fw, mate, true);
 		}
-#undef FACT
+		P.paired = 1; P.minIns = (uint32_t)pol.min_ins; P.maxIns = (uint32_t)pol.max_ins;
+		P.mate1Fw = pol.mate1_fw ? 1u : 0u; P.mate2Fw = pol.mate2_fw ? 1u : 0u;
+		P.pairTries = (uint32_t)pol.pair_tries; P.allowContain = pol.allow_contain ? 1u : 0u;
+		/* Exact/OneMM/TwoMM/ThreeMMRefAligner for -v, Seed{0..3}RefAligner(seedLen, qualCutoff) for -n
+		 * (aligner_0mm.h:303, aligner_1mm.h:417, aligner_23mm.h:608-612, aligner_seed_mm.h:668-676) */
+		P.refSeeded = pol.mode == BT_MODE_N ? 1u : 0u; P.refMms = (uint32_t)pol.mms;
+		P.refSeedLen = (uint32_t)pol.seed_len; P.refQualMax = pol.mode == BT_MODE_N ? (uint32_t)pol.qual_thresh : INF;
 	}
-#undef LEAF
 	return ok ? BT_OK : BT_ERR_ARG;
+}
+
+int bt_host_compile_best(const bt_policy& pol, BfProgram* prog) { return compile_best(pol, false, prog); }
+int bt_host_compile_best_paired(const bt_policy& pol, BfProgram* prog) { return compile_best(pol, true, prog); }
+
+/* ---- the 2-bit reference ------------------------------------------------------------------------
+ * <base>.3.ebwt: u32 1, u32 nRecords, then per unambiguous stretch { u32 off (Ns before it), u32 len,
+ * u8 first (1 = first stretch of a sequence) }; <base>.4.ebwt: the bases of all stretches, 4 per byte,
+ * first base in the low bits (reference.h:35-240, ref_read.h:57-87).  A sequence whose first record
+ * has len 0 is all gaps and has no index in the Ebwt (reference.h:160-176). */
+int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost* out)
+{
+	File f3(base + ".3.ebwt");
+	if (!f3.f) return BT_ERR_IO;
+	uint32_t one = 0, nrec = 0;
+	if (!f3.rd(&one, 4) || !f3.rd(&nrec, 4)) return BT_ERR_IO;
+	if (one != 1 || nrec == 0 || nrec > (1u << 28)) return BT_ERR_FORMAT;
+	struct Rec { uint32_t off, len; uint8_t first; };
+	std::vector<Rec> recs(nrec);
+	uint64_t cum = 0;
+	for (uint32_t i = 0; i < nrec; i++) {
+		if (!f3.rd(&recs[i].off, 4) || !f3.rd(&recs[i].len, 4) || !f3.rd(&recs[i].first, 1)) return BT_ERR_IO;
+		cum += recs[i].len;
+	}
+	std::vector<uint8_t> packed((cum + 3) / 4);
+	{
+		File f4(base + ".4.ebwt");
+		if (!f4.f) return BT_ERR_IO;
+		if (!f4.rd(packed.data(), packed.size())) return BT_ERR_IO;
+	}
+	BtRefHost& R = *out;
+	R = BtRefHost();
+	const uint32_t nRefs = idx.nPat;
+	R.start.resize(nRefs); R.approxLen.assign(nRefs, 0);
+	uint64_t total = 0;
+	for (uint32_t t = 0; t < nRefs; t++) { R.start[t] = total; total += ((uint64_t)idx.plen[t] + 63u) & ~63ull; }
+	R.bits.assign((size_t)(total / 16u) + 4u, 0u);
+	R.nmask.assign((size_t)(total / 32u) + 4u, 0xffffffffu);
+	int64_t t = -1; bool live = false; uint64_t pos = 0, src = 0;
+	for (uint32_t i = 0; i < nrec; i++) {
+		const Rec& r = recs[i];
+		if (r.first) {
+			live = r.len > 0;
+			if (live) { t++; pos = 0; if ((uint64_t)t >= nRefs) return BT_ERR_FORMAT; }
+		}
+		if (r.len == 0) continue;
+		if (!live) { src += r.len; continue; }
+		pos += r.off;
+		if (pos + r.len > idx.plen[(size_t)t]) return BT_ERR_FORMAT;
+		const uint64_t g0 = R.start[(size_t)t] + pos;
+		for (uint32_t k = 0; k < r.len; k++, src++) {
+			const uint32_t c = (packed[(size_t)(src >> 2)] >> (2u * (uint32_t)(src & 3u))) & 3u;
+			const uint64_t g = g0 + k;
+			R.bits[(size_t)(g >> 4)] |= c << (2u * (uint32_t)(g & 15u));
+			R.nmask[(size_t)(g >> 5)] &= ~(1u << (uint32_t)(g & 31u));
+		}
+		pos += r.len;
+		R.approxLen[(size_t)t] = (uint32_t)pos;
+	}
+	if ((uint64_t)(t + 1) != nRefs) return BT_ERR_FORMAT;
+	return BT_OK;
 }

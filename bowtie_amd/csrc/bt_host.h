@@ -45,5 +45,16 @@ int bt_host_compile_program(const bt_policy& pol, BtProgram* prog);
 /* The same for the stateful best-first workers (pol.best): the driver tree of
  * Unpaired{Exact,1mm,23mm,Seed}AlignerFactory::create() as a BfProgram (bt_best.h). */
 int bt_host_compile_best(const bt_policy& pol, BfProgram* prog);
+/* ... and of Paired*AlignerFactory::create() with --best (PairedBWAlignerV2): both mates' drivers in
+ * one cost-aware driver, doubled sink limits, the RefAligner parameters. */
+int bt_host_compile_best_paired(const bt_policy& pol, BfProgram* prog);
+
+/* The 2-bit reference of <base>.3.ebwt / .4.ebwt (BitPairReference, reference.h:35-120) unpacked into
+ * the position space BtRefDev describes.  Returns BT_OK or BT_ERR_IO / BT_ERR_FORMAT. */
+struct BtRefHost {
+	std::vector<uint32_t> bits, nmask, approxLen;
+	std::vector<uint64_t> start;
+};
+int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost* out);
 
 #endif

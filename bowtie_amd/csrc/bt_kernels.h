@@ -40,6 +40,7 @@ struct BtBestArgs {
 	const BfProgram*  prog;      /* device memory */
 	const BtIndexDev* ix;        /* [2] */
 	const BtBatchDev* batch;
+	const BtRefDev*   ref;       /* paired-end: the 2-bit reference (device memory); NULL otherwise */
 	uint32_t*  arenas;           /* [nLanes][arenaWords] */
 	uint32_t   arenaWords;
 	uint32_t*  nextRead;

@@ -103,7 +103,7 @@ typedef struct bt_hit {
 	uint16_t nmm;             /* # mismatches                                                 */
 	uint8_t  stratum;         /* Hit::stratum                                                 */
 	uint8_t  fw;              /* Hit::fw                                                      */
-	uint8_t  pad[2];
+	uint8_t  pad[2];          /* pad[0] = Hit::mate: 0 unpaired, 1 / 2 mate of a paired alignment */
 } bt_hit;                         /* 24 bytes */
 
 /* mm_pool entry: bits 0-9 = offset from the read's 5' end (Hit::mms), bits 12-13 = reference
@@ -186,6 +186,18 @@ void bt_ctx_destroy(bt_ctx* ctx);
  *                            (optional, device pointer to bt_op_counts) is accumulated into. */
 int  bt_align_batch(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, bt_op_counts* counts);
 int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out,
+                           bt_op_counts* counts_dev);
+/* Paired-end (-1/-2 with --best).  Replaces: BitPairReference's constructor (reference.h:35-240) --
+ * <base>.3.ebwt / .4.ebwt into HBM -- and, per batch of pairs, PairedBWAlignerV2::setQuery/advance
+ * (aligner.h:1571-1701) with RefAligner::find (ref_aligner.h:63-101) for the second mate.  The ctx
+ * must have been created with pol.best; the pair options are pol.min_ins .. pol.allow_contain.
+ * in1/in2: mates 1 and 2, same n_reads.  out: hit_cap slots per *pair* (even): the alignments of a
+ * pair are adjacent, upstream mate first, bt_hit.pad[0] = 1 or 2 says which mate a record is; n_hits
+ * counts mate alignments (two per reported pair), as the reference's sink does. */
+int  bt_index_load_reference(bt_index* idx);
+int  bt_align_pairs(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
+                    bt_op_counts* counts);
+int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
                            bt_op_counts* counts_dev);
 int  bt_ctx_sync(bt_ctx* ctx);
 /* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */

@@ -1560,7 +1560,7 @@ int bto_align_pair_best(const bto_index* ixFw, const bto_index* ixBw, const bto_
 								if (toff + alen + qlen < (uint32_t)minins + 1) end = 0;
 							}
 						}
-						if (end - begin >= qlen) {          /* unsigned, as in the reference (aligner.h:1964) */
+						if (end >= begin && end - begin >= qlen) {   /* aligner.h:1964 */
 							uint32_t result = 0;
 							if (ref_find_one(pol, refs->seq[tidx], oseq, oqual, qlen, tidx, begin, end, fw,
 							                 pairFw ? &pairs_fw : &pairs_rc, toff, found, &result)) {

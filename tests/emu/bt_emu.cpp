@@ -12,7 +12,7 @@
 #include <vector>
 #include "../../bowtie_amd/csrc/bt_host.h"
 
-struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; bool mirror; };
+struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
 
 static void bind(EmuIndex* e, int m)
 {
@@ -25,6 +25,7 @@ extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
 {
 	EmuIndex* e = new EmuIndex();
 	e->mirror = need_mirror != 0;
+	e->base = base;
 	if (bt_host_index_load(base, true, offrate, &e->h[0]) != BT_OK) { delete e; return nullptr; }
 	e->h[0].ebwt.resize(e->h[0].ebwt.size() + 128); e->h[0].ftab.resize(e->h[0].ftab.size() + 4); e->h[0].offs.resize(e->h[0].offs.size() + 4);
 	bind(e, 0);
@@ -172,6 +173,46 @@ static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, 
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
 	for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
+	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
+	if (counts) {
+		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
+		counts->ftab = X.c_ftab; counts->offs = X.c_offs; counts->rstarts = X.c_rst; counts->same_pair = X.c_same;
+		counts->frames = X.c_frames;
+	}
+	return BT_OK;
+}
+
+/* Paired-end through the best-first engine (bf_run_pair).  Hits come in pairs (upstream mate, downstream
+ * mate) in the hit_cap slots of each pair. */
+extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batch* in1, const bt_read_batch* in2,
+                               bt_hit_batch* out, bt_op_counts* counts, uint32_t arenaWords)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	if (in1->n_reads != in2->n_reads) return BT_ERR_ARG;
+	BfProgram P;
+	int rc = bt_host_compile_best_paired(*pol, &P);
+	if (rc != BT_OK) return rc;
+	if (P.needMirror && !e->mirror) return BT_ERR_ARG;
+	if (!e->haveRef) {
+		rc = bt_host_ref_load(e->base, e->h[0], &e->ref);
+		if (rc != BT_OK) return rc;
+		e->refd.bits = e->ref.bits.data(); e->refd.nmask = e->ref.nmask.data(); e->refd.start = e->ref.start.data();
+		e->refd.approxLen = e->ref.approxLen.data(); e->refd.nRefs = (uint32_t)e->ref.start.size(); e->refd.pad = 0;
+		e->haveRef = true;
+	}
+	BtBatchDev B;
+	memset(&B, 0, sizeof(B));
+	B.seq = in1->seq; B.qual = in1->qual; B.len = in1->len; B.seed = in1->seed; B.n_reads = in1->n_reads; B.stride = in1->stride;
+	B.seq2 = in2->seq; B.qual2 = in2->qual; B.len2 = in2->len; B.seed2 = in2->seed; B.stride2 = in2->stride;
+	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
+	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
+	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
+	if (arenaWords < 256u) arenaWords = 1u << 22;
+	std::vector<uint32_t> arena(arenaWords);
+	BfLane X;
+	memset(&X, 0, sizeof(X));
+	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
+	for (uint32_t rd = 0; rd < in1->n_reads; rd++) bf_run_pair(X, B, rd);
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;

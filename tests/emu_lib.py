@@ -38,6 +38,8 @@ def lib():
         L.emu_rank4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
                                       C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 5
+        L.emu_align_pairs.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC), C.POINTER(A.ReadBatchC),
+                                      C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts), C.c_uint32]
         _lib = L
     return _lib
 
@@ -77,3 +79,21 @@ class EmuAligner:
             raise RuntimeError("emu_align_batch rc=%d" % rc)
         return unpack_hits(n, hit_cap, hits, n_hits, status, pool, int(pol.khits), int(pol.mhits),
                            bool(pol.all_hits), sample_max=bool(pol.sample_max))
+
+    def align_pairs(self, pol: A.Policy, b1: ReadBatch, b2: ReadBatch, hit_cap=None, mm_per_hit=8, counts=None, arena_words=0):
+        """-> per pair (hits: upstream mate, downstream mate, ..., hitsForThisRead, status)"""
+        from bowtie_amd.aligner import pack_batch, unpack_pair_hits
+        n = b1.n
+        hit_cap = hit_cap or (128 if pol.all_hits else max(2, min(2 * int(pol.khits), 128)))
+        k1, rb1 = pack_batch(b1)
+        k2, rb2 = pack_batch(b2)
+        hits = np.zeros(n * hit_cap, dtype=A.HIT_DTYPE)
+        n_hits = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint8)
+        pool = np.zeros(max(1, n * hit_cap * mm_per_hit), dtype=np.uint16)
+        hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, pool.ctypes.data, len(pool), 0)
+        rc = lib().emu_align_pairs(self.h, C.byref(pol), C.byref(rb1), C.byref(rb2), C.byref(hb),
+                                   C.byref(counts) if counts is not None else None, arena_words)
+        if rc != 0:
+            raise RuntimeError("emu_align_pairs rc=%d" % rc)
+        return unpack_pair_hits(n, hit_cap, hits, n_hits, status, pool, pol)

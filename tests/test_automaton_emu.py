@@ -194,3 +194,26 @@ def test_emu_best_first_max_length_reads(emu):
     for mode in ("v2_best", "n2_best", "v3"):
         kw = T.MODES[mode]
         T.compare_results(e.align(A.make_policy(**kw), batch), T.oracle_results("e_coli", batch, kw), mode)
+
+
+@pytest.mark.parametrize("run", T.paired_runs(), ids=lambda r: r["file"][:-7])
+def test_emu_paired_matches_reference_sam(run, emu):
+    """Paired-end (bf_run_pair: PairedBWAlignerV2 + reference window scan on the 2-bit reference loaded
+    from .3/.4.ebwt) on the host build of the device code."""
+    b1, b2 = T.pair_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = emu[run["index"]].align_pairs(A.make_policy(**kw), b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    T.check_pairs_against_golden(run, res, b1, b2, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500"])
+def test_emu_paired_vs_oracle_counts(mode, emu):
+    kw = T.MODES[mode]
+    b1, b2 = T.pair_set("multi", "pe50")
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    cap = 2048 if kw.get("all_hits") else None
+    want = T.oracle_pair_results("multi", b1, b2, kw, cap=cap, counts=oc)
+    got = emu["multi"].align_pairs(A.make_policy(**kw), b1, b2, hit_cap=cap, counts=ec)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(ec, f), f

@@ -295,3 +295,44 @@ def test_gpu_best_first_large_batch_properties(gidx):
     pb = ReadBatch(sub.seq[perm], sub.qual[perm], sub.len[perm], sub.seed[perm], [sub.names[i] for i in perm])
     rp = al.align(pb)
     T.compare_results(rp, [want[i] for i in perm], "permuted")
+
+
+# ---- paired-end (bt_align_pairs: PairedBWAlignerV2 + reference window scan) -------------------------
+@pytest.mark.parametrize("run", T.paired_runs(), ids=lambda r: r["file"][:-7])
+def test_gpu_paired_matches_reference_sam(run, gidx):
+    b1, b2 = T.pair_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    al = aligner(gidx, run["index"], kw)
+    res = al.align_pairs(b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    T.check_pairs_against_golden(run, res, b1, b2, gidx[run["index"]].refnames)
+
+
+@pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500"])
+def test_gpu_paired_vs_oracle_counts(mode, gidx):
+    import oracle_lib as OL
+    kw = T.MODES[mode]
+    b1, b2 = T.pair_set("multi", "pe50")
+    oc, gc = OL.OpCounts(), A.OpCounts()
+    cap = 2048 if kw.get("all_hits") else None
+    want = T.oracle_pair_results("multi", b1, b2, kw, cap=cap, counts=oc)
+    got = aligner(gidx, "multi", kw).align_pairs(b1, b2, hit_cap=cap, counts=gc)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(gc, f), f
+
+
+def test_gpu_paired_config5_shape(gidx):
+    """BASELINE config 5's shape on e_coli: 2 x 50 bp pairs, -n 1 --best -X 500: a 20 k-pair sample
+    against the oracle, idempotence."""
+    from bowtie_amd.synth import synth_pairs
+    kw = T.MODES["pe_n1_best_X500"]
+    b1, b2 = synth_pairs(T.joined_text("e_coli"), 20000, 50, seed=5050)
+    al = aligner(gidx, "e_coli", kw)
+    r1 = al.align_pairs(b1, b2)
+    assert T.result_digest(r1) == T.result_digest(al.align_pairs(b1, b2))
+    from bowtie_amd.reads import ReadBatch
+    idx = np.arange(0, 20000, 13)
+    s1 = ReadBatch(b1.seq[idx], b1.qual[idx], b1.len[idx], b1.seed[idx], [b1.names[i] for i in idx])
+    s2 = ReadBatch(b2.seq[idx], b2.qual[idx], b2.len[idx], b2.seed[idx], [b2.names[i] for i in idx])
+    T.compare_results([r1[i] for i in idx], T.oracle_pair_results("e_coli", s1, s2, kw), "config-5 shape")
+    assert sum(1 for h, _, _ in r1 if h) > 15000
