@@ -35,7 +35,7 @@ import torch         # noqa: E402
 
 from bowtie_amd import _abi as A            # noqa: E402
 from bowtie_amd import aligner as AL        # noqa: E402
-from bowtie_amd.synth import synth_reads_torch  # noqa: E402
+from bowtie_amd.synth import synth_reads_torch, synth_pairs_torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # HBM-side bytes per read of bt_search_kernel, measured with rocprofv3 PMC (separate --pmc FETCH_SIZE and
@@ -57,6 +57,12 @@ WORKLOADS = {
     # the best-first engine (--best): bt_best_kernel
     "ecoli_n2_best_100": dict(index="ecoli", length=100, pol=dict(mode="n", mms=2, best=True), mm_dist=(0, 1, 2, 2, 3, 4), reads=2_000_000),
     "big_n2_best_100": dict(index="big", length=100, pol=dict(mode="n", mms=2, best=True), mm_dist=(0, 1, 2, 2, 3, 4), reads=32_000_000),
+    # paired-end (BASELINE config 5): 2 x 50 bp, -n 1 --best -X 500; `reads` = pairs per GPU per step
+    # (config 5 = 100 M pairs over 8 GPUs = 12.5 M per GPU)
+    "ecoli_pe_n1_best_50": dict(index="ecoli", length=50, paired=True, pol=dict(mode="n", mms=1, best=True, max_ins=500),
+                                mm_dist=(0, 0, 1, 1, 2), reads=1_000_000),
+    "big_pe_n1_best_50": dict(index="big", length=50, paired=True, pol=dict(mode="n", mms=1, best=True, max_ins=500),
+                              mm_dist=(0, 0, 1, 1, 2), reads=12_500_000),
 }
 
 
@@ -83,6 +89,9 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
     args = ["-v", str(pol["mms"])] if pol["mode"] == "v" else ["-n", str(pol["mms"]), "-l", "28", "-e", "70"]
     if pol.get("best"):
         args.append("--best")
+    paired = bool(wl.get("paired"))
+    if paired:
+        args += ["-X", str(pol.get("max_ins", 250))]
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
     cores = os.cpu_count() or 1
     if os.path.exists(ref_bin):
@@ -92,12 +101,20 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
         with tempfile.TemporaryDirectory() as td:
             n = 200_000
             for attempt in range(2):
-                batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
                 fq = os.path.join(td, "s.fq")
-                write_fastq(batch, fq)
+                if paired:
+                    from bowtie_amd.synth import synth_pairs
+                    n = min(n, 400_000)                     # the numpy pair generator is a python loop
+                    b1, b2 = synth_pairs(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
+                    write_fastq(b1, fq + ".1"); write_fastq(b2, fq + ".2")
+                    inputs = ["-1", fq + ".1", "-2", fq + ".2"]
+                else:
+                    batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
+                    write_fastq(batch, fq)
+                    inputs = [fq]
                 t0 = time.perf_counter()
                 p = subprocess.run([ref_bin, "--wrapper", "basic-0", "-p", str(cores)] + args +
-                                   ["-x", base, fq, os.devnull], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                                   ["-x", base] + inputs + [os.devnull], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 wall = time.perf_counter() - t0
                 if p.returncode != 0:
                     break
@@ -170,10 +187,15 @@ def main():
 
     # ---- reads: synthetic, generated straight into HBM, sharded by rank -------------------------
     t0 = time.perf_counter()
-    rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
+    paired = bool(wl.get("paired"))
+    rb2 = None
+    if paired:
+        rb, rb2 = synth_pairs_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
+    else:
+        rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
     if not args.verify:
         del text_t
-    hit_cap = 1
+    hit_cap = 2 if paired else 1
     mm_cap = n * 8
     pol = A.make_policy(**wl["pol"])
     lib = AL.lib()
@@ -197,6 +219,12 @@ def main():
     log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
     rbc = A.ReadBatchC(n, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(),
                        rb["seed"].data_ptr())
+    rbc2 = None
+    if paired:
+        rbc2 = A.ReadBatchC(n, rb2["stride"], rb2["seq"].data_ptr(), rb2["qual"].data_ptr(), rb2["len"].data_ptr(),
+                            rb2["seed"].data_ptr())
+        if lib.bt_index_load_reference(idx._h) != 0:
+            raise RuntimeError("bt_index_load_reference failed")
     n_hits, status = pipes[0]["n_hits"], pipes[0]["status"]
     iters_t = None
     if args.iters_hist:
@@ -214,7 +242,10 @@ def main():
     def step(k):
         o = pipes[k % len(pipes)]
         retire(o)
-        rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(o["hbc"]), None)
+        if paired:
+            rc = lib.bt_align_pairs_device(o["al"]._h, C.byref(rbc), C.byref(rbc2), C.byref(o["hbc"]), None)
+        else:
+            rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(o["hbc"]), None)
         if rc != 0:
             raise RuntimeError("bt_align_batch_device: " + AL.strerror(rc))
         o["busy"] = True
@@ -275,15 +306,17 @@ def main():
     if rank == 0:
         per_launch = {k: v / max(1, args.steps) for k, v in c.items()}
         kavg = sum(kernel_ms) / len(kernel_ms)
-        abytes = algorithmic_bytes(per_launch, n, L, aligned)
+        abytes = algorithmic_bytes(per_launch, n * (2 if paired else 1), L, aligned * (2 if paired else 1))
         achieved = abytes / (kavg * 1e-3) / 1e9
         out = {
-            "metric": "aligned reads/sec (whole node)", "value": reads_all * args.steps / wall,
+            "metric": "aligned reads/sec (whole node)", "value": reads_all * (2 if paired else 1) * args.steps / wall,
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": args.workload, "index": index_note, "read_len": L,
-                       "policy": wl["pol"], "reads_per_gpu_per_step": n,
+                       "policy": wl["pol"], "reads_per_gpu_per_step": n * (2 if paired else 1),
+                       "value_counts": "reads processed, aligned or not (a pair = 2 reads)",
+                       "pairs_per_gpu_per_step": n if paired else None,
                        "reads_with_alignment_per_s": aligned_all * args.steps / wall,
                        "pct_aligned": 100.0 * aligned_all / reads_all, "reads_overflowed": bad_all,
                        "pipelined_contexts": len(pipes),

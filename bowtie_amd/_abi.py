@@ -67,7 +67,7 @@ class OutOpts(C.Structure):
 
 class OutTally(C.Structure):
     _fields_ = [("aligned", C.c_uint64), ("unaligned", C.c_uint64), ("maxed", C.c_uint64), ("reported", C.c_uint64),
-                ("sample_max", C.c_uint64)]
+                ("sample_max", C.c_uint64), ("reported_paired", C.c_uint64)]
 
 
 HIT_DTYPE = [("tidx", "<u4"), ("toff", "<u4"), ("oms", "<u4"), ("mm_off", "<u4"), ("cost", "<u2"),

@@ -23,7 +23,7 @@ EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_
            "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
            "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_mm_used", "bt_ctx_last_retried",
            "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase", "bt_bench_gather",
-           "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_error", "bt_reads_close", "bt_format_hits",
+           "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_error", "bt_reads_close", "bt_format_hits", "bt_format_pairs",
            "bt_format_sam_header", "bt_format_summary", "bt_text_free"]
 _lib = None
 

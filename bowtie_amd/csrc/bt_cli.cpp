@@ -11,6 +11,7 @@
  * that of the reference run with -p 1.  Everything the search does happens behind the C ABI; this
  * file holds no alignment logic and has no CPU search path.
  */
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -43,7 +44,8 @@ struct Options {
 	std::vector<std::string> rg_fields;
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
-	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false;
+	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false, paired = false;
+	std::string mates1, mates2;
 	bool suppress_set = false, int_quals = false;
 	uint32_t batch_reads = 4u << 20;
 	std::string cmdline;
@@ -127,7 +129,15 @@ void usage(FILE* o)
 	    "  --seed <int>       seed for random number generator\n"
 	    "  --version          print version information and quit\n"
 	    "  -h/--help          print this usage message\n"
-	    "Not in this build (paired-end, SURVEY.md 8f-1): -1/-2 --12 --interleaved -I/-X --ff/--fr/--rf -Q -z\n",
+	    "Paired-end (with --best: the reference's PairedBWAlignerV2):\n"
+	    "  -1 <m1> -2 <m2>    files with #1 and #2 mates (comma-separated lists; same format options as <s>)\n"
+	    "  -I/--minins <int>  minimum insert size (default: 0)\n"
+	    "  -X/--maxins <int>  maximum insert size (default: 250)\n"
+	    "  --fr/--rf/--ff     -1, -2 mates align fw/rev, rev/fw, fw/fw (default: --fr)\n"
+	    "  --pairtries <int>  max # anchors tried per pair (default: 100)\n"
+	    "  --allow-contain    one mate alignment may contain the other\n"
+	    "Not in this build: paired-end without --best (PairedBWAlignerV1), --12 --interleaved -Q -z,\n"
+	    "  -M and --al/--un/--max with pairs\n",
 	    o);
 }
 
@@ -143,7 +153,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_BEST, O_STRATA, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -162,18 +172,18 @@ const LongOpt LONGS[] = {
 	{"mmsweep", 0, O_IGNORED}, {"prewidth", 1, O_IGNORED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_UNSUPPORTED},
 	/* the best-first engine and everything that needs it */
 	{"best", 0, O_BEST}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_STRATA},
-	{"minins", 1, O_UNSUPPORTED_ARG}, {"maxins", 1, O_UNSUPPORTED_ARG}, {"ff", 0, O_UNSUPPORTED}, {"fr", 0, O_UNSUPPORTED},
-	{"rf", 0, O_UNSUPPORTED}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_UNSUPPORTED_ARG},
+	{"minins", 1, 'I'}, {"maxins", 1, 'X'}, {"ff", 0, O_FF}, {"fr", 0, O_FR},
+	{"rf", 0, O_RF}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_PAIRTRIES},
 	{"integer-quals", 0, O_INTQUALS}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
 	{"al", 1, O_AL}, {"un", 1, O_UN}, {"max", 1, O_MAX}, {"phased", 0, O_UNSUPPORTED},
 	{"strandfix", 0, O_IGNORED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
-	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_UNSUPPORTED},
+	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_ALLOW_CONTAIN},
 	{"orig", 1, O_UNSUPPORTED_ARG}, {"filepar", 0, O_UNSUPPORTED}, {"noreconcile", 0, O_UNSUPPORTED},
 	{nullptr, 0, 0}
 };
 /* short options taking an argument */
-const char* SHORT_ARG = "us35oenlpkmMBxvF";
-const char* SHORT_UNSUPPORTED_ARG = "12IXQw";
+const char* SHORT_ARG = "us35oenlpkmMBxvF12IX";
+const char* SHORT_UNSUPPORTED_ARG = "Qw";
 const char* SHORT_UNSUPPORTED = "bz";
 
 void parse_args(int argc, char** argv, Options* O)
@@ -253,6 +263,15 @@ void parse_args(int argc, char** argv, Options* O)
 		case 'k': O->pol.khits = (uint32_t)parse_int(val, 1, "-k arg must be at least 1"); break;
 		case 'M': O->pol.sample_max = 1;    /* falls through: -M <n> is -m <n> plus sampling (ebwt_search.cpp:721-725) */
 		case 'm': O->pol.mhits = (uint32_t)parse_int(val, 1, "-m arg must be at least 1"); break;
+		case '1': if (!O->mates1.empty()) O->mates1.push_back(','); O->mates1.append(val); break;
+		case '2': if (!O->mates2.empty()) O->mates2.push_back(','); O->mates2.append(val); break;
+		case 'I': O->pol.min_ins = (int32_t)parse_int(val, 0, "-I arg must be positive"); break;
+		case 'X': O->pol.max_ins = (int32_t)parse_int(val, 1, "-X arg must be at least 1"); break;
+		case O_FF: O->pol.mate1_fw = 1; O->pol.mate2_fw = 1; break;
+		case O_RF: O->pol.mate1_fw = 0; O->pol.mate2_fw = 1; break;
+		case O_FR: O->pol.mate1_fw = 1; O->pol.mate2_fw = 0; break;
+		case O_PAIRTRIES: O->pol.pair_tries = (int32_t)parse_int(val, 1, "--pairtries arg must be at least 1"); break;
+		case O_ALLOW_CONTAIN: O->pol.allow_contain = 1; break;
 		case O_BEST: O->pol.best = 1; break;
 		case O_STRATA: O->pol.strata = 1; break;
 		case 'B': O->out.off_base = (int32_t)parse_int(val, -999999, "-B/--offbase arg must be at least -999999"); break;
@@ -345,6 +364,15 @@ void parse_args(int argc, char** argv, Options* O)
 		die("--strata has no effect unless combined with -m, -a, or -k N where N > 1");
 	/* --maxbts: 125 for the phase programs, 800 for the best-first workers (ebwt_search.cpp:185-186) */
 	if (O->pol.best && !O->maxbts_set) O->pol.max_bts = 800;
+	/* the insert-size limits as resolveOutstandingInRef sees them (aligner.h:1921-1935): reduced by the
+	 * trimming at the outer ends of the fragment (a mate shorter than its trims is skipped anyway) */
+	{
+		int mn = O->pol.min_ins, mx = O->pol.max_ins;
+		const int o1 = O->pol.mate1_fw ? O->rd.trim5 : O->rd.trim3, o2 = O->pol.mate2_fw ? O->rd.trim3 : O->rd.trim5;
+		mn = mn - o1 < 0 ? 0 : mn - o1; mx = mx - o1 < 0 ? 0 : mx - o1;
+		mn = mn - o2 < 0 ? 0 : mn - o2; mx = mx - o2 < 0 ? 0 : mx - o2;
+		O->pol.min_ins = mn; O->pol.max_ins = mx;
+	}
 	if (O->pol.mode == BT_MODE_N && O->pol.mms > 3) die("-n/--seedmms arg must be at most 3");
 	/* positionals: [<ebwt>] <reads> [<hits>] (ebwt_search.cpp:2930-2975) */
 	size_t pi = 0;
@@ -352,8 +380,20 @@ void parse_args(int argc, char** argv, Options* O)
 		if (pi >= pos.size()) { fprintf(stderr, "No index, query, or output file specified!\n"); usage(stderr); exit(1); }
 		O->index = pos[pi++];
 	}
+	O->paired = !O->mates1.empty() || !O->mates2.empty();
+	if (O->paired) {
+		/* ebwt_search.cpp:855-860 */
+		const size_t c1 = (size_t)std::count(O->mates1.begin(), O->mates1.end(), ',') + (O->mates1.empty() ? 0 : 1);
+		const size_t c2 = (size_t)std::count(O->mates2.begin(), O->mates2.end(), ',') + (O->mates2.empty() ? 0 : 1);
+		if (c1 != c2 && O->rd.format != BT_FMT_CMDLINE)
+			die("Error: %zu mate files/sequences were specified with -1, but %zu\nmate files/sequences were specified with -2.  The same number of mate files/\nsequences must be specified with -1 and -2.", c1, c2);
+		if (!O->pol.best) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
+		if (O->pol.sample_max) die("Error: -M with paired-end reads is not in this build");
+		if (!O->dump_al.empty() || !O->dump_un.empty() || !O->dump_max.empty()) die("Error: --al/--un/--max with paired-end reads are not in this build");
+	} else {
 	if (pi >= pos.size()) { fprintf(stderr, "No query or output file specified!\n"); usage(stderr); exit(1); }
 	O->reads = pos[pi++];
+	}
 	if (pi < pos.size()) O->hits_file = pos[pi++];
 	if (pi < pos.size()) { fprintf(stderr, "Extra parameter(s) specified: "); for (; pi < pos.size(); pi++) fprintf(stderr, "\"%s\"%s", pos[pi].c_str(), pi + 1 < pos.size() ? ", " : "\n"); exit(1); }
 	if (O->int_quals) {
@@ -398,6 +438,8 @@ void print_timer(const char* msg, double secs)
 struct Job {
 	bt_read_batch rb;                        /* view into `store` */
 	std::unique_ptr<BtHostBatch> store;
+	bt_read_batch rb2;                       /* paired-end: the second mates */
+	std::unique_ptr<BtHostBatch> store2;
 	uint32_t hit_cap = 1;
 	std::vector<bt_hit> hits;
 	std::vector<uint32_t> n_hits;
@@ -437,8 +479,44 @@ bt_read_batch one_read(const bt_read_batch& rb, uint32_t i)
 /* Search one batch.  Hit slots are uniform per read (bt_hit_batch); reads that report more than the
  * first pass had slots for (-a, large -k) or whose mismatch lists outgrew the pool are searched
  * again, together, with as many slots as the hungriest of them needs.  "" = ok. */
+/* pairs: slots per pair = 2 x hits wanted; pairs that have more (-a) are searched again with room for all */
+std::string search_job_pairs(bt_ctx* ctx, const Options& O, Job* j)
+{
+	const uint32_t n = j->rb.n_reads;
+	const bool all = O.pol.all_hits != 0;
+	j->hit_cap = all ? 16u : 2u * (O.pol.khits > 32u ? 32u : O.pol.khits);
+	for (int pass = 0; pass < 2; pass++) {
+		j->hits.assign((size_t)n * j->hit_cap, bt_hit());
+		j->n_hits.assign(n, 0); j->status.assign(n, 0);
+		uint32_t maxlen = 6;
+		if (pass) for (uint32_t i = 0; i < n; i++) { if (j->rb.len[i] > maxlen) maxlen = j->rb.len[i]; if (j->rb2.len[i] > maxlen) maxlen = j->rb2.len[i]; }
+		j->mm_pool.resize((size_t)n * j->hit_cap * maxlen + 1024u);
+		bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
+		int rc = bt_align_pairs(ctx, &j->rb, &j->rb2, &hb, nullptr);
+		j->mm_used = hb.mm_pool_used;
+		if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
+		uint32_t need = 0; bool pool_short = false;
+		const uint32_t maxv = O.pol.mhits == 0xffffffffu ? 0xffffffffu : O.pol.mhits * 2u;
+		for (uint32_t i = 0; i < n; i++) {
+			if (j->status[i] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
+			if (j->status[i] & BT_ST_MMPOOL) pool_short = true;
+			const uint32_t tot = j->n_hits[i];
+			if (tot > maxv) continue;
+			const uint32_t want = all ? tot : (tot < 2u * O.pol.khits ? tot : 2u * O.pol.khits);
+			if (want > need) need = want;
+		}
+		if (need <= j->hit_cap && !pool_short) break;
+		if (pass == 1) return "Error: a read exceeded the search scratch space";
+		/* simplest correct thing for the rare batch with a greedy pair: the whole batch again, wider */
+		if (need > j->hit_cap) j->hit_cap = (need + 1u) & ~1u;
+		if ((uint64_t)n * j->hit_cap > (64ull << 20)) return "Error: too many alignments per pair for one batch; lower --batch";
+	}
+	return "";
+}
+
 std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 {
+	if (O.paired) return search_job_pairs(ctx, O, j);
 	const uint32_t n = j->rb.n_reads;
 	const bool all = O.pol.all_hits != 0;
 	j->hit_cap = all ? 16u : (O.pol.khits > 64u ? 64u : O.pol.khits);
@@ -562,6 +640,14 @@ int main(int argc, char** argv)
 	}
 	bt_index* idx = idxs[0];
 	if (O.timing) print_timer("Time loading forward and mirror index: ", now_s() - t0);
+	if (O.paired) {
+		const double tr = now_s();
+		for (size_t d = 0; d < ND; d++) {
+			rc = bt_index_load_reference(idxs[d]);
+			if (rc != BT_OK) die("Could not open reference-string index file %s.3.ebwt / .4.ebwt for reading: %s", base.c_str(), bt_strerror(rc));
+		}
+		if (O.timing) print_timer("Time loading reference: ", now_s() - tr);
+	}
 	bt_index_info info;
 	bt_index_info_get(idx, &info);
 	BtRefNames refs;
@@ -589,7 +675,10 @@ int main(int argc, char** argv)
 	std::string open_err;
 	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
 	if (dumping) O.rd.flags |= BT_READ_KEEP_RAW;
-	BtReadStream* rs = bt_io_open(O.reads.c_str(), O.rd, &open_err);
+	bt_read_opts rd1 = O.rd, rd2 = O.rd;
+	rd1.flags |= BT_READ_MATE1; rd2.flags |= BT_READ_MATE2;
+	BtReadStream* rs = bt_io_open(O.paired ? O.mates1.c_str() : O.reads.c_str(), O.paired ? rd1 : O.rd, &open_err);
+	BtReadStream* rs2 = O.paired ? bt_io_open(O.mates2.c_str(), rd2, &open_err) : nullptr;
 	const int G = (int)ctxs.size();
 	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
 	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
@@ -611,6 +700,19 @@ int main(int argc, char** argv)
 			busy_read += now_s() - tb;
 			if (r != BT_OK) j->error = err;
 			j->rb = j->store->view();
+			if (O.paired && r == BT_OK) {
+				j->store2.reset(new BtHostBatch());
+				if (abort_run.load()) j->store2->n = 0;
+				else r = bt_io_next(rs2, O.batch_reads, T, j->store2.get(), &err);
+				if (r != BT_OK) j->error = err;
+				j->rb2 = j->store2->view();
+				if (r == BT_OK && j->rb2.n_reads != j->rb.n_reads) {
+					/* PatternComposer (pat.cpp:198-212) */
+					j->error = j->rb.n_reads < j->rb2.n_reads ? "Error, fewer reads in file specified with -1 than in file specified with -2"
+					                                          : "Error, fewer reads in file specified with -2 than in file specified with -1";
+					r = BT_ERR_READS;
+				}
+			}
 			if (r != BT_OK || j->rb.n_reads == 0) {
 				/* the end (or an input error, reported in its place in the order): one marker per searcher */
 				j->last = true;
@@ -624,7 +726,7 @@ int main(int argc, char** argv)
 	});
 
 	/* ---- stage 3: writer ---- */
-	bt_out_tally tally = {0, 0, 0, 0, 0};
+	bt_out_tally tally = {0, 0, 0, 0, 0, 0};
 	std::string fatal;
 	FILE *f_al = nullptr, *f_un = nullptr, *f_max = nullptr;
 	std::thread writer([&] {
@@ -645,7 +747,13 @@ int main(int argc, char** argv)
 			if (!fatal.empty()) continue;
 			const double tb = now_s();
 			const uint32_t n = j->rb.n_reads;
-			if (!O.quiet && (O.pol.mode == BT_MODE_N || O.pol.best)) {
+			if (!O.quiet && O.paired) {
+				/* PairedBWAlignerV2::setQuery (aligner.h:1579-1588) */
+				for (uint32_t i = 0; i < n; i++) if (j->rb.len[i] < 4u || j->rb2.len[i] < 4u) {
+					const std::string nm(j->store->names.data() + j->store->name_off[i], (size_t)(j->store->name_off[i + 1] - j->store->name_off[i]));
+					fprintf(stderr, "Warning: Skipping pair %s because a mate is less than 4 characters long\n", nm.c_str());
+				}
+			} else if (!O.quiet && (O.pol.mode == BT_MODE_N || O.pol.best)) {
 				/* search_seeded_phase1.c:17-20 / UnpairedAlignerV2::setQuery (aligner.h:440-444) */
 				for (uint32_t i = 0; i < n; i++) if (j->rb.len[i] < 4u) {
 					const std::string nm(j->store->names.data() + j->store->name_off[i], (size_t)(j->store->name_off[i + 1] - j->store->name_off[i]));
@@ -674,9 +782,14 @@ int main(int argc, char** argv)
 				for (uint32_t p = 0; p < pieces; p++)
 					segs.push_back({lo + (uint32_t)((uint64_t)(hi - lo) * p / pieces), lo + (uint32_t)((uint64_t)(hi - lo) * (p + 1) / pieces), -1});
 			}
-			parts.resize(segs.size()); tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0, 0});
+			parts.resize(segs.size()); tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0, 0, 0});
 			auto run = [&](size_t si) {
 				const Seg& sg = segs[si];
+				if (O.paired) {
+					bt_io_format_pairs(j->rb, names, noff, j->rb2, j->store2->names.data(), j->store2->name_off.data(), hb, refs, O.out,
+					                   sg.lo, sg.hi, &parts[si], &tl[si]);
+					return;
+				}
 				if (sg.wide < 0) { bt_io_format(j->rb, names, noff, hb, refs, O.out, sg.lo, sg.hi, &parts[si], &tl[si]); return; }
 				Job::Wide& w = j->wide[(size_t)sg.wide];
 				/* a one-read view whose slot count holds every hit of that read */
@@ -697,7 +810,7 @@ int main(int argc, char** argv)
 			for (size_t si = 0; si < segs.size(); si++) {
 				fwrite(parts[si].data(), 1, parts[si].size(), fout);
 				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
-				tally.sample_max |= tl[si].sample_max;
+				tally.sample_max |= tl[si].sample_max; tally.reported_paired += tl[si].reported_paired;
 			}
 			if (dumping) {
 				/* HitSink::dumpAlign / dumpUnal / dumpMaxed (hit.h:385-488): the read's record as it stood in
@@ -754,6 +867,7 @@ int main(int argc, char** argv)
 	if (f_un) fclose(f_un);
 	if (f_max) fclose(f_max);
 	bt_io_close(rs);
+	if (rs2) bt_io_close(rs2);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
 	for (bt_index* x : idxs) bt_index_free(x);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }

@@ -745,7 +745,40 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 }
 
 
+/* Read::fixMateName (read.h:141-165) + finalizePair (pat.cpp:76-88): a mate's name ends in /1 (/2) --
+ * appended unless already there -- and its seed is computed over that name */
+static void fix_mate_names(BtHostBatch* batch, int mate, uint32_t global_seed)
+{
+	const uint32_t n = batch->n;
+	std::string names;
+	std::vector<uint64_t> off((size_t)n + 1);
+	names.reserve(batch->names.size() + 2ull * n);
+	const char digit = mate == 1 ? '1' : '2';
+	for (uint32_t i = 0; i < n; i++) {
+		const char* nm = batch->names.data() + batch->name_off[i];
+		const size_t nn = (size_t)(batch->name_off[i + 1] - batch->name_off[i]);
+		off[i] = names.size();
+		names.append(nm, nn);
+		if (nn < 2 || nm[nn - 2] != '/' || nm[nn - 1] != digit) { names.push_back('/'); names.push_back(digit); }
+	}
+	off[n] = names.size();
+	batch->names.swap(names);
+	batch->name_off.swap(off);
+	for (uint32_t i = 0; i < n; i++)
+		batch->seed[i] = rand_seed(batch->seq + (size_t)i * batch->stride, batch->qual + (size_t)i * batch->stride, batch->len[i],
+		                           batch->names.data() + batch->name_off[i], (size_t)(batch->name_off[i + 1] - batch->name_off[i]), global_seed);
+}
+
+static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err);
 int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
+{
+	const int rc = io_next_impl(s, max_reads, threads, batch, err);
+	if (rc == BT_OK && batch->n > 0 && (s->o.flags & (BT_READ_MATE1 | BT_READ_MATE2)))
+		fix_mate_names(batch, (s->o.flags & BT_READ_MATE1) ? 1 : 2, s->o.seed);
+	return rc;
+}
+
+static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
 {
 	s->raw.clear(); s->recs.clear();
 	batch->n = 0;
@@ -1055,6 +1088,100 @@ void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* na
 	}
 }
 
+/* SAMHitSink::append for a mate of a paired alignment (sam.cpp:129-257): QNAME without its /1 or /2,
+ * FLAG 1|2|64/128 (+16, +32), MRNM '=', MPOS, ISIZE */
+static void sam_pair_hit(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
+                         const bt_hit& h, const uint16_t* mm, const bt_hit& mh, uint32_t mlen, uint32_t xms,
+                         const BtRefNames& refs, const bt_out_opts& op)
+{
+	static const char dna[] = "ACGT";
+	const bool fw = h.fw != 0;
+	put_qname(o, nm, nn >= 2 ? nn - 2 : 0, !op.no_qname_trunc);
+	const uint32_t flags = 1u | 2u | (h.pad[0] == 1 ? 64u : 128u) | (fw ? 0u : 16u) | (mh.fw ? 0u : 32u);
+	o->push_back('\t'); put_u(o, flags);
+	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
+	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
+	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", op.mapq); o->append(b); }
+	o->push_back('\t'); put_u(o, L); o->append("M\t=\t");
+	put_u(o, (uint64_t)mh.toff + 1u);
+	o->push_back('\t');
+	{
+		int64_t ins;
+		if (h.toff > mh.toff) ins = -((int64_t)h.toff - (int64_t)mh.toff + (int64_t)L);
+		else ins = (int64_t)mh.toff - (int64_t)h.toff + (int64_t)mlen;
+		char b[32]; snprintf(b, sizeof(b), "%lld", (long long)ins); o->append(b);
+	}
+	o->push_back('\t');
+	put_seq(o, seq, L, fw);
+	o->push_back('\t');
+	put_qual(o, qual, L, fw);
+	o->append("\tXA:i:"); put_u(o, h.stratum);
+	o->append("\tMD:Z:");
+	const uint32_t n = h.nmm;
+	uint32_t run_from = 0;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint16_t e = fw ? mm[k] : mm[n - 1 - k];
+		const uint32_t col = fw ? BT_MM_POS(e) : (L - 1u - BT_MM_POS(e));
+		put_u(o, col - run_from);
+		o->push_back(dna[BT_MM_REFC(e)]);
+		run_from = col + 1u;
+	}
+	put_u(o, L - run_from);
+	o->append("\tNM:i:"); put_u(o, n);
+	if (xms > 0) { o->append("\tXM:i:"); put_u(o, xms); }
+	o->push_back('\n');
+}
+
+/* one mate of a pair that did not align (SAMHitSink::reportUnOrMax, sam.cpp:57-124): FLAG 77 / 141 */
+static void sam_pair_unaligned(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
+                               int mate, const bt_out_opts& op)
+{
+	put_qname(o, nm, nn >= 2 ? nn - 2 : 0, !op.no_qname_trunc);
+	o->append(mate == 1 ? "\t77\t*\t0\t0\t*\t*\t0\t0\t" : "\t141\t*\t0\t0\t*\t*\t0\t0\t");
+	put_seq(o, seq, L, true);
+	o->push_back('\t');
+	put_qual(o, qual, L, true);
+	o->append("\tXM:i:0\n");
+}
+
+void bt_io_format_pairs(const bt_read_batch& r1, const char* names1, const uint64_t* off1,
+                        const bt_read_batch& r2, const char* names2, const uint64_t* off2, const bt_hit_batch& hb,
+                        const BtRefNames& refs, const bt_out_opts& op, uint32_t lo, uint32_t hi, std::string* out,
+                        bt_out_tally* tally)
+{
+	/* finishRead with createMult(2)'s doubled limits (hit.h:741-786, 1012-1016) */
+	const uint32_t maxv = op.mhits == 0xffffffffu ? 0xffffffffu : op.mhits * 2u;
+	const uint32_t lim = op.all_hits ? hb.hit_cap : (hb.hit_cap < op.khits * 2u ? hb.hit_cap : op.khits * 2u);
+	for (uint32_t i = lo; i < hi; i++) {
+		const uint32_t tot = hb.n_hits[i];
+		const bt_read_batch* rb[2] = { &r1, &r2 };
+		const char* nm[2] = { names1 + off1[i], names2 + off2[i] };
+		const size_t nn[2] = { (size_t)(off1[i + 1] - off1[i]), (size_t)(off2[i + 1] - off2[i]) };
+		if (tot == 0) {
+			if (tally) tally->unaligned++;
+			if (op.sam && !op.no_unal)
+				for (int m = 0; m < 2; m++)
+					sam_pair_unaligned(out, nm[m], nn[m], rb[m]->seq + (size_t)i * rb[m]->stride, rb[m]->qual + (size_t)i * rb[m]->stride,
+					                   rb[m]->len[i], m + 1, op);
+			continue;
+		}
+		if (tot > maxv) { if (tally) tally->maxed++; continue; }
+		uint32_t np = tot < lim ? tot : lim;
+		np &= ~1u;
+		if (tally) { tally->aligned++; tally->reported_paired += np; }
+		for (uint32_t k = 0; k < np; k++) {
+			const bt_hit& h = hb.hits[(size_t)i * hb.hit_cap + k];
+			const bt_hit& mh = hb.hits[(size_t)i * hb.hit_cap + (k ^ 1u)];
+			const int m = h.pad[0] == 2 ? 1 : 0;
+			const uint8_t* seq = rb[m]->seq + (size_t)i * rb[m]->stride;
+			const uint8_t* qual = rb[m]->qual + (size_t)i * rb[m]->stride;
+			const uint16_t* mm = hb.mm_pool ? hb.mm_pool + h.mm_off : nullptr;
+			if (op.sam) sam_pair_hit(out, nm[m], nn[m], seq, qual, rb[m]->len[i], h, mm, mh, rb[m ^ 1]->len[i], np / 2u, refs, op);
+			else verbose_hit(out, nm[m], nn[m], seq, qual, rb[m]->len[i], h, mm, rb[m]->seed[i], refs, op);
+		}
+	}
+}
+
 void bt_io_sam_header(const BtRefNames& refs, const bt_out_opts& op, const char* cmdline, const char* rgline,
                       std::string* o)
 {
@@ -1087,8 +1214,10 @@ void bt_io_summary(const bt_out_tally& t, std::string* o)
 		         (unsigned long long)t.maxed, mx);
 		o->append(b);
 	}
-	if (t.reported == 0) o->append("No alignments\n");
-	else { snprintf(b, sizeof(b), "Reported %llu alignments\n", (unsigned long long)t.reported); o->append(b); }
+	if (t.reported == 0 && t.reported_paired == 0) o->append("No alignments\n");
+	else if (t.reported_paired > 0 && t.reported == 0) { snprintf(b, sizeof(b), "Reported %llu paired-end alignments\n", (unsigned long long)(t.reported_paired >> 1)); o->append(b); }
+	else if (t.reported_paired == 0) { snprintf(b, sizeof(b), "Reported %llu alignments\n", (unsigned long long)t.reported); o->append(b); }
+	else { snprintf(b, sizeof(b), "Reported %llu paired-end alignments and %llu singleton alignments\n", (unsigned long long)(t.reported_paired >> 1), (unsigned long long)t.reported); o->append(b); }
 }
 
 /* ---- C entry points (include/bowtie_amd.h) ---------------------------------------------------- */
@@ -1168,6 +1297,24 @@ extern "C" int bt_format_sam_header(const char* const* refnames, const uint32_t*
 	*text = text_out(s, text_len);
 	return *text ? BT_OK : BT_ERR_IO;
 }
+extern "C" int bt_format_pairs(const bt_read_batch* r1, const char* names1, const uint64_t* name_off1,
+                               const bt_read_batch* r2, const char* names2, const uint64_t* name_off2,
+                               const bt_hit_batch* hits, const char* const* refnames, const uint32_t* reflens,
+                               uint32_t n_refs, const bt_out_opts* o, char** text, size_t* text_len, bt_out_tally* tally)
+{
+	if (!r1 || !r2 || !names1 || !names2 || !name_off1 || !name_off2 || !hits || !o || !text || r1->n_reads != r2->n_reads) return BT_ERR_ARG;
+	BtRefNames refs;
+	for (uint32_t i = 0; i < n_refs; i++) { refs.names.emplace_back(refnames && refnames[i] ? refnames[i] : ""); refs.lens.push_back(reflens ? reflens[i] : 0); }
+	std::string s;
+	bt_io_format_pairs(*r1, names1, name_off1, *r2, names2, name_off2, *hits, refs, *o, 0, r1->n_reads, &s, tally);
+	char* p = (char*)malloc(s.size() + 1);
+	if (!p) return BT_ERR_ARG;
+	memcpy(p, s.data(), s.size()); p[s.size()] = 0;
+	*text = p;
+	if (text_len) *text_len = s.size();
+	return BT_OK;
+}
+
 extern "C" int bt_format_summary(const bt_out_tally* tally, char** text, size_t* text_len)
 {
 	if (!tally || !text) return BT_ERR_ARG;

@@ -53,6 +53,11 @@ struct BtRefNames {
 void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* name_off, const bt_hit_batch& hb,
                   const BtRefNames& refs, const bt_out_opts& o, uint32_t lo, uint32_t hi, std::string* out,
                   bt_out_tally* tally);
+/* the same for pairs (hit slots per pair hold adjacent mate alignments, upstream mate first) */
+void bt_io_format_pairs(const bt_read_batch& r1, const char* names1, const uint64_t* off1,
+                        const bt_read_batch& r2, const char* names2, const uint64_t* off2, const bt_hit_batch& hb,
+                        const BtRefNames& refs, const bt_out_opts& o, uint32_t lo, uint32_t hi, std::string* out,
+                        bt_out_tally* tally);
 void bt_io_sam_header(const BtRefNames& refs, const bt_out_opts& o, const char* cmdline, const char* rgline,
                       std::string* out);
 void bt_io_summary(const bt_out_tally& t, std::string* out);

@@ -349,6 +349,45 @@ def write_index(base: str, arrays: dict, plen: np.ndarray, rstarts: np.ndarray, 
         f.write(np.asarray(a["offs"], dtype="<u4").tobytes())
 
 
+def write_reference(base: str, text: np.ndarray, plen: np.ndarray, rstarts: np.ndarray):
+    """`.3.ebwt` / `.4.ebwt` (BitPairReference, reference.h:35-240): per unambiguous stretch a record
+    {u32 off = Ns before it, u32 len, u8 first-of-its-sequence}; the stretches' bases 4 per byte, first base
+    in the low bits.  `text` = joined text (codes 0..3), rstarts = [nFrag][3] (joined offset, tidx, offset
+    within the sequence)."""
+    rst = np.asarray(rstarts, dtype=np.int64).reshape(-1, 3)
+    n = len(text)
+    recs = []
+    prev_t, prev_end = -1, 0
+
+    def close_seq():
+        # trailing Ns of a sequence get a record of their own with no bases (as bowtie-build writes them)
+        if prev_t >= 0 and int(plen[prev_t]) > prev_end:
+            recs.append((int(plen[prev_t]) - prev_end, 0, 0))
+
+    for f in range(len(rst)):
+        joff, tidx, foff = (int(x) for x in rst[f])
+        flen = (int(rst[f + 1, 0]) if f + 1 < len(rst) else n) - joff
+        first = tidx != prev_t
+        if first:
+            close_seq()
+            prev_end = 0
+        recs.append((foff - prev_end, flen, 1 if first else 0))
+        prev_t, prev_end = tidx, foff + flen
+    close_seq()
+    with open(base + ".3.ebwt", "wb") as f:
+        f.write(struct.pack("<iI", 1, len(recs)))
+        for off, ln, first in recs:
+            f.write(struct.pack("<IIB", off, ln, first))
+    t = np.asarray(text, dtype=np.uint8)
+    pad = (-n) % 4
+    if pad:
+        t = np.concatenate([t, np.zeros(pad, dtype=np.uint8)])
+    q = t.reshape(-1, 4)
+    packed = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
+    with open(base + ".4.ebwt", "wb") as f:
+        f.write(packed.tobytes())
+
+
 def build_index(seqs: Sequence[np.ndarray], names: Sequence[str], base: str, device="cpu",
                 off_rate: int = 5, ftab_chars: int = 10) -> np.ndarray:
     """Index `seqs` (codes 0..4) into base.{1,2}.ebwt and base.rev.{1,2}.ebwt; returns the joined
@@ -365,6 +404,7 @@ def build_index(seqs: Sequence[np.ndarray], names: Sequence[str], base: str, dev
         arr = build_arrays(t, off_rate, ftab_chars)
         del t
         write_index(base + suffix, arr, plen, rstarts, nm)
+    write_reference(base, fw, plen, rstarts)
     return fw
 
 
@@ -446,6 +486,7 @@ def ensure_big_index(total_bp: int, device, rank: int = 0, world: int = 1, cache
             write_index(base + suffix, arr, plen, rstarts, names)
             del arr, t
             torch.cuda.empty_cache() if torch.cuda.is_available() else None
+        write_reference(base, text.cpu().numpy(), plen, rstarts)
         with open(done, "w") as f:
             f.write("%.1f\n" % (time.perf_counter() - t0))
     if world > 1:

@@ -25,11 +25,11 @@ class ReadInputError(ValueError):
 def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, quals: str = "phred33",
                  seed: int = 0, skip: int = 0, upto: int = 0, max_reads: int = 1 << 20,
                  threads: int = 1, careful: bool = False, keep_raw: bool = False,
-                 cont: Tuple[int, int] = (0, 0)) -> Iterator[ReadBatch]:
+                 cont: Tuple[int, int] = (0, 0), mate: int = 0) -> Iterator[ReadBatch]:
     """Yield ReadBatch objects (copies) of up to max_reads reads each; keep_raw adds `.raw`, the list of
     the reads' records as they stood in the input."""
     L = lib()
-    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0), skip, upto,
+    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0) | (4 if mate == 1 else 8 if mate == 2 else 0), skip, upto,
                    cont[0], cont[1])
     h = C.c_void_p()
     rc = L.bt_reads_open(spec.encode(), C.byref(o), C.byref(h))
@@ -102,6 +102,7 @@ def pack_hits(per_read, hit_cap: int):
             r = hits[i * hit_cap + k]
             r["tidx"], r["toff"], r["oms"], r["cost"], r["stratum"], r["fw"] = h.tidx, h.toff, h.oms, h.cost, h.stratum, int(h.fw)
             r["mm_off"], r["nmm"] = len(pool), len(h.mms)
+            r["pad"][0] = getattr(h, "mate", 0)
             pool.extend((p & 0x3FF) | (c << 12) for p, c in h.mms)
     return hits, n_hits, status, np.array(pool + [0], dtype=np.uint16)
 
@@ -136,6 +137,30 @@ def format_hits(batch: ReadBatch, hits, n_hits, status, mm_pool, hit_cap: int, r
                           C.byref(opts), C.byref(text), C.byref(tlen), C.byref(tally))
     if rc != A.BT_OK:
         raise BowtieAmdError(rc, "bt_format_hits")
+    try:
+        return C.string_at(text, tlen.value), tally
+    finally:
+        L.bt_text_free(text)
+
+
+def format_pairs(b1: ReadBatch, b2: ReadBatch, hits, n_hits, status, mm_pool, hit_cap: int, refnames: Sequence[str],
+                 reflens: Sequence[int], opts: A.OutOpts) -> Tuple[bytes, A.OutTally]:
+    """bt_format_pairs: the paired hit layout of bt_align_pairs -> the reference's text."""
+    from .aligner import pack_batch
+    L = lib()
+    k1, rb1 = pack_batch(b1)
+    k2, rb2 = pack_batch(b2)
+    hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, mm_pool.ctypes.data, len(mm_pool), 0)
+    blob1, off1 = _names_blob(b1.names)
+    blob2, off2 = _names_blob(b2.names)
+    arr, lens = _refs(refnames, reflens)
+    text, tlen, tally = C.c_void_p(), C.c_size_t(), A.OutTally()
+    L.bt_format_pairs.argtypes = None
+    rc = L.bt_format_pairs(C.byref(rb1), blob1, C.c_void_p(off1.ctypes.data), C.byref(rb2), blob2, C.c_void_p(off2.ctypes.data),
+                           C.byref(hb), arr, C.c_void_p(lens.ctypes.data), C.c_uint32(len(refnames)), C.byref(opts),
+                           C.byref(text), C.byref(tlen), C.byref(tally))
+    if rc != A.BT_OK:
+        raise BowtieAmdError(rc, "bt_format_pairs")
     try:
         return C.string_at(text, tlen.value), tally
     finally:

@@ -183,3 +183,79 @@ def synth_pairs(text: np.ndarray, n: int, length: int, frag_lo: int = 200, frag_
         names = [("%s%d/%d" % (name_prefix, i, mate)).encode() for i in range(n)]
         out.append(ReadBatch(pseq, pqual, lens, rand_seeds(pseq, pqual, lens, names, 0), names))
     return out[0], out[1]
+
+
+def synth_pairs_torch(text_t, n: int, length: int, frag_lo: int = 200, frag_hi: int = 450, mm_dist=(0, 0, 1, 1, 2),
+                      seed: int = 777, n_frac: float = 0.01, qlo: int = 10, qhi: int = 40, first_id: int = 0,
+                      chunk: int = 2_000_000):
+    """Device twin of synth_pairs(): two dicts like synth_reads_torch()'s (mates 1 and 2), --fr pairs cut
+    from fragments of frag_lo..frag_hi bases; names r<id>/1 and r<id>/2 (seeds follow genRandSeed over them)."""
+    import torch
+    dev = text_t.device
+    stride = max(16, (length + 15) & ~15)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    T = text_t.numel()
+    mmd = torch.tensor(list(mm_dist), device=dev)
+    base = ((0 + 101) * 59 * 61 * 67 * 71 * 73 * 79 * 83) & 0xFFFFFFFF
+    out = []
+    for mate in (1, 2):
+        out.append({"seq": torch.full((n, stride), 4, dtype=torch.uint8, device=dev),
+                    "qual": torch.full((n, stride), 33, dtype=torch.uint8, device=dev),
+                    "seed": torch.empty(n, dtype=torch.int32, device=dev),
+                    "len": torch.full((n,), length, dtype=torch.int16, device=dev),
+                    "n": n, "stride": stride, "length": length})
+    ar = torch.arange(length, device=dev)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        flen = torch.randint(max(frag_lo, length), frag_hi + 1, (m,), generator=g, device=dev)
+        start = torch.randint(0, T - frag_hi, (m,), generator=g, device=dev)
+        strand = torch.rand(m, generator=g, device=dev) < 0.5
+        rows = torch.arange(m, device=dev)
+        ids = torch.arange(first_id + lo, first_id + lo + m, dtype=torch.int64, device=dev)
+        ndig = torch.ones_like(ids)
+        p = 10
+        for _ in range(11):
+            ndig += (ids >= p).to(torch.int64)
+            p *= 10
+        for mate in (1, 2):
+            # the fragment on its strand: F = text[start:start+flen] or its reverse complement;
+            # mate 1 = F[:L], mate 2 = revcomp(F[-L:])
+            left = text_t[(start[:, None] + ar[None, :])]                               # first L bases of the text fragment
+            right = text_t[((start + flen - length)[:, None] + ar[None, :])]            # last L bases
+            if mate == 1:
+                s_ = torch.where(strand[:, None], 3 - right.flip(1), left)
+            else:
+                s_ = torch.where(strand[:, None], left, 3 - right.flip(1))
+            s_ = s_.clone()
+            nmm = mmd[torch.randint(0, len(mm_dist), (m,), generator=g, device=dev)]
+            for k in range(int(max(mm_dist)) if len(mm_dist) else 0):
+                pos = torch.randint(0, length, (m,), generator=g, device=dev)
+                add = torch.randint(1, 4, (m,), generator=g, device=dev).to(torch.uint8)
+                cur = s_[rows, pos]
+                s_[rows, pos] = torch.where(nmm > k, (cur + add) & 3, cur)
+            if n_frac > 0:
+                hasn = torch.rand(m, generator=g, device=dev) < n_frac
+                pos = torch.randint(0, length, (m,), generator=g, device=dev)
+                cur = s_[rows, pos]
+                s_[rows, pos] = torch.where(hasn, torch.full_like(cur, 4), cur)
+            q = (torch.randint(qlo, qhi + 1, (m, length), generator=g, device=dev) + 33).to(torch.uint8)
+            o = out[mate - 1]
+            o["seq"][lo:lo + m, :length] = s_
+            o["qual"][lo:lo + m, :length] = q
+            acc = torch.full((m,), base, dtype=torch.int64, device=dev)
+            for i in range(length):
+                acc ^= s_[:, i].to(torch.int64) << ((i & 15) << 1)
+                acc ^= q[:, i].to(torch.int64) << ((i & 3) << 3)
+            acc ^= ord("r")
+            for k in range(12):
+                e = ndig - 1 - k
+                valid = e >= 0
+                div = torch.pow(torch.tensor(10, dtype=torch.int64, device=dev), e.clamp(min=0))
+                dig = (ids // div) % 10 + ord("0")
+                acc ^= torch.where(valid, dig << (((k + 1) & 3) << 3), torch.zeros_like(dig))
+            acc ^= torch.full_like(ids, ord("/")) << (((ndig + 1) & 3) << 3)
+            acc ^= torch.full_like(ids, ord("0") + mate) << (((ndig + 2) & 3) << 3)
+            acc &= 0xFFFFFFFF
+            o["seed"][lo:lo + m] = torch.where(acc >= 2 ** 31, acc - 2 ** 32, acc).to(torch.int32)
+    return out[0], out[1]

@@ -254,6 +254,8 @@ int bt_bench_gather(bt_ctx* ctx, int mirror, uint32_t n_blocks, uint32_t iters, 
 #define BT_QUAL_INT_SOLEXA 4 /* --integer-quals --solexa-quals                                   */
 #define BT_READ_CAREFUL  1u /* every record through the step-by-step parser (testing)            */
 #define BT_READ_KEEP_RAW 2u /* keep each read's record text (Read::readOrigBuf) for --al/--un/--max */
+#define BT_READ_MATE1    4u /* the file holds first mates (-1): names end in /1 -- appended unless there --  */
+#define BT_READ_MATE2    8u /* ... second mates (-2), /2; the seed covers the name (read.h:141-165, pat.cpp:76-88) */
 
 typedef struct bt_read_opts {
 	int32_t  format;       /* BT_FMT_*                                                        */
@@ -303,7 +305,7 @@ typedef struct bt_out_opts {
 } bt_out_opts;
 
 /* HitSink::finish's counters (hit.h:270-346) */
-typedef struct bt_out_tally { uint64_t aligned, unaligned, maxed, reported, sample_max; } bt_out_tally;
+typedef struct bt_out_tally { uint64_t aligned, unaligned, maxed, reported, sample_max, reported_paired; } bt_out_tally;
 
 /* text of all reads of the batch, in read order; *text is malloc'ed (bt_text_free).  tally
  * (optional) is added to. */
@@ -311,6 +313,12 @@ int  bt_format_hits(const bt_read_batch* reads, const char* names, const uint64_
                     const bt_hit_batch* hits, const char* const* refnames, const uint32_t* reflens,
                     uint32_t n_refs, const bt_out_opts* o, char** text, size_t* text_len,
                     bt_out_tally* tally);
+/* the same for pairs (bt_align_pairs' hit layout): two records per reported pair, upstream mate
+ * first; a pair counts once in aligned / unaligned / maxed and twice in reported_paired */
+int  bt_format_pairs(const bt_read_batch* r1, const char* names1, const uint64_t* name_off1,
+                     const bt_read_batch* r2, const char* names2, const uint64_t* name_off2,
+                     const bt_hit_batch* hits, const char* const* refnames, const uint32_t* reflens,
+                     uint32_t n_refs, const bt_out_opts* o, char** text, size_t* text_len, bt_out_tally* tally);
 /* SAMHitSink::appendHeaders (sam.cpp:20-49) */
 int  bt_format_sam_header(const char* const* refnames, const uint32_t* reflens, uint32_t n_refs,
                           const bt_out_opts* o, const char* cmdline, const char* rgline,

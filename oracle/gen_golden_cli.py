@@ -20,7 +20,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from bowtie_amd.synth import synth_reads, write_fastq   # noqa: E402
+from bowtie_amd.synth import synth_reads, synth_pairs, write_fastq   # noqa: E402
 import oracle_lib as OL                                   # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -102,6 +102,20 @@ def make_inputs():
     b = synth_reads(text, 150, 50, mm_dist=(0, 0, 1, 2), seed=515)
     b.names = [nm + (b" lane 3" if i % 7 == 0 else b"") for i, nm in enumerate(b.names)]
     write_fastq(b, os.path.join(D, "multi.fq"))
+    # read pairs for the multi-sequence index: most names end in /1 and /2, some are bare (the reference
+    # appends the suffix), one has a description, one pair has a 3-base mate (skipped with a warning)
+    p1, p2 = synth_pairs(text, 150, 40, frag_lo=120, frag_hi=300, seed=4040)
+    for i in range(150):
+        if i % 11 == 3:
+            p1.names[i] = p1.names[i][:-2]; p2.names[i] = p2.names[i][:-2]
+        if i == 20:
+            p1.names[i] = b"frag20 lane 3/1"; p2.names[i] = b"frag20 lane 3/2"
+    p2.len[57] = 3
+    write_fastq(p1, os.path.join(D, "pe_1.fq"))
+    write_fastq(p2, os.path.join(D, "pe_2.fq"))
+    e1, e2 = synth_pairs(oi_e.joined_text(), 120, 50, seed=5151)
+    write_fastq(e1, os.path.join(D, "pee_1.fq"))
+    write_fastq(e2, os.path.join(D, "pee_2.fq"))
     return plain
 
 
@@ -166,6 +180,15 @@ def cases(plain):
         ("n2_trim_short_sam", E, ["-3", "33", "-n", "2", "-S", "--sam-nohead"], "cli/io.fq"),
         ("n2_trim_away", E, ["-3", "40", "-n", "2", "-S", "--sam-nohead"], "cli/io.fq"),
         ("best_trim_away", E, ["-5", "20", "-3", "20", "--best", "-v", "1"], "cli/io.fq"),
+        # paired-end (-1/-2 --best: PairedBWAlignerV2); no <s> argument
+        ("pe_default", M, ["--best", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_sam_head", M, ["--best", "-S", "-X", "400", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_n1_k3_sam", M, ["--best", "-n", "1", "-k", "3", "-X", "350", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_a_strata_cost", M, ["--best", "--strata", "-a", "-v", "2", "-X", "400", "--cost", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_m1_I100", M, ["--best", "-m", "1", "-I", "100", "-X", "300", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_trim_ff", M, ["--best", "--ff", "-5", "2", "-3", "3", "-X", "300", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_ecoli_config5", E, ["-n", "1", "--best", "-X", "500", "-S", "--sam-nohead", "--no-unal", "-1", "cli/pee_1.fq", "-2", "cli/pee_2.fq"], ""),
+        ("pe_ecoli_two_files", E, ["-v", "2", "--best", "-X", "500", "-1", "cli/pee_1.fq,cli/pe_1.fq", "-2", "cli/pee_2.fq,cli/pe_2.fq"], ""),
     ]
 
 
@@ -174,7 +197,7 @@ def main():
     manifest = {"reference": "BenLangmead/bowtie v1.3.1", "cwd": "tests/golden", "cases": []}
     for name, idx, args, reads in cases(plain):
         dump_paths = {k: os.path.join(D, "_dump_%s.txt" % k) for k in ("AL", "UN", "MAX") if k in args}
-        cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + [dump_paths.get(a, a) for a in args] + ["-x", idx, reads]
+        cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + [dump_paths.get(a, a) for a in args] + ["-x", idx] + ([reads] if reads else [])
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=G)
         dumps = {}
         for k, path in dump_paths.items():

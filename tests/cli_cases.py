@@ -42,6 +42,13 @@ def interpret(args):
         elif a == "--best": pol["best"] = True
         elif a == "--strata": pol["strata"] = True
         elif a == "-a": pol["all_hits"] = True
+        elif a == "-1": ex["mates1"] = next(it)
+        elif a == "-2": ex["mates2"] = next(it)
+        elif a == "-I": pol["min_ins"] = int(next(it))
+        elif a == "-X": pol["max_ins"] = int(next(it))
+        elif a == "--ff": pol.update(mate1_fw=True, mate2_fw=True)
+        elif a == "--rf": pol.update(mate1_fw=False, mate2_fw=True)
+        elif a == "--fr": pol.update(mate1_fw=True, mate2_fw=False)
         elif a == "--nofw": pol["nofw"] = True
         elif a == "--norc": pol["norc"] = True
         elif a == "--maxbts": pol["max_bts"] = int(next(it))

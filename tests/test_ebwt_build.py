@@ -13,7 +13,7 @@ import common as T
 import refrun as R
 from bowtie_amd import ebwt_build as EB
 
-EXTS = ("1.ebwt", "2.ebwt", "rev.1.ebwt", "rev.2.ebwt")
+EXTS = ("1.ebwt", "2.ebwt", "3.ebwt", "4.ebwt", "rev.1.ebwt", "rev.2.ebwt")
 
 
 def read_fa(path):

@@ -15,7 +15,7 @@ BIN = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
 
 
 def run(args, index, reads, extra=()):
-    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + list(extra) + list(args) + ["-x", index, reads]
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + list(extra) + list(args) + ["-x", index] + ([reads] if reads else [])
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
 
 
@@ -61,7 +61,8 @@ def test_cli_matches_reference(case, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["fq_default", "multi_all", "multi_sam_notrunc", "fq_gz_two_files", "multi_all_m3", "dump_multi_m3", "dump_fq",
-                                  "best_strata_a", "bigM_sam_dump", "bigM_k2_cost", "best_trim_short"])
+                                  "best_strata_a", "bigM_sam_dump", "bigM_k2_cost", "best_trim_short",
+                                  "pe_sam_head", "pe_a_strata_cost", "pe_n1_k3_sam"])
 def test_cli_small_batches_and_threads_do_not_change_output(name, tmp_path):
     """Many tiny GPU batches, several host threads: same bytes (batches concatenate in read order;
     -a reads with more hits than the first pass had slots for take the second pass)."""
@@ -90,7 +91,8 @@ def test_cli_output_file_and_quiet(tmp_path):
     (["-c", "-v", "1"], "A", "Error: Reads must be at least 2 characters long in 1-mismatch mode"),
     (["--strata"], "cli/io.fq", "--strata must be combined with --best"),
     (["--best", "--strata"], "cli/io.fq", "--strata has no effect unless combined with"),
-    (["-1", "a.fq", "-2", "b.fq"], "cli/io.fq", "does not have"),
+    (["-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], "", "add --best"),
+    (["--best", "-1", "cli/pe_1.fq", "-2", "cli/pee_2.fq"], "", "fewer reads in file specified with -2"),
 ])
 def test_cli_errors(args, reads, msg):
     p = run(args, "e_coli", reads)

@@ -13,8 +13,28 @@ from bowtie_amd import hostio as H
 from bowtie_amd.reads import pack_reads, parse_fastq
 
 
+def run_case_paired(case, rd, pol, out, ex):
+    oi = T.oracle_index(case["index"])
+    spec = lambda x: ",".join(os.path.join(T.G, f) for f in x.split(","))
+    b1 = H.read_all(spec(ex["mates1"]), mate=1, **rd)
+    b2 = H.read_all(spec(ex["mates2"]), mate=2, **rd)
+    # the insert limits as the aligner sees them: less the trimming at the fragment's outer ends (aligner.h:1921-1935)
+    o1 = rd.get("trim5", 0) if pol.get("mate1_fw", True) else rd.get("trim3", 0)
+    o2 = rd.get("trim3", 0) if pol.get("mate2_fw", False) else rd.get("trim5", 0)
+    pol = dict(pol, min_ins=max(0, max(0, pol.get("min_ins", 0) - o1) - o2), max_ins=max(0, max(0, pol.get("max_ins", 250) - o1) - o2))
+    cap = 2048 if pol.get("all_hits") else 2 * pol.get("khits", 1)
+    per = T.oracle_pair_results(case["index"], b1, b2, pol, cap=cap)
+    hits, nh, st, pool = H.pack_hits(per, cap)
+    opts = H.out_opts(**out)
+    text, tally = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    ex["per_read"] = per
+    return b1, text, tally, opts, ex, oi
+
+
 def run_case(case):
     rd, pol, out, ex = CC.interpret(case["args"])
+    if "mates1" in ex:
+        return run_case_paired(case, rd, pol, out, ex)
     batch = H.read_all(CC.reads_spec(case), keep_raw=bool(case.get("dumps")), **rd)
     oi = T.oracle_index(case["index"])
     cap = 1024 if pol.get("all_hits") else max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
