@@ -38,15 +38,20 @@ from bowtie_amd import aligner as AL        # noqa: E402
 from bowtie_amd.synth import synth_reads_torch, synth_pairs_torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
-# HBM-side bytes per read of bt_search_kernel, measured with rocprofv3 PMC (separate --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE passes over a 16 M-read launch of the same workload, profiles/r1_final/pmc_big_n2_100_16M.txt)
-# and corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies this kernel's 128-byte
-# side-pair fetches at 64 B (calibrated on the probe kernel, whose bytes are known:
-# profiles/r1_final/calib_fetch_size.txt), so it is doubled; WRITE_SIZE calibrates exact.
-#   (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / reads = (2 x 1.297e9 + 7.11e8) x 1024 / 16e6 = 212 KB/read
-# bench.py cannot run the profiler on itself, so `traffic` is that per-read figure times the reads of one
-# launch; null for workloads not profiled.
-MEASURED_HBM_BYTES_PER_READ = {"big_n2_100": (2 * 1.297e9 + 7.11e8) * 1024.0 / 16_000_000}
+# HBM-side traffic per read, measured with rocprofv3 PMC (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE
+# passes, gfx950-corrected as MI355X_MICROARCH.md prescribes): bench.py cannot run the profiler on itself,
+# so the figures live in profiles/traffic.json keyed by (kernel template instance, workload) and are used
+# only when the kernel this run launched is the one that was profiled -- otherwise `traffic` is null.
+def measured_traffic(kernel: str, workload: str):
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if e["kernel"] == kernel and e["workload"] == workload:
+                    return e
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
 
 WORKLOADS = {
     "ecoli_v0_36": dict(index="ecoli", length=36, pol=dict(mode="v", mms=0), mm_dist=(0,), reads=4_000_000),
@@ -79,12 +84,60 @@ def algorithmic_bytes(c: dict, n_reads: int, length: int, hits: int) -> float:
         n_reads * (2.0 * length + 16.0) + hits * 36.0
 
 
-def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0):
-    """Reference bowtie (oracle/_ref, unmodified, all host cores) on a bounded FASTQ sample of the
-    same workload; falls back to the single-core C restatement if the binary is not on the box."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _gpu_sam(idx, pol, batches):
+    """SAM text of the product for a host-side sample (one ReadBatch, or two for pairs): bt_align_batch /
+    bt_align_pairs + the C++ formatter -- what bowtie-amd prints for these reads."""
+    from bowtie_amd import hostio as H
+    lib = AL.lib()
+    al = AL.Aligner(idx, pol)
+    n = batches[0].n
+    paired = len(batches) == 2
+    cap = 2 if paired else 1
+    keep = [AL.pack_batch(b) for b in batches]
+    hits = np.zeros(n * cap, dtype=A.HIT_DTYPE)
+    n_hits = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.uint8)
+    pool = np.zeros(n * cap * 12 + 1024, dtype=np.uint16)
+    hb = A.HitBatchC(cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, pool.ctypes.data, len(pool), 0)
+    if paired:
+        if lib.bt_index_load_reference(idx._h) != 0:
+            raise RuntimeError("bt_index_load_reference failed")
+        rc = lib.bt_align_pairs(al._h, C.byref(keep[0][1]), C.byref(keep[1][1]), C.byref(hb), None)
+    else:
+        rc = lib.bt_align_batch(al._h, C.byref(keep[0][1]), C.byref(hb), None)
+    if rc != 0:
+        raise RuntimeError("GPU search of the diff sample failed: " + AL.strerror(rc))
+    opts = H.out_opts(sam=True, khits=1)
+    if paired:
+        text, _ = H.format_pairs(batches[0], batches[1], hits, n_hits, status, pool, cap, idx.refnames, idx.reflens, opts)
+    else:
+        text, _ = H.format_hits(batches[0], hits, n_hits, status, pool, cap, idx.refnames, idx.reflens, opts)
+    al.close()
+    return text
+
+
+def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: float = 10.0):
+    """Reference bowtie (oracle/_ref, unmodified) on bounded FASTQ samples of the same workload, on this
+    box's host cores: a -p sweep (two sample sizes per setting: the difference cancels index load and
+    thread start-up), -p 1, the reference's own "Time searching" (-t), and -- parity at this scale,
+    against the real thing -- the reference's SAM for the first sample compared line by line with the
+    product's SAM for the same reads.  Falls back to the single-core C restatement when the binary is
+    not on the box."""
+    import re
     import subprocess
     import tempfile
-    from bowtie_amd.synth import synth_reads, write_fastq
+    from bowtie_amd.synth import synth_reads, synth_pairs, write_fastq
     pol = wl["pol"]
     args = ["-v", str(pol["mms"])] if pol["mode"] == "v" else ["-n", str(pol["mms"]), "-l", "28", "-e", "70"]
     if pol.get("best"):
@@ -94,39 +147,74 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
         args += ["-X", str(pol.get("max_ins", 250))]
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
     cores = os.cpu_count() or 1
+    unit = 2 if paired else 1                      # reads per sample item
     if os.path.exists(ref_bin):
-        # two runs of different size: the difference cancels the fixed cost (index load from the
-        # page cache, spawning `cores` threads), leaving the reference's search throughput
-        runs = []
         with tempfile.TemporaryDirectory() as td:
-            n = 200_000
-            for attempt in range(2):
-                fq = os.path.join(td, "s.fq")
+            def make(n, seed):
+                fq = os.path.join(td, "s%d" % seed)
                 if paired:
-                    from bowtie_amd.synth import synth_pairs
-                    n = min(n, 400_000)                     # the numpy pair generator is a python loop
-                    b1, b2 = synth_pairs(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
-                    write_fastq(b1, fq + ".1"); write_fastq(b2, fq + ".2")
-                    inputs = ["-1", fq + ".1", "-2", fq + ".2"]
-                else:
-                    batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321 + attempt)
-                    write_fastq(batch, fq)
-                    inputs = [fq]
+                    b = synth_pairs(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=seed)
+                    write_fastq(b[0], fq + ".1.fq"); write_fastq(b[1], fq + ".2.fq")
+                    return list(b), ["-1", fq + ".1.fq", "-2", fq + ".2.fq"]
+                b = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=seed)
+                write_fastq(b, fq + ".fq")
+                return [b], [fq + ".fq"]
+
+            def run(p, inputs, out=os.devnull, extra=()):
                 t0 = time.perf_counter()
-                p = subprocess.run([ref_bin, "--wrapper", "basic-0", "-p", str(cores)] + args +
-                                   ["-x", base] + inputs + [os.devnull], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                r = subprocess.run([ref_bin, "--wrapper", "basic-0", "-t", "-p", str(p)] + args + list(extra) +
+                                   ["-x", base] + inputs + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 wall = time.perf_counter() - t0
-                if p.returncode != 0:
-                    break
-                runs.append((n, wall))
-                n = int(min(8_000_000, max(600_000, 2.0 * seconds * n / wall)))
-        if len(runs) == 2:
-            (n1, t1), (n2, t2) = runs
-            rate = (n2 - n1) / (t2 - t1) if t2 > 1.2 * t1 else n2 / t2
-            return {"value": rate, "unit": "reads/s", "cores": cores, "kind": "reference",
-                    "sample": "unmodified bowtie-align-s -p %d %s on the same index: %d reads in %.2fs and %d reads "
-                              "in %.2fs wall (incl. index load); value = (n2-n1)/(t2-t1)" %
-                              (cores, " ".join(args), n1, t1, n2, t2)}
+                if r.returncode != 0:
+                    raise RuntimeError("reference failed: " + r.stderr.decode(errors="replace")[-300:])
+                m = re.search(r"Time searching: (\d+):(\d+):(\d+)", r.stderr.decode(errors="replace"))
+                ts = int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3)) if m else None
+                return wall, ts
+
+            nA = 40_000 if paired else 200_000
+            bA, inA = make(nA, 4321)
+            # size the larger sample from a first run at all cores
+            wA, _ = run(cores, inA)
+            nB = int(min(2_000_000 // unit if paired else 4_000_000, max(3 * nA, seconds * nA / max(wA, 0.5))))
+            if paired:
+                nB = min(nB, 300_000)              # the numpy pair generator is a python loop
+            bB, inB = make(nB, 4322)
+            sweep = {}
+            for p in sorted({min(32, cores), min(64, cores), min(128, cores), cores}):
+                w1, _ = run(p, inA)
+                w2, ts2 = run(p, inB)
+                rate = (nB - nA) * unit / (w2 - w1) if w2 > 1.15 * w1 else nB * unit / w2
+                sweep[p] = {"reads_per_s": rate, "n1": nA * unit, "t1": w1, "n2": nB * unit, "t2": w2, "time_searching_s": ts2}
+            best_p = max(sweep, key=lambda k: sweep[k]["reads_per_s"])
+            # one core
+            n1 = max(2000, int(nA * 0.02))
+            b1, in1 = make(n1, 4323)
+            w1a, _ = run(1, in1)
+            n1b = 3 * n1
+            b1b, in1b = make(n1b, 4324)
+            w1b, _ = run(1, in1b)
+            p1 = (n1b - n1) * unit / (w1b - w1a) if w1b > 1.15 * w1a else n1b * unit / w1b
+            out = {"value": sweep[best_p]["reads_per_s"], "unit": "reads/s", "cores": best_p, "kind": "reference",
+                   "host_cores": cores, "cpu_model": _cpu_model(), "p1_value": p1,
+                   "time_searching_s": sweep[best_p]["time_searching_s"], "p_sweep": sweep,
+                   "sample": "unmodified bowtie-align-s %s on the same index, -p sweep; per setting %d and %d reads, "
+                             "value = (n2-n1)/(t2-t1) of the fastest setting (-p %d)" % (" ".join(args), nA * unit, nB * unit, best_p)}
+            # parity against the reference itself on the first sample (output order: --reorder = input order)
+            if idx is not None:
+                sam_path = os.path.join(td, "ref.sam")
+                run(best_p, inA, out=sam_path, extra=["-S", "--sam-nohead", "--reorder"])
+                with open(sam_path, "rb") as f:
+                    want = f.read().split(b"\n")
+                got = _gpu_sam(idx, A.make_policy(**pol), bA).split(b"\n")
+                bad = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))
+                out["reads_diffed_vs_reference"] = nA * unit
+                out["diff_mismatches"] = bad
+                if bad:
+                    for a, b in zip(got, want):
+                        if a != b:
+                            out["first_diff"] = {"got": a.decode(errors="replace")[:300], "want": b.decode(errors="replace")[:300]}
+                            break
+            return out
     # port: the C restatement, one core
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as OL
@@ -134,12 +222,16 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, seconds: float = 12.0
     oi = OL.OracleIndex(base)
     opol = OL.make_policy(**pol)
     n = 2000
-    batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321)
     t0 = time.perf_counter()
-    R.oracle_search(oi, opol, batch)
+    if paired:
+        b1, b2 = synth_pairs(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321)
+        R.oracle_search_pairs(oi, opol, b1, b2)
+    else:
+        batch = synth_reads(text_np, n, wl["length"], mm_dist=wl["mm_dist"], seed=4321)
+        R.oracle_search(oi, opol, batch)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic %d-bp reads through oracle/bt_oracle.c via ctypes, %.2fs" % (n, wl["length"], dt)}
+    return {"value": n * unit / dt, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": "%d synthetic %d-bp reads through oracle/bt_oracle.c via ctypes, %.2fs" % (n * unit, wl["length"], dt)}
 
 
 def main():
@@ -153,8 +245,11 @@ def main():
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--verify", action="store_true",
-                    help="after the timed steps, re-check every reported hit of the last step against the genome (bowtie_amd/verify.py)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false",
+                    help="skip re-checking every reported hit of the last step against the genome (bowtie_amd/verify.py; unpaired workloads)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the workload's reads per GPU (default); strong: that many reads in total, sharded over the GPUs")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
     args = ap.parse_args()
 
@@ -163,13 +258,27 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local = local % torch.cuda.device_count()      # several ranks may share a GPU (gloo, tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
     wl = WORKLOADS[args.workload]
     n = args.reads or wl["reads"]
+    n_total = n
+    shard = None
+    if args.scaling == "strong":
+        # BASELINE config 4 as written: the reads are one pool, sharded contiguously by rank
+        per = n // world
+        lo = rank * per + min(rank, n % world)
+        n = per + (1 if rank < n % world else 0)
+        shard = (lo, lo + n)
+    if wl.get("paired"):
+        args.verify = False
     L = wl["length"]
 
     # ---- index: in HBM before anything is timed ------------------------------------------------
@@ -192,7 +301,10 @@ def main():
     if paired:
         rb, rb2 = synth_pairs_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
     else:
-        rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
+        if shard is not None:
+            rb = synth_reads_torch(text_t, n_total, L, mm_dist=wl["mm_dist"], seed=1000, shard=shard)
+        else:
+            rb = synth_reads_torch(text_t, n, L, mm_dist=wl["mm_dist"], seed=1000 + rank, first_id=rank * n)
     if not args.verify:
         del text_t
     hit_cap = 2 if paired else 1
@@ -295,23 +407,39 @@ def main():
              100.0 * it[it > 20000].sum().item() / max(1.0, it.sum().item())))
     aligned = int((n_hits > 0).sum().item())
     bad = int(((status & (A.BT_ST_OVERFLOW | A.BT_ST_MMPOOL)) != 0).sum().item())
-    tot = torch.tensor([wall, float(aligned), float(n), float(bad)], dtype=torch.float64, device=dev)
+    # HitSink's five counters (hit.h:169-175, 280-289) for this rank's shard of the last step, + reads and
+    # reads the product could not finish: one int64 all-reduce over xGMI is the whole collective
+    mult = 2 if paired else 1
+    mh = int(pol.mhits)
+    maxv = 0xFFFFFFFF if mh == 0xFFFFFFFF else mh * mult
+    nh = n_hits.to(torch.int64) & 0xFFFFFFFF
+    is_max = nh > maxv
+    is_al = (nh > 0) & ~is_max
+    kk = (0x7FFFFFFF if pol.all_hits else int(pol.khits) * mult)
+    rep = torch.where(is_al, nh.clamp(max=kk), torch.zeros_like(nh)).sum()
+    cnt5 = torch.stack([is_al.sum(), rep if not paired else torch.zeros_like(rep), rep if paired else torch.zeros_like(rep),
+                        (nh == 0).sum(), is_max.sum(), torch.tensor(n, device=dev), torch.tensor(bad, device=dev)]).to(torch.int64)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # the hit-count reduce over xGMI
-        wall = float(mx[0].item())
-    aligned_all, reads_all, bad_all = float(tot[1].item()), float(tot[2].item()), float(tot[3].item())
+        if args.dist_backend != "nccl":
+            cnt5, wall_t = cnt5.cpu(), wall_t.cpu()
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt5, op=dist.ReduceOp.SUM)     # the hit-count reduce
+        wall = float(wall_t[0].item())
+    c5 = [int(x) for x in cnt5.tolist()]
+    aligned_all, reads_all, bad_all = float(c5[0] + c5[4]), float(c5[5]), float(c5[6])
 
     if rank == 0:
         per_launch = {k: v / max(1, args.steps) for k, v in c.items()}
         kavg = sum(kernel_ms) / len(kernel_ms)
+        kname = (lib.bt_ctx_last_kernel_name(pipes[0]["al"]._h) or b"").decode()
+        tr = measured_traffic(kname, args.workload)
         abytes = algorithmic_bytes(per_launch, n * (2 if paired else 1), L, aligned * (2 if paired else 1))
         achieved = abytes / (kavg * 1e-3) / 1e9
         out = {
             "metric": "aligned reads/sec (whole node)", "value": reads_all * (2 if paired else 1) * args.steps / wall,
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": args.workload, "index": index_note, "read_len": L,
                        "policy": wl["pol"], "reads_per_gpu_per_step": n * (2 if paired else 1),
@@ -319,16 +447,17 @@ def main():
                        "pairs_per_gpu_per_step": n if paired else None,
                        "reads_with_alignment_per_s": aligned_all * args.steps / wall,
                        "pct_aligned": 100.0 * aligned_all / reads_all, "reads_overflowed": bad_all,
+                       "hit_counters_last_step": {"aligned": c5[0], "reported": c5[1], "reported_paired": c5[2],
+                                                  "unaligned": c5[3], "maxed": c5[4]},
                        "pipelined_contexts": len(pipes),
                        "hits_verified_against_text": verified["checked"] if verified else None,
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (MEASURED_HBM_BYTES_PER_READ[args.workload] * n
-                                     if args.workload in MEASURED_HBM_BYTES_PER_READ and not args.genome else None),
-                         "traffic_note": "rocprofv3 (2 x FETCH_SIZE + WRITE_SIZE) per read, gfx950-calibrated (profiles/r1_final/calib_fetch_size.txt), x reads per launch",
+                         "traffic": (tr["hbm_bytes_per_read"] * n * mult if tr and not args.genome else None),
+                         "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this kernel on this workload in profiles/traffic.json"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
-                         "kernel": "bt_best_kernel" if wl["pol"].get("best") else "bt_search_kernel", "kernel_ms_avg": kavg,
+                         "kernel": kname, "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": abytes,
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n,
@@ -336,7 +465,10 @@ def main():
                          "wave_rounds_per_launch": per_launch["wave_rounds"]},
         }
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(base, wl, text_np)
+            cb = cpu_baseline(base, wl, text_np, idx)
+            out["cpu_baseline"] = cb
+            out["config"]["reads_diffed_vs_reference"] = cb.get("reads_diffed_vs_reference")
+            out["config"]["diff_mismatches"] = cb.get("diff_mismatches")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

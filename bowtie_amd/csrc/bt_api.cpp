@@ -55,6 +55,7 @@ struct bt_ctx {
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
 	uint32_t last_retried = 0;
+	char last_kernel[64] = "";         /* the kernel variant the last batch ran (as rocprofv3 names it) */
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
 	uint32_t *d_order = nullptr, *d_hist = nullptr; uint8_t* d_bucket = nullptr; uint32_t orderCap = 0;
@@ -321,6 +322,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_best_kernel");
 	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
@@ -414,6 +416,13 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.poolIn = nullptr; A.poolInCount = nullptr;
 	A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
 	A.heavyRounds = c->heavy0;
+	{
+		/* the template instance bt_launch_search picks (bt_kernels.hip) */
+		const bool ext = A.poolIn || A.poolOut || A.order;
+		const int o = rl == 2 ? 3 : (rl ? (c->occ == 1 ? 1 : 2) : (c->occ < 1 ? 1 : (c->occ > 4 ? 4 : c->occ)));
+		snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<%d,%s,%s,%s>", o, ext ? "true" : "false",
+		         rl ? "true" : "false", rl == 2 ? "true" : "false");
+	}
 	if (bt_launch_search(&A, nBlocks, c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
 	if (offload) {
 		/* level 1: the parked reads, one per lane; those that reach heavy1 rounds move on to pool 2 */
@@ -634,6 +643,8 @@ extern "C" float bt_ctx_last_kernel_ms(bt_ctx* c)
 }
 
 /* profiling build only (-DBT_PROFILE): wavefront cycles per automaton section, PS_N values */
+extern "C" const char* bt_ctx_last_kernel_name(bt_ctx* c) { return c ? c->last_kernel : ""; }
+
 extern "C" int bt_ctx_prof_sections(bt_ctx* c, uint64_t* out, int n)
 {
 	if (!c || !out) return BT_ERR_ARG;

@@ -82,14 +82,29 @@ def write_fastq(batch: ReadBatch, path: str) -> None:
 # ---- torch twin: batches generated directly in HBM (bench.py) -------------------------------
 def synth_reads_torch(text_t, n: int, length: int, mm_dist=(0, 1, 2, 2, 3, 4), seed: int = 12345,
                       n_frac: float = 0.01, qlo: int = 10, qhi: int = 40, first_id: int = 0,
-                      global_seed: int = 0, stride: int | None = None, chunk: int = 2_000_000):
+                      global_seed: int = 0, stride: int | None = None, chunk: int = 2_000_000,
+                      shard: tuple | None = None):
     """text_t: uint8 torch tensor (codes 0..3) on the target device.  Returns a dict of device
     tensors {seq [n,stride] u8, qual [n,stride] u8, len [n] i16 (bit pattern of u16), seed [n] i32
     (bit pattern of u32)} laid out as bt_read_batch wants.  Same distribution as synth_reads()
     (not the same stream: torch's generator); per-read seeds follow genRandSeed (pat.cpp:21-57)
-    with names r<first_id + i>."""
+    with names r<first_id + i>.
+    shard = (lo, hi): only reads [lo, hi) of the n-read set (every chunk of `chunk` reads has its own
+    generator stream, so a shard holds exactly the reads the whole set has at those positions)."""
     import torch
     dev = text_t.device
+    if shard is not None:
+        lo_s, hi_s = shard
+        parts = []
+        for c0 in range((lo_s // chunk) * chunk, hi_s, chunk):
+            m = min(chunk, n - c0)
+            part = synth_reads_torch(text_t, m, length, mm_dist, seed * 1000003 + c0 // chunk + 1, n_frac, qlo, qhi,
+                                     first_id + c0, global_seed, stride, chunk)
+            a, b = max(lo_s, c0) - c0, min(hi_s, c0 + m) - c0
+            parts.append({k: (v[a:b] if hasattr(v, "shape") else v) for k, v in part.items()})
+        out = {k: (torch.cat([p_[k] for p_ in parts]) if hasattr(parts[0][k], "shape") else parts[0][k]) for k in parts[0]}
+        out["n"] = hi_s - lo_s
+        return out
     stride = stride or max(16, (length + 15) & ~15)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)

@@ -217,6 +217,8 @@ int  bt_ctx_counts(bt_ctx* ctx, bt_op_counts* out, int reset);
 /* milliseconds the search kernel(s) of the last bt_align_batch[_device] call took, measured with
  * HIP events on the ctx stream (valid after bt_ctx_sync). */
 float bt_ctx_last_kernel_ms(bt_ctx* ctx);
+/* name of the kernel (template instance) the last batch ran, as a profiler lists it */
+const char* bt_ctx_last_kernel_name(bt_ctx* ctx);
 
 const char* bt_strerror(int code);
 const char* bt_version(void);

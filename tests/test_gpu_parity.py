@@ -336,3 +336,26 @@ def test_gpu_paired_config5_shape(gidx):
     s2 = ReadBatch(b2.seq[idx], b2.qual[idx], b2.len[idx], b2.seed[idx], [b2.names[i] for i in idx])
     T.compare_results([r1[i] for i in idx], T.oracle_pair_results("e_coli", s1, s2, kw), "config-5 shape")
     assert sum(1 for h, _, _ in r1 if h) > 15000
+
+
+def test_gpu_bench_two_ranks_equal_one(tmp_path):
+    """bench.py's N > 1 path (init_process_group, read sharding, the int64 counter all-reduce): two ranks
+    sharing the one GPU over gloo, strong scaling, must report the same hit counters as one rank over
+    the same read pool."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(T.ROOT, "bench.py")
+    common = ["--workload", "ecoli_n2_100", "--reads", "300000", "--steps", "1", "--warmup", "0", "--no-cpu",
+              "--scaling", "strong", "--no-verify"]
+    one = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", bench, "--gpus", "2",
+                          "--dist-backend", "gloo"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()[-2000:]
+    j1 = json.loads(one.stdout.decode().strip().split("\n")[-1])
+    j2 = json.loads(two.stdout.decode().strip().split("\n")[-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert j1["config"]["hit_counters_last_step"] == j2["config"]["hit_counters_last_step"]
+    assert j1["config"]["hit_counters_last_step"]["aligned"] > 200000
