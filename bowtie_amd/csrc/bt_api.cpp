@@ -38,6 +38,7 @@ struct bt_ctx {
 	BfProgram* d_bprog = nullptr; BtIndexDev* d_ix = nullptr; BtBatchDev* d_batch = nullptr;
 	BfProgram* d_bprog_pe = nullptr; bool have_pe = false;      /* the paired program, compiled on first use */
 	uint32_t* arenas = nullptr; uint32_t arenaWords = 0; uint32_t arenaLanes = 0;
+	uint32_t* bigArenas = nullptr; uint32_t* retryList = nullptr; uint32_t retryCap = 0;   /* on-device second pass */
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -54,7 +55,7 @@ struct bt_ctx {
 	uint32_t heavy0 = 0, heavy1 = 0;
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
-	uint32_t last_retried = 0;
+	uint32_t last_retried = 0, last_dev_retried = 0;
 	char last_kernel[64] = "";         /* the kernel variant the last batch ran (as rocprofv3 names it) */
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
@@ -282,6 +283,8 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->d_ix) (void)hipFree(c->d_ix);
 	if (c->d_batch) (void)hipFree(c->d_batch);
 	if (c->arenas) (void)hipFree(c->arenas);
+	if (c->bigArenas) (void)hipFree(c->bigArenas);
+	if (c->retryList) (void)hipFree(c->retryList);
 	if (c->stage) (void)hipFree(c->stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -321,9 +324,27 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
+	A.workList = nullptr; A.workCount = nullptr;
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_best_kernel");
 	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
+	if (!c->is_big && env_u32("BT_BEST_DEVICE_RETRY", 1)) {
+		/* reads that outgrew their arena: collected and searched again on the stream, 1024 lanes with 16 MB
+		 * arenas each -- the caller of the device-pointer entry points sees finished results only */
+		const uint32_t bigWords = 1u << 22, bigLanes = 1024u;
+		if (!c->bigArenas) HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u));
+		if (c->retryCap < in->n_reads) {
+			if (c->retryList) (void)hipFree(c->retryList);
+			c->retryList = nullptr;
+			HIPCHK(hipMalloc((void**)&c->retryList, (size_t)in->n_reads * 4u));
+			c->retryCap = in->n_reads;
+		}
+		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 2, c->stream) != 0) return BT_ERR_DEVICE;
+		BtBestArgs A2 = A;
+		A2.arenas = c->bigArenas; A2.arenaWords = bigWords; A2.nextRead = c->d_cursor + 3;
+		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2;
+		if (bt_launch_best(&A2, bigLanes / BT_BLOCK, c->stream) != 0) return BT_ERR_DEVICE;
+	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
 	return BT_OK;
@@ -631,6 +652,7 @@ extern "C" int bt_ctx_sync(bt_ctx* c)
 	if (!c) return BT_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipMemcpy(&c->last_mm_used, c->d_cursor + 1, 4, hipMemcpyDeviceToHost));
+	if (c->best && !c->is_big) HIPCHK(hipMemcpy(&c->last_dev_retried, c->d_cursor + 2, 4, hipMemcpyDeviceToHost));
 	return BT_OK;
 }
 
@@ -657,7 +679,7 @@ extern "C" int bt_ctx_prof_sections(bt_ctx* c, uint64_t* out, int n)
 extern "C" void bt_ctx_set_iters_buffer(bt_ctx* c, uint32_t* dev_ptr) { if (c) c->iters_dev = dev_ptr; }
 
 extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
-extern "C" uint32_t bt_ctx_last_retried(bt_ctx* c) { return c ? c->last_retried : 0; }
+extern "C" uint32_t bt_ctx_last_retried(bt_ctx* c) { return c ? c->last_retried + c->last_dev_retried : 0; }
 
 extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 {

@@ -33,10 +33,11 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 	X.cap = A.arenaWords;
 	X.ix = IX; X.P = &PROG; X.ref = &REF;
 	const bool paired = PROG.paired != 0;
-	const uint32_t n = BATCH.n_reads;
+	const uint32_t n = A.workList ? *A.workCount : BATCH.n_reads;
 	for (;;) {
-		const uint32_t rd = atomicAdd(A.nextRead, 1u);
-		if (rd >= n) break;
+		const uint32_t w = atomicAdd(A.nextRead, 1u);
+		if (w >= n) break;
+		const uint32_t rd = A.workList ? A.workList[w] : w;
 		/* a read that outgrows its arena is searched again by the host through the twin context:
 		 * its partial work is not tallied */
 		const BfLane before = X;
@@ -55,6 +56,17 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 		atomicAdd(&A.counts[CN_RSTARTS], (unsigned long long)X.c_rst); atomicAdd(&A.counts[CN_FRAMES], (unsigned long long)X.c_frames);
 		atomicAdd(&A.counts[CN_SAMEPAIR], (unsigned long long)X.c_same);
 	}
+}
+
+__global__ void bt_collect_flagged_kernel(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && (status[i] & flag)) list[atomicAdd(count, 1u)] = i;
+}
+extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, void* stream)
+{
+	hipLaunchKernelGGL(bt_collect_flagged_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, n, flag, list, count);
+	return (int)hipGetLastError();
 }
 
 extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)

@@ -45,9 +45,13 @@ struct BtBestArgs {
 	uint32_t   arenaWords;
 	uint32_t*  nextRead;
 	unsigned long long* counts;
+	/* second pass over the reads that outgrew their arena in the first: their ids and how many */
+	const uint32_t* workList; const uint32_t* workCount;
 };
 
 extern "C" {
+/* ids of the reads whose status has `flag` set -> list[0 .. *count) (order unspecified) */
+int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, void* stream);
 int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream);
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */
