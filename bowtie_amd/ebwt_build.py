@@ -190,7 +190,7 @@ def suffix_array(s: torch.Tensor) -> torch.Tensor:
             rank[el] = g
         del staged
         h *= 2
-        if h > 4 * (n + 1):
+        if h > 8 * (n + 1) + 128:
             raise RuntimeError("suffix_array: doubling did not converge")
     return sa
 

@@ -54,14 +54,18 @@ def interpret(args):
         elif a == "--maxbts": pol["max_bts"] = int(next(it))
         elif a == "-y": pol["max_bts"] = 0x7FFFFFFF
         elif a == "-o": next(it)                       # SA sampling only: results do not depend on it
+        elif a == "--quiet": ex["quiet"] = True
+        elif a == "-q": rd["fmt"] = "fastq"
+        elif a == "--allow-contain": pol["allow_contain"] = True
+        elif a == "--pairtries": pol["pair_tries"] = int(next(it))
         elif a == "-f": rd["fmt"] = "fasta"
         elif a == "-r": rd["fmt"] = "raw"
         elif a == "-c": rd["fmt"] = "cmdline"
         elif a == "-F":
             k, iv = next(it).split(",")
             rd["fmt"] = "fasta-cont"; rd["cont"] = (int(k), int(iv))
-        elif a == "-5": rd["trim5"] = int(next(it))
-        elif a == "-3": rd["trim3"] = int(next(it))
+        elif a in ("-5", "--trim5"): rd["trim5"] = int(next(it))
+        elif a in ("-3", "--trim3"): rd["trim3"] = int(next(it))
         elif a == "-s": rd["skip"] = int(next(it))
         elif a == "-u": rd["upto"] = int(next(it))
         elif a == "--seed": rd["seed"] = int(next(it))

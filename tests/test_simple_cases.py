@@ -1,0 +1,122 @@
+"""The reference's own known-answer suite (scripts/test/simple_tests.pl:42-890: 8-base genomes,
+ftabChars > genome length, every read format, -m, trimming, edits strings, paired-end geometry incl.
+--allow-contain) as data: tests/golden/simple (oracle/gen_simple_tests.py ran every case through the
+unmodified reference binary; paired cases also with --best, the aligner this build has).
+
+CPU: C++ read parsers -> oracle search -> C++ formatters == the reference's stdout.
+GPU (-m gpu): the bowtie-amd binary on the same command lines == the reference's stdout / exit status."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+import cli_cases as CC
+import common as T
+import oracle_lib as OL
+from bowtie_amd import ebwt_build as EB
+from bowtie_amd import hostio as H
+from test_ebwt_build import read_fa
+
+D = os.path.join(T.G, "simple")
+BIN = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
+
+
+def manifest():
+    with open(os.path.join(D, "MANIFEST.json")) as f:
+        return json.load(f)
+
+
+def all_runs(paired_variant="best"):
+    """(case, run): unpaired cases as the harness runs them; paired ones in their --best variant
+    (without it the reference uses PairedBWAlignerV1, which this build refuses)."""
+    out = []
+    for c in manifest()["cases"]:
+        for r in c.get("runs", []):
+            if r["variant"] == (paired_variant if c["paired"] else "asis"):
+                out.append((c, r))
+    return out
+
+
+@pytest.fixture(scope="session")
+def simple_index(tmp_path_factory):
+    """ref_<k>.fa -> index files, built by bowtie_amd/ebwt_build.py (byte-identical to bowtie-build on
+    these references: asserted when the fixtures were generated)."""
+    root = tmp_path_factory.mktemp("simple_idx")
+    built = {}
+
+    def get(ref):
+        if ref not in built:
+            names, seqs = read_fa(os.path.join(T.G, ref))
+            base = str(root / os.path.basename(ref)[:-3])
+            EB.build_index(seqs, names, base)
+            built[ref] = base
+        return built[ref]
+    return get
+
+
+def expected(run) -> bytes:
+    with gzip.open(os.path.join(T.G, run["file"]), "rb") as f:
+        return f.read()
+
+
+_oi = {}
+
+
+@pytest.mark.parametrize("case,run", all_runs(), ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+def test_simple_case_oracle_and_host_io(case, run, simple_index):
+    base = simple_index(case["ref"])
+    rd, pol, out, ex = CC.interpret(run["args"])
+    spec = lambda x: x if rd.get("fmt") == "cmdline" else ",".join(os.path.join(T.G, f) for f in x.split(","))
+    want = expected(run)
+    try:
+        if case["paired"]:
+            b1 = H.read_all(spec(case["reads"][1]), mate=1, **rd)
+            b2 = H.read_all(spec(case["reads"][3]), mate=2, **rd)
+        else:
+            b1 = H.read_all(spec(case["reads"][0]), **rd)
+    except H.ReadInputError:
+        assert run["returncode"] != 0
+        return
+    assert run["returncode"] == 0, "the reference aborted on this input; the parser must too"
+    if b1 is None:
+        assert want == b""
+        return
+    if base not in _oi:
+        _oi[base] = OL.OracleIndex(base)
+    oi = _oi[base]
+    opol = OL.make_policy(**pol)
+    import refrun as R
+    opts = H.out_opts(**out)
+    if case["paired"]:
+        cap = 4096 if pol.get("all_hits") else 2 * pol.get("khits", 1)
+        per = R.oracle_search_pairs(oi, opol, b1, b2, cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        text, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    else:
+        cap = 4096 if pol.get("all_hits") else pol.get("khits", 1)
+        per = R.oracle_search(oi, opol, b1, cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        text, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    assert text == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,run", all_runs(), ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+def test_simple_case_bowtie_amd(case, run, simple_index):
+    base = simple_index(case["ref"])
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + run["args"] + ["-x", base] + case["reads"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
+    assert (p.returncode != 0) == (run["returncode"] != 0), p.stderr.decode(errors="replace")
+    if run["returncode"] == 0:
+        assert p.stdout == expected(run)
+
+
+@pytest.mark.gpu
+def test_paired_without_best_is_refused(simple_index):
+    c = [c for c in manifest()["cases"] if c.get("paired") and c.get("runs")][0]
+    r = [r for r in c["runs"] if r["variant"] == "asis"][0]
+    p = subprocess.run([BIN] + r["args"] + ["-x", simple_index(c["ref"])] + c["reads"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=T.G, timeout=600)
+    assert p.returncode == 1 and b"add --best" in p.stderr
