@@ -52,7 +52,7 @@ struct bt_ctx {
 	                                      [3] pool1 count, [4] pool1 cursor, [5] pool2 count, [6] pool2 cursor */
 	BtPoolRec *pool1 = nullptr, *pool2 = nullptr;
 	uint32_t pool1Cap = 0, pool2Cap = 0, nSlots = 0;
-	uint32_t heavy0 = 0, heavy1 = 0;
+	uint32_t heavy0 = 0, heavy1 = 0, parkLive = 0;
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
 	uint32_t last_retried = 0, last_dev_retried = 0;
@@ -176,6 +176,12 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
 		want1 = n_reads / 64u + 4096u;
 		want2 = n_reads / 512u + 1024u;
 	}
+	if (c->parkLive > 0 && n_reads > c->nLanes) {
+		/* drain-time consolidation: at most parkLive of every 64 lanes park */
+		const uint32_t w1 = c->nLanes / 64u * c->parkLive + 4096u, w2 = w1 / 4u + 1024u;
+		if (w1 > want1) want1 = w1;
+		if (w2 > want2) want2 = w2;
+	}
 	if (c->frames && maxLen <= c->maxLen && want1 <= c->pool1Cap && want2 <= c->pool2Cap) return BT_OK;
 	ctx_free_scratch(c);
 	if (c->pool1) (void)hipFree(c->pool1);
@@ -246,6 +252,8 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	 * utilisation but lengthens the batch tail; BT_HEAVY0=<rounds> turns it on */
 	c->heavy0 = env_u32("BT_HEAVY0", 0);
 	c->heavy1 = env_u32("BT_HEAVY1", 65536);
+	/* drain-time consolidation of stragglers (see BtKernelArgs::parkLive); BT_DRAIN_PARK=0 turns it off */
+	c->parkLive = env_u32("BT_DRAIN_PARK", 0);
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_warm, sizeof(BtWarm)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
@@ -365,7 +373,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	memset(&A, 0, sizeof(A));
 	/* short reads (all of today's sequencers' single-end lengths up to 112) keep the whole read in LDS */
 	int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
-	if (rl && c->rl3 && c->heavy0 == 0 && !env_u32("BT_SCHEDULE", 0)) {
+	if (rl && c->rl3 && (c->heavy0 == 0 || env_u32("BT_RL3_WITH_HEAVY", 0)) && !env_u32("BT_SCHEDULE", 0)) {
 		uint32_t longest = maxLen;
 		if (lens_on_device && maxLen > BT_RL3_MAXLEN) {
 			/* only the row stride is known here: one small reduction over len[] settles it */
@@ -409,7 +417,8 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	const uint32_t maxBlocks = launchLanes / BT_BLOCK;
 	if (nBlocks > maxBlocks) nBlocks = maxBlocks;
-	const bool offload = c->pool1 != nullptr && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
+	const bool offload = c->pool1 != nullptr && ((c->heavy0 > 0 && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes)) ||
+	                                             (c->parkLive > 0 && in->n_reads > c->nLanes));
 	const uint32_t init[8] = {0, 0, c->nLanes, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
 	/* heavy-first schedule (see bt_weight_kernel); timed with the search since it is part of a step.
@@ -436,7 +445,8 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.nextRead = c->d_cursor;
 	A.poolIn = nullptr; A.poolInCount = nullptr;
 	A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
-	A.heavyRounds = c->heavy0;
+	A.heavyRounds = c->heavy0 ? c->heavy0 : 0xffffffffu;
+	A.parkLive = offload ? c->parkLive : 0u;
 	{
 		/* the template instance bt_launch_search picks (bt_kernels.hip) */
 		const bool ext = A.poolIn || A.poolOut || A.order;
@@ -451,13 +461,13 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		A.nextRead = c->d_cursor + 4;
 		A.poolIn = c->pool1; A.poolInCount = c->d_cursor + 3;
 		A.poolOut = c->pool2; A.poolOutCount = c->d_cursor + 5; A.poolOutCap = c->pool2Cap;
-		A.heavyRounds = c->heavy1;
+		A.heavyRounds = c->heavy0 ? c->heavy1 : 0xffffffffu;
 		if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
 		/* level 2: run whatever is left to completion */
 		A.nextRead = c->d_cursor + 6;
 		A.poolIn = c->pool2; A.poolInCount = c->d_cursor + 5;
 		A.poolOut = nullptr; A.poolOutCount = nullptr; A.poolOutCap = 0;
-		A.heavyRounds = 0xffffffffu;
+		A.heavyRounds = 0xffffffffu; A.parkLive = 0;
 		if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
 	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));

@@ -32,6 +32,10 @@ struct BtKernelArgs {
 	const BtPoolRec* poolIn;  const uint32_t* poolInCount;      /* NULL at level 0               */
 	BtPoolRec* poolOut;       uint32_t* poolOutCount;  uint32_t poolOutCap;   /* NULL at the last level */
 	uint32_t   heavyRounds;      /* park reads that reach this many rounds                       */
+	uint32_t   parkLive;         /* > 0: once the batch's cursor has run dry, a wavefront with at most this
+	                                many reads still running parks them and exits -- the stragglers are
+	                                consolidated into full wavefronts by the follow-up launch, and the CU
+	                                slots go to whatever is queued behind (the next batch's kernel)      */
 	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
 };
 

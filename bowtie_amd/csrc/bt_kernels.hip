@@ -205,7 +205,26 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
 		 * have run out of work simply carry an empty request */
-		const bool live = L.state != ST_IDLE;
+		bool live = L.state != ST_IDLE;
+		if (EXT && A.poolOut && A.parkLive) {
+			/* drain-time consolidation: the cursor is dry (some lane of this wavefront found it so) and only
+			 * a few reads are still running here */
+			const unsigned long long lv = __ballot(live);
+			if (lv != 0 && __ballot(drained) != 0 && (uint32_t)__builtin_popcountll(lv) <= A.parkLive) {
+				if (live) {
+					const uint32_t slot = atomicAdd(A.poolOutCount, 1u);
+					if (slot < A.poolOutCap) {
+						BtPoolRec* r = A.poolOut + slot;
+						BT_UNROLL
+						for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); ((BtU4*)r->w)[k] = v; }
+						{ BtU4 v; v.x = S.slot; v.y = 0; v.z = 0; v.w = 0; ((BtU4*)r->w)[12] = v; }
+						{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; ((BtU4*)r->w)[13] = v; }
+						{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); ((BtU4*)r->w)[14] = v; }
+						L.state = ST_IDLE; live = false; drained = true;
+					}
+				}
+			}
+		}
 		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
 		if (__ballot(live) == 0) break;
 		/* op counters: wave-uniform tallies in scalar registers (ballot + popcount), flushed once
