@@ -7,6 +7,7 @@ BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, B
 BT_FMT_FASTQ, BT_FMT_FASTA, BT_FMT_RAW, BT_FMT_CMDLINE, BT_FMT_FASTA_CONT = range(5)
 BT_QUAL_PHRED33, BT_QUAL_PHRED64, BT_QUAL_SOLEXA64 = range(3)
 BT_MODE_V, BT_MODE_N = 0, 1
+BT_INDEX_BT2, BT_INDEX_EBWT, BT_INDEX_BT2L, BT_INDEX_EBWTL, BT_INDEX_SWAPPED = 0, 1, 2, 3, 16
 BT_ST_SKIPPED, BT_ST_HITCAP, BT_ST_TOOSHORT, BT_ST_OVERFLOW, BT_ST_MMPOOL = 1, 2, 4, 8, 16
 
 
@@ -48,7 +49,8 @@ class OpCounts(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("len", C.c_uint32), ("n_pat", C.c_uint32), ("n_frag", C.c_uint32),
                 ("ftab_chars", C.c_uint32), ("off_rate", C.c_uint32), ("z_off", C.c_uint32),
-                ("ebwt_bytes", C.c_uint64), ("offs_bytes", C.c_uint64), ("has_mirror", C.c_int32)]
+                ("ebwt_bytes", C.c_uint64), ("offs_bytes", C.c_uint64), ("has_mirror", C.c_int32),
+                ("variant", C.c_int32)]
 
 
 class ReadOpts(C.Structure):

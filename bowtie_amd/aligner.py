@@ -20,7 +20,7 @@ from .reads import ReadBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("BT_LIB", "libbowtie_amd.so"))
 EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_refname",
-           "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
+           "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_index_digest", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
            "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_ctx_sync", "bt_ctx_last_kernel_ms", "bt_ctx_last_kernel_name", "bt_ctx_last_mm_used", "bt_ctx_last_retried",
            "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase", "bt_bench_gather",
            "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_error", "bt_reads_close", "bt_format_hits", "bt_format_pairs",
@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
         L.bt_index_reflen.argtypes = [C.c_void_p, C.c_uint32]
         L.bt_index_reflen.restype = C.c_uint32
         L.bt_index_restore_text.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
+        L.bt_index_digest.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]
         L.bt_index_free.argtypes = [C.c_void_p]
         L.bt_index_free.restype = None
         L.bt_ctx_create.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.c_void_p, C.POINTER(C.c_void_p)]
@@ -108,11 +109,18 @@ def strerror(code: int) -> str:
     return lib().bt_strerror(code).decode()
 
 
+def index_digest(base: str, mirror: bool = False):
+    """bt_index_digest: [variant | swapped, len, digests of ebwt, ftab, eftab, offs, plen+rstarts, scalars]."""
+    out = (C.c_uint64 * 8)()
+    rc = lib().bt_index_digest(base.encode(), int(mirror), out)
+    if rc != A.BT_OK:
+        raise BowtieAmdError(rc, "bt_index_digest(%s)" % base)
+    return [int(x) for x in out]
+
+
 def restore_text(base: str) -> np.ndarray:
     """Joined reference text (codes 0..3) of an index, recovered on the host (bowtie-inspect's job)."""
-    with open(base + ".1.ebwt", "rb") as f:
-        hdr = np.frombuffer(f.read(8), dtype="<u4")
-    out = np.zeros(int(hdr[1]), dtype=np.uint8)
+    out = np.zeros(index_digest(base)[1], dtype=np.uint8)
     rc = lib().bt_index_restore_text(base.encode(), out.ctypes.data, len(out))
     if rc != A.BT_OK:
         raise BowtieAmdError(rc, "bt_index_restore_text(%s)" % base)

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <exception>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -19,6 +20,7 @@
 
 struct bt_index {
 	int device = 0;
+	int variant = 1;               /* which of .bt2/.ebwt/.bt2l/.ebwtl the base named (bt_host_index_variant) */
 	bool has_mirror = false;
 	BtIndexHost host[2];           /* big arrays are released after upload; names/plen stay */
 	BtIndexDev  dev[2];
@@ -100,9 +102,13 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 	ix->device = device;
 	ix->has_mirror = need_mirror != 0;
 	ix->base = ebwt_base;
+	ix->variant = bt_host_index_variant(ebwt_base);
+	if (ix->variant < 0) { bt_index_free(ix); return BT_ERR_IO; }
 	for (int m = 0; m < (need_mirror ? 2 : 1); m++) {
 		std::string base = std::string(ebwt_base) + (m ? ".rev" : "");
-		int rc = bt_host_index_load(base, m == 0, offrate_override, &ix->host[m]);
+		int rc;
+		try { rc = bt_host_index_load(base, m == 0, offrate_override, &ix->host[m], ix->variant); }
+		catch (const std::exception&) { rc = BT_ERR_FORMAT; }          /* a header that asks for absurd array sizes */
 		if (rc != BT_OK) { bt_index_free(ix); return rc; }
 		BtIndexHost& h = ix->host[m];
 		BtIndexDev& d = ix->dev[m];
@@ -134,6 +140,7 @@ extern "C" void bt_index_info_get(const bt_index* idx, bt_index_info* info)
 	info->off_rate = (uint32_t)h.offRate; info->z_off = h.zOff;
 	info->ebwt_bytes = idx->ebwt_bytes; info->offs_bytes = idx->offs_bytes;
 	info->has_mirror = idx->has_mirror ? 1 : 0;
+	info->variant = idx->variant | (h.swapped ? BT_INDEX_SWAPPED : 0);
 }
 extern "C" const char* bt_index_refname(const bt_index* idx, uint32_t tidx)
 {
@@ -219,18 +226,28 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
 	return BT_OK;
 }
 
+static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* stream);
+
 extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* stream, bt_ctx** out)
 {
 	if (!idx || !pol || !out) return BT_ERR_ARG;
 	*out = nullptr;
 	bt_ctx* c = new bt_ctx();
+	const int rc = ctx_init(c, idx, pol, stream);
+	if (rc != BT_OK) { bt_ctx_destroy(c); return rc; }      /* whatever was allocated before the failure goes back */
+	*out = c;
+	return BT_OK;
+}
+
+static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* stream)
+{
 	c->idx = idx; c->pol = *pol;
 	c->best = pol->best != 0;
 	int rc = c->best ? bt_host_compile_best(*pol, &c->bprog) : bt_host_compile_program(*pol, &c->prog);
-	if (rc != BT_OK) { delete c; return rc; }
+	if (rc != BT_OK) return rc;
 	bool need_mirror = c->best && c->bprog.needMirror;
 	for (int i = 0; !c->best && i < c->prog.nsteps; i++) need_mirror |= c->prog.steps[i].mirror != 0;
-	if (need_mirror && !idx->has_mirror) { delete c; return BT_ERR_ARG; }
+	if (need_mirror && !idx->has_mirror) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(idx->device));
 	if (stream) c->stream = (hipStream_t)stream;
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -267,14 +284,13 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 		/* the best-first kernel is built for two waves per SIMD (248 VGPRs): two 256-lane blocks per CU */
 		c->nLanes = c->cus * 2u * BT_BLOCK;
 	}
-	*out = c;
 	return BT_OK;
 }
 
 extern "C" void bt_ctx_destroy(bt_ctx* c)
 {
 	if (!c) return;
-	(void)hipStreamSynchronize(c->stream);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->big) bt_ctx_destroy(c->big);
 	ctx_free_scratch(c);
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
@@ -491,7 +507,9 @@ extern "C" int bt_index_load_reference(bt_index* ix)
 	if (ix->d_ref) return BT_OK;
 	HIPCHK(hipSetDevice(ix->device));
 	BtRefHost R;
-	int rc = bt_host_ref_load(ix->base, ix->host[0], &R);
+	int rc;
+	try { rc = bt_host_ref_load(ix->base, ix->host[0], &R, ix->variant); }
+	catch (const std::exception&) { rc = BT_ERR_FORMAT; }
 	if (rc != BT_OK) return rc;
 	BtRefDev d;
 	memset(&d, 0, sizeof(d));
@@ -871,10 +889,41 @@ extern "C" int bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64
 {
 	if (!ebwt_base || !out) return BT_ERR_ARG;
 	BtIndexHost h;
-	int rc = bt_host_index_load(ebwt_base, true, -1, &h);
+	int rc;
+	try { rc = bt_host_index_load(ebwt_base, true, -1, &h); } catch (const std::exception&) { rc = BT_ERR_FORMAT; }
 	if (rc != BT_OK) return rc;
 	if (cap < h.len) return BT_ERR_ARG;
 	bt_host_restore_text(h, out);
+	return BT_OK;
+}
+
+/* Host-side: what an index base holds once loaded -- the variant found on disk, the text length, and a digest
+ * (FNV-1a 64) of each array of the in-memory image.  Two bases that load to the same image (a .ebwtl, .bt2 or
+ * other-endian copy of the same index) give the same digests. */
+extern "C" int bt_index_digest(const char* ebwt_base, int mirror, uint64_t out[8])
+{
+	if (!ebwt_base || !out) return BT_ERR_ARG;
+	BtIndexHost h;
+	const int variant = bt_host_index_variant(ebwt_base);
+	if (variant < 0) return BT_ERR_IO;
+	int rc;
+	try { rc = bt_host_index_load(std::string(ebwt_base) + (mirror ? ".rev" : ""), !mirror, -1, &h, variant); }
+	catch (const std::exception&) { rc = BT_ERR_FORMAT; }
+	if (rc != BT_OK) return rc;
+	auto fnv = [](const void* p, size_t n, uint64_t hsh = 1469598103934665603ull) {
+		const uint8_t* b = (const uint8_t*)p;
+		for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; }
+		return hsh;
+	};
+	out[0] = (uint64_t)variant | (h.swapped ? 16u : 0u);
+	out[1] = h.len;
+	out[2] = fnv(h.ebwt.data(), h.ebwt.size());
+	out[3] = fnv(h.ftab.data(), 4 * h.ftab.size());
+	out[4] = fnv(h.eftab.data(), 4 * h.eftab.size());
+	out[5] = fnv(h.offs.data(), 4 * h.offs.size());
+	out[6] = fnv(h.rstarts.data(), 4 * h.rstarts.size(), fnv(h.plen.data(), 4 * h.plen.size()));
+	uint32_t tail[8] = {h.zOff, h.fchr[0], h.fchr[1], h.fchr[2], h.fchr[3], h.fchr[4], (uint32_t)h.offRate, (uint32_t)h.ftabChars};
+	out[7] = fnv(tail, sizeof(tail));
 	return BT_OK;
 }
 
@@ -883,7 +932,7 @@ extern "C" const char* bt_strerror(int code)
 	switch (code) {
 	case BT_OK: return "ok";
 	case BT_ERR_IO: return "index file missing or truncated";
-	case BT_ERR_FORMAT: return "not a small little-endian lineRate-6 .ebwt index";
+	case BT_ERR_FORMAT: return "not a bowtie index this build can hold (.ebwt/.ebwtl/.bt2/.bt2l with fewer than 2^32-1 rows)";
 	case BT_ERR_ARG: return "bad argument";
 	case BT_ERR_DEVICE: return "HIP device error";
 	case BT_ERR_READ_SHORT: return "read shorter than the alignment mode allows";

@@ -126,7 +126,9 @@ enum { BR_ID = 0, BR_D01, BR_D23, BR_RDLEN /* rdepth | len<<16 */, BR_COSTHAM /*
 
 #define BF_ALW 10u     /* tops[4] bots[4] info pad; info = i | quallo<<16 | elim mask<<24 | eliminated<<28 */
 #define BF_RESERVED 64u
-#define BF_BPOOL_LIM 1927u      /* AllocOnlyPool<Branch>: 256 KB chunk / sizeof(Branch) = 136 (pool.h:198) */
+/* AllocOnlyPool<Branch>: 256 KB chunk / sizeof(Branch) (pool.h:32,198): 136 bytes in the 32-bit build, 160 in the
+ * 64-bit one (BtIndexDev::wide) */
+#define BF_BPOOL_LIM(X) ((X).ix[0].wide ? 1638u : 1927u)
 #define BF_ADV_COST_CHANGES 2
 
 struct BfChase {                  /* RangeChaser + RowChaser state */
@@ -321,7 +323,7 @@ BF_INL void pm_reset(BfLane& X, uint32_t d)                    /* PathManager::r
 BF_FN uint32_t pm_alloc_id(BfLane& X, uint32_t d)
 {
 	uint32_t cur = AW(d + LF_BP) & 0xffffu, pool = AW(d + LF_BP) >> 16;
-	if (cur + 1u >= BF_BPOOL_LIM) {
+	if (cur + 1u >= BF_BPOOL_LIM(X)) {
 		if (pool >= 2u) { X.ovf = 1; return 0; }
 		uint32_t last = AW(d + LF_BPLAST);
 		last = pool == 0 ? ((last & 0xffff0000u) | cur) : ((last & 0xffffu) | (cur << 16));

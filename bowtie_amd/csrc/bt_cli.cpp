@@ -417,11 +417,14 @@ bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), 
 /* adjustEbwtBase (ebwt.h): the prefix as given, else under $BOWTIE_INDEXES */
 std::string find_index(const std::string& base)
 {
-	if (file_exists(base + ".1.ebwt")) return base;
+	auto there = [](const std::string& b) {
+		return file_exists(b + ".1.ebwt") || file_exists(b + ".1.bt2") || file_exists(b + ".1.ebwtl") || file_exists(b + ".1.bt2l");
+	};
+	if (there(base)) return base;
 	const char* dir = getenv("BOWTIE_INDEXES");
 	if (dir && *dir) {
 		std::string p = std::string(dir) + (dir[strlen(dir) - 1] == '/' ? "" : "/") + base;
-		if (file_exists(p + ".1.ebwt")) return p;
+		if (there(p)) return p;
 	}
 	return base;
 }

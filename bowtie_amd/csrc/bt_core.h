@@ -1080,7 +1080,12 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.ra_sd + L.nmuts == 0 && !L.reportExacts) { L.ret = 0; L.state = ST_RA_END; break; }
 			{
 				const uint32_t spread = L.ra_bot - L.ra_top;
-				L.ra_r = L.ra_top + (bt_rnd_u32(L) % spread);
+				uint32_t r = bt_rnd_u32(L);
+				if (C.ix[0].wide) {                                     /* nextU<TIndexOffU>() of the 64-bit build: random_source.h:56-62 */
+					const uint64_t r64 = ((uint64_t)r << 32) | bt_rnd_u32(L);
+					r = (uint32_t)(r64 % spread);
+				} else r %= spread;
+				L.ra_r = L.ra_top + r;
 				L.ra_i = 0;
 			}
 			L.state = ST_ROW_BEGIN;

@@ -14,40 +14,193 @@ struct File {
 };
 }  // namespace
 
-int bt_host_index_load(const std::string& base, bool fw, int offrate_override, BtIndexHost* out)
+/* ---- the .ebwt family -----------------------------------------------------------------------------
+ * Four on-disk variants hold the same index (ebwt.h:2835-3445, EbwtParams::init ebwt.h:138-183):
+ *
+ *   <base>.1.ebwt   32-bit offsets, 64-byte sides in fw/bw pairs: 56 BWT bytes + 2 u32 counters
+ *                   ([A][C] after a backward side, [G][T] after a forward one), 224 rows per side
+ *   <base>.1.ebwtl  the BOWTIE_64BIT_INDEX build (btypes.h:4-14): every offset is a u64, lineRate 7,
+ *                   128-byte sides = 112 BWT bytes + 2 u64 counters, 448 rows per side
+ *   <base>.1.bt2    bowtie2-build's layout (isBt2Index, ebwt.h:173-180,2240-2328): all sides forward,
+ *   <base>.1.bt2l   sideSz - 4*OFF_SIZE BWT bytes followed by the 4 counters [A][C][G][T] before the side
+ *
+ * each in either byte order (first word 1 or 1<<24, ebwt.h:2926-2937).  Whatever the file holds, the
+ * image the kernels read is the first layout: the BWT symbols are re-dealt into 224-row sides and
+ * the counters recomputed, offsets are narrowed to 32 bits (an index of 2^32-1 or more rows is
+ * refused: device rows are u32).  What does not survive the conversion, and so is kept as a flag, is
+ * the 64-bit build's arithmetic: h.wide (see BtIndexDev::wide).                                      */
+namespace {
+struct Reader {
+	File& f; bool swap, wide, ok = true, narrow = true;
+	uint32_t u32() {
+		uint32_t v = 0;
+		if (!f.rd(&v, 4)) ok = false;
+		return swap ? __builtin_bswap32(v) : v;
+	}
+	uint64_t off() {                    /* a TIndexOffU */
+		if (!wide) return u32();
+		uint64_t v = 0;
+		if (!f.rd(&v, 8)) ok = false;
+		return swap ? __builtin_bswap64(v) : v;
+	}
+	/* n offsets -> u32 (eftab references in ftab are ~k in the file's width: the low word is ~k) */
+	bool offs(std::vector<uint32_t>& out, uint64_t n, bool check) {
+		out.resize((size_t)n);
+		if (!wide) {
+			if (!f.rd(out.data(), 4ull * n)) return ok = false;
+			if (swap) for (auto& v : out) v = __builtin_bswap32(v);
+			return true;
+		}
+		std::vector<uint64_t> buf((size_t)(n < (1u << 20) ? n : (1u << 20)));
+		for (uint64_t i = 0; i < n; ) {
+			const uint64_t m = n - i < buf.size() ? n - i : buf.size();
+			if (!f.rd(buf.data(), 8ull * m)) return ok = false;
+			for (uint64_t k = 0; k < m; k++) {
+				const uint64_t v = swap ? __builtin_bswap64(buf[(size_t)k]) : buf[(size_t)k];
+				if (check && (v >> 32) != 0 && (v >> 32) != 0xffffffffull) narrow = false;
+				out[(size_t)(i + k)] = (uint32_t)v;
+			}
+			i += m;
+		}
+		return true;
+	}
+};
+
+/* Source BWT -> the 64-byte-side layout.  sym(row) of the source: */
+struct SrcBwt {
+	const uint8_t* p; uint32_t sideSz, sideBwtSz; bool bt2;
+	uint32_t sym(uint64_t row) const {
+		const uint32_t per = sideBwtSz * 4u;
+		const uint64_t side = row / per; uint32_t co = (uint32_t)(row % per);
+		uint32_t by = co >> 2, bp = co & 3u;
+		if (!bt2 && (side & 1u) == 0) { by = sideBwtSz - by - 1u; bp ^= 3u; }    /* backward sides run the other way */
+		return (p[side * sideSz + by] >> (2u * bp)) & 3u;
+	}
+};
+
+void repack_sides(const SrcBwt& src, uint64_t srcRows, uint32_t zOff, uint32_t len, std::vector<uint8_t>* out)
+{
+	const uint32_t bwtSz = len / 4u + 1u;
+	const uint32_t numSidePairs = (bwtSz + 2u * 56u - 1u) / (2u * 56u);
+	out->assign((size_t)numSidePairs * 128u, 0);
+	uint32_t cnt[4] = {0, 0, 0, 0};                  /* occurrences in rows before the cursor, '$' not counted */
+	uint64_t row = 0;
+	for (uint32_t p = 0; p < numSidePairs; p++) {
+		uint8_t* bw = out->data() + (size_t)p * 128u; uint8_t* fwd = bw + 64;
+		for (uint32_t k = 0; k < 224u; k++, row++) {          /* backward side: stored reversed */
+			const uint32_t c = row < srcRows ? src.sym(row) : 0u;
+			if (row != zOff) cnt[c]++;
+			const uint32_t by = 56u - (k >> 2) - 1u, bp = (k & 3u) ^ 3u;
+			bw[by] |= (uint8_t)(c << (2u * bp));
+		}
+		/* after the backward side: [A][C] here, [G][T] behind the forward side -- all four as of this point */
+		memcpy(bw + 56, &cnt[0], 4); memcpy(bw + 60, &cnt[1], 4);
+		memcpy(fwd + 56, &cnt[2], 4); memcpy(fwd + 60, &cnt[3], 4);
+		for (uint32_t k = 0; k < 224u; k++, row++) {
+			const uint32_t c = row < srcRows ? src.sym(row) : 0u;
+			if (row != zOff) cnt[c]++;
+			fwd[k >> 2] |= (uint8_t)(c << (2u * (k & 3u)));
+		}
+	}
+}
+
+const char* const kExt[4] = {"bt2", "ebwt", "bt2l", "ebwtl"};
+}  // namespace
+
+/* Which of the four an index base names: bowtie prefers .bt2 over .ebwt (adjustEbwtBase, ebwt.cpp:36-48)
+ * and its wrapper picks the 64-bit binary only when there is no small index (bowtie:52-81). */
+int bt_host_index_variant(const std::string& base)
+{
+	for (int v = 0; v < 4; v++) {
+		File f(base + ".1." + kExt[v]);
+		if (f.f) return v;
+	}
+	return -1;
+}
+const char* bt_host_index_ext(int variant) { return variant >= 0 && variant < 4 ? kExt[variant] : "ebwt"; }
+
+int bt_host_index_load(const std::string& base, bool fw, int offrate_override, BtIndexHost* out, int variant)
 {
 	BtIndexHost& h = *out;
 	h = BtIndexHost();
 	h.fw = fw;
-	File f1(base + ".1.ebwt");
+	if (variant < 0) variant = bt_host_index_variant(base);
+	if (variant < 0) return BT_ERR_IO;
+	const bool bt2 = (variant & 1) == 0, wide = variant >= 2;
+	const std::string ext = kExt[variant];
+	File f1(base + ".1." + ext);
 	if (!f1.f) return BT_ERR_IO;
 	uint32_t one = 0;
 	if (!f1.rd(&one, 4)) return BT_ERR_IO;
-	if (one != 1) return BT_ERR_FORMAT;                 /* other-endian or not an index */
-	if (!f1.rd(&h.len, 4) || !f1.rd(&h.lineRate, 4) || !f1.rd(&h.linesPerSide, 4) ||
-	    !f1.rd(&h.offRate, 4) || !f1.rd(&h.ftabChars, 4) || !f1.rd(&h.flags, 4)) return BT_ERR_IO;
-	/* SideLocus::initFromRow hard-codes 224 symbols per side (ebwt.h:1477): only lineRate 6,
-	 * linesPerSide 1 is a valid small index, and that is all bowtie-build emits. */
-	if (h.lineRate != 6 || h.linesPerSide != 1 || h.ftabChars < 1 || h.ftabChars > 15 ||
+	if (one != 1 && one != (1u << 24)) return BT_ERR_FORMAT;          /* not an index */
+	Reader R{f1, one != 1, wide};
+	const uint64_t len64 = R.off();
+	h.lineRate = (int32_t)R.u32(); h.linesPerSide = (int32_t)R.u32(); h.offRate = (int32_t)R.u32();
+	h.ftabChars = (int32_t)R.u32(); h.flags = (int32_t)R.u32();
+	if (!R.ok) return BT_ERR_IO;
+	/* SideLocus::initFromRow hard-codes the rows per side (ebwt.h:1469-1479): 56*OFF_SIZE*4 (48*OFF_SIZE*4 for
+	 * bt2), i.e. lineRate 6 (7 when wide) with one line per side is the only geometry that works there */
+	const int32_t wantLine = wide ? 7 : 6;
+	if (bt2) h.linesPerSide = 1;                                       /* EbwtParams::init ebwt.h:149 */
+	if (h.lineRate != wantLine || h.linesPerSide != 1 || h.ftabChars < 1 || h.ftabChars > 15 ||
 	    h.offRate < 0 || h.offRate > 31) return BT_ERR_FORMAT;
-	if (h.flags < 0 && ((-h.flags) & 4)) return BT_ERR_FORMAT;    /* EBWT_ENTIRE_REV: bt2 layout */
+	if (len64 == 0 || len64 >= 0xffffffffull) return BT_ERR_FORMAT;    /* device rows are 32-bit */
+	h.len = (uint32_t)len64;
+	h.wide = wide; h.bt2 = bt2; h.swapped = R.swap;
+	const uint32_t offSize = wide ? 8u : 4u;
+	const uint32_t srcSideSz = 1u << h.lineRate;
+	const uint32_t srcSideBwtSz = srcSideSz - (bt2 ? 4u : 2u) * offSize;
 	const uint32_t bwtLen = h.len + 1u;
 	const uint32_t bwtSz = h.len / 4u + 1u;
-	const uint32_t numSidePairs = (bwtSz + 2u * 56u - 1u) / (2u * 56u);
-	const uint64_t ebwtTotLen = (uint64_t)numSidePairs * 128u;
+	uint64_t srcTotLen;
+	if (bt2) srcTotLen = (uint64_t)((bwtSz + srcSideBwtSz - 1u) / srcSideBwtSz) * srcSideSz;
+	else     srcTotLen = (uint64_t)((bwtSz + 2u * srcSideBwtSz - 1u) / (2u * srcSideBwtSz)) * (2u * srcSideSz);
 	const uint32_t ftabLen = (1u << (2 * h.ftabChars)) + 1u;
 	const uint32_t eftabLen = 2u * (uint32_t)h.ftabChars;
 	const uint32_t offsLen = (uint32_t)(((uint64_t)bwtLen + (1ull << h.offRate) - 1ull) >> h.offRate);
-	if (!f1.rd(&h.nPat, 4)) return BT_ERR_IO;
-	h.plen.resize(h.nPat);
-	if (!f1.rd(h.plen.data(), 4ull * h.nPat) || !f1.rd(&h.nFrag, 4)) return BT_ERR_IO;
-	h.rstarts.resize(3ull * h.nFrag);
-	h.ebwt.resize(ebwtTotLen);
-	h.ftab.resize(ftabLen);
-	h.eftab.resize(eftabLen);
-	if (!f1.rd(h.rstarts.data(), 12ull * h.nFrag) || !f1.rd(h.ebwt.data(), ebwtTotLen) ||
-	    !f1.rd(&h.zOff, 4) || !f1.rd(h.fchr, 20) || !f1.rd(h.ftab.data(), 4ull * ftabLen) ||
-	    !f1.rd(h.eftab.data(), 4ull * eftabLen)) return BT_ERR_IO;
+	const uint64_t nPat = R.off();
+	if (!R.ok) return BT_ERR_IO;
+	if (nPat == 0 || nPat > h.len) return BT_ERR_FORMAT;
+	h.nPat = (uint32_t)nPat;
+	if (!R.offs(h.plen, nPat, true)) return BT_ERR_IO;
+	const uint64_t nFrag = R.off();
+	if (!R.ok) return BT_ERR_IO;
+	if (nFrag == 0 || nFrag > h.len) return BT_ERR_FORMAT;
+	h.nFrag = (uint32_t)nFrag;
+	if (!R.offs(h.rstarts, 3ull * nFrag, true)) return BT_ERR_IO;
+	std::vector<uint8_t> src;
+	std::vector<uint8_t>& raw = (!wide && !bt2) ? h.ebwt : src;
+	raw.resize((size_t)srcTotLen);
+	if (!f1.rd(raw.data(), (size_t)srcTotLen)) return BT_ERR_IO;
+	if (R.swap && !wide && !bt2) {
+		/* the two counters behind each side are words too (ebwt.h:3154-3162); the other layouts' counters
+		 * are recomputed below and never read */
+		for (uint64_t o = 56; o + 8 <= srcTotLen; o += 64) {
+			uint32_t c[2];
+			memcpy(c, raw.data() + o, 8);
+			c[0] = __builtin_bswap32(c[0]); c[1] = __builtin_bswap32(c[1]);
+			memcpy(raw.data() + o, c, 8);
+		}
+	}
+	const uint64_t zOff = R.off();
+	uint64_t fchr[5];
+	for (int i = 0; i < 5; i++) fchr[i] = R.off();
+	if (!R.ok) return BT_ERR_IO;
+	if (zOff > h.len || fchr[4] != h.len) return BT_ERR_FORMAT;
+	for (int i = 0; i < 5; i++) { if (fchr[i] > h.len || (i && fchr[i] < fchr[i - 1])) return BT_ERR_FORMAT; h.fchr[i] = (uint32_t)fchr[i]; }
+	h.zOff = (uint32_t)zOff;
+	if (!R.offs(h.ftab, ftabLen, false) || !R.offs(h.eftab, eftabLen, true)) return BT_ERR_IO;
+	if (!R.narrow) return BT_ERR_FORMAT;
+	if (wide || bt2) {
+		SrcBwt sb{src.data(), srcSideSz, srcSideBwtSz, bt2};
+		repack_sides(sb, bwtLen, h.zOff, h.len, &h.ebwt);
+		h.lineRate = 6;
+	}
+	/* fragments must tile the joined text in order (joinedToTextOff's binary search, ebwt.h:2569-2629) */
+	for (uint32_t i = 0; i < h.nFrag; i++) {
+		const uint32_t lo = h.rstarts[3 * i], up = i + 1 < h.nFrag ? h.rstarts[3 * i + 3] : h.len;
+		if (lo >= up || up > h.len || h.rstarts[3 * i + 1] >= h.nPat) return BT_ERR_FORMAT;
+	}
 	/* reference names: '\n'-separated, '\0'-terminated (ebwt.h:3452-3531) */
 	{
 		std::string cur;
@@ -59,12 +212,14 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 		if (!cur.empty() && h.refnames.size() < h.nPat) h.refnames.push_back(cur);
 		while (h.refnames.size() < h.nPat) h.refnames.push_back(std::to_string(h.refnames.size()));
 	}
-	File f2(base + ".2.ebwt");
+	File f2(base + ".2." + ext);
 	if (!f2.f) return BT_ERR_IO;
 	if (!f2.rd(&one, 4)) return BT_ERR_IO;
-	if (one != 1) return BT_ERR_FORMAT;
-	std::vector<uint32_t> offs(offsLen);
-	if (!f2.rd(offs.data(), 4ull * offsLen)) return BT_ERR_IO;
+	if (one != (R.swap ? (1u << 24) : 1u)) return BT_ERR_FORMAT;
+	Reader R2{f2, R.swap, wide};
+	std::vector<uint32_t> offs;
+	if (!R2.offs(offs, offsLen, true)) return BT_ERR_IO;
+	if (!R2.narrow) return BT_ERR_FORMAT;
 	if (offrate_override > h.offRate && offrate_override < 32) {
 		const uint32_t diff = (uint32_t)(offrate_override - h.offRate);
 		uint32_t sampled = offsLen >> diff;
@@ -83,7 +238,7 @@ void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d)
 	memset(d, 0, sizeof(*d));
 	d->len = h.len; d->zOff = h.zOff; d->ftabChars = (uint32_t)h.ftabChars;
 	d->offRate = (uint32_t)h.offRate; d->offMask = 0xffffffffu << h.offRate;
-	d->nFrag = h.nFrag; d->nPat = h.nPat; d->fw = h.fw ? 1u : 0u;
+	d->nFrag = h.nFrag; d->nPat = h.nPat; d->fw = h.fw ? 1u : 0u; d->wide = h.wide ? 1u : 0u;
 	for (int i = 0; i < 5; i++) d->fchr[i] = h.fchr[i];
 	/* postReadInit (ebwt.h:1043-1059), restated as (side, storage-symbol) of '$' */
 	d->zSide = h.zOff / 224u;
@@ -350,23 +505,35 @@ int bt_host_compile_best_paired(const bt_policy& pol, BfProgram* prog) { return 
  * u8 first (1 = first stretch of a sequence) }; <base>.4.ebwt: the bases of all stretches, 4 per byte,
  * first base in the low bits (reference.h:35-240, ref_read.h:57-87).  A sequence whose first record
  * has len 0 is all gaps and has no index in the Ebwt (reference.h:160-176). */
-int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost* out)
+int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost* out, int variant)
 {
-	File f3(base + ".3.ebwt");
+	if (variant < 0) variant = bt_host_index_variant(base);
+	if (variant < 0) return BT_ERR_IO;
+	const std::string ext = kExt[variant];
+	File f3(base + ".3." + ext);
 	if (!f3.f) return BT_ERR_IO;
-	uint32_t one = 0, nrec = 0;
-	if (!f3.rd(&one, 4) || !f3.rd(&nrec, 4)) return BT_ERR_IO;
-	if (one != 1 || nrec == 0 || nrec > (1u << 28)) return BT_ERR_FORMAT;
+	uint32_t one = 0;
+	if (!f3.rd(&one, 4)) return BT_ERR_IO;
+	if (one != 1 && one != (1u << 24)) return BT_ERR_FORMAT;
+	Reader R3{f3, one != 1, variant >= 2};
+	const uint64_t nrec64 = R3.off();
+	if (!R3.ok) return BT_ERR_IO;
+	if (nrec64 == 0 || nrec64 > (1u << 28)) return BT_ERR_FORMAT;
+	const uint32_t nrec = (uint32_t)nrec64;
 	struct Rec { uint32_t off, len; uint8_t first; };
 	std::vector<Rec> recs(nrec);
 	uint64_t cum = 0;
 	for (uint32_t i = 0; i < nrec; i++) {
-		if (!f3.rd(&recs[i].off, 4) || !f3.rd(&recs[i].len, 4) || !f3.rd(&recs[i].first, 1)) return BT_ERR_IO;
+		const uint64_t o = R3.off(), l = R3.off();
+		if (!R3.ok || !f3.rd(&recs[i].first, 1)) return BT_ERR_IO;
+		if ((o >> 32) || (l >> 32)) return BT_ERR_FORMAT;
+		recs[i].off = (uint32_t)o; recs[i].len = (uint32_t)l;
 		cum += recs[i].len;
 	}
+	if (cum > idx.len) return BT_ERR_FORMAT;
 	std::vector<uint8_t> packed((cum + 3) / 4);
 	{
-		File f4(base + ".4.ebwt");
+		File f4(base + ".4." + ext);
 		if (!f4.f) return BT_ERR_IO;
 		if (!f4.rd(packed.data(), packed.size())) return BT_ERR_IO;
 	}

@@ -19,6 +19,9 @@ struct BtIndexHost {
 	int32_t  lineRate = 0, linesPerSide = 0, offRate = 0, ftabChars = 0, flags = 0;
 	uint32_t fchr[5] = {0, 0, 0, 0, 0};
 	bool     fw = true;
+	bool     wide = false;      /* came from a 64-bit (.ebwtl/.bt2l) build: see BtIndexDev::wide         */
+	bool     bt2 = false;       /* came in bowtie2-build's side layout                                  */
+	bool     swapped = false;   /* was written on a machine of the other byte order                      */
 	std::vector<uint8_t>  ebwt;
 	std::vector<uint32_t> plen, rstarts, ftab, eftab, offs;
 	std::vector<std::string> refnames;
@@ -27,7 +30,12 @@ struct BtIndexHost {
 
 /* Returns BT_OK or BT_ERR_*.  offrate_override (>= index offRate) subsamples offs[] the way
  * -o does (ebwt.h:2988-3001, 3301-3327); -1 keeps the index's own rate. */
-int bt_host_index_load(const std::string& base, bool fw, int offrate_override, BtIndexHost* out);
+int bt_host_index_load(const std::string& base, bool fw, int offrate_override, BtIndexHost* out, int variant = -1);
+
+/* The on-disk variant an index base names: 0 .bt2, 1 .ebwt, 2 .bt2l, 3 .ebwtl (-1: none found), in the
+ * order the reference looks for them; and its file extension. */
+int bt_host_index_variant(const std::string& base);
+const char* bt_host_index_ext(int variant);
 
 /* Fill the device-visible descriptor from host-side geometry (pointers are left to the caller). */
 void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d);
@@ -55,6 +63,6 @@ struct BtRefHost {
 	std::vector<uint32_t> bits, nmask, approxLen;
 	std::vector<uint64_t> start;
 };
-int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost* out);
+int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost* out, int variant = -1);
 
 #endif

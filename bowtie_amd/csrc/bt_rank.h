@@ -53,6 +53,11 @@ struct BtIndexDev {
 	const uint32_t* plen;
 	uint32_t len, zOff, zSide, zSym, ftabChars, offRate, offMask, nFrag, fw, nPat;
 	uint32_t fchr[5];
+	uint32_t wide;             /* the index is a 64-bit (.ebwtl) build.  Its rows still fit 32 bits here, but the
+	                              reference binary that serves it is compiled with 64-bit offsets, and two things
+	                              a user can see follow the offset width: the row a hit is reported from is drawn
+	                              with nextU<TIndexOffU>() (two draws, ebwt_search_backtrack.h:1538), and a
+	                              best-first Branch is 160 bytes, so 1638 of them fit a pool chunk (pool.h:32)   */
 };
 
 /* ---- global-memory accessors ---------------------------------------------------------------

@@ -154,7 +154,20 @@ typedef struct bt_index_info {
 	uint32_t len, n_pat, n_frag, ftab_chars, off_rate, z_off;
 	uint64_t ebwt_bytes, offs_bytes;
 	int32_t  has_mirror;
+	int32_t  variant;       /* BT_INDEX_* of the files the image was loaded from, | BT_INDEX_SWAPPED */
 } bt_index_info;
+
+/* The .ebwt family (ebwt.h:138-183, 2926-2973; btypes.h:4-28).  bt_index_load looks for them in the
+ * reference's order -- <base>.1.bt2, .1.ebwt, then the 64-bit builds .1.bt2l, .1.ebwtl (adjustEbwtBase
+ * ebwt.cpp:36-48; the `bowtie` wrapper's choice of the -l binary, bowtie:52-81) -- in either byte
+ * order, and converts what it finds to one in-memory layout.  64-bit builds load when the index has
+ * fewer than 2^32-1 rows (BT_ERR_FORMAT otherwise), and keep the two behaviours of the 64-bit
+ * binary that a user can see (see BtIndexDev::wide in csrc/bt_rank.h). */
+#define BT_INDEX_BT2      0
+#define BT_INDEX_EBWT     1
+#define BT_INDEX_BT2L     2
+#define BT_INDEX_EBWTL    3
+#define BT_INDEX_SWAPPED  16
 
 typedef struct bt_index bt_index;   /* device-resident fw (+ mirror) index image              */
 typedef struct bt_ctx   bt_ctx;     /* per-GPU stream, scratch, queues                        */
@@ -171,6 +184,10 @@ void bt_index_free(bt_index* idx);
 /* Host-side utility (no GPU): joined reference text of <base>.1.ebwt as codes 0..3, `len` bytes
  * (Ebwt::restore, ebwt.h:2793-2824; what bowtie-inspect prints).  cap = bytes available in out. */
 int  bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64_t cap);
+/* Host-side utility (no GPU): out[0] = BT_INDEX_* (| BT_INDEX_SWAPPED) found for the base, out[1] = text
+ * length, out[2..7] = FNV-1a-64 digests of the loaded image's arrays (ebwt, ftab, eftab, offs,
+ * plen+rstarts, zOff/fchr/offRate/ftabChars).  Equal digests = the same image, whatever the files. */
+int  bt_index_digest(const char* ebwt_base, int mirror, uint64_t out[8]);
 
 /* Replaces: the per-thread set-up at the top of each worker (sink, params, 1..9
  * GreedyDFSRangeSource objects; ebwt_search.cpp:1155, 2082-2134, 2413-2539).  One ctx per GPU,

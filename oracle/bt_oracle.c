@@ -383,7 +383,10 @@ static int dfs_report_full(dfs_t* s, uint32_t stackDepth, uint32_t top, uint32_t
 {
 	if (stackDepth == 0 && !s->reportExacts) return 0;
 	uint32_t spread = bot - top;
-	uint32_t r = top + (rnd_u32(s) % spread);
+	uint32_t r = rnd_u32(s);
+	if (s->ix->wide) { uint64_t r64 = ((uint64_t)r << 32) | rnd_u32(s); r = (uint32_t)(r64 % spread); }   /* nextU<TIndexOffU>() */
+	else r %= spread;
+	r += top;
 	for (uint32_t i = 0; i < spread; i++) {
 		uint32_t ri = r + i;
 		if (ri >= bot) ri -= spread;

@@ -41,6 +41,7 @@
 #define ADV_COST_CHANGES 2
 #define ADV_STEP         3
 #define BPOOL_LIM        1927u      /* chunkSz(256 KB) / sizeof(Branch)(136) */
+#define BPOOL_LIM_WIDE   1638u      /* ... / sizeof(Branch)(160) in the BOWTIE_64BIT_INDEX build (bto_index.wide) */
 #define BRANCH_BUDGET    400000     /* stand-in for ChunkPool exhaustion */
 
 /* qual.h:15, qual.cpp:4-32 */
@@ -235,6 +236,7 @@ static int cost_compare(const branch_t* a, const branch_t* b)   /* true -> b bef
 typedef struct {
 	branch_t** q; int sz, cap;
 	uint32_t bpCur, bpPool;          /* AllocOnlyPool<Branch>::cur_, curPool_ */
+	uint32_t bpLim;                  /* its lim_ (0 = BPOOL_LIM) */
 	uint32_t lastCur[64];            /* lastCurInPool_ */
 	uint16_t minCost;
 	int* btCnt;
@@ -288,7 +290,7 @@ static branch_t* heap_pop(pathman_t* pm)               /* std::pop_heap + pop_ba
 /* AllocOnlyPool<Branch>::alloc + lastId (pool.h:216-223, 320-322, 335-352) */
 static uint32_t pm_alloc_id(pathman_t* pm)
 {
-	if (pm->bpCur + 1 >= BPOOL_LIM) {
+	if (pm->bpCur + 1 >= (pm->bpLim ? pm->bpLim : BPOOL_LIM)) {
 		if (pm->bpPool < 63) pm->lastCur[pm->bpPool] = pm->bpCur;
 		pm->bpPool++; pm->bpCur = 0;
 	}
@@ -713,6 +715,7 @@ static driver_t* single_new(env_t* env, int maq, int qualOrder, const single_spe
 	d->type = DR_SINGLE; d->done = 1; d->env = env; d->maq = maq; d->qualOrder = qualOrder;
 	d->fw = sp->fw; d->mate1 = sp->mate1;
 	d->rs = (rsrc_t*)calloc(1, sizeof(rsrc_t));
+	d->pm.bpLim = sp->ebwt->wide ? BPOOL_LIM_WIDE : BPOOL_LIM;
 	d->rs->ebwt = sp->ebwt; d->rs->fw = sp->fw; d->rs->qualLim = sp->qualLim; d->rs->reportExacts = sp->reportExacts;
 	d->rs->halfAndHalf = sp->halfAndHalf; d->rs->partial = sp->partial; d->rs->maqPenalty = maq; d->rs->qualOrder = qualOrder;
 	d->rs->env = env; d->rs->curRange.top = OFF_MASK; d->rs->seedRange.top = OFF_MASK;

@@ -42,7 +42,7 @@ class OIndex(C.Structure):
                 ("ebwt", C.POINTER(C.c_uint8)), ("plen", C.POINTER(C.c_uint32)),
                 ("rstarts", C.POINTER(C.c_uint32)), ("ftab", C.POINTER(C.c_uint32)),
                 ("eftab", C.POINTER(C.c_uint32)), ("offs", C.POINTER(C.c_uint32)),
-                ("refnames", C.POINTER(C.c_char_p))]
+                ("refnames", C.POINTER(C.c_char_p)), ("wide", C.c_int32)]
 
 
 
@@ -96,7 +96,8 @@ def lib() -> C.CDLL:
 class OracleIndex:
     """fw (+ mirror) index pair loaded by the oracle's own .ebwt parser."""
 
-    def __init__(self, base: str, need_mirror: bool = True):
+    def __init__(self, base: str, need_mirror: bool = True, wide: bool = False):
+        """wide: restate bowtie-align-l (the 64-bit build) on this index's arrays (see bto_index.wide)."""
         L = lib()
         self.fw = OIndex()
         rc = L.bto_index_load(base.encode(), 1, C.byref(self.fw))
@@ -108,6 +109,9 @@ class OracleIndex:
             rc = L.bto_index_load((base + ".rev").encode(), 0, C.byref(self.bw))
             if rc:
                 raise IOError("oracle: cannot load %s.rev (rc=%d)" % (base, rc))
+        self.fw.wide = int(wide)
+        if self.bw is not None:
+            self.bw.wide = int(wide)
         self.refnames = [self.fw.refnames[i].decode() for i in range(self.fw.nPat)]
         self.reflens = [int(self.fw.plen[i]) for i in range(self.fw.nPat)]
 
