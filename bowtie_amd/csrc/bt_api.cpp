@@ -54,7 +54,7 @@ struct bt_ctx {
 	                                      [3] pool1 count, [4] pool1 cursor, [5] pool2 count, [6] pool2 cursor */
 	BtPoolRec *pool1 = nullptr, *pool2 = nullptr;
 	uint32_t pool1Cap = 0, pool2Cap = 0, nSlots = 0;
-	uint32_t heavy0 = 0, heavy1 = 0, parkLive = 0;
+	uint32_t heavy0 = 0, heavy1 = 0;
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
 	uint32_t last_retried = 0, last_dev_retried = 0;
@@ -183,12 +183,6 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
 		want1 = n_reads / 64u + 4096u;
 		want2 = n_reads / 512u + 1024u;
 	}
-	if (c->parkLive > 0 && n_reads > c->nLanes) {
-		/* drain-time consolidation: at most parkLive of every 64 lanes park */
-		const uint32_t w1 = c->nLanes / 64u * c->parkLive + 4096u, w2 = w1 / 4u + 1024u;
-		if (w1 > want1) want1 = w1;
-		if (w2 > want2) want2 = w2;
-	}
 	if (c->frames && maxLen <= c->maxLen && want1 <= c->pool1Cap && want2 <= c->pool2Cap) return BT_OK;
 	ctx_free_scratch(c);
 	if (c->pool1) (void)hipFree(c->pool1);
@@ -264,13 +258,11 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	 * +15..23 % over two blocks, profiles/README.md); BT_NO_RL3=1 keeps every launch at blocksPerCU */
 	c->rl3 = env_u32("BT_NO_RL3", 0) == 0 && c->occ == 2;
 	c->nLanes = c->cus * (c->rl3 && c->blocksPerCU < 3u ? 3u : c->blocksPerCU) * BT_BLOCK;
-	HIPCHK(hipMalloc((void**)&c->d_cursor, 32));
+	HIPCHK(hipMalloc((void**)&c->d_cursor, 64));
 	/* heavy-read offload is off by default: measured on MI355X (profiles/README.md) it raises lane
 	 * utilisation but lengthens the batch tail; BT_HEAVY0=<rounds> turns it on */
 	c->heavy0 = env_u32("BT_HEAVY0", 0);
 	c->heavy1 = env_u32("BT_HEAVY1", 65536);
-	/* drain-time consolidation of stragglers (see BtKernelArgs::parkLive); BT_DRAIN_PARK=0 turns it off */
-	c->parkLive = env_u32("BT_DRAIN_PARK", 0);
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_warm, sizeof(BtWarm)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
@@ -316,6 +308,20 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	delete c;
 }
 
+/* list of the reads a second pass takes: room for one read in 16 (at least 64 K); the few that might not fit keep
+ * their BT_STF_OVERFLOW flag */
+static int ctx_ensure_retry_list(bt_ctx* c, uint32_t n_reads)
+{
+	uint32_t want = n_reads / 16u;
+	if (want < 65536u) want = n_reads < 65536u ? n_reads : 65536u;
+	if (c->retryCap >= want && c->retryList) return BT_OK;
+	if (c->retryList) (void)hipFree(c->retryList);
+	c->retryList = nullptr; c->retryCap = 0;
+	HIPCHK(hipMalloc((void**)&c->retryList, (size_t)want * 4u));
+	c->retryCap = want;
+	return BT_OK;
+}
+
 /* the best-first engine: one launch of bt_best_kernel, every lane with its own arena */
 static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, unsigned long long* counts_dev,
                            const bt_read_batch* in2 = nullptr)
@@ -357,20 +363,30 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		 * arenas each -- the caller of the device-pointer entry points sees finished results only */
 		const uint32_t bigWords = 1u << 22, bigLanes = 1024u;
 		if (!c->bigArenas) HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u));
-		if (c->retryCap < in->n_reads) {
-			if (c->retryList) (void)hipFree(c->retryList);
-			c->retryList = nullptr;
-			HIPCHK(hipMalloc((void**)&c->retryList, (size_t)in->n_reads * 4u));
-			c->retryCap = in->n_reads;
-		}
-		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 2, c->stream) != 0) return BT_ERR_DEVICE;
+		const int rrc = ctx_ensure_retry_list(c, in->n_reads);
+		if (rrc != BT_OK) return rrc;
+		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 2, c->retryCap, c->stream) != 0) return BT_ERR_DEVICE;
 		BtBestArgs A2 = A;
 		A2.arenas = c->bigArenas; A2.arenaWords = bigWords; A2.nextRead = c->d_cursor + 3;
-		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2;
+		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2; A2.workCap = c->retryCap;
 		if (bt_launch_best(&A2, bigLanes / BT_BLOCK, c->stream) != 0) return BT_ERR_DEVICE;
 	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
+	return BT_OK;
+}
+
+/* the twin context that re-runs reads whose search outgrew the per-read scratch: few lanes, worst-case arenas */
+static int ctx_ensure_big(bt_ctx* c, uint32_t maxLen, void* stream)
+{
+	if (c->big) return BT_OK;
+	bt_ctx* b = nullptr;
+	const int rc = bt_ctx_create(c->idx, &c->pol, stream, &b);
+	if (rc != BT_OK) return rc;
+	b->is_big = true; b->heavy0 = 0;
+	b->nLanes = BT_BLOCK * (maxLen > 256 ? 1u : 16u);
+	b->cus = 1; b->blocksPerCU = b->nLanes / BT_BLOCK; b->rl3 = false;
+	c->big = b;
 	return BT_OK;
 }
 
@@ -389,19 +405,12 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	memset(&A, 0, sizeof(A));
 	/* short reads (all of today's sequencers' single-end lengths up to 112) keep the whole read in LDS */
 	int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
+	bool both = false;                /* longest read known on the device only: enqueue both builds, gated */
 	if (rl && c->rl3 && (c->heavy0 == 0 || env_u32("BT_RL3_WITH_HEAVY", 0)) && !env_u32("BT_SCHEDULE", 0)) {
-		uint32_t longest = maxLen;
-		if (lens_on_device && maxLen > BT_RL3_MAXLEN) {
-			/* only the row stride is known here: one small reduction over len[] settles it */
-			uint32_t* d_max = c->d_cursor + 7;
-			HIPCHK(hipMemsetAsync(d_max, 0, 4, c->stream));
-			if (bt_launch_maxlen(in->len, in->n_reads, d_max, c->stream) != 0) return BT_ERR_DEVICE;
-			HIPCHK(hipMemcpyAsync(&longest, d_max, 4, hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(hipStreamSynchronize(c->stream));
-		}
-		if (longest <= BT_RL3_MAXLEN) rl = 2;                 /* three blocks per CU: the LDS diet */
+		/* only the row stride is known here: one small reduction over len[] settles it, on the stream (below) */
+		if (lens_on_device && maxLen > BT_RL3_MAXLEN) both = true;
+		if (maxLen <= BT_RL3_MAXLEN || both) rl = 2;          /* three blocks per CU: the LDS diet */
 	}
-	const uint32_t launchLanes = c->cus * (rl == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
 	BtCold cold;
 	memset(&cold, 0, sizeof(cold));
 	cold.P = c->prog;
@@ -430,13 +439,20 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	A.nextSlot = c->d_cursor + 2;
-	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
-	const uint32_t maxBlocks = launchLanes / BT_BLOCK;
-	if (nBlocks > maxBlocks) nBlocks = maxBlocks;
-	const bool offload = c->pool1 != nullptr && ((c->heavy0 > 0 && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes)) ||
-	                                             (c->parkLive > 0 && in->n_reads > c->nLanes));
-	const uint32_t init[8] = {0, 0, c->nLanes, 0, 0, 0, 0, 0};
+	const bool offload = c->pool1 != nullptr && c->heavy0 > 0 && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
+	/* the device-pointer entry point hands back finished results: reads that outgrow their scratch are searched
+	 * again on the stream (below), through the twin context's worst-case arenas; BT_DEVICE_RETRY=0 leaves them flagged */
+	const bool devRetry = lens_on_device && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
+	if (devRetry) {
+		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
+		if ((rc = ctx_ensure_scratch(c->big, maxLen, 0)) != BT_OK) return rc;
+		if ((rc = ctx_ensure_retry_list(c, in->n_reads)) != BT_OK) return rc;
+	}
+	/* [0] read cursor, [1] mismatch-pool cursor, [2] next free scratch slot, [3..6] heavy-read pools, [7] longest read,
+	 * [8] reads to search again, [9] their cursor, [10] next free slot of the twin's scratch */
+	const uint32_t init[16] = {0, 0, c->nLanes, 0, 0, 0, 0, 0, 0, 0, devRetry ? c->big->nLanes : 0u, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	if (both && bt_launch_maxlen(in->len, in->n_reads, c->d_cursor + 7, c->stream) != 0) return BT_ERR_DEVICE;
 	/* heavy-first schedule (see bt_weight_kernel); timed with the search since it is part of a step.
 	 * Off by default (BT_SCHEDULE=1 enables): measured on MI355X it does not shorten the batch tail --
 	 * the tail is set by the longest single read, not by when it starts (profiles/README.md). */
@@ -457,34 +473,68 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		                       c->d_bucket, c->d_hist, c->d_order, c->stream) != 0) return BT_ERR_DEVICE;
 		A.order = c->d_order;
 	}
-	/* level 0: all reads; reads that reach heavy0 rounds are parked in pool 1 */
-	A.nextRead = c->d_cursor;
-	A.poolIn = nullptr; A.poolInCount = nullptr;
-	A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
-	A.heavyRounds = c->heavy0 ? c->heavy0 : 0xffffffffu;
-	A.parkLive = offload ? c->parkLive : 0u;
-	{
-		/* the template instance bt_launch_search picks (bt_kernels.hip) */
-		const bool ext = A.poolIn || A.poolOut || A.order;
-		const int o = rl == 2 ? 3 : (rl ? (c->occ == 1 ? 1 : 2) : (c->occ < 1 ? 1 : (c->occ > 4 ? 4 : c->occ)));
-		snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<%d,%s,%s,%s>", o, ext ? "true" : "false",
-		         rl ? "true" : "false", rl == 2 ? "true" : "false");
+	auto launch_levels = [&](int rlv) -> int {
+		const uint32_t launchLanes = c->cus * (rlv == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
+		uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
+		const uint32_t maxBlocks = launchLanes / BT_BLOCK;
+		if (nBlocks > maxBlocks) nBlocks = maxBlocks;
+		/* level 0: all reads; reads that reach heavy0 rounds are parked in pool 1 */
+		A.nextRead = c->d_cursor;
+		A.poolIn = nullptr; A.poolInCount = nullptr;
+		A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
+		A.heavyRounds = c->heavy0 ? c->heavy0 : 0xffffffffu;
+		{
+			/* the template instance bt_launch_search picks (bt_kernels.hip) */
+			const bool ext = A.poolIn || A.poolOut || A.order;
+			const int o = rlv == 2 ? 3 : (rlv ? (c->occ == 1 ? 1 : 2) : (c->occ < 1 ? 1 : (c->occ > 4 ? 4 : c->occ)));
+			snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<%d,%s,%s,%s>", o, ext ? "true" : "false",
+			         rlv ? "true" : "false", rlv == 2 ? "true" : "false");
+		}
+		if (bt_launch_search(&A, nBlocks, c->occ, rlv, c->stream) != 0) return BT_ERR_DEVICE;
+		if (offload) {
+			/* level 1: the parked reads, one per lane; those that reach heavy1 rounds move on to pool 2 */
+			auto blocksFor = [&](uint32_t cap) { uint32_t b = (cap + BT_BLOCK - 1) / BT_BLOCK; return b > maxBlocks ? maxBlocks : (b ? b : 1u); };
+			A.nextRead = c->d_cursor + 4;
+			A.poolIn = c->pool1; A.poolInCount = c->d_cursor + 3;
+			A.poolOut = c->pool2; A.poolOutCount = c->d_cursor + 5; A.poolOutCap = c->pool2Cap;
+			A.heavyRounds = c->heavy0 ? c->heavy1 : 0xffffffffu;
+			if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, rlv, c->stream) != 0) return BT_ERR_DEVICE;
+			/* level 2: run whatever is left to completion */
+			A.nextRead = c->d_cursor + 6;
+			A.poolIn = c->pool2; A.poolInCount = c->d_cursor + 5;
+			A.poolOut = nullptr; A.poolOutCount = nullptr; A.poolOutCap = 0;
+			A.heavyRounds = 0xffffffffu;
+			if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, rlv, c->stream) != 0) return BT_ERR_DEVICE;
+		}
+		return BT_OK;
+	};
+	if (both) {
+		/* the batch's longest read is on the device only (c->d_cursor[7], reduced above): both builds are
+		 * enqueued, each gated on it; the one it rules out returns at once.  No host wait. */
+		A.gate = c->d_cursor + 7;
+		A.gateLo = BT_RL3_MAXLEN + 1u; A.gateHi = 0xffffffffu;
+		if ((rc = launch_levels(1)) != BT_OK) return rc;
+		A.gateLo = 0; A.gateHi = BT_RL3_MAXLEN;
+		if ((rc = launch_levels(2)) != BT_OK) return rc;
+		snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<3|2,*,true,*> (gated)");
+	} else {
+		A.gate = nullptr;
+		if ((rc = launch_levels(rl)) != BT_OK) return rc;
 	}
-	if (bt_launch_search(&A, nBlocks, c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
-	if (offload) {
-		/* level 1: the parked reads, one per lane; those that reach heavy1 rounds move on to pool 2 */
-		auto blocksFor = [&](uint32_t cap) { uint32_t b = (cap + BT_BLOCK - 1) / BT_BLOCK; return b > maxBlocks ? maxBlocks : (b ? b : 1u); };
-		A.nextRead = c->d_cursor + 4;
-		A.poolIn = c->pool1; A.poolInCount = c->d_cursor + 3;
-		A.poolOut = c->pool2; A.poolOutCount = c->d_cursor + 5; A.poolOutCap = c->pool2Cap;
-		A.heavyRounds = c->heavy0 ? c->heavy1 : 0xffffffffu;
-		if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
-		/* level 2: run whatever is left to completion */
-		A.nextRead = c->d_cursor + 6;
-		A.poolIn = c->pool2; A.poolInCount = c->d_cursor + 5;
-		A.poolOut = nullptr; A.poolOutCount = nullptr; A.poolOutCap = 0;
-		A.heavyRounds = 0xffffffffu; A.parkLive = 0;
-		if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, rl, c->stream) != 0) return BT_ERR_DEVICE;
+	if (devRetry) {
+		const bt_ctx* b = c->big;
+		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 8, c->retryCap, c->stream) != 0)
+			return BT_ERR_DEVICE;
+		BtKernelArgs R = A;                               /* same batch, index and output arrays (d_cold, d_warm) */
+		R.gate = nullptr;
+		R.frames = b->frames; R.pairs = b->pairs; R.meta = b->meta; R.pals = b->pals;
+		R.nLanes = b->nLanes; R.nSlots = b->nSlots; R.frCap = b->frCap; R.entCap = b->entCap; R.palCap = b->palCap;
+		R.nextRead = c->d_cursor + 9; R.nextSlot = c->d_cursor + 10;
+		R.order = c->retryList; R.orderCount = c->d_cursor + 8; R.orderCap = c->retryCap;
+		R.poolIn = nullptr; R.poolInCount = nullptr; R.poolOut = nullptr; R.poolOutCount = nullptr; R.poolOutCap = 0;
+		R.heavyRounds = 0xffffffffu;
+		if (bt_launch_search(&R, b->nLanes / BT_BLOCK, c->occ, maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0) ? 1 : 0, c->stream) != 0)
+			return BT_ERR_DEVICE;
 	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
@@ -680,7 +730,7 @@ extern "C" int bt_ctx_sync(bt_ctx* c)
 	if (!c) return BT_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipMemcpy(&c->last_mm_used, c->d_cursor + 1, 4, hipMemcpyDeviceToHost));
-	if (c->best && !c->is_big) HIPCHK(hipMemcpy(&c->last_dev_retried, c->d_cursor + 2, 4, hipMemcpyDeviceToHost));
+	if (!c->is_big) HIPCHK(hipMemcpy(&c->last_dev_retried, c->d_cursor + (c->best ? 2 : 8), 4, hipMemcpyDeviceToHost));
 	return BT_OK;
 }
 
@@ -777,15 +827,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 		for (uint32_t i = 0; i < n; i++) if (out->status[i] & BT_STF_OVERFLOW) redo.push_back(i);
 	c->last_retried = (uint32_t)redo.size();
 	if (!redo.empty()) {
-		if (!c->big) {
-			bt_ctx* b = nullptr;
-			rc = bt_ctx_create(c->idx, &c->pol, nullptr, &b);
-			if (rc != BT_OK) return rc;
-			b->is_big = true; b->heavy0 = 0;
-			b->nLanes = BT_BLOCK * (maxLen > 256 ? 1u : 16u);
-			b->cus = 1; b->blocksPerCU = b->nLanes / BT_BLOCK; b->rl3 = false;
-			c->big = b;
-		}
+		if ((rc = ctx_ensure_big(c, maxLen, nullptr)) != BT_OK) return rc;
 		const uint32_t m = (uint32_t)redo.size();
 		std::vector<uint8_t> sseq((size_t)m * in->stride), squal((size_t)m * in->stride), sst(m);
 		std::vector<uint16_t> slen(m); std::vector<uint32_t> sseed(m), snh(m);

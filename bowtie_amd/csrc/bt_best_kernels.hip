@@ -33,7 +33,7 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 	X.cap = A.arenaWords;
 	X.ix = IX; X.P = &PROG; X.ref = &REF;
 	const bool paired = PROG.paired != 0;
-	const uint32_t n = A.workList ? *A.workCount : BATCH.n_reads;
+	const uint32_t n = A.workList ? (*A.workCount < A.workCap ? *A.workCount : A.workCap) : BATCH.n_reads;
 	for (;;) {
 		const uint32_t w = atomicAdd(A.nextRead, 1u);
 		if (w >= n) break;
@@ -58,14 +58,15 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 	}
 }
 
-__global__ void bt_collect_flagged_kernel(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count)
+/* indices of the reads whose status carries `flag`, at most `cap` of them (*count keeps counting) */
+__global__ void bt_collect_flagged_kernel(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, uint32_t cap)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && (status[i] & flag)) list[atomicAdd(count, 1u)] = i;
+	if (i < n && (status[i] & flag)) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) list[k] = i; }
 }
-extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, void* stream)
+extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, uint32_t cap, void* stream)
 {
-	hipLaunchKernelGGL(bt_collect_flagged_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, n, flag, list, count);
+	hipLaunchKernelGGL(bt_collect_flagged_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, n, flag, list, count, cap);
 	return (int)hipGetLastError();
 }
 

@@ -32,10 +32,13 @@ struct BtKernelArgs {
 	const BtPoolRec* poolIn;  const uint32_t* poolInCount;      /* NULL at level 0               */
 	BtPoolRec* poolOut;       uint32_t* poolOutCount;  uint32_t poolOutCap;   /* NULL at the last level */
 	uint32_t   heavyRounds;      /* park reads that reach this many rounds                       */
-	uint32_t   parkLive;         /* > 0: once the batch's cursor has run dry, a wavefront with at most this
-	                                many reads still running parks them and exits -- the stragglers are
-	                                consolidated into full wavefronts by the follow-up launch, and the CU
-	                                slots go to whatever is queued behind (the next batch's kernel)      */
+	const uint32_t* orderCount;  /* non-null (with order): the pick-up list's length lives on the device -- min(*orderCount,
+	                                orderCap) entries.  The on-stream second pass over reads that outgrew their scratch */
+	uint32_t   orderCap;
+	const uint32_t* gate;        /* non-null: run only if gateLo <= *gate <= gateHi.  Lets the host enqueue both
+	                                builds of the kernel for a batch whose longest read is only known on the
+	                                device (bt_align_batch_device) without waiting for it                 */
+	uint32_t   gateLo, gateHi;
 	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
 };
 
@@ -50,12 +53,12 @@ struct BtBestArgs {
 	uint32_t*  nextRead;
 	unsigned long long* counts;
 	/* second pass over the reads that outgrew their arena in the first: their ids and how many */
-	const uint32_t* workList; const uint32_t* workCount;
+	const uint32_t* workList; const uint32_t* workCount; uint32_t workCap;
 };
 
 extern "C" {
 /* ids of the reads whose status has `flag` set -> list[0 .. *count) (order unspecified) */
-int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, void* stream);
+int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, uint32_t cap, void* stream);
 int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream);
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	__shared__ BtWarm WARM;                                    /* index geometry (see BtWarm) */
 	__shared__ BtArena ARENA;                                  /* scratch arena bases + capacities */
+	if (A.gate) { const uint32_t v = *BT_GP(const uint32_t, A.gate); if (v < A.gateLo || v > A.gateHi) return; }
 	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
 	for (uint32_t i = threadIdx.x; i < sizeof(BtProgram) / 4; i += blockDim.x)
 		((uint32_t*)&PROG)[i] = ((const uint32_t*)&A.cold->P)[i];
@@ -93,6 +94,8 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
 	bool drained = false;
 	const BtCold* cold = A.cold;
+	uint32_t nReads = A.H.n_reads;
+	if (EXT && A.orderCount) { const uint32_t v = *BT_GP(const uint32_t, A.orderCount); nReads = v < A.orderCap ? v : A.orderCap; }
 	uint32_t sc_iters = 0, sc_rounds = 0, sc_fetch = 0, sc_chase = 0, sc_lfex = 0, sc_lf2 = 0, sc_lf1 = 0, sc_same = 0;
 
 	for (;;) {
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 					if (RL) bt_rl_load(L, A.H, S);
 					break;                                   /* its request is served at the top of the next round */
 				}
-				if (w >= A.H.n_reads) { drained = true; break; }
+				if (w >= nReads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
 				bt_lane_start<RL>(L, PROG, A.H, *cold, S, (EXT && A.order) ? BT_GP(const uint32_t, A.order)[w] : w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
@@ -205,26 +208,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
 		 * have run out of work simply carry an empty request */
-		bool live = L.state != ST_IDLE;
-		if (EXT && A.poolOut && A.parkLive) {
-			/* drain-time consolidation: the cursor is dry (some lane of this wavefront found it so) and only
-			 * a few reads are still running here */
-			const unsigned long long lv = __ballot(live);
-			if (lv != 0 && __ballot(drained) != 0 && (uint32_t)__builtin_popcountll(lv) <= A.parkLive) {
-				if (live) {
-					const uint32_t slot = atomicAdd(A.poolOutCount, 1u);
-					if (slot < A.poolOutCap) {
-						BtPoolRec* r = A.poolOut + slot;
-						BT_UNROLL
-						for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); ((BtU4*)r->w)[k] = v; }
-						{ BtU4 v; v.x = S.slot; v.y = 0; v.z = 0; v.w = 0; ((BtU4*)r->w)[12] = v; }
-						{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; ((BtU4*)r->w)[13] = v; }
-						{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); ((BtU4*)r->w)[14] = v; }
-						L.state = ST_IDLE; live = false; drained = true;
-					}
-				}
-			}
-		}
+		const bool live = L.state != ST_IDLE;
 		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
 		if (__ballot(live) == 0) break;
 		/* op counters: wave-uniform tallies in scalar registers (ballot + popcount), flushed once

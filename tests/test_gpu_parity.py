@@ -230,6 +230,64 @@ def test_gpu_hits_verify_against_text_large(gidx):
         assert {k: v for k, v in r.items() if k != "checked"} == dict(bad_window=0, bad_mm_count=0, bad_mm_list=0, bad_policy=0, bad_cost=0)
 
 
+def _device_align(al, batch, stride, hit_cap):
+    """bt_align_batch_device on a copy of `batch` in HBM with rows `stride` bytes apart -> unpack_hits()'s list."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    n = batch.n
+    seq = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    qual = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    seq[:, :batch.stride] = torch.from_numpy(np.ascontiguousarray(batch.seq)).to(dev)
+    qual[:, :batch.stride] = torch.from_numpy(np.ascontiguousarray(batch.qual)).to(dev)
+    ln = torch.from_numpy(batch.len.astype(np.int16)).to(dev)
+    seed = torch.from_numpy(batch.seed.view(np.int32).copy()).to(dev)
+    hits = torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev)
+    n_hits = torch.zeros(n, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    pool = torch.zeros(n * hit_cap * 8, dtype=torch.int16, device=dev)
+    rbc = A.ReadBatchC(n, stride, seq.data_ptr(), qual.data_ptr(), ln.data_ptr(), seed.data_ptr())
+    hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), pool.data_ptr(), pool.numel(), 0)
+    assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
+    assert AL.lib().bt_ctx_sync(al._h) == 0
+    pol = al.policy
+    return AL.unpack_hits(n, hit_cap, hits.cpu().numpy().view(A.HIT_DTYPE), n_hits.cpu().numpy().view(np.uint32), status.cpu().numpy(),
+                          pool.cpu().numpy().view(np.uint16), int(pol.khits), int(pol.mhits), bool(pol.all_hits),
+                          sample_max=bool(pol.sample_max))
+
+
+@pytest.mark.parametrize("rname", ["syn100", "syn110"])
+def test_gpu_device_path_settles_the_build_on_the_device(rname, gidx):
+    """Rows 112 bytes apart: whether the three-blocks-per-CU build (reads <= 104) may run depends on the longest
+    read, which only the device knows.  Both builds are enqueued, gated on the reduced maximum -- the host does
+    not wait -- and whichever runs gives the host path's results."""
+    batch = T.read_set("multi", rname)
+    kw = T.MODES["n2_k3"]
+    al = aligner(gidx, "multi", kw)
+    want = al.align(batch, hit_cap=8)
+    got = _device_align(al, batch, 112, 8)
+    assert b"gated" in AL.lib().bt_ctx_last_kernel_name(al._h)
+    T.compare_results(got, want, "device path, stride 112, " + rname)
+
+
+def test_gpu_device_path_retries_overflowed_reads_on_the_stream(gidx, monkeypatch):
+    """bt_align_batch_device with absurdly small arenas: the reads that outgrow them are collected and searched again
+    on the same stream (no host copy); what the caller reads back after the sync is complete and equals the oracle's."""
+    monkeypatch.setenv("BT_ENTRY_CAP", "24")
+    monkeypatch.setenv("BT_FRAME_CAP", "3")
+    monkeypatch.setenv("BT_PARTIAL_CAP", "4")
+    for index, rname, mode in (("multi", "syn100", "n2"), ("multi", "syn50lowq", "n3"), ("e_coli", "syn76", "v2"), ("multi", "syn36", "n2_k3"),
+                               ("multi", "syn150", "n2")):
+        batch = T.read_set(index, rname)
+        kw = T.MODES[mode]
+        al = aligner(gidx, index, kw)
+        cap = T.hit_cap_for(kw)
+        got = _device_align(al, batch, (batch.stride + 15) // 16 * 16, cap)
+        assert AL.lib().bt_ctx_last_retried(al._h) > batch.n // 20, mode
+        assert not any(st & A.BT_ST_OVERFLOW for _, _, st in got)
+        T.compare_results(got, T.oracle_results(index, batch, kw, cap=cap), "device retry " + mode)
+
+
 # ---- the best-first engine (--best, --strata, -M, -v 3): bt_best_kernel ---------------------------
 BEST_RAGGED = ["n2_best", "v3", "v2_a_best_strata", "n3_best", "n2_M3", "v1_best", "n1_best", "n0_best_a_m3",
                "n3_best_a_l12_e200", "n2_k2_best_strata_m5"]
