@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
+    ap.add_argument("--no-carry", action="store_true",
+                    help="run every batch to its last read before the next starts (bt_ctx_set_carry off); by default the "
+                         "searches still running when a batch's reads are all handed out are resumed by the next step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip re-checking every reported hit of the last step against the genome (bowtie_amd/verify.py; unpaired workloads)")
@@ -315,17 +318,26 @@ def main():
     # output buffers, take the steps round-robin.  A step's last few long-running reads (the
     # backtracking tail) then drain while the next step's wavefronts already fill the machine --
     # what a host driver double-buffering read batches does.
+    # Carry-over (bt_ctx_set_carry, include/bowtie_amd.h): the reads still being searched when a step's reads have
+    # all been handed out are parked and resumed by the context's next step, so a step's results are complete when
+    # the next step (or the closing bt_ctx_sync, inside the timed region) is.  Each context therefore alternates
+    # between two sets of output arrays.
+    carry = (not args.no_carry) and not paired and not wl["pol"].get("best") and L <= 112
     pipes = []
     for pi in range(max(1, args.pipes)):
         st = torch.cuda.current_stream() if pi == 0 else torch.cuda.Stream()
-        o = dict(stream=st,
-                 hits=torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev),
-                 n_hits=torch.zeros(n, dtype=torch.int32, device=dev),
-                 status=torch.zeros(n, dtype=torch.uint8, device=dev),
-                 mm_pool=torch.zeros(mm_cap, dtype=torch.int16, device=dev), busy=False)
+        o = dict(stream=st, busy=False, sets=[])
+        for si in range(2 if carry else 1):
+            d = dict(hits=torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev),
+                     n_hits=torch.zeros(n, dtype=torch.int32, device=dev),
+                     status=torch.zeros(n, dtype=torch.uint8, device=dev),
+                     mm_pool=torch.zeros(mm_cap, dtype=torch.int16, device=dev))
+            d["hbc"] = A.HitBatchC(hit_cap, d["hits"].data_ptr(), d["n_hits"].data_ptr(), d["status"].data_ptr(),
+                                   d["mm_pool"].data_ptr(), mm_cap, 0)
+            o["sets"].append(d)
         o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
-        o["hbc"] = A.HitBatchC(hit_cap, o["hits"].data_ptr(), o["n_hits"].data_ptr(), o["status"].data_ptr(),
-                               o["mm_pool"].data_ptr(), mm_cap, 0)
+        if carry and lib.bt_ctx_set_carry(o["al"]._h, 1) != 0:
+            raise RuntimeError("bt_ctx_set_carry failed")
         pipes.append(o)
     torch.cuda.synchronize()
     log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
@@ -337,30 +349,37 @@ def main():
                             rb2["seed"].data_ptr())
         if lib.bt_index_load_reference(idx._h) != 0:
             raise RuntimeError("bt_index_load_reference failed")
-    n_hits, status = pipes[0]["n_hits"], pipes[0]["status"]
     iters_t = None
     if args.iters_hist:
         iters_t = torch.zeros(n, dtype=torch.int32, device=dev)
         lib.bt_ctx_set_iters_buffer(pipes[0]["al"]._h, iters_t.data_ptr())
-    kernel_ms = []
+    kernel_ms, flush_ms = [], []
+    last = {}
 
     def retire(o):
         if o["busy"]:
-            if lib.bt_ctx_sync(o["al"]._h) != 0:
+            if lib.bt_ctx_sync(o["al"]._h) != 0:      # with carry-over: finishes the parked reads first
                 raise RuntimeError("bt_ctx_sync failed")
-            kernel_ms.append(float(lib.bt_ctx_last_kernel_ms(o["al"]._h)))   # HIP events on the kernel's stream
+            nl = C.c_uint32()
+            lib.bt_ctx_span_ms(o["al"]._h, C.byref(nl))
+            for i in range(max(0, nl.value - 16), nl.value):       # HIP events on the kernel's stream, per launch
+                kernel_ms.append(float(lib.bt_ctx_launch_ms(o["al"]._h, i)))
+            flush_ms.append(float(lib.bt_ctx_launch_ms(o["al"]._h, -1)))
             o["busy"] = False
 
     def step(k):
         o = pipes[k % len(pipes)]
-        retire(o)
+        if not carry:
+            retire(o)
+        d = o["sets"][(k // len(pipes)) % len(o["sets"])]
         if paired:
-            rc = lib.bt_align_pairs_device(o["al"]._h, C.byref(rbc), C.byref(rbc2), C.byref(o["hbc"]), None)
+            rc = lib.bt_align_pairs_device(o["al"]._h, C.byref(rbc), C.byref(rbc2), C.byref(d["hbc"]), None)
         else:
-            rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(o["hbc"]), None)
+            rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(d["hbc"]), None)
         if rc != 0:
             raise RuntimeError("bt_align_batch_device: " + AL.strerror(rc))
         o["busy"] = True
+        last["set"] = d
 
     def barrier():
         for o in pipes:
@@ -376,6 +395,7 @@ def main():
     for o in pipes:
         lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 1)        # reset: count the timed steps only
     kernel_ms.clear()
+    flush_ms.clear()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
@@ -392,7 +412,7 @@ def main():
         # size-independent parity property at full size: every hit is re-derived from the text
         from bowtie_amd import verify as V
         tl, plen, rstarts = V.read_fragments(base)
-        o = pipes[(args.steps - 1) % len(pipes)] if args.steps > 0 else pipes[0]
+        o = last["set"]
         t1 = time.perf_counter()
         verified = V.verify_hits(text_t, tl, rstarts, rb["seq"], rb["qual"], L, o["hits"], o["n_hits"], o["mm_pool"],
                                  dict(wl["pol"], seed_len=28, qual_thresh=70))
@@ -405,6 +425,7 @@ def main():
         log("[bench] LF rounds per read: mean %.1f  p50/p90/p99/p99.9/p99.99/max = %s  (reads > 20k rounds: %d, their share of all rounds %.1f%%)" %
             (it.mean().item(), [int(x) for x in qs.tolist()], int((it > 20000).sum().item()),
              100.0 * it[it > 20000].sum().item() / max(1.0, it.sum().item())))
+    n_hits, status = last["set"]["n_hits"], last["set"]["status"]
     aligned = int((n_hits > 0).sum().item())
     bad = int(((status & (A.BT_ST_OVERFLOW | A.BT_ST_MMPOOL)) != 0).sum().item())
     # HitSink's five counters (hit.h:169-175, 280-289) for this rank's shard of the last step, + reads and
@@ -431,7 +452,10 @@ def main():
 
     if rank == 0:
         per_launch = {k: v / max(1, args.steps) for k, v in c.items()}
-        kavg = sum(kernel_ms) / len(kernel_ms)
+        # a step's launch time: its own launches (main kernel + second pass) plus its share of the closing launch
+        # that finishes the reads carried out of the last step
+        kmain = sum(kernel_ms) / len(kernel_ms)
+        kavg = kmain + sum(flush_ms) / max(1, args.steps)
         kname = (lib.bt_ctx_last_kernel_name(pipes[0]["al"]._h) or b"").decode()
         tr = measured_traffic(kname, args.workload)
         abytes = algorithmic_bytes(per_launch, n * (2 if paired else 1), L, aligned * (2 if paired else 1))
@@ -457,7 +481,8 @@ def main():
                          "traffic": (tr["hbm_bytes_per_read"] * n * mult if tr and not args.genome else None),
                          "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this kernel on this workload in profiles/traffic.json"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
-                         "kernel": kname, "kernel_ms_avg": kavg,
+                         "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
+                         "carry_over": carry, "flush_ms_total": sum(flush_ms),
                          "algorithmic_bytes_per_launch": abytes,
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n,

@@ -31,6 +31,9 @@ struct bt_index {
 	uint64_t ref_bytes = 0;
 };
 
+/* What one call describes to the kernels: the batch (reads in, results out) and the fields of BtHot that follow it */
+struct BatchView { BtBatchDev B; const uint8_t* seq; const uint8_t* qual; uint32_t stride, n_reads; };
+
 struct bt_ctx {
 	const bt_index* idx = nullptr;
 	bt_policy pol;
@@ -50,18 +53,24 @@ struct bt_ctx {
 	bool rl3 = true;                        /* the three-blocks-per-CU build may be used */
 	int occ = 2;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint16_t* meta = nullptr; uint64_t* pals = nullptr;
-	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [2] spare-slot cursor,
-	                                      [3] pool1 count, [4] pool1 cursor, [5] pool2 count, [6] pool2 cursor */
-	BtPoolRec *pool1 = nullptr, *pool2 = nullptr;
-	uint32_t pool1Cap = 0, pool2Cap = 0, nSlots = 0;
-	uint32_t heavy0 = 0, heavy1 = 0;
+	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [7] longest read, [8..10] second pass */
+	uint32_t nSlots = 0;
+	/* carry-over (bt_kernels.h): the reads the last launch parked and what describes their batch */
+	bool carry = false, carryPending = false, carryRetry = false;
+	int carryParity = 0, carryRl = 0;
+	BtPoolRec* carryPool[2] = {nullptr, nullptr}; uint32_t carryCap = 0;
+	uint32_t* d_carry = nullptr;
+	BatchView prev; uint32_t prevMaxLen = 0;
+	BtCold* d_cold_prev = nullptr;
+	uint32_t* lastMmCursor = nullptr;
+	hipEvent_t evSpan = nullptr; bool spanOpen = false; uint32_t spanLaunches = 0;
+	hipEvent_t evRing[16][2] = {}; hipEvent_t evFlush[2] = {nullptr, nullptr}; bool flushTimed = false;
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
-	uint32_t last_retried = 0, last_dev_retried = 0;
+	uint32_t last_retried = 0, last_dev_retried = 0, last_carried = 0;
 	char last_kernel[64] = "";         /* the kernel variant the last batch ran (as rocprofv3 names it) */
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
-	uint32_t *d_order = nullptr, *d_hist = nullptr; uint8_t* d_bucket = nullptr; uint32_t orderCap = 0;
 	unsigned long long* d_counts = nullptr;
 	/* staging for the host-pointer entry point */
 	void* stage = nullptr; size_t stage_bytes = 0;
@@ -172,26 +181,22 @@ static void ctx_free_scratch(bt_ctx* c)
 	c->frames = c->pairs = nullptr; c->meta = nullptr; c->pals = nullptr;
 }
 
-/* (re)size the per-slot arenas for reads up to maxLen and batches of n_reads.  Slots beyond the
- * nLanes resident lanes back the reads that get parked as "heavy" (see BtPoolRec). */
-static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
+/* (re)size the per-slot arenas for reads up to maxLen.  One slot per resident lane; with carry-over two sets of
+ * them (a parked read keeps its slot through the next launch) and the two pools of parked-read records. */
+static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 {
-	/* heavy-read offload only pays (and only has anything to offload) on batches that keep the
-	 * lanes refilling for a while */
-	uint32_t want1 = 0, want2 = 0;
-	if (c->heavy0 > 0 && n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes)) {
-		want1 = n_reads / 64u + 4096u;
-		want2 = n_reads / 512u + 1024u;
-	}
-	if (c->frames && maxLen <= c->maxLen && want1 <= c->pool1Cap && want2 <= c->pool2Cap) return BT_OK;
+	const uint32_t wantSlots = c->nLanes * (carry ? 2u : 1u);
+	if (c->frames && maxLen <= c->maxLen && wantSlots <= c->nSlots) return BT_OK;
 	ctx_free_scratch(c);
-	if (c->pool1) (void)hipFree(c->pool1);
-	if (c->pool2) (void)hipFree(c->pool2);
-	c->pool1 = c->pool2 = nullptr;
 	c->maxLen = maxLen < 64 ? 64 : (maxLen > c->maxLen ? maxLen : c->maxLen);
-	c->pool1Cap = want1 > c->pool1Cap ? want1 : c->pool1Cap;
-	c->pool2Cap = want2 > c->pool2Cap ? want2 : c->pool2Cap;
-	c->nSlots = c->nLanes + c->pool1Cap + c->pool2Cap;
+	c->nSlots = wantSlots > c->nSlots ? wantSlots : c->nSlots;
+	if (carry && !c->carryPool[0]) {
+		c->carryCap = c->nLanes;
+		for (int k = 0; k < 2; k++) HIPCHK(hipMalloc((void**)&c->carryPool[k], (size_t)c->carryCap * sizeof(BtPoolRec)));
+		HIPCHK(hipMalloc((void**)&c->d_carry, 32));
+		HIPCHK(hipMemset(c->d_carry, 0, 32));
+		HIPCHK(hipMalloc((void**)&c->d_cold_prev, sizeof(BtCold)));
+	}
 	const bool seeded = c->pol.mode == BT_MODE_N;
 	/* range-stack entries per slot: every frame may span the whole read.  -v k has k+1 frames;
 	 * -n: frames are bounded by -e / min penalty (10) unless the read has Phred<5 bases. */
@@ -215,8 +220,6 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, uint32_t n_reads)
 	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nSlots * c->entCap * 32u));
 	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nSlots * c->entCap * 2u));
 	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nSlots * c->palCap * 8u));
-	if (c->pool1Cap) HIPCHK(hipMalloc((void**)&c->pool1, (size_t)c->pool1Cap * sizeof(BtPoolRec)));
-	if (c->pool2Cap) HIPCHK(hipMalloc((void**)&c->pool2, (size_t)c->pool2Cap * sizeof(BtPoolRec)));
 	return BT_OK;
 }
 
@@ -259,10 +262,11 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	c->rl3 = env_u32("BT_NO_RL3", 0) == 0 && c->occ == 2;
 	c->nLanes = c->cus * (c->rl3 && c->blocksPerCU < 3u ? 3u : c->blocksPerCU) * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 64));
-	/* heavy-read offload is off by default: measured on MI355X (profiles/README.md) it raises lane
-	 * utilisation but lengthens the batch tail; BT_HEAVY0=<rounds> turns it on */
-	c->heavy0 = env_u32("BT_HEAVY0", 0);
-	c->heavy1 = env_u32("BT_HEAVY1", 65536);
+	/* carry-over between the launches of this context (bt_kernels.h): asked for with bt_ctx_set_carry or BT_CARRY=1 */
+	c->carry = env_u32("BT_CARRY", 0) != 0;
+	HIPCHK(hipEventCreate(&c->evSpan));
+	for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate(&c->evRing[i][k]));
+	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate(&c->evFlush[k]));
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_warm, sizeof(BtWarm)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
@@ -288,11 +292,12 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_cold) (void)hipFree(c->d_cold);
 	if (c->d_warm) (void)hipFree(c->d_warm);
-	if (c->d_order) (void)hipFree(c->d_order);
-	if (c->d_hist) (void)hipFree(c->d_hist);
-	if (c->d_bucket) (void)hipFree(c->d_bucket);
-	if (c->pool1) (void)hipFree(c->pool1);
-	if (c->pool2) (void)hipFree(c->pool2);
+	for (int k = 0; k < 2; k++) if (c->carryPool[k]) (void)hipFree(c->carryPool[k]);
+	if (c->d_carry) (void)hipFree(c->d_carry);
+	if (c->d_cold_prev) (void)hipFree(c->d_cold_prev);
+	if (c->evSpan) (void)hipEventDestroy(c->evSpan);
+	for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) if (c->evRing[i][k]) (void)hipEventDestroy(c->evRing[i][k]);
+	for (int k = 0; k < 2; k++) if (c->evFlush[k]) (void)hipEventDestroy(c->evFlush[k]);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->d_bprog) (void)hipFree(c->d_bprog);
 	if (c->d_bprog_pe) (void)hipFree(c->d_bprog_pe);
@@ -383,10 +388,90 @@ static int ctx_ensure_big(bt_ctx* c, uint32_t maxLen, void* stream)
 	bt_ctx* b = nullptr;
 	const int rc = bt_ctx_create(c->idx, &c->pol, stream, &b);
 	if (rc != BT_OK) return rc;
-	b->is_big = true; b->heavy0 = 0;
+	b->is_big = true;
 	b->nLanes = BT_BLOCK * (maxLen > 256 ? 1u : 16u);
 	b->cus = 1; b->blocksPerCU = b->nLanes / BT_BLOCK; b->rl3 = false;
 	c->big = b;
+	return BT_OK;
+}
+
+static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
+{
+	memset(warm, 0, sizeof(*warm));
+	for (int m = 0; m < 2; m++) {
+		const BtIndexDev& d = c->idx->dev[m];
+		A->H.ebwt[m] = d.ebwt; A->H.zSide[m] = d.zSide; A->H.zSym[m] = d.zSym;
+		warm->zOff[m] = d.zOff; warm->offMask[m] = d.offMask; warm->ftab[m] = d.ftab; warm->offs[m] = d.offs;
+		warm->offRate[m] = d.offRate; warm->ftabChars[m] = d.ftabChars; warm->len[m] = d.len;
+		for (int k = 0; k < 5; k++) A->H.fchr[m][k] = d.fchr[k];
+	}
+}
+
+/* Second pass, on the stream, over the reads of `v` whose search outgrew the per-read scratch: collected from the
+ * status array and searched again through the twin context's worst-case arenas.  `d_cold` describes `v` as B. */
+static int enqueue_retry(bt_ctx* c, const BtKernelArgs& A0, const BatchView& v, const BtCold* d_cold, uint32_t maxLen)
+{
+	const bt_ctx* b = c->big;
+	HIPCHK(hipMemsetAsync(c->d_cursor + 8, 0, 12, c->stream));
+	{ const uint32_t lanes = b->nLanes; HIPCHK(hipMemcpyAsync(c->d_cursor + 10, &lanes, 4, hipMemcpyHostToDevice, c->stream)); }
+	if (bt_launch_collect_flagged(v.B.status, v.n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 8, c->retryCap, c->stream) != 0)
+		return BT_ERR_DEVICE;
+	BtKernelArgs R = A0;                              /* same index */
+	R.H.seq = v.seq; R.H.qual = v.qual; R.H.stride = v.stride; R.H.n_reads = v.n_reads;
+	R.cold = d_cold;
+	R.gate = nullptr;
+	R.frames = b->frames; R.pairs = b->pairs; R.meta = b->meta; R.pals = b->pals;
+	R.nLanes = b->nLanes; R.nSlots = b->nSlots; R.frCap = b->frCap; R.entCap = b->entCap; R.palCap = b->palCap; R.slotBase = 0;
+	R.nextRead = c->d_cursor + 9;
+	R.order = c->retryList; R.orderCount = c->d_cursor + 8; R.orderCap = c->retryCap;
+	R.carryIn = nullptr; R.carryInCount = nullptr; R.carryCursor = nullptr;
+	R.carryOut = nullptr; R.carryOutCount = nullptr; R.carryOutCap = 0;
+	if (bt_launch_search(&R, b->nLanes / BT_BLOCK, c->occ, maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0) ? 1 : 0, c->stream) != 0)
+		return BT_ERR_DEVICE;
+	return BT_OK;
+}
+
+/* Finish the reads the last launch parked (carry-over): a launch with no fresh reads that adopts them and runs
+ * them to the end, then the second pass over that batch.  After it the context holds nothing in flight. */
+static int ctx_flush_carry(bt_ctx* c)
+{
+	if (!c->carryPending) return BT_OK;
+	HIPCHK(hipSetDevice(c->idx->device));
+	const int p = c->carryParity;                     /* the parity the next launch would have had */
+	BtKernelArgs A;
+	memset(&A, 0, sizeof(A));
+	BtWarm warm;
+	fill_index_args(c, &A, &warm);
+	BtCold cold;
+	memset(&cold, 0, sizeof(cold));
+	cold.P = c->prog; cold.ix[0] = c->idx->dev[0]; cold.ix[1] = c->idx->dev[1];
+	cold.B = c->prev.B; cold.Bprev = c->prev.B;
+	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_carry + 2, 0, 4, c->stream));
+	A.H.seq = c->prev.seq; A.H.qual = c->prev.qual; A.H.stride = c->prev.stride; A.H.n_reads = 0;
+	A.cold = c->d_cold; A.warm = c->d_warm;
+	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
+	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
+	A.slotBase = (uint32_t)p * c->nLanes;
+	A.counts = c->d_counts;
+	A.nextRead = c->d_cursor;
+	A.carryIn = c->carryPool[1 - p]; A.carryInCount = c->d_carry + (1 - p); A.carryCursor = c->d_carry + 2;
+	A.prevSeq = c->prev.seq; A.prevQual = c->prev.qual; A.prevStride = c->prev.stride;
+	const uint32_t lanes = c->cus * (c->carryRl == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
+	HIPCHK(hipEventRecord(c->evFlush[0], c->stream));
+	if (bt_launch_search(&A, lanes / BT_BLOCK, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	c->carryPending = false;
+	if (c->carryRetry) {
+		const int rc = enqueue_retry(c, A, c->prev, c->d_cold, c->prevMaxLen);
+		if (rc != BT_OK) return rc;
+	}
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipEventRecord(c->evFlush[1], c->stream));
+	c->flushTimed = true;
+	c->lastMmCursor = c->d_carry + 4 + (1 - p);
 	return BT_OK;
 }
 
@@ -399,144 +484,130 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	    ((uintptr_t)in->seq & 15u) != 0 || ((uintptr_t)in->qual & 15u) != 0) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
 	if (c->best) return run_best_device(c, in, out, counts_dev);
-	int rc = ctx_ensure_scratch(c, maxLen, in->n_reads);
-	if (rc != BT_OK) return rc;
+	int rc;
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
 	/* short reads (all of today's sequencers' single-end lengths up to 112) keep the whole read in LDS */
 	int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
 	bool both = false;                /* longest read known on the device only: enqueue both builds, gated */
-	if (rl && c->rl3 && (c->heavy0 == 0 || env_u32("BT_RL3_WITH_HEAVY", 0)) && !env_u32("BT_SCHEDULE", 0)) {
+	if (rl && c->rl3) {
 		/* only the row stride is known here: one small reduction over len[] settles it, on the stream (below) */
 		if (lens_on_device && maxLen > BT_RL3_MAXLEN) both = true;
 		if (maxLen <= BT_RL3_MAXLEN || both) rl = 2;          /* three blocks per CU: the LDS diet */
 	}
-	BtCold cold;
-	memset(&cold, 0, sizeof(cold));
-	cold.P = c->prog;
-	cold.ix[0] = c->idx->dev[0]; cold.ix[1] = c->idx->dev[1];
-	cold.B.seq = in->seq; cold.B.qual = in->qual; cold.B.len = in->len; cold.B.seed = in->seed;
-	cold.B.n_reads = in->n_reads; cold.B.stride = in->stride;
-	cold.B.hits = (BtHitRec*)out->hits; cold.B.hit_cap = out->hit_cap;
-	cold.B.n_hits = out->n_hits; cold.B.status = out->status;
-	cold.B.mm_pool = out->mm_pool; cold.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
-	cold.B.mm_pool_used = c->d_cursor + 1;
-	cold.B.iters = c->iters_dev;
-	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
-	BtWarm warm;
-	memset(&warm, 0, sizeof(warm));
-	for (int m = 0; m < 2; m++) {
-		const BtIndexDev& d = c->idx->dev[m];
-		A.H.ebwt[m] = d.ebwt; A.H.zSide[m] = d.zSide; A.H.zSym[m] = d.zSym;
-		warm.zOff[m] = d.zOff; warm.offMask[m] = d.offMask; warm.ftab[m] = d.ftab; warm.offs[m] = d.offs;
-		warm.offRate[m] = d.offRate; warm.ftabChars[m] = d.ftabChars; warm.len[m] = d.len;
-		for (int k = 0; k < 5; k++) A.H.fchr[m][k] = d.fchr[k];
+	/* carry-over (bt_kernels.h): device-pointer batches on a context that asked for it, reads in LDS, one build */
+	const bool carry = c->carry && lens_on_device && !c->is_big && rl != 0 && !both && counts_dev == nullptr;
+	if (c->carryPending && (!carry || rl != c->carryRl || maxLen > c->maxLen)) {
+		if ((rc = ctx_flush_carry(c)) != BT_OK) return rc;
 	}
-	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
-	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
-	A.cold = c->d_cold; A.warm = c->d_warm;
-	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
-	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
-	A.counts = counts_dev ? counts_dev : c->d_counts;
-	A.nextSlot = c->d_cursor + 2;
-	const bool offload = c->pool1 != nullptr && c->heavy0 > 0 && in->n_reads >= env_u32("BT_HEAVY_MIN_BATCH", 4u * c->nLanes);
+	if ((rc = ctx_ensure_scratch(c, maxLen, carry)) != BT_OK) return rc;
 	/* the device-pointer entry point hands back finished results: reads that outgrow their scratch are searched
 	 * again on the stream (below), through the twin context's worst-case arenas; BT_DEVICE_RETRY=0 leaves them flagged */
 	const bool devRetry = lens_on_device && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
 	if (devRetry) {
 		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
-		if ((rc = ctx_ensure_scratch(c->big, maxLen, 0)) != BT_OK) return rc;
+		if ((rc = ctx_ensure_scratch(c->big, maxLen, false)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_retry_list(c, in->n_reads)) != BT_OK) return rc;
 	}
-	/* [0] read cursor, [1] mismatch-pool cursor, [2] next free scratch slot, [3..6] heavy-read pools, [7] longest read,
-	 * [8] reads to search again, [9] their cursor, [10] next free slot of the twin's scratch */
-	const uint32_t init[16] = {0, 0, c->nLanes, 0, 0, 0, 0, 0, 0, 0, devRetry ? c->big->nLanes : 0u, 0, 0, 0, 0, 0};
+	const int p = carry ? c->carryParity : 0;
+	BatchView cur;
+	memset(&cur, 0, sizeof(cur));
+	cur.B.seq = in->seq; cur.B.qual = in->qual; cur.B.len = in->len; cur.B.seed = in->seed;
+	cur.B.n_reads = in->n_reads; cur.B.stride = in->stride;
+	cur.B.hits = (BtHitRec*)out->hits; cur.B.hit_cap = out->hit_cap;
+	cur.B.n_hits = out->n_hits; cur.B.status = out->status;
+	cur.B.mm_pool = out->mm_pool; cur.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
+	cur.B.mm_pool_used = carry ? c->d_carry + 4 + p : c->d_cursor + 1;
+	cur.B.iters = c->iters_dev;
+	cur.seq = in->seq; cur.qual = in->qual; cur.stride = in->stride; cur.n_reads = in->n_reads;
+	const bool adopt = carry && c->carryPending;
+	BtCold cold;
+	memset(&cold, 0, sizeof(cold));
+	cold.P = c->prog;
+	cold.ix[0] = c->idx->dev[0]; cold.ix[1] = c->idx->dev[1];
+	cold.B = cur.B;
+	cold.Bprev = adopt ? c->prev.B : cur.B;
+	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+	BtWarm warm;
+	fill_index_args(c, &A, &warm);
+	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
+	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	A.cold = c->d_cold; A.warm = c->d_warm;
+	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
+	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
+	A.slotBase = (uint32_t)p * c->nLanes;
+	A.counts = counts_dev ? counts_dev : c->d_counts;
+	/* [0] read cursor, [1] mismatch-pool cursor, [7] longest read, [8] reads to search again, [9] their cursor,
+	 * [10] (unused by the kernel) the twin's lane count */
+	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	if (carry) {
+		/* d_carry: [0],[1] reads parked by the launches of either parity, [2] adoption cursor, [4],[5] the two
+		 * batches' mismatch-pool cursors */
+		HIPCHK(hipMemsetAsync(c->d_carry + p, 0, 4, c->stream));
+		HIPCHK(hipMemsetAsync(c->d_carry + 2, 0, 4, c->stream));
+		HIPCHK(hipMemsetAsync(c->d_carry + 4 + p, 0, 4, c->stream));
+		A.carryOut = c->carryPool[p]; A.carryOutCount = c->d_carry + p; A.carryOutCap = c->carryCap;
+		if (adopt) {
+			A.carryIn = c->carryPool[1 - p]; A.carryInCount = c->d_carry + (1 - p); A.carryCursor = c->d_carry + 2;
+			A.prevSeq = c->prev.seq; A.prevQual = c->prev.qual; A.prevStride = c->prev.stride;
+		}
+	}
 	if (both && bt_launch_maxlen(in->len, in->n_reads, c->d_cursor + 7, c->stream) != 0) return BT_ERR_DEVICE;
-	/* heavy-first schedule (see bt_weight_kernel); timed with the search since it is part of a step.
-	 * Off by default (BT_SCHEDULE=1 enables): measured on MI355X it does not shorten the batch tail --
-	 * the tail is set by the longest single read, not by when it starts (profiles/README.md). */
+	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
+	hipEvent_t* ring = c->evRing[c->spanLaunches & 15u];
+	c->spanLaunches++;
+	HIPCHK(hipEventRecord(ring[0], c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	A.order = nullptr;
-	if (in->n_reads >= env_u32("BT_SCHEDULE_MIN_BATCH", 4u * c->nLanes) && env_u32("BT_SCHEDULE", 0)) {
-		if (c->orderCap < in->n_reads) {
-			if (c->d_order) (void)hipFree(c->d_order);
-			if (c->d_bucket) (void)hipFree(c->d_bucket);
-			c->d_order = nullptr; c->d_bucket = nullptr; c->orderCap = 0;
-			HIPCHK(hipMalloc((void**)&c->d_order, (size_t)in->n_reads * 4u));
-			HIPCHK(hipMalloc((void**)&c->d_bucket, (size_t)in->n_reads));
-			if (!c->d_hist) HIPCHK(hipMalloc((void**)&c->d_hist, 64 * 4));
-			c->orderCap = in->n_reads;
-		}
-		const BtIndexDev& d0 = c->idx->dev[0];
-		if (bt_launch_schedule(in->seq, in->len, in->stride, in->n_reads, d0.ftab, d0.ftabChars, d0.len,
-		                       c->d_bucket, c->d_hist, c->d_order, c->stream) != 0) return BT_ERR_DEVICE;
-		A.order = c->d_order;
-	}
-	auto launch_levels = [&](int rlv) -> int {
+	auto launch_main = [&](int rlv) -> int {
 		const uint32_t launchLanes = c->cus * (rlv == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
 		uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
-		const uint32_t maxBlocks = launchLanes / BT_BLOCK;
+		if (adopt) nBlocks = launchLanes / BT_BLOCK;        /* there is a parked read for (nearly) every lane */
+		uint32_t maxBlocks = launchLanes / BT_BLOCK;
+		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);   /* tests: a small grid makes small batches drain */
+		if (lim && lim < maxBlocks) maxBlocks = lim;
 		if (nBlocks > maxBlocks) nBlocks = maxBlocks;
-		/* level 0: all reads; reads that reach heavy0 rounds are parked in pool 1 */
-		A.nextRead = c->d_cursor;
-		A.poolIn = nullptr; A.poolInCount = nullptr;
-		A.poolOut = offload ? c->pool1 : nullptr; A.poolOutCount = c->d_cursor + 3; A.poolOutCap = c->pool1Cap;
-		A.heavyRounds = c->heavy0 ? c->heavy0 : 0xffffffffu;
 		{
 			/* the template instance bt_launch_search picks (bt_kernels.hip) */
-			const bool ext = A.poolIn || A.poolOut || A.order;
+			const bool ext = A.carryIn || A.carryOut || A.order;
 			const int o = rlv == 2 ? 3 : (rlv ? (c->occ == 1 ? 1 : 2) : (c->occ < 1 ? 1 : (c->occ > 4 ? 4 : c->occ)));
 			snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<%d,%s,%s,%s>", o, ext ? "true" : "false",
 			         rlv ? "true" : "false", rlv == 2 ? "true" : "false");
 		}
-		if (bt_launch_search(&A, nBlocks, c->occ, rlv, c->stream) != 0) return BT_ERR_DEVICE;
-		if (offload) {
-			/* level 1: the parked reads, one per lane; those that reach heavy1 rounds move on to pool 2 */
-			auto blocksFor = [&](uint32_t cap) { uint32_t b = (cap + BT_BLOCK - 1) / BT_BLOCK; return b > maxBlocks ? maxBlocks : (b ? b : 1u); };
-			A.nextRead = c->d_cursor + 4;
-			A.poolIn = c->pool1; A.poolInCount = c->d_cursor + 3;
-			A.poolOut = c->pool2; A.poolOutCount = c->d_cursor + 5; A.poolOutCap = c->pool2Cap;
-			A.heavyRounds = c->heavy0 ? c->heavy1 : 0xffffffffu;
-			if (bt_launch_search(&A, blocksFor(c->pool1Cap), c->occ, rlv, c->stream) != 0) return BT_ERR_DEVICE;
-			/* level 2: run whatever is left to completion */
-			A.nextRead = c->d_cursor + 6;
-			A.poolIn = c->pool2; A.poolInCount = c->d_cursor + 5;
-			A.poolOut = nullptr; A.poolOutCount = nullptr; A.poolOutCap = 0;
-			A.heavyRounds = 0xffffffffu;
-			if (bt_launch_search(&A, blocksFor(c->pool2Cap), c->occ, rlv, c->stream) != 0) return BT_ERR_DEVICE;
-		}
-		return BT_OK;
+		return bt_launch_search(&A, nBlocks, c->occ, rlv, c->stream) != 0 ? BT_ERR_DEVICE : BT_OK;
 	};
 	if (both) {
 		/* the batch's longest read is on the device only (c->d_cursor[7], reduced above): both builds are
 		 * enqueued, each gated on it; the one it rules out returns at once.  No host wait. */
 		A.gate = c->d_cursor + 7;
 		A.gateLo = BT_RL3_MAXLEN + 1u; A.gateHi = 0xffffffffu;
-		if ((rc = launch_levels(1)) != BT_OK) return rc;
+		if ((rc = launch_main(1)) != BT_OK) return rc;
 		A.gateLo = 0; A.gateHi = BT_RL3_MAXLEN;
-		if ((rc = launch_levels(2)) != BT_OK) return rc;
+		if ((rc = launch_main(2)) != BT_OK) return rc;
 		snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<3|2,*,true,*> (gated)");
 	} else {
 		A.gate = nullptr;
-		if ((rc = launch_levels(rl)) != BT_OK) return rc;
+		if ((rc = launch_main(rl)) != BT_OK) return rc;
 	}
 	if (devRetry) {
-		const bt_ctx* b = c->big;
-		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 8, c->retryCap, c->stream) != 0)
-			return BT_ERR_DEVICE;
-		BtKernelArgs R = A;                               /* same batch, index and output arrays (d_cold, d_warm) */
-		R.gate = nullptr;
-		R.frames = b->frames; R.pairs = b->pairs; R.meta = b->meta; R.pals = b->pals;
-		R.nLanes = b->nLanes; R.nSlots = b->nSlots; R.frCap = b->frCap; R.entCap = b->entCap; R.palCap = b->palCap;
-		R.nextRead = c->d_cursor + 9; R.nextSlot = c->d_cursor + 10;
-		R.order = c->retryList; R.orderCount = c->d_cursor + 8; R.orderCap = c->retryCap;
-		R.poolIn = nullptr; R.poolInCount = nullptr; R.poolOut = nullptr; R.poolOutCount = nullptr; R.poolOutCap = 0;
-		R.heavyRounds = 0xffffffffu;
-		if (bt_launch_search(&R, b->nLanes / BT_BLOCK, c->occ, maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0) ? 1 : 0, c->stream) != 0)
-			return BT_ERR_DEVICE;
+		/* over a batch whose reads have all finished: this one, or with carry-over the one before it */
+		if (!carry) rc = enqueue_retry(c, A, cur, c->d_cold, maxLen);
+		else if (adopt) {
+			BtCold pc = cold;
+			pc.B = c->prev.B; pc.Bprev = c->prev.B;
+			HIPCHK(hipMemcpyAsync(c->d_cold_prev, &pc, sizeof(pc), hipMemcpyHostToDevice, c->stream));
+			rc = enqueue_retry(c, A, c->prev, c->d_cold_prev, c->prevMaxLen);
+		}
+		if (rc != BT_OK) return rc;
 	}
+	if (carry) {
+		c->prev = cur; c->prevMaxLen = maxLen; c->carryPending = true; c->carryRl = rl; c->carryRetry = devRetry;
+		c->carryParity = 1 - p;
+		c->lastMmCursor = c->d_carry + 4 + p;
+	} else c->lastMmCursor = c->d_cursor + 1;
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipEventRecord(ring[1], c->stream));
 	c->timed = true;
 	return BT_OK;
 }
@@ -677,7 +748,7 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 			bt_ctx* b = nullptr;
 			rc = bt_ctx_create(c->idx, &c->pol, nullptr, &b);
 			if (rc != BT_OK) return rc;
-			b->is_big = true; b->heavy0 = 0;
+			b->is_big = true;
 			c->big = b;
 		}
 		const uint32_t m = (uint32_t)redo.size();
@@ -725,11 +796,50 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 	return worst;
 }
 
+/* Carry-over between the launches of this context (see bt_kernels.h).  On: a bt_align_batch_device call returns
+ * its batch's results complete only once the NEXT call's stream work is, or after bt_ctx_sync. */
+extern "C" int bt_ctx_set_carry(bt_ctx* c, int on)
+{
+	if (!c) return BT_ERR_ARG;
+	if (!on && c->carryPending) { const int rc = ctx_flush_carry(c); if (rc != BT_OK) return rc; }
+	c->carry = on != 0;
+	return BT_OK;
+}
+
+/* milliseconds from the start of the first launch since the last bt_ctx_sync to the end of the last one, and how
+ * many batches that was (call after bt_ctx_sync) */
+extern "C" float bt_ctx_span_ms(bt_ctx* c, uint32_t* n_launches)
+{
+	float ms = 0.f;
+	if (n_launches) *n_launches = c ? c->spanLaunches : 0;
+	if (!c || c->spanLaunches == 0) return 0.f;
+	if (hipEventElapsedTime(&ms, c->evSpan, c->ev1) != hipSuccess) return -1.f;
+	return ms;
+}
+
+/* duration of the i-th launch since the last-but-one bt_ctx_sync ... i.e. of the span bt_ctx_span_ms reports (the
+ * last 16 are kept); i = -1: the flush launch at the end of the span (0 if there was none).  Call after bt_ctx_sync. */
+extern "C" float bt_ctx_launch_ms(bt_ctx* c, int i)
+{
+	float ms = 0.f;
+	if (!c) return 0.f;
+	if (i < 0) { if (!c->flushTimed) return 0.f; return hipEventElapsedTime(&ms, c->evFlush[0], c->evFlush[1]) == hipSuccess ? ms : -1.f; }
+	if ((uint32_t)i >= c->spanLaunches || (uint32_t)i + 16u < c->spanLaunches) return 0.f;
+	return hipEventElapsedTime(&ms, c->evRing[i & 15][0], c->evRing[i & 15][1]) == hipSuccess ? ms : -1.f;
+}
+
 extern "C" int bt_ctx_sync(bt_ctx* c)
 {
 	if (!c) return BT_ERR_ARG;
+	if (c->carryPending) { const int rc = ctx_flush_carry(c); if (rc != BT_OK) return rc; }
 	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(hipMemcpy(&c->last_mm_used, c->d_cursor + 1, 4, hipMemcpyDeviceToHost));
+	c->spanOpen = false;
+	if (c->d_carry) {
+		uint32_t k[2] = {0, 0};
+		HIPCHK(hipMemcpy(k, c->d_carry, 8, hipMemcpyDeviceToHost));
+		c->last_carried = k[0] + k[1];
+	}
+	HIPCHK(hipMemcpy(&c->last_mm_used, c->lastMmCursor ? c->lastMmCursor : c->d_cursor + 1, 4, hipMemcpyDeviceToHost));
 	if (!c->is_big) HIPCHK(hipMemcpy(&c->last_dev_retried, c->d_cursor + (c->best ? 2 : 8), 4, hipMemcpyDeviceToHost));
 	return BT_OK;
 }
@@ -757,6 +867,8 @@ extern "C" int bt_ctx_prof_sections(bt_ctx* c, uint64_t* out, int n)
 extern "C" void bt_ctx_set_iters_buffer(bt_ctx* c, uint32_t* dev_ptr) { if (c) c->iters_dev = dev_ptr; }
 
 extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
+/* after bt_ctx_sync: reads the last two launches parked for their successors (carry-over; diagnostics) */
+extern "C" uint32_t bt_ctx_last_carried(bt_ctx* c) { return c ? c->last_carried : 0; }
 extern "C" uint32_t bt_ctx_last_retried(bt_ctx* c) { return c ? c->last_retried + c->last_dev_retried : 0; }
 
 extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)

@@ -155,7 +155,8 @@ struct BtWarm {
 struct BtCold {
 	BtProgram  P;
 	BtIndexDev ix[2];            /* [0] index of the text, [1] mirror index */
-	BtBatchDev B;
+	BtBatchDev B;                /* the batch being searched ...                                          */
+	BtBatchDev Bprev;            /* ... and the one before it: where the results of carried-over reads go  */
 };
 
 #define BT_STF_SKIPPED   1u
@@ -236,7 +237,7 @@ struct BtLane {
 	/* searcher (GreedyDFSRangeSource members) */
 	uint32_t qlen : 11, mirror : 1, readFw : 1, rev : 1, reportExacts : 1, considerQuals : 1, halfAndHalf : 1,
 	         maq : 1, reportPartials : 2, bailed : 1, nsFtab0 : 1;
-	uint32_t d5 : 11, d3 : 11;
+	uint32_t d5 : 11, d3 : 11, carried : 1;      /* carried: the read belongs to the previous batch (C.B[1]) */
 	uint32_t unrev : 11, r1 : 11;
 	uint32_t r2 : 11, r3 : 11;
 	uint32_t qualThresh;
@@ -451,7 +452,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
 	L.cchunk = 0xffu;
-	L.iters = 0; L.tosValid = 0; L.ccValid = 0;
+	L.iters = 0; L.tosValid = 0; L.ccValid = 0; L.carried = 0;
 	L.state = ST_PHASE_NEXT;
 	const uint32_t plen = L.plen;
 	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
@@ -579,7 +580,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
                         const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
 	const BtIndexDev* IX = C.ix;
-	const BtBatchDev& B = C.B;
+	const BtBatchDev& B = L.carried ? C.Bprev : C.B;
 	/* The states are visited in an order that lets the usual chains finish in one sweep (child
 	 * failed: FRAME_RETURN -> CHILD_RET -> BT_LOOP; phase change: FRAME_RETURN -> SEARCH_END ->
 	 * PHASE_NEXT -> SEARCH_BEGIN).  Within a block `break` leaves the block; a block that sets `req`

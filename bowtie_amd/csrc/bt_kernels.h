@@ -7,11 +7,14 @@
 
 #define BT_BLOCK 256
 
-/* A read that has run for more than `heavyRounds` rounds is taken out of its lane: the lane's whole
- * state (automaton + pending request + scratch slot) is parked in a pool record and the lane pulls
- * the next read.  A follow-up launch of the same kernel adopts the parked reads, one per lane, so
- * the few reads that backtrack for 10^5 rounds neither hold 63 idle lanes hostage nor keep the
- * batch's other wavefronts from retiring. */
+/* Carry-over.  When the read cursor of a launch runs dry, every lane is in the middle of a read, and the reads
+ * that backtrack for 10^5 rounds would keep their wavefronts -- and through them the workgroups' LDS -- for
+ * seconds after the rest have finished (the "tail": at 16 M reads per launch more than half the launch).
+ * Instead the lanes park what they are doing: the lane's whole state (automaton, pending request, scratch slot)
+ * goes into a pool record, the wavefront exits, and the next launch on the same context picks the parked reads
+ * up first, mixed in with its own fresh reads.  A read carried into a launch is finished by that launch (it is
+ * not parked a second time), so the results of batch k are complete when launch k+1 is, or after the flush
+ * launch bt_ctx_sync enqueues. */
 #define BT_POOL_WORDS 64
 struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot, [52..53] request kind/n, [56..59] request a/x */
 
@@ -19,19 +22,20 @@ struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */
 	const BtCold* cold;          /* device memory: program, full index descriptors, batch        */
 	const BtWarm* warm;          /* device memory; each workgroup copies it to LDS               */
-	/* per-slot scratch arenas (see BtScratch); slots 0..nLanes-1 belong to the lanes of the first
-	 * launch, the rest are handed out when a lane parks a heavy read and needs a fresh slot      */
+	/* per-slot scratch arenas (see BtScratch).  Lane g of a launch works in slot slotBase + g; a read carried over
+	 * from the previous launch keeps the slot it was parked with (the launches of a context alternate between
+	 * two sets of slots)                                                                           */
 	uint32_t*  frames;           /* [nSlots][frCap][12]                                          */
 	uint32_t*  pairs;            /* [nSlots][entCap][8]                                          */
 	uint16_t*  meta;             /* [nSlots][entCap] mask | Phred<<8                             */
 	uint64_t*  pals;             /* [nSlots][palCap]                                             */
-	uint32_t   nLanes, nSlots, frCap, entCap, palCap;
-	uint32_t*  nextRead;         /* work cursor: read ids (level 0) or pool records (level > 0)  */
-	const uint32_t* order;       /* optional: read id for each cursor value (heavy-first schedule) */
-	uint32_t*  nextSlot;         /* spare-slot cursor (starts at nLanes)                         */
-	const BtPoolRec* poolIn;  const uint32_t* poolInCount;      /* NULL at level 0               */
-	BtPoolRec* poolOut;       uint32_t* poolOutCount;  uint32_t poolOutCap;   /* NULL at the last level */
-	uint32_t   heavyRounds;      /* park reads that reach this many rounds                       */
+	uint32_t   nLanes, nSlots, frCap, entCap, palCap, slotBase;
+	uint32_t*  nextRead;         /* work cursor: read ids                                        */
+	const uint32_t* order;       /* optional: read id for each cursor value                      */
+	/* carry-over (see above): reads parked by the previous launch, and where this one parks its own */
+	const BtPoolRec* carryIn; const uint32_t* carryInCount; uint32_t* carryCursor;
+	BtPoolRec* carryOut;      uint32_t* carryOutCount;      uint32_t carryOutCap;
+	const uint8_t* prevSeq; const uint8_t* prevQual; uint32_t prevStride;   /* the previous batch's reads (cold->B[1] has the rest) */
 	const uint32_t* orderCount;  /* non-null (with order): the pick-up list's length lives on the device -- min(*orderCount,
 	                                orderCap) entries.  The on-stream second pass over reads that outgrew their scratch */
 	uint32_t   orderCap;
@@ -62,9 +66,6 @@ int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, 
 int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream);
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */
-int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
-                       const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
-                       uint8_t* bucket, uint32_t* hist, uint32_t* order, void* stream);
 int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, uint32_t iters, uint32_t dep, uint32_t* sink, void* stream);
 int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
                          uint8_t* L, void* stream);

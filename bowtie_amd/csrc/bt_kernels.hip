@@ -52,8 +52,8 @@ __device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint
 	dev_rank4_loaded(s, row, q0, q1, q2, q3, oth, lf, L);
 }
 
-/* EXT = true compiles in the optional machinery (heavy-read parking/adoption, heavy-first pick-up
- * order); the default launch uses the leaner EXT = false build of the same source. */
+/* EXT = true compiles in carry-over (parking at the end of a launch, adoption at the start of the next) and the
+ * pick-up list of the overflow second pass; a launch that needs neither uses the leaner EXT = false build. */
 /* LITE (with RL): the LDS diet that lets three blocks share a CU -- the read in 39 words (<= 104 bases) and
  * the top-of-stack record only, no candidate caches (51 KB per block instead of 72). */
 template <int OCC, bool EXT, bool RL, bool LITE>
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		ARENA.frCap = A.frCap; ARENA.entCap = A.entCap; ARENA.palCap = A.palCap; ARENA.pad = 0;
 	}
 	__syncthreads();
-	S.a = &ARENA; S.slot = g;
+	S.a = &ARENA; S.slot = (EXT ? A.slotBase : 0u) + g;
 	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	BtReq req;
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
 	bool drained = false;
+	bool poolDry = !(EXT && A.carryIn);                     /* nothing (left) to adopt from the previous launch */
 	const BtCold* cold = A.cold;
 	uint32_t nReads = A.H.n_reads;
 	if (EXT && A.orderCount) { const uint32_t v = *BT_GP(const uint32_t, A.orderCount); nReads = v < A.orderCap ? v : A.orderCap; }
@@ -103,6 +104,28 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		 * the whole loop: they are read where they are used */
 		asm volatile("" : "+s"(cold));
 
+		if (EXT && !poolDry) {
+			/* adopt the reads the previous launch parked before any fresh one: state, scratch slot, pending request */
+			bool failed = false;
+			if (L.state == ST_IDLE) {
+				const uint32_t w = atomicAdd(A.carryCursor, 1u);
+				if (w < *BT_GP(const uint32_t, A.carryInCount)) {
+					const BtPoolRec* r = A.carryIn + w;
+					BT_UNROLL
+					for (int k = 0; k < 12; k++) { const BtU4 v = ((const BtU4*)r->w)[k]; __builtin_memcpy((char*)&L + 16 * k, &v, 16); }
+					{ const BtU4 v = ((const BtU4*)r->w)[12]; S.slot = v.x; }
+					{ const BtU4 v = ((const BtU4*)r->w)[13]; req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
+					{ const BtU4 v = ((const BtU4*)r->w)[14]; req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
+					L.tosValid = 0; L.ccValid = 0; L.carried = 1;
+					if (RL) {
+						BT_NOUNROLL
+						for (uint32_t base = 0; base < L.plen; base += 16u)
+							bt_rl_store_chunk(S, base, bt_ld4(A.prevSeq + L.roff + base), bt_ld4(A.prevQual + L.roff + base));
+					}
+				} else failed = true;
+			}
+			if (__ballot(failed) != 0) poolDry = true;
+		}
 		/* ---- the round's memory requests: every lane's loads are issued, then one wait ---------- */
 		BT_PROF_T0(t_rank);
 		BtRes res;
@@ -162,21 +185,10 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		/* ---- advance every lane to its next request, pulling new reads as old ones finish ------- */
 		for (;;) {
 			if (L.state == ST_IDLE) {
+				if (EXT) S.slot = A.slotBase + blockIdx.x * BT_BLOCK + threadIdx.x;   /* the lane's own slot (after an adopted read) */
+				if (EXT && !poolDry) break;                  /* parked reads first: adopted at the top of the next round */
 				if (drained) break;
 				const uint32_t w = atomicAdd(A.nextRead, 1u);
-				if (EXT && A.poolIn) {
-					/* adopt a parked read: state, scratch slot and its pending request */
-					if (w >= *A.poolInCount) { drained = true; break; }
-					const BtPoolRec* r = A.poolIn + w;
-					BT_UNROLL
-					for (int k = 0; k < 12; k++) { const BtU4 v = ((const BtU4*)r->w)[k]; __builtin_memcpy((char*)&L + 16 * k, &v, 16); }
-					{ const BtU4 v = ((const BtU4*)r->w)[12]; S.slot = v.x; }
-					{ const BtU4 v = ((const BtU4*)r->w)[13]; req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
-					{ const BtU4 v = ((const BtU4*)r->w)[14]; req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
-					L.tosValid = 0; L.ccValid = 0;
-					if (RL) bt_rl_load(L, A.H, S);
-					break;                                   /* its request is served at the top of the next round */
-				}
 				if (w >= nReads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
 				bt_lane_start<RL>(L, PROG, A.H, *cold, S, (EXT && A.order) ? BT_GP(const uint32_t, A.order)[w] : w);
@@ -186,29 +198,32 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state == ST_IDLE) continue;
-			if (EXT && A.poolOut && L.iters >= A.heavyRounds) {
-				/* park this read (it resumes, bit for bit, in the next launch) and free the lane */
-				const uint32_t slot = atomicAdd(A.poolOutCount, 1u);
-				const uint32_t fresh = atomicAdd(A.nextSlot, 1u);
-				if (slot < A.poolOutCap && fresh < A.nSlots) {
-					BtPoolRec* r = A.poolOut + slot;
-					BT_UNROLL
-					for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); ((BtU4*)r->w)[k] = v; }
-					{ BtU4 v; v.x = S.slot; v.y = 0; v.z = 0; v.w = 0; ((BtU4*)r->w)[12] = v; }
-					{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; ((BtU4*)r->w)[13] = v; }
-					{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); ((BtU4*)r->w)[14] = v; }
-					S.slot = fresh;
-					L.state = ST_IDLE;
-					req.kind = RQ_NONE; req.wchunk = 0xffffu;
-					continue;
-				}
-				/* pool or slot arena full: the read simply stays in its lane */
-			}
 			break;
 		}
 		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
 		 * have run out of work simply carry an empty request */
-		const bool live = L.state != ST_IDLE;
+		bool live = L.state != ST_IDLE;
+		if (EXT && A.carryOut) {
+			/* the cursor is dry (a lane of this wavefront found it so, or a look at it every 16th round says so):
+			 * fresh reads still running here are parked for the next launch; reads carried into this launch stay */
+			bool dry = __ballot(drained) != 0;
+			if (!dry && (sc_rounds & 15u) == 15u) dry = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.nextRead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)nReads;
+			if (dry) {
+				drained = true;
+				if (live && !L.carried) {
+					const uint32_t slot = atomicAdd(A.carryOutCount, 1u);
+					if (slot < A.carryOutCap) {
+						BtPoolRec* r = A.carryOut + slot;
+						BT_UNROLL
+						for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); ((BtU4*)r->w)[k] = v; }
+						{ BtU4 v; v.x = S.slot; v.y = 0; v.z = 0; v.w = 0; ((BtU4*)r->w)[12] = v; }
+						{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; ((BtU4*)r->w)[13] = v; }
+						{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); ((BtU4*)r->w)[14] = v; }
+						L.state = ST_IDLE; live = false;
+					}
+				}
+			}
+		}
 		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
 		if (__ballot(live) == 0) break;
 		/* op counters: wave-uniform tallies in scalar registers (ballot + popcount), flushed once
@@ -237,80 +252,6 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	if (threadIdx.x < CN_N + PS_N && A.counts) atomicAdd(&A.counts[threadIdx.x], CNT[threadIdx.x]);
 }
 
-/* ---- heavy-first scheduling ------------------------------------------------------------------
- * The time a read takes is dominated by how repetitive its sequence is (a read from a high-copy
- * repeat family backtracks for 10^4..10^5 rounds; the median read needs ~200).  Reads are therefore
- * handed to the lanes longest-expected-first: a cheap proxy for the expected work -- the number of
- * occurrences in the text of a few 10-mers of the read, i.e. ftab range sizes -- is bucketed by
- * magnitude and the read ids are counting-sorted by bucket, heaviest bucket first.  Only the order
- * in which lanes pick up reads changes; results are indexed by read id. */
-__global__ void bt_weight_kernel(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
-                                 const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
-                                 uint8_t* bucket, uint32_t* hist)
-{
-	__shared__ uint32_t h[32];
-	if (threadIdx.x < 32) h[threadIdx.x] = 0;
-	__syncthreads();
-	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
-	if (rd < n) {
-		const uint8_t* s = seq + (uint64_t)rd * stride;
-		const uint32_t L = len[rd];
-		uint32_t weight = 0;
-		if (L >= ftabChars) {
-			const uint32_t nwin = 6, span = L - ftabChars;
-			for (uint32_t w = 0; w < nwin; w++) {
-				const uint32_t p0 = (uint32_t)(((uint64_t)span * w) / (nwin - 1));
-				uint32_t k = 0; bool ok = true;
-				for (uint32_t i = 0; i < ftabChars; i++) {
-					const uint32_t c = s[p0 + i];
-					if (c > 3u) ok = false;
-					k = (k << 2) | (c & 3u);
-				}
-				if (!ok) continue;
-				/* suffixes starting with this k-mer: [ftab[k], ftab[k+1]) up to the handful of
-				 * end-of-text entries, which are ignored for a weight */
-				const uint32_t a = ftab[k], b = ftab[k + 1];
-				if (a <= textLen && b <= textLen && b > a) weight += (b - a);
-			}
-		}
-		const uint32_t bk = weight == 0 ? 0u : 32u - (uint32_t)__builtin_clz(weight);   /* 0..32 */
-		const uint32_t bb = bk > 31u ? 31u : bk;
-		bucket[rd] = (uint8_t)bb;
-		atomicAdd(&h[bb], 1u);
-	}
-	__syncthreads();
-	if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
-/* hist[0..32) -> start offsets with the heaviest bucket first; cursors[32..64) */
-__global__ void bt_schedule_offsets_kernel(uint32_t* hist)
-{
-	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		uint32_t acc = 0;
-		for (int b = 31; b >= 0; b--) { const uint32_t c = hist[b]; hist[32 + b] = acc; acc += c; }
-	}
-}
-
-__global__ void bt_schedule_scatter_kernel(const uint8_t* bucket, uint32_t n, uint32_t* hist, uint32_t* order)
-{
-	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
-	if (rd >= n) return;
-	const uint32_t pos = atomicAdd(&hist[32 + bucket[rd]], 1u);
-	order[pos] = rd;
-}
-
-extern "C" int bt_launch_schedule(const uint8_t* seq, const uint16_t* len, uint32_t stride, uint32_t n,
-                                  const uint32_t* ftab, uint32_t ftabChars, uint32_t textLen,
-                                  uint8_t* bucket, uint32_t* hist, uint32_t* order, void* stream)
-{
-	hipStream_t st = (hipStream_t)stream;
-	if (hipMemsetAsync(hist, 0, 64 * sizeof(uint32_t), st) != hipSuccess) return 1;
-	const uint32_t nb = (n + 255) / 256;
-	hipLaunchKernelGGL(bt_weight_kernel, dim3(nb), dim3(256), 0, st, seq, len, stride, n, ftab, ftabChars, textLen, bucket, hist);
-	hipLaunchKernelGGL(bt_schedule_offsets_kernel, dim3(1), dim3(64), 0, st, hist);
-	hipLaunchKernelGGL(bt_schedule_scatter_kernel, dim3(nb), dim3(256), 0, st, bucket, n, hist, order);
-	return (int)hipGetLastError();
-}
 
 __global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)
 {
@@ -383,7 +324,7 @@ extern "C" int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, ui
 extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
-	const bool ext = a->poolIn || a->poolOut || a->order;
+	const bool ext = a->carryIn || a->carryOut || a->order;
 #define BT_LAUNCH(O, R, T) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
                                 else hipLaunchKernelGGL((bt_search_kernel<O, false, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
 	if (rl == 2) {

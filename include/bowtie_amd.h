@@ -217,6 +217,22 @@ int  bt_align_pairs(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* 
 int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
                            bt_op_counts* counts_dev);
 int  bt_ctx_sync(bt_ctx* ctx);
+/* Carry-over between the batches of a context (what the reference's worker threads get for free: a thread that
+ * finishes its read takes the next one, whatever "batch" it came from -- ebwt_search.cpp:1180-1230's GET_READ loop).
+ * Off (default): every bt_align_batch_device call runs its batch to the last read before the next one starts.  On:
+ * when a batch's reads have all been handed out, the searches still running are parked and the following call on
+ * this context resumes them alongside its own reads, so the minority of reads that backtrack for a long time never
+ * leave the GPU idle.  The contract changes accordingly: the results of a batch are complete when the stream work
+ * of the NEXT bt_align_batch_device call on the context is, or after bt_ctx_sync (which finishes whatever is
+ * parked); the batch's input and output arrays must stay valid until then.  Reads <= 112 bases, unpaired,
+ * phase-program engine; other batches are simply run to completion as before. */
+int  bt_ctx_set_carry(bt_ctx* ctx, int on);
+/* timing of the launches since the previous bt_ctx_sync (call after the next one): total milliseconds from the first
+ * launch's start to the last one's end and the number of batches; the i-th batch's own launches (the last 16 are
+ * kept; i = -1: the closing flush of parked reads, 0 without carry-over) */
+float bt_ctx_span_ms(bt_ctx* ctx, uint32_t* n_launches);
+float bt_ctx_launch_ms(bt_ctx* ctx, int i);
+uint32_t bt_ctx_last_carried(bt_ctx* ctx);   /* after bt_ctx_sync: reads the last two launches parked (diagnostics) */
 /* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */
 uint32_t bt_ctx_last_mm_used(bt_ctx* ctx);
 /* reads of the last bt_align_batch that outgrew their search arenas and were re-run with worst-case

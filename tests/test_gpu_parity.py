@@ -288,6 +288,76 @@ def test_gpu_device_path_retries_overflowed_reads_on_the_stream(gidx, monkeypatc
         T.compare_results(got, T.oracle_results(index, batch, kw, cap=cap), "device retry " + mode)
 
 
+def _device_align_many(al, batches, stride, hit_cap):
+    """A run of bt_align_batch_device calls on one context (each batch with its own arrays in HBM), one bt_ctx_sync at
+    the end -> [unpack_hits() list per batch]."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    keep = []
+    for batch in batches:
+        n = batch.n
+        seq = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        qual = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        seq[:, :batch.stride] = torch.from_numpy(np.ascontiguousarray(batch.seq)).to(dev)
+        qual[:, :batch.stride] = torch.from_numpy(np.ascontiguousarray(batch.qual)).to(dev)
+        ln = torch.from_numpy(batch.len.astype(np.int16)).to(dev)
+        seed = torch.from_numpy(batch.seed.view(np.int32).copy()).to(dev)
+        hits = torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev)
+        n_hits = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        status = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        pool = torch.zeros(n * hit_cap * 8, dtype=torch.int16, device=dev)
+        rbc = A.ReadBatchC(n, stride, seq.data_ptr(), qual.data_ptr(), ln.data_ptr(), seed.data_ptr())
+        hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), pool.data_ptr(), pool.numel(), 0)
+        keep.append((seq, qual, ln, seed, hits, n_hits, status, pool, rbc, hbc, n))
+        assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
+    assert AL.lib().bt_ctx_sync(al._h) == 0
+    pol = al.policy
+    out = []
+    for (_, _, _, _, hits, n_hits, status, pool, _, _, n) in keep:
+        out.append(AL.unpack_hits(n, hit_cap, hits.cpu().numpy().view(A.HIT_DTYPE), n_hits.cpu().numpy().view(np.uint32),
+                                  status.cpu().numpy(), pool.cpu().numpy().view(np.uint16), int(pol.khits), int(pol.mhits),
+                                  bool(pol.all_hits), sample_max=bool(pol.sample_max)))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["n2", "v2", "n3", "n2_k3", "n1_a_m20"])
+def test_gpu_carry_over_between_batches(mode, gidx, monkeypatch):
+    """bt_ctx_set_carry: with a two-workgroup grid every batch leaves reads running when its cursor runs dry; they are
+    parked, resumed by the next call, and the last ones finished by bt_ctx_sync.  Each batch's results -- written to
+    its own arrays, some of them by the launch after its own -- equal the oracle's."""
+    monkeypatch.setenv("BT_MAX_BLOCKS", "2")
+    kw = T.MODES[mode]
+    cap = T.hit_cap_for(kw)
+    al = aligner(gidx, "multi", kw)
+    assert AL.lib().bt_ctx_set_carry(al._h, 1) == 0
+    names = ["syn100", "syn36", "syn50lowq", "syn76", "syn100", "syn12"] if "all_hits" not in kw else ["syn100", "syn36", "syn50lowq", "syn76"]
+    batches = [T.read_set("multi", r) for r in names]
+    got = _device_align_many(al, batches, 112, cap)
+    assert AL.lib().bt_ctx_last_carried(al._h) > 0
+    for r, b, g in zip(names, batches, got):
+        T.compare_results(g, T.oracle_results("multi", b, kw, cap=cap), "carry-over %s %s" % (mode, r))
+
+
+def test_gpu_carry_over_many_small_launches_equal_one_big(gidx, monkeypatch):
+    """Size-independent property: 40 k reads as one batch without carry-over and as 20 carried batches of 2 k give the
+    same per-read results (digest), and the parked reads' scratch slots never collide (which would corrupt them)."""
+    monkeypatch.setenv("BT_MAX_BLOCKS", "4")
+    kw = T.MODES["n2"]
+    text = T.joined_text("e_coli")
+    big = synth_reads(text, 40000, 76, mm_dist=(0, 1, 2, 2, 3, 4), seed=4242)
+    al = aligner(gidx, "e_coli", kw)
+    whole = _device_align(al, big, 80, 1)
+    al2 = aligner(gidx, "e_coli", kw)
+    assert AL.lib().bt_ctx_set_carry(al2._h, 1) == 0
+    from bowtie_amd.reads import ReadBatch
+    parts = [ReadBatch(big.seq[i:i + 2000], big.qual[i:i + 2000], big.len[i:i + 2000], big.seed[i:i + 2000], big.names[i:i + 2000])
+             for i in range(0, 40000, 2000)]
+    got = _device_align_many(al2, parts, 80, 1)
+    assert AL.lib().bt_ctx_last_carried(al2._h) > 0
+    assert T.result_digest([x for g in got for x in g]) == T.result_digest(whole)
+
+
 # ---- the best-first engine (--best, --strata, -M, -v 3): bt_best_kernel ---------------------------
 BEST_RAGGED = ["n2_best", "v3", "v2_a_best_strata", "n3_best", "n2_M3", "v1_best", "n1_best", "n0_best_a_m3",
                "n3_best_a_l12_e200", "n2_k2_best_strata_m5"]
