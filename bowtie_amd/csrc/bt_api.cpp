@@ -76,6 +76,7 @@ struct bt_ctx {
 	void* stage = nullptr; size_t stage_bytes = 0;
 	uint32_t last_mm_used = 0;
 	uint32_t* iters_dev = nullptr;     /* optional per-read iteration counts (diagnostics) */
+	struct bt_stream* hs = nullptr;    /* bt_align_stream_*: staging slots of the batches in flight */
 };
 
 template <class T> static int upload(bt_index* ix, const std::vector<T>& v, const T** out, size_t pad_elems = 0)
@@ -224,6 +225,7 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 }
 
 static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* stream);
+static void ctx_free_stream(bt_ctx* c);
 
 extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* stream, bt_ctx** out)
 {
@@ -296,6 +298,7 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->d_carry) (void)hipFree(c->d_carry);
 	if (c->d_cold_prev) (void)hipFree(c->d_cold_prev);
 	if (c->evSpan) (void)hipEventDestroy(c->evSpan);
+	ctx_free_stream(c);
 	for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) if (c->evRing[i][k]) (void)hipEventDestroy(c->evRing[i][k]);
 	for (int k = 0; k < 2; k++) if (c->evFlush[k]) (void)hipEventDestroy(c->evFlush[k]);
 	if (c->d_counts) (void)hipFree(c->d_counts);
@@ -475,8 +478,10 @@ static int ctx_flush_carry(bt_ctx* c)
 	return BT_OK;
 }
 
+/* lens_on_device: maxLen is only the row stride (the lengths are in HBM); async: the caller does not wait for this
+ * batch before handing over the next -- carry-over and the on-stream second pass apply */
 static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uint32_t maxLen,
-                      unsigned long long* counts_dev, bool lens_on_device)
+                      unsigned long long* counts_dev, bool lens_on_device, bool async)
 {
 	if (in->n_reads == 0) { c->timed = false; return BT_OK; }
 	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
@@ -496,14 +501,14 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		if (maxLen <= BT_RL3_MAXLEN || both) rl = 2;          /* three blocks per CU: the LDS diet */
 	}
 	/* carry-over (bt_kernels.h): device-pointer batches on a context that asked for it, reads in LDS, one build */
-	const bool carry = c->carry && lens_on_device && !c->is_big && rl != 0 && !both && counts_dev == nullptr;
+	const bool carry = c->carry && async && !c->is_big && rl != 0 && !both && counts_dev == nullptr;
 	if (c->carryPending && (!carry || rl != c->carryRl || maxLen > c->maxLen)) {
 		if ((rc = ctx_flush_carry(c)) != BT_OK) return rc;
 	}
 	if ((rc = ctx_ensure_scratch(c, maxLen, carry)) != BT_OK) return rc;
 	/* the device-pointer entry point hands back finished results: reads that outgrow their scratch are searched
 	 * again on the stream (below), through the twin context's worst-case arenas; BT_DEVICE_RETRY=0 leaves them flagged */
-	const bool devRetry = lens_on_device && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
+	const bool devRetry = async && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
 	if (devRetry) {
 		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_scratch(c->big, maxLen, false)) != BT_OK) return rc;
@@ -536,6 +541,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
 	A.slotBase = (uint32_t)p * c->nLanes;
+	A.nextRead = c->d_cursor;
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	/* [0] read cursor, [1] mismatch-pool cursor, [7] longest read, [8] reads to search again, [9] their cursor,
 	 * [10] (unused by the kernel) the twin's lane count */
@@ -617,7 +623,7 @@ extern "C" int bt_align_batch_device(bt_ctx* c, const bt_read_batch* in, bt_hit_
 {
 	if (!c || !in || !out) return BT_ERR_ARG;
 	/* lengths live in HBM: size the scratch for the row stride (>= every length) */
-	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev, true);
+	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev, true, true);
 }
 
 /* Replaces: BitPairReference's constructor (reference.h:35-240; ebwt_search.cpp:3162-3171 loads it
@@ -921,7 +927,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
 	if (counts) HIPCHK(hipMemsetAsync(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long), c->stream));
-	int rc = run_device(c, &din, &dout, maxLen, nullptr, false);
+	int rc = run_device(c, &din, &dout, maxLen, nullptr, false, false);
 	if (rc != BT_OK) return rc;
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out->n_hits, d + o_nh, 4ull * n, hipMemcpyDeviceToHost, c->stream));
@@ -980,6 +986,142 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 		else if ((out->status[i] & (BT_STF_OVERFLOW | BT_STF_MMPOOL)) && worst == BT_OK) worst = BT_ERR_OVERFLOW;
 	}
 	return worst;
+}
+
+static void ctx_free_stream(bt_ctx* c);
+/* ---- a stream of host batches ---------------------------------------------------------------------
+ * bt_align_batch waits for its batch; a driver that has the next batch ready (a FASTQ reader ahead of
+ * the GPU) hands batches over one after the other instead and collects them in order.  Three staging
+ * areas in HBM take turns: while batch k is searched, batch k-1's results travel back and batch k+1's
+ * reads travel in.  With carry-over on, batch k's last reads finish inside launch k+1, so a batch is
+ * collectable once its successor has been submitted (or on flush).                                  */
+struct bt_stream_slot {
+	void* dev = nullptr; size_t bytes = 0;
+	const bt_read_batch* in = nullptr; bt_hit_batch* out = nullptr; void* tag = nullptr;
+	size_t o_hits = 0, o_nh = 0, o_st = 0, o_mm = 0;
+	uint32_t n = 0; uint32_t mm_used = 0; uint32_t* mmCursor = nullptr;
+	hipEvent_t done = nullptr, up = nullptr;
+	int state = 0;                       /* 0 free, 1 launched (results not yet on their way back), 2 copy-back enqueued */
+};
+struct bt_stream {
+	bt_stream_slot slot[3]; uint64_t submitted = 0, collected = 0;
+	hipStream_t copy = nullptr; hipEvent_t searched = nullptr;       /* PCIe traffic runs beside the search, not in its stream */
+};
+
+/* results of a batch whose searches are all enqueued: back to the host on the copy stream, once the search stream
+ * has got that far */
+static int stream_copy_back(bt_ctx* c, bt_stream_slot& s)
+{
+	uint8_t* d = (uint8_t*)s.dev;
+	bt_hit_batch* out = s.out;
+	hipStream_t cs = c->hs->copy;
+	HIPCHK(hipEventRecord(c->hs->searched, c->stream));
+	HIPCHK(hipStreamWaitEvent(cs, c->hs->searched, 0));
+	HIPCHK(hipMemcpyAsync(&s.mm_used, s.mmCursor, 4, hipMemcpyDeviceToHost, cs));
+	HIPCHK(hipMemcpyAsync(out->n_hits, d + s.o_nh, 4ull * s.n, hipMemcpyDeviceToHost, cs));
+	HIPCHK(hipMemcpyAsync(out->status, d + s.o_st, s.n, hipMemcpyDeviceToHost, cs));
+	HIPCHK(hipMemcpyAsync(out->hits, d + s.o_hits, (size_t)s.n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, cs));
+	if (out->mm_pool_cap) HIPCHK(hipMemcpyAsync(out->mm_pool, d + s.o_mm, 2ull * out->mm_pool_cap, hipMemcpyDeviceToHost, cs));
+	HIPCHK(hipEventRecord(s.done, cs));
+	s.state = 2;
+	return BT_OK;
+}
+
+static void ctx_free_stream(bt_ctx* c)
+{
+	if (!c->hs) return;
+	for (auto& s : c->hs->slot) { if (s.dev) (void)hipFree(s.dev); if (s.done) (void)hipEventDestroy(s.done); if (s.up) (void)hipEventDestroy(s.up); }
+	if (c->hs->copy) (void)hipStreamDestroy(c->hs->copy);
+	if (c->hs->searched) (void)hipEventDestroy(c->hs->searched);
+	delete c->hs;
+	c->hs = nullptr;
+}
+
+extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, void* tag)
+{
+	if (!c || !in || !out || in->n_reads == 0) return BT_ERR_ARG;
+	const uint32_t n = in->n_reads;
+	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
+	    out->hit_cap == 0 || (in->stride & 15u) != 0) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(c->idx->device));
+	if (!c->hs) {
+		c->hs = new bt_stream();
+		HIPCHK(hipStreamCreateWithFlags(&c->hs->copy, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&c->hs->searched, hipEventDisableTiming));
+	}
+	bt_stream& S = *c->hs;
+	if (S.submitted - S.collected >= 2) return BT_ERR_ARG;          /* collect first: at most two batches are in flight */
+	uint32_t maxLen = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		if (in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;
+		if (in->len[i] > maxLen) maxLen = in->len[i];
+	}
+	HIPCHK(hipSetDevice(c->idx->device));
+	bt_stream_slot& s = S.slot[S.submitted % 3];
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t o_seq = 0, o_qual = o_seq + al((size_t)n * in->stride), o_len = o_qual + al((size_t)n * in->stride),
+	             o_seed = o_len + al(2ull * n), o_hits = o_seed + al(4ull * n),
+	             o_nh = o_hits + al((size_t)n * out->hit_cap * sizeof(bt_hit)), o_st = o_nh + al(4ull * n),
+	             o_mm = o_st + al(n), total = o_mm + al(2ull * out->mm_pool_cap);
+	if (total > s.bytes) {
+		if (s.dev) (void)hipFree(s.dev);
+		s.dev = nullptr; s.bytes = 0;
+		HIPCHK(hipMalloc(&s.dev, total));
+		s.bytes = total;
+	}
+	if (!s.done) { HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s.up, hipEventDisableTiming)); }
+	uint8_t* d = (uint8_t*)s.dev;
+	hipStream_t cs = S.copy;
+	HIPCHK(hipMemcpyAsync(d + o_seq, in->seq, (size_t)n * in->stride, hipMemcpyHostToDevice, cs));
+	HIPCHK(hipMemcpyAsync(d + o_qual, in->qual, (size_t)n * in->stride, hipMemcpyHostToDevice, cs));
+	HIPCHK(hipMemcpyAsync(d + o_len, in->len, 2ull * n, hipMemcpyHostToDevice, cs));
+	HIPCHK(hipMemcpyAsync(d + o_seed, in->seed, 4ull * n, hipMemcpyHostToDevice, cs));
+	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_mm - o_hits, cs));
+	HIPCHK(hipEventRecord(s.up, cs));
+	HIPCHK(hipStreamWaitEvent(c->stream, s.up, 0));
+	bt_read_batch din = *in;
+	din.seq = d + o_seq; din.qual = d + o_qual; din.len = (const uint16_t*)(d + o_len); din.seed = (const uint32_t*)(d + o_seed);
+	bt_hit_batch dout = *out;
+	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
+	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
+	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true);
+	if (rc != BT_OK) return rc;
+	s.in = in; s.out = out; s.tag = tag; s.n = n; s.o_hits = o_hits; s.o_nh = o_nh; s.o_st = o_st; s.o_mm = o_mm;
+	s.mmCursor = c->lastMmCursor; s.state = 1;
+	S.submitted++;
+	/* what the launch just enqueued finished (carry-over) or this very batch (none parked): on its way back */
+	if (c->carryPending) {
+		if (S.submitted - S.collected == 2) { bt_stream_slot& p = S.slot[(S.submitted - 2) % 3]; if (p.state == 1) return stream_copy_back(c, p); }
+		return BT_OK;
+	}
+	for (uint64_t k = S.collected; k < S.submitted; k++) { bt_stream_slot& p = S.slot[k % 3]; if (p.state == 1) { const int r2 = stream_copy_back(c, p); if (r2 != BT_OK) return r2; } }
+	return BT_OK;
+}
+
+/* The oldest submitted batch, finished: its bt_hit_batch is filled (mm_pool_used included), *tag is what came with
+ * it.  flush != 0: nothing follows -- finish the parked reads now.  Without flush the call needs a successor to have
+ * been submitted when carry-over is on (BT_ERR_ARG otherwise).  *tag = NULL with BT_OK: nothing in flight. */
+extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
+{
+	if (!c || !tag) return BT_ERR_ARG;
+	*tag = nullptr;
+	if (!c->hs || c->hs->submitted == c->hs->collected) return BT_OK;
+	bt_stream& S = *c->hs;
+	HIPCHK(hipSetDevice(c->idx->device));
+	bt_stream_slot& s = S.slot[S.collected % 3];
+	if (s.state == 1) {
+		if (!flush) return BT_ERR_ARG;
+		const int rc = ctx_flush_carry(c);
+		if (rc != BT_OK) return rc;
+		const int r2 = stream_copy_back(c, s);
+		if (r2 != BT_OK) return r2;
+	}
+	HIPCHK(hipEventSynchronize(s.done));
+	s.out->mm_pool_used = s.mm_used < s.out->mm_pool_cap ? s.mm_used : s.out->mm_pool_cap;
+	*tag = s.tag;
+	s.state = 0;
+	S.collected++;
+	return BT_OK;
 }
 
 /* ---- probes ---------------------------------------------------------------------------------- */

@@ -43,6 +43,7 @@ struct Options {
 	std::string dump_al, dump_un, dump_max;   /* --al / --un / --max */
 	std::vector<std::string> rg_fields;
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
+	bool no_stream = false;
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false, paired = false;
 	std::string mates1, mates2;
@@ -125,6 +126,8 @@ void usage(FILE* o)
 	    "  --device <list>    GPU(s) to run on, e.g. 0,1,2,3: index replicated, batches dealt out (default: 0)\n"
 	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
+	    "  --no-stream        search whole batches side by side (--inflight) instead of streaming them\n"
+	    "                     through one context per GPU with carry-over between batches\n"
 	    "Other:\n"
 	    "  --seed <int>       seed for random number generator\n"
 	    "  --version          print version information and quit\n"
@@ -153,7 +156,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -164,7 +167,7 @@ const LongOpt LONGS[] = {
 	{"usage", 0, O_USAGE}, {"sam", 0, 'S'}, {"sam-no-qname-trunc", 0, O_SAM_NOTRUNC}, {"sam-nohead", 0, O_SAM_NOHEAD},
 	{"sam-nosq", 0, O_SAM_NOSQ}, {"sam-noSQ", 0, O_SAM_NOSQ}, {"sam-RG", 1, O_SAM_RG}, {"suppress", 1, O_SUPPRESS}, {"mapq", 1, O_MAPQ},
 	{"cost", 0, O_COST}, {"showseed", 0, O_SHOWSEED}, {"no-unal", 0, O_NO_UNAL}, {"quiet", 0, O_QUIET}, {"device", 1, O_DEVICE},
-	{"batch", 1, O_BATCH}, {"inflight", 1, O_INFLIGHT}, {"wrapper", 1, O_WRAPPER},
+	{"batch", 1, O_BATCH}, {"inflight", 1, O_INFLIGHT}, {"no-stream", 0, O_NOSTREAM}, {"wrapper", 1, O_WRAPPER},
 	/* accepted and without effect here (host-memory / CPU-threading knobs of the reference) */
 	{"reads-per-batch", 1, O_IGNORED_ARG}, {"chunkmbs", 1, O_IGNORED_ARG}, {"chunksz", 1, O_IGNORED_ARG}, {"chunkverbose", 0, O_IGNORED},
 	{"verbose", 0, O_IGNORED}, {"startverbose", 0, O_IGNORED}, {"sanity", 0, O_IGNORED}, {"reorder", 0, O_IGNORED},
@@ -321,6 +324,7 @@ void parse_args(int argc, char** argv, Options* O)
 			break;
 		}
 		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
+		case O_NOSTREAM: O->no_stream = true; break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
 		case O_INTQUALS: O->int_quals = true; break;
@@ -449,6 +453,7 @@ struct Job {
 	std::vector<uint8_t> status;
 	std::vector<uint16_t> mm_pool;
 	uint32_t mm_used = 0;
+	bt_hit_batch hb;                         /* view into the four arrays above (what the search fills) */
 	/* reads whose hits did not fit the uniform slots: searched again alone with room for all */
 	struct Wide { uint32_t read; uint32_t hit_cap; std::vector<bt_hit> hits; std::vector<uint16_t> pool; uint32_t n_hits; uint8_t status; };
 	std::vector<Wide> wide;
@@ -517,9 +522,9 @@ std::string search_job_pairs(bt_ctx* ctx, const Options& O, Job* j)
 	return "";
 }
 
-std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
+/* size a job's result arrays for the first pass */
+void search_prepare(const Options& O, Job* j)
 {
-	if (O.paired) return search_job_pairs(ctx, O, j);
 	const uint32_t n = j->rb.n_reads;
 	const bool all = O.pol.all_hits != 0;
 	j->hit_cap = all ? 16u : (O.pol.khits > 64u ? 64u : O.pol.khits);
@@ -528,9 +533,27 @@ std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 	j->hits.resize((size_t)n * j->hit_cap);
 	j->n_hits.assign(n, 0); j->status.assign(n, 0);
 	j->mm_pool.resize((size_t)n * j->hit_cap * 6u + 1024u);
-	bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
-	int rc = bt_align_batch(ctx, &j->rb, &hb, nullptr);
-	j->mm_used = hb.mm_pool_used;
+	j->hb = bt_hit_batch{ j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
+}
+
+std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc);
+
+std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
+{
+	if (O.paired) return search_job_pairs(ctx, O, j);
+	search_prepare(O, j);
+	const int rc = bt_align_batch(ctx, &j->rb, &j->hb, nullptr);
+	return search_finish(ctx, O, j, rc);
+}
+
+/* the first pass is back (rc = what bt_align_batch said, or worked out from the status bytes after a streamed
+ * search): errors the reference stops at, and the second pass for reads with more hits than slots.  ctx: a context
+ * with nothing in flight. */
+std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc)
+{
+	const uint32_t n = j->rb.n_reads;
+	const bool all = O.pol.all_hits != 0;
+	j->mm_used = j->hb.mm_pool_used;
 	if (rc == BT_ERR_READ_SHORT) {
 		/* the reference stops at the first such read (search_1mm_phase1.c:12-15, search_23mm_phase1.c:13-20) */
 		for (uint32_t i = 0; i < n; i++) if (j->status[i] & BT_ST_TOOSHORT) {
@@ -655,10 +678,20 @@ int main(int argc, char** argv)
 	bt_index_info_get(idx, &info);
 	BtRefNames refs;
 	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
-	std::vector<bt_ctx*> ctxs((size_t)O.inflight * ND, nullptr);          /* searcher g works on GPU g % ND */
+	/* Unpaired searches through the phase programs are streamed: one searcher per GPU keeps its context fed and
+	 * the reads a batch leaves running are carried into the next one (bt_ctx_set_carry).  --no-stream, paired-end
+	 * and --best runs search `--inflight` whole batches side by side instead. */
+	const bool streamed = !O.paired && !O.pol.best && !O.no_stream;
+	std::vector<bt_ctx*> ctxs((size_t)(streamed ? 1 : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */
+	std::vector<bt_ctx*> redo_ctxs(streamed ? ctxs.size() : 0, nullptr);
 	for (size_t g = 0; g < ctxs.size(); g++) {
 		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+		if (streamed) {
+			if (bt_ctx_set_carry(ctxs[g], 1) != BT_OK) die("Error: bt_ctx_set_carry failed");
+			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
+			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+		}
 	}
 
 	/* ---- output ---- */
@@ -845,15 +878,57 @@ int main(int argc, char** argv)
 	const double t_search = now_s();
 	std::vector<std::thread> searchers;
 	for (int g = 0; g < G; g++) searchers.emplace_back([&, g] {
+		if (!streamed) {
+			for (;;) {
+				std::unique_ptr<Job> j = to_gpu.take();
+				if (j->last) { to_out.put(std::move(j)); return; }
+				if (!abort_run.load()) {
+					const double tb = now_s();
+					j->error = search_job(ctxs[(size_t)g], O, j.get());
+					busy_gpu[(size_t)g] += now_s() - tb;
+				}
+				to_out.put(std::move(j));
+			}
+		}
+		/* Streamed: this thread keeps one context fed (bt_align_stream_*, carry-over on): a batch goes in, the
+		 * one before it comes out -- its last reads were finished by the launch of the one just submitted -- and is
+		 * post-processed on the thread's second context while the GPU works on. */
+		bt_ctx* cs = ctxs[(size_t)g];
+		bt_ctx* cr = redo_ctxs[(size_t)g];
+		std::unique_ptr<Job> prev;
+		auto finish = [&](int flush) {
+			void* tag = nullptr;
+			const int rc = bt_align_stream_collect(cs, &tag, flush);
+			if (rc != BT_OK || tag != (void*)prev.get()) prev->error = std::string("Error: search failed: ") + bt_strerror(rc != BT_OK ? rc : BT_ERR_DEVICE);
+			else {
+				int st = BT_OK;
+				for (uint32_t i = 0; i < prev->rb.n_reads && st == BT_OK; i++) if (prev->status[i] & BT_ST_TOOSHORT) st = BT_ERR_READ_SHORT;
+				prev->error = search_finish(cr, O, prev.get(), st);
+			}
+			to_out.put(std::move(prev));
+		};
 		for (;;) {
 			std::unique_ptr<Job> j = to_gpu.take();
-			if (j->last) { to_out.put(std::move(j)); return; }
-			if (!abort_run.load()) {
-				const double tb = now_s();
-				j->error = search_job(ctxs[(size_t)g], O, j.get());
+			const double tb = now_s();
+			if (j->last || abort_run.load()) {
+				if (prev) finish(1);
 				busy_gpu[(size_t)g] += now_s() - tb;
+				const bool end = j->last;
+				to_out.put(std::move(j));
+				if (end) return;
+				continue;
 			}
-			to_out.put(std::move(j));
+			search_prepare(O, j.get());
+			const int rc = bt_align_stream_submit(cs, &j->rb, &j->hb, j.get());
+			if (rc != BT_OK) {
+				if (prev) finish(1);
+				j->error = std::string("Error: search failed: ") + bt_strerror(rc);
+				to_out.put(std::move(j));
+				continue;
+			}
+			if (prev) finish(0);
+			prev = std::move(j);
+			busy_gpu[(size_t)g] += now_s() - tb;
 		}
 	});
 	for (auto& x : searchers) x.join();
@@ -872,6 +947,7 @@ int main(int argc, char** argv)
 	bt_io_close(rs);
 	if (rs2) bt_io_close(rs2);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
+	for (bt_ctx* c : redo_ctxs) bt_ctx_destroy(c);
 	for (bt_index* x : idxs) bt_index_free(x);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }

@@ -216,6 +216,15 @@ int  bt_align_pairs(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* 
                     bt_op_counts* counts);
 int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
                            bt_op_counts* counts_dev);
+/* A stream of host batches through one context: bt_align_stream_submit uploads a batch and enqueues its search
+ * without waiting (PCIe traffic on a copy stream of its own, three staging areas in HBM taking turns);
+ * bt_align_stream_collect returns the oldest submitted batch once its bt_hit_batch is filled (`*tag` = the value
+ * given at submit; NULL = nothing in flight).  At most two batches are in flight: submit, then collect the previous
+ * one.  With carry-over (below) a batch can be collected once its successor has been submitted; pass flush != 0
+ * when there is none (end of input).  `in`, `out` and the arrays they point at stay the caller's and must live
+ * until the batch is collected.  What the reference does with a FASTQ reader feeding its worker threads. */
+int  bt_align_stream_submit(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, void* tag);
+int  bt_align_stream_collect(bt_ctx* ctx, void** tag, int flush);
 int  bt_ctx_sync(bt_ctx* ctx);
 /* Carry-over between the batches of a context (what the reference's worker threads get for free: a thread that
  * finishes its read takes the next one, whatever "batch" it came from -- ebwt_search.cpp:1180-1230's GET_READ loop).

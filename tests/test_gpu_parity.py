@@ -358,6 +358,46 @@ def test_gpu_carry_over_many_small_launches_equal_one_big(gidx, monkeypatch):
     assert T.result_digest([x for g in got for x in g]) == T.result_digest(whole)
 
 
+@pytest.mark.parametrize("carry", [0, 1])
+def test_gpu_host_batches_streamed(carry, gidx, monkeypatch):
+    """bt_align_stream_submit / _collect: host batches handed over one after the other (three staging areas in HBM,
+    PCIe on a copy stream), collected in order -- with carry-over a batch is collectable once its successor is in --
+    each equal to the oracle's results."""
+    import ctypes as C
+    monkeypatch.setenv("BT_MAX_BLOCKS", "2")
+    kw = T.MODES["n2_k3"]
+    cap = 8
+    al = aligner(gidx, "multi", kw)
+    L = AL.lib()
+    assert L.bt_ctx_set_carry(al._h, carry) == 0
+    names = ["syn100", "syn36", "syn150", "syn50lowq", "syn76", "syn100"]      # syn150 (> 112 bases) cannot be carried: forces a flush
+    jobs = []
+    for r in names:
+        b = T.read_set("multi", r)
+        k, rb = AL.pack_batch(b)
+        hits = np.zeros(b.n * cap, dtype=A.HIT_DTYPE)
+        n_hits = np.zeros(b.n, dtype=np.uint32)
+        status = np.zeros(b.n, dtype=np.uint8)
+        pool = np.zeros(b.n * cap * 8, dtype=np.uint16)
+        hb = A.HitBatchC(cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, pool.ctypes.data, len(pool), 0)
+        jobs.append(dict(b=b, keep=k, rb=rb, hits=hits, n_hits=n_hits, status=status, pool=pool, hb=hb))
+    done = []
+    tag = C.c_void_p()
+    for i, j in enumerate(jobs):
+        assert L.bt_align_stream_submit(al._h, C.byref(j["rb"]), C.byref(j["hb"]), C.c_void_p(i + 1)) == 0
+        if i > 0:
+            assert L.bt_align_stream_collect(al._h, C.byref(tag), 0) == 0
+            done.append(tag.value)
+    assert L.bt_align_stream_collect(al._h, C.byref(tag), 1) == 0
+    done.append(tag.value)
+    assert L.bt_align_stream_collect(al._h, C.byref(tag), 1) == 0 and tag.value is None
+    assert done == list(range(1, len(jobs) + 1))
+    pol = al.policy
+    for r, j in zip(names, jobs):
+        got = AL.unpack_hits(j["b"].n, cap, j["hits"], j["n_hits"], j["status"], j["pool"], int(pol.khits), int(pol.mhits), bool(pol.all_hits))
+        T.compare_results(got, T.oracle_results("multi", j["b"], kw, cap=cap), "streamed %s carry=%d" % (r, carry))
+
+
 # ---- the best-first engine (--best, --strata, -M, -v 3): bt_best_kernel ---------------------------
 BEST_RAGGED = ["n2_best", "v3", "v2_a_best_strata", "n3_best", "n2_M3", "v1_best", "n1_best", "n0_best_a_m3",
                "n3_best_a_l12_e200", "n2_k2_best_strata_m5"]
