@@ -338,6 +338,7 @@ def main():
         o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
         if carry and lib.bt_ctx_set_carry(o["al"]._h, 1) != 0:
             raise RuntimeError("bt_ctx_set_carry failed")
+        lib.bt_ctx_set_max_read_len(o["al"]._h, L)         # synthetic reads: all of length L (rows are padded to 16)
         pipes.append(o)
     torch.cuda.synchronize()
     log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))

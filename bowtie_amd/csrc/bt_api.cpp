@@ -68,6 +68,7 @@ struct bt_ctx {
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
 	uint32_t last_retried = 0, last_dev_retried = 0, last_carried = 0;
+	uint32_t maxLenHint = 0;           /* bt_ctx_set_max_read_len */
 	char last_kernel[64] = "";         /* the kernel variant the last batch ran (as rocprofv3 names it) */
 	BtCold* d_cold = nullptr;
 	BtWarm* d_warm = nullptr;
@@ -622,8 +623,9 @@ extern "C" int bt_align_batch_device(bt_ctx* c, const bt_read_batch* in, bt_hit_
                                      bt_op_counts* counts_dev)
 {
 	if (!c || !in || !out) return BT_ERR_ARG;
-	/* lengths live in HBM: size the scratch for the row stride (>= every length) */
-	return run_device(c, in, out, in->stride, (unsigned long long*)counts_dev, true, true);
+	/* lengths live in HBM: size the scratch for the row stride (>= every length), or for what the caller vouched for */
+	const uint32_t hint = c->maxLenHint && c->maxLenHint < in->stride ? c->maxLenHint : 0u;
+	return run_device(c, in, out, hint ? hint : in->stride, (unsigned long long*)counts_dev, hint == 0, true);
 }
 
 /* Replaces: BitPairReference's constructor (reference.h:35-240; ebwt_search.cpp:3162-3171 loads it
@@ -800,6 +802,16 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 	for (uint32_t i = 0; i < n; i++)
 		if ((out->status[i] & (BT_STF_OVERFLOW | BT_STF_MMPOOL)) && worst == BT_OK) worst = BT_ERR_OVERFLOW;
 	return worst;
+}
+
+/* The caller's word that no read of the device-pointer batches to come is longer than max_len (0 = no such promise):
+ * the build of the kernel follows from it without a look at the lengths in HBM.  A read that breaks the promise is
+ * not searched and comes back flagged BT_ST_OVERFLOW. */
+extern "C" int bt_ctx_set_max_read_len(bt_ctx* c, uint32_t max_len)
+{
+	if (!c) return BT_ERR_ARG;
+	c->maxLenHint = max_len;
+	return BT_OK;
 }
 
 /* Carry-over between the launches of this context (see bt_kernels.h).  On: a bt_align_batch_device call returns

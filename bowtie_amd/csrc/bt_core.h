@@ -454,6 +454,11 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	L.cchunk = 0xffu;
 	L.iters = 0; L.tosValid = 0; L.ccValid = 0; L.carried = 0;
 	L.state = ST_PHASE_NEXT;
+	if (RL && L.plen > S.rlQual * 8u) {
+		/* longer than this build keeps in LDS (the caller's bt_ctx_set_max_read_len promise did not hold): not
+		 * searched, flagged */
+		L.plen = 0; L.status = BT_STF_OVERFLOW;
+	}
 	const uint32_t plen = L.plen;
 	const uint32_t qs = plen < P.seedLen ? plen : P.seedLen;
 	/* one pass of 16-byte loads over the read: does it contain an N at all (almost never), and

@@ -236,6 +236,11 @@ int  bt_ctx_sync(bt_ctx* ctx);
  * parked); the batch's input and output arrays must stay valid until then.  Reads <= 112 bases, unpaired,
  * phase-program engine; other batches are simply run to completion as before. */
 int  bt_ctx_set_carry(bt_ctx* ctx, int on);
+/* bt_align_batch_device sees the read lengths in HBM only; which build of the kernel a batch can use (reads kept
+ * in LDS up to 104 / 112 bases, ebwt_search_backtrack.h:90-140's query accessors) then has to be settled on the
+ * device.  A driver that knows its reads (a sequencer's fixed length) says so here: max_len = the longest read of
+ * the batches to come, 0 = unknown again.  A longer read is not searched and is flagged BT_ST_OVERFLOW. */
+int  bt_ctx_set_max_read_len(bt_ctx* ctx, uint32_t max_len);
 /* timing of the launches since the previous bt_ctx_sync (call after the next one): total milliseconds from the first
  * launch's start to the last one's end and the number of batches; the i-th batch's own launches (the last 16 are
  * kept; i = -1: the closing flush of parked reads, 0 without carry-over) */

@@ -2,8 +2,9 @@
 # round-2 GPU pass 2: new GPU tests (index family, gated device path, on-stream retry, carry-over) and the carry-over A/B
 export TMPDIR=/tmp
 O=gpurun_out/r2c; mkdir -p $O
-( time timeout 900 python -m pytest tests/test_index_family.py tests/test_gpu_parity.py -m gpu -x -q -k "family or large_index or other_endian or cli_on_large or carry or device_path or hits_verify or overflow" ) > $O/gputests_new.txt 2>&1
+( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py tests/test_gpu_cli.py -m gpu -x -q -k "carry or device_path or streamed or scale or 100mbp or cli" ) > $O/gputests_new.txt 2>&1
 tail -15 $O/gputests_new.txt
+grep -q " passed" $O/gputests_new.txt && ! grep -q "failed\|Aborted\|error" $O/gputests_new.txt || { echo "tests failed: stopping"; grep -B5 -A60 "Error\|FAILED\|assert" $O/gputests_new.txt | head -200; exit 1; }
 run() { # name, args...
   local name=$1; shift
   timeout 600 python bench.py "$@" > $O/$name.json 2> $O/$name.err
@@ -22,4 +23,3 @@ run b16_carry_p2    --reads 16000000 --steps 6 --warmup 2 --pipes 2 --no-cpu --n
 run b4_carry_p1     --reads 4000000 --steps 12 --warmup 2 --pipes 1 --no-cpu --no-verify
 run b200_carry      --no-cpu
 run b200_nocarry    --no-cpu --no-verify --no-carry
-timeout 300 python bench.py --reads 16000000 --steps 1 --warmup 0 --pipes 1 --no-cpu --no-verify --no-carry --iters-hist > $O/iters16.json 2> $O/iters16.err; grep "LF rounds" $O/iters16.err

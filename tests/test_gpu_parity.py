@@ -331,6 +331,7 @@ def test_gpu_carry_over_between_batches(mode, gidx, monkeypatch):
     cap = T.hit_cap_for(kw)
     al = aligner(gidx, "multi", kw)
     assert AL.lib().bt_ctx_set_carry(al._h, 1) == 0
+    assert AL.lib().bt_ctx_set_max_read_len(al._h, 100) == 0      # rows are 112 apart; no read is longer than 100
     names = ["syn100", "syn36", "syn50lowq", "syn76", "syn100", "syn12"] if "all_hits" not in kw else ["syn100", "syn36", "syn50lowq", "syn76"]
     batches = [T.read_set("multi", r) for r in names]
     got = _device_align_many(al, batches, 112, cap)
