@@ -32,17 +32,19 @@ def scale(tmp_path_factory):
 
 
 def _reference_sam(base, args, inputs, out):
-    r = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", str(min(32, os.cpu_count() or 1)), "-S", "--sam-nohead", "--reorder"] +
-                       args + ["-x", base] + inputs + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    # one thread: its output order is the input order (and the reference's --reorder with several threads does not
+    # return on runs that suppress reads with -m: observed on this very case, bowtie-align-s -p 4 --reorder ... -m 3)
+    r = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "-S", "--sam-nohead"] +
+                       args + ["-x", base] + inputs + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-400:]
     with open(out, "rb") as f:
         return f.read().split(b"\n")
 
 
 @pytest.mark.parametrize("name,pol,args,length,n", [
-    ("n2", dict(mode="n", mms=2, seed_len=28, qual_thresh=70), ["-n", "2", "-l", "28", "-e", "70"], 100, 60000),
-    ("v2_k2", dict(mode="v", mms=2, khits=2), ["-v", "2", "-k", "2"], 76, 40000),
-    ("n2_best_strata_m3", dict(mode="n", mms=2, best=True, strata=True, mhits=3, max_bts=800), ["-n", "2", "--best", "--strata", "-m", "3"], 50, 30000),
+    ("n2", dict(mode="n", mms=2, seed_len=28, qual_thresh=70), ["-n", "2", "-l", "28", "-e", "70"], 100, 40000),
+    ("v2_k2", dict(mode="v", mms=2, khits=2), ["-v", "2", "-k", "2"], 76, 30000),
+    ("n2_best_strata_m3", dict(mode="n", mms=2, best=True, strata=True, mhits=3, max_bts=800), ["-n", "2", "--best", "--strata", "-m", "3"], 50, 20000),
 ])
 def test_gpu_sam_equals_reference_on_100mbp_index(name, pol, args, length, n, scale):
     import bench
@@ -70,7 +72,7 @@ def test_gpu_paired_sam_equals_reference_on_100mbp_index(scale):
     """BASELINE config 5's shape (-1/-2 -n 1 --best -X 250, 50-bp mates) at this size."""
     import bench
     from bowtie_amd.synth import synth_pairs, write_fastq
-    n = 15000
+    n = 10000
     b1, b2 = synth_pairs(scale["text"], n, 50, mm_dist=(0, 0, 1, 1, 2), seed=555)
     f1, f2 = os.path.join(scale["dir"], "pe_1.fq"), os.path.join(scale["dir"], "pe_2.fq")
     write_fastq(b1, f1)
