@@ -42,6 +42,19 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # passes, gfx950-corrected as MI355X_MICROARCH.md prescribes): bench.py cannot run the profiler on itself,
 # so the figures live in profiles/traffic.json keyed by (kernel template instance, workload) and are used
 # only when the kernel this run launched is the one that was profiled -- otherwise `traffic` is null.
+def gather_ceiling(index_kind: str):
+    """Measured ceiling of the access pattern itself on this GPU: independent random 128-byte side-pair gathers over
+    the index image (scripts/gather_ceiling.py -> bt_bench_gather), best configuration, GB/s at 128 B per query."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2", "gather_big.json" if index_kind == "big" else "gather_ecoli.json")) as f:
+            j = json.load(f)
+        best = max(j["runs"], key=lambda r: r["GBps_128B_per_query"])
+        return {"GBps": best["GBps_128B_per_query"], "Gqueries_per_s": best["Gqueries_per_s"],
+                "source": "profiles/r2/%s" % ("gather_big.json" if index_kind == "big" else "gather_ecoli.json")}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def measured_traffic(kernel: str, workload: str):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -244,9 +257,11 @@ def main():
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
-    ap.add_argument("--no-carry", action="store_true",
-                    help="run every batch to its last read before the next starts (bt_ctx_set_carry off); by default the "
-                         "searches still running when a batch's reads are all handed out are resumed by the next step")
+    ap.add_argument("--carry", type=int, default=-1,
+                    help="bt_ctx_set_carry: launches a read may ride along with the steps after its own (0 = every step runs "
+                         "to its last read before the next starts).  Default: 0 for steps of 50 M reads or more -- there the "
+                         "tail is a small part of the step and costs nothing extra, see profiles/README.md -- else 12.")
+    ap.add_argument("--no-carry", action="store_true", help="same as --carry 0")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip re-checking every reported hit of the last step against the genome (bowtie_amd/verify.py; unpaired workloads)")
@@ -322,12 +337,17 @@ def main():
     # all been handed out are parked and resumed by the context's next step, so a step's results are complete when
     # the next step (or the closing bt_ctx_sync, inside the timed region) is.  Each context therefore alternates
     # between two sets of output arrays.
-    carry = (not args.no_carry) and not paired and not wl["pol"].get("best") and L <= 112
+    carry_age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (0 if n >= 50_000_000 else 12))
+    if paired or wl["pol"].get("best") or L > 112:
+        carry_age = 0
+    carry_age = min(carry_age, 12)
+    carry = carry_age > 0
     pipes = []
     for pi in range(max(1, args.pipes)):
         st = torch.cuda.current_stream() if pi == 0 else torch.cuda.Stream()
         o = dict(stream=st, busy=False, sets=[])
-        for si in range(2 if carry else 1):
+        # a step's outputs stay in use until the last of its reads is done: carry_age launches later at most
+        for si in range(min(carry_age + 1, max(args.steps, args.warmup, 1)) if carry else 1):
             d = dict(hits=torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev),
                      n_hits=torch.zeros(n, dtype=torch.int32, device=dev),
                      status=torch.zeros(n, dtype=torch.uint8, device=dev),
@@ -336,7 +356,7 @@ def main():
                                    d["mm_pool"].data_ptr(), mm_cap, 0)
             o["sets"].append(d)
         o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
-        if carry and lib.bt_ctx_set_carry(o["al"]._h, 1) != 0:
+        if carry and lib.bt_ctx_set_carry(o["al"]._h, carry_age) != 0:
             raise RuntimeError("bt_ctx_set_carry failed")
         lib.bt_ctx_set_max_read_len(o["al"]._h, L)         # synthetic reads: all of length L (rows are padded to 16)
         pipes.append(o)
@@ -483,13 +503,20 @@ def main():
                          "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this kernel on this workload in profiles/traffic.json"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
-                         "carry_over": carry, "flush_ms_total": sum(flush_ms),
+                         "carry_over_launches": carry_age, "flush_ms_total": sum(flush_ms),
                          "algorithmic_bytes_per_launch": abytes,
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n,
                          "mean_active_lanes_per_round": per_launch["lane_iters"] / max(1.0, per_launch["wave_rounds"]),
                          "wave_rounds_per_launch": per_launch["wave_rounds"]},
         }
+        gc = gather_ceiling(wl["index"]) if not args.genome else None
+        if gc:
+            # the kernel's rank traffic (the 128-byte gathers) against what the memory system delivers for that
+            # pattern alone; `frac` above stays against the 8 TB/s streaming peak
+            out["roofline"]["gather_ceiling_GBps"] = gc["GBps"]
+            out["roofline"]["frac_of_gather_ceiling"] = achieved / gc["GBps"]
+            out["roofline"]["gather_ceiling_source"] = gc["source"]
         if not args.no_cpu:
             cb = cpu_baseline(base, wl, text_np, idx)
             out["cpu_baseline"] = cb

@@ -56,12 +56,16 @@ struct bt_ctx {
 	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [7] longest read, [8..10] second pass */
 	uint32_t nSlots = 0;
 	/* carry-over (bt_kernels.h): the reads the last launch parked and what describes their batch */
-	bool carry = false, carryPending = false, carryRetry = false;
-	int carryParity = 0, carryRl = 0;
-	BtPoolRec* carryPool[2] = {nullptr, nullptr}; uint32_t carryCap = 0;
-	uint32_t* d_carry = nullptr;
-	BatchView prev; uint32_t prevMaxLen = 0;
-	BtCold* d_cold_prev = nullptr;
+	bool carry = false, carryPending = false;
+	uint32_t carryAge = 1;                 /* launches a read may be carried through (bt_ctx_set_carry) */
+	int carryRl = 0; uint32_t carryBlocks = 0;   /* build and grid of the launches whose lanes the records belong to */
+	BtPoolRec* pool = nullptr;             /* [nLanes]: lane g's parked read */
+	uint32_t launchSeq = 1;                /* number of the next carry launch; its batch sits in ring[launchSeq % 16] */
+	uint32_t* d_carry = nullptr;           /* [0..15] reads parked by the last launch per ring slot, [16..31] the ring batches' mismatch-pool cursors */
+	BatchView ring[BT_BATCH_RING]; bool ringRetry[BT_BATCH_RING] = {}; uint32_t ringMaxLen[BT_BATCH_RING] = {};
+	uint32_t* hostParked = nullptr;        /* pinned [16 launches][16 ring slots]: parkedOf after each launch */
+	hipEvent_t evLaunch[BT_BATCH_RING] = {};
+	BtCold* d_cold_prev = nullptr;         /* the descriptor of a second pass over a ring batch */
 	uint32_t* lastMmCursor = nullptr;
 	hipEvent_t evSpan = nullptr; bool spanOpen = false; uint32_t spanLaunches = 0;
 	hipEvent_t evRing[16][2] = {}; hipEvent_t evFlush[2] = {nullptr, nullptr}; bool flushTimed = false;
@@ -183,22 +187,24 @@ static void ctx_free_scratch(bt_ctx* c)
 	c->frames = c->pairs = nullptr; c->meta = nullptr; c->pals = nullptr;
 }
 
-/* (re)size the per-slot arenas for reads up to maxLen.  One slot per resident lane; with carry-over two sets of
- * them (a parked read keeps its slot through the next launch) and the two pools of parked-read records. */
+/* (re)size the per-slot arenas for reads up to maxLen: one slot per resident lane.  With carry-over also the pool
+ * of parked-lane records and the counters around it. */
 static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 {
-	const uint32_t wantSlots = c->nLanes * (carry ? 2u : 1u);
-	if (c->frames && maxLen <= c->maxLen && wantSlots <= c->nSlots) return BT_OK;
-	ctx_free_scratch(c);
-	c->maxLen = maxLen < 64 ? 64 : (maxLen > c->maxLen ? maxLen : c->maxLen);
-	c->nSlots = wantSlots > c->nSlots ? wantSlots : c->nSlots;
-	if (carry && !c->carryPool[0]) {
-		c->carryCap = c->nLanes;
-		for (int k = 0; k < 2; k++) HIPCHK(hipMalloc((void**)&c->carryPool[k], (size_t)c->carryCap * sizeof(BtPoolRec)));
-		HIPCHK(hipMalloc((void**)&c->d_carry, 32));
-		HIPCHK(hipMemset(c->d_carry, 0, 32));
+	if (carry && !c->pool) {
+		HIPCHK(hipMalloc((void**)&c->pool, (size_t)c->nLanes * sizeof(BtPoolRec)));
+		HIPCHK(hipMemset(c->pool, 0, (size_t)c->nLanes * sizeof(BtPoolRec)));
+		HIPCHK(hipMalloc((void**)&c->d_carry, 32 * 4));
+		HIPCHK(hipMemset(c->d_carry, 0, 32 * 4));
+		HIPCHK(hipHostMalloc((void**)&c->hostParked, BT_BATCH_RING * BT_BATCH_RING * 4));
+		memset(c->hostParked, 0, BT_BATCH_RING * BT_BATCH_RING * 4);
+		for (int i = 0; i < BT_BATCH_RING; i++) HIPCHK(hipEventCreateWithFlags(&c->evLaunch[i], hipEventDisableTiming));
 		HIPCHK(hipMalloc((void**)&c->d_cold_prev, sizeof(BtCold)));
 	}
+	if (c->frames && maxLen <= c->maxLen) return BT_OK;
+	ctx_free_scratch(c);
+	c->maxLen = maxLen < 64 ? 64 : (maxLen > c->maxLen ? maxLen : c->maxLen);
+	c->nSlots = c->nLanes;
 	const bool seeded = c->pol.mode == BT_MODE_N;
 	/* range-stack entries per slot: every frame may span the whole read.  -v k has k+1 frames;
 	 * -n: frames are bounded by -e / min penalty (10) unless the read has Phred<5 bases. */
@@ -266,7 +272,9 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	c->nLanes = c->cus * (c->rl3 && c->blocksPerCU < 3u ? 3u : c->blocksPerCU) * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 64));
 	/* carry-over between the launches of this context (bt_kernels.h): asked for with bt_ctx_set_carry or BT_CARRY=1 */
-	c->carry = env_u32("BT_CARRY", 0) != 0;
+	c->carryAge = env_u32("BT_CARRY", 0);
+	if (c->carryAge > BT_BATCH_RING - 2) c->carryAge = BT_BATCH_RING - 2;
+	c->carry = c->carryAge != 0;
 	HIPCHK(hipEventCreate(&c->evSpan));
 	for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate(&c->evRing[i][k]));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate(&c->evFlush[k]));
@@ -295,8 +303,10 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_cold) (void)hipFree(c->d_cold);
 	if (c->d_warm) (void)hipFree(c->d_warm);
-	for (int k = 0; k < 2; k++) if (c->carryPool[k]) (void)hipFree(c->carryPool[k]);
+	if (c->pool) (void)hipFree(c->pool);
 	if (c->d_carry) (void)hipFree(c->d_carry);
+	if (c->hostParked) (void)hipHostFree(c->hostParked);
+	for (int i = 0; i < BT_BATCH_RING; i++) if (c->evLaunch[i]) (void)hipEventDestroy(c->evLaunch[i]);
 	if (c->d_cold_prev) (void)hipFree(c->d_cold_prev);
 	if (c->evSpan) (void)hipEventDestroy(c->evSpan);
 	ctx_free_stream(c);
@@ -412,12 +422,12 @@ static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
 }
 
 /* Second pass, on the stream, over the reads of `v` whose search outgrew the per-read scratch: collected from the
- * status array and searched again through the twin context's worst-case arenas.  `d_cold` describes `v` as B. */
+ * status array and searched again through the twin context's worst-case arenas.  `d_cold` must describe `v` as its
+ * current batch (B, curBid and ring[curBid]). */
 static int enqueue_retry(bt_ctx* c, const BtKernelArgs& A0, const BatchView& v, const BtCold* d_cold, uint32_t maxLen)
 {
 	const bt_ctx* b = c->big;
 	HIPCHK(hipMemsetAsync(c->d_cursor + 8, 0, 12, c->stream));
-	{ const uint32_t lanes = b->nLanes; HIPCHK(hipMemcpyAsync(c->d_cursor + 10, &lanes, 4, hipMemcpyHostToDevice, c->stream)); }
 	if (bt_launch_collect_flagged(v.B.status, v.n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 8, c->retryCap, c->stream) != 0)
 		return BT_ERR_DEVICE;
 	BtKernelArgs R = A0;                              /* same index */
@@ -425,64 +435,75 @@ static int enqueue_retry(bt_ctx* c, const BtKernelArgs& A0, const BatchView& v, 
 	R.cold = d_cold;
 	R.gate = nullptr;
 	R.frames = b->frames; R.pairs = b->pairs; R.meta = b->meta; R.pals = b->pals;
-	R.nLanes = b->nLanes; R.nSlots = b->nSlots; R.frCap = b->frCap; R.entCap = b->entCap; R.palCap = b->palCap; R.slotBase = 0;
+	R.nLanes = b->nLanes; R.nSlots = b->nSlots; R.frCap = b->frCap; R.entCap = b->entCap; R.palCap = b->palCap;
 	R.nextRead = c->d_cursor + 9;
 	R.order = c->retryList; R.orderCount = c->d_cursor + 8; R.orderCap = c->retryCap;
-	R.carryIn = nullptr; R.carryInCount = nullptr; R.carryCursor = nullptr;
-	R.carryOut = nullptr; R.carryOutCount = nullptr; R.carryOutCap = 0;
+	R.pool = nullptr; R.adopt = 0; R.park = 0; R.parkedOf = nullptr;
 	if (bt_launch_search(&R, b->nLanes / BT_BLOCK, c->occ, maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0) ? 1 : 0, c->stream) != 0)
 		return BT_ERR_DEVICE;
 	return BT_OK;
 }
 
-/* Finish the reads the last launch parked (carry-over): a launch with no fresh reads that adopts them and runs
- * them to the end, then the second pass over that batch.  After it the context holds nothing in flight. */
+static void fill_cold(const bt_ctx* c, BtCold* cold, const BtBatchDev& cur, uint32_t curBid)
+{
+	memset(cold, 0, sizeof(*cold));
+	cold->P = c->prog;
+	cold->ix[0] = c->idx->dev[0]; cold->ix[1] = c->idx->dev[1];
+	cold->B = cur; cold->curBid = curBid;
+	for (int i = 0; i < BT_BATCH_RING; i++) cold->ring[i] = c->ring[i].B;
+	cold->ring[curBid] = cur;
+}
+
+/* Finish the reads the last launch parked (carry-over): a launch of the same grid with no fresh reads, in which
+ * every lane picks its parked read up and runs it to the end; then the second pass over the batches that are due
+ * one.  After it the context holds nothing in flight. */
 static int ctx_flush_carry(bt_ctx* c)
 {
 	if (!c->carryPending) return BT_OK;
 	HIPCHK(hipSetDevice(c->idx->device));
-	const int p = c->carryParity;                     /* the parity the next launch would have had */
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
 	BtWarm warm;
 	fill_index_args(c, &A, &warm);
+	const uint32_t bid = c->launchSeq & (BT_BATCH_RING - 1u);
 	BtCold cold;
-	memset(&cold, 0, sizeof(cold));
-	cold.P = c->prog; cold.ix[0] = c->idx->dev[0]; cold.ix[1] = c->idx->dev[1];
-	cold.B = c->prev.B; cold.Bprev = c->prev.B;
+	BtBatchDev none;
+	memset(&none, 0, sizeof(none));
+	fill_cold(c, &cold, none, bid);
 	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemsetAsync(c->d_carry + 2, 0, 4, c->stream));
-	A.H.seq = c->prev.seq; A.H.qual = c->prev.qual; A.H.stride = c->prev.stride; A.H.n_reads = 0;
+	HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));
+	A.H.seq = nullptr; A.H.qual = nullptr; A.H.stride = 0; A.H.n_reads = 0;
 	A.cold = c->d_cold; A.warm = c->d_warm;
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
-	A.slotBase = (uint32_t)p * c->nLanes;
 	A.counts = c->d_counts;
 	A.nextRead = c->d_cursor;
-	A.carryIn = c->carryPool[1 - p]; A.carryInCount = c->d_carry + (1 - p); A.carryCursor = c->d_carry + 2;
-	A.prevSeq = c->prev.seq; A.prevQual = c->prev.qual; A.prevStride = c->prev.stride;
-	const uint32_t lanes = c->cus * (c->carryRl == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
+	A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = 1; A.park = 0; A.maxAge = 0; A.parkedOf = c->d_carry;
 	HIPCHK(hipEventRecord(c->evFlush[0], c->stream));
-	if (bt_launch_search(&A, lanes / BT_BLOCK, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	c->launchSeq++;
 	c->carryPending = false;
-	if (c->carryRetry) {
-		const int rc = enqueue_retry(c, A, c->prev, c->d_cold, c->prevMaxLen);
+	for (int i = 0; i < BT_BATCH_RING; i++) if (c->ringRetry[i]) {
+		BtCold pc;
+		fill_cold(c, &pc, c->ring[i].B, (uint32_t)i);
+		HIPCHK(hipMemcpyAsync(c->d_cold_prev, &pc, sizeof(pc), hipMemcpyHostToDevice, c->stream));
+		const int rc = enqueue_retry(c, A, c->ring[i], c->d_cold_prev, c->ringMaxLen[i]);
 		if (rc != BT_OK) return rc;
+		c->ringRetry[i] = false;
 	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipEventRecord(c->evFlush[1], c->stream));
 	c->flushTimed = true;
-	c->lastMmCursor = c->d_carry + 4 + (1 - p);
 	return BT_OK;
 }
 
 /* lens_on_device: maxLen is only the row stride (the lengths are in HBM); async: the caller does not wait for this
  * batch before handing over the next -- carry-over and the on-stream second pass apply */
 static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uint32_t maxLen,
-                      unsigned long long* counts_dev, bool lens_on_device, bool async)
+                      unsigned long long* counts_dev, bool lens_on_device, bool async, bool retry_on_stream = true)
 {
 	if (in->n_reads == 0) { c->timed = false; return BT_OK; }
 	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
@@ -501,21 +522,27 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		if (lens_on_device && maxLen > BT_RL3_MAXLEN) both = true;
 		if (maxLen <= BT_RL3_MAXLEN || both) rl = 2;          /* three blocks per CU: the LDS diet */
 	}
-	/* carry-over (bt_kernels.h): device-pointer batches on a context that asked for it, reads in LDS, one build */
+	/* carry-over (bt_kernels.h): batches the caller does not wait for, on a context that asked for it, reads in LDS,
+	 * one build; every such launch has the same grid, because a parked read belongs to its lane */
 	const bool carry = c->carry && async && !c->is_big && rl != 0 && !both && counts_dev == nullptr;
-	if (c->carryPending && (!carry || rl != c->carryRl || maxLen > c->maxLen)) {
+	uint32_t gridBlocks = c->cus * (rl == 2 ? 3u : c->blocksPerCU);
+	{
+		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);   /* tests: a small grid makes small batches drain */
+		if (lim && lim < gridBlocks) gridBlocks = lim;
+	}
+	if (c->carryPending && (!carry || rl != c->carryRl || gridBlocks != c->carryBlocks || maxLen > c->maxLen)) {
 		if ((rc = ctx_flush_carry(c)) != BT_OK) return rc;
 	}
 	if ((rc = ctx_ensure_scratch(c, maxLen, carry)) != BT_OK) return rc;
 	/* the device-pointer entry point hands back finished results: reads that outgrow their scratch are searched
 	 * again on the stream (below), through the twin context's worst-case arenas; BT_DEVICE_RETRY=0 leaves them flagged */
-	const bool devRetry = async && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
+	const bool devRetry = async && retry_on_stream && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
 	if (devRetry) {
 		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_scratch(c->big, maxLen, false)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_retry_list(c, in->n_reads)) != BT_OK) return rc;
 	}
-	const int p = carry ? c->carryParity : 0;
+	const uint32_t bid = carry ? (c->launchSeq & (BT_BATCH_RING - 1u)) : 0u;
 	BatchView cur;
 	memset(&cur, 0, sizeof(cur));
 	cur.B.seq = in->seq; cur.B.qual = in->qual; cur.B.len = in->len; cur.B.seed = in->seed;
@@ -523,16 +550,13 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	cur.B.hits = (BtHitRec*)out->hits; cur.B.hit_cap = out->hit_cap;
 	cur.B.n_hits = out->n_hits; cur.B.status = out->status;
 	cur.B.mm_pool = out->mm_pool; cur.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
-	cur.B.mm_pool_used = carry ? c->d_carry + 4 + p : c->d_cursor + 1;
+	cur.B.mm_pool_used = carry ? c->d_carry + BT_BATCH_RING + bid : c->d_cursor + 1;
 	cur.B.iters = c->iters_dev;
 	cur.seq = in->seq; cur.qual = in->qual; cur.stride = in->stride; cur.n_reads = in->n_reads;
 	const bool adopt = carry && c->carryPending;
+	if (carry) { c->ring[bid] = cur; c->ringRetry[bid] = devRetry; c->ringMaxLen[bid] = maxLen; }
 	BtCold cold;
-	memset(&cold, 0, sizeof(cold));
-	cold.P = c->prog;
-	cold.ix[0] = c->idx->dev[0]; cold.ix[1] = c->idx->dev[1];
-	cold.B = cur.B;
-	cold.Bprev = adopt ? c->prev.B : cur.B;
+	fill_cold(c, &cold, cur.B, bid);
 	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
 	BtWarm warm;
 	fill_index_args(c, &A, &warm);
@@ -541,24 +565,16 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.cold = c->d_cold; A.warm = c->d_warm;
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
-	A.slotBase = (uint32_t)p * c->nLanes;
 	A.nextRead = c->d_cursor;
 	A.counts = counts_dev ? counts_dev : c->d_counts;
-	/* [0] read cursor, [1] mismatch-pool cursor, [7] longest read, [8] reads to search again, [9] their cursor,
-	 * [10] (unused by the kernel) the twin's lane count */
+	/* [0] read cursor, [1] mismatch-pool cursor, [7] longest read, [8] reads to search again, [9] their cursor */
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
 	if (carry) {
-		/* d_carry: [0],[1] reads parked by the launches of either parity, [2] adoption cursor, [4],[5] the two
-		 * batches' mismatch-pool cursors */
-		HIPCHK(hipMemsetAsync(c->d_carry + p, 0, 4, c->stream));
-		HIPCHK(hipMemsetAsync(c->d_carry + 2, 0, 4, c->stream));
-		HIPCHK(hipMemsetAsync(c->d_carry + 4 + p, 0, 4, c->stream));
-		A.carryOut = c->carryPool[p]; A.carryOutCount = c->d_carry + p; A.carryOutCap = c->carryCap;
-		if (adopt) {
-			A.carryIn = c->carryPool[1 - p]; A.carryInCount = c->d_carry + (1 - p); A.carryCursor = c->d_carry + 2;
-			A.prevSeq = c->prev.seq; A.prevQual = c->prev.qual; A.prevStride = c->prev.stride;
-		}
+		HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));                 /* this launch's parked counts */
+		HIPCHK(hipMemsetAsync(c->d_carry + BT_BATCH_RING + bid, 0, 4, c->stream));           /* this batch's mismatch-pool cursor */
+		A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = adopt ? 1u : 0u; A.park = 1u;
+		A.maxAge = c->carryAge; A.parkedOf = c->d_carry;
 	}
 	if (both && bt_launch_maxlen(in->len, in->n_reads, c->d_cursor + 7, c->stream) != 0) return BT_ERR_DEVICE;
 	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
@@ -568,16 +584,14 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	A.order = nullptr;
 	auto launch_main = [&](int rlv) -> int {
-		const uint32_t launchLanes = c->cus * (rlv == 2 ? 3u : c->blocksPerCU) * BT_BLOCK;
-		uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
-		if (adopt) nBlocks = launchLanes / BT_BLOCK;        /* there is a parked read for (nearly) every lane */
-		uint32_t maxBlocks = launchLanes / BT_BLOCK;
-		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);   /* tests: a small grid makes small batches drain */
+		uint32_t maxBlocks = c->cus * (rlv == 2 ? 3u : c->blocksPerCU);
+		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);
 		if (lim && lim < maxBlocks) maxBlocks = lim;
-		if (nBlocks > maxBlocks) nBlocks = maxBlocks;
+		uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
+		if (carry || nBlocks > maxBlocks) nBlocks = maxBlocks;     /* carry-over: always the whole grid */
 		{
 			/* the template instance bt_launch_search picks (bt_kernels.hip) */
-			const bool ext = A.carryIn || A.carryOut || A.order;
+			const bool ext = A.pool || A.order;
 			const int o = rlv == 2 ? 3 : (rlv ? (c->occ == 1 ? 1 : 2) : (c->occ < 1 ? 1 : (c->occ > 4 ? 4 : c->occ)));
 			snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<%d,%s,%s,%s>", o, ext ? "true" : "false",
 			         rlv ? "true" : "false", rlv == 2 ? "true" : "false");
@@ -597,22 +611,20 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		A.gate = nullptr;
 		if ((rc = launch_main(rl)) != BT_OK) return rc;
 	}
-	if (devRetry) {
-		/* over a batch whose reads have all finished: this one, or with carry-over the one before it */
-		if (!carry) rc = enqueue_retry(c, A, cur, c->d_cold, maxLen);
-		else if (adopt) {
-			BtCold pc = cold;
-			pc.B = c->prev.B; pc.Bprev = c->prev.B;
-			HIPCHK(hipMemcpyAsync(c->d_cold_prev, &pc, sizeof(pc), hipMemcpyHostToDevice, c->stream));
-			rc = enqueue_retry(c, A, c->prev, c->d_cold_prev, c->prevMaxLen);
-		}
-		if (rc != BT_OK) return rc;
-	}
 	if (carry) {
-		c->prev = cur; c->prevMaxLen = maxLen; c->carryPending = true; c->carryRl = rl; c->carryRetry = devRetry;
-		c->carryParity = 1 - p;
-		c->lastMmCursor = c->d_carry + 4 + p;
-	} else c->lastMmCursor = c->d_cursor + 1;
+		/* which ring batches still have reads parked after this launch: to the host, for whoever wants to know when a
+		 * batch is complete (bt_align_stream_collect) */
+		const uint32_t k = c->launchSeq & (BT_BATCH_RING - 1u);
+		HIPCHK(hipMemcpyAsync(c->hostParked + (size_t)k * BT_BATCH_RING, c->d_carry, BT_BATCH_RING * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipEventRecord(c->evLaunch[k], c->stream));
+		c->carryPending = true; c->carryRl = rl; c->carryBlocks = gridBlocks;
+		c->launchSeq++;
+		c->lastMmCursor = c->d_carry + BT_BATCH_RING + bid;
+		/* the second pass waits for the batch to be complete: ctx_flush_carry */
+	} else {
+		if (devRetry && (rc = enqueue_retry(c, A, cur, c->d_cold, maxLen)) != BT_OK) return rc;
+		c->lastMmCursor = c->d_cursor + 1;
+	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipEventRecord(ring[1], c->stream));
 	c->timed = true;
@@ -816,11 +828,12 @@ extern "C" int bt_ctx_set_max_read_len(bt_ctx* c, uint32_t max_len)
 
 /* Carry-over between the launches of this context (see bt_kernels.h).  On: a bt_align_batch_device call returns
  * its batch's results complete only once the NEXT call's stream work is, or after bt_ctx_sync. */
-extern "C" int bt_ctx_set_carry(bt_ctx* c, int on)
+extern "C" int bt_ctx_set_carry(bt_ctx* c, int launches)
 {
-	if (!c) return BT_ERR_ARG;
-	if (!on && c->carryPending) { const int rc = ctx_flush_carry(c); if (rc != BT_OK) return rc; }
-	c->carry = on != 0;
+	if (!c || launches < 0) return BT_ERR_ARG;
+	if (c->carryPending) { const int rc = ctx_flush_carry(c); if (rc != BT_OK) return rc; }
+	c->carry = launches != 0;
+	c->carryAge = launches > BT_BATCH_RING - 2 ? BT_BATCH_RING - 2 : (uint32_t)launches;
 	return BT_OK;
 }
 
@@ -852,10 +865,12 @@ extern "C" int bt_ctx_sync(bt_ctx* c)
 	if (c->carryPending) { const int rc = ctx_flush_carry(c); if (rc != BT_OK) return rc; }
 	HIPCHK(hipStreamSynchronize(c->stream));
 	c->spanOpen = false;
-	if (c->d_carry) {
-		uint32_t k[2] = {0, 0};
-		HIPCHK(hipMemcpy(k, c->d_carry, 8, hipMemcpyDeviceToHost));
-		c->last_carried = k[0] + k[1];
+	if (c->hostParked) {
+		/* diagnostics: reads parked by the launches of the span just closed (all of them: the flush parks none) */
+		uint32_t tot = 0;
+		for (int i = 0; i < BT_BATCH_RING * BT_BATCH_RING; i++) tot += c->hostParked[i];
+		c->last_carried = tot;
+		memset(c->hostParked, 0, BT_BATCH_RING * BT_BATCH_RING * 4);
 	}
 	HIPCHK(hipMemcpy(&c->last_mm_used, c->lastMmCursor ? c->lastMmCursor : c->d_cursor + 1, 4, hipMemcpyDeviceToHost));
 	if (!c->is_big) HIPCHK(hipMemcpy(&c->last_dev_retried, c->d_cursor + (c->best ? 2 : 8), 4, hipMemcpyDeviceToHost));
@@ -1003,32 +1018,36 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 static void ctx_free_stream(bt_ctx* c);
 /* ---- a stream of host batches ---------------------------------------------------------------------
  * bt_align_batch waits for its batch; a driver that has the next batch ready (a FASTQ reader ahead of
- * the GPU) hands batches over one after the other instead and collects them in order.  Three staging
- * areas in HBM take turns: while batch k is searched, batch k-1's results travel back and batch k+1's
- * reads travel in.  With carry-over on, batch k's last reads finish inside launch k+1, so a batch is
- * collectable once its successor has been submitted (or on flush).                                  */
+ * the GPU) hands batches over one after the other instead and collects them, in order, as they become
+ * complete.  Every batch in flight has a staging area in HBM (recycled); uploads and the results' way
+ * back use a copy stream of their own.  With carry-over a batch is complete when none of its reads is
+ * parked any more -- the launches report that (BtKernelArgs::parkedOf), the host looks it up here.   */
 struct bt_stream_slot {
 	void* dev = nullptr; size_t bytes = 0;
 	const bt_read_batch* in = nullptr; bt_hit_batch* out = nullptr; void* tag = nullptr;
 	size_t o_hits = 0, o_nh = 0, o_st = 0, o_mm = 0;
 	uint32_t n = 0; uint32_t mm_used = 0; uint32_t* mmCursor = nullptr;
 	hipEvent_t done = nullptr, up = nullptr;
+	uint32_t seq = 0, bid = 0; bool carried = false;       /* the carry launch that took it (0: run to completion at once) */
 	int state = 0;                       /* 0 free, 1 launched (results not yet on their way back), 2 copy-back enqueued */
 };
 struct bt_stream {
-	bt_stream_slot slot[3]; uint64_t submitted = 0, collected = 0;
+	std::vector<bt_stream_slot*> slots;                  /* all staging areas */
+	std::vector<bt_stream_slot*> inflight;               /* submitted, not yet collected; oldest first */
 	hipStream_t copy = nullptr; hipEvent_t searched = nullptr;       /* PCIe traffic runs beside the search, not in its stream */
 };
 
-/* results of a batch whose searches are all enqueued: back to the host on the copy stream, once the search stream
- * has got that far */
-static int stream_copy_back(bt_ctx* c, bt_stream_slot& s)
+/* results of a batch whose searches have all finished (or are all enqueued, when after_stream): back to the host on
+ * the copy stream */
+static int stream_copy_back(bt_ctx* c, bt_stream_slot& s, bool after_stream)
 {
 	uint8_t* d = (uint8_t*)s.dev;
 	bt_hit_batch* out = s.out;
 	hipStream_t cs = c->hs->copy;
-	HIPCHK(hipEventRecord(c->hs->searched, c->stream));
-	HIPCHK(hipStreamWaitEvent(cs, c->hs->searched, 0));
+	if (after_stream) {
+		HIPCHK(hipEventRecord(c->hs->searched, c->stream));
+		HIPCHK(hipStreamWaitEvent(cs, c->hs->searched, 0));
+	}
 	HIPCHK(hipMemcpyAsync(&s.mm_used, s.mmCursor, 4, hipMemcpyDeviceToHost, cs));
 	HIPCHK(hipMemcpyAsync(out->n_hits, d + s.o_nh, 4ull * s.n, hipMemcpyDeviceToHost, cs));
 	HIPCHK(hipMemcpyAsync(out->status, d + s.o_st, s.n, hipMemcpyDeviceToHost, cs));
@@ -1042,7 +1061,7 @@ static int stream_copy_back(bt_ctx* c, bt_stream_slot& s)
 static void ctx_free_stream(bt_ctx* c)
 {
 	if (!c->hs) return;
-	for (auto& s : c->hs->slot) { if (s.dev) (void)hipFree(s.dev); if (s.done) (void)hipEventDestroy(s.done); if (s.up) (void)hipEventDestroy(s.up); }
+	for (auto* s : c->hs->slots) { if (s->dev) (void)hipFree(s->dev); if (s->done) (void)hipEventDestroy(s->done); if (s->up) (void)hipEventDestroy(s->up); delete s; }
 	if (c->hs->copy) (void)hipStreamDestroy(c->hs->copy);
 	if (c->hs->searched) (void)hipEventDestroy(c->hs->searched);
 	delete c->hs;
@@ -1062,14 +1081,17 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 		HIPCHK(hipEventCreateWithFlags(&c->hs->searched, hipEventDisableTiming));
 	}
 	bt_stream& S = *c->hs;
-	if (S.submitted - S.collected >= 2) return BT_ERR_ARG;          /* collect first: at most two batches are in flight */
+	/* a ring slot is reused after BT_BATCH_RING launches: nothing that old may still be in flight */
+	if (S.inflight.size() >= BT_BATCH_RING - 2u) return BT_ERR_ARG;  /* collect (or flush) first */
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < n; i++) {
 		if (in->len[i] > 1024 || in->len[i] > in->stride) return BT_ERR_ARG;
 		if (in->len[i] > maxLen) maxLen = in->len[i];
 	}
-	HIPCHK(hipSetDevice(c->idx->device));
-	bt_stream_slot& s = S.slot[S.submitted % 3];
+	bt_stream_slot* sp = nullptr;
+	for (auto* x : S.slots) if (x->state == 0) { sp = x; break; }
+	if (!sp) { sp = new bt_stream_slot(); S.slots.push_back(sp); }
+	bt_stream_slot& s = *sp;
 	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	const size_t o_seq = 0, o_qual = o_seq + al((size_t)n * in->stride), o_len = o_qual + al((size_t)n * in->stride),
 	             o_seed = o_len + al(2ull * n), o_hits = o_seed + al(4ull * n),
@@ -1096,43 +1118,56 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	bt_hit_batch dout = *out;
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
-	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true);
+	const uint32_t seq0 = c->launchSeq;
+	const bool wasPending = c->carryPending;
+	/* reads that outgrow their scratch stay flagged (BT_ST_OVERFLOW) for the caller: no second pass on the stream here */
+	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false);
 	if (rc != BT_OK) return rc;
 	s.in = in; s.out = out; s.tag = tag; s.n = n; s.o_hits = o_hits; s.o_nh = o_nh; s.o_st = o_st; s.o_mm = o_mm;
 	s.mmCursor = c->lastMmCursor; s.state = 1;
-	S.submitted++;
-	/* what the launch just enqueued finished (carry-over) or this very batch (none parked): on its way back */
-	if (c->carryPending) {
-		if (S.submitted - S.collected == 2) { bt_stream_slot& p = S.slot[(S.submitted - 2) % 3]; if (p.state == 1) return stream_copy_back(c, p); }
-		return BT_OK;
-	}
-	for (uint64_t k = S.collected; k < S.submitted; k++) { bt_stream_slot& p = S.slot[k % 3]; if (p.state == 1) { const int r2 = stream_copy_back(c, p); if (r2 != BT_OK) return r2; } }
+	const bool carriedNow = c->carryPending;                       /* run_device parked this batch's last reads */
+	const bool flushed = wasPending && (c->launchSeq - seq0) == (carriedNow ? 2u : 1u);   /* ... after finishing what was parked before */
+	if (flushed) for (auto* x : S.inflight) if (x->state == 1) { x->carried = false; const int r2 = stream_copy_back(c, *x, true); if (r2 != BT_OK) return r2; }
+	S.inflight.push_back(sp);
+	if (!carriedNow) { s.carried = false; return stream_copy_back(c, s, true); }
+	s.carried = true; s.seq = c->launchSeq - 1u; s.bid = s.seq & (BT_BATCH_RING - 1u);
 	return BT_OK;
 }
 
-/* The oldest submitted batch, finished: its bt_hit_batch is filled (mm_pool_used included), *tag is what came with
- * it.  flush != 0: nothing follows -- finish the parked reads now.  Without flush the call needs a successor to have
- * been submitted when carry-over is on (BT_ERR_ARG otherwise).  *tag = NULL with BT_OK: nothing in flight. */
+/* The oldest submitted batch, if it is complete: its bt_hit_batch is filled (mm_pool_used included) and *tag is what
+ * came with it.  *tag = NULL with BT_OK: nothing in flight, or (flush == 0) the oldest batch still has reads being
+ * searched -- submit more, or ask again later.  flush != 0: nothing follows, finish whatever is parked now. */
 extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 {
 	if (!c || !tag) return BT_ERR_ARG;
 	*tag = nullptr;
-	if (!c->hs || c->hs->submitted == c->hs->collected) return BT_OK;
+	if (!c->hs || c->hs->inflight.empty()) return BT_OK;
 	bt_stream& S = *c->hs;
 	HIPCHK(hipSetDevice(c->idx->device));
-	bt_stream_slot& s = S.slot[S.collected % 3];
+	bt_stream_slot& s = *S.inflight.front();
 	if (s.state == 1) {
-		if (!flush) return BT_ERR_ARG;
-		const int rc = ctx_flush_carry(c);
-		if (rc != BT_OK) return rc;
-		const int r2 = stream_copy_back(c, s);
-		if (r2 != BT_OK) return r2;
-	}
+		bool complete = false;
+		if (s.carried && !flush) {
+			/* the latest finished launch since the batch's own says how many of its reads are still parked */
+			for (uint32_t q = c->launchSeq - 1u; q >= s.seq; q--) {          /* seq >= 1 */
+				const uint32_t k = q & (BT_BATCH_RING - 1u);
+				if (hipEventQuery(c->evLaunch[k]) == hipSuccess) { complete = c->hostParked[(size_t)k * BT_BATCH_RING + s.bid] == 0; break; }
+			}
+			if (!complete) return BT_OK;
+			const int r2 = stream_copy_back(c, s, false);
+			if (r2 != BT_OK) return r2;
+		} else {
+			if (!flush) return BT_ERR_ARG;                          /* cannot happen: uncarried batches are copied back at submit */
+			const int rc = ctx_flush_carry(c);
+			if (rc != BT_OK) return rc;
+			for (auto* x : S.inflight) if (x->state == 1) { const int r2 = stream_copy_back(c, *x, true); if (r2 != BT_OK) return r2; }
+		}
+	} else if (!flush && hipEventQuery(s.done) != hipSuccess) return BT_OK;
 	HIPCHK(hipEventSynchronize(s.done));
 	s.out->mm_pool_used = s.mm_used < s.out->mm_pool_cap ? s.mm_used : s.out->mm_pool_cap;
 	*tag = s.tag;
 	s.state = 0;
-	S.collected++;
+	S.inflight.erase(S.inflight.begin());
 	return BT_OK;
 }
 

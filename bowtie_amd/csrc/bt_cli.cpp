@@ -536,7 +536,7 @@ void search_prepare(const Options& O, Job* j)
 	j->hb = bt_hit_batch{ j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
 }
 
-std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc);
+std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc, bool streamed_first_pass = false);
 
 std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 {
@@ -549,7 +549,7 @@ std::string search_job(bt_ctx* ctx, const Options& O, Job* j)
 /* the first pass is back (rc = what bt_align_batch said, or worked out from the status bytes after a streamed
  * search): errors the reference stops at, and the second pass for reads with more hits than slots.  ctx: a context
  * with nothing in flight. */
-std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc)
+std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc, bool streamed_first_pass)
 {
 	const uint32_t n = j->rb.n_reads;
 	const bool all = O.pol.all_hits != 0;
@@ -568,7 +568,13 @@ std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc)
 	std::vector<uint32_t> redo, need;
 	for (uint32_t i = 0; i < n; i++) {
 		const uint32_t tot = j->n_hits[i];
-		if (j->status[i] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
+		if (j->status[i] & BT_ST_OVERFLOW) {
+			/* a streamed search leaves reads that outgrew their scratch flagged: bt_align_batch below runs them again
+			 * with worst-case arenas.  After that pass the flag is fatal. */
+			if (!streamed_first_pass) return "Error: a read exceeded the search scratch space";
+			redo.push_back(i); need.push_back(j->hit_cap);
+			continue;
+		}
 		if (tot > O.pol.mhits && !O.pol.sample_max) continue;         /* nothing of it is printed */
 		const uint32_t want = tot > O.pol.mhits ? O.pol.mhits : (all ? tot : (tot < O.pol.khits ? tot : O.pol.khits));
 		if (want > j->hit_cap || (j->status[i] & BT_ST_MMPOOL)) { redo.push_back(i); need.push_back(want > j->hit_cap ? want : j->hit_cap); }
@@ -688,7 +694,7 @@ int main(int argc, char** argv)
 		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 		if (streamed) {
-			if (bt_ctx_set_carry(ctxs[g], 1) != BT_OK) die("Error: bt_ctx_set_carry failed");
+			if (bt_ctx_set_carry(ctxs[g], 12) != BT_OK) die("Error: bt_ctx_set_carry failed");
 			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 		}
@@ -890,44 +896,50 @@ int main(int argc, char** argv)
 				to_out.put(std::move(j));
 			}
 		}
-		/* Streamed: this thread keeps one context fed (bt_align_stream_*, carry-over on): a batch goes in, the
-		 * one before it comes out -- its last reads were finished by the launch of the one just submitted -- and is
-		 * post-processed on the thread's second context while the GPU works on. */
+		/* Streamed: this thread keeps one context fed (bt_align_stream_*, carry-over on): batches go in one after the
+		 * other; a batch comes out when the last of its reads is done -- the long-running ones ride along with the
+		 * batches behind it -- and is post-processed on the thread's second context while the GPU works on. */
 		bt_ctx* cs = ctxs[(size_t)g];
 		bt_ctx* cr = redo_ctxs[(size_t)g];
-		std::unique_ptr<Job> prev;
-		auto finish = [&](int flush) {
-			void* tag = nullptr;
-			const int rc = bt_align_stream_collect(cs, &tag, flush);
-			if (rc != BT_OK || tag != (void*)prev.get()) prev->error = std::string("Error: search failed: ") + bt_strerror(rc != BT_OK ? rc : BT_ERR_DEVICE);
-			else {
-				int st = BT_OK;
-				for (uint32_t i = 0; i < prev->rb.n_reads && st == BT_OK; i++) if (prev->status[i] & BT_ST_TOOSHORT) st = BT_ERR_READ_SHORT;
-				prev->error = search_finish(cr, O, prev.get(), st);
+		std::deque<std::unique_ptr<Job>> fl;                   /* in flight, oldest first */
+		auto drain = [&](int flush) {
+			while (!fl.empty()) {
+				void* tag = nullptr;
+				const int rc = bt_align_stream_collect(cs, &tag, flush);
+				if (rc == BT_OK && !tag) return;                /* the oldest is not complete yet */
+				std::unique_ptr<Job> p = std::move(fl.front());
+				fl.pop_front();
+				if (rc != BT_OK || tag != (void*)p.get()) p->error = std::string("Error: search failed: ") + bt_strerror(rc != BT_OK ? rc : BT_ERR_DEVICE);
+				else {
+					int st = BT_OK;
+					for (uint32_t i = 0; i < p->rb.n_reads && st == BT_OK; i++) if (p->status[i] & BT_ST_TOOSHORT) st = BT_ERR_READ_SHORT;
+					p->error = search_finish(cr, O, p.get(), st, true);
+				}
+				to_out.put(std::move(p));
 			}
-			to_out.put(std::move(prev));
 		};
 		for (;;) {
 			std::unique_ptr<Job> j = to_gpu.take();
 			const double tb = now_s();
 			if (j->last || abort_run.load()) {
-				if (prev) finish(1);
+				drain(1);
 				busy_gpu[(size_t)g] += now_s() - tb;
 				const bool end = j->last;
 				to_out.put(std::move(j));
 				if (end) return;
 				continue;
 			}
+			if (fl.size() >= 10) drain(1);                     /* reads older than ten batches: finish them now */
 			search_prepare(O, j.get());
 			const int rc = bt_align_stream_submit(cs, &j->rb, &j->hb, j.get());
 			if (rc != BT_OK) {
-				if (prev) finish(1);
+				drain(1);
 				j->error = std::string("Error: search failed: ") + bt_strerror(rc);
 				to_out.put(std::move(j));
 				continue;
 			}
-			if (prev) finish(0);
-			prev = std::move(j);
+			fl.push_back(std::move(j));
+			drain(0);
 			busy_gpu[(size_t)g] += now_s() - tb;
 		}
 	});

@@ -152,11 +152,14 @@ struct BtWarm {
 	const uint32_t* offs[2];
 	uint32_t zOff[2], offMask[2], offRate[2], ftabChars[2], len[2];
 };
+#define BT_BATCH_RING 16
 struct BtCold {
 	BtProgram  P;
 	BtIndexDev ix[2];            /* [0] index of the text, [1] mirror index */
-	BtBatchDev B;                /* the batch being searched ...                                          */
-	BtBatchDev Bprev;            /* ... and the one before it: where the results of carried-over reads go  */
+	BtBatchDev B;                /* the batch being searched (= ring[curBid])                             */
+	uint32_t   curBid, pad;
+	BtBatchDev ring[BT_BATCH_RING];   /* the batches reads still in flight belong to (carry-over): a read's results go
+	                                     to ring[L.bid]                                                            */
 };
 
 #define BT_STF_SKIPPED   1u
@@ -237,7 +240,7 @@ struct BtLane {
 	/* searcher (GreedyDFSRangeSource members) */
 	uint32_t qlen : 11, mirror : 1, readFw : 1, rev : 1, reportExacts : 1, considerQuals : 1, halfAndHalf : 1,
 	         maq : 1, reportPartials : 2, bailed : 1, nsFtab0 : 1;
-	uint32_t d5 : 11, d3 : 11, carried : 1;      /* carried: the read belongs to the previous batch (C.B[1]) */
+	uint32_t d5 : 11, d3 : 11, bid : 4;          /* bid: the read's batch is C.ring[bid] */
 	uint32_t unrev : 11, r1 : 11;
 	uint32_t r2 : 11, r3 : 11;
 	uint32_t qualThresh;
@@ -452,7 +455,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	L.step = 31; L.npals = 0; L.palIdx = 0; L.nmuts = 0; L.palIdxBefore = 0;
 	L.mirror = 0; L.readFw = 1; L.rev = 0;
 	L.cchunk = 0xffu;
-	L.iters = 0; L.tosValid = 0; L.ccValid = 0; L.carried = 0;
+	L.iters = 0; L.tosValid = 0; L.ccValid = 0; L.bid = C.curBid;
 	L.state = ST_PHASE_NEXT;
 	if (RL && L.plen > S.rlQual * 8u) {
 		/* longer than this build keeps in LDS (the caller's bt_ctx_set_max_read_len promise did not hold): not
@@ -585,7 +588,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
                         const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
 	const BtIndexDev* IX = C.ix;
-	const BtBatchDev& B = L.carried ? C.Bprev : C.B;
+	const BtBatchDev& B = C.ring[L.bid];
 	/* The states are visited in an order that lets the usual chains finish in one sweep (child
 	 * failed: FRAME_RETURN -> CHILD_RET -> BT_LOOP; phase change: FRAME_RETURN -> SEARCH_END ->
 	 * PHASE_NEXT -> SEARCH_BEGIN).  Within a block `break` leaves the block; a block that sets `req`

@@ -10,11 +10,12 @@
 /* Carry-over.  When the read cursor of a launch runs dry, every lane is in the middle of a read, and the reads
  * that backtrack for 10^5 rounds would keep their wavefronts -- and through them the workgroups' LDS -- for
  * seconds after the rest have finished (the "tail": at 16 M reads per launch more than half the launch).
- * Instead the lanes park what they are doing: the lane's whole state (automaton, pending request, scratch slot)
- * goes into a pool record, the wavefront exits, and the next launch on the same context picks the parked reads
- * up first, mixed in with its own fresh reads.  A read carried into a launch is finished by that launch (it is
- * not parked a second time), so the results of batch k are complete when launch k+1 is, or after the flush
- * launch bt_ctx_sync enqueues. */
+ * Instead the lanes park what they are doing: lane g writes its whole state (automaton + pending request) to
+ * pool[g], the wavefront exits, and lane g of the context's next launch -- same grid, same scratch slot g --
+ * picks it up again before taking fresh reads.  A read stays with its lane until it is done, through as many
+ * launches as it takes up to `maxAge`; a read that old is no longer parked but finished by the launch it is in.
+ * So the results of batch k are complete when launch k + maxAge is, or after the flush launch bt_ctx_sync
+ * enqueues; which batches still have reads parked after a launch is in parkedOf[]. */
 #define BT_POOL_WORDS 64
 struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot, [52..53] request kind/n, [56..59] request a/x */
 
@@ -22,20 +23,20 @@ struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */
 	const BtCold* cold;          /* device memory: program, full index descriptors, batch        */
 	const BtWarm* warm;          /* device memory; each workgroup copies it to LDS               */
-	/* per-slot scratch arenas (see BtScratch).  Lane g of a launch works in slot slotBase + g; a read carried over
-	 * from the previous launch keeps the slot it was parked with (the launches of a context alternate between
-	 * two sets of slots)                                                                           */
+	/* per-slot scratch arenas (see BtScratch): lane g works in slot g                              */
 	uint32_t*  frames;           /* [nSlots][frCap][12]                                          */
 	uint32_t*  pairs;            /* [nSlots][entCap][8]                                          */
 	uint16_t*  meta;             /* [nSlots][entCap] mask | Phred<<8                             */
 	uint64_t*  pals;             /* [nSlots][palCap]                                             */
-	uint32_t   nLanes, nSlots, frCap, entCap, palCap, slotBase;
+	uint32_t   nLanes, nSlots, frCap, entCap, palCap;
 	uint32_t*  nextRead;         /* work cursor: read ids                                        */
 	const uint32_t* order;       /* optional: read id for each cursor value                      */
-	/* carry-over (see above): reads parked by the previous launch, and where this one parks its own */
-	const BtPoolRec* carryIn; const uint32_t* carryInCount; uint32_t* carryCursor;
-	BtPoolRec* carryOut;      uint32_t* carryOutCount;      uint32_t carryOutCap;
-	const uint8_t* prevSeq; const uint8_t* prevQual; uint32_t prevStride;   /* the previous batch's reads (cold->B[1] has the rest) */
+	/* carry-over (see above) */
+	BtPoolRec* pool;             /* [nLanes]; NULL = none                                        */
+	uint32_t   launchSeq;        /* this launch's number on its context; a record is live if stamped launchSeq - 1 */
+	uint32_t   adopt, park;      /* pick parked reads up at the start / park at the end          */
+	uint32_t   maxAge;           /* launches a read may be carried through (< BT_BATCH_RING - 1) */
+	uint32_t*  parkedOf;         /* [BT_BATCH_RING] reads parked by this launch, per batch-ring slot */
 	const uint32_t* orderCount;  /* non-null (with order): the pick-up list's length lives on the device -- min(*orderCount,
 	                                orderCap) entries.  The on-stream second pass over reads that outgrew their scratch */
 	uint32_t   orderCap;

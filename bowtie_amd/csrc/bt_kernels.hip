@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		ARENA.frCap = A.frCap; ARENA.entCap = A.entCap; ARENA.palCap = A.palCap; ARENA.pad = 0;
 	}
 	__syncthreads();
-	S.a = &ARENA; S.slot = (EXT ? A.slotBase : 0u) + g;
+	S.a = &ARENA; S.slot = g;
 	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
@@ -92,40 +92,37 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	L.state = ST_IDLE;
 	BtReq req;
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
-	bool drained = false;
-	bool poolDry = !(EXT && A.carryIn);                     /* nothing (left) to adopt from the previous launch */
+	bool drained = false, parkNow = false;
 	const BtCold* cold = A.cold;
 	uint32_t nReads = A.H.n_reads;
 	if (EXT && A.orderCount) { const uint32_t v = *BT_GP(const uint32_t, A.orderCount); nReads = v < A.orderCap ? v : A.orderCap; }
 	uint32_t sc_iters = 0, sc_rounds = 0, sc_fetch = 0, sc_chase = 0, sc_lfex = 0, sc_lf2 = 0, sc_lf1 = 0, sc_same = 0;
+
+	if (EXT && A.pool && A.adopt) {
+		/* carry-over: what lane g of the previous launch parked -- state and pending request; the scratch slot is g
+		 * as ever, and the read goes back into LDS from its own batch's arrays */
+		const BtPoolRec* r = A.pool + g;
+		if (BT_GP(const uint32_t, r->w)[60] == A.launchSeq - 1u) {
+			BT_UNROLL
+			for (int k = 0; k < 12; k++) { const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * k); __builtin_memcpy((char*)&L + 16 * k, &v, 16); }
+			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 13); req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
+			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 14); req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
+			L.tosValid = 0; L.ccValid = 0;
+			if (RL) {
+				const BtBatchDev* pb = &cold->ring[L.bid];
+				const uint8_t* ps = *BT_GP(const uint8_t* const, &pb->seq) + L.roff;
+				const uint8_t* pq = *BT_GP(const uint8_t* const, &pb->qual) + L.roff;
+				BT_NOUNROLL
+				for (uint32_t base = 0; base < L.plen; base += 16u) bt_rl_store_chunk(S, base, bt_ld4(ps + base), bt_ld4(pq + base));
+			}
+		}
+	}
 
 	for (;;) {
 		/* keep the compiler from hoisting the cold descriptor's fields into scalar registers for
 		 * the whole loop: they are read where they are used */
 		asm volatile("" : "+s"(cold));
 
-		if (EXT && !poolDry) {
-			/* adopt the reads the previous launch parked before any fresh one: state, scratch slot, pending request */
-			bool failed = false;
-			if (L.state == ST_IDLE) {
-				const uint32_t w = atomicAdd(A.carryCursor, 1u);
-				if (w < *BT_GP(const uint32_t, A.carryInCount)) {
-					const BtPoolRec* r = A.carryIn + w;
-					BT_UNROLL
-					for (int k = 0; k < 12; k++) { const BtU4 v = ((const BtU4*)r->w)[k]; __builtin_memcpy((char*)&L + 16 * k, &v, 16); }
-					{ const BtU4 v = ((const BtU4*)r->w)[12]; S.slot = v.x; }
-					{ const BtU4 v = ((const BtU4*)r->w)[13]; req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
-					{ const BtU4 v = ((const BtU4*)r->w)[14]; req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
-					L.tosValid = 0; L.ccValid = 0; L.carried = 1;
-					if (RL) {
-						BT_NOUNROLL
-						for (uint32_t base = 0; base < L.plen; base += 16u)
-							bt_rl_store_chunk(S, base, bt_ld4(A.prevSeq + L.roff + base), bt_ld4(A.prevQual + L.roff + base));
-					}
-				} else failed = true;
-			}
-			if (__ballot(failed) != 0) poolDry = true;
-		}
 		/* ---- the round's memory requests: every lane's loads are issued, then one wait ---------- */
 		BT_PROF_T0(t_rank);
 		BtRes res;
@@ -185,8 +182,6 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		/* ---- advance every lane to its next request, pulling new reads as old ones finish ------- */
 		for (;;) {
 			if (L.state == ST_IDLE) {
-				if (EXT) S.slot = A.slotBase + blockIdx.x * BT_BLOCK + threadIdx.x;   /* the lane's own slot (after an adopted read) */
-				if (EXT && !poolDry) break;                  /* parked reads first: adopted at the top of the next round */
 				if (drained) break;
 				const uint32_t w = atomicAdd(A.nextRead, 1u);
 				if (w >= nReads) { drained = true; break; }
@@ -202,28 +197,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
 		 * have run out of work simply carry an empty request */
-		bool live = L.state != ST_IDLE;
-		if (EXT && A.carryOut) {
-			/* the cursor is dry (a lane of this wavefront found it so, or a look at it every 16th round says so):
-			 * fresh reads still running here are parked for the next launch; reads carried into this launch stay */
-			bool dry = __ballot(drained) != 0;
-			if (!dry && (sc_rounds & 15u) == 15u) dry = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.nextRead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)nReads;
-			if (dry) {
-				drained = true;
-				if (live && !L.carried) {
-					const uint32_t slot = atomicAdd(A.carryOutCount, 1u);
-					if (slot < A.carryOutCap) {
-						BtPoolRec* r = A.carryOut + slot;
-						BT_UNROLL
-						for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); ((BtU4*)r->w)[k] = v; }
-						{ BtU4 v; v.x = S.slot; v.y = 0; v.z = 0; v.w = 0; ((BtU4*)r->w)[12] = v; }
-						{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; ((BtU4*)r->w)[13] = v; }
-						{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); ((BtU4*)r->w)[14] = v; }
-						L.state = ST_IDLE; live = false;
-					}
-				}
-			}
-		}
+		const bool live = L.state != ST_IDLE;
 		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
 		if (__ballot(live) == 0) break;
 		/* op counters: wave-uniform tallies in scalar registers (ballot + popcount), flushed once
@@ -240,6 +214,26 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			sc_same += (uint32_t)__builtin_popcountll(__ballot(isR && req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u));
 		}
 		if (live) L.iters++;
+		if (EXT && A.pool && A.park) {
+			/* the cursor is dry (a lane of this wavefront found it so, or a look at it every 16th round says so): the
+			 * wavefront stops here and parks what its lanes are doing (below, after the loop) -- unless one of them
+			 * holds a read that has been carried long enough: then it runs on until that read is done */
+			bool dry = __ballot(drained) != 0;
+			if (!dry && (sc_rounds & 15u) == 15u) dry = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.nextRead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)nReads;
+			if (dry) {
+				drained = true;
+				if (__ballot(live && ((cold->curBid - L.bid) & (BT_BATCH_RING - 1u)) >= A.maxAge) == 0) { parkNow = true; break; }
+			}
+		}
+	}
+	if (EXT && parkNow && L.state != ST_IDLE) {
+		BtPoolRec* r = A.pool + (blockIdx.x * BT_BLOCK + threadIdx.x);
+		BT_UNROLL
+		for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); bt_st4((uint8_t*)r->w + 16 * k, v); }
+		{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 13, v); }
+		{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); bt_st4((uint8_t*)r->w + 16 * 14, v); }
+		{ BtU4 v; v.x = A.launchSeq; v.y = 0; v.z = 0; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 15, v); }
+		atomicAdd(A.parkedOf + L.bid, 1u);
 	}
 	if ((threadIdx.x & 63u) == 0) {
 		atomicAdd(&CNT[CN_ITERS], (unsigned long long)sc_iters); atomicAdd(&CNT[CN_WROUNDS], (unsigned long long)sc_rounds);
@@ -324,7 +318,7 @@ extern "C" int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, ui
 extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
-	const bool ext = a->carryIn || a->carryOut || a->order;
+	const bool ext = a->pool || a->order;
 #define BT_LAUNCH(O, R, T) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
                                 else hipLaunchKernelGGL((bt_search_kernel<O, false, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
 	if (rl == 2) {

@@ -217,25 +217,28 @@ int  bt_align_pairs(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* 
 int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
                            bt_op_counts* counts_dev);
 /* A stream of host batches through one context: bt_align_stream_submit uploads a batch and enqueues its search
- * without waiting (PCIe traffic on a copy stream of its own, three staging areas in HBM taking turns);
- * bt_align_stream_collect returns the oldest submitted batch once its bt_hit_batch is filled (`*tag` = the value
- * given at submit; NULL = nothing in flight).  At most two batches are in flight: submit, then collect the previous
- * one.  With carry-over (below) a batch can be collected once its successor has been submitted; pass flush != 0
- * when there is none (end of input).  `in`, `out` and the arrays they point at stay the caller's and must live
- * until the batch is collected.  What the reference does with a FASTQ reader feeding its worker threads. */
+ * without waiting (PCIe traffic on a copy stream of its own, a staging area in HBM per batch in flight);
+ * bt_align_stream_collect hands back the oldest submitted batch if it is complete -- its bt_hit_batch filled,
+ * `*tag` = the value given at submit -- and `*tag = NULL` otherwise (not complete yet, or nothing in flight): the
+ * call does not wait unless flush != 0, which finishes whatever is still being searched (end of input).  At most
+ * 14 batches may be in flight.  Reads that outgrow the search scratch come back flagged BT_ST_OVERFLOW (no second
+ * pass on the stream); run them through bt_align_batch.  `in`, `out` and the arrays they point at stay the caller's
+ * and must live until the batch is collected.  What the reference does with a FASTQ reader feeding its worker
+ * threads. */
 int  bt_align_stream_submit(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, void* tag);
 int  bt_align_stream_collect(bt_ctx* ctx, void** tag, int flush);
 int  bt_ctx_sync(bt_ctx* ctx);
 /* Carry-over between the batches of a context (what the reference's worker threads get for free: a thread that
  * finishes its read takes the next one, whatever "batch" it came from -- ebwt_search.cpp:1180-1230's GET_READ loop).
- * Off (default): every bt_align_batch_device call runs its batch to the last read before the next one starts.  On:
- * when a batch's reads have all been handed out, the searches still running are parked and the following call on
- * this context resumes them alongside its own reads, so the minority of reads that backtrack for a long time never
- * leave the GPU idle.  The contract changes accordingly: the results of a batch are complete when the stream work
- * of the NEXT bt_align_batch_device call on the context is, or after bt_ctx_sync (which finishes whatever is
- * parked); the batch's input and output arrays must stay valid until then.  Reads <= 112 bases, unpaired,
- * phase-program engine; other batches are simply run to completion as before. */
-int  bt_ctx_set_carry(bt_ctx* ctx, int on);
+ * launches = 0 (default): every bt_align_batch_device call runs its batch to the last read before the next one
+ * starts.  launches = n (1..14): when a batch's reads have all been handed out, the searches still running are
+ * parked and the following call on this context resumes them alongside its own reads -- a read may ride along for
+ * up to n launches, after which the launch it is in finishes it -- so the minority of reads that backtrack for a
+ * long time never leave the GPU idle.  The contract changes accordingly: the results of a batch are complete when
+ * the stream work of the n-th bt_align_batch_device call after its own is, or after bt_ctx_sync (which finishes
+ * whatever is parked); the batch's input and output arrays must stay valid until then.  Reads <= 112 bases,
+ * unpaired, phase-program engine; other batches are simply run to completion as before. */
+int  bt_ctx_set_carry(bt_ctx* ctx, int launches);
 /* bt_align_batch_device sees the read lengths in HBM only; which build of the kernel a batch can use (reads kept
  * in LDS up to 104 / 112 bases, ebwt_search_backtrack.h:90-140's query accessors) then has to be settled on the
  * device.  A driver that knows its reads (a sequencer's fixed length) says so here: max_len = the longest read of

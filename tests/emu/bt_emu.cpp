@@ -61,6 +61,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
 	cold.ix[0] = e->d[0]; cold.ix[1] = e->d[1];
+	cold.curBid = 0; cold.ring[0] = cold.B;            /* one batch, nothing carried */
 	BtHot H;
 	memset(&H, 0, sizeof(H));
 	BtWarm W;
