@@ -43,7 +43,7 @@ struct Options {
 	std::string dump_al, dump_un, dump_max;   /* --al / --un / --max */
 	std::vector<std::string> rg_fields;
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
-	bool no_stream = false;
+	bool no_stream = false, stream = false;
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false, paired = false;
 	std::string mates1, mates2;
@@ -126,8 +126,10 @@ void usage(FILE* o)
 	    "  --device <list>    GPU(s) to run on, e.g. 0,1,2,3: index replicated, batches dealt out (default: 0)\n"
 	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
-	    "  --no-stream        search whole batches side by side (--inflight) instead of streaming them\n"
-	    "                     through one context per GPU with carry-over between batches\n"
+	    "  --stream           (experimental) stream unpaired batches through one context per GPU with\n"
+	    "                     carry-over between batches instead of searching --inflight whole batches\n"
+	    "                     side by side; faults on some -a runs, see DESIGN.md\n"
+	    "  --no-stream        the default\n"
 	    "Other:\n"
 	    "  --seed <int>       seed for random number generator\n"
 	    "  --version          print version information and quit\n"
@@ -156,7 +158,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_STREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -167,7 +169,7 @@ const LongOpt LONGS[] = {
 	{"usage", 0, O_USAGE}, {"sam", 0, 'S'}, {"sam-no-qname-trunc", 0, O_SAM_NOTRUNC}, {"sam-nohead", 0, O_SAM_NOHEAD},
 	{"sam-nosq", 0, O_SAM_NOSQ}, {"sam-noSQ", 0, O_SAM_NOSQ}, {"sam-RG", 1, O_SAM_RG}, {"suppress", 1, O_SUPPRESS}, {"mapq", 1, O_MAPQ},
 	{"cost", 0, O_COST}, {"showseed", 0, O_SHOWSEED}, {"no-unal", 0, O_NO_UNAL}, {"quiet", 0, O_QUIET}, {"device", 1, O_DEVICE},
-	{"batch", 1, O_BATCH}, {"inflight", 1, O_INFLIGHT}, {"no-stream", 0, O_NOSTREAM}, {"wrapper", 1, O_WRAPPER},
+	{"batch", 1, O_BATCH}, {"inflight", 1, O_INFLIGHT}, {"no-stream", 0, O_NOSTREAM}, {"stream", 0, O_STREAM}, {"wrapper", 1, O_WRAPPER},
 	/* accepted and without effect here (host-memory / CPU-threading knobs of the reference) */
 	{"reads-per-batch", 1, O_IGNORED_ARG}, {"chunkmbs", 1, O_IGNORED_ARG}, {"chunksz", 1, O_IGNORED_ARG}, {"chunkverbose", 0, O_IGNORED},
 	{"verbose", 0, O_IGNORED}, {"startverbose", 0, O_IGNORED}, {"sanity", 0, O_IGNORED}, {"reorder", 0, O_IGNORED},
@@ -325,6 +327,7 @@ void parse_args(int argc, char** argv, Options* O)
 		}
 		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
 		case O_NOSTREAM: O->no_stream = true; break;
+		case O_STREAM: O->stream = true; break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
 		case O_INTQUALS: O->int_quals = true; break;
@@ -684,17 +687,18 @@ int main(int argc, char** argv)
 	bt_index_info_get(idx, &info);
 	BtRefNames refs;
 	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
-	/* Unpaired searches through the phase programs are streamed: one searcher per GPU keeps its context fed and
-	 * the reads a batch leaves running are carried into the next one (bt_ctx_set_carry).  --no-stream, paired-end
-	 * and --best runs search `--inflight` whole batches side by side instead. */
-	const bool streamed = !O.paired && !O.pol.best && !O.no_stream;
+	/* `--inflight` whole batches are searched side by side, each on its own context and stream.  --stream
+	 * (experimental: unpaired, phase-program engine) instead keeps one context per GPU fed through
+	 * bt_align_stream_* with the reads a batch leaves running carried into the next ones (bt_ctx_set_carry). */
+	const bool streamed = !O.paired && !O.pol.best && O.stream && !O.no_stream;
 	std::vector<bt_ctx*> ctxs((size_t)(streamed ? 1 : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */
 	std::vector<bt_ctx*> redo_ctxs(streamed ? ctxs.size() : 0, nullptr);
 	for (size_t g = 0; g < ctxs.size(); g++) {
 		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 		if (streamed) {
-			if (bt_ctx_set_carry(ctxs[g], 12) != BT_OK) die("Error: bt_ctx_set_carry failed");
+			const char* cv = getenv("BT_CLI_CARRY");          /* diagnostics: launches a read may ride along (0 = none) */
+			if (bt_ctx_set_carry(ctxs[g], cv && *cv ? atoi(cv) : 12) != BT_OK) die("Error: bt_ctx_set_carry failed");
 			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 		}

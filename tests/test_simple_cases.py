@@ -106,7 +106,9 @@ def test_simple_case_oracle_and_host_io(case, run, simple_index):
 @pytest.mark.parametrize("case,run", all_runs(), ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
 def test_simple_case_bowtie_amd(case, run, simple_index):
     base = simple_index(case["ref"])
-    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + run["args"] + ["-x", base] + case["reads"]
+    # BT_TEST_CLI_EXTRA: extra bowtie-amd options for every case (e.g. "--stream" to put the suite through the
+    # experimental streamed search)
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + os.environ.get("BT_TEST_CLI_EXTRA", "").split() + run["args"] + ["-x", base] + case["reads"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
     assert (p.returncode != 0) == (run["returncode"] != 0), p.stderr.decode(errors="replace")
     if run["returncode"] == 0:
