@@ -55,11 +55,14 @@ def gather_ceiling(index_kind: str):
         return None
 
 
+KERNEL_ROUND = 2       # bump when bt_kernels.hip / bt_core.h change: PMC profiles of older sources no longer describe the kernel
+
+
 def measured_traffic(kernel: str, workload: str):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for e in json.load(f)["entries"]:
-                if e["kernel"] == kernel and e["workload"] == workload:
+                if e["kernel"] == kernel and e["workload"] == workload and e.get("kernel_round") == KERNEL_ROUND:
                     return e
     except (OSError, ValueError, KeyError):
         pass
@@ -500,7 +503,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tr["hbm_bytes_per_read"] * n * mult if tr and not args.genome else None),
-                         "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this kernel on this workload in profiles/traffic.json"),
+                         "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this round's source of this kernel on this workload in profiles/traffic.json (round 1 measured 217 KB/read, 1.9 x algorithmic)"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
                          "carry_over_launches": carry_age, "flush_ms_total": sum(flush_ms),
