@@ -260,10 +260,11 @@ def main():
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
-    ap.add_argument("--carry", type=int, default=-1,
-                    help="bt_ctx_set_carry: launches a read may ride along with the steps after its own (0 = every step runs "
-                         "to its last read before the next starts).  Default: 0 for steps of 50 M reads or more -- there the "
-                         "tail is a small part of the step and costs nothing extra, see profiles/README.md -- else 12.")
+    ap.add_argument("--carry", type=int, default=0,
+                    help="bt_ctx_set_carry: launches a read may ride along with the steps after its own.  Default 0: every "
+                         "step runs to its last read before the next starts.  Opt-in: it more than doubles the rate of "
+                         "16 M-read steps (profiles/README.md) but faults on two tiny inputs of the simple_tests suite "
+                         "(DESIGN.md 4.3), and gains nothing at 200 M reads per step.")
     ap.add_argument("--no-carry", action="store_true", help="same as --carry 0")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
@@ -340,7 +341,7 @@ def main():
     # all been handed out are parked and resumed by the context's next step, so a step's results are complete when
     # the next step (or the closing bt_ctx_sync, inside the timed region) is.  Each context therefore alternates
     # between two sets of output arrays.
-    carry_age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (0 if n >= 50_000_000 else 12))
+    carry_age = 0 if args.no_carry else max(0, args.carry)
     if paired or wl["pol"].get("best") or L > 112:
         carry_age = 0
     carry_age = min(carry_age, 12)

@@ -483,7 +483,10 @@ static int ctx_flush_carry(bt_ctx* c)
 	A.nextRead = c->d_cursor;
 	A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = 1; A.park = 0; A.maxAge = 0; A.parkedOf = c->d_carry;
 	HIPCHK(hipEventRecord(c->evFlush[0], c->stream));
+	const bool dbg = env_u32("BT_CARRY_DEBUG", 0) != 0;       /* diagnostics: name and fence every carry launch */
+	if (dbg) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] flush launch seq=%u blocks=%u rl=%d ...\n", c->launchSeq, c->carryBlocks, c->carryRl); }
 	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	if (dbg) { const int e = (int)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] flush launch done rc=%d\n", e); }
 	c->launchSeq++;
 	c->carryPending = false;
 	for (int i = 0; i < BT_BATCH_RING; i++) if (c->ringRetry[i]) {
@@ -609,7 +612,10 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<3|2,*,true,*> (gated)");
 	} else {
 		A.gate = nullptr;
+		const bool dbg = carry && env_u32("BT_CARRY_DEBUG", 0) != 0;
+		if (dbg) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] main launch seq=%u bid=%u adopt=%d n_reads=%u blocks=%u rl=%d maxAge=%u ...\n", c->launchSeq, bid, (int)adopt, in->n_reads, gridBlocks, rl, c->carryAge); }
 		if ((rc = launch_main(rl)) != BT_OK) return rc;
+		if (dbg) { const int e = (int)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] main launch done rc=%d\n", e); }
 	}
 	if (carry) {
 		/* which ring batches still have reads parked after this launch: to the host, for whoever wants to know when a
