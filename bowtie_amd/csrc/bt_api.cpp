@@ -470,12 +470,16 @@ static int ctx_flush_carry(bt_ctx* c)
 	BtBatchDev none;
 	memset(&none, 0, sizeof(none));
 	fill_cold(c, &cold, none, bid);
+	const BatchView& lastB = c->ring[(c->launchSeq - 1u) & (BT_BATCH_RING - 1u)];
+	const uint32_t keep = env_u32("BT_FLUSH_KEEP_BATCH", 0);   /* diagnostics: 1 = the last batch stands in as the current one */
+	if (keep) cold.B = lastB.B;
 	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));
 	A.H.seq = nullptr; A.H.qual = nullptr; A.H.stride = 0; A.H.n_reads = 0;
+	if (keep) { A.H.seq = lastB.seq; A.H.qual = lastB.qual; A.H.stride = lastB.stride; }
 	A.cold = c->d_cold; A.warm = c->d_warm;
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
