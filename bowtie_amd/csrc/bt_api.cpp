@@ -582,6 +582,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		HIPCHK(hipMemsetAsync(c->d_carry + BT_BATCH_RING + bid, 0, 4, c->stream));           /* this batch's mismatch-pool cursor */
 		A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = adopt ? 1u : 0u; A.park = 1u;
 		A.maxAge = c->carryAge; A.parkedOf = c->d_carry;
+		A.parkMinRounds = env_u32("BT_PARK_MIN_ROUNDS", 0);
 	}
 	if (both && bt_launch_maxlen(in->len, in->n_reads, c->d_cursor + 7, c->stream) != 0) return BT_ERR_DEVICE;
 	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
@@ -619,7 +620,21 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		const bool dbg = carry && env_u32("BT_CARRY_DEBUG", 0) != 0;
 		if (dbg) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] main launch seq=%u bid=%u adopt=%d n_reads=%u blocks=%u rl=%d maxAge=%u ...\n", c->launchSeq, bid, (int)adopt, in->n_reads, gridBlocks, rl, c->carryAge); }
 		if ((rc = launch_main(rl)) != BT_OK) return rc;
-		if (dbg) { const int e = (int)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] main launch done rc=%d\n", e); }
+		if (dbg) {
+			const int e = (int)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] main launch done rc=%d\n", e);
+			/* what the first lanes parked: the automaton state a continuation starts from */
+			const uint32_t nd = in->n_reads < 4u ? in->n_reads : 4u;
+			std::vector<BtPoolRec> recs(nd);
+			if (hipMemcpy(recs.data(), c->pool, nd * sizeof(BtPoolRec), hipMemcpyDeviceToHost) == hipSuccess)
+				for (uint32_t g = 0; g < nd; g++) {
+					BtLane L; memcpy(&L, recs[g].w, sizeof(L));
+					fprintf(stderr, "[carry] pool[%u] stamp=%u%s rd=%u bid=%u state=%u step=%u kind=%u mirror=%u readFw=%u rev=%u qlen=%u plen=%u sd=%u depth=%u d=%u top=%u bot=%u iters=%u nhits=%u stored=%u status=%u req{kind=%u n=%u a=%llx x=%llx}\n",
+					        g, recs[g].w[60], recs[g].w[60] == c->launchSeq ? "(live)" : "(stale)", L.rd, (unsigned)L.bid, (unsigned)L.state, (unsigned)L.step, (unsigned)L.kind,
+					        (unsigned)L.mirror, (unsigned)L.readFw, (unsigned)L.rev, (unsigned)L.qlen, (unsigned)L.plen, (unsigned)L.sd, (unsigned)L.depth, (unsigned)L.d, L.top, L.bot,
+					        L.iters, L.nhits, (unsigned)L.stored, (unsigned)L.status, recs[g].w[52], recs[g].w[53],
+					        (unsigned long long)(((uint64_t)recs[g].w[57] << 32) | recs[g].w[56]), (unsigned long long)(((uint64_t)recs[g].w[59] << 32) | recs[g].w[58]));
+				}
+		}
 	}
 	if (carry) {
 		/* which ring batches still have reads parked after this launch: to the host, for whoever wants to know when a

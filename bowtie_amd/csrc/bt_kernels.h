@@ -36,6 +36,7 @@ struct BtKernelArgs {
 	uint32_t   launchSeq;        /* this launch's number on its context; a record is live if stamped launchSeq - 1 */
 	uint32_t   adopt, park;      /* pick parked reads up at the start / park at the end          */
 	uint32_t   maxAge;           /* launches a read may be carried through (< BT_BATCH_RING - 1) */
+	uint32_t   parkMinRounds;    /* diagnostics (BT_PARK_MIN_ROUNDS): a wavefront parks no earlier than its round N */
 	uint32_t*  parkedOf;         /* [BT_BATCH_RING] reads parked by this launch, per batch-ring slot */
 	const uint32_t* orderCount;  /* non-null (with order): the pick-up list's length lives on the device -- min(*orderCount,
 	                                orderCap) entries.  The on-stream second pass over reads that outgrew their scratch */

@@ -110,8 +110,8 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			L.tosValid = 0; L.ccValid = 0;
 			if (RL) {
 				const BtBatchDev* pb = &cold->ring[L.bid];
-				const uint8_t* ps = *BT_GP(const uint8_t* const, &pb->seq) + L.roff;
-				const uint8_t* pq = *BT_GP(const uint8_t* const, &pb->qual) + L.roff;
+				const uint8_t* ps = pb->seq + L.roff;
+				const uint8_t* pq = pb->qual + L.roff;
 				BT_NOUNROLL
 				for (uint32_t base = 0; base < L.plen; base += 16u) bt_rl_store_chunk(S, base, bt_ld4(ps + base), bt_ld4(pq + base));
 			}
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			if (!dry && (sc_rounds & 15u) == 15u) dry = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.nextRead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)nReads;
 			if (dry) {
 				drained = true;
-				if (__ballot(live && ((cold->curBid - L.bid) & (BT_BATCH_RING - 1u)) >= A.maxAge) == 0) { parkNow = true; break; }
+				if (sc_rounds >= A.parkMinRounds && __ballot(live && ((cold->curBid - L.bid) & (BT_BATCH_RING - 1u)) >= A.maxAge) == 0) { parkNow = true; break; }
 			}
 		}
 	}
