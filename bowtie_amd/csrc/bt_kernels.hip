@@ -14,6 +14,7 @@
  * everything they call for a read.
  */
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "bt_core.h"
 #include "bt_kernels.h"
 
@@ -318,7 +319,7 @@ extern "C" int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, ui
 extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
-	const bool ext = a->pool || a->order;
+	const bool ext = a->pool || a->order || getenv("BT_FORCE_EXT") != nullptr;   /* BT_FORCE_EXT: diagnostics */
 #define BT_LAUNCH(O, R, T) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
                                 else hipLaunchKernelGGL((bt_search_kernel<O, false, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
 	if (rl == 2) {
