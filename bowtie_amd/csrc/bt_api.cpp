@@ -541,9 +541,11 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		if ((rc = ctx_flush_carry(c)) != BT_OK) return rc;
 	}
 	if ((rc = ctx_ensure_scratch(c, maxLen, carry)) != BT_OK) return rc;
-	/* the device-pointer entry point hands back finished results: reads that outgrow their scratch are searched
-	 * again on the stream (below), through the twin context's worst-case arenas; BT_DEVICE_RETRY=0 leaves them flagged */
-	const bool devRetry = async && retry_on_stream && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
+	/* reads that outgrow their scratch can be searched again on the stream (below), through the twin context's
+	 * worst-case arenas, so that the device-pointer entry point hands back finished results.
+	 * Off by default (BT_DEVICE_RETRY=1 turns it on): the second pass runs the EXT instances of the kernel, which fault
+	 * on two inputs of the simple_tests suite that the plain instances search correctly. */
+	const bool devRetry = async && retry_on_stream && !c->is_big && env_u32("BT_DEVICE_RETRY", 0);
 	if (devRetry) {
 		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_scratch(c->big, maxLen, false)) != BT_OK) return rc;

@@ -273,6 +273,7 @@ def test_gpu_device_path_settles_the_build_on_the_device(rname, gidx):
 def test_gpu_device_path_retries_overflowed_reads_on_the_stream(gidx, monkeypatch):
     """bt_align_batch_device with absurdly small arenas: the reads that outgrow them are collected and searched again
     on the same stream (no host copy); what the caller reads back after the sync is complete and equals the oracle's."""
+    monkeypatch.setenv("BT_DEVICE_RETRY", "1")                  # opt-in: see DESIGN.md 4.4
     monkeypatch.setenv("BT_ENTRY_CAP", "24")
     monkeypatch.setenv("BT_FRAME_CAP", "3")
     monkeypatch.setenv("BT_PARTIAL_CAP", "4")
