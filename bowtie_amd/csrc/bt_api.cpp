@@ -593,6 +593,15 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	HIPCHK(hipEventRecord(ring[0], c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	A.order = nullptr;
+#ifdef BT_TRACE
+	uint32_t* d_trace = nullptr;
+	const uint32_t traceCap = 4096;
+	if (getenv("BT_TRACE_READ")) {
+		HIPCHK(hipMalloc((void**)&d_trace, (4 + 12 * traceCap) * 4));
+		HIPCHK(hipMemset(d_trace, 0, (4 + 12 * traceCap) * 4));
+		A.trace = d_trace; A.traceRead = (uint32_t)atoi(getenv("BT_TRACE_READ")); A.traceCap = traceCap;
+	}
+#endif
 	auto launch_main = [&](int rlv) -> int {
 		uint32_t maxBlocks = c->cus * (rlv == 2 ? 3u : c->blocksPerCU);
 		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);
@@ -655,6 +664,23 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipEventRecord(ring[1], c->stream));
 	c->timed = true;
+#ifdef BT_TRACE
+	if (d_trace) {
+		/* copy what was written even if the kernel faulted later: the copy may fail, then nothing is printed */
+		std::vector<uint32_t> h(4 + 12 * traceCap);
+		(void)hipStreamSynchronize(c->stream);
+		if (hipMemcpy(h.data(), d_trace, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+			const uint32_t n = h[0] < traceCap ? h[0] : traceCap;
+			fprintf(stderr, "[trace] read %u: %u rounds recorded, kernel %s\n", A.traceRead, h[0], c->last_kernel);
+			for (uint32_t k = 0; k < n; k++) {
+				const uint32_t* t = h.data() + 4 + 12 * k;
+				fprintf(stderr, "[trace] r=%u st=%u step=%u mir=%u fw=%u rev=%u req=%u n=%u a=%08x%08x x=%08x%08x top=%u bot=%u d=%u sd=%u\n",
+				        t[0], t[1], t[2] & 255u, (t[2] >> 8) & 1u, (t[2] >> 9) & 1u, (t[2] >> 10) & 1u, t[3], t[4], t[6], t[5], t[8], t[7], t[9], t[10], t[11] & 0xffffu, t[11] >> 16);
+			}
+		}
+		(void)hipFree(d_trace);
+	}
+#endif
 	return BT_OK;
 }
 

@@ -46,6 +46,12 @@ struct BtKernelArgs {
 	                                device (bt_align_batch_device) without waiting for it                 */
 	uint32_t   gateLo, gateHi;
 	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
+#ifdef BT_TRACE
+	/* diagnostics build only (make -C bowtie_amd/csrc trace): every round of the lane that holds read `traceRead`
+	 * appends 12 words to trace[] (trace[0] = records written): round, state, step|mirror|readFw|rev, request kind,
+	 * n, a lo/hi, x lo/hi, top, bot, d|sd */
+	uint32_t*  trace; uint32_t traceRead, traceCap;
+#endif
 };
 
 /* the best-first kernel (bt_best_kernels.hip) */

@@ -124,6 +124,17 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		 * the whole loop: they are read where they are used */
 		asm volatile("" : "+s"(cold));
 
+#ifdef BT_TRACE
+		if (A.trace && L.state != ST_IDLE && L.rd == A.traceRead) {
+			const uint32_t k = atomicAdd(A.trace, 1u);
+			if (k < A.traceCap) {
+				uint32_t* t = A.trace + 4u + 12u * k;
+				t[0] = sc_rounds; t[1] = L.state; t[2] = L.step | (L.mirror << 8) | (L.readFw << 9) | (L.rev << 10) | (L.bid << 12);
+				t[3] = req.kind; t[4] = req.n; t[5] = (uint32_t)req.a; t[6] = (uint32_t)(req.a >> 32);
+				t[7] = (uint32_t)req.x; t[8] = (uint32_t)(req.x >> 32); t[9] = L.top; t[10] = L.bot; t[11] = L.d | (L.sd << 16);
+			}
+		}
+#endif
 		/* ---- the round's memory requests: every lane's loads are issued, then one wait ---------- */
 		BT_PROF_T0(t_rank);
 		BtRes res;

@@ -122,3 +122,21 @@ def test_paired_without_best_is_refused(simple_index):
     p = subprocess.run([BIN] + r["args"] + ["-x", simple_index(c["ref"])] + c["reads"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, cwd=T.G, timeout=600)
     assert p.returncode == 1 and b"add --best" in p.stderr
+
+
+KNOWN_FAULT = [(c, r) for c, r in all_runs() if c["id"] in (5, 100)]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("BT_RUN_KNOWN_FAULT") != "1",
+                    reason="open defect (DESIGN.md 4.4): faults the GPU on purpose; set BT_RUN_KNOWN_FAULT=1 to run")
+@pytest.mark.parametrize("case,run", KNOWN_FAULT, ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+def test_ext_kernel_instances_on_the_two_tiny_inputs(case, run, simple_index, monkeypatch):
+    """Regression test for the open defect: the EXT=true instances of bt_search_kernel (carry-over, on-stream second
+    pass) fault on these two inputs; BT_FORCE_EXT=1 makes the plain path launch them.  Expected to pass once fixed."""
+    monkeypatch.setenv("BT_FORCE_EXT", "1")
+    base = simple_index(case["ref"])
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + run["args"] + ["-x", base] + case["reads"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=120)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-300:]
+    assert p.stdout == expected(run)
