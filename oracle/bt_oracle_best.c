@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdlib.h>
 #include "bt_oracle.h"
 
 #define OFF_MASK 0xffffffffu
@@ -1610,6 +1611,247 @@ int bto_align_pair_best(const bto_index* ixFw, const bto_index* ixBw, const bto_
 	}
 	if (budget < 0) st |= BT_ST_OVERFLOW;
 	drv_free(driver);
+	free(rd); free(found); free(pairs_fw.a); free(pairs_rc.a);
+	if (sink.dropped && sink.hitsForThisRead <= sink.max) st |= BT_ST_HITCAP;
+	if (n_hits_total) *n_hits_total = sink.hitsForThisRead;
+	if (status) *status = st;
+	if (sink.strata) for (int i = 0; i < sink.stored; i++) sink.hits[i].oms = (uint32_t)sink.stored / 2u - 1u;
+	if (sink.hitsForThisRead > sink.max) return pol->sample_max ? sink.stored : 0;
+	int n = sink.stored;
+	if ((uint32_t)n > sink.n) n = (int)sink.n;
+	return n;
+}
+
+
+/* ==========================================================================================
+ * PairedBWAlignerV1 (aligner.h:606-1480): paired-end WITHOUT --best -- the reference's default
+ * ("useV1", ebwt_search.cpp:232,776).  The same four per-mate, per-strand drivers the factories
+ * build for V2 (aligner_0mm.h:178-243, aligner_1mm.h:286-432, aligner_23mm.h:358-628,
+ * aligner_seed_mm.h:705-1330), but each behind its own cost-aware driver and driven separately:
+ * first the pairing in which mate 1 is on its own strand ("fw": L = mate 1, R = mate 2), then the
+ * other one (L = mate 2, R = mate 1).  dontReconcileMates is true by default (ebwt_search.cpp:219),
+ * so every offset found for a range of one mate goes straight to resolveOutstandingInRef
+ * (aligner.h:951-1086): the other mate is looked for in the 2-bit reference.
+ * ======================================================================================== */
+typedef struct {
+	driver_t* drL; driver_t* drR;                /* NULL = StubRangeSourceDriver (range_source.h:1891) */
+	int chaseL, chaseR, delayedL, delayedR;
+	uint32_t offsLsz, offsRsz;
+} v1_orient_t;
+
+#define V1_DONE(d)  ((d) == NULL || (d)->done)
+#define V1_FOUND(d) ((d) != NULL && (d)->foundRange)
+
+static driver_t* v1_block(env_t* env, const bto_index* fwI, const bto_index* bwI, const bt_policy* pol, int* btCnt,
+                          int mate1, int fw)
+{
+	g_mate1 = mate1;
+	driver_t* d;
+	if (pol->mode == BT_MODE_V && pol->mms == 0) {
+		/* aligner_0mm.h:178-243: the bare EbwtRangeSourceDriver, no cost-aware wrapper */
+		single_spec_t sp = spec(fwI, fw, OFF_MASK, 1, 0, 0, 0, 0, 1, PIN_TO_LEN, PIN_TO_LEN, PIN_TO_LEN, PIN_TO_LEN, NULL);
+		d = single_new(env, pol->maq_round, 1, &sp);
+	} else {
+		d = cost_new(env, 1);                    /* mixedMode = false: no cost_calc_paired */
+		add_block(d, env, fwI, bwI, pol, btCnt, fw, 1);
+	}
+	g_mate1 = 1;
+	return d;
+}
+
+int bto_align_pair_v1(const bto_index* ixFw, const bto_index* ixBw, const bto_refs* refs, const bt_policy* pol,
+                      const uint8_t* seq1, const uint8_t* qual1, int len1, uint32_t seed1,
+                      const uint8_t* seq2, const uint8_t* qual2, int len2, uint32_t seed2,
+                      bto_hit* hits, int cap, uint32_t* n_hits_total, uint32_t* status, bt_op_counts* counts)
+{
+	if (len1 < 0 || len1 > BTO_MAXLEN || len2 < 0 || len2 > BTO_MAXLEN || !refs) return -BT_ERR_ARG;
+	if ((pol->mode == BT_MODE_N || pol->mms > 0) && !ixBw) return -BT_ERR_ARG;
+	sink_t sink;
+	memset(&sink, 0, sizeof(sink));
+	/* createMult(2): as for V2 */
+	sink.strata = pol->strata; sink.all = pol->all_hits;
+	sink.n = pol->all_hits ? (pol->strata ? (0xffffffffu / 2) * 2u : 0xffffffffu) : pol->khits * 2u;
+	sink.max = pol->mhits == 0xffffffffu ? 0xffffffffu : pol->mhits * 2u;
+	sink.bestStratum = 999;
+	sink.hits = hits; sink.cap = cap;
+	uint32_t st = 0;
+	int budget = BRANCH_BUDGET;
+	env_t env = { &budget, counts };
+	if (len1 < 4 || len2 < 4) {                 /* aligner.h:733-742 */
+		if (n_hits_total) *n_hits_total = 0;
+		if (status) *status = BT_ST_SKIPPED;
+		return 0;
+	}
+	read_t* rd = (read_t*)calloc(2, sizeof(read_t));
+	read_init(&rd[0], seq1, qual1, (uint32_t)len1, seed1);
+	read_init(&rd[1], seq2, qual2, (uint32_t)len2, seed2);
+	int btCntStore = pol->max_bts;
+	int* btCnt = (pol->mode == BT_MODE_N && pol->mms >= 2) ? &btCntStore : NULL;
+	const int fw1 = pol->mate1_fw, fw2 = pol->mate2_fw;
+	int do1Fw = 1, do1Rc = 1, do2Fw = 1, do2Rc = 1;
+	if (pol->nofw) { if (fw1) do1Fw = 0; else do1Rc = 0; if (fw2) do2Fw = 0; else do2Rc = 0; }
+	if (pol->norc) { if (fw1) do1Rc = 0; else do1Fw = 0; if (fw2) do2Rc = 0; else do2Fw = 0; }
+	driver_t* d1Fw = do1Fw ? v1_block(&env, ixFw, ixBw, pol, btCnt, 1, 1) : NULL;
+	driver_t* d1Rc = do1Rc ? v1_block(&env, ixFw, ixBw, pol, btCnt, 1, 0) : NULL;
+	driver_t* d2Fw = do2Fw ? v1_block(&env, ixFw, ixBw, pol, btCnt, 0, 1) : NULL;
+	driver_t* d2Rc = do2Rc ? v1_block(&env, ixFw, ixBw, pol, btCnt, 0, 0) : NULL;
+	driver_t* all[4] = { d1Fw, d1Rc, d2Fw, d2Rc };
+	for (int i = 0; i < 4; i++) if (all[i]) drv_set_query(all[i], rd, NULL);     /* aligner.h:743-746 */
+	if (btCnt) *btCnt = pol->max_bts;
+	uint32_t alRnd = seed1;                       /* Aligner::rand_.init(bufa_->seed) */
+	chaser_t ch; memset(&ch, 0, sizeof(ch));
+	ch.probes = counts ? &counts->rstarts : NULL;
+	ch.offTidx = OFF_MASK;
+	v1_orient_t O[2];
+	memset(O, 0, sizeof(O));
+	O[0].drL = fw1 ? d1Fw : d1Rc; O[0].drR = fw2 ? d2Fw : d2Rc;       /* aligner.h:670-682 */
+	O[1].drL = fw2 ? d2Rc : d2Fw; O[1].drR = fw1 ? d1Rc : d1Fw;       /* aligner.h:684-696 */
+	pairset_t pairs_fw = {0, 0, 0}, pairs_rc = {0, 0, 0};
+	range_t* found = (range_t*)malloc(sizeof(range_t));
+	const uint32_t qlen1 = rd[0].len, qlen2 = rd[1].len;
+	const uint32_t symCeil = pol->mhits;            /* "mhits, // for symCeiling" (ebwt_search.cpp:1275) */
+	uint32_t mixedAttempts = 0;
+	int done = 0, doneFw = 0, doneFwFirst = 1, o = 0;
+	const int dbg = getenv("BTO_V1_DEBUG") != NULL;
+#define V1LOG(...) do { if (dbg) fprintf(stderr, __VA_ARGS__); } while (0)
+	while (!done) {
+		/* ---- advance() (aligner.h:815-847) ---- */
+		if (doneFw && doneFwFirst) { o = 1; doneFwFirst = 0; mixedAttempts = 0; }
+		v1_orient_t* X = &O[o];
+		if ((X->chaseL || X->chaseR) && ch.offTidx == OFF_MASK && !ch.done) { chaser_advance(&ch, &env); continue; }
+		/* ---- advanceOrientation(pairFw = !doneFw) (aligner.h:1091-1320) ---- */
+		const int pairFw = !doneFw;
+		int* donePair = (o == 0) ? &doneFw : &done;
+		int returned = 0;
+		for (int side = 0; side < 2 && !returned; side++) {
+			/* side 0: a row of L's range is being chased; side 1: of R's */
+			int* chaseMe = side == 0 ? &X->chaseL : &X->chaseR;
+			if (!*chaseMe) continue;
+			if (side == 1 && X->chaseL) break;      /* "else if" */
+			driver_t* drMe = side == 0 ? X->drL : X->drR;
+			driver_t* drOther = side == 0 ? X->drR : X->drL;
+			int* delayedOther = side == 0 ? &X->delayedR : &X->delayedL;
+			int* chaseOther = side == 0 ? &X->chaseR : &X->chaseL;
+			if (ch.offTidx != OFF_MASK) {
+				if (!done) {
+					/* mixed mode always (overThresh || dontReconcile_): resolveOutstandingInRef (aligner.h:951-1086) */
+					const range_t* range = drv_range(drMe);
+					const int off1 = side == 0 ? pairFw : !pairFw;
+					const uint32_t tidx = ch.offTidx, toff = ch.offToff;
+					int ret = 0;
+					const int matchRight = off1 ? !doneFw : doneFw;
+					int fw = off1 ? fw2 : fw1;
+					if (doneFw) fw = !fw;
+					const read_t* om = &rd[off1 ? 1 : 0];                      /* the outstanding mate */
+					const uint8_t* oseq = fw ? om->pat[1][1] : om->pat[0][1];   /* patFw : patRc */
+					const uint8_t* oqual = fw ? om->qual[0] : om->qual[1];
+					const uint32_t qlen = om->len, alen = off1 ? rd[0].len : rd[1].len;
+					const int minins = pol->min_ins, maxins = pol->max_ins;
+					if ((uint32_t)maxins > (qlen > alen ? qlen : alen)) {
+						uint32_t begin, end;
+						const uint32_t insDiff = (uint32_t)(maxins - minins);
+						const int contain = pol->allow_contain;
+						if (matchRight) {
+							end = toff + (uint32_t)maxins;
+							begin = toff + (contain ? 0 : 1);
+							if (!contain && qlen < alen) begin += alen - qlen;
+							if (end > insDiff + qlen) { uint32_t b2 = end - insDiff - qlen; if (b2 > begin) begin = b2; }
+							if (refs->approxLen[tidx] < end) end = refs->approxLen[tidx];
+							if (refs->approxLen[tidx] < begin) begin = refs->approxLen[tidx];
+						} else {
+							begin = (toff + alen < (uint32_t)maxins) ? 0 : toff + alen - (uint32_t)maxins;
+							const uint32_t mi = alen < qlen ? alen : qlen;
+							if (contain) end = toff + alen;                     /* V1: no "- 1" (aligner.h:1046) */
+							else {
+								end = toff + mi - 1;
+								const uint32_t e2 = toff + alen - (uint32_t)minins + qlen - 1;
+								if (e2 < end) end = e2;
+								if (toff + alen + qlen < (uint32_t)minins + 1) end = 0;
+							}
+						}
+						/* "if(end - begin < qlen) return false" is unsigned there; end < begin would send the
+						 * reference's find() a wrapped spread (it asserts end > begin): not restated */
+						if (end >= begin && end - begin >= qlen) {
+							uint32_t result = 0;
+							if (ref_find_one(pol, refs->seq[tidx], oseq, oqual, qlen, tidx, begin, end, fw,
+							                 doneFw ? &pairs_rc : &pairs_fw, toff, found, &result)) {
+								range_t* r = found;
+								r->fw = fw; r->cost = (uint16_t)(r->cost | (r->stratum << 14));
+								r->mate1 = !off1; r->top = range->top; r->bot = range->bot;
+								const int ebwtLFw = matchRight ? (range->ebwt->fw != 0) : 1;
+								const int ebwtRFw = matchRight ? 1 : (range->ebwt->fw != 0);
+								const range_t* rL = matchRight ? range : r;
+								const range_t* rR = matchRight ? r : range;
+								const uint32_t up = matchRight ? toff : result, dn = matchRight ? result : toff;
+								/* report (aligner.h:856-936): upstream mate first; pairFw = !doneFw_ */
+								const int pf = !doneFw;
+								const uint32_t oms = (rL->bot - rL->top < rR->bot - rR->top ? rL->bot - rL->top : rR->bot - rR->top) - 1;
+								const uint32_t lenL = pf ? rd[0].len : rd[1].len, lenR = pf ? rd[1].len : rd[0].len;
+								ret = al_report_ex(&sink, rL, tidx, up, lenL, ebwtLFw, pf ? 1 : 2, oms);
+								if (!ret) ret = al_report_ex(&sink, rR, tidx, dn, lenR, ebwtRFw, pf ? 2 : 1, oms);
+							}
+						}
+					}
+					V1LOG("[v1] o=%d side=%d attempt at %u:%u -> ret=%d stored=%d\n", o, side, tidx, toff, ret, sink.stored);
+					done = ret;
+					if (++mixedAttempts > (uint32_t)pol->pair_tries) { *donePair = 1; returned = 1; break; }
+				}
+				ch.offTidx = OFF_MASK;                  /* rchase_->reset() */
+			} else {
+				/* the chaser has been through the whole range */
+				*chaseMe = 0;
+				if (drMe) drMe->foundRange = 0;
+				if (*delayedOther) {
+					const range_t* r = drv_range(drOther);
+					const uint32_t qlen = side == 0 ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1);
+					chaser_set_top_bot(&ch, r->top, r->bot, qlen, &alRnd, r->ebwt, &env);
+					*chaseOther = 1; *delayedOther = 0;
+				}
+			}
+			break;
+		}
+		if (returned) continue;
+		if (!done && !*donePair && !X->chaseL && !X->chaseR) {
+			/* look for more ranges for whichever mate has fewer candidates */
+			int side;
+			if ((X->offsLsz < X->offsRsz || V1_DONE(X->drR)) && !V1_DONE(X->drL)) side = 0;
+			else if (!V1_DONE(X->drR)) side = 1;
+			else { V1LOG("[v1] o=%d both drivers done btCnt=%d\n", o, btCnt ? *btCnt : -1); *donePair = 1; continue; }
+			driver_t* drMe = side == 0 ? X->drL : X->drR;
+			driver_t* drOther = side == 0 ? X->drR : X->drL;
+			uint32_t* szMe = side == 0 ? &X->offsLsz : &X->offsRsz;
+			uint32_t* szOther = side == 0 ? &X->offsRsz : &X->offsLsz;
+			int* delayedMe = side == 0 ? &X->delayedL : &X->delayedR;
+			int* delayedOther = side == 0 ? &X->delayedR : &X->delayedL;
+			int* chaseMe = side == 0 ? &X->chaseL : &X->chaseR;
+			int* chaseOther = side == 0 ? &X->chaseR : &X->chaseL;
+			if (V1_DONE(drOther) && *szOther == 0) { V1LOG("[v1] o=%d give up (other done, 0 cand) side=%d btCnt=%d\n", o, side, btCnt ? *btCnt : -1); *donePair = 1; continue; }     /* no pair in this orientation */
+			if (!drMe->foundRange) drv_advance(drMe, ADV_FOUND_RANGE);
+			if (drMe->foundRange) {
+				const range_t* rm = drv_range(drMe);
+				V1LOG("[v1] o=%d side=%d found range [%u,%u) cost=%u btCnt=%d\n", o, side, rm->top, rm->bot, rm->cost, btCnt ? *btCnt : -1);
+				*szMe += rm->bot - rm->top;
+				if (*szOther == 0 && *szMe > 3) {       /* (!dontReconcile_ || sz > 3), dontReconcile_ == true */
+					*delayedMe = 1;
+				} else {
+					if (*szMe > symCeil && *szOther > symCeil) { *donePair = 1; continue; }
+					if (*delayedOther && *szOther < *szMe) {
+						/* first range for both mates: chase the smaller one first */
+						*delayedOther = 0; *delayedMe = 1; *chaseOther = 1;
+						const range_t* r = drv_range(drOther);
+						const uint32_t qlen = side == 0 ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1);
+						chaser_set_top_bot(&ch, r->top, r->bot, qlen, &alRnd, r->ebwt, &env);
+					} else {
+						*chaseMe = 1;
+						const uint32_t qlen = side == 0 ? (doneFw ? qlen2 : qlen1) : (doneFw ? qlen1 : qlen2);
+						chaser_set_top_bot(&ch, rm->top, rm->bot, qlen, &alRnd, rm->ebwt, &env);
+					}
+				}
+			}
+		}
+	}
+	if (budget < 0) st |= BT_ST_OVERFLOW;
+	for (int i = 0; i < 4; i++) if (all[i]) drv_free(all[i]);
 	free(rd); free(found); free(pairs_fw.a); free(pairs_rc.a);
 	if (sink.dropped && sink.hitsForThisRead <= sink.max) st |= BT_ST_HITCAP;
 	if (n_hits_total) *n_hits_total = sink.hitsForThisRead;

@@ -71,3 +71,33 @@ PAIRED_MODES = {
 }
 # (index, pair set name) -> how tests regenerate the pairs (tests/common.py: pair_set)
 PAIR_SETS = [("e_coli", "e_coli_1000_pe"), ("e_coli", "pe50"), ("multi", "pe50"), ("multi", "pe100"), ("multi", "pe30"), ("e_coli", "pe75")]
+
+
+# Paired-end WITHOUT --best: PairedBWAlignerV1, the reference's default paired-end aligner (aligner.h:606-1480).
+# name -> (bowtie options, make_policy keywords).  The backtrack budget: the reference has two defaults,
+# maxBtsBetter = 125 for the non-stateful seeded worker and maxBts = 800 for every stateful aligner
+# (ebwt_search.cpp:185-186, 2416-2529 vs 2644, 2670) -- and paired-end is always stateful, --best or not.
+PAIRED_V1_MODES = {
+    "pev1_n2_X500": (["-n", "2", "-X", "500"], dict(mode="n", mms=2, max_ins=500)),
+    "pev1_n0_X500": (["-n", "0", "-X", "500"], dict(mode="n", mms=0, max_ins=500)),
+    "pev1_n1_X500": (["-n", "1", "-X", "500"], dict(mode="n", mms=1, max_ins=500)),
+    "pev1_n3_X500": (["-n", "3", "-X", "500"], dict(mode="n", mms=3, max_ins=500)),
+    "pev1_v0_X500": (["-v", "0", "-X", "500"], dict(mode="v", mms=0, max_ins=500)),
+    "pev1_v1_X500": (["-v", "1", "-X", "500"], dict(mode="v", mms=1, max_ins=500)),
+    "pev1_v2_X500": (["-v", "2", "-X", "500"], dict(mode="v", mms=2, max_ins=500)),
+    "pev1_n2_default_X": (["-n", "2"], dict(mode="n", mms=2, max_ins=250)),
+    "pev1_n2_X400_I250_k3": (["-n", "2", "-X", "400", "-I", "250", "-k", "3"], dict(mode="n", mms=2, max_ins=400, min_ins=250, khits=3)),
+    "pev1_n2_X500_ff": (["-n", "2", "-X", "500", "--ff"], dict(mode="n", mms=2, max_ins=500, mate1_fw=True, mate2_fw=True)),
+    "pev1_n2_X500_rf": (["-n", "2", "-X", "500", "--rf"], dict(mode="n", mms=2, max_ins=500, mate1_fw=False, mate2_fw=True)),
+    "pev1_n2_X500_m1": (["-n", "2", "-X", "500", "-m", "1"], dict(mode="n", mms=2, max_ins=500, mhits=1)),
+    "pev1_n1_X500_a": (["-n", "1", "-X", "500", "-a"], dict(mode="n", mms=1, max_ins=500, all_hits=True)),
+    "pev1_v2_X500_nofw": (["-v", "2", "-X", "500", "--nofw"], dict(mode="v", mms=2, max_ins=500, nofw=True)),
+    "pev1_n2_X500_norc_k2": (["-n", "2", "-X", "500", "--norc", "-k", "2"], dict(mode="n", mms=2, max_ins=500, norc=True, khits=2)),
+    "pev1_v2_X500_pairtries2_k4": (["-v", "2", "-X", "500", "--pairtries", "2", "-k", "4"], dict(mode="v", mms=2, max_ins=500, pair_tries=2, khits=4)),
+    "pev1_n2_X500_allow_contain": (["-n", "2", "-X", "500", "--allow-contain"], dict(mode="n", mms=2, max_ins=500, allow_contain=True)),
+    "pev1_n2_l20_e100_X500": (["-n", "2", "-l", "20", "-e", "100", "-X", "500"], dict(mode="n", mms=2, seed_len=20, qual_thresh=100, max_ins=500)),
+    "pev1_n2_maxbts10_X500": (["-n", "2", "--maxbts", "10", "-X", "500"], dict(mode="n", mms=2, max_bts=10, max_ins=500)),
+    "pev1_n2_nomaq_X500": (["-n", "2", "--nomaqround", "-X", "500"], dict(mode="n", mms=2, maq_round=False, max_ins=500)),
+}
+for _k, (_a, _kw) in PAIRED_V1_MODES.items():
+    _kw.setdefault("max_bts", 800)

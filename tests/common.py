@@ -14,6 +14,7 @@ import refrun as R
 from bowtie_amd import _abi as A
 from bowtie_amd.reads import pack_reads, parse_fastq
 from bowtie_amd.synth import synth_reads
+from best_modes import PAIRED_V1_MODES  # noqa: E402
 from best_modes import BEST_MODES, PAIRED_MODES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,6 +40,7 @@ MODES = {
 }
 MODES.update({k: v[1] for k, v in BEST_MODES.items()})
 MODES.update({k: v[1] for k, v in PAIRED_MODES.items()})
+MODES.update({k: v[1] for k, v in PAIRED_V1_MODES.items()})      # paired-end without --best (PairedBWAlignerV1)
 
 
 @lru_cache(maxsize=None)
@@ -86,9 +88,21 @@ def check_pairs_against_golden(run: dict, per_pair, b1, b2, refnames):
     assert hashlib.md5(sam).hexdigest() == run["md5"], run["file"] + ": full-SAM md5 differs"
 
 
-def oracle_pair_results(index: str, b1, b2, kw, cap=None, counts=None):
+def oracle_pair_results(index: str, b1, b2, kw, cap=None, counts=None, v1=False):
     pol = OL.make_policy(**kw)
-    return R.oracle_search_pairs(oracle_index(index), pol, b1, b2, cap=cap, counts=counts)
+    return R.oracle_search_pairs(oracle_index(index), pol, b1, b2, cap=cap, counts=counts, v1=v1)
+
+
+@lru_cache(maxsize=None)
+def pe_v1_manifest():
+    with open(os.path.join(G, "pe_v1", "MANIFEST.json")) as f:
+        return json.load(f)
+
+
+def paired_v1_runs(index=None, reads=None, modes=None):
+    """tests/golden/pe_v1 (oracle/gen_golden_pe_v1.py): the reference's paired-end output without --best."""
+    return [r for r in pe_v1_manifest()["runs"]
+            if (not index or r["index"] == index) and (not reads or r["reads"] in reads) and (not modes or r["mode"] in modes)]
 
 
 def golden_runs(index=None, reads=None, modes=None):

@@ -84,6 +84,11 @@ def lib() -> C.CDLL:
         L.bto_refs_build.argtypes = [C.POINTER(OIndex)]
         L.bto_refs_build.restype = C.c_void_p
         L.bto_refs_free.argtypes = [C.c_void_p]
+        L.bto_align_pair_v1.argtypes = [C.POINTER(OIndex), C.POINTER(OIndex), C.c_void_p, C.POINTER(Policy),
+                                        C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
+                                        C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
+                                        C.POINTER(OHit), C.c_int, C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), C.POINTER(OpCounts)]
         L.bto_align_pair_best.argtypes = [C.POINTER(OIndex), C.POINTER(OIndex), C.c_void_p, C.POINTER(Policy),
                                           C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
                                           C.c_char_p, C.c_char_p, C.c_int, C.c_uint32,
@@ -162,13 +167,15 @@ class OracleIndex:
         return out
 
     def align_pair(self, pol: Policy, seq1, qual1: bytes, seed1: int, seq2, qual2: bytes, seed2: int,
-                   cap: int = 16, counts: Optional[OpCounts] = None):
-        """PairedBWAlignerV2 for one pair -> (hits: upstream mate, downstream mate, ..., n_hits_total, status)"""
+                   cap: int = 16, counts: Optional[OpCounts] = None, v1: bool = False):
+        """PairedBWAlignerV2 (--best) or, v1=True, PairedBWAlignerV1 (the reference's default paired-end aligner)
+        for one pair -> (hits: upstream mate, downstream mate, ..., n_hits_total, status)"""
         if getattr(self, "_refs", None) is None:
             self._refs = lib().bto_refs_build(C.byref(self.fw))
         hits = (OHit * cap)()
         tot, st = C.c_uint32(), C.c_uint32()
-        n = lib().bto_align_pair_best(C.byref(self.fw), C.byref(self.bw) if self.bw is not None else None, self._refs,
+        fn = lib().bto_align_pair_v1 if v1 else lib().bto_align_pair_best
+        n = fn(C.byref(self.fw), C.byref(self.bw) if self.bw is not None else None, self._refs,
                                       C.byref(pol), seq1.tobytes(), bytes(qual1), len(seq1), seed1,
                                       seq2.tobytes(), bytes(qual2), len(seq2), seed2, hits, cap,
                                       C.byref(tot), C.byref(st), C.byref(counts) if counts is not None else None)

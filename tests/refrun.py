@@ -91,14 +91,14 @@ def run_reference_pairs(args: List[str], index_base: str, reads1: str, reads2: s
     return p.stdout
 
 
-def oracle_search_pairs(oidx, pol, b1: ReadBatch, b2: ReadBatch, cap: Optional[int] = None, counts=None):
+def oracle_search_pairs(oidx, pol, b1: ReadBatch, b2: ReadBatch, cap: Optional[int] = None, counts=None, v1: bool = False):
     cap = cap or (128 if pol.all_hits else max(2, min(2 * int(pol.khits), 128)))
     res = []
     for i in range(b1.n):
         L1, L2 = int(b1.len[i]), int(b2.len[i])
         hits, total, st = oidx.align_pair(pol, b1.seq[i, :L1], b1.qual[i, :L1].tobytes(), int(b1.seed[i]),
                                           b2.seq[i, :L2], b2.qual[i, :L2].tobytes(), int(b2.seed[i]),
-                                          cap=cap, counts=counts)
+                                          cap=cap, counts=counts, v1=v1)
         res.append(([O.Hit(h["tidx"], h["toff"], h["oms"], h["cost"], h["stratum"], h["fw"], h["mms"], h["mate"])
                      for h in hits], total, st))
     return res
