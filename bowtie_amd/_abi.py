@@ -18,7 +18,7 @@ class Policy(C.Structure):
                 ("mhits", C.c_uint32), ("all_hits", C.c_int32), ("best", C.c_int32),
                 ("strata", C.c_int32), ("sample_max", C.c_int32), ("min_ins", C.c_int32), ("max_ins", C.c_int32),
                 ("mate1_fw", C.c_int32), ("mate2_fw", C.c_int32), ("pair_tries", C.c_int32),
-                ("allow_contain", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("allow_contain", C.c_int32), ("pe_v1", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class ReadBatchC(C.Structure):
@@ -79,14 +79,15 @@ HIT_DTYPE = [("tidx", "<u4"), ("toff", "<u4"), ("oms", "<u4"), ("mm_off", "<u4")
 def make_policy(mode="n", mms=2, seed_len=28, qual_thresh=70, max_bts=None, nofw=False, norc=False,
                 maq_round=True, khits=1, mhits=0xFFFFFFFF, all_hits=False, best=False, strata=False,
                 sample_max=False, min_ins=0, max_ins=250, mate1_fw=True, mate2_fw=False, pair_tries=100,
-                allow_contain=False) -> Policy:
+                allow_contain=False, pe_v1=False) -> Policy:
     """Reference defaults: -n 2 -l 28 -e 70 -k 1, --maxbts 125 (800 for the best-first workers)
     (ebwt_search.cpp:153-253).  --strata, -M and -v 3 imply the best-first workers
     (ebwt_search.cpp:851-853, 877-887)."""
-    best = bool(best or strata or sample_max or (mode == "v" and mms == 3))
+    # pe_v1: paired-end without --best (PairedBWAlignerV1) -- still the stateful engine, with its 800 backtracks
+    best = bool(best or strata or sample_max or (mode == "v" and mms == 3) or pe_v1)
     if max_bts is None:
         max_bts = 800 if best else 125
     return Policy(BT_MODE_V if mode == "v" else BT_MODE_N, mms, seed_len, qual_thresh, max_bts,
                   int(nofw), int(norc), int(maq_round), khits, mhits, int(all_hits), int(best),
                   int(strata), int(sample_max), min_ins, max_ins, int(mate1_fw), int(mate2_fw), pair_tries,
-                  int(allow_contain))
+                  int(allow_contain), int(pe_v1))

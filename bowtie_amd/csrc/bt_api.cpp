@@ -248,7 +248,8 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* stream)
 {
 	c->idx = idx; c->pol = *pol;
-	c->best = pol->best != 0;
+	c->best = pol->best != 0 || pol->pe_v1 != 0;
+	c->pol.best = c->best ? 1 : 0;
 	int rc = c->best ? bt_host_compile_best(*pol, &c->bprog) : bt_host_compile_program(*pol, &c->prog);
 	if (rc != BT_OK) return rc;
 	bool need_mirror = c->best && c->bprog.needMirror;

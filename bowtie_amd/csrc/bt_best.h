@@ -82,6 +82,8 @@ struct BfProgram {
 	/* the RefAligner the pair's second mate is found with (ref_aligner.h): k mismatches end to end
 	 * (-v k) or k in the seed with a quality ceiling (-n k) */
 	uint32_t refSeeded, refMms, refSeedLen, refQualMax;
+	/* PairedBWAlignerV1 (no --best): the same nodes, grouped by (mate, strand) under four cost-aware drivers */
+	uint32_t pairedV1, symCeil;
 };
 
 /* the 2-bit reference with its N mask (BitPairReference, reference.h:35-120), one position space
@@ -862,7 +864,7 @@ template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, ui
 /* mateEliminated (range_source.h:2266-2280): only the aligner's own driver mixes mates */
 template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
 {
-	if (LEVEL != 0 || !X.P->paired) return false;
+	if (LEVEL != 0 || !X.P->paired || X.P->pairedV1) return false;      /* V1's drivers hold one mate each */
 	const uint32_t n = AW(d + CA_NACT);
 	bool m1 = false, m2 = false;
 	for (uint32_t i = 0; i < n; i++) {
@@ -982,28 +984,58 @@ BF_FN uint32_t child_range(BfLane& X, uint32_t d)
 }
 
 /* the static part of the tree (Unpaired*Factory::create()) */
+/* one child of a cost-aware driver: a leaf, or a seeded driver with its seed generator and extender */
+BF_FN uint32_t bf_make_node(BfLane& X, const BfNode nd)
+{
+	const BfProgram& P = *X.P;
+	const uint32_t d = bf_alloc(X, BF_DRW);
+	if (nd.kind == BF_LEAF) { if (!X.ovf) leaf_init(X, d, nd.spec); }
+	else {
+		const uint32_t gen = bf_alloc(X, BF_DRW), full = bf_alloc(X, BF_DRW);
+		if (X.ovf) return d;
+		leaf_init(X, gen, nd.genSpec);
+		cost_init(X, full, 0, 0);
+		for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
+		AW(d + DR_KIND) = BF_SEEDED | ((uint32_t)nd.fw << 8) | ((uint32_t)P.specs[nd.spec].mate << 9);
+		AW(d + DR_FLAGS) = BF_F_DONE;
+		AW(d + SD_FULL) = full; AW(d + SD_SEED) = gen; AW(d + SD_FACT) = nd.spec;
+	}
+	return d;
+}
+
 BF_FN uint32_t bf_build_tree(BfLane& X)
 {
 	const BfProgram& P = *X.P;
 	const uint32_t top = bf_alloc(X, BF_DRW);
 	cost_init(X, top, P.strandFix, P.nnodes);
 	for (uint32_t i = 0; i < P.nnodes && !X.ovf; i++) {
-		const BfNode nd = P.nodes[i];
-		const uint32_t d = bf_alloc(X, BF_DRW);
-		if (nd.kind == BF_LEAF) leaf_init(X, d, nd.spec);
-		else {
-			const uint32_t gen = bf_alloc(X, BF_DRW), full = bf_alloc(X, BF_DRW);
-			if (X.ovf) break;
-			leaf_init(X, gen, nd.genSpec);
-			cost_init(X, full, 0, 0);
-			for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
-			AW(d + DR_KIND) = BF_SEEDED | ((uint32_t)nd.fw << 8) | ((uint32_t)P.specs[nd.spec].mate << 9);
-			AW(d + DR_FLAGS) = BF_F_DONE;
-			AW(d + SD_FULL) = full; AW(d + SD_SEED) = gen; AW(d + SD_FACT) = nd.spec;
-		}
+		const uint32_t d = bf_make_node(X, P.nodes[i]);
+		if (X.ovf) break;
 		cost_add_rss(X, top, d);
 	}
 	return top;
+}
+
+/* PairedBWAlignerV1's four drivers: tops[mate * 2 + (fw ? 0 : 1)] = driver1Fw, driver1Rc, driver2Fw, driver2Rc;
+ * 0 = StubRangeSourceDriver (that strand of that mate is not searched: --nofw / --norc) */
+BF_FN void bf_build_tree_v1(BfLane& X, uint32_t tops[4])
+{
+	const BfProgram& P = *X.P;
+	uint32_t cnt[4] = {0, 0, 0, 0};
+	for (uint32_t i = 0; i < P.nnodes; i++) {
+		const BfSpec& sp = P.specs[P.nodes[i].spec];
+		cnt[sp.mate * 2u + (sp.fw ? 0u : 1u)]++;
+	}
+	for (uint32_t b = 0; b < 4u; b++) {
+		tops[b] = 0;
+		if (cnt[b] && !X.ovf) { tops[b] = bf_alloc(X, BF_DRW); if (!X.ovf) cost_init(X, tops[b], P.strandFix, cnt[b]); }
+	}
+	for (uint32_t i = 0; i < P.nnodes && !X.ovf; i++) {
+		const BfSpec& sp = P.specs[P.nodes[i].spec];
+		const uint32_t d = bf_make_node(X, P.nodes[i]);
+		if (X.ovf) break;
+		cost_add_rss(X, tops[sp.mate * 2u + (sp.fw ? 0u : 1u)], d);
+	}
 }
 
 /* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
@@ -1320,7 +1352,7 @@ BF_FN bool bf_resolve_in_ref(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint
 	} else {
 		begin = (toff + alen < maxins) ? 0u : toff + alen - maxins;
 		const uint32_t mi = alen < qlen ? alen : qlen;
-		if (P.allowContain) end = toff + alen - 1u;
+		if (P.allowContain) end = toff + alen - (P.pairedV1 ? 0u : 1u);       /* aligner.h:1046 (V1) / :1958 (V2) */
 		else {
 			end = toff + mi - 1u;
 			const uint32_t e2 = toff + alen - minins + qlen - 1u;
@@ -1394,6 +1426,108 @@ BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				} else done = true;
 			}
 		}
+	}
+	bf_read_end(X, B, 2u);
+}
+
+/* PairedBWAlignerV1::setQuery + advance() until done (aligner.h:726-847, advanceOrientation :1091-1320) with
+ * dontReconcileMates (the default, ebwt_search.cpp:219): first the pairing in which mate 1 lies on its own strand
+ * (L = mate 1, R = mate 2), then the other (L = mate 2, R = mate 1); every offset found for a range of one mate goes
+ * to the reference scan for the other (bf_resolve_in_ref). */
+struct BfV1Orient { uint32_t drL, drR; bool chaseL, chaseR, delayedL, delayedR; uint32_t szL, szR; };
+
+BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
+{
+	bf_read_begin(X, B, rd);
+	if (X.R[0].len < 4u || X.R[1].len < 4u) {
+		X.status |= BT_STF_SKIPPED;
+	} else {
+		const BfProgram& P = *X.P;
+		uint32_t tops[4];
+		bf_build_tree_v1(X, tops);
+		const uint32_t maxLen = X.R[0].len > X.R[1].len ? X.R[0].len : X.R[1].len;
+		const uint32_t pairsFw = bf_alloc(X, 3), pairsRc = bf_alloc(X, 3), mmBuf = bf_alloc(X, maxLen);
+		BfChase ch;
+		bf_chase_init(ch);
+		bool done = true;
+		if (!X.ovf) {
+			AW(pairsFw) = AW(pairsFw + 1u) = AW(pairsFw + 2u) = 0; AW(pairsRc) = AW(pairsRc + 1u) = AW(pairsRc + 2u) = 0;
+			for (uint32_t b = 0; b < 4u && !X.ovf; b++) if (tops[b]) cost_set_query<0>(X, tops[b]);
+			done = false;
+		}
+		const bool fw1 = P.mate1Fw != 0, fw2 = P.mate2Fw != 0;
+		BfV1Orient O[2];
+		O[0].drL = fw1 ? tops[0] : tops[1]; O[0].drR = fw2 ? tops[2] : tops[3];      /* aligner.h:670-682 */
+		O[1].drL = fw2 ? tops[3] : tops[2]; O[1].drR = fw1 ? tops[1] : tops[0];      /* aligner.h:684-696 */
+		for (int k = 0; k < 2; k++) { O[k].chaseL = O[k].chaseR = O[k].delayedL = O[k].delayedR = false; O[k].szL = O[k].szR = 0; }
+		const uint32_t qlen1 = X.R[0].len, qlen2 = X.R[1].len;
+		uint32_t attempts = 0, o = 0;
+		bool doneFw = false, doneFwFirst = true;
+#define V1_DONE(d)  ((d) == 0u || dr_done(X, (d)))
+		auto chase_range_of = [&](uint32_t top, uint32_t qlen) {
+			const uint32_t leaf = AW(top + CA_LAST);
+			ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, qlen);
+		};
+		while (!done && !X.ovf) {
+			if (doneFw && doneFwFirst) { o = 1; doneFwFirst = false; attempts = 0; }
+			BfV1Orient& Q = O[o];
+			if ((Q.chaseL || Q.chaseR) && ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
+			bool& donePair = (o == 0) ? doneFw : done;
+			bool returned = false;
+			if (Q.chaseL || Q.chaseR) {
+				const bool sideL = Q.chaseL;
+				const uint32_t drMe = sideL ? Q.drL : Q.drR, drOther = sideL ? Q.drR : Q.drL;
+				bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
+				bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
+				bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
+				if (ch.tidx != BT_OFF_MASK) {
+					if (!done) {
+						done = bf_resolve_in_ref(X, B, AW(drMe + CA_LAST), ch.tidx, ch.toff, pairsFw, pairsRc, mmBuf);
+						if (++attempts > P.pairTries) { donePair = true; returned = true; }
+					}
+					if (!returned) ch.tidx = BT_OFF_MASK;                       /* rchase_->reset() */
+				} else {
+					chaseMe = false;
+					dr_set(X, drMe, BF_F_FOUND, false);
+					if (delayedOther) {
+						chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
+						chaseOther = true; delayedOther = false;
+					}
+				}
+			}
+			if (returned) continue;
+			if (!done && !donePair && !Q.chaseL && !Q.chaseR) {
+				bool sideL;
+				if ((Q.szL < Q.szR || V1_DONE(Q.drR)) && !V1_DONE(Q.drL)) sideL = true;
+				else if (!V1_DONE(Q.drR)) sideL = false;
+				else { donePair = true; continue; }
+				const uint32_t drMe = sideL ? Q.drL : Q.drR, drOther = sideL ? Q.drR : Q.drL;
+				uint32_t& szMe = sideL ? Q.szL : Q.szR;
+				uint32_t& szOther = sideL ? Q.szR : Q.szL;
+				bool& delayedMe = sideL ? Q.delayedL : Q.delayedR;
+				bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
+				bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
+				bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
+				if (V1_DONE(drOther) && szOther == 0) { donePair = true; continue; }     /* no pair in this orientation */
+				if (!dr_found(X, drMe)) cost_advance<0>(X, drMe);
+				if (dr_found(X, drMe)) {
+					const uint32_t leaf = AW(drMe + CA_LAST);
+					szMe += AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP);
+					if (szOther == 0 && szMe > 3u) delayedMe = true;                     /* dontReconcile_: aligner.h:1233 */
+					else {
+						if (szMe > P.symCeil && szOther > P.symCeil) { donePair = true; continue; }
+						if (delayedOther && szOther < szMe) {
+							delayedOther = false; delayedMe = true; chaseOther = true;
+							chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
+						} else {
+							chaseMe = true;
+							chase_range_of(drMe, sideL ? (doneFw ? qlen2 : qlen1) : (doneFw ? qlen1 : qlen2));
+						}
+					}
+				}
+			}
+		}
+#undef V1_DONE
 	}
 	bf_read_end(X, B, 2u);
 }

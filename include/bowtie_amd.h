@@ -77,7 +77,12 @@ typedef struct bt_policy {
 	int32_t  mate2_fw;
 	int32_t  pair_tries;   /* --pairtries (100): anchors tried per pair (aligner.h:1855)       */
 	int32_t  allow_contain;/* --allow-contain                                                  */
-	int32_t  reserved[2];
+	int32_t  pe_v1;        /* pairs only: 1 = PairedBWAlignerV1 (aligner.h:606-1480), the reference's paired-end
+	                          aligner when --best is NOT given (ebwt_search.cpp:232, 776); 0 = PairedBWAlignerV2
+	                          (--best).  Either way the stateful engine runs (best is taken as set) and max_bts
+	                          defaults to 800 (ebwt_search.cpp:186, 2644, 2670).  NOT YET RUN ON A GPU: verified
+	                          against the reference only through the host emulator   */
+	int32_t  reserved[1];
 } bt_policy;
 
 void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 -k 1          */

@@ -206,6 +206,30 @@ def test_emu_paired_matches_reference_sam(run, emu):
     T.check_pairs_against_golden(run, res, b1, b2, T.oracle_index(run["index"]).refnames)
 
 
+@pytest.mark.parametrize("run", T.paired_v1_runs(), ids=lambda r: r["file"][6:-7])
+def test_emu_paired_without_best_matches_reference_sam(run, emu):
+    """Paired-end without --best (bf_run_pair_v1: PairedBWAlignerV1 -- four separately driven cost-aware drivers, the
+    two pairings one after the other) on the host build of the device code, against the reference's outputs."""
+    b1, b2 = T.pair_set(run["index"], run["reads"])
+    kw = dict(T.MODES[run["mode"]], pe_v1=True)
+    res = emu[run["index"]].align_pairs(A.make_policy(**kw), b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    T.check_pairs_against_golden(run, res, b1, b2, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("mode", ["pev1_n2_X500", "pev1_v2_X500", "pev1_n3_X500", "pev1_n1_X500_a", "pev1_n2_X400_I250_k3"])
+def test_emu_paired_without_best_vs_oracle_counts(mode, emu):
+    """... and op count for op count against the oracle's restatement of the same aligner."""
+    kw = T.MODES[mode]
+    b1, b2 = T.pair_set("multi", "pe50")
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    cap = 2048 if kw.get("all_hits") else None
+    want = T.oracle_pair_results("multi", b1, b2, kw, cap=cap, counts=oc, v1=True)
+    got = emu["multi"].align_pairs(A.make_policy(**dict(kw, pe_v1=True)), b1, b2, hit_cap=cap, counts=ec)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
+        assert getattr(oc, f) == getattr(ec, f), f
+
+
 @pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500"])
 def test_emu_paired_vs_oracle_counts(mode, emu):
     kw = T.MODES[mode]

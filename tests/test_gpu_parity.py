@@ -481,6 +481,18 @@ def test_gpu_paired_matches_reference_sam(run, gidx):
     T.check_pairs_against_golden(run, res, b1, b2, gidx[run["index"]].refnames)
 
 
+@pytest.mark.skipif(os.environ.get("BT_RUN_UNVERIFIED") != "1",
+                    reason="bf_run_pair_v1 has only been verified in the host emulator so far (DESIGN.md 4.2); BT_RUN_UNVERIFIED=1 runs it")
+@pytest.mark.parametrize("run", T.paired_v1_runs(), ids=lambda r: r["file"][6:-7])
+def test_gpu_paired_without_best_matches_reference_sam(run, gidx):
+    """Paired-end without --best (PairedBWAlignerV1) on the GPU against the reference's outputs."""
+    b1, b2 = T.pair_set(run["index"], run["reads"])
+    kw = dict(T.MODES[run["mode"]], pe_v1=True)
+    al = aligner(gidx, run["index"], kw)
+    res = al.align_pairs(b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    T.check_pairs_against_golden(run, res, b1, b2, gidx[run["index"]].refnames)
+
+
 @pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500"])
 def test_gpu_paired_vs_oracle_counts(mode, gidx):
     import oracle_lib as OL
