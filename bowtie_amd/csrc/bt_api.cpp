@@ -250,6 +250,9 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	c->idx = idx; c->pol = *pol;
 	c->best = pol->best != 0 || pol->pe_v1 != 0;
 	c->pol.best = c->best ? 1 : 0;
+#ifndef BT_PE_V1
+	if (pol->pe_v1) return BT_ERR_ARG;       /* bf_run_pair_v1 is compiled into the kernel with make PE_V1=1 only (bt_best.h) */
+#endif
 	int rc = c->best ? bt_host_compile_best(*pol, &c->bprog) : bt_host_compile_program(*pol, &c->prog);
 	if (rc != BT_OK) return rc;
 	bool need_mirror = c->best && c->bprog.needMirror;

@@ -47,6 +47,16 @@
 #define BF_FN static
 #define BF_INL static inline
 #endif
+/* PairedBWAlignerV1 support (bf_run_pair_v1): always in host builds (the test emulator); in the device build only
+ * with -DBT_PE_V1 (make PE_V1=1) until it has been run on a GPU -- without the flag the kernel is, instruction for
+ * instruction, the one the GPU suite was run on (checked by diffing the device assembly). */
+#if defined(BT_PE_V1) || !defined(__HIP_DEVICE_COMPILE__)
+#define BF_HAVE_V1 1
+#define BF_IS_V1(P) ((P).paired == 2u)
+#else
+#define BF_HAVE_V1 0
+#define BF_IS_V1(P) false
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
 #else
@@ -82,9 +92,9 @@ struct BfProgram {
 	/* the RefAligner the pair's second mate is found with (ref_aligner.h): k mismatches end to end
 	 * (-v k) or k in the seed with a quality ceiling (-n k) */
 	uint32_t refSeeded, refMms, refSeedLen, refQualMax;
-	/* PairedBWAlignerV1 (no --best): the same nodes, grouped by (mate, strand) under four cost-aware drivers */
-	uint32_t pairedV1, symCeil;
 };
+/* BfProgram::paired: 0 unpaired, 1 PairedBWAlignerV2 (--best), 2 PairedBWAlignerV1 (no --best: the same nodes, grouped
+ * by (mate, strand) under four cost-aware drivers; its symCeiling is -m = sinkMax / 2) */
 
 /* the 2-bit reference with its N mask (BitPairReference, reference.h:35-120), one position space
  * for all sequences: reference t occupies positions [start[t], start[t] + len) */
@@ -864,7 +874,7 @@ template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, ui
 /* mateEliminated (range_source.h:2266-2280): only the aligner's own driver mixes mates */
 template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
 {
-	if (LEVEL != 0 || !X.P->paired || X.P->pairedV1) return false;      /* V1's drivers hold one mate each */
+	if (LEVEL != 0 || !X.P->paired || BF_IS_V1(*X.P)) return false;      /* V1's drivers hold one mate each */
 	const uint32_t n = AW(d + CA_NACT);
 	bool m1 = false, m2 = false;
 	for (uint32_t i = 0; i < n; i++) {
@@ -984,6 +994,31 @@ BF_FN uint32_t child_range(BfLane& X, uint32_t d)
 }
 
 /* the static part of the tree (Unpaired*Factory::create()) */
+BF_FN uint32_t bf_build_tree(BfLane& X)
+{
+	const BfProgram& P = *X.P;
+	const uint32_t top = bf_alloc(X, BF_DRW);
+	cost_init(X, top, P.strandFix, P.nnodes);
+	for (uint32_t i = 0; i < P.nnodes && !X.ovf; i++) {
+		const BfNode nd = P.nodes[i];
+		const uint32_t d = bf_alloc(X, BF_DRW);
+		if (nd.kind == BF_LEAF) leaf_init(X, d, nd.spec);
+		else {
+			const uint32_t gen = bf_alloc(X, BF_DRW), full = bf_alloc(X, BF_DRW);
+			if (X.ovf) break;
+			leaf_init(X, gen, nd.genSpec);
+			cost_init(X, full, 0, 0);
+			for (uint32_t k = 0; k < BF_DRW; k++) AW(d + k) = 0;
+			AW(d + DR_KIND) = BF_SEEDED | ((uint32_t)nd.fw << 8) | ((uint32_t)P.specs[nd.spec].mate << 9);
+			AW(d + DR_FLAGS) = BF_F_DONE;
+			AW(d + SD_FULL) = full; AW(d + SD_SEED) = gen; AW(d + SD_FACT) = nd.spec;
+		}
+		cost_add_rss(X, top, d);
+	}
+	return top;
+}
+
+#if BF_HAVE_V1
 /* one child of a cost-aware driver: a leaf, or a seeded driver with its seed generator and extender */
 BF_FN uint32_t bf_make_node(BfLane& X, const BfNode nd)
 {
@@ -1001,19 +1036,6 @@ BF_FN uint32_t bf_make_node(BfLane& X, const BfNode nd)
 		AW(d + SD_FULL) = full; AW(d + SD_SEED) = gen; AW(d + SD_FACT) = nd.spec;
 	}
 	return d;
-}
-
-BF_FN uint32_t bf_build_tree(BfLane& X)
-{
-	const BfProgram& P = *X.P;
-	const uint32_t top = bf_alloc(X, BF_DRW);
-	cost_init(X, top, P.strandFix, P.nnodes);
-	for (uint32_t i = 0; i < P.nnodes && !X.ovf; i++) {
-		const uint32_t d = bf_make_node(X, P.nodes[i]);
-		if (X.ovf) break;
-		cost_add_rss(X, top, d);
-	}
-	return top;
 }
 
 /* PairedBWAlignerV1's four drivers: tops[mate * 2 + (fw ? 0 : 1)] = driver1Fw, driver1Rc, driver2Fw, driver2Rc;
@@ -1037,6 +1059,7 @@ BF_FN void bf_build_tree_v1(BfLane& X, uint32_t tops[4])
 		cost_add_rss(X, tops[sp.mate * 2u + (sp.fw ? 0u : 1u)], d);
 	}
 }
+#endif
 
 /* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
  * ebwt_search.cpp passes NULL caches) ------------------------------------------------------------- */
@@ -1352,7 +1375,7 @@ BF_FN bool bf_resolve_in_ref(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint
 	} else {
 		begin = (toff + alen < maxins) ? 0u : toff + alen - maxins;
 		const uint32_t mi = alen < qlen ? alen : qlen;
-		if (P.allowContain) end = toff + alen - (P.pairedV1 ? 0u : 1u);       /* aligner.h:1046 (V1) / :1958 (V2) */
+		if (P.allowContain) end = toff + alen - (BF_IS_V1(P) ? 0u : 1u);       /* aligner.h:1046 (V1) / :1958 (V2) */
 		else {
 			end = toff + mi - 1u;
 			const uint32_t e2 = toff + alen - minins + qlen - 1u;
@@ -1430,6 +1453,7 @@ BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 	bf_read_end(X, B, 2u);
 }
 
+#if BF_HAVE_V1
 /* PairedBWAlignerV1::setQuery + advance() until done (aligner.h:726-847, advanceOrientation :1091-1320) with
  * dontReconcileMates (the default, ebwt_search.cpp:219): first the pairing in which mate 1 lies on its own strand
  * (L = mate 1, R = mate 2), then the other (L = mate 2, R = mate 1); every offset found for a range of one mate goes
@@ -1461,6 +1485,7 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 		O[1].drL = fw2 ? tops[3] : tops[2]; O[1].drR = fw1 ? tops[1] : tops[0];      /* aligner.h:684-696 */
 		for (int k = 0; k < 2; k++) { O[k].chaseL = O[k].chaseR = O[k].delayedL = O[k].delayedR = false; O[k].szL = O[k].szR = 0; }
 		const uint32_t qlen1 = X.R[0].len, qlen2 = X.R[1].len;
+		const uint32_t symCeil = P.sinkMax == 0xffffffffu ? 0xffffffffu : P.sinkMax / 2u;   /* -m ("mhits, // for symCeiling") */
 		uint32_t attempts = 0, o = 0;
 		bool doneFw = false, doneFwFirst = true;
 #define V1_DONE(d)  ((d) == 0u || dr_done(X, (d)))
@@ -1515,7 +1540,7 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 					szMe += AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP);
 					if (szOther == 0 && szMe > 3u) delayedMe = true;                     /* dontReconcile_: aligner.h:1233 */
 					else {
-						if (szMe > P.symCeil && szOther > P.symCeil) { donePair = true; continue; }
+						if (szMe > symCeil && szOther > symCeil) { donePair = true; continue; }
 						if (delayedOther && szOther < szMe) {
 							delayedOther = false; delayedMe = true; chaseOther = true;
 							chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
@@ -1531,6 +1556,7 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 	}
 	bf_read_end(X, B, 2u);
 }
+#endif
 
 #undef AW
 #endif /* BT_BEST_H_ */

@@ -41,8 +41,10 @@ __global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
 		/* a read that outgrows its arena is searched again by the host through the twin context:
 		 * its partial work is not tallied */
 		const BfLane before = X;
-		if (paired) { if (PROG.pairedV1) bf_run_pair_v1(X, BATCH, rd); else bf_run_pair(X, BATCH, rd); }
-		else bf_run_read(X, BATCH, rd);
+#if BF_HAVE_V1
+		if (paired && BF_IS_V1(PROG)) bf_run_pair_v1(X, BATCH, rd); else
+#endif
+		if (paired) bf_run_pair(X, BATCH, rd); else bf_run_read(X, BATCH, rd);
 		if (X.status & BT_STF_OVERFLOW) {
 			X.c_lfex = before.c_lfex; X.c_lf2 = before.c_lf2; X.c_lf1 = before.c_lf1; X.c_chase = before.c_chase;
 			X.c_ftab = before.c_ftab; X.c_offs = before.c_offs; X.c_rst = before.c_rst; X.c_same = before.c_same;

@@ -491,7 +491,7 @@ static int compile_best(const bt_policy& pol, bool paired, BfProgram* prog)
 		P.pairTries = (uint32_t)pol.pair_tries; P.allowContain = pol.allow_contain ? 1u : 0u;
 		/* without --best the same drivers are driven by PairedBWAlignerV1, each (mate, strand) block behind a
 		 * cost-aware driver of its own ("if(v1_)" in the factories); symCeiling is -m (ebwt_search.cpp:1275) */
-		P.pairedV1 = pol.pe_v1 ? 1u : 0u; P.symCeil = pol.mhits;
+		if (pol.pe_v1) P.paired = 2;
 		/* Exact/OneMM/TwoMM/ThreeMMRefAligner for -v, Seed{0..3}RefAligner(seedLen, qualCutoff) for -n
 		 * (aligner_0mm.h:303, aligner_1mm.h:417, aligner_23mm.h:608-612, aligner_seed_mm.h:668-676) */
 		P.refSeeded = pol.mode == BT_MODE_N ? 1u : 0u; P.refMms = (uint32_t)pol.mms;

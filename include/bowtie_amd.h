@@ -81,7 +81,8 @@ typedef struct bt_policy {
 	                          aligner when --best is NOT given (ebwt_search.cpp:232, 776); 0 = PairedBWAlignerV2
 	                          (--best).  Either way the stateful engine runs (best is taken as set) and max_bts
 	                          defaults to 800 (ebwt_search.cpp:186, 2644, 2670).  NOT YET RUN ON A GPU: verified
-	                          against the reference only through the host emulator   */
+	                          against the reference only through the host emulator, and compiled into the kernel
+	                          only with `make PE_V1=1` -- otherwise bt_ctx_create returns BT_ERR_ARG */
 	int32_t  reserved[1];
 } bt_policy;
 

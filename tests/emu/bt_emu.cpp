@@ -213,7 +213,7 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
-	for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (P.pairedV1) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
+	for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;

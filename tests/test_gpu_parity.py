@@ -482,7 +482,8 @@ def test_gpu_paired_matches_reference_sam(run, gidx):
 
 
 @pytest.mark.skipif(os.environ.get("BT_RUN_UNVERIFIED") != "1",
-                    reason="bf_run_pair_v1 has only been verified in the host emulator so far (DESIGN.md 4.2); BT_RUN_UNVERIFIED=1 runs it")
+                    reason="bf_run_pair_v1 has only been verified in the host emulator so far (DESIGN.md 4.2): build with "
+                           "`make -C bowtie_amd/csrc PE_V1=1` and set BT_RUN_UNVERIFIED=1")
 @pytest.mark.parametrize("run", T.paired_v1_runs(), ids=lambda r: r["file"][6:-7])
 def test_gpu_paired_without_best_matches_reference_sam(run, gidx):
     """Paired-end without --best (PairedBWAlignerV1) on the GPU against the reference's outputs."""
