@@ -104,8 +104,12 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		 * as ever, and the read goes back into LDS from its own batch's arrays */
 		const BtPoolRec* r = A.pool + g;
 		if (BT_GP(const uint32_t, r->w)[60] == A.launchSeq - 1u) {
+			/* word by word into the lane state: a 16-byte-piece copy makes the compiler keep BtLane as twelve
+			 * 4-word vectors for the whole round loop, a different (and larger) kernel than the plain build */
+			uint32_t lw[48];
 			BT_UNROLL
-			for (int k = 0; k < 12; k++) { const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * k); __builtin_memcpy((char*)&L + 16 * k, &v, 16); }
+			for (int k = 0; k < 12; k++) { const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * k); lw[4 * k] = v.x; lw[4 * k + 1] = v.y; lw[4 * k + 2] = v.z; lw[4 * k + 3] = v.w; }
+			__builtin_memcpy(&L, lw, sizeof(L));
 			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 13); req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
 			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 14); req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
 			L.tosValid = 0; L.ccValid = 0;
@@ -240,8 +244,10 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	}
 	if (EXT && parkNow && L.state != ST_IDLE) {
 		BtPoolRec* r = A.pool + (blockIdx.x * BT_BLOCK + threadIdx.x);
+		uint32_t lw[48];
+		__builtin_memcpy(lw, &L, sizeof(L));
 		BT_UNROLL
-		for (int k = 0; k < 12; k++) { BtU4 v; __builtin_memcpy(&v, (const char*)&L + 16 * k, 16); bt_st4((uint8_t*)r->w + 16 * k, v); }
+		for (int k = 0; k < 12; k++) { BtU4 v; v.x = lw[4 * k]; v.y = lw[4 * k + 1]; v.z = lw[4 * k + 2]; v.w = lw[4 * k + 3]; bt_st4((uint8_t*)r->w + 16 * k, v); }
 		{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 13, v); }
 		{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); bt_st4((uint8_t*)r->w + 16 * 14, v); }
 		{ BtU4 v; v.x = A.launchSeq; v.y = 0; v.z = 0; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 15, v); }

@@ -11,6 +11,14 @@
 #include <string.h>
 #include <vector>
 #include "../../bowtie_amd/csrc/bt_host.h"
+/* EMU_MSAN (tests/emu/emu_msan.cpp, clang -fsanitize=memory): everything the kernel leaves undefined -- LDS, the
+ * scratch arenas, the parts of a round's result nothing wrote -- is poisoned, so a read of it is reported */
+#ifdef EMU_MSAN
+#include <sanitizer/msan_interface.h>
+#define EMU_POISON(p, n) __msan_poison((p), (n))
+#else
+#define EMU_POISON(p, n) ((void)0)
+#endif
 
 struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
 
@@ -89,6 +97,9 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	BtArena arena;
 	arena.frames = (uint32_t*)frames4.data(); arena.pairs = (uint32_t*)pairs4.data(); arena.meta = meta.data(); arena.pals = pals.data();
 	arena.frCap = frCap; arena.entCap = entCap; arena.palCap = palCap; arena.pad = 0;
+	EMU_POISON(frames4.data(), frames4.size() * sizeof(BtU4)); EMU_POISON(pairs4.data(), pairs4.size() * sizeof(BtU4));
+	EMU_POISON(meta.data(), meta.size() * 2); EMU_POISON(pals.data(), pals.size() * 8);
+	EMU_POISON(tos.data(), tos.size() * 4); EMU_POISON(rlbuf.data(), rlbuf.size() * 4);
 	for (uint32_t g = 0; g < nLanes; g++) {
 		memset(&lanes[g], 0, sizeof(BtLane));
 		memset(&res[g], 0, sizeof(BtRes));
@@ -126,6 +137,8 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 				if (req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u) BT_COUNT(CN_SAMEPAIR);
 				const BtIndexDev& ix = e->d[L.mirror];
 				uint32_t lf[4], la, dummy;
+				EMU_POISON(&res[g].q[1], 16); EMU_POISON(&res[g].q[2], 16);     /* what the kernel's rank branch leaves unset */
+				memset(&res[g].q[3], 0, 16); memset(&res[g].x, 0, 16);
 				bt_rank4(ix, (uint32_t)req.a, lf, &la);
 				res[g].q[0].x = lf[0]; res[g].q[0].y = lf[1]; res[g].q[0].z = lf[2]; res[g].q[0].w = lf[3];
 				res[g].q[2].x = la;
@@ -138,6 +151,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 					res[g].q[1].x = lf[0]; res[g].q[1].y = lf[1]; res[g].q[1].z = lf[2]; res[g].q[1].w = lf[3];
 				}
 			} else {
+				memset(&res[g], 0, sizeof(BtRes));
 				for (uint32_t k = 0; k < req.n; k++) memcpy(&res[g].q[k], (const uint8_t*)(uintptr_t)req.a + 16 * k, 16);
 				if (req.x) memcpy(&res[g].x, (const void*)(uintptr_t)req.x, 16);
 			}
