@@ -2,6 +2,8 @@
 per lane) against the oracle, where no GPU exists.  The automaton is driven exactly like the
 kernel drives it: lock-step lanes, LF requests answered between steps, lanes refilled from a
 cursor.  This checks the *logic*; GPU parity proper is tests/test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -241,3 +243,48 @@ def test_emu_paired_vs_oracle_counts(mode, emu):
     T.compare_results(got, want, mode)
     for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
         assert getattr(oc, f) == getattr(ec, f), f
+
+
+# ---- the automaton under MemorySanitizer ------------------------------------------------------
+MSAN_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _msan_available():
+    import glob
+    return os.path.exists(MSAN_CLANG) and bool(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.msan-x86_64.a"))
+
+
+@pytest.mark.skipif(not _msan_available(), reason="needs clang with the MemorySanitizer runtime")
+def test_automaton_reads_nothing_uninitialised_on_the_dollar_row_inputs(tmp_path):
+    """tests/emu/emu_msan.cpp: the automaton with LDS, the scratch arenas and the unwritten words of a round's result
+    poisoned, on the two simple_tests inputs that extend a one-row range at the '$' row, in all three
+    builds of the automaton.  Reports from the loader's std::string (uninstrumented libstdc++) are not the automaton's."""
+    import subprocess
+    from bowtie_amd import ebwt_build as EB
+    lut = np.full(256, 4, np.uint8)
+    for i, ch in enumerate("ACGT"):
+        lut[ord(ch)] = i
+    enc = lambda s: lut[np.frombuffer(s.encode(), dtype=np.uint8)]
+    EB.build_index([enc("ACGTTCGT")], ["r"], str(tmp_path / "c100"))
+    EB.build_index([enc("AGCATCGATCAG")], ["seq1"], str(tmp_path / "c5"))
+    exe = str(tmp_path / "emu_msan")
+    subprocess.check_call([MSAN_CLANG, "-fsanitize=memory", "-fsanitize-recover=memory", "-fno-omit-frame-pointer", "-g", "-O1",
+                           "-std=c++17", "-w", "-o", exe, os.path.join(T.ROOT, "tests", "emu", "emu_msan.cpp"),
+                           os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_host.cpp")])
+    env = dict(os.environ, MSAN_OPTIONS="halt_on_error=0:exitcode=0")
+    runs = [("c100", ["v", "0", "1", "1"], ["GTTC"], ["read 0: 1 hits status 0"]),
+            ("c100", ["n", "0", "1", "1"], ["GTTC"], ["read 0: 1 hits status 0"]),
+            ("c5", ["n", "2", "1", "1"], ["AGCATCGATC", "GCATCGATCA", "CATCGATCAG"],
+             ["read 0: 1 hits status 0", "read 1: 1 hits status 0", "read 2: 1 hits status 0"])]
+    for idx, pol, reads, want in runs:
+        for rl_mode in ("2", "0", "1"):
+            p = subprocess.run([exe, str(tmp_path / idx)] + pol + ["64", rl_mode] + reads, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            err = p.stderr.decode(errors="replace")
+            frames0 = [l for l in err.splitlines() if l.lstrip().startswith("#0 ")]
+            mine = [l for l in frames0 if "File::File" not in l and "operator new" not in l]
+            assert not mine, "\n".join(mine[:5])
+            out = p.stdout.decode()
+            assert "rc 0" in out
+            for w in want:
+                assert w in out, out
