@@ -15,7 +15,14 @@
 #include "bt_best.h"
 #include "bt_kernels.h"
 
-__global__ __launch_bounds__(BT_BLOCK) void bt_best_kernel(BtBestArgs A)
+/* -DBT_BEST_MIN_BLOCKS=2: ask the register allocator for two blocks per CU (the default build takes all 512 registers
+ * of a SIMD lane for one wave); which is faster is a measurement (scripts/r3_gpu_first.sh) */
+#ifdef BT_BEST_MIN_BLOCKS
+#define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
+#else
+#define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK)
+#endif
+__global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 {
 	__shared__ BfProgram PROG;
 	__shared__ BtIndexDev IX[2];
