@@ -263,8 +263,8 @@ def main():
     ap.add_argument("--carry", type=int, default=0,
                     help="bt_ctx_set_carry: launches a read may ride along with the steps after its own.  Default 0: every "
                          "step runs to its last read before the next starts.  Opt-in: it more than doubles the rate of "
-                         "16 M-read steps (profiles/README.md) but faults on two tiny inputs of the simple_tests suite "
-                         "(DESIGN.md 4.3), and gains nothing at 200 M reads per step.")
+                         "16 M-read steps (profiles/README.md), gains nothing at 200 M reads per step, and launches kernel "
+                         "instances the whole GPU suite has not yet run through since their fix (DESIGN.md 4.4).")
     ap.add_argument("--no-carry", action="store_true", help="same as --carry 0")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", dest="verify", action="store_false",

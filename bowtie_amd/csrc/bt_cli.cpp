@@ -126,9 +126,9 @@ void usage(FILE* o)
 	    "  --device <list>    GPU(s) to run on, e.g. 0,1,2,3: index replicated, batches dealt out (default: 0)\n"
 	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
-	    "  --stream           (experimental) stream unpaired batches through one context per GPU with\n"
+	    "  --stream           (opt-in) stream unpaired batches through one context per GPU with\n"
 	    "                     carry-over between batches instead of searching --inflight whole batches\n"
-	    "                     side by side; faults on some -a runs, see DESIGN.md\n"
+	    "                     side by side\n"
 	    "  --no-stream        the default\n"
 	    "Other:\n"
 	    "  --seed <int>       seed for random number generator\n"
@@ -688,7 +688,7 @@ int main(int argc, char** argv)
 	BtRefNames refs;
 	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
 	/* `--inflight` whole batches are searched side by side, each on its own context and stream.  --stream
-	 * (experimental: unpaired, phase-program engine) instead keeps one context per GPU fed through
+	 * (opt-in: unpaired, phase-program engine) instead keeps one context per GPU fed through
 	 * bt_align_stream_* with the reads a batch leaves running carried into the next ones (bt_ctx_set_carry). */
 	const bool streamed = !O.paired && !O.pol.best && O.stream && !O.no_stream;
 	std::vector<bt_ctx*> ctxs((size_t)(streamed ? 1 : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */

@@ -244,9 +244,9 @@ int  bt_ctx_sync(bt_ctx* ctx);
  * the stream work of the n-th bt_align_batch_device call after its own is, or after bt_ctx_sync (which finishes
  * whatever is parked); the batch's input and output arrays must stay valid until then.  Reads <= 112 bases,
  * unpaired, phase-program engine; other batches are simply run to completion as before.
- * EXPERIMENTAL: carry-over launches another template instance of the search kernel, and that instance has an open
- * defect -- a GPU memory fault on two tiny inputs of the reference's simple_tests suite that the default instance
- * searches correctly.  Measured gain: 8.44 M against 4.3 M reads/s at 16 M reads per batch. */
+ * OPT-IN: carry-over launches other template instances of the search kernel; they faulted on two tiny inputs of the
+ * reference's simple_tests suite until a late fix that the whole GPU suite has not yet run through.
+ * Measured gain: 8.44 M against 4.3 M reads/s at 16 M reads per batch. */
 int  bt_ctx_set_carry(bt_ctx* ctx, int launches);
 /* bt_align_batch_device sees the read lengths in HBM only; which build of the kernel a batch can use (reads kept
  * in LDS up to 104 / 112 bases, ebwt_search_backtrack.h:90-140's query accessors) then has to be settled on the

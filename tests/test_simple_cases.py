@@ -124,19 +124,29 @@ def test_paired_without_best_is_refused(simple_index):
     assert p.returncode == 1 and b"add --best" in p.stderr
 
 
-KNOWN_FAULT = [(c, r) for c, r in all_runs() if c["id"] in (5, 100)]
+DOLLAR_ROW = [(c, r) for c, r in all_runs() if c["id"] in (5, 100)]
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("BT_RUN_KNOWN_FAULT") != "1",
-                    reason="open defect (DESIGN.md 4.4): faults the GPU on purpose; set BT_RUN_KNOWN_FAULT=1 to run")
-@pytest.mark.parametrize("case,run", KNOWN_FAULT, ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+@pytest.mark.parametrize("case,run", DOLLAR_ROW, ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
 def test_ext_kernel_instances_on_the_two_tiny_inputs(case, run, simple_index, monkeypatch):
-    """Regression test for the open defect: the EXT=true instances of bt_search_kernel (carry-over, on-stream second
-    pass) fault on these two inputs; BT_FORCE_EXT=1 makes the plain path launch them.  Expected to pass once fixed."""
+    """Regression test: the EXT=true instances of bt_search_kernel (carry-over, on-stream second pass)
+    used to fault on these two inputs -- the ones that extend a one-row range at the '$' row with the base the '$' is
+    stored as.  BT_FORCE_EXT=1 makes the plain path launch the EXT instances."""
     monkeypatch.setenv("BT_FORCE_EXT", "1")
     base = simple_index(case["ref"])
     cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + run["args"] + ["-x", base] + case["reads"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=120)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-300:]
+    assert p.stdout == expected(run)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,run", DOLLAR_ROW, ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+def test_streamed_binary_on_the_two_tiny_inputs(case, run, simple_index):
+    """The same two inputs through `bowtie-amd --stream` (carry-over: park, adopt, closing launch)."""
+    base = simple_index(case["ref"])
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1", "--stream"] + run["args"] + ["-x", base] + case["reads"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=120)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-300:]
     assert p.stdout == expected(run)
