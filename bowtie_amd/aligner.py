@@ -23,7 +23,7 @@ EXPORTS = ["bt_policy_default", "bt_index_load", "bt_index_info_get", "bt_index_
            "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_index_digest", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
            "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_align_stream_submit", "bt_align_stream_collect", "bt_ctx_sync", "bt_ctx_set_carry", "bt_ctx_set_max_read_len", "bt_ctx_span_ms", "bt_ctx_launch_ms", "bt_ctx_last_carried", "bt_ctx_last_kernel_ms", "bt_ctx_last_kernel_name", "bt_ctx_last_mm_used", "bt_ctx_last_retried",
            "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase", "bt_bench_gather",
-           "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_error", "bt_reads_close", "bt_format_hits", "bt_format_pairs",
+           "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_paired_count", "bt_reads_error", "bt_reads_close", "bt_format_hits", "bt_format_pairs",
            "bt_format_sam_header", "bt_format_summary", "bt_text_free"]
 _lib = None
 
@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.bt_reads_next.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(A.ReadBatchC),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.bt_reads_raw.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.bt_reads_paired_count.argtypes = [C.c_void_p]
+        L.bt_reads_paired_count.restype = C.c_uint32
         L.bt_reads_error.argtypes = [C.c_void_p]
         L.bt_reads_error.restype = C.c_char_p
         L.bt_reads_close.argtypes = [C.c_void_p]

@@ -47,6 +47,9 @@ struct Options {
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false, paired = false;
 	std::string mates1, mates2;
+	std::string tab12, ileaved;              /* --12 / --interleaved file lists */
+	std::string quals, quals1, quals2;       /* -Q / --Q1 / --Q2 */
+	bool interleaved = false;
 	bool suppress_set = false, int_quals = false;
 	uint32_t batch_reads = 4u << 20;
 	std::string cmdline;
@@ -76,6 +79,9 @@ void usage(FILE* o)
 	    "  -F <len>,<int>     query input files are FASTA whose reads are the <len>-mers at every\n"
 	    "                     <int>-th position of each record\n"
 	    "  -r                 query input files are raw one-sequence-per-line\n"
+	    "  --12 <files>       tab-delimited reads, one per line: name, seq, quals -- or, for a pair, name,\n"
+	    "                     seq1, quals1, seq2, quals2 (a file holds one kind); needs --best\n"
+	    "  --interleaved <files>  FASTQ in which first and second mates alternate; needs --best\n"
 	    "  -c                 query sequences given on cmd line (as <s>)\n"
 	    "  -s/--skip <int>    skip the first <int> reads in the input\n"
 	    "  -u/--qupto <int>   stop after first <int> reads (excl. skipped reads)\n"
@@ -158,7 +164,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_STREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_STREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_TAB12, O_ILEAVED, O_QUALS1, O_QUALS2, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -178,8 +184,8 @@ const LongOpt LONGS[] = {
 	/* the best-first engine and everything that needs it */
 	{"best", 0, O_BEST}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_STRATA},
 	{"minins", 1, 'I'}, {"maxins", 1, 'X'}, {"ff", 0, O_FF}, {"fr", 0, O_FR},
-	{"rf", 0, O_RF}, {"12", 1, O_UNSUPPORTED_ARG}, {"interleaved", 1, O_UNSUPPORTED_ARG}, {"pairtries", 1, O_PAIRTRIES},
-	{"integer-quals", 0, O_INTQUALS}, {"quals", 1, O_UNSUPPORTED_ARG}, {"Q1", 1, O_UNSUPPORTED_ARG}, {"Q2", 1, O_UNSUPPORTED_ARG},
+	{"rf", 0, O_RF}, {"12", 1, O_TAB12}, {"interleaved", 1, O_ILEAVED}, {"pairtries", 1, O_PAIRTRIES},
+	{"integer-quals", 0, O_INTQUALS}, {"quals", 1, 'Q'}, {"Q1", 1, O_QUALS1}, {"Q2", 1, O_QUALS2},
 	{"al", 1, O_AL}, {"un", 1, O_UN}, {"max", 1, O_MAX}, {"phased", 0, O_UNSUPPORTED},
 	{"strandfix", 0, O_IGNORED}, {"pev2", 0, O_UNSUPPORTED}, {"reportse", 0, O_UNSUPPORTED}, {"hadoopout", 0, O_UNSUPPORTED},
 	{"partition", 1, O_UNSUPPORTED_ARG}, {"range", 0, O_UNSUPPORTED}, {"isarate", 1, O_UNSUPPORTED_ARG}, {"allow-contain", 0, O_ALLOW_CONTAIN},
@@ -187,9 +193,59 @@ const LongOpt LONGS[] = {
 	{nullptr, 0, 0}
 };
 /* short options taking an argument */
-const char* SHORT_ARG = "us35oenlpkmMBxvF12IX";
-const char* SHORT_UNSUPPORTED_ARG = "Qw";
+const char* SHORT_ARG = "us35oenlpkmMBxvF12IXQ";
+const char* SHORT_UNSUPPORTED_ARG = "w";
 const char* SHORT_UNSUPPORTED = "bz";
+
+/* --12: does the file's first record carry a second end?  (The reference decides per record and aligns pairs and
+ * single reads side by side, pat.h:990-995; here a file is one or the other, checked batch by batch.) */
+std::vector<std::string> split_commas(const std::string& s)
+{
+	std::vector<std::string> v;
+	size_t b = 0;
+	while (b <= s.size()) {
+		const size_t e = s.find(',', b);
+		const std::string t = s.substr(b, e == std::string::npos ? std::string::npos : e - b);
+		if (!t.empty()) v.push_back(t);
+		if (e == std::string::npos) break;
+		b = e + 1;
+	}
+	return v;
+}
+
+/* the i-th quality file goes with the i-th read file (CFilePatternSource::open, pat.cpp:333-347) */
+void drop_reads_without_quals(std::string* reads, const std::string& quals)
+{
+	if (quals.empty() || reads->empty()) return;
+	const std::vector<std::string> r = split_commas(*reads), q = split_commas(quals);
+	std::string kept;
+	for (size_t i = 0; i < r.size(); i++) {
+		bool ok = true;
+		if (i < q.size() && q[i] != "-") {
+			FILE* f = fopen(q[i].c_str(), "rb");
+			if (f) fclose(f);
+			else { fprintf(stderr, "Warning: Could not open quality file \"%s\" for reading; skipping...\n", q[i].c_str()); ok = false; }
+		}
+		/* a read file that is left out keeps its place in the list, marked (bt_io.cpp: st_open_next): the run then ends
+		 * the way the reference's does when the files left cannot be read */
+		if (!kept.empty()) kept.push_back(',');
+		kept.append(ok ? r[i] : std::string("\x01") + r[i]);
+	}
+	*reads = kept;
+}
+
+bool tabbed_is_paired(const std::string& files, bt_read_opts rd)
+{
+	rd.flags &= ~(uint32_t)(BT_READ_MATE1 | BT_READ_MATE2);
+	rd.skip = 0; rd.upto = 0;
+	std::string err;
+	BtReadStream* s = bt_io_open(files.c_str(), rd, &err);
+	BtHostBatch b;
+	const int rc = bt_io_next(s, 1, 1, &b, &err);
+	const bool paired = rc == BT_OK && b.n > 0 && b.n_paired > 0;
+	bt_io_close(s);
+	return paired;
+}
 
 void parse_args(int argc, char** argv, Options* O)
 {
@@ -270,6 +326,11 @@ void parse_args(int argc, char** argv, Options* O)
 		case 'm': O->pol.mhits = (uint32_t)parse_int(val, 1, "-m arg must be at least 1"); break;
 		case '1': if (!O->mates1.empty()) O->mates1.push_back(','); O->mates1.append(val); break;
 		case '2': if (!O->mates2.empty()) O->mates2.push_back(','); O->mates2.append(val); break;
+		case 'Q': if (!O->quals.empty()) O->quals.push_back(','); O->quals.append(val); break;
+		case O_QUALS1: if (!O->quals1.empty()) O->quals1.push_back(','); O->quals1.append(val); break;
+		case O_QUALS2: if (!O->quals2.empty()) O->quals2.push_back(','); O->quals2.append(val); break;
+		case O_TAB12: if (!O->tab12.empty()) O->tab12.push_back(','); O->tab12.append(val); O->rd.format = BT_FMT_TABBED; break;
+		case O_ILEAVED: if (!O->ileaved.empty()) O->ileaved.push_back(','); O->ileaved.append(val); O->rd.format = BT_FMT_FASTQ; break;
 		case 'I': O->pol.min_ins = (int32_t)parse_int(val, 0, "-I arg must be positive"); break;
 		case 'X': O->pol.max_ins = (int32_t)parse_int(val, 1, "-X arg must be at least 1"); break;
 		case O_FF: O->pol.mate1_fw = 1; O->pol.mate2_fw = 1; break;
@@ -387,6 +448,16 @@ void parse_args(int argc, char** argv, Options* O)
 		if (pi >= pos.size()) { fprintf(stderr, "No index, query, or output file specified!\n"); usage(stderr); exit(1); }
 		O->index = pos[pi++];
 	}
+	const bool one_file = !O->tab12.empty() || !O->ileaved.empty();
+	if (one_file) {
+		/* --12 / --interleaved (ebwt_search.cpp:626-627): one file carries both mates.  Whether its records are pairs
+		 * or not, the reference then runs its stateful aligners (:3001-3002) */
+		if (!O->mates1.empty() || !O->mates2.empty() || (!O->tab12.empty() && !O->ileaved.empty()))
+			die("Error: --12 / --interleaved cannot be combined with -1/-2 or with each other in this build");
+		if (!O->pol.best) die("Error: --12 / --interleaved input runs the reference's stateful aligners, which this build has for --best only; add --best");
+		if (!O->ileaved.empty()) { O->mates1 = O->mates2 = O->ileaved; O->interleaved = true; }
+		else if (tabbed_is_paired(O->tab12, O->rd)) O->mates1 = O->mates2 = O->tab12;
+	}
 	O->paired = !O->mates1.empty() || !O->mates2.empty();
 	if (O->paired) {
 		/* ebwt_search.cpp:855-860 */
@@ -397,9 +468,20 @@ void parse_args(int argc, char** argv, Options* O)
 		if (!O->pol.best) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
 		if (O->pol.sample_max) die("Error: -M with paired-end reads is not in this build");
 		if (!O->dump_al.empty() || !O->dump_un.empty() || !O->dump_max.empty()) die("Error: --al/--un/--max with paired-end reads are not in this build");
+	} else if (one_file) {
+		O->reads = O->tab12;
 	} else {
 	if (pi >= pos.size()) { fprintf(stderr, "No query or output file specified!\n"); usage(stderr); exit(1); }
 	O->reads = pos[pi++];
+	}
+	if (!O->quals.empty() || !O->quals1.empty() || !O->quals2.empty()) {
+		/* -Q / --Q1 / --Q2: the reference hands the quality files to its FASTA reader only (ebwt_search.cpp:2925-2927),
+		 * which opens each next to its read file and never reads from it (pat.cpp:333-347): a quality file that cannot
+		 * be opened takes its read file out of the run, nothing else happens */
+		if (O->rd.format != BT_FMT_FASTA) die("Error: -Q/--Q1/--Q2 go with -f; with other formats the reference reads qualities as integers, which this build does with --integer-quals");
+		drop_reads_without_quals(&O->reads, O->quals);
+		drop_reads_without_quals(&O->mates1, O->quals1);
+		drop_reads_without_quals(&O->mates2, O->quals2);
 	}
 	if (pi < pos.size()) O->hits_file = pos[pi++];
 	if (pi < pos.size()) { fprintf(stderr, "Extra parameter(s) specified: "); for (; pi < pos.size(); pi++) fprintf(stderr, "\"%s\"%s", pos[pi].c_str(), pi + 1 < pos.size() ? ", " : "\n"); exit(1); }
@@ -648,10 +730,55 @@ std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc, bool st
 
 }  // namespace
 
+const char* const mixed_msg = "Error: the --12 input mixes paired and unpaired records; this build takes them from separate files";
+
+/* the read stream(s) of the run: one for unpaired input, one per mate for pairs (for --12 / --interleaved both over
+ * the same file, each keeping its mate) */
+void open_read_streams(Options& O, BtReadStream** rs, BtReadStream** rs2)
+{
+	std::string open_err;
+	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
+	if (dumping) O.rd.flags |= BT_READ_KEEP_RAW;
+	bt_read_opts rd1 = O.rd, rd2 = O.rd;
+	rd1.flags |= BT_READ_MATE1; rd2.flags |= BT_READ_MATE2;
+	if (O.interleaved) { rd1.flags |= BT_READ_INTERLEAVED; rd2.flags |= BT_READ_INTERLEAVED; }
+	*rs = bt_io_open(O.paired ? O.mates1.c_str() : O.reads.c_str(), O.paired ? rd1 : O.rd, &open_err);
+	*rs2 = O.paired ? bt_io_open(O.mates2.c_str(), rd2, &open_err) : nullptr;
+}
+
+/* BT_CLI_INPUT_ONLY=1 (tests, no GPU needed): parse the input the way the run would and list it -- one line per read,
+ * "<name>\t<length>" (pairs: both mates on the line) -- without loading an index */
+int list_input(Options& O)
+{
+	BtReadStream* rs = nullptr; BtReadStream* rs2 = nullptr;
+	open_read_streams(O, &rs, &rs2);
+	const bool tabbed = O.rd.format == BT_FMT_TABBED;
+	BtHostBatch b1, b2;
+	std::string err;
+	for (;;) {
+		int r = bt_io_next(rs, O.batch_reads, O.threads, &b1, &err);
+		if (r == BT_OK && tabbed && b1.n_paired != (O.paired ? b1.n : 0u)) { err = mixed_msg; r = BT_ERR_READS; }
+		if (r == BT_OK && O.paired) {
+			r = bt_io_next(rs2, O.batch_reads, O.threads, &b2, &err);
+			if (r == BT_OK && b2.n != b1.n) { err = "mate streams differ in length"; r = BT_ERR_READS; }
+		}
+		if (r != BT_OK) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+		if (b1.n == 0) break;
+		for (uint32_t i = 0; i < b1.n; i++) {
+			printf("%.*s\t%u", (int)(b1.name_off[i + 1] - b1.name_off[i]), b1.names.data() + b1.name_off[i], (unsigned)b1.len[i]);
+			if (O.paired) printf("\t%.*s\t%u", (int)(b2.name_off[i + 1] - b2.name_off[i]), b2.names.data() + b2.name_off[i], (unsigned)b2.len[i]);
+			printf("\n");
+		}
+	}
+	bt_io_close(rs); if (rs2) bt_io_close(rs2);
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
 	Options O;
 	parse_args(argc, argv, &O);
+	if (getenv("BT_CLI_INPUT_ONLY")) return list_input(O);
 	const double t_all = now_s();
 
 	/* ---- index into HBM ---- */
@@ -718,13 +845,10 @@ int main(int argc, char** argv)
 	}
 
 	/* ---- stage 1: reader ---- */
-	std::string open_err;
+	BtReadStream* rs = nullptr; BtReadStream* rs2 = nullptr;
+	open_read_streams(O, &rs, &rs2);
+	const bool tabbed = O.rd.format == BT_FMT_TABBED;
 	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
-	if (dumping) O.rd.flags |= BT_READ_KEEP_RAW;
-	bt_read_opts rd1 = O.rd, rd2 = O.rd;
-	rd1.flags |= BT_READ_MATE1; rd2.flags |= BT_READ_MATE2;
-	BtReadStream* rs = bt_io_open(O.paired ? O.mates1.c_str() : O.reads.c_str(), O.paired ? rd1 : O.rd, &open_err);
-	BtReadStream* rs2 = O.paired ? bt_io_open(O.mates2.c_str(), rd2, &open_err) : nullptr;
 	const int G = (int)ctxs.size();
 	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
 	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
@@ -745,6 +869,7 @@ int main(int argc, char** argv)
 			else r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
 			busy_read += now_s() - tb;
 			if (r != BT_OK) j->error = err;
+			else if (tabbed && j->store->n_paired != (O.paired ? j->store->n : 0u)) { j->error = mixed_msg; r = BT_ERR_READS; }
 			j->rb = j->store->view();
 			if (O.paired && r == BT_OK) {
 				j->store2.reset(new BtHostBatch());

@@ -60,6 +60,8 @@ struct BtReadStream {
 	uint64_t rdid = 0;                    /* next read id (counts skipped reads too)             */
 	uint64_t limit = ~0ull;               /* first read id that is not processed                 */
 	bool done = false;
+	bool open_failed = false;             /* the files left could not be opened: the run fails (CFilePatternSource::open
+	                                         throws, pat.cpp:296-357) once the reads before them are out            */
 	std::string raw;                      /* the batch's record texts                            */
 	/* -F: the sliding window over the FASTA text (FastaContinuousPatternSource's members) */
 	size_t c_eat = 0, c_bufcur = 0; bool c_begin = true; uint64_t c_cur = 0, c_last = 0;
@@ -97,13 +99,19 @@ static bool st_open_next(BtReadStream* s, std::string* err, bool keep_window = f
 	if (s->f) { gzclose(s->f); s->f = nullptr; }
 	if (s->item >= s->items.size()) return false;
 	const std::string& fn = s->items[s->item++];
-	s->f = (fn == "-") ? gzdopen(0, "rb") : gzopen(fn.c_str(), "rb");
+	/* a name starting with \x01: a file the caller has already taken out of the run and said so (bowtie-amd: its -Q
+	 * partner could not be opened) -- it counts as one that does not open, silently */
+	const bool taken_out = !fn.empty() && fn[0] == '\x01';
+	s->f = taken_out ? nullptr : (fn == "-") ? gzdopen(0, "rb") : gzopen(fn.c_str(), "rb");
 	if (!s->f) {
-		/* the reference warns and moves on to the next file (pat.cpp:301-305); with none left the
-		 * run simply has no reads */
-		*err = "Warning: Could not open read file \"" + fn + "\" for reading; skipping...";
-		fprintf(stderr, "%s\n", err->c_str());
-		err->clear();
+		/* the reference warns and moves on to the next file (pat.cpp:301-319); if none of the files left opens, the
+		 * run fails (:357) */
+		if (!taken_out) {
+			*err = "Warning: Could not open read file \"" + fn + "\" for reading; skipping...";
+			fprintf(stderr, "%s\n", err->c_str());
+			err->clear();
+		}
+		if (s->item >= s->items.size()) { s->open_failed = true; return false; }
 		return st_open_next(s, err, keep_window);
 	}
 	gzbuffer(s->f, 1u << 20);
@@ -280,6 +288,7 @@ struct BtParsed {
 	std::string seq, qual;      /* codes 0..4, Phred+33 */
 	size_t name_b = 0, name_n = 0;   /* name = rec[name_b, name_b + name_n), or the read id when empty */
 	bool ok = true;             /* false: the record ended prematurely -- the reference skips it */
+	bool paired = false;        /* --12: the record had a second end */
 };
 
 static const uint8_t* asc2dna_table()
@@ -466,6 +475,60 @@ static bool parse_raw(const char* r, size_t n, const bt_read_opts& o, BtParsed* 
 	return true;
 }
 
+/* --12 (TabbedPatternSource::parse, pat.cpp:1017-1127): "name<TAB>seq<TAB>quals", optionally followed by
+ * "<TAB>seq2<TAB>quals2" -- the second end of a pair, under the same name.  A line that stops before the
+ * qualities of an end is dropped whole.  Sequence characters that are no letters are skipped; the number of
+ * qualities is compared with the number of bases before either is trimmed.  Both ends are parsed (their errors
+ * are the record's); the one the stream was opened for is kept. */
+static bool parse_tabbed(const char* r, size_t n, const bt_read_opts& o, uint64_t rdid, BtParsed* p, std::string* err)
+{
+	const uint8_t* a2d = asc2dna_table();
+	const bool want2 = (o.flags & BT_READ_MATE2) != 0;
+	size_t cur = 0;
+	int c = (unsigned char)r[cur++];
+	p->name_b = 0; p->name_n = 0;
+	while (c != '\t' && cur < n) { p->name_n++; c = (unsigned char)r[cur++]; }
+	if (cur >= n) { p->ok = false; return true; }
+	for (int e = 0; e < 2 && c == '\t'; e++) {
+		std::string seq, qual;
+		int nchar = 0, nqual = 0;
+		c = (unsigned char)r[cur++];
+		while (c != '\t' && cur < n) {
+			if (isalpha(c)) { if (nchar++ >= o.trim5) seq.push_back((char)a2d[c]); }
+			c = (unsigned char)r[cur++];
+		}
+		if (cur >= n) { p->seq.clear(); p->qual.clear(); p->ok = false; return true; }
+		trim_end(seq, (size_t)o.trim3);
+		c = (unsigned char)r[cur++];
+		while (c != '\t' && c != '\n' && c != '\r') {
+			if (c == ' ') {
+				*err = "Encountered a space parsing the quality string for read " + name_of(r, *p, rdid) + "\n"
+				       "If this is a FASTQ file with integer (non-ASCII-encoded) qualities, please\n"
+				       "re-run Bowtie with the --integer-quals option.";
+				return false;
+			}
+			char q;
+			if (!qual_to_phred33(c, o.qual_enc, &q, err)) return false;
+			if (++nqual > o.trim5) qual.push_back(q);
+			if (cur >= n) break;
+			c = (unsigned char)r[cur++];
+		}
+		if (nchar > nqual) {
+			*err = "Too few quality values for read: " + name_of(r, *p, rdid) + "\n\tare you sure this is a FASTQ-int file?";
+			return false;
+		}
+		if (nqual > nchar) {
+			*err = "Reads file contained a pattern with more than 1024 quality values.\n"
+			       "Please truncate reads and quality values and and re-run Bowtie";
+			return false;
+		}
+		trim_end(qual, (size_t)o.trim3);
+		if (e == 1) p->paired = true;
+		if ((e == 1) == want2) { p->seq.swap(seq); p->qual.swap(qual); }
+	}
+	return true;
+}
+
 static bool parse_fasta_cont(const char* r, size_t n, const bt_read_opts& o, BtParsed* p)
 {
 	const uint8_t* a2d = asc2dna_table();
@@ -623,7 +686,11 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		}
 	}
 	const size_t n = recs.size();
-	if (n == 0) { batch->n = 0; return BT_OK; }
+	if (n == 0) {
+		batch->n = 0;
+		if (s->open_failed) { *err = "Error: could not open the remaining read file(s)"; return BT_ERR_READS; }
+		return BT_OK;
+	}
 	if (maxline > 1040u) maxline = 1040u;
 	const uint32_t stride = (maxline + 15u) & ~15u;
 	batch->reset((uint32_t)n, stride);
@@ -781,8 +848,9 @@ int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* ba
 static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
 {
 	s->raw.clear(); s->recs.clear();
-	batch->n = 0;
-	if (s->o.format == BT_FMT_FASTQ && !(s->o.flags & BT_READ_CAREFUL)) return next_fastq(s, max_reads, threads, batch, err);
+	batch->n = 0; batch->n_paired = 0;
+	if (s->done && s->open_failed) { *err = "Error: could not open the remaining read file(s)"; return BT_ERR_READS; }
+	if (s->o.format == BT_FMT_FASTQ && !(s->o.flags & (BT_READ_CAREFUL | BT_READ_INTERLEAVED))) return next_fastq(s, max_reads, threads, batch, err);
 	/* ---- light parse (sequential) ---- */
 	while (!s->done && s->recs.size() < max_reads) {
 		if (s->rdid >= s->limit) { s->done = true; break; }
@@ -799,7 +867,20 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 		if (!s->f && !st_open_next(s, err)) { s->done = true; break; }
 		const size_t off = s->raw.size();
 		int rc;
-		if (s->o.format == BT_FMT_FASTQ) rc = light_fastq(s, err);
+		if (s->o.format == BT_FMT_FASTQ && (s->o.flags & BT_READ_INTERLEAVED)) {
+			/* two records per read id: the first mate's, then the second mate's (pat.cpp:841-851); this stream
+			 * keeps the one it was opened for.  A last record without a partner is dropped. */
+			rc = light_fastq(s, err);
+			if (rc == 1) {
+				const size_t mid = s->raw.size();
+				const int rc2 = light_fastq(s, err);
+				if (rc2 < 0) return BT_ERR_READS;
+				if (rc2 == 0) { s->raw.resize(off); rc = 0; }
+				else if (s->o.flags & BT_READ_MATE2) s->raw.erase(off, mid - off);
+				else s->raw.resize(mid);
+			}
+		}
+		else if (s->o.format == BT_FMT_FASTQ) rc = light_fastq(s, err);
 		else if (s->o.format == BT_FMT_FASTA) rc = light_fasta(s, err);
 		else if (s->o.format == BT_FMT_FASTA_CONT) rc = light_fasta_cont(s, err);
 		else rc = light_raw(s, err);
@@ -810,7 +891,10 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 		s->rdid++;
 	}
 	const size_t nrec = s->recs.size();
-	if (nrec == 0) return BT_OK;
+	if (nrec == 0) {
+		if (s->open_failed) { *err = "Error: could not open the remaining read file(s)"; return BT_ERR_READS; }
+		return BT_OK;
+	}
 
 	/* ---- per-record parse (parallel) ---- */
 	std::vector<BtParsed> parsed(nrec);
@@ -828,6 +912,7 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 			case BT_FMT_FASTA: ok = parse_fasta(r, rc.len, s->o, &parsed[i]); break;
 			case BT_FMT_RAW: ok = parse_raw(r, rc.len, s->o, &parsed[i]); break;
 			case BT_FMT_FASTA_CONT: ok = parse_fasta_cont(r, rc.len, s->o, &parsed[i]); break;
+			case BT_FMT_TABBED: ok = parse_tabbed(r, rc.len, s->o, rc.rdid, &parsed[i], &errs[(size_t)t]); break;
 			default: ok = parse_cmdline(r, rc.len, s->o, rc.rdid, &parsed[i], &errs[(size_t)t]); break;
 			}
 			if (ok && parsed[i].seq.size() > 1024) {
@@ -860,6 +945,8 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 	const uint32_t n = (uint32_t)keep.size();
 	const uint32_t stride = (uint32_t)((maxlen + 15u) & ~(size_t)15u);
 	batch->reset(n, stride);
+	batch->n_paired = 0;
+	for (uint32_t k = 0; k < n; k++) if (parsed[keep[k]].paired) batch->n_paired++;
 	batch->rdid.resize(n);
 	batch->name_off.assign((size_t)n + 1, 0);
 	batch->names.clear();
@@ -1230,7 +1317,11 @@ struct bt_reads {
 extern "C" int bt_reads_open(const char* spec, const bt_read_opts* opts, bt_reads** out)
 {
 	if (!spec || !opts || !out) return BT_ERR_ARG;
-	if (opts->format < BT_FMT_FASTQ || opts->format > BT_FMT_FASTA_CONT || opts->trim5 < 0 || opts->trim3 < 0) return BT_ERR_ARG;
+	if (opts->format < BT_FMT_FASTQ || opts->format > BT_FMT_TABBED || opts->trim5 < 0 || opts->trim3 < 0) return BT_ERR_ARG;
+	/* the reference's tabbed reader has no usable integer-quality branch (pat.cpp:1079-1092 mangles the values after
+	 * a space); interleaving is a FASTQ notion, one mate per stream */
+	if (opts->format == BT_FMT_TABBED && (opts->qual_enc == BT_QUAL_INT || opts->qual_enc == BT_QUAL_INT_SOLEXA)) return BT_ERR_ARG;
+	if ((opts->flags & BT_READ_INTERLEAVED) && (opts->format != BT_FMT_FASTQ || !(opts->flags & (BT_READ_MATE1 | BT_READ_MATE2)))) return BT_ERR_ARG;
 	if (opts->format == BT_FMT_FASTA_CONT && (opts->cont_len < 1 || opts->cont_len >= 1024 || opts->cont_freq < 1)) return BT_ERR_ARG;
 	bt_reads* r = new bt_reads();
 	r->s = bt_io_open(spec, *opts, &r->err);
@@ -1255,6 +1346,7 @@ extern "C" int bt_reads_raw(const bt_reads* r, const char** raw, const uint64_t*
 	*raw = r->batch.raw.data(); *raw_off = r->batch.raw_off.data();
 	return BT_OK;
 }
+extern "C" uint32_t bt_reads_paired_count(const bt_reads* r) { return r ? r->batch.n_paired : 0u; }
 extern "C" const char* bt_reads_error(const bt_reads* r) { return r ? r->err.c_str() : ""; }
 extern "C" void bt_reads_close(bt_reads* r)
 {

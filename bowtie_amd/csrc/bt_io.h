@@ -27,6 +27,7 @@ struct BtHostBatch {
 	std::string names;
 	std::vector<uint64_t> raw_off;        /* bt_read_opts.reserved bit 1: n + 1 offsets into raw   */
 	std::string raw;                      /* each read's record as it stood in the input (Read::readOrigBuf) */
+	uint32_t n_paired = 0;                /* BT_FMT_TABBED: reads whose record had a second end    */
 	size_t cap_bytes = 0;
 
 	BtHostBatch() {}

@@ -13,7 +13,7 @@ from .aligner import BowtieAmdError, lib
 from .reads import ReadBatch
 
 FORMATS = {"fastq": A.BT_FMT_FASTQ, "fasta": A.BT_FMT_FASTA, "raw": A.BT_FMT_RAW, "cmdline": A.BT_FMT_CMDLINE,
-           "fasta-cont": A.BT_FMT_FASTA_CONT}
+           "fasta-cont": A.BT_FMT_FASTA_CONT, "tabbed": A.BT_FMT_TABBED}
 QUALS = {"phred33": A.BT_QUAL_PHRED33, "phred64": A.BT_QUAL_PHRED64, "solexa": A.BT_QUAL_SOLEXA64,
          "int": 3, "int-solexa": 4}
 
@@ -25,11 +25,13 @@ class ReadInputError(ValueError):
 def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, quals: str = "phred33",
                  seed: int = 0, skip: int = 0, upto: int = 0, max_reads: int = 1 << 20,
                  threads: int = 1, careful: bool = False, keep_raw: bool = False,
-                 cont: Tuple[int, int] = (0, 0), mate: int = 0) -> Iterator[ReadBatch]:
+                 cont: Tuple[int, int] = (0, 0), mate: int = 0, interleaved: bool = False) -> Iterator[ReadBatch]:
     """Yield ReadBatch objects (copies) of up to max_reads reads each; keep_raw adds `.raw`, the list of
-    the reads' records as they stood in the input."""
+    the reads' records as they stood in the input.  fmt "tabbed" (--12): `mate` 2 delivers the records' second
+    ends, and every batch carries `.n_paired`, the number of its reads whose record had one.  `interleaved`
+    (--interleaved, FASTQ): `mate` 1 / 2 deliver the even / odd records."""
     L = lib()
-    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0) | (4 if mate == 1 else 8 if mate == 2 else 0), skip, upto,
+    o = A.ReadOpts(FORMATS[fmt], trim5, trim3, QUALS[quals], seed, int(careful) | (2 if keep_raw else 0) | (4 if mate == 1 else 8 if mate == 2 else 0) | (16 if interleaved else 0), skip, upto,
                    cont[0], cont[1])
     h = C.c_void_p()
     rc = L.bt_reads_open(spec.encode(), C.byref(o), C.byref(h))
@@ -56,6 +58,7 @@ def read_batches(spec: str, fmt: str = "fastq", trim5: int = 0, trim3: int = 0, 
             blob = C.string_at(names, int(off[n]))
             nm = [blob[int(off[i]):int(off[i + 1])] for i in range(n)]
             rbatch = ReadBatch(seq, qual, ln, sd, nm)
+            rbatch.n_paired = int(L.bt_reads_paired_count(h))
             if keep_raw:
                 rp, ro = C.c_void_p(), C.c_void_p()
                 if L.bt_reads_raw(h, C.byref(rp), C.byref(ro)) != A.BT_OK:

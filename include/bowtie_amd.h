@@ -307,6 +307,10 @@ int bt_bench_gather(bt_ctx* ctx, int mirror, uint32_t n_blocks, uint32_t iters, 
 #define BT_FMT_RAW      2   /* -r            RawPatternSource          pat.cpp:1129-1213        */
 #define BT_FMT_CMDLINE  3   /* -c            VectorPatternSource       pat.cpp:359-528          */
 #define BT_FMT_FASTA_CONT 4 /* -F <len>,<freq>  FastaContinuousPatternSource pat.cpp:651-793     */
+#define BT_FMT_TABBED   5   /* --12          TabbedPatternSource       pat.cpp:977-1127: one record per line,
+                               "name\tseq\tquals" or "name\tseq1\tquals1\tseq2\tquals2"; with BT_READ_MATE2 the
+                               second end is delivered, otherwise the first (bt_reads_paired_count tells which
+                               records had two)                                                       */
 #define BT_QUAL_PHRED33  0  /* charToPhred33, qual.h:89-127                                      */
 #define BT_QUAL_PHRED64  1  /* --phred64-quals / --solexa1.3-quals                               */
 #define BT_QUAL_SOLEXA64 2  /* --solexa-quals                                                    */
@@ -317,6 +321,9 @@ int bt_bench_gather(bt_ctx* ctx, int mirror, uint32_t n_blocks, uint32_t iters, 
 #define BT_READ_KEEP_RAW 2u /* keep each read's record text (Read::readOrigBuf) for --al/--un/--max */
 #define BT_READ_MATE1    4u /* the file holds first mates (-1): names end in /1 -- appended unless there --  */
 #define BT_READ_MATE2    8u /* ... second mates (-2), /2; the seed covers the name (read.h:141-165, pat.cpp:76-88) */
+#define BT_READ_INTERLEAVED 16u /* --interleaved (FASTQ): records alternate first mate, second mate (pat.cpp:797-856);
+                                   with BT_READ_MATE1 / BT_READ_MATE2 the even / odd records are delivered, a
+                                   trailing record without its mate is dropped                          */
 
 typedef struct bt_read_opts {
 	int32_t  format;       /* BT_FMT_*                                                        */
@@ -343,6 +350,8 @@ int  bt_reads_next(bt_reads* r, uint32_t max_reads, int threads, bt_read_batch* 
 /* with BT_READ_KEEP_RAW: the records of the batch last returned, raw_off[n+1] offsets into raw --
  * what the reference dumps for --al / --un / --max (hit.h:385-488) */
 int  bt_reads_raw(const bt_reads* r, const char** raw, const uint64_t** raw_off);
+/* BT_FMT_TABBED: how many reads of the batch last returned came from records with a second end */
+uint32_t bt_reads_paired_count(const bt_reads* r);
 const char* bt_reads_error(const bt_reads* r);
 void bt_reads_close(bt_reads* r);
 

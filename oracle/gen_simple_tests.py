@@ -15,7 +15,8 @@ genomes, every read format, -m, edits strings, paired-end geometry), re-expresse
     -S), and stdout + exit status are stored (MANIFEST.json, <case>.<mode>.out.gz).
     Paired cases are run as written (PairedBWAlignerV1; bowtie-amd refuses those) and once more
     with --best appended (PairedBWAlignerV2), which is the variant the tests compare.
-Cases in --12 / --interleaved format are listed as skipped (not in this build).
+    Cases in --12 / --interleaved format are run as written and with --best appended too: with such input the
+    reference always takes its stateful aligners, whether the records are pairs or not.
 """
 import gzip
 import hashlib
@@ -68,8 +69,12 @@ def inputs_of(c, k):
     if "cont_fasta_reads" in c:
         files[base + ".fa"] = c["cont_fasta_reads"]
         return None, files, [os.path.join("simple", base + ".fa")]
-    if "tabbed" in c or "interleaved" in c:
-        return "skip", files, None
+    if "tabbed" in c:
+        files[base + ".tab"] = c["tabbed"]
+        return None, files, ["--12", os.path.join("simple", base + ".tab")]
+    if "interleaved" in c:
+        files[base + ".il.fq"] = c["interleaved"]
+        return None, files, ["--interleaved", os.path.join("simple", base + ".il.fq")]
     if "mate1s" in c:
         files[base + ".1.fq"] = fastq_of(c["mate1s"], c.get("qual1s"), c.get("names"), 1)
         files[base + ".2.fq"] = fastq_of(c["mate2s"], c.get("qual2s"), c.get("names"), 2)
@@ -133,11 +138,16 @@ def main():
         a0 = c.get("args", "")
         argsets = [shlex.split(x) for x in (a0 if isinstance(a0, list) else [a0])]
         tail = ["--quiet"] + shlex.split(c["report"] if "report" in c else "-a")
-        paired = rargs[0] == "-1"
+        # --12 / --interleaved: the file says whether its records are pairs; either way the reference then runs its
+        # stateful aligners (ebwt_search.cpp:3001-3002), which bowtie-amd has for --best only
+        one_file = rargs[0] in ("--12", "--interleaved")
+        paired = rargs[0] == "-1" or (one_file and bool(c.get("paired")))
         entry.update({"reads": rargs, "paired": paired, "runs": []})
+        if one_file:
+            entry["needs_best"] = True
         for ai, aset in enumerate(argsets):
             args = ([fmt] if fmt else []) + aset + tail
-            variants = [("asis", [])] + ([("best", ["--best"])] if paired and "--best" not in args else [])
+            variants = [("asis", [])] + ([("best", ["--best"])] if (paired or one_file) and "--best" not in args else [])
             for vname, extra in variants:
                 for mode, margs in (("default", []), ("sam", ["-S", "--sam-nohead"])):
                     cmd = [os.path.join(BIN, "bowtie-align-s"), "--wrapper", "basic-0", "-p", "1"] + args + extra + margs + \

@@ -33,7 +33,11 @@ def test_version_and_help():
     (["-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "add --best"),
     (["--best", "-1", "a.fq,c.fq", "-2", "b.fq", "-x", "e_coli"], "must be specified with -1 and -2"),
     (["--best", "-M", "3", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "-M with paired-end"),
-    (["--12", "a.tab", "-x", "e_coli"], "does not have"),
+    (["--12", "a.tab", "-x", "e_coli"], "add --best"),
+    (["--interleaved", "a.fq", "-x", "e_coli"], "add --best"),
+    (["--best", "--12", "a.tab", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "cannot be combined"),
+    (["-Q", "a.qual", "-x", "e_coli", "cli/io.fq"], "go with -f"),
+    (["--pev2", "-x", "e_coli", "cli/io.fq"], "does not have"),
     (["--integer-quals", "-f", "-x", "e_coli", "cli/io.fa"], "is for FASTQ input"),
     (["-C", "-x", "e_coli", "cli/io.fq"], "colorspace"),
     (["-k", "0", "-x", "e_coli", "cli/io.fq"], "-k arg must be at least 1"),
@@ -56,3 +60,38 @@ def test_last_of_v_and_n_wins():
     # -v 3 followed by -n 2 is a -n 2 run (and then fails for want of a GPU or index, not for its options)
     p = run("-v", "3", "-n", "2", "-x", "no_such_index", "cli/io.fq")
     assert p.returncode == 1 and b"Could not locate" in p.stderr or b"HIP" in p.stderr or b"could not load" in p.stderr
+
+
+def _list_input(*args):
+    import os
+    env = dict(os.environ, BT_CLI_INPUT_ONLY="1")
+    return subprocess.run([BIN, "--wrapper", "basic-0"] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, env=env, timeout=60)
+
+
+def test_read_files_that_do_not_open(tmp_path):
+    """CFilePatternSource::open (pat.cpp:296-357): a file that does not open is skipped with a warning -- unless none of
+    the files after it opens either, then the run fails (checked on the reference: exit status 1)."""
+    ok = tmp_path / "ok.fa"
+    ok.write_text(">a\nACGTACGTACGTACGTACGTAAA\n")
+    p = _list_input("-f", "-x", "none", "/nonexistent.fa," + str(ok))
+    assert p.returncode == 0 and p.stdout == b"a\t23\n" and b"Could not open read file \"/nonexistent.fa\"" in p.stderr
+    p = _list_input("-f", "-x", "none", str(ok) + ",/nonexistent.fa")
+    assert p.returncode == 1 and p.stdout == b"a\t23\n"
+    p = _list_input("-x", "none", "/nonexistent.fq")
+    assert p.returncode == 1 and p.stdout == b""
+
+
+def test_quality_files_are_only_opened(tmp_path):
+    """-Q / --Q1 / --Q2 with -f (pat.cpp:333-347): the reference opens the quality file next to its read file and never
+    reads it; one that does not open takes its read file out of the run."""
+    ok = tmp_path / "ok.fa"
+    ok.write_text(">a\nACGTACGTACGTACGTACGTAAA\n")
+    q = tmp_path / "ok.qual"
+    q.write_text(">a\n40 40 40\n")
+    p = _list_input("-f", "-Q", str(q), "-x", "none", str(ok))
+    assert p.returncode == 0 and p.stdout == b"a\t23\n" and p.stderr == b""
+    p = _list_input("-f", "--quals", "/nonexistent.qual," + str(q), "-x", "none", "cli/io.fa," + str(ok))
+    assert p.returncode == 0 and p.stdout == b"a\t23\n"
+    assert p.stderr.decode().strip() == 'Warning: Could not open quality file "/nonexistent.qual" for reading; skipping...'
+    p = _list_input("-f", "-Q", "/nonexistent.qual", "-x", "none", str(ok))
+    assert p.returncode == 1 and p.stdout == b""

@@ -34,7 +34,9 @@ def all_runs(paired_variant="best"):
     out = []
     for c in manifest()["cases"]:
         for r in c.get("runs", []):
-            if r["variant"] == (paired_variant if c["paired"] else "asis"):
+            # --12 / --interleaved input puts the reference on its stateful aligners whether the records are pairs
+            # or not (ebwt_search.cpp:3001-3002): compared in the --best variant as well
+            if r["variant"] == (paired_variant if (c["paired"] or c.get("needs_best")) else "asis"):
                 out.append((c, r))
     return out
 
@@ -70,8 +72,18 @@ def test_simple_case_oracle_and_host_io(case, run, simple_index):
     rd, pol, out, ex = CC.interpret(run["args"])
     spec = lambda x: x if rd.get("fmt") == "cmdline" else ",".join(os.path.join(T.G, f) for f in x.split(","))
     want = expected(run)
+    one_file = case["reads"][0] in ("--12", "--interleaved")
+    if one_file:
+        rd.update(dict(fmt="tabbed") if case["reads"][0] == "--12" else dict(interleaved=True))
     try:
-        if case["paired"]:
+        if one_file and case["paired"]:
+            b1 = H.read_all(spec(case["reads"][1]), mate=1, **rd)
+            b2 = H.read_all(spec(case["reads"][1]), mate=2, **rd)
+            assert b1 is None or rd.get("interleaved") or b1.n_paired == b1.n
+        elif one_file:
+            b1 = H.read_all(spec(case["reads"][1]), **rd)
+            assert b1 is None or b1.n_paired == 0
+        elif case["paired"]:
             b1 = H.read_all(spec(case["reads"][1]), mate=1, **rd)
             b2 = H.read_all(spec(case["reads"][3]), mate=2, **rd)
         else:
@@ -97,6 +109,83 @@ def test_simple_case_oracle_and_host_io(case, run, simple_index):
     else:
         cap = 4096 if pol.get("all_hits") else pol.get("khits", 1)
         per = R.oracle_search(oi, opol, b1, cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        text, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    assert text == want
+
+
+@pytest.mark.parametrize("case,run", [(c, r) for c, r in all_runs() if "sam" not in r["file"]],
+                         ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+def test_binary_reads_the_input_the_way_the_parsers_do(case, run):
+    """bowtie-amd's own reading of its command line and input (which files, which format, pairs or not -- for --12 it
+    looks at the first record), checked without a GPU: BT_CLI_INPUT_ONLY=1 lists the reads it would search."""
+    env = dict(os.environ, BT_CLI_INPUT_ONLY="1")
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + run["args"] + ["-x", "/nonexistent"] + case["reads"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, env=env, timeout=60)
+    rd, pol, out, ex = CC.interpret(run["args"])
+    spec = lambda x: x if rd.get("fmt") == "cmdline" else ",".join(os.path.join(T.G, f) for f in x.split(","))
+    one_file = case["reads"][0] in ("--12", "--interleaved")
+    if one_file:
+        rd.update(dict(fmt="tabbed") if case["reads"][0] == "--12" else dict(interleaved=True))
+    f1, f2 = (case["reads"][1], case["reads"][1]) if one_file else (case["reads"][1], case["reads"][3]) if case["paired"] else (case["reads"][0], None)
+    try:
+        b1 = H.read_all(spec(f1), mate=1 if case["paired"] else 0, **rd)
+        b2 = H.read_all(spec(f2), mate=2, **rd) if case["paired"] else None
+    except H.ReadInputError:
+        assert p.returncode == 1
+        return
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-300:]
+    rows = [l.split("\t") for l in p.stdout.decode().splitlines()]
+    want = []
+    for i in range(b1.n if b1 is not None else 0):
+        row = [b1.names[i].decode(), str(int(b1.len[i]))]
+        if case["paired"]:
+            row += [b2.names[i].decode(), str(int(b2.len[i]))]
+        want.append(row)
+    assert rows == want
+
+
+_emu = {}
+
+
+@pytest.mark.parametrize("case,run", all_runs(), ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
+def test_simple_case_automaton_emu(case, run, simple_index):
+    """The same cases with the host build of the device automatons (tests/emu) doing the search instead of the
+    oracle: C++ parser -> bt_core.h / bt_best.h on the host -> C++ formatter == the reference's output."""
+    import emu_lib as E
+    from bowtie_amd import _abi as A
+    if run["returncode"] != 0:
+        pytest.skip("an input error: nothing reaches the search")
+    base = simple_index(case["ref"])
+    rd, pol, out, ex = CC.interpret(run["args"])
+    spec = lambda x: x if rd.get("fmt") == "cmdline" else ",".join(os.path.join(T.G, f) for f in x.split(","))
+    one_file = case["reads"][0] in ("--12", "--interleaved")
+    if one_file:
+        rd.update(dict(fmt="tabbed") if case["reads"][0] == "--12" else dict(interleaved=True))
+    f1, f2 = (case["reads"][1], case["reads"][1]) if one_file else (case["reads"][1], case["reads"][3]) if case["paired"] else (case["reads"][0], None)
+    if case["paired"]:
+        b1, b2 = H.read_all(spec(f1), mate=1, **rd), H.read_all(spec(f2), mate=2, **rd)
+    else:
+        b1 = H.read_all(spec(f1), **rd)
+    want = expected(run)
+    if b1 is None:
+        assert want == b""
+        return
+    if base not in _emu:
+        _emu[base] = E.EmuAligner(base)
+    if base not in _oi:
+        _oi[base] = OL.OracleIndex(base)
+    oi = _oi[base]
+    p = A.make_policy(**pol)
+    opts = H.out_opts(**out)
+    if case["paired"]:
+        cap = 4096 if pol.get("all_hits") else 2 * pol.get("khits", 1)
+        per = _emu[base].align_pairs(p, b1, b2, hit_cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        text, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    else:
+        cap = 4096 if pol.get("all_hits") else pol.get("khits", 1)
+        per = _emu[base].align(p, b1, hit_cap=cap, lite=not p.best)
         hits, nh, st, pool = H.pack_hits(per, cap)
         text, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
     assert text == want
