@@ -196,6 +196,16 @@ def pack_batch(batch: ReadBatch):
                                                ln.ctypes.data, seed.ctypes.data)
 
 
+def pair_hit_cap(pol) -> int:
+    """Hit slots per pair: two per alignment wanted; with -M the first mhits pairs are kept for the sampling."""
+    if pol.all_hits:
+        return 128
+    want = 2 * int(pol.khits)
+    if pol.sample_max:
+        want = max(want, 2 * int(pol.mhits))
+    return max(2, min(want, 128))
+
+
 def unpack_pair_hits(n: int, hit_cap: int, hits, n_hits, status, mm_pool, pol):
     """Paired-end results: per pair (hits: upstream mate, downstream mate, ..., hitsForThisRead, status),
     finishRead's rules with the doubled -k / -m of createMult(2) (hit.h:741-786)."""
@@ -206,8 +216,9 @@ def unpack_pair_hits(n: int, hit_cap: int, hits, n_hits, status, mm_pool, pol):
     for i in range(n):
         tot = int(n_hits[i])
         hs: List[Hit] = []
-        if tot <= maxv:
-            for k in range(min(tot, lim)):
+        if tot <= maxv or pol.sample_max:
+            # over the -m ceiling with -M: the first mhits pairs were buffered, one of them gets printed
+            for k in range(min(tot, lim) if tot <= maxv else min(maxv, hit_cap) & ~1):
                 h = hits[i * hit_cap + k]
                 off, nmm = int(h["mm_off"]), int(h["nmm"])
                 mms = [(int(e) & 0x3FF, (int(e) >> 12) & 3) for e in mm_pool[off:off + nmm]]
@@ -279,7 +290,7 @@ class Aligner:
         if rc != A.BT_OK:
             raise BowtieAmdError(rc, "bt_index_load_reference")
         n = b1.n
-        hit_cap = hit_cap or (128 if self.policy.all_hits else max(2, min(2 * int(self.policy.khits), 128)))
+        hit_cap = hit_cap or pair_hit_cap(self.policy)
         k1, rb1 = pack_batch(b1)
         k2, rb2 = pack_batch(b2)
         hits = np.zeros(n * hit_cap, dtype=A.HIT_DTYPE)

@@ -466,7 +466,6 @@ void parse_args(int argc, char** argv, Options* O)
 		if (c1 != c2 && O->rd.format != BT_FMT_CMDLINE)
 			die("Error: %zu mate files/sequences were specified with -1, but %zu\nmate files/sequences were specified with -2.  The same number of mate files/\nsequences must be specified with -1 and -2.", c1, c2);
 		if (!O->pol.best) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
-		if (O->pol.sample_max) die("Error: -M with paired-end reads is not in this build");
 		if (!O->dump_al.empty() || !O->dump_un.empty() || !O->dump_max.empty()) die("Error: --al/--un/--max with paired-end reads are not in this build");
 	} else if (one_file) {
 		O->reads = O->tab12;
@@ -578,6 +577,8 @@ std::string search_job_pairs(bt_ctx* ctx, const Options& O, Job* j)
 	const uint32_t n = j->rb.n_reads;
 	const bool all = O.pol.all_hits != 0;
 	j->hit_cap = all ? 16u : 2u * (O.pol.khits > 32u ? 32u : O.pol.khits);
+	/* -M: a pair over the ceiling keeps its first mhits alignments, one of which is printed (at most 64 are kept) */
+	if (O.pol.sample_max && !all) { const uint32_t w = 2u * (O.pol.mhits > 64u ? 64u : O.pol.mhits); if (w > j->hit_cap) j->hit_cap = w; }
 	for (int pass = 0; pass < 2; pass++) {
 		j->hits.assign((size_t)n * j->hit_cap, bt_hit());
 		j->n_hits.assign(n, 0); j->status.assign(n, 0);

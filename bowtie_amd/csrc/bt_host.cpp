@@ -475,7 +475,6 @@ static int compile_best(const bt_policy& pol, bool paired, BfProgram* prog)
 		/* Paired*AlignerFactory::create() with v1_ == false: -v: 1Fw 1Rc 2Fw 2Rc (aligner_0mm.h:320-327,
 		 * aligner_1mm.h:286-415, aligner_23mm.h:358-606); -n: 1Fw 2Fw 1Rc 2Rc (aligner_seed_mm.h:705-1290) */
 		if (pol.max_ins < 0 || pol.min_ins < 0 || pol.pair_tries < 0) return BT_ERR_ARG;
-		if (pol.sample_max) return BT_ERR_ARG;     /* -M sampling of pairs (hit.cpp:27-55) is not built */
 		bool d1f = true, d1r = true, d2f = true, d2r = true;
 		if (pol.nofw) { if (pol.mate1_fw) d1f = false; else d1r = false; if (pol.mate2_fw) d2f = false; else d2r = false; }
 		if (pol.norc) { if (pol.mate1_fw) d1r = false; else d1f = false; if (pol.mate2_fw) d2r = false; else d2f = false; }

@@ -1179,7 +1179,7 @@ void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* na
  * FLAG 1|2|64/128 (+16, +32), MRNM '=', MPOS, ISIZE */
 static void sam_pair_hit(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
                          const bt_hit& h, const uint16_t* mm, const bt_hit& mh, uint32_t mlen, uint32_t xms,
-                         const BtRefNames& refs, const bt_out_opts& op)
+                         const BtRefNames& refs, const bt_out_opts& op, int mapq_override = -1)
 {
 	static const char dna[] = "ACGT";
 	const bool fw = h.fw != 0;
@@ -1188,7 +1188,7 @@ static void sam_pair_hit(std::string* o, const char* nm, size_t nn, const uint8_
 	o->push_back('\t'); put_u(o, flags);
 	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
 	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
-	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", op.mapq); o->append(b); }
+	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", mapq_override >= 0 ? mapq_override : op.mapq); o->append(b); }
 	o->push_back('\t'); put_u(o, L); o->append("M\t=\t");
 	put_u(o, (uint64_t)mh.toff + 1u);
 	o->push_back('\t');
@@ -1252,7 +1252,48 @@ void bt_io_format_pairs(const bt_read_batch& r1, const char* names1, const uint6
 					                   rb[m]->len[i], m + 1, op);
 			continue;
 		}
-		if (tot > maxv) { if (tally) tally->maxed++; continue; }
+		if (tot > maxv) {
+			if (tally) tally->maxed++;
+			if (op.sample_max) {
+				/* -M for pairs (VerboseHitSink::reportMaxed hit.cpp:27-55, SAMHitSink::reportMaxed sam.cpp:274-299): of the
+				 * -M pairs that were buffered, those whose better mate is in the best stratum seen; one of them, picked with
+				 * the first draw of the first mate's generator */
+				uint32_t nb = maxv < hb.hit_cap ? maxv : hb.hit_cap;
+				nb &= ~1u;
+				const bt_hit* hs = hb.hits + (size_t)i * hb.hit_cap;
+				uint32_t best = 999, num = 0;
+				for (uint32_t k = 0; k + 1 < nb; k += 2) {
+					const uint32_t st = hs[k].stratum < hs[k + 1].stratum ? hs[k].stratum : hs[k + 1].stratum;
+					if (st < best) { best = st; num = 1; } else if (st == best) num++;
+				}
+				if (num > 0) {
+					uint32_t last = r1.seed[i];
+					last = 1664525u * last + 1013904223u;
+					uint32_t r = last >> 16;
+					last = 1664525u * last + 1013904223u;
+					r = (r ^ last) % num;
+					uint32_t seen = 0;
+					for (uint32_t k = 0; k + 1 < nb; k += 2) {
+						const uint32_t st = hs[k].stratum < hs[k + 1].stratum ? hs[k].stratum : hs[k + 1].stratum;
+						if (st != best) continue;
+						if (seen++ != r) continue;
+						for (uint32_t e = 0; e < 2; e++) {
+							bt_hit h = hs[k + e];
+							const bt_hit& mh = hs[k + (e ^ 1u)];
+							const int m = h.pad[0] == 2 ? 1 : 0;
+							const uint8_t* seq = rb[m]->seq + (size_t)i * rb[m]->stride;
+							const uint8_t* qual = rb[m]->qual + (size_t)i * rb[m]->stride;
+							const uint16_t* mm = hb.mm_pool ? hb.mm_pool + h.mm_off : nullptr;
+							if (op.sam) sam_pair_hit(out, nm[m], nn[m], seq, qual, rb[m]->len[i], h, mm, mh, rb[m ^ 1]->len[i], nb / 2u + 1u, refs, op, 0);
+							else { h.oms = nb / 2u; verbose_hit(out, nm[m], nn[m], seq, qual, rb[m]->len[i], h, mm, rb[m]->seed[i], refs, op); }
+						}
+						break;
+					}
+					if (tally) { tally->aligned++; tally->reported_paired += 2; tally->sample_max = 1; }
+				}
+			}
+			continue;
+		}
 		uint32_t np = tot < lim ? tot : lim;
 		np &= ~1u;
 		if (tally) { tally->aligned++; tally->reported_paired += np; }

@@ -186,6 +186,8 @@ def cases(plain):
         ("pe_n1_k3_sam", M, ["--best", "-n", "1", "-k", "3", "-X", "350", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_a_strata_cost", M, ["--best", "--strata", "-a", "-v", "2", "-X", "400", "--cost", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_m1_I100", M, ["--best", "-m", "1", "-I", "100", "-X", "300", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_M1_sam", M, ["--best", "-M", "1", "-X", "400", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_M2_strata_default", M, ["--best", "--strata", "-M", "2", "-v", "2", "-X", "400", "--cost", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_trim_ff", M, ["--best", "--ff", "-5", "2", "-3", "3", "-X", "300", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_ecoli_config5", E, ["-n", "1", "--best", "-X", "500", "-S", "--sam-nohead", "--no-unal", "-1", "cli/pee_1.fq", "-2", "cli/pee_2.fq"], ""),
         ("pe_ecoli_two_files", E, ["-v", "2", "--best", "-X", "500", "-1", "cli/pee_1.fq,cli/pe_1.fq", "-2", "cli/pee_2.fq,cli/pe_2.fq"], ""),

@@ -68,6 +68,10 @@ PAIRED_MODES = {
                            dict(mode="n", mms=2, best=True, max_ins=500, mate1_fw=False, mate2_fw=True)),
     "pe_n2_best_X500_pairtries2_k4": (["-n", "2", "--best", "-X", "500", "--pairtries", "2", "-k", "4"],
                                       dict(mode="n", mms=2, best=True, max_ins=500, pair_tries=2, khits=4)),
+    # -M for pairs: one of the buffered pairs of the best stratum, at random (hit.cpp:27-55, sam.cpp:274-299)
+    "pe_n2_best_X500_M1": (["-n", "2", "--best", "-X", "500", "-M", "1"], dict(mode="n", mms=2, best=True, max_ins=500, mhits=1, sample_max=True)),
+    "pe_v2_strata_X500_M2": (["-v", "2", "--best", "--strata", "-X", "500", "-M", "2"],
+                             dict(mode="v", mms=2, strata=True, max_ins=500, mhits=2, sample_max=True)),
 }
 # (index, pair set name) -> how tests regenerate the pairs (tests/common.py: pair_set)
 PAIR_SETS = [("e_coli", "e_coli_1000_pe"), ("e_coli", "pe50"), ("multi", "pe50"), ("multi", "pe100"), ("multi", "pe30"), ("e_coli", "pe75")]

@@ -75,7 +75,8 @@ def paired_runs(index=None, reads=None, modes=None):
 
 def check_pairs_against_golden(run: dict, per_pair, b1, b2, refnames):
     pol = MODES[run["mode"]]
-    sam = R.render_pairs(b1, b2, per_pair, refnames, sam=True, mhits=pol.get("mhits", 0xFFFFFFFF))
+    sam = R.render_pairs(b1, b2, per_pair, refnames, sam=True, mhits=pol.get("mhits", 0xFFFFFFFF),
+                         sample_max=bool(pol.get("sample_max")))
     with gzip.open(os.path.join(G, run["file"]), "rb") as f:
         want = f.read()
     got = strip_sam(sam)

@@ -82,9 +82,9 @@ class EmuAligner:
 
     def align_pairs(self, pol: A.Policy, b1: ReadBatch, b2: ReadBatch, hit_cap=None, mm_per_hit=8, counts=None, arena_words=0):
         """-> per pair (hits: upstream mate, downstream mate, ..., hitsForThisRead, status)"""
-        from bowtie_amd.aligner import pack_batch, unpack_pair_hits
+        from bowtie_amd.aligner import pack_batch, pair_hit_cap, unpack_pair_hits
         n = b1.n
-        hit_cap = hit_cap or (128 if pol.all_hits else max(2, min(2 * int(pol.khits), 128)))
+        hit_cap = hit_cap or pair_hit_cap(pol)
         k1, rb1 = pack_batch(b1)
         k2, rb2 = pack_batch(b2)
         hits = np.zeros(n * hit_cap, dtype=A.HIT_DTYPE)

@@ -92,7 +92,8 @@ def run_reference_pairs(args: List[str], index_base: str, reads1: str, reads2: s
 
 
 def oracle_search_pairs(oidx, pol, b1: ReadBatch, b2: ReadBatch, cap: Optional[int] = None, counts=None, v1: bool = False):
-    cap = cap or (128 if pol.all_hits else max(2, min(2 * int(pol.khits), 128)))
+    from bowtie_amd.aligner import pair_hit_cap
+    cap = cap or pair_hit_cap(pol)
     res = []
     for i in range(b1.n):
         L1, L2 = int(b1.len[i]), int(b2.len[i])
@@ -104,7 +105,8 @@ def oracle_search_pairs(oidx, pol, b1: ReadBatch, b2: ReadBatch, cap: Optional[i
     return res
 
 
-def render_pairs(b1: ReadBatch, b2: ReadBatch, per_pair, refnames, sam: bool, mhits: int = 0xFFFFFFFF) -> bytes:
+def render_pairs(b1: ReadBatch, b2: ReadBatch, per_pair, refnames, sam: bool, mhits: int = 0xFFFFFFFF,
+                 sample_max: bool = False) -> bytes:
     """per_pair[i] = (hits: upstream mate, downstream mate, ..., n_hits_total, status) -> reference text.
     finishRead (hit.h:741-786) with the doubled -k/-m of createMult(2); XM:i = pairs reported."""
     out = []
@@ -123,6 +125,21 @@ def render_pairs(b1: ReadBatch, b2: ReadBatch, per_pair, refnames, sam: bool, mh
                                                 mate_len=len(reads[m.mate][1])))
                     else:
                         out.append(O.format_verbose(name, seq, qual, h, refnames))
+        elif maxed and sample_max and len(hits) >= 2:
+            # -M for pairs (hit.cpp:27-55, sam.cpp:274-299): of the buffered pairs, those whose better mate is in the best
+            # stratum; one of them, picked with the first draw of the first mate's generator
+            strata = [min(hits[k].stratum, hits[k + 1].stratum) for k in range(0, len(hits) - 1, 2)]
+            best = min(strata)
+            cands = [k for k, st in enumerate(strata) if st == best]
+            k = 2 * cands[_rand_u32(int(b1.seed[i])) % len(cands)]
+            for h, m in ((hits[k], hits[k + 1]), (hits[k + 1], hits[k])):
+                name, seq, qual = reads[h.mate]
+                if sam:
+                    out.append(O.format_sam(name, seq, qual, h, refnames, mapq=0, xms=len(hits) // 2 + 1, mate_hit=m,
+                                            mate_len=len(reads[m.mate][1])))
+                else:
+                    import dataclasses
+                    out.append(O.format_verbose(name, seq, qual, dataclasses.replace(h, oms=len(hits) // 2), refnames))
         elif sam and not maxed:
             for mate in (1, 2):
                 name, seq, qual = reads[mate]

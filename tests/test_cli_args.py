@@ -32,7 +32,6 @@ def test_version_and_help():
     (["--best", "--strata", "-x", "e_coli", "cli/io.fq"], "--strata has no effect unless combined with"),
     (["-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "add --best"),
     (["--best", "-1", "a.fq,c.fq", "-2", "b.fq", "-x", "e_coli"], "must be specified with -1 and -2"),
-    (["--best", "-M", "3", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "-M with paired-end"),
     (["--12", "a.tab", "-x", "e_coli"], "add --best"),
     (["--interleaved", "a.fq", "-x", "e_coli"], "add --best"),
     (["--best", "--12", "a.tab", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "cannot be combined"),

@@ -22,7 +22,7 @@ def run_case_paired(case, rd, pol, out, ex):
     o1 = rd.get("trim5", 0) if pol.get("mate1_fw", True) else rd.get("trim3", 0)
     o2 = rd.get("trim3", 0) if pol.get("mate2_fw", False) else rd.get("trim5", 0)
     pol = dict(pol, min_ins=max(0, max(0, pol.get("min_ins", 0) - o1) - o2), max_ins=max(0, max(0, pol.get("max_ins", 250) - o1) - o2))
-    cap = 2048 if pol.get("all_hits") else 2 * pol.get("khits", 1)
+    cap = 2048 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
     per = T.oracle_pair_results(case["index"], b1, b2, pol, cap=cap)
     hits, nh, st, pool = H.pack_hits(per, cap)
     opts = H.out_opts(**out)
