@@ -145,7 +145,8 @@ void bt_io_close(BtReadStream* s)
 }
 
 /* ---- light parse: one record's text appended to s->raw ------------------------------------- */
-/* Each returns 1 = a record was appended, 0 = the current file is finished, -1 = error. */
+/* Each returns 1 = a record was appended, 0 = the current file is finished, -1 = error (light_fastq: -2 = the file
+ * ended inside a record). */
 
 static int light_fastq(BtReadStream* s, std::string* err)
 {
@@ -177,10 +178,11 @@ static int light_fastq(BtReadStream* s, std::string* err)
 		const int c = st_getc(s);
 		if (c < 0) {
 			if (newlines == 1) { raw.push_back('\n'); newlines = 0; break; }   /* EOF stands in for the last newline */
-			/* clean end of file, or EOF inside a record: the partial record is dropped (the
-			 * reference's light parser additionally loses the record before a truncated one) */
+			/* clean end of file (0), or EOF inside a record (-2): the partial record is dropped, and the caller gives
+			 * up the record before it as well, as the reference's light parser does (pat.cpp:826-856: `aborted`) */
+			const bool clean = newlines == 4;          /* no line of a record was complete yet (its characters are lost all the same) */
 			raw.resize(start);
-			return 0;
+			return clean ? 0 : -2;
 		}
 		s->pos--;            /* window refilled: take the bulk path */
 	}
@@ -289,6 +291,7 @@ struct BtParsed {
 	size_t name_b = 0, name_n = 0;   /* name = rec[name_b, name_b + name_n), or the read id when empty */
 	bool ok = true;             /* false: the record ended prematurely -- the reference skips it */
 	bool paired = false;        /* --12: the record had a second end */
+	bool name_as_is = false;    /* --12: an empty name stays empty (the other readers put the read id there) */
 };
 
 static const uint8_t* asc2dna_table()
@@ -342,7 +345,7 @@ static void trim_end(std::string& s, size_t n) { s.resize(n >= s.size() ? 0 : s.
 
 static std::string name_of(const char* rec, const BtParsed& p, uint64_t rdid)
 {
-	if (p.name_n) return std::string(rec + p.name_b, p.name_n);
+	if (p.name_n || p.name_as_is) return std::string(rec + p.name_b, p.name_n);
 	char b[24]; snprintf(b, sizeof(b), "%llu", (unsigned long long)rdid);
 	return b;
 }
@@ -486,7 +489,7 @@ static bool parse_tabbed(const char* r, size_t n, const bt_read_opts& o, uint64_
 	const bool want2 = (o.flags & BT_READ_MATE2) != 0;
 	size_t cur = 0;
 	int c = (unsigned char)r[cur++];
-	p->name_b = 0; p->name_n = 0;
+	p->name_b = 0; p->name_n = 0; p->name_as_is = true;
 	while (c != '\t' && cur < n) { p->name_n++; c = (unsigned char)r[cur++]; }
 	if (cur >= n) { p->ok = false; return true; }
 	for (int e = 0; e < 2 && c == '\t'; e++) {
@@ -623,8 +626,9 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 	std::vector<FqRec> recs;
 	recs.reserve(max_reads < (1u << 22) ? max_reads : (1u << 22));
 	uint32_t maxline = 1;
+	bool at_limit = false;
 	while (!s->done && recs.size() < max_reads) {
-		if (s->rdid >= s->limit) { s->done = true; break; }
+		if (s->rdid >= s->limit) { s->done = true; at_limit = true; break; }
 		if (!s->f) {
 			/* the next file continues the same window: this batch's records stay where they are */
 			if (!st_open_next(s, err, true)) { s->done = true; break; }
@@ -668,9 +672,9 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		s->rdid++; s->file_recs++;
 		if (s->pos >= s->end && s->feof) { gzclose(s->f); s->f = nullptr; }
 	}
-	if (recs.size() == max_reads && s->f && !s->done && s->file_recs % 16u != 0) {
-		/* the batch is full: look (without consuming) whether the file ends inside the next record,
-		 * because that would take this batch's last record with it */
+	if ((at_limit || (recs.size() == max_reads && !s->done)) && s->f && s->file_recs % 16u != 0) {
+		/* the batch is full (or -u is reached: the reference's reader is a batch ahead of that): look (without consuming)
+		 * whether the file ends inside the next record, because that would take this batch's last record with it */
 		size_t p = s->pos; int k = 0;
 		while (k < 3) {
 			const char* b = s->buf.data();
@@ -853,7 +857,18 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 	if (s->o.format == BT_FMT_FASTQ && !(s->o.flags & (BT_READ_CAREFUL | BT_READ_INTERLEAVED))) return next_fastq(s, max_reads, threads, batch, err);
 	/* ---- light parse (sequential) ---- */
 	while (!s->done && s->recs.size() < max_reads) {
-		if (s->rdid >= s->limit) { s->done = true; break; }
+		if (s->rdid >= s->limit) {
+			s->done = true;
+			/* -u reached: the reference's FASTQ reader is up to a batch ahead, and a file that ends inside the next
+			 * record takes the last read with it there too */
+			if (s->o.format == BT_FMT_FASTQ && s->f && s->file_recs % 16u != 0) {
+				const size_t off = s->raw.size();
+				const int rc = light_fastq(s, err);
+				s->raw.resize(off);
+				if (rc == -2) { s->rdid--; if (!s->recs.empty() && s->recs.back().rdid == s->rdid) { s->raw.resize(s->recs.back().off); s->recs.pop_back(); } }
+			}
+			break;
+		}
 		if (s->o.format == BT_FMT_CMDLINE) {
 			if (s->item >= s->items.size()) { s->done = true; break; }
 			const std::string& it = s->items[s->item++];
@@ -874,8 +889,8 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 			if (rc == 1) {
 				const size_t mid = s->raw.size();
 				const int rc2 = light_fastq(s, err);
-				if (rc2 < 0) return BT_ERR_READS;
-				if (rc2 == 0) { s->raw.resize(off); rc = 0; }
+				if (rc2 == -1) return BT_ERR_READS;
+				if (rc2 <= 0) { s->raw.resize(off); rc = rc2; }
 				else if (s->o.flags & BT_READ_MATE2) s->raw.erase(off, mid - off);
 				else s->raw.resize(mid);
 			}
@@ -884,11 +899,20 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 		else if (s->o.format == BT_FMT_FASTA) rc = light_fasta(s, err);
 		else if (s->o.format == BT_FMT_FASTA_CONT) rc = light_fasta_cont(s, err);
 		else rc = light_raw(s, err);
-		if (rc < 0) return BT_ERR_READS;
+		if (rc == -1) return BT_ERR_READS;
+		if (rc == -2) {
+			/* the file ended inside a record: the reference's reader drops the read (pair) before it too -- unless that
+			 * one closed a 16-read batch -- and hands its read id on (the same rule as in next_fastq) */
+			if (s->file_recs % 16u != 0) {
+				s->rdid--;
+				if (!s->recs.empty() && s->recs.back().rdid == s->rdid) { s->raw.resize(s->recs.back().off); s->recs.pop_back(); }
+			}
+			rc = 0;
+		}
 		if (rc == 0) { gzclose(s->f); s->f = nullptr; continue; }
 		if (s->rdid >= s->o.skip) s->recs.push_back({off, (uint32_t)(s->raw.size() - off), s->rdid});
 		else s->raw.resize(off);                    /* skipped reads are never parsed */
-		s->rdid++;
+		s->rdid++; s->file_recs++;
 	}
 	const size_t nrec = s->recs.size();
 	if (nrec == 0) {
@@ -954,7 +978,7 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 		const BtParsed& p = parsed[keep[k]];
 		const BtRec& rc = s->recs[keep[k]];
 		batch->name_off[k] = batch->names.size();
-		if (p.name_n) batch->names.append(s->raw.data() + rc.off + p.name_b, p.name_n);
+		if (p.name_n || p.name_as_is) batch->names.append(s->raw.data() + rc.off + p.name_b, p.name_n);
 		else { char b[24]; snprintf(b, sizeof(b), "%llu", (unsigned long long)rc.rdid); batch->names.append(b); }
 		batch->rdid[k] = rc.rdid;
 	}

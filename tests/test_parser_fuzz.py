@@ -1,0 +1,205 @@
+"""Differential test of the --12 (tab-delimited) reader against the unmodified reference binary (oracle/_ref, built by
+`make -C oracle ref`): seeded random files -- well-formed and not -- through `bowtie-align-s --12` on one side and
+C++ parser -> oracle -> C++ formatter on the other; same text, same exit status.  No GPU."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import common as T
+import oracle_lib as OL
+import refrun as R
+from bowtie_amd import ebwt_build as EB
+from bowtie_amd import hostio as H
+
+REF_BIN = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-s")
+GENOME = "AGCATCGATCAGTATCTGACCGTTAGGCATTACGGATCCATGCAAGTCTTGACGTACGGTCAATGC"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="needs the reference binary (make -C oracle ref)")
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    root = tmp_path_factory.mktemp("fuzz_idx")
+    lut = np.full(256, 4, np.uint8)
+    for i, ch in enumerate("ACGT"):
+        lut[ord(ch)] = i
+    base = str(root / "g")
+    EB.build_index([lut[np.frombuffer(GENOME.encode(), dtype=np.uint8)]], ["g0 tiny"], base)
+    return base, OL.OracleIndex(base)
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+
+
+def _read(rng, paired_mate=False):
+    L = rng.choice([4, 5, 8, 12, 16, 20, 25])
+    p = rng.randrange(0, len(GENOME) - L)
+    s = GENOME[p:p + L]
+    if rng.random() < 0.5:
+        s = _rc(s)
+    s = list(s)
+    for _ in range(rng.choice([0, 0, 0, 1, 2])):
+        s[rng.randrange(L)] = rng.choice("ACGTN")
+    s = "".join(s)
+    r = rng.random()
+    if r < 0.1:
+        s = s.lower()
+    elif r < 0.15:
+        k = rng.randrange(L)
+        s = s[:k] + rng.choice(".-*5") + s[k:]          # characters that are no letters are skipped
+    elif r < 0.2:
+        k = rng.randrange(L)
+        s = s[:k] + rng.choice("RYKMX") + s[k + 1:]     # letters that are no bases read as N
+    return s
+
+
+def _quals(rng, s, allow_bad):
+    n = sum(ch.isalpha() for ch in s)
+    q = "".join(rng.choice("!#+5?IIIII") for _ in range(n))
+    if allow_bad:
+        r = rng.random()
+        if r < 0.04 and n > 1:
+            q = q[:-1]
+        elif r < 0.08:
+            q = q + "I"
+        elif r < 0.10 and n > 2:
+            q = q[:1] + " " + q[2:]
+    return q
+
+
+def make_file(seed):
+    rng = random.Random(seed)
+    paired = rng.random() < 0.4
+    allow_bad = rng.random() < 0.3
+    lines = []
+    for i in range(rng.randrange(1, 9)):
+        name = rng.choice(["r%d" % i, "read %d extra" % i, "", "x/1", "q%d/2" % i])
+        s1 = _read(rng)
+        rec = [name, s1, _quals(rng, s1, allow_bad)]
+        if paired:
+            s2 = _read(rng)
+            rec += [s2, _quals(rng, s2, allow_bad)]
+        r = rng.random()
+        if r < 0.03:
+            rec = rec[:2]                              # the line stops before the qualities
+        elif r < 0.05:
+            rec = rec[:1]
+        elif r < 0.08:
+            rec[1] = ""; rec[2] = ""                   # an empty read
+        lines.append("\t".join(rec))
+    sep = rng.choice(["\n", "\n", "\r\n", "\n\n", "\n\r\n\n"])
+    text = rng.choice(["", "\n", "\n\r\n"]) + sep.join(lines) + rng.choice(["", "\n", "\n\n"])
+    opts = rng.choice([[], [], ["-5", "2"], ["-3", "3"], ["-5", "1", "-3", "1"], ["-s", "1"], ["-u", "2"]])
+    pol = rng.choice([["-v", "2"], ["-n", "2", "-l", "8"], ["-v", "0"], ["-n", "1", "-l", "6", "-e", "100"]])
+    return text, paired, opts + pol
+
+
+@pytest.mark.parametrize("seed", range(500))
+def test_tabbed_reader_against_the_reference(seed, tiny, tmp_path):
+    base, oi = tiny
+    text, paired, args = make_file(seed)
+    f = tmp_path / "in.tab"
+    f.write_bytes(text.encode())
+    args = args + ["--quiet", "-a", "--best"] + (["-X", "200"] if paired else [])
+    ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, "--12", str(f)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    if ref.returncode != 0 and "-u" in args:
+        pytest.skip("the reference parses one read past -u and reports that one's errors; this reader stops at the limit")
+    import cli_cases as CC
+    rd, pol, out, ex = CC.interpret(args)
+    rd["fmt"] = "tabbed"
+    try:
+        b0 = H.read_all(str(f), **rd)
+        if b0 is not None and 0 < b0.n_paired < b0.n:
+            pytest.skip("a file that mixes paired and unpaired records (not generated on purpose)")
+        is_paired = b0 is not None and b0.n_paired == b0.n and b0.n > 0
+        if is_paired:
+            b1, b2 = H.read_all(str(f), mate=1, **rd), H.read_all(str(f), mate=2, **rd)
+    except H.ReadInputError:
+        assert ref.returncode == 1, ref.stderr.decode(errors="replace")[-300:]
+        return
+    assert ref.returncode == 0, ref.stderr.decode(errors="replace")[-300:]
+    if b0 is None:
+        assert ref.stdout == b""
+        return
+    opol = OL.make_policy(**pol)
+    opts = H.out_opts(**out)
+    cap = 4096
+    if is_paired:
+        per = R.oracle_search_pairs(oi, opol, b1, b2, cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    else:
+        per = R.oracle_search(oi, opol, b0, cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        got, _ = H.format_hits(b0, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+    assert got == ref.stdout
+
+
+def make_fastq(seed):
+    rng = random.Random(1000 + seed)
+    paired = rng.random() < 0.4
+    recs = []
+    for i in range(rng.randrange(1, 7) * (2 if paired else 1)):
+        name = rng.choice(["r%d" % i, "read %d extra" % i, "", "x/1", "q%d/2" % i])
+        s1 = _read(rng)
+        q = _quals(rng, s1, False)
+        if rng.random() < 0.06:
+            s1, q = "", ""
+        plus = rng.choice(["+", "+", "+" + name])
+        nl = rng.choice(["\n", "\n", "\r\n"])
+        recs.append("@" + name + nl + s1 + nl + plus + nl + q)
+    text = rng.choice(["", "\n", "\n\r\n"]) + "".join(r + rng.choice(["\n", "\n", "\n\n", "\r\n"]) for r in recs[:-1]) + recs[-1] + rng.choice(["", "\n", "\n\n"])
+    opts = rng.choice([[], [], ["-5", "2"], ["-3", "3"], ["-5", "1", "-3", "1"], ["-s", "1"], ["-u", "2"]])
+    pol = rng.choice([["-v", "2"], ["-n", "2", "-l", "8"], ["-v", "0"], ["-n", "1", "-l", "6", "-e", "100"]])
+    return text, paired, opts + pol
+
+
+@pytest.mark.parametrize("seed", range(500))
+def test_fastq_reader_against_the_reference(seed, tiny, tmp_path):
+    """Well-formed FASTQ with the variations real files have (blank lines, CRLF, lower case, dots, empty reads, names
+    with spaces or none, '+name' lines, no final newline): plain through the default engine, interleaved pairs through
+    --best.  Both the bulk path and the step-by-step parser."""
+    base, oi = tiny
+    text, paired, args = make_fastq(seed)
+    f = tmp_path / "in.fq"
+    f.write_bytes(text.encode())
+    args = args + ["--quiet", "-a"] + (["--best", "-X", "200"] if paired else [])
+    ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base] + (["--interleaved", str(f)] if paired else [str(f)]),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    if b"is less than" in ref.stderr:
+        pytest.skip("a read shorter than the mode allows: the aligner's error, not the reader's")
+    if ref.returncode != 0 and "-u" in args:
+        pytest.skip("the reference parses one read past -u and reports that one's errors; this reader stops at the limit")
+    import cli_cases as CC
+    rd, pol, out, ex = CC.interpret(args)
+    opol = OL.make_policy(**pol)
+    opts = H.out_opts(**out)
+    cap = 4096
+    for careful in (False, True):
+        try:
+            if paired:
+                b1 = H.read_all(str(f), mate=1, interleaved=True, **rd)
+                b2 = H.read_all(str(f), mate=2, interleaved=True, **rd)
+            else:
+                b1 = H.read_all(str(f), careful=careful, **rd)
+        except H.ReadInputError:
+            assert ref.returncode == 1, ref.stderr.decode(errors="replace")[-300:]
+            continue
+        assert ref.returncode == 0, ref.stderr.decode(errors="replace")[-300:]
+        if b1 is None:
+            assert ref.stdout == b""
+            continue
+        if paired:
+            per = R.oracle_search_pairs(oi, opol, b1, b2, cap=cap)
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+        else:
+            per = R.oracle_search(oi, opol, b1, cap=cap)
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+        assert got == ref.stdout
