@@ -203,3 +203,57 @@ def test_fastq_reader_against_the_reference(seed, tiny, tmp_path):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
         assert got == ref.stdout
+
+
+def make_fasta_or_raw(seed):
+    rng = random.Random(5000 + seed)
+    raw = rng.random() < 0.35
+    recs = []
+    for i in range(rng.randrange(1, 8)):
+        s1 = _read(rng)
+        if rng.random() < 0.07:
+            s1 = ""
+        nl = rng.choice(["\n", "\n", "\r\n"])
+        if raw:
+            recs.append(s1)
+        else:
+            name = rng.choice(["r%d" % i, "read %d extra" % i, "", "x/1"])
+            if len(s1) > 6 and rng.random() < 0.3:               # a sequence over two lines
+                k = rng.randrange(1, len(s1))
+                s1 = s1[:k] + nl + s1[k:]
+            recs.append(">" + name + nl + s1)
+    text = rng.choice(["", "\n", "\n\r\n"]) + "".join(r + rng.choice(["\n", "\n", "\n\n", "\r\n"]) for r in recs[:-1]) + recs[-1] + rng.choice(["", "\n", "\n\n"])
+    opts = rng.choice([[], [], ["-5", "2"], ["-3", "3"], ["-5", "1", "-3", "1"], ["-s", "1"], ["-u", "2"]])
+    pol = rng.choice([["-v", "2"], ["-n", "2", "-l", "8"], ["-v", "0"], ["-n", "1", "-l", "6", "-e", "100"]])
+    return text, raw, opts + pol
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_fasta_and_raw_readers_against_the_reference(seed, tiny, tmp_path):
+    base, oi = tiny
+    text, raw, args = make_fasta_or_raw(seed)
+    f = tmp_path / ("in.raw" if raw else "in.fa")
+    f.write_bytes(text.encode())
+    args = ["-r" if raw else "-f"] + args + ["--quiet", "-a"]
+    ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, str(f)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    if b"is less than" in ref.stderr:
+        pytest.skip("a read shorter than the mode allows: the aligner's error, not the reader's")
+    if ref.returncode < 0:
+        pytest.skip("the reference itself crashes on this input (signal %d: one-base reads in -v 0)" % -ref.returncode)
+    import cli_cases as CC
+    rd, pol, out, ex = CC.interpret(args)
+    try:
+        b1 = H.read_all(str(f), **rd)
+    except H.ReadInputError:
+        assert ref.returncode == 1, ref.stderr.decode(errors="replace")[-300:]
+        return
+    assert ref.returncode == 0, ref.stderr.decode(errors="replace")[-300:]
+    if b1 is None:
+        assert ref.stdout == b""
+        return
+    cap = 4096
+    per = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
+    hits, nh, st, pool = H.pack_hits(per, cap)
+    got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, H.out_opts(**out))
+    assert got == ref.stdout
