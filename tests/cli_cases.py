@@ -51,6 +51,7 @@ def interpret(args):
         elif a == "--fr": pol.update(mate1_fw=True, mate2_fw=False)
         elif a == "--nofw": pol["nofw"] = True
         elif a == "--norc": pol["norc"] = True
+        elif a == "--nomaqround": pol["maq_round"] = False
         elif a == "--maxbts": pol["max_bts"] = int(next(it))
         elif a == "-y": pol["max_bts"] = 0x7FFFFFFF
         elif a == "-o": next(it)                       # SA sampling only: results do not depend on it

@@ -1,0 +1,191 @@
+"""Differential test of the search engines against the unmodified reference binary (oracle/_ref) on seeded random
+small genomes -- several sequences, N gaps, repeats, lengths from 8 bases up, so that the '$' row, the eftab, fragment
+ends and reads longer than the genome come up all the time -- with random reads and option sets: the reference's output
+against (a) the oracle and (b) the host build of the device automatons (tests/emu), each between the C++ parser and the
+C++ formatter.  Unpaired through both engines (default and --best / --strata / -M), pairs through --best.  No GPU."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import cli_cases as CC
+import common as T
+import emu_lib as E
+import oracle_lib as OL
+import refrun as R
+from bowtie_amd import _abi as A
+from bowtie_amd import ebwt_build as EB
+from bowtie_amd import hostio as H
+
+REF_BIN = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-s")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="needs the reference binary (make -C oracle ref)")
+
+LUT = np.full(256, 4, np.uint8)
+for _i, _ch in enumerate("ACGT"):
+    LUT[ord(_ch)] = _i
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def make_genome(rng):
+    seqs = []
+    for _ in range(rng.choice([1, 1, 2, 3])):
+        L = rng.choice([8, 12, 20, 40, 80, 150, 300])
+        alpha = rng.choice(["ACGT", "ACGT", "AC", "AAAC"])           # low-complexity genomes make many multi-mappers
+        s = [rng.choice(alpha) for _ in range(L)]
+        if L >= 40 and rng.random() < 0.5:                            # a repeat
+            k = rng.randrange(8, L // 3)
+            a, b = rng.randrange(0, L - k), rng.randrange(0, L - k)
+            s[b:b + k] = s[a:a + k]
+        if L >= 20 and rng.random() < 0.4:                            # an N gap: two fragments
+            a = rng.randrange(2, L - 4)
+            for i in range(a, min(L - 2, a + rng.randrange(1, 5))):
+                s[i] = "N"
+        seqs.append("".join(s))
+    return seqs
+
+
+def make_reads(rng, seqs, n, lens):
+    out = []
+    for i in range(n):
+        L = rng.choice(lens)
+        g = rng.choice(seqs)
+        if len(g) >= L and rng.random() < 0.85:
+            p = rng.randrange(0, len(g) - L + 1)
+            s = list(g[p:p + L].replace("N", "A"))
+            for _ in range(rng.choice([0, 0, 1, 1, 2, 3])):
+                s[rng.randrange(L)] = rng.choice("ACGT")
+            if rng.random() < 0.05:
+                s[rng.randrange(L)] = "N"
+            s = "".join(s)
+            if rng.random() < 0.5:
+                s = _rc(s.replace("N", "X")).replace("X", "N")
+        else:
+            s = "".join(rng.choice("ACGT") for _ in range(L))
+        q = "".join(rng.choice("!+5?IIII") for _ in range(L))
+        out.append(("r%d" % i, s, q))
+    return out
+
+
+UNPAIRED_POLICIES = [
+    ["-v", "0"], ["-v", "1"], ["-v", "2"], ["-n", "0", "-l", "6"], ["-n", "1", "-l", "8"], ["-n", "2", "-l", "10"],
+    ["-n", "3", "-l", "12", "-e", "120"], ["-n", "2", "-l", "8", "-e", "40"], ["-n", "2", "-l", "8", "--nomaqround"],
+    ["-v", "2", "--best"], ["-v", "3"], ["-n", "2", "-l", "8", "--best"], ["-n", "3", "-l", "10", "--best", "--strata", "-k", "3"],
+    ["-v", "2", "--best", "--strata", "-m", "2", "-k", "2"], ["-n", "1", "-l", "6", "--best", "-M", "2"], ["-v", "1", "--best", "-M", "1"],
+]
+REPORTS = [[], [], ["-k", "3"], ["-a"], ["-a"], ["-m", "1"], ["-k", "2", "-m", "3"], ["--nofw"], ["--norc"], ["-a", "--maxbts", "5"]]
+
+
+def _write_fastq(path, reads, mate=0):
+    with open(path, "w") as f:
+        for name, s, q in reads:
+            f.write("@%s%s\n%s\n+\n%s\n" % (name, "/%d" % mate if mate else "", s, q))
+
+
+def _args_ok(args):
+    a = set(args)
+    if "--strata" in a and not ({"-a", "-k", "-m", "-M"} & a):
+        return False
+    return True
+
+
+def _policy(pol):
+    return A.make_policy(**pol)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "600"))))
+def test_unpaired_engines_against_the_reference(seed, tmp_path):
+    rng = random.Random(seed)
+    seqs = make_genome(rng)
+    base = str(tmp_path / "g")
+    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d" % i for i in range(len(seqs))], base,
+                   ftab_chars=rng.choice([1, 2, 3, 4, 6]), off_rate=rng.choice([1, 2, 3, 5]))
+    reads = make_reads(rng, seqs, rng.randrange(4, 14), [4, 5, 7, 10, 12, 16, 22, 30])
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads)
+    for _ in range(3):
+        pol_args = rng.choice(UNPAIRED_POLICIES)
+        rep = [x for x in rng.choice(REPORTS)]
+        if "-M" in pol_args or "-m" in pol_args or ("-k" in pol_args and "-k" in rep):
+            rep = [x for x in rep if x not in ("-m", "-k", "1", "2", "3")] if ("-M" in pol_args or "-m" in pol_args) else []
+        args = pol_args + rep + rng.choice([[], ["-S", "--sam-nohead"]]) + ["--seed", str(rng.randrange(0, 5))]
+        if not _args_ok(args):
+            continue
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, fq],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if ref.returncode != 0:
+            assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
+            continue                                   # a read shorter than the mode allows: the reference stops with an error
+        rd, pol, out, ex = CC.interpret(args)
+        b1 = H.read_all(fq, **rd)
+        oi = OL.OracleIndex(base)
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
+        p = _policy(pol)
+        per_o = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
+        per_e = E.EmuAligner(base).align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5), no_rl=(not p.best and rng.random() < 0.3))
+        for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            assert got == ref.stdout, (who, seqs, args)
+
+
+PAIRED_POLICIES = [["-v", "0"], ["-v", "1"], ["-v", "2"], ["-n", "1", "-l", "8"], ["-n", "2", "-l", "10"], ["-v", "3"], ["-n", "3", "-l", "8", "-e", "100"]]
+PAIRED_REPORTS = [[], ["-k", "2"], ["-a"], ["-m", "1"], ["-a", "--strata"], ["-M", "1"], ["--ff"], ["--rf"], ["--nofw"], ["--allow-contain"], ["--pairtries", "2"]]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "400"))))
+def test_paired_engine_against_the_reference(seed, tmp_path):
+    rng = random.Random(10_000 + seed)
+    seqs = [s for s in make_genome(rng)]
+    seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([60, 120, 250]))))     # room for a fragment
+    base = str(tmp_path / "g")
+    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d" % i for i in range(len(seqs))], base,
+                   ftab_chars=rng.choice([1, 2, 4, 6]), off_rate=rng.choice([1, 3, 5]))
+    m1, m2 = [], []
+    for i in range(rng.randrange(3, 10)):
+        g = rng.choice(seqs)
+        L1, L2 = rng.choice([5, 8, 12, 20]), rng.choice([5, 8, 12, 20])
+        F = rng.randrange(max(L1, L2), max(L1, L2) + 60)
+        if len(g) >= F and rng.random() < 0.85:
+            p = rng.randrange(0, len(g) - F + 1)
+            frag = g[p:p + F].replace("N", "C")
+            a, b = list(frag[:L1]), list(_rc(frag[F - L2:]))
+            for s in (a, b):
+                for _ in range(rng.choice([0, 0, 1, 2])):
+                    s[rng.randrange(len(s))] = rng.choice("ACGT")
+            a, b = "".join(a), "".join(b)
+            if rng.random() < 0.3:
+                a, b = b, a
+        else:
+            a = "".join(rng.choice("ACGT") for _ in range(L1)); b = "".join(rng.choice("ACGT") for _ in range(L2))
+        m1.append(("p%d" % i, a, "".join(rng.choice("!+5?IIII") for _ in a)))
+        m2.append(("p%d" % i, b, "".join(rng.choice("!+5?IIII") for _ in b)))
+    f1, f2 = str(tmp_path / "m_1.fq"), str(tmp_path / "m_2.fq")
+    _write_fastq(f1, m1, 1)
+    _write_fastq(f2, m2, 2)
+    for _ in range(3):
+        args = rng.choice(PAIRED_POLICIES) + ["--best"] + rng.choice(PAIRED_REPORTS) + \
+            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], ["-S", "--sam-nohead"]])
+        if not _args_ok(args):
+            continue
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, "-1", f1, "-2", f2],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if ref.returncode != 0:
+            assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
+            continue
+        rd, pol, out, ex = CC.interpret(args)
+        b1, b2 = H.read_all(f1, mate=1, **rd), H.read_all(f2, mate=2, **rd)
+        oi = OL.OracleIndex(base)
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
+        per_o = R.oracle_search_pairs(oi, OL.make_policy(**pol), b1, b2, cap=cap)
+        per_e = E.EmuAligner(base).align_pairs(_policy(pol), b1, b2, hit_cap=cap)
+        for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            assert got == ref.stdout, (who, seqs, args)
