@@ -140,7 +140,18 @@ PAIRED_REPORTS = [[], ["-k", "2"], ["-a"], ["-m", "1"], ["-a", "--strata"], ["-M
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "400"))))
 def test_paired_engine_against_the_reference(seed, tmp_path):
-    rng = random.Random(10_000 + seed)
+    _paired_fuzz(seed, tmp_path, best=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "400"))))
+def test_paired_engine_without_best_against_the_reference(seed, tmp_path):
+    """PairedBWAlignerV1 (pairs without --best): oracle and the host build of bf_run_pair_v1 (the device code that has
+    not run on a GPU yet)."""
+    _paired_fuzz(seed, tmp_path, best=False)
+
+
+def _paired_fuzz(seed, tmp_path, best):
+    rng = random.Random((10_000 if best else 20_000) + seed)
     seqs = [s for s in make_genome(rng)]
     seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([60, 120, 250]))))     # room for a fragment
     base = str(tmp_path / "g")
@@ -169,7 +180,8 @@ def test_paired_engine_against_the_reference(seed, tmp_path):
     _write_fastq(f1, m1, 1)
     _write_fastq(f2, m2, 2)
     for _ in range(3):
-        args = rng.choice(PAIRED_POLICIES) + ["--best"] + rng.choice(PAIRED_REPORTS) + \
+        args = rng.choice(PAIRED_POLICIES if best else PAIRED_POLICIES[:5] + PAIRED_POLICIES[6:]) + (["--best"] if best else []) + \
+            rng.choice(PAIRED_REPORTS if best else [r for r in PAIRED_REPORTS if "--strata" not in r and "-M" not in r]) + \
             rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], ["-S", "--sam-nohead"]])
         if not _args_ok(args):
             continue
@@ -183,7 +195,9 @@ def test_paired_engine_against_the_reference(seed, tmp_path):
         oi = OL.OracleIndex(base)
         opts = H.out_opts(**out)
         cap = 4096 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
-        per_o = R.oracle_search_pairs(oi, OL.make_policy(**pol), b1, b2, cap=cap)
+        if not best:
+            pol = dict(pol, pe_v1=True)
+        per_o = R.oracle_search_pairs(oi, OL.make_policy(**pol), b1, b2, cap=cap, v1=not best)
         per_e = E.EmuAligner(base).align_pairs(_policy(pol), b1, b2, hit_cap=cap)
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
