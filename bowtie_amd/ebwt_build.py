@@ -349,15 +349,18 @@ def write_index(base: str, arrays: dict, plen: np.ndarray, rstarts: np.ndarray, 
         f.write(np.asarray(a["offs"], dtype="<u4").tobytes())
 
 
-def write_reference(base: str, text: np.ndarray, plen: np.ndarray, rstarts: np.ndarray):
+def write_reference(base: str, text: np.ndarray, plen: np.ndarray, rstarts: np.ndarray, gaps_only=()):
     """`.3.ebwt` / `.4.ebwt` (BitPairReference, reference.h:35-240): per unambiguous stretch a record
     {u32 off = Ns before it, u32 len, u8 first-of-its-sequence}; the stretches' bases 4 per byte, first base
     in the low bits.  `text` = joined text (codes 0..3), rstarts = [nFrag][3] (joined offset, tidx, offset
-    within the sequence)."""
+    within the sequence).  gaps_only: (k, length) for every input sequence that has no base at all and stands
+    before the k-th sequence that has: bowtie-build gives each a record of its own, {length, 0, 0}."""
     rst = np.asarray(rstarts, dtype=np.int64).reshape(-1, 3)
     n = len(text)
     recs = []
     prev_t, prev_end = -1, 0
+    gaps = list(gaps_only)                 # in input order
+    gi = 0
 
     def close_seq():
         # trailing Ns of a sequence get a record of their own with no bases (as bowtie-build writes them)
@@ -371,9 +374,13 @@ def write_reference(base: str, text: np.ndarray, plen: np.ndarray, rstarts: np.n
         if first:
             close_seq()
             prev_end = 0
+            while gi < len(gaps) and gaps[gi][0] <= tidx:
+                recs.append((int(gaps[gi][1]), 0, 0)); gi += 1
         recs.append((foff - prev_end, flen, 1 if first else 0))
         prev_t, prev_end = tidx, foff + flen
     close_seq()
+    while gi < len(gaps):
+        recs.append((int(gaps[gi][1]), 0, 0)); gi += 1
     with open(base + ".3.ebwt", "wb") as f:
         f.write(struct.pack("<iI", 1, len(recs)))
         for off, ln, first in recs:
@@ -404,7 +411,13 @@ def build_index(seqs: Sequence[np.ndarray], names: Sequence[str], base: str, dev
         arr = build_arrays(t, off_rate, ftab_chars)
         del t
         write_index(base + suffix, arr, plen, rstarts, nm)
-    write_reference(base, fw, plen, rstarts)
+    gaps_only, k = [], 0
+    for sq in seqs:
+        if (sq != 4).any():
+            k += 1
+        elif len(sq):
+            gaps_only.append((k, len(sq)))
+    write_reference(base, fw, plen, rstarts, gaps_only)
     return fw
 
 

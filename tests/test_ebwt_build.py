@@ -31,6 +31,7 @@ def read_fa(path):
     lut = np.full(256, 4, np.uint8)
     for i, c in enumerate("ACGT"):
         lut[ord(c)] = i
+        lut[ord(c.lower())] = i
     return names, [lut[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs]
 
 
@@ -75,6 +76,48 @@ def test_random_genome_vs_reference_build(tmp_path):
         names, seqs = read_fa(str(fa))
         EB.build_index(seqs, names, str(tmp_path / "mine"), off_rate=offrate, ftab_chars=ftab)
         assert same(str(tmp_path / "mine"), str(tmp_path / "ref"))
+
+
+@pytest.mark.skipif(not R.have_ref_binary(), reason="needs oracle/_ref/bowtie-build-s")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "60"))))
+def test_random_genomes_vs_reference_build(seed, tmp_path):
+    """Seeded random genomes -- 1 to 6 sequences of 1 to 6000 bases, N runs anywhere (leading, trailing, whole
+    sequences), repeats, homopolymers, lower case -- at random --offrate / --ftabchars: all six files byte for byte."""
+    import random
+    rng = random.Random(seed)
+    recs = []
+    for k in range(rng.randrange(1, 7)):
+        L = rng.choice([1, 3, 8, 30, 100, 500, 2000, 6000])
+        alpha = rng.choice(["ACGT", "ACGT", "ACGT", "AC", "T", "ACGTN"])
+        s = [rng.choice(alpha) for _ in range(L)]
+        for _ in range(rng.choice([0, 0, 1, 3])):
+            a = rng.randrange(0, L); b = min(L, a + rng.choice([1, 2, 5, 40]))
+            s[a:b] = "N" * (b - a)
+        if L >= 100 and rng.random() < 0.5:
+            k2 = rng.randrange(10, L // 3); a = rng.randrange(0, L - k2); b = rng.randrange(0, L - k2)
+            s[b:b + k2] = s[a:a + k2]
+        if rng.random() < 0.1:
+            s = ["N"] * L                                            # a sequence with nothing in it
+        s = "".join(s)
+        if rng.random() < 0.2:
+            s = s.lower()
+        recs.append((">seq%d some description" % k if rng.random() < 0.5 else ">s%d" % k, s))
+    if all(set(s.upper()) <= {"N"} for _, s in recs):
+        recs.append((">last", "ACGTACGTAC"))
+    fa = tmp_path / "r.fa"
+    with open(fa, "w") as f:
+        for h, s in recs:
+            f.write(h + "\n")
+            w = rng.choice([60, 70, 10**9])
+            for i in range(0, len(s), w):
+                f.write(s[i:i + w] + "\n")
+    offrate, ftab = rng.choice([1, 2, 3, 5, 7]), rng.choice([1, 2, 4, 6, 8])
+    subprocess.run([os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-s"), "--offrate", str(offrate),
+                    "--ftabchars", str(ftab), "-q", str(fa), str(tmp_path / "ref")], check=True)
+    names, seqs = read_fa(str(fa))
+    EB.build_index(seqs, names, str(tmp_path / "mine"), off_rate=offrate, ftab_chars=ftab)
+    for e in EXTS:
+        assert open(str(tmp_path / "mine") + "." + e, "rb").read() == open(str(tmp_path / "ref") + "." + e, "rb").read(), e
 
 
 def test_synthetic_genome_index_is_searchable(tmp_path):
