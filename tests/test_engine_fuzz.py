@@ -80,6 +80,23 @@ UNPAIRED_POLICIES = [
 REPORTS = [[], [], ["-k", "3"], ["-a"], ["-a"], ["-m", "1"], ["-k", "2", "-m", "3"], ["--nofw"], ["--norc"], ["-a", "--maxbts", "5"]]
 
 
+def out_options(rng):
+    """A random set of output options: the formatters' columns and SAM fields against the reference's too."""
+    if rng.random() < 0.5:
+        o = ["-S", "--sam-nohead"]
+        for opt, p in ((["--mapq", str(rng.choice([0, 7, 40]))], 0.3), (["--no-unal"], 0.3), (["--fullref"], 0.2),
+                       (["--sam-no-qname-trunc"], 0.2), (["--refidx"], 0.1)):
+            if rng.random() < p:
+                o += opt
+        return o
+    o = []
+    for opt, p in ((["-B", str(rng.choice([1, 5]))], 0.3), (["--refidx"], 0.3), (["--fullref"], 0.2), (["--cost"], 0.3),
+                   (["--showseed"], 0.2), (["--suppress", rng.choice(["1", "2,3", "5,6,7", "8"])], 0.3)):
+        if rng.random() < p:
+            o += opt
+    return o
+
+
 def _write_fastq(path, reads, mate=0):
     with open(path, "w") as f:
         for name, s, q in reads:
@@ -102,7 +119,7 @@ def test_unpaired_engines_against_the_reference(seed, tmp_path):
     rng = random.Random(seed)
     seqs = make_genome(rng)
     base = str(tmp_path / "g")
-    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d" % i for i in range(len(seqs))], base,
+    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d some description" % i if i % 2 == 0 else "t%d" % i for i in range(len(seqs))], base,
                    ftab_chars=rng.choice([1, 2, 3, 4, 6]), off_rate=rng.choice([1, 2, 3, 5]))
     reads = make_reads(rng, seqs, rng.randrange(4, 14), [4, 5, 7, 10, 12, 16, 22, 30])
     fq = str(tmp_path / "r.fq")
@@ -112,7 +129,7 @@ def test_unpaired_engines_against_the_reference(seed, tmp_path):
         rep = [x for x in rng.choice(REPORTS)]
         if "-M" in pol_args or "-m" in pol_args or ("-k" in pol_args and "-k" in rep):
             rep = [x for x in rep if x not in ("-m", "-k", "1", "2", "3")] if ("-M" in pol_args or "-m" in pol_args) else []
-        args = pol_args + rep + rng.choice([[], ["-S", "--sam-nohead"]]) + ["--seed", str(rng.randrange(0, 5))]
+        args = pol_args + rep + out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
         if not _args_ok(args):
             continue
         ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, fq],
@@ -155,7 +172,7 @@ def _paired_fuzz(seed, tmp_path, best):
     seqs = [s for s in make_genome(rng)]
     seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([60, 120, 250]))))     # room for a fragment
     base = str(tmp_path / "g")
-    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d" % i for i in range(len(seqs))], base,
+    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d some description" % i if i % 2 == 0 else "t%d" % i for i in range(len(seqs))], base,
                    ftab_chars=rng.choice([1, 2, 4, 6]), off_rate=rng.choice([1, 3, 5]))
     m1, m2 = [], []
     for i in range(rng.randrange(3, 10)):
@@ -182,7 +199,7 @@ def _paired_fuzz(seed, tmp_path, best):
     for _ in range(3):
         args = rng.choice(PAIRED_POLICIES if best else PAIRED_POLICIES[:5] + PAIRED_POLICIES[6:]) + (["--best"] if best else []) + \
             rng.choice(PAIRED_REPORTS if best else [r for r in PAIRED_REPORTS if "--strata" not in r and "-M" not in r]) + \
-            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], ["-S", "--sam-nohead"]])
+            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + out_options(rng)
         if not _args_ok(args):
             continue
         ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, "-1", f1, "-2", f2],
