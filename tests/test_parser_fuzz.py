@@ -257,3 +257,44 @@ def test_fasta_and_raw_readers_against_the_reference(seed, tiny, tmp_path):
     hits, nh, st, pool = H.pack_hits(per, cap)
     got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, H.out_opts(**out))
     assert got == ref.stdout
+
+
+def test_parsers_under_address_and_ub_sanitizers(tmp_path):
+    """tests/emu/io_asan.cpp: bt_io.cpp's readers built with -fsanitize=address,undefined, over the fuzz files of this module
+    in every format and mate mode plus files of random bytes, in batches of 1 to 3 reads."""
+    exe = str(tmp_path / "io_asan")
+    r = subprocess.run(["g++", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-std=c++17", "-w",
+                        "-o", exe, os.path.join(T.ROOT, "tests", "emu", "io_asan.cpp"), os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_io.cpp"),
+                        "-lz", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    runs = []
+
+    def add(fmt, flags, path, t5=0, t3=0, batch=3):
+        runs.append([exe, str(fmt), str(flags), str(t5), str(t3), str(batch), path])
+
+    for seed in range(60):
+        for maker, name, fmts in ((make_file, "t.tab", [(5, fl) for fl in (0, 4, 8, 2)]),
+                                  (make_fastq, "q.fq", [(0, fl) for fl in (0, 1, 2, 4 | 16, 8 | 16)])):
+            text = maker(seed)[0]
+            path = str(tmp_path / ("%d%s" % (seed, name)))
+            with open(path, "wb") as f:
+                f.write(text.encode())
+            for fmt, fl in fmts:
+                add(fmt, fl, path, seed % 3, seed % 2, 2)
+        text, raw, _ = make_fasta_or_raw(seed)
+        path = str(tmp_path / ("%df" % seed))
+        with open(path, "wb") as f:
+            f.write(text.encode())
+        add(2 if raw else 1, 0, path, seed % 3, seed % 2)
+        if not raw:
+            add(4, 0, path)
+        rng = random.Random(seed)
+        path = str(tmp_path / ("%dj" % seed))
+        with open(path, "wb") as f:
+            f.write(bytes(rng.choice(b"ACGTN@+>\t\n\r I!5") for _ in range(rng.randrange(0, 200))))
+        for fmt in (0, 1, 2, 4, 5):
+            add(fmt, 2, path, 1, 1, 1)
+    for cmd in runs:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert p.returncode == 0 and b"ERROR" not in p.stderr and b"runtime error" not in p.stderr, (cmd[1:], p.stderr.decode(errors="replace")[-800:])
