@@ -269,3 +269,49 @@ def test_loader_survives_damaged_index_files(tmp_path):
         assert p.returncode == 0 and b"ERROR" not in p.stderr and b"runtime error" not in p.stderr, (seed, e, kind, p.stderr.decode(errors="replace")[-800:])
         seen.add(p.stdout.split(b" len")[0])
     assert len(seen) >= 4          # loaded, and each of the three parts refused at least once
+
+
+BUILD_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-l")
+
+
+@pytest.mark.skipif(not os.path.exists(BUILD_L), reason="needs oracle/_ref/bowtie-build-l")
+@pytest.mark.parametrize("seed", range(40))
+def test_random_genomes_every_family_member_loads_to_the_same_image(seed, tmp_path):
+    """Seeded random genomes (several sequences, N gaps, all-N sequences aside): the small index, bowtie-build-l's 64-bit
+    index of the same FASTA, and the other-endian and .bt2-layout re-writes all load to one image (same digest of every
+    array), forward and mirror, and the BWT inverts to the genome."""
+    import random
+    from bowtie_amd import ebwt_build as EB
+    from test_ebwt_build import read_fa
+    rng = random.Random(seed)
+    recs = []
+    for k in range(rng.randrange(1, 5)):
+        L = rng.choice([8, 30, 100, 500, 2000])
+        s = [rng.choice(rng.choice(["ACGT", "ACGT", "AC"])) for _ in range(L)]
+        for _ in range(rng.choice([0, 0, 1, 2])):
+            a = rng.randrange(0, L)
+            b = min(L, a + rng.choice([1, 2, 5, 40]))
+            s[a:b] = "N" * (b - a)
+        if all(c == "N" for c in s):
+            s[0] = "A"
+        recs.append((">s%d words" % k, "".join(s)))
+    fa = str(tmp_path / "r.fa")
+    with open(fa, "w") as f:
+        for h, s in recs:
+            f.write(h + "\n" + s + "\n")
+    off, ftab = rng.choice([1, 3, 5]), rng.choice([1, 3, 6])
+    names, seqs = read_fa(fa)
+    small = str(tmp_path / "small")
+    EB.build_index(seqs, names, small, off_rate=off, ftab_chars=ftab)
+    large = str(tmp_path / "large")
+    subprocess.run([BUILD_L, "--offrate", str(off), "--ftabchars", str(ftab), "-q", fa, large], check=True, stderr=subprocess.DEVNULL)
+    V.write_swapped(small, str(tmp_path / "be"))
+    V.write_bt2(small, str(tmp_path / "bt2"))
+    for mirror in (False, True):
+        want = AL.index_digest(small, mirror)
+        for other, variant in ((large, A.BT_INDEX_EBWTL), (str(tmp_path / "be"), A.BT_INDEX_EBWT | A.BT_INDEX_SWAPPED), (str(tmp_path / "bt2"), A.BT_INDEX_BT2)):
+            got = AL.index_digest(other, mirror)
+            assert got[0] == variant and got[1:] == want[1:], (other, mirror)
+    text = np.concatenate([sq[sq != 4] for sq in seqs])
+    for b in (small, large, str(tmp_path / "bt2")):
+        assert (AL.restore_text(b) == text).all()
