@@ -466,7 +466,6 @@ void parse_args(int argc, char** argv, Options* O)
 		if (c1 != c2 && O->rd.format != BT_FMT_CMDLINE)
 			die("Error: %zu mate files/sequences were specified with -1, but %zu\nmate files/sequences were specified with -2.  The same number of mate files/\nsequences must be specified with -1 and -2.", c1, c2);
 		if (!O->pol.best) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
-		if (!O->dump_al.empty() || !O->dump_un.empty() || !O->dump_max.empty()) die("Error: --al/--un/--max with paired-end reads are not in this build");
 	} else if (one_file) {
 		O->reads = O->tab12;
 	} else {
@@ -901,6 +900,7 @@ int main(int argc, char** argv)
 	bt_out_tally tally = {0, 0, 0, 0, 0, 0};
 	std::string fatal;
 	FILE *f_al = nullptr, *f_un = nullptr, *f_max = nullptr;
+	FILE *f_al2 = nullptr, *f_un2 = nullptr, *f_max2 = nullptr;      /* pairs: the second mates' files */
 	std::thread writer([&] {
 		std::vector<std::unique_ptr<Job>> held;              /* finished out of turn */
 		uint64_t next_seq = 0; int lasts = 0;
@@ -989,6 +989,11 @@ int main(int argc, char** argv)
 				 * the input; files are created when the first read goes to them; without --max, reads over
 				 * the -m ceiling go to --un */
 				const BtHostBatch& sb = *j->store;
+				/* pairs: each mate's record to <name>_1<.ext> / <name>_2<.ext> (HitSink::openOf, hit.h:629-660) -- except
+				 * for --12 input, whose one record per pair goes to <name> as it is (onePairFile_); the -m ceiling counts
+				 * mate alignments, two per pair */
+				const bool two_files = O.paired && !tabbed;
+				const uint32_t ceiling = O.paired ? (O.pol.mhits == 0xffffffffu ? 0xffffffffu : O.pol.mhits * 2u) : O.pol.mhits;
 				size_t wi = 0;
 				for (uint32_t i = 0; i < n; i++) {
 					uint32_t tot = j->n_hits[i];
@@ -996,11 +1001,20 @@ int main(int argc, char** argv)
 					if (wi < j->wide.size() && j->wide[wi].read == i) tot = j->wide[wi].n_hits;
 					FILE** f; const std::string* nm;
 					if (tot == 0) { f = &f_un; nm = &O.dump_un; }
-					else if (tot > O.pol.mhits) { if (!O.dump_max.empty()) { f = &f_max; nm = &O.dump_max; } else { f = &f_un; nm = &O.dump_un; } }
+					else if (tot > ceiling) { if (!O.dump_max.empty()) { f = &f_max; nm = &O.dump_max; } else { f = &f_un; nm = &O.dump_un; } }
 					else { f = &f_al; nm = &O.dump_al; }
 					if (nm->empty()) continue;
-					if (!*f) { *f = fopen(nm->c_str(), "wb"); if (!*f) { if (fatal.empty()) fatal = "Error: could not open read dump file " + *nm; abort_run.store(true); break; } }
+					FILE** f2 = f == &f_un ? &f_un2 : f == &f_max ? &f_max2 : &f_al2;
+					if (!*f) {
+						const size_t dot = nm->find_last_of('.');
+						const std::string n1 = !two_files ? *nm : dot == std::string::npos ? *nm + "_1" : nm->substr(0, dot) + "_1" + nm->substr(dot);
+						const std::string n2 = dot == std::string::npos ? *nm + "_2" : nm->substr(0, dot) + "_2" + nm->substr(dot);
+						*f = fopen(n1.c_str(), "wb");
+						if (two_files) *f2 = fopen(n2.c_str(), "wb");
+						if (!*f || (two_files && !*f2)) { if (fatal.empty()) fatal = "Error: could not open read dump file " + *nm; abort_run.store(true); break; }
+					}
 					fwrite(sb.raw.data() + sb.raw_off[i], 1, (size_t)(sb.raw_off[i + 1] - sb.raw_off[i]), *f);
+					if (two_files) { const BtHostBatch& s2 = *j->store2; fwrite(s2.raw.data() + s2.raw_off[i], 1, (size_t)(s2.raw_off[i + 1] - s2.raw_off[i]), *f2); }
 				}
 			}
 			busy_write += now_s() - tb;
@@ -1086,6 +1100,9 @@ int main(int argc, char** argv)
 	if (f_al) fclose(f_al);
 	if (f_un) fclose(f_un);
 	if (f_max) fclose(f_max);
+	if (f_al2) fclose(f_al2);
+	if (f_un2) fclose(f_un2);
+	if (f_max2) fclose(f_max2);
 	bt_io_close(rs);
 	if (rs2) bt_io_close(rs2);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);

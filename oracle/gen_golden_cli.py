@@ -186,6 +186,8 @@ def cases(plain):
         ("pe_n1_k3_sam", M, ["--best", "-n", "1", "-k", "3", "-X", "350", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_a_strata_cost", M, ["--best", "--strata", "-a", "-v", "2", "-X", "400", "--cost", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_m1_I100", M, ["--best", "-m", "1", "-I", "100", "-X", "300", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_dump_m1", M, ["--best", "-m", "1", "-X", "400", "--al", "AL", "--un", "UN", "--max", "MAX", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
+        ("pe_dump_M1_nomax_sam", M, ["--best", "-M", "1", "-X", "400", "-S", "--sam-nohead", "--al", "AL", "--un", "UN", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_M1_sam", M, ["--best", "-M", "1", "-X", "400", "-S", "--sam-nohead", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_M2_strata_default", M, ["--best", "--strata", "-M", "2", "-v", "2", "-X", "400", "--cost", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
         ("pe_trim_ff", M, ["--best", "--ff", "-5", "2", "-3", "3", "-X", "300", "-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], ""),
@@ -202,16 +204,19 @@ def main():
         cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + [dump_paths.get(a, a) for a in args] + ["-x", idx] + ([reads] if reads else [])
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=G)
         dumps = {}
+        paired_dumps = "-1" in args and bool(dump_paths)        # pairs: <name>_1.txt and <name>_2.txt (hit.h:629-660)
         for k, path in dump_paths.items():
-            data = b""
-            if os.path.exists(path):
-                with open(path, "rb") as f:
-                    data = f.read()
-                os.remove(path)
-            fn = "cli/%s.%s.gz" % (name, k.lower())
-            with gzip.GzipFile(os.path.join(G, fn), "wb", mtime=0) as f:
-                f.write(data)
-            dumps[k] = fn
+            for tag in (("_1", "_2") if paired_dumps else ("",)):
+                src = path[:-4] + tag + ".txt"
+                data = b""
+                if os.path.exists(src):
+                    with open(src, "rb") as f:
+                        data = f.read()
+                    os.remove(src)
+                fn = "cli/%s.%s%s.gz" % (name, k.lower(), tag)
+                with gzip.GzipFile(os.path.join(G, fn), "wb", mtime=0) as f:
+                    f.write(data)
+                dumps[k + tag] = fn
         entry = {"name": name, "index": idx, "args": args, "reads": reads, "returncode": p.returncode, "dumps": dumps,
                  "stderr": p.stderr.decode(errors="replace").strip().split("\n"),
                  "md5": hashlib.md5(p.stdout).hexdigest(), "file": "cli/%s.out.gz" % name}

@@ -21,8 +21,10 @@ def run(args, index, reads, extra=()):
 
 def with_dump_paths(case, tmp_path):
     """AL / UN / MAX in a case's arguments stand for dump files: real paths for this run."""
-    paths = {k: str(tmp_path / (k + ".txt")) for k in case.get("dumps", {})}
-    return [paths.get(a, a) for a in case["args"]], paths
+    # pairs: the keys are AL_1, AL_2, ... -- the files bowtie makes of the name AL.txt (hit.h:629-660)
+    dumps = case.get("dumps", {})
+    paths = {k.split("_")[0]: str(tmp_path / (k.split("_")[0] + ".txt")) for k in dumps}
+    return [paths.get(a, a) for a in case["args"]], {k: str(tmp_path / (k + ".txt")) for k in dumps}
 
 
 def split_pg(text: bytes):

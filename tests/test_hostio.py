@@ -16,8 +16,9 @@ from bowtie_amd.reads import pack_reads, parse_fastq
 def run_case_paired(case, rd, pol, out, ex):
     oi = T.oracle_index(case["index"])
     spec = lambda x: ",".join(os.path.join(T.G, f) for f in x.split(","))
-    b1 = H.read_all(spec(ex["mates1"]), mate=1, **rd)
-    b2 = H.read_all(spec(ex["mates2"]), mate=2, **rd)
+    b1 = H.read_all(spec(ex["mates1"]), mate=1, keep_raw=bool(case.get("dumps")), **rd)
+    b2 = H.read_all(spec(ex["mates2"]), mate=2, keep_raw=bool(case.get("dumps")), **rd)
+    ex["b2"] = b2
     # the insert limits as the aligner sees them: less the trimming at the fragment's outer ends (aligner.h:1921-1935)
     o1 = rd.get("trim5", 0) if pol.get("mate1_fw", True) else rd.get("trim3", 0)
     o2 = rd.get("trim3", 0) if pol.get("mate2_fw", False) else rd.get("trim5", 0)
@@ -60,7 +61,17 @@ def test_parse_and_format_match_reference(case):
         for i, (a, b) in enumerate(zip(g, w)):
             assert a == b, "%s: line %d" % (case["name"], i)
         assert len(g) == len(w), case["name"]
-    if case.get("dumps"):
+    if case.get("dumps") and "b2" in ex:
+        # pairs: first mates' records to <name>_1, second mates' to <name>_2; the ceiling counts mate alignments
+        ceiling = 0xFFFFFFFF if opts.mhits == 0xFFFFFFFF else 2 * opts.mhits
+        got = {k + t: b"" for k in ("AL", "UN", "MAX") for t in ("_1", "_2")}
+        for r1, r2, (hs, tot, st) in zip(batch.raw, ex["b2"].raw, ex["per_read"]):
+            k = "UN" if tot == 0 else ("AL" if tot <= ceiling else ("MAX" if "MAX_1" in case["dumps"] else "UN"))
+            got[k + "_1"] += r1
+            got[k + "_2"] += r2
+        for k in case["dumps"]:
+            assert got[k] == CC.expected_dump(case, k), (case["name"], k)
+    elif case.get("dumps"):
         # --al / --un / --max: each read's record text goes to the file of its class (hit.h:385-488)
         mhits = opts.mhits
         got = {"AL": b"", "UN": b"", "MAX": b""}
