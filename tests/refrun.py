@@ -6,7 +6,7 @@ import os
 import subprocess
 from typing import List, Optional
 
-from bowtie_amd import output as O
+import pyformat as O
 from bowtie_amd.reads import ReadBatch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
