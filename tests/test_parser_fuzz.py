@@ -298,3 +298,80 @@ def test_parsers_under_address_and_ub_sanitizers(tmp_path):
     for cmd in runs:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         assert p.returncode == 0 and b"ERROR" not in p.stderr and b"runtime error" not in p.stderr, (cmd[1:], p.stderr.decode(errors="replace")[-800:])
+
+
+def make_other(seed):
+    """-c sequences, -F k-mers of FASTA records, and FASTQ in the other quality encodings."""
+    rng = random.Random(9000 + seed)
+    kind = rng.choice(["cmdline", "cont", "phred64", "solexa", "int", "int-solexa"])
+    pol = rng.choice([["-v", "2"], ["-n", "2", "-l", "8"], ["-v", "1"]])
+    opts = rng.choice([[], [], ["-5", "2"], ["-3", "3"], ["-s", "1"], ["-u", "2"]])
+    if kind == "cmdline":
+        items = []
+        for i in range(rng.randrange(1, 6)):
+            s1 = _read(rng)
+            items.append(s1 + (":" + _quals(rng, s1, False) if rng.random() < 0.5 else ""))
+        return kind, None, ["-c"] + opts + pol, ",".join(items)
+    if kind == "cont":
+        recs = []
+        for i in range(rng.randrange(1, 4)):
+            L = rng.choice([5, 12, 30, 60])
+            p = rng.randrange(0, len(GENOME) - L)
+            s1 = GENOME[p:p + L]
+            if rng.random() < 0.3:
+                k = rng.randrange(L); s1 = s1[:k] + rng.choice("N-.x") + s1[k:]
+            if L > 20 and rng.random() < 0.5:
+                s1 = s1[:17] + "\n" + s1[17:]
+            recs.append(">" + rng.choice(["c%d" % i, "c%d more words" % i, ""]) + "\n" + s1 + "\n")
+        return kind, "".join(recs), ["-F", "%d,%d" % (rng.choice([4, 6, 9, 15]), rng.choice([1, 2, 5]))] + pol, None
+    recs = []
+    for i in range(rng.randrange(1, 6)):
+        s1 = "".join(ch for ch in _read(rng) if ch.isalpha())
+        ph = [rng.choice([0, 2, 10, 20, 30, 40]) for _ in s1]
+        if kind == "phred64":
+            q = "".join(chr(64 + v) for v in ph)
+        elif kind == "solexa":
+            q = "".join(chr(64 + v - rng.choice([0, 0, 5])) for v in ph)            # Solexa scale goes below 0
+        else:
+            q = " ".join(str(v - (rng.choice([0, 3]) if kind == "int-solexa" else 0)) for v in ph)
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, s1, q))
+    flag = {"phred64": ["--phred64-quals"], "solexa": ["--solexa-quals"], "int": ["--integer-quals"],
+            "int-solexa": ["--integer-quals", "--solexa-quals"]}[kind]
+    return kind, "".join(recs), flag + opts + pol, None
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_other_input_options_against_the_reference(seed, tiny, tmp_path):
+    base, oi = tiny
+    kind, text, args, cseq = make_other(seed)
+    args = args + ["--quiet", "-a"]
+    if text is not None:
+        f = tmp_path / ("in.fa" if kind == "cont" else "in.fq")
+        f.write_bytes(text.encode())
+        src = str(f)
+    else:
+        src = cseq
+    ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, src],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    if b"is less than" in ref.stderr or b"Reads must be" in ref.stderr or ref.returncode < 0 or (ref.returncode != 0 and "-u" in args):
+        pytest.skip("the aligner's error / a crash of the reference / the read past -u")
+    if "--integer-quals" in args and ("-3" in args or "-5" in args):
+        # known deviation (DESIGN.md 5): the reference leaves integer qualities untrimmed at the 3' end (pat.cpp:918-936), so
+        # its reads then carry more qualities than bases; this reader trims both alike
+        pytest.skip("trimming with --integer-quals: the reference's quality string keeps its trimmed end")
+    import cli_cases as CC
+    rd, pol, out, ex = CC.interpret(args)
+    try:
+        b1 = H.read_all(src, **rd)
+    except H.ReadInputError:
+        assert ref.returncode == 1, ref.stderr.decode(errors="replace")[-300:]
+        return
+    assert ref.returncode == 0, ref.stderr.decode(errors="replace")[-300:]
+    if b1 is None:
+        assert ref.stdout == b""
+        return
+    cap = 4096
+    per = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
+    hits, nh, st, pool = H.pack_hits(per, cap)
+    got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, H.out_opts(**out))
+    assert got == ref.stdout
