@@ -273,7 +273,7 @@ def test_parsers_under_address_and_ub_sanitizers(tmp_path):
     def add(fmt, flags, path, t5=0, t3=0, batch=3):
         runs.append([exe, str(fmt), str(flags), str(t5), str(t3), str(batch), path])
 
-    for seed in range(60):
+    for seed in range(30):
         for maker, name, fmts in ((make_file, "t.tab", [(5, fl) for fl in (0, 4, 8, 2)]),
                                   (make_fastq, "q.fq", [(0, fl) for fl in (0, 1, 2, 4 | 16, 8 | 16)])):
             text = maker(seed)[0]
