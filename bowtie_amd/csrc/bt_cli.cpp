@@ -455,6 +455,9 @@ void parse_args(int argc, char** argv, Options* O)
 		if (!O->mates1.empty() || !O->mates2.empty() || (!O->tab12.empty() && !O->ileaved.empty()))
 			die("Error: --12 / --interleaved cannot be combined with -1/-2 or with each other in this build");
 		if (!O->pol.best) die("Error: --12 / --interleaved input runs the reference's stateful aligners, which this build has for --best only; add --best");
+		/* both mate streams open the file, and a --12 file is looked into beforehand: not possible with a pipe */
+		for (const std::string& f : split_commas(O->tab12.empty() ? O->ileaved : O->tab12))
+			if (f == "-") die("Error: --12 / --interleaved input from standard input is not in this build; give a file");
 		if (!O->ileaved.empty()) { O->mates1 = O->mates2 = O->ileaved; O->interleaved = true; }
 		else if (tabbed_is_paired(O->tab12, O->rd)) O->mates1 = O->mates2 = O->tab12;
 	}

@@ -34,6 +34,7 @@ def test_version_and_help():
     (["--best", "-1", "a.fq,c.fq", "-2", "b.fq", "-x", "e_coli"], "must be specified with -1 and -2"),
     (["--12", "a.tab", "-x", "e_coli"], "add --best"),
     (["--interleaved", "a.fq", "-x", "e_coli"], "add --best"),
+    (["--best", "--12", "-", "-x", "e_coli"], "standard input"),
     (["--best", "--12", "a.tab", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "cannot be combined"),
     (["-Q", "a.qual", "-x", "e_coli", "cli/io.fq"], "go with -f"),
     (["--pev2", "-x", "e_coli", "cli/io.fq"], "does not have"),
