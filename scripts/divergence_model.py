@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--reads", type=int, default=6000)
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--index", default=os.path.join(ROOT, "tests/golden/e_coli"))
+    ap.add_argument("--synthetic", type=int, default=0, help="index a synthetic genome of this many bases (the benchmark's generator) instead")
     ap.add_argument("--top", type=float, default=6.0, help="cost of the request-issue-and-rank section in state-block units")
     a = ap.parse_args()
     build_probe()
@@ -80,8 +81,15 @@ def main():
     from bowtie_amd import _abi as A
     from bowtie_amd.synth import synth_reads
     import common as T
-    text = T.joined_text(os.path.basename(a.index)) if os.path.basename(a.index) in ("e_coli", "multi") else None
-    assert text is not None, "give one of the fixture indexes"
+    if a.synthetic:
+        # the benchmark's synthetic genome (repeat families and all) at a size the CPU indexes in a minute
+        import torch
+        from bowtie_amd import ebwt_build as EB
+        a.index, text, note = EB.ensure_big_index(a.synthetic, torch.device("cpu"), cache_dir=W)
+        print(note)
+    else:
+        text = T.joined_text(os.path.basename(a.index)) if os.path.basename(a.index) in ("e_coli", "multi") else None
+        assert text is not None, "give one of the fixture indexes, or --synthetic <bp>"
     batch = synth_reads(text, a.reads, a.len, mm_dist=(0, 1, 2, 2, 3, 4), seed=11)
     L = E.lib()
     L.emu_trace.restype = C.POINTER(C.c_uint64)
