@@ -223,3 +223,74 @@ def _paired_fuzz(seed, tmp_path, best):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
             assert got == ref.stdout, (who, seqs, args)
+
+
+MEDIUM_POLICIES = [
+    ["-n", "2"], ["-n", "2", "-l", "28", "-e", "70"], ["-n", "3", "-l", "20", "-e", "140"], ["-n", "1", "-l", "36"], ["-n", "0"],
+    ["-v", "2"], ["-v", "1"], ["-v", "3"], ["-n", "2", "-y"], ["-n", "2", "--maxbts", "20"], ["-n", "3", "--nomaqround", "-e", "90"],
+    ["-n", "2", "--best"], ["-n", "3", "-l", "24", "--best", "--strata", "-k", "4"], ["-v", "2", "--best", "-M", "3"], ["-n", "2", "--best", "-m", "2"],
+]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_MEDIUM_SEEDS", "4"))))
+def test_unpaired_engines_on_medium_genomes_against_the_reference(seed, tmp_path):
+    """The same on genomes of 2 to 50 kbp with repeat families and real read lengths (36 to 100 bases), at the reference's
+    default index parameters: deeper backtracking, seed extension, the quality budget."""
+    rng = random.Random(50_000 + seed)
+    L = rng.choice([2000, 10000, 50000])
+    fam = ["".join(rng.choice("ACGT") for _ in range(rng.choice([60, 150, 400]))) for _ in range(3)]
+    s = [rng.choice("ACGT") for _ in range(L)]
+    for _ in range(L // 600):
+        f = list(rng.choice(fam))
+        for _ in range(rng.choice([0, 1, 3, 8])):
+            f[rng.randrange(len(f))] = rng.choice("ACGT")
+        p = rng.randrange(0, L - len(f))
+        s[p:p + len(f)] = f
+    if rng.random() < 0.5:
+        p = rng.randrange(100, L - 100)
+        s[p:p + rng.choice([1, 10, 50])] = "N" * len(s[p:p + rng.choice([1, 10, 50])])
+    seqs = ["".join(s)]
+    if rng.random() < 0.5:
+        seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([300, 3000]))))
+    base = str(tmp_path / "g")
+    EB.build_index([LUT[np.frombuffer(x.encode(), dtype=np.uint8)] for x in seqs], ["chr%d desc" % i for i in range(len(seqs))], base,
+                   ftab_chars=rng.choice([6, 8, 10]), off_rate=rng.choice([3, 5]))
+    rl = rng.choice([36, 50, 76, 100])
+    reads = []
+    for i in range(rng.randrange(15, 40)):
+        g = rng.choice(seqs)
+        p = rng.randrange(0, len(g) - rl)
+        r = list(g[p:p + rl].replace("N", "A"))
+        for _ in range(rng.choice([0, 1, 2, 2, 3, 4, 6])):
+            r[rng.randrange(rl)] = rng.choice("ACGT")
+        r = "".join(r)
+        if rng.random() < 0.5:
+            r = _rc(r)
+        q = "".join(rng.choice("#+5:?DIIII") for _ in range(rl))
+        reads.append(("r%d" % i, r, q))
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads)
+    for _ in range(2):
+        pol_args = rng.choice(MEDIUM_POLICIES)
+        rep = rng.choice([[], [], ["-k", "3"], ["-a"], ["-m", "1"], ["--nofw"], ["--norc"]])
+        if "-M" in pol_args or "-m" in pol_args or "-k" in pol_args:
+            rep = [x for x in rep if x in ("--nofw", "--norc")]
+        args = pol_args + rep + out_options(rng) + ["--seed", str(rng.randrange(0, 3))]
+        if not _args_ok(args):
+            continue
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, fq],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert ref.returncode == 0, (args, ref.stderr[-300:])
+        rd, pol, out, ex = CC.interpret(args)
+        b1 = H.read_all(fq, **rd)
+        oi = OL.OracleIndex(base)
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
+        p = _policy(pol)
+        per_o = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
+        per_e = E.EmuAligner(base).align(p, b1, hit_cap=cap, lite=(not p.best and rl <= 100 and rng.random() < 0.5),
+                                         no_rl=(not p.best and rng.random() < 0.3), pal_cap=16384)
+        for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            assert got == ref.stdout, (who, args)
