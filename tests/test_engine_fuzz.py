@@ -294,3 +294,70 @@ def test_unpaired_engines_on_medium_genomes_against_the_reference(seed, tmp_path
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
             assert got == ref.stdout, (who, args)
+
+
+def _medium_genome(rng):
+    L = rng.choice([2000, 10000, 50000])
+    fam = ["".join(rng.choice("ACGT") for _ in range(rng.choice([60, 150, 400]))) for _ in range(3)]
+    s = [rng.choice("ACGT") for _ in range(L)]
+    for _ in range(L // 600):
+        f = list(rng.choice(fam))
+        for _ in range(rng.choice([0, 1, 3, 8])):
+            f[rng.randrange(len(f))] = rng.choice("ACGT")
+        p = rng.randrange(0, L - len(f))
+        s[p:p + len(f)] = f
+    seqs = ["".join(s)]
+    if rng.random() < 0.5:
+        seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([600, 3000]))))
+    return seqs
+
+
+@pytest.mark.parametrize("best", [True, False], ids=["best", "without_best"])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_MEDIUM_SEEDS", "3"))))
+def test_paired_engines_on_medium_genomes_against_the_reference(seed, best, tmp_path):
+    rng = random.Random(70_000 + seed)
+    seqs = _medium_genome(rng)
+    base = str(tmp_path / "g")
+    EB.build_index([LUT[np.frombuffer(x.encode(), dtype=np.uint8)] for x in seqs], ["chr%d desc" % i for i in range(len(seqs))], base,
+                   ftab_chars=rng.choice([6, 8, 10]), off_rate=rng.choice([3, 5]))
+    rl = rng.choice([36, 50, 75])
+    m1, m2 = [], []
+    for i in range(rng.randrange(10, 30)):
+        g = rng.choice(seqs)
+        F = rng.randrange(max(rl, 120), min(len(g), 450))
+        p = rng.randrange(0, len(g) - F + 1)
+        frag = g[p:p + F].replace("N", "C")
+        a, b = list(frag[:rl]), list(_rc(frag[F - rl:]))
+        for x in (a, b):
+            for _ in range(rng.choice([0, 0, 1, 2, 3])):
+                x[rng.randrange(rl)] = rng.choice("ACGT")
+        a, b = "".join(a), "".join(b)
+        if rng.random() < 0.2:
+            a, b = b, a
+        m1.append(("p%d" % i, a, "".join(rng.choice("#+5:?DIIII") for _ in a)))
+        m2.append(("p%d" % i, b, "".join(rng.choice("#+5:?DIIII") for _ in b)))
+    f1, f2 = str(tmp_path / "m_1.fq"), str(tmp_path / "m_2.fq")
+    _write_fastq(f1, m1, 1)
+    _write_fastq(f2, m2, 2)
+    pols = [["-n", "2"], ["-n", "1", "-l", "30"], ["-v", "2"], ["-v", "0"], ["-n", "3", "-e", "120"], ["-v", "1"]] + ([["-v", "3"]] if best else [])
+    reps = [[], ["-k", "2"], ["-a"], ["-m", "1"], ["--ff"], ["--nofw"], ["--pairtries", "3"]] + ([["-M", "1"], ["-a", "--strata"]] if best else [])
+    for _ in range(2):
+        args = rng.choice(pols) + (["--best"] if best else []) + rng.choice(reps) + rng.choice([["-X", "500"], ["-X", "300", "-I", "100"], []]) + out_options(rng)
+        if not _args_ok(args):
+            continue
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, "-1", f1, "-2", f2],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert ref.returncode == 0, (args, ref.stderr[-300:])
+        rd, pol, out, ex = CC.interpret(args)
+        if not best:
+            pol = dict(pol, pe_v1=True)
+        b1, b2 = H.read_all(f1, mate=1, **rd), H.read_all(f2, mate=2, **rd)
+        oi = OL.OracleIndex(base)
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
+        per_o = R.oracle_search_pairs(oi, OL.make_policy(**pol), b1, b2, cap=cap, v1=not best)
+        per_e = E.EmuAligner(base).align_pairs(_policy(pol), b1, b2, hit_cap=cap)
+        for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            assert got == ref.stdout, (who, args)
