@@ -114,7 +114,7 @@ def _policy(pol):
     return A.make_policy(**pol)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "600"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "250"))))
 def test_unpaired_engines_against_the_reference(seed, tmp_path):
     rng = random.Random(seed)
     seqs = make_genome(rng)
@@ -158,12 +158,12 @@ PAIRED_POLICIES = [["-v", "0"], ["-v", "1"], ["-v", "2"], ["-n", "1", "-l", "8"]
 PAIRED_REPORTS = [[], ["-k", "2"], ["-a"], ["-m", "1"], ["-a", "--strata"], ["-M", "1"], ["--ff"], ["--rf"], ["--nofw"], ["--allow-contain"], ["--pairtries", "2"]]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "200"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "120"))))
 def test_paired_engine_against_the_reference(seed, tmp_path):
     _paired_fuzz(seed, tmp_path, best=True)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "150"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "100"))))
 def test_paired_engine_without_best_against_the_reference(seed, tmp_path):
     """PairedBWAlignerV1 (pairs without --best): oracle and the host build of bf_run_pair_v1 (the device code that has
     not run on a GPU yet)."""
