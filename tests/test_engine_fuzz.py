@@ -361,3 +361,53 @@ def test_paired_engines_on_medium_genomes_against_the_reference(seed, best, tmp_
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
             assert got == ref.stdout, (who, args)
+
+
+REF_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-l")
+BUILD_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-l")
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_L) and os.path.exists(BUILD_L)), reason="needs the 64-bit reference binaries (make -C oracle ref)")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "60"))))
+def test_the_64_bit_build_against_bowtie_align_l(seed, tmp_path):
+    """bowtie-align-l on bowtie-build-l's index of the same random genomes (its two visible differences from the 32-bit
+    build: two generator draws per reported row range, a smaller branch pool): against the oracle in its 64-bit mode on
+    the small index, and against the host build of the device automatons on the .ebwtl files as the loader converts them."""
+    rng = random.Random(30_000 + seed)
+    seqs = make_genome(rng)
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        for i, sq in enumerate(seqs):
+            f.write(">s%d words\n%s\n" % (i, sq))
+    off, ftab = rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 3, 4, 6])
+    small, large = str(tmp_path / "small"), str(tmp_path / "large")
+    EB.build_index([LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d words" % i for i in range(len(seqs))], small, ftab_chars=ftab, off_rate=off)
+    subprocess.run([BUILD_L, "--offrate", str(off), "--ftabchars", str(ftab), "-q", fa, large], check=True, stderr=subprocess.DEVNULL)
+    reads = make_reads(rng, seqs, rng.randrange(4, 14), [4, 5, 7, 10, 12, 16, 22, 30])
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads)
+    oi = OL.OracleIndex(small, wide=True)
+    for _ in range(3):
+        pol_args = rng.choice(UNPAIRED_POLICIES)
+        rep = [x for x in rng.choice(REPORTS)]
+        if "-M" in pol_args or "-m" in pol_args or ("-k" in pol_args and "-k" in rep):
+            rep = [x for x in rep if x not in ("-m", "-k", "1", "2", "3")] if ("-M" in pol_args or "-m" in pol_args) else []
+        args = pol_args + rep + out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
+        if not _args_ok(args):
+            continue
+        ref = subprocess.run([REF_L, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", large, fq],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if ref.returncode != 0:
+            assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
+            continue
+        rd, pol, out, ex = CC.interpret(args)
+        b1 = H.read_all(fq, **rd)
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
+        p = _policy(pol)
+        per_o = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
+        per_e = E.EmuAligner(large).align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5))
+        for who, per in (("oracle (64-bit mode)", per_o), ("device automaton on the .ebwtl index", per_e)):
+            hits, nh, st, pool = H.pack_hits(per, cap)
+            got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            assert got == ref.stdout, (who, seqs, args)
