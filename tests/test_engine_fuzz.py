@@ -202,7 +202,7 @@ def _paired_fuzz(seed, tmp_path, best):
     for _ in range(3):
         args = rng.choice(PAIRED_POLICIES if best else PAIRED_POLICIES[:5] + PAIRED_POLICIES[6:]) + (["--best"] if best else []) + \
             rng.choice(PAIRED_REPORTS if best else [r for r in PAIRED_REPORTS if "--strata" not in r and "-M" not in r]) + \
-            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + out_options(rng)
+            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"], ["-5", "2", "-3", "1"]]) + out_options(rng)
         if not _args_ok(args):
             continue
         ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, "-1", f1, "-2", f2],
@@ -212,6 +212,10 @@ def _paired_fuzz(seed, tmp_path, best):
             continue
         rd, pol, out, ex = CC.interpret(args)
         b1, b2 = H.read_all(f1, mate=1, **rd), H.read_all(f2, mate=2, **rd)
+        # the insert limits as the aligner sees them: less the trimming at the fragment's outer ends (aligner.h:1921-1935)
+        o1 = rd.get("trim5", 0) if pol.get("mate1_fw", True) else rd.get("trim3", 0)
+        o2 = rd.get("trim3", 0) if pol.get("mate2_fw", False) else rd.get("trim5", 0)
+        pol = dict(pol, min_ins=max(0, max(0, pol.get("min_ins", 0) - o1) - o2), max_ins=max(0, max(0, pol.get("max_ins", 250) - o1) - o2))
         oi = OL.OracleIndex(base)
         opts = H.out_opts(**out)
         cap = 4096 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
