@@ -97,6 +97,11 @@ def out_options(rng):
     return o
 
 
+
+def _summary_of(stderr: bytes):
+    return [l for l in stderr.decode(errors="replace").strip().split("\n") if l.startswith("#") or l.startswith("Reported") or l.startswith("No align")]
+
+
 def _write_fastq(path, reads, mate=0):
     with open(path, "w") as f:
         for name, s, q in reads:
@@ -135,7 +140,7 @@ def test_unpaired_engines_against_the_reference(seed, tmp_path):
         args = pol_args + rep + out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
         if not _args_ok(args):
             continue
-        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, fq],
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fq],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         if ref.returncode != 0:
             assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
@@ -150,8 +155,9 @@ def test_unpaired_engines_against_the_reference(seed, tmp_path):
         per_e = E.EmuAligner(base).align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5), no_rl=(not p.best and rng.random() < 0.3))
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
-            got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
             assert got == ref.stdout, (who, seqs, args)
+            assert H.summary(tally).strip().split("\n") == _summary_of(ref.stderr), (who, args)
 
 
 PAIRED_POLICIES = [["-v", "0"], ["-v", "1"], ["-v", "2"], ["-n", "1", "-l", "8"], ["-n", "2", "-l", "10"], ["-v", "3"], ["-n", "3", "-l", "8", "-e", "100"]]
@@ -205,7 +211,7 @@ def _paired_fuzz(seed, tmp_path, best):
             rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"], ["-5", "2", "-3", "1"]]) + out_options(rng)
         if not _args_ok(args):
             continue
-        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, "-1", f1, "-2", f2],
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, "-1", f1, "-2", f2],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         if ref.returncode != 0:
             assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
@@ -225,8 +231,9 @@ def _paired_fuzz(seed, tmp_path, best):
         per_e = E.EmuAligner(base).align_pairs(_policy(pol), b1, b2, hit_cap=cap)
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
-            got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            got, tally = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
             assert got == ref.stdout, (who, seqs, args)
+            assert H.summary(tally).strip().split("\n") == _summary_of(ref.stderr), (who, args)
 
 
 MEDIUM_POLICIES = [
@@ -282,7 +289,7 @@ def test_unpaired_engines_on_medium_genomes_against_the_reference(seed, tmp_path
         args = pol_args + rep + out_options(rng) + ["--seed", str(rng.randrange(0, 3))]
         if not _args_ok(args):
             continue
-        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, fq],
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fq],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert ref.returncode == 0, (args, ref.stderr[-300:])
         rd, pol, out, ex = CC.interpret(args)
@@ -349,7 +356,7 @@ def test_paired_engines_on_medium_genomes_against_the_reference(seed, best, tmp_
         args = rng.choice(pols) + (["--best"] if best else []) + rng.choice(reps) + rng.choice([["-X", "500"], ["-X", "300", "-I", "100"], []]) + out_options(rng)
         if not _args_ok(args):
             continue
-        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", base, "-1", f1, "-2", f2],
+        ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, "-1", f1, "-2", f2],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert ref.returncode == 0, (args, ref.stderr[-300:])
         rd, pol, out, ex = CC.interpret(args)
@@ -399,7 +406,7 @@ def test_the_64_bit_build_against_bowtie_align_l(seed, tmp_path):
         args = pol_args + rep + out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
         if not _args_ok(args):
             continue
-        ref = subprocess.run([REF_L, "--wrapper", "basic-0", "-p", "1", "--quiet"] + args + ["-x", large, fq],
+        ref = subprocess.run([REF_L, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", large, fq],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         if ref.returncode != 0:
             assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
@@ -413,5 +420,6 @@ def test_the_64_bit_build_against_bowtie_align_l(seed, tmp_path):
         per_e = E.EmuAligner(large).align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5))
         for who, per in (("oracle (64-bit mode)", per_o), ("device automaton on the .ebwtl index", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
-            got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
             assert got == ref.stdout, (who, seqs, args)
+            assert H.summary(tally).strip().split("\n") == _summary_of(ref.stderr), (who, args)
