@@ -1,0 +1,98 @@
+"""GPU: the bowtie-amd binary against the unmodified reference binary, live, on seeded random tiny genomes (the generators
+of test_engine_fuzz.py: '$' row, eftab, fragment ends, reads longer than the genome all come up constantly) with random
+reads, pairs and option sets -- stdout and the summary on stderr, byte for byte.  Unpaired through both engines (a third of
+the default-engine runs through --stream, i.e. the carry-over kernel instances), pairs through --best.  oracle/_ref
+travels to the GPU box with the repository.  Named to run last: what it could find is rare-path trouble in the kernels."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import common as T
+import test_engine_fuzz as F
+from bowtie_amd import ebwt_build as EB
+
+BIN = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(F.REF_BIN), reason="needs oracle/_ref/bowtie-align-s")]
+
+
+def _both(args, tail, extra=()):
+    ref = subprocess.run([F.REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    got = subprocess.run([BIN, "--wrapper", "basic-0", "-p", "1"] + list(extra) + args + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    return ref, got
+
+
+def _check(ref, got, what):
+    if ref.returncode != 0:
+        # a read shorter than the mode allows: both stop with the reference's message
+        assert ref.returncode > 0 and got.returncode == 1, (what, ref.stderr[-200:], got.stderr[-200:])
+        return
+    assert got.returncode == 0, (what, got.stderr.decode(errors="replace")[-400:])
+    assert got.stdout == ref.stdout, what
+    assert F._summary_of(got.stderr) == F._summary_of(ref.stderr), what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_SEEDS", "60"))))
+def test_binary_against_the_reference_unpaired(seed, tmp_path):
+    rng = random.Random(seed)
+    seqs = F.make_genome(rng)
+    base = str(tmp_path / "g")
+    EB.build_index([F.LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d some description" % i if i % 2 == 0 else "t%d" % i for i in range(len(seqs))],
+                   base, ftab_chars=rng.choice([1, 2, 3, 4, 6]), off_rate=rng.choice([1, 2, 3, 5]))
+    lens = [4, 5, 7, 10, 12, 16, 22, 30]
+    if max(len(g) for g in seqs) >= 150 and rng.random() < 0.5:
+        lens = [30, 60, 105, 110, 113, 130]
+    reads = F.make_reads(rng, seqs, rng.randrange(4, 14), lens)
+    fq = str(tmp_path / "r.fq")
+    F._write_fastq(fq, reads)
+    for _ in range(3):
+        pol_args = rng.choice(F.UNPAIRED_POLICIES)
+        rep = [x for x in rng.choice(F.REPORTS)]
+        if "-M" in pol_args or "-m" in pol_args or ("-k" in pol_args and "-k" in rep):
+            rep = [x for x in rep if x not in ("-m", "-k", "1", "2", "3")] if ("-M" in pol_args or "-m" in pol_args) else []
+        args = pol_args + rep + F.out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
+        if not F._args_ok(args):
+            continue
+        stateful = "--best" in args or "--strata" in args or "-M" in args or args[:2] == ["-v", "3"]
+        extra = ["--stream"] if (not stateful and rng.random() < 0.34) else []
+        ref, got = _both(args, ["-x", base, fq], extra)
+        _check(ref, got, (seqs, extra + args))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_SEEDS", "40"))))
+def test_binary_against_the_reference_paired(seed, tmp_path):
+    rng = random.Random(10_000 + seed)
+    seqs = [s for s in F.make_genome(rng)]
+    seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([60, 120, 250]))))
+    base = str(tmp_path / "g")
+    EB.build_index([F.LUT[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs], ["s%d" % i for i in range(len(seqs))], base,
+                   ftab_chars=rng.choice([1, 2, 4, 6]), off_rate=rng.choice([1, 3, 5]))
+    m1, m2 = [], []
+    for i in range(rng.randrange(3, 10)):
+        g = rng.choice(seqs)
+        L1, L2 = rng.choice([5, 8, 12, 20]), rng.choice([5, 8, 12, 20])
+        Fr = rng.randrange(max(L1, L2), max(L1, L2) + 60)
+        if len(g) >= Fr and rng.random() < 0.85:
+            p = rng.randrange(0, len(g) - Fr + 1)
+            frag = g[p:p + Fr].replace("N", "C")
+            a, b = list(frag[:L1]), list(F._rc(frag[Fr - L2:]))
+            for s in (a, b):
+                for _ in range(rng.choice([0, 0, 1, 2])):
+                    s[rng.randrange(len(s))] = rng.choice("ACGT")
+            a, b = "".join(a), "".join(b)
+        else:
+            a = "".join(rng.choice("ACGT") for _ in range(L1)); b = "".join(rng.choice("ACGT") for _ in range(L2))
+        m1.append(("p%d" % i, a, "".join(rng.choice("!+5?IIII") for _ in a)))
+        m2.append(("p%d" % i, b, "".join(rng.choice("!+5?IIII") for _ in b)))
+    f1, f2 = str(tmp_path / "m_1.fq"), str(tmp_path / "m_2.fq")
+    F._write_fastq(f1, m1, 1)
+    F._write_fastq(f2, m2, 2)
+    for _ in range(3):
+        args = rng.choice(F.PAIRED_POLICIES) + ["--best"] + rng.choice(F.PAIRED_REPORTS) + \
+            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"]]) + F.out_options(rng)
+        if not F._args_ok(args):
+            continue
+        ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2])
+        _check(ref, got, (seqs, args))
