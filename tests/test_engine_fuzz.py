@@ -22,6 +22,12 @@ from bowtie_amd import hostio as H
 REF_BIN = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-s")
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="needs the reference binary (make -C oracle ref)")
 
+def _seeds(n):
+    """BT_FUZZ_OFFSET moves the window of seeds (one-off runs over fresh ones)."""
+    o = int(os.environ.get("BT_FUZZ_OFFSET", "0"))
+    return range(o, o + n)
+
+
 LUT = np.full(256, 4, np.uint8)
 for _i, _ch in enumerate("ACGT"):
     LUT[ord(_ch)] = _i
@@ -119,7 +125,7 @@ def _policy(pol):
     return A.make_policy(**pol)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "250"))))
+@pytest.mark.parametrize("seed", _seeds(int(os.environ.get("BT_FUZZ_SEEDS", "250"))))
 def test_unpaired_engines_against_the_reference(seed, tmp_path):
     rng = random.Random(seed)
     seqs = make_genome(rng)
@@ -164,12 +170,12 @@ PAIRED_POLICIES = [["-v", "0"], ["-v", "1"], ["-v", "2"], ["-n", "1", "-l", "8"]
 PAIRED_REPORTS = [[], ["-k", "2"], ["-a"], ["-m", "1"], ["-a", "--strata"], ["-M", "1"], ["--ff"], ["--rf"], ["--nofw"], ["--allow-contain"], ["--pairtries", "2"]]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "120"))))
+@pytest.mark.parametrize("seed", _seeds(int(os.environ.get("BT_FUZZ_SEEDS", "120"))))
 def test_paired_engine_against_the_reference(seed, tmp_path):
     _paired_fuzz(seed, tmp_path, best=True)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "100"))))
+@pytest.mark.parametrize("seed", _seeds(int(os.environ.get("BT_FUZZ_SEEDS", "100"))))
 def test_paired_engine_without_best_against_the_reference(seed, tmp_path):
     """PairedBWAlignerV1 (pairs without --best): oracle and the host build of bf_run_pair_v1 (the device code that has
     not run on a GPU yet)."""
@@ -243,7 +249,7 @@ MEDIUM_POLICIES = [
 ]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_MEDIUM_SEEDS", "4"))))
+@pytest.mark.parametrize("seed", _seeds(int(os.environ.get("BT_FUZZ_MEDIUM_SEEDS", "4"))))
 def test_unpaired_engines_on_medium_genomes_against_the_reference(seed, tmp_path):
     """The same on genomes of 2 to 50 kbp with repeat families and real read lengths (36 to 100 bases), at the reference's
     default index parameters: deeper backtracking, seed extension, the quality budget."""
@@ -324,7 +330,7 @@ def _medium_genome(rng):
 
 
 @pytest.mark.parametrize("best", [True, False], ids=["best", "without_best"])
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_MEDIUM_SEEDS", "3"))))
+@pytest.mark.parametrize("seed", _seeds(int(os.environ.get("BT_FUZZ_MEDIUM_SEEDS", "3"))))
 def test_paired_engines_on_medium_genomes_against_the_reference(seed, best, tmp_path):
     rng = random.Random(70_000 + seed)
     seqs = _medium_genome(rng)
@@ -379,7 +385,7 @@ BUILD_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-l")
 
 
 @pytest.mark.skipif(not (os.path.exists(REF_L) and os.path.exists(BUILD_L)), reason="needs the 64-bit reference binaries (make -C oracle ref)")
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_SEEDS", "60"))))
+@pytest.mark.parametrize("seed", _seeds(int(os.environ.get("BT_FUZZ_SEEDS", "60"))))
 def test_the_64_bit_build_against_bowtie_align_l(seed, tmp_path):
     """bowtie-align-l on bowtie-build-l's index of the same random genomes (its two visible differences from the 32-bit
     build: two generator draws per reported row range, a smaller branch pool): against the oracle in its 64-bit mode on
