@@ -180,7 +180,8 @@ const LongOpt LONGS[] = {
 	{"reads-per-batch", 1, O_IGNORED_ARG}, {"chunkmbs", 1, O_IGNORED_ARG}, {"chunksz", 1, O_IGNORED_ARG}, {"chunkverbose", 0, O_IGNORED},
 	{"verbose", 0, O_IGNORED}, {"startverbose", 0, O_IGNORED}, {"sanity", 0, O_IGNORED}, {"reorder", 0, O_IGNORED},
 	{"thread-ceiling", 1, O_IGNORED_ARG}, {"thread-piddir", 1, O_IGNORED_ARG}, {"mm", 0, O_IGNORED}, {"shmem", 0, O_IGNORED},
-	{"mmsweep", 0, O_IGNORED}, {"prewidth", 1, O_IGNORED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_UNSUPPORTED},
+	{"mmsweep", 0, O_IGNORED}, {"prewidth", 1, O_IGNORED_ARG}, {"cachelim", 1, O_IGNORED_ARG}, {"cachesz", 1, O_IGNORED_ARG},
+	{"pause", 0, O_IGNORED}, {"stats", 0, O_IGNORED}, {"reportopps", 0, O_UNSUPPORTED}, {"mixthresh", 1, O_UNSUPPORTED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_UNSUPPORTED},
 	/* the best-first engine and everything that needs it */
 	{"best", 0, O_BEST}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_STRATA},
 	{"minins", 1, 'I'}, {"maxins", 1, 'X'}, {"ff", 0, O_FF}, {"fr", 0, O_FR},
