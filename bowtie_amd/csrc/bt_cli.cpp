@@ -276,13 +276,13 @@ void parse_args(int argc, char** argv, Options* O)
 				else { if (i + 1 >= argc) die("bowtie-amd: option '--%s' requires an argument", name.c_str()); val = argv[++i]; }
 			}
 			if (id == O_UNSUPPORTED || id == O_UNSUPPORTED_ARG)
-				die("Error: --%s needs the reference's best-first / paired-end engine, which this build does not have (SURVEY.md 8f-1)", name.c_str());
+				die("Error: --%s selects a part of the reference that this build does not have (DESIGN.md 1: what is not built)", name.c_str());
 			if (id == O_IGNORED || id == O_IGNORED_ARG) continue;
 		} else {
 			/* a short option with its value (attached or next argument), or a bundle of flags */
 			const char c = a[1];
 			if (strchr(SHORT_UNSUPPORTED_ARG, c) || strchr(SHORT_UNSUPPORTED, c))
-				die("Error: -%c needs a part of the reference this build does not have (SURVEY.md 8f-1)", c);
+				die("Error: -%c selects a part of the reference that this build does not have (DESIGN.md 1: what is not built)", c);
 			if (strchr(SHORT_ARG, c)) {
 				if (a[2]) val = a + 2;
 				else { if (i + 1 >= argc) die("bowtie-amd: option requires an argument -- '%c'", c); val = argv[++i]; }
