@@ -1341,7 +1341,10 @@ void bt_io_sam_header(const BtRefNames& refs, const bt_out_opts& op, const char*
 	if (!op.sam_nosq) {
 		for (size_t i = 0; i < refs.lens.size(); i++) {
 			o->append("@SQ\tSN:");
-			put_ref(o, refs, (uint32_t)i, op);
+			/* names here even with --refidx, which only changes the alignment records (the header is written from the
+			 * names read off the index, ebwt_search.cpp:3220-3226) */
+			bt_out_opts named = op; named.ref_idx = 0;
+			put_ref(o, refs, (uint32_t)i, named);
 			o->append("\tLN:"); put_u(o, refs.lens[i]); o->push_back('\n');
 		}
 	}

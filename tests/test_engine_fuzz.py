@@ -89,7 +89,15 @@ REPORTS = [[], [], ["-k", "3"], ["-a"], ["-a"], ["-m", "1"], ["-k", "2", "-m", "
 def out_options(rng):
     """A random set of output options: the formatters' columns and SAM fields against the reference's too."""
     if rng.random() < 0.5:
-        o = ["-S", "--sam-nohead"]
+        o = ["-S"]
+        r = rng.random()
+        if r < 0.6:
+            o += ["--sam-nohead"]
+        else:                                                    # with the header: @HD, @SQ (or not), @RG, @PG
+            if r < 0.75:
+                o += ["--sam-nosq"]
+            if r > 0.85:
+                o += ["--sam-RG", "ID:g%d" % rng.randrange(9), "--sam-RG", "SM:x y"]
         for opt, p in ((["--mapq", str(rng.choice([0, 7, 40]))], 0.3), (["--no-unal"], 0.3), (["--fullref"], 0.2),
                        (["--sam-no-qname-trunc"], 0.2), (["--refidx"], 0.1)):
             if rng.random() < p:
@@ -102,6 +110,16 @@ def out_options(rng):
             o += opt
     return o
 
+
+
+def _header_for(ref_stdout: bytes, oi, opts, ex) -> bytes:
+    """The SAM header the formatter writes for this run; the @PG line quotes the command line, so the reference's own is
+    handed in."""
+    if not opts.sam or ex["sam_nohead"]:
+        return b""
+    head = [l for l in ref_stdout.split(b"\n") if l.startswith(b"@")]
+    cl = head[-1].split(b'CL:"', 1)[1][:-1].decode()
+    return H.sam_header(oi.refnames, oi.reflens, opts, cl, "\t".join(ex["rg"]) or None)
 
 
 def _summary_of(stderr: bytes):
@@ -159,9 +177,11 @@ def test_unpaired_engines_against_the_reference(seed, tmp_path):
         p = _policy(pol)
         per_o = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
         per_e = E.EmuAligner(base).align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5), no_rl=(not p.best and rng.random() < 0.3))
+        head = _header_for(ref.stdout, oi, opts, ex)
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            got = head + got
             assert got == ref.stdout, (who, seqs, args)
             assert H.summary(tally).strip().split("\n") == _summary_of(ref.stderr), (who, args)
 
@@ -235,9 +255,11 @@ def _paired_fuzz(seed, tmp_path, best):
             pol = dict(pol, pe_v1=True)
         per_o = R.oracle_search_pairs(oi, OL.make_policy(**pol), b1, b2, cap=cap, v1=not best)
         per_e = E.EmuAligner(base).align_pairs(_policy(pol), b1, b2, hit_cap=cap)
+        head = _header_for(ref.stdout, oi, opts, ex)
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, tally = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            got = head + got
             assert got == ref.stdout, (who, seqs, args)
             assert H.summary(tally).strip().split("\n") == _summary_of(ref.stderr), (who, args)
 
@@ -307,10 +329,11 @@ def test_unpaired_engines_on_medium_genomes_against_the_reference(seed, tmp_path
         per_o = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
         per_e = E.EmuAligner(base).align(p, b1, hit_cap=cap, lite=(not p.best and rl <= 100 and rng.random() < 0.5),
                                          no_rl=(not p.best and rng.random() < 0.3), pal_cap=16384)
+        head = _header_for(ref.stdout, oi, opts, ex)
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, _ = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
-            assert got == ref.stdout, (who, args)
+            assert head + got == ref.stdout, (who, args)
 
 
 def _medium_genome(rng):
@@ -374,10 +397,11 @@ def test_paired_engines_on_medium_genomes_against_the_reference(seed, best, tmp_
         cap = 4096 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
         per_o = R.oracle_search_pairs(oi, OL.make_policy(**pol), b1, b2, cap=cap, v1=not best)
         per_e = E.EmuAligner(base).align_pairs(_policy(pol), b1, b2, hit_cap=cap)
+        head = _header_for(ref.stdout, oi, opts, ex)
         for who, per in (("oracle", per_o), ("device automaton (host build)", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
-            assert got == ref.stdout, (who, args)
+            assert head + got == ref.stdout, (who, args)
 
 
 REF_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-l")
@@ -424,8 +448,10 @@ def test_the_64_bit_build_against_bowtie_align_l(seed, tmp_path):
         p = _policy(pol)
         per_o = R.oracle_search(oi, OL.make_policy(**pol), b1, cap=cap)
         per_e = E.EmuAligner(large).align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5))
+        head = _header_for(ref.stdout, oi, opts, ex)
         for who, per in (("oracle (64-bit mode)", per_o), ("device automaton on the .ebwtl index", per_e)):
             hits, nh, st, pool = H.pack_hits(per, cap)
             got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+            got = head + got
             assert got == ref.stdout, (who, seqs, args)
             assert H.summary(tally).strip().split("\n") == _summary_of(ref.stderr), (who, args)

@@ -30,7 +30,8 @@ def _check(ref, got, what):
         assert ref.returncode > 0 and got.returncode == 1, (what, ref.stderr[-200:], got.stderr[-200:])
         return
     assert got.returncode == 0, (what, got.stderr.decode(errors="replace")[-400:])
-    assert got.stdout == ref.stdout, what
+    strip_pg = lambda b: b"\n".join(l for l in b.split(b"\n") if not l.startswith(b"@PG"))     # @PG quotes the command line
+    assert strip_pg(got.stdout) == strip_pg(ref.stdout), what
     assert F._summary_of(got.stderr) == F._summary_of(ref.stderr), what
 
 
