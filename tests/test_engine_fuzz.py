@@ -73,7 +73,7 @@ def make_reads(rng, seqs, n, lens):
         else:
             s = "".join(rng.choice("ACGT") for _ in range(L))
         q = "".join(rng.choice("!+5?IIII") for _ in range(L))
-        out.append(("r%d" % i, s, q))
+        out.append((rng.choice(["r%d", "r%d", "r%d with words", "r%d/1", "read_%d\ttabbed"]) % i, s, q))
     return out
 
 
