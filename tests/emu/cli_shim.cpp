@@ -1,0 +1,105 @@
+/*
+ * cli_shim.cpp -- TEST INFRASTRUCTURE ONLY.  The GPU-side entry points of the C ABI (include/bowtie_amd.h) answered by the
+ * host build of the device automatons (bt_emu.cpp), as a library for LD_PRELOAD under the bowtie-amd binary: lets the
+ * binary's own host logic -- option handling, batching, the second pass for reads with many hits, pairs, read dumps,
+ * tallies, output order -- run against the reference's outputs where no GPU exists.  Nothing in the product loads it; without
+ * it (and without a GPU) bowtie-amd stops at "could not load index".  The searches it performs are the emulator's.
+ */
+#include "bt_emu.cpp"
+#include <mutex>
+
+static std::mutex g_emu_mutex;        /* the emulator loads the 2-bit reference on first use: one search at a time */
+
+struct bt_index { void* emu = nullptr; bool mirror = false; int variant = 1; };
+struct bt_ctx { const bt_index* ix = nullptr; bt_policy pol; bool best = false; };
+
+extern "C" int bt_index_load(const char* base, int need_mirror, int offrate_override, int device, bt_index** out)
+{
+	(void)device;
+	if (!base || !out) return BT_ERR_ARG;
+	*out = nullptr;
+	const int variant = bt_host_index_variant(base);
+	if (variant < 0) return BT_ERR_IO;
+	void* e = nullptr;
+	try { e = emu_index_load(base, need_mirror, offrate_override); } catch (const std::exception&) { return BT_ERR_FORMAT; }
+	if (!e) return BT_ERR_FORMAT;
+	bt_index* ix = new bt_index();
+	ix->emu = e; ix->mirror = need_mirror != 0; ix->variant = variant;
+	*out = ix;
+	return BT_OK;
+}
+extern "C" void bt_index_info_get(const bt_index* idx, bt_index_info* info)
+{
+	memset(info, 0, sizeof(*info));
+	const BtIndexHost& h = ((EmuIndex*)idx->emu)->h[0];
+	info->len = h.len; info->n_pat = h.nPat; info->n_frag = h.nFrag; info->ftab_chars = (uint32_t)h.ftabChars;
+	info->off_rate = (uint32_t)h.offRate; info->z_off = h.zOff;
+	info->has_mirror = idx->mirror ? 1 : 0;
+	info->variant = idx->variant | (h.swapped ? BT_INDEX_SWAPPED : 0);
+}
+extern "C" const char* bt_index_refname(const bt_index* idx, uint32_t t)
+{
+	const BtIndexHost& h = ((EmuIndex*)idx->emu)->h[0];
+	return t < h.refnames.size() ? h.refnames[t].c_str() : nullptr;
+}
+extern "C" uint32_t bt_index_reflen(const bt_index* idx, uint32_t t)
+{
+	const BtIndexHost& h = ((EmuIndex*)idx->emu)->h[0];
+	return t < h.plen.size() ? h.plen[t] : 0;
+}
+extern "C" void bt_index_free(bt_index* idx) { if (idx) { emu_index_free(idx->emu); delete idx; } }
+extern "C" int bt_index_load_reference(bt_index* ix) { return ix ? BT_OK : BT_ERR_ARG; }       /* emu_align_pairs loads it on first use */
+
+extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* stream, bt_ctx** out)
+{
+	(void)stream;
+	if (!idx || !pol || !out) return BT_ERR_ARG;
+	*out = nullptr;
+	if (pol->pe_v1) return BT_ERR_ARG;                      /* as the default build of the library answers */
+	bt_ctx* c = new bt_ctx();
+	c->ix = idx; c->pol = *pol; c->best = pol->best != 0;
+	if (c->best) { BfProgram P; const int rc = bt_host_compile_best(*pol, &P); if (rc != BT_OK) { delete c; return rc; } }
+	else { BtProgram P; const int rc = bt_host_compile_program(*pol, &P); if (rc != BT_OK) { delete c; return rc; } }
+	*out = c;
+	return BT_OK;
+}
+extern "C" void bt_ctx_destroy(bt_ctx* c) { delete c; }
+
+/* the return code of bt_align_batch / bt_align_pairs (bt_api.cpp): the worst thing that happened to a read */
+static int worst_status(const bt_hit_batch* out, uint32_t n)
+{
+	int worst = BT_OK;
+	for (uint32_t i = 0; i < n; i++) {
+		if (out->status[i] & BT_ST_TOOSHORT) worst = BT_ERR_READ_SHORT;
+		else if ((out->status[i] & (BT_ST_OVERFLOW | BT_ST_MMPOOL)) && worst == BT_OK) worst = BT_ERR_OVERFLOW;
+	}
+	return worst;
+}
+
+extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, bt_op_counts* counts)
+{
+	if (!c || !in || !out) return BT_ERR_ARG;
+	if (in->n_reads == 0) return BT_OK;
+	uint32_t maxLen = 1;
+	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
+	/* arenas no read of the batch can outgrow (the library reaches the same through its second pass) */
+	const uint32_t L = maxLen < 64 ? 64 : maxLen;
+	const uint32_t frCap = L + 8u, entCap = (L * (L + 3u) / 2u + 64u + 7u) & ~7u;
+	std::lock_guard<std::mutex> lock(g_emu_mutex);
+	const int rc = emu_align_batch(c->ix->emu, &c->pol, in, out, counts, 64, frCap, c->best ? 0u : entCap, 1u << 16, 0);
+	if (rc != BT_OK) return rc;
+	return worst_status(out, in->n_reads);
+}
+extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out, bt_op_counts* counts)
+{
+	if (!c || !in1 || !in2 || !out) return BT_ERR_ARG;
+	if (in1->n_reads == 0) return BT_OK;
+	std::lock_guard<std::mutex> lock(g_emu_mutex);
+	const int rc = emu_align_pairs(c->ix->emu, &c->pol, in1, in2, out, counts, 0);
+	if (rc != BT_OK) return rc;
+	return worst_status(out, in1->n_reads);
+}
+/* --stream needs the asynchronous entry points: not emulated */
+extern "C" int bt_ctx_set_carry(bt_ctx*, int) { return BT_ERR_ARG; }
+extern "C" int bt_align_stream_submit(bt_ctx*, const bt_read_batch*, bt_hit_batch*, void*) { return BT_ERR_ARG; }
+extern "C" int bt_align_stream_collect(bt_ctx*, void**, int) { return BT_ERR_ARG; }

@@ -1,0 +1,36 @@
+"""The bowtie-amd binary's own host logic without a GPU: tests/emu/cli_shim.cpp answers the GPU-side entry points of the C
+ABI with the host build of the device automatons (LD_PRELOAD, test infrastructure only), and the tests that drive the
+binary -- the reference-made command-line cases, every simple_tests.pl case, the differential fuzz against the live
+reference binary -- run here as they will on the GPU.  What this checks is bt_cli.cpp (options, batching, the second pass
+for reads with many hits, pairs, --12 / --interleaved, read dumps, tallies, output order) and bt_io.cpp under it; the
+searches themselves are the emulator's, whose parity has its own tests."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import common as T
+
+SHIM = os.path.join(T.ROOT, "tests", "emu", "libcli_shim.so")
+SRCS = [os.path.join(T.ROOT, "tests", "emu", "cli_shim.cpp"), os.path.join(T.ROOT, "tests", "emu", "bt_emu.cpp"),
+        os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_host.cpp"), os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_core.h"),
+        os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_best.h")]
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if not os.path.exists(SHIM) or any(os.path.getmtime(SHIM) < os.path.getmtime(s) for s in SRCS):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(T.ROOT, "include"), "-o", SHIM,
+                               SRCS[0], SRCS[2]])
+    return SHIM
+
+
+@pytest.mark.parametrize("files", [["tests/test_gpu_cli.py"], ["tests/test_simple_cases.py"], ["tests/test_zz_gpu_fuzz.py"]], ids=lambda f: f[0][6:-3])
+def test_binary_suites_through_the_cpu_shim(files, shim):
+    env = dict(os.environ, BT_TEST_CLI_SHIM="1", LD_PRELOAD=shim, BT_GPU_FUZZ_SEEDS="30")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=T.ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    tail = p.stdout.decode(errors="replace")[-1500:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and " failed" not in tail, tail
