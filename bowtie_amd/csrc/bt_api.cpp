@@ -105,6 +105,15 @@ extern "C" void bt_policy_default(bt_policy* p)
 	p->max_ins = 250; p->mate1_fw = 1; p->pair_tries = 100;
 }
 
+extern "C" int bt_has_pe_v1(void)
+{
+#ifdef BT_PE_V1
+	return 1;
+#else
+	return 0;
+#endif
+}
+
 extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate_override, int device,
                              bt_index** out)
 {

@@ -469,7 +469,12 @@ void parse_args(int argc, char** argv, Options* O)
 		const size_t c2 = (size_t)std::count(O->mates2.begin(), O->mates2.end(), ',') + (O->mates2.empty() ? 0 : 1);
 		if (c1 != c2 && O->rd.format != BT_FMT_CMDLINE)
 			die("Error: %zu mate files/sequences were specified with -1, but %zu\nmate files/sequences were specified with -2.  The same number of mate files/\nsequences must be specified with -1 and -2.", c1, c2);
-		if (!O->pol.best) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
+		if (!O->pol.best) {
+			/* the reference's default paired-end aligner, PairedBWAlignerV1: in the library only when it was built with it */
+			if (!bt_has_pe_v1() || one_file) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
+			O->pol.pe_v1 = 1;
+			if (!O->maxbts_set) O->pol.max_bts = 800;              /* every stateful aligner: ebwt_search.cpp:185-186, 2644, 2670 */
+		}
 	} else if (one_file) {
 		O->reads = O->tab12;
 	} else {

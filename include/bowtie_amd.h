@@ -82,11 +82,14 @@ typedef struct bt_policy {
 	                          (--best).  Either way the stateful engine runs (best is taken as set) and max_bts
 	                          defaults to 800 (ebwt_search.cpp:186, 2644, 2670).  NOT YET RUN ON A GPU: verified
 	                          against the reference only through the host emulator, and compiled into the kernel
-	                          only with `make PE_V1=1` -- otherwise bt_ctx_create returns BT_ERR_ARG */
+	                          only with `make PE_V1=1` (bt_has_pe_v1() says which) -- otherwise bt_ctx_create returns BT_ERR_ARG
+	                           */
 	int32_t  reserved[1];
 } bt_policy;
 
 void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 -k 1          */
+int  bt_has_pe_v1(void);                /* 1: this build of the library takes bt_policy.pe_v1 (make PE_V1=1), 0: it answers
+                                           it with BT_ERR_ARG                                    */
 
 /* ---- reads in: what PatternSourcePerThread hands the worker (read.h:42-273) -------------- */
 typedef struct bt_read_batch {

@@ -28,7 +28,7 @@ def manifest():
         return json.load(f)
 
 
-def all_runs(paired_variant="best"):
+def all_runs(paired_variant=os.environ.get("BT_SIMPLE_PAIRED_VARIANT", "best")):
     """(case, run): unpaired cases as the harness runs them; paired ones in their --best variant
     (without it the reference uses PairedBWAlignerV1, which this build refuses)."""
     out = []
@@ -36,7 +36,7 @@ def all_runs(paired_variant="best"):
         for r in c.get("runs", []):
             # --12 / --interleaved input puts the reference on its stateful aligners whether the records are pairs
             # or not (ebwt_search.cpp:3001-3002): compared in the --best variant as well
-            if r["variant"] == (paired_variant if (c["paired"] or c.get("needs_best")) else "asis"):
+            if r["variant"] == ("best" if c.get("needs_best") else paired_variant if c["paired"] else "asis"):
                 out.append((c, r))
     return out
 

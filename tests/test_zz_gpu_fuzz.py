@@ -64,9 +64,28 @@ def test_binary_against_the_reference_unpaired(seed, tmp_path):
         _check(ref, got, (seqs, extra + args))
 
 
+def _has_pe_v1():
+    if os.environ.get("BT_TEST_CLI_SHIM") == "1":
+        return os.environ.get("BT_SHIM_PE_V1") == "1"
+    from bowtie_amd import aligner as AL
+    return bool(AL.lib().bt_has_pe_v1())
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_SEEDS", "40"))))
 def test_binary_against_the_reference_paired(seed, tmp_path):
-    rng = random.Random(10_000 + seed)
+    _paired(seed, tmp_path, True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_SEEDS", "40"))))
+def test_binary_against_the_reference_paired_without_best(seed, tmp_path):
+    """The reference's default paired-end aligner -- for a library built with make PE_V1=1."""
+    if not _has_pe_v1():
+        pytest.skip("this build of the library does not take paired-end input without --best")
+    _paired(seed, tmp_path, False)
+
+
+def _paired(seed, tmp_path, best):
+    rng = random.Random((10_000 if best else 20_000) + seed)
     seqs = [s for s in F.make_genome(rng)]
     seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([60, 120, 250]))))
     base = str(tmp_path / "g")
@@ -93,7 +112,8 @@ def test_binary_against_the_reference_paired(seed, tmp_path):
     F._write_fastq(f1, m1, 1)
     F._write_fastq(f2, m2, 2)
     for _ in range(3):
-        args = rng.choice(F.PAIRED_POLICIES) + ["--best"] + rng.choice(F.PAIRED_REPORTS) + \
+        args = rng.choice(F.PAIRED_POLICIES if best else F.PAIRED_POLICIES[:5] + F.PAIRED_POLICIES[6:]) + (["--best"] if best else []) + \
+            rng.choice(F.PAIRED_REPORTS if best else [r for r in F.PAIRED_REPORTS if "--strata" not in r and "-M" not in r]) + \
             rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"]]) + F.out_options(rng)
         if not F._args_ok(args):
             continue
