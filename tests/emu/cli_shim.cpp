@@ -6,12 +6,13 @@
  * it (and without a GPU) bowtie-amd stops at "could not load index".  The searches it performs are the emulator's.
  */
 #include "bt_emu.cpp"
+#include <deque>
 #include <mutex>
 
 static std::mutex g_emu_mutex;        /* the emulator loads the 2-bit reference on first use: one search at a time */
 
 struct bt_index { void* emu = nullptr; bool mirror = false; int variant = 1; };
-struct bt_ctx { const bt_index* ix = nullptr; bt_policy pol; bool best = false; };
+struct bt_ctx { const bt_index* ix = nullptr; bt_policy pol; bool best = false; std::deque<void*> done; };
 
 /* BT_SHIM_PE_V1=1: answer as a library built with make PE_V1=1 would (the emulator has bf_run_pair_v1 either way) */
 extern "C" int bt_has_pe_v1(void) { const char* e = getenv("BT_SHIM_PE_V1"); return e && e[0] == '1'; }
@@ -103,7 +104,22 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 	if (rc != BT_OK) return rc;
 	return worst_status(out, in1->n_reads);
 }
-/* --stream needs the asynchronous entry points: not emulated */
-extern "C" int bt_ctx_set_carry(bt_ctx*, int) { return BT_ERR_ARG; }
-extern "C" int bt_align_stream_submit(bt_ctx*, const bt_read_batch*, bt_hit_batch*, void*) { return BT_ERR_ARG; }
-extern "C" int bt_align_stream_collect(bt_ctx*, void**, int) { return BT_ERR_ARG; }
+/* --stream: the asynchronous entry points, answered synchronously -- a submitted batch is searched at once and is the next
+ * one collected; reads come back flagged rather than as an error code, as from the library's stream */
+extern "C" int bt_ctx_set_carry(bt_ctx* c, int launches) { return c && launches >= 0 && launches <= 14 ? BT_OK : BT_ERR_ARG; }
+extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, void* tag)
+{
+	if (!c || !in || !out || !tag || c->best) return BT_ERR_ARG;
+	const int rc = bt_align_batch(c, in, out, nullptr);
+	if (rc != BT_OK && rc != BT_ERR_OVERFLOW && rc != BT_ERR_READ_SHORT) return rc;
+	c->done.push_back(tag);
+	return BT_OK;
+}
+extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
+{
+	(void)flush;
+	if (!c || !tag) return BT_ERR_ARG;
+	*tag = nullptr;
+	if (!c->done.empty()) { *tag = c->done.front(); c->done.pop_front(); }
+	return BT_OK;
+}

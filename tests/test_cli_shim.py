@@ -3,7 +3,8 @@ ABI with the host build of the device automatons (LD_PRELOAD, test infrastructur
 binary -- the reference-made command-line cases, every simple_tests.pl case, the differential fuzz against the live
 reference binary -- run here as they will on the GPU.  What this checks is bt_cli.cpp (options, batching, the second pass
 for reads with many hits, pairs, --12 / --interleaved, read dumps, tallies, output order) and bt_io.cpp under it; the
-searches themselves are the emulator's, whose parity has its own tests."""
+searches themselves are the emulator's, whose parity has its own tests.  One run puts every case through --stream: the
+binary's streamed search loop (the shim answers the asynchronous entry points synchronously)."""
 import os
 import subprocess
 import sys
@@ -27,6 +28,7 @@ def shim():
 
 
 @pytest.mark.parametrize("files,pe_v1", [(["tests/test_gpu_cli.py"], False), (["tests/test_simple_cases.py"], False), (["tests/test_zz_gpu_fuzz.py"], False),
+                                         (["tests/test_gpu_cli.py", "tests/test_simple_cases.py", "--stream"], False),
                                          (["tests/test_simple_cases.py", "-k", "test_simple_case_bowtie_amd"], True),
                                          (["tests/test_zz_gpu_fuzz.py", "-k", "without_best"], True)],
                          ids=lambda x: x[0][6:-3] if isinstance(x, list) else ("as_a_PE_V1_build" if x else "as_the_default_build"))
@@ -34,6 +36,11 @@ def test_binary_suites_through_the_cpu_shim(files, pe_v1, shim):
     """pe_v1: the shim answers as a library built with make PE_V1=1 does, and the binary then takes paired-end input
     without --best (the reference's default paired-end aligner): the simple_tests.pl pairs as written, and the fuzz."""
     env = dict(os.environ, BT_TEST_CLI_SHIM="1", LD_PRELOAD=shim, BT_GPU_FUZZ_SEEDS="30")
+    if files[-1] == "--stream":
+        # every unpaired default-engine run through the binary's streamed search loop (the shim answers the asynchronous
+        # entry points synchronously)
+        files = files[:-1]
+        env["BT_TEST_CLI_EXTRA"] = "--stream"
     if pe_v1:
         env.update(BT_SHIM_PE_V1="1", BT_SIMPLE_PAIRED_VARIANT="asis")
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=T.ROOT, env=env,

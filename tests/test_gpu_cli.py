@@ -15,7 +15,8 @@ BIN = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
 
 
 def run(args, index, reads, extra=()):
-    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + list(extra) + list(args) + ["-x", index] + ([reads] if reads else [])
+    # BT_TEST_CLI_EXTRA: extra bowtie-amd options for every run (e.g. "--stream"); paired runs ignore --stream by themselves
+    cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + os.environ.get("BT_TEST_CLI_EXTRA", "").split() + list(extra) + list(args) + ["-x", index] + ([reads] if reads else [])
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
 
 

@@ -234,8 +234,6 @@ def test_ext_kernel_instances_on_the_two_tiny_inputs(case, run, simple_index, mo
 @pytest.mark.parametrize("case,run", DOLLAR_ROW, ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
 def test_streamed_binary_on_the_two_tiny_inputs(case, run, simple_index):
     """The same two inputs through `bowtie-amd --stream` (carry-over: park, adopt, closing launch)."""
-    if os.environ.get("BT_TEST_CLI_SHIM") == "1":
-        pytest.skip("the CPU shim under the binary has no asynchronous entry points")
     base = simple_index(case["ref"])
     cmd = [BIN, "--wrapper", "basic-0", "-p", "1", "--stream"] + run["args"] + ["-x", base] + case["reads"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=120)

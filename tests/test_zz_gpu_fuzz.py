@@ -58,8 +58,6 @@ def test_binary_against_the_reference_unpaired(seed, tmp_path):
             continue
         stateful = "--best" in args or "--strata" in args or "-M" in args or args[:2] == ["-v", "3"]
         extra = ["--stream"] if (not stateful and rng.random() < 0.34) else []
-        if os.environ.get("BT_TEST_CLI_SHIM") == "1":
-            extra = []                              # the shim (tests/emu/cli_shim.cpp) has no asynchronous entry points
         ref, got = _both(args, ["-x", base, fq], extra)
         _check(ref, got, (seqs, extra + args))
 
