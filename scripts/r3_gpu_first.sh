@@ -43,6 +43,11 @@ fi
 # ---- 2. paired-end without --best on the GPU: the -DBT_PE_V1 build --------------------------------
 BT_LIB=libbowtie_amd_pev1.so BT_RUN_UNVERIFIED=1 timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -k without_best > $O/pe_v1.txt 2>&1
 say "PairedBWAlignerV1 on the GPU: $(tail -1 $O/pe_v1.txt)"
+# the binary on that library (it asks bt_has_pe_v1): the paired simple_tests.pl cases as written, and the fuzz against the live reference
+BT_LIB=libbowtie_amd_pev1.so LD_PRELOAD=$PWD/bowtie_amd/libbowtie_amd_pev1.so BT_SIMPLE_PAIRED_VARIANT=asis timeout 300 python -m pytest tests/test_simple_cases.py -m gpu -q -k test_simple_case_bowtie_amd > $O/pe_v1_simple.txt 2>&1
+say "  simple_tests.pl pairs without --best through bowtie-amd: $(tail -1 $O/pe_v1_simple.txt)"
+BT_LIB=libbowtie_amd_pev1.so LD_PRELOAD=$PWD/bowtie_amd/libbowtie_amd_pev1.so timeout 300 python -m pytest tests/test_zz_gpu_fuzz.py -m gpu -q -k without_best > $O/pe_v1_fuzz.txt 2>&1
+say "  bowtie-amd against the live reference, pairs without --best: $(tail -1 $O/pe_v1_fuzz.txt)"
 
 # ---- 3. bt_best_kernel at two blocks per CU (256 VGPRs, no spill) against the default (266, one block) ---------
 for wl in ecoli_n2_best_100 ecoli_pe_n1_best_50; do
