@@ -58,6 +58,7 @@ def test_binary_against_the_reference_unpaired(seed, tmp_path):
             continue
         stateful = "--best" in args or "--strata" in args or "-M" in args or args[:2] == ["-v", "3"]
         extra = ["--stream"] if (not stateful and rng.random() < 0.34) else []
+        extra = extra + rng.choice([[], [], ["--batch", "3"], ["--batch", "2", "--inflight", "3"]])      # tiny batches: boundaries, order
         ref, got = _both(args, ["-x", base, fq], extra)
         _check(ref, got, (seqs, extra + args))
 
@@ -115,5 +116,5 @@ def _paired(seed, tmp_path, best):
             rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"]]) + F.out_options(rng)
         if not F._args_ok(args):
             continue
-        ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2])
+        ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2], rng.choice([[], [], ["--batch", "2"], ["--batch", "3", "--inflight", "1"]]))
         _check(ref, got, (seqs, args))
