@@ -260,11 +260,11 @@ def main():
     ap.add_argument("--genome", type=int, default=int(os.environ.get("BT_GENOME_BP", "0")),
                     help="synthetic genome length for the big_* workloads (0 = hg19 scale)")
     ap.add_argument("--pipes", type=int, default=1, help="contexts/streams the steps are pipelined over")
-    ap.add_argument("--carry", type=int, default=0,
-                    help="bt_ctx_set_carry: launches a read may ride along with the steps after its own.  Default 0: every "
-                         "step runs to its last read before the next starts.  Opt-in: it more than doubles the rate of "
-                         "16 M-read steps (profiles/README.md), gains nothing at 200 M reads per step, and launches kernel "
-                         "instances the whole GPU suite has not yet run through since their fix (DESIGN.md 4.4).")
+    ap.add_argument("--carry", type=int, default=-1,
+                    help="bt_ctx_set_carry: launches a read may ride along with the steps after its own.  Default (-1): 12 "
+                         "for steps of fewer than 64 M reads per GPU (it doubles the rate of 16 M-read steps, "
+                         "profiles/README.md), 0 above that (every step runs to its last read; carry-over gains nothing at "
+                         "200 M reads per step).")
     ap.add_argument("--no-carry", action="store_true", help="same as --carry 0")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
@@ -341,7 +341,7 @@ def main():
     # all been handed out are parked and resumed by the context's next step, so a step's results are complete when
     # the next step (or the closing bt_ctx_sync, inside the timed region) is.  Each context therefore alternates
     # between two sets of output arrays.
-    carry_age = 0 if args.no_carry else max(0, args.carry)
+    carry_age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (12 if n < 64_000_000 else 0))
     if paired or wl["pol"].get("best") or L > 112:
         carry_age = 0
     carry_age = min(carry_age, 12)

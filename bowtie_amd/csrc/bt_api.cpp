@@ -107,11 +107,7 @@ extern "C" void bt_policy_default(bt_policy* p)
 
 extern "C" int bt_has_pe_v1(void)
 {
-#ifdef BT_PE_V1
 	return 1;
-#else
-	return 0;
-#endif
 }
 
 extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate_override, int device,
@@ -259,9 +255,6 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	c->idx = idx; c->pol = *pol;
 	c->best = pol->best != 0 || pol->pe_v1 != 0;
 	c->pol.best = c->best ? 1 : 0;
-#ifndef BT_PE_V1
-	if (pol->pe_v1) return BT_ERR_ARG;       /* bf_run_pair_v1 is compiled into the kernel with make PE_V1=1 only (bt_best.h) */
-#endif
 	int rc = c->best ? bt_host_compile_best(*pol, &c->bprog) : bt_host_compile_program(*pol, &c->prog);
 	if (rc != BT_OK) return rc;
 	bool need_mirror = c->best && c->bprog.needMirror;
@@ -284,6 +277,7 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	c->rl3 = env_u32("BT_NO_RL3", 0) == 0 && c->occ == 2;
 	c->nLanes = c->cus * (c->rl3 && c->blocksPerCU < 3u ? 3u : c->blocksPerCU) * BT_BLOCK;
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 64));
+	HIPCHK(hipMemset(c->d_cursor, 0, 64));
 	/* carry-over between the launches of this context (bt_kernels.h): asked for with bt_ctx_set_carry or BT_CARRY=1 */
 	c->carryAge = env_u32("BT_CARRY", 0);
 	if (c->carryAge > BT_BATCH_RING - 2) c->carryAge = BT_BATCH_RING - 2;
@@ -301,8 +295,9 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 		HIPCHK(hipMalloc((void**)&c->d_batch, sizeof(BtBatchDev)));
 		HIPCHK(hipMemcpy(c->d_bprog, &c->bprog, sizeof(BfProgram), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(c->d_ix, idx->dev, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
-		/* the best-first kernel is built for two waves per SIMD (248 VGPRs): two 256-lane blocks per CU */
-		c->nLanes = c->cus * 2u * BT_BLOCK;
+		/* blocks per CU = waves per SIMD the best-first kernel was compiled for (bt_best_kernels.hip, BT_BEST_MIN_BLOCKS);
+		 * BT_BEST_BLOCKS_PER_CU overrides it for A/B runs */
+		c->nLanes = c->cus * env_u32("BT_BEST_BLOCKS_PER_CU", bt_best_blocks_per_cu()) * BT_BLOCK;
 	}
 	return BT_OK;
 }
@@ -361,7 +356,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	/* arena words per lane: typical reads need a few thousand; a read that outgrows its arena is
 	 * flagged (BT_STF_OVERFLOW) and re-run by bt_align_batch through the twin context's 16 MB arenas */
 	const uint32_t words = c->is_big ? (1u << 22) : env_u32("BT_BEST_ARENA_WORDS", 16384u);
-	const uint32_t lanes = c->is_big ? (c->nLanes > 1024u ? 1024u : c->nLanes) : c->nLanes;
+	const uint32_t lanes = c->is_big ? (c->nLanes > 256u ? 256u : c->nLanes) : c->nLanes;
 	if (!c->arenas || c->arenaWords != words || c->arenaLanes < lanes) {
 		if (c->arenas) (void)hipFree(c->arenas);
 		c->arenas = nullptr;
@@ -387,13 +382,19 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
 	A.workList = nullptr; A.workCount = nullptr;
+	/* per-launch HIP events, as on the phase-program path (bt_ctx_span_ms / bt_ctx_launch_ms) */
+	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
+	hipEvent_t* ring = c->evRing[c->spanLaunches & 15u];
+	c->spanLaunches++;
+	HIPCHK(hipEventRecord(ring[0], c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_best_kernel");
 	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
 	if (!c->is_big && env_u32("BT_BEST_DEVICE_RETRY", 1)) {
-		/* reads that outgrew their arena: collected and searched again on the stream, 1024 lanes with 16 MB
-		 * arenas each -- the caller of the device-pointer entry points sees finished results only */
-		const uint32_t bigWords = 1u << 22, bigLanes = 1024u;
+		/* reads that outgrew their arena: collected and searched again on the stream, 256 lanes with 16 MB
+		 * arenas each (4 GiB; such reads are rare) -- the caller of the device-pointer entry points sees finished
+		 * results only */
+		const uint32_t bigWords = 1u << 22, bigLanes = 256u;
 		if (!c->bigArenas) HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u));
 		const int rrc = ctx_ensure_retry_list(c, in->n_reads);
 		if (rrc != BT_OK) return rrc;
@@ -403,6 +404,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2; A2.workCap = c->retryCap;
 		if (bt_launch_best(&A2, bigLanes / BT_BLOCK, c->stream) != 0) return BT_ERR_DEVICE;
 	}
+	HIPCHK(hipEventRecord(ring[1], c->stream));
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	c->timed = true;
 	return BT_OK;
@@ -559,7 +561,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	 * Off by default (BT_DEVICE_RETRY=1 turns it on): the second pass runs the EXT instances of the kernel, whose fault on
 	 * two inputs of the simple_tests suite was fixed too late in round 2 for the whole GPU suite to run through them
 	 * (DESIGN.md 4.4). */
-	const bool devRetry = async && retry_on_stream && !c->is_big && env_u32("BT_DEVICE_RETRY", 0);
+	const bool devRetry = async && retry_on_stream && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
 	if (devRetry) {
 		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_scratch(c->big, maxLen, false)) != BT_OK) return rc;

@@ -47,16 +47,10 @@
 #define BF_FN static
 #define BF_INL static inline
 #endif
-/* PairedBWAlignerV1 support (bf_run_pair_v1): always in host builds (the test emulator); in the device build only
- * with -DBT_PE_V1 (make PE_V1=1) until it has been run on a GPU -- without the flag the kernel is, instruction for
- * instruction, the one the GPU suite was run on (checked by diffing the device assembly). */
-#if defined(BT_PE_V1) || !defined(__HIP_DEVICE_COMPILE__)
+/* PairedBWAlignerV1 (bf_run_pair_v1, the reference's default paired-end aligner): part of every build since round 3
+ * (GPU-verified against the 120 reference outputs of tests/golden/pe_v1) */
 #define BF_HAVE_V1 1
 #define BF_IS_V1(P) ((P).paired == 2u)
-#else
-#define BF_HAVE_V1 0
-#define BF_IS_V1(P) false
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
 #else

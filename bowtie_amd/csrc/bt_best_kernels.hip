@@ -80,6 +80,16 @@ extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint
 	return (int)hipGetLastError();
 }
 
+/* blocks per CU the kernel's register budget allows (= waves per SIMD: 256-lane blocks, 4 SIMDs) */
+extern "C" uint32_t bt_best_blocks_per_cu(void)
+{
+#ifdef BT_BEST_MIN_BLOCKS
+	return BT_BEST_MIN_BLOCKS;
+#else
+	return 2u;
+#endif
+}
+
 extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)
 {
 	hipLaunchKernelGGL(bt_best_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);

@@ -46,6 +46,7 @@ struct Options {
 	bool no_stream = false, stream = false;
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false, paired = false;
+	bool best_given = false;     /* --best itself: what clears the reference's useV1 (ebwt_search.cpp:776); -v 3 / -M only set `stateful` */
 	std::string mates1, mates2;
 	std::string tab12, ileaved;              /* --12 / --interleaved file lists */
 	std::string quals, quals1, quals2;       /* -Q / --Q1 / --Q2 */
@@ -132,23 +133,23 @@ void usage(FILE* o)
 	    "  --device <list>    GPU(s) to run on, e.g. 0,1,2,3: index replicated, batches dealt out (default: 0)\n"
 	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
-	    "  --stream           (opt-in) stream unpaired batches through one context per GPU with\n"
-	    "                     carry-over between batches instead of searching --inflight whole batches\n"
-	    "                     side by side\n"
-	    "  --no-stream        the default\n"
+	    "  --stream           the default for unpaired reads without --best: batches stream through one\n"
+	    "                     context per GPU, reads still running when a batch ends are carried into the next\n"
+	    "  --no-stream        search --inflight whole batches side by side instead\n"
 	    "Other:\n"
 	    "  --seed <int>       seed for random number generator\n"
 	    "  --version          print version information and quit\n"
 	    "  -h/--help          print this usage message\n"
-	    "Paired-end (with --best: the reference's PairedBWAlignerV2):\n"
+	    "Paired-end (without --best: the reference's PairedBWAlignerV1, its default; with --best: PairedBWAlignerV2):\n"
 	    "  -1 <m1> -2 <m2>    files with #1 and #2 mates (comma-separated lists; same format options as <s>)\n"
 	    "  -I/--minins <int>  minimum insert size (default: 0)\n"
 	    "  -X/--maxins <int>  maximum insert size (default: 250)\n"
 	    "  --fr/--rf/--ff     -1, -2 mates align fw/rev, rev/fw, fw/fw (default: --fr)\n"
 	    "  --pairtries <int>  max # anchors tried per pair (default: 100)\n"
 	    "  --allow-contain    one mate alignment may contain the other\n"
-	    "Not in this build: paired-end without --best (PairedBWAlignerV1), --12 --interleaved -Q -z,\n"
-	    "  -M and --al/--un/--max with pairs\n",
+	    "  --12 <f> / --interleaved <f>   pairs (or, --12, unpaired reads) from one tab-delimited / FASTQ file\n"
+	    "Not in this build: -z, --mm / --shmem, --12 / --interleaved from standard input, a --12 file that mixes\n"
+	    "  paired and unpaired records, indexes of 2^32-1 rows or more\n",
 	    o);
 }
 
@@ -339,7 +340,7 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_FR: O->pol.mate1_fw = 1; O->pol.mate2_fw = 0; break;
 		case O_PAIRTRIES: O->pol.pair_tries = (int32_t)parse_int(val, 1, "--pairtries arg must be at least 1"); break;
 		case O_ALLOW_CONTAIN: O->pol.allow_contain = 1; break;
-		case O_BEST: O->pol.best = 1; break;
+		case O_BEST: O->pol.best = 1; O->best_given = true; break;
 		case O_STRATA: O->pol.strata = 1; break;
 		case 'B': O->out.off_base = (int32_t)parse_int(val, -999999, "-B/--offbase arg must be at least -999999"); break;
 		case 'x': O->index = val; break;
@@ -455,7 +456,6 @@ void parse_args(int argc, char** argv, Options* O)
 		 * or not, the reference then runs its stateful aligners (:3001-3002) */
 		if (!O->mates1.empty() || !O->mates2.empty() || (!O->tab12.empty() && !O->ileaved.empty()))
 			die("Error: --12 / --interleaved cannot be combined with -1/-2 or with each other in this build");
-		if (!O->pol.best) die("Error: --12 / --interleaved input runs the reference's stateful aligners, which this build has for --best only; add --best");
 		/* both mate streams open the file, and a --12 file is looked into beforehand: not possible with a pipe */
 		for (const std::string& f : split_commas(O->tab12.empty() ? O->ileaved : O->tab12))
 			if (f == "-") die("Error: --12 / --interleaved input from standard input is not in this build; give a file");
@@ -467,16 +467,20 @@ void parse_args(int argc, char** argv, Options* O)
 		/* ebwt_search.cpp:855-860 */
 		const size_t c1 = (size_t)std::count(O->mates1.begin(), O->mates1.end(), ',') + (O->mates1.empty() ? 0 : 1);
 		const size_t c2 = (size_t)std::count(O->mates2.begin(), O->mates2.end(), ',') + (O->mates2.empty() ? 0 : 1);
-		if (c1 != c2 && O->rd.format != BT_FMT_CMDLINE)
+		if (c1 != c2)
 			die("Error: %zu mate files/sequences were specified with -1, but %zu\nmate files/sequences were specified with -2.  The same number of mate files/\nsequences must be specified with -1 and -2.", c1, c2);
-		if (!O->pol.best) {
-			/* the reference's default paired-end aligner, PairedBWAlignerV1: in the library only when it was built with it */
-			if (!bt_has_pe_v1() || one_file) die("Error: paired-end alignment without --best runs the reference's PairedBWAlignerV1, which this build does not have; add --best");
+		if (!O->best_given) {
+			/* the reference's default paired-end aligner, PairedBWAlignerV1 (useV1, ebwt_search.cpp:232): only --best
+			 * itself selects PairedBWAlignerV2 (:776) -- -v 3 and -M make the run stateful but leave useV1 alone */
 			O->pol.pe_v1 = 1;
 			if (!O->maxbts_set) O->pol.max_bts = 800;              /* every stateful aligner: ebwt_search.cpp:185-186, 2644, 2670 */
 		}
 	} else if (one_file) {
+		/* unpaired records in a --12 file: the run is stateful all the same (:3001-3002), i.e. UnpairedAlignerV2 --
+		 * what --best selects for unpaired reads */
 		O->reads = O->tab12;
+		O->pol.best = 1;
+		if (!O->maxbts_set) O->pol.max_bts = 800;
 	} else {
 	if (pi >= pos.size()) { fprintf(stderr, "No query or output file specified!\n"); usage(stderr); exit(1); }
 	O->reads = pos[pi++];
@@ -826,7 +830,7 @@ int main(int argc, char** argv)
 	/* `--inflight` whole batches are searched side by side, each on its own context and stream.  --stream
 	 * (opt-in: unpaired, phase-program engine) instead keeps one context per GPU fed through
 	 * bt_align_stream_* with the reads a batch leaves running carried into the next ones (bt_ctx_set_carry). */
-	const bool streamed = !O.paired && !O.pol.best && O.stream && !O.no_stream;
+	const bool streamed = !O.paired && !O.pol.best && !O.no_stream;      /* --stream is the default (round 3: GPU-verified) */
 	std::vector<bt_ctx*> ctxs((size_t)(streamed ? 1 : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */
 	std::vector<bt_ctx*> redo_ctxs(streamed ? ctxs.size() : 0, nullptr);
 	for (size_t g = 0; g < ctxs.size(); g++) {

@@ -3,8 +3,8 @@
  *
  * This is the drop-in boundary for the one data-parallel path of BenLangmead/bowtie v1.3.1 that
  * this project accelerates: everything a reference worker thread does for a read between
- * GET_READ and FINISH_READ (ebwt_search.cpp:923-961) in the default (non --best, unpaired)
- * search modes:
+ * GET_READ and FINISH_READ (ebwt_search.cpp:923-961).  The phase-program engine (default, non --best,
+ * unpaired search modes):
  *
  *     exactSearchWorker                    ebwt_search.cpp:1130   (-v 0)
  *     mismatchSearchWorkerFull             ebwt_search.cpp:1606   (-v 1)
@@ -14,7 +14,10 @@
  * i.e. GreedyDFSRangeSource::backtrack (ebwt_search_backtrack.h:237-1091), the Ebwt rank/LF
  * primitives (ebwt.h:1418-1523, 1696-2560), Ebwt::reportChaseOne/joinedToTextOff
  * (ebwt.h:2569-2755), the phase scripts search_*.c and the per-read stop/continue policy of
- * NGoodHitSinkPerThread / AllHitSinkPerThread (hit.h:969-985, 1201-1209).
+ * NGoodHitSinkPerThread / AllHitSinkPerThread (hit.h:969-985, 1201-1209); and the best-first engine
+ * (`--best`, `--strata`, `-M`, `-v 3`, and every paired-end run): the *Stateful workers
+ * (ebwt_search.cpp:1223, 1509, 1955, 2609) with UnpairedAlignerV2, PairedBWAlignerV1 (pairs without --best,
+ * aligner.h:606-1480) and PairedBWAlignerV2 (pairs with --best, aligner.h:1483-2051).
  *
  * The reference has no FFI for this path (it is one C++ process); the seams this ABI replaces
  * are cited per entry point.  Plain pointers and sizes only; no exceptions cross the boundary
@@ -36,7 +39,8 @@ extern "C" {
 /* ---- error codes ------------------------------------------------------------------------ */
 #define BT_OK              0
 #define BT_ERR_IO          1   /* index file missing / short read                             */
-#define BT_ERR_FORMAT      2   /* not a small little-endian lineRate-6 .ebwt index            */
+#define BT_ERR_FORMAT      2   /* not a bowtie index family member this loader reads (.ebwt,
+                                  .ebwtl / .bt2l with < 2^32-1 rows, .bt2 side layout), or damaged */
 #define BT_ERR_ARG         3   /* bad policy / batch                                          */
 #define BT_ERR_DEVICE      4   /* HIP runtime error (no GPU, OOM, launch failure)             */
 #define BT_ERR_READ_SHORT  5   /* read shorter than the mode allows (reference: throw 1,
@@ -80,16 +84,12 @@ typedef struct bt_policy {
 	int32_t  pe_v1;        /* pairs only: 1 = PairedBWAlignerV1 (aligner.h:606-1480), the reference's paired-end
 	                          aligner when --best is NOT given (ebwt_search.cpp:232, 776); 0 = PairedBWAlignerV2
 	                          (--best).  Either way the stateful engine runs (best is taken as set) and max_bts
-	                          defaults to 800 (ebwt_search.cpp:186, 2644, 2670).  NOT YET RUN ON A GPU: verified
-	                          against the reference only through the host emulator, and compiled into the kernel
-	                          only with `make PE_V1=1` (bt_has_pe_v1() says which) -- otherwise bt_ctx_create returns BT_ERR_ARG
-	                           */
+	                          defaults to 800 (ebwt_search.cpp:186, 2644, 2670) */
 	int32_t  reserved[1];
 } bt_policy;
 
 void bt_policy_default(bt_policy* p);   /* reference defaults: -n 2 -l 28 -e 70 -k 1          */
-int  bt_has_pe_v1(void);                /* 1: this build of the library takes bt_policy.pe_v1 (make PE_V1=1), 0: it answers
-                                           it with BT_ERR_ARG                                    */
+int  bt_has_pe_v1(void);                /* 1: this build of the library takes bt_policy.pe_v1 (every build since round 3) */
 
 /* ---- reads in: what PatternSourcePerThread hands the worker (read.h:42-273) -------------- */
 typedef struct bt_read_batch {

@@ -56,5 +56,5 @@ for wl in ecoli_n2_best_100 ecoli_pe_n1_best_50; do
     say "$wl $lib: $(python -c "import json,sys; d=json.loads(open('$O/bench_${wl}_${lib%.so}.json').read().strip().splitlines()[-1]); print('%.3f M reads/s, kernel %.1f ms' % (d['value']/1e6, d.get('kernel_ms_avg', 0)))" 2>&1 | tail -1)"
   done
 done
-BT_LIB=libbowtie_amd_best2.so timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "best or paired" > $O/best2_tests.txt 2>&1; say "best2 build, best-first + paired GPU tests: $(tail -1 $O/best2_tests.txt)"
+[ -n "$R3_BEST2_TESTS" ] && BT_LIB=libbowtie_amd_best2.so timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "best or paired" > $O/best2_tests.txt 2>&1; say "best2 build, best-first + paired GPU tests: $(tail -1 $O/best2_tests.txt)"
 cat $S

@@ -14,8 +14,7 @@ static std::mutex g_emu_mutex;        /* the emulator loads the 2-bit reference 
 struct bt_index { void* emu = nullptr; bool mirror = false; int variant = 1; };
 struct bt_ctx { const bt_index* ix = nullptr; bt_policy pol; bool best = false; std::deque<void*> done; };
 
-/* BT_SHIM_PE_V1=1: answer as a library built with make PE_V1=1 would (the emulator has bf_run_pair_v1 either way) */
-extern "C" int bt_has_pe_v1(void) { const char* e = getenv("BT_SHIM_PE_V1"); return e && e[0] == '1'; }
+extern "C" int bt_has_pe_v1(void) { return 1; }
 
 extern "C" int bt_index_load(const char* base, int need_mirror, int offrate_override, int device, bt_index** out)
 {
@@ -59,7 +58,6 @@ extern "C" int bt_ctx_create(const bt_index* idx, const bt_policy* pol, void* st
 	(void)stream;
 	if (!idx || !pol || !out) return BT_ERR_ARG;
 	*out = nullptr;
-	if (pol->pe_v1 && !bt_has_pe_v1()) return BT_ERR_ARG;   /* as the default build of the library answers */
 	bt_ctx* c = new bt_ctx();
 	c->ix = idx; c->pol = *pol; c->best = pol->best != 0 || pol->pe_v1 != 0;
 	c->pol.best = c->best ? 1 : 0;

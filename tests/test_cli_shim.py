@@ -27,22 +27,16 @@ def shim():
     return SHIM
 
 
-@pytest.mark.parametrize("files,pe_v1", [(["tests/test_gpu_cli.py"], False), (["tests/test_simple_cases.py"], False), (["tests/test_zz_gpu_fuzz.py"], False),
-                                         (["tests/test_gpu_cli.py", "--stream"], False),
-                                         (["tests/test_simple_cases.py", "-k", "test_simple_case_bowtie_amd"], True),
-                                         (["tests/test_zz_gpu_fuzz.py", "-k", "without_best"], True)],
-                         ids=lambda x: x[0][6:-3] if isinstance(x, list) else ("as_a_PE_V1_build" if x else "as_the_default_build"))
-def test_binary_suites_through_the_cpu_shim(files, pe_v1, shim):
-    """pe_v1: the shim answers as a library built with make PE_V1=1 does, and the binary then takes paired-end input
-    without --best (the reference's default paired-end aligner): the simple_tests.pl pairs as written, and the fuzz."""
+@pytest.mark.parametrize("files", [["tests/test_gpu_cli.py"], ["tests/test_simple_cases.py"], ["tests/test_zz_gpu_fuzz.py"],
+                                   ["tests/test_gpu_cli.py", "--no-stream"], ["tests/test_simple_cases.py", "-k", "test_simple_case_bowtie_amd", "--no-stream"]],
+                         ids=lambda x: x[0][6:-3] + ("_no_stream" if x[-1] == "--no-stream" else ""))
+def test_binary_suites_through_the_cpu_shim(files, shim):
+    """The binary streams unpaired default-engine batches by default (the shim answers the asynchronous entry points
+    synchronously); the --no-stream runs put the same cases through the whole-batch search loop."""
     env = dict(os.environ, BT_TEST_CLI_SHIM="1", LD_PRELOAD=shim, BT_GPU_FUZZ_SEEDS="12")
-    if files[-1] == "--stream":
-        # every unpaired default-engine run through the binary's streamed search loop (the shim answers the asynchronous
-        # entry points synchronously)
+    if files[-1] == "--no-stream":
         files = files[:-1]
-        env["BT_TEST_CLI_EXTRA"] = "--stream"
-    if pe_v1:
-        env.update(BT_SHIM_PE_V1="1", BT_SIMPLE_PAIRED_VARIANT="asis")
+        env["BT_TEST_CLI_EXTRA"] = "--no-stream"
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=T.ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
     tail = p.stdout.decode(errors="replace")[-1500:]

@@ -232,11 +232,12 @@ def _paired_fuzz(seed, tmp_path, best):
     _write_fastq(f1, m1, 1)
     _write_fastq(f2, m2, 2)
     for _ in range(3):
-        args = rng.choice(PAIRED_POLICIES if best else PAIRED_POLICIES[:5] + PAIRED_POLICIES[6:]) + (["--best"] if best else []) + \
-            rng.choice(PAIRED_REPORTS if best else [r for r in PAIRED_REPORTS if "--strata" not in r and "-M" not in r]) + \
+        args = rng.choice(PAIRED_POLICIES) + (["--best"] if best else []) + rng.choice(PAIRED_REPORTS) + \
             rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"], ["-5", "2", "-3", "1"]]) + out_options(rng)
         if not _args_ok(args):
             continue
+        if not best and "--strata" in args and "-M" not in args and args[:2] != ["-v", "3"]:
+            continue            # "--strata must be combined with --best" unless -v 3 / -M made the run stateful already
         ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, "-1", f1, "-2", f2],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         if ref.returncode != 0:
@@ -385,6 +386,8 @@ def test_paired_engines_on_medium_genomes_against_the_reference(seed, best, tmp_
         args = rng.choice(pols) + (["--best"] if best else []) + rng.choice(reps) + rng.choice([["-X", "500"], ["-X", "300", "-I", "100"], []]) + out_options(rng)
         if not _args_ok(args):
             continue
+        if not best and "--strata" in args and "-M" not in args and args[:2] != ["-v", "3"]:
+            continue            # "--strata must be combined with --best" unless -v 3 / -M made the run stateful already
         ref = subprocess.run([REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, "-1", f1, "-2", f2],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert ref.returncode == 0, (args, ref.stderr[-300:])

@@ -94,7 +94,7 @@ def test_cli_output_file_and_quiet(tmp_path):
     (["-c", "-v", "1"], "A", "Error: Reads must be at least 2 characters long in 1-mismatch mode"),
     (["--strata"], "cli/io.fq", "--strata must be combined with --best"),
     (["--best", "--strata"], "cli/io.fq", "--strata has no effect unless combined with"),
-    (["-1", "cli/pe_1.fq", "-2", "cli/pe_2.fq"], "", "add --best"),
+    (["-c", "-1", "ACGTACGTAC,TTTTACGTAC", "-2", "ACGTACGTAC"], "", "2 mate files/sequences were specified with -1, but 1"),
     (["--best", "-1", "cli/pe_1.fq", "-2", "cli/pee_2.fq"], "", "fewer reads in file specified with -2"),
 ])
 def test_cli_errors(args, reads, msg):

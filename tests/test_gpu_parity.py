@@ -273,7 +273,7 @@ def test_gpu_device_path_settles_the_build_on_the_device(rname, gidx):
 def test_gpu_device_path_retries_overflowed_reads_on_the_stream(gidx, monkeypatch):
     """bt_align_batch_device with absurdly small arenas: the reads that outgrow them are collected and searched again
     on the same stream (no host copy); what the caller reads back after the sync is complete and equals the oracle's."""
-    monkeypatch.setenv("BT_DEVICE_RETRY", "1")                  # opt-in: see DESIGN.md 4.4
+    monkeypatch.setenv("BT_DEVICE_RETRY", "1")                  # the default since round 3
     monkeypatch.setenv("BT_ENTRY_CAP", "24")
     monkeypatch.setenv("BT_FRAME_CAP", "3")
     monkeypatch.setenv("BT_PARTIAL_CAP", "4")
@@ -481,9 +481,6 @@ def test_gpu_paired_matches_reference_sam(run, gidx):
     T.check_pairs_against_golden(run, res, b1, b2, gidx[run["index"]].refnames)
 
 
-@pytest.mark.skipif(os.environ.get("BT_RUN_UNVERIFIED") != "1",
-                    reason="bf_run_pair_v1 has only been verified in the host emulator so far (DESIGN.md 4.2): build with "
-                           "`make -C bowtie_amd/csrc PE_V1=1` and set BT_RUN_UNVERIFIED=1")
 @pytest.mark.parametrize("run", T.paired_v1_runs(), ids=lambda r: r["file"][6:-7])
 def test_gpu_paired_without_best_matches_reference_sam(run, gidx):
     """Paired-end without --best (PairedBWAlignerV1) on the GPU against the reference's outputs."""

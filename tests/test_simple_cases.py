@@ -28,17 +28,27 @@ def manifest():
         return json.load(f)
 
 
-def all_runs(paired_variant=os.environ.get("BT_SIMPLE_PAIRED_VARIANT", "best")):
-    """(case, run): unpaired cases as the harness runs them; paired ones in their --best variant
-    (without it the reference uses PairedBWAlignerV1, which this build refuses)."""
+def all_runs():
+    """(case, run): every case as the harness runs it ("asis": pairs go through PairedBWAlignerV1, the reference's
+    default; --12 / --interleaved input puts the reference on its stateful aligners whether the records are pairs or
+    not, ebwt_search.cpp:3001-3002), and the paired / one-file cases once more with --best added (PairedBWAlignerV2)."""
     out = []
     for c in manifest()["cases"]:
         for r in c.get("runs", []):
-            # --12 / --interleaved input puts the reference on its stateful aligners whether the records are pairs
-            # or not (ebwt_search.cpp:3001-3002): compared in the --best variant as well
-            if r["variant"] == ("best" if c.get("needs_best") else paired_variant if c["paired"] else "asis"):
+            if r["variant"] == "asis" or (r["variant"] == "best" and (c["paired"] or c.get("needs_best"))):
                 out.append((c, r))
     return out
+
+
+def engine_policy(case, run, pol):
+    """what the reference's choice of aligner means for bt_policy: pairs without --best -> PairedBWAlignerV1; unpaired
+    records from a --12 file -> the stateful unpaired aligner, i.e. what --best selects"""
+    one_file = case["reads"][0] in ("--12", "--interleaved")
+    if case["paired"] and "--best" not in run["args"]:
+        return dict(pol, pe_v1=True)
+    if one_file and not case["paired"]:
+        return dict(pol, best=True)
+    return pol
 
 
 @pytest.fixture(scope="session")
@@ -98,12 +108,13 @@ def test_simple_case_oracle_and_host_io(case, run, simple_index):
     if base not in _oi:
         _oi[base] = OL.OracleIndex(base)
     oi = _oi[base]
+    pol = engine_policy(case, run, pol)
     opol = OL.make_policy(**pol)
     import refrun as R
     opts = H.out_opts(**out)
     if case["paired"]:
         cap = 4096 if pol.get("all_hits") else 2 * pol.get("khits", 1)
-        per = R.oracle_search_pairs(oi, opol, b1, b2, cap=cap)
+        per = R.oracle_search_pairs(oi, opol, b1, b2, cap=cap, v1=bool(pol.get("pe_v1")))
         hits, nh, st, pool = H.pack_hits(per, cap)
         text, _ = H.format_pairs(b1, b2, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
     else:
@@ -176,7 +187,7 @@ def test_simple_case_automaton_emu(case, run, simple_index):
     if base not in _oi:
         _oi[base] = OL.OracleIndex(base)
     oi = _oi[base]
-    p = A.make_policy(**pol)
+    p = A.make_policy(**engine_policy(case, run, pol))
     opts = H.out_opts(**out)
     if case["paired"]:
         cap = 4096 if pol.get("all_hits") else 2 * pol.get("khits", 1)
@@ -202,15 +213,6 @@ def test_simple_case_bowtie_amd(case, run, simple_index):
     assert (p.returncode != 0) == (run["returncode"] != 0), p.stderr.decode(errors="replace")
     if run["returncode"] == 0:
         assert p.stdout == expected(run)
-
-
-@pytest.mark.gpu
-def test_paired_without_best_is_refused(simple_index):
-    c = [c for c in manifest()["cases"] if c.get("paired") and c.get("runs")][0]
-    r = [r for r in c["runs"] if r["variant"] == "asis"][0]
-    p = subprocess.run([BIN] + r["args"] + ["-x", simple_index(c["ref"])] + c["reads"], stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, cwd=T.G, timeout=600)
-    assert p.returncode == 1 and b"add --best" in p.stderr
 
 
 DOLLAR_ROW = [(c, r) for c, r in all_runs() if c["id"] in (5, 100)]

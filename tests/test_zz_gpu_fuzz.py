@@ -57,17 +57,10 @@ def test_binary_against_the_reference_unpaired(seed, tmp_path):
         if not F._args_ok(args):
             continue
         stateful = "--best" in args or "--strata" in args or "-M" in args or args[:2] == ["-v", "3"]
-        extra = ["--stream"] if (not stateful and rng.random() < 0.34) else []
+        extra = ["--no-stream"] if (not stateful and rng.random() < 0.34) else []      # streaming is the default
         extra = extra + rng.choice([[], [], ["--batch", "3"], ["--batch", "2", "--inflight", "3"]])      # tiny batches: boundaries, order
         ref, got = _both(args, ["-x", base, fq], extra)
         _check(ref, got, (seqs, extra + args))
-
-
-def _has_pe_v1():
-    if os.environ.get("BT_TEST_CLI_SHIM") == "1":
-        return os.environ.get("BT_SHIM_PE_V1") == "1"
-    from bowtie_amd import aligner as AL
-    return bool(AL.lib().bt_has_pe_v1())
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_SEEDS", "40"))))
@@ -77,9 +70,7 @@ def test_binary_against_the_reference_paired(seed, tmp_path):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_SEEDS", "40"))))
 def test_binary_against_the_reference_paired_without_best(seed, tmp_path):
-    """The reference's default paired-end aligner -- for a library built with make PE_V1=1."""
-    if not _has_pe_v1():
-        pytest.skip("this build of the library does not take paired-end input without --best")
+    """The reference's default paired-end aligner, PairedBWAlignerV1."""
     _paired(seed, tmp_path, False)
 
 
@@ -111,10 +102,11 @@ def _paired(seed, tmp_path, best):
     F._write_fastq(f1, m1, 1)
     F._write_fastq(f2, m2, 2)
     for _ in range(3):
-        args = rng.choice(F.PAIRED_POLICIES if best else F.PAIRED_POLICIES[:5] + F.PAIRED_POLICIES[6:]) + (["--best"] if best else []) + \
-            rng.choice(F.PAIRED_REPORTS if best else [r for r in F.PAIRED_REPORTS if "--strata" not in r and "-M" not in r]) + \
+        args = rng.choice(F.PAIRED_POLICIES) + (["--best"] if best else []) + rng.choice(F.PAIRED_REPORTS) + \
             rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"]]) + F.out_options(rng)
         if not F._args_ok(args):
             continue
+        if not best and "--strata" in args and "-M" not in args and args[:2] != ["-v", "3"]:
+            continue            # "--strata must be combined with --best" unless -v 3 / -M made the run stateful already
         ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2], rng.choice([[], [], ["--batch", "2"], ["--batch", "3", "--inflight", "1"]]))
         _check(ref, got, (seqs, args))
