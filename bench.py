@@ -143,7 +143,7 @@ def _gpu_sam(idx, pol, batches):
     return text
 
 
-def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: float = 10.0):
+def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: float = 10.0, diff_only: bool = False):
     """Reference bowtie (oracle/_ref, unmodified) on bounded FASTQ samples of the same workload, on this
     box's host cores: a -p sweep (two sample sizes per setting: the difference cancels index load and
     thread start-up), -p 1, the reference's own "Time searching" (-t), and -- parity at this scale,
@@ -189,6 +189,18 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: fl
 
             nA = 40_000 if paired else 200_000
             bA, inA = make(nA, 4321)
+            if diff_only:
+                # the parity leg alone: the reference's SAM for the sample against the product's
+                p = min(64, cores)
+                sam_path = os.path.join(td, "ref.sam")
+                w, _ = run(p, inA, out=sam_path, extra=["-S", "--sam-nohead", "--reorder"])
+                with open(sam_path, "rb") as f:
+                    want = f.read().split(b"\n")
+                got = _gpu_sam(idx, A.make_policy(**pol), bA).split(b"\n")
+                bad = sum(1 for a, b in zip(got, want) if a != b) + abs(len(got) - len(want))
+                return {"value": nA * unit / w, "unit": "reads/s", "cores": p, "kind": "reference", "host_cores": cores,
+                        "cpu_model": _cpu_model(), "reads_diffed_vs_reference": nA * unit, "diff_mismatches": bad,
+                        "sample": "unmodified bowtie-align-s %s -p %d on %d reads, index load included (diff only, no sweep)" % (" ".join(args), p, nA * unit)}
             # size the larger sample from a first run at all cores
             wA, _ = run(cores, inA)
             nB = int(min(2_000_000 // unit if paired else 4_000_000, max(3 * nA, seconds * nA / max(wA, 0.5))))
@@ -273,6 +285,14 @@ def main():
                     help="weak: the workload's reads per GPU (default); strong: that many reads in total, sharded over the GPUs")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
+    ap.add_argument("--also", default="auto",
+                    help="comma-separated workloads to run afterwards (2 steps each, own process, SAM diff against the reference) "
+                         "and report under config.other_workloads; 'auto' = BASELINE configs 3 and 5 (big_v2_76, "
+                         "big_pe_n1_best_50) after the default single-GPU run, nothing otherwise; 'none' = nothing")
+    ap.add_argument("--cpu-diff-only", action="store_true",
+                    help="CPU leg: only the SAM diff of a sample against the reference binary (no -p sweep)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="with --gpus N > 1 and weak scaling: skip the second, strong-scaling measurement (config.strong)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -330,7 +350,6 @@ def main():
     if not args.verify:
         del text_t
     hit_cap = 2 if paired else 1
-    mm_cap = n * 8
     pol = A.make_policy(**wl["pol"])
     lib = AL.lib()
     # Software pipelining across steps: `--pipes` contexts, each with its own HIP stream, scratch and
@@ -341,96 +360,107 @@ def main():
     # all been handed out are parked and resumed by the context's next step, so a step's results are complete when
     # the next step (or the closing bt_ctx_sync, inside the timed region) is.  Each context therefore alternates
     # between two sets of output arrays.
-    carry_age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (12 if n < 64_000_000 else 0))
-    if paired or wl["pol"].get("best") or L > 112:
-        carry_age = 0
-    carry_age = min(carry_age, 12)
-    carry = carry_age > 0
-    pipes = []
-    for pi in range(max(1, args.pipes)):
-        st = torch.cuda.current_stream() if pi == 0 else torch.cuda.Stream()
-        o = dict(stream=st, busy=False, sets=[])
-        # a step's outputs stay in use until the last of its reads is done: carry_age launches later at most
-        for si in range(min(carry_age + 1, max(args.steps, args.warmup, 1)) if carry else 1):
-            d = dict(hits=torch.zeros(n * hit_cap * 24, dtype=torch.uint8, device=dev),
-                     n_hits=torch.zeros(n, dtype=torch.int32, device=dev),
-                     status=torch.zeros(n, dtype=torch.uint8, device=dev),
-                     mm_pool=torch.zeros(mm_cap, dtype=torch.int16, device=dev))
-            d["hbc"] = A.HitBatchC(hit_cap, d["hits"].data_ptr(), d["n_hits"].data_ptr(), d["status"].data_ptr(),
-                                   d["mm_pool"].data_ptr(), mm_cap, 0)
-            o["sets"].append(d)
-        o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
-        if carry and lib.bt_ctx_set_carry(o["al"]._h, carry_age) != 0:
-            raise RuntimeError("bt_ctx_set_carry failed")
-        lib.bt_ctx_set_max_read_len(o["al"]._h, L)         # synthetic reads: all of length L (rows are padded to 16)
-        pipes.append(o)
-    torch.cuda.synchronize()
-    log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
-    rbc = A.ReadBatchC(n, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(),
-                       rb["seed"].data_ptr())
-    rbc2 = None
-    if paired:
-        rbc2 = A.ReadBatchC(n, rb2["stride"], rb2["seq"].data_ptr(), rb2["qual"].data_ptr(), rb2["len"].data_ptr(),
-                            rb2["seed"].data_ptr())
-        if lib.bt_index_load_reference(idx._h) != 0:
-            raise RuntimeError("bt_index_load_reference failed")
-    iters_t = None
-    if args.iters_hist:
-        iters_t = torch.zeros(n, dtype=torch.int32, device=dev)
-        lib.bt_ctx_set_iters_buffer(pipes[0]["al"]._h, iters_t.data_ptr())
-    kernel_ms, flush_ms = [], []
-    last = {}
+    def carry_for(n_use):
+        age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (12 if n_use < 64_000_000 else 0))
+        if paired or wl["pol"].get("best") or L > 112:
+            age = 0
+        return min(age, 12)
 
-    def retire(o):
-        if o["busy"]:
-            if lib.bt_ctx_sync(o["al"]._h) != 0:      # with carry-over: finishes the parked reads first
-                raise RuntimeError("bt_ctx_sync failed")
-            nl = C.c_uint32()
-            lib.bt_ctx_span_ms(o["al"]._h, C.byref(nl))
-            for i in range(max(0, nl.value - 16), nl.value):       # HIP events on the kernel's stream, per launch
-                kernel_ms.append(float(lib.bt_ctx_launch_ms(o["al"]._h, i)))
-            flush_ms.append(float(lib.bt_ctx_launch_ms(o["al"]._h, -1)))
-            o["busy"] = False
+    if paired and lib.bt_index_load_reference(idx._h) != 0:
+        raise RuntimeError("bt_index_load_reference failed")
+    iters_t = torch.zeros(n, dtype=torch.int32, device=dev) if args.iters_hist else None
 
-    def step(k):
-        o = pipes[k % len(pipes)]
-        if not carry:
-            retire(o)
-        d = o["sets"][(k // len(pipes)) % len(o["sets"])]
-        if paired:
-            rc = lib.bt_align_pairs_device(o["al"]._h, C.byref(rbc), C.byref(rbc2), C.byref(d["hbc"]), None)
-        else:
-            rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(d["hbc"]), None)
-        if rc != 0:
-            raise RuntimeError("bt_align_batch_device: " + AL.strerror(rc))
-        o["busy"] = True
-        last["set"] = d
-
-    def barrier():
-        for o in pipes:
-            retire(o)
-        if world > 1:
-            dist.barrier()
+    def measure(n_use, steps, warmup):
+        """`warmup` untimed + `steps` timed steps over the first n_use reads of this rank's buffer: contexts, output
+        arrays, the barrier + synchronize bracket, op counters of the timed steps."""
+        carry_age = carry_for(n_use)
+        carry = carry_age > 0
+        mm_cap = n_use * 8
+        pipes = []
+        for pi in range(max(1, args.pipes)):
+            st = torch.cuda.current_stream() if pi == 0 else torch.cuda.Stream()
+            o = dict(stream=st, busy=False, sets=[])
+            # a step's outputs stay in use until the last of its reads is done: carry_age launches later at most
+            for si in range(min(carry_age + 1, max(steps, warmup, 1)) if carry else 1):
+                d = dict(hits=torch.zeros(n_use * hit_cap * 24, dtype=torch.uint8, device=dev),
+                         n_hits=torch.zeros(n_use, dtype=torch.int32, device=dev),
+                         status=torch.zeros(n_use, dtype=torch.uint8, device=dev),
+                         mm_pool=torch.zeros(mm_cap, dtype=torch.int16, device=dev))
+                d["hbc"] = A.HitBatchC(hit_cap, d["hits"].data_ptr(), d["n_hits"].data_ptr(), d["status"].data_ptr(),
+                                       d["mm_pool"].data_ptr(), mm_cap, 0)
+                o["sets"].append(d)
+            o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
+            if carry and lib.bt_ctx_set_carry(o["al"]._h, carry_age) != 0:
+                raise RuntimeError("bt_ctx_set_carry failed")
+            lib.bt_ctx_set_max_read_len(o["al"]._h, L)         # synthetic reads: all of length L (rows are padded to 16)
+            pipes.append(o)
         torch.cuda.synchronize()
+        rbc = A.ReadBatchC(n_use, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(),
+                           rb["seed"].data_ptr())
+        rbc2 = None
+        if paired:
+            rbc2 = A.ReadBatchC(n_use, rb2["stride"], rb2["seq"].data_ptr(), rb2["qual"].data_ptr(), rb2["len"].data_ptr(),
+                                rb2["seed"].data_ptr())
+        if iters_t is not None:
+            lib.bt_ctx_set_iters_buffer(pipes[0]["al"]._h, iters_t.data_ptr())
+        kernel_ms, flush_ms = [], []
+        last = {}
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    cnt = A.OpCounts()
-    for o in pipes:
-        lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 1)        # reset: count the timed steps only
-    kernel_ms.clear()
-    flush_ms.clear()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    wall = time.perf_counter() - t0
-    c = {}
-    for o in pipes:
-        lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 0)
-        for kk, v in cnt.as_dict().items():
-            c[kk] = c.get(kk, 0) + v
+        def retire(o):
+            if o["busy"]:
+                if lib.bt_ctx_sync(o["al"]._h) != 0:      # with carry-over: finishes the parked reads first
+                    raise RuntimeError("bt_ctx_sync failed")
+                nl = C.c_uint32()
+                lib.bt_ctx_span_ms(o["al"]._h, C.byref(nl))
+                for i in range(max(0, nl.value - 16), nl.value):       # HIP events on the kernel's stream, per launch
+                    kernel_ms.append(float(lib.bt_ctx_launch_ms(o["al"]._h, i)))
+                flush_ms.append(float(lib.bt_ctx_launch_ms(o["al"]._h, -1)))
+                o["busy"] = False
+
+        def step(k):
+            o = pipes[k % len(pipes)]
+            if not carry:
+                retire(o)
+            d = o["sets"][(k // len(pipes)) % len(o["sets"])]
+            if paired:
+                rc = lib.bt_align_pairs_device(o["al"]._h, C.byref(rbc), C.byref(rbc2), C.byref(d["hbc"]), None)
+            else:
+                rc = lib.bt_align_batch_device(o["al"]._h, C.byref(rbc), C.byref(d["hbc"]), None)
+            if rc != 0:
+                raise RuntimeError("bt_align_batch_device: " + AL.strerror(rc))
+            o["busy"] = True
+            last["set"] = d
+
+        def barrier():
+            for o in pipes:
+                retire(o)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for k in range(warmup):
+            step(k)
+        barrier()
+        cnt = A.OpCounts()
+        for o in pipes:
+            lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 1)        # reset: count the timed steps only
+        kernel_ms.clear()
+        flush_ms.clear()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        barrier()
+        wall = time.perf_counter() - t0
+        c = {}
+        for o in pipes:
+            lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 0)
+            for kk, v in cnt.as_dict().items():
+                c[kk] = c.get(kk, 0) + v
+        return dict(wall=wall, c=c, kernel_ms=kernel_ms, flush_ms=flush_ms, last=last, pipes=pipes, carry_age=carry_age)
+
+    log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
+    M = measure(n, args.steps, args.warmup)
+    wall, c, kernel_ms, flush_ms, last, pipes, carry_age = M["wall"], M["c"], M["kernel_ms"], M["flush_ms"], M["last"], M["pipes"], M["carry_age"]
 
     verified = None
     if args.verify:
@@ -475,19 +505,41 @@ def main():
     c5 = [int(x) for x in cnt5.tolist()]
     aligned_all, reads_all, bad_all = float(c5[0] + c5[4]), float(c5[5]), float(c5[6])
 
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong:
+        # the other regime in the same line: the workload's reads in total (BASELINE config 4 as written: 200 M reads
+        # over the node), sharded -- every rank takes the first n_total / world reads of its own buffer
+        n_s = max(1, n_total // world)
+        for o in pipes:
+            o["sets"].clear()
+        last.clear()
+        torch.cuda.empty_cache()
+        Ms = measure(n_s, args.steps, args.warmup)
+        ws = torch.tensor([Ms["wall"]], dtype=torch.float64, device=dev)
+        if args.dist_backend != "nccl":
+            ws = ws.cpu()
+        dist.all_reduce(ws, op=dist.ReduceOp.MAX)
+        wall_s = float(ws[0].item())
+        strong = {"reads_total_per_step": n_s * world * mult, "reads_per_gpu_per_step": n_s * mult,
+                  "value": n_s * world * mult * args.steps / wall_s, "unit": "reads/s", "ms_per_step": wall_s * 1e3 / args.steps,
+                  "carry_over_launches": Ms["carry_age"]}
+
     if rank == 0:
         per_launch = {k: v / max(1, args.steps) for k, v in c.items()}
         # a step's launch time: its own launches (main kernel + second pass) plus its share of the closing launch
         # that finishes the reads carried out of the last step
-        kmain = sum(kernel_ms) / len(kernel_ms)
+        kmain = sum(kernel_ms) / max(1, len(kernel_ms))
         kavg = kmain + sum(flush_ms) / max(1, args.steps)
+        if kavg <= 0:                     # a library without per-launch events: the step's wall time stands in
+            kavg = kmain = wall * 1e3 / max(1, args.steps)
         kname = (lib.bt_ctx_last_kernel_name(pipes[0]["al"]._h) or b"").decode()
         tr = measured_traffic(kname, args.workload)
         abytes = algorithmic_bytes(per_launch, n * (2 if paired else 1), L, aligned * (2 if paired else 1))
         achieved = abytes / (kavg * 1e-3) / 1e9
         out = {
             "metric": "aligned reads/sec (whole node)", "value": reads_all * (2 if paired else 1) * args.steps / wall,
-            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "reads/s", "aligned_reads_per_s": aligned_all * args.steps / wall,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": args.workload, "index": index_note, "read_len": L,
@@ -500,7 +552,8 @@ def main():
                                                   "unaligned": c5[3], "maxed": c5[4]},
                        "pipelined_contexts": len(pipes),
                        "hits_verified_against_text": verified["checked"] if verified else None,
-                       "parallelism": "reads sharded x%d, index replicated" % world},
+                       "parallelism": "reads sharded x%d, index replicated" % world,
+                       "strong": strong},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tr["hbm_bytes_per_read"] * n * mult if tr and not args.genome else None),
@@ -522,10 +575,36 @@ def main():
             out["roofline"]["frac_of_gather_ceiling"] = achieved / gc["GBps"]
             out["roofline"]["gather_ceiling_source"] = gc["source"]
         if not args.no_cpu:
-            cb = cpu_baseline(base, wl, text_np, idx)
+            cb = cpu_baseline(base, wl, text_np, idx, diff_only=args.cpu_diff_only)
             out["cpu_baseline"] = cb
             out["config"]["reads_diffed_vs_reference"] = cb.get("reads_diffed_vs_reference")
             out["config"]["diff_mismatches"] = cb.get("diff_mismatches")
+        also = args.also
+        if also == "auto":
+            also = "big_v2_76,big_pe_n1_best_50" if (world == 1 and args.workload == "big_n2_100" and not args.reads and not args.genome
+                                                     and not args.no_cpu) else "none"
+        if also != "none" and world == 1:
+            # BASELINE configs 3 and 5 in the same line: each in its own process (the index cache under /tmp is reused),
+            # 2 timed steps, every hit re-verified where the workload allows it, a sample diffed against the reference
+            import subprocess
+            del rb, rb2, M, pipes, last
+            torch.cuda.empty_cache()
+            out["config"]["other_workloads"] = {}
+            for name in [x for x in also.split(",") if x]:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "2", "--warmup", "1",
+                                    "--cpu-diff-only", "--also", "none"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                try:
+                    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                    out["config"]["other_workloads"][name] = {
+                        "value": d["value"], "unit": d["unit"], "aligned_reads_per_s": d.get("aligned_reads_per_s"),
+                        "ms_per_step": d["ms_per_step"], "steps": d["steps"], "reads_per_gpu_per_step": d["config"]["reads_per_gpu_per_step"],
+                        "roofline_frac": d["roofline"]["frac"], "kernel": d["roofline"]["kernel"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
+                        "hits_verified_against_text": d["config"].get("hits_verified_against_text"),
+                        "reads_diffed_vs_reference": d["config"].get("reads_diffed_vs_reference"),
+                        "diff_mismatches": d["config"].get("diff_mismatches"),
+                        "cpu_reference_reads_per_s_incl_index_load": d.get("cpu_baseline", {}).get("value")}
+                except (IndexError, ValueError, KeyError) as e:
+                    out["config"]["other_workloads"][name] = {"error": "%s: %s" % (type(e).__name__, r.stderr.decode(errors="replace")[-300:])}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -306,11 +306,13 @@ class Aligner:
         self.last_retried = int(lib().bt_ctx_last_retried(self._h))
         return unpack_pair_hits(n, hit_cap, hits, n_hits, status, pool, self.policy)
 
-    def probe_rank(self, rows: np.ndarray, mirror: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    def probe_rank(self, rows: np.ndarray, mirror: bool = False, sides: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """LF(row, ACGT) and the BWT character at `row`: from the 32-byte rank blocks the search kernels query, or
+        (sides=True) straight from the index files' 224-symbol side layout."""
         rows = np.ascontiguousarray(rows, dtype=np.uint32)
         lf = np.zeros((len(rows), 4), dtype=np.uint32)
         L = np.zeros(len(rows), dtype=np.uint8)
-        rc = lib().bt_probe_rank(self._h, int(mirror), rows.ctypes.data, len(rows), lf.ctypes.data, L.ctypes.data)
+        rc = lib().bt_probe_rank(self._h, int(mirror) | (2 if sides else 0), rows.ctypes.data, len(rows), lf.ctypes.data, L.ctypes.data)
         if rc != A.BT_OK:
             raise BowtieAmdError(rc, "bt_probe_rank")
         return lf, L

@@ -25,7 +25,7 @@ struct bt_index {
 	BtIndexHost host[2];           /* big arrays are released after upload; names/plen stay */
 	BtIndexDev  dev[2];
 	std::vector<void*> allocs;
-	uint64_t ebwt_bytes = 0, offs_bytes = 0;
+	uint64_t blk_bytes = 0; uint64_t ebwt_bytes = 0, offs_bytes = 0;
 	std::string base;
 	BtRefDev* d_ref = nullptr;     /* the 2-bit reference, loaded on demand (bt_index_load_reference) */
 	uint64_t ref_bytes = 0;
@@ -141,6 +141,17 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 		    (r2 = upload(ix, h.eftab, &d.eftab)) || (r2 = upload(ix, h.offs, &d.offs, 4)) ||
 		    (r2 = upload(ix, h.rstarts, &d.rstarts)) || (r2 = upload(ix, h.plen, &d.plen))) {
 			bt_index_free(ix); return r2;
+		}
+		{
+			/* the rank blocks the search kernels query (bt_rank.h), derived on the device from the side layout just
+			 * uploaded: 32 bytes per 64 BWT rows */
+			const uint64_t nb = bt_blk_count(h.len);
+			uint8_t* blk = nullptr;
+			if (hipMalloc((void**)&blk, nb * BT_BLK_BYTES) != hipSuccess) { bt_index_free(ix); return BT_ERR_DEVICE; }
+			ix->allocs.push_back(blk);
+			if (bt_launch_blk_build(&d, blk, (uint32_t)nb, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) { bt_index_free(ix); return BT_ERR_DEVICE; }
+			d.blk = blk;
+			ix->blk_bytes += nb * BT_BLK_BYTES;
 		}
 		ix->ebwt_bytes += h.ebwt.size(); ix->offs_bytes += h.offs.size() * 4ull;
 		std::vector<uint8_t>().swap(h.ebwt);
@@ -391,10 +402,11 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_best_kernel");
 	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
 	if (!c->is_big && env_u32("BT_BEST_DEVICE_RETRY", 1)) {
-		/* reads that outgrew their arena: collected and searched again on the stream, 256 lanes with 16 MB
-		 * arenas each (4 GiB; such reads are rare) -- the caller of the device-pointer entry points sees finished
-		 * results only */
-		const uint32_t bigWords = 1u << 22, bigLanes = 256u;
+		/* reads that outgrew their arena: collected and searched again on the stream, 1024 lanes with 16 MB
+		 * arenas each -- the caller of the device-pointer entry points sees finished results only.  (256 lanes were
+		 * tried to save memory: on the hg19-scale index enough reads come here that the pass then takes several
+		 * times as long as the main launch, profiles/r3/.) */
+		const uint32_t bigWords = 1u << 22, bigLanes = env_u32("BT_BEST_RETRY_LANES", 1024u);
 		if (!c->bigArenas) HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u));
 		const int rrc = ctx_ensure_retry_list(c, in->n_reads);
 		if (rrc != BT_OK) return rrc;
@@ -429,7 +441,7 @@ static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
 	memset(warm, 0, sizeof(*warm));
 	for (int m = 0; m < 2; m++) {
 		const BtIndexDev& d = c->idx->dev[m];
-		A->H.ebwt[m] = d.ebwt; A->H.zSide[m] = d.zSide; A->H.zSym[m] = d.zSym;
+		A->H.blk[m] = d.blk; A->H.zBlk[m] = d.zBlk; A->H.zPos[m] = d.zPos;
 		warm->zOff[m] = d.zOff; warm->offMask[m] = d.offMask; warm->ftab[m] = d.ftab; warm->offs[m] = d.offs;
 		warm->offRate[m] = d.offRate; warm->ftabChars[m] = d.ftabChars; warm->len[m] = d.len;
 		for (int k = 0; k < 5; k++) A->H.fchr[m][k] = d.fchr[k];
@@ -1243,13 +1255,15 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 /* ---- probes ---------------------------------------------------------------------------------- */
 extern "C" int bt_probe_rank(bt_ctx* c, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L)
 {
+	const uint32_t sides = (uint32_t)mirror & 2u;          /* bit 1: rank from the side layout (see the header) */
+	mirror &= 1;
 	if (!c || !rows || !lf || !L || (mirror && !c->idx->has_mirror)) return BT_ERR_ARG;
 	if (n == 0) return BT_OK;
 	HIPCHK(hipSetDevice(c->idx->device));
 	uint32_t *d_rows = nullptr, *d_lf = nullptr; uint8_t* d_L = nullptr;
 	HIPCHK(hipMalloc((void**)&d_rows, 4ull * n)); HIPCHK(hipMalloc((void**)&d_lf, 16ull * n)); HIPCHK(hipMalloc((void**)&d_L, n));
 	HIPCHK(hipMemcpy(d_rows, rows, 4ull * n, hipMemcpyHostToDevice));
-	int rc = bt_launch_probe_rank(&c->idx->dev[mirror ? 1 : 0], d_rows, n, d_lf, d_L, c->stream);
+	int rc = bt_launch_probe_rank(&c->idx->dev[mirror ? 1 : 0], d_rows, n, d_lf, d_L, sides, c->stream);
 	if (rc == 0) rc = (int)hipStreamSynchronize(c->stream);
 	if (rc == 0) { (void)hipMemcpy(lf, d_lf, 16ull * n, hipMemcpyDeviceToHost); (void)hipMemcpy(L, d_L, n, hipMemcpyDeviceToHost); }
 	(void)hipFree(d_rows); (void)hipFree(d_lf); (void)hipFree(d_L);
@@ -1281,19 +1295,21 @@ extern "C" int bt_probe_chase(bt_ctx* c, int mirror, const uint32_t* rows, uint3
 extern "C" int bt_bench_gather(bt_ctx* c, int mirror, uint32_t n_blocks, uint32_t iters, int dependent,
                                float* ms_out, double* gbs_out)
 {
+	const bool sides = (mirror & 2) != 0;                  /* bit 1: gather 128-byte side pairs instead of 32-byte rank blocks */
+	mirror &= 1;
 	if (!c || !ms_out || !gbs_out || n_blocks == 0 || iters == 0 || (mirror && !c->idx->has_mirror)) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
 	uint32_t* sink = c->d_cursor + 7;
 	for (int rep = 0; rep < 2; rep++) {            /* first pass warms the TLBs */
 		HIPCHK(hipEventRecord(c->ev0, c->stream));
-		if (bt_launch_gather_bench(&c->idx->dev[mirror ? 1 : 0], n_blocks, iters, dependent ? 1u : 0u, sink, c->stream) != 0) return BT_ERR_DEVICE;
+		if (bt_launch_gather_bench(&c->idx->dev[mirror ? 1 : 0], n_blocks, iters, (dependent ? 1u : 0u) | (sides ? 2u : 0u), sink, c->stream) != 0) return BT_ERR_DEVICE;
 		HIPCHK(hipEventRecord(c->ev1, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
 	}
 	float ms = 0.f;
 	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	*ms_out = ms;
-	*gbs_out = (double)n_blocks * 256.0 * iters * 128.0 / (ms * 1e-3) / 1e9;
+	*gbs_out = (double)n_blocks * 256.0 * iters * (sides ? 128.0 : 32.0) / (ms * 1e-3) / 1e9;
 	return BT_OK;
 }
 

@@ -15,13 +15,16 @@
 #include "bt_best.h"
 #include "bt_kernels.h"
 
-/* -DBT_BEST_MIN_BLOCKS=2: ask the register allocator for two blocks per CU (the default build takes all 512 registers
- * of a SIMD lane for one wave); which is faster is a measurement (scripts/r3_gpu_first.sh) */
-#ifdef BT_BEST_MIN_BLOCKS
-#define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
-#else
-#define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK)
+/* Blocks per CU = waves per SIMD the register allocator is asked to fit.  Every lane runs its own control flow with its
+ * loads where the data is needed, so what the kernel lives on is waves to switch to while one waits: measured on the
+ * e_coli best-first workloads (profiles/r3/best_occupancy.txt), 1 wave per SIMD (all 512 registers, no spill) 2.87 /
+ * 6.78 M reads/s single-end / paired, 3 waves 5.15 / 12.26, 4 waves 5.94 / 13.22, 6 waves (80 registers, the rest
+ * spilled to scratch, which is coalesced and cached) 6.20 / 13.90, 8 waves 5.62 / 14.16.  -DBT_BEST_MIN_BLOCKS=<n>
+ * builds another (make bestsweep). */
+#ifndef BT_BEST_MIN_BLOCKS
+#define BT_BEST_MIN_BLOCKS 6
 #endif
+#define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
 __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 {
 	__shared__ BfProgram PROG;
@@ -83,11 +86,7 @@ extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint
 /* blocks per CU the kernel's register budget allows (= waves per SIMD: 256-lane blocks, 4 SIMDs) */
 extern "C" uint32_t bt_best_blocks_per_cu(void)
 {
-#ifdef BT_BEST_MIN_BLOCKS
 	return BT_BEST_MIN_BLOCKS;
-#else
-	return 2u;
-#endif
 }
 
 extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)

@@ -139,8 +139,8 @@ struct BtBatchDev {
  * the per-position / per-SA-step code touches; BtCold lives in device memory and is read where
  * it is used (phase changes, reporting). */
 struct BtHot {
-	const uint8_t* ebwt[2];
-	uint32_t zSide[2], zSym[2];
+	const uint8_t* blk[2];            /* the rank blocks (bt_rank.h) of the text index and of the mirror index */
+	uint32_t zBlk[2], zPos[2];
 	uint32_t fchr[2][5];
 	const uint8_t* seq; const uint8_t* qual;
 	uint32_t stride, n_reads;

@@ -244,6 +244,7 @@ void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d)
 	d->zSide = h.zOff / 224u;
 	const uint32_t co = h.zOff % 224u;
 	d->zSym = (d->zSide & 1u) ? co : (223u - co);
+	d->zBlk = h.zOff / BT_BLK_ROWS; d->zPos = h.zOff % BT_BLK_ROWS;
 }
 
 void bt_host_restore_text(const BtIndexHost& h, uint8_t* out)
@@ -256,7 +257,7 @@ void bt_host_restore_text(const BtIndexHost& h, uint8_t* out)
 	uint32_t i = h.len, jumps = 0;            /* the row of the suffix "$" (sorts last) */
 	while (i != h.zOff && jumps < h.len) {
 		uint32_t lf[4], L;
-		bt_rank4(d, i, lf, &L);
+		bt_rank4_sides(d, i, lf, &L);
 		out[h.len - 1u - jumps] = (uint8_t)L;
 		i = lf[L];
 		jumps++;

@@ -77,7 +77,8 @@ int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, v
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */
 int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, uint32_t iters, uint32_t dep, uint32_t* sink, void* stream);
 int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
-                         uint8_t* L, void* stream);
+                         uint8_t* L, uint32_t sides, void* stream);
+int bt_launch_blk_build(const BtIndexDev* ix, uint8_t* out, uint32_t nBlocks, void* stream);
 int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
                           uint32_t* joined, uint32_t* tidx, uint32_t* toff, void* stream);
 }

@@ -18,39 +18,35 @@
 #include "bt_core.h"
 #include "bt_kernels.h"
 
-struct BtRankSel { const uint8_t* ebwt; uint32_t zSide, zSym, f0, f1, f2, f3; };
-
-/* rank from the row's side already in registers (q0..q3 = its 64 bytes) + the partner side's
- * 8 counter bytes */
-__device__ __forceinline__ void dev_rank4_loaded(const BtRankSel& s, uint32_t row, const BtU4& q0, const BtU4& q1,
-                                                 const BtU4& q2, const BtU4& q3, const uint2& oth, uint32_t lf[4], uint32_t* L)
+/* ---- deriving the rank blocks from the index files' side layout (bt_rank.h), once per index at load -------------
+ * one wavefront per block of 64 BWT rows: every lane reads its row's symbol, two ballots make the bit planes, lane 0
+ * ranks the block's first row the old way for the four absolute counters */
+__device__ __forceinline__ uint32_t dev_rowL_sides(const BtIndexDev& ix, uint32_t row)
 {
-	const uint32_t sideNum = row / BT_SIDE_SYMS;
-	const uint32_t charOff = row - sideNum * BT_SIDE_SYMS;
-	const bool fw = (sideNum & 1u) != 0;
-	uint64_t w[7];
-	w[0] = ((uint64_t)q0.y << 32) | q0.x; w[1] = ((uint64_t)q0.w << 32) | q0.z;
-	w[2] = ((uint64_t)q1.y << 32) | q1.x; w[3] = ((uint64_t)q1.w << 32) | q1.z;
-	w[4] = ((uint64_t)q2.y << 32) | q2.x; w[5] = ((uint64_t)q2.w << 32) | q2.z;
-	w[6] = ((uint64_t)q3.y << 32) | q3.x;
-	uint32_t occ[4];
-	occ[0] = fw ? oth.x : q3.z; occ[1] = fw ? oth.y : q3.w;
-	occ[2] = fw ? q3.z : oth.x; occ[3] = fw ? q3.w : oth.y;
-	BtIndexDev ix;
-	ix.zSide = s.zSide; ix.zSym = s.zSym;
-	ix.fchr[0] = s.f0; ix.fchr[1] = s.f1; ix.fchr[2] = s.f2; ix.fchr[3] = s.f3;
-	bt_rank4_words(ix, sideNum, charOff, w, occ, lf, L);
+	const uint32_t sideNum = row / BT_SIDE_SYMS, charOff = row - sideNum * BT_SIDE_SYMS;
+	const uint32_t li = (sideNum & 1u) ? charOff : (BT_SIDE_SYMS - 1u - charOff);
+	return ((uint32_t)BT_GP(const uint8_t, ix.ebwt)[(uint64_t)sideNum * 64u + (li >> 2)] >> (2u * (li & 3u))) & 3u;
 }
-
-/* rank at `row` (probe kernels): 4 x 16-byte loads of the row's side + one 8-byte load of the partner counters */
-__device__ __forceinline__ void dev_rank4(const BtRankSel& s, uint32_t row, uint32_t lf[4], uint32_t* L)
+__global__ __launch_bounds__(256) void bt_blk_build_kernel(BtIndexDev ix, uint8_t* out, uint32_t nBlocks)
 {
-	const uint32_t sideNum = row / BT_SIDE_SYMS;
-	const uint8_t* side = s.ebwt + (uint64_t)sideNum * 64u;
-	const BtU4 q0 = bt_ld4(side), q1 = bt_ld4(side + 16), q2 = bt_ld4(side + 32), q3 = bt_ld4(side + 48);
-	const bt_vec2 ot = *BT_GP(const bt_vec2, (sideNum & 1u) ? side - 8 : side + 120);
-	const uint2 oth = make_uint2(ot.x, ot.y);
-	dev_rank4_loaded(s, row, q0, q1, q2, q3, oth, lf, L);
+	const uint32_t b = blockIdx.x * 4u + threadIdx.x / 64u, lane = threadIdx.x & 63u;
+	if (b >= nBlocks) return;
+	const uint64_t row = (uint64_t)b * BT_BLK_ROWS + lane;
+	const uint32_t L = row <= ix.len ? dev_rowL_sides(ix, (uint32_t)row) : 0u;
+	const unsigned long long p0 = __ballot(L & 1u), p1 = __ballot(L & 2u);
+	if (lane == 0) {
+		uint32_t lf[4] = {0, 0, 0, 0}, dummy;
+		if (row <= (uint64_t)ix.len + 1u) bt_rank4_sides(ix, (uint32_t)row, lf, &dummy);
+		BtU4 o, p;
+		o.x = lf[0]; o.y = lf[1]; o.z = lf[2]; o.w = lf[3];
+		p.x = (uint32_t)p0; p.y = (uint32_t)(p0 >> 32); p.z = (uint32_t)p1; p.w = (uint32_t)(p1 >> 32);
+		bt_st4(out + (uint64_t)b * BT_BLK_BYTES, o); bt_st4(out + (uint64_t)b * BT_BLK_BYTES + 16, p);
+	}
+}
+extern "C" int bt_launch_blk_build(const BtIndexDev* ix, uint8_t* out, uint32_t nBlocks, void* stream)
+{
+	hipLaunchKernelGGL(bt_blk_build_kernel, dim3((nBlocks + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *ix, out, nBlocks);
+	return (int)hipGetLastError();
 }
 
 /* EXT = true compiles in carry-over (parking at the end of a launch, adoption at the start of the next) and the
@@ -145,48 +141,39 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		{
 			const bool isRank = req.kind == RQ_RANK;
 			const bool isFetch = req.kind == RQ_FETCH;
-			BtRankSel sel;
 			const bool m = L.mirror != 0;
-			sel.ebwt = m ? A.H.ebwt[1] : A.H.ebwt[0];
-			sel.zSide = m ? A.H.zSide[1] : A.H.zSide[0];
-			sel.zSym = m ? A.H.zSym[1] : A.H.zSym[0];
-			sel.f0 = m ? A.H.fchr[1][0] : A.H.fchr[0][0];
-			sel.f1 = m ? A.H.fchr[1][1] : A.H.fchr[0][1];
-			sel.f2 = m ? A.H.fchr[1][2] : A.H.fchr[0][2];
-			sel.f3 = m ? A.H.fchr[1][3] : A.H.fchr[0][3];
+			const uint8_t* blk = m ? A.H.blk[1] : A.H.blk[0];
+			const uint32_t zBlk = m ? A.H.zBlk[1] : A.H.zBlk[0], zPos = m ? A.H.zPos[1] : A.H.zPos[0];
 			const uint32_t rowA = (uint32_t)req.a, rowB = (uint32_t)req.x;
-			const uint32_t sideA = rowA / BT_SIDE_SYMS, sideB = rowB / BT_SIDE_SYMS;
-			const uint8_t* pA = isRank ? sel.ebwt + (uint64_t)sideA * 64u : (const uint8_t*)(uintptr_t)req.a;
-			const uint8_t* pB = sel.ebwt + (uint64_t)sideB * 64u;
-			const uint32_t nA = isRank ? 4u : (isFetch ? req.n : 0u);
+			const uint32_t bA = rowA / BT_BLK_ROWS, bB = rowB / BT_BLK_ROWS;
 			const bool hasB = isRank && req.n == 2;
+			/* pieces 0,1: rank row A's block, or the first two pieces of a fetch; pieces 2,3: row B's block, or the
+			 * fetch's third and fourth piece */
+			const uint8_t* pA = isRank ? blk + (uint64_t)bA * BT_BLK_BYTES : (const uint8_t*)(uintptr_t)req.a;
+			const uint8_t* pB = hasB ? blk + (uint64_t)bB * BT_BLK_BYTES : pA + 32;
+			const uint32_t nA = isRank ? 4u - (hasB ? 0u : 2u) : (isFetch ? req.n : 0u);
 			const bool hasW = !RL && isRank && req.wchunk != 0xffffu;   /* next read window rides along (register-window build) */
 			const bool hasX = (isFetch && req.x != 0) || hasW;
 			const uint8_t* pX = hasW ? A.H.qual + L.roff + (uint64_t)req.wchunk * 16u : (const uint8_t*)(uintptr_t)req.x;
 			const uint8_t* pW = A.H.seq + L.roff + (uint64_t)req.wchunk * 16u;
-			BtU4 qa[4] = {}, qb[4] = {}, qx = {}, qw = {};
-			uint2 oa = make_uint2(0, 0), ob = make_uint2(0, 0);
+			BtU4 qa[4] = {}, qx = {}, qw = {};
 			/* every address a lane can ask for is global memory (index, scratch arenas, ftab, SA sample,
 			 * reads): plain global loads, not FLAT ones (see BT_GP) */
-			BT_UNROLL
-			for (uint32_t k = 0; k < 4u; k++) if (k < nA) qa[k] = bt_ld4(pA + 16u * k);
-			if (isRank) { const bt_vec2 t = *BT_GP(const bt_vec2, (sideA & 1u) ? pA - 8 : pA + 120); oa = make_uint2(t.x, t.y); }
-			if (hasB) {
-				BT_UNROLL
-				for (uint32_t k = 0; k < 4u; k++) qb[k] = bt_ld4(pB + 16u * k);
-				const bt_vec2 t = *BT_GP(const bt_vec2, (sideB & 1u) ? pB - 8 : pB + 120); ob = make_uint2(t.x, t.y);
-			}
+			if (nA > 0u) qa[0] = bt_ld4(pA);
+			if (nA > 1u) qa[1] = bt_ld4(pA + 16);
+			if (nA > 2u) qa[2] = bt_ld4(pB);
+			if (nA > 3u) qa[3] = bt_ld4(pB + 16);
 			if (hasX) qx = bt_ld4(pX);
 			if (hasW) qw = bt_ld4(pW);
 			if (isRank) {
 				uint32_t lf[4], la;
-				dev_rank4_loaded(sel, rowA, qa[0], qa[1], qa[2], qa[3], oa, lf, &la);
+				bt_rank4_blk(qa[0], qa[1], rowA % BT_BLK_ROWS, bA == zBlk, zPos, lf, &la);
 				res.q[0].x = lf[0]; res.q[0].y = lf[1]; res.q[0].z = lf[2]; res.q[0].w = lf[3];
 				res.q[2].x = la;
 				res.q[3] = qw; res.x = qx;
 				if (hasB) {
 					uint32_t dummy;
-					dev_rank4_loaded(sel, rowB, qb[0], qb[1], qb[2], qb[3], ob, lf, &dummy);
+					bt_rank4_blk(qa[2], qa[3], rowB % BT_BLK_ROWS, bB == zBlk, zPos, lf, &dummy);
 					res.q[1].x = lf[0]; res.q[1].y = lf[1]; res.q[1].z = lf[2]; res.q[1].w = lf[3];
 				}
 			} else {
@@ -265,15 +252,13 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 }
 
 
-__global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout)
+/* sides != 0: rank from the index files' side layout instead of the rank blocks the search uses */
+__global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout, uint32_t sides)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	BtRankSel sel;
-	sel.ebwt = ix.ebwt; sel.zSide = ix.zSide; sel.zSym = ix.zSym;
-	sel.f0 = ix.fchr[0]; sel.f1 = ix.fchr[1]; sel.f2 = ix.fchr[2]; sel.f3 = ix.fchr[3];
 	uint32_t r[4], L;
-	dev_rank4(sel, rows[i], r, &L);
+	if (sides) bt_rank4_sides(ix, rows[i], r, &L); else bt_rank4(ix, rows[i], r, &L);
 	lf[i * 4 + 0] = r[0]; lf[i * 4 + 1] = r[1]; lf[i * 4 + 2] = r[2]; lf[i * 4 + 3] = r[3];
 	Lout[i] = (uint8_t)L;
 }
@@ -283,13 +268,10 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	BtRankSel sel;
-	sel.ebwt = ix.ebwt; sel.zSide = ix.zSide; sel.zSym = ix.zSym;
-	sel.f0 = ix.fchr[0]; sel.f1 = ix.fchr[1]; sel.f2 = ix.fchr[2]; sel.f3 = ix.fchr[3];
 	uint32_t row = rows[i], jumps = 0;
 	while ((row & ix.offMask) != row && row != ix.zOff) {
 		uint32_t r[4], L;
-		dev_rank4(sel, row, r, &L);
+		bt_rank4(ix, row, r, &L);
 		row = r[L];
 		jumps++;
 	}
@@ -300,24 +282,22 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
 	tidx[i] = t; toff[i] = o;
 }
 
-/* Random 128-byte-gather ceiling: every thread does `iters` independent rank queries at
- * pseudo-random rows of the index -- the memory access pattern of the search kernels with all the
- * search logic taken away.  Each query touches one aligned 128-byte side pair (4 x 16-byte loads of the
- * row's side + 8 counter bytes of the partner side).  `dep` != 0 makes each query's row depend on the
- * previous result (an SA walk's dependency chain) instead of being known up front. */
+/* Random-gather ceiling: every thread does `iters` independent rank queries at pseudo-random rows of
+ * the index -- the memory access pattern of the search kernels with all the search logic taken away.  Each query
+ * touches one 32-byte rank block (dep bit 1 clear; what the search kernels gather), or one aligned 128-byte side pair
+ * of the index files' layout (dep bit 1 set: 4 x 16-byte loads of the row's side + 8 counter bytes of the partner
+ * side).  dep bit 0 makes each query's row depend on the previous result (an SA walk's dependency chain) instead of
+ * being known up front. */
 __global__ __launch_bounds__(256) void bt_gather_bench_kernel(BtIndexDev ix, uint32_t iters, uint32_t dep, uint32_t* sink)
 {
-	BtRankSel sel;
-	sel.ebwt = ix.ebwt; sel.zSide = ix.zSide; sel.zSym = ix.zSym;
-	sel.f0 = ix.fchr[0]; sel.f1 = ix.fchr[1]; sel.f2 = ix.fchr[2]; sel.f3 = ix.fchr[3];
 	uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u, acc = 0;
 	for (uint32_t k = 0; k < iters; k++) {
 		x ^= x << 13; x ^= x >> 17; x ^= x << 5;
 		const uint32_t row = (uint32_t)(((uint64_t)x * ix.len) >> 32);
 		uint32_t r[4], L;
-		dev_rank4(sel, row, r, &L);
+		if (dep & 2u) bt_rank4_sides(ix, row, r, &L); else bt_rank4(ix, row, r, &L);
 		acc += r[L];
-		if (dep) x += r[L];
+		if (dep & 1u) x += r[L];
 	}
 	if (acc == 0x12345678u) sink[0] = acc;
 }
@@ -369,10 +349,10 @@ extern "C" int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, 
 	return (int)hipGetLastError();
 }
 extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
-                                    uint8_t* L, void* stream)
+                                    uint8_t* L, uint32_t sides, void* stream)
 {
 	hipLaunchKernelGGL(bt_probe_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-	                   *ix, rows, n, lf, L);
+	                   *ix, rows, n, lf, L, sides);
 	return (int)hipGetLastError();
 }
 extern "C" int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,

@@ -15,6 +15,19 @@
  *   the pair's midpoint.  The '$' symbol is stored as an A; it is un-counted when it lies
  *   within the counted span (storage symbol zSym of side zSide, span test: n > zSym).
  *
+ * That is the layout of the index FILES (bt_rank4_sides).  What the search kernels query is a second image the
+ * loader derives from it once, laid out for this GPU rather than for a CPU's cache lines -- HBM is plentiful here
+ * (288 GB; the image costs 0.5 byte per BWT row) and instruction issue is what the search is short of:
+ *
+ *   rank block b (32 bytes, one aligned sector) covers BWT rows 64b .. 64b+63:
+ *       u32 occ[4]   LF(64b, c) for c = A,C,G,T  (absolute: fchr[c] + occurrences before the block, '$' excluded)
+ *       u64 plane0   bit i = low  bit of the symbol at row 64b+i
+ *       u64 plane1   bit i = high bit of the symbol at row 64b+i
+ *   LF(row,c) = occ[c] + (number of c among the first row%64 symbols of the block): three 64-bit popcounts of
+ *   masked planes (T = p0&p1, C = p0-T, G = p1-T, A by subtraction) -- about 35 instructions per row where the
+ *   224-symbol side costs about 240, one 32-byte load instead of 64 + 8 bytes out of a 128-byte pair, no division
+ *   by 224, no forward/backward sides.  Same numbers: the probe tests compare both with the reference's (App. D).
+ *
  * Compiles for gfx950 (hipcc) and for the host (g++; used by the state-machine unit tests).
  */
 #ifndef BT_RANK_H_
@@ -53,6 +66,8 @@ struct BtIndexDev {
 	const uint32_t* plen;
 	uint32_t len, zOff, zSide, zSym, ftabChars, offRate, offMask, nFrag, fw, nPat;
 	uint32_t fchr[5];
+	const uint8_t*  blk;       /* the rank blocks: (len + 1) / 64 + 2 of them, 32 bytes each (see above)          */
+	uint32_t zBlk, zPos;       /* zOff / 64, zOff % 64                                                             */
 	uint32_t wide;             /* the index is a 64-bit (.ebwtl) build.  Its rows still fit 32 bits here, but the
 	                              reference binary that serves it is compiled with 64-bit offsets, and two things
 	                              a user can see follow the offset width: the row a hit is reported from is drawn
@@ -145,8 +160,9 @@ BT_UNROLL
 	}
 }
 
-/* Plain-load form: one lane fetches its own side (64 B) + the partner side's counters (8 B). */
-BT_HD void bt_rank4(const BtIndexDev& ix, uint32_t row, uint32_t lf[4], uint32_t* L)
+/* Rank straight from the index files' side layout: one lane fetches its own side (64 B) + the partner side's counters
+ * (8 B).  Used to derive the rank blocks and by the probes; the search kernels use bt_rank4 below. */
+BT_HD void bt_rank4_sides(const BtIndexDev& ix, uint32_t row, uint32_t lf[4], uint32_t* L)
 {
 	const uint32_t sideNum = row / BT_SIDE_SYMS;
 	const uint32_t charOff = row - sideNum * BT_SIDE_SYMS;
@@ -162,6 +178,60 @@ BT_UNROLL
 	if (sideNum & 1u) { occ[0] = (uint32_t)oth; occ[1] = (uint32_t)(oth >> 32); occ[2] = (uint32_t)own; occ[3] = (uint32_t)(own >> 32); }
 	else              { occ[0] = (uint32_t)own; occ[1] = (uint32_t)(own >> 32); occ[2] = (uint32_t)oth; occ[3] = (uint32_t)(oth >> 32); }
 	bt_rank4_words(ix, sideNum, charOff, w, occ, lf, L);
+}
+
+/* ---- rank blocks ------------------------------------------------------------------------------------------------ */
+#define BT_BLK_BYTES 32u
+#define BT_BLK_ROWS 64u
+BT_HD uint64_t bt_blk_count(uint32_t len) { return (uint64_t)(len + 1u) / BT_BLK_ROWS + 2u; }
+/* LF(row, ACGT) and rowL from a rank block's eight words: o = occ[4], p = plane0 lo/hi, plane1 lo/hi; n = row % 64;
+ * zHere: the block is the one holding the '$' row (which is stored as an A and must not count as one) */
+BT_HD void bt_rank4_blk(const BtU4& o, const BtU4& p, uint32_t n, bool zHere, uint32_t zPos, uint32_t lf[4], uint32_t* L)
+{
+	const uint64_t p0 = ((uint64_t)p.y << 32) | p.x, p1 = ((uint64_t)p.w << 32) | p.z;
+	const uint64_t m = (1ull << n) - 1ull;                /* n = 0..63 */
+	const uint64_t a = p0 & m, b = p1 & m;
+	const uint32_t cLo = (uint32_t)__builtin_popcountll(a), cHi = (uint32_t)__builtin_popcountll(b), cT = (uint32_t)__builtin_popcountll(a & b);
+	uint32_t cA = n - cLo - cHi + cT;
+	if (zHere && n > zPos) cA--;
+	lf[0] = o.x + cA; lf[1] = o.y + (cLo - cT); lf[2] = o.z + (cHi - cT); lf[3] = o.w + cT;
+	*L = ((uint32_t)(p0 >> n) & 1u) | (((uint32_t)(p1 >> n) & 1u) << 1);
+}
+/* the rank the search uses: one 32-byte block per BWT row queried */
+BT_HD void bt_rank4(const BtIndexDev& ix, uint32_t row, uint32_t lf[4], uint32_t* L)
+{
+	const uint32_t b = row / BT_BLK_ROWS;
+	const uint8_t* q = ix.blk + (uint64_t)b * BT_BLK_BYTES;
+	const BtU4 o = bt_ld4(q), p = bt_ld4(q + 16);
+	bt_rank4_blk(o, p, row % BT_BLK_ROWS, b == ix.zBlk, ix.zPos, lf, L);
+}
+/* Derive the rank blocks of one index from its side layout (host; the GPU loader does the same in a kernel,
+ * bt_kernels.hip: bt_blk_build_kernel): running counts over the BWT, '$' skipped. */
+BT_HD void bt_blk_build_host(const BtIndexDev& ix, uint8_t* out)
+{
+	uint32_t cnt[4] = {0, 0, 0, 0};
+	const uint64_t nb = bt_blk_count(ix.len);
+	for (uint64_t b = 0; b < nb; b++) {
+		uint32_t w[8];
+		for (int c = 0; c < 4; c++) w[c] = ix.fchr[c] + cnt[c];
+		uint64_t p0 = 0, p1 = 0;
+		for (uint32_t i = 0; i < BT_BLK_ROWS; i++) {
+			const uint64_t row = b * BT_BLK_ROWS + i;
+			if (row > ix.len) break;
+			uint32_t lf[4], L;
+			{
+				/* rowL (ebwt.h:1696-1704): storage symbol charOff of a forward side, 223 - charOff of a backward one */
+				const uint32_t sideNum = (uint32_t)row / BT_SIDE_SYMS, charOff = (uint32_t)row - sideNum * BT_SIDE_SYMS;
+				const uint32_t li = (sideNum & 1u) ? charOff : (BT_SIDE_SYMS - 1u - charOff);
+				L = (ix.ebwt[(uint64_t)sideNum * 64u + (li >> 2)] >> (2u * (li & 3u))) & 3u;
+				(void)lf;
+			}
+			p0 |= (uint64_t)(L & 1u) << i; p1 |= (uint64_t)(L >> 1) << i;
+			if (row != ix.zOff) cnt[L]++;
+		}
+		w[4] = (uint32_t)p0; w[5] = (uint32_t)(p0 >> 32); w[6] = (uint32_t)p1; w[7] = (uint32_t)(p1 >> 32);
+		memcpy(out + b * BT_BLK_BYTES, w, BT_BLK_BYTES);
+	}
 }
 
 /* ftabHi / ftabLo (ebwt.h:985-1034) */

@@ -8,8 +8,10 @@
  * (tests/test_gpu_*.py) through the C ABI.
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "../../bowtie_amd/csrc/bt_host.h"
 /* EMU_MSAN (tests/emu/emu_msan.cpp, clang -fsanitize=memory): everything the kernel leaves undefined -- LDS, the
  * scratch arenas, the parts of a round's result nothing wrote -- is poisoned, so a read of it is reported */
@@ -20,13 +22,17 @@
 #define EMU_POISON(p, n) ((void)0)
 #endif
 
-struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
+struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; std::vector<uint8_t> blk[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
 
 static void bind(EmuIndex* e, int m)
 {
 	bt_host_index_describe(e->h[m], &e->d[m]);
 	e->d[m].ebwt = e->h[m].ebwt.data(); e->d[m].ftab = e->h[m].ftab.data(); e->d[m].eftab = e->h[m].eftab.data();
 	e->d[m].offs = e->h[m].offs.data(); e->d[m].rstarts = e->h[m].rstarts.data(); e->d[m].plen = e->h[m].plen.data();
+	/* the rank blocks the search queries (bt_rank.h), derived from the sides as the GPU loader derives them */
+	e->blk[m].assign((size_t)bt_blk_count(e->d[m].len) * BT_BLK_BYTES, 0);
+	bt_blk_build_host(e->d[m], e->blk[m].data());
+	e->d[m].blk = e->blk[m].data();
 }
 
 extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
@@ -50,6 +56,12 @@ extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint3
 {
 	EmuIndex* e = (EmuIndex*)p;
 	bt_rank4(e->d[mirror ? 1 : 0], row, lf, L);
+}
+/* the same from the index files' side layout */
+extern "C" void emu_rank4_sides(void* p, int mirror, uint32_t row, uint32_t* lf, uint32_t* L)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	bt_rank4_sides(e->d[mirror ? 1 : 0], row, lf, L);
 }
 
 /* Same contract as bt_align_batch (host pointers); nLanes lock-step lanes. */
@@ -75,7 +87,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	BtWarm W;
 	memset(&W, 0, sizeof(W));
 	for (int m = 0; m < 2; m++) {
-		H.ebwt[m] = e->d[m].ebwt; H.zSide[m] = e->d[m].zSide; H.zSym[m] = e->d[m].zSym; W.zOff[m] = e->d[m].zOff;
+		H.blk[m] = e->d[m].blk; H.zBlk[m] = e->d[m].zBlk; H.zPos[m] = e->d[m].zPos; W.zOff[m] = e->d[m].zOff;
 		W.offMask[m] = e->d[m].offMask; W.ftab[m] = e->d[m].ftab; W.offs[m] = e->d[m].offs; W.offRate[m] = e->d[m].offRate;
 		W.ftabChars[m] = e->d[m].ftabChars; W.len[m] = e->d[m].len;
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];

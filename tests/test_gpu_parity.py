@@ -24,6 +24,25 @@ def aligner(gidx, name, kw):
     return AL.Aligner(gidx[name], A.make_policy(**kw))
 
 
+@pytest.mark.parametrize("index", ["e_coli", "multi"])
+def test_probe_rank_blocks_equal_the_side_layout(index, gidx):
+    """The 32-byte rank blocks the loader derives on the GPU (bt_blk_build_kernel) against the index files' side layout
+    they are derived from: every row around the '$' row, around block and side boundaries and at both ends, and
+    20 000 random rows, text index and mirror index."""
+    al = aligner(gidx, index, T.MODES["v0"])
+    info = gidx[index].info
+    n, z = int(info.len), int(info.z_off)
+    rng = np.random.default_rng(5)
+    special = [0, 1, 2, 63, 64, 65, 223, 224, 225, 447, 448, 449, n - 1, n, n + 1] + list(range(max(0, z - 70), min(n + 1, z + 70)))
+    rows = np.array(sorted(set(r for r in special if 0 <= r <= n + 1)) + list(rng.integers(0, n + 2, size=20000)), dtype=np.uint32)
+    for mirror in (False, True):
+        lf_b, L_b = al.probe_rank(rows, mirror=mirror)
+        lf_s, L_s = al.probe_rank(rows, mirror=mirror, sides=True)
+        assert (lf_b == lf_s).all(), (index, mirror, rows[(lf_b != lf_s).any(axis=1)][:5])
+        ok = rows <= n                                 # the BWT has rows 0..len
+        assert (L_b[ok] == L_s[ok]).all(), (index, mirror)
+
+
 def test_probe_rank_known_answers(gidx):
     with open(os.path.join(T.G, "rank_vectors.json")) as f:
         v = json.load(f)
