@@ -736,7 +736,8 @@ extern "C" int bt_index_load_reference(bt_index* ix)
 	BtRefDev d;
 	memset(&d, 0, sizeof(d));
 	int r2;
-	if ((r2 = upload(ix, R.bits, &d.bits)) || (r2 = upload(ix, R.nmask, &d.nmask)) || (r2 = upload(ix, R.start, &d.start)) ||
+	/* + 8 words each: the mate finder reads the 2-bit reference and its N mask in 64-bit pieces, three / two at a time */
+	if ((r2 = upload(ix, R.bits, &d.bits, 8)) || (r2 = upload(ix, R.nmask, &d.nmask, 8)) || (r2 = upload(ix, R.start, &d.start)) ||
 	    (r2 = upload(ix, R.approxLen, &d.approxLen))) return r2;
 	d.nRefs = (uint32_t)R.start.size();
 	void* p = nullptr;

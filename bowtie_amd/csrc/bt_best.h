@@ -1297,10 +1297,48 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 	const uint32_t slen = P.refSeeded ? (qlen < P.refSeedLen ? qlen : P.refSeedLen) : qlen;
 	const uint64_t base = BT_GP(const uint64_t, rf.start)[tidx];
 	const uint32_t lim = end - qlen - begin, halfway = begin + (lim >> 1);
+	/* Packed pre-filter (reads of up to 64 bases): the mate as 2-bit codes in two 64-bit words, the reference under each
+	 * candidate position cut out of three 64-bit pieces of the 2-bit reference that stay in registers while the
+	 * candidates walk away from the middle (one set for the positions below it, one for those above: a new piece every
+	 * 32 candidates) -- one XOR + popcount says whether the seed's mismatches can be within refMms, one AND whether the
+	 * span touches an N.  Only candidates that pass are then looked at base by base below, which decides exactly as
+	 * before (the reference's naive scan compares base by base throughout). */
+	const bool packed = qlen <= 64u;
+	uint64_t rq[2] = {0, 0}, rn[2] = {0, 0}, sm[2] = {0, 0}, lm[2] = {0, 0};
+	uint64_t W[2][3] = {{0, 0, 0}, {0, 0, 0}}, N[2][2] = {{0, 0}, {0, 0}}, K[2] = {~0ull, ~0ull};
+	if (packed) {
+		for (uint32_t j = 0; j < qlen; j++) {
+			const uint32_t q = bf_base(M, fw, 1u, j);
+			const uint64_t bit = 1ull << (2u * (j & 31u));
+			if (q < 4u) rq[j >> 5] |= (uint64_t)q << (2u * (j & 31u)); else rn[j >> 5] |= bit;
+			lm[j >> 5] |= bit;
+			if (fw ? (j < slen) : (j >= qlen - slen)) sm[j >> 5] |= bit;
+		}
+	}
+	const uint64_t nspan = qlen >= 64u ? ~0ull : ((1ull << qlen) - 1ull);
 	bool hi = false;
 	for (uint32_t i = 1; i <= lim + 1u; i++) {
 		const uint32_t ri = hi ? halfway + (i >> 1) : halfway - (i >> 1);
+		const uint32_t side = hi ? 1u : 0u;
 		hi = !hi;
+		if (packed) {
+			const uint64_t p = base + ri;
+			if ((p >> 5) != K[side]) {
+				K[side] = p >> 5;
+				BF_G const uint64_t* b64 = (BF_G const uint64_t*)rf.bits; BF_G const uint64_t* n64 = (BF_G const uint64_t*)rf.nmask;
+				W[side][0] = b64[K[side]]; W[side][1] = b64[K[side] + 1u]; W[side][2] = b64[K[side] + 2u];
+				N[side][0] = n64[p >> 6]; N[side][1] = n64[(p >> 6) + 1u];
+			}
+			const uint32_t t = (uint32_t)(p & 63u), s2 = 2u * (uint32_t)(p & 31u);
+			const uint64_t nn = t ? (N[side][0] >> t) | (N[side][1] << (64u - t)) : N[side][0];
+			if (nn & nspan) continue;                                      /* a reference N / gap under the mate */
+			const uint64_t a0 = s2 ? (W[side][0] >> s2) | (W[side][1] << (64u - s2)) : W[side][0];
+			const uint64_t a1 = s2 ? (W[side][1] >> s2) | (W[side][2] << (64u - s2)) : W[side][1];
+			const uint64_t x0 = a0 ^ rq[0], x1 = a1 ^ rq[1];
+			const uint64_t m0 = (((x0 | (x0 >> 1)) & 0x5555555555555555ull) | rn[0]) & lm[0];
+			const uint64_t m1 = (((x1 | (x1 >> 1)) & 0x5555555555555555ull) | rn[1]) & lm[1];
+			if ((uint32_t)__builtin_popcountll(m0 & sm[0]) + (uint32_t)__builtin_popcountll(m1 & sm[1]) > P.refMms) continue;
+		}
 		bool match = true;
 		uint32_t mms = 0, seedMms = 0, ham = 0;
 		for (uint32_t j = 0; j < qlen; j++) {

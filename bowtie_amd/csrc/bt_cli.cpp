@@ -591,31 +591,79 @@ std::string search_job_pairs(bt_ctx* ctx, const Options& O, Job* j)
 	j->hit_cap = all ? 16u : 2u * (O.pol.khits > 32u ? 32u : O.pol.khits);
 	/* -M: a pair over the ceiling keeps its first mhits alignments, one of which is printed (at most 64 are kept) */
 	if (O.pol.sample_max && !all) { const uint32_t w = 2u * (O.pol.mhits > 64u ? 64u : O.pol.mhits); if (w > j->hit_cap) j->hit_cap = w; }
-	for (int pass = 0; pass < 2; pass++) {
-		j->hits.assign((size_t)n * j->hit_cap, bt_hit());
-		j->n_hits.assign(n, 0); j->status.assign(n, 0);
-		uint32_t maxlen = 6;
-		if (pass) for (uint32_t i = 0; i < n; i++) { if (j->rb.len[i] > maxlen) maxlen = j->rb.len[i]; if (j->rb2.len[i] > maxlen) maxlen = j->rb2.len[i]; }
-		j->mm_pool.resize((size_t)n * j->hit_cap * maxlen + 1024u);
-		bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
-		int rc = bt_align_pairs(ctx, &j->rb, &j->rb2, &hb, nullptr);
-		j->mm_used = hb.mm_pool_used;
-		if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
-		uint32_t need = 0; bool pool_short = false;
-		const uint32_t maxv = O.pol.mhits == 0xffffffffu ? 0xffffffffu : O.pol.mhits * 2u;
-		for (uint32_t i = 0; i < n; i++) {
-			if (j->status[i] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
-			if (j->status[i] & BT_ST_MMPOOL) pool_short = true;
-			const uint32_t tot = j->n_hits[i];
-			if (tot > maxv) continue;
-			const uint32_t want = all ? tot : (tot < 2u * O.pol.khits ? tot : 2u * O.pol.khits);
-			if (want > need) need = want;
+	j->hits.assign((size_t)n * j->hit_cap, bt_hit());
+	j->n_hits.assign(n, 0); j->status.assign(n, 0);
+	j->mm_pool.resize((size_t)n * j->hit_cap * 6u + 1024u);
+	bt_hit_batch hb = { j->hit_cap, j->hits.data(), j->n_hits.data(), j->status.data(), j->mm_pool.data(), (uint32_t)j->mm_pool.size(), 0 };
+	int rc = bt_align_pairs(ctx, &j->rb, &j->rb2, &hb, nullptr);
+	j->mm_used = hb.mm_pool_used;
+	if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
+	/* pairs with more alignments than the uniform slots hold (-a, large -k on repetitive references), or whose
+	 * mismatch lists outgrew the pool: those pairs alone are searched again with room for all, as search_finish
+	 * does for unpaired reads */
+	const uint32_t maxv = O.pol.mhits == 0xffffffffu ? 0xffffffffu : O.pol.mhits * 2u;
+	std::vector<uint32_t> redo, need;
+	for (uint32_t i = 0; i < n; i++) {
+		if (j->status[i] & BT_ST_OVERFLOW) return "Error: a read exceeded the search scratch space";
+		const uint32_t tot = j->n_hits[i];
+		if (tot > maxv && !O.pol.sample_max) continue;               /* nothing of it is printed */
+		const uint32_t want = tot > maxv ? maxv : (all ? tot : (tot < 2u * O.pol.khits ? tot : 2u * O.pol.khits));
+		if (want > j->hit_cap || (j->status[i] & BT_ST_MMPOOL)) { redo.push_back(i); need.push_back(((want > j->hit_cap ? want : j->hit_cap) + 1u) & ~1u); }
+	}
+	size_t at = 0;
+	while (at < redo.size()) {
+		/* a group whose slot matrix stays under 16 M hits; a single pair may exceed that on its own */
+		size_t end = at; uint32_t cap = 0; uint32_t maxlen = 6;
+		while (end < redo.size()) {
+			const uint32_t c2 = need[end] > cap ? need[end] : cap;
+			if (end > at && (uint64_t)c2 * (end - at + 1) > (16ull << 20)) break;
+			cap = c2;
+			const uint32_t i = redo[end];
+			if (j->rb.len[i] > maxlen) maxlen = j->rb.len[i];
+			if (j->rb2.len[i] > maxlen) maxlen = j->rb2.len[i];
+			end++;
 		}
-		if (need <= j->hit_cap && !pool_short) break;
-		if (pass == 1) return "Error: a read exceeded the search scratch space";
-		/* simplest correct thing for the rare batch with a greedy pair: the whole batch again, wider */
-		if (need > j->hit_cap) j->hit_cap = (need + 1u) & ~1u;
-		if ((uint64_t)n * j->hit_cap > (64ull << 20)) return "Error: too many alignments per pair for one batch; lower --batch";
+		if ((uint64_t)cap > (256ull << 20)) return "Error: too many alignments for one pair (more than 128 M)";
+		const uint32_t m = (uint32_t)(end - at);
+		BtHostBatch s1, s2;
+		s1.reset(m, j->rb.stride); s2.reset(m, j->rb2.stride);
+		for (uint32_t k = 0; k < m; k++) {
+			const uint32_t i = redo[at + k];
+			memcpy(s1.seq + (size_t)k * s1.stride, j->rb.seq + (size_t)i * j->rb.stride, j->rb.stride);
+			memcpy(s1.qual + (size_t)k * s1.stride, j->rb.qual + (size_t)i * j->rb.stride, j->rb.stride);
+			s1.len[k] = j->rb.len[i]; s1.seed[k] = j->rb.seed[i];
+			memcpy(s2.seq + (size_t)k * s2.stride, j->rb2.seq + (size_t)i * j->rb2.stride, j->rb2.stride);
+			memcpy(s2.qual + (size_t)k * s2.stride, j->rb2.qual + (size_t)i * j->rb2.stride, j->rb2.stride);
+			s2.len[k] = j->rb2.len[i]; s2.seed[k] = j->rb2.seed[i];
+		}
+		const bt_read_batch r1 = s1.view(), r2 = s2.view();
+		std::vector<bt_hit> sh((size_t)m * cap);
+		std::vector<uint32_t> snh(m); std::vector<uint8_t> sst(m);
+		uint64_t pool_n = (uint64_t)m * cap * maxlen + 1024u;          /* a full-length mismatch list per alignment */
+		if (pool_n > 0xfffffff0ull) pool_n = 0xfffffff0ull;
+		std::vector<uint16_t> sp((size_t)pool_n);
+		bt_hit_batch shb = { cap, sh.data(), snh.data(), sst.data(), sp.data(), (uint32_t)sp.size(), 0 };
+		rc = bt_align_pairs(ctx, &r1, &r2, &shb, nullptr);
+		if (rc != BT_OK && rc != BT_ERR_OVERFLOW) return std::string("Error: search failed: ") + bt_strerror(rc);
+		for (uint32_t k = 0; k < m; k++) {
+			if (sst[k] & (BT_ST_OVERFLOW | BT_ST_MMPOOL)) return "Error: a read exceeded the search scratch space";
+			Job::Wide w;
+			w.read = redo[at + k]; w.n_hits = snh[k]; w.status = sst[k];
+			const uint32_t tot = snh[k];
+			uint32_t keep = tot > maxv ? maxv : (all ? tot : (tot < 2u * O.pol.khits ? tot : 2u * O.pol.khits));
+			if (keep > cap) keep = cap;
+			w.hit_cap = keep ? keep : 2u;
+			w.hits.assign(sh.begin() + (size_t)k * cap, sh.begin() + (size_t)k * cap + w.hit_cap);
+			for (uint32_t h = 0; h < keep; h++) {              /* the pair's mismatch lists, re-based */
+				bt_hit& x = w.hits[h];
+				const uint32_t off = (uint32_t)w.pool.size();
+				w.pool.insert(w.pool.end(), sp.begin() + x.mm_off, sp.begin() + x.mm_off + x.nmm);
+				x.mm_off = off;
+			}
+			if (w.pool.empty()) w.pool.push_back(0);
+			j->wide.push_back(std::move(w));
+		}
+		at = end;
 	}
 	return "";
 }
@@ -773,7 +821,11 @@ int list_input(Options& O)
 		if (r == BT_OK && tabbed && b1.n_paired != (O.paired ? b1.n : 0u)) { err = mixed_msg; r = BT_ERR_READS; }
 		if (r == BT_OK && O.paired) {
 			r = bt_io_next(rs2, O.batch_reads, O.threads, &b2, &err);
-			if (r == BT_OK && b2.n != b1.n) { err = "mate streams differ in length"; r = BT_ERR_READS; }
+			if (r == BT_OK && !bt_io_intersect_pairs(&b1, &b2)) {
+				err = b1.end_rdid < b2.end_rdid ? "Error, fewer reads in file specified with -1 than in file specified with -2"
+				                                : "Error, fewer reads in file specified with -2 than in file specified with -1";
+				r = BT_ERR_READS;
+			}
 		}
 		if (r != BT_OK) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
 		if (b1.n == 0) break;
@@ -889,11 +941,14 @@ int main(int argc, char** argv)
 				if (abort_run.load()) j->store2->n = 0;
 				else r = bt_io_next(rs2, O.batch_reads, T, j->store2.get(), &err);
 				if (r != BT_OK) j->error = err;
+				/* a mate record that does not parse takes its pair out of the run (pat.cpp:96-127), not just itself */
+				const bool same_end = r != BT_OK || bt_io_intersect_pairs(j->store.get(), j->store2.get());
+				j->rb = j->store->view();
 				j->rb2 = j->store2->view();
-				if (r == BT_OK && j->rb2.n_reads != j->rb.n_reads) {
+				if (r == BT_OK && !same_end) {
 					/* PatternComposer (pat.cpp:198-212) */
-					j->error = j->rb.n_reads < j->rb2.n_reads ? "Error, fewer reads in file specified with -1 than in file specified with -2"
-					                                          : "Error, fewer reads in file specified with -2 than in file specified with -1";
+					j->error = j->store->end_rdid < j->store2->end_rdid ? "Error, fewer reads in file specified with -1 than in file specified with -2"
+					                                                    : "Error, fewer reads in file specified with -2 than in file specified with -1";
 					r = BT_ERR_READS;
 				}
 			}
@@ -971,8 +1026,18 @@ int main(int argc, char** argv)
 			auto run = [&](size_t si) {
 				const Seg& sg = segs[si];
 				if (O.paired) {
-					bt_io_format_pairs(j->rb, names, noff, j->rb2, j->store2->names.data(), j->store2->name_off.data(), hb, refs, O.out,
-					                   sg.lo, sg.hi, &parts[si], &tl[si]);
+					if (sg.wide < 0) {
+						bt_io_format_pairs(j->rb, names, noff, j->rb2, j->store2->names.data(), j->store2->name_off.data(), hb, refs, O.out,
+						                   sg.lo, sg.hi, &parts[si], &tl[si]);
+						return;
+					}
+					/* a pair that was searched again with room for all its alignments: a one-pair view */
+					Job::Wide& w = j->wide[(size_t)sg.wide];
+					const bt_read_batch one1 = one_read(j->rb, w.read), one2 = one_read(j->rb2, w.read);
+					bt_hit_batch hw = { w.hit_cap, w.hits.data(), &w.n_hits, &w.status, w.pool.data(), (uint32_t)w.pool.size(), 0 };
+					const uint64_t* noff2 = j->store2->name_off.data();
+					const uint64_t off1[2] = { noff[w.read], noff[w.read + 1] }, off2[2] = { noff2[w.read], noff2[w.read + 1] };
+					bt_io_format_pairs(one1, names, off1, one2, j->store2->names.data(), off2, hw, refs, O.out, 0, 1, &parts[si], &tl[si]);
 					return;
 				}
 				if (sg.wide < 0) { bt_io_format(j->rb, names, noff, hb, refs, O.out, sg.lo, sg.hi, &parts[si], &tl[si]); return; }

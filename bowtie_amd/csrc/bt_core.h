@@ -255,10 +255,10 @@ struct BtLane {
 	uint32_t cand : 11, scanCb : 16;         /* scanCb: next chunk (8 records) of a running frame scan */
 	uint32_t ebase;
 	/* per-position temporaries that live across the wait + control */
-	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, state : 5, ra_cont : 2;
+	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, ra_cont : 2;
 	/* pending backtrack target */
 	uint32_t pi : 11, pj : 2, btham : 16;
-	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1, wpf : 1;
+	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1, wpf : 1, cchunk : 8;   /* cchunk: the cached 16-byte chunk of the read (register-window build), 0xff = none */
 	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
@@ -266,7 +266,7 @@ struct BtLane {
 	uint32_t crow, cjumps;
 	uint32_t iters;
 	/* register window over the read: 16 bases + 16 quals around the current position */
-	uint32_t cchunk;                 /* index of the cached 16-byte chunk, 0xff = none */
+	uint32_t state;                  /* ST_*: in a word of its own -- every guard of the sweep tests it */
 	uint32_t cs0, cs1, cs2, cs3, cq0, cq1, cq2, cq3;
 };
 
@@ -372,7 +372,10 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 #define HSEL(f) (L.mirror ? H.f[1] : H.f[0])          /* hot: scalar registers */
 #define WSEL(f) (L.mirror ? W.f[1] : W.f[0])          /* warm: LDS */
 #define HFCHR(k) (L.mirror ? H.fchr[1][k] : H.fchr[0][k])
-#define ST_IS(x) (L.state == (x) && req.kind == RQ_NONE)
+/* a block that emits its request leaves the lane in a state no LATER block of the sweep takes (its own *_DONE /
+ * *_FETCHED state) -- except the three that are entered straight from the block before them with the request pending */
+#define ST_IS(x) (L.state == (x))
+#define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE)
 
 #define BT_REQ_RANK1(R) do { req.kind = RQ_RANK; req.n = 1; req.a = (R); } while (0)
 #define BT_REQ_RANK2(RA, RB) do { req.kind = RQ_RANK; req.n = 2; req.a = (RA); req.x = (RB); } while (0)
@@ -582,6 +585,37 @@ BT_HD void bt_scan_request(const BtLane& L, const BtScratch& S, uint32_t c_lo, B
 	BT_REQ_FETCH(&META((uint64_t)lo * 8u), hi - lo + 1u, nullptr);
 }
 
+/* One fetched piece (eight 16-bit records, the deepest last) of a frame scan.  Re-scan (:1004-1058): the reference's
+ * walk from the deepest record down, restarting its tallies whenever a strictly lower quality shows up -- low = the
+ * lowest affordable quality so far, num = untried substitutions at that quality, cnd / cel = the deepest record of that
+ * quality (relative index t = e - e_lo) and its eliminated-set.  t0 = first record of the piece - e_lo; records with
+ * t outside [0, span] are not part of the scan. */
+struct BtScanAcc { uint32_t low, num, cnd, cel; };
+BT_HD void bt_rescan_piece(const BtU4& q, uint32_t t0, uint32_t span, uint32_t qlim, BtScanAcc& a)
+{
+	const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+	BT_UNROLL
+	for (int k = 7; k >= 0; k--) {
+		const uint32_t el = (w[k >> 1] >> ((k & 1) * 16)) & 15u, kq = (w[k >> 1] >> ((k & 1) * 16 + 8)) & 0xffu;
+		const uint32_t t = t0 + (uint32_t)k;
+		const uint32_t key = (t <= span && el != 15u && kq <= qlim) ? kq : 0xffffffffu;
+		const bool lt = key < a.low;
+		a.low = lt ? key : a.low; a.num = lt ? 0u : a.num; a.cnd = lt ? t : a.cnd; a.cel = lt ? el : a.cel;
+		a.num += (key == a.low) ? 4u - (uint32_t)__builtin_popcount(el) : 0u;
+	}
+}
+/* Target scan (:767-812): the deepest record that still has an untried substitution of the eligible quality */
+BT_HD void bt_candscan_piece(const BtU4& q, uint32_t t0, uint32_t span, uint32_t lowq, bool anyq, uint32_t& cnd)
+{
+	const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+	BT_UNROLL
+	for (int k = 0; k < 8; k++) {                 /* shallow to deep: the last hit stays */
+		const uint32_t el = (w[k >> 1] >> ((k & 1) * 16)) & 15u, kq = (w[k >> 1] >> ((k & 1) * 16 + 8)) & 0xffu;
+		const uint32_t t = t0 + (uint32_t)k;
+		cnd = (t <= span && el != 15u && (kq == lowq || anyq)) ? t : cnd;
+	}
+}
+
 /* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
 template <bool RL>
 BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
@@ -738,36 +772,26 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			{
 				const uint32_t P = L.qualThresh >= L.ham ? L.qualThresh - L.ham : 0xffffffffu;
 				if (P == 0xffffffffu) qlim = 0xffffffffu;         /* nothing affordable: marks "none" below */
-				else if (!L.maq) qlim = P;
+				else if (!L.maq) qlim = P > 0xffu ? 0xffu : P;
 				else qlim = P >= 30u ? 0xffu : P >= 20u ? 24u : P >= 10u ? 14u : 4u;
 			}
-			const bool none = qlim == 0xffffffffu;
-			uint32_t low = L.lowAltQual, num = L.eligibleNum, cnd = 0xffffffffu, elc = 0;
-			BT_NOUNROLL
-			for (int t = 3; t >= 0; t--) {
-				if ((uint32_t)t > hi - lo) continue;
-				const uint32_t wv[4] = {bt_sel4((uint32_t)t, res.q[0].x, res.q[1].x, res.q[2].x, res.q[3].x),
-				                        bt_sel4((uint32_t)t, res.q[0].y, res.q[1].y, res.q[2].y, res.q[3].y),
-				                        bt_sel4((uint32_t)t, res.q[0].z, res.q[1].z, res.q[2].z, res.q[3].z),
-				                        bt_sel4((uint32_t)t, res.q[0].w, res.q[1].w, res.q[2].w, res.q[3].w)};
-				BT_UNROLL
-				for (int k = 7; k >= 0; k--) {
-					const uint32_t v = (k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu);
-					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k;
-					const uint32_t el = v & 15u, kq = v >> 8;
-					const bool ok = !none && e <= e_hi && e >= e_lo && el != 15u && kq <= qlim;
-					const uint32_t live = 4u - (uint32_t)__builtin_popcount(el);
-					if (ok && kq < low) {
-						low = kq; num = 0; cnd = e;
-						elc = (el & 1u) == 0 ? 0u : (el & 2u) == 0 ? 1u : (el & 4u) == 0 ? 2u : 3u;
-					}
-					num += (ok && kq == low) ? live : 0u;
+			if (qlim != 0xffffffffu) {
+				BtScanAcc a; a.low = L.lowAltQual; a.num = L.eligibleNum; a.cnd = 0xffffffffu; a.cel = 0;
+				const uint32_t span = e_hi - e_lo, t0 = lo * 8u - e_lo, np = hi - lo;     /* t0 may be "negative": wraps above span */
+				BT_NOUNROLL
+				for (int t = 3; t >= 0; t--) {                    /* one copy of the eight-record walk: the kernel is short of registers */
+					if ((uint32_t)t > np) continue;
+					BtU4 pc;
+					pc.x = bt_sel4((uint32_t)t, res.q[0].x, res.q[1].x, res.q[2].x, res.q[3].x); pc.y = bt_sel4((uint32_t)t, res.q[0].y, res.q[1].y, res.q[2].y, res.q[3].y);
+					pc.z = bt_sel4((uint32_t)t, res.q[0].z, res.q[1].z, res.q[2].z, res.q[3].z); pc.w = bt_sel4((uint32_t)t, res.q[0].w, res.q[1].w, res.q[2].w, res.q[3].w);
+					bt_rescan_piece(pc, t0 + 8u * (uint32_t)t, span, qlim, a);
 				}
-			}
-			L.lowAltQual = low; L.eligibleNum = num;
-			if (cnd != 0xffffffffu) {
-				L.cand = L.depth + (cnd - L.ebase); L.candValid = 1; L.ccValid = 0;
-				L.elcint = elc; L.elignore = 0;
+				L.lowAltQual = a.low; L.eligibleNum = a.num;
+				if (a.cnd != 0xffffffffu) {
+					L.cand = kmin + a.cnd; L.candValid = 1; L.ccValid = 0;
+					L.elcint = (a.cel & 1u) == 0 ? 0u : (a.cel & 2u) == 0 ? 1u : (a.cel & 4u) == 0 ? 2u : 3u;
+					L.elignore = 0;
+				}
 			}
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_RESCAN; break; }
 			L.state = ST_BT_LOOP;
@@ -884,7 +908,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 		} while (0); BT_PROF_ADD(PS_SEARCH_BEGIN, t_search_begin); }
 
-		if (ST_IS(ST_FTABSEQ_DONE)) { BT_PROF_T0(t_ftabseq_done); do {
+		if (ST_IS_NOREQ(ST_FTABSEQ_DONE)) { BT_PROF_T0(t_ftabseq_done); do {
 			const uint32_t ftabChars = WSEL(ftabChars);
 			const uint32_t i0 = L.qlen - ftabChars, i1 = L.qlen - 1u;
 			const uint32_t j0 = L.rev ? (L.plen - 1u - i1) : i0;
@@ -904,7 +928,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			L.state = ST_FTAB_DONE;
 		} while (0); BT_PROF_ADD(PS_FTABSEQ_DONE, t_ftabseq_done); }
 
-		if (ST_IS(ST_FTAB_DONE)) { BT_PROF_T0(t_ftab_done); do {
+		if (ST_IS_NOREQ(ST_FTAB_DONE)) { BT_PROF_T0(t_ftab_done); do {
 			const uint32_t ftabChars = WSEL(ftabChars), len = WSEL(len);
 			const uint32_t ftabOff = L.ra_r;
 			uint32_t top = bt_u4_word(res.q[0], ftabOff & 3u);
@@ -943,31 +967,26 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			const uint32_t c_lo = e_lo >> 3;
 			if (L.state == ST_CANDSCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_CANDSCAN_DONE; break; }
 			const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
-			bool found = false;
-			uint32_t cnd = 0;
-			BT_NOUNROLL
-			for (int t = 3; t >= 0; t--) {
-				if ((uint32_t)t > hi - lo) continue;
-				const uint32_t wv[4] = {bt_sel4((uint32_t)t, res.q[0].x, res.q[1].x, res.q[2].x, res.q[3].x),
-				                        bt_sel4((uint32_t)t, res.q[0].y, res.q[1].y, res.q[2].y, res.q[3].y),
-				                        bt_sel4((uint32_t)t, res.q[0].z, res.q[1].z, res.q[2].z, res.q[3].z),
-				                        bt_sel4((uint32_t)t, res.q[0].w, res.q[1].w, res.q[2].w, res.q[3].w)};
-				BT_UNROLL
-				for (int k = 7; k >= 0; k--) {
-					const uint32_t v = (k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu);
-					const uint32_t e = (lo + (uint32_t)t) * 8u + (uint32_t)k;
-					const bool hit = !found && e <= e_hi && e >= e_lo && ((v >> 8) == L.lowAltQual || !L.considerQuals) && (v & 15u) != 15u;
-					cnd = hit ? e : cnd;
-					found = found || hit;
+			uint32_t cnd = 0xffffffffu;
+			{
+				const uint32_t span = e_hi - e_lo, t0 = lo * 8u - e_lo, np = hi - lo;
+				const bool anyq = !L.considerQuals;
+				BT_NOUNROLL
+				for (uint32_t t = 0; t <= np; t++) {
+					BtU4 pc;
+					pc.x = bt_sel4(t, res.q[0].x, res.q[1].x, res.q[2].x, res.q[3].x); pc.y = bt_sel4(t, res.q[0].y, res.q[1].y, res.q[2].y, res.q[3].y);
+					pc.z = bt_sel4(t, res.q[0].z, res.q[1].z, res.q[2].z, res.q[3].z); pc.w = bt_sel4(t, res.q[0].w, res.q[1].w, res.q[2].w, res.q[3].w);
+					bt_candscan_piece(pc, t0 + 8u * t, span, L.lowAltQual, anyq, cnd);
 				}
 			}
-			if (found) { L.cand = L.depth + (cnd - L.ebase); L.candValid = 1; L.ccValid = 0; }
+			const bool found = cnd != 0xffffffffu;
+			if (found) { L.cand = L.depth + cnd; L.candValid = 1; L.ccValid = 0; }
 			if (found) { L.state = ST_BT_LOOP; break; }
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_CANDSCAN; break; }
 			L.state = ST_ABORT;                                   /* cannot happen: altNum > 0 */
 		} while (0); BT_PROF_ADD(PS_CANDSCAN, t_candscan); }
 
-		if (ST_IS(ST_BT_PICK)) { BT_PROF_T0(t_bt_pick); do {
+		if (ST_IS_NOREQ(ST_BT_PICK)) { BT_PROF_T0(t_bt_pick); do {
 			const uint32_t i = L.cand;
 			const uint32_t e = L.ebase + (i - L.depth);
 			const uint32_t ts = S.tosStride;
@@ -1339,4 +1358,5 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 #undef WSEL
 #undef HFCHR
 #undef ST_IS
+#undef ST_IS_NOREQ
 #endif /* BT_CORE_H_ */

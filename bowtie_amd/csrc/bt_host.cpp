@@ -546,8 +546,8 @@ int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost*
 	R.start.resize(nRefs); R.approxLen.assign(nRefs, 0);
 	uint64_t total = 0;
 	for (uint32_t t = 0; t < nRefs; t++) { R.start[t] = total; total += ((uint64_t)idx.plen[t] + 63u) & ~63ull; }
-	R.bits.assign((size_t)(total / 16u) + 4u, 0u);
-	R.nmask.assign((size_t)(total / 32u) + 4u, 0xffffffffu);
+	R.bits.assign((size_t)(total / 16u) + 16u, 0u);            /* + padding: the mate finder reads 64-bit pieces past the end */
+	R.nmask.assign((size_t)(total / 32u) + 16u, 0xffffffffu);
 	int64_t t = -1; bool live = false; uint64_t pos = 0, src = 0;
 	for (uint32_t i = 0; i < nrec; i++) {
 		const Rec& r = recs[i];

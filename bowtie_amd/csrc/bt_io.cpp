@@ -37,6 +37,49 @@ void BtHostBatch::reset(uint32_t n_reads, uint32_t stride_bytes)
 	len.assign(n_reads, 0); seed.assign(n_reads, 0);
 }
 
+static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)
+{
+	std::string names, raw;
+	std::vector<uint64_t> noff(keep.size() + 1), roff;
+	const bool has_raw = b->raw_off.size() == (size_t)b->n + 1;
+	if (has_raw) roff.resize(keep.size() + 1);
+	uint32_t np = 0;
+	for (size_t k = 0; k < keep.size(); k++) {
+		const uint32_t i = keep[k];
+		if (i != k) {
+			memmove(b->seq + k * b->stride, b->seq + (size_t)i * b->stride, b->stride);
+			memmove(b->qual + k * b->stride, b->qual + (size_t)i * b->stride, b->stride);
+			b->len[k] = b->len[i]; b->seed[k] = b->seed[i]; b->rdid[k] = b->rdid[i];
+		}
+		noff[k] = names.size(); names.append(b->names, b->name_off[i], b->name_off[i + 1] - b->name_off[i]);
+		if (has_raw) { roff[k] = raw.size(); raw.append(b->raw, b->raw_off[i], b->raw_off[i + 1] - b->raw_off[i]); }
+	}
+	noff[keep.size()] = names.size();
+	if (has_raw) { roff[keep.size()] = raw.size(); b->raw.swap(raw); b->raw_off.swap(roff); }
+	b->names.swap(names); b->name_off.swap(noff);
+	b->n = (uint32_t)keep.size();
+	b->len.resize(b->n); b->seed.resize(b->n); b->rdid.resize(b->n);
+	b->first_rdid = b->n ? b->rdid[0] : 0;
+	if (b->n_paired > b->n) b->n_paired = b->n;
+	(void)np;
+}
+
+bool bt_io_intersect_pairs(BtHostBatch* a, BtHostBatch* b)
+{
+	const bool same_end = a->end_rdid == b->end_rdid;
+	bool equal = a->n == b->n;
+	for (uint32_t i = 0; equal && i < a->n; i++) equal = a->rdid[i] == b->rdid[i];
+	if (equal) return same_end;
+	std::vector<uint32_t> ka, kb;
+	uint32_t i = 0, k = 0;
+	while (i < a->n && k < b->n) {
+		if (a->rdid[i] == b->rdid[k]) { ka.push_back(i++); kb.push_back(k++); }
+		else if (a->rdid[i] < b->rdid[k]) i++; else k++;
+	}
+	compact_batch(a, ka); compact_batch(b, kb);
+	return same_end;
+}
+
 bt_read_batch BtHostBatch::view() const
 {
 	bt_read_batch b;
@@ -844,6 +887,7 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
 {
 	const int rc = io_next_impl(s, max_reads, threads, batch, err);
+	batch->end_rdid = s->rdid;                    /* also for an empty batch (end of input) */
 	if (rc == BT_OK && batch->n > 0 && (s->o.flags & (BT_READ_MATE1 | BT_READ_MATE2)))
 		fix_mate_names(batch, (s->o.flags & BT_READ_MATE1) ? 1 : 2, s->o.seed);
 	return rc;

@@ -18,6 +18,8 @@
 struct BtHostBatch {
 	uint32_t n = 0, stride = 16;
 	uint64_t first_rdid = 0;              /* rdid[0]                                             */
+	uint64_t end_rdid = 0;                /* read id the stream stands at after this batch: records taken from the input,
+	                                         the ones that did not parse (and are not in the batch) included */
 	uint8_t* seq = nullptr;               /* [cap][stride] codes 0..4, rows padded with 4        */
 	uint8_t* qual = nullptr;              /* [cap][stride] Phred+33, rows padded with '!'        */
 	std::vector<uint16_t> len;
@@ -44,6 +46,11 @@ BtReadStream* bt_io_open(const char* spec, const bt_read_opts& opts, std::string
 /* next <= max_reads reads; returns BT_OK (batch.n == 0 at the end) or an error code with *err set */
 int bt_io_next(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err);
 void bt_io_close(BtReadStream* s);
+/* Two mate batches read side by side: keep the pairs both of whose mates parsed.  A record that does not parse drops
+ * out of its own batch only; the reference parses the two mates of a read id together and skips the pair when either
+ * fails (pat.cpp:96-127), so the batches are intersected on the read id.  Returns false if the two streams stand at
+ * different read ids afterwards (one file has fewer records). */
+bool bt_io_intersect_pairs(BtHostBatch* a, BtHostBatch* b);
 
 struct BtRefNames {
 	std::vector<std::string> names;

@@ -27,9 +27,12 @@ def build_probe():
     os.makedirs(W + "/emu", exist_ok=True)
     s = open(os.path.join(ROOT, "bowtie_amd/csrc/bt_core.h")).read()
     s = s.replace("#ifndef BT_CORE_H_", 'extern "C" { extern unsigned long long* bt_visit_mask; }\n#define BT_VISIT(x) (*bt_visit_mask |= 1ull << (x))\n#ifndef BT_CORE_H_', 1)
-    old = "#define ST_IS(x) (L.state == (x) && req.kind == RQ_NONE)"
+    old = "#define ST_IS(x) (L.state == (x))"
     assert old in s
-    s = s.replace(old, "#define ST_IS(x) (L.state == (x) && req.kind == RQ_NONE && (BT_VISIT(x), true))")
+    s = s.replace(old, "#define ST_IS(x) (L.state == (x) && (BT_VISIT(x), true))")
+    old = "#define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE)"
+    assert old in s
+    s = s.replace(old, "#define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE && (BT_VISIT(x), true))")
     for pat in ["\t\tif (!RL && L.state == ST_WIN_DONE) {", "\t\tif (L.state == ST_CHASE_LFDONE) {", "\t\tif (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST) {",
                 "\t\tif (L.state == ST_STEP_BEGIN) {", "\t\tif (L.state == ST_CHASE_CHECK) {"]:
         assert pat in s, pat

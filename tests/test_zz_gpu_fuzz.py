@@ -110,3 +110,51 @@ def _paired(seed, tmp_path, best):
             continue            # "--strata must be combined with --best" unless -v 3 / -M made the run stateful already
         ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2], rng.choice([[], [], ["--batch", "2"], ["--batch", "3", "--inflight", "1"]]))
         _check(ref, got, (seqs, args))
+
+
+@pytest.mark.parametrize("best", [True, False], ids=["best", "without_best"])
+def test_binary_pairs_with_more_alignments_than_the_uniform_slots(best, tmp_path):
+    """A tandem repeat gives every pair dozens of paired alignments: under -a / a large -k the pairs that outgrow the
+    batch's uniform hit slots are searched again on their own with room for all (the whole batch used to be widened,
+    and a 4 M-pair batch then refused with "lower --batch")."""
+    rng = random.Random(99)
+    unit = "".join(rng.choice("ACGT") for _ in range(37))
+    flank = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    g = flank(60) + unit * 14 + flank(60)
+    base = str(tmp_path / "g")
+    EB.build_index([F.LUT[np.frombuffer(g.encode(), dtype=np.uint8)]], ["rep"], base, ftab_chars=4, off_rate=2)
+    m1, m2 = [], []
+    for i in range(6):
+        p = 60 + 37 * rng.randrange(0, 3) + rng.randrange(0, 37)
+        a, b = g[p:p + 20], F._rc(g[p + 50:p + 70])
+        m1.append(("p%d" % i, a, "I" * 20)); m2.append(("p%d" % i, b, "I" * 20))
+    m1.append(("u0", flank(20), "I" * 20)); m2.append(("u0", flank(20), "I" * 20))          # and one that does not align
+    f1, f2 = str(tmp_path / "m_1.fq"), str(tmp_path / "m_2.fq")
+    F._write_fastq(f1, m1, 1)
+    F._write_fastq(f2, m2, 2)
+    for args in (["-v", "0", "-a", "-X", "200"], ["-v", "1", "-k", "20", "-X", "120"], ["-n", "1", "-l", "10", "-a", "-X", "150", "-S"]):
+        ref, got = _both(args + (["--best"] if best else []), ["-x", base, "-1", f1, "-2", f2])
+        assert ref.stdout.count(b"\n") > 60          # the case does what it says
+        _check(ref, got, args)
+
+
+def test_binary_drops_the_pair_when_one_mate_record_does_not_parse(tmp_path):
+    """A mate record without a sequence (FASTA) or cut short takes its PAIR out of the run in the reference, which parses
+    the two mates of a read id together (pat.cpp:96-127); the later pairs stay aligned with each other."""
+    rng = random.Random(5)
+    g = "".join(rng.choice("ACGT") for _ in range(400))
+    base = str(tmp_path / "g")
+    EB.build_index([F.LUT[np.frombuffer(g.encode(), dtype=np.uint8)]], ["g"], base, ftab_chars=4, off_rate=2)
+    pairs = []
+    for i in range(9):
+        p = rng.randrange(0, 300)
+        pairs.append((g[p:p + 24], F._rc(g[p + 60:p + 84])))
+    for bad1, bad2 in ((2, None), (None, 5), (1, 6), (3, 3)):
+        f1, f2 = str(tmp_path / "m_1.fa"), str(tmp_path / "m_2.fa")
+        with open(f1, "w") as a, open(f2, "w") as b:
+            for i, (x, y) in enumerate(pairs):
+                a.write(">p%d\n%s\n" % (i, "" if i == bad1 else x))
+                b.write(">p%d\n%s\n" % (i, "" if i == bad2 else y))
+        for args in (["-f", "-v", "1", "-X", "200"], ["-f", "-v", "0", "-X", "200", "--best", "-S"]):
+            ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2], ["--batch", "4"])
+            _check(ref, got, (bad1, bad2, args))
