@@ -561,6 +561,7 @@ def main():
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
                          "carry_over_launches": carry_age, "flush_ms_total": sum(flush_ms),
+                         "reads_searched_again_last_step": sum(int(lib.bt_ctx_last_retried(o["al"]._h)) for o in pipes),
                          "algorithmic_bytes_per_launch": abytes,
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
                          "lane_iters_per_read": per_launch["lane_iters"] / n,

@@ -43,7 +43,7 @@ struct bt_ctx {
 	BfProgram* d_bprog = nullptr; BtIndexDev* d_ix = nullptr; BtBatchDev* d_batch = nullptr;
 	BfProgram* d_bprog_pe = nullptr; bool have_pe = false;      /* the paired program, compiled on first use */
 	uint32_t* arenas = nullptr; uint32_t arenaWords = 0; uint32_t arenaLanes = 0;
-	uint32_t* bigArenas = nullptr; uint32_t* retryList = nullptr; uint32_t retryCap = 0;   /* on-device second pass */
+	uint32_t* bigArenas = nullptr; uint32_t bigArenaLanes = 0; uint32_t* retryList = nullptr; uint32_t retryCap = 0;   /* on-device second pass */
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -366,8 +366,19 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 {
 	/* arena words per lane: typical reads need a few thousand; a read that outgrows its arena is
 	 * flagged (BT_STF_OVERFLOW) and re-run by bt_align_batch through the twin context's 16 MB arenas */
-	const uint32_t words = c->is_big ? (1u << 22) : env_u32("BT_BEST_ARENA_WORDS", 16384u);
-	const uint32_t lanes = c->is_big ? (c->nLanes > 256u ? 256u : c->nLanes) : c->nLanes;
+	/* 64 K words (256 KB) per lane: on the hg19-scale index a few per cent of 100-bp -n 2 --best reads need between
+	 * 16 K and 64 K words -- reads with hundreds of seed extenders, the slow ones -- and whatever outgrows its arena
+	 * lands in the second pass below, which has a thousand lanes instead of a quarter of a million: with 16 K-word
+	 * arenas that pass took minutes per million reads (profiles/r3/best_arena.txt) */
+	const uint32_t words = c->is_big ? (1u << 22) : env_u32("BT_BEST_ARENA_WORDS", 65536u);
+	/* one arena per lane that the launch can use: a small batch does not fill the grid, and 64 KB x 393 216 lanes
+	 * (six blocks per CU) are 26 GB that a thousand-read batch has no use for */
+	uint32_t lanes = c->is_big ? (c->nLanes > 256u ? 256u : c->nLanes) : c->nLanes;
+	{
+		const uint64_t need = ((uint64_t)in->n_reads + BT_BLOCK - 1u) / BT_BLOCK * BT_BLOCK;
+		if (need < lanes) lanes = (uint32_t)need;
+		if (lanes < BT_BLOCK) lanes = BT_BLOCK;
+	}
 	if (!c->arenas || c->arenaWords != words || c->arenaLanes < lanes) {
 		if (c->arenas) (void)hipFree(c->arenas);
 		c->arenas = nullptr;
@@ -406,8 +417,9 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		 * arenas each -- the caller of the device-pointer entry points sees finished results only.  (256 lanes were
 		 * tried to save memory: on the hg19-scale index enough reads come here that the pass then takes several
 		 * times as long as the main launch, profiles/r3/.) */
-		const uint32_t bigWords = 1u << 22, bigLanes = env_u32("BT_BEST_RETRY_LANES", 1024u);
-		if (!c->bigArenas) HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u));
+		const uint32_t bigWords = 1u << 22, bigLanes = env_u32("BT_BEST_RETRY_LANES", in->n_reads >= (1u << 18) ? 1024u : 256u);
+		if (c->bigArenas && c->bigArenaLanes < bigLanes) { (void)hipFree(c->bigArenas); c->bigArenas = nullptr; }
+		if (!c->bigArenas) { HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u)); c->bigArenaLanes = bigLanes; }
 		const int rrc = ctx_ensure_retry_list(c, in->n_reads);
 		if (rrc != BT_OK) return rrc;
 		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 2, c->retryCap, c->stream) != 0) return BT_ERR_DEVICE;

@@ -21,8 +21,10 @@
  * 6.78 M reads/s single-end / paired, 3 waves 5.15 / 12.26, 4 waves 5.94 / 13.22, 6 waves (80 registers, the rest
  * spilled to scratch, which is coalesced and cached) 6.20 / 13.90, 8 waves 5.62 / 14.16.  -DBT_BEST_MIN_BLOCKS=<n>
  * builds another (make bestsweep). */
+/* Default: four.  Six is a few per cent faster on e_coli, but every lane owns an arena (bt_api.cpp: 256 KB since the
+ * hg19-scale measurement of profiles/r3/best_arena.txt), and four blocks per CU keep that at 67 GB per context. */
 #ifndef BT_BEST_MIN_BLOCKS
-#define BT_BEST_MIN_BLOCKS 6
+#define BT_BEST_MIN_BLOCKS 4
 #endif
 #define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
 __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)

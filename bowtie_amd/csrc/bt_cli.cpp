@@ -846,6 +846,49 @@ int main(int argc, char** argv)
 	if (getenv("BT_CLI_INPUT_ONLY")) return list_input(O);
 	const double t_all = now_s();
 
+	/* ---- the first batch of reads is parsed while the index loads ---- */
+	BtReadStream* rs = nullptr; BtReadStream* rs2 = nullptr;
+	open_read_streams(O, &rs, &rs2);
+	const bool tabbed = O.rd.format == BT_FMT_TABBED;
+	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
+	const int T = O.threads;
+	double busy_read = 0, busy_write = 0;
+	std::atomic<bool> abort_run(false);
+	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
+	/* one batch from the input into a job: returns BT_OK or the error it left in j->error */
+	auto read_job = [&](Job* j) -> int {
+		if (!spare.try_take(&j->store)) j->store.reset(new BtHostBatch());
+		std::string err;
+		const double tb = now_s();
+		int r = BT_OK;
+		if (abort_run.load()) j->store->n = 0;
+		else r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
+		busy_read += now_s() - tb;
+		if (r != BT_OK) j->error = err;
+		else if (tabbed && j->store->n_paired != (O.paired ? j->store->n : 0u)) { j->error = mixed_msg; r = BT_ERR_READS; }
+		j->rb = j->store->view();
+		if (O.paired && r == BT_OK) {
+			j->store2.reset(new BtHostBatch());
+			if (abort_run.load()) j->store2->n = 0;
+			else r = bt_io_next(rs2, O.batch_reads, T, j->store2.get(), &err);
+			if (r != BT_OK) j->error = err;
+			/* a mate record that does not parse takes its pair out of the run (pat.cpp:96-127), not just itself */
+			const bool same_end = r != BT_OK || bt_io_intersect_pairs(j->store.get(), j->store2.get());
+			j->rb = j->store->view();
+			j->rb2 = j->store2->view();
+			if (r == BT_OK && !same_end) {
+				/* PatternComposer (pat.cpp:198-212) */
+				j->error = j->store->end_rdid < j->store2->end_rdid ? "Error, fewer reads in file specified with -1 than in file specified with -2"
+				                                                    : "Error, fewer reads in file specified with -2 than in file specified with -1";
+				r = BT_ERR_READS;
+			}
+		}
+		return r;
+	};
+	std::unique_ptr<Job> first_job(new Job());
+	int first_rc = BT_OK;
+	std::thread prefetch([&] { first_rc = read_job(first_job.get()); });
+
 	/* ---- index into HBM ---- */
 	const std::string base = find_index(O.index);
 	if (O.devices.empty()) O.devices.push_back(0);
@@ -861,6 +904,7 @@ int main(int argc, char** argv)
 		for (auto& x : th) x.join();
 		for (size_t d = 0; d < ND; d++) if (rcs[d] != BT_OK) { rc = rcs[d]; break; }
 	}
+	prefetch.join();
 	if (rc != BT_OK) {
 		if (rc == BT_ERR_IO) die("Could not locate a Bowtie index corresponding to basename \"%s\"", O.index.c_str());
 		die("Error: could not load index \"%s\": %s", O.index.c_str(), bt_strerror(rc));
@@ -910,48 +954,17 @@ int main(int argc, char** argv)
 	}
 
 	/* ---- stage 1: reader ---- */
-	BtReadStream* rs = nullptr; BtReadStream* rs2 = nullptr;
-	open_read_streams(O, &rs, &rs2);
-	const bool tabbed = O.rd.format == BT_FMT_TABBED;
-	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
 	const int G = (int)ctxs.size();
 	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
-	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
-	const int T = O.threads;
-	double busy_read = 0, busy_write = 0;
 	std::vector<double> busy_gpu((size_t)G, 0.0);
-	std::atomic<bool> abort_run(false);
 	std::thread reader([&] {
 		uint64_t seq = 0;
 		for (;;) {
-			std::unique_ptr<Job> j(new Job());
+			std::unique_ptr<Job> j;
+			int r;
+			if (first_job) { j = std::move(first_job); r = first_rc; }        /* parsed while the index was loading */
+			else { j.reset(new Job()); r = read_job(j.get()); }
 			j->seq = seq++;
-			if (!spare.try_take(&j->store)) j->store.reset(new BtHostBatch());
-			std::string err;
-			const double tb = now_s();
-			int r = BT_OK;
-			if (abort_run.load()) j->store->n = 0;
-			else r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
-			busy_read += now_s() - tb;
-			if (r != BT_OK) j->error = err;
-			else if (tabbed && j->store->n_paired != (O.paired ? j->store->n : 0u)) { j->error = mixed_msg; r = BT_ERR_READS; }
-			j->rb = j->store->view();
-			if (O.paired && r == BT_OK) {
-				j->store2.reset(new BtHostBatch());
-				if (abort_run.load()) j->store2->n = 0;
-				else r = bt_io_next(rs2, O.batch_reads, T, j->store2.get(), &err);
-				if (r != BT_OK) j->error = err;
-				/* a mate record that does not parse takes its pair out of the run (pat.cpp:96-127), not just itself */
-				const bool same_end = r != BT_OK || bt_io_intersect_pairs(j->store.get(), j->store2.get());
-				j->rb = j->store->view();
-				j->rb2 = j->store2->view();
-				if (r == BT_OK && !same_end) {
-					/* PatternComposer (pat.cpp:198-212) */
-					j->error = j->store->end_rdid < j->store2->end_rdid ? "Error, fewer reads in file specified with -1 than in file specified with -2"
-					                                                    : "Error, fewer reads in file specified with -2 than in file specified with -1";
-					r = BT_ERR_READS;
-				}
-			}
 			if (r != BT_OK || j->rb.n_reads == 0) {
 				/* the end (or an input error, reported in its place in the order): one marker per searcher */
 				j->last = true;

@@ -525,7 +525,10 @@ static bool parse_raw(const char* r, size_t n, const bt_read_opts& o, BtParsed* 
  * "<TAB>seq2<TAB>quals2" -- the second end of a pair, under the same name.  A line that stops before the
  * qualities of an end is dropped whole.  Sequence characters that are no letters are skipped; the number of
  * qualities is compared with the number of bases before either is trimmed.  Both ends are parsed (their errors
- * are the record's); the one the stream was opened for is kept. */
+ * are the record's); the one the stream was opened for is kept.
+ * A close restatement of TabbedPatternSource::parse (pat.cpp:1017-1127), loop for loop, kept that way on purpose: what
+ * malformed lines do (which are dropped, which are errors, with which message) follows from the order of its tests,
+ * and the differential parser fuzz (tests/test_parser_fuzz.py) holds it to that. */
 static bool parse_tabbed(const char* r, size_t n, const bt_read_opts& o, uint64_t rdid, BtParsed* p, std::string* err)
 {
 	const uint8_t* a2d = asc2dna_table();

@@ -12,7 +12,7 @@ PMCGRP=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_
 if [ -n "${PMC_ONLY:-}" ]; then PMCGRP=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS"); fi
 for grp in "${PMCGRP[@]}"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --kernel-include-regex "bt_search" --output-format csv -d $OUT/pmc_$name -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --pmc $grp --kernel-include-regex "${KREGEX:-bt_search}" --output-format csv -d $OUT/pmc_$name -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu > $OUT/pmc_$name.log 2>&1
 done
 # summarise
 python - "$OUT" <<'PY'
@@ -26,7 +26,7 @@ for d in sorted(glob.glob(out + "/pmc_*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
-            if "bt_search" in row.get("Kernel_Name", ""):
+            if os.environ.get("KREGEX", "bt_search") in row.get("Kernel_Name", ""):
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             print("  PMC %-32s per-dispatch %s" % (k, ["%.4g" % x for x in v]))

@@ -16,6 +16,7 @@ def pytest_configure(config):
         import oracle_lib
         oracle_lib.lib()
         emu_lib.lib()
+        emu_lib.shim()
 
 
 def _has_gpu() -> bool:

@@ -26,6 +26,22 @@ def build():
                            SRCS[0], SRCS[1]])
 
 
+SHIM_PATH = os.path.join(EMU_DIR, "libcli_shim.so")
+SHIM_SRCS = [os.path.join(EMU_DIR, "cli_shim.cpp"), os.path.join(EMU_DIR, "bt_emu.cpp")] + SRCS[1:]
+
+
+def shim():
+    """tests/emu/libcli_shim.so (the GPU-side entry points of the C ABI answered by the host build, LD_PRELOADed under
+    the bowtie-amd binary by tests/test_cli_shim.py), rebuilt when stale.  Called from conftest.py in the main process, so
+    that xdist workers never race on the file."""
+    if not os.path.exists(SHIM_PATH) or any(os.path.getmtime(SHIM_PATH) < os.path.getmtime(s) for s in SHIM_SRCS):
+        tmp = SHIM_PATH + ".tmp%d" % os.getpid()
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include"), "-o", tmp,
+                               SHIM_SRCS[0], SHIM_SRCS[2]])
+        os.replace(tmp, SHIM_PATH)
+    return SHIM_PATH
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -30,10 +30,8 @@ def test_version_and_help():
 @pytest.mark.parametrize("args,msg", [
     (["--strata", "-x", "e_coli", "cli/io.fq"], "--strata must be combined with --best"),
     (["--best", "--strata", "-x", "e_coli", "cli/io.fq"], "--strata has no effect unless combined with"),
-    (["-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "add --best"),
     (["--best", "-1", "a.fq,c.fq", "-2", "b.fq", "-x", "e_coli"], "must be specified with -1 and -2"),
-    (["--12", "a.tab", "-x", "e_coli"], "add --best"),
-    (["--interleaved", "a.fq", "-x", "e_coli"], "add --best"),
+    (["-c", "-1", "ACGTACGTAC,TTTTACGTAC", "-2", "ACGTACGTAC", "-x", "e_coli"], "must be specified with -1 and -2"),
     (["--best", "--12", "-", "-x", "e_coli"], "standard input"),
     (["--best", "--12", "a.tab", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "cannot be combined"),
     (["-Q", "a.qual", "-x", "e_coli", "cli/io.fq"], "go with -f"),

@@ -21,10 +21,8 @@ SRCS = [os.path.join(T.ROOT, "tests", "emu", "cli_shim.cpp"), os.path.join(T.ROO
 
 @pytest.fixture(scope="module")
 def shim():
-    if not os.path.exists(SHIM) or any(os.path.getmtime(SHIM) < os.path.getmtime(s) for s in SRCS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(T.ROOT, "include"), "-o", SHIM,
-                               SRCS[0], SRCS[2]])
-    return SHIM
+    import emu_lib
+    return emu_lib.shim()            # built by conftest.py in the main process; this only checks it is fresh
 
 
 @pytest.mark.parametrize("files", [["tests/test_gpu_cli.py"], ["tests/test_simple_cases.py"], ["tests/test_zz_gpu_fuzz.py"],

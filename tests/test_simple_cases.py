@@ -232,6 +232,30 @@ def test_ext_kernel_instances_on_the_two_tiny_inputs(case, run, simple_index, mo
     assert p.stdout == expected(run)
 
 
+INSTANCES = [dict(BT_OCC=str(o), BT_NO_RL="1") for o in (1, 2, 3, 4)] + [dict(BT_OCC=str(o), BT_NO_RL3="1") for o in (1, 2)] + [dict()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["0", "1"], ids=["plain", "EXT"])
+@pytest.mark.parametrize("inst", INSTANCES, ids=lambda d: "_".join("%s%s" % (k[3:], v) for k, v in d.items()) or "RL3")
+def test_every_kernel_instance_on_the_dollar_row_inputs(inst, ext, simple_index):
+    """Fence around DESIGN.md 4.4's miscompile: the two inputs that extend a one-row range at the '$' row through EVERY
+    template instance of bt_search_kernel -- register-window builds for 1..4 waves per SIMD, the two-block read-in-LDS
+    builds, the three-block one, each plain and EXT (carry-over / second-pass code compiled in) -- not only the ones
+    the defaults happen to launch."""
+    for case, run in DOLLAR_ROW:
+        if "sam" in run["file"]:
+            continue
+        base = simple_index(case["ref"])
+        env = dict(os.environ, **inst)
+        if ext == "1":
+            env["BT_FORCE_EXT"] = "1"
+        cmd = [BIN, "--wrapper", "basic-0", "-p", "1", "--no-stream"] + run["args"] + ["-x", base] + case["reads"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, env=env, timeout=120)
+        assert p.returncode == 0, (inst, ext, p.stderr.decode(errors="replace")[-300:])
+        assert p.stdout == expected(run), (inst, ext, run["file"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,run", DOLLAR_ROW, ids=lambda x: (x["name"].replace(" ", "_") + "#%d" % x["id"]) if "name" in x else x["file"][14:-7])
 def test_streamed_binary_on_the_two_tiny_inputs(case, run, simple_index):
