@@ -43,19 +43,20 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # so the figures live in profiles/traffic.json keyed by (kernel template instance, workload) and are used
 # only when the kernel this run launched is the one that was profiled -- otherwise `traffic` is null.
 def gather_ceiling(index_kind: str):
-    """Measured ceiling of the access pattern itself on this GPU: independent random 128-byte side-pair gathers over
-    the index image (scripts/gather_ceiling.py -> bt_bench_gather), best configuration, GB/s at 128 B per query."""
+    """Measured ceiling of the access pattern itself on this GPU: independent random rank queries over the index image
+    with nothing else going on (bt_bench_gather; round 3: the 32-byte rank blocks the kernels gather), best
+    configuration, priced at SURVEY 8(d)'s 128 bytes per query so that it compares with roofline.achieved."""
+    src = ("profiles/r3/gather_big.json" if index_kind == "big" else "profiles/r2/gather_ecoli.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r2", "gather_big.json" if index_kind == "big" else "gather_ecoli.json")) as f:
+        with open(os.path.join(ROOT, src)) as f:
             j = json.load(f)
         best = max(j["runs"], key=lambda r: r["GBps_128B_per_query"])
-        return {"GBps": best["GBps_128B_per_query"], "Gqueries_per_s": best["Gqueries_per_s"],
-                "source": "profiles/r2/%s" % ("gather_big.json" if index_kind == "big" else "gather_ecoli.json")}
+        return {"GBps": best["GBps_128B_per_query"], "Gqueries_per_s": best["Gqueries_per_s"], "source": src}
     except (OSError, ValueError, KeyError):
         return None
 
 
-KERNEL_ROUND = 2       # bump when bt_kernels.hip / bt_core.h change: PMC profiles of older sources no longer describe the kernel
+KERNEL_ROUND = 3       # bump when bt_kernels.hip / bt_core.h change: PMC profiles of older sources no longer describe the kernel
 
 
 def measured_traffic(kernel: str, workload: str):
@@ -361,7 +362,10 @@ def main():
     # the next step (or the closing bt_ctx_sync, inside the timed region) is.  Each context therefore alternates
     # between two sets of output arrays.
     def carry_for(n_use):
-        age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (12 if n_use < 64_000_000 else 0))
+        # default: where the backtracking tail is long (-n modes) and the step is small enough for it to matter; -v steps
+        # finish within a few hundred rounds of each other and only pay for the closing launch (big_v2_76, 50 M reads:
+        # 28.4 M reads/s with carry-over against 36 M without, profiles/r3)
+        age = 0 if args.no_carry else (args.carry if args.carry >= 0 else (12 if (n_use < 64_000_000 and wl["pol"]["mode"] == "n") else 0))
         if paired or wl["pol"].get("best") or L > 112:
             age = 0
         return min(age, 12)
@@ -500,7 +504,13 @@ def main():
         if args.dist_backend != "nccl":
             cnt5, wall_t = cnt5.cpu(), wall_t.cpu()
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt5, op=dist.ReduceOp.SUM)     # the hit-count reduce
+        mine = cnt5.clone()
+        dist.all_reduce(cnt5, op=dist.ReduceOp.SUM)     # the hit-count reduce (RCCL over xGMI with the nccl backend)
+        # the reduce checked against the per-rank counters gathered one by one
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        if not torch.equal(torch.stack(parts).sum(dim=0), cnt5):
+            raise SystemExit("bench.py: the all-reduced hit counters differ from the sum of the per-rank counters")
         wall = float(wall_t[0].item())
     c5 = [int(x) for x in cnt5.tolist()]
     aligned_all, reads_all, bad_all = float(c5[0] + c5[4]), float(c5[5]), float(c5[6])
@@ -557,7 +567,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tr["hbm_bytes_per_read"] * n * mult if tr and not args.genome else None),
-                         "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this round's source of this kernel on this workload in profiles/traffic.json (round 1 measured 217 KB/read, 1.9 x algorithmic)"),
+                         "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this round's source of this kernel on this workload in profiles/traffic.json (round 3 measured 213 KB/read on big_n2_100, an upper bound: 1.9 x algorithmic)"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
                          "carry_over_launches": carry_age, "flush_ms_total": sum(flush_ms),

@@ -247,9 +247,8 @@ int  bt_ctx_sync(bt_ctx* ctx);
  * the stream work of the n-th bt_align_batch_device call after its own is, or after bt_ctx_sync (which finishes
  * whatever is parked); the batch's input and output arrays must stay valid until then.  Reads <= 112 bases,
  * unpaired, phase-program engine; other batches are simply run to completion as before.
- * OPT-IN: carry-over launches other template instances of the search kernel; they faulted on two tiny inputs of the
- * reference's simple_tests suite until a late fix that the whole GPU suite has not yet run through.
- * Measured gain: 8.44 M against 4.3 M reads/s at 16 M reads per batch. */
+ * bowtie-amd and bench.py (steps under 64 M reads) use it by default since round 3.
+ * Measured gain: 8.44 M against 4.3 M reads/s at 16 M reads per batch (round 2). */
 int  bt_ctx_set_carry(bt_ctx* ctx, int launches);
 /* bt_align_batch_device sees the read lengths in HBM only; which build of the kernel a batch can use (reads kept
  * in LDS up to 104 / 112 bases, ebwt_search_backtrack.h:90-140's query accessors) then has to be settled on the
@@ -286,8 +285,9 @@ const char* bt_strerror(int code);
 const char* bt_version(void);
 
 /* ---- kernel-level probes (known-answer tests against the reference's Ebwt methods) -------- */
-/* rows[n] -> lf[n][4] = mapLFEx (ebwt.h:2334), L[n] = rowL (ebwt.h:1696); mirror=1 probes the
- * .rev index.  Host pointers. */
+/* rows[n] -> lf[n][4] = mapLFEx (ebwt.h:2334), L[n] = rowL (ebwt.h:1696).  mirror bit 0: probe the .rev index;
+ * bit 1: rank from the index files' 224-symbol side layout instead of the 32-byte rank blocks the search kernels
+ * query (bt_rank.h) -- the two must agree.  Host pointers. */
 int bt_probe_rank(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L);
 /* rows[n] -> joined-text offset via the SA walk of reportChaseOne (ebwt.h:2727-2746) and
  * (tidx,toff) via joinedToTextOff (ebwt.h:2569) for a query of length qlen; tidx=0xffffffff when
@@ -295,10 +295,10 @@ int bt_probe_rank(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uin
 int bt_probe_chase(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t qlen,
                    uint32_t* joined_off, uint32_t* tidx, uint32_t* toff);
 
-/* Measurement aid: the random-128-byte-gather ceiling of this GPU on this index --
- * n_blocks x 256 lanes each doing `iters` rank queries at pseudo-random rows (dependent != 0: each
- * row derived from the previous answer, as in an SA walk), timed with HIP events.
- * *gbs = queries x 128 B / time. */
+/* Measurement aid: the random-gather ceiling of this GPU on this index -- n_blocks x 256 lanes each
+ * doing `iters` rank queries at pseudo-random rows (dependent != 0: each row derived from the previous answer, as in an
+ * SA walk), timed with HIP events.  mirror bit 0: the .rev index; bit 1: gather 128-byte side pairs of the index files'
+ * layout instead of the 32-byte rank blocks the search kernels gather.  *gbs_out counts 32 (128) bytes per query. */
 int bt_bench_gather(bt_ctx* ctx, int mirror, uint32_t n_blocks, uint32_t iters, int dependent,
                     float* ms, double* gbs);
 

@@ -7,8 +7,9 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-if [ -z "${PMC_ONLY:-}${SKIP_TRACE:-}" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu > $OUT/trace.log 2>&1; fi
+if [ -z "${PMC_ONLY:-}${SKIP_TRACE:-}${PMC_TRAFFIC:-}" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu > $OUT/trace.log 2>&1; fi
 PMCGRP=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum")
+if [ -n "${PMC_TRAFFIC:-}" ]; then PMCGRP=("FETCH_SIZE" "WRITE_SIZE"); fi
 if [ -n "${PMC_ONLY:-}" ]; then PMCGRP=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS"); fi
 for grp in "${PMCGRP[@]}"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)

@@ -108,6 +108,18 @@ def test_cli_missing_index():
     assert p.returncode == 1 and "Could not locate a Bowtie index" in p.stderr.decode()
 
 
+def test_cli_two_gpus_when_the_box_has_them():
+    """--device 0,1 on a box with at least two GPUs: one index replica each, batches dealt round-robin, output in input
+    order (skipped on the one-GPU test box; the 8-GPU node runs it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    case = [c for c in CC.cases() if c["name"] == "multi_all"][0]
+    p = run(case["args"], case["index"], case["reads"], extra=["--device", "0,1", "--batch", "11"])
+    assert p.returncode == 0, p.stderr.decode(errors="replace")
+    assert p.stdout == CC.expected(case)
+
+
 def test_cli_batches_dealt_to_several_devices_keep_the_order():
     """--device takes a list: one index replica per entry, batches dealt round-robin, output in input
     order.  One GPU is all a test box has, so it is listed twice."""
