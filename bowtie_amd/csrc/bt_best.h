@@ -209,6 +209,8 @@ BF_INL void br_prep(BfLane& X, uint32_t b)
 BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32_t rdepth, uint32_t len, uint32_t cost,
                       uint32_t ham, uint32_t top, uint32_t bot, uint32_t parent, uint32_t edit, uint32_t hilo)
 {
+	/* branch records start on a 16-byte boundary: leaf_advance_branch reads one in four 16-byte pieces */
+	if (X.top & 3u) (void)bf_alloc(X, 4u - (X.top & 3u));
 	const uint32_t b = bf_alloc(X, BF_BRW);
 	AW(b + BR_ID) = id; AW(b + BR_D01) = d01; AW(b + BR_D23) = d23;
 	AW(b + BR_RDLEN) = rdepth | (len << 16); AW(b + BR_COSTHAM) = (cost & 0xffffu) | (ham << 16);
@@ -613,14 +615,25 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 	const uint32_t depth5 = AW(d + LF_D53) & 0xffffu, depth3 = AW(d + LF_D53) >> 16;
 	const uint32_t maq = X.P->maq;
 	bool found = false;
+	const bool seedEdits = (AW(d + LF_RSFLAGS) & 8u) != 0;          /* the query carries a seed's edits: fixed while the leaf advances */
 	do {
 		const uint32_t br = pm_front(X, d);
-		const uint32_t rdepth = br_rdepth(X, br), blen = br_len(X, br);
+		/* the front branch's record in one go (four independent 16-byte loads, one wait) instead of a dozen dependent
+		 * word loads spread over the step: every lane runs its own control flow here, so each load a step waits for
+		 * is a memory latency the whole wavefront sits through */
+		uint32_t R[BF_BRW];
+		{
+			const BtU4 r0 = bt_ld4((const void*)(X.A + br)), r1 = bt_ld4((const void*)(X.A + br + 4u));
+			const BtU4 r2 = bt_ld4((const void*)(X.A + br + 8u)), r3 = bt_ld4((const void*)(X.A + br + 12u));
+			R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+			R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
+		}
+		const uint32_t rdepth = R[BR_RDLEN] & 0xffffu, blen = R[BR_RDLEN] >> 16;
 		const uint32_t depth = rdepth + blen;
-		const uint32_t cost = br_cost(X, br);
-		const uint32_t nedits = br_nedits(X, br);
+		const uint32_t cost = R[BR_COSTHAM] & 0xffffu;
+		const uint32_t nedits = R[BR_EDIT] >> 16;
 		uint32_t cur = 0;
-		uint32_t top = AW(br + BR_TOP), bot = AW(br + BR_BOT);
+		uint32_t top = R[BR_TOP], bot = R[BR_BOT];
 		bool curtail = false, hit = false;
 		/* hhCheckTop (:2444-2475) */
 		if (sp.halfAndHalf && ((depth == depth5 && nedits == 0) || (depth == depth3 && nedits < sp.halfAndHalf))) {
@@ -628,14 +641,14 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 		} else {
 			cur = qlen - depth - 1u;
 			if (depth < qlen) {
-				const uint32_t c = leaf_qry(X, d, sp, cur);
+				const uint32_t c = seedEdits ? leaf_qry(X, d, sp, cur) : bf_base(X.R[sp.mate], sp.fw, !sp.mirror, cur);
 				const uint32_t q = bt_mm_penalty(maq, bf_phred(bf_qualc(X.R[sp.mate], sp.fw, !sp.mirror, cur)));
-				const uint32_t ham = br_ham(X, br);
-				const uint32_t d0 = AW(br + BR_D01) & 0xffffu;
+				const uint32_t ham = R[BR_COSTHAM] >> 16;
+				const uint32_t d0 = R[BR_D01] & 0xffffu;
 				const bool alt = depth >= d0 && ham + q <= sp.qualLim;
 				uint32_t otop = top;
 				if (c == 4u && depth > 0) top = bot = 1;
-				const uint32_t fl = AW(br + BR_FLAGS);
+				const uint32_t fl = R[BR_FLAGS];
 				uint32_t tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
 				bool ranges = false;
 				if (top == 0 && bot == 0) {
@@ -646,7 +659,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 				} else if (alt && (bot > top || c == 4u)) {
 					if (fl & BRF_LBOT) {
 						uint32_t L;
-						const uint32_t ra = AW(br + BR_LTOP), rb = AW(br + BR_LBOT);
+						const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
 						bt_rank4(ix, ra, tops, &L);
 						bt_rank4(ix, rb, bots, &L);
 						X.c_lfex++; if (ra / 448u == rb / 448u) X.c_same++;
@@ -655,7 +668,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 						X.c_lf1++;
 						if (otop != ix.zOff) {
 							uint32_t lf[4], L;
-							bt_rank4(ix, AW(br + BR_LTOP), lf, &L);
+							bt_rank4(ix, R[BR_LTOP], lf, &L);
 							otop = lf[L];
 							tops[L] = otop; bots[L] = otop + 1u;
 						}
@@ -668,11 +681,11 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 						if (top + 1u == bot) {
 							/* mapLF1(top_, ltop_, c) (ebwt.h:2494-2524) */
 							X.c_lf1++;
-							bt_rank4(ix, AW(br + BR_LTOP), lf, &L);
+							bt_rank4(ix, R[BR_LTOP], lf, &L);
 							if (L != c || top == ix.zOff) top = bot = BT_OFF_MASK;
 							else { top = lf[c]; bot = top + 1u; }
 						} else {
-							const uint32_t ra = AW(br + BR_LTOP), rb = AW(br + BR_LBOT);
+							const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
 							X.c_lf2++; if (ra / 448u == rb / 448u) X.c_same++;
 							bt_rank4(ix, ra, lf, &L); top = lf[c];
 							bt_rank4(ix, rb, lf, &L); bot = lf[c];
@@ -687,10 +700,10 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 						for (uint32_t k = 0; k < 4u; k++) if (c != k && bots[k] > tops[k]) mask &= ~(1u << k);
 					}
 					if (mask != 0xfu && depth >= d0) {
-						const uint32_t nalt = AW(br + BR_NALT);
+						const uint32_t nalt = R[BR_NALT];
 						const uint32_t rec = bf_alloc(X, BF_ALW);
 						if (nalt == 0) { AW(br + BR_ALT) = rec; X.growing = br; }
-						else if (X.growing != br || rec != AW(br + BR_ALT) + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
+						else if (X.growing != br || rec != R[BR_ALT] + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
 						if (!X.ovf) {
 							for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
 							AW(rec + 8u) = blen | (q << 16) | (mask << 24);
@@ -710,7 +723,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			if (sp.halfAndHalf) {
 				if (depth == depth5 - 1u && !empty) hhOk = nedits > 0;
 				else if (depth == depth3 - 1u && !empty) {
-					const uint32_t hilo = AW(br + BR_HILO);
+					const uint32_t hilo = R[BR_HILO];
 					hhOk = nedits >= sp.halfAndHalf && (hilo & 0xffffu) != 0 && (hilo >> 16) != 0;
 				}
 			}
@@ -718,7 +731,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			else if (hit && !invalidExact) {
 				AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
 				const uint32_t sn = (AW(d + LF_RSFLAGS) & 8u) ? (AW(d + LF_SEED) >> 16) : 0u;
-				AW(d + LF_CURCOST) = br_cost(X, br) | ((nedits + sn) << 16);
+				AW(d + LF_CURCOST) = cost | ((nedits + sn) << 16);
 				AW(d + LF_CURBR) = br;
 				found = true;
 				curtail = true;
