@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include <errno.h>
@@ -147,9 +148,9 @@ void usage(FILE* o)
 	    "  --fr/--rf/--ff     -1, -2 mates align fw/rev, rev/fw, fw/fw (default: --fr)\n"
 	    "  --pairtries <int>  max # anchors tried per pair (default: 100)\n"
 	    "  --allow-contain    one mate alignment may contain the other\n"
-	    "  --12 <f> / --interleaved <f>   pairs (or, --12, unpaired reads) from one tab-delimited / FASTQ file\n"
-	    "Not in this build: -z, --mm / --shmem, --12 / --interleaved from standard input, a --12 file that mixes\n"
-	    "  paired and unpaired records, indexes of 2^32-1 rows or more\n",
+	    "  --12 <f> / --interleaved <f>   pairs (--12: also unpaired reads, or both) from one tab-delimited / FASTQ file;\n"
+	    "                     - = standard input (spooled to a temporary file)\n"
+	    "Not in this build: -z, --mm / --shmem, indexes of 2^32-1 rows or more\n",
 	    o);
 }
 
@@ -236,17 +237,29 @@ void drop_reads_without_quals(std::string* reads, const std::string& quals)
 	*reads = kept;
 }
 
-bool tabbed_is_paired(const std::string& files, bt_read_opts rd)
+/* --12 - / --interleaved -: the two mate streams each read the input from the start, which a pipe cannot give them;
+ * standard input goes to a temporary file (removed at exit) and its name stands in */
+std::string g_spooled;
+void remove_spooled() { if (!g_spooled.empty()) unlink(g_spooled.c_str()); }
+std::string spool_stdin()
 {
-	rd.flags &= ~(uint32_t)(BT_READ_MATE1 | BT_READ_MATE2);
-	rd.skip = 0; rd.upto = 0;
-	std::string err;
-	BtReadStream* s = bt_io_open(files.c_str(), rd, &err);
-	BtHostBatch b;
-	const int rc = bt_io_next(s, 1, 1, &b, &err);
-	const bool paired = rc == BT_OK && b.n > 0 && b.n_paired > 0;
-	bt_io_close(s);
-	return paired;
+	if (!g_spooled.empty()) return g_spooled;                  /* "-" twice: one stream of bytes, one file */
+	const char* td = getenv("TMPDIR");
+	std::string path = std::string(td && *td ? td : "/tmp") + "/bowtie_amd_stdin_XXXXXX";
+	std::vector<char> buf(path.begin(), path.end()); buf.push_back(0);
+	const int fd = mkstemp(buf.data());
+	if (fd < 0) die("Error: could not create a temporary file for standard input");
+	g_spooled = buf.data();
+	atexit(remove_spooled);
+	std::vector<char> blk(1 << 20);
+	for (;;) {
+		const ssize_t n = read(0, blk.data(), blk.size());
+		if (n < 0) die("Error: reading standard input failed");
+		if (n == 0) break;
+		for (ssize_t off = 0; off < n;) { const ssize_t w = write(fd, blk.data() + off, (size_t)(n - off)); if (w <= 0) die("Error: writing %s failed", g_spooled.c_str()); off += w; }
+	}
+	close(fd);
+	return g_spooled;
 }
 
 void parse_args(int argc, char** argv, Options* O)
@@ -456,11 +469,18 @@ void parse_args(int argc, char** argv, Options* O)
 		 * or not, the reference then runs its stateful aligners (:3001-3002) */
 		if (!O->mates1.empty() || !O->mates2.empty() || (!O->tab12.empty() && !O->ileaved.empty()))
 			die("Error: --12 / --interleaved cannot be combined with -1/-2 or with each other in this build");
-		/* both mate streams open the file, and a --12 file is looked into beforehand: not possible with a pipe */
-		for (const std::string& f : split_commas(O->tab12.empty() ? O->ileaved : O->tab12))
-			if (f == "-") die("Error: --12 / --interleaved input from standard input is not in this build; give a file");
+		/* both mate streams open the file: standard input is spooled to a temporary file first */
+		{
+			std::string& spec = O->tab12.empty() ? O->ileaved : O->tab12;
+			std::string out;
+			for (const std::string& f : split_commas(spec)) {
+				if (!out.empty()) out.push_back(',');
+				out.append(f == "-" ? spool_stdin() : f);
+			}
+			spec = out;
+		}
 		if (!O->ileaved.empty()) { O->mates1 = O->mates2 = O->ileaved; O->interleaved = true; }
-		else if (tabbed_is_paired(O->tab12, O->rd)) O->mates1 = O->mates2 = O->tab12;
+		else O->mates1 = O->mates2 = O->tab12;      /* a --12 file may hold pairs, unpaired reads or both (pat.cpp:977-1127) */
 	}
 	O->paired = !O->mates1.empty() || !O->mates2.empty();
 	if (O->paired) {
@@ -475,12 +495,6 @@ void parse_args(int argc, char** argv, Options* O)
 			O->pol.pe_v1 = 1;
 			if (!O->maxbts_set) O->pol.max_bts = 800;              /* every stateful aligner: ebwt_search.cpp:185-186, 2644, 2670 */
 		}
-	} else if (one_file) {
-		/* unpaired records in a --12 file: the run is stateful all the same (:3001-3002), i.e. UnpairedAlignerV2 --
-		 * what --best selects for unpaired reads */
-		O->reads = O->tab12;
-		O->pol.best = 1;
-		if (!O->maxbts_set) O->pol.max_bts = 800;
 	} else {
 	if (pi >= pos.size()) { fprintf(stderr, "No query or output file specified!\n"); usage(stderr); exit(1); }
 	O->reads = pos[pi++];
@@ -556,6 +570,10 @@ struct Job {
 	bool last = false;
 	uint64_t seq = 0;                        /* position in the input: the writer restores this order */
 	std::string error;
+	/* a --12 batch: its unpaired records as a job of their own (searched by the unpaired stateful aligner), and how the
+	 * input interleaved pairs (1) and unpaired reads (0) */
+	std::unique_ptr<Job> unp;
+	std::vector<uint8_t> order;
 };
 
 template <class T> class Chan {
@@ -791,7 +809,6 @@ std::string search_finish(bt_ctx* ctx, const Options& O, Job* j, int rc, bool st
 
 }  // namespace
 
-const char* const mixed_msg = "Error: the --12 input mixes paired and unpaired records; this build takes them from separate files";
 
 /* the read stream(s) of the run: one for unpaired input, one per mate for pairs (for --12 / --interleaved both over
  * the same file, each keeping its mate) */
@@ -818,7 +835,8 @@ int list_input(Options& O)
 	std::string err;
 	for (;;) {
 		int r = bt_io_next(rs, O.batch_reads, O.threads, &b1, &err);
-		if (r == BT_OK && tabbed && b1.n_paired != (O.paired ? b1.n : 0u)) { err = mixed_msg; r = BT_ERR_READS; }
+		BtHostBatch bu;
+		std::vector<uint8_t> order;
 		if (r == BT_OK && O.paired) {
 			r = bt_io_next(rs2, O.batch_reads, O.threads, &b2, &err);
 			if (r == BT_OK && !bt_io_intersect_pairs(&b1, &b2)) {
@@ -826,10 +844,15 @@ int list_input(Options& O)
 				                                : "Error, fewer reads in file specified with -2 than in file specified with -1";
 				r = BT_ERR_READS;
 			}
+			if (r == BT_OK && tabbed) bt_io_split_tabbed(&b1, &b2, &bu, &order);
 		}
 		if (r != BT_OK) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-		if (b1.n == 0) break;
-		for (uint32_t i = 0; i < b1.n; i++) {
+		if (b1.n == 0 && bu.n == 0) break;
+		if (order.empty()) order.assign(b1.n, 1);
+		uint32_t ip = 0, iu = 0;
+		for (uint8_t isp : order) {
+			if (!isp) { printf("%.*s\t%u\n", (int)(bu.name_off[iu + 1] - bu.name_off[iu]), bu.names.data() + bu.name_off[iu], (unsigned)bu.len[iu]); iu++; continue; }
+			const uint32_t i = ip++;
 			printf("%.*s\t%u", (int)(b1.name_off[i + 1] - b1.name_off[i]), b1.names.data() + b1.name_off[i], (unsigned)b1.len[i]);
 			if (O.paired) printf("\t%.*s\t%u", (int)(b2.name_off[i + 1] - b2.name_off[i]), b2.names.data() + b2.name_off[i], (unsigned)b2.len[i]);
 			printf("\n");
@@ -865,7 +888,6 @@ int main(int argc, char** argv)
 		else r = bt_io_next(rs, O.batch_reads, T, j->store.get(), &err);
 		busy_read += now_s() - tb;
 		if (r != BT_OK) j->error = err;
-		else if (tabbed && j->store->n_paired != (O.paired ? j->store->n : 0u)) { j->error = mixed_msg; r = BT_ERR_READS; }
 		j->rb = j->store->view();
 		if (O.paired && r == BT_OK) {
 			j->store2.reset(new BtHostBatch());
@@ -881,6 +903,15 @@ int main(int argc, char** argv)
 				j->error = j->store->end_rdid < j->store2->end_rdid ? "Error, fewer reads in file specified with -1 than in file specified with -2"
 				                                                    : "Error, fewer reads in file specified with -2 than in file specified with -1";
 				r = BT_ERR_READS;
+			}
+			if (r == BT_OK && tabbed) {
+				/* a --12 batch: the unpaired records leave for a job of their own */
+				std::unique_ptr<Job> u(new Job());
+				u->store.reset(new BtHostBatch());
+				bt_io_split_tabbed(j->store.get(), j->store2.get(), u->store.get(), &j->order);
+				j->rb = j->store->view(); j->rb2 = j->store2->view();
+				if (u->store->n) { u->rb = u->store->view(); j->unp = std::move(u); }
+				else j->order.clear();
 			}
 		}
 		return r;
@@ -929,9 +960,19 @@ int main(int argc, char** argv)
 	const bool streamed = !O.paired && !O.pol.best && !O.no_stream;      /* --stream is the default (round 3: GPU-verified) */
 	std::vector<bt_ctx*> ctxs((size_t)(streamed ? 1 : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */
 	std::vector<bt_ctx*> redo_ctxs(streamed ? ctxs.size() : 0, nullptr);
+	/* --12 input: the file's unpaired records run the stateful unpaired aligner (ebwt_search.cpp:3001-3002,
+	 * MixedMultiAligner) -- the best-first engine without the pair machinery, on a context of its own */
+	Options OU = O;
+	OU.paired = false; OU.pol.pe_v1 = 0; OU.pol.best = 1;
+	if (!O.maxbts_set) OU.pol.max_bts = 800;
+	std::vector<bt_ctx*> unp_ctxs(O.rd.format == BT_FMT_TABBED && O.paired ? ctxs.size() : 0, nullptr);
 	for (size_t g = 0; g < ctxs.size(); g++) {
 		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+		if (!unp_ctxs.empty()) {
+			rc = bt_ctx_create(idxs[g % ND], &OU.pol, nullptr, &unp_ctxs[g]);
+			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
+		}
 		if (streamed) {
 			const char* cv = getenv("BT_CLI_CARRY");          /* diagnostics: launches a read may ride along (0 = none) */
 			if (bt_ctx_set_carry(ctxs[g], cv && *cv ? atoi(cv) : 12) != BT_OK) die("Error: bt_ctx_set_carry failed");
@@ -965,7 +1006,7 @@ int main(int argc, char** argv)
 			if (first_job) { j = std::move(first_job); r = first_rc; }        /* parsed while the index was loading */
 			else { j.reset(new Job()); r = read_job(j.get()); }
 			j->seq = seq++;
-			if (r != BT_OK || j->rb.n_reads == 0) {
+			if (r != BT_OK || (j->rb.n_reads == 0 && !j->unp)) {
 				/* the end (or an input error, reported in its place in the order): one marker per searcher */
 				j->last = true;
 				const uint64_t sq = j->seq;
@@ -999,6 +1040,83 @@ int main(int argc, char** argv)
 			if (j->last) { if (++lasts == G && held.empty()) return; continue; }
 			if (!fatal.empty()) continue;
 			const double tb = now_s();
+			if (j->unp) {
+				/* a --12 batch with unpaired records: pairs and unpaired reads were searched as two jobs; the output
+				 * follows the input, run by run of the same kind */
+				Job* const JP = j.get(); Job* const JU = j->unp.get();
+				auto name_of = [](const BtHostBatch& b, uint32_t i) { return std::string(b.names.data() + b.name_off[i], (size_t)(b.name_off[i + 1] - b.name_off[i])); };
+				auto format_run = [&](Job* J, bool pairs, uint32_t lo, uint32_t hi, std::string* text) {
+					bt_hit_batch hb = { J->hit_cap, J->hits.data(), J->n_hits.data(), J->status.data(), J->mm_pool.data(), (uint32_t)J->mm_pool.size(), J->mm_used };
+					const char* names = J->store->names.data(); const uint64_t* noff = J->store->name_off.data();
+					uint32_t at = lo;
+					while (at < hi) {
+						/* the next read of the run that was searched again with wider slots, if any */
+						const Job::Wide* w = nullptr;
+						for (auto& x : J->wide) if (x.read >= at && x.read < hi && (!w || x.read < w->read)) w = &x;
+						const uint32_t upto = w ? w->read : hi;
+						bt_out_tally tl = {0, 0, 0, 0, 0, 0};
+						if (upto > at) {
+							if (pairs) bt_io_format_pairs(J->rb, names, noff, J->rb2, J->store2->names.data(), J->store2->name_off.data(), hb, refs, O.out, at, upto, text, &tl);
+							else bt_io_format(J->rb, names, noff, hb, refs, O.out, at, upto, text, &tl);
+						}
+						if (w) {
+							Job::Wide& ww = const_cast<Job::Wide&>(*w);
+							bt_hit_batch hw = { ww.hit_cap, ww.hits.data(), &ww.n_hits, &ww.status, ww.pool.data(), (uint32_t)ww.pool.size(), 0 };
+							const bt_read_batch one1 = one_read(J->rb, ww.read);
+							const uint64_t off1[2] = { noff[ww.read], noff[ww.read + 1] };
+							if (pairs) {
+								const bt_read_batch one2 = one_read(J->rb2, ww.read);
+								const uint64_t* noff2 = J->store2->name_off.data();
+								const uint64_t off2[2] = { noff2[ww.read], noff2[ww.read + 1] };
+								bt_io_format_pairs(one1, names, off1, one2, J->store2->names.data(), off2, hw, refs, O.out, 0, 1, text, &tl);
+							} else bt_io_format(one1, names, off1, hw, refs, O.out, 0, 1, text, &tl);
+						}
+						tally.aligned += tl.aligned; tally.unaligned += tl.unaligned; tally.maxed += tl.maxed; tally.reported += tl.reported;
+						tally.sample_max |= tl.sample_max; tally.reported_paired += tl.reported_paired;
+						at = w ? w->read + 1 : hi;
+					}
+				};
+				auto total_hits = [](Job* J, uint32_t i) { for (auto& x : J->wide) if (x.read == i) return x.n_hits; return J->n_hits[i]; };
+				std::string text;
+				uint32_t ip = 0, iu = 0;
+				size_t at = 0;
+				while (at < j->order.size() && fatal.empty()) {
+					const bool pairs = j->order[at] != 0;
+					size_t end = at;
+					while (end < j->order.size() && (j->order[end] != 0) == pairs) end++;
+					const uint32_t cnt = (uint32_t)(end - at);
+					Job* J = pairs ? JP : JU;
+					uint32_t& cur = pairs ? ip : iu;
+					if (!O.quiet) for (uint32_t i = cur; i < cur + cnt; i++) {
+						if (pairs && (J->rb.len[i] < 4u || J->rb2.len[i] < 4u)) fprintf(stderr, "Warning: Skipping pair %s because a mate is less than 4 characters long\n", name_of(*J->store, i).c_str());
+						if (!pairs && J->rb.len[i] < 4u) fprintf(stderr, "Warning: Skipping read %s because it is less than 4 characters long\n", name_of(*J->store, i).c_str());
+					}
+					format_run(J, pairs, cur, cur + cnt, &text);
+					if (dumping) {
+						/* one record per read or pair, as it stood in the file (HitSink::dumpAlign / dumpUnal / dumpMaxed with
+						 * onePairFile_, hit.h:385-488); the -m ceiling counts mate alignments for pairs */
+						const uint32_t ceiling = pairs ? (O.pol.mhits == 0xffffffffu ? 0xffffffffu : O.pol.mhits * 2u) : O.pol.mhits;
+						for (uint32_t i = cur; i < cur + cnt; i++) {
+							const uint32_t tot = total_hits(J, i);
+							FILE** f; const std::string* nm;
+							if (tot == 0) { f = &f_un; nm = &O.dump_un; }
+							else if (tot > ceiling) { if (!O.dump_max.empty()) { f = &f_max; nm = &O.dump_max; } else { f = &f_un; nm = &O.dump_un; } }
+							else { f = &f_al; nm = &O.dump_al; }
+							if (nm->empty()) continue;
+							if (!*f) { *f = fopen(nm->c_str(), "wb"); if (!*f) { fatal = "Error: could not open read dump file " + *nm; abort_run.store(true); break; } }
+							const BtHostBatch& sb = *J->store;
+							fwrite(sb.raw.data() + sb.raw_off[i], 1, (size_t)(sb.raw_off[i + 1] - sb.raw_off[i]), *f);
+						}
+					}
+					cur += cnt;
+					at = end;
+				}
+				fwrite(text.data(), 1, text.size(), fout);
+				busy_write += now_s() - tb;
+				j->wide.clear();
+				spare.try_put(j->store);
+				continue;
+			}
 			const uint32_t n = j->rb.n_reads;
 			if (!O.quiet && O.paired) {
 				/* PairedBWAlignerV2::setQuery (aligner.h:1579-1588) */
@@ -1125,7 +1243,8 @@ int main(int argc, char** argv)
 				if (j->last) { to_out.put(std::move(j)); return; }
 				if (!abort_run.load()) {
 					const double tb = now_s();
-					j->error = search_job(ctxs[(size_t)g], O, j.get());
+					if (j->rb.n_reads) j->error = search_job(ctxs[(size_t)g], O, j.get());
+					if (j->unp && j->error.empty()) j->error = search_job(unp_ctxs[(size_t)g], OU, j->unp.get());
 					busy_gpu[(size_t)g] += now_s() - tb;
 				}
 				to_out.put(std::move(j));
@@ -1198,6 +1317,7 @@ int main(int argc, char** argv)
 	if (rs2) bt_io_close(rs2);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
 	for (bt_ctx* c : redo_ctxs) bt_ctx_destroy(c);
+	for (bt_ctx* c : unp_ctxs) bt_ctx_destroy(c);
 	for (bt_index* x : idxs) bt_index_free(x);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }

@@ -64,6 +64,35 @@ static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)
 	(void)np;
 }
 
+void bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order)
+{
+	order->assign(a->n, 1);
+	unp->n = 0; unp->n_paired = 0; unp->paired.clear();
+	if (a->paired.size() != a->n || a->n_paired == a->n) { a->paired.clear(); b->paired.clear(); return; }       /* pairs only */
+	std::vector<uint32_t> kp, ku;
+	for (uint32_t i = 0; i < a->n; i++) { if (a->paired[i]) kp.push_back(i); else { ku.push_back(i); (*order)[i] = 0; } }
+	/* the unpaired reads: rows of `a` as they are (names and seeds were left alone by the mate-name fix) */
+	unp->reset((uint32_t)ku.size(), a->stride);
+	unp->rdid.resize(ku.size()); unp->name_off.assign(ku.size() + 1, 0); unp->names.clear();
+	const bool has_raw = a->raw_off.size() == (size_t)a->n + 1;
+	unp->raw.clear(); unp->raw_off.clear();
+	if (has_raw) unp->raw_off.resize(ku.size() + 1);
+	for (size_t k = 0; k < ku.size(); k++) {
+		const uint32_t i = ku[k];
+		memcpy(unp->seq + k * unp->stride, a->seq + (size_t)i * a->stride, a->stride);
+		memcpy(unp->qual + k * unp->stride, a->qual + (size_t)i * a->stride, a->stride);
+		unp->len[k] = a->len[i]; unp->seed[k] = a->seed[i]; unp->rdid[k] = a->rdid[i];
+		unp->name_off[k] = unp->names.size(); unp->names.append(a->names, a->name_off[i], a->name_off[i + 1] - a->name_off[i]);
+		if (has_raw) { unp->raw_off[k] = unp->raw.size(); unp->raw.append(a->raw, a->raw_off[i], a->raw_off[i + 1] - a->raw_off[i]); }
+	}
+	unp->name_off[ku.size()] = unp->names.size();
+	if (has_raw) unp->raw_off[ku.size()] = unp->raw.size();
+	unp->first_rdid = unp->n ? unp->rdid[0] : 0; unp->end_rdid = a->end_rdid;
+	a->paired.clear(); b->paired.clear();
+	compact_batch(a, kp); compact_batch(b, kp);
+	a->n_paired = a->n; b->n_paired = b->n;
+}
+
 bool bt_io_intersect_pairs(BtHostBatch* a, BtHostBatch* b)
 {
 	const bool same_end = a->end_rdid == b->end_rdid;
@@ -876,13 +905,15 @@ static void fix_mate_names(BtHostBatch* batch, int mate, uint32_t global_seed)
 		const size_t nn = (size_t)(batch->name_off[i + 1] - batch->name_off[i]);
 		off[i] = names.size();
 		names.append(nm, nn);
+		/* an unpaired record of a --12 file stays an unpaired read: finalize(), not finalizePair() (pat.cpp:64-88) */
+		if (!batch->paired.empty() && !batch->paired[i]) continue;
 		if (nn < 2 || nm[nn - 2] != '/' || nm[nn - 1] != digit) { names.push_back('/'); names.push_back(digit); }
 	}
 	off[n] = names.size();
 	batch->names.swap(names);
 	batch->name_off.swap(off);
 	for (uint32_t i = 0; i < n; i++)
-		batch->seed[i] = rand_seed(batch->seq + (size_t)i * batch->stride, batch->qual + (size_t)i * batch->stride, batch->len[i],
+		if (batch->paired.empty() || batch->paired[i]) batch->seed[i] = rand_seed(batch->seq + (size_t)i * batch->stride, batch->qual + (size_t)i * batch->stride, batch->len[i],
 		                           batch->names.data() + batch->name_off[i], (size_t)(batch->name_off[i + 1] - batch->name_off[i]), global_seed);
 }
 
@@ -1017,7 +1048,9 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 	const uint32_t stride = (uint32_t)((maxlen + 15u) & ~(size_t)15u);
 	batch->reset(n, stride);
 	batch->n_paired = 0;
-	for (uint32_t k = 0; k < n; k++) if (parsed[keep[k]].paired) batch->n_paired++;
+	batch->paired.clear();
+	if (s->o.format == BT_FMT_TABBED) batch->paired.resize(n);
+	for (uint32_t k = 0; k < n; k++) if (parsed[keep[k]].paired) { batch->n_paired++; batch->paired[k] = 1; }
 	batch->rdid.resize(n);
 	batch->name_off.assign((size_t)n + 1, 0);
 	batch->names.clear();

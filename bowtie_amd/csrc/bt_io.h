@@ -30,6 +30,7 @@ struct BtHostBatch {
 	std::vector<uint64_t> raw_off;        /* bt_read_opts.reserved bit 1: n + 1 offsets into raw   */
 	std::string raw;                      /* each read's record as it stood in the input (Read::readOrigBuf) */
 	uint32_t n_paired = 0;                /* BT_FMT_TABBED: reads whose record had a second end    */
+	std::vector<uint8_t> paired;          /* BT_FMT_TABBED: per read, 1 = its record had a second end (empty for other formats) */
 	size_t cap_bytes = 0;
 
 	BtHostBatch() {}
@@ -51,6 +52,11 @@ void bt_io_close(BtReadStream* s);
  * fails (pat.cpp:96-127), so the batches are intersected on the read id.  Returns false if the two streams stand at
  * different read ids afterwards (one file has fewer records). */
 bool bt_io_intersect_pairs(BtHostBatch* a, BtHostBatch* b);
+/* A --12 file may hold pairs and unpaired reads (TabbedPatternSource, pat.cpp:977-1127: three fields or five).  a / b =
+ * the batches of the two mate streams over that file (same records; an unpaired record's second end is empty).  Moves
+ * the unpaired reads to `unp`, leaves the pairs in a / b, and says in `order` how the input interleaved them
+ * (1 = the next pair, 0 = the next unpaired read). */
+void bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order);
 
 struct BtRefNames {
 	std::vector<std::string> names;

@@ -125,6 +125,9 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		scr[g].rlQual = lite ? BT_RL3_SEQ_WORDS : BT_RL_SEQ_WORDS;
 	}
 	uint32_t next = 0, live = nLanes;
+	/* EMU_PARK_EVERY=<n>: every lane is parked and adopted again (carry-over) in one round out of n, at random */
+	const uint32_t parkEvery = getenv("EMU_PARK_EVERY") ? (uint32_t)atoi(getenv("EMU_PARK_EVERY")) : 0u;
+	uint32_t parkRng = 12345u;
 	while (live > 0) {
 		for (uint32_t g = 0; g < nLanes; g++) {
 			if (drained[g]) continue;
@@ -141,6 +144,15 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 			if (drained[g]) continue;
 			BT_COUNT(CN_ITERS);
 			L.iters++;
+			if (parkEvery && (parkRng = parkRng * 1664525u + 1013904223u, (parkRng >> 8) % parkEvery == 0)) {
+				/* carry-over as the kernel does it (bt_kernels.hip): the lane's state and pending request survive, what sat
+				 * in LDS does not -- the top-of-stack record and candidate cache are invalid, the read is loaded again */
+				for (uint32_t k = 0; k < BT_LDS_WORDS; k++) tos[(size_t)k * nLanes + g] = 0xdeadbeefu;
+				for (uint32_t k = 0; k < BT_RL_WORDS; k++) rlbuf[(size_t)k * nLanes + g] = 0xdeadbeefu;
+				L.tosValid = 0; L.ccValid = 0;
+				if (RL) for (uint32_t base = 0; base < L.plen; base += 16u)
+					bt_rl_store_chunk(scr[g], base, bt_ld4(in->seq + L.roff + base), bt_ld4(in->qual + L.roff + base));
+			}
 			if (req.kind == RQ_RANK) {
 				if (L.lfk == LFK_CHASE) BT_COUNT(CN_CHASE);
 				else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);

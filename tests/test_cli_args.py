@@ -32,7 +32,6 @@ def test_version_and_help():
     (["--best", "--strata", "-x", "e_coli", "cli/io.fq"], "--strata has no effect unless combined with"),
     (["--best", "-1", "a.fq,c.fq", "-2", "b.fq", "-x", "e_coli"], "must be specified with -1 and -2"),
     (["-c", "-1", "ACGTACGTAC,TTTTACGTAC", "-2", "ACGTACGTAC", "-x", "e_coli"], "must be specified with -1 and -2"),
-    (["--best", "--12", "-", "-x", "e_coli"], "standard input"),
     (["--best", "--12", "a.tab", "-1", "a.fq", "-2", "b.fq", "-x", "e_coli"], "cannot be combined"),
     (["-Q", "a.qual", "-x", "e_coli", "cli/io.fq"], "go with -f"),
     (["--pev2", "-x", "e_coli", "cli/io.fq"], "does not have"),

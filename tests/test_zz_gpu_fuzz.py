@@ -158,3 +158,65 @@ def test_binary_drops_the_pair_when_one_mate_record_does_not_parse(tmp_path):
         for args in (["-f", "-v", "1", "-X", "200"], ["-f", "-v", "0", "-X", "200", "--best", "-S"]):
             ref, got = _both(args, ["-x", base, "-1", f1, "-2", f2], ["--batch", "4"])
             _check(ref, got, (bad1, bad2, args))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_GPU_FUZZ_MIXED_SEEDS", "6"))))
+def test_binary_on_a_tabbed_file_with_pairs_and_unpaired_reads(seed, tmp_path):
+    """A --12 file may mix five-field (paired) and three-field (unpaired) records (TabbedPatternSource, pat.cpp:977-1127):
+    the reference aligns the pairs with its paired aligner (V1 without --best, V2 with it), the unpaired reads with the
+    stateful unpaired one, and writes everything in input order -- with tiny batches, -a / -k / -m, dumps and SAM."""
+    rng = random.Random(700 + seed)
+    g = "".join(rng.choice("ACGT") for _ in range(600))
+    g2 = "".join(rng.choice("ACGT") for _ in range(300))
+    base = str(tmp_path / "g")
+    EB.build_index([F.LUT[np.frombuffer(x.encode(), dtype=np.uint8)] for x in (g, g2)], ["g", "h"], base, ftab_chars=4, off_rate=2)
+    lines = []
+    for i in range(rng.randrange(6, 16)):
+        src = rng.choice((g, g2))
+        L = rng.choice([18, 24, 30])
+        p = rng.randrange(0, len(src) - 160)
+        a = list(src[p:p + L]); b = list(F._rc(src[p + 90:p + 90 + L]))
+        for s_ in (a, b):
+            for _ in range(rng.choice([0, 0, 1, 2])):
+                s_[rng.randrange(L)] = rng.choice("ACGT")
+        qa = "".join(rng.choice("!+5?IIII") for _ in range(L)); qb = "".join(rng.choice("!+5?IIII") for _ in range(L))
+        kind = rng.random()
+        if kind < 0.4:
+            lines.append("u%d\t%s\t%s" % (i, "".join(a), qa))
+        elif kind < 0.5:
+            lines.append("s%d\tACG\tIII" % i)                   # shorter than 4: skipped with a warning
+        else:
+            lines.append("p%d\t%s\t%s\t%s\t%s" % (i, "".join(a), qa, "".join(b), qb))
+    tab = str(tmp_path / "mixed.tab")
+    with open(tab, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    for _ in range(3):
+        args = rng.choice([["-v", "1"], ["-n", "2", "-l", "10"], ["-v", "2", "--best"], ["-n", "1", "-l", "8", "--best", "-k", "3"], ["-v", "0", "-a"],
+                           ["-v", "2", "-m", "1"], ["-v", "3"], ["-n", "2", "-l", "12", "-M", "1"]]) + rng.choice([["-X", "200"], ["-X", "150", "-I", "20"]]) + F.out_options(rng)
+        if not F._args_ok(args):
+            continue
+        ref, got = _both(args, ["-x", base, "--12", tab], rng.choice([[], ["--batch", "3"], ["--batch", "5", "--inflight", "1"]]))
+        _check(ref, got, (lines, args))
+
+
+@pytest.mark.parametrize("fmt", ["--12", "--interleaved"])
+def test_binary_reads_one_file_pairs_from_standard_input(fmt, tmp_path):
+    """`--12 -` / `--interleaved -`: both mate streams need the input from its start, so the binary spools standard input
+    to a temporary file; same output as the reference's on the same bytes."""
+    rng = random.Random(11)
+    g = "".join(rng.choice("ACGT") for _ in range(500))
+    base = str(tmp_path / "g")
+    EB.build_index([F.LUT[np.frombuffer(g.encode(), dtype=np.uint8)]], ["g"], base, ftab_chars=4, off_rate=2)
+    recs = []
+    for i in range(7):
+        p = rng.randrange(0, 300)
+        recs.append(("p%d" % i, g[p:p + 22], F._rc(g[p + 80:p + 102])))
+    if fmt == "--12":
+        data = "".join("%s\t%s\t%s\t%s\t%s\n" % (n, a, "I" * 22, b, "I" * 22) for n, a, b in recs)
+    else:
+        data = "".join("@%s/1\n%s\n+\n%s\n@%s/2\n%s\n+\n%s\n" % (n, a, "I" * 22, n, b, "I" * 22) for n, a, b in recs)
+    for args in (["-v", "1", "-X", "200"], ["-v", "1", "-X", "200", "--best", "-S"]):
+        ref = subprocess.run([F.REF_BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fmt, "-"], input=data.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        got = subprocess.run([BIN, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fmt, "-"], input=data.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert ref.stdout.count(b"\n") >= 10
+        _check(ref, got, (fmt, args))
