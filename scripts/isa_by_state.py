@@ -30,13 +30,13 @@ def main():
     core = open(os.path.join(CS, "bt_core.h")).read().splitlines()
     marks = []
     for i, l in enumerate(core, 1):
-        mm = re.search(r"if \(ST_IS\((ST_\w+)\)", l)
+        mm = re.search(r"if \(ST_IS(?:_NOREQ)?\((ST_\w+)\)", l)
         if mm:
             marks.append((i, mm.group(1)))
         for pat, nm in (("if (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST)", "ST_STEP_LFDONE/POST"), ("if (L.state == ST_STEP_BEGIN) {", "ST_STEP_BEGIN"),
                         ("if (L.state == ST_CHASE_CHECK) {", "ST_CHASE_CHECK"), ("if (L.state == ST_CHASE_LFDONE) {", "ST_CHASE_LFDONE"),
                         ("BT_HD void bt_lane_run(", "(bt_lane_run head)"), ("BT_HD void bt_lane_slow(", "(bt_lane_slow head)"),
-                        ("BT_HD void bt_lane_start(", "bt_lane_start"), ("BT_HD bool bt_report_hit(", "bt_report_hit"), ("BT_HD void bt_lane_finish(", "bt_lane_finish")):
+                        ("BT_HD void bt_lane_start(", "bt_lane_start"), ("BT_HD void bt_rescan_piece(", "ST_RESCAN (bt_rescan_piece)"), ("BT_HD void bt_candscan_piece(", "ST_CANDSCAN (bt_candscan_piece)"), ("BT_HD bool bt_report_hit(", "bt_report_hit"), ("BT_HD void bt_lane_finish(", "bt_lane_finish")):
             if pat in l:
                 marks.append((i, nm))
     marks.sort()

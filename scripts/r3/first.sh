@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of round 3: settles what round 2 left unmeasured.
 #   here (no GPU):   make -C bowtie_amd/csrc all variants
-#   then:            gpurun --timeout 1500 -- 'bash scripts/r3_gpu_first.sh'
+#   then:            gpurun --timeout 1500 -- 'bash scripts/r3/first.sh'
 # Everything is bounded by its own `timeout`; results under gpurun_out/r3a/ (SUMMARY.txt first).
 export TMPDIR=/tmp
 O=gpurun_out/r3a; mkdir -p $O

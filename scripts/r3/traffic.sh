@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3, second GPU call: what round 2 left unmeasured about bt_search_kernel on the hg19-scale index.
-#   gpurun --timeout 1500 -- 'bash scripts/r3_gpu_traffic.sh'
+#   gpurun --timeout 1500 -- 'bash scripts/r3/traffic.sh'
 # 1. PMC passes on a 16 M-read launch (scripts/prof.sh: FETCH_SIZE / WRITE_SIZE in their own passes, then the SQ groups),
 #    never combined with sys/hip/hsa traces -> HBM bytes per read (roofline.traffic; apply the gfx950 FETCH_SIZE correction
 #    of profiles/r1_final/calib_fetch_size.txt) and VALU/SALU instructions per wave-round.
