@@ -544,6 +544,18 @@ std::string find_index(const std::string& base)
 }
 
 double now_s() { struct timeval tv; gettimeofday(&tv, nullptr); return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec; }
+/* BT_CLI_TIMELINE=1: when each stage took up and let go of each batch, printed (seconds since the start) at the end of
+ * the run -- where the pipeline of reader, searcher and writer waits */
+struct Timeline {
+	bool on = getenv("BT_CLI_TIMELINE") != nullptr;
+	double t0 = now_s();
+	std::mutex m;
+	struct Ev { double t; const char* what; uint64_t seq; };
+	std::vector<Ev> evs;
+	void mark(const char* what, uint64_t seq) { if (!on) return; const double t = now_s() - t0; std::lock_guard<std::mutex> l(m); evs.push_back({t, what, seq}); }
+	void print() { if (!on) return; for (const Ev& e : evs) fprintf(stderr, "[timeline] %9.4f  batch %-3llu %s\n", e.t, (unsigned long long)e.seq, e.what); }
+};
+static Timeline g_tl;
 void print_timer(const char* msg, double secs)
 {
 	/* Timer::write (timer.h): hh:mm:ss */
@@ -942,6 +954,7 @@ int main(int argc, char** argv)
 	}
 	bt_index* idx = idxs[0];
 	if (O.timing) print_timer("Time loading forward and mirror index: ", now_s() - t0);
+	g_tl.mark("index loaded", 0);
 	if (O.paired) {
 		const double tr = now_s();
 		for (size_t d = 0; d < ND; d++) {
@@ -1003,8 +1016,8 @@ int main(int argc, char** argv)
 		for (;;) {
 			std::unique_ptr<Job> j;
 			int r;
-			if (first_job) { j = std::move(first_job); r = first_rc; }        /* parsed while the index was loading */
-			else { j.reset(new Job()); r = read_job(j.get()); }
+			if (first_job) { j = std::move(first_job); r = first_rc; g_tl.mark("read: parsed while the index was loading", seq); }
+			else { g_tl.mark("read: begin", seq); j.reset(new Job()); r = read_job(j.get()); g_tl.mark("read: parsed", seq); }
 			j->seq = seq++;
 			if (r != BT_OK || (j->rb.n_reads == 0 && !j->unp)) {
 				/* the end (or an input error, reported in its place in the order): one marker per searcher */
@@ -1014,7 +1027,9 @@ int main(int argc, char** argv)
 				for (int g = 1; g < G; g++) { std::unique_ptr<Job> e(new Job()); e->last = true; e->seq = sq + (uint64_t)g; to_gpu.put(std::move(e)); }
 				return;
 			}
+			const uint64_t sq = j->seq;
 			to_gpu.put(std::move(j));
+			g_tl.mark("read: handed to the searcher's queue", sq);
 		}
 	});
 
@@ -1025,6 +1040,7 @@ int main(int argc, char** argv)
 	FILE *f_al2 = nullptr, *f_un2 = nullptr, *f_max2 = nullptr;      /* pairs: the second mates' files */
 	std::thread writer([&] {
 		std::vector<std::unique_ptr<Job>> held;              /* finished out of turn */
+		std::vector<std::string> parts;                      /* formatted text, one buffer per piece of a batch */
 		uint64_t next_seq = 0; int lasts = 0;
 		for (;;) {
 			std::unique_ptr<Job> j;
@@ -1118,6 +1134,7 @@ int main(int argc, char** argv)
 				continue;
 			}
 			const uint32_t n = j->rb.n_reads;
+			g_tl.mark("write: begin", j->seq);
 			if (!O.quiet && O.paired) {
 				/* PairedBWAlignerV2::setQuery (aligner.h:1579-1588) */
 				for (uint32_t i = 0; i < n; i++) if (j->rb.len[i] < 4u || j->rb2.len[i] < 4u) {
@@ -1139,7 +1156,6 @@ int main(int argc, char** argv)
 			std::vector<uint32_t> cuts; cuts.push_back(0);
 			for (auto& w : j->wide) { cuts.push_back(w.read); cuts.push_back(w.read + 1); }
 			cuts.push_back(n);
-			std::vector<std::string> parts;
 			std::vector<bt_out_tally> tl;
 			struct Seg { uint32_t lo, hi; int wide; };
 			std::vector<Seg> segs;
@@ -1148,12 +1164,24 @@ int main(int argc, char** argv)
 				uint32_t lo = cuts[c], hi = cuts[c + 1];
 				if (lo >= hi) continue;
 				if (is_wide) { segs.push_back({lo, hi, (int)(c / 2)}); continue; }
-				/* split plain segments across the threads */
-				const uint32_t pieces = (hi - lo) >= 8192 ? (uint32_t)T : 1u;
+				/* split plain segments across the threads: several pieces each, so that the first ones are on their way to
+				 * the file while the rest are still being formatted */
+				uint32_t pieces = (hi - lo) >= 8192 ? (uint32_t)T * 4u : 1u;
+				if (pieces > 1u && pieces > (hi - lo) / 4096u) pieces = (hi - lo) / 4096u;      /* >= 2: hi - lo >= 8192 */
 				for (uint32_t p = 0; p < pieces; p++)
 					segs.push_back({lo + (uint32_t)((uint64_t)(hi - lo) * p / pieces), lo + (uint32_t)((uint64_t)(hi - lo) * (p + 1) / pieces), -1});
 			}
-			parts.resize(segs.size()); tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0, 0, 0});
+			/* the text buffers keep their memory from batch to batch */
+			if (parts.size() < segs.size()) parts.resize(segs.size());
+			tl.assign(segs.size(), bt_out_tally{0, 0, 0, 0, 0, 0});
+			{
+				const size_t per_read = (O.paired ? 2u : 1u) * (2u * (size_t)j->rb.stride + 96u) + (size_t)(noff[n] / (n ? n : 1u));
+				for (size_t si = 0; si < segs.size(); si++) {
+					parts[si].clear();
+					const size_t want = (size_t)(segs[si].hi - segs[si].lo) * per_read;
+					if (segs[si].wide < 0 && parts[si].capacity() < want) parts[si].reserve(want);
+				}
+			}
 			auto run = [&](size_t si) {
 				const Seg& sg = segs[si];
 				if (O.paired) {
@@ -1182,17 +1210,35 @@ int main(int argc, char** argv)
 				const uint64_t off[2] = { noff[w.read], noff[w.read + 1] };
 				bt_io_format(one, names, off, hw, refs, O.out, 0, 1, &parts[si], &tl[si]);
 			};
+			double t_wait = 0;                                   /* this thread waiting for a piece's text */
 			if (T > 1 && segs.size() > 1) {
+				/* pieces are formatted in order of appearance by T threads and written, in order, by this one as they finish */
 				std::vector<std::thread> th;
-				std::mutex m; size_t next = 0;
-				for (int t = 0; t < T; t++) th.emplace_back([&] { for (;;) { size_t si; { std::lock_guard<std::mutex> l(m); si = next++; } if (si >= segs.size()) return; run(si); } });
+				std::mutex m; std::condition_variable cv; size_t next = 0;
+				std::vector<char> ready(segs.size(), 0);
+				for (int t = 0; t < T; t++) th.emplace_back([&] {
+					for (;;) {
+						size_t si; { std::lock_guard<std::mutex> l(m); si = next++; }
+						if (si >= segs.size()) return;
+						run(si);
+						{ std::lock_guard<std::mutex> l(m); ready[si] = 1; }
+						cv.notify_all();
+					}
+				});
+				for (size_t si = 0; si < segs.size(); si++) {
+					const double tw = now_s();
+					{ std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return ready[si] != 0; }); }
+					t_wait += now_s() - tw;
+					fwrite(parts[si].data(), 1, parts[si].size(), fout);
+				}
 				for (auto& x : th) x.join();
-			} else for (size_t si = 0; si < segs.size(); si++) run(si);
+			} else for (size_t si = 0; si < segs.size(); si++) { run(si); fwrite(parts[si].data(), 1, parts[si].size(), fout); }
+			const double tf = now_s();
 			for (size_t si = 0; si < segs.size(); si++) {
-				fwrite(parts[si].data(), 1, parts[si].size(), fout);
 				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
 				tally.sample_max |= tl[si].sample_max; tally.reported_paired += tl[si].reported_paired;
 			}
+			if (getenv("BT_IO_PROFILE")) fprintf(stderr, "[io] batch of %u: format on %d threads + write %.3f s (%zu pieces; %.3f s of it waiting for text)\n", n, T, tf - tb, segs.size(), t_wait);
 			if (dumping) {
 				/* HitSink::dumpAlign / dumpUnal / dumpMaxed (hit.h:385-488): the read's record as it stood in
 				 * the input; files are created when the first read goes to them; without --max, reads over
@@ -1227,6 +1273,7 @@ int main(int argc, char** argv)
 				}
 			}
 			busy_write += now_s() - tb;
+			g_tl.mark("write: done", j->seq);
 			j->wide.clear();
 			spare.try_put(j->store);
 		}
@@ -1263,19 +1310,23 @@ int main(int argc, char** argv)
 				if (rc == BT_OK && !tag) return;                /* the oldest is not complete yet */
 				std::unique_ptr<Job> p = std::move(fl.front());
 				fl.pop_front();
+				g_tl.mark("search: results back", p->seq);
 				if (rc != BT_OK || tag != (void*)p.get()) p->error = std::string("Error: search failed: ") + bt_strerror(rc != BT_OK ? rc : BT_ERR_DEVICE);
 				else {
 					int st = BT_OK;
 					for (uint32_t i = 0; i < p->rb.n_reads && st == BT_OK; i++) if (p->status[i] & BT_ST_TOOSHORT) st = BT_ERR_READ_SHORT;
 					p->error = search_finish(cr, O, p.get(), st, true);
 				}
+				const uint64_t sq = p->seq;
 				to_out.put(std::move(p));
+				g_tl.mark("search: handed to the writer's queue", sq);
 			}
 		};
 		for (;;) {
 			std::unique_ptr<Job> j = to_gpu.take();
 			const double tb = now_s();
 			if (j->last || abort_run.load()) {
+				g_tl.mark("search: end of input, finishing what is parked", j->seq);
 				drain(1);
 				busy_gpu[(size_t)g] += now_s() - tb;
 				const bool end = j->last;
@@ -1284,8 +1335,11 @@ int main(int argc, char** argv)
 				continue;
 			}
 			if (fl.size() >= 10) drain(1);                     /* reads older than ten batches: finish them now */
+			g_tl.mark("search: taken", j->seq);
 			search_prepare(O, j.get());
+			g_tl.mark("search: result arrays ready", j->seq);
 			const int rc = bt_align_stream_submit(cs, &j->rb, &j->hb, j.get());
+			g_tl.mark("search: submitted (uploaded, launch enqueued)", j->seq);
 			if (rc != BT_OK) {
 				drain(1);
 				j->error = std::string("Error: search failed: ") + bt_strerror(rc);
@@ -1322,5 +1376,7 @@ int main(int argc, char** argv)
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }
 	if (O.timing) print_timer("Overall time: ", now_s() - t_all);
+	g_tl.mark("end", 0);
+	g_tl.print();
 	return 0;
 }

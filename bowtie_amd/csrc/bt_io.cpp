@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <zlib.h>
 
 #include <thread>
@@ -119,13 +120,27 @@ bt_read_batch BtHostBatch::view() const
 /* ---- the stream -------------------------------------------------------------------------- */
 struct BtRec { size_t off; uint32_t len; uint64_t rdid; };
 
+/* the file window: grows without being zero-filled (realloc moves big blocks by remapping, not by copying) */
+struct BtWindow {
+	char* p = nullptr; size_t n = 0;
+	BtWindow() {}
+	~BtWindow() { free(p); }
+	BtWindow(const BtWindow&) = delete;
+	BtWindow& operator=(const BtWindow&) = delete;
+	char* data() { return p; }
+	const char* data() const { return p; }
+	size_t size() const { return n; }
+	char& operator[](size_t i) { return p[i]; }
+	void resize(size_t m) { char* q = (char*)realloc(p, m ? m : 1); if (!q) throw std::bad_alloc(); p = q; n = m; }
+};
+
 struct BtReadStream {
 	bt_read_opts o;
 	std::vector<std::string> items;       /* file names, or the -c sequences                     */
 	size_t item = 0;
 	gzFile f = nullptr;
 	bool file_first = true;               /* nothing of the current file consumed yet            */
-	std::vector<char> buf;                /* file window                                         */
+	BtWindow buf;                         /* file window                                         */
 	size_t pos = 0, end = 0;
 	bool feof = false;
 	uint64_t file_recs = 0;               /* complete records seen in the current file           */
@@ -682,13 +697,19 @@ static uint32_t rand_seed(const uint8_t* seq, const uint8_t* qual, size_t len, c
  * above, which follows the reference's parser step by step (and produces its error messages). */
 struct FqRec { size_t off; uint32_t e[4]; uint64_t rdid; };   /* e[k]: offset of line k's '\n' from off */
 
+static double io_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static double g_io_fill_s = 0;        /* BT_IO_PROFILE: time inside gzread */
+
 static bool fq_more(BtReadStream* s)
 {
 	if (s->feof || !s->f) return false;
 	if (s->buf.size() - s->end < (16u << 20)) s->buf.resize(s->buf.size() + s->buf.size() / 2 + (32u << 20));
 	size_t room = s->buf.size() - s->end;
-	if (room > (1u << 30)) room = 1u << 30;
+	/* no further ahead than this: what a batch leaves over is moved to the front of the window by the next one */
+	if (room > (64u << 20)) room = 64u << 20;
+	const double t0 = io_now();
 	const int got = gzread(s->f, s->buf.data() + s->end, (unsigned)room);
+	g_io_fill_s += io_now() - t0;
 	if (got <= 0) { s->feof = true; return false; }
 	s->end += (size_t)got;
 	return true;
@@ -696,6 +717,8 @@ static bool fq_more(BtReadStream* s)
 
 static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
 {
+	static const bool prof = getenv("BT_IO_PROFILE") != nullptr;
+	const double tp0 = prof ? io_now() : 0; const double fill0 = g_io_fill_s;
 	/* the window keeps only what the previous batch did not use */
 	if (s->pos > 0) { memmove(s->buf.data(), s->buf.data() + s->pos, s->end - s->pos); s->end -= s->pos; s->pos = 0; }
 	std::vector<FqRec> recs;
@@ -770,6 +793,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		if (s->open_failed) { *err = "Error: could not open the remaining read file(s)"; return BT_ERR_READS; }
 		return BT_OK;
 	}
+	const double tp1 = prof ? io_now() : 0;
 	if (maxline > 1040u) maxline = 1040u;
 	const uint32_t stride = (maxline + 15u) & ~15u;
 	batch->reset((uint32_t)n, stride);
@@ -785,6 +809,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 	for (int c = 0; c < 256; c++) seqcode[c] = (isalpha(c) || c == '.') ? a2d[c == '.' ? 'N' : c] : 0xff;
 	const bt_read_opts o = s->o;
 	const char* W = s->buf.data();
+	const double tp2 = prof ? io_now() : 0;
 	auto work = [&](int t) {
 		const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
 		for (size_t i = lo; i < hi; i++) {
@@ -853,24 +878,35 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 	size_t first_err = (size_t)-1; int et = -1;
 	for (int t = 0; t < T; t++) if (err_at[(size_t)t] < first_err) { first_err = err_at[(size_t)t]; et = t; }
 	if (et >= 0) { *err = errs[(size_t)et]; batch->n = 0; return BT_ERR_READS; }
-	/* names: offsets are a running sum, so this part is sequential (and short) */
+	const double tp3 = prof ? io_now() : 0;
+	/* names: the offsets are a running sum (sequential, short); the copies are not */
 	batch->name_off.resize(n + 1);
 	uint64_t tot = 0;
-	for (size_t i = 0; i < n; i++) { batch->name_off[i] = tot; tot += name_n[i] ? name_n[i] : 20u; }
-	batch->names.resize((size_t)tot);
-	tot = 0;
 	for (size_t i = 0; i < n; i++) {
 		batch->name_off[i] = tot;
-		if (name_n[i]) { memcpy(&batch->names[(size_t)tot], W + recs[i].off + name_b[i], name_n[i]); tot += name_n[i]; }
-		else {
-			char b[24]; const int k = snprintf(b, sizeof(b), "%llu", (unsigned long long)recs[i].rdid);
-			memcpy(&batch->names[(size_t)tot], b, (size_t)k);
-			batch->seed[i] = rand_seed(batch->seq + i * stride, batch->qual + i * stride, batch->len[i], b, (size_t)k, o.seed);
-			tot += (uint64_t)k;
-		}
+		if (name_n[i]) tot += name_n[i];
+		else { char b[24]; tot += (uint64_t)snprintf(b, sizeof(b), "%llu", (unsigned long long)recs[i].rdid); }
 	}
 	batch->name_off[n] = tot;
 	batch->names.resize((size_t)tot);
+	auto copy_names = [&](int t) {
+		const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+		for (size_t i = lo; i < hi; i++) {
+			char* dst = &batch->names[(size_t)batch->name_off[i]];
+			if (name_n[i]) memcpy(dst, W + recs[i].off + name_b[i], name_n[i]);
+			else {
+				char b[24]; const int k = snprintf(b, sizeof(b), "%llu", (unsigned long long)recs[i].rdid);
+				memcpy(dst, b, (size_t)k);
+				batch->seed[i] = rand_seed(batch->seq + i * stride, batch->qual + i * stride, batch->len[i], b, (size_t)k, o.seed);
+			}
+		}
+	};
+	if (T == 1 || n < 4096) { for (int t = 0; t < T; t++) copy_names(t); }
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(copy_names, t);
+		for (auto& x : th) x.join();
+	}
 	batch->raw_off.clear(); batch->raw.clear();
 	if (o.flags & BT_READ_KEEP_RAW) {
 		/* the records themselves, for --al/--un/--max: what the reference keeps as readOrigBuf (a final
@@ -887,6 +923,8 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		}
 	}
 	batch->first_rdid = batch->rdid[0];
+	if (prof) fprintf(stderr, "[io] fastq batch of %zu: window+scan %.3f s (of which reading the file %.3f), buffers %.3f, records on %d threads %.3f, names %.3f\n",
+	                  n, tp1 - tp0, g_io_fill_s - fill0, tp2 - tp1, T, tp3 - tp2, io_now() - tp3);
 	return BT_OK;
 }
 
@@ -1108,9 +1146,14 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 /* ---- output ---------------------------------------------------------------------------------- */
 static inline void put_u(std::string* o, uint64_t v)
 {
-	char b[24]; int n = 0;
-	do { b[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
-	while (n) o->push_back(b[--n]);
+	if (v < 10u) { o->push_back((char)('0' + v)); return; }
+	char b[24]; int n = 24;
+	do { b[--n] = (char)('0' + v % 10u); v /= 10u; } while (v);
+	o->append(b + n, (size_t)(24 - n));
+}
+static inline void put_i(std::string* o, int64_t v)
+{
+	if (v < 0) { o->push_back('-'); put_u(o, (uint64_t)(-v)); } else put_u(o, (uint64_t)v);
 }
 static inline void put_ref(std::string* o, const BtRefNames& refs, uint32_t tidx, const bt_out_opts& op)
 {
@@ -1129,14 +1172,21 @@ static inline void put_qname(std::string* o, const char* nm, size_t n, bool trun
 /* the read as aligned: reverse-complemented / reversed for '-' hits (Hit::patSeq, Hit::quals) */
 static inline void put_seq(std::string* o, const uint8_t* seq, uint32_t L, bool fw)
 {
+	/* one resize, then plain stores: a push_back per character is most of a formatter thread's time */
 	static const char fwc[] = "ACGTN", rcc[] = "TGCAN";
-	if (fw) for (uint32_t i = 0; i < L; i++) o->push_back(fwc[seq[i] > 4 ? 4 : seq[i]]);
-	else for (uint32_t i = L; i-- > 0;) o->push_back(rcc[seq[i] > 4 ? 4 : seq[i]]);
+	const size_t at = o->size();
+	o->resize(at + L);
+	char* d = &(*o)[0] + at;
+	if (fw) for (uint32_t i = 0; i < L; i++) d[i] = fwc[seq[i] > 4 ? 4 : seq[i]];
+	else for (uint32_t i = 0; i < L; i++) d[i] = rcc[seq[L - 1u - i] > 4 ? 4 : seq[L - 1u - i]];
 }
 static inline void put_qual(std::string* o, const uint8_t* q, uint32_t L, bool fw)
 {
-	if (fw) o->append((const char*)q, L);
-	else for (uint32_t i = L; i-- > 0;) o->push_back((char)q[i]);
+	if (fw) { o->append((const char*)q, L); return; }
+	const size_t at = o->size();
+	o->resize(at + L);
+	char* d = &(*o)[0] + at;
+	for (uint32_t i = 0; i < L; i++) d[i] = (char)q[L - 1u - i];
 }
 
 struct MmList { uint32_t n; uint16_t e[64]; };
@@ -1191,7 +1241,7 @@ static void sam_hit(std::string* o, const char* nm, size_t nn, const uint8_t* se
 	o->push_back('\t'); put_u(o, fw ? 0u : 16u);
 	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
 	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
-	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", mapq_override >= 0 ? mapq_override : op.mapq); o->append(b); }
+	o->push_back('\t'); put_i(o, mapq_override >= 0 ? mapq_override : op.mapq);
 	o->push_back('\t'); put_u(o, L); o->append("M\t*\t0\t0\t");
 	put_seq(o, seq, L, fw);
 	o->push_back('\t');
@@ -1292,7 +1342,7 @@ static void sam_pair_hit(std::string* o, const char* nm, size_t nn, const uint8_
 	o->push_back('\t'); put_u(o, flags);
 	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
 	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
-	o->push_back('\t'); { char b[16]; snprintf(b, sizeof(b), "%d", mapq_override >= 0 ? mapq_override : op.mapq); o->append(b); }
+	o->push_back('\t'); put_i(o, mapq_override >= 0 ? mapq_override : op.mapq);
 	o->push_back('\t'); put_u(o, L); o->append("M\t=\t");
 	put_u(o, (uint64_t)mh.toff + 1u);
 	o->push_back('\t');
@@ -1300,7 +1350,7 @@ static void sam_pair_hit(std::string* o, const char* nm, size_t nn, const uint8_
 		int64_t ins;
 		if (h.toff > mh.toff) ins = -((int64_t)h.toff - (int64_t)mh.toff + (int64_t)L);
 		else ins = (int64_t)mh.toff - (int64_t)h.toff + (int64_t)mlen;
-		char b[32]; snprintf(b, sizeof(b), "%lld", (long long)ins); o->append(b);
+		put_i(o, (int64_t)ins);
 	}
 	o->push_back('\t');
 	put_seq(o, seq, L, fw);

@@ -40,3 +40,28 @@ def test_binary_suites_through_the_cpu_shim(files, shim):
     tail = p.stdout.decode(errors="replace")[-1500:]
     assert p.returncode == 0, tail
     assert " passed" in tail and " failed" not in tail, tail
+
+
+def test_formatter_pieces_reach_the_file_in_order(shim, tmp_path):
+    """The writer formats a big batch in pieces on -p threads and writes them as they finish, in order: the text is the
+    one thread's text.  The shim's SHIM_NULL_SEARCH answers (made-up alignments, no search) make a batch of tens of
+    thousands of reads cheap here."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n, L = 60000, 50
+    fq = tmp_path / "r.fq"
+    with open(fq, "wb") as f:
+        bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))]
+        quals = (rng.integers(2, 41, size=(n, L)) + 33).astype(np.uint8)
+        f.write(b"".join(b"@r%d x\n%s\n+\n%s\n" % (i, bases[i].tobytes(), quals[i].tobytes()) for i in range(n)))
+    env = dict(os.environ, LD_PRELOAD=shim, SHIM_NULL_SEARCH="1")
+    base = os.path.join(T.ROOT, "tests", "golden", "e_coli")
+    binary = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
+    for fmt in ([], ["-S"]):
+        outs = []
+        for threads, batch in ((1, 60000), (4, 60000), (3, 25000)):
+            p = subprocess.run([binary, "-p", str(threads), "--batch", str(batch)] + fmt + ["-x", base, str(fq)], env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert p.returncode == 0, p.stderr.decode(errors="replace")
+            outs.append(b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")))
+        assert len(outs[0]) > n * L and outs[0] == outs[1] == outs[2]
