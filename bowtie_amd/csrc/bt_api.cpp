@@ -1265,6 +1265,14 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 	return BT_OK;
 }
 
+extern "C" void* bt_host_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+extern "C" void bt_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 /* ---- probes ---------------------------------------------------------------------------------- */
 extern "C" int bt_probe_rank(bt_ctx* c, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L)
 {

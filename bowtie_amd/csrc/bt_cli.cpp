@@ -883,6 +883,9 @@ int main(int argc, char** argv)
 
 	/* ---- the first batch of reads is parsed while the index loads ---- */
 	BtReadStream* rs = nullptr; BtReadStream* rs2 = nullptr;
+	/* BT_CLI_PINNED=1: read batches live in page-locked memory from the library, so that bt_align_stream_submit's uploads
+	 * are DMAs beside the running search (not the default until it has been measured on the GPU) */
+	if (getenv("BT_CLI_PINNED") && atoi(getenv("BT_CLI_PINNED")) != 0) bt_io_set_allocator(bt_host_alloc, bt_host_free);
 	open_read_streams(O, &rs, &rs2);
 	const bool tabbed = O.rd.format == BT_FMT_TABBED;
 	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();

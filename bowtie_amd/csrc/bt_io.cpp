@@ -22,20 +22,37 @@
 #include <thread>
 
 /* ---- batch storage ----------------------------------------------------------------------- */
-BtHostBatch::~BtHostBatch() { free(seq); free(qual); }
+static void* default_alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255u) & ~(size_t)255u); }
+static void* (*g_alloc)(size_t) = default_alloc;
+static void (*g_dealloc)(void*) = free;
+void bt_io_set_allocator(void* (*alloc)(size_t), void (*dealloc)(void*))
+{
+	g_alloc = alloc ? alloc : default_alloc; g_dealloc = dealloc ? dealloc : free;
+}
+
+BtHostBatch::~BtHostBatch() { if (block) block_free(block); }
 
 void BtHostBatch::reset(uint32_t n_reads, uint32_t stride_bytes)
 {
 	n = n_reads; stride = stride_bytes;
-	const size_t need = ((size_t)n_reads * stride_bytes + 63u) & ~(size_t)63u;
-	if (need > cap_bytes) {
-		free(seq); free(qual);
-		cap_bytes = need + need / 4 + 64;
-		cap_bytes = (cap_bytes + 63u) & ~(size_t)63u;
-		seq = (uint8_t*)aligned_alloc(64, cap_bytes);
-		qual = (uint8_t*)aligned_alloc(64, cap_bytes);
+	const size_t need = ((size_t)n_reads * stride_bytes + 255u) & ~(size_t)255u;
+	if (need > cap_bytes || n_reads > cap_reads || !block) {
+		if (block) block_free(block);
+		block = nullptr;
+		size_t rows = need > cap_bytes ? need + need / 4 + 256 : cap_bytes;
+		rows = (rows + 255u) & ~(size_t)255u;
+		uint32_t reads = n_reads > cap_reads ? n_reads + n_reads / 4u + 64u : cap_reads;
+		const size_t lens = ((size_t)reads * 2u + 255u) & ~(size_t)255u, seeds = ((size_t)reads * 4u + 255u) & ~(size_t)255u;
+		void* (*a)(size_t) = g_alloc; void (*d)(void*) = g_dealloc;
+		void* b = a(2u * rows + lens + seeds);
+		if (!b && a != default_alloc) { a = default_alloc; d = free; b = a(2u * rows + lens + seeds); }   /* no pinned memory left: plain memory */
+		if (!b) throw std::bad_alloc();
+		block = b; block_free = d; cap_bytes = rows; cap_reads = reads;
+		seq = (uint8_t*)b; qual = seq + rows;
+		len.p = (uint16_t*)(qual + rows); seed.p = (uint32_t*)(qual + rows + lens);
 	}
-	len.assign(n_reads, 0); seed.assign(n_reads, 0);
+	len.n = n_reads; seed.n = n_reads;
+	memset(len.p, 0, (size_t)n_reads * 2u); memset(seed.p, 0, (size_t)n_reads * 4u);
 }
 
 static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)

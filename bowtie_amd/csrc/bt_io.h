@@ -14,6 +14,22 @@
 
 #include "../../include/bowtie_amd.h"
 
+/* a column of a batch: a view into the batch's one allocation (vector-like as far as the parsers need) */
+template <typename T> struct BtCol {
+	T* p = nullptr; size_t n = 0;
+	T& operator[](size_t i) { return p[i]; }
+	const T& operator[](size_t i) const { return p[i]; }
+	T* data() { return p; }
+	const T* data() const { return p; }
+	size_t size() const { return n; }
+	void resize(size_t m) { n = m; }          /* never beyond what BtHostBatch::reset sized it for */
+};
+
+/* Where batches get their memory (sequence and quality rows, lengths, seeds: what is uploaded).  Default: the C
+ * library's.  The binary can hand in the library's pinned-memory allocator (bt_host_alloc / bt_host_free), which makes the
+ * uploads of bt_align_stream_submit asynchronous.  Set before the first batch is made. */
+void bt_io_set_allocator(void* (*alloc)(size_t bytes), void (*dealloc)(void* p));
+
 /* one batch of parsed reads, laid out as bt_read_batch wants it (rows 16-byte aligned) */
 struct BtHostBatch {
 	uint32_t n = 0, stride = 16;
@@ -22,8 +38,8 @@ struct BtHostBatch {
 	                                         the ones that did not parse (and are not in the batch) included */
 	uint8_t* seq = nullptr;               /* [cap][stride] codes 0..4, rows padded with 4        */
 	uint8_t* qual = nullptr;              /* [cap][stride] Phred+33, rows padded with '!'        */
-	std::vector<uint16_t> len;
-	std::vector<uint32_t> seed;
+	BtCol<uint16_t> len;
+	BtCol<uint32_t> seed;
 	std::vector<uint64_t> rdid;           /* TReadId of each read (names default to it)          */
 	std::vector<uint64_t> name_off;       /* n + 1 offsets into names                            */
 	std::string names;
@@ -31,7 +47,10 @@ struct BtHostBatch {
 	std::string raw;                      /* each read's record as it stood in the input (Read::readOrigBuf) */
 	uint32_t n_paired = 0;                /* BT_FMT_TABBED: reads whose record had a second end    */
 	std::vector<uint8_t> paired;          /* BT_FMT_TABBED: per read, 1 = its record had a second end (empty for other formats) */
-	size_t cap_bytes = 0;
+	size_t cap_bytes = 0;                 /* bytes of each of seq / qual inside `block` */
+	uint32_t cap_reads = 0;               /* reads len / seed have room for                      */
+	void* block = nullptr;                /* the one allocation: seq | qual | len | seed         */
+	void (*block_free)(void*) = nullptr;  /* what releases it (the allocator it came from)       */
 
 	BtHostBatch() {}
 	~BtHostBatch();

@@ -236,6 +236,12 @@ int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_
  * threads. */
 int  bt_align_stream_submit(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, void* tag);
 int  bt_align_stream_collect(bt_ctx* ctx, void** tag, int flush);
+/* Page-locked host memory for the arrays of a bt_read_batch handed to bt_align_stream_submit: from such memory the
+ * upload is a DMA the call does not wait for (from ordinary memory the runtime stages it and the call returns when it
+ * is done).  NULL when there is none to be had; ordinary memory works everywhere.  (A reader thread's parse buffers:
+ * the reference's PatternSourcePerThread owns the equivalent, pat.h:163-201.) */
+void* bt_host_alloc(size_t bytes);
+void  bt_host_free(void* p);
 int  bt_ctx_sync(bt_ctx* ctx);
 /* Carry-over between the batches of a context (what the reference's worker threads get for free: a thread that
  * finishes its read takes the next one, whatever "batch" it came from -- ebwt_search.cpp:1180-1230's GET_READ loop).

@@ -130,6 +130,8 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 	if (rc != BT_OK) return rc;
 	return worst_status(out, in1->n_reads);
 }
+extern "C" void* bt_host_alloc(size_t bytes) { return bytes ? aligned_alloc(256, (bytes + 255u) & ~(size_t)255u) : nullptr; }
+extern "C" void bt_host_free(void* p) { free(p); }
 /* --stream: the asynchronous entry points, answered synchronously -- a submitted batch is searched at once and is the next
  * one collected; reads come back flagged rather than as an error code, as from the library's stream */
 extern "C" int bt_ctx_set_carry(bt_ctx* c, int launches) { return c && launches >= 0 && launches <= 14 ? BT_OK : BT_ERR_ARG; }

@@ -26,12 +26,16 @@ def shim():
 
 
 @pytest.mark.parametrize("files", [["tests/test_gpu_cli.py"], ["tests/test_simple_cases.py"], ["tests/test_zz_gpu_fuzz.py"],
-                                   ["tests/test_gpu_cli.py", "--no-stream"], ["tests/test_simple_cases.py", "-k", "test_simple_case_bowtie_amd", "--no-stream"]],
-                         ids=lambda x: x[0][6:-3] + ("_no_stream" if x[-1] == "--no-stream" else ""))
+                                   ["tests/test_gpu_cli.py", "--no-stream"], ["tests/test_simple_cases.py", "-k", "test_simple_case_bowtie_amd", "--no-stream"],
+                                   ["tests/test_gpu_cli.py", "pinned"]],
+                         ids=lambda x: x[0][6:-3] + ("_no_stream" if x[-1] == "--no-stream" else "_pinned_batches" if x[-1] == "pinned" else ""))
 def test_binary_suites_through_the_cpu_shim(files, shim):
     """The binary streams unpaired default-engine batches by default (the shim answers the asynchronous entry points
     synchronously); the --no-stream runs put the same cases through the whole-batch search loop."""
     env = dict(os.environ, BT_TEST_CLI_SHIM="1", LD_PRELOAD=shim, BT_GPU_FUZZ_SEEDS="12")
+    if files[-1] == "pinned":                       # BT_CLI_PINNED: the read batches come from the library's bt_host_alloc
+        files = files[:-1]
+        env["BT_CLI_PINNED"] = "1"
     if files[-1] == "--no-stream":
         files = files[:-1]
         env["BT_TEST_CLI_EXTRA"] = "--no-stream"
