@@ -44,8 +44,9 @@ void BtHostBatch::reset(uint32_t n_reads, uint32_t stride_bytes)
 		uint32_t reads = n_reads > cap_reads ? n_reads + n_reads / 4u + 64u : cap_reads;
 		const size_t lens = ((size_t)reads * 2u + 255u) & ~(size_t)255u, seeds = ((size_t)reads * 4u + 255u) & ~(size_t)255u;
 		void* (*a)(size_t) = g_alloc; void (*d)(void*) = g_dealloc;
-		void* b = a(2u * rows + lens + seeds);
-		if (!b && a != default_alloc) { a = default_alloc; d = free; b = a(2u * rows + lens + seeds); }   /* no pinned memory left: plain memory */
+		const size_t total = 2u * rows + lens + seeds + 256u;          /* never an empty request */
+		void* b = a(total);
+		if (!b && a != default_alloc) { a = default_alloc; d = free; b = a(total); }   /* no pinned memory left: plain memory */
 		if (!b) throw std::bad_alloc();
 		block = b; block_free = d; cap_bytes = rows; cap_reads = reads;
 		seq = (uint8_t*)b; qual = seq + rows;
