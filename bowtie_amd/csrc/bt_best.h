@@ -50,6 +50,11 @@
 /* PairedBWAlignerV1 (bf_run_pair_v1, the reference's default paired-end aligner): part of every build since round 3
  * (GPU-verified against the 120 reference outputs of tests/golden/pe_v1) */
 #define BF_HAVE_V1 1
+/* 1: leaf_advance_branch keeps a branch it is simply extending in registers from step to step (see there).  Off in the
+ * shipped build until it has run on a GPU: the host build of the engine is bit-identical either way (tests/emu). */
+#ifndef BF_FAST_EXTEND
+#define BF_FAST_EXTEND 0
+#endif
 #define BF_IS_V1(P) ((P).paired == 2u)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
@@ -616,7 +621,32 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 	const uint32_t maq = X.P->maq;
 	bool found = false;
 	const bool seedEdits = (AW(d + LF_RSFLAGS) & 8u) != 0;          /* the query carries a seed's edits: fixed while the leaf advances */
+#if BF_FAST_EXTEND
+	/* A branch that is simply extended -- no alternative taken, nothing curtailed -- stays the queue's front with its
+	 * cost (the queue is not touched, and PathManager::splitAndPrep on such a front only preps it): the next step then
+	 * goes on from the record in registers, prepped in place, instead of reading the queue, the front's flags and cost
+	 * and the record again (six dependent waits a base); and its base and quality were fetched beside this step's
+	 * rank loads.  What the arena holds afterwards is what the long way round writes. */
+	bool reuse = false, havePf = false;
+	uint32_t pfC = 0, pfQ = 0;
+	uint32_t seedN = 0, seedM[3] = {0, 0, 0};
+	if (seedEdits) { seedN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) seedM[k] = AW(d + LF_SEEDMM0 + k); }
+	uint32_t br = 0;
+	uint32_t R[BF_BRW];
+#endif
 	do {
+#if BF_FAST_EXTEND
+		if (!reuse) {
+			br = pm_front(X, d);
+			const BtU4 r0 = bt_ld4((const void*)(X.A + br)), r1 = bt_ld4((const void*)(X.A + br + 4u));
+			const BtU4 r2 = bt_ld4((const void*)(X.A + br + 8u)), r3 = bt_ld4((const void*)(X.A + br + 12u));
+			R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+			R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
+			havePf = false;
+		}
+		reuse = false;
+		bool extended = false;
+#else
 		const uint32_t br = pm_front(X, d);
 		/* the front branch's record in one go (four independent 16-byte loads, one wait) instead of a dozen dependent
 		 * word loads spread over the step: every lane runs its own control flow here, so each load a step waits for
@@ -628,6 +658,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
 			R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
 		}
+#endif
 		const uint32_t rdepth = R[BR_RDLEN] & 0xffffu, blen = R[BR_RDLEN] >> 16;
 		const uint32_t depth = rdepth + blen;
 		const uint32_t cost = R[BR_COSTHAM] & 0xffffu;
@@ -641,8 +672,20 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 		} else {
 			cur = qlen - depth - 1u;
 			if (depth < qlen) {
+#if BF_FAST_EXTEND
+				uint32_t c = havePf ? pfC : bf_base(X.R[sp.mate], sp.fw, !sp.mirror, cur);
+				if (seedEdits) {
+					const uint32_t full = X.R[sp.mate].len;                    /* leaf_qry's overrides, from registers */
+					for (uint32_t k = 0; k < 3u; k++) if (k < seedN && full - (seedM[k] & 0xffffu) - 1u == cur) c = seedM[k] >> 16;
+				}
+				const uint32_t q = bt_mm_penalty(maq, bf_phred(havePf ? pfQ : bf_qualc(X.R[sp.mate], sp.fw, !sp.mirror, cur)));
+				/* the next position's base and quality, in flight beside this step's rank loads */
+				havePf = cur > 0;
+				if (havePf) { pfC = bf_base(X.R[sp.mate], sp.fw, !sp.mirror, cur - 1u); pfQ = bf_qualc(X.R[sp.mate], sp.fw, !sp.mirror, cur - 1u); }
+#else
 				const uint32_t c = seedEdits ? leaf_qry(X, d, sp, cur) : bf_base(X.R[sp.mate], sp.fw, !sp.mirror, cur);
 				const uint32_t q = bt_mm_penalty(maq, bf_phred(bf_qualc(X.R[sp.mate], sp.fw, !sp.mirror, cur)));
+#endif
 				const uint32_t ham = R[BR_COSTHAM] >> 16;
 				const uint32_t d0 = R[BR_D01] & 0xffffu;
 				const bool alt = depth >= d0 && ham + q <= sp.qualLim;
@@ -708,6 +751,10 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 							for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
 							AW(rec + 8u) = blen | (q << 16) | (mask << 24);
 							AW(br + BR_NALT) = nalt + 1u;
+#if BF_FAST_EXTEND
+							if (nalt == 0) R[BR_ALT] = rec;
+							R[BR_NALT] = nalt + 1u;
+#endif
 						}
 					}
 				}
@@ -736,10 +783,28 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 				found = true;
 				curtail = true;
 			} else if (empty || cur == 0) curtail = true;
+#if BF_FAST_EXTEND
+			else { R[BR_RDLEN] = rdepth | ((blen + 1u) << 16); AW(br + BR_RDLEN) = R[BR_RDLEN]; extended = true; }   /* Branch::extend */
+#else
 			else AW(br + BR_RDLEN) = rdepth | ((blen + 1u) << 16);        /* Branch::extend */
+#endif
 		}
 		if (curtail) pm_curtail(X, d, br, depth3);
 		if (X.ovf) break;
+#if BF_FAST_EXTEND
+		if (extended && (R[BR_FLAGS] & (BRF_DELAYED | BRF_CURTAILED)) == 0) {
+			/* splitAndPrep on an untouched queue whose front is this branch: the backtrack budget's check, then prep */
+			if (sp.useBtCnt != 0 && X.btCnt == 0) { pm_reset(X, d); break; }
+			uint32_t f = R[BR_FLAGS];
+			if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; R[BR_LTOP] = top; R[BR_LBOT] = bot; AW(br + BR_LTOP) = top; AW(br + BR_LBOT) = bot; }
+			else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; AW(br + BR_LTOP) = top; }
+			R[BR_FLAGS] = f; AW(br + BR_FLAGS) = f;
+			R[BR_TOP] = top; R[BR_BOT] = bot;
+			reuse = true;
+			continue;
+		}
+		havePf = false;
+#endif
 		if (!pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0)) pm_reset(X, d);
 		if (X.ovf) break;
 		if (pm_size(X, d) == 0) break;

@@ -44,7 +44,8 @@ def main():
     p = subprocess.run(ours, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     out["bowtie_amd_s"] = time.perf_counter() - t0
     out["bowtie_amd_reads_per_s"] = a.reads / out["bowtie_amd_s"]
-    out["bowtie_amd_stderr"] = p.stderr.decode(errors="replace").strip().split("\n")[-8:]
+    lines = p.stderr.decode(errors="replace").strip().split("\n")
+    out["bowtie_amd_stderr"] = lines if os.environ.get("BT_CLI_TIMELINE") else lines[-8:]       # the timeline comes after the summary
     ref = os.path.join(ROOT, "oracle", "_ref", "bowtie-align-s")
     if os.path.exists(ref) and not a.no_ref:
         cores = os.cpu_count() or 1

@@ -15,18 +15,22 @@ from bowtie_amd.reads import ReadBatch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
-LIB_PATH = os.path.join(EMU_DIR, "libbt_emu.so")
+# BT_EMU_DEFINES="-DBF_FAST_EXTEND=1": the host build with an experiment's compile-time switch on, in a library of its own
+DEFS = os.environ.get("BT_EMU_DEFINES", "").split()
+_SUFFIX = "" if not DEFS else "_" + "".join(ch if ch.isalnum() else "_" for ch in "".join(DEFS))
+LIB_PATH = os.path.join(EMU_DIR, "libbt_emu%s.so" % _SUFFIX)
 SRCS = [os.path.join(EMU_DIR, "bt_emu.cpp")] + [os.path.join(ROOT, "bowtie_amd", "csrc", f) for f in
                                                 ("bt_host.cpp", "bt_host.h", "bt_core.h", "bt_rank.h", "bt_best.h")]
 _lib = None
 
 
 def build():
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", LIB_PATH,
-                           SRCS[0], SRCS[1]])
+    tmp = LIB_PATH + ".tmp%d" % os.getpid()
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w"] + DEFS + ["-o", tmp, SRCS[0], SRCS[1]])
+    os.replace(tmp, LIB_PATH)
 
 
-SHIM_PATH = os.path.join(EMU_DIR, "libcli_shim.so")
+SHIM_PATH = os.path.join(EMU_DIR, "libcli_shim%s.so" % _SUFFIX)
 SHIM_SRCS = [os.path.join(EMU_DIR, "cli_shim.cpp"), os.path.join(EMU_DIR, "bt_emu.cpp")] + SRCS[1:]
 
 
@@ -36,7 +40,7 @@ def shim():
     that xdist workers never race on the file."""
     if not os.path.exists(SHIM_PATH) or any(os.path.getmtime(SHIM_PATH) < os.path.getmtime(s) for s in SHIM_SRCS):
         tmp = SHIM_PATH + ".tmp%d" % os.getpid()
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include"), "-o", tmp,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w"] + DEFS + ["-I" + os.path.join(ROOT, "include"), "-o", tmp,
                                SHIM_SRCS[0], SHIM_SRCS[2]])
         os.replace(tmp, SHIM_PATH)
     return SHIM_PATH
