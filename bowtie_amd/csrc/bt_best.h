@@ -155,6 +155,10 @@ struct BfLane {                   /* per-lane registers / private memory */
 	const BfProgram* P;
 	const BtRefDev* ref;          /* paired-end only                                              */
 	BfRead R[2];                  /* the read / the two mates                                     */
+#if BF_FAST_EXTEND
+	uint32_t hasN;                /* bit m: mate m holds an N (found once, at bf_read_begin)      */
+	uint32_t pm[6];               /* the leaf's PathManager words LF_HEAP..LF_RND while leaf_set_query / leaf_advance run (pm_enter / pm_leave) */
+#endif
 	uint32_t rd;
 	int32_t  btCnt;
 	uint32_t alRnd;
@@ -173,6 +177,20 @@ BF_INL uint32_t bf_rnd(uint32_t& last)                       /* RandomSource::ne
 	return ret ^ last;
 }
 BF_INL uint32_t bf_rnd_at(BfLane& X, uint32_t off) { uint32_t s = AW(off); uint32_t r = bf_rnd(s); AW(off) = s; return r; }
+/* The six PathManager words of a leaf (queue base, size | capacity, branch-pool cursors, queue cost, generator) are read
+ * at the head of nearly every dependent chain of loads in the leaf's code.  BF_FAST_EXTEND: they live in the lane for
+ * the duration of leaf_set_query / leaf_advance (pm_enter loads them, pm_leave stores them; nothing else runs between). */
+#if BF_FAST_EXTEND
+#define PMW(w) (X.pm[(w) - LF_HEAP])
+#define PM_RND(X, d) bf_rnd(X.pm[LF_RND - LF_HEAP])
+BF_INL void pm_enter(BfLane& X, uint32_t d) { for (uint32_t k = 0; k < 6u; k++) X.pm[k] = AW(d + LF_HEAP + k); }
+BF_INL void pm_leave(BfLane& X, uint32_t d) { for (uint32_t k = 0; k < 6u; k++) AW(d + LF_HEAP + k) = X.pm[k]; }
+#else
+#define PMW(w) AW(d + (w))
+#define PM_RND(X, d) bf_rnd_at(X, (d) + LF_RND)
+#define pm_enter(X, d) ((void)0)
+#define pm_leave(X, d) ((void)0)
+#endif
 
 BF_INL uint32_t bf_alloc(BfLane& X, uint32_t n)
 {
@@ -217,6 +235,22 @@ BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32
 	/* branch records start on a 16-byte boundary: leaf_advance_branch reads one in four 16-byte pieces */
 	if (X.top & 3u) (void)bf_alloc(X, 4u - (X.top & 3u));
 	const uint32_t b = bf_alloc(X, BF_BRW);
+#if BF_FAST_EXTEND
+	/* the record in four 16-byte stores, prepped from the values at hand (br_prep reads back what was just stored) */
+	{
+		uint32_t f = 0, lt = 0, lb = 0;
+		if (bot > top + 1u) { f = BRF_LTOP | BRF_LBOT; lt = top; lb = bot; }
+		else if (bot > top) { f = BRF_LTOP; lt = top; }
+		BtU4 q0, q1, q2, q3;
+		q0.x = id; q0.y = d01; q0.z = d23; q0.w = rdepth | (len << 16);
+		q1.x = (cost & 0xffffu) | (ham << 16); q1.y = top; q1.z = bot; q1.w = f;
+		q2.x = lt; q2.y = lb; q2.z = 0; q2.w = 0;
+		q3.x = parent; q3.y = edit; q3.z = hilo; q3.w = 0;
+		bt_st4((void*)(X.A + b), q0); bt_st4((void*)(X.A + b + 4u), q1); bt_st4((void*)(X.A + b + 8u), q2); bt_st4((void*)(X.A + b + 12u), q3);
+	}
+	X.c_frames++;
+	return b;
+#endif
 	AW(b + BR_ID) = id; AW(b + BR_D01) = d01; AW(b + BR_D23) = d23;
 	AW(b + BR_RDLEN) = rdepth | (len << 16); AW(b + BR_COSTHAM) = (cost & 0xffffu) | (ham << 16);
 	AW(b + BR_TOP) = top; AW(b + BR_BOT) = bot; AW(b + BR_FLAGS) = 0;
@@ -273,14 +307,14 @@ BF_FN bool bf_before(BfLane& X, uint32_t a, uint32_t b)        /* CostCompare()(
 
 BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)          /* PathManager::push (range_source.h:1361-1372) */
 {
-	uint32_t heap = AW(d + LF_HEAP), sz = AW(d + LF_HEAPSZ) & 0xffffu, cap = AW(d + LF_HEAPSZ) >> 16;
+	uint32_t heap = PMW(LF_HEAP), sz = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
 	if (sz == cap) {
 		const uint32_t ncap = cap ? cap * 2u : 8u;
 		if (ncap > 0xffffu) { X.ovf = 1; return; }
 		const uint32_t nh = bf_alloc(X, ncap);
 		if (X.ovf) return;
 		for (uint32_t k = 0; k < sz; k++) AW(nh + k) = AW(heap + k);
-		heap = nh; cap = ncap; AW(d + LF_HEAP) = heap;
+		heap = nh; cap = ncap; PMW(LF_HEAP) = heap;
 	}
 	uint32_t hole = sz;
 	while (hole > 0) {
@@ -289,15 +323,15 @@ BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)          /* PathManager::p
 		AW(heap + hole) = pv; hole = parent;
 	}
 	AW(heap + hole) = v;
-	AW(d + LF_HEAPSZ) = (sz + 1u) | (cap << 16);
-	AW(d + LF_PMCOST) = br_cost(X, AW(heap));
+	PMW(LF_HEAPSZ) = (sz + 1u) | (cap << 16);
+	PMW(LF_PMCOST) = br_cost(X, AW(heap));
 }
 
 /* PathManager::pop (range_source.h:1337-1356).  minCost is read from the queue's front even when
  * the queue has just become empty: vector::front() then still sees the element just removed. */
 BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 {
-	const uint32_t heap = AW(d + LF_HEAP), n = AW(d + LF_HEAPSZ) & 0xffffu, cap = AW(d + LF_HEAPSZ) >> 16;
+	const uint32_t heap = PMW(LF_HEAP), n = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
 	const uint32_t top = AW(heap);
 	if (n > 1u) {
 		const uint32_t value = AW(heap + n - 1u);
@@ -320,41 +354,41 @@ BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 		}
 		AW(heap + hole) = value;
 	}
-	AW(d + LF_HEAPSZ) = (n - 1u) | (cap << 16);
-	AW(d + LF_PMCOST) = br_cost(X, n > 1u ? AW(heap) : top);
+	PMW(LF_HEAPSZ) = (n - 1u) | (cap << 16);
+	PMW(LF_PMCOST) = br_cost(X, n > 1u ? AW(heap) : top);
 	return top;
 }
 
-BF_INL uint32_t pm_size(BfLane& X, uint32_t d) { return AW(d + LF_HEAPSZ) & 0xffffu; }
-BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return AW(AW(d + LF_HEAP)); }
+BF_INL uint32_t pm_size(BfLane& X, uint32_t d) { return PMW(LF_HEAPSZ) & 0xffffu; }
+BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return AW(PMW(LF_HEAP)); }
 BF_INL void pm_reset(BfLane& X, uint32_t d)                    /* PathManager::reset (range_source.h:1386-1399) */
 {
-	AW(d + LF_HEAPSZ) &= 0xffff0000u; AW(d + LF_BP) = 0; AW(d + LF_BPLAST) = 0; AW(d + LF_PMCOST) = 0;
+	PMW(LF_HEAPSZ) &= 0xffff0000u; PMW(LF_BP) = 0; PMW(LF_BPLAST) = 0; PMW(LF_PMCOST) = 0;
 }
 
 /* AllocOnlyPool<Branch>::alloc + lastId (pool.h:216-223, 320-322, 335-352) */
 BF_FN uint32_t pm_alloc_id(BfLane& X, uint32_t d)
 {
-	uint32_t cur = AW(d + LF_BP) & 0xffffu, pool = AW(d + LF_BP) >> 16;
+	uint32_t cur = PMW(LF_BP) & 0xffffu, pool = PMW(LF_BP) >> 16;
 	if (cur + 1u >= BF_BPOOL_LIM(X)) {
 		if (pool >= 2u) { X.ovf = 1; return 0; }
-		uint32_t last = AW(d + LF_BPLAST);
+		uint32_t last = PMW(LF_BPLAST);
 		last = pool == 0 ? ((last & 0xffff0000u) | cur) : ((last & 0xffffu) | (cur << 16));
-		AW(d + LF_BPLAST) = last;
+		PMW(LF_BPLAST) = last;
 		pool++; cur = 0;
 	}
 	cur++;
-	AW(d + LF_BP) = cur | (pool << 16);
+	PMW(LF_BP) = cur | (pool << 16);
 	return (pool << 16) | cur;
 }
 /* AllocOnlyPool<Branch>::free(T*) (pool.h:279-292): only the topmost element's id is given back */
 BF_FN void pm_free_id(BfLane& X, uint32_t d, uint32_t id)
 {
-	uint32_t cur = AW(d + LF_BP) & 0xffffu, pool = AW(d + LF_BP) >> 16;
+	uint32_t cur = PMW(LF_BP) & 0xffffu, pool = PMW(LF_BP) >> 16;
 	if (cur > 0 && id == ((pool << 16) | cur)) {
 		cur--;
-		if (cur == 0 && pool > 0) { pool--; const uint32_t last = AW(d + LF_BPLAST); cur = pool == 0 ? (last & 0xffffu) : (last >> 16); }
-		AW(d + LF_BP) = cur | (pool << 16);
+		if (cur == 0 && pool > 0) { pool--; const uint32_t last = PMW(LF_BPLAST); cur = pool == 0 ? (last & 0xffffu) : (last >> 16); }
+		PMW(LF_BP) = cur | (pool << 16);
 	}
 }
 
@@ -367,6 +401,104 @@ BF_FN void pm_curtail(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen)
 	else if (br_cost(X, br) != orig) { const uint32_t p = pm_pop(X, d); pm_push(X, d, p); }
 }
 
+#if BF_FAST_EXTEND
+/* pm_curtail + br_curtail for the branch whose record leaf_advance_branch holds in registers (R == what the arena has):
+ * only the alternatives' info words are fetched */
+BF_FN void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen, const uint32_t* R)
+{
+	const uint32_t alt = R[BR_ALT], n = R[BR_NALT], rdepth = R[BR_RDLEN] & 0xffffu;
+	uint32_t lowest = 0xffffu;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t info = AW(alt + k * BF_ALW + 8u);
+		if (info >> 28) continue;
+		const uint32_t c = alt_cost(info, rdepth, seedLen);
+		if (c < lowest) lowest = c;
+	}
+	uint32_t f = R[BR_FLAGS];
+	const uint32_t orig = R[BR_COSTHAM] & 0xffffu;
+	uint32_t ncost = orig;
+	if (lowest > 0 && lowest != 0xffffu) { ncost = (orig + lowest) & 0xffffu; AW(br + BR_COSTHAM) = (R[BR_COSTHAM] & 0xffff0000u) | ncost; }
+	else if (lowest == 0xffffu) f |= BRF_EXHAUSTED;
+	f |= BRF_CURTAILED;
+	AW(br + BR_FLAGS) = f;
+	if (X.growing == br) X.growing = 0;
+	if (f & BRF_EXHAUSTED) { pm_pop(X, d); pm_free_id(X, d, R[BR_ID]); }
+	else if (ncost != orig) { const uint32_t p = pm_pop(X, d); pm_push(X, d, p); }
+}
+
+/* br_split with the branch's record and the chosen alternative's ranges fetched in one go each */
+BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uint32_t depth5)
+{
+	const uint32_t id = pm_alloc_id(X, d);
+	uint32_t P[BF_BRW];
+	{
+		const BtU4 r0 = bt_ld4((const void*)(X.A + b)), r1 = bt_ld4((const void*)(X.A + b + 4u));
+		const BtU4 r2 = bt_ld4((const void*)(X.A + b + 8u)), r3 = bt_ld4((const void*)(X.A + b + 12u));
+		P[0] = r0.x; P[1] = r0.y; P[2] = r0.z; P[3] = r0.w; P[4] = r1.x; P[5] = r1.y; P[6] = r1.z; P[7] = r1.w;
+		P[8] = r2.x; P[9] = r2.y; P[10] = r2.z; P[11] = r2.w; P[12] = r3.x; P[13] = r3.y; P[14] = r3.z; P[15] = r3.w;
+	}
+	const uint32_t alt = P[BR_ALT], n = P[BR_NALT], rdepth = P[BR_RDLEN] & 0xffffu;
+	uint32_t tied[3] = {0, 0, 0}, numTied = 0, numNotElim = 0, best = 0xffffu, next = 0xffffu;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t info = AW(alt + k * BF_ALW + 8u);
+		if (info >> 28) continue;
+		numNotElim++;
+		const uint32_t c = alt_cost(info, rdepth, seedLen);
+		if (c < best) { next = best; best = c; numTied = 1; tied[0] = k; }
+		else if (c == best) {
+			if (numTied < 3u) tied[numTied++] = k;
+			else { tied[0] = tied[1]; tied[1] = tied[2]; tied[2] = k; }
+		} else if (c < next) next = c;
+	}
+	uint32_t r = 0;
+	if (numTied > 1u) r = PM_RND(X, d) % numTied;
+	const uint32_t rec = alt + tied[r] * BF_ALW;
+	uint32_t W[9];
+	for (uint32_t k = 0; k < 9u; k++) W[k] = AW(rec + k);
+	uint32_t info = W[8];
+	const uint32_t pos = info & 0xffffu;
+	uint32_t mask = (info >> 24) & 0xfu;
+	const uint32_t num = 4u - (uint32_t)__builtin_popcount(mask);
+	uint32_t chr = 0, last = 0;
+	if (num > 1u) {
+		uint32_t tot = 0;
+		for (uint32_t c = 0; c < 4u; c++) if (!((mask >> c) & 1u)) tot += W[4u + c] - W[c];
+		uint32_t dart = PM_RND(X, d) % tot;
+		for (uint32_t c = 0; c < 4u; c++) {
+			if ((mask >> c) & 1u) continue;
+			const uint32_t w = W[4u + c] - W[c];
+			chr = c;
+			if (c == 3u || dart < w) break;
+			dart -= w;
+		}
+		mask |= 1u << chr;
+		info = (info & ~(0xfu << 24)) | (mask << 24);
+	} else {
+		last = 1;
+		chr = !(mask & 1u) ? 0u : !(mask & 2u) ? 1u : !(mask & 4u) ? 2u : 3u;
+		info |= 1u << 28;
+	}
+	AW(rec + 8u) = info;
+	const uint32_t top = W[chr], bot = W[4u + chr];
+	const uint32_t depth = pos + rdepth;
+	const uint32_t d01 = P[BR_D01], d23 = P[BR_D23];
+	const uint32_t d0 = d01 & 0xffffu, d1 = d01 >> 16, d2 = d23 & 0xffffu, d3 = d23 >> 16;
+	const uint32_t nd0 = depth < d1 ? d1 : d0, nd1 = depth < d2 ? d2 : d1, nd2 = depth < d3 ? d3 : d2;
+	const uint32_t hamadd = best & 0x3fffu;
+	uint32_t hilo = P[BR_HILO];
+	if (depth < depth5) hilo += 1u; else if (depth < seedLen) hilo += 1u << 16;
+	const uint32_t bcost = P[BR_COSTHAM] & 0xffffu, bham = P[BR_COSTHAM] >> 16, bned = P[BR_EDIT] >> 16;
+	const uint32_t nb = br_new(X, id, nd0 | (nd1 << 16), nd2 | (d3 << 16), depth + 1u, 0, bcost,
+	                           (bham + hamadd) & 0xffffu, top, bot, b, depth | (chr << 10) | ((bned + 1u) << 16), hilo);
+	uint32_t f = P[BR_FLAGS];
+	if (numNotElim == 1u && last) f |= BRF_EXHAUSTED;
+	else if (numTied == 1u && last && best != next) {
+		f = (f & 0xffffu) | BRF_DELAYED | (((bcost - best + next) & 0xffffu) << 16);
+	}
+	AW(b + BR_FLAGS) = f;
+	return nb;
+}
+#else
 /* Branch::splitBranch + RangeState::pickEdit (range_source.h:644-773, 321-485) */
 BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uint32_t depth5)
 {
@@ -385,7 +517,7 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 		} else if (c < next) next = c;
 	}
 	uint32_t r = 0;
-	if (numTied > 1u) r = bf_rnd_at(X, d + LF_RND) % numTied;
+	if (numTied > 1u) r = PM_RND(X, d) % numTied;
 	const uint32_t rec = alt + tied[r] * BF_ALW;
 	uint32_t info = AW(rec + 8u);
 	const uint32_t pos = info & 0xffffu;
@@ -395,7 +527,7 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 	if (num > 1u) {
 		uint32_t tot = 0;
 		for (uint32_t c = 0; c < 4u; c++) if (!((mask >> c) & 1u)) tot += AW(rec + 4u + c) - AW(rec + c);
-		uint32_t dart = bf_rnd_at(X, d + LF_RND) % tot;
+		uint32_t dart = PM_RND(X, d) % tot;
 		for (uint32_t c = 0; c < 4u; c++) {
 			if ((mask >> c) & 1u) continue;
 			const uint32_t w = AW(rec + 4u + c) - AW(rec + c);
@@ -430,6 +562,7 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 	AW(b + BR_FLAGS) = f;
 	return nb;
 }
+#endif
 
 /* PathManager::splitAndPrep (range_source.h:1460-1518); false = the search of this leaf ends now */
 BF_FN bool pm_split_and_prep(BfLane& X, uint32_t d, uint32_t seedLen, uint32_t depth5, bool useBtCnt)
@@ -513,12 +646,13 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	const BtIndexDev& ix = X.ix[sp.mirror];
 	const uint32_t maq = X.P->maq;
 	AW(d + DR_FLAGS) = 0;
+	pm_enter(X, d);
 	pm_reset(X, d);
 	const BfRead& R = X.R[sp.mate];
 	const uint32_t len = R.len;
 	AW(d + LF_RSFLAGS) = 0;
 	if (seedSrc) leaf_take_seed(X, d, seedSrc);
-	AW(d + LF_RND) = R.seed;
+	PMW(LF_RND) = R.seed;
 	/* initRangeSource */
 	const uint32_t s = sp.seedLen > 0 ? (sp.seedLen < len ? sp.seedLen : len) : len;
 	uint32_t sRight = s >> 1;
@@ -567,12 +701,31 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		if (r2 != r3) maxmms = 3;
 		if (qlen <= maxmms) { rsf |= 1u | 4u; go = false; }
 	}
+#if BF_FAST_EXTEND
+	/* leaf_qry with the seed's edits read once instead of at every character */
+	uint32_t sqN = 0, sqM[3] = {0, 0, 0};
+	if (valid) { sqN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) sqM[k] = AW(d + LF_SEEDMM0 + k); }
+	auto qry = [&](uint32_t i) -> uint32_t {
+		uint32_t c = bf_base(R, sp.fw, !sp.mirror, i);
+		for (uint32_t k = 0; k < 3u; k++) if (k < sqN && len - (sqM[k] & 0xffffu) - 1u == i) c = sqM[k] >> 16;
+		return c;
+	};
+#define BF_LQ(i) qry(i)
+#else
+#define BF_LQ(i) leaf_qry(X, d, sp, (i))
+#endif
 	uint32_t nsInFtab = 0;
+#if BF_FAST_EXTEND
+	/* a read without an N has none in its seed or its ftab characters (a seed's edits put in reference bases): the two
+	 * tallies below are a base fetch per position, each waited for before the next */
+	if (go && ((X.hasN >> sp.mate) & 1u)) {
+#else
 	if (go) {
+#endif
 		/* tallyNs (ebwt_search_backtrack.h:2490-2523) */
 		uint32_t nsInSeed = 0;
 		for (uint32_t i = 0; i < r3 && go; i++) {
-			if (leaf_qry(X, d, sp, qlen - i - 1u) == 4u) {
+			if (BF_LQ(qlen - i - 1u) == 4u) {
 				nsInSeed++;
 				if (nsInSeed == 1u) { if (i < r0) go = false; }
 				else if (nsInSeed == 2u) { if (i < r1) go = false; }
@@ -580,7 +733,7 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 				else go = false;
 			}
 		}
-		if (go) for (uint32_t i = 0; i < ix.ftabChars && i < qlen; i++) if (leaf_qry(X, d, sp, qlen - i - 1u) == 4u) nsInFtab++;
+		if (go) for (uint32_t i = 0; i < ix.ftabChars && i < qlen; i++) if (BF_LQ(qlen - i - 1u) == 4u) nsInFtab++;
 	}
 	if (go) {
 		const uint32_t ftabChars = ix.ftabChars;
@@ -588,8 +741,8 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		const bool skipInvalidExact = !sp.reportExacts && qlen == ftabChars;
 		const uint32_t d01 = r0 | (r1 << 16), d23 = r2 | (r3 << 16);
 		if (nsInFtab == 0 && m >= ftabChars && !skipInvalidExact) {
-			uint32_t off = leaf_qry(X, d, sp, qlen - ftabChars);                /* calcFtabOff (:2530-2544) */
-			for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | leaf_qry(X, d, sp, qlen - i);
+			uint32_t off = BF_LQ(qlen - ftabChars);                /* calcFtabOff (:2530-2544) */
+			for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | BF_LQ(qlen - i);
 			const uint32_t top = bt_ftab_hi(ix, off), bot = bt_ftab_lo(ix, off + 1u);
 			X.c_ftab++;
 			if (qlen == ftabChars && bot > top) {
@@ -610,7 +763,9 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	const uint32_t mc = icost > minCost ? icost : minCost;
 	AW(d + DR_COST) = mc | (minCost << 16);
 	AW(d + DR_FLAGS) = ((rsf & 1u) ? BF_F_DONE : 0u) | ((rsf & 2u) ? BF_F_FOUND : 0u);
+	pm_leave(X, d);
 }
+#undef BF_LQ
 
 /* EbwtRangeSource::advanceBranch (ebwt_search_backtrack.h:2059-2361), until = ADV_COST_CHANGES */
 BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
@@ -625,9 +780,10 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 	/* A branch that is simply extended -- no alternative taken, nothing curtailed -- stays the queue's front with its
 	 * cost (the queue is not touched, and PathManager::splitAndPrep on such a front only preps it): the next step then
 	 * goes on from the record in registers, prepped in place, instead of reading the queue, the front's flags and cost
-	 * and the record again (six dependent waits a base); and its base and quality were fetched beside this step's
-	 * rank loads.  What the arena holds afterwards is what the long way round writes. */
-	bool reuse = false, havePf = false;
+	 * and the record again (six dependent waits a base); its base and quality were fetched beside this step's rank
+	 * loads; and the record's words go back to the arena once, when the streak ends.  What the arena holds then is what
+	 * the long way round writes. */
+	bool reuse = false, havePf = false, dirty = false;
 	uint32_t pfC = 0, pfQ = 0;
 	uint32_t seedN = 0, seedM[3] = {0, 0, 0};
 	if (seedEdits) { seedN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) seedM[k] = AW(d + LF_SEEDMM0 + k); }
@@ -645,7 +801,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			havePf = false;
 		}
 		reuse = false;
-		bool extended = false;
+		bool extended = false, tbNew = false;
 #else
 		const uint32_t br = pm_front(X, d);
 		/* the front branch's record in one go (four independent 16-byte loads, one wait) instead of a dozen dependent
@@ -761,7 +917,11 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			} else {
 				cur = 0;
 			}
+#if BF_FAST_EXTEND
+			tbNew = true;                                  /* written when the streak ends (below) */
+#else
 			AW(br + BR_TOP) = top; AW(br + BR_BOT) = bot;
+#endif
 			const bool empty = top == bot;
 			hit = cur == 0 && !empty;
 			const bool invalidExact = hit && nedits == 0 && !sp.reportExacts;
@@ -784,27 +944,32 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 				curtail = true;
 			} else if (empty || cur == 0) curtail = true;
 #if BF_FAST_EXTEND
-			else { R[BR_RDLEN] = rdepth | ((blen + 1u) << 16); AW(br + BR_RDLEN) = R[BR_RDLEN]; extended = true; }   /* Branch::extend */
+			else { R[BR_RDLEN] = rdepth | ((blen + 1u) << 16); extended = true; }   /* Branch::extend */
 #else
 			else AW(br + BR_RDLEN) = rdepth | ((blen + 1u) << 16);        /* Branch::extend */
 #endif
 		}
-		if (curtail) pm_curtail(X, d, br, depth3);
-		if (X.ovf) break;
 #if BF_FAST_EXTEND
-		if (extended && (R[BR_FLAGS] & (BRF_DELAYED | BRF_CURTAILED)) == 0) {
-			/* splitAndPrep on an untouched queue whose front is this branch: the backtrack budget's check, then prep */
-			if (sp.useBtCnt != 0 && X.btCnt == 0) { pm_reset(X, d); break; }
+		if (extended && !X.ovf && (R[BR_FLAGS] & (BRF_DELAYED | BRF_CURTAILED)) == 0 && !(sp.useBtCnt != 0 && X.btCnt == 0)) {
+			/* splitAndPrep on an untouched queue whose front is this branch does one thing, prep: done on the registers */
 			uint32_t f = R[BR_FLAGS];
-			if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; R[BR_LTOP] = top; R[BR_LBOT] = bot; AW(br + BR_LTOP) = top; AW(br + BR_LBOT) = bot; }
-			else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; AW(br + BR_LTOP) = top; }
-			R[BR_FLAGS] = f; AW(br + BR_FLAGS) = f;
-			R[BR_TOP] = top; R[BR_BOT] = bot;
-			reuse = true;
+			if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; R[BR_LTOP] = top; R[BR_LBOT] = bot; }
+			else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; }
+			R[BR_FLAGS] = f; R[BR_TOP] = top; R[BR_BOT] = bot;
+			dirty = true; reuse = true;
 			continue;
 		}
-		havePf = false;
+		/* the streak ends here: the arena gets what its steps would have written one by one, before anything reads it */
+		if (tbNew) { AW(br + BR_TOP) = top; AW(br + BR_BOT) = bot; }
+		else if (dirty) { AW(br + BR_TOP) = R[BR_TOP]; AW(br + BR_BOT) = R[BR_BOT]; }
+		if (dirty) { AW(br + BR_FLAGS) = R[BR_FLAGS]; AW(br + BR_LTOP) = R[BR_LTOP]; AW(br + BR_LBOT) = R[BR_LBOT]; }
+		if (dirty || extended) AW(br + BR_RDLEN) = R[BR_RDLEN];
+		dirty = false; havePf = false;
+		if (curtail) pm_curtail_regs(X, d, br, depth3, R);
+#else
+		if (curtail) pm_curtail(X, d, br, depth3);
 #endif
+		if (X.ovf) break;
 		if (!pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0)) pm_reset(X, d);
 		if (X.ovf) break;
 		if (pm_size(X, d) == 0) break;
@@ -817,15 +982,21 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 BF_FN void leaf_advance(BfLane& X, uint32_t d)
 {
 	uint32_t fl = AW(d + DR_FLAGS);
+#if BF_FAST_EXTEND
+	if ((fl & BF_F_DONE) || (AW(d + LF_HEAPSZ) & 0xffffu) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
+	pm_enter(X, d);
+#else
 	if ((fl & BF_F_DONE) || pm_size(X, d) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
+#endif
 	const BfSpec& sp = leaf_spec(X, d);
 	leaf_advance_branch(X, d, sp);
 	fl &= ~(BF_F_DONE | BF_F_FOUND);
 	if (pm_size(X, d) == 0) fl |= BF_F_DONE;
-	const uint32_t pmc = AW(d + LF_PMCOST), adj = AW(d + DR_COST) >> 16;
+	const uint32_t pmc = PMW(LF_PMCOST), adj = AW(d + DR_COST) >> 16;
 	if (pmc != 0) AW(d + DR_COST) = (pmc > adj ? pmc : adj) | (adj << 16);
 	if (AW(d + LF_RSFLAGS) & 2u) fl |= BF_F_FOUND;
 	AW(d + DR_FLAGS) = fl;
+	pm_leave(X, d);
 }
 
 /* ---- the inner drivers ------------------------------------------------------------------------ */
@@ -1267,6 +1438,29 @@ BF_INL bool bf_irrelevant(const BfLane& X, uint32_t cost)       /* NBestFirstStr
 	return X.P->sinkStrata && X.nhits && (cost >> 14) > X.bestStratum;
 }
 
+#if BF_FAST_EXTEND
+/* does the read hold an N (code 4)?  Its row in 16-byte pieces (rows are 16-byte aligned and padded with 4s past the
+ * read's end, which are masked off) */
+BF_FN uint32_t bf_has_n(const BfRead& R)
+{
+	uint32_t any = 0;
+	for (uint32_t base = 0; base < R.len; base += 16u) {
+		const BtU4 v = bt_ld4((const void*)(R.seq + base));
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		for (uint32_t k = 0; k < 4u; k++) {
+			const uint32_t at = base + 4u * k;
+			if (at >= R.len) break;
+			const uint32_t t = w[k] ^ 0x04040404u;
+			uint32_t z = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;      /* 0x80 per byte that is 4 */
+			const uint32_t left = R.len - at;
+			if (left < 4u) z &= (1u << (8u * left)) - 1u;
+			any |= z;
+		}
+	}
+	return any != 0 ? 1u : 0u;
+}
+#endif
+
 BF_FN void bf_read_begin(BfLane& X, const BtBatchDev& B, uint32_t rd)
 {
 	X.rd = rd;
@@ -1285,6 +1479,9 @@ BF_FN void bf_read_begin(BfLane& X, const BtBatchDev& B, uint32_t rd)
 	X.nhits = 0; X.stored = 0; X.bestStratum = 999; X.status = 0;
 	X.alRnd = X.R[0].seed;                                      /* Aligner::rand_.init(bufa_->seed) */
 	X.btCnt = (int32_t)X.P->maxBts;
+#if BF_FAST_EXTEND
+	X.hasN = bf_has_n(X.R[0]) | (B.seq2 ? bf_has_n(X.R[1]) << 1 : 0u);
+#endif
 }
 BF_FN void bf_read_end(BfLane& X, const BtBatchDev& B, uint32_t mult)
 {
