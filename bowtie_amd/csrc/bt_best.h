@@ -49,6 +49,11 @@
 #endif
 /* PairedBWAlignerV1 (bf_run_pair_v1, the reference's default paired-end aligner): part of every build since round 3
  * (GPU-verified against the 120 reference outputs of tests/golden/pe_v1) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BF_UNROLL16 _Pragma("unroll 16")
+#else
+#define BF_UNROLL16
+#endif
 #define BF_HAVE_V1 1
 /* 1: leaf_advance_branch keeps a branch it is simply extending in registers from step to step (see there).  Off in the
  * shipped build until it has run on a GPU: the host build of the engine is bit-identical either way (tests/emu). */
@@ -305,6 +310,85 @@ BF_FN bool bf_before(BfLane& X, uint32_t a, uint32_t b)        /* CostCompare()(
 	return AW(b + BR_ID) < AW(a + BR_ID);
 }
 
+#if BF_FAST_EXTEND
+/* what CostCompare looks at, fetched in one go (the record's first two 16-byte pieces) instead of field by field as the
+ * comparison proceeds */
+struct BfKey { uint32_t cost, un, depth, id; };
+BF_INL BfKey bf_key(BfLane& X, uint32_t b)
+{
+	const BtU4 q0 = bt_ld4((const void*)(X.A + b)), q1 = bt_ld4((const void*)(X.A + b + 4u));
+	BfKey k;
+	k.id = q0.x; k.depth = ((q0.w & 0xffffu) + (q0.w >> 16)) & 0xffffu;
+	k.cost = q1.x & 0xffffu; k.un = (q1.w & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0 ? 1u : 0u;
+	return k;
+}
+BF_INL bool bf_before_k(const BfKey& a, const BfKey& b)        /* bf_before on fetched keys */
+{
+	if (a.cost != b.cost) return b.cost < a.cost;
+	if (b.un && !a.un) return false;
+	if (a.un && !b.un) return true;
+	if (a.depth != b.depth) return a.depth < b.depth;
+	return b.id < a.id;
+}
+BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)
+{
+	uint32_t heap = PMW(LF_HEAP), sz = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
+	if (sz == cap) {
+		const uint32_t ncap = cap ? cap * 2u : 8u;
+		if (ncap > 0xffffu) { X.ovf = 1; return; }
+		const uint32_t nh = bf_alloc(X, ncap);
+		if (X.ovf) return;
+		for (uint32_t k = 0; k < sz; k++) AW(nh + k) = AW(heap + k);
+		heap = nh; cap = ncap; PMW(LF_HEAP) = heap;
+	}
+	const BfKey kv = bf_key(X, v);
+	uint32_t hole = sz;
+	while (hole > 0) {
+		const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
+		if (!bf_before_k(bf_key(X, pv), kv)) break;
+		AW(heap + hole) = pv; hole = parent;
+	}
+	AW(heap + hole) = v;
+	PMW(LF_HEAPSZ) = (sz + 1u) | (cap << 16);
+	PMW(LF_PMCOST) = hole == 0 ? kv.cost : br_cost(X, AW(heap));
+}
+BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
+{
+	const uint32_t heap = PMW(LF_HEAP), n = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
+	const uint32_t top = AW(heap);
+	uint32_t frontCost = 0; bool haveFront = false;
+	if (n > 1u) {
+		const uint32_t value = AW(heap + n - 1u);
+		AW(heap + n - 1u) = top;
+		const BfKey kval = bf_key(X, value);
+		const uint32_t len = n - 1u;
+		uint32_t hole = 0, second = 0;
+		while (second < (len - 1u) / 2u) {
+			second = 2u * (second + 1u);
+			const uint32_t hs = AW(heap + second), hs1 = AW(heap + second - 1u);
+			uint32_t pick = hs;
+			if (bf_before_k(bf_key(X, hs), bf_key(X, hs1))) { second--; pick = hs1; }
+			AW(heap + hole) = pick; hole = second;
+		}
+		if ((len & 1u) == 0 && second == (len - 2u) / 2u) {
+			second = 2u * (second + 1u);
+			AW(heap + hole) = AW(heap + second - 1u); hole = second - 1u;
+		}
+		while (hole > 0) {
+			const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
+			if (!bf_before_k(bf_key(X, pv), kval)) break;
+			AW(heap + hole) = pv; hole = parent;
+		}
+		AW(heap + hole) = value;
+		if (hole == 0) { frontCost = kval.cost; haveFront = true; }
+	}
+	PMW(LF_HEAPSZ) = (n - 1u) | (cap << 16);
+	PMW(LF_PMCOST) = haveFront ? frontCost : br_cost(X, n > 1u ? AW(heap) : top);
+	return top;
+}
+#define BF_PM_PUSH_POP_DONE 1
+#endif
+#if !defined(BF_PM_PUSH_POP_DONE)
 BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)          /* PathManager::push (range_source.h:1361-1372) */
 {
 	uint32_t heap = PMW(LF_HEAP), sz = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
@@ -358,6 +442,7 @@ BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 	PMW(LF_PMCOST) = br_cost(X, n > 1u ? AW(heap) : top);
 	return top;
 }
+#endif
 
 BF_INL uint32_t pm_size(BfLane& X, uint32_t d) { return PMW(LF_HEAPSZ) & 0xffffu; }
 BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return AW(PMW(LF_HEAP)); }
@@ -408,11 +493,16 @@ BF_FN void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen,
 {
 	const uint32_t alt = R[BR_ALT], n = R[BR_NALT], rdepth = R[BR_RDLEN] & 0xffffu;
 	uint32_t lowest = 0xffffu;
-	for (uint32_t k = 0; k < n; k++) {
-		const uint32_t info = AW(alt + k * BF_ALW + 8u);
-		if (info >> 28) continue;
-		const uint32_t c = alt_cost(info, rdepth, seedLen);
-		if (c < lowest) lowest = c;
+	for (uint32_t k0 = 0; k0 < n; k0 += 4u) {
+		/* four alternatives' info words in flight at a time (they sit ten words apart) */
+		uint32_t in4[4];
+		for (uint32_t j = 0; j < 4u; j++) in4[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
+		for (uint32_t j = 0; j < 4u; j++) {
+			const uint32_t info = in4[j];
+			if (info >> 28) continue;
+			const uint32_t c = alt_cost(info, rdepth, seedLen);
+			if (c < lowest) lowest = c;
+		}
 	}
 	uint32_t f = R[BR_FLAGS];
 	const uint32_t orig = R[BR_COSTHAM] & 0xffffu;
@@ -439,16 +529,20 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 	}
 	const uint32_t alt = P[BR_ALT], n = P[BR_NALT], rdepth = P[BR_RDLEN] & 0xffffu;
 	uint32_t tied[3] = {0, 0, 0}, numTied = 0, numNotElim = 0, best = 0xffffu, next = 0xffffu;
-	for (uint32_t k = 0; k < n; k++) {
-		const uint32_t info = AW(alt + k * BF_ALW + 8u);
-		if (info >> 28) continue;
-		numNotElim++;
-		const uint32_t c = alt_cost(info, rdepth, seedLen);
-		if (c < best) { next = best; best = c; numTied = 1; tied[0] = k; }
-		else if (c == best) {
-			if (numTied < 3u) tied[numTied++] = k;
-			else { tied[0] = tied[1]; tied[1] = tied[2]; tied[2] = k; }
-		} else if (c < next) next = c;
+	for (uint32_t k0 = 0; k0 < n; k0 += 4u) {
+		uint32_t in4[4];
+		for (uint32_t j = 0; j < 4u; j++) in4[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
+		for (uint32_t j = 0; j < 4u; j++) {
+			const uint32_t info = in4[j], k = k0 + j;
+			if (info >> 28) continue;
+			numNotElim++;
+			const uint32_t c = alt_cost(info, rdepth, seedLen);
+			if (c < best) { next = best; best = c; numTied = 1; tied[0] = k; }
+			else if (c == best) {
+				if (numTied < 3u) tied[numTied++] = k;
+				else { tied[0] = tied[1]; tied[1] = tied[2]; tied[2] = k; }
+			} else if (c < next) next = c;
+		}
 	}
 	uint32_t r = 0;
 	if (numTied > 1u) r = PM_RND(X, d) % numTied;
@@ -1037,6 +1131,43 @@ BF_FN void cost_sort_actives(BfLane& X, uint32_t d)
 {
 	const uint32_t vec = AW(d + CA_ACT);
 	uint32_t n = AW(d + CA_NACT), sz = n;
+#if BF_FAST_EXTEND
+	if (n <= 16u) {
+		/* the same selection sort (and the same draws) on a copy of what it looks at: every child's flags and cost are
+		 * fetched once, side by side, instead of inside the two loops, each fetch waited for */
+		uint32_t v[16], fl[16], co[16];
+		BF_UNROLL16 for (uint32_t i = 0; i < 16u; i++) v[i] = i < n ? (uint32_t)AW(vec + i) : 0u;
+		BF_UNROLL16 for (uint32_t i = 0; i < 16u; i++) { fl[i] = i < n ? (uint32_t)AW(v[i] + DR_FLAGS) : 0u; co[i] = i < n ? ((uint32_t)AW(v[i] + DR_COST) & 0xffffu) : 0u; }
+		const uint32_t n0 = n;
+		uint32_t rs = AW(d + CA_RND);
+		bool drew = false;
+		for (uint32_t i = 0; i < sz;) {
+			if ((fl[i] & BF_F_DONE) && !(fl[i] & BF_F_FOUND)) {
+				for (uint32_t k = i; k + 1u < n; k++) { v[k] = v[k + 1u]; fl[k] = fl[k + 1u]; co[k] = co[k + 1u]; }
+				n--; sz--;
+				continue;
+			}
+			uint32_t minCost = co[i], minOff = i;
+			for (uint32_t j = i + 1u; j < sz; j++) {
+				if ((fl[j] & BF_F_DONE) && !(fl[j] & BF_F_FOUND)) continue;
+				const uint32_t cj = co[j];
+				if (cj < minCost) { minCost = cj; minOff = j; }
+				else if (cj == minCost) { drew = true; if (bf_rnd(rs) & 0x1000u) minOff = j; }
+			}
+			if (i != minOff) {
+				uint32_t t = v[i]; v[i] = v[minOff]; v[minOff] = t;
+				t = fl[i]; fl[i] = fl[minOff]; fl[minOff] = t;
+				t = co[i]; co[i] = co[minOff]; co[minOff] = t;
+			}
+			i++;
+		}
+		for (uint32_t k = 0; k < n0; k++) AW(vec + k) = v[k];          /* the slots past n included: what the in-place shifts leave there */
+		if (drew) AW(d + CA_RND) = rs;
+		AW(d + CA_NACT) = n;
+		if (AW(d + CA_DELAYED) == 0 && sz > 0) dr_set_mincost(X, d, co[0]);
+		return;
+	}
+#endif
 	for (uint32_t i = 0; i < sz;) {
 		const uint32_t vi = AW(vec + i);
 		if (dr_done(X, vi) && !dr_found(X, vi)) {
@@ -1120,6 +1251,16 @@ template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
 	if (LEVEL != 0 || !X.P->paired || BF_IS_V1(*X.P)) return false;      /* V1's drivers hold one mate each */
 	const uint32_t n = AW(d + CA_NACT);
 	bool m1 = false, m2 = false;
+#if BF_FAST_EXTEND
+	if (n <= 16u) {
+		const uint32_t vec = AW(d + CA_ACT);
+		uint32_t a[16], fl[16], kd[16];
+		BF_UNROLL16 for (uint32_t i = 0; i < 16u; i++) a[i] = i < n ? (uint32_t)AW(vec + i) : 0u;
+		BF_UNROLL16 for (uint32_t i = 0; i < 16u; i++) { fl[i] = i < n ? (uint32_t)AW(a[i] + DR_FLAGS) : BF_F_DONE; kd[i] = i < n ? (uint32_t)AW(a[i] + DR_KIND) : 0u; }
+		BF_UNROLL16 for (uint32_t i = 0; i < 16u; i++) if (i < n && !(fl[i] & BF_F_DONE)) { if ((kd[i] >> 9) & 1u) m2 = true; else m1 = true; }
+		return !m1 || !m2;
+	}
+#endif
 	for (uint32_t i = 0; i < n; i++) {
 		const uint32_t a = AW(AW(d + CA_ACT) + i);
 		if (!dr_done(X, a)) { if (dr_mate(X, a)) m2 = true; else m1 = true; }
