@@ -60,6 +60,11 @@
 #ifndef BF_FAST_EXTEND
 #define BF_FAST_EXTEND 0
 #endif
+/* part of the above that can be measured apart: the cost-aware driver's sort and mate check work on gathered copies of
+ * their children's flags and costs (48-word local arrays, which the compiler keeps in scratch memory) */
+#ifndef BF_FAST_GATHER
+#define BF_FAST_GATHER BF_FAST_EXTEND
+#endif
 #define BF_IS_V1(P) ((P).paired == 2u)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
@@ -1131,7 +1136,7 @@ BF_FN void cost_sort_actives(BfLane& X, uint32_t d)
 {
 	const uint32_t vec = AW(d + CA_ACT);
 	uint32_t n = AW(d + CA_NACT), sz = n;
-#if BF_FAST_EXTEND
+#if BF_FAST_GATHER
 	if (n <= 16u) {
 		/* the same selection sort (and the same draws) on a copy of what it looks at: every child's flags and cost are
 		 * fetched once, side by side, instead of inside the two loops, each fetch waited for */
@@ -1251,7 +1256,7 @@ template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
 	if (LEVEL != 0 || !X.P->paired || BF_IS_V1(*X.P)) return false;      /* V1's drivers hold one mate each */
 	const uint32_t n = AW(d + CA_NACT);
 	bool m1 = false, m2 = false;
-#if BF_FAST_EXTEND
+#if BF_FAST_GATHER
 	if (n <= 16u) {
 		const uint32_t vec = AW(d + CA_ACT);
 		uint32_t a[16], fl[16], kd[16];

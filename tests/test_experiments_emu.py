@@ -13,7 +13,8 @@ import common as T
 
 @pytest.mark.parametrize("defines, files", [
     ("-DBF_FAST_EXTEND=1", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
-], ids=["fast_extend"])
+    ("-DBF_FAST_EXTEND=1 -DBF_FAST_GATHER=0", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
+], ids=["fast_extend", "fast_extend_without_gathers"])
 def test_experiment_is_bit_identical_in_the_host_build(defines, files):
     env = dict(os.environ, BT_EMU_DEFINES=defines)
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "not gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=T.ROOT, env=env,
