@@ -498,12 +498,12 @@ BF_FN void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen,
 {
 	const uint32_t alt = R[BR_ALT], n = R[BR_NALT], rdepth = R[BR_RDLEN] & 0xffffu;
 	uint32_t lowest = 0xffffu;
-	for (uint32_t k0 = 0; k0 < n; k0 += 4u) {
-		/* four alternatives' info words in flight at a time (they sit ten words apart) */
-		uint32_t in4[4];
-		for (uint32_t j = 0; j < 4u; j++) in4[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
-		for (uint32_t j = 0; j < 4u; j++) {
-			const uint32_t info = in4[j];
+	for (uint32_t k0 = 0; k0 < n; k0 += 8u) {
+		/* eight alternatives' info words in flight at a time (they sit ten words apart) */
+		uint32_t in8[8];
+		for (uint32_t j = 0; j < 8u; j++) in8[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
+		for (uint32_t j = 0; j < 8u; j++) {
+			const uint32_t info = in8[j];
 			if (info >> 28) continue;
 			const uint32_t c = alt_cost(info, rdepth, seedLen);
 			if (c < lowest) lowest = c;
@@ -534,11 +534,11 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 	}
 	const uint32_t alt = P[BR_ALT], n = P[BR_NALT], rdepth = P[BR_RDLEN] & 0xffffu;
 	uint32_t tied[3] = {0, 0, 0}, numTied = 0, numNotElim = 0, best = 0xffffu, next = 0xffffu;
-	for (uint32_t k0 = 0; k0 < n; k0 += 4u) {
-		uint32_t in4[4];
-		for (uint32_t j = 0; j < 4u; j++) in4[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
-		for (uint32_t j = 0; j < 4u; j++) {
-			const uint32_t info = in4[j], k = k0 + j;
+	for (uint32_t k0 = 0; k0 < n; k0 += 8u) {
+		uint32_t in8[8];
+		for (uint32_t j = 0; j < 8u; j++) in8[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
+		for (uint32_t j = 0; j < 8u; j++) {
+			const uint32_t info = in8[j], k = k0 + j;
 			if (info >> 28) continue;
 			numNotElim++;
 			const uint32_t c = alt_cost(info, rdepth, seedLen);
