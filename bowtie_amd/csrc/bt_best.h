@@ -167,7 +167,7 @@ struct BfLane {                   /* per-lane registers / private memory */
 	BfRead R[2];                  /* the read / the two mates                                     */
 #if BF_FAST_EXTEND
 	uint32_t hasN;                /* bit m: mate m holds an N (found once, at bf_read_begin)      */
-	uint32_t pm[6];               /* the leaf's PathManager words LF_HEAP..LF_RND while leaf_set_query / leaf_advance run (pm_enter / pm_leave) */
+	uint32_t pm[7];               /* the leaf's PathManager words LF_HEAP..LF_RND while leaf_set_query / leaf_advance run (pm_enter / pm_leave); [6] = the queue's front */
 #endif
 	uint32_t rd;
 	int32_t  btCnt;
@@ -193,7 +193,12 @@ BF_INL uint32_t bf_rnd_at(BfLane& X, uint32_t off) { uint32_t s = AW(off); uint3
 #if BF_FAST_EXTEND
 #define PMW(w) (X.pm[(w) - LF_HEAP])
 #define PM_RND(X, d) bf_rnd(X.pm[LF_RND - LF_HEAP])
-BF_INL void pm_enter(BfLane& X, uint32_t d) { for (uint32_t k = 0; k < 6u; k++) X.pm[k] = AW(d + LF_HEAP + k); }
+BF_INL void pm_enter(BfLane& X, uint32_t d)
+{
+	for (uint32_t k = 0; k < 6u; k++) X.pm[k] = AW(d + LF_HEAP + k);
+	X.pm[6] = (X.pm[LF_HEAPSZ - LF_HEAP] & 0xffffu) ? (uint32_t)AW(X.pm[0]) : 0u;          /* kept equal to heap[0] by every store to it (PM_HSET) */
+}
+#define PM_HSET(heap, idx, x) do { const uint32_t hs_i = (idx), hs_x = (x); AW((heap) + hs_i) = hs_x; if (hs_i == 0) X.pm[6] = hs_x; } while (0)
 BF_INL void pm_leave(BfLane& X, uint32_t d) { for (uint32_t k = 0; k < 6u; k++) AW(d + LF_HEAP + k) = X.pm[k]; }
 #else
 #define PMW(w) AW(d + (w))
@@ -351,9 +356,9 @@ BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)
 	while (hole > 0) {
 		const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
 		if (!bf_before_k(bf_key(X, pv), kv)) break;
-		AW(heap + hole) = pv; hole = parent;
+		PM_HSET(heap, hole, pv); hole = parent;
 	}
-	AW(heap + hole) = v;
+	PM_HSET(heap, hole, v);
 	PMW(LF_HEAPSZ) = (sz + 1u) | (cap << 16);
 	PMW(LF_PMCOST) = hole == 0 ? kv.cost : br_cost(X, AW(heap));
 }
@@ -364,7 +369,7 @@ BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 	uint32_t frontCost = 0; bool haveFront = false;
 	if (n > 1u) {
 		const uint32_t value = AW(heap + n - 1u);
-		AW(heap + n - 1u) = top;
+		PM_HSET(heap, n - 1u, top);
 		const BfKey kval = bf_key(X, value);
 		const uint32_t len = n - 1u;
 		uint32_t hole = 0, second = 0;
@@ -373,18 +378,18 @@ BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 			const uint32_t hs = AW(heap + second), hs1 = AW(heap + second - 1u);
 			uint32_t pick = hs;
 			if (bf_before_k(bf_key(X, hs), bf_key(X, hs1))) { second--; pick = hs1; }
-			AW(heap + hole) = pick; hole = second;
+			PM_HSET(heap, hole, pick); hole = second;
 		}
 		if ((len & 1u) == 0 && second == (len - 2u) / 2u) {
 			second = 2u * (second + 1u);
-			AW(heap + hole) = AW(heap + second - 1u); hole = second - 1u;
+			PM_HSET(heap, hole, (uint32_t)AW(heap + second - 1u)); hole = second - 1u;
 		}
 		while (hole > 0) {
 			const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
 			if (!bf_before_k(bf_key(X, pv), kval)) break;
-			AW(heap + hole) = pv; hole = parent;
+			PM_HSET(heap, hole, pv); hole = parent;
 		}
-		AW(heap + hole) = value;
+		PM_HSET(heap, hole, value);
 		if (hole == 0) { frontCost = kval.cost; haveFront = true; }
 	}
 	PMW(LF_HEAPSZ) = (n - 1u) | (cap << 16);
@@ -450,7 +455,11 @@ BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 #endif
 
 BF_INL uint32_t pm_size(BfLane& X, uint32_t d) { return PMW(LF_HEAPSZ) & 0xffffu; }
+#if BF_FAST_EXTEND
+BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return X.pm[6]; }
+#else
 BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return AW(PMW(LF_HEAP)); }
+#endif
 BF_INL void pm_reset(BfLane& X, uint32_t d)                    /* PathManager::reset (range_source.h:1386-1399) */
 {
 	PMW(LF_HEAPSZ) &= 0xffff0000u; PMW(LF_BP) = 0; PMW(LF_BPLAST) = 0; PMW(LF_PMCOST) = 0;
@@ -678,14 +687,24 @@ BF_FN bool pm_split_and_prep(BfLane& X, uint32_t d, uint32_t seedLen, uint32_t d
 		f = pm_front(X, d);
 		if (X.ovf) return false;
 	}
+#if BF_FAST_EXTEND
+	uint32_t fresh = 0;                                  /* the branch br_split made: br_new stored it prepped */
+#endif
 	if (AW(f + BR_FLAGS) & BRF_CURTAILED) {
 		if (useBtCnt) { if (--X.btCnt == 0) return false; }
 		const uint32_t nb = br_split(X, d, f, seedLen, depth5);
 		if (X.ovf) return false;
 		if (AW(f + BR_FLAGS) & BRF_EXHAUSTED) { pm_pop(X, d); pm_free_id(X, d, AW(f + BR_ID)); }
 		pm_push(X, d, nb);
+#if BF_FAST_EXTEND
+		fresh = nb;
+#endif
 	}
+#if BF_FAST_EXTEND
+	if (pm_size(X, d) && pm_front(X, d) != fresh) br_prep(X, pm_front(X, d));
+#else
 	if (pm_size(X, d)) br_prep(X, pm_front(X, d));
+#endif
 	return true;
 }
 
@@ -1056,6 +1075,9 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; }
 			R[BR_FLAGS] = f; R[BR_TOP] = top; R[BR_BOT] = bot;
 			dirty = true; reuse = true;
+#if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+			if ((uint32_t)AW(PMW(LF_HEAP)) != br || X.pm[6] != br || PMW(LF_PMCOST) != cost) { fprintf(stderr, "BF_CHECK: the extended branch is not the queue's front\n"); abort(); }
+#endif
 			continue;
 		}
 		/* the streak ends here: the arena gets what its steps would have written one by one, before anything reads it */
@@ -1072,7 +1094,16 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 		if (!pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0)) pm_reset(X, d);
 		if (X.ovf) break;
 		if (pm_size(X, d) == 0) break;
+#if BF_FAST_EXTEND
+		/* the queue's cost word is its front's cost: every change of a queued branch's cost (curtail, a delayed increase) is
+		 * followed by a pop and a push, which set it */
+#if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+		if (PMW(LF_PMCOST) != br_cost(X, AW(PMW(LF_HEAP))) || X.pm[6] != (uint32_t)AW(PMW(LF_HEAP))) { fprintf(stderr, "BF_CHECK: queue cost / front cache out of step\n"); abort(); }
+#endif
+		if (PMW(LF_PMCOST) != cost) break;
+#else
 		if (br_cost(X, pm_front(X, d)) != cost) break;
+#endif
 	} while (!found);
 	AW(d + LF_RSFLAGS) = (AW(d + LF_RSFLAGS) & ~2u) | (found ? 2u : 0u);
 }

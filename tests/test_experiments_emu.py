@@ -1,7 +1,8 @@
 """Compile-time experiments of the device engines, checked in their host build (tests/emu, no GPU): a switch that is off in
 the shipped library because it has not run on a GPU yet must at least leave every answer and every operation count of the
 emulator tests what it was.  The emulator is rebuilt with the switch (emu_lib.py: BT_EMU_DEFINES, a library of its own)
-and the tests that drive the engine through it run again in a child pytest."""
+and the tests that drive the engine through it run again in a child pytest.  -DBF_CHECK=1 compiles in the host-only
+assertions of the shortcuts' assumptions (bt_best.h)."""
 import os
 import subprocess
 import sys
@@ -12,8 +13,8 @@ import common as T
 
 
 @pytest.mark.parametrize("defines, files", [
-    ("-DBF_FAST_EXTEND=1", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
-    ("-DBF_FAST_EXTEND=1 -DBF_FAST_GATHER=0", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
+    ("-DBF_FAST_EXTEND=1 -DBF_CHECK=1", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
+    ("-DBF_FAST_EXTEND=1 -DBF_FAST_GATHER=0 -DBF_CHECK=1", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
 ], ids=["fast_extend", "fast_extend_without_gathers"])
 def test_experiment_is_bit_identical_in_the_host_build(defines, files):
     env = dict(os.environ, BT_EMU_DEFINES=defines)
