@@ -755,6 +755,28 @@ BF_FN void leaf_take_seed(BfLane& X, uint32_t d, uint32_t src)
 	AW(d + LF_RSFLAGS) |= 8u;
 }
 
+#if BF_FAST_EXTEND
+/* the two lowest quality characters (the lowest twice if it occurs twice) among query offsets qlen-k-1, k in [k0, k1), of
+ * the string a leaf reads its penalties from -- a contiguous stretch of the stored row either way round, fetched in
+ * 16-byte pieces instead of a character at a time */
+BF_FN void bf_qual_low2(const BfRead& R, uint32_t fw, uint32_t ebwtFw, uint32_t qlen, uint32_t k0, uint32_t k1, uint32_t& l1, uint32_t& l2)
+{
+	l1 = 0xffu; l2 = 0xffu;
+	if (k1 <= k0) return;
+	const uint32_t lo = (fw == ebwtFw) ? qlen - k1 : R.len - qlen + k0, hi = (fw == ebwtFw) ? qlen - k0 : R.len - qlen + k1;
+	for (uint32_t base = lo & ~15u; base < hi; base += 16u) {
+		const BtU4 v = bt_ld4((const void*)(R.qual + base));
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		for (uint32_t j = 0; j < 16u; j++) {
+			const uint32_t i = base + j;
+			if (i < lo || i >= hi) continue;
+			const uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+			if (c < l1) { l2 = l1; l1 = c; } else if (c < l2) l2 = c;
+		}
+	}
+}
+#endif
+
 /* SingleRangeSourceDriver::setQueryImpl (range_source.h:1750-1771) with EbwtRangeSource::setQuery
  * (ebwt_search_backtrack.h:1831-1870), EbwtRangeSourceDriver::initRangeSource (:2721-2806) and
  * EbwtRangeSource::initBranch (:1920-2051) */
@@ -788,19 +810,29 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	} else if (!sp.halfAndHalf && r0 < s) {
 		minCost = 1u << 14;
 		uint32_t low = 0xffu;
+#if BF_FAST_EXTEND
+		{ uint32_t l2; bf_qual_low2(R, sp.fw, ebwtFw, qlen, r0, s, low, l2); }
+#else
 		for (uint32_t k = r0; k < s; k++) { const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u); if (c < low) low = c; }
+#endif
 		minCost += bt_mm_penalty(maq, bf_phred(low));
 	} else if (sp.halfAndHalf && sRight > 0 && sRight < (s - 1u)) {
 		minCost = (sp.seed ? 3u : 2u) << 14;
 		uint32_t low1 = 0xffu;
+		uint32_t l21 = 0xffu, l22 = 0xffu;
+#if BF_FAST_EXTEND
+		{ uint32_t l2; bf_qual_low2(R, sp.fw, ebwtFw, qlen, 0, sRight, low1, l2); }
+		bf_qual_low2(R, sp.fw, ebwtFw, qlen, sRight, s, l21, l22);
+		minCost += bt_mm_penalty(maq, bf_phred(low1));
+#else
 		for (uint32_t k = 0; k < sRight; k++) { const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u); if (c < low1) low1 = c; }
 		minCost += bt_mm_penalty(maq, bf_phred(low1));
-		uint32_t l21 = 0xffu, l22 = 0xffu;
 		for (uint32_t k = sRight; k < s; k++) {
 			const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u);
 			if (c < l21) { if (l21 != 0xffu) l22 = l21; l21 = c; }
 			else if (c < l22) l22 = c;
 		}
+#endif
 		minCost += bt_mm_penalty(maq, bf_phred(l21));
 		if (sp.halfAndHalf > 2 && l22 != 0xffu) minCost += bt_mm_penalty(maq, bf_phred(l22));
 	}
