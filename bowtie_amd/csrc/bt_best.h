@@ -129,6 +129,7 @@ enum {
 	LF_SEED            /* seedRange: cost | n<<16 */, LF_SEEDMM0, LF_SEEDMM1, LF_SEEDMM2 /* mms | refc<<16 */,
 	/* cost-aware (CostAwareRangeSourceDriver) */
 	CA_RSS = 3, CA_NRSS /* n | cap<<16 */, CA_ACT, CA_NACT, CA_RND, CA_LAST, CA_DELAYED, CA_OPTS /* 1 strandFix, 2 patsrc set */,
+	CA_KEY /* BF_FAST_GATHER: the sort's key array */, CA_KEYCAP,
 	/* seeded (EbwtSeededRangeSourceDriver) */
 	SD_FULL = 3, SD_SEED, SD_FACT
 };
@@ -1338,6 +1339,55 @@ BF_FN void cost_sort_actives(BfLane& X, uint32_t d)
 		if (drew) AW(d + CA_RND) = rs;
 		AW(d + CA_NACT) = n;
 		if (AW(d + CA_DELAYED) == 0 && sz > 0) dr_set_mincost(X, d, co[0]);
+		return;
+	}
+	{
+		/* more children than that (a seeded driver with hundreds of extenders: the reads that take longest): the same sort
+		 * on a key array in the arena beside the vector -- cost | dead << 16 per child, gathered once, eight at a time --
+		 * so that the inner loop reads one contiguous word per child instead of the child's offset, then its flags, then
+		 * its cost */
+		uint32_t key = AW(d + CA_KEY), kcap = AW(d + CA_KEYCAP);
+		if (kcap < n) {
+			const uint32_t ncap = (n + n / 2u + 15u) & ~7u;
+			key = bf_alloc(X, ncap);
+			if (X.ovf) return;                                 /* the read is on its way to a larger arena */
+			AW(d + CA_KEY) = key; AW(d + CA_KEYCAP) = ncap;
+		}
+		for (uint32_t i0 = 0; i0 < n; i0 += 8u) {
+			uint32_t v8[8], f8[8], c8[8];
+			for (uint32_t j = 0; j < 8u; j++) v8[j] = i0 + j < n ? (uint32_t)AW(vec + i0 + j) : 0u;
+			for (uint32_t j = 0; j < 8u; j++) { f8[j] = i0 + j < n ? (uint32_t)AW(v8[j] + DR_FLAGS) : 0u; c8[j] = i0 + j < n ? (uint32_t)AW(v8[j] + DR_COST) : 0u; }
+			for (uint32_t j = 0; j < 8u; j++) if (i0 + j < n) AW(key + i0 + j) = (c8[j] & 0xffffu) | (((f8[j] & BF_F_DONE) && !(f8[j] & BF_F_FOUND)) ? 0x10000u : 0u);
+		}
+		uint32_t rs = AW(d + CA_RND);
+		bool drew = false;
+		for (uint32_t i = 0; i < sz;) {
+			const uint32_t ki = AW(key + i);
+			if (ki >> 16) {
+				for (uint32_t k = i; k + 1u < n; k++) { AW(vec + k) = AW(vec + k + 1u); AW(key + k) = AW(key + k + 1u); }
+				n--; sz--;
+				continue;
+			}
+			uint32_t minCost = ki & 0xffffu, minOff = i;
+			for (uint32_t j0 = i + 1u; j0 < sz; j0 += 8u) {
+				uint32_t k8[8];
+				for (uint32_t j = 0; j < 8u; j++) k8[j] = j0 + j < sz ? (uint32_t)AW(key + j0 + j) : 0x10000u;
+				for (uint32_t j = 0; j < 8u; j++) {
+					if (k8[j] >> 16) continue;
+					const uint32_t cj = k8[j] & 0xffffu;
+					if (cj < minCost) { minCost = cj; minOff = j0 + j; }
+					else if (cj == minCost) { drew = true; if (bf_rnd(rs) & 0x1000u) minOff = j0 + j; }
+				}
+			}
+			if (i != minOff) {
+				uint32_t t = AW(vec + i); AW(vec + i) = AW(vec + minOff); AW(vec + minOff) = t;
+				t = AW(key + i); AW(key + i) = AW(key + minOff); AW(key + minOff) = t;
+			}
+			i++;
+		}
+		if (drew) AW(d + CA_RND) = rs;
+		AW(d + CA_NACT) = n;
+		if (AW(d + CA_DELAYED) == 0 && sz > 0) dr_set_mincost(X, d, (uint32_t)AW(key) & 0xffffu);
 		return;
 	}
 #endif
