@@ -65,6 +65,13 @@
 #ifndef BF_FAST_GATHER
 #define BF_FAST_GATHER BF_FAST_EXTEND
 #endif
+/* another part that can be measured apart: the aligner's driver is advanced by bf_advance_top, which walks down to the
+ * leaf that is due (the first halves of cost_advance / seeded_advance), advances it at ONE place in the code, and walks
+ * back up (their second halves) -- so that the lanes of a wavefront, each with its own leaf, run their extension loops
+ * together whichever kind of node the leaf hangs from */
+#ifndef BF_ONE_LEAF_SITE
+#define BF_ONE_LEAF_SITE BF_FAST_EXTEND
+#endif
 #define BF_IS_V1(P) ((P).paired == 2u)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
@@ -1600,6 +1607,130 @@ BF_FN uint32_t child_range(BfLane& X, uint32_t d)
 	return d;
 }
 
+#if BF_ONE_LEAF_SITE
+/* cost_advance from the return of child_advance on: foundFirstRange, sortActives (range_source.h:2186-2210) */
+template <int LEVEL> BF_FN void cost_advance_post(BfLane& X, uint32_t d, uint32_t p, uint32_t precost)
+{
+	bool needsSort = false;
+	if (dr_found(X, p)) {
+		const uint32_t r = child_range(X, p);
+		needsSort = cost_found_first_range<LEVEL>(X, d, r, dr_fw(X, p), dr_mate(X, p));
+		dr_set(X, p, BF_F_FOUND, false);
+	}
+	if (dr_done(X, p) || precost != dr_mincost(X, p) || needsSort) {
+		cost_sort_actives(X, d);
+		if (cost_mate_eliminated<LEVEL>(X, d) || AW(d + CA_NACT) == 0) { AW(d + CA_NACT) = 0; dr_set(X, d, BF_F_DONE, AW(d + CA_DELAYED) == 0); }
+	}
+}
+/* seeded_advance from the return of leaf_advance(seed) on (ebwt_search_backtrack.h:3049-3083) */
+BF_FN void seeded_post_seed(BfLane& X, uint32_t d, uint32_t seed, uint32_t full)
+{
+	if (dr_found(X, seed)) {
+		dr_set(X, seed, BF_F_FOUND, false);
+		const uint32_t scost = AW(seed + LF_CURCOST) & 0xffffu;
+		AW(d + DR_COST) = dr_mincost(X, d) | (scost << 16);
+		const uint32_t part = bf_alloc(X, BF_DRW);
+		if (X.ovf) return;
+		leaf_init(X, part, AW(d + SD_FACT));
+		AW(full + CA_LAST) = 0; AW(full + CA_DELAYED) = 0; dr_set(X, full, BF_F_DONE, false);
+		leaf_set_query(X, part, seed);
+		cost_add_rss(X, full, part);
+		if (X.ovf) return;
+		const uint32_t na = AW(full + CA_NACT);
+		AW(AW(full + CA_ACT) + na) = part; AW(full + CA_NACT) = na + 1u;
+		dr_set_mincost(X, full, 0);
+		cost_sort_actives(X, full);
+		if (dr_found(X, full)) { dr_set(X, d, BF_F_FOUND, true); dr_set(X, full, BF_F_FOUND, false); }
+	}
+	if (dr_mincost(X, seed) > dr_mincost(X, d)) {
+		uint32_t mc = dr_mincost(X, seed);
+		if (!dr_done(X, full) && dr_mincost(X, full) < mc) mc = dr_mincost(X, full);
+		dr_set_mincost(X, d, mc);
+	}
+}
+/* seeded_advance from the return of cost_advance<1>(full) on (:3085-3100) */
+BF_FN void seeded_post_full(BfLane& X, uint32_t d, uint32_t seed, uint32_t full, uint32_t old)
+{
+	if (dr_found(X, full)) { dr_set(X, d, BF_F_FOUND, true); dr_set(X, full, BF_F_FOUND, false); }
+	if (dr_mincost(X, full) > old) {
+		const uint32_t a = dr_mincost(X, full), b = dr_mincost(X, seed);
+		dr_set_mincost(X, d, a < b ? a : b);
+	}
+}
+/* cost_advance<0>(d) -- the aligner's own driver -- with the leaf it gets to advanced at one place (see BF_ONE_LEAF_SITE):
+ * statement for statement cost_advance<0>, child_advance<0>, seeded_advance and cost_advance<1> up to their calls,
+ * the call, then what follows it in each, innermost first */
+BF_FN void bf_advance_top(BfLane& X, uint32_t d)
+{
+	/* cost_advance<0>, first half */
+	AW(d + CA_LAST) = 0;
+	const uint32_t actSz = AW(d + CA_NACT);
+	if (AW(d + CA_DELAYED)) {
+		AW(d + CA_LAST) = AW(d + CA_DELAYED); AW(d + CA_DELAYED) = 0;
+		dr_set(X, d, BF_F_FOUND, true);
+		if (actSz > 0) { const uint32_t a0 = dr_mincost(X, AW(AW(d + CA_ACT))); if (a0 > dr_mincost(X, d)) dr_set_mincost(X, d, a0); }
+		else dr_set(X, d, BF_F_DONE, true);
+		return;
+	}
+	if (cost_mate_eliminated<0>(X, d) || actSz == 0) { AW(d + CA_NACT) = 0; dr_set(X, d, BF_F_DONE, true); return; }
+	const uint32_t p = AW(AW(d + CA_ACT));
+	const uint32_t precost = dr_mincost(X, p);
+	uint32_t leaf = 0, seed = 0, full = 0, old = 0, p2 = 0, precost1 = 0;
+	enum { NONE, SEED_BRANCH, FULL_BRANCH, FULL_CHILD };
+	uint32_t after = NONE;                                 /* which second halves are due once the leaf has been advanced */
+	if (!dr_found(X, p)) {
+		if (dr_kind(X, p) != BF_SEEDED) leaf = p;          /* child_advance<0>: a leaf */
+		else {
+			/* seeded_advance(p), first half */
+			seed = AW(p + SD_SEED); full = AW(p + SD_FULL);
+			bool back = false;
+			if (dr_done(X, seed) && dr_done(X, full) && !dr_found(X, seed) && !dr_found(X, full)) { dr_set(X, p, BF_F_DONE, true); back = true; }
+			if (!back && dr_done(X, seed) && !dr_found(X, seed)) {
+				dr_set_mincost(X, seed, 0xffffu);
+				if (dr_mincost(X, full) > dr_mincost(X, p)) { dr_set_mincost(X, p, dr_mincost(X, full)); back = true; }
+			}
+			if (!back && dr_done(X, full) && !dr_found(X, full)) {
+				dr_set_mincost(X, full, 0xffffu);
+				if (dr_mincost(X, seed) > dr_mincost(X, p)) { dr_set_mincost(X, p, dr_mincost(X, seed)); back = true; }
+			}
+			if (!back) {
+				if (dr_mincost(X, full) > dr_mincost(X, seed)) {
+					after = SEED_BRANCH;
+					if (!dr_found(X, seed)) leaf = seed;
+				} else {
+					after = FULL_BRANCH;
+					old = dr_mincost(X, full);
+					if (!dr_found(X, full)) {
+						/* cost_advance<1>(full), first half (no mates to eliminate below the aligner's driver) */
+						AW(full + CA_LAST) = 0;
+						const uint32_t actSz1 = AW(full + CA_NACT);
+						if (AW(full + CA_DELAYED)) {
+							AW(full + CA_LAST) = AW(full + CA_DELAYED); AW(full + CA_DELAYED) = 0;
+							dr_set(X, full, BF_F_FOUND, true);
+							if (actSz1 > 0) { const uint32_t a0 = dr_mincost(X, AW(AW(full + CA_ACT))); if (a0 > dr_mincost(X, full)) dr_set_mincost(X, full, a0); }
+							else dr_set(X, full, BF_F_DONE, true);
+						} else if (actSz1 == 0) { AW(full + CA_NACT) = 0; dr_set(X, full, BF_F_DONE, true); }
+						else {
+							after = FULL_CHILD;
+							p2 = AW(AW(full + CA_ACT));
+							precost1 = dr_mincost(X, p2);
+							if (!dr_found(X, p2)) leaf = p2;       /* child_advance<1>: always a leaf */
+						}
+					}
+				}
+			}
+		}
+	}
+	/* the one place */
+	if (leaf) leaf_advance(X, leaf);
+	/* second halves, innermost first */
+	if (after == FULL_CHILD) { cost_advance_post<1>(X, full, p2, precost1); after = FULL_BRANCH; }
+	if (after == FULL_BRANCH) seeded_post_full(X, p, seed, full, old);
+	else if (after == SEED_BRANCH) seeded_post_seed(X, p, seed, full);
+	cost_advance_post<0>(X, d, p, precost);
+}
+#endif
+
 /* the static part of the tree (Unpaired*Factory::create()) */
 BF_FN uint32_t bf_build_tree(BfLane& X)
 {
@@ -1666,6 +1797,12 @@ BF_FN void bf_build_tree_v1(BfLane& X, uint32_t tops[4])
 		cost_add_rss(X, tops[sp.mate * 2u + (sp.fw ? 0u : 1u)], d);
 	}
 }
+#endif
+
+#if BF_ONE_LEAF_SITE
+#define BF_ADVANCE_TOP(X, d) bf_advance_top(X, d)
+#else
+#define BF_ADVANCE_TOP(X, d) cost_advance<0>(X, d)
 #endif
 
 /* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
@@ -1904,7 +2041,7 @@ BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 					else dr_set(X, drv, BF_F_FOUND, false);
 				} else {
 					done = bf_irrelevant(X, dr_mincost(X, drv));
-					if (!done) cost_advance<0>(X, drv);
+					if (!done) BF_ADVANCE_TOP(X, drv);
 				}
 				if (dr_done(X, drv) && !dr_found(X, drv) && !chase) done = true;
 			}
@@ -2109,7 +2246,7 @@ BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 			if (!done && !chase) {
 				if (!dr_done(X, drv)) {
 					done = bf_irrelevant(X, dr_mincost(X, drv));
-					if (!done) cost_advance<0>(X, drv);
+					if (!done) BF_ADVANCE_TOP(X, drv);
 					if (dr_found(X, drv)) {
 						chase = true;
 						dr_set(X, drv, BF_F_FOUND, false);
@@ -2205,7 +2342,7 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
 				bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
 				if (V1_DONE(drOther) && szOther == 0) { donePair = true; continue; }     /* no pair in this orientation */
-				if (!dr_found(X, drMe)) cost_advance<0>(X, drMe);
+				if (!dr_found(X, drMe)) BF_ADVANCE_TOP(X, drMe);
 				if (dr_found(X, drMe)) {
 					const uint32_t leaf = AW(drMe + CA_LAST);
 					szMe += AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP);
