@@ -11,7 +11,9 @@ export TMPDIR=/tmp
 O=gpurun_out/r4a; mkdir -p $O
 S=$O/SUMMARY.txt; : > $S
 say() { echo "$*" | tee -a $S; }
-make -s -C bowtie_amd/csrc variants > $O/make.txt 2>&1 || say "make variants failed: $(tail -2 $O/make.txt)"
+# the variant libraries travel with the snapshot when they were built before the call (make -C bowtie_amd/csrc variants, ~4 min:
+# do that on the CPU side, after the last source change); built here only if missing
+[ -f bowtie_amd/libbowtie_amd_fastext.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_ng.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_ms.so ] || { make -s -C bowtie_amd/csrc variants > $O/make.txt 2>&1 || say "make variants failed: $(tail -2 $O/make.txt)"; }
 val() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('%.3f M reads/s, %.1f ms/step' % (d['value']/1e6, d['ms_per_step']))" 2>&1 | tail -1; }
 
 # ---- 1. fast extend ----
