@@ -19,9 +19,12 @@ val() { python -c "import json,sys; d=json.loads(open('$1').read().strip().split
 # ---- 1. fast extend ----
 BT_LIB=libbowtie_amd_fastext.so timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py -m gpu -q -x -k "best or paired or config5 or v3 or M3 or strata" > $O/fastext_parity.txt 2>&1
 say "fast-extend library, best-first / paired GPU tests: $(tail -1 $O/fastext_parity.txt)"
-for lib in libbowtie_amd.so libbowtie_amd_fastext.so libbowtie_amd_fastext_ng.so libbowtie_amd_fastext_ms.so; do
+for lib in libbowtie_amd.so libbowtie_amd_fastext.so; do
 	f=$O/bench_big_pe_$lib; BT_LIB=$lib timeout 240 python bench.py --workload big_pe_n1_best_50 --steps 2 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib big_pe_n1_best_50 (round 3: 3.29 M reads/s): $(val $f.json)"
 	f=$O/bench_big_n2_best_$lib; BT_LIB=$lib timeout 300 python bench.py --workload big_n2_best_100 --reads 16000000 --steps 2 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib big_n2_best_100 16 M reads (round 3: 0.85 M reads/s): $(val $f.json)"
+done
+# the parts of the switch apart (_ng: no driver-level gathers, _ms: the reference's several leaf call sites), on the quick workloads
+for lib in libbowtie_amd.so libbowtie_amd_fastext.so libbowtie_amd_fastext_ng.so libbowtie_amd_fastext_ms.so; do
 	for wl in ecoli_n2_best_100 ecoli_pe_n1_best_50; do f=$O/bench_${wl}_$lib; BT_LIB=$lib timeout 120 python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib $wl (round 3: 6.6 / 30.8 M): $(val $f.json)"; done
 done
 
