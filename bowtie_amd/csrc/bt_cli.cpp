@@ -575,6 +575,7 @@ struct Job {
 	std::vector<uint8_t> status;
 	std::vector<uint16_t> mm_pool;
 	uint32_t mm_used = 0;
+	bool prepared = false;                   /* search_prepare has sized the four arrays for this batch */
 	bt_hit_batch hb;                         /* view into the four arrays above (what the search fills) */
 	/* reads whose hits did not fit the uniform slots: searched again alone with room for all */
 	struct Wide { uint32_t read; uint32_t hit_cap; std::vector<bt_hit> hits; std::vector<uint16_t> pool; uint32_t n_hits; uint8_t status; };
@@ -701,6 +702,8 @@ std::string search_job_pairs(bt_ctx* ctx, const Options& O, Job* j)
 /* size a job's result arrays for the first pass */
 void search_prepare(const Options& O, Job* j)
 {
+	if (j->prepared) return;
+	j->prepared = true;
 	const uint32_t n = j->rb.n_reads;
 	const bool all = O.pol.all_hits != 0;
 	j->hit_cap = all ? 16u : (O.pol.khits > 64u ? 64u : O.pol.khits);
@@ -893,6 +896,10 @@ int main(int argc, char** argv)
 	double busy_read = 0, busy_write = 0;
 	std::atomic<bool> abort_run(false);
 	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
+	/* ... and result arrays: a batch's four arrays (some 150 MB for 4 M reads) keep their memory from batch to batch */
+	struct ResultBufs { std::vector<bt_hit> hits; std::vector<uint32_t> n_hits; std::vector<uint8_t> status; std::vector<uint16_t> mm_pool; };
+	Chan<std::unique_ptr<ResultBufs>> spare_res(8);
+	const bool will_stream = !O.paired && !O.pol.best && !O.no_stream;      /* what `streamed` below says once the index is there */
 	/* one batch from the input into a job: returns BT_OK or the error it left in j->error */
 	auto read_job = [&](Job* j) -> int {
 		if (!spare.try_take(&j->store)) j->store.reset(new BtHostBatch());
@@ -928,6 +935,15 @@ int main(int argc, char** argv)
 				if (u->store->n) { u->rb = u->store->view(); j->unp = std::move(u); }
 				else j->order.clear();
 			}
+		}
+		if (r == BT_OK && will_stream && j->rb.n_reads) {
+			/* the streamed searcher's thread is the one the GPU waits for: the batch's result arrays are sized here, on the
+			 * reader's thread, out of recycled memory */
+			const double tp = now_s();
+			std::unique_ptr<ResultBufs> rbuf;
+			if (spare_res.try_take(&rbuf)) { j->hits.swap(rbuf->hits); j->n_hits.swap(rbuf->n_hits); j->status.swap(rbuf->status); j->mm_pool.swap(rbuf->mm_pool); }
+			search_prepare(O, j);
+			busy_read += now_s() - tp;
 		}
 		return r;
 	};
@@ -1278,6 +1294,11 @@ int main(int argc, char** argv)
 			busy_write += now_s() - tb;
 			g_tl.mark("write: done", j->seq);
 			j->wide.clear();
+			if (will_stream) {
+				std::unique_ptr<ResultBufs> rbuf(new ResultBufs());
+				rbuf->hits.swap(j->hits); rbuf->n_hits.swap(j->n_hits); rbuf->status.swap(j->status); rbuf->mm_pool.swap(j->mm_pool);
+				spare_res.try_put(rbuf);
+			}
 			spare.try_put(j->store);
 		}
 	});
