@@ -2082,9 +2082,38 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 	const bool packed = qlen <= 64u;
 	uint64_t rq[2] = {0, 0}, rn[2] = {0, 0}, sm[2] = {0, 0}, lm[2] = {0, 0};
 	uint64_t W[2][3] = {{0, 0, 0}, {0, 0, 0}}, N[2][2] = {{0, 0}, {0, 0}}, K[2] = {~0ull, ~0ull};
+#if BF_FAST_EXTEND
+	/* the mate's bases (and, for -n, qualities) as they are stored, in registers: 16-byte pieces of its rows instead of a
+	 * fetch per character here and in the base-by-base decision below */
+	uint32_t mw[16], qw[16];
+	for (uint32_t k = 0; k < 16u; k++) { mw[k] = 0; qw[k] = 0; }
+	if (packed) {
+		for (uint32_t c = 0; c * 16u < qlen; c++) {
+			const BtU4 v = bt_ld4((const void*)(M.seq + 16u * c));
+			mw[4u * c] = v.x; mw[4u * c + 1u] = v.y; mw[4u * c + 2u] = v.z; mw[4u * c + 3u] = v.w;
+			if (P.refSeeded) {
+				const BtU4 u = bt_ld4((const void*)(M.qual + 16u * c));
+				qw[4u * c] = u.x; qw[4u * c + 1u] = u.y; qw[4u * c + 2u] = u.z; qw[4u * c + 3u] = u.w;
+			}
+		}
+	}
+	auto mbase = [&](uint32_t j) -> uint32_t {             /* bf_base(M, fw, 1, j) */
+		const uint32_t idx = fw ? j : qlen - 1u - j;
+		const uint32_t c = (mw[idx >> 2] >> (8u * (idx & 3u))) & 0xffu;
+		return (!fw && c < 4u) ? (c ^ 3u) : c;
+	};
+	auto mqual = [&](uint32_t j) -> uint32_t {             /* bf_qualc(M, fw, 1, j) */
+		const uint32_t idx = fw ? j : qlen - 1u - j;
+		return (qw[idx >> 2] >> (8u * (idx & 3u))) & 0xffu;
+	};
+#endif
 	if (packed) {
 		for (uint32_t j = 0; j < qlen; j++) {
+#if BF_FAST_EXTEND
+			const uint32_t q = mbase(j);
+#else
 			const uint32_t q = bf_base(M, fw, 1u, j);
+#endif
 			const uint64_t bit = 1ull << (2u * (j & 31u));
 			if (q < 4u) rq[j >> 5] |= (uint64_t)q << (2u * (j & 31u)); else rn[j >> 5] |= bit;
 			lm[j >> 5] |= bit;
@@ -2092,6 +2121,9 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 		}
 	}
 	const uint64_t nspan = qlen >= 64u ? ~0ull : ((1ull << qlen) - 1ull);
+#if BF_FAST_EXTEND
+	uint64_t pm0 = 0, pm1 = 0, pa0 = 0, pa1 = 0;           /* the candidate's mismatch masks and reference words */
+#endif
 	bool hi = false;
 	for (uint32_t i = 1; i <= lim + 1u; i++) {
 		const uint32_t ri = hi ? halfway + (i >> 1) : halfway - (i >> 1);
@@ -2114,9 +2146,34 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 			const uint64_t m0 = (((x0 | (x0 >> 1)) & 0x5555555555555555ull) | rn[0]) & lm[0];
 			const uint64_t m1 = (((x1 | (x1 >> 1)) & 0x5555555555555555ull) | rn[1]) & lm[1];
 			if ((uint32_t)__builtin_popcountll(m0 & sm[0]) + (uint32_t)__builtin_popcountll(m1 & sm[1]) > P.refMms) continue;
+#if BF_FAST_EXTEND
+			pm0 = m0; pm1 = m1; pa0 = a0; pa1 = a1;
+#endif
 		}
 		bool match = true;
 		uint32_t mms = 0, seedMms = 0, ham = 0;
+#if BF_FAST_EXTEND
+		if (packed) {
+			/* the same decision from the registers: the mismatching offsets are the set bits of the two masks, in ascending
+			 * order; the reference has no N under the mate (checked above) */
+			for (uint32_t w = 0; w < 2u && match; w++) {
+				uint64_t bits = w ? pm1 : pm0;
+				const uint64_t aw = w ? pa1 : pa0;
+				while (bits) {
+					const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+					bits &= bits - 1ull;
+					const uint32_t j = 32u * w + (b >> 1), rc = (uint32_t)(aw >> b) & 3u;
+					const bool inSeed = fw ? (j < slen) : (j >= qlen - slen);
+					if (inSeed && ++seedMms > P.refMms) { match = false; break; }
+					if (P.refSeeded) {
+						ham += bt_mm_penalty(P.maq, bf_phred(mqual(j)));
+						if (ham > P.refQualMax) { match = false; break; }
+					}
+					AW(mmBuf + mms) = j | (rc << 16); mms++;
+				}
+			}
+		} else
+#endif
 		for (uint32_t j = 0; j < qlen; j++) {
 			const uint32_t rc = ref_base(rf, base + ri + j);
 			if (rc & 4u) { match = false; break; }
