@@ -888,7 +888,7 @@ int main(int argc, char** argv)
 	BtReadStream* rs = nullptr; BtReadStream* rs2 = nullptr;
 	/* BT_CLI_PINNED=1: read batches live in page-locked memory from the library, so that bt_align_stream_submit's uploads
 	 * are DMAs beside the running search (not the default until it has been measured on the GPU) */
-	if (getenv("BT_CLI_PINNED") && atoi(getenv("BT_CLI_PINNED")) != 0) bt_io_set_allocator(bt_host_alloc, bt_host_free);
+	if (getenv("BT_CLI_PINNED") && atoi(getenv("BT_CLI_PINNED")) != 0) bt_io_set_allocator(bt_host_alloc, bt_host_free);          /* see `pinned` below */
 	open_read_streams(O, &rs, &rs2);
 	const bool tabbed = O.rd.format == BT_FMT_TABBED;
 	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
@@ -949,7 +949,19 @@ int main(int argc, char** argv)
 	};
 	std::unique_ptr<Job> first_job(new Job());
 	int first_rc = BT_OK;
-	std::thread prefetch([&] { first_rc = read_job(first_job.get()); });
+	const bool pinned = getenv("BT_CLI_PINNED") && atoi(getenv("BT_CLI_PINNED")) != 0;
+	std::thread prefetch([&] {
+		first_rc = read_job(first_job.get());
+		/* page-locking a batch's memory takes a good part of the time it takes to parse one: with BT_CLI_PINNED the batches
+		 * that will be recycled for the rest of the run are made here, while the index loads, not one per batch later */
+		if (pinned && first_rc == BT_OK && !O.paired && first_job->rb.n_reads == O.batch_reads)
+			for (int k = 0; k < 5; k++) {
+				std::unique_ptr<BtHostBatch> b(new BtHostBatch());
+				b->reset(first_job->rb.n_reads, first_job->rb.stride);
+				b->n = 0;
+				if (!spare.try_put(b)) break;
+			}
+	});
 
 	/* ---- index into HBM ---- */
 	const std::string base = find_index(O.index);
