@@ -72,6 +72,12 @@
 #ifndef BF_ONE_LEAF_SITE
 #define BF_ONE_LEAF_SITE BF_FAST_EXTEND
 #endif
+/* and another: a read's run as begin / one turn of its loop / end (bf_run_begin, bf_run_step, bf_run_end), so that the
+ * kernel can give a lane its next read while the wavefront's other lanes are still on theirs, instead of the whole
+ * wavefront waiting for its slowest read before any lane takes a new one */
+#ifndef BF_REFILL
+#define BF_REFILL BF_FAST_EXTEND
+#endif
 #define BF_IS_V1(P) ((P).paired == 2u)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
@@ -2420,6 +2426,237 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 #undef V1_DONE
 	}
 	bf_read_end(X, B, 2u);
+}
+#endif
+
+#if BF_REFILL
+/* ---- the three runners above, resumable: the same statements, the loops' locals in a struct ------------------------ */
+struct BfRun {
+	uint32_t kind;                /* 0 idle, 1 bf_run_read, 2 bf_run_pair, 3 bf_run_pair_v1 */
+	uint32_t live;                /* the loop is to be gone through (the read was long enough, the tree fitted) */
+	BfChase ch;
+	bool done, chase;
+	uint32_t drv;
+	uint32_t pairsFw, pairsRc, mmBuf, attempts;
+	BfV1Orient O[2];
+	uint32_t o, qlen1, qlen2, symCeil;
+	bool doneFw, doneFwFirst;
+	uint32_t c0[9];               /* the lane's op counters when the read began (a read that overflows is not tallied) */
+};
+
+BF_FN void bf_run_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfRun& R, uint32_t kind)
+{
+	R.kind = kind; R.live = 0; R.done = true; R.chase = false; R.attempts = 0;
+	R.c0[0] = X.c_lfex; R.c0[1] = X.c_lf2; R.c0[2] = X.c_lf1; R.c0[3] = X.c_chase; R.c0[4] = X.c_ftab;
+	R.c0[5] = X.c_offs; R.c0[6] = X.c_rst; R.c0[7] = X.c_same; R.c0[8] = X.c_frames;
+	bf_read_begin(X, B, rd);
+	if (X.R[0].len < 4u || (kind != 1u && X.R[1].len < 4u)) { X.status |= BT_STF_SKIPPED; return; }
+	R.live = 1;
+	bf_chase_init(R.ch);
+	if (kind == 1u) {
+		R.drv = bf_build_tree(X);
+		if (!X.ovf) { cost_set_query<0>(X, R.drv); R.done = dr_done(X, R.drv); }
+		return;
+	}
+	const uint32_t maxLen = X.R[0].len > X.R[1].len ? X.R[0].len : X.R[1].len;
+	if (kind == 2u) {
+		R.drv = bf_build_tree(X);
+		R.pairsFw = bf_alloc(X, 3); R.pairsRc = bf_alloc(X, 3); R.mmBuf = bf_alloc(X, maxLen);
+		if (!X.ovf) {
+			AW(R.pairsFw) = AW(R.pairsFw + 1u) = AW(R.pairsFw + 2u) = 0; AW(R.pairsRc) = AW(R.pairsRc + 1u) = AW(R.pairsRc + 2u) = 0;
+			cost_set_query<0>(X, R.drv);
+			R.done = false;
+		}
+		return;
+	}
+#if BF_HAVE_V1
+	const BfProgram& P = *X.P;
+	uint32_t tops[4];
+	bf_build_tree_v1(X, tops);
+	R.pairsFw = bf_alloc(X, 3); R.pairsRc = bf_alloc(X, 3); R.mmBuf = bf_alloc(X, maxLen);
+	if (!X.ovf) {
+		AW(R.pairsFw) = AW(R.pairsFw + 1u) = AW(R.pairsFw + 2u) = 0; AW(R.pairsRc) = AW(R.pairsRc + 1u) = AW(R.pairsRc + 2u) = 0;
+		for (uint32_t b = 0; b < 4u && !X.ovf; b++) if (tops[b]) cost_set_query<0>(X, tops[b]);
+		R.done = false;
+	}
+	const bool fw1 = P.mate1Fw != 0, fw2 = P.mate2Fw != 0;
+	R.O[0].drL = fw1 ? tops[0] : tops[1]; R.O[0].drR = fw2 ? tops[2] : tops[3];      /* aligner.h:670-682 */
+	R.O[1].drL = fw2 ? tops[3] : tops[2]; R.O[1].drR = fw1 ? tops[1] : tops[0];      /* aligner.h:684-696 */
+	for (int k = 0; k < 2; k++) { R.O[k].chaseL = R.O[k].chaseR = R.O[k].delayedL = R.O[k].delayedR = false; R.O[k].szL = R.O[k].szR = 0; }
+	R.qlen1 = X.R[0].len; R.qlen2 = X.R[1].len;
+	R.symCeil = P.sinkMax == 0xffffffffu ? 0xffffffffu : P.sinkMax / 2u;   /* -m ("mhits, // for symCeiling") */
+	R.o = 0; R.doneFw = false; R.doneFwFirst = true;
+#endif
+}
+
+/* one turn of bf_run_read's loop; false: the loop's condition no longer holds */
+BF_FN bool bf_step_read(BfLane& X, const BtBatchDev& B, BfRun& R)
+{
+	if (R.done || X.ovf) return false;
+	BfChase& ch = R.ch;
+	const uint32_t drv = R.drv;
+	if (R.chase) {
+		if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); return true; }
+		if (ch.tidx != BT_OFF_MASK) {
+			const uint32_t leaf = AW(drv + CA_LAST);
+			R.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+			                        !leaf_spec(X, leaf).mirror);
+			ch.tidx = BT_OFF_MASK;
+		} else {
+			R.chase = false;
+			dr_set(X, drv, BF_F_FOUND, false);
+			R.done = dr_done(X, drv);
+		}
+	}
+	if (!R.done && !R.chase) {
+		if (dr_found(X, drv)) {
+			const uint32_t leaf = AW(drv + CA_LAST);
+			const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
+			ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
+			if (ch.tidx != BT_OFF_MASK) {
+				R.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+				                        !leaf_spec(X, leaf).mirror);
+				ch.tidx = BT_OFF_MASK;
+			}
+			if (!ch.done && !bf_irrelevant(X, cost)) R.chase = true;
+			else dr_set(X, drv, BF_F_FOUND, false);
+		} else {
+			R.done = bf_irrelevant(X, dr_mincost(X, drv));
+			if (!R.done) BF_ADVANCE_TOP(X, drv);
+		}
+		if (dr_done(X, drv) && !dr_found(X, drv) && !R.chase) R.done = true;
+	}
+	return true;
+}
+
+/* one turn of bf_run_pair's loop */
+BF_FN bool bf_step_pair(BfLane& X, const BtBatchDev& B, BfRun& R)
+{
+	if (R.done || X.ovf) return false;
+	BfChase& ch = R.ch;
+	const uint32_t drv = R.drv;
+	if (R.chase) {
+		if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); return true; }
+		if (ch.tidx != BT_OFF_MASK) {
+			/* resolveOutstanding (aligner.h:1849-1871) */
+			const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, R.pairsFw, R.pairsRc, R.mmBuf);
+			if (++R.attempts > X.P->pairTries || ret) R.done = true;
+			ch.tidx = BT_OFF_MASK;
+		} else {
+			R.chase = false;
+			R.done = dr_done(X, drv);
+		}
+	}
+	if (!R.done && !R.chase) {
+		if (!dr_done(X, drv)) {
+			R.done = bf_irrelevant(X, dr_mincost(X, drv));
+			if (!R.done) BF_ADVANCE_TOP(X, drv);
+			if (dr_found(X, drv)) {
+				R.chase = true;
+				dr_set(X, drv, BF_F_FOUND, false);
+				const uint32_t leaf = AW(drv + CA_LAST);
+				const BfSpec& sp = leaf_spec(X, leaf);
+				ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
+			}
+		} else R.done = true;
+	}
+	return true;
+}
+
+#if BF_HAVE_V1
+/* one turn of bf_run_pair_v1's loop */
+BF_FN bool bf_step_pair_v1(BfLane& X, const BtBatchDev& B, BfRun& R)
+{
+	if (R.done || X.ovf) return false;
+	const BfProgram& P = *X.P;
+	BfChase& ch = R.ch;
+	bool& done = R.done;
+	bool& doneFw = R.doneFw;
+	const uint32_t qlen1 = R.qlen1, qlen2 = R.qlen2, symCeil = R.symCeil;
+#define V1_DONE(d)  ((d) == 0u || dr_done(X, (d)))
+	auto chase_range_of = [&](uint32_t top, uint32_t qlen) {
+		const uint32_t leaf = AW(top + CA_LAST);
+		ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, qlen);
+	};
+	if (doneFw && R.doneFwFirst) { R.o = 1; R.doneFwFirst = false; R.attempts = 0; }
+	BfV1Orient& Q = R.O[R.o];
+	if ((Q.chaseL || Q.chaseR) && ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); return true; }
+	bool& donePair = (R.o == 0) ? doneFw : done;
+	bool returned = false;
+	if (Q.chaseL || Q.chaseR) {
+		const bool sideL = Q.chaseL;
+		const uint32_t drMe = sideL ? Q.drL : Q.drR, drOther = sideL ? Q.drR : Q.drL;
+		bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
+		bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
+		bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
+		if (ch.tidx != BT_OFF_MASK) {
+			if (!done) {
+				done = bf_resolve_in_ref(X, B, AW(drMe + CA_LAST), ch.tidx, ch.toff, R.pairsFw, R.pairsRc, R.mmBuf);
+				if (++R.attempts > P.pairTries) { donePair = true; returned = true; }
+			}
+			if (!returned) ch.tidx = BT_OFF_MASK;                       /* rchase_->reset() */
+		} else {
+			chaseMe = false;
+			dr_set(X, drMe, BF_F_FOUND, false);
+			if (delayedOther) {
+				chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
+				chaseOther = true; delayedOther = false;
+			}
+		}
+	}
+	if (returned) return true;
+	if (!done && !donePair && !Q.chaseL && !Q.chaseR) {
+		bool sideL;
+		if ((Q.szL < Q.szR || V1_DONE(Q.drR)) && !V1_DONE(Q.drL)) sideL = true;
+		else if (!V1_DONE(Q.drR)) sideL = false;
+		else { donePair = true; return true; }
+		const uint32_t drMe = sideL ? Q.drL : Q.drR, drOther = sideL ? Q.drR : Q.drL;
+		uint32_t& szMe = sideL ? Q.szL : Q.szR;
+		uint32_t& szOther = sideL ? Q.szR : Q.szL;
+		bool& delayedMe = sideL ? Q.delayedL : Q.delayedR;
+		bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
+		bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
+		bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
+		if (V1_DONE(drOther) && szOther == 0) { donePair = true; return true; }     /* no pair in this orientation */
+		if (!dr_found(X, drMe)) BF_ADVANCE_TOP(X, drMe);
+		if (dr_found(X, drMe)) {
+			const uint32_t leaf = AW(drMe + CA_LAST);
+			szMe += AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP);
+			if (szOther == 0 && szMe > 3u) delayedMe = true;                     /* dontReconcile_: aligner.h:1233 */
+			else {
+				if (szMe > symCeil && szOther > symCeil) { donePair = true; return true; }
+				if (delayedOther && szOther < szMe) {
+					delayedOther = false; delayedMe = true; chaseOther = true;
+					chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
+				} else {
+					chaseMe = true;
+					chase_range_of(drMe, sideL ? (doneFw ? qlen2 : qlen1) : (doneFw ? qlen1 : qlen2));
+				}
+			}
+		}
+	}
+#undef V1_DONE
+	return true;
+}
+#endif
+
+BF_FN bool bf_run_step(BfLane& X, const BtBatchDev& B, BfRun& R)
+{
+	if (!R.live) return false;
+#if BF_HAVE_V1
+	if (R.kind == 3u) return bf_step_pair_v1(X, B, R);
+#endif
+	return R.kind == 2u ? bf_step_pair(X, B, R) : bf_step_read(X, B, R);
+}
+
+BF_FN void bf_run_end(BfLane& X, const BtBatchDev& B, BfRun& R)
+{
+	bf_read_end(X, B, R.kind == 1u ? 1u : 2u);
+	if (X.status & BT_STF_OVERFLOW) {
+		X.c_lfex = R.c0[0]; X.c_lf2 = R.c0[1]; X.c_lf1 = R.c0[2]; X.c_chase = R.c0[3]; X.c_ftab = R.c0[4];
+		X.c_offs = R.c0[5]; X.c_rst = R.c0[6]; X.c_same = R.c0[7]; X.c_frames = R.c0[8];
+	}
+	R.kind = 0;
 }
 #endif
 

@@ -13,7 +13,7 @@ S=$O/SUMMARY.txt; : > $S
 say() { echo "$*" | tee -a $S; }
 # the variant libraries travel with the snapshot when they were built before the call (make -C bowtie_amd/csrc variants, ~4 min:
 # do that on the CPU side, after the last source change); built here only if missing
-[ -f bowtie_amd/libbowtie_amd_fastext.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_ng.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_ms.so ] || { make -s -C bowtie_amd/csrc variants > $O/make.txt 2>&1 || say "make variants failed: $(tail -2 $O/make.txt)"; }
+[ -f bowtie_amd/libbowtie_amd_fastext.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_ng.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_ms.so ] && [ -f bowtie_amd/libbowtie_amd_fastext_nr.so ] || { make -s -C bowtie_amd/csrc variants > $O/make.txt 2>&1 || say "make variants failed: $(tail -2 $O/make.txt)"; }
 val() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('%.3f M reads/s, %.1f ms/step' % (d['value']/1e6, d['ms_per_step']))" 2>&1 | tail -1; }
 
 # ---- 1. fast extend ----
@@ -23,8 +23,9 @@ for lib in libbowtie_amd.so libbowtie_amd_fastext.so; do
 	f=$O/bench_big_pe_$lib; BT_LIB=$lib timeout 240 python bench.py --workload big_pe_n1_best_50 --steps 2 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib big_pe_n1_best_50 (round 3: 3.29 M reads/s): $(val $f.json)"
 	f=$O/bench_big_n2_best_$lib; BT_LIB=$lib timeout 300 python bench.py --workload big_n2_best_100 --reads 16000000 --steps 2 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib big_n2_best_100 16 M reads (round 3: 0.85 M reads/s): $(val $f.json)"
 done
-# the parts of the switch apart (_ng: no driver-level gathers, _ms: the reference's several leaf call sites), on the quick workloads
-for lib in libbowtie_amd.so libbowtie_amd_fastext.so libbowtie_amd_fastext_ng.so libbowtie_amd_fastext_ms.so; do
+# the parts of the switch apart (_ng: no driver-level gathers, _ms: the reference's several leaf call sites, _nr: reads handed
+# out a wavefront at a time), on the quick workloads
+for lib in libbowtie_amd.so libbowtie_amd_fastext.so libbowtie_amd_fastext_ng.so libbowtie_amd_fastext_ms.so libbowtie_amd_fastext_nr.so; do
 	for wl in ecoli_n2_best_100 ecoli_pe_n1_best_50; do f=$O/bench_${wl}_$lib; BT_LIB=$lib timeout 120 python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib $wl (round 3: 6.6 / 30.8 M): $(val $f.json)"; done
 done
 

@@ -211,7 +211,12 @@ static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, 
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
+#if BF_REFILL
+	/* the kernel's loop in that build: a read is begun, stepped through and ended */
+	{ BfRun R; for (uint32_t rd = 0; rd < in->n_reads; rd++) { bf_run_begin(X, B, rd, R, 1u); while (bf_run_step(X, B, R)) {} bf_run_end(X, B, R); } }
+#else
 	for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
+#endif
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
@@ -251,7 +256,11 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
+#if BF_REFILL
+	{ BfRun R; for (uint32_t rd = 0; rd < in1->n_reads; rd++) { bf_run_begin(X, B, rd, R, BF_IS_V1(P) ? 3u : 2u); while (bf_run_step(X, B, R)) {} bf_run_end(X, B, R); } }
+#else
 	for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
+#endif
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
