@@ -2496,7 +2496,8 @@ BF_FN bool bf_step_read(BfLane& X, const BtBatchDev& B, BfRun& R)
 	BfChase& ch = R.ch;
 	const uint32_t drv = R.drv;
 	if (R.chase) {
-		if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); return true; }
+		/* the reference's loop comes back here turn after turn until the walk has an answer: the same calls, in one go */
+		while (ch.tidx == BT_OFF_MASK && !ch.done) ch_advance(X, ch);
 		if (ch.tidx != BT_OFF_MASK) {
 			const uint32_t leaf = AW(drv + CA_LAST);
 			R.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
@@ -2536,7 +2537,8 @@ BF_FN bool bf_step_pair(BfLane& X, const BtBatchDev& B, BfRun& R)
 	BfChase& ch = R.ch;
 	const uint32_t drv = R.drv;
 	if (R.chase) {
-		if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); return true; }
+		/* the reference's loop comes back here turn after turn until the walk has an answer: the same calls, in one go */
+		while (ch.tidx == BT_OFF_MASK && !ch.done) ch_advance(X, ch);
 		if (ch.tidx != BT_OFF_MASK) {
 			/* resolveOutstanding (aligner.h:1849-1871) */
 			const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, R.pairsFw, R.pairsRc, R.mmBuf);
@@ -2580,7 +2582,7 @@ BF_FN bool bf_step_pair_v1(BfLane& X, const BtBatchDev& B, BfRun& R)
 	};
 	if (doneFw && R.doneFwFirst) { R.o = 1; R.doneFwFirst = false; R.attempts = 0; }
 	BfV1Orient& Q = R.O[R.o];
-	if ((Q.chaseL || Q.chaseR) && ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); return true; }
+	if (Q.chaseL || Q.chaseR) while (ch.tidx == BT_OFF_MASK && !ch.done) ch_advance(X, ch);      /* turn after turn in the reference's loop */
 	bool& donePair = (R.o == 0) ? doneFw : done;
 	bool returned = false;
 	if (Q.chaseL || Q.chaseR) {
