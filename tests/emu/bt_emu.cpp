@@ -191,6 +191,34 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	return BT_OK;
 }
 
+#if BF_REFILL
+/* bt_best_kernel's loop in the BF_REFILL build, for one "wavefront" of W lanes gone through side by side: lanes take a
+ * read when `least` of them wait for one (or none is working), step their reads turn by turn and leave when the cursor
+ * is dry -- the same decisions as the kernel's, its ballots being counts over the lanes still in the loop.  Checks what
+ * the kernel's loop has to get right: every read run exactly once, by some lane, and the loop ends. */
+static void emu_best_wave(std::vector<BfLane>& XS, const BtBatchDev& B, uint32_t n, uint32_t kind, uint32_t least)
+{
+	const size_t W = XS.size();
+	std::vector<BfRun> R(W);
+	std::vector<char> drained(W, 0), gone(W, 0);
+	for (auto& r : R) r.kind = 0;
+	uint32_t next = 0;
+	for (;;) {
+		uint32_t working = 0, waiting = 0, alive = 0;
+		for (size_t l = 0; l < W; l++) if (!gone[l]) { alive++; if (R[l].kind != 0) working++; else if (!drained[l]) waiting++; }
+		if (!alive) break;
+		for (size_t l = 0; l < W; l++) if (!gone[l] && R[l].kind == 0 && !drained[l] && (working == 0 || waiting >= least)) {
+			const uint32_t w = next++;
+			if (w >= n) drained[l] = 1; else bf_run_begin(XS[l], B, w, R[l], kind);
+		}
+		for (size_t l = 0; l < W; l++) if (!gone[l]) {
+			if (R[l].kind == 0) { if (drained[l]) gone[l] = 1; continue; }
+			if (!bf_run_step(XS[l], B, R[l])) bf_run_end(XS[l], B, R[l]);
+		}
+	}
+}
+#endif
+
 /* The best-first engine (bowtie_amd/csrc/bt_best.h), one read after the other, each in an arena of
  * arenaWords 32-bit words. */
 static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
@@ -207,14 +235,25 @@ static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, 
 	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
+#if BF_REFILL
+	/* the kernel's loop in that build, 24 lanes side by side (arenas from calloc: untouched pages cost nothing) */
+	const size_t W = in->n_reads < 24u ? (in->n_reads ? in->n_reads : 1u) : 24u;
+	uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
+	if (!arenas) return BT_ERR_DEVICE;
+	std::vector<BfLane> XS(W);
+	for (size_t l = 0; l < W; l++) { memset(&XS[l], 0, sizeof(BfLane)); XS[l].A = arenas + l * (size_t)arenaWords; XS[l].cap = arenaWords; XS[l].ix = e->d; XS[l].P = &P; }
+	emu_best_wave(XS, B, in->n_reads, 1u, 6u);
+	BfLane X = XS[0];
+	for (size_t l = 1; l < W; l++) {
+		X.c_lfex += XS[l].c_lfex; X.c_lf2 += XS[l].c_lf2; X.c_lf1 += XS[l].c_lf1; X.c_chase += XS[l].c_chase; X.c_ftab += XS[l].c_ftab;
+		X.c_offs += XS[l].c_offs; X.c_rst += XS[l].c_rst; X.c_same += XS[l].c_same; X.c_frames += XS[l].c_frames;
+	}
+	free(arenas);
+#else
 	std::vector<uint32_t> arena(arenaWords);
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
-#if BF_REFILL
-	/* the kernel's loop in that build: a read is begun, stepped through and ended */
-	{ BfRun R; for (uint32_t rd = 0; rd < in->n_reads; rd++) { bf_run_begin(X, B, rd, R, 1u); while (bf_run_step(X, B, R)) {} bf_run_end(X, B, R); } }
-#else
 	for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
 #endif
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
@@ -252,13 +291,24 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
 	if (arenaWords < 256u) arenaWords = 1u << 22;
+#if BF_REFILL
+	const size_t W = in1->n_reads < 24u ? (in1->n_reads ? in1->n_reads : 1u) : 24u;
+	uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
+	if (!arenas) return BT_ERR_DEVICE;
+	std::vector<BfLane> XS(W);
+	for (size_t l = 0; l < W; l++) { memset(&XS[l], 0, sizeof(BfLane)); XS[l].A = arenas + l * (size_t)arenaWords; XS[l].cap = arenaWords; XS[l].ix = e->d; XS[l].P = &P; XS[l].ref = &e->refd; }
+	emu_best_wave(XS, B, in1->n_reads, BF_IS_V1(P) ? 3u : 2u, 6u);
+	BfLane X = XS[0];
+	for (size_t l = 1; l < W; l++) {
+		X.c_lfex += XS[l].c_lfex; X.c_lf2 += XS[l].c_lf2; X.c_lf1 += XS[l].c_lf1; X.c_chase += XS[l].c_chase; X.c_ftab += XS[l].c_ftab;
+		X.c_offs += XS[l].c_offs; X.c_rst += XS[l].c_rst; X.c_same += XS[l].c_same; X.c_frames += XS[l].c_frames;
+	}
+	free(arenas);
+#else
 	std::vector<uint32_t> arena(arenaWords);
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
-#if BF_REFILL
-	{ BfRun R; for (uint32_t rd = 0; rd < in1->n_reads; rd++) { bf_run_begin(X, B, rd, R, BF_IS_V1(P) ? 3u : 2u); while (bf_run_step(X, B, R)) {} bf_run_end(X, B, R); } }
-#else
 	for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
 #endif
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
