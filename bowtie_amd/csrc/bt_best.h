@@ -905,8 +905,29 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		const bool skipInvalidExact = !sp.reportExacts && qlen == ftabChars;
 		const uint32_t d01 = r0 | (r1 << 16), d23 = r2 | (r3 << 16);
 		if (nsInFtab == 0 && m >= ftabChars && !skipInvalidExact) {
+#if BF_FAST_EXTEND
+			/* calcFtabOff (:2530-2544) on the query's last ftabChars characters taken from two 16-byte pieces of the stored
+			 * row (they are next to each other there, whichever way round the leaf reads it) instead of one fetch each */
+			uint32_t off;
+			{
+				const uint32_t a = qlen - ftabChars;                     /* offsets a .. qlen-1 */
+				const uint32_t lo = (sp.fw == ebwtFw) ? a : len - qlen, base16 = lo & ~15u;
+				const BtU4 v0 = bt_ld4((const void*)(R.seq + base16)), v1 = bt_ld4((const void*)(R.seq + base16 + (lo + ftabChars > base16 + 16u ? 16u : 0u)));
+				const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+				auto chr = [&](uint32_t i) -> uint32_t {               /* leaf_qry(i) for i in [a, qlen) */
+					const uint32_t sidx = ((sp.fw == ebwtFw) ? i : len - 1u - i) - base16;
+					uint32_t c = (w8[sidx >> 2] >> (8u * (sidx & 3u))) & 0xffu;
+					if (!sp.fw && c < 4u) c ^= 3u;
+					for (uint32_t k = 0; k < 3u; k++) if (k < sqN && len - (sqM[k] & 0xffffu) - 1u == i) c = sqM[k] >> 16;
+					return c;
+				};
+				off = chr(a);
+				for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | chr(qlen - i);
+			}
+#else
 			uint32_t off = BF_LQ(qlen - ftabChars);                /* calcFtabOff (:2530-2544) */
 			for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | BF_LQ(qlen - i);
+#endif
 			const uint32_t top = bt_ftab_hi(ix, off), bot = bt_ftab_lo(ix, off + 1u);
 			X.c_ftab++;
 			if (qlen == ftabChars && bot > top) {
