@@ -24,8 +24,8 @@ for lib in libbowtie_amd.so libbowtie_amd_fastext.so; do
 	f=$O/bench_big_n2_best_$lib; BT_LIB=$lib timeout 300 python bench.py --workload big_n2_best_100 --reads 16000000 --steps 2 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib big_n2_best_100 16 M reads (round 3: 0.85 M reads/s): $(val $f.json)"
 done
 # the parts of the switch apart (_ng: no driver-level gathers, _ms: the reference's several leaf call sites, _nr: reads handed
-# out a wavefront at a time), on the quick workloads
-for lib in libbowtie_amd.so libbowtie_amd_fastext.so libbowtie_amd_fastext_ng.so libbowtie_amd_fastext_ms.so libbowtie_amd_fastext_nr.so; do
+# out a wavefront at a time, _r32 / _r4: lanes refilled when 32 / 4 wait instead of 16), on the quick workloads
+for lib in libbowtie_amd.so libbowtie_amd_fastext.so libbowtie_amd_fastext_ng.so libbowtie_amd_fastext_ms.so libbowtie_amd_fastext_nr.so libbowtie_amd_fastext_r32.so libbowtie_amd_fastext_r4.so; do
 	for wl in ecoli_n2_best_100 ecoli_pe_n1_best_50; do f=$O/bench_${wl}_$lib; BT_LIB=$lib timeout 120 python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --also none > $f.json 2> $f.log; say "$lib $wl (round 3: 6.6 / 30.8 M): $(val $f.json)"; done
 done
 
