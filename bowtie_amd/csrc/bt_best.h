@@ -800,7 +800,16 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	const BtIndexDev& ix = X.ix[sp.mirror];
 	const uint32_t maq = X.P->maq;
 	AW(d + DR_FLAGS) = 0;
+#if BF_FAST_EXTEND
+	/* a leaf's query is set once, right after leaf_init zeroed its record (the tree is rebuilt for every read, an extender
+	 * is made for every seed hit): its PathManager words are zeros, no need to fetch them */
+#if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+	for (uint32_t k = 0; k < 6u; k++) if ((uint32_t)AW(d + LF_HEAP + k) != 0u) { fprintf(stderr, "BF_CHECK: leaf_set_query on a used leaf\n"); abort(); }
+#endif
+	for (uint32_t k = 0; k < 7u; k++) X.pm[k] = 0;
+#else
 	pm_enter(X, d);
+#endif
 	pm_reset(X, d);
 	const BfRead& R = X.R[sp.mate];
 	const uint32_t len = R.len;
