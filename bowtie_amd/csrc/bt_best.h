@@ -1470,8 +1470,16 @@ template <int LEVEL> BF_FN void cost_set_query(BfLane& X, uint32_t d)
 	AW(d + CA_RND) = X.R[0].seed;                             /* patsrc->bufa().seed */
 	const uint32_t n = AW(d + CA_NRSS) & 0xffffu;
 	if (n == 0) return;
+#if BF_FAST_EXTEND
+	{
+		/* the two vectors' offsets once, each child's offset once (setting a child's query does not touch the vectors) */
+		const uint32_t rss = AW(d + CA_RSS), act = AW(d + CA_ACT);
+		for (uint32_t i = 0; i < n; i++) { const uint32_t c = AW(rss + i); child_set_query<LEVEL>(X, c, 0); AW(act + i) = c; }
+	}
+#else
 	for (uint32_t i = 0; i < n; i++) child_set_query<LEVEL>(X, AW(AW(d + CA_RSS) + i), 0);
 	for (uint32_t i = 0; i < n; i++) AW(AW(d + CA_ACT) + i) = AW(AW(d + CA_RSS) + i);
+#endif
 	AW(d + CA_NACT) = n;
 	dr_set_mincost(X, d, 0);
 	cost_sort_actives(X, d);
