@@ -58,7 +58,8 @@ def build_probe():
     for f in ("bt_rank.h", "bt_best.h", "bt_host.h", "bt_host.cpp", "bt_kernels.h", "bt_io.h"):
         t = open(os.path.join(ROOT, "bowtie_amd/csrc", f)).read().replace("../../include/bowtie_amd.h", os.path.join(ROOT, "include/bowtie_amd.h"))
         open(os.path.join(W, f), "w").write(t)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", W + "/libbt_emu_dv.so", W + "/emu/bt_emu.cpp", W + "/bt_host.cpp"])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w"] + os.environ.get("BT_EMU_DEFINES", "").split() +
+                          ["-o", W + "/libbt_emu_dv.so", W + "/emu/bt_emu.cpp", W + "/bt_host.cpp"])     # e.g. BT_EMU_DEFINES=-DBT_LOCAL_LOOPS=1
 
 
 def popcount(a):
