@@ -1940,6 +1940,23 @@ BF_FN bool bf_emit_hit(BfLane& X, const BtBatchDev& B, uint32_t fw, bool flip, u
 			if (off + nmm <= B.mm_pool_cap) {
 				h.mm_off = off;
 				auto mm = BT_GP(uint16_t, B.mm_pool + off);
+#if BF_FAST_EXTEND
+				/* up to 16 mismatches are put in order in the lane and stored once: the pool is never read (sorting in place
+				 * waits for its own stores to come back, and reads a line other lanes' lists share) */
+				uint16_t ee[16];
+				if (nmm <= 16u) {
+					for (uint32_t i = 0; i < nmm; i++) {
+						uint32_t m, refc;
+						getmm(i, m, refc);
+						const uint32_t pos = flip ? alen - m - 1u : m;
+						const uint16_t e16 = (uint16_t)(pos | (refc << 12));
+						int j = (int)i - 1;
+						while (j >= 0 && (ee[j] & 0x3ffu) > (e16 & 0x3ffu)) { ee[j + 1] = ee[j]; j--; }
+						ee[j + 1] = e16;
+					}
+					for (uint32_t i = 0; i < nmm; i++) mm[i] = ee[i];
+				} else
+#endif
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t m, refc;
 					getmm(i, m, refc);

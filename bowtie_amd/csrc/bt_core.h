@@ -374,6 +374,9 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 #define HFCHR(k) (L.mirror ? H.fchr[1][k] : H.fchr[0][k])
 /* a block that emits its request leaves the lane in a state no LATER block of the sweep takes (its own *_DONE /
  * *_FETCHED state) -- except the three that are entered straight from the block before them with the request pending */
+#ifndef BT_MM_SORT_REGS
+#define BT_MM_SORT_REGS 0
+#endif
 #define ST_IS(x) (L.state == (x))
 #define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE)
 
@@ -532,6 +535,30 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 				h.mm_off = off;
 				const bool flip = (ixfw != 0) != (L.readFw != 0);
 				auto mm = BT_GP(uint16_t, B.mm_pool + off);
+#if BT_MM_SORT_REGS
+				/* experiment: up to 16 mismatches are put in order in the lane and stored once, so that no
+				 * line of the output is ever read by the kernel */
+				if (nmm <= 16u) {
+					uint16_t ee[16];
+					BT_NOUNROLL
+					for (uint32_t i = 0; i < nmm; i++) {
+						uint32_t pos, refc;
+						if (i < L.ra_sd) { uint32_t v = FRW(i, FR_MM); pos = v & 0xffffu; refc = (v >> 16) & 3u; }
+						else {
+							const uint32_t k = i - L.ra_sd;
+							pos = k == 0 ? L.mutpos0 : k == 1 ? L.mutpos1 : L.mutpos2;
+							refc = k == 0 ? L.mutnew0 : k == 1 ? L.mutnew1 : L.mutnew2;
+						}
+						if (flip) pos = L.qlen - pos - 1u;
+						const uint16_t e = (uint16_t)(pos | (refc << 12));
+						int j = (int)i - 1;
+						while (j >= 0 && (ee[j] & 0x3ffu) > (e & 0x3ffu)) { ee[j + 1] = ee[j]; j--; }
+						ee[j + 1] = e;
+					}
+					BT_NOUNROLL
+					for (uint32_t i = 0; i < nmm; i++) mm[i] = ee[i];
+				} else
+#endif
 				BT_NOUNROLL
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t pos, refc;

@@ -51,4 +51,11 @@ if cmp -s <(grep -v '^@PG' /tmp/cli_default.sam) <(grep -v '^@PG' /tmp/cli_ours.
 ( for w in 1 2 3 4 5; do ( for i in 1 2 3 4; do timeout 120 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -n 0 -k "best_first_vs_oracle_ragged" > /dev/null 2>&1; done ) & done
   for i in $(seq 1 20); do timeout 120 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -n 0 -k "host_batches_streamed" > $O/streamed_$i.txt 2>&1; echo "repeat $i: $(tail -1 $O/streamed_$i.txt)"; done; wait ) > $O/streamed_repeats.txt 2>&1
 say "streamed test, 20 repeats under load: $(grep -c ' passed' $O/streamed_repeats.txt) passed, $(grep -c 'failed' $O/streamed_repeats.txt) failed"
+# ... and through the library that never reads a line of the pool (DESIGN.md 4.3's candidate explanation): only worth its time if
+# the repeats above failed at least once
+if grep -q 'failed' $O/streamed_repeats.txt && [ -f bowtie_amd/libbowtie_amd_mmsort.so ]; then
+	( for w in 1 2 3 4 5; do ( for i in 1 2 3 4; do timeout 120 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -n 0 -k "best_first_vs_oracle_ragged" > /dev/null 2>&1; done ) & done
+	  for i in $(seq 1 20); do BT_LIB=libbowtie_amd_mmsort.so timeout 120 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -n 0 -k "host_batches_streamed" > $O/streamed_mmsort_$i.txt 2>&1; echo "repeat $i: $(tail -1 $O/streamed_mmsort_$i.txt)"; done; wait ) > $O/streamed_mmsort_repeats.txt 2>&1
+	say "the same through libbowtie_amd_mmsort.so: $(grep -c ' passed' $O/streamed_mmsort_repeats.txt) passed, $(grep -c 'failed' $O/streamed_mmsort_repeats.txt) failed"
+fi
 cat $S

@@ -17,7 +17,8 @@ import common as T
     # the parts that have switches of their own, all off: the sorts in place, the leaf advanced where the reference does it,
     # a read run by one call
     ("-DBF_FAST_EXTEND=1 -DBF_FAST_GATHER=0 -DBF_ONE_LEAF_SITE=0 -DBF_REFILL=0 -DBF_CHECK=1", ["tests/test_automaton_emu.py", "-k", "best or paired or v3 or M3 or strata"]),
-], ids=["fast_extend", "fast_extend_sorts_and_leaf_sites_as_in_the_reference"])
+    ("-DBT_MM_SORT_REGS=1", ["tests/test_automaton_emu.py", "-k", "not best and not paired"]),
+], ids=["fast_extend", "fast_extend_sorts_and_leaf_sites_as_in_the_reference", "mismatch_lists_sorted_in_the_lane"])
 def test_experiment_is_bit_identical_in_the_host_build(defines, files):
     env = dict(os.environ, BT_EMU_DEFINES=defines)
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "not gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=T.ROOT, env=env,
