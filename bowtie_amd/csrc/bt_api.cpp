@@ -549,7 +549,8 @@ static int ctx_flush_carry(bt_ctx* c)
 /* lens_on_device: maxLen is only the row stride (the lengths are in HBM); async: the caller does not wait for this
  * batch before handing over the next -- carry-over and the on-stream second pass apply */
 static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uint32_t maxLen,
-                      unsigned long long* counts_dev, bool lens_on_device, bool async, bool retry_on_stream = true)
+                      unsigned long long* counts_dev, bool lens_on_device, bool async, bool retry_on_stream = true,
+                      uint32_t* mmCursorDev = nullptr)
 {
 	if (in->n_reads == 0) { c->timed = false; return BT_OK; }
 	if (!in->seq || !in->qual || !in->len || !in->seed || !out->hits || !out->n_hits || !out->status ||
@@ -599,7 +600,9 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	cur.B.hits = (BtHitRec*)out->hits; cur.B.hit_cap = out->hit_cap;
 	cur.B.n_hits = out->n_hits; cur.B.status = out->status;
 	cur.B.mm_pool = out->mm_pool; cur.B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
-	cur.B.mm_pool_used = carry ? c->d_carry + BT_BATCH_RING + bid : c->d_cursor + 1;
+	/* the batch's mismatch-pool cursor: the caller's own word (a stream slot's: it outlives the launches that follow), or
+	 * the ring's with carry-over, or the context's */
+	cur.B.mm_pool_used = mmCursorDev ? mmCursorDev : (carry ? c->d_carry + BT_BATCH_RING + bid : c->d_cursor + 1);
 	cur.B.iters = c->iters_dev;
 	cur.seq = in->seq; cur.qual = in->qual; cur.stride = in->stride; cur.n_reads = in->n_reads;
 	const bool adopt = carry && c->carryPending;
@@ -621,11 +624,12 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
 	if (carry) {
 		HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));                 /* this launch's parked counts */
-		HIPCHK(hipMemsetAsync(c->d_carry + BT_BATCH_RING + bid, 0, 4, c->stream));           /* this batch's mismatch-pool cursor */
+		if (!mmCursorDev) HIPCHK(hipMemsetAsync(c->d_carry + BT_BATCH_RING + bid, 0, 4, c->stream));   /* this batch's mismatch-pool cursor */
 		A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = adopt ? 1u : 0u; A.park = 1u;
 		A.maxAge = c->carryAge; A.parkedOf = c->d_carry;
 		A.parkMinRounds = env_u32("BT_PARK_MIN_ROUNDS", 0);
 	}
+	if (mmCursorDev) HIPCHK(hipMemsetAsync(mmCursorDev, 0, 4, c->stream));
 	if (both && bt_launch_maxlen(in->len, in->n_reads, c->d_cursor + 7, c->stream) != 0) return BT_ERR_DEVICE;
 	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
 	hipEvent_t* ring = c->evRing[c->spanLaunches & 15u];
@@ -695,11 +699,11 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		HIPCHK(hipEventRecord(c->evLaunch[k], c->stream));
 		c->carryPending = true; c->carryRl = rl; c->carryBlocks = gridBlocks;
 		c->launchSeq++;
-		c->lastMmCursor = c->d_carry + BT_BATCH_RING + bid;
+		c->lastMmCursor = mmCursorDev ? mmCursorDev : c->d_carry + BT_BATCH_RING + bid;
 		/* the second pass waits for the batch to be complete: ctx_flush_carry */
 	} else {
 		if (devRetry && (rc = enqueue_retry(c, A, cur, c->d_cold, maxLen)) != BT_OK) return rc;
-		c->lastMmCursor = c->d_cursor + 1;
+		c->lastMmCursor = mmCursorDev ? mmCursorDev : c->d_cursor + 1;
 	}
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipEventRecord(ring[1], c->stream));
@@ -817,7 +821,7 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 		o_seed[m] = cur; cur += al(4ull * n);
 	}
 	const size_t o_hits = cur, o_nh = o_hits + al((size_t)n * out->hit_cap * sizeof(bt_hit)), o_st = o_nh + al(4ull * n),
-	             o_mm = o_st + al(n), total = o_mm + al(2ull * out->mm_pool_cap);
+	             o_mm = o_st + al(n), o_cur = o_mm + al(2ull * out->mm_pool_cap), total = o_cur + 256;
 	if (total > c->stage_bytes) {
 		if (c->stage) (void)hipFree(c->stage);
 		c->stage = nullptr; c->stage_bytes = 0;
@@ -1029,7 +1033,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	const size_t o_seq = 0, o_qual = o_seq + al((size_t)n * in->stride), o_len = o_qual + al((size_t)n * in->stride),
 	             o_seed = o_len + al(2ull * n), o_hits = o_seed + al(4ull * n),
 	             o_nh = o_hits + al((size_t)n * out->hit_cap * sizeof(bt_hit)), o_st = o_nh + al(4ull * n),
-	             o_mm = o_st + al(n), total = o_mm + al(2ull * out->mm_pool_cap);
+	             o_mm = o_st + al(n), o_cur = o_mm + al(2ull * out->mm_pool_cap), total = o_cur + 256;
 	if (total > c->stage_bytes) {
 		if (c->stage) (void)hipFree(c->stage);
 		c->stage = nullptr; c->stage_bytes = 0;
@@ -1190,7 +1194,7 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	const size_t o_seq = 0, o_qual = o_seq + al((size_t)n * in->stride), o_len = o_qual + al((size_t)n * in->stride),
 	             o_seed = o_len + al(2ull * n), o_hits = o_seed + al(4ull * n),
 	             o_nh = o_hits + al((size_t)n * out->hit_cap * sizeof(bt_hit)), o_st = o_nh + al(4ull * n),
-	             o_mm = o_st + al(n), total = o_mm + al(2ull * out->mm_pool_cap);
+	             o_mm = o_st + al(n), o_cur = o_mm + al(2ull * out->mm_pool_cap), total = o_cur + 256;
 	if (total > s.bytes) {
 		if (s.dev) (void)hipFree(s.dev);
 		s.dev = nullptr; s.bytes = 0;
@@ -1205,6 +1209,10 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	HIPCHK(hipMemcpyAsync(d + o_len, in->len, 2ull * n, hipMemcpyHostToDevice, cs));
 	HIPCHK(hipMemcpyAsync(d + o_seed, in->seed, 4ull * n, hipMemcpyHostToDevice, cs));
 	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_mm - o_hits, cs));
+	/* diagnostics: BT_STREAM_POISON=1 fills the mismatch pool's staging region with 0xff, so that an entry the
+	 * host reads without the kernel having written it is recognisable (position 0x3ff, base 3) instead of looking like another
+	 * read's entry left over from whoever had the memory before */
+	if (env_u32("BT_STREAM_POISON", 0) && out->mm_pool_cap) HIPCHK(hipMemsetAsync(d + o_mm, 0xff, 2ull * out->mm_pool_cap, cs));
 	HIPCHK(hipEventRecord(s.up, cs));
 	HIPCHK(hipStreamWaitEvent(c->stream, s.up, 0));
 	bt_read_batch din = *in;
@@ -1215,7 +1223,9 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	const uint32_t seq0 = c->launchSeq;
 	const bool wasPending = c->carryPending;
 	/* reads that outgrow their scratch stay flagged (BT_ST_OVERFLOW) for the caller: no second pass on the stream here */
-	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false);
+	/* the mismatch-pool cursor lives in the staging area: the context's own (d_cursor[1]) is reset by the next launch, which
+	 * may be enqueued before this batch's results have been copied */
+	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false, (uint32_t*)(d + o_cur));
 	if (rc != BT_OK) return rc;
 	s.in = in; s.out = out; s.tag = tag; s.n = n; s.o_hits = o_hits; s.o_nh = o_nh; s.o_st = o_st; s.o_mm = o_mm;
 	s.mmCursor = c->lastMmCursor; s.state = 1;
@@ -1248,7 +1258,7 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 				if (hipEventQuery(c->evLaunch[k]) == hipSuccess) { complete = c->hostParked[(size_t)k * BT_BATCH_RING + s.bid] == 0; break; }
 			}
 			if (!complete) return BT_OK;
-			const int r2 = stream_copy_back(c, s, false);
+			const int r2 = stream_copy_back(c, s, env_u32("BT_STREAM_ORDERED", 0) != 0);
 			if (r2 != BT_OK) return r2;
 		} else {
 			if (!flush) return BT_ERR_ARG;                          /* cannot happen: uncarried batches are copied back at submit */
@@ -1259,6 +1269,32 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 	} else if (!flush && hipEventQuery(s.done) != hipSuccess) return BT_OK;
 	HIPCHK(hipEventSynchronize(s.done));
 	s.out->mm_pool_used = s.mm_used < s.out->mm_pool_cap ? s.mm_used : s.out->mm_pool_cap;
+	if (env_u32("BT_STREAM_RECHECK", 0)) {
+		/* diagnostics: with the device idle, what the staging area holds now against what the copy stream
+		 * delivered -- a difference means the copy ran before the batch's last writes were there */
+		HIPCHK(hipDeviceSynchronize());
+		const uint8_t* d = (const uint8_t*)s.dev;
+		std::vector<uint8_t> t;
+		auto cmp = [&](const char* what, const void* host, size_t off, size_t bytes) -> int {
+			t.resize(bytes);
+			if (bytes == 0) return 0;
+			if (hipMemcpy(t.data(), d + off, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+			size_t nd = 0, first = 0;
+			for (size_t i = 0; i < bytes; i++) if (t[i] != ((const uint8_t*)host)[i]) { if (!nd) first = i; nd++; }
+			if (nd) fprintf(stderr, "[stream-recheck] tag %p carried=%d seq=%u bid=%u: %s differs in %zu of %zu bytes (first at %zu): delivered early\n",
+			                s.tag, (int)s.carried, s.seq, s.bid, what, nd, bytes, first);
+			return nd ? 1 : 0;
+		};
+		int bad = 0;
+		bad |= cmp("n_hits", s.out->n_hits, s.o_nh, 4ull * s.n);
+		bad |= cmp("status", s.out->status, s.o_st, s.n);
+		bad |= cmp("hits", s.out->hits, s.o_hits, (size_t)s.n * s.out->hit_cap * sizeof(bt_hit));
+		bad |= cmp("mm_pool", s.out->mm_pool, s.o_mm, 2ull * s.out->mm_pool_used);
+		uint32_t cur = 0;
+		if (hipMemcpy(&cur, s.mmCursor, 4, hipMemcpyDeviceToHost) == hipSuccess && s.carried && cur != s.mm_used)
+			fprintf(stderr, "[stream-recheck] tag %p: mm cursor %u now, %u delivered\n", s.tag, cur, s.mm_used);
+		if (bad > 0 && env_u32("BT_STREAM_RECHECK", 0) > 1) return BT_ERR_DEVICE;
+	}
 	*tag = s.tag;
 	s.state = 0;
 	S.inflight.erase(S.inflight.begin());
