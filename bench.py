@@ -263,6 +263,70 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: fl
             "sample": "%d synthetic %d-bp reads through oracle/bt_oracle.c via ctypes, %.2fs" % (n * unit, wl["length"], dt)}
 
 
+def launch_ranks(args) -> int:
+    """Re-run this command line as `--gpus` ranks of one node under torch.distributed.run (one process per GPU, rendezvous
+    on 127.0.0.1, a free port); rank 0's JSON line is this process's output.  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    if not args.dry_ranks and args.dist_backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print("bench.py: --gpus %d over RCCL needs %d GPUs, this node shows %d" % (args.gpus, args.gpus, have), file=sys.stderr)
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL on this host: dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def reduce_counters(dist, cnt5, wall_t, world, backend):
+    """The run's only collective (hit.h:169-175, 280-289: HitSink's counters are per process): SUM of the per-rank hit
+    counters and MAX of the per-rank wall time -- RCCL over xGMI with the nccl backend -- checked against the per-rank
+    counters gathered one by one.  Returns (summed counters, max wall)."""
+    if backend != "nccl":
+        cnt5, wall_t = cnt5.cpu(), wall_t.cpu()
+    dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    mine = cnt5.clone()
+    dist.all_reduce(cnt5, op=dist.ReduceOp.SUM)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    if not torch.equal(torch.stack(parts).sum(dim=0), cnt5):
+        raise SystemExit("bench.py: the all-reduced hit counters differ from the sum of the per-rank counters")
+    return cnt5, float(wall_t[0].item())
+
+
+def dry_ranks(args, rank, world):
+    """--dry-ranks: everything a rank does around the search -- rendezvous, the counter reduce and its check, rank 0's
+    line -- with made-up counters and no GPU."""
+    import torch.distributed as dist
+    backend = "gloo" if not torch.cuda.is_available() else args.dist_backend
+    if world > 1:
+        dist.init_process_group(backend)
+    cnt5 = torch.tensor([100 + rank, 90 + rank, 0, 10 + rank, rank, 110 + 2 * rank, 0], dtype=torch.int64)
+    wall_t = torch.tensor([1.0 + 0.25 * rank], dtype=torch.float64)
+    wall = float(wall_t[0])
+    if world > 1:
+        if backend == "nccl":
+            dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+            cnt5, wall_t = cnt5.to(dev), wall_t.to(dev)
+        cnt5, wall = reduce_counters(dist, cnt5, wall_t, world, backend)
+    if rank == 0:
+        c5 = [int(x) for x in cnt5.tolist()]
+        print(json.dumps({"metric": "aligned reads/sec (whole node)", "dry": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "value": (c5[0] + c5[4]) * args.steps / wall, "reads_processed_per_s": c5[5] * args.steps / wall,
+                          "unit": "reads/s", "scaling": args.scaling, "dist_backend": backend,
+                          "config": {"hit_counters_last_step": {"aligned": c5[0], "reported": c5[1], "reported_paired": c5[2],
+                                                                "unaligned": c5[3], "maxed": c5[4]}, "reads": c5[5]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,13 +358,25 @@ def main():
                     help="CPU leg: only the SAM diff of a sample against the reference binary (no -p sweep)")
     ap.add_argument("--no-strong", action="store_true",
                     help="with --gpus N > 1 and weak scaling: skip the second, strong-scaling measurement (config.strong)")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="no GPU work: start the ranks, reduce made-up per-rank hit counters the way the real run does, print the "
+                         "line's skeleton (CPU test of the launch + reduce path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own (the driver's command shape): start one rank per GPU ourselves, the way
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...` would
+        raise SystemExit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_ranks:
+        return dry_ranks(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if world > 1 and args.dist_backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d" % (world, world, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()      # several ranks may share a GPU (gloo, tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -501,17 +577,7 @@ def main():
                         (nh == 0).sum(), is_max.sum(), torch.tensor(n, device=dev), torch.tensor(bad, device=dev)]).to(torch.int64)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
-        if args.dist_backend != "nccl":
-            cnt5, wall_t = cnt5.cpu(), wall_t.cpu()
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-        mine = cnt5.clone()
-        dist.all_reduce(cnt5, op=dist.ReduceOp.SUM)     # the hit-count reduce (RCCL over xGMI with the nccl backend)
-        # the reduce checked against the per-rank counters gathered one by one
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        if not torch.equal(torch.stack(parts).sum(dim=0), cnt5):
-            raise SystemExit("bench.py: the all-reduced hit counters differ from the sum of the per-rank counters")
-        wall = float(wall_t[0].item())
+        cnt5, wall = reduce_counters(dist, cnt5, wall_t, world, args.dist_backend)      # the hit-count reduce
     c5 = [int(x) for x in cnt5.tolist()]
     aligned_all, reads_all, bad_all = float(c5[0] + c5[4]), float(c5[5]), float(c5[6])
 
@@ -531,7 +597,10 @@ def main():
         dist.all_reduce(ws, op=dist.ReduceOp.MAX)
         wall_s = float(ws[0].item())
         strong = {"reads_total_per_step": n_s * world * mult, "reads_per_gpu_per_step": n_s * mult,
-                  "value": n_s * world * mult * args.steps / wall_s, "unit": "reads/s", "ms_per_step": wall_s * 1e3 / args.steps,
+                  "reads_processed_per_s": n_s * world * mult * args.steps / wall_s,
+                  "value": n_s * world * mult * args.steps / wall_s * (aligned_all / max(1.0, reads_all)), "unit": "reads/s",
+                  "value_counts": "aligned reads/s = reads processed/s x the weak run's aligned fraction (same read generator)",
+                  "ms_per_step": wall_s * 1e3 / args.steps,
                   "carry_over_launches": Ms["carry_age"]}
 
     if rank == 0:
@@ -547,16 +616,20 @@ def main():
         abytes = algorithmic_bytes(per_launch, n * (2 if paired else 1), L, aligned * (2 if paired else 1))
         achieved = abytes / (kavg * 1e-3) / 1e9
         out = {
-            "metric": "aligned reads/sec (whole node)", "value": reads_all * (2 if paired else 1) * args.steps / wall,
-            "unit": "reads/s", "aligned_reads_per_s": aligned_all * args.steps / wall,
+            # `value` is the metric as worded: reads that aligned, per second, over all GPUs (a pair = 2 reads);
+            # `reads_processed_per_s` counts every read put through the aligner, aligned or not (rounds 1-3 reported that as `value`)
+            "metric": "aligned reads/sec (whole node)", "value": aligned_all * mult * args.steps / wall,
+            "unit": "reads/s", "aligned_reads_per_s": aligned_all * mult * args.steps / wall,
+            "reads_processed_per_s": reads_all * mult * args.steps / wall,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": args.workload, "index": index_note, "read_len": L,
                        "policy": wl["pol"], "reads_per_gpu_per_step": n * (2 if paired else 1),
-                       "value_counts": "reads processed, aligned or not (a pair = 2 reads)",
+                       "value_counts": "reads with at least one reported alignment, or more than -m allows (a pair = 2 reads); reads_processed_per_s counts every read",
+
                        "pairs_per_gpu_per_step": n if paired else None,
-                       "reads_with_alignment_per_s": aligned_all * args.steps / wall,
+                       "reads_with_alignment_per_s": aligned_all * mult * args.steps / wall,
                        "pct_aligned": 100.0 * aligned_all / reads_all, "reads_overflowed": bad_all,
                        "hit_counters_last_step": {"aligned": c5[0], "reported": c5[1], "reported_paired": c5[2],
                                                   "unaligned": c5[3], "maxed": c5[4]},
@@ -566,7 +639,10 @@ def main():
                        "strong": strong},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # PMC traffic, per launch: with the guide's gfx950 correction (FETCH_SIZE x 2) -- an upper bound for
+                         # 32-byte gathers -- and as the counters tally it (x 1, what the calibration on known-count gathers says)
                          "traffic": (tr["hbm_bytes_per_read"] * n * mult if tr and not args.genome else None),
+                         "traffic_as_tallied": (tr["hbm_bytes_per_read_as_tallied"] * n * mult if tr and not args.genome and tr.get("hbm_bytes_per_read_as_tallied") else None),
                          "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this round's source of this kernel on this workload in profiles/traffic.json (round 3 measured 213 KB/read on big_n2_100, an upper bound: 1.9 x algorithmic)"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
@@ -587,6 +663,8 @@ def main():
             out["roofline"]["gather_ceiling_source"] = gc["source"]
         if not args.no_cpu:
             cb = cpu_baseline(base, wl, text_np, idx, diff_only=args.cpu_diff_only)
+            cb["value_counts"] = "reads processed per second; the reference's results are the product's (diff_mismatches), so the same fraction aligns"
+            cb["aligned_reads_per_s"] = cb["value"] * aligned_all / max(1.0, reads_all)
             out["cpu_baseline"] = cb
             out["config"]["reads_diffed_vs_reference"] = cb.get("reads_diffed_vs_reference")
             out["config"]["diff_mismatches"] = cb.get("diff_mismatches")
@@ -609,7 +687,10 @@ def main():
                     out["config"]["other_workloads"][name] = {
                         "value": d["value"], "unit": d["unit"], "aligned_reads_per_s": d.get("aligned_reads_per_s"),
                         "ms_per_step": d["ms_per_step"], "steps": d["steps"], "reads_per_gpu_per_step": d["config"]["reads_per_gpu_per_step"],
+                        "reads_processed_per_s": d.get("reads_processed_per_s"),
                         "roofline_frac": d["roofline"]["frac"], "kernel": d["roofline"]["kernel"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
+                        "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],
+                        "traffic": d["roofline"].get("traffic"), "traffic_as_tallied": d["roofline"].get("traffic_as_tallied"),
                         "hits_verified_against_text": d["config"].get("hits_verified_against_text"),
                         "reads_diffed_vs_reference": d["config"].get("reads_diffed_vs_reference"),
                         "diff_mismatches": d["config"].get("diff_mismatches"),

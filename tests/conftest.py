@@ -8,6 +8,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    # six workers when pytest-xdist is there and the command line does not say otherwise (-n 0 for none): the CPU suite in
+    # about three minutes, the GPU suite (one MI355X shared by the workers, each test with its own contexts) well inside the
+    # driver's limit.  Without the plugin the suite simply runs in one process.
+    if config.pluginmanager.hasplugin("xdist") and getattr(config.option, "numprocesses", None) is None \
+            and not os.environ.get("BT_TEST_WORKERS") == "0":
+        config.option.numprocesses = int(os.environ.get("BT_TEST_WORKERS", "6"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if not hasattr(config, "workerinput"):

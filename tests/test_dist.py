@@ -66,3 +66,34 @@ def test_shard_covers_everything():
             spans = [shard(n, r, world) for r in range(world)]
             assert sum(max(0, b - a) for a, b in spans) == n
             assert all(spans[i][1] == spans[i + 1][0] or spans[i + 1][0] >= n for i in range(world - 1))
+
+
+@pytest.mark.parametrize("how", ["self", "torchrun"])
+def test_bench_gpus_2_starts_two_ranks(how):
+    """`python bench.py --gpus 2 ...` on its own -- the shape of the driver's command -- starts two ranks itself; under
+    torch.distributed.run it uses the ranks it is given.  --dry-ranks: rendezvous, the counter reduce with its all-gather
+    check and rank 0's line, no GPU.  Counters: rank r contributes aligned 100+r, maxed r, reads 110+2r; wall 1+0.25r."""
+    import json
+    import socket
+    import subprocess
+    bench = os.path.join(T.ROOT, "bench.py")
+    tail = ["--gpus", "2", "--steps", "2", "--dist-backend", "gloo", "--dry-ranks"]
+    if how == "self":
+        cmd = [sys.executable, bench] + tail
+    else:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), bench] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-800:]
+    lines = [x for x in r.stdout.decode().splitlines() if x.startswith("{")]
+    assert len(lines) == 1                               # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2
+    assert d["config"]["hit_counters_last_step"]["aligned"] == 201 and d["config"]["hit_counters_last_step"]["maxed"] == 1
+    assert d["config"]["reads"] == 222
+    assert abs(d["value"] - 202 * 2 / 1.25) < 1e-9       # max over ranks of the wall time
+    assert abs(d["reads_processed_per_s"] - 222 * 2 / 1.25) < 1e-9
