@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <exception>
+#include <mutex>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -29,6 +30,12 @@ struct bt_index {
 	std::string base;
 	BtRefDev* d_ref = nullptr;     /* the 2-bit reference, loaded on demand (bt_index_load_reference) */
 	uint64_t ref_bytes = 0;
+	/* the worst-case arenas of the best-first engine's second pass (reads that outgrew their own arena): one set per
+	 * index replica = per device, shared by every context on it -- the passes of different contexts take turns on it
+	 * through `retryFree` (recorded after a pass, waited for by the next one's stream) */
+	mutable std::mutex retryMu;
+	mutable uint32_t* retryArenas = nullptr; mutable uint32_t retryArenaLanes = 0;
+	mutable hipEvent_t retryFree = nullptr;
 };
 
 /* What one call describes to the kernels: the batch (reads in, results out) and the fields of BtHot that follow it */
@@ -42,8 +49,8 @@ struct bt_ctx {
 	BfProgram bprog;
 	BfProgram* d_bprog = nullptr; BtIndexDev* d_ix = nullptr; BtBatchDev* d_batch = nullptr;
 	BfProgram* d_bprog_pe = nullptr; bool have_pe = false;      /* the paired program, compiled on first use */
-	uint32_t* arenas = nullptr; uint32_t arenaWords = 0; uint32_t arenaLanes = 0;
-	uint32_t* bigArenas = nullptr; uint32_t bigArenaLanes = 0; uint32_t* retryList = nullptr; uint32_t retryCap = 0;   /* on-device second pass */
+	uint32_t* arenas = nullptr; uint32_t arenaWords = 0; uint32_t arenaLanes = 0; uint32_t arenaAsked = 0;   /* arenaAsked: the lanes wanted when arenaLanes were got */
+	uint32_t* retryList = nullptr; uint32_t retryCap = 0;   /* on-device second pass (its arenas: bt_index::retryArenas) */
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -185,6 +192,8 @@ extern "C" void bt_index_free(bt_index* idx)
 {
 	if (!idx) return;
 	for (void* p : idx->allocs) (void)hipFree(p);
+	if (idx->retryFree) { (void)hipEventSynchronize(idx->retryFree); (void)hipEventDestroy(idx->retryFree); }
+	if (idx->retryArenas) (void)hipFree(idx->retryArenas);
 	delete idx;
 }
 
@@ -337,7 +346,6 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->d_ix) (void)hipFree(c->d_ix);
 	if (c->d_batch) (void)hipFree(c->d_batch);
 	if (c->arenas) (void)hipFree(c->arenas);
-	if (c->bigArenas) (void)hipFree(c->bigArenas);
 	if (c->retryList) (void)hipFree(c->retryList);
 	if (c->stage) (void)hipFree(c->stage);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -379,12 +387,30 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		if (need < lanes) lanes = (uint32_t)need;
 		if (lanes < BT_BLOCK) lanes = BT_BLOCK;
 	}
-	if (!c->arenas || c->arenaWords != words || c->arenaLanes < lanes) {
+	if (!c->arenas || c->arenaWords != words || (c->arenaLanes < lanes && c->arenaAsked < lanes)) {
 		if (c->arenas) (void)hipFree(c->arenas);
-		c->arenas = nullptr;
-		HIPCHK(hipMalloc((void**)&c->arenas, (size_t)lanes * words * 4u));
+		c->arenas = nullptr; c->arenaLanes = 0; c->arenaAsked = lanes;
+		/* a context takes at most 45 % of what the device has free now (BT_BEST_ARENA_FRAC, per cent): the contexts of one
+		 * device -- bowtie-amd keeps --inflight of them, and another set for the unpaired records of a --12 file -- then
+		 * all fit, the later ones with fewer lanes; and an allocation that fails all the same is tried again with half
+		 * the lanes rather than ending the run (a launch with fewer lanes is slower, not wrong) */
+		size_t freeB = 0, totB = 0;
+		if (hipMemGetInfo(&freeB, &totB) == hipSuccess) {
+			const uint64_t budget = (uint64_t)freeB / 100u * env_u32("BT_BEST_ARENA_FRAC", 45u);
+			const uint64_t fit = budget / ((uint64_t)words * 4u) / BT_BLOCK * BT_BLOCK;
+			if (fit < lanes) lanes = fit < BT_BLOCK ? BT_BLOCK : (uint32_t)fit;
+		} else (void)hipGetLastError();
+		for (;;) {
+			if (hipMalloc((void**)&c->arenas, (size_t)lanes * words * 4u) == hipSuccess) break;
+			(void)hipGetLastError();
+			c->arenas = nullptr;
+			if (lanes <= BT_BLOCK) { fprintf(stderr, "bowtie_amd: no device memory for the best-first arenas (%u words per lane)\n", words); return BT_ERR_DEVICE; }
+			lanes = lanes / 2u / BT_BLOCK * BT_BLOCK;
+			if (lanes < BT_BLOCK) lanes = BT_BLOCK;
+		}
 		c->arenaWords = words; c->arenaLanes = lanes;
 	}
+	if (c->arenaLanes < lanes) lanes = c->arenaLanes;
 	BtBatchDev B;
 	memset(&B, 0, sizeof(B));
 	B.seq = in->seq; B.qual = in->qual; B.len = in->len; B.seed = in->seed;
@@ -417,16 +443,36 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		 * arenas each -- the caller of the device-pointer entry points sees finished results only.  (256 lanes were
 		 * tried to save memory: on the hg19-scale index enough reads come here that the pass then takes several
 		 * times as long as the main launch, profiles/r3/.) */
-		const uint32_t bigWords = 1u << 22, bigLanes = env_u32("BT_BEST_RETRY_LANES", in->n_reads >= (1u << 18) ? 1024u : 256u);
-		if (c->bigArenas && c->bigArenaLanes < bigLanes) { (void)hipFree(c->bigArenas); c->bigArenas = nullptr; }
-		if (!c->bigArenas) { HIPCHK(hipMalloc((void**)&c->bigArenas, (size_t)bigLanes * bigWords * 4u)); c->bigArenaLanes = bigLanes; }
+		const uint32_t bigWords = 1u << 22;
+		uint32_t bigLanes = env_u32("BT_BEST_RETRY_LANES", in->n_reads >= (1u << 18) ? 1024u : 256u);
 		const int rrc = ctx_ensure_retry_list(c, in->n_reads);
 		if (rrc != BT_OK) return rrc;
 		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 2, c->retryCap, c->stream) != 0) return BT_ERR_DEVICE;
+		/* the arenas of this pass belong to the index replica: whoever enqueues a pass holds the lock while it does, waits
+		 * (on its stream) for the pass before it and leaves the event for the next */
+		const bt_index* ix = c->idx;
+		std::lock_guard<std::mutex> lock(ix->retryMu);
+		if (!ix->retryFree) HIPCHK(hipEventCreateWithFlags(&ix->retryFree, hipEventDisableTiming));
+		if (ix->retryArenas && ix->retryArenaLanes < bigLanes) {
+			size_t freeB = 0, totB = 0;
+			const bool room = hipMemGetInfo(&freeB, &totB) == hipSuccess && (uint64_t)freeB / 2u > (uint64_t)bigLanes * bigWords * 4u;
+			if (room) { HIPCHK(hipEventSynchronize(ix->retryFree)); (void)hipFree(ix->retryArenas); ix->retryArenas = nullptr; ix->retryArenaLanes = 0; }
+			else bigLanes = ix->retryArenaLanes;               /* no room to grow: the pass runs on what there is */
+		}
+		while (!ix->retryArenas) {
+			if (hipMalloc((void**)&ix->retryArenas, (size_t)bigLanes * bigWords * 4u) == hipSuccess) { ix->retryArenaLanes = bigLanes; break; }
+			(void)hipGetLastError();
+			ix->retryArenas = nullptr;
+			if (bigLanes <= BT_BLOCK) { fprintf(stderr, "bowtie_amd: no device memory for the best-first second pass\n"); return BT_ERR_DEVICE; }
+			bigLanes /= 2u;
+		}
+		if (bigLanes > ix->retryArenaLanes) bigLanes = ix->retryArenaLanes;
+		HIPCHK(hipStreamWaitEvent(c->stream, ix->retryFree, 0));
 		BtBestArgs A2 = A;
-		A2.arenas = c->bigArenas; A2.arenaWords = bigWords; A2.nextRead = c->d_cursor + 3;
+		A2.arenas = ix->retryArenas; A2.arenaWords = bigWords; A2.nextRead = c->d_cursor + 3;
 		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2; A2.workCap = c->retryCap;
 		if (bt_launch_best(&A2, bigLanes / BT_BLOCK, c->stream) != 0) return BT_ERR_DEVICE;
+		HIPCHK(hipEventRecord(ix->retryFree, c->stream));
 	}
 	HIPCHK(hipEventRecord(ring[1], c->stream));
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -1225,7 +1271,9 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	/* reads that outgrow their scratch stay flagged (BT_ST_OVERFLOW) for the caller: no second pass on the stream here */
 	/* the mismatch-pool cursor lives in the staging area: the context's own (d_cursor[1]) is reset by the next launch, which
 	 * may be enqueued before this batch's results have been copied */
-	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false, (uint32_t*)(d + o_cur));
+	/* BT_STREAM_OLD_CURSOR=1 (diagnostics): the cursors rounds 2-3 used -- the ring's for a carried batch, the
+	 * context's otherwise */
+	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false, env_u32("BT_STREAM_OLD_CURSOR", 0) ? nullptr : (uint32_t*)(d + o_cur));
 	if (rc != BT_OK) return rc;
 	s.in = in; s.out = out; s.tag = tag; s.n = n; s.o_hits = o_hits; s.o_nh = o_nh; s.o_st = o_st; s.o_mm = o_mm;
 	s.mmCursor = c->lastMmCursor; s.state = 1;

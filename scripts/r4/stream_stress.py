@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--mode", default="n2_k3")
     ap.add_argument("--no-permute", action="store_true")
     a = ap.parse_args()
+    if os.environ.get("STRESS_NO_PERMUTE"):
+        a.no_permute = True
     kw = T.MODES[a.mode]
     cap = 8
     names = ["syn100", "syn36", "syn150", "syn50lowq", "syn76", "syn100"]
@@ -117,7 +119,7 @@ def main():
             if len(reports) < 5:
                 reports.append(dict(round=rounds - 1, carry=carry, what=what))
         del al
-    print(json.dumps(dict(tag=a.tag, rounds=rounds, fails=fails, env={k: os.environ.get(k) for k in ("BT_STREAM_POISON", "BT_STREAM_ORDERED", "BT_STREAM_RECHECK", "BT_MAX_BLOCKS", "BT_LIB")}, reports=reports)))
+    print(json.dumps(dict(tag=a.tag, rounds=rounds, fails=fails, env={k: os.environ.get(k) for k in ("BT_STREAM_POISON", "BT_STREAM_ORDERED", "BT_STREAM_RECHECK", "BT_STREAM_OLD_CURSOR", "STRESS_NO_PERMUTE", "BT_MAX_BLOCKS", "BT_LIB")}, reports=reports)))
 
 
 if __name__ == "__main__":
