@@ -15,6 +15,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include "bt_core.h"
 #include "bt_kernels.h"
 
@@ -78,7 +79,12 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	}
 	__syncthreads();
 	S.a = &ARENA; S.slot = g;
-	static_assert(sizeof(BtLane) == 48 * 4, "pool record layout: 12 pieces of lane state, slot, request");
+	/* pool record: the lane's state in 16-byte pieces from the front, request at pieces 13 and 14, stamp at 15.  Builds that
+	 * keep the read in LDS (RL) have no use for the register window at the end of BtLane: it is neither parked nor adopted,
+	 * so it occupies no registers in them */
+	constexpr int LANE_PIECES = (int)((sizeof(BtLane) + 15) / 16), LANE_PIECES_RL = (int)((offsetof(BtLane, cs0) + 15) / 16);
+	constexpr int PIECES = RL ? LANE_PIECES_RL : LANE_PIECES;
+	static_assert(LANE_PIECES <= 13, "pool record layout: at most 13 pieces of lane state, then request and stamp");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
 	S.noCC = LITE ? 1u : 0u;
@@ -102,10 +108,10 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		if (BT_GP(const uint32_t, r->w)[60] == A.launchSeq - 1u) {
 			/* word by word into the lane state: a 16-byte-piece copy makes the compiler keep BtLane as twelve
 			 * 4-word vectors for the whole round loop, a different (and larger) kernel than the plain build */
-			uint32_t lw[48];
+			uint32_t lw[4 * LANE_PIECES] = {};
 			BT_UNROLL
-			for (int k = 0; k < 12; k++) { const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * k); lw[4 * k] = v.x; lw[4 * k + 1] = v.y; lw[4 * k + 2] = v.z; lw[4 * k + 3] = v.w; }
-			__builtin_memcpy(&L, lw, sizeof(L));
+			for (int k = 0; k < PIECES; k++) { const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * k); lw[4 * k] = v.x; lw[4 * k + 1] = v.y; lw[4 * k + 2] = v.z; lw[4 * k + 3] = v.w; }
+			__builtin_memcpy(&L, lw, RL ? offsetof(BtLane, cs0) : sizeof(L));
 			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 13); req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
 			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 14); req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
 			L.tosValid = 0; L.ccValid = 0;
@@ -119,6 +125,17 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 	}
 
+#if BT_DEFER_SLOW
+	/* The gate of the slow-state sweep (bt_core.h, BT_DEFER_SLOW): it opens every slowPeriod-th round of the wavefront, or
+	 * when at least slowMin of its lanes stand before it, or when the wavefront is about to park.  Called by the lanes
+	 * that are in a slow state, so the ballot counts exactly those. */
+	BtRes res;
+	bool forceOpen = false;
+	const uint32_t slowPeriod = A.slowPeriod ? A.slowPeriod : 1u, slowMin = A.slowMin ? A.slowMin : 65u;
+	auto gate = [&]() -> bool {
+		return forceOpen || (sc_rounds % slowPeriod) == 0u || (uint32_t)__builtin_popcountll(__ballot(1)) >= slowMin;
+	};
+#endif
 	for (;;) {
 		/* keep the compiler from hoisting the cold descriptor's fields into scalar registers for
 		 * the whole loop: they are read where they are used */
@@ -137,7 +154,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 #endif
 		/* ---- the round's memory requests: every lane's loads are issued, then one wait ---------- */
 		BT_PROF_T0(t_rank);
+#if !BT_DEFER_SLOW
 		BtRes res;
+#endif
 		{
 			const bool isRank = req.kind == RQ_RANK;
 			const bool isFetch = req.kind == RQ_FETCH;
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 					bt_rank4_blk(qa[2], qa[3], rowB % BT_BLK_ROWS, bB == zBlk, zPos, lf, &dummy);
 					res.q[1].x = lf[0]; res.q[1].y = lf[1]; res.q[1].z = lf[2]; res.q[1].w = lf[3];
 				}
-			} else {
+			} else if (!BT_DEFER_SLOW || isFetch) {    /* a lane whose sweep was deferred keeps the answer it has */
 				res.q[0] = qa[0]; res.q[1] = qa[1]; res.q[2] = qa[2]; res.q[3] = qa[3]; res.x = qx;
 			}
 		}
@@ -193,7 +212,11 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
+#if BT_DEFER_SLOW
+			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT, gate);
+#else
 			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
+#endif
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state == ST_IDLE) continue;
 			break;
@@ -225,16 +248,23 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			if (!dry && (sc_rounds & 15u) == 15u) dry = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.nextRead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)nReads;
 			if (dry) {
 				drained = true;
-				if (sc_rounds >= A.parkMinRounds && __ballot(live && ((cold->curBid - L.bid) & (BT_BATCH_RING - 1u)) >= A.maxAge) == 0) { parkNow = true; break; }
+				if (sc_rounds >= A.parkMinRounds && __ballot(live && ((cold->curBid - L.bid) & (BT_BATCH_RING - 1u)) >= A.maxAge) == 0) {
+#if BT_DEFER_SLOW
+					/* a lane whose sweep was deferred holds an answer that is not part of what is parked: one more round with
+					 * the gate open gives every such lane its next request */
+					if (__ballot(live && req.kind == RQ_NONE) != 0) forceOpen = true; else
+#endif
+					{ parkNow = true; break; }
+				}
 			}
 		}
 	}
 	if (EXT && parkNow && L.state != ST_IDLE) {
 		BtPoolRec* r = A.pool + (blockIdx.x * BT_BLOCK + threadIdx.x);
-		uint32_t lw[48];
-		__builtin_memcpy(lw, &L, sizeof(L));
+		uint32_t lw[4 * LANE_PIECES] = {};
+		__builtin_memcpy(lw, &L, RL ? offsetof(BtLane, cs0) : sizeof(L));
 		BT_UNROLL
-		for (int k = 0; k < 12; k++) { BtU4 v; v.x = lw[4 * k]; v.y = lw[4 * k + 1]; v.z = lw[4 * k + 2]; v.w = lw[4 * k + 3]; bt_st4((uint8_t*)r->w + 16 * k, v); }
+		for (int k = 0; k < PIECES; k++) { BtU4 v; v.x = lw[4 * k]; v.y = lw[4 * k + 1]; v.z = lw[4 * k + 2]; v.w = lw[4 * k + 3]; bt_st4((uint8_t*)r->w + 16 * k, v); }
 		{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 13, v); }
 		{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); bt_st4((uint8_t*)r->w + 16 * 14, v); }
 		{ BtU4 v; v.x = A.launchSeq; v.y = 0; v.z = 0; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 15, v); }

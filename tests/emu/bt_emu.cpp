@@ -128,6 +128,13 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	/* EMU_PARK_EVERY=<n>: every lane is parked and adopted again (carry-over) in one round out of n, at random */
 	const uint32_t parkEvery = getenv("EMU_PARK_EVERY") ? (uint32_t)atoi(getenv("EMU_PARK_EVERY")) : 0u;
 	uint32_t parkRng = 12345u;
+#if BT_DEFER_SLOW
+	/* the gate of the slow-state sweep: open one time in EMU_DEFER (default 3), drawn per lane and round -- a lane that
+	 * finds it closed comes back next round with its state and the answer to its last request untouched */
+	const uint32_t deferEvery = getenv("EMU_DEFER") ? (uint32_t)atoi(getenv("EMU_DEFER")) : 3u;
+	uint32_t gateRng = 4711u;
+	auto gate = [&]() -> bool { gateRng = gateRng * 1664525u + 1013904223u; return deferEvery <= 1u || (gateRng >> 9) % deferEvery == 0; };
+#endif
 	while (live > 0) {
 		for (uint32_t g = 0; g < nLanes; g++) {
 			if (drained[g]) continue;
@@ -138,7 +145,11 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
 					bt_lane_start<RL>(L, P, H, cold, scr[g], next++);
 				}
+#if BT_DEFER_SLOW
+				bt_lane_run<RL>(L, P, H, W, cold, scr[g], res[g], req, CNT, gate);
+#else
 				bt_lane_run<RL>(L, P, H, W, cold, scr[g], res[g], req, CNT);
+#endif
 				if (L.state != ST_IDLE) break;
 			}
 			if (drained[g]) continue;
@@ -174,7 +185,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 					bt_rank4(ix, (uint32_t)req.x, lf, &dummy);
 					res[g].q[1].x = lf[0]; res[g].q[1].y = lf[1]; res[g].q[1].z = lf[2]; res[g].q[1].w = lf[3];
 				}
-			} else {
+			} else if (!BT_DEFER_SLOW || req.kind == RQ_FETCH) {
 				memset(&res[g], 0, sizeof(BtRes));
 				for (uint32_t k = 0; k < req.n; k++) memcpy(&res[g].q[k], (const uint8_t*)(uintptr_t)req.a + 16 * k, 16);
 				if (req.x) memcpy(&res[g].x, (const void*)(uintptr_t)req.x, 16);
