@@ -1353,7 +1353,7 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 extern "C" void* bt_host_alloc(size_t bytes)
 {
 	void* p = nullptr;
-	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess /* any thread, any device */) { (void)hipGetLastError(); return nullptr; }
 	return p;
 }
 extern "C" void bt_host_free(void* p) { if (p) (void)hipHostFree(p); }

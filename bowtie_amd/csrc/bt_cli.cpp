@@ -947,6 +947,10 @@ int main(int argc, char** argv)
 		}
 		return r;
 	};
+	/* the index is located before the first batch's thread starts: find_index() leaves through exit() when there is none,
+	 * and no thread of ours may be inside the reader then */
+	const std::string base = find_index(O.index);
+	if (O.devices.empty()) O.devices.push_back(0);
 	std::unique_ptr<Job> first_job(new Job());
 	int first_rc = BT_OK;
 	const bool pinned = getenv("BT_CLI_PINNED") && atoi(getenv("BT_CLI_PINNED")) != 0;
@@ -963,9 +967,6 @@ int main(int argc, char** argv)
 			}
 	});
 
-	/* ---- index into HBM ---- */
-	const std::string base = find_index(O.index);
-	if (O.devices.empty()) O.devices.push_back(0);
 	const size_t ND = O.devices.size();
 	std::vector<bt_index*> idxs(ND, nullptr);
 	double t0 = now_s();
@@ -978,6 +979,7 @@ int main(int argc, char** argv)
 		for (auto& x : th) x.join();
 		for (size_t d = 0; d < ND; d++) if (rcs[d] != BT_OK) { rc = rcs[d]; break; }
 	}
+	/* ---- index into HBM (above) ---- */
 	prefetch.join();
 	if (rc != BT_OK) {
 		if (rc == BT_ERR_IO) die("Could not locate a Bowtie index corresponding to basename \"%s\"", O.index.c_str());

@@ -721,7 +721,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 	/* The states are visited in an order that lets the usual chains finish in one sweep (child
 	 * failed: FRAME_RETURN -> CHILD_RET -> BT_LOOP; phase change: FRAME_RETURN -> SEARCH_END ->
 	 * PHASE_NEXT -> SEARCH_BEGIN).  Within a block `break` leaves the block; a block that sets `req`
-	 * ends the lane's round (no later block runs: ST_IS tests req). */
+	 * ends the lane's round: it leaves the lane in a state no LATER block of the sweep takes (ST_IS does not test req; the three
+	 * blocks entered straight from the one before them use ST_IS_NOREQ), and the while condition ends the sweep. */
 	while (BT_IS_SLOW(L.state) && req.kind == RQ_NONE) {
 		BT_PROF_PASS();
 		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */

@@ -61,6 +61,7 @@ static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)
 	std::string names, raw;
 	std::vector<uint64_t> noff(keep.size() + 1), roff;
 	const bool has_raw = b->raw_off.size() == (size_t)b->n + 1;
+	const bool has_paired = b->paired.size() == (size_t)b->n;      /* --12: which records had a second end */
 	if (has_raw) roff.resize(keep.size() + 1);
 	uint32_t np = 0;
 	for (size_t k = 0; k < keep.size(); k++) {
@@ -69,7 +70,9 @@ static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)
 			memmove(b->seq + k * b->stride, b->seq + (size_t)i * b->stride, b->stride);
 			memmove(b->qual + k * b->stride, b->qual + (size_t)i * b->stride, b->stride);
 			b->len[k] = b->len[i]; b->seed[k] = b->seed[i]; b->rdid[k] = b->rdid[i];
+			if (has_paired) b->paired[k] = b->paired[i];
 		}
+		if (has_paired && b->paired[k]) np++;
 		noff[k] = names.size(); names.append(b->names, b->name_off[i], b->name_off[i + 1] - b->name_off[i]);
 		if (has_raw) { roff[k] = raw.size(); raw.append(b->raw, b->raw_off[i], b->raw_off[i + 1] - b->raw_off[i]); }
 	}
@@ -79,15 +82,19 @@ static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)
 	b->n = (uint32_t)keep.size();
 	b->len.resize(b->n); b->seed.resize(b->n); b->rdid.resize(b->n);
 	b->first_rdid = b->n ? b->rdid[0] : 0;
-	if (b->n_paired > b->n) b->n_paired = b->n;
-	(void)np;
+	if (has_paired) { b->paired.resize(b->n); b->n_paired = np; }
+	else if (b->n_paired > b->n) b->n_paired = b->n;
 }
 
 void bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order)
 {
 	order->assign(a->n, 1);
 	unp->n = 0; unp->n_paired = 0; unp->paired.clear();
-	if (a->paired.size() != a->n || a->n_paired == a->n) { a->paired.clear(); b->paired.clear(); return; }       /* pairs only */
+	if (!a->paired.empty() && a->paired.size() != a->n) {       /* the column did not follow its batch: never guess which records were pairs */
+		fprintf(stderr, "bt_io_split_tabbed: %zu pair flags for %u records\n", a->paired.size(), a->n);
+		abort();
+	}
+	if (a->paired.empty() || a->n_paired == a->n) { a->paired.clear(); b->paired.clear(); return; }       /* pairs only */
 	std::vector<uint32_t> kp, ku;
 	for (uint32_t i = 0; i < a->n; i++) { if (a->paired[i]) kp.push_back(i); else { ku.push_back(i); (*order)[i] = 0; } }
 	/* the unpaired reads: rows of `a` as they are (names and seeds were left alone by the mate-name fix) */

@@ -13,6 +13,10 @@ def pytest_cmdline_main(config):
     # six workers when pytest-xdist is there and the command line does not say otherwise (-n 0 for none): the CPU suite in
     # about three minutes, the GPU suite (one MI355X shared by the workers, each test with its own contexts) well inside the
     # driver's limit.  Without the plugin the suite simply runs in one process.
+    # An xdist WORKER runs this hook too, with numprocesses reset to None: it must never ask for workers of its own (it would
+    # become a controller, and so would each of its six: a fork storm).
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return
     if config.pluginmanager.hasplugin("xdist") and getattr(config.option, "numprocesses", None) is None \
             and not os.environ.get("BT_TEST_WORKERS") == "0":
         config.option.numprocesses = int(os.environ.get("BT_TEST_WORKERS", "6"))
