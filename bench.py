@@ -396,8 +396,6 @@ def main():
         lo = rank * per + min(rank, n % world)
         n = per + (1 if rank < n % world else 0)
         shard = (lo, lo + n)
-    if wl.get("paired"):
-        args.verify = False
     L = wl["length"]
 
     # ---- index: in HBM before anything is timed ------------------------------------------------
@@ -549,8 +547,14 @@ def main():
         tl, plen, rstarts = V.read_fragments(base)
         o = last["set"]
         t1 = time.perf_counter()
-        verified = V.verify_hits(text_t, tl, rstarts, rb["seq"], rb["qual"], L, o["hits"], o["n_hits"], o["mm_pool"],
-                                 dict(wl["pol"], seed_len=28, qual_thresh=70))
+        if paired:
+            # pairs: both mates' windows and mismatch lists + same reference, upstream mate first, orientation, fragment
+            # length, containment (bowtie_amd/verify.py: verify_pairs); `checked` counts pairs
+            verified = V.verify_pairs(text_t, tl, rstarts, rb["seq"], rb["qual"], rb2["seq"], rb2["qual"], L, L, o["hits"],
+                                      o["n_hits"], o["mm_pool"], dict(wl["pol"], seed_len=28, qual_thresh=70), hit_cap=hit_cap)
+        else:
+            verified = V.verify_hits(text_t, tl, rstarts, rb["seq"], rb["qual"], L, o["hits"], o["n_hits"], o["mm_pool"],
+                                     dict(wl["pol"], seed_len=28, qual_thresh=70))
         log("[bench] verify: %s in %.1fs" % (verified, time.perf_counter() - t1))
         if any(v for k, v in verified.items() if k != "checked"):
             raise SystemExit("bench.py --verify: reported hits fail the re-check: %s" % verified)
@@ -635,6 +639,7 @@ def main():
                                                   "unaligned": c5[3], "maxed": c5[4]},
                        "pipelined_contexts": len(pipes),
                        "hits_verified_against_text": verified["checked"] if verified else None,
+                       "verified_unit": ("pairs (both mates + pair constraints)" if paired else "hits") if verified else None,
                        "parallelism": "reads sharded x%d, index replicated" % world,
                        "strong": strong},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

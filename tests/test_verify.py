@@ -52,3 +52,84 @@ def test_tampered_hits_are_caught():
     H6[aligned[3], 0] = int(rstarts[0, 1]); H6[aligned[3], 1] = int(rstarts[0, 2]) + int(rstarts[1, 0]) - 50
     r = V.verify_hits(length=100, pol=kw, **t)
     assert r["bad_window"] >= 1
+
+
+def pair_tensors(index, b1, b2, per, cap=2):
+    hits, nh, st, pool = H.pack_hits(per, cap)
+    ln, plen, rstarts = V.read_fragments(os.path.join(T.G, index))
+    text = torch.from_numpy(T.joined_text(index).copy())
+    return dict(text_t=text, text_len=ln, rstarts=rstarts, seq1=torch.from_numpy(b1.seq.copy()), qual1=torch.from_numpy(b1.qual.copy()),
+                seq2=torch.from_numpy(b2.seq.copy()), qual2=torch.from_numpy(b2.qual.copy()),
+                hits_u8=torch.from_numpy(hits.view(np.uint8).copy()), n_hits=torch.from_numpy(nh.astype(np.int32)),
+                mm_pool=torch.from_numpy(pool.view(np.int16).copy()))
+
+
+def revcomp_batch(b):
+    import copy
+    r = copy.copy(b)
+    r.seq, r.qual = b.seq.copy(), b.qual.copy()
+    for i in range(b.n):
+        L = int(b.len[i])
+        s = b.seq[i, :L][::-1]
+        r.seq[i, :L] = np.where(s < 4, 3 - s, s)
+        r.qual[i, :L] = b.qual[i, :L][::-1]
+    return r
+
+
+PAIR_RULES = dict(bad_window=0, bad_mm_count=0, bad_mm_list=0, bad_policy=0, bad_cost=0, bad_mates=0, bad_order=0,
+                  bad_orientation=0, bad_insert=0, bad_containment=0, odd_count=0)
+
+
+@pytest.mark.parametrize("index,reads,mode,v1", [
+    ("e_coli", "pe50", "pe_n1_best_X500", False), ("e_coli", "pe50", "pe_n2_best_X500_ff", False),
+    ("e_coli", "pe50", "pe_n2_best_X500_rf", False), ("e_coli", "pe50", "pe_n2_best_X400_I250_k3", False),
+    ("e_coli", "pe50", "pe_v2_best_X500", False), ("multi", "pe50", "pe_n2_best_X500", False),
+    ("e_coli", "pe50", "pe_n2_best_X500", True)])
+def test_oracle_pairs_verify_clean(index, reads, mode, v1):
+    """what the oracle reports for pairs (the golden-pinned PairedBWAlignerV2 / V1 restatements) passes every rule of
+    verify_pairs -- with --ff / --rf, -I and -k 3 (the first pair of each is the one re-derived)"""
+    b1, b2 = T.pair_set(index, reads)
+    # the synthetic pairs are --fr fragments: --ff wants mate 2 as its reverse complement, --rf both mates
+    if mode.endswith("_ff"):
+        b2 = revcomp_batch(b2)
+    elif mode.endswith("_rf"):
+        b1, b2 = revcomp_batch(b1), revcomp_batch(b2)
+    per = T.oracle_pair_results(index, b1, b2, T.MODES[mode], v1=v1)
+    cap = max(2, max(len(h) for h, _, _ in per))
+    t = pair_tensors(index, b1, b2, per, cap=cap)
+    r = V.verify_pairs(len1=50, len2=50, pol=T.MODES[mode], hit_cap=cap, chunk=61, **t)
+    assert r["checked"] == sum(1 for h, _, _ in per if len(h) >= 2) > 50
+    assert {k: v for k, v in r.items() if k != "checked"} == PAIR_RULES
+
+
+def test_tampered_pairs_are_caught():
+    b1, b2 = T.pair_set("e_coli", "pe50")
+    mode = T.MODES["pe_n1_best_X500"]
+    per = T.oracle_pair_results("e_coli", b1, b2, mode)
+    t = pair_tensors("e_coli", b1, b2, per)
+    H6 = t["hits_u8"].view(torch.int32).view(-1, 2, 6)
+    al = (t["n_hits"] >= 2).nonzero().flatten()
+    base = V.verify_pairs(len1=50, len2=50, pol=mode, **t)
+    assert {k: v for k, v in base.items() if k != "checked"} == PAIR_RULES
+
+    def with_change(fn):
+        keep = H6.clone()
+        fn()
+        r = V.verify_pairs(len1=50, len2=50, pol=mode, **t)
+        H6.copy_(keep)
+        return r
+    i = int(al[0])
+    r = with_change(lambda: H6[i].copy_(H6[i].flip(0)))                                   # downstream mate first
+    assert r["bad_order"] == 1
+    r = with_change(lambda: H6[i, 1, 5].copy_(H6[i, 1, 5] ^ 0x30000))                     # both records say the same mate
+    assert r["bad_mates"] == 1
+    r = with_change(lambda: H6[i, 1, 1].add_(600))                                        # fragment longer than -X
+    assert r["bad_insert"] == 1 and r["bad_mm_count"] >= 1
+    r = with_change(lambda: (H6[i, 0, 5].copy_(H6[i, 0, 5] ^ 0x100), H6[i, 1, 5].copy_(H6[i, 1, 5] ^ 0x100)))
+    assert r["bad_orientation"] == 1                                                       # both strands flipped: not --fr
+    r = with_change(lambda: H6[i, 1, 1].copy_(H6[i, 0, 1]))                                # same start: one contains the other
+    assert r["bad_containment"] == 1
+    r = V.verify_pairs(len1=50, len2=50, pol=dict(mode, max_ins=60), **t)                  # the policy, not the hits
+    assert r["bad_insert"] > 10
+    t["n_hits"][int(al[1])] = 3
+    assert V.verify_pairs(len1=50, len2=50, pol=mode, **t)["odd_count"] == 1
