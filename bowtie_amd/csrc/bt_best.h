@@ -30,9 +30,9 @@
  *   * Edit lists are parent-linked (a branch stores its own edit and its parent's offset).
  *   * Each PathManager's heap is an array of branch offsets, doubled on demand.
  *
- * This first version runs each lane's automaton straight through (loads where the data is
- * needed, divergent control flow inside the wavefront); it is the parity baseline for the
- * --best path, not yet a tuned kernel.
+ * Every lane runs its own control flow (loads where the data is needed): the kernel is plain SIMT, not
+ * organised into lock-step rounds the way bt_core.h's engine is.  DESIGN.md 4.2 has the measurements
+ * of what that costs and of what has been done about it.
  */
 #ifndef BT_BEST_H_
 #define BT_BEST_H_
@@ -79,6 +79,21 @@
 #define BF_REFILL BF_FAST_EXTEND
 #endif
 #define BF_IS_V1(P) ((P).paired == 2u)
+/* Section timers of the profiling build (-DBF_PROFILE, `make bestprof`; scripts/best_sections.py): wavefront cycles, passes
+ * and lanes per section, tallied by the first active lane into bf_prof[] (bt_best_kernels.hip).  Sections nest (a leaf's
+ * advance contains the streak, the curtail and the split); a section entered by some of a wavefront's lanes while the
+ * others wait counts what the wavefront spends on those lanes.  No-ops in the product build. */
+enum { BP_RUN = 0, BP_BEGIN, BP_SETQ, BP_ADV, BP_LEAF, BP_STREAK, BP_CURTAIL, BP_SPLIT, BP_SORT, BP_CHASE, BP_REPORT, BP_REF, BP_END, BP_FRONT, BP_N };   /* BP_N <= 16 */
+#if defined(BF_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long bf_prof[3 * 16];
+#define BF_PT0(v) const unsigned long long v = __builtin_readcyclecounter()
+#define BF_PADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
+	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) { atomicAdd(&bf_prof[3 * (k)], __builtin_readcyclecounter() - (v)); \
+		atomicAdd(&bf_prof[3 * (k) + 1], 1ull); atomicAdd(&bf_prof[3 * (k) + 2], (unsigned long long)__builtin_popcountll(ex_)); } } while (0)
+#else
+#define BF_PT0(v)
+#define BF_PADD(k, v)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BF_G __attribute__((address_space(1)))
 #else
@@ -796,6 +811,7 @@ BF_FN void bf_qual_low2(const BfRead& R, uint32_t fw, uint32_t ebwtFw, uint32_t 
  * EbwtRangeSource::initBranch (:1920-2051) */
 BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 {
+	BF_PT0(t_setq);
 	const BfSpec& sp = leaf_spec(X, d);
 	const BtIndexDev& ix = X.ix[sp.mirror];
 	const uint32_t maq = X.P->maq;
@@ -958,6 +974,7 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	AW(d + DR_COST) = mc | (minCost << 16);
 	AW(d + DR_FLAGS) = ((rsf & 1u) ? BF_F_DONE : 0u) | ((rsf & 2u) ? BF_F_FOUND : 0u);
 	pm_leave(X, d);
+	BF_PADD(BP_SETQ, t_setq);
 }
 #undef BF_LQ
 
@@ -985,6 +1002,7 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 	uint32_t seedN = 0, seedM[3] = {0, 0, 0};
 	if (seedEdits) { seedN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) seedM[k] = AW(d + LF_SEEDMM0 + k); }
 	do {
+		BF_PT0(t_front);
 		const uint32_t br = pm_front(X, d);
 		uint32_t R[BF_BRW];
 		{
@@ -993,12 +1011,14 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
 			R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
 		}
+		BF_PADD(BP_FRONT, t_front);
 		const uint32_t cost = R[BR_COSTHAM] & 0xffffu;               /* fixed while the branch is extended */
 		const uint32_t nedits = R[BR_EDIT] >> 16;
 		const uint32_t rdepth = R[BR_RDLEN] & 0xffffu;
 		uint32_t top = 0, bot = 0;
 		bool curtail = false, extended = false, tbNew = false, dirty = false, havePf = false;
 		uint32_t pfC = 0, pfQ = 0;
+		BF_PT0(t_streak);
 		for (;;) {                                                     /* the streak: one step per turn */
 			const uint32_t blen = R[BR_RDLEN] >> 16;
 			const uint32_t depth = rdepth + blen;
@@ -1128,14 +1148,15 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			if ((uint32_t)AW(PMW(LF_HEAP)) != br || X.pm[6] != br || PMW(LF_PMCOST) != cost) { fprintf(stderr, "BF_CHECK: the extended branch is not the queue's front\n"); abort(); }
 #endif
 		}
+		BF_PADD(BP_STREAK, t_streak);
 		/* the streak ends here: the arena gets what its steps would have written one by one, before anything reads it */
 		if (tbNew) { AW(br + BR_TOP) = top; AW(br + BR_BOT) = bot; }
 		else if (dirty) { AW(br + BR_TOP) = R[BR_TOP]; AW(br + BR_BOT) = R[BR_BOT]; }
 		if (dirty) { AW(br + BR_FLAGS) = R[BR_FLAGS]; AW(br + BR_LTOP) = R[BR_LTOP]; AW(br + BR_LBOT) = R[BR_LBOT]; }
 		if (dirty || extended) AW(br + BR_RDLEN) = R[BR_RDLEN];
-		if (curtail) pm_curtail_regs(X, d, br, depth3, R);
+		{ BF_PT0(t_curtail); if (curtail) pm_curtail_regs(X, d, br, depth3, R); BF_PADD(BP_CURTAIL, t_curtail); }
 		if (X.ovf) break;
-		if (!pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0)) pm_reset(X, d);
+		{ BF_PT0(t_split); const bool sp_ok = pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0); BF_PADD(BP_SPLIT, t_split); if (!sp_ok) pm_reset(X, d); }
 		if (X.ovf) break;
 		if (pm_size(X, d) == 0) break;
 		/* the queue's cost word is its front's cost: every change of a queued branch's cost (curtail, a delayed increase) is
@@ -1278,9 +1299,9 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 			} else if (empty || cur == 0) curtail = true;
 			else AW(br + BR_RDLEN) = rdepth | ((blen + 1u) << 16);        /* Branch::extend */
 		}
-		if (curtail) pm_curtail(X, d, br, depth3);
+		{ BF_PT0(t_curtail); if (curtail) pm_curtail(X, d, br, depth3); BF_PADD(BP_CURTAIL, t_curtail); }
 		if (X.ovf) break;
-		if (!pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0)) pm_reset(X, d);
+		{ BF_PT0(t_split); const bool sp_ok = pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0); BF_PADD(BP_SPLIT, t_split); if (!sp_ok) pm_reset(X, d); }
 		if (X.ovf) break;
 		if (pm_size(X, d) == 0) break;
 		if (br_cost(X, pm_front(X, d)) != cost) break;
@@ -1300,7 +1321,7 @@ BF_FN void leaf_advance(BfLane& X, uint32_t d)
 	if ((fl & BF_F_DONE) || pm_size(X, d) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
 #endif
 	const BfSpec& sp = leaf_spec(X, d);
-	leaf_advance_branch(X, d, sp);
+	{ BF_PT0(t_leaf); leaf_advance_branch(X, d, sp); BF_PADD(BP_LEAF, t_leaf); }
 	fl &= ~(BF_F_DONE | BF_F_FOUND);
 	if (pm_size(X, d) == 0) fl |= BF_F_DONE;
 	const uint32_t pmc = PMW(LF_PMCOST), adj = AW(d + DR_COST) >> 16;
@@ -1344,7 +1365,9 @@ BF_FN void cost_add_rss(BfLane& X, uint32_t d, uint32_t p)
 }
 
 /* CostAwareRangeSourceDriver::sortActives (range_source.h:2370-2415) */
-BF_FN void cost_sort_actives(BfLane& X, uint32_t d)
+BF_FN void cost_sort_actives_body(BfLane& X, uint32_t d);
+BF_FN void cost_sort_actives(BfLane& X, uint32_t d) { BF_PT0(t_sort); cost_sort_actives_body(X, d); BF_PADD(BP_SORT, t_sort); }
+BF_FN void cost_sort_actives_body(BfLane& X, uint32_t d)
 {
 	const uint32_t vec = AW(d + CA_ACT);
 	uint32_t n = AW(d + CA_NACT), sz = n;
@@ -1844,9 +1867,9 @@ BF_FN void bf_build_tree_v1(BfLane& X, uint32_t tops[4])
 #endif
 
 #if BF_ONE_LEAF_SITE
-#define BF_ADVANCE_TOP(X, d) bf_advance_top(X, d)
+#define BF_ADVANCE_TOP(X, d) do { BF_PT0(t_adv); bf_advance_top(X, d); BF_PADD(BP_ADV, t_adv); } while (0)
 #else
-#define BF_ADVANCE_TOP(X, d) cost_advance<0>(X, d)
+#define BF_ADVANCE_TOP(X, d) do { BF_PT0(t_adv); cost_advance<0>(X, d); BF_PADD(BP_ADV, t_adv); } while (0)
 #endif
 
 /* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
@@ -1892,23 +1915,27 @@ BF_FN void ch_set_row(BfLane& X, BfChase& c, uint32_t row)
 }
 BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uint32_t mirror, uint32_t qlen)
 {
+	BF_PT0(t_chase);
 	c.mirror = mirror; c.qlen = qlen; c.top = top; c.bot = bot;
 	c.irow = top + (bf_rnd(X.alRnd) % (bot - top));
 	c.done = 0; c.tidx = BT_OFF_MASK;
 	ch_set_row(X, c, c.irow);
+	BF_PADD(BP_CHASE, t_chase);
 }
 BF_FN void ch_advance(BfLane& X, BfChase& c)
 {
+	BF_PT0(t_chase);
 	c.tidx = BT_OFF_MASK;
 	if (c.cDone) {
 		c.row++;
 		if (c.row == c.bot) c.row = c.top;
-		if (c.row == c.irow) { c.done = 1; return; }
-		ch_set_row(X, c, c.row);
+		if (c.row == c.irow) c.done = 1;
+		else ch_set_row(X, c, c.row);
 	} else {
 		ch_row_advance(X, c);
 		if (c.cDone) ch_row_off(X, c);
 	}
+	BF_PADD(BP_CHASE, t_chase);
 }
 
 /* ---- sink + hit record -------------------------------------------------------------------------
@@ -1981,8 +2008,17 @@ BF_FN bool bf_emit_hit(BfLane& X, const BtBatchDev& B, uint32_t fw, bool flip, u
 }
 
 /* a hit from a leaf's current range: its edits are the found branch's chain plus the seed range's */
+BF_FN bool bf_report_leaf_body(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff, uint32_t mate, uint32_t oms, bool ebwtFw);
 BF_FN bool bf_report_leaf(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff, uint32_t mate,
                           uint32_t oms, bool ebwtFw)
+{
+	BF_PT0(t_report);
+	const bool r = bf_report_leaf_body(X, B, leaf, tidx, toff, mate, oms, ebwtFw);
+	BF_PADD(BP_REPORT, t_report);
+	return r;
+}
+BF_FN bool bf_report_leaf_body(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff, uint32_t mate,
+                               uint32_t oms, bool ebwtFw)
 {
 	const BfSpec& sp = leaf_spec(X, leaf);
 	const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu, nmm = AW(leaf + LF_CURCOST) >> 16;
@@ -2047,6 +2083,7 @@ BF_FN void bf_read_begin(BfLane& X, const BtBatchDev& B, uint32_t rd)
 }
 BF_FN void bf_read_end(BfLane& X, const BtBatchDev& B, uint32_t mult)
 {
+	BF_PT0(t_end);
 	if (X.ovf) X.status |= BT_STF_OVERFLOW;
 	/* NBestFirstStrat::finishReadImpl (hit.h:1098-1110): every buffered hit's oms = #buffered / mult - 1 */
 	if (X.P->sinkStrata) {
@@ -2055,6 +2092,7 @@ BF_FN void bf_read_end(BfLane& X, const BtBatchDev& B, uint32_t mult)
 	}
 	BT_GP(uint32_t, B.n_hits)[X.rd] = X.nhits;
 	BT_GP(uint8_t, B.status)[X.rd] = (uint8_t)X.status;
+	BF_PADD(BP_END, t_end);
 }
 BF_INL void bf_chase_init(BfChase& ch)
 {
@@ -2065,6 +2103,7 @@ BF_INL void bf_chase_init(BfChase& ch)
 /* ---- one read: UnpairedAlignerV2::setQuery + advance() until done (aligner.h:434-567) ---------- */
 BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 {
+	BF_PT0(t_begin);
 	bf_read_begin(X, B, rd);
 	if (X.R[0].len < 4u) {
 		X.status |= BT_STF_SKIPPED;
@@ -2074,6 +2113,7 @@ BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 		bf_chase_init(ch);
 		bool done = true, chase = false;
 		if (!X.ovf) { cost_set_query<0>(X, drv); done = dr_done(X, drv); }
+		BF_PADD(BP_BEGIN, t_begin);
 		while (!done && !X.ovf) {
 			if (chase) {
 				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
@@ -2274,8 +2314,17 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 /* PairedBWAlignerV2::resolveOutstandingInRef + report (aligner.h:1883-1997, 1720-1788): the anchor
  * mate's range `leaf` resolved to (tidx, toff); look for the other mate in the window the insert
  * constraints allow and report the pair, upstream mate first.  true = the sink says stop. */
+BF_FN bool bf_resolve_in_ref_body(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff, uint32_t pairsFw, uint32_t pairsRc, uint32_t mmBuf);
 BF_FN bool bf_resolve_in_ref(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff,
                              uint32_t pairsFw, uint32_t pairsRc, uint32_t mmBuf)
+{
+	BF_PT0(t_ref);
+	const bool r = bf_resolve_in_ref_body(X, B, leaf, tidx, toff, pairsFw, pairsRc, mmBuf);
+	BF_PADD(BP_REF, t_ref);
+	return r;
+}
+BF_FN bool bf_resolve_in_ref_body(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint32_t tidx, uint32_t toff,
+                                  uint32_t pairsFw, uint32_t pairsRc, uint32_t mmBuf)
 {
 	const BfProgram& P = *X.P;
 	const BfSpec& sp = leaf_spec(X, leaf);
@@ -2332,6 +2381,7 @@ BF_FN bool bf_resolve_in_ref(BfLane& X, const BtBatchDev& B, uint32_t leaf, uint
 /* PairedBWAlignerV2::setQuery + advance() until done (aligner.h:1571-1701), reportSe off */
 BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 {
+	BF_PT0(t_begin);
 	bf_read_begin(X, B, rd);
 	if (X.R[0].len < 4u || X.R[1].len < 4u) {
 		X.status |= BT_STF_SKIPPED;
@@ -2348,6 +2398,7 @@ BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 			cost_set_query<0>(X, drv);
 			done = false;
 		}
+		BF_PADD(BP_BEGIN, t_begin);
 		while (!done && !X.ovf) {
 			if (chase) {
 				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }

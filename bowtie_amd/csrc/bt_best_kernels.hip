@@ -12,6 +12,9 @@
  * unpaired reads (MixedMultiAligner::run + UnpairedAlignerV2, aligner.h:244-360, 381-599).
  */
 #include <hip/hip_runtime.h>
+#if defined(BF_PROFILE)
+__device__ unsigned long long bf_prof[3 * 16];      /* bt_best.h: cycles, passes, lanes per section (BP_*) */
+#endif
 #include "bt_best.h"
 #include "bt_kernels.h"
 
@@ -81,10 +84,12 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 		/* a read that outgrows its arena is searched again by the host through the twin context:
 		 * its partial work is not tallied */
 		const BfLane before = X;
+		BF_PT0(t_run);
 #if BF_HAVE_V1
 		if (paired && BF_IS_V1(PROG)) bf_run_pair_v1(X, BATCH, rd); else
 #endif
 		if (paired) bf_run_pair(X, BATCH, rd); else bf_run_read(X, BATCH, rd);
+		BF_PADD(BP_RUN, t_run);
 		if (X.status & BT_STF_OVERFLOW) {
 			X.c_lfex = before.c_lfex; X.c_lf2 = before.c_lf2; X.c_lf1 = before.c_lf1; X.c_chase = before.c_chase;
 			X.c_ftab = before.c_ftab; X.c_offs = before.c_offs; X.c_rst = before.c_rst; X.c_same = before.c_same;
@@ -112,6 +117,22 @@ extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint
 {
 	hipLaunchKernelGGL(bt_collect_flagged_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, n, flag, list, count, cap);
 	return (int)hipGetLastError();
+}
+
+/* the profiling build's section tallies (bt_best.h, BF_PROFILE): out[3 * n] = cycles, passes, lanes per section; reset != 0
+ * clears them.  Returns the number of sections, 0 in a build without them. */
+extern "C" int bt_best_prof_read(unsigned long long* out, int cap, int reset)
+{
+#if defined(BF_PROFILE)
+	unsigned long long h[3 * 16] = {};
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bf_prof), sizeof(h)) != hipSuccess) return 0;
+	for (int i = 0; i < 3 * BP_N && i < cap; i++) out[i] = h[i];
+	if (reset) { unsigned long long z[3 * 16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bf_prof), z, sizeof(z)); }
+	return BP_N;
+#else
+	(void)out; (void)cap; (void)reset;
+	return 0;
+#endif
 }
 
 /* blocks per CU the kernel's register budget allows (= waves per SIMD: 256-lane blocks, 4 SIMDs) */

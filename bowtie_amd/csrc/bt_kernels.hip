@@ -2,12 +2,12 @@
  * bt_kernels.hip -- gfx950 kernels of the FM-index search path.
  *
  *   bt_search_kernel : one lane = one read automaton (bt_core.h).  The 64 reads of a wavefront
- *                      advance in lock step from LF-mapping to LF-mapping; the rank gathers of
- *                      all lanes (one 64-byte side + the partner side's 8 counter bytes per BWT
- *                      row, i.e. one 128-byte side pair) are issued together at one program
- *                      point, whatever phase / backtrack frame / SA walk each read is in.
- *                      Lanes that finish a read pull the next one from a global counter
- *                      (wave-aggregated atomic), so wavefronts stay full until the batch drains.
+ *                      advance in lock step from request to request; the rank gathers of all lanes
+ *                      (one 32-byte rank block per BWT row -- four absolute counters and the two
+ *                      bit planes of the block's 64 rows, bt_rank.h -- or up to 4+1 16-byte pieces
+ *                      of a fetch) are issued together at one program point, whatever phase /
+ *                      backtrack frame / SA walk each read is in.  Lanes that finish a read pull the
+ *                      next one from a global counter, so wavefronts stay full until the batch drains.
  *   bt_probe_*       : known-answer probes of rank/LF and the SA walk.
  *
  * Replaces (reference, CPU): the worker loops of ebwt_search.cpp:1130/1606/2056/2378 and
