@@ -504,7 +504,6 @@ static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
 		warm->offRate[m] = d.offRate; warm->ftabChars[m] = d.ftabChars; warm->len[m] = d.len;
 		for (int k = 0; k < 5; k++) A->H.fchr[m][k] = d.fchr[k];
 	}
-	A->slowPeriod = env_u32("BT_SLOW_PERIOD", 0); A->slowMin = env_u32("BT_SLOW_MIN", 0);   /* BT_DEFER_SLOW builds only */
 }
 
 /* Second pass, on the stream, over the reads of `v` whose search outgrew the per-read scratch: collected from the

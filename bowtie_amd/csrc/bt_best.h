@@ -55,29 +55,18 @@
 #define BF_UNROLL16
 #endif
 #define BF_HAVE_V1 1
-/* 1: leaf_advance_branch keeps a branch it is simply extending in registers from step to step (see there).  Off in the
- * shipped build until it has run on a GPU: the host build of the engine is bit-identical either way (tests/emu). */
-#ifndef BF_FAST_EXTEND
-#define BF_FAST_EXTEND 0
-#endif
-/* part of the above that can be measured apart: the cost-aware driver's sort and mate check work on gathered copies of
- * their children's flags and costs (48-word local arrays, which the compiler keeps in scratch memory) */
-#ifndef BF_FAST_GATHER
-#define BF_FAST_GATHER BF_FAST_EXTEND
-#endif
-/* another part that can be measured apart: the aligner's driver is advanced by bf_advance_top, which walks down to the
- * leaf that is due (the first halves of cost_advance / seeded_advance), advances it at ONE place in the code, and walks
- * back up (their second halves) -- so that the lanes of a wavefront, each with its own leaf, run their extension loops
- * together whichever kind of node the leaf hangs from */
-#ifndef BF_ONE_LEAF_SITE
-#define BF_ONE_LEAF_SITE BF_FAST_EXTEND
-#endif
-/* and another: a read's run as begin / one turn of its loop / end (bf_run_begin, bf_run_step, bf_run_end), so that the
- * kernel can give a lane its next read while the wavefront's other lanes are still on theirs, instead of the whole
- * wavefront waiting for its slowest read before any lane takes a new one */
-#ifndef BF_REFILL
-#define BF_REFILL BF_FAST_EXTEND
-#endif
+/* How the engine is organised around what a lane waits for (round 4: measured on the GPU against the reference-shaped
+ * code it replaced, profiles/r4/first_call_SUMMARY.txt and third_call_SUMMARY.txt -- 1.9x / 1.7x on e_coli, 1.6x / 1.4x at
+ * hg19 scale; the other halves of those forks are gone):
+ *   * leaf_advance_branch keeps a branch it is simply extending in registers from step to step (the streak, see there);
+ *   * a leaf's six PathManager words live in the lane while the leaf is worked on (pm_enter / pm_leave);
+ *   * the cost-aware driver's sort and mate check work on gathered copies of their children's flags and costs;
+ *   * the aligner's driver is advanced by bf_advance_top, which walks down to the leaf that is due (the first halves of
+ *     cost_advance / seeded_advance), advances it at ONE place in the code, and walks back up (their second halves) -- so
+ *     that the lanes of a wavefront, each with its own leaf, run their extension loops together whichever kind of node the
+ *     leaf hangs from.
+ * Reads are handed out a wavefront at a time (bt_best_kernels.hip): a loop that gave a lane its next read while the others
+ * were still on theirs was measured 3.4x slower on e_coli (every turn then pays for some lane's tree set-up). */
 #define BF_IS_V1(P) ((P).paired == 2u)
 /* Section timers of the profiling build (-DBF_PROFILE, `make bestprof`; scripts/best_sections.py): wavefront cycles, passes
  * and lanes per section, tallied by the first active lane into bf_prof[] (bt_best_kernels.hip).  Sections nest (a leaf's
@@ -157,7 +146,7 @@ enum {
 	LF_SEED            /* seedRange: cost | n<<16 */, LF_SEEDMM0, LF_SEEDMM1, LF_SEEDMM2 /* mms | refc<<16 */,
 	/* cost-aware (CostAwareRangeSourceDriver) */
 	CA_RSS = 3, CA_NRSS /* n | cap<<16 */, CA_ACT, CA_NACT, CA_RND, CA_LAST, CA_DELAYED, CA_OPTS /* 1 strandFix, 2 patsrc set */,
-	CA_KEY /* BF_FAST_GATHER: the sort's key array */, CA_KEYCAP,
+	CA_KEY /* the sort's key array (drivers with more than sixteen children) */, CA_KEYCAP,
 	/* seeded (EbwtSeededRangeSourceDriver) */
 	SD_FULL = 3, SD_SEED, SD_FACT
 };
@@ -194,10 +183,8 @@ struct BfLane {                   /* per-lane registers / private memory */
 	const BfProgram* P;
 	const BtRefDev* ref;          /* paired-end only                                              */
 	BfRead R[2];                  /* the read / the two mates                                     */
-#if BF_FAST_EXTEND
 	uint32_t hasN;                /* bit m: mate m holds an N (found once, at bf_read_begin)      */
 	uint32_t pm[7];               /* the leaf's PathManager words LF_HEAP..LF_RND while leaf_set_query / leaf_advance run (pm_enter / pm_leave); [6] = the queue's front */
-#endif
 	uint32_t rd;
 	int32_t  btCnt;
 	uint32_t alRnd;
@@ -217,9 +204,8 @@ BF_INL uint32_t bf_rnd(uint32_t& last)                       /* RandomSource::ne
 }
 BF_INL uint32_t bf_rnd_at(BfLane& X, uint32_t off) { uint32_t s = AW(off); uint32_t r = bf_rnd(s); AW(off) = s; return r; }
 /* The six PathManager words of a leaf (queue base, size | capacity, branch-pool cursors, queue cost, generator) are read
- * at the head of nearly every dependent chain of loads in the leaf's code.  BF_FAST_EXTEND: they live in the lane for
+ * at the head of nearly every dependent chain of loads in the leaf's code: they live in the lane for
  * the duration of leaf_set_query / leaf_advance (pm_enter loads them, pm_leave stores them; nothing else runs between). */
-#if BF_FAST_EXTEND
 #define PMW(w) (X.pm[(w) - LF_HEAP])
 #define PM_RND(X, d) bf_rnd(X.pm[LF_RND - LF_HEAP])
 BF_INL void pm_enter(BfLane& X, uint32_t d)
@@ -229,12 +215,6 @@ BF_INL void pm_enter(BfLane& X, uint32_t d)
 }
 #define PM_HSET(heap, idx, x) do { const uint32_t hs_i = (idx), hs_x = (x); AW((heap) + hs_i) = hs_x; if (hs_i == 0) X.pm[6] = hs_x; } while (0)
 BF_INL void pm_leave(BfLane& X, uint32_t d) { for (uint32_t k = 0; k < 6u; k++) AW(d + LF_HEAP + k) = X.pm[k]; }
-#else
-#define PMW(w) AW(d + (w))
-#define PM_RND(X, d) bf_rnd_at(X, (d) + LF_RND)
-#define pm_enter(X, d) ((void)0)
-#define pm_leave(X, d) ((void)0)
-#endif
 
 BF_INL uint32_t bf_alloc(BfLane& X, uint32_t n)
 {
@@ -279,7 +259,6 @@ BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32
 	/* branch records start on a 16-byte boundary: leaf_advance_branch reads one in four 16-byte pieces */
 	if (X.top & 3u) (void)bf_alloc(X, 4u - (X.top & 3u));
 	const uint32_t b = bf_alloc(X, BF_BRW);
-#if BF_FAST_EXTEND
 	/* the record in four 16-byte stores, prepped from the values at hand (br_prep reads back what was just stored) */
 	{
 		uint32_t f = 0, lt = 0, lb = 0;
@@ -294,7 +273,6 @@ BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32
 	}
 	X.c_frames++;
 	return b;
-#endif
 	AW(b + BR_ID) = id; AW(b + BR_D01) = d01; AW(b + BR_D23) = d23;
 	AW(b + BR_RDLEN) = rdepth | (len << 16); AW(b + BR_COSTHAM) = (cost & 0xffffu) | (ham << 16);
 	AW(b + BR_TOP) = top; AW(b + BR_BOT) = bot; AW(b + BR_FLAGS) = 0;
@@ -349,7 +327,6 @@ BF_FN bool bf_before(BfLane& X, uint32_t a, uint32_t b)        /* CostCompare()(
 	return AW(b + BR_ID) < AW(a + BR_ID);
 }
 
-#if BF_FAST_EXTEND
 /* what CostCompare looks at, fetched in one go (the record's first two 16-byte pieces) instead of field by field as the
  * comparison proceeds */
 struct BfKey { uint32_t cost, un, depth, id; };
@@ -425,70 +402,9 @@ BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
 	PMW(LF_PMCOST) = haveFront ? frontCost : br_cost(X, n > 1u ? AW(heap) : top);
 	return top;
 }
-#define BF_PM_PUSH_POP_DONE 1
-#endif
-#if !defined(BF_PM_PUSH_POP_DONE)
-BF_FN void pm_push(BfLane& X, uint32_t d, uint32_t v)          /* PathManager::push (range_source.h:1361-1372) */
-{
-	uint32_t heap = PMW(LF_HEAP), sz = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
-	if (sz == cap) {
-		const uint32_t ncap = cap ? cap * 2u : 8u;
-		if (ncap > 0xffffu) { X.ovf = 1; return; }
-		const uint32_t nh = bf_alloc(X, ncap);
-		if (X.ovf) return;
-		for (uint32_t k = 0; k < sz; k++) AW(nh + k) = AW(heap + k);
-		heap = nh; cap = ncap; PMW(LF_HEAP) = heap;
-	}
-	uint32_t hole = sz;
-	while (hole > 0) {
-		const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
-		if (!bf_before(X, pv, v)) break;
-		AW(heap + hole) = pv; hole = parent;
-	}
-	AW(heap + hole) = v;
-	PMW(LF_HEAPSZ) = (sz + 1u) | (cap << 16);
-	PMW(LF_PMCOST) = br_cost(X, AW(heap));
-}
-
-/* PathManager::pop (range_source.h:1337-1356).  minCost is read from the queue's front even when
- * the queue has just become empty: vector::front() then still sees the element just removed. */
-BF_FN uint32_t pm_pop(BfLane& X, uint32_t d)
-{
-	const uint32_t heap = PMW(LF_HEAP), n = PMW(LF_HEAPSZ) & 0xffffu, cap = PMW(LF_HEAPSZ) >> 16;
-	const uint32_t top = AW(heap);
-	if (n > 1u) {
-		const uint32_t value = AW(heap + n - 1u);
-		AW(heap + n - 1u) = top;
-		const uint32_t len = n - 1u;
-		uint32_t hole = 0, second = 0;
-		while (second < (len - 1u) / 2u) {
-			second = 2u * (second + 1u);
-			if (bf_before(X, AW(heap + second), AW(heap + second - 1u))) second--;
-			AW(heap + hole) = AW(heap + second); hole = second;
-		}
-		if ((len & 1u) == 0 && second == (len - 2u) / 2u) {
-			second = 2u * (second + 1u);
-			AW(heap + hole) = AW(heap + second - 1u); hole = second - 1u;
-		}
-		while (hole > 0) {
-			const uint32_t parent = (hole - 1u) / 2u, pv = AW(heap + parent);
-			if (!bf_before(X, pv, value)) break;
-			AW(heap + hole) = pv; hole = parent;
-		}
-		AW(heap + hole) = value;
-	}
-	PMW(LF_HEAPSZ) = (n - 1u) | (cap << 16);
-	PMW(LF_PMCOST) = br_cost(X, n > 1u ? AW(heap) : top);
-	return top;
-}
-#endif
 
 BF_INL uint32_t pm_size(BfLane& X, uint32_t d) { return PMW(LF_HEAPSZ) & 0xffffu; }
-#if BF_FAST_EXTEND
 BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return X.pm[6]; }
-#else
-BF_INL uint32_t pm_front(BfLane& X, uint32_t d) { return AW(PMW(LF_HEAP)); }
-#endif
 BF_INL void pm_reset(BfLane& X, uint32_t d)                    /* PathManager::reset (range_source.h:1386-1399) */
 {
 	PMW(LF_HEAPSZ) &= 0xffff0000u; PMW(LF_BP) = 0; PMW(LF_BPLAST) = 0; PMW(LF_PMCOST) = 0;
@@ -529,7 +445,6 @@ BF_FN void pm_curtail(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen)
 	else if (br_cost(X, br) != orig) { const uint32_t p = pm_pop(X, d); pm_push(X, d, p); }
 }
 
-#if BF_FAST_EXTEND
 /* pm_curtail + br_curtail for the branch whose record leaf_advance_branch holds in registers (R == what the arena has):
  * only the alternatives' info words are fetched */
 BF_FN void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen, const uint32_t* R)
@@ -635,71 +550,6 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 	AW(b + BR_FLAGS) = f;
 	return nb;
 }
-#else
-/* Branch::splitBranch + RangeState::pickEdit (range_source.h:644-773, 321-485) */
-BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uint32_t depth5)
-{
-	const uint32_t id = pm_alloc_id(X, d);
-	const uint32_t alt = AW(b + BR_ALT), n = AW(b + BR_NALT), rdepth = br_rdepth(X, b);
-	uint32_t tied[3] = {0, 0, 0}, numTied = 0, numNotElim = 0, best = 0xffffu, next = 0xffffu;
-	for (uint32_t k = 0; k < n; k++) {
-		const uint32_t info = AW(alt + k * BF_ALW + 8u);
-		if (info >> 28) continue;
-		numNotElim++;
-		const uint32_t c = alt_cost(info, rdepth, seedLen);
-		if (c < best) { next = best; best = c; numTied = 1; tied[0] = k; }
-		else if (c == best) {
-			if (numTied < 3u) tied[numTied++] = k;
-			else { tied[0] = tied[1]; tied[1] = tied[2]; tied[2] = k; }
-		} else if (c < next) next = c;
-	}
-	uint32_t r = 0;
-	if (numTied > 1u) r = PM_RND(X, d) % numTied;
-	const uint32_t rec = alt + tied[r] * BF_ALW;
-	uint32_t info = AW(rec + 8u);
-	const uint32_t pos = info & 0xffffu;
-	uint32_t mask = (info >> 24) & 0xfu;                           /* bit c set: substitution to c already tried / impossible */
-	const uint32_t num = 4u - (uint32_t)__builtin_popcount(mask);
-	uint32_t chr = 0, last = 0;
-	if (num > 1u) {
-		uint32_t tot = 0;
-		for (uint32_t c = 0; c < 4u; c++) if (!((mask >> c) & 1u)) tot += AW(rec + 4u + c) - AW(rec + c);
-		uint32_t dart = PM_RND(X, d) % tot;
-		for (uint32_t c = 0; c < 4u; c++) {
-			if ((mask >> c) & 1u) continue;
-			const uint32_t w = AW(rec + 4u + c) - AW(rec + c);
-			chr = c;
-			if (c == 3u || dart < w) break;
-			dart -= w;
-		}
-		mask |= 1u << chr;
-		info = (info & ~(0xfu << 24)) | (mask << 24);
-	} else {
-		last = 1;
-		chr = !(mask & 1u) ? 0u : !(mask & 2u) ? 1u : !(mask & 4u) ? 2u : 3u;
-		info |= 1u << 28;
-	}
-	AW(rec + 8u) = info;
-	const uint32_t top = AW(rec + chr), bot = AW(rec + 4u + chr);
-	const uint32_t depth = pos + rdepth;
-	uint32_t d01 = AW(b + BR_D01), d23 = AW(b + BR_D23);
-	const uint32_t d0 = d01 & 0xffffu, d1 = d01 >> 16, d2 = d23 & 0xffffu, d3 = d23 >> 16;
-	const uint32_t nd0 = depth < d1 ? d1 : d0, nd1 = depth < d2 ? d2 : d1, nd2 = depth < d3 ? d3 : d2;
-	const uint32_t hamadd = best & 0x3fffu;
-	uint32_t hilo = AW(b + BR_HILO);
-	if (depth < depth5) hilo += 1u; else if (depth < seedLen) hilo += 1u << 16;
-	const uint32_t nb = br_new(X, id, nd0 | (nd1 << 16), nd2 | (d3 << 16), depth + 1u, 0, br_cost(X, b),
-	                           (br_ham(X, b) + hamadd) & 0xffffu, top, bot, b,
-	                           depth | (chr << 10) | ((br_nedits(X, b) + 1u) << 16), hilo);
-	uint32_t f = AW(b + BR_FLAGS);
-	if (numNotElim == 1u && last) f |= BRF_EXHAUSTED;
-	else if (numTied == 1u && last && best != next) {
-		f = (f & 0xffffu) | BRF_DELAYED | (((br_cost(X, b) - best + next) & 0xffffu) << 16);
-	}
-	AW(b + BR_FLAGS) = f;
-	return nb;
-}
-#endif
 
 /* PathManager::splitAndPrep (range_source.h:1460-1518); false = the search of this leaf ends now */
 BF_FN bool pm_split_and_prep(BfLane& X, uint32_t d, uint32_t seedLen, uint32_t depth5, bool useBtCnt)
@@ -716,24 +566,16 @@ BF_FN bool pm_split_and_prep(BfLane& X, uint32_t d, uint32_t seedLen, uint32_t d
 		f = pm_front(X, d);
 		if (X.ovf) return false;
 	}
-#if BF_FAST_EXTEND
 	uint32_t fresh = 0;                                  /* the branch br_split made: br_new stored it prepped */
-#endif
 	if (AW(f + BR_FLAGS) & BRF_CURTAILED) {
 		if (useBtCnt) { if (--X.btCnt == 0) return false; }
 		const uint32_t nb = br_split(X, d, f, seedLen, depth5);
 		if (X.ovf) return false;
 		if (AW(f + BR_FLAGS) & BRF_EXHAUSTED) { pm_pop(X, d); pm_free_id(X, d, AW(f + BR_ID)); }
 		pm_push(X, d, nb);
-#if BF_FAST_EXTEND
 		fresh = nb;
-#endif
 	}
-#if BF_FAST_EXTEND
 	if (pm_size(X, d) && pm_front(X, d) != fresh) br_prep(X, pm_front(X, d));
-#else
-	if (pm_size(X, d)) br_prep(X, pm_front(X, d));
-#endif
 	return true;
 }
 
@@ -784,7 +626,6 @@ BF_FN void leaf_take_seed(BfLane& X, uint32_t d, uint32_t src)
 	AW(d + LF_RSFLAGS) |= 8u;
 }
 
-#if BF_FAST_EXTEND
 /* the two lowest quality characters (the lowest twice if it occurs twice) among query offsets qlen-k-1, k in [k0, k1), of
  * the string a leaf reads its penalties from -- a contiguous stretch of the stored row either way round, fetched in
  * 16-byte pieces instead of a character at a time */
@@ -804,7 +645,6 @@ BF_FN void bf_qual_low2(const BfRead& R, uint32_t fw, uint32_t ebwtFw, uint32_t 
 		}
 	}
 }
-#endif
 
 /* SingleRangeSourceDriver::setQueryImpl (range_source.h:1750-1771) with EbwtRangeSource::setQuery
  * (ebwt_search_backtrack.h:1831-1870), EbwtRangeSourceDriver::initRangeSource (:2721-2806) and
@@ -816,16 +656,12 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	const BtIndexDev& ix = X.ix[sp.mirror];
 	const uint32_t maq = X.P->maq;
 	AW(d + DR_FLAGS) = 0;
-#if BF_FAST_EXTEND
 	/* a leaf's query is set once, right after leaf_init zeroed its record (the tree is rebuilt for every read, an extender
 	 * is made for every seed hit): its PathManager words are zeros, no need to fetch them */
 #if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
 	for (uint32_t k = 0; k < 6u; k++) if ((uint32_t)AW(d + LF_HEAP + k) != 0u) { fprintf(stderr, "BF_CHECK: leaf_set_query on a used leaf\n"); abort(); }
 #endif
 	for (uint32_t k = 0; k < 7u; k++) X.pm[k] = 0;
-#else
-	pm_enter(X, d);
-#endif
 	pm_reset(X, d);
 	const BfRead& R = X.R[sp.mate];
 	const uint32_t len = R.len;
@@ -849,29 +685,15 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 	} else if (!sp.halfAndHalf && r0 < s) {
 		minCost = 1u << 14;
 		uint32_t low = 0xffu;
-#if BF_FAST_EXTEND
 		{ uint32_t l2; bf_qual_low2(R, sp.fw, ebwtFw, qlen, r0, s, low, l2); }
-#else
-		for (uint32_t k = r0; k < s; k++) { const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u); if (c < low) low = c; }
-#endif
 		minCost += bt_mm_penalty(maq, bf_phred(low));
 	} else if (sp.halfAndHalf && sRight > 0 && sRight < (s - 1u)) {
 		minCost = (sp.seed ? 3u : 2u) << 14;
 		uint32_t low1 = 0xffu;
 		uint32_t l21 = 0xffu, l22 = 0xffu;
-#if BF_FAST_EXTEND
 		{ uint32_t l2; bf_qual_low2(R, sp.fw, ebwtFw, qlen, 0, sRight, low1, l2); }
 		bf_qual_low2(R, sp.fw, ebwtFw, qlen, sRight, s, l21, l22);
 		minCost += bt_mm_penalty(maq, bf_phred(low1));
-#else
-		for (uint32_t k = 0; k < sRight; k++) { const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u); if (c < low1) low1 = c; }
-		minCost += bt_mm_penalty(maq, bf_phred(low1));
-		for (uint32_t k = sRight; k < s; k++) {
-			const uint32_t c = bf_qualc(R, sp.fw, ebwtFw, qlen - k - 1u);
-			if (c < l21) { if (l21 != 0xffu) l22 = l21; l21 = c; }
-			else if (c < l22) l22 = c;
-		}
-#endif
 		minCost += bt_mm_penalty(maq, bf_phred(l21));
 		if (sp.halfAndHalf > 2 && l22 != 0xffu) minCost += bt_mm_penalty(maq, bf_phred(l22));
 	}
@@ -890,7 +712,6 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		if (r2 != r3) maxmms = 3;
 		if (qlen <= maxmms) { rsf |= 1u | 4u; go = false; }
 	}
-#if BF_FAST_EXTEND
 	/* leaf_qry with the seed's edits read once instead of at every character */
 	uint32_t sqN = 0, sqM[3] = {0, 0, 0};
 	if (valid) { sqN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) sqM[k] = AW(d + LF_SEEDMM0 + k); }
@@ -900,17 +721,10 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		return c;
 	};
 #define BF_LQ(i) qry(i)
-#else
-#define BF_LQ(i) leaf_qry(X, d, sp, (i))
-#endif
 	uint32_t nsInFtab = 0;
-#if BF_FAST_EXTEND
 	/* a read without an N has none in its seed or its ftab characters (a seed's edits put in reference bases): the two
 	 * tallies below are a base fetch per position, each waited for before the next */
 	if (go && ((X.hasN >> sp.mate) & 1u)) {
-#else
-	if (go) {
-#endif
 		/* tallyNs (ebwt_search_backtrack.h:2490-2523) */
 		uint32_t nsInSeed = 0;
 		for (uint32_t i = 0; i < r3 && go; i++) {
@@ -930,7 +744,6 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		const bool skipInvalidExact = !sp.reportExacts && qlen == ftabChars;
 		const uint32_t d01 = r0 | (r1 << 16), d23 = r2 | (r3 << 16);
 		if (nsInFtab == 0 && m >= ftabChars && !skipInvalidExact) {
-#if BF_FAST_EXTEND
 			/* calcFtabOff (:2530-2544) on the query's last ftabChars characters taken from two 16-byte pieces of the stored
 			 * row (they are next to each other there, whichever way round the leaf reads it) instead of one fetch each */
 			uint32_t off;
@@ -949,10 +762,6 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 				off = chr(a);
 				for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | chr(qlen - i);
 			}
-#else
-			uint32_t off = BF_LQ(qlen - ftabChars);                /* calcFtabOff (:2530-2544) */
-			for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | BF_LQ(qlen - i);
-#endif
 			const uint32_t top = bt_ftab_hi(ix, off), bot = bt_ftab_lo(ix, off + 1u);
 			X.c_ftab++;
 			if (qlen == ftabChars && bot > top) {
@@ -979,10 +788,9 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 #undef BF_LQ
 
 /* EbwtRangeSource::advanceBranch (ebwt_search_backtrack.h:2059-2361), until = ADV_COST_CHANGES */
-#if BF_FAST_EXTEND
 BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 {
-	/* BF_FAST_EXTEND: the same steps as the version below, organised around what a lane waits for.
+	/* The reference's steps, organised around what a lane waits for.
 	 * A branch that is simply extended -- no alternative taken, nothing curtailed -- stays the queue's front with its
 	 * cost (the queue is not touched, and PathManager::splitAndPrep on such a front only preps it): the next step goes on
 	 * from the record in registers, prepped in place, instead of reading the queue, the front's flags and cost and the
@@ -1168,158 +976,13 @@ BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
 	} while (!found);
 	AW(d + LF_RSFLAGS) = (AW(d + LF_RSFLAGS) & ~2u) | (found ? 2u : 0u);
 }
-#else
-BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
-{
-	const BtIndexDev& ix = X.ix[sp.mirror];
-	const uint32_t qlen = AW(d + LF_QLEN) & 0xffffu;
-	const uint32_t depth5 = AW(d + LF_D53) & 0xffffu, depth3 = AW(d + LF_D53) >> 16;
-	const uint32_t maq = X.P->maq;
-	bool found = false;
-	const bool seedEdits = (AW(d + LF_RSFLAGS) & 8u) != 0;          /* the query carries a seed's edits: fixed while the leaf advances */
-	do {
-		const uint32_t br = pm_front(X, d);
-		/* the front branch's record in one go (four independent 16-byte loads, one wait) instead of a dozen dependent
-		 * word loads spread over the step: every lane runs its own control flow here, so each load a step waits for
-		 * is a memory latency the whole wavefront sits through */
-		uint32_t R[BF_BRW];
-		{
-			const BtU4 r0 = bt_ld4((const void*)(X.A + br)), r1 = bt_ld4((const void*)(X.A + br + 4u));
-			const BtU4 r2 = bt_ld4((const void*)(X.A + br + 8u)), r3 = bt_ld4((const void*)(X.A + br + 12u));
-			R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
-			R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
-		}
-		const uint32_t rdepth = R[BR_RDLEN] & 0xffffu, blen = R[BR_RDLEN] >> 16;
-		const uint32_t depth = rdepth + blen;
-		const uint32_t cost = R[BR_COSTHAM] & 0xffffu;
-		const uint32_t nedits = R[BR_EDIT] >> 16;
-		uint32_t cur = 0;
-		uint32_t top = R[BR_TOP], bot = R[BR_BOT];
-		bool curtail = false, hit = false;
-		/* hhCheckTop (:2444-2475) */
-		if (sp.halfAndHalf && ((depth == depth5 && nedits == 0) || (depth == depth3 && nedits < sp.halfAndHalf))) {
-			curtail = true;
-		} else {
-			cur = qlen - depth - 1u;
-			if (depth < qlen) {
-				const uint32_t c = seedEdits ? leaf_qry(X, d, sp, cur) : bf_base(X.R[sp.mate], sp.fw, !sp.mirror, cur);
-				const uint32_t q = bt_mm_penalty(maq, bf_phred(bf_qualc(X.R[sp.mate], sp.fw, !sp.mirror, cur)));
-				const uint32_t ham = R[BR_COSTHAM] >> 16;
-				const uint32_t d0 = R[BR_D01] & 0xffffu;
-				const bool alt = depth >= d0 && ham + q <= sp.qualLim;
-				uint32_t otop = top;
-				if (c == 4u && depth > 0) top = bot = 1;
-				const uint32_t fl = R[BR_FLAGS];
-				uint32_t tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
-				bool ranges = false;
-				if (top == 0 && bot == 0) {
-					tops[0] = ix.fchr[0]; bots[0] = tops[1] = ix.fchr[1]; bots[1] = tops[2] = ix.fchr[2];
-					bots[2] = tops[3] = ix.fchr[3]; bots[3] = ix.fchr[4];
-					ranges = true;
-					if (c < 4u) { top = tops[c]; bot = bots[c]; }
-				} else if (alt && (bot > top || c == 4u)) {
-					if (fl & BRF_LBOT) {
-						uint32_t L;
-						const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
-						bt_rank4(ix, ra, tops, &L);
-						bt_rank4(ix, rb, bots, &L);
-						X.c_lfex++; if (ra / 448u == rb / 448u) X.c_same++;
-					} else {
-						/* mapLF1(otop, ltop_) (ebwt.h:2530-2560) */
-						X.c_lf1++;
-						if (otop != ix.zOff) {
-							uint32_t lf[4], L;
-							bt_rank4(ix, R[BR_LTOP], lf, &L);
-							otop = lf[L];
-							tops[L] = otop; bots[L] = otop + 1u;
-						}
-					}
-					ranges = true;
-					if (c < 4u) { top = tops[c]; bot = bots[c]; } else top = bot = 1;
-				} else if (bot > top) {
-					if (c < 4u) {
-						uint32_t lf[4], L;
-						if (top + 1u == bot) {
-							/* mapLF1(top_, ltop_, c) (ebwt.h:2494-2524) */
-							X.c_lf1++;
-							bt_rank4(ix, R[BR_LTOP], lf, &L);
-							if (L != c || top == ix.zOff) top = bot = BT_OFF_MASK;
-							else { top = lf[c]; bot = top + 1u; }
-						} else {
-							const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
-							X.c_lf2++; if (ra / 448u == rb / 448u) X.c_same++;
-							bt_rank4(ix, ra, lf, &L); top = lf[c];
-							bt_rank4(ix, rb, lf, &L); bot = lf[c];
-						}
-					}
-				}
-				if (ranges) {
-					/* Branch::installRanges (range_source.h:970-1023): a record only for a position that
-					 * is a legitimate place to branch from and still has an untried substitution */
-					uint32_t mask = 0xfu;
-					if (q <= sp.qualLim - ham) {
-						for (uint32_t k = 0; k < 4u; k++) if (c != k && bots[k] > tops[k]) mask &= ~(1u << k);
-					}
-					if (mask != 0xfu && depth >= d0) {
-						const uint32_t nalt = R[BR_NALT];
-						const uint32_t rec = bf_alloc(X, BF_ALW);
-						if (nalt == 0) { AW(br + BR_ALT) = rec; X.growing = br; }
-						else if (X.growing != br || rec != R[BR_ALT] + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
-						if (!X.ovf) {
-							for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
-							AW(rec + 8u) = blen | (q << 16) | (mask << 24);
-							AW(br + BR_NALT) = nalt + 1u;
-						}
-					}
-				}
-			} else {
-				cur = 0;
-			}
-			AW(br + BR_TOP) = top; AW(br + BR_BOT) = bot;
-			const bool empty = top == bot;
-			hit = cur == 0 && !empty;
-			const bool invalidExact = hit && nedits == 0 && !sp.reportExacts;
-			/* hhCheck (:2397-2436) */
-			bool hhOk = true;
-			if (sp.halfAndHalf) {
-				if (depth == depth5 - 1u && !empty) hhOk = nedits > 0;
-				else if (depth == depth3 - 1u && !empty) {
-					const uint32_t hilo = R[BR_HILO];
-					hhOk = nedits >= sp.halfAndHalf && (hilo & 0xffffu) != 0 && (hilo >> 16) != 0;
-				}
-			}
-			if (!hhOk) { curtail = true; hit = false; }
-			else if (hit && !invalidExact) {
-				AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
-				const uint32_t sn = (AW(d + LF_RSFLAGS) & 8u) ? (AW(d + LF_SEED) >> 16) : 0u;
-				AW(d + LF_CURCOST) = cost | ((nedits + sn) << 16);
-				AW(d + LF_CURBR) = br;
-				found = true;
-				curtail = true;
-			} else if (empty || cur == 0) curtail = true;
-			else AW(br + BR_RDLEN) = rdepth | ((blen + 1u) << 16);        /* Branch::extend */
-		}
-		{ BF_PT0(t_curtail); if (curtail) pm_curtail(X, d, br, depth3); BF_PADD(BP_CURTAIL, t_curtail); }
-		if (X.ovf) break;
-		{ BF_PT0(t_split); const bool sp_ok = pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0); BF_PADD(BP_SPLIT, t_split); if (!sp_ok) pm_reset(X, d); }
-		if (X.ovf) break;
-		if (pm_size(X, d) == 0) break;
-		if (br_cost(X, pm_front(X, d)) != cost) break;
-	} while (!found);
-	AW(d + LF_RSFLAGS) = (AW(d + LF_RSFLAGS) & ~2u) | (found ? 2u : 0u);
-}
-#endif
 
 /* SingleRangeSourceDriver::advanceImpl (range_source.h:1777-1838) */
 BF_FN void leaf_advance(BfLane& X, uint32_t d)
 {
 	uint32_t fl = AW(d + DR_FLAGS);
-#if BF_FAST_EXTEND
 	if ((fl & BF_F_DONE) || (AW(d + LF_HEAPSZ) & 0xffffu) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
 	pm_enter(X, d);
-#else
-	if ((fl & BF_F_DONE) || pm_size(X, d) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
-#endif
 	const BfSpec& sp = leaf_spec(X, d);
 	{ BF_PT0(t_leaf); leaf_advance_branch(X, d, sp); BF_PADD(BP_LEAF, t_leaf); }
 	fl &= ~(BF_F_DONE | BF_F_FOUND);
@@ -1371,7 +1034,6 @@ BF_FN void cost_sort_actives_body(BfLane& X, uint32_t d)
 {
 	const uint32_t vec = AW(d + CA_ACT);
 	uint32_t n = AW(d + CA_NACT), sz = n;
-#if BF_FAST_GATHER
 	if (n <= 16u) {
 		/* the same selection sort (and the same draws) on a copy of what it looks at: every child's flags and cost are
 		 * fetched once, side by side, instead of inside the two loops, each fetch waited for */
@@ -1456,7 +1118,6 @@ BF_FN void cost_sort_actives_body(BfLane& X, uint32_t d)
 		if (AW(d + CA_DELAYED) == 0 && sz > 0) dr_set_mincost(X, d, (uint32_t)AW(key) & 0xffffu);
 		return;
 	}
-#endif
 	for (uint32_t i = 0; i < sz;) {
 		const uint32_t vi = AW(vec + i);
 		if (dr_done(X, vi) && !dr_found(X, vi)) {
@@ -1493,16 +1154,11 @@ template <int LEVEL> BF_FN void cost_set_query(BfLane& X, uint32_t d)
 	AW(d + CA_RND) = X.R[0].seed;                             /* patsrc->bufa().seed */
 	const uint32_t n = AW(d + CA_NRSS) & 0xffffu;
 	if (n == 0) return;
-#if BF_FAST_EXTEND
 	{
 		/* the two vectors' offsets once, each child's offset once (setting a child's query does not touch the vectors) */
 		const uint32_t rss = AW(d + CA_RSS), act = AW(d + CA_ACT);
 		for (uint32_t i = 0; i < n; i++) { const uint32_t c = AW(rss + i); child_set_query<LEVEL>(X, c, 0); AW(act + i) = c; }
 	}
-#else
-	for (uint32_t i = 0; i < n; i++) child_set_query<LEVEL>(X, AW(AW(d + CA_RSS) + i), 0);
-	for (uint32_t i = 0; i < n; i++) AW(AW(d + CA_ACT) + i) = AW(AW(d + CA_RSS) + i);
-#endif
 	AW(d + CA_NACT) = n;
 	dr_set_mincost(X, d, 0);
 	cost_sort_actives(X, d);
@@ -1548,7 +1204,6 @@ template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
 	if (LEVEL != 0 || !X.P->paired || BF_IS_V1(*X.P)) return false;      /* V1's drivers hold one mate each */
 	const uint32_t n = AW(d + CA_NACT);
 	bool m1 = false, m2 = false;
-#if BF_FAST_GATHER
 	if (n <= 16u) {
 		const uint32_t vec = AW(d + CA_ACT);
 		uint32_t a[16], fl[16], kd[16];
@@ -1557,7 +1212,6 @@ template <int LEVEL> BF_FN bool cost_mate_eliminated(BfLane& X, uint32_t d)
 		BF_UNROLL16 for (uint32_t i = 0; i < 16u; i++) if (i < n && !(fl[i] & BF_F_DONE)) { if ((kd[i] >> 9) & 1u) m2 = true; else m1 = true; }
 		return !m1 || !m2;
 	}
-#endif
 	for (uint32_t i = 0; i < n; i++) {
 		const uint32_t a = AW(AW(d + CA_ACT) + i);
 		if (!dr_done(X, a)) { if (dr_mate(X, a)) m2 = true; else m1 = true; }
@@ -1674,7 +1328,6 @@ BF_FN uint32_t child_range(BfLane& X, uint32_t d)
 	return d;
 }
 
-#if BF_ONE_LEAF_SITE
 /* cost_advance from the return of child_advance on: foundFirstRange, sortActives (range_source.h:2186-2210) */
 template <int LEVEL> BF_FN void cost_advance_post(BfLane& X, uint32_t d, uint32_t p, uint32_t precost)
 {
@@ -1724,7 +1377,7 @@ BF_FN void seeded_post_full(BfLane& X, uint32_t d, uint32_t seed, uint32_t full,
 		dr_set_mincost(X, d, a < b ? a : b);
 	}
 }
-/* cost_advance<0>(d) -- the aligner's own driver -- with the leaf it gets to advanced at one place (see BF_ONE_LEAF_SITE):
+/* cost_advance<0>(d) -- the aligner's own driver -- with the leaf it gets to advanced at one place (see the head of this file):
  * statement for statement cost_advance<0>, child_advance<0>, seeded_advance and cost_advance<1> up to their calls,
  * the call, then what follows it in each, innermost first */
 BF_FN void bf_advance_top(BfLane& X, uint32_t d)
@@ -1796,7 +1449,6 @@ BF_FN void bf_advance_top(BfLane& X, uint32_t d)
 	else if (after == SEED_BRANCH) seeded_post_seed(X, p, seed, full);
 	cost_advance_post<0>(X, d, p, precost);
 }
-#endif
 
 /* the static part of the tree (Unpaired*Factory::create()) */
 BF_FN uint32_t bf_build_tree(BfLane& X)
@@ -1866,11 +1518,7 @@ BF_FN void bf_build_tree_v1(BfLane& X, uint32_t tops[4])
 }
 #endif
 
-#if BF_ONE_LEAF_SITE
 #define BF_ADVANCE_TOP(X, d) do { BF_PT0(t_adv); bf_advance_top(X, d); BF_PADD(BP_ADV, t_adv); } while (0)
-#else
-#define BF_ADVANCE_TOP(X, d) do { BF_PT0(t_adv); cost_advance<0>(X, d); BF_PADD(BP_ADV, t_adv); } while (0)
-#endif
 
 /* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
  * ebwt_search.cpp passes NULL caches) ------------------------------------------------------------- */
@@ -1967,7 +1615,6 @@ BF_FN bool bf_emit_hit(BfLane& X, const BtBatchDev& B, uint32_t fw, bool flip, u
 			if (off + nmm <= B.mm_pool_cap) {
 				h.mm_off = off;
 				auto mm = BT_GP(uint16_t, B.mm_pool + off);
-#if BF_FAST_EXTEND
 				/* up to 16 mismatches are put in order in the lane and stored once: the pool is never read (sorting in place
 				 * waits for its own stores to come back, and reads a line other lanes' lists share) */
 				uint16_t ee[16];
@@ -1983,7 +1630,6 @@ BF_FN bool bf_emit_hit(BfLane& X, const BtBatchDev& B, uint32_t fw, bool flip, u
 					}
 					for (uint32_t i = 0; i < nmm; i++) mm[i] = ee[i];
 				} else
-#endif
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t m, refc;
 					getmm(i, m, refc);
@@ -2036,7 +1682,6 @@ BF_INL bool bf_irrelevant(const BfLane& X, uint32_t cost)       /* NBestFirstStr
 	return X.P->sinkStrata && X.nhits && (cost >> 14) > X.bestStratum;
 }
 
-#if BF_FAST_EXTEND
 /* does the read hold an N (code 4)?  Its row in 16-byte pieces (rows are 16-byte aligned and padded with 4s past the
  * read's end, which are masked off) */
 BF_FN uint32_t bf_has_n(const BfRead& R)
@@ -2057,7 +1702,6 @@ BF_FN uint32_t bf_has_n(const BfRead& R)
 	}
 	return any != 0 ? 1u : 0u;
 }
-#endif
 
 BF_FN void bf_read_begin(BfLane& X, const BtBatchDev& B, uint32_t rd)
 {
@@ -2077,9 +1721,7 @@ BF_FN void bf_read_begin(BfLane& X, const BtBatchDev& B, uint32_t rd)
 	X.nhits = 0; X.stored = 0; X.bestStratum = 999; X.status = 0;
 	X.alRnd = X.R[0].seed;                                      /* Aligner::rand_.init(bufa_->seed) */
 	X.btCnt = (int32_t)X.P->maxBts;
-#if BF_FAST_EXTEND
 	X.hasN = bf_has_n(X.R[0]) | (B.seq2 ? bf_has_n(X.R[1]) << 1 : 0u);
-#endif
 }
 BF_FN void bf_read_end(BfLane& X, const BtBatchDev& B, uint32_t mult)
 {
@@ -2183,7 +1825,6 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 	const bool packed = qlen <= 64u;
 	uint64_t rq[2] = {0, 0}, rn[2] = {0, 0}, sm[2] = {0, 0}, lm[2] = {0, 0};
 	uint64_t W[2][3] = {{0, 0, 0}, {0, 0, 0}}, N[2][2] = {{0, 0}, {0, 0}}, K[2] = {~0ull, ~0ull};
-#if BF_FAST_EXTEND
 	/* the mate's bases (and, for -n, qualities) as they are stored, in registers: 16-byte pieces of its rows instead of a
 	 * fetch per character here and in the base-by-base decision below */
 	uint32_t mw[16], qw[16];
@@ -2207,14 +1848,9 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 		const uint32_t idx = fw ? j : qlen - 1u - j;
 		return (qw[idx >> 2] >> (8u * (idx & 3u))) & 0xffu;
 	};
-#endif
 	if (packed) {
 		for (uint32_t j = 0; j < qlen; j++) {
-#if BF_FAST_EXTEND
 			const uint32_t q = mbase(j);
-#else
-			const uint32_t q = bf_base(M, fw, 1u, j);
-#endif
 			const uint64_t bit = 1ull << (2u * (j & 31u));
 			if (q < 4u) rq[j >> 5] |= (uint64_t)q << (2u * (j & 31u)); else rn[j >> 5] |= bit;
 			lm[j >> 5] |= bit;
@@ -2222,9 +1858,7 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 		}
 	}
 	const uint64_t nspan = qlen >= 64u ? ~0ull : ((1ull << qlen) - 1ull);
-#if BF_FAST_EXTEND
 	uint64_t pm0 = 0, pm1 = 0, pa0 = 0, pa1 = 0;           /* the candidate's mismatch masks and reference words */
-#endif
 	bool hi = false;
 	for (uint32_t i = 1; i <= lim + 1u; i++) {
 		const uint32_t ri = hi ? halfway + (i >> 1) : halfway - (i >> 1);
@@ -2247,13 +1881,10 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 			const uint64_t m0 = (((x0 | (x0 >> 1)) & 0x5555555555555555ull) | rn[0]) & lm[0];
 			const uint64_t m1 = (((x1 | (x1 >> 1)) & 0x5555555555555555ull) | rn[1]) & lm[1];
 			if ((uint32_t)__builtin_popcountll(m0 & sm[0]) + (uint32_t)__builtin_popcountll(m1 & sm[1]) > P.refMms) continue;
-#if BF_FAST_EXTEND
 			pm0 = m0; pm1 = m1; pa0 = a0; pa1 = a1;
-#endif
 		}
 		bool match = true;
 		uint32_t mms = 0, seedMms = 0, ham = 0;
-#if BF_FAST_EXTEND
 		if (packed) {
 			/* the same decision from the registers: the mismatching offsets are the set bits of the two masks, in ascending
 			 * order; the reference has no N under the mate (checked above) */
@@ -2274,7 +1905,6 @@ BF_FN bool bf_ref_find_one(BfLane& X, uint32_t tidx, const BfRead& M, uint32_t f
 				}
 			}
 		} else
-#endif
 		for (uint32_t j = 0; j < qlen; j++) {
 			const uint32_t rc = ref_base(rf, base + ri + j);
 			if (rc & 4u) { match = false; break; }
@@ -2535,238 +2165,6 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 }
 #endif
 
-#if BF_REFILL
-/* ---- the three runners above, resumable: the same statements, the loops' locals in a struct ------------------------ */
-struct BfRun {
-	uint32_t kind;                /* 0 idle, 1 bf_run_read, 2 bf_run_pair, 3 bf_run_pair_v1 */
-	uint32_t live;                /* the loop is to be gone through (the read was long enough, the tree fitted) */
-	BfChase ch;
-	bool done, chase;
-	uint32_t drv;
-	uint32_t pairsFw, pairsRc, mmBuf, attempts;
-	BfV1Orient O[2];
-	uint32_t o, qlen1, qlen2, symCeil;
-	bool doneFw, doneFwFirst;
-	uint32_t c0[9];               /* the lane's op counters when the read began (a read that overflows is not tallied) */
-};
-
-BF_FN void bf_run_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfRun& R, uint32_t kind)
-{
-	R.kind = kind; R.live = 0; R.done = true; R.chase = false; R.attempts = 0;
-	R.c0[0] = X.c_lfex; R.c0[1] = X.c_lf2; R.c0[2] = X.c_lf1; R.c0[3] = X.c_chase; R.c0[4] = X.c_ftab;
-	R.c0[5] = X.c_offs; R.c0[6] = X.c_rst; R.c0[7] = X.c_same; R.c0[8] = X.c_frames;
-	bf_read_begin(X, B, rd);
-	if (X.R[0].len < 4u || (kind != 1u && X.R[1].len < 4u)) { X.status |= BT_STF_SKIPPED; return; }
-	R.live = 1;
-	bf_chase_init(R.ch);
-	if (kind == 1u) {
-		R.drv = bf_build_tree(X);
-		if (!X.ovf) { cost_set_query<0>(X, R.drv); R.done = dr_done(X, R.drv); }
-		return;
-	}
-	const uint32_t maxLen = X.R[0].len > X.R[1].len ? X.R[0].len : X.R[1].len;
-	if (kind == 2u) {
-		R.drv = bf_build_tree(X);
-		R.pairsFw = bf_alloc(X, 3); R.pairsRc = bf_alloc(X, 3); R.mmBuf = bf_alloc(X, maxLen);
-		if (!X.ovf) {
-			AW(R.pairsFw) = AW(R.pairsFw + 1u) = AW(R.pairsFw + 2u) = 0; AW(R.pairsRc) = AW(R.pairsRc + 1u) = AW(R.pairsRc + 2u) = 0;
-			cost_set_query<0>(X, R.drv);
-			R.done = false;
-		}
-		return;
-	}
-#if BF_HAVE_V1
-	const BfProgram& P = *X.P;
-	uint32_t tops[4];
-	bf_build_tree_v1(X, tops);
-	R.pairsFw = bf_alloc(X, 3); R.pairsRc = bf_alloc(X, 3); R.mmBuf = bf_alloc(X, maxLen);
-	if (!X.ovf) {
-		AW(R.pairsFw) = AW(R.pairsFw + 1u) = AW(R.pairsFw + 2u) = 0; AW(R.pairsRc) = AW(R.pairsRc + 1u) = AW(R.pairsRc + 2u) = 0;
-		for (uint32_t b = 0; b < 4u && !X.ovf; b++) if (tops[b]) cost_set_query<0>(X, tops[b]);
-		R.done = false;
-	}
-	const bool fw1 = P.mate1Fw != 0, fw2 = P.mate2Fw != 0;
-	R.O[0].drL = fw1 ? tops[0] : tops[1]; R.O[0].drR = fw2 ? tops[2] : tops[3];      /* aligner.h:670-682 */
-	R.O[1].drL = fw2 ? tops[3] : tops[2]; R.O[1].drR = fw1 ? tops[1] : tops[0];      /* aligner.h:684-696 */
-	for (int k = 0; k < 2; k++) { R.O[k].chaseL = R.O[k].chaseR = R.O[k].delayedL = R.O[k].delayedR = false; R.O[k].szL = R.O[k].szR = 0; }
-	R.qlen1 = X.R[0].len; R.qlen2 = X.R[1].len;
-	R.symCeil = P.sinkMax == 0xffffffffu ? 0xffffffffu : P.sinkMax / 2u;   /* -m ("mhits, // for symCeiling") */
-	R.o = 0; R.doneFw = false; R.doneFwFirst = true;
-#endif
-}
-
-/* one turn of bf_run_read's loop; false: the loop's condition no longer holds */
-BF_FN bool bf_step_read(BfLane& X, const BtBatchDev& B, BfRun& R)
-{
-	if (R.done || X.ovf) return false;
-	BfChase& ch = R.ch;
-	const uint32_t drv = R.drv;
-	if (R.chase) {
-		/* the reference's loop comes back here turn after turn until the walk has an answer: the same calls, in one go */
-		while (ch.tidx == BT_OFF_MASK && !ch.done) ch_advance(X, ch);
-		if (ch.tidx != BT_OFF_MASK) {
-			const uint32_t leaf = AW(drv + CA_LAST);
-			R.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
-			                        !leaf_spec(X, leaf).mirror);
-			ch.tidx = BT_OFF_MASK;
-		} else {
-			R.chase = false;
-			dr_set(X, drv, BF_F_FOUND, false);
-			R.done = dr_done(X, drv);
-		}
-	}
-	if (!R.done && !R.chase) {
-		if (dr_found(X, drv)) {
-			const uint32_t leaf = AW(drv + CA_LAST);
-			const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
-			ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
-			if (ch.tidx != BT_OFF_MASK) {
-				R.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
-				                        !leaf_spec(X, leaf).mirror);
-				ch.tidx = BT_OFF_MASK;
-			}
-			if (!ch.done && !bf_irrelevant(X, cost)) R.chase = true;
-			else dr_set(X, drv, BF_F_FOUND, false);
-		} else {
-			R.done = bf_irrelevant(X, dr_mincost(X, drv));
-			if (!R.done) BF_ADVANCE_TOP(X, drv);
-		}
-		if (dr_done(X, drv) && !dr_found(X, drv) && !R.chase) R.done = true;
-	}
-	return true;
-}
-
-/* one turn of bf_run_pair's loop */
-BF_FN bool bf_step_pair(BfLane& X, const BtBatchDev& B, BfRun& R)
-{
-	if (R.done || X.ovf) return false;
-	BfChase& ch = R.ch;
-	const uint32_t drv = R.drv;
-	if (R.chase) {
-		/* the reference's loop comes back here turn after turn until the walk has an answer: the same calls, in one go */
-		while (ch.tidx == BT_OFF_MASK && !ch.done) ch_advance(X, ch);
-		if (ch.tidx != BT_OFF_MASK) {
-			/* resolveOutstanding (aligner.h:1849-1871) */
-			const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, R.pairsFw, R.pairsRc, R.mmBuf);
-			if (++R.attempts > X.P->pairTries || ret) R.done = true;
-			ch.tidx = BT_OFF_MASK;
-		} else {
-			R.chase = false;
-			R.done = dr_done(X, drv);
-		}
-	}
-	if (!R.done && !R.chase) {
-		if (!dr_done(X, drv)) {
-			R.done = bf_irrelevant(X, dr_mincost(X, drv));
-			if (!R.done) BF_ADVANCE_TOP(X, drv);
-			if (dr_found(X, drv)) {
-				R.chase = true;
-				dr_set(X, drv, BF_F_FOUND, false);
-				const uint32_t leaf = AW(drv + CA_LAST);
-				const BfSpec& sp = leaf_spec(X, leaf);
-				ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
-			}
-		} else R.done = true;
-	}
-	return true;
-}
-
-#if BF_HAVE_V1
-/* one turn of bf_run_pair_v1's loop */
-BF_FN bool bf_step_pair_v1(BfLane& X, const BtBatchDev& B, BfRun& R)
-{
-	if (R.done || X.ovf) return false;
-	const BfProgram& P = *X.P;
-	BfChase& ch = R.ch;
-	bool& done = R.done;
-	bool& doneFw = R.doneFw;
-	const uint32_t qlen1 = R.qlen1, qlen2 = R.qlen2, symCeil = R.symCeil;
-#define V1_DONE(d)  ((d) == 0u || dr_done(X, (d)))
-	auto chase_range_of = [&](uint32_t top, uint32_t qlen) {
-		const uint32_t leaf = AW(top + CA_LAST);
-		ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, qlen);
-	};
-	if (doneFw && R.doneFwFirst) { R.o = 1; R.doneFwFirst = false; R.attempts = 0; }
-	BfV1Orient& Q = R.O[R.o];
-	if (Q.chaseL || Q.chaseR) while (ch.tidx == BT_OFF_MASK && !ch.done) ch_advance(X, ch);      /* turn after turn in the reference's loop */
-	bool& donePair = (R.o == 0) ? doneFw : done;
-	bool returned = false;
-	if (Q.chaseL || Q.chaseR) {
-		const bool sideL = Q.chaseL;
-		const uint32_t drMe = sideL ? Q.drL : Q.drR, drOther = sideL ? Q.drR : Q.drL;
-		bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
-		bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
-		bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
-		if (ch.tidx != BT_OFF_MASK) {
-			if (!done) {
-				done = bf_resolve_in_ref(X, B, AW(drMe + CA_LAST), ch.tidx, ch.toff, R.pairsFw, R.pairsRc, R.mmBuf);
-				if (++R.attempts > P.pairTries) { donePair = true; returned = true; }
-			}
-			if (!returned) ch.tidx = BT_OFF_MASK;                       /* rchase_->reset() */
-		} else {
-			chaseMe = false;
-			dr_set(X, drMe, BF_F_FOUND, false);
-			if (delayedOther) {
-				chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
-				chaseOther = true; delayedOther = false;
-			}
-		}
-	}
-	if (returned) return true;
-	if (!done && !donePair && !Q.chaseL && !Q.chaseR) {
-		bool sideL;
-		if ((Q.szL < Q.szR || V1_DONE(Q.drR)) && !V1_DONE(Q.drL)) sideL = true;
-		else if (!V1_DONE(Q.drR)) sideL = false;
-		else { donePair = true; return true; }
-		const uint32_t drMe = sideL ? Q.drL : Q.drR, drOther = sideL ? Q.drR : Q.drL;
-		uint32_t& szMe = sideL ? Q.szL : Q.szR;
-		uint32_t& szOther = sideL ? Q.szR : Q.szL;
-		bool& delayedMe = sideL ? Q.delayedL : Q.delayedR;
-		bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
-		bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
-		bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
-		if (V1_DONE(drOther) && szOther == 0) { donePair = true; return true; }     /* no pair in this orientation */
-		if (!dr_found(X, drMe)) BF_ADVANCE_TOP(X, drMe);
-		if (dr_found(X, drMe)) {
-			const uint32_t leaf = AW(drMe + CA_LAST);
-			szMe += AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP);
-			if (szOther == 0 && szMe > 3u) delayedMe = true;                     /* dontReconcile_: aligner.h:1233 */
-			else {
-				if (szMe > symCeil && szOther > symCeil) { donePair = true; return true; }
-				if (delayedOther && szOther < szMe) {
-					delayedOther = false; delayedMe = true; chaseOther = true;
-					chase_range_of(drOther, sideL ? (doneFw ? qlen1 : qlen2) : (doneFw ? qlen2 : qlen1));
-				} else {
-					chaseMe = true;
-					chase_range_of(drMe, sideL ? (doneFw ? qlen2 : qlen1) : (doneFw ? qlen1 : qlen2));
-				}
-			}
-		}
-	}
-#undef V1_DONE
-	return true;
-}
-#endif
-
-BF_FN bool bf_run_step(BfLane& X, const BtBatchDev& B, BfRun& R)
-{
-	if (!R.live) return false;
-#if BF_HAVE_V1
-	if (R.kind == 3u) return bf_step_pair_v1(X, B, R);
-#endif
-	return R.kind == 2u ? bf_step_pair(X, B, R) : bf_step_read(X, B, R);
-}
-
-BF_FN void bf_run_end(BfLane& X, const BtBatchDev& B, BfRun& R)
-{
-	bf_read_end(X, B, R.kind == 1u ? 1u : 2u);
-	if (X.status & BT_STF_OVERFLOW) {
-		X.c_lfex = R.c0[0]; X.c_lf2 = R.c0[1]; X.c_lf1 = R.c0[2]; X.c_chase = R.c0[3]; X.c_ftab = R.c0[4];
-		X.c_offs = R.c0[5]; X.c_rst = R.c0[6]; X.c_same = R.c0[7]; X.c_frames = R.c0[8];
-	}
-	R.kind = 0;
-}
-#endif
 
 #undef AW
 #endif /* BT_BEST_H_ */

@@ -49,34 +49,6 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 	X.ix = IX; X.P = &PROG; X.ref = &REF;
 	const bool paired = PROG.paired != 0;
 	const uint32_t n = A.workList ? (*A.workCount < A.workCap ? *A.workCount : A.workCap) : BATCH.n_reads;
-#if BF_REFILL
-	/* A lane takes its next read while the other lanes of its wavefront are still on theirs (the loop below the #else hands
-	 * out reads a wavefront at a time: every lane then waits for the slowest of the 64).  What beginning a read costs --
-	 * the tree, every leaf's set-up -- the wavefront pays once per turn in which any lane begins one, so lanes wait until
-	 * BF_REFILL_MIN of them want a read (or none is working). */
-#ifndef BF_REFILL_MIN
-#define BF_REFILL_MIN 16
-#endif
-	{
-		BfRun R;
-		R.kind = 0;
-		bool drained = false;
-		const uint32_t kind = paired ? (BF_IS_V1(PROG) ? 3u : 2u) : 1u;
-		for (;;) {
-			const unsigned long long working = __ballot(R.kind != 0);
-			if (R.kind == 0 && !drained) {
-				const unsigned long long waiting = __ballot(1);
-				if (working == 0 || (uint32_t)__builtin_popcountll(waiting) >= (uint32_t)BF_REFILL_MIN) {
-					const uint32_t w = atomicAdd(A.nextRead, 1u);
-					if (w >= n) drained = true;
-					else bf_run_begin(X, BATCH, A.workList ? A.workList[w] : w, R, kind);
-				}
-			}
-			if (R.kind == 0) { if (drained) break; continue; }
-			if (!bf_run_step(X, BATCH, R)) bf_run_end(X, BATCH, R);
-		}
-	}
-#else
 	for (;;) {
 		const uint32_t w = atomicAdd(A.nextRead, 1u);
 		if (w >= n) break;
@@ -96,7 +68,6 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 			X.c_frames = before.c_frames;
 		}
 	}
-#endif
 	if (A.counts) {
 		/* op counters (bt_op_counts order: lfex lf2 lf1 chase ftab offs rstarts frames lane_iters same_pair) */
 		atomicAdd(&A.counts[CN_LFEX], (unsigned long long)X.c_lfex); atomicAdd(&A.counts[CN_LF2], (unsigned long long)X.c_lf2);

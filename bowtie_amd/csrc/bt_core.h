@@ -265,9 +265,6 @@ struct BtLane {
 	uint32_t ra_top, ra_bot, ra_r, ra_i;
 	uint32_t crow, cjumps;
 	uint32_t iters;
-#if BT_MM_REGS
-	uint32_t mmA, mmB;               /* mismatches of backtrack levels 0,1 | 2,3: 16 bits each, query offset | refc<<12 */
-#endif
 	/* register window over the read: 16 bases + 16 quals around the current position */
 	uint32_t state;                  /* ST_*: in a word of its own -- every guard of the sweep tests it */
 	uint32_t cs0, cs1, cs2, cs3, cq0, cq1, cq2, cq3;
@@ -376,35 +373,9 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 #define WSEL(f) (L.mirror ? W.f[1] : W.f[0])          /* warm: LDS */
 #define HFCHR(k) (L.mirror ? H.fchr[1][k] : H.fchr[0][k])
 /* the mismatch chosen at backtrack level i: query offset | refc<<16 (the FR_MM word of the frame record) */
-#if BT_MM_REGS
-#define BT_FR_MM(i) bt_fr_mm(L, S, (i))
-#else
 #define BT_FR_MM(i) FRW((i), FR_MM)
-#endif
 /* a block that emits its request leaves the lane in a state no LATER block of the sweep takes (its own *_DONE /
  * *_FETCHED state) -- except the three that are entered straight from the block before them with the request pending */
-#ifndef BT_MM_SORT_REGS
-#define BT_MM_SORT_REGS 0
-#endif
-/* BT_MM_REGS: the mismatches chosen at the first four backtrack levels live in two words of the lane (as well as being
- * what the half-and-half checks, calcStratum and the hit's mismatch list are made from) instead of in the frame records in
- * HBM: none of those then waits for a load in the middle of a round, and a hit's list is put in order in the lane and
- * stored once (no output line is ever read).  Levels beyond the fourth stay in the frame records. */
-#ifndef BT_MM_REGS
-#define BT_MM_REGS 0
-#endif
-/* BT_SKIP_DEAD_PAIRS: a position's four (top,bot) ranges are stored only if the position has an alternative at all -- the
- * only reader of the range stack is the fetch of a chosen backtrack target, and a position whose eliminated-set is full
- * is never chosen */
-#ifndef BT_SKIP_DEAD_PAIRS
-#define BT_SKIP_DEAD_PAIRS 0
-#endif
-/* BT_DEFER_SLOW: the sweep over the slow states is entered only when the wavefront's gate says so (bt_kernels.hip: enough
- * lanes want it, or one has waited long enough); a lane that finds the gate closed keeps its state and the answer to its
- * last request and asks again next round */
-#ifndef BT_DEFER_SLOW
-#define BT_DEFER_SLOW 0
-#endif
 #define ST_IS(x) (L.state == (x))
 #define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE)
 
@@ -443,16 +414,6 @@ BT_HD void bt_read_get(const BtLane& L, const BtScratch& S, uint32_t i, uint32_t
 	*q_out = v >= 33u ? v - 33u : 0u;
 }
 
-#if BT_MM_REGS
-BT_HD uint32_t bt_fr_mm(const BtLane& L, const BtScratch& S, uint32_t i)
-{
-	if (i < 4u) {
-		const uint32_t w = (i & 2u) ? L.mmB : L.mmA, h = (i & 1u) ? (w >> 16) : (w & 0xffffu);
-		return (h & 0x3ffu) | ((h >> 12) << 16);
-	}
-	return FRW(i, FR_MM);
-}
-#endif
 
 /* hhCheckTop (ebwt_search_backtrack.h:1200-1275) */
 BT_HD bool bt_hh_check_top(const BtLane& L, const BtScratch& S, uint32_t d)
@@ -574,59 +535,6 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 				h.mm_off = off;
 				const bool flip = (ixfw != 0) != (L.readFw != 0);
 				auto mm = BT_GP(uint16_t, B.mm_pool + off);
-#if BT_MM_REGS
-				/* every entry comes from the lane (levels 0..3, the seedling's substitutions): each is stored once, at the
-				 * place the reference's ordered list gives it -- the number of entries before it (Hit::mms is a bitset: by
-				 * position; equal positions keep their order, as the insertion below does) */
-				if (L.ra_sd <= 4u) {
-					auto entry = [&](uint32_t j) -> uint32_t {
-						uint32_t pos, refc;
-						if (j < L.ra_sd) { const uint32_t v = bt_fr_mm(L, S, j); pos = v & 0xffffu; refc = (v >> 16) & 3u; }
-						else {
-							const uint32_t k = j - L.ra_sd;
-							pos = k == 0 ? L.mutpos0 : k == 1 ? L.mutpos1 : L.mutpos2;
-							refc = k == 0 ? L.mutnew0 : k == 1 ? L.mutnew1 : L.mutnew2;
-						}
-						if (flip) pos = L.qlen - pos - 1u;
-						return (pos | (refc << 12)) & 0xffffu;
-					};
-					BT_NOUNROLL
-					for (uint32_t i = 0; i < nmm; i++) {
-						const uint32_t ei = entry(i), pi = ei & 0x3ffu;
-						uint32_t rank = 0;
-						BT_NOUNROLL
-						for (uint32_t j = 0; j < nmm; j++) {
-							const uint32_t pj = entry(j) & 0x3ffu;
-							rank += (pj < pi || (pj == pi && j < i)) ? 1u : 0u;
-						}
-						mm[rank] = (uint16_t)ei;
-					}
-				} else
-#endif
-#if BT_MM_SORT_REGS
-				/* experiment: up to 16 mismatches are put in order in the lane and stored once, so that no
-				 * line of the output is ever read by the kernel */
-				if (nmm <= 16u) {
-					uint16_t ee[16];
-					BT_NOUNROLL
-					for (uint32_t i = 0; i < nmm; i++) {
-						uint32_t pos, refc;
-						if (i < L.ra_sd) { uint32_t v = BT_FR_MM(i); pos = v & 0xffffu; refc = (v >> 16) & 3u; }
-						else {
-							const uint32_t k = i - L.ra_sd;
-							pos = k == 0 ? L.mutpos0 : k == 1 ? L.mutpos1 : L.mutpos2;
-							refc = k == 0 ? L.mutnew0 : k == 1 ? L.mutnew1 : L.mutnew2;
-						}
-						if (flip) pos = L.qlen - pos - 1u;
-						const uint16_t e = (uint16_t)(pos | (refc << 12));
-						int j = (int)i - 1;
-						while (j >= 0 && (ee[j] & 0x3ffu) > (e & 0x3ffu)) { ee[j + 1] = ee[j]; j--; }
-						ee[j + 1] = e;
-					}
-					BT_NOUNROLL
-					for (uint32_t i = 0; i < nmm; i++) mm[i] = ee[i];
-				} else
-#endif
 				BT_NOUNROLL
 				for (uint32_t i = 0; i < nmm; i++) {
 					uint32_t pos, refc;
@@ -1132,12 +1040,6 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (i < L.f1)      { nu = L.f1; n1 = L.f2; n2 = L.f3; }
 			else if (i < L.f2) { n1 = L.f2; n2 = L.f3; }
 			else if (i < L.f3) { n2 = L.f3; }
-#if BT_MM_REGS
-			if (L.sd < 4u) {
-				const uint32_t h = icur | (btcint << 12), sh = (L.sd & 1u) * 16u;
-				if (L.sd & 2u) L.mmB = (L.mmB & ~(0xffffu << sh)) | (h << sh); else L.mmA = (L.mmA & ~(0xffffu << sh)) | (h << sh);
-			} else
-#endif
 			FRW(L.sd, FR_MM) = icur | (btcint << 16);
 			L.pi = i; L.pj = j; L.pbttop = bttop; L.pbtbot = btbot; L.btham = btham;
 			if (i + 1u == L.qlen) {
@@ -1253,14 +1155,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
  * Advance one lane until it has a memory request for this round (req.kind != RQ_NONE) or has
  * finished its read (state ST_IDLE).  `res` is the answer to the lane's previous request.
  */
-#if defined(__HIPCC__)
-struct BtGateOpen { __host__ __device__ bool operator()() const { return true; } };
-#else
-struct BtGateOpen { bool operator()() const { return true; } };
-#endif
-template <bool RL, class Gate = BtGateOpen>
+template <bool RL>
 BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
-                       const BtRes& res, BtReq& req, unsigned long long* CNT, Gate gate = Gate())
+                       const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
 	for (;;) {
@@ -1294,10 +1191,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				const uint32_t ac = bt_sel4(c & 3u, ta[0], ta[1], ta[2], ta[3]);
 				const uint32_t bc = bt_sel4(c & 3u, tb[0], tb[1], tb[2], tb[3]);
 				if (L.lfk == LFK_EX2) {
-#if !BT_SKIP_DEAD_PAIRS
 					bt_st4(PT4(e), res.q[0]);
 					bt_st4(PB4(e), res.q[1]);
-#endif
 					if (c < 4u) { L.top = ac; L.bot = bc; }
 				} else if (L.lfk == LFK_C2) {
 					L.top = ac; L.bot = bc;
@@ -1319,11 +1214,6 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				BT_UNROLL
 				for (uint32_t i = 0; i < 4u; i++) nz |= (tb[i] != ta[i] && i != c) ? (1u << i) : 0u;
 				el = ~nz & 15u;
-#if BT_SKIP_DEAD_PAIRS
-				/* the range stack's only reader is the fetch of a chosen target (ST_BT_LOOP), and a position without an
-				 * alternative is never one */
-				if (L.state == ST_STEP_LFDONE && L.lfk == LFK_EX2 && nz != 0) { bt_st4(PT4(e), res.q[0]); bt_st4(PB4(e), res.q[1]); }
-#endif
 				const uint32_t na = (uint32_t)__builtin_popcount(nz);
 				L.altNum = L.altNum + na;
 				if (L.fl_elig && nz != 0) {
@@ -1383,10 +1273,6 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 		/* ---- everything else ---------------------------------------------------------------- */
 		{
 			BT_PROF_T0(t_slow);
-#if BT_DEFER_SLOW
-			/* gate closed: the lane comes back next round as it is -- no request, `res` kept by the caller */
-			if (BT_IS_SLOW(L.state) && !gate()) return;
-#endif
 			if (BT_IS_SLOW(L.state)) bt_lane_slow<RL>(L, P, H, W, C, S, res, req, CNT);
 			BT_PROF_ADD(PS_SLOW, t_slow);
 		}

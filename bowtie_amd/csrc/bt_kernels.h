@@ -46,7 +46,6 @@ struct BtKernelArgs {
 	                                device (bt_align_batch_device) without waiting for it                 */
 	uint32_t   gateLo, gateHi;
 	unsigned long long* counts;  /* CN_N x u64 = bt_op_counts                                    */
-	uint32_t   slowPeriod, slowMin;  /* BT_DEFER_SLOW builds: the sweep's gate (bt_kernels.hip); 0, 0 = always open */
 #ifdef BT_TRACE
 	/* diagnostics build only (make -C bowtie_amd/csrc trace): every round of the lane that holds read `traceRead`
 	 * appends 12 words to trace[] (trace[0] = records written): round, state, step|mirror|readFw|rev, request kind,

@@ -125,17 +125,6 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 	}
 
-#if BT_DEFER_SLOW
-	/* The gate of the slow-state sweep (bt_core.h, BT_DEFER_SLOW): it opens every slowPeriod-th round of the wavefront, or
-	 * when at least slowMin of its lanes stand before it, or when the wavefront is about to park.  Called by the lanes
-	 * that are in a slow state, so the ballot counts exactly those. */
-	BtRes res;
-	bool forceOpen = false;
-	const uint32_t slowPeriod = A.slowPeriod ? A.slowPeriod : 1u, slowMin = A.slowMin ? A.slowMin : 65u;
-	auto gate = [&]() -> bool {
-		return forceOpen || (sc_rounds % slowPeriod) == 0u || (uint32_t)__builtin_popcountll(__ballot(1)) >= slowMin;
-	};
-#endif
 	for (;;) {
 		/* keep the compiler from hoisting the cold descriptor's fields into scalar registers for
 		 * the whole loop: they are read where they are used */
@@ -154,9 +143,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 #endif
 		/* ---- the round's memory requests: every lane's loads are issued, then one wait ---------- */
 		BT_PROF_T0(t_rank);
-#if !BT_DEFER_SLOW
 		BtRes res;
-#endif
 		{
 			const bool isRank = req.kind == RQ_RANK;
 			const bool isFetch = req.kind == RQ_FETCH;
@@ -195,7 +182,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 					bt_rank4_blk(qa[2], qa[3], rowB % BT_BLK_ROWS, bB == zBlk, zPos, lf, &dummy);
 					res.q[1].x = lf[0]; res.q[1].y = lf[1]; res.q[1].z = lf[2]; res.q[1].w = lf[3];
 				}
-			} else if (!BT_DEFER_SLOW || isFetch) {    /* a lane whose sweep was deferred keeps the answer it has */
+			} else {
 				res.q[0] = qa[0]; res.q[1] = qa[1]; res.q[2] = qa[2]; res.q[3] = qa[3]; res.x = qx;
 			}
 		}
@@ -212,11 +199,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
 			BT_PROF_T0(t_loop);
-#if BT_DEFER_SLOW
-			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT, gate);
-#else
 			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
-#endif
 			BT_PROF_ADD(PS_LOOP, t_loop);
 			if (L.state == ST_IDLE) continue;
 			break;
@@ -249,11 +232,6 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			if (dry) {
 				drained = true;
 				if (sc_rounds >= A.parkMinRounds && __ballot(live && ((cold->curBid - L.bid) & (BT_BATCH_RING - 1u)) >= A.maxAge) == 0) {
-#if BT_DEFER_SLOW
-					/* a lane whose sweep was deferred holds an answer that is not part of what is parked: one more round with
-					 * the gate open gives every such lane its next request */
-					if (__ballot(live && req.kind == RQ_NONE) != 0) forceOpen = true; else
-#endif
 					{ parkNow = true; break; }
 				}
 			}
