@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <unistd.h>
 #include <vector>
 
@@ -1042,7 +1043,9 @@ int main(int argc, char** argv)
 
 	/* ---- stage 1: reader ---- */
 	const int G = (int)ctxs.size();
-	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 2);
+	/* the searcher never waits for the writer: a batch's results are a few hundred MB of host memory, and a searcher held up
+	 * here stops feeding the GPU (round 4's timeline of a 64 M-read run: 1.8 s of every 10 with nothing enqueued) */
+	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 64);
 	std::vector<double> busy_gpu((size_t)G, 0.0);
 	std::thread reader([&] {
 		uint64_t seq = 0;
@@ -1372,7 +1375,15 @@ int main(int argc, char** argv)
 				if (end) return;
 				continue;
 			}
-			if (fl.size() >= 10) drain(1);                     /* reads older than ten batches: finish them now */
+			/* With carry-over a batch is complete when the launches behind it have finished what it left running: up to twelve
+			 * of them.  At the library's limit of batches in flight (BT_BATCH_RING - 2) the oldest is therefore waited for --
+			 * the launches it depends on are all enqueued -- not forced out: forcing (flush) stops the wavefronts from taking
+			 * new reads until the stragglers are done, which is what a 64 M-read run spent 2.8 s of its 18 on in round 4's
+			 * timeline. */
+			while (fl.size() >= 13 && !abort_run.load()) {
+				drain(0);
+				if (fl.size() >= 13) std::this_thread::sleep_for(std::chrono::microseconds(500));
+			}
 			g_tl.mark("search: taken", j->seq);
 			search_prepare(O, j.get());
 			g_tl.mark("search: result arrays ready", j->seq);
@@ -1405,12 +1416,16 @@ int main(int argc, char** argv)
 	if (f_al2) fclose(f_al2);
 	if (f_un2) fclose(f_un2);
 	if (f_max2) fclose(f_max2);
+	g_tl.mark("teardown: output files closed", 0);
 	bt_io_close(rs);
 	if (rs2) bt_io_close(rs2);
+	g_tl.mark("teardown: inputs closed", 0);
 	for (bt_ctx* c : ctxs) bt_ctx_destroy(c);
 	for (bt_ctx* c : redo_ctxs) bt_ctx_destroy(c);
 	for (bt_ctx* c : unp_ctxs) bt_ctx_destroy(c);
+	g_tl.mark("teardown: contexts destroyed", 0);
 	for (bt_index* x : idxs) bt_index_free(x);
+	g_tl.mark("teardown: index freed", 0);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }
 	if (O.timing) print_timer("Overall time: ", now_s() - t_all);

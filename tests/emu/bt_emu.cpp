@@ -128,13 +128,6 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	/* EMU_PARK_EVERY=<n>: every lane is parked and adopted again (carry-over) in one round out of n, at random */
 	const uint32_t parkEvery = getenv("EMU_PARK_EVERY") ? (uint32_t)atoi(getenv("EMU_PARK_EVERY")) : 0u;
 	uint32_t parkRng = 12345u;
-#if BT_DEFER_SLOW
-	/* the gate of the slow-state sweep: open one time in EMU_DEFER (default 3), drawn per lane and round -- a lane that
-	 * finds it closed comes back next round with its state and the answer to its last request untouched */
-	const uint32_t deferEvery = getenv("EMU_DEFER") ? (uint32_t)atoi(getenv("EMU_DEFER")) : 3u;
-	uint32_t gateRng = 4711u;
-	auto gate = [&]() -> bool { gateRng = gateRng * 1664525u + 1013904223u; return deferEvery <= 1u || (gateRng >> 9) % deferEvery == 0; };
-#endif
 	while (live > 0) {
 		for (uint32_t g = 0; g < nLanes; g++) {
 			if (drained[g]) continue;
@@ -145,11 +138,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
 					bt_lane_start<RL>(L, P, H, cold, scr[g], next++);
 				}
-#if BT_DEFER_SLOW
-				bt_lane_run<RL>(L, P, H, W, cold, scr[g], res[g], req, CNT, gate);
-#else
 				bt_lane_run<RL>(L, P, H, W, cold, scr[g], res[g], req, CNT);
-#endif
 				if (L.state != ST_IDLE) break;
 			}
 			if (drained[g]) continue;
@@ -185,7 +174,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 					bt_rank4(ix, (uint32_t)req.x, lf, &dummy);
 					res[g].q[1].x = lf[0]; res[g].q[1].y = lf[1]; res[g].q[1].z = lf[2]; res[g].q[1].w = lf[3];
 				}
-			} else if (!BT_DEFER_SLOW || req.kind == RQ_FETCH) {
+			} else {
 				memset(&res[g], 0, sizeof(BtRes));
 				for (uint32_t k = 0; k < req.n; k++) memcpy(&res[g].q[k], (const uint8_t*)(uintptr_t)req.a + 16 * k, 16);
 				if (req.x) memcpy(&res[g].x, (const void*)(uintptr_t)req.x, 16);
@@ -202,33 +191,6 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 	return BT_OK;
 }
 
-#if BF_REFILL
-/* bt_best_kernel's loop in the BF_REFILL build, for one "wavefront" of W lanes gone through side by side: lanes take a
- * read when `least` of them wait for one (or none is working), step their reads turn by turn and leave when the cursor
- * is dry -- the same decisions as the kernel's, its ballots being counts over the lanes still in the loop.  Checks what
- * the kernel's loop has to get right: every read run exactly once, by some lane, and the loop ends. */
-static void emu_best_wave(std::vector<BfLane>& XS, const BtBatchDev& B, uint32_t n, uint32_t kind, uint32_t least)
-{
-	const size_t W = XS.size();
-	std::vector<BfRun> R(W);
-	std::vector<char> drained(W, 0), gone(W, 0);
-	for (auto& r : R) r.kind = 0;
-	uint32_t next = 0;
-	for (;;) {
-		uint32_t working = 0, waiting = 0, alive = 0;
-		for (size_t l = 0; l < W; l++) if (!gone[l]) { alive++; if (R[l].kind != 0) working++; else if (!drained[l]) waiting++; }
-		if (!alive) break;
-		for (size_t l = 0; l < W; l++) if (!gone[l] && R[l].kind == 0 && !drained[l] && (working == 0 || waiting >= least)) {
-			const uint32_t w = next++;
-			if (w >= n) drained[l] = 1; else bf_run_begin(XS[l], B, w, R[l], kind);
-		}
-		for (size_t l = 0; l < W; l++) if (!gone[l]) {
-			if (R[l].kind == 0) { if (drained[l]) gone[l] = 1; continue; }
-			if (!bf_run_step(XS[l], B, R[l])) bf_run_end(XS[l], B, R[l]);
-		}
-	}
-}
-#endif
 
 /* The best-first engine (bowtie_amd/csrc/bt_best.h), one read after the other, each in an arena of
  * arenaWords 32-bit words. */
@@ -246,27 +208,11 @@ static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, 
 	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
-#if BF_REFILL
-	/* the kernel's loop in that build, 24 lanes side by side (arenas from calloc: untouched pages cost nothing) */
-	const size_t W = in->n_reads < 24u ? (in->n_reads ? in->n_reads : 1u) : 24u;
-	uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
-	if (!arenas) return BT_ERR_DEVICE;
-	std::vector<BfLane> XS(W);
-	for (size_t l = 0; l < W; l++) { memset(&XS[l], 0, sizeof(BfLane)); XS[l].A = arenas + l * (size_t)arenaWords; XS[l].cap = arenaWords; XS[l].ix = e->d; XS[l].P = &P; }
-	emu_best_wave(XS, B, in->n_reads, 1u, 6u);
-	BfLane X = XS[0];
-	for (size_t l = 1; l < W; l++) {
-		X.c_lfex += XS[l].c_lfex; X.c_lf2 += XS[l].c_lf2; X.c_lf1 += XS[l].c_lf1; X.c_chase += XS[l].c_chase; X.c_ftab += XS[l].c_ftab;
-		X.c_offs += XS[l].c_offs; X.c_rst += XS[l].c_rst; X.c_same += XS[l].c_same; X.c_frames += XS[l].c_frames;
-	}
-	free(arenas);
-#else
 	std::vector<uint32_t> arena(arenaWords);
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
 	for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
-#endif
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
@@ -302,26 +248,11 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
 	if (arenaWords < 256u) arenaWords = 1u << 22;
-#if BF_REFILL
-	const size_t W = in1->n_reads < 24u ? (in1->n_reads ? in1->n_reads : 1u) : 24u;
-	uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
-	if (!arenas) return BT_ERR_DEVICE;
-	std::vector<BfLane> XS(W);
-	for (size_t l = 0; l < W; l++) { memset(&XS[l], 0, sizeof(BfLane)); XS[l].A = arenas + l * (size_t)arenaWords; XS[l].cap = arenaWords; XS[l].ix = e->d; XS[l].P = &P; XS[l].ref = &e->refd; }
-	emu_best_wave(XS, B, in1->n_reads, BF_IS_V1(P) ? 3u : 2u, 6u);
-	BfLane X = XS[0];
-	for (size_t l = 1; l < W; l++) {
-		X.c_lfex += XS[l].c_lfex; X.c_lf2 += XS[l].c_lf2; X.c_lf1 += XS[l].c_lf1; X.c_chase += XS[l].c_chase; X.c_ftab += XS[l].c_ftab;
-		X.c_offs += XS[l].c_offs; X.c_rst += XS[l].c_rst; X.c_same += XS[l].c_same; X.c_frames += XS[l].c_frames;
-	}
-	free(arenas);
-#else
 	std::vector<uint32_t> arena(arenaWords);
 	BfLane X;
 	memset(&X, 0, sizeof(X));
 	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
 	for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
-#endif
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
