@@ -787,211 +787,263 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 }
 #undef BF_LQ
 
-/* EbwtRangeSource::advanceBranch (ebwt_search_backtrack.h:2059-2361), until = ADV_COST_CHANGES */
-BF_FN void leaf_advance_branch(BfLane& X, uint32_t d, const BfSpec& sp)
+/* EbwtRangeSource::advanceBranch (ebwt_search_backtrack.h:2059-2361), until = ADV_COST_CHANGES, inside
+ * SingleRangeSourceDriver::advanceImpl (range_source.h:1777-1838) -- as five pieces over one record of locals, so that the
+ * same statements serve the engine run call by call (leaf_advance below: the pieces in their loops) and the wavefront
+ * automaton at the end of this file (one piece per round, whichever leaf of whichever read a lane is on).
+ *
+ * The reference's steps, organised around what a lane waits for.  A branch that is simply extended -- no alternative taken,
+ * nothing curtailed -- stays the queue's front with its cost (the queue is not touched, and PathManager::splitAndPrep on
+ * such a front only preps it): the next step goes on from the record in registers (la_step), prepped in place, instead of
+ * reading the queue, the front's flags and cost and the record again (six dependent waits a base); its base and quality
+ * were fetched beside this step's rank loads; and the record's words go back to the arena once, when the streak ends
+ * (la_send).  What the arena holds after a streak is what the long way round writes. */
+struct BfLeafSt {
+	uint32_t d;                   /* the leaf */
+	uint32_t spec;                /* its BfSpec */
+	uint32_t fl;                  /* its DR_FLAGS when the advance began */
+	uint32_t qlen, depth5, depth3;
+	uint32_t seedN, seedM[3];     /* the seed's edits the query carries (seedEdits): fixed while the leaf advances */
+	uint32_t br, R[BF_BRW];       /* the queue's front and its record */
+	uint32_t cost, nedits, rdepth;/* of that branch: fixed while it is extended */
+	uint32_t top, bot, pfC, pfQ;
+	bool seedEdits, found, curtail, extended, tbNew, dirty, havePf;
+};
+
+/* leaf_advance's prologue; false: the leaf is done, there is nothing to advance (its flags say so now) */
+BF_FN bool la_enter(BfLane& X, BfLeafSt& S, uint32_t d)
 {
-	/* The reference's steps, organised around what a lane waits for.
-	 * A branch that is simply extended -- no alternative taken, nothing curtailed -- stays the queue's front with its
-	 * cost (the queue is not touched, and PathManager::splitAndPrep on such a front only preps it): the next step goes on
-	 * from the record in registers, prepped in place, instead of reading the queue, the front's flags and cost and the
-	 * record again (six dependent waits a base); its base and quality were fetched beside this step's rank loads; and
-	 * the record's words go back to the arena once, when the streak ends.  The streak is a loop of its own, so that the
-	 * lanes of a wavefront that are extending do so together and meet again for what follows (curtail, split, queue):
-	 * that part is then gone through once for all of them instead of once per lane that needs it.  What the arena holds
-	 * after a streak is what the long way round writes. */
+	const uint32_t fl = AW(d + DR_FLAGS);
+	if ((fl & BF_F_DONE) || (AW(d + LF_HEAPSZ) & 0xffffu) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return false; }
+	pm_enter(X, d);
+	S.d = d; S.fl = fl; S.spec = (AW(d + DR_KIND) >> 16) & 0xffu;
+	S.qlen = AW(d + LF_QLEN) & 0xffffu;
+	const uint32_t d53 = AW(d + LF_D53);
+	S.depth5 = d53 & 0xffffu; S.depth3 = d53 >> 16;
+	S.found = false;
+	S.seedEdits = (AW(d + LF_RSFLAGS) & 8u) != 0;
+	S.seedN = 0; S.seedM[0] = S.seedM[1] = S.seedM[2] = 0;
+	if (S.seedEdits) { S.seedN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) S.seedM[k] = AW(d + LF_SEEDMM0 + k); }
+	return true;
+}
+
+/* the queue's front, its record in one go (four independent 16-byte loads, one wait) */
+BF_FN void la_front(BfLane& X, BfLeafSt& S)
+{
+	BF_PT0(t_front);
+	const uint32_t br = pm_front(X, S.d);
+	uint32_t* R = S.R;
+	{
+		const BtU4 r0 = bt_ld4((const void*)(X.A + br)), r1 = bt_ld4((const void*)(X.A + br + 4u));
+		const BtU4 r2 = bt_ld4((const void*)(X.A + br + 8u)), r3 = bt_ld4((const void*)(X.A + br + 12u));
+		R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+		R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
+	}
+	S.br = br;
+	S.cost = R[BR_COSTHAM] & 0xffffu;
+	S.nedits = R[BR_EDIT] >> 16;
+	S.rdepth = R[BR_RDLEN] & 0xffffu;
+	S.top = S.bot = 0;
+	S.curtail = S.extended = S.tbNew = S.dirty = S.havePf = false;
+	S.pfC = S.pfQ = 0;
+	BF_PADD(BP_FRONT, t_front);
+}
+
+/* one step of the streak; true: the branch was simply extended and the next step goes on from the registers */
+BF_FN bool la_step(BfLane& X, BfLeafSt& S)
+{
+	const BfSpec& sp = X.P->specs[S.spec];
 	const BtIndexDev& ix = X.ix[sp.mirror];
-	const uint32_t qlen = AW(d + LF_QLEN) & 0xffffu;
-	const uint32_t depth5 = AW(d + LF_D53) & 0xffffu, depth3 = AW(d + LF_D53) >> 16;
+	const uint32_t d = S.d, br = S.br, qlen = S.qlen, depth5 = S.depth5, depth3 = S.depth3;
 	const uint32_t maq = X.P->maq;
 	const BfRead& RD = X.R[sp.mate];
 	const uint32_t ebwtFw = !sp.mirror;
-	bool found = false;
-	const bool seedEdits = (AW(d + LF_RSFLAGS) & 8u) != 0;          /* the query carries a seed's edits: fixed while the leaf advances */
-	uint32_t seedN = 0, seedM[3] = {0, 0, 0};
-	if (seedEdits) { seedN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) seedM[k] = AW(d + LF_SEEDMM0 + k); }
-	do {
-		BF_PT0(t_front);
-		const uint32_t br = pm_front(X, d);
-		uint32_t R[BF_BRW];
-		{
-			const BtU4 r0 = bt_ld4((const void*)(X.A + br)), r1 = bt_ld4((const void*)(X.A + br + 4u));
-			const BtU4 r2 = bt_ld4((const void*)(X.A + br + 8u)), r3 = bt_ld4((const void*)(X.A + br + 12u));
-			R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
-			R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
-		}
-		BF_PADD(BP_FRONT, t_front);
-		const uint32_t cost = R[BR_COSTHAM] & 0xffffu;               /* fixed while the branch is extended */
-		const uint32_t nedits = R[BR_EDIT] >> 16;
-		const uint32_t rdepth = R[BR_RDLEN] & 0xffffu;
-		uint32_t top = 0, bot = 0;
-		bool curtail = false, extended = false, tbNew = false, dirty = false, havePf = false;
-		uint32_t pfC = 0, pfQ = 0;
-		BF_PT0(t_streak);
-		for (;;) {                                                     /* the streak: one step per turn */
-			const uint32_t blen = R[BR_RDLEN] >> 16;
-			const uint32_t depth = rdepth + blen;
-			uint32_t cur = 0;
-			top = R[BR_TOP]; bot = R[BR_BOT];
-			curtail = false; extended = false; tbNew = false;
-			bool hit = false;
-			/* hhCheckTop (:2444-2475) */
-			if (sp.halfAndHalf && ((depth == depth5 && nedits == 0) || (depth == depth3 && nedits < sp.halfAndHalf))) {
-				curtail = true;
-			} else {
-				cur = qlen - depth - 1u;
-				if (depth < qlen) {
-					uint32_t c = havePf ? pfC : bf_base(RD, sp.fw, ebwtFw, cur);
-					if (seedEdits) {
-						const uint32_t full = RD.len;                          /* leaf_qry's overrides, from registers */
-						for (uint32_t k = 0; k < 3u; k++) if (k < seedN && full - (seedM[k] & 0xffffu) - 1u == cur) c = seedM[k] >> 16;
-					}
-					const uint32_t q = bt_mm_penalty(maq, bf_phred(havePf ? pfQ : bf_qualc(RD, sp.fw, ebwtFw, cur)));
-					/* the next position's base and quality, in flight beside this step's rank loads */
-					havePf = cur > 0;
-					if (havePf) { pfC = bf_base(RD, sp.fw, ebwtFw, cur - 1u); pfQ = bf_qualc(RD, sp.fw, ebwtFw, cur - 1u); }
-					const uint32_t ham = R[BR_COSTHAM] >> 16;
-					const uint32_t d0 = R[BR_D01] & 0xffffu;
-					const bool alt = depth >= d0 && ham + q <= sp.qualLim;
-					uint32_t otop = top;
-					if (c == 4u && depth > 0) top = bot = 1;
-					const uint32_t fl = R[BR_FLAGS];
-					uint32_t tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
-					bool ranges = false;
-					if (top == 0 && bot == 0) {
-						tops[0] = ix.fchr[0]; bots[0] = tops[1] = ix.fchr[1]; bots[1] = tops[2] = ix.fchr[2];
-						bots[2] = tops[3] = ix.fchr[3]; bots[3] = ix.fchr[4];
-						ranges = true;
-						if (c < 4u) { top = tops[c]; bot = bots[c]; }
-					} else if (alt && (bot > top || c == 4u)) {
-						if (fl & BRF_LBOT) {
-							uint32_t L;
-							const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
-							bt_rank4(ix, ra, tops, &L);
-							bt_rank4(ix, rb, bots, &L);
-							X.c_lfex++; if (ra / 448u == rb / 448u) X.c_same++;
-						} else {
-							/* mapLF1(otop, ltop_) (ebwt.h:2530-2560) */
-							X.c_lf1++;
-							if (otop != ix.zOff) {
-								uint32_t lf[4], L;
-								bt_rank4(ix, R[BR_LTOP], lf, &L);
-								otop = lf[L];
-								tops[L] = otop; bots[L] = otop + 1u;
-							}
-						}
-						ranges = true;
-						if (c < 4u) { top = tops[c]; bot = bots[c]; } else top = bot = 1;
-					} else if (bot > top) {
-						if (c < 4u) {
-							uint32_t lf[4], L;
-							if (top + 1u == bot) {
-								/* mapLF1(top_, ltop_, c) (ebwt.h:2494-2524) */
-								X.c_lf1++;
-								bt_rank4(ix, R[BR_LTOP], lf, &L);
-								if (L != c || top == ix.zOff) top = bot = BT_OFF_MASK;
-								else { top = lf[c]; bot = top + 1u; }
-							} else {
-								const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
-								X.c_lf2++; if (ra / 448u == rb / 448u) X.c_same++;
-								bt_rank4(ix, ra, lf, &L); top = lf[c];
-								bt_rank4(ix, rb, lf, &L); bot = lf[c];
-							}
-						}
-					}
-					if (ranges) {
-						/* Branch::installRanges (range_source.h:970-1023): a record only for a position that
-						 * is a legitimate place to branch from and still has an untried substitution */
-						uint32_t mask = 0xfu;
-						if (q <= sp.qualLim - ham) {
-							for (uint32_t k = 0; k < 4u; k++) if (c != k && bots[k] > tops[k]) mask &= ~(1u << k);
-						}
-						if (mask != 0xfu && depth >= d0) {
-							const uint32_t nalt = R[BR_NALT];
-							const uint32_t rec = bf_alloc(X, BF_ALW);
-							if (nalt == 0) { AW(br + BR_ALT) = rec; X.growing = br; }
-							else if (X.growing != br || rec != R[BR_ALT] + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
-							if (!X.ovf) {
-								for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
-								AW(rec + 8u) = blen | (q << 16) | (mask << 24);
-								AW(br + BR_NALT) = nalt + 1u;
-								if (nalt == 0) R[BR_ALT] = rec;
-								R[BR_NALT] = nalt + 1u;
-							}
-						}
-					}
-				} else {
-					cur = 0;
-				}
-				tbNew = true;                                  /* top and bot are written when the streak ends (below) */
-				const bool empty = top == bot;
-				hit = cur == 0 && !empty;
-				const bool invalidExact = hit && nedits == 0 && !sp.reportExacts;
-				/* hhCheck (:2397-2436) */
-				bool hhOk = true;
-				if (sp.halfAndHalf) {
-					if (depth == depth5 - 1u && !empty) hhOk = nedits > 0;
-					else if (depth == depth3 - 1u && !empty) {
-						const uint32_t hilo = R[BR_HILO];
-						hhOk = nedits >= sp.halfAndHalf && (hilo & 0xffffu) != 0 && (hilo >> 16) != 0;
-					}
-				}
-				if (!hhOk) { curtail = true; hit = false; }
-				else if (hit && !invalidExact) {
-					AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
-					AW(d + LF_CURCOST) = cost | ((nedits + (seedEdits ? seedN : 0u)) << 16);
-					AW(d + LF_CURBR) = br;
-					found = true;
-					curtail = true;
-				} else if (empty || cur == 0) curtail = true;
-				else { R[BR_RDLEN] = rdepth | ((blen + 1u) << 16); extended = true; }   /* Branch::extend */
+	uint32_t* R = S.R;
+	const uint32_t cost = S.cost, nedits = S.nedits, rdepth = S.rdepth;
+	const uint32_t blen = R[BR_RDLEN] >> 16;
+	const uint32_t depth = rdepth + blen;
+	uint32_t cur = 0;
+	uint32_t top = R[BR_TOP], bot = R[BR_BOT];
+	bool curtail = false, extended = false, tbNew = false;
+	bool hit = false;
+	/* hhCheckTop (:2444-2475) */
+	if (sp.halfAndHalf && ((depth == depth5 && nedits == 0) || (depth == depth3 && nedits < sp.halfAndHalf))) {
+		curtail = true;
+	} else {
+		cur = qlen - depth - 1u;
+		if (depth < qlen) {
+			uint32_t c = S.havePf ? S.pfC : bf_base(RD, sp.fw, ebwtFw, cur);
+			if (S.seedEdits) {
+				const uint32_t full = RD.len;                          /* leaf_qry's overrides, from registers */
+				for (uint32_t k = 0; k < 3u; k++) if (k < S.seedN && full - (S.seedM[k] & 0xffffu) - 1u == cur) c = S.seedM[k] >> 16;
 			}
-			if (!(extended && !X.ovf && (R[BR_FLAGS] & (BRF_DELAYED | BRF_CURTAILED)) == 0 && !(sp.useBtCnt != 0 && X.btCnt == 0))) break;
-			/* splitAndPrep on an untouched queue whose front is this branch does one thing, prep: done on the registers */
-			uint32_t f = R[BR_FLAGS];
-			if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; R[BR_LTOP] = top; R[BR_LBOT] = bot; }
-			else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; }
-			R[BR_FLAGS] = f; R[BR_TOP] = top; R[BR_BOT] = bot;
-			dirty = true;
-#if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
-			if ((uint32_t)AW(PMW(LF_HEAP)) != br || X.pm[6] != br || PMW(LF_PMCOST) != cost) { fprintf(stderr, "BF_CHECK: the extended branch is not the queue's front\n"); abort(); }
-#endif
+			const uint32_t q = bt_mm_penalty(maq, bf_phred(S.havePf ? S.pfQ : bf_qualc(RD, sp.fw, ebwtFw, cur)));
+			/* the next position's base and quality, in flight beside this step's rank loads */
+			S.havePf = cur > 0;
+			if (S.havePf) { S.pfC = bf_base(RD, sp.fw, ebwtFw, cur - 1u); S.pfQ = bf_qualc(RD, sp.fw, ebwtFw, cur - 1u); }
+			const uint32_t ham = R[BR_COSTHAM] >> 16;
+			const uint32_t d0 = R[BR_D01] & 0xffffu;
+			const bool alt = depth >= d0 && ham + q <= sp.qualLim;
+			uint32_t otop = top;
+			if (c == 4u && depth > 0) top = bot = 1;
+			const uint32_t fl = R[BR_FLAGS];
+			uint32_t tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
+			bool ranges = false;
+			/* which LF-mapping the step needs is decided first, the rows' rank blocks are fetched at ONE place in the code --
+			 * the lanes of a wavefront that are stepping, whatever their cases, wait for them once -- and the case is
+			 * finished afterwards: 1 = the four ranges of both rows (countFwSideEx x 2), 2 = mapLF1(otop, ltop_)
+			 * (ebwt.h:2530-2560), 3 = mapLF1(top_, ltop_, c) (ebwt.h:2494-2524), 4 = mapLF of both rows for c */
+			uint32_t lfCase = 0;
+			bool altCase = false;
+			if (top == 0 && bot == 0) {
+				tops[0] = ix.fchr[0]; bots[0] = tops[1] = ix.fchr[1]; bots[1] = tops[2] = ix.fchr[2];
+				bots[2] = tops[3] = ix.fchr[3]; bots[3] = ix.fchr[4];
+				ranges = true;
+				if (c < 4u) { top = tops[c]; bot = bots[c]; }
+			} else if (alt && (bot > top || c == 4u)) {
+				if (fl & BRF_LBOT) lfCase = 1u;
+				else { X.c_lf1++; if (otop != ix.zOff) lfCase = 2u; }
+				ranges = true; altCase = true;
+			} else if (bot > top) {
+				if (c < 4u) lfCase = (top + 1u == bot) ? 3u : 4u;
+			}
+			if (lfCase) {
+				uint32_t la[4], lb[4] = {0, 0, 0, 0}, LA, LB;
+				const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
+				const bool two = lfCase == 1u || lfCase == 4u;
+				bt_rank4(ix, ra, la, &LA);
+				if (two) bt_rank4(ix, rb, lb, &LB);
+				if (lfCase == 1u) {
+					for (uint32_t k = 0; k < 4u; k++) { tops[k] = la[k]; bots[k] = lb[k]; }
+					X.c_lfex++; if (ra / 448u == rb / 448u) X.c_same++;
+				} else if (lfCase == 2u) {
+					otop = la[LA];
+					tops[LA] = otop; bots[LA] = otop + 1u;
+				} else if (lfCase == 3u) {
+					X.c_lf1++;
+					if (LA != c || top == ix.zOff) top = bot = BT_OFF_MASK;
+					else { top = la[c]; bot = top + 1u; }
+				} else {
+					X.c_lf2++; if (ra / 448u == rb / 448u) X.c_same++;
+					top = la[c]; bot = lb[c];
+				}
+			}
+			if (altCase) { if (c < 4u) { top = tops[c]; bot = bots[c]; } else top = bot = 1; }
+			if (ranges) {
+				/* Branch::installRanges (range_source.h:970-1023): a record only for a position that
+				 * is a legitimate place to branch from and still has an untried substitution */
+				uint32_t mask = 0xfu;
+				if (q <= sp.qualLim - ham) {
+					for (uint32_t k = 0; k < 4u; k++) if (c != k && bots[k] > tops[k]) mask &= ~(1u << k);
+				}
+				if (mask != 0xfu && depth >= d0) {
+					const uint32_t nalt = R[BR_NALT];
+					const uint32_t rec = bf_alloc(X, BF_ALW);
+					if (nalt == 0) { AW(br + BR_ALT) = rec; X.growing = br; }
+					else if (X.growing != br || rec != R[BR_ALT] + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
+					if (!X.ovf) {
+						for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
+						AW(rec + 8u) = blen | (q << 16) | (mask << 24);
+						AW(br + BR_NALT) = nalt + 1u;
+						if (nalt == 0) R[BR_ALT] = rec;
+						R[BR_NALT] = nalt + 1u;
+					}
+				}
+			}
+		} else {
+			cur = 0;
 		}
-		BF_PADD(BP_STREAK, t_streak);
-		/* the streak ends here: the arena gets what its steps would have written one by one, before anything reads it */
-		if (tbNew) { AW(br + BR_TOP) = top; AW(br + BR_BOT) = bot; }
-		else if (dirty) { AW(br + BR_TOP) = R[BR_TOP]; AW(br + BR_BOT) = R[BR_BOT]; }
-		if (dirty) { AW(br + BR_FLAGS) = R[BR_FLAGS]; AW(br + BR_LTOP) = R[BR_LTOP]; AW(br + BR_LBOT) = R[BR_LBOT]; }
-		if (dirty || extended) AW(br + BR_RDLEN) = R[BR_RDLEN];
-		{ BF_PT0(t_curtail); if (curtail) pm_curtail_regs(X, d, br, depth3, R); BF_PADD(BP_CURTAIL, t_curtail); }
-		if (X.ovf) break;
-		{ BF_PT0(t_split); const bool sp_ok = pm_split_and_prep(X, d, depth3, depth5, sp.useBtCnt != 0); BF_PADD(BP_SPLIT, t_split); if (!sp_ok) pm_reset(X, d); }
-		if (X.ovf) break;
-		if (pm_size(X, d) == 0) break;
-		/* the queue's cost word is its front's cost: every change of a queued branch's cost (curtail, a delayed increase) is
-		 * followed by a pop and a push, which set it */
+		tbNew = true;                                  /* top and bot are written when the streak ends (la_send) */
+		const bool empty = top == bot;
+		hit = cur == 0 && !empty;
+		const bool invalidExact = hit && nedits == 0 && !sp.reportExacts;
+		/* hhCheck (:2397-2436) */
+		bool hhOk = true;
+		if (sp.halfAndHalf) {
+			if (depth == depth5 - 1u && !empty) hhOk = nedits > 0;
+			else if (depth == depth3 - 1u && !empty) {
+				const uint32_t hilo = R[BR_HILO];
+				hhOk = nedits >= sp.halfAndHalf && (hilo & 0xffffu) != 0 && (hilo >> 16) != 0;
+			}
+		}
+		if (!hhOk) { curtail = true; hit = false; }
+		else if (hit && !invalidExact) {
+			AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
+			AW(d + LF_CURCOST) = cost | ((nedits + (S.seedEdits ? S.seedN : 0u)) << 16);
+			AW(d + LF_CURBR) = br;
+			S.found = true;
+			curtail = true;
+		} else if (empty || cur == 0) curtail = true;
+		else { R[BR_RDLEN] = rdepth | ((blen + 1u) << 16); extended = true; }   /* Branch::extend */
+	}
+	S.top = top; S.bot = bot; S.curtail = curtail; S.extended = extended; S.tbNew = tbNew;
+	if (!(extended && !X.ovf && (R[BR_FLAGS] & (BRF_DELAYED | BRF_CURTAILED)) == 0 && !(sp.useBtCnt != 0 && X.btCnt == 0))) return false;
+	/* splitAndPrep on an untouched queue whose front is this branch does one thing, prep: done on the registers */
+	uint32_t f = R[BR_FLAGS];
+	if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; R[BR_LTOP] = top; R[BR_LBOT] = bot; }
+	else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; }
+	R[BR_FLAGS] = f; R[BR_TOP] = top; R[BR_BOT] = bot;
+	S.dirty = true;
 #if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
-		if (PMW(LF_PMCOST) != br_cost(X, AW(PMW(LF_HEAP))) || X.pm[6] != (uint32_t)AW(PMW(LF_HEAP))) { fprintf(stderr, "BF_CHECK: queue cost / front cache out of step\n"); abort(); }
+	if ((uint32_t)AW(PMW(LF_HEAP)) != br || X.pm[6] != br || PMW(LF_PMCOST) != cost) { fprintf(stderr, "BF_CHECK: the extended branch is not the queue's front\n"); abort(); }
 #endif
-		if (PMW(LF_PMCOST) != cost) break;
-	} while (!found);
-	AW(d + LF_RSFLAGS) = (AW(d + LF_RSFLAGS) & ~2u) | (found ? 2u : 0u);
+	return true;
 }
 
-/* SingleRangeSourceDriver::advanceImpl (range_source.h:1777-1838) */
-BF_FN void leaf_advance(BfLane& X, uint32_t d)
+/* the streak has ended: the arena gets what its steps would have written one by one, before anything reads it; curtail,
+ * splitAndPrep.  true: the leaf's advance goes on with the queue's new front (la_front), false: it is over (la_exit) */
+BF_FN bool la_send(BfLane& X, BfLeafSt& S)
 {
-	uint32_t fl = AW(d + DR_FLAGS);
-	if ((fl & BF_F_DONE) || (AW(d + LF_HEAPSZ) & 0xffffu) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return; }
-	pm_enter(X, d);
-	const BfSpec& sp = leaf_spec(X, d);
-	{ BF_PT0(t_leaf); leaf_advance_branch(X, d, sp); BF_PADD(BP_LEAF, t_leaf); }
-	fl &= ~(BF_F_DONE | BF_F_FOUND);
+	const BfSpec& sp = X.P->specs[S.spec];
+	const uint32_t d = S.d, br = S.br;
+	const uint32_t* R = S.R;
+	if (S.tbNew) { AW(br + BR_TOP) = S.top; AW(br + BR_BOT) = S.bot; }
+	else if (S.dirty) { AW(br + BR_TOP) = R[BR_TOP]; AW(br + BR_BOT) = R[BR_BOT]; }
+	if (S.dirty) { AW(br + BR_FLAGS) = R[BR_FLAGS]; AW(br + BR_LTOP) = R[BR_LTOP]; AW(br + BR_LBOT) = R[BR_LBOT]; }
+	if (S.dirty || S.extended) AW(br + BR_RDLEN) = R[BR_RDLEN];
+	{ BF_PT0(t_curtail); if (S.curtail) pm_curtail_regs(X, d, br, S.depth3, R); BF_PADD(BP_CURTAIL, t_curtail); }
+	if (X.ovf) return false;
+	{ BF_PT0(t_split); const bool sp_ok = pm_split_and_prep(X, d, S.depth3, S.depth5, sp.useBtCnt != 0); BF_PADD(BP_SPLIT, t_split); if (!sp_ok) pm_reset(X, d); }
+	if (X.ovf) return false;
+	if (pm_size(X, d) == 0) return false;
+	/* the queue's cost word is its front's cost: every change of a queued branch's cost (curtail, a delayed increase) is
+	 * followed by a pop and a push, which set it */
+#if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+	if (PMW(LF_PMCOST) != br_cost(X, AW(PMW(LF_HEAP))) || X.pm[6] != (uint32_t)AW(PMW(LF_HEAP))) { fprintf(stderr, "BF_CHECK: queue cost / front cache out of step\n"); abort(); }
+#endif
+	if (PMW(LF_PMCOST) != S.cost) return false;
+	return !S.found;
+}
+
+/* leaf_advance's epilogue: the range source's and the driver's flags and cost */
+BF_FN void la_exit(BfLane& X, BfLeafSt& S)
+{
+	const uint32_t d = S.d;
+	const uint32_t rsf = (AW(d + LF_RSFLAGS) & ~2u) | (S.found ? 2u : 0u);
+	AW(d + LF_RSFLAGS) = rsf;
+	uint32_t fl = S.fl & ~(BF_F_DONE | BF_F_FOUND);
 	if (pm_size(X, d) == 0) fl |= BF_F_DONE;
 	const uint32_t pmc = PMW(LF_PMCOST), adj = AW(d + DR_COST) >> 16;
 	if (pmc != 0) AW(d + DR_COST) = (pmc > adj ? pmc : adj) | (adj << 16);
-	if (AW(d + LF_RSFLAGS) & 2u) fl |= BF_F_FOUND;
+	if (rsf & 2u) fl |= BF_F_FOUND;
 	AW(d + DR_FLAGS) = fl;
 	pm_leave(X, d);
+}
+
+/* SingleRangeSourceDriver::advanceImpl (range_source.h:1777-1838): the pieces in their loops */
+BF_FN void leaf_advance(BfLane& X, uint32_t d)
+{
+	BfLeafSt S;
+	if (!la_enter(X, S, d)) return;
+	BF_PT0(t_leaf);
+	do {
+		la_front(X, S);
+		BF_PT0(t_streak);
+		while (la_step(X, S)) { }
+		BF_PADD(BP_STREAK, t_streak);
+	} while (la_send(X, S));
+	BF_PADD(BP_LEAF, t_leaf);
+	la_exit(X, S);
 }
 
 /* ---- the inner drivers ------------------------------------------------------------------------ */
