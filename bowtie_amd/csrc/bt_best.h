@@ -1429,11 +1429,17 @@ BF_FN void seeded_post_full(BfLane& X, uint32_t d, uint32_t seed, uint32_t full,
 		dr_set_mincost(X, d, a < b ? a : b);
 	}
 }
-/* cost_advance<0>(d) -- the aligner's own driver -- with the leaf it gets to advanced at one place (see the head of this file):
- * statement for statement cost_advance<0>, child_advance<0>, seeded_advance and cost_advance<1> up to their calls,
- * the call, then what follows it in each, innermost first */
-BF_FN void bf_advance_top(BfLane& X, uint32_t d)
+/* cost_advance<0>(d) -- the aligner's own driver -- with the leaf it gets to advanced at one place (see the head of this
+ * file): statement for statement cost_advance<0>, child_advance<0>, seeded_advance and cost_advance<1> up to their calls
+ * (adv_pre), the call, then what follows it in each, innermost first (adv_post) */
+struct BfAdvSt { uint32_t d, p, precost, leaf, seed, full, old, p2, precost1, after; };
+enum { BF_AFTER_NONE = 0, BF_AFTER_SEED_BRANCH, BF_AFTER_FULL_BRANCH, BF_AFTER_FULL_CHILD };
+
+/* the first halves, down to the leaf that is due (S.leaf, 0: none); false: the driver's advance ended here (a delayed range
+ * handed out, nothing left to advance) and there are no second halves to go through */
+BF_FN bool adv_pre(BfLane& X, BfAdvSt& S, uint32_t d)
 {
+	S.d = d; S.leaf = 0; S.seed = 0; S.full = 0; S.old = 0; S.p2 = 0; S.precost1 = 0; S.after = BF_AFTER_NONE; S.p = 0; S.precost = 0;
 	/* cost_advance<0>, first half */
 	AW(d + CA_LAST) = 0;
 	const uint32_t actSz = AW(d + CA_NACT);
@@ -1442,19 +1448,18 @@ BF_FN void bf_advance_top(BfLane& X, uint32_t d)
 		dr_set(X, d, BF_F_FOUND, true);
 		if (actSz > 0) { const uint32_t a0 = dr_mincost(X, AW(AW(d + CA_ACT))); if (a0 > dr_mincost(X, d)) dr_set_mincost(X, d, a0); }
 		else dr_set(X, d, BF_F_DONE, true);
-		return;
+		return false;
 	}
-	if (cost_mate_eliminated<0>(X, d) || actSz == 0) { AW(d + CA_NACT) = 0; dr_set(X, d, BF_F_DONE, true); return; }
+	if (cost_mate_eliminated<0>(X, d) || actSz == 0) { AW(d + CA_NACT) = 0; dr_set(X, d, BF_F_DONE, true); return false; }
 	const uint32_t p = AW(AW(d + CA_ACT));
-	const uint32_t precost = dr_mincost(X, p);
-	uint32_t leaf = 0, seed = 0, full = 0, old = 0, p2 = 0, precost1 = 0;
-	enum { NONE, SEED_BRANCH, FULL_BRANCH, FULL_CHILD };
-	uint32_t after = NONE;                                 /* which second halves are due once the leaf has been advanced */
+	S.p = p;
+	S.precost = dr_mincost(X, p);
 	if (!dr_found(X, p)) {
-		if (dr_kind(X, p) != BF_SEEDED) leaf = p;          /* child_advance<0>: a leaf */
+		if (dr_kind(X, p) != BF_SEEDED) S.leaf = p;          /* child_advance<0>: a leaf */
 		else {
 			/* seeded_advance(p), first half */
-			seed = AW(p + SD_SEED); full = AW(p + SD_FULL);
+			const uint32_t seed = AW(p + SD_SEED), full = AW(p + SD_FULL);
+			S.seed = seed; S.full = full;
 			bool back = false;
 			if (dr_done(X, seed) && dr_done(X, full) && !dr_found(X, seed) && !dr_found(X, full)) { dr_set(X, p, BF_F_DONE, true); back = true; }
 			if (!back && dr_done(X, seed) && !dr_found(X, seed)) {
@@ -1467,11 +1472,11 @@ BF_FN void bf_advance_top(BfLane& X, uint32_t d)
 			}
 			if (!back) {
 				if (dr_mincost(X, full) > dr_mincost(X, seed)) {
-					after = SEED_BRANCH;
-					if (!dr_found(X, seed)) leaf = seed;
+					S.after = BF_AFTER_SEED_BRANCH;
+					if (!dr_found(X, seed)) S.leaf = seed;
 				} else {
-					after = FULL_BRANCH;
-					old = dr_mincost(X, full);
+					S.after = BF_AFTER_FULL_BRANCH;
+					S.old = dr_mincost(X, full);
 					if (!dr_found(X, full)) {
 						/* cost_advance<1>(full), first half (no mates to eliminate below the aligner's driver) */
 						AW(full + CA_LAST) = 0;
@@ -1483,23 +1488,33 @@ BF_FN void bf_advance_top(BfLane& X, uint32_t d)
 							else dr_set(X, full, BF_F_DONE, true);
 						} else if (actSz1 == 0) { AW(full + CA_NACT) = 0; dr_set(X, full, BF_F_DONE, true); }
 						else {
-							after = FULL_CHILD;
-							p2 = AW(AW(full + CA_ACT));
-							precost1 = dr_mincost(X, p2);
-							if (!dr_found(X, p2)) leaf = p2;       /* child_advance<1>: always a leaf */
+							S.after = BF_AFTER_FULL_CHILD;
+							S.p2 = AW(AW(full + CA_ACT));
+							S.precost1 = dr_mincost(X, S.p2);
+							if (!dr_found(X, S.p2)) S.leaf = S.p2;       /* child_advance<1>: always a leaf */
 						}
 					}
 				}
 			}
 		}
 	}
-	/* the one place */
-	if (leaf) leaf_advance(X, leaf);
-	/* second halves, innermost first */
-	if (after == FULL_CHILD) { cost_advance_post<1>(X, full, p2, precost1); after = FULL_BRANCH; }
-	if (after == FULL_BRANCH) seeded_post_full(X, p, seed, full, old);
-	else if (after == SEED_BRANCH) seeded_post_seed(X, p, seed, full);
-	cost_advance_post<0>(X, d, p, precost);
+	return true;
+}
+/* the second halves, innermost first */
+BF_FN void adv_post(BfLane& X, BfAdvSt& S)
+{
+	uint32_t after = S.after;
+	if (after == BF_AFTER_FULL_CHILD) { cost_advance_post<1>(X, S.full, S.p2, S.precost1); after = BF_AFTER_FULL_BRANCH; }
+	if (after == BF_AFTER_FULL_BRANCH) seeded_post_full(X, S.p, S.seed, S.full, S.old);
+	else if (after == BF_AFTER_SEED_BRANCH) seeded_post_seed(X, S.p, S.seed, S.full);
+	cost_advance_post<0>(X, S.d, S.p, S.precost);
+}
+BF_FN void bf_advance_top(BfLane& X, uint32_t d)
+{
+	BfAdvSt S;
+	if (!adv_pre(X, S, d)) return;
+	if (S.leaf) leaf_advance(X, S.leaf);                  /* the one place */
+	adv_post(X, S);
 }
 
 /* the static part of the tree (Unpaired*Factory::create()) */
@@ -1582,18 +1597,6 @@ BF_FN void ch_row_set(BfLane& X, BfChase& c, uint32_t row)
 	if ((row & ix.offMask) == row) { c.cOff = BT_GP(const uint32_t, ix.offs)[row >> ix.offRate]; c.cDone = 1; X.c_offs++; return; }
 	c.cDone = 0; c.cJumps = 0; c.cOff = BT_OFF_MASK;
 }
-BF_FN void ch_row_advance(BfLane& X, BfChase& c)
-{
-	const BtIndexDev& ix = X.ix[c.mirror];
-	while (!c.cDone) {
-		uint32_t lf[4], L;
-		bt_rank4(ix, c.cRow, lf, &L);
-		c.cRow = lf[L];
-		c.cJumps++; X.c_chase++;
-		if (c.cRow == ix.zOff) { c.cOff = c.cJumps; c.cDone = 1; }
-		else if ((c.cRow & ix.offMask) == c.cRow) { c.cOff = BT_GP(const uint32_t, ix.offs)[c.cRow >> ix.offRate] + c.cJumps; c.cDone = 1; X.c_offs++; }
-	}
-}
 BF_FN void ch_row_off(BfLane& X, BfChase& c)
 {
 	uint32_t tidx = BT_OFF_MASK, toff = BT_OFF_MASK;
@@ -1622,9 +1625,10 @@ BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uin
 	ch_set_row(X, c, c.irow);
 	BF_PADD(BP_CHASE, t_chase);
 }
-BF_FN void ch_advance(BfLane& X, BfChase& c)
+/* one row of the walk resolved, or one LF step of it: RangeChaser::advance (range_chaser.h:150-209) a piece at a time --
+ * ch_advance below is this in a loop, the wavefront automaton takes a piece per round */
+BF_FN void ch_advance_piece(BfLane& X, BfChase& c)
 {
-	BF_PT0(t_chase);
 	c.tidx = BT_OFF_MASK;
 	if (c.cDone) {
 		c.row++;
@@ -1632,9 +1636,22 @@ BF_FN void ch_advance(BfLane& X, BfChase& c)
 		if (c.row == c.irow) c.done = 1;
 		else ch_set_row(X, c, c.row);
 	} else {
-		ch_row_advance(X, c);
+		/* RowChaser::advance: one LF step */
+		const BtIndexDev& ix = X.ix[c.mirror];
+		uint32_t lf[4], L;
+		bt_rank4(ix, c.cRow, lf, &L);
+		c.cRow = lf[L];
+		c.cJumps++; X.c_chase++;
+		if (c.cRow == ix.zOff) { c.cOff = c.cJumps; c.cDone = 1; }
+		else if ((c.cRow & ix.offMask) == c.cRow) { c.cOff = BT_GP(const uint32_t, ix.offs)[c.cRow >> ix.offRate] + c.cJumps; c.cDone = 1; X.c_offs++; }
 		if (c.cDone) ch_row_off(X, c);
 	}
+}
+BF_FN void ch_advance(BfLane& X, BfChase& c)
+{
+	BF_PT0(t_chase);
+	const bool walking = !c.cDone;
+	do ch_advance_piece(X, c); while (walking && !c.cDone);
 	BF_PADD(BP_CHASE, t_chase);
 }
 
