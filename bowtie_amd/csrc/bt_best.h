@@ -2235,5 +2235,179 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 #endif
 
 
+/* ---- the wavefront automaton ----------------------------------------------------------------------------------------
+ * bf_run_read / bf_run_pair above run one read from start to finish, and a wavefront that runs 64 of them side by side
+ * spends its time where a few lanes are: in round 4's section profile (profiles/r4/fourth_call_best_sections.txt) a pass
+ * over the streak loop served 6 of the 64 lanes on e_coli and 3 at hg19 scale, a pass over the SA walk 2 -- every loop's
+ * trip count is some lane's, and a read's turns are the slowest read's.  Here the same pieces (la_*, adv_*,
+ * ch_advance_piece, the runners' turns) are states of ONE loop per wavefront (bt_best_kernels.hip):
+ *   * a HOT round takes every lane that is extending a branch or walking the suffix array one step on -- the front's
+ *     record, one query position (its rank blocks fetched at one place in the code for all lanes), the end of a streak
+ *     (curtail, split, queue), one LF step of a walk -- whichever leaf of whichever read the lane is on;
+ *   * lanes that need anything else (a driver's second halves, the runner's turn -- reporting, the mate's window --, the
+ *     next driver's first halves, a new read) wait until enough of them do, and a COLD sweep takes them through those
+ *     states together; a lane takes its next read there, while the other lanes are wherever they are.
+ * The statements a read goes through, and their order, are those of bf_run_read / bf_run_pair (which remain: the host
+ * build's reference for this loop, tests/emu, and PairedBWAlignerV1's runner, which is not taken apart). */
+enum { BA_TAKE = 0, BA_IDLE, BA_END, BA_LEAF_EXIT, BA_POST, BA_RUN, BA_PRE, BA_LEAF_ENTER,      /* cold */
+       BA_FRONT, BA_STEP, BA_SEND, BA_CHASE };                                                 /* hot */
+#define BA_IS_HOT(ph) ((ph) >= BA_FRONT)
+#define BA_IS_PENDING(ph) ((ph) >= BA_LEAF_EXIT && (ph) <= BA_LEAF_ENTER)     /* cold, and not waiting for a read */
+
+struct BfAuto {
+	uint32_t phase;
+	uint32_t kind;                /* 1 bf_run_read, 2 bf_run_pair */
+	uint32_t live;                /* the loop is to be gone through (the read was long enough, the tree fitted) */
+	uint32_t afterAdv;            /* the runner's turn goes on behind its BF_ADVANCE_TOP */
+	bool done, chase;
+	uint32_t drv, pairsFw, pairsRc, mmBuf, attempts;
+	uint32_t c0[9];               /* the lane's op counters when the read began (a read that overflows is not tallied) */
+	BfChase ch;
+	BfAdvSt adv;
+	BfLeafSt leaf;
+};
+
+/* bf_run_read / bf_run_pair down to their loops */
+BF_FN void bf_auto_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfAuto& S)
+{
+	BF_PT0(t_begin);
+	S.live = 0; S.done = true; S.chase = false; S.attempts = 0; S.afterAdv = 0;
+	S.c0[0] = X.c_lfex; S.c0[1] = X.c_lf2; S.c0[2] = X.c_lf1; S.c0[3] = X.c_chase; S.c0[4] = X.c_ftab;
+	S.c0[5] = X.c_offs; S.c0[6] = X.c_rst; S.c0[7] = X.c_same; S.c0[8] = X.c_frames;
+	bf_read_begin(X, B, rd);
+	if (X.R[0].len < 4u || (S.kind != 1u && X.R[1].len < 4u)) { X.status |= BT_STF_SKIPPED; return; }
+	S.live = 1;
+	bf_chase_init(S.ch);
+	S.drv = bf_build_tree(X);
+	if (S.kind == 1u) {
+		if (!X.ovf) { cost_set_query<0>(X, S.drv); S.done = dr_done(X, S.drv); }
+	} else {
+		const uint32_t maxLen = X.R[0].len > X.R[1].len ? X.R[0].len : X.R[1].len;
+		S.pairsFw = bf_alloc(X, 3); S.pairsRc = bf_alloc(X, 3); S.mmBuf = bf_alloc(X, maxLen);
+		if (!X.ovf) {
+			AW(S.pairsFw) = AW(S.pairsFw + 1u) = AW(S.pairsFw + 2u) = 0; AW(S.pairsRc) = AW(S.pairsRc + 1u) = AW(S.pairsRc + 2u) = 0;
+			cost_set_query<0>(X, S.drv);
+			S.done = false;
+		}
+	}
+	BF_PADD(BP_BEGIN, t_begin);
+}
+BF_FN void bf_auto_end(BfLane& X, const BtBatchDev& B, BfAuto& S)
+{
+	bf_read_end(X, B, S.kind == 1u ? 1u : 2u);
+	if (X.status & BT_STF_OVERFLOW) {
+		X.c_lfex = S.c0[0]; X.c_lf2 = S.c0[1]; X.c_lf1 = S.c0[2]; X.c_chase = S.c0[3]; X.c_ftab = S.c0[4];
+		X.c_offs = S.c0[5]; X.c_rst = S.c0[6]; X.c_same = S.c0[7]; X.c_frames = S.c0[8];
+	}
+}
+
+/* the turns of bf_run_read's / bf_run_pair's loop, up to the one that needs the driver advanced (-> BA_PRE; the turn goes
+ * on behind the advance: afterAdv), a piece of the SA walk (-> BA_CHASE) or nothing any more (-> BA_END) */
+BF_FN void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
+{
+	BfChase& ch = S.ch;
+	const uint32_t drv = S.drv;
+	if (!S.live) { S.phase = BA_END; return; }
+	if (S.kind == 1u) {
+		if (S.afterAdv) { S.afterAdv = 0; if (dr_done(X, drv) && !dr_found(X, drv) && !S.chase) S.done = true; }
+		for (;;) {
+			if (S.done || X.ovf) { S.phase = BA_END; return; }
+			if (S.chase) {
+				if (ch.tidx == BT_OFF_MASK && !ch.done) { S.phase = BA_CHASE; return; }
+				if (ch.tidx != BT_OFF_MASK) {
+					const uint32_t leaf = AW(drv + CA_LAST);
+					S.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+					                        !leaf_spec(X, leaf).mirror);
+					ch.tidx = BT_OFF_MASK;
+				} else {
+					S.chase = false;
+					dr_set(X, drv, BF_F_FOUND, false);
+					S.done = dr_done(X, drv);
+				}
+			}
+			if (!S.done && !S.chase) {
+				if (dr_found(X, drv)) {
+					const uint32_t leaf = AW(drv + CA_LAST);
+					const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
+					ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
+					if (ch.tidx != BT_OFF_MASK) {
+						S.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+						                        !leaf_spec(X, leaf).mirror);
+						ch.tidx = BT_OFF_MASK;
+					}
+					if (!ch.done && !bf_irrelevant(X, cost)) S.chase = true;
+					else dr_set(X, drv, BF_F_FOUND, false);
+				} else {
+					S.done = bf_irrelevant(X, dr_mincost(X, drv));
+					if (!S.done) { S.afterAdv = 1; S.phase = BA_PRE; return; }
+				}
+				if (dr_done(X, drv) && !dr_found(X, drv) && !S.chase) S.done = true;
+			}
+		}
+	}
+	/* bf_run_pair */
+	bool tail = S.afterAdv != 0;      /* behind the advance: the found check of the turn that asked for it */
+	S.afterAdv = 0;
+	for (;;) {
+		if (!tail) {
+			if (S.done || X.ovf) { S.phase = BA_END; return; }
+			if (S.chase) {
+				if (ch.tidx == BT_OFF_MASK && !ch.done) { S.phase = BA_CHASE; return; }
+				if (ch.tidx != BT_OFF_MASK) {
+					/* resolveOutstanding (aligner.h:1849-1871) */
+					const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, S.pairsFw, S.pairsRc, S.mmBuf);
+					if (++S.attempts > X.P->pairTries || ret) S.done = true;
+					ch.tidx = BT_OFF_MASK;
+				} else {
+					S.chase = false;
+					S.done = dr_done(X, drv);
+				}
+			}
+			if (S.done || S.chase) continue;
+			if (dr_done(X, drv)) { S.done = true; continue; }
+			S.done = bf_irrelevant(X, dr_mincost(X, drv));
+			if (!S.done) { S.afterAdv = 1; S.phase = BA_PRE; return; }
+		}
+		tail = false;
+		if (dr_found(X, drv)) {
+			S.chase = true;
+			dr_set(X, drv, BF_F_FOUND, false);
+			const uint32_t leaf = AW(drv + CA_LAST);
+			const BfSpec& sp = leaf_spec(X, leaf);
+			ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
+		}
+	}
+}
+
+/* one hot round of one lane; sendOk: streaks that have ended are finished this round (the wavefront's gate) */
+BF_FN void bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
+{
+	if (S.phase == BA_FRONT) { la_front(X, S.leaf); S.phase = BA_STEP; }
+	if (S.phase == BA_STEP) { if (!la_step(X, S.leaf)) S.phase = BA_SEND; }
+	if (S.phase == BA_SEND && sendOk) S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT;
+	if (S.phase == BA_CHASE) { ch_advance_piece(X, S.ch); if (S.ch.tidx != BT_OFF_MASK || S.ch.done) S.phase = BA_RUN; }
+}
+
+/* one pass of the cold sweep for one lane; takeOk: lanes that wait for a read take one (take() -> its number, or
+ * 0xffffffff when the batch has none left) */
+template <class Take>
+BF_FN void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk, Take take)
+{
+	if (S.phase == BA_END) { bf_auto_end(X, B, S); S.phase = BA_TAKE; }
+	if (S.phase == BA_TAKE && takeOk) {
+		const uint32_t rd = take();
+		if (rd == 0xffffffffu) S.phase = BA_IDLE;
+		else { bf_auto_begin(X, B, rd, S); S.phase = BA_RUN; }
+	}
+	if (S.phase == BA_LEAF_EXIT) { la_exit(X, S.leaf); S.phase = BA_POST; }
+	if (S.phase == BA_POST) { adv_post(X, S.adv); S.phase = BA_RUN; }
+	if (S.phase == BA_RUN) bf_auto_run(X, B, S);
+	if (S.phase == BA_PRE) {
+		if (!adv_pre(X, S.adv, S.drv)) S.phase = BA_RUN;             /* no second halves: the runner's turn goes on (next pass) */
+		else S.phase = S.adv.leaf ? BA_LEAF_ENTER : BA_POST;
+	}
+	if (S.phase == BA_LEAF_ENTER) S.phase = la_enter(X, S.leaf, S.adv.leaf) ? BA_FRONT : BA_POST;
+}
+
 #undef AW
 #endif /* BT_BEST_H_ */

@@ -30,25 +30,40 @@ __device__ unsigned long long bf_prof[3 * 16];      /* bt_best.h: cycles, passes
 #define BT_BEST_MIN_BLOCKS 4
 #endif
 #define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
-__global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
+/* what both kernels begin with: the batch's descriptors into LDS, the lane's record */
+#define BT_BEST_PROLOGUE \
+	__shared__ BfProgram PROG; \
+	__shared__ BtIndexDev IX[2]; \
+	__shared__ BtBatchDev BATCH; \
+	__shared__ BtRefDev REF; \
+	for (uint32_t i = threadIdx.x; i < sizeof(BfProgram) / 4; i += blockDim.x) ((uint32_t*)&PROG)[i] = ((const uint32_t*)A.prog)[i]; \
+	for (uint32_t i = threadIdx.x; i < 2 * sizeof(BtIndexDev) / 4; i += blockDim.x) ((uint32_t*)IX)[i] = ((const uint32_t*)A.ix)[i]; \
+	for (uint32_t i = threadIdx.x; i < sizeof(BtBatchDev) / 4; i += blockDim.x) ((uint32_t*)&BATCH)[i] = ((const uint32_t*)A.batch)[i]; \
+	if (A.ref) for (uint32_t i = threadIdx.x; i < sizeof(BtRefDev) / 4; i += blockDim.x) ((uint32_t*)&REF)[i] = ((const uint32_t*)A.ref)[i]; \
+	__syncthreads(); \
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; \
+	BfLane X; \
+	__builtin_memset(&X, 0, sizeof(X)); \
+	X.A = (BF_G uint32_t*)(A.arenas + (uint64_t)g * A.arenaWords); \
+	X.cap = A.arenaWords; \
+	X.ix = IX; X.P = &PROG; X.ref = &REF; \
+	const bool paired = PROG.paired != 0; \
+	const uint32_t n = A.workList ? (*A.workCount < A.workCap ? *A.workCount : A.workCap) : BATCH.n_reads
+#define BT_BEST_EPILOGUE \
+	if (A.counts) { \
+		/* op counters (bt_op_counts order: lfex lf2 lf1 chase ftab offs rstarts frames lane_iters same_pair) */ \
+		atomicAdd(&A.counts[CN_LFEX], (unsigned long long)X.c_lfex); atomicAdd(&A.counts[CN_LF2], (unsigned long long)X.c_lf2); \
+		atomicAdd(&A.counts[CN_LF1], (unsigned long long)X.c_lf1); atomicAdd(&A.counts[CN_CHASE], (unsigned long long)X.c_chase); \
+		atomicAdd(&A.counts[CN_FTAB], (unsigned long long)X.c_ftab); atomicAdd(&A.counts[CN_OFFS], (unsigned long long)X.c_offs); \
+		atomicAdd(&A.counts[CN_RSTARTS], (unsigned long long)X.c_rst); atomicAdd(&A.counts[CN_FRAMES], (unsigned long long)X.c_frames); \
+		atomicAdd(&A.counts[CN_SAMEPAIR], (unsigned long long)X.c_same); \
+	}
+
+/* every lane its read from start to finish, reads handed out a wavefront at a time: PairedBWAlignerV1's runner, and the
+ * others' for comparison (BT_BEST_NESTED=1) */
+__global__ BT_BEST_BOUNDS void bt_best_nested_kernel(BtBestArgs A)
 {
-	__shared__ BfProgram PROG;
-	__shared__ BtIndexDev IX[2];
-	__shared__ BtBatchDev BATCH;
-	__shared__ BtRefDev REF;
-	for (uint32_t i = threadIdx.x; i < sizeof(BfProgram) / 4; i += blockDim.x) ((uint32_t*)&PROG)[i] = ((const uint32_t*)A.prog)[i];
-	for (uint32_t i = threadIdx.x; i < 2 * sizeof(BtIndexDev) / 4; i += blockDim.x) ((uint32_t*)IX)[i] = ((const uint32_t*)A.ix)[i];
-	for (uint32_t i = threadIdx.x; i < sizeof(BtBatchDev) / 4; i += blockDim.x) ((uint32_t*)&BATCH)[i] = ((const uint32_t*)A.batch)[i];
-	if (A.ref) for (uint32_t i = threadIdx.x; i < sizeof(BtRefDev) / 4; i += blockDim.x) ((uint32_t*)&REF)[i] = ((const uint32_t*)A.ref)[i];
-	__syncthreads();
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	BfLane X;
-	__builtin_memset(&X, 0, sizeof(X));
-	X.A = (BF_G uint32_t*)(A.arenas + (uint64_t)g * A.arenaWords);
-	X.cap = A.arenaWords;
-	X.ix = IX; X.P = &PROG; X.ref = &REF;
-	const bool paired = PROG.paired != 0;
-	const uint32_t n = A.workList ? (*A.workCount < A.workCap ? *A.workCount : A.workCap) : BATCH.n_reads;
+	BT_BEST_PROLOGUE;
 	for (;;) {
 		const uint32_t w = atomicAdd(A.nextRead, 1u);
 		if (w >= n) break;
@@ -68,14 +83,44 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 			X.c_frames = before.c_frames;
 		}
 	}
-	if (A.counts) {
-		/* op counters (bt_op_counts order: lfex lf2 lf1 chase ftab offs rstarts frames lane_iters same_pair) */
-		atomicAdd(&A.counts[CN_LFEX], (unsigned long long)X.c_lfex); atomicAdd(&A.counts[CN_LF2], (unsigned long long)X.c_lf2);
-		atomicAdd(&A.counts[CN_LF1], (unsigned long long)X.c_lf1); atomicAdd(&A.counts[CN_CHASE], (unsigned long long)X.c_chase);
-		atomicAdd(&A.counts[CN_FTAB], (unsigned long long)X.c_ftab); atomicAdd(&A.counts[CN_OFFS], (unsigned long long)X.c_offs);
-		atomicAdd(&A.counts[CN_RSTARTS], (unsigned long long)X.c_rst); atomicAdd(&A.counts[CN_FRAMES], (unsigned long long)X.c_frames);
-		atomicAdd(&A.counts[CN_SAMEPAIR], (unsigned long long)X.c_same);
+	BT_BEST_EPILOGUE
+}
+
+/* the wavefront automaton (bt_best.h): one loop per wavefront, hot rounds for the lanes that extend a branch or walk the
+ * suffix array, a cold sweep for the rest when enough of them wait for one; a lane takes its next read in the sweep */
+__global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
+{
+	BT_BEST_PROLOGUE;
+	BfAuto S;
+	__builtin_memset(&S, 0, sizeof(S));
+	S.phase = BA_TAKE;
+	S.kind = paired ? 2u : 1u;
+	const uint32_t coldMin = A.coldMin ? A.coldMin : 1u, takeMin = A.takeMin ? A.takeMin : 1u;
+	const uint32_t sendPeriod = A.sendPeriod ? A.sendPeriod : 1u, sendMin = A.sendMin ? A.sendMin : 1u;
+	uint32_t round = 0;
+	auto take = [&]() -> uint32_t {
+		const uint32_t w = atomicAdd(A.nextRead, 1u);
+		if (w >= n) return 0xffffffffu;
+		return A.workList ? A.workList[w] : w;
+	};
+	for (;;) {
+		const bool hot = BA_IS_HOT(S.phase);
+		const unsigned long long hotM = __ballot(hot), coldM = __ballot(!hot && S.phase != BA_IDLE);
+		if (!hotM && !coldM) break;
+		if (hotM && (uint32_t)__builtin_popcountll(coldM) < coldMin) {
+			round++;
+			const bool sendOk = (round % sendPeriod) == 0u || (uint32_t)__builtin_popcountll(__ballot(S.phase == BA_SEND)) >= sendMin;
+			if (hot) bf_auto_hot(X, S, sendOk);
+			continue;
+		}
+		/* the cold sweep: new reads when enough lanes wait for one, or when nothing else is left to do */
+		const unsigned long long takeM = __ballot(S.phase == BA_TAKE || S.phase == BA_END);
+		const bool takeOk = (uint32_t)__builtin_popcountll(takeM) >= takeMin || takeM == (hotM | coldM);
+		if (!hot) bf_auto_cold(X, BATCH, S, takeOk, take);
+		/* a second pass for the lanes the first one left in the middle (a driver's advance that ended without a leaf, a read just begun) */
+		if (__ballot(BA_IS_PENDING(S.phase)) != 0) { if (BA_IS_PENDING(S.phase)) bf_auto_cold(X, BATCH, S, false, take); }
 	}
+	BT_BEST_EPILOGUE
 }
 
 /* indices of the reads whose status carries `flag`, at most `cap` of them (*count keeps counting) */
@@ -114,6 +159,7 @@ extern "C" uint32_t bt_best_blocks_per_cu(void)
 
 extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)
 {
-	hipLaunchKernelGGL(bt_best_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
+	if (a->nested) hipLaunchKernelGGL(bt_best_nested_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
+	else hipLaunchKernelGGL(bt_best_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
 	return (int)hipGetLastError();
 }

@@ -66,6 +66,11 @@ struct BtBestArgs {
 	unsigned long long* counts;
 	/* second pass over the reads that outgrew their arena in the first: their ids and how many */
 	const uint32_t* workList; const uint32_t* workCount; uint32_t workCap;
+	/* which loop runs the reads (bt_best_kernels.hip): 1 = every lane its read from start to finish (PairedBWAlignerV1
+	 * always; BT_BEST_NESTED=1 for the rest), 0 = the wavefront automaton of bt_best.h, with its gates: a cold sweep when
+	 * coldMin lanes wait for one, new reads when takeMin lanes wait for one, ended streaks finished every sendPeriod-th
+	 * round or when sendMin lanes wait for it */
+	uint32_t nested, coldMin, takeMin, sendPeriod, sendMin;
 };
 
 extern "C" {

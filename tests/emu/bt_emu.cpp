@@ -192,8 +192,43 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 }
 
 
-/* The best-first engine (bowtie_amd/csrc/bt_best.h), one read after the other, each in an arena of
- * arenaWords 32-bit words. */
+/* bt_best_kernel's loop -- the wavefront automaton of bt_best.h -- for one "wavefront" of W lanes gone through side by side:
+ * the same decisions as the kernel's (hot round or cold sweep, new reads, the gate of the ended streaks), its ballots
+ * being counts over the lanes.  Checks what the loop has to get right on top of the pieces it calls: every read run
+ * exactly once, by some lane, each lane's pieces in the order bf_run_read / bf_run_pair go through them, and the loop ends. */
+static void emu_best_wave(std::vector<BfLane>& XS, const BtBatchDev& B, uint32_t n, uint32_t kind,
+                          uint32_t coldMin, uint32_t takeMin, uint32_t sendPeriod, uint32_t sendMin)
+{
+	const size_t W = XS.size();
+	std::vector<BfAuto> S(W);
+	for (auto& a : S) { memset(&a, 0, sizeof(a)); a.phase = BA_TAKE; a.kind = kind; }
+	uint32_t next = 0, round = 0, sweeps = 0;
+	auto take = [&]() -> uint32_t { return next < n ? next++ : 0xffffffffu; };
+	for (;;) {
+		uint32_t nHot = 0, nCold = 0, nTake = 0, nSend = 0;
+		for (size_t l = 0; l < W; l++) {
+			if (BA_IS_HOT(S[l].phase)) nHot++; else if (S[l].phase != BA_IDLE) nCold++;
+			if (S[l].phase == BA_TAKE || S[l].phase == BA_END) nTake++;
+			if (S[l].phase == BA_SEND) nSend++;
+		}
+		if (!nHot && !nCold) break;
+		if (nHot && nCold < coldMin) {
+			round++;
+			const bool sendOk = (round % sendPeriod) == 0u || nSend >= sendMin;
+			for (size_t l = 0; l < W; l++) if (BA_IS_HOT(S[l].phase)) bf_auto_hot(XS[l], S[l], sendOk);
+			continue;
+		}
+		const bool takeOk = nTake >= takeMin || nTake == nHot + nCold;
+		for (size_t l = 0; l < W; l++) if (!BA_IS_HOT(S[l].phase)) bf_auto_cold(XS[l], B, S[l], takeOk, take);
+		for (size_t l = 0; l < W; l++) if (BA_IS_PENDING(S[l].phase)) bf_auto_cold(XS[l], B, S[l], false, take);
+		sweeps++;
+	}
+	if (getenv("BT_EMU_VERBOSE")) fprintf(stderr, "[emu] automaton: %u reads, %zu lanes, %u hot rounds, %u cold sweeps\n", n, W, round, sweeps);
+}
+static uint32_t emu_env_u32(const char* name, uint32_t dflt) { const char* v = getenv(name); return v && *v ? (uint32_t)strtoul(v, nullptr, 0) : dflt; }
+
+/* The best-first engine (bowtie_amd/csrc/bt_best.h): the kernel's loop with 24 lanes side by side, each in an arena of
+ * arenaWords 32-bit words (BT_EMU_BEST_NESTED=1: one read after the other by bf_run_read, as bt_best_nested_kernel does). */
 static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
                         bt_op_counts* counts, uint32_t arenaWords)
 {
@@ -208,11 +243,28 @@ static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, 
 	B.hits = (BtHitRec*)out->hits; B.hit_cap = out->hit_cap; B.n_hits = out->n_hits; B.status = out->status;
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
-	std::vector<uint32_t> arena(arenaWords);
 	BfLane X;
-	memset(&X, 0, sizeof(X));
-	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
-	for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
+	if (emu_env_u32("BT_EMU_BEST_NESTED", 0)) {
+		std::vector<uint32_t> arena(arenaWords);
+		memset(&X, 0, sizeof(X));
+		X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P;
+		for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
+	} else {
+		/* arenas from calloc: untouched pages cost nothing */
+		const size_t W = in->n_reads < 24u ? (in->n_reads ? in->n_reads : 1u) : 24u;
+		uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
+		if (!arenas) return BT_ERR_DEVICE;
+		std::vector<BfLane> XS(W);
+		for (size_t l = 0; l < W; l++) { memset(&XS[l], 0, sizeof(BfLane)); XS[l].A = arenas + l * (size_t)arenaWords; XS[l].cap = arenaWords; XS[l].ix = e->d; XS[l].P = &P; }
+		emu_best_wave(XS, B, in->n_reads, 1u, emu_env_u32("BT_BEST_COLD_MIN", 6), emu_env_u32("BT_BEST_TAKE_MIN", 5),
+		              emu_env_u32("BT_BEST_SEND_PERIOD", 3), emu_env_u32("BT_BEST_SEND_MIN", 4));
+		X = XS[0];
+		for (size_t l = 1; l < W; l++) {
+			X.c_lfex += XS[l].c_lfex; X.c_lf2 += XS[l].c_lf2; X.c_lf1 += XS[l].c_lf1; X.c_chase += XS[l].c_chase; X.c_ftab += XS[l].c_ftab;
+			X.c_offs += XS[l].c_offs; X.c_rst += XS[l].c_rst; X.c_same += XS[l].c_same; X.c_frames += XS[l].c_frames;
+		}
+		free(arenas);
+	}
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;
@@ -248,11 +300,27 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool_cap;
 	uint32_t mmUsed = 0; B.mm_pool_used = &mmUsed;
 	if (arenaWords < 256u) arenaWords = 1u << 22;
-	std::vector<uint32_t> arena(arenaWords);
 	BfLane X;
-	memset(&X, 0, sizeof(X));
-	X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
-	for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
+	if (BF_IS_V1(P) || emu_env_u32("BT_EMU_BEST_NESTED", 0)) {
+		std::vector<uint32_t> arena(arenaWords);
+		memset(&X, 0, sizeof(X));
+		X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
+		for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
+	} else {
+		const size_t W = in1->n_reads < 24u ? (in1->n_reads ? in1->n_reads : 1u) : 24u;
+		uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
+		if (!arenas) return BT_ERR_DEVICE;
+		std::vector<BfLane> XS(W);
+		for (size_t l = 0; l < W; l++) { memset(&XS[l], 0, sizeof(BfLane)); XS[l].A = arenas + l * (size_t)arenaWords; XS[l].cap = arenaWords; XS[l].ix = e->d; XS[l].P = &P; XS[l].ref = &e->refd; }
+		emu_best_wave(XS, B, in1->n_reads, 2u, emu_env_u32("BT_BEST_COLD_MIN", 6), emu_env_u32("BT_BEST_TAKE_MIN", 5),
+		              emu_env_u32("BT_BEST_SEND_PERIOD", 3), emu_env_u32("BT_BEST_SEND_MIN", 4));
+		X = XS[0];
+		for (size_t l = 1; l < W; l++) {
+			X.c_lfex += XS[l].c_lfex; X.c_lf2 += XS[l].c_lf2; X.c_lf1 += XS[l].c_lf1; X.c_chase += XS[l].c_chase; X.c_ftab += XS[l].c_ftab;
+			X.c_offs += XS[l].c_offs; X.c_rst += XS[l].c_rst; X.c_same += XS[l].c_same; X.c_frames += XS[l].c_frames;
+		}
+		free(arenas);
+	}
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
 	if (counts) {
 		counts->lfex = X.c_lfex; counts->lf2 = X.c_lf2; counts->lf1 = X.c_lf1; counts->chase = X.c_chase;

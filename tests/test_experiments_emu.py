@@ -12,11 +12,17 @@ import pytest
 import common as T
 
 
-@pytest.mark.parametrize("defines, files", [
-    ("-DBF_CHECK=1", ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
-], ids=["shortcut_assumptions_hold"])
-def test_engine_assertions_hold_in_the_host_build(defines, files):
-    env = dict(os.environ, BT_EMU_DEFINES=defines)
+@pytest.mark.parametrize("defines, extra_env, files", [
+    ("-DBF_CHECK=1", {}, ["tests/test_automaton_emu.py", "tests/test_engine_fuzz.py", "-k", "best or paired or v3 or M3 or strata"]),
+    # the emulator runs the best-first engine through the kernel's loop (the wavefront automaton, 24 lanes side by side); this
+    # child runs it call by call instead (bf_run_read / bf_run_pair, what bt_best_nested_kernel does): both give the reference's answers
+    ("-DBF_CHECK=1", {"BT_EMU_BEST_NESTED": "1"}, ["tests/test_automaton_emu.py", "-k", "best or paired or v3 or M3 or strata"]),
+    # the automaton's gates at other settings: a cold sweep for every lane that wants one, and gates that are never met early
+    ("", {"BT_BEST_COLD_MIN": "1", "BT_BEST_TAKE_MIN": "1", "BT_BEST_SEND_PERIOD": "1"}, ["tests/test_automaton_emu.py", "-k", "best or paired"]),
+    ("", {"BT_BEST_COLD_MIN": "24", "BT_BEST_TAKE_MIN": "24", "BT_BEST_SEND_PERIOD": "7", "BT_BEST_SEND_MIN": "24"}, ["tests/test_automaton_emu.py", "-k", "best or paired"]),
+], ids=["shortcut_assumptions_hold", "call_by_call", "gates_open", "gates_late"])
+def test_engine_assertions_hold_in_the_host_build(defines, extra_env, files):
+    env = dict(os.environ, BT_EMU_DEFINES=defines, **extra_env)
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "not gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=T.ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
     tail = p.stdout.decode(errors="replace")[-1500:]
