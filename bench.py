@@ -352,6 +352,9 @@ def main():
                     help="weak: the workload's reads per GPU (default); strong: that many reads in total, sharded over the GPUs")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--iters-hist", action="store_true", help="print the per-read LF-round distribution (diagnostics)")
+    ap.add_argument("--env-sweep", default="",
+                    help="diagnostics: after the measurement, the same workload again (same process, index and reads resident) under each "
+                         "of these environments -- 'label:NAME=V,NAME=V;label2:...' -- e.g. the gates of bt_best_kernel; one rank only")
     ap.add_argument("--also", default="auto",
                     help="comma-separated workloads to run afterwards (2 steps each, own process, SAM diff against the reference) "
                          "and report under config.other_workloads; 'auto' = BASELINE configs 3 and 5 (big_v2_76, "
@@ -689,6 +692,36 @@ def main():
             out["cpu_baseline"] = cb
             out["config"]["reads_diffed_vs_reference"] = cb.get("reads_diffed_vs_reference")
             out["config"]["diff_mismatches"] = cb.get("diff_mismatches")
+        if args.env_sweep and world == 1:
+            # A/B of library settings that are read at launch time (BT_BEST_*): contexts of the main measurement closed first,
+            # so that every setting's contexts find the same free memory
+            ref_hits = int(last["set"]["n_hits"].to(torch.int64).sum().item())
+            for o in pipes:
+                o["al"].close()
+            out["env_sweep"] = []
+            for item in [x for x in args.env_sweep.split(";") if x]:
+                label, _, kvs = item.partition(":")
+                kv = dict(x.split("=", 1) for x in kvs.split(",") if x)
+                old_env = {k: os.environ.get(k) for k in kv}
+                os.environ.update(kv)
+                try:
+                    Ms = measure(n, max(1, min(args.steps, 2)), 1)
+                finally:
+                    for k, v in old_env.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                hs = int(Ms["last"]["set"]["n_hits"].to(torch.int64).sum().item())
+                rec = {"label": label, "env": kv, "reads_processed_per_s": n * mult * max(1, min(args.steps, 2)) / Ms["wall"],
+                       "kernel_ms_avg": sum(Ms["kernel_ms"]) / max(1, len(Ms["kernel_ms"])), "n_hits_sum_equal": hs == ref_hits}
+                out["env_sweep"].append(rec)
+                log("[bench] env-sweep %-22s %8.3f M reads/s  kernel %9.1f ms  same hit count: %s" %
+                    (label, rec["reads_processed_per_s"] / 1e6, rec["kernel_ms_avg"], rec["n_hits_sum_equal"]))
+                for o in Ms["pipes"]:
+                    o["al"].close()
+                del Ms
+                torch.cuda.empty_cache()
         also = args.also
         if also == "auto":
             also = "big_v2_76,big_pe_n1_best_50" if (world == 1 and args.workload == "big_n2_100" and not args.reads and not args.genome
