@@ -557,6 +557,8 @@ def main():
     log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
     M = measure(n, args.steps, args.warmup)
     wall, c, kernel_ms, flush_ms, last, pipes, carry_age = M["wall"], M["c"], M["kernel_ms"], M["flush_ms"], M["last"], M["pipes"], M["carry_age"]
+    log("[bench] main measurement: %.3f M reads/s on this rank, %.1f ms per step, kernel %.1f ms" %
+        (n * (2 if paired else 1) * args.steps / wall / 1e6, 1e3 * wall / args.steps, sum(kernel_ms) / max(1, len(kernel_ms))))
 
     verified = None
     if args.verify:

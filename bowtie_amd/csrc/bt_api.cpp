@@ -431,8 +431,10 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
 	A.workList = nullptr; A.workCount = nullptr; A.workCap = 0;
 	A.nested = (in2 && c->pol.pe_v1) || env_u32("BT_BEST_NESTED", 0) ? 1u : 0u;
+	/* the gates' defaults: scripts/best_wave_model.py's pick, then the GPU A/B of profiles/r4/ */
 	A.coldMin = env_u32("BT_BEST_COLD_MIN", 16); A.takeMin = env_u32("BT_BEST_TAKE_MIN", 16);
-	A.sendPeriod = env_u32("BT_BEST_SEND_PERIOD", 1); A.sendMin = env_u32("BT_BEST_SEND_MIN", 8);
+	A.sendPeriod = env_u32("BT_BEST_SEND_PERIOD", 4); A.sendMin = env_u32("BT_BEST_SEND_MIN", 24);
+	A.sweepTwice = env_u32("BT_BEST_SWEEP_TWICE", 0);
 	/* per-launch HIP events, as on the phase-program path (bt_ctx_span_ms / bt_ctx_launch_ms) */
 	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
 	hipEvent_t* ring = c->evRing[c->spanLaunches & 15u];

@@ -2380,12 +2380,15 @@ BF_FN void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 }
 
 /* one hot round of one lane; sendOk: streaks that have ended are finished this round (the wavefront's gate) */
-BF_FN void bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
+/* -> what the lane went through: 1 a step, 2 the end of a streak, 4 a piece of a walk (the host's wave model counts them) */
+BF_FN uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 {
+	uint32_t did = 0;
 	if (S.phase == BA_FRONT) { la_front(X, S.leaf); S.phase = BA_STEP; }
-	if (S.phase == BA_STEP) { if (!la_step(X, S.leaf)) S.phase = BA_SEND; }
-	if (S.phase == BA_SEND && sendOk) S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT;
-	if (S.phase == BA_CHASE) { ch_advance_piece(X, S.ch); if (S.ch.tidx != BT_OFF_MASK || S.ch.done) S.phase = BA_RUN; }
+	if (S.phase == BA_STEP) { did |= 1u; if (!la_step(X, S.leaf)) S.phase = BA_SEND; }
+	if (S.phase == BA_SEND && sendOk) { did |= 2u; S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT; }
+	if (S.phase == BA_CHASE) { did |= 4u; ch_advance_piece(X, S.ch); if (S.ch.tidx != BT_OFF_MASK || S.ch.done) S.phase = BA_RUN; }
+	return did;
 }
 
 /* one pass of the cold sweep for one lane; takeOk: lanes that wait for a read take one (take() -> its number, or

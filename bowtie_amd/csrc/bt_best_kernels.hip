@@ -107,18 +107,22 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 		const bool hot = BA_IS_HOT(S.phase);
 		const unsigned long long hotM = __ballot(hot), coldM = __ballot(!hot && S.phase != BA_IDLE);
 		if (!hotM && !coldM) break;
-		if (hotM && (uint32_t)__builtin_popcountll(coldM) < coldMin) {
-			round++;
-			const bool sendOk = (round % sendPeriod) == 0u || (uint32_t)__builtin_popcountll(__ballot(S.phase == BA_SEND)) >= sendMin;
-			if (hot) bf_auto_hot(X, S, sendOk);
-			continue;
-		}
-		/* the cold sweep: new reads when enough lanes wait for one, or when nothing else is left to do */
+		/* lanes that wait for a read take one when enough of them do, or when nothing else is left to do; a cold sweep is
+		 * due when enough lanes have something to do in it (lanes that wait for a read count only when they may take one:
+		 * a sweep that could do nothing for them must not keep the hot lanes from their rounds) */
 		const unsigned long long takeM = __ballot(S.phase == BA_TAKE || S.phase == BA_END);
 		const bool takeOk = (uint32_t)__builtin_popcountll(takeM) >= takeMin || takeM == (hotM | coldM);
+		const uint32_t nSweep = (uint32_t)__builtin_popcountll(takeOk ? coldM : (coldM & ~takeM));
+		if (hotM && nSweep < coldMin) {
+			round++;
+			const bool sendOk = (round % sendPeriod) == 0u || (uint32_t)__builtin_popcountll(__ballot(S.phase == BA_SEND)) >= sendMin;
+			if (hot) (void)bf_auto_hot(X, S, sendOk);
+			continue;
+		}
 		if (!hot) bf_auto_cold(X, BATCH, S, takeOk, take);
-		/* a second pass for the lanes the first one left in the middle (a driver's advance that ended without a leaf, a read just begun) */
-		if (__ballot(BA_IS_PENDING(S.phase)) != 0) { if (BA_IS_PENDING(S.phase)) bf_auto_cold(X, BATCH, S, false, take); }
+		/* the lanes the pass left in the middle (a driver's advance that ended without a leaf) go on in the next sweep -- or in a
+		 * second pass right away (sweepTwice), which the wave model prices at more than their waiting costs */
+		if (A.sweepTwice && __ballot(BA_IS_PENDING(S.phase)) != 0) { if (BA_IS_PENDING(S.phase)) bf_auto_cold(X, BATCH, S, false, take); }
 	}
 	BT_BEST_EPILOGUE
 }

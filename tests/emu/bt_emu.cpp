@@ -200,9 +200,12 @@ static void emu_best_wave(std::vector<BfLane>& XS, const BtBatchDev& B, uint32_t
                           uint32_t coldMin, uint32_t takeMin, uint32_t sendPeriod, uint32_t sendMin)
 {
 	const size_t W = XS.size();
+	const bool sweepTwice = getenv("BT_BEST_SWEEP_TWICE") && atoi(getenv("BT_BEST_SWEEP_TWICE")) != 0;
 	std::vector<BfAuto> S(W);
 	for (auto& a : S) { memset(&a, 0, sizeof(a)); a.phase = BA_TAKE; a.kind = kind; }
 	uint32_t next = 0, round = 0, sweeps = 0;
+	/* the wave model's tallies (BT_EMU_VERBOSE): rounds and lanes per piece */
+	unsigned long long stepR = 0, stepL = 0, sendR = 0, sendL = 0, chaseR = 0, chaseL = 0, sweepL = 0, sweep2 = 0, sweep2L = 0, takeS = 0, takeL = 0, idleL = 0;
 	auto take = [&]() -> uint32_t { return next < n ? next++ : 0xffffffffu; };
 	for (;;) {
 		uint32_t nHot = 0, nCold = 0, nTake = 0, nSend = 0;
@@ -212,18 +215,40 @@ static void emu_best_wave(std::vector<BfLane>& XS, const BtBatchDev& B, uint32_t
 			if (S[l].phase == BA_SEND) nSend++;
 		}
 		if (!nHot && !nCold) break;
-		if (nHot && nCold < coldMin) {
+		const bool takeOk = nTake >= takeMin || nTake == nHot + nCold;
+		const uint32_t nSweep = takeOk ? nCold : nCold - nTake;
+		if (nHot && nSweep < coldMin) {
 			round++;
 			const bool sendOk = (round % sendPeriod) == 0u || nSend >= sendMin;
-			for (size_t l = 0; l < W; l++) if (BA_IS_HOT(S[l].phase)) bf_auto_hot(XS[l], S[l], sendOk);
+			uint32_t a = 0, b = 0, c = 0;
+			for (size_t l = 0; l < W; l++) if (BA_IS_HOT(S[l].phase)) {
+				const uint32_t did = bf_auto_hot(XS[l], S[l], sendOk);
+				a += did & 1u; b += (did >> 1) & 1u; c += (did >> 2) & 1u;
+				if (!did) idleL++;
+			}
+			idleL += nCold;
+			if (a) { stepR++; stepL += a; } if (b) { sendR++; sendL += b; } if (c) { chaseR++; chaseL += c; }
 			continue;
 		}
-		const bool takeOk = nTake >= takeMin || nTake == nHot + nCold;
-		for (size_t l = 0; l < W; l++) if (!BA_IS_HOT(S[l].phase)) bf_auto_cold(XS[l], B, S[l], takeOk, take);
-		for (size_t l = 0; l < W; l++) if (BA_IS_PENDING(S[l].phase)) bf_auto_cold(XS[l], B, S[l], false, take);
+		uint32_t t = 0, k = 0;
+		for (size_t l = 0; l < W; l++) if (!BA_IS_HOT(S[l].phase)) {
+			const bool wasTake = S[l].phase == BA_TAKE || S[l].phase == BA_END;
+			if (S[l].phase != BA_IDLE && (takeOk || !wasTake)) k++;
+			bf_auto_cold(XS[l], B, S[l], takeOk, take);
+			if (wasTake && takeOk && S[l].phase != BA_IDLE && S[l].phase != BA_TAKE) t++;
+		}
+		sweepL += k;
+		if (t) { takeS++; takeL += t; }
+		k = 0;
+		if (sweepTwice) for (size_t l = 0; l < W; l++) if (BA_IS_PENDING(S[l].phase)) { bf_auto_cold(XS[l], B, S[l], false, take); k++; }
+		if (k) { sweep2++; sweep2L += k; }
 		sweeps++;
 	}
-	if (getenv("BT_EMU_VERBOSE")) fprintf(stderr, "[emu] automaton: %u reads, %zu lanes, %u hot rounds, %u cold sweeps\n", n, W, round, sweeps);
+	if (getenv("BT_EMU_VERBOSE"))
+		fprintf(stderr, "[emu] automaton: %u reads, %zu lanes, gates %u/%u/%u/%u: %u hot rounds (step %llu x %.1f lanes, send %llu x %.1f, chase %llu x %.1f; idle lane-rounds %llu), "
+		        "%u cold sweeps x %.1f lanes (second pass %llu x %.1f; reads taken in %llu x %.1f)\n", n, W, coldMin, takeMin, sendPeriod, sendMin, round,
+		        stepR, stepR ? (double)stepL / stepR : 0.0, sendR, sendR ? (double)sendL / sendR : 0.0, chaseR, chaseR ? (double)chaseL / chaseR : 0.0, idleL,
+		        sweeps, sweeps ? (double)sweepL / sweeps : 0.0, sweep2, sweep2 ? (double)sweep2L / sweep2 : 0.0, takeS, takeS ? (double)takeL / takeS : 0.0);
 }
 static uint32_t emu_env_u32(const char* name, uint32_t dflt) { const char* v = getenv(name); return v && *v ? (uint32_t)strtoul(v, nullptr, 0) : dflt; }
 
@@ -251,7 +276,7 @@ static int emu_run_best(void* p, const bt_policy* pol, const bt_read_batch* in, 
 		for (uint32_t rd = 0; rd < in->n_reads; rd++) bf_run_read(X, B, rd);
 	} else {
 		/* arenas from calloc: untouched pages cost nothing */
-		const size_t W = in->n_reads < 24u ? (in->n_reads ? in->n_reads : 1u) : 24u;
+		const size_t WL = emu_env_u32("BT_EMU_WAVE_LANES", 24), W = in->n_reads < WL ? (in->n_reads ? in->n_reads : 1u) : WL;
 		uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
 		if (!arenas) return BT_ERR_DEVICE;
 		std::vector<BfLane> XS(W);
@@ -307,7 +332,7 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 		X.A = arena.data(); X.cap = arenaWords; X.ix = e->d; X.P = &P; X.ref = &e->refd;
 		for (uint32_t rd = 0; rd < in1->n_reads; rd++) { if (BF_IS_V1(P)) bf_run_pair_v1(X, B, rd); else bf_run_pair(X, B, rd); }
 	} else {
-		const size_t W = in1->n_reads < 24u ? (in1->n_reads ? in1->n_reads : 1u) : 24u;
+		const size_t WL = emu_env_u32("BT_EMU_WAVE_LANES", 24), W = in1->n_reads < WL ? (in1->n_reads ? in1->n_reads : 1u) : WL;
 		uint32_t* arenas = (uint32_t*)calloc(W * (size_t)arenaWords + 1u, 4);
 		if (!arenas) return BT_ERR_DEVICE;
 		std::vector<BfLane> XS(W);
