@@ -430,7 +430,16 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
 	A.workList = nullptr; A.workCount = nullptr; A.workCap = 0;
-	A.nested = (in2 && c->pol.pe_v1) || env_u32("BT_BEST_NESTED", 0) ? 1u : 0u;
+	/* Which loop: the wavefront automaton shares the waits of a wavefront's lanes, the call-by-call kernel spends fewer
+	 * instructions per lane.  Measured (profiles/r4/sixth_call_automaton_AB.txt): on the hg19-scale index, where every rank
+	 * is an HBM latency, the automaton is 1.38x (pairs, BASELINE config 5) and 1.50x (single-end --best) as fast; on
+	 * e_coli, whose index sits in the L2 caches, 0.48x / 0.72x.  So: the automaton when the index does not fit the
+	 * Infinity Cache (256 MB; the rank blocks are half a byte per base), BT_BEST_NESTED=0/1 to say otherwise. */
+	{
+		const char* nv = getenv("BT_BEST_NESTED");
+		const bool small = (uint64_t)c->idx->dev[0].len < (512ull << 20);
+		A.nested = (in2 && c->pol.pe_v1) || (nv && *nv ? atoi(nv) != 0 : small) ? 1u : 0u;
+	}
 	/* the gates' defaults: scripts/best_wave_model.py's pick, then the GPU A/B of profiles/r4/ */
 	A.coldMin = env_u32("BT_BEST_COLD_MIN", 16); A.takeMin = env_u32("BT_BEST_TAKE_MIN", 16);
 	A.sendPeriod = env_u32("BT_BEST_SEND_PERIOD", 4); A.sendMin = env_u32("BT_BEST_SEND_MIN", 24);
@@ -441,7 +450,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	c->spanLaunches++;
 	HIPCHK(hipEventRecord(ring[0], c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
-	snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_best_kernel");
+	snprintf(c->last_kernel, sizeof(c->last_kernel), A.nested ? "bt_best_nested_kernel" : "bt_best_kernel");
 	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
 	if (!c->is_big && env_u32("BT_BEST_DEVICE_RETRY", 1)) {
 		/* reads that outgrew their arena: collected and searched again on the stream, 1024 lanes with 16 MB

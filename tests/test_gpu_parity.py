@@ -580,3 +580,44 @@ def test_gpu_bench_two_ranks_equal_one(tmp_path):
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong"
     assert j1["config"]["hit_counters_last_step"] == j2["config"]["hit_counters_last_step"]
     assert j1["config"]["hit_counters_last_step"]["aligned"] > 200000
+
+
+# ---- the wavefront automaton (bt_best_kernel) on the small indexes ------------------------------------------------------
+# The library picks the best-first loop by index size: on e_coli / multi the tests above run the call-by-call kernel
+# (bt_best_nested_kernel).  BT_BEST_NESTED=0 (read at every launch) puts the same inputs through the automaton.
+from best_modes import BEST_MODES
+
+
+@pytest.fixture
+def automaton(monkeypatch):
+    monkeypatch.setenv("BT_BEST_NESTED", "0")
+
+
+@pytest.mark.parametrize("run", [r for r in T.golden_runs() if r["mode"] in BEST_MODES], ids=lambda r: r["file"][:-7])
+def test_gpu_automaton_matches_reference_sam(run, gidx, automaton):
+    test_gpu_matches_reference_sam(run, gidx)
+
+
+@pytest.mark.parametrize("run", T.paired_runs(), ids=lambda r: r["file"][:-7])
+def test_gpu_automaton_paired_matches_reference_sam(run, gidx, automaton):
+    test_gpu_paired_matches_reference_sam(run, gidx)
+
+
+@pytest.mark.parametrize("mode", BEST_RAGGED)
+def test_gpu_automaton_best_first_vs_oracle_ragged(mode, gidx, automaton):
+    test_gpu_best_first_vs_oracle_ragged(mode, gidx)
+
+
+@pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500"])
+def test_gpu_automaton_paired_vs_oracle_counts(mode, gidx, automaton):
+    test_gpu_paired_vs_oracle_counts(mode, gidx)
+
+
+def test_gpu_automaton_large_batches(gidx, automaton):
+    test_gpu_best_first_large_batch_properties(gidx)
+    test_gpu_paired_config5_shape(gidx)
+
+
+def test_gpu_automaton_arena_overflow_retry(gidx, monkeypatch):
+    monkeypatch.setenv("BT_BEST_NESTED", "0")
+    test_gpu_best_first_arena_overflow_retry(gidx, monkeypatch)
