@@ -56,14 +56,17 @@ def gather_ceiling(index_kind: str):
         return None
 
 
-KERNEL_ROUND = 3       # bump when bt_kernels.hip / bt_core.h change: PMC profiles of older sources no longer describe the kernel
+# the round whose source a kernel's PMC profile must have been taken on to describe it still: bump a kernel's entry when its
+# source changes.  bt_search_kernel: round 3 (round 4 changed nothing in it: its device code differs from the measured one by
+# the size of the argument block only); the best-first kernels: round 4 (the automaton, the organised engine)
+KERNEL_ROUNDS = {"bt_search_kernel": 3, "bt_best_kernel": 4, "bt_best_nested_kernel": 4}
 
 
 def measured_traffic(kernel: str, workload: str):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for e in json.load(f)["entries"]:
-                if e["kernel"] == kernel and e["workload"] == workload and e.get("kernel_round") == KERNEL_ROUND:
+                if e["kernel"] == kernel and e["workload"] == workload and e.get("kernel_round") == KERNEL_ROUNDS.get(kernel.split("<")[0]):
                     return e
     except (OSError, ValueError, KeyError):
         pass
