@@ -485,6 +485,9 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		BtBestArgs A2 = A;
 		A2.arenas = ix->retryArenas; A2.arenaWords = bigWords; A2.nextRead = c->d_cursor + 3;
 		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2; A2.workCap = c->retryCap;
+		/* the second pass has a few hundred reads for its thousand lanes -- a lane or two per wavefront, nothing to share --
+		 * and lasts as long as its slowest read: each lane on its own, call by call */
+		A2.nested = env_u32("BT_BEST_RETRY_NESTED", 1) ? 1u : A.nested;
 		if (bt_launch_best(&A2, bigLanes / BT_BLOCK, c->stream) != 0) return BT_ERR_DEVICE;
 		HIPCHK(hipEventRecord(ix->retryFree, c->stream));
 	}
