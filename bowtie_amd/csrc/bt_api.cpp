@@ -429,7 +429,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 	if (nBlocks > lanes / BT_BLOCK) nBlocks = lanes / BT_BLOCK;
-	A.workList = nullptr; A.workCount = nullptr; A.workCap = 0;
+	A.workList = nullptr; A.workCount = nullptr; A.workCap = 0; A.laneStride = 1;
 	/* Which loop: the wavefront automaton shares the waits of a wavefront's lanes, the call-by-call kernel spends fewer
 	 * instructions per lane.  Measured (profiles/r4/sixth_call_automaton_AB.txt): on the hg19-scale index, where every rank
 	 * is an HBM latency, the automaton is 1.38x (pairs, BASELINE config 5) and 1.50x (single-end --best) as fast; on
@@ -485,10 +485,17 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		BtBestArgs A2 = A;
 		A2.arenas = ix->retryArenas; A2.arenaWords = bigWords; A2.nextRead = c->d_cursor + 3;
 		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2; A2.workCap = c->retryCap;
-		/* the second pass has a few hundred reads for its thousand lanes -- a lane or two per wavefront, nothing to share --
-		 * and lasts as long as its slowest read: each lane on its own, call by call */
-		A2.nested = env_u32("BT_BEST_RETRY_NESTED", 1) ? 1u : A.nested;
-		if (bt_launch_best(&A2, bigLanes / BT_BLOCK, c->stream) != 0) return BT_ERR_DEVICE;
+		/* The second pass lasts as long as its slowest read, and that read is the slower the more of its kind share its
+		 * wavefront: the pass's few hundred reads used to fill five wavefronts (a wavefront's 64 lanes take consecutive
+		 * items).  Only every 16th lane takes reads in this launch -- the same thousand arenas, over 256 wavefronts of four.
+		 * (Measured before that, profiles/r4/eighth_call_second_pass.txt: 64 to a wavefront the call-by-call kernel needs
+		 * 3.4 s for config 5's 316 pairs, the automaton 2.0 s.) */
+		uint32_t stride = env_u32("BT_BEST_RETRY_STRIDE", 16);
+		if (stride < 1u) stride = 1u;
+		if (stride > 64u) stride = 64u;
+		A2.laneStride = stride;
+		A2.nested = env_u32("BT_BEST_RETRY_NESTED", 0) ? 1u : A.nested;
+		if (bt_launch_best(&A2, bigLanes / BT_BLOCK * stride, c->stream) != 0) return BT_ERR_DEVICE;
 		HIPCHK(hipEventRecord(ix->retryFree, c->stream));
 	}
 	HIPCHK(hipEventRecord(ring[1], c->stream));

@@ -44,7 +44,9 @@ __device__ unsigned long long bf_prof[3 * 16];      /* bt_best.h: cycles, passes
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; \
 	BfLane X; \
 	__builtin_memset(&X, 0, sizeof(X)); \
-	X.A = (BF_G uint32_t*)(A.arenas + (uint64_t)g * A.arenaWords); \
+	const uint32_t laneStride = A.laneStride > 1u ? A.laneStride : 1u; \
+	const bool laneOn = (threadIdx.x % laneStride) == 0u; \
+	X.A = (BF_G uint32_t*)(A.arenas + (uint64_t)(g / laneStride) * A.arenaWords); \
 	X.cap = A.arenaWords; \
 	X.ix = IX; X.P = &PROG; X.ref = &REF; \
 	const bool paired = PROG.paired != 0; \
@@ -64,7 +66,7 @@ __device__ unsigned long long bf_prof[3 * 16];      /* bt_best.h: cycles, passes
 __global__ BT_BEST_BOUNDS void bt_best_nested_kernel(BtBestArgs A)
 {
 	BT_BEST_PROLOGUE;
-	for (;;) {
+	if (laneOn) for (;;) {
 		const uint32_t w = atomicAdd(A.nextRead, 1u);
 		if (w >= n) break;
 		const uint32_t rd = A.workList ? A.workList[w] : w;
@@ -93,7 +95,7 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 	BT_BEST_PROLOGUE;
 	BfAuto S;
 	__builtin_memset(&S, 0, sizeof(S));
-	S.phase = BA_TAKE;
+	S.phase = laneOn ? BA_TAKE : BA_IDLE;
 	S.kind = paired ? 2u : 1u;
 	const uint32_t coldMin = A.coldMin ? A.coldMin : 1u, takeMin = A.takeMin ? A.takeMin : 1u;
 	const uint32_t sendPeriod = A.sendPeriod ? A.sendPeriod : 1u, sendMin = A.sendMin ? A.sendMin : 1u;

@@ -70,6 +70,8 @@ struct BtBestArgs {
 	 * always; BT_BEST_NESTED=1 for the rest), 0 = the wavefront automaton of bt_best.h, with its gates: a cold sweep when
 	 * coldMin lanes wait for one, new reads when takeMin lanes wait for one, ended streaks finished every sendPeriod-th
 	 * round or when sendMin lanes wait for it */
+	uint32_t laneStride;   /* > 1: only every laneStride-th lane of a block takes reads, arena g / laneStride (the second pass: its few
+	                        * hundred heavy reads over many wavefronts instead of 64 to a wavefront) */
 	uint32_t nested, coldMin, takeMin, sendPeriod, sendMin, sweepTwice;   /* sweepTwice: a second pass of a sweep for the lanes its first left in the middle */
 };
 
