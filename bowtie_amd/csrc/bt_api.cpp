@@ -487,10 +487,12 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		A2.workList = c->retryList; A2.workCount = c->d_cursor + 2; A2.workCap = c->retryCap;
 		/* The second pass lasts as long as its slowest read, and that read is the slower the more of its kind share its
 		 * wavefront: the pass's few hundred reads used to fill five wavefronts (a wavefront's 64 lanes take consecutive
-		 * items).  Only every 16th lane takes reads in this launch -- the same thousand arenas, over 256 wavefronts of four.
-		 * (Measured before that, profiles/r4/eighth_call_second_pass.txt: 64 to a wavefront the call-by-call kernel needs
-		 * 3.4 s for config 5's 316 pairs, the automaton 2.0 s.) */
-		uint32_t stride = env_u32("BT_BEST_RETRY_STRIDE", 16);
+		 * items), and rocprofv3 showed the pass to be half of config 5's step.  Only one lane of a wavefront takes reads in
+		 * this launch -- the same thousand arenas, a wavefront each.  Measured on config 5's 316 pairs (profiles/r4/
+		 * eighth_call_second_pass.txt, ninth_call_second_pass_stride.txt; step = main launch + this pass): 64 to a
+		 * wavefront 4.2 s per step (call by call: 5.5 s), every 16th lane 2.8 s (call by call: 2.5 s), one per wavefront
+		 * 2.45 s = 10.2 M reads/s against 5.9 M. */
+		uint32_t stride = env_u32("BT_BEST_RETRY_STRIDE", 64);
 		if (stride < 1u) stride = 1u;
 		if (stride > 64u) stride = 64u;
 		A2.laneStride = stride;
