@@ -83,3 +83,17 @@ def test_gpu_paired_sam_equals_reference_on_100mbp_index(scale):
     got = bench._gpu_sam(scale["idx"], pol, [b1, b2]).split(b"\n")
     bad = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
     assert len(got) == len(want) and not bad, (len(got), len(want), got[bad[0]] if bad else None, want[bad[0]] if bad else None)
+
+
+# The library runs the best-first engine call by call on an index of this size (bt_api.cpp picks the loop by index size);
+# BT_BEST_NESTED=0 puts the same inputs through the wavefront automaton (bt_best_kernel), against the live reference too.
+def test_gpu_best_sam_equals_reference_on_100mbp_index_through_the_automaton(scale, monkeypatch):
+    monkeypatch.setenv("BT_BEST_NESTED", "0")
+    test_gpu_sam_equals_reference_on_100mbp_index(
+        "n2_best_strata_m3_automaton", dict(mode="n", mms=2, best=True, strata=True, mhits=3, max_bts=800),
+        ["-n", "2", "--best", "--strata", "-m", "3"], 50, 20000, scale)
+
+
+def test_gpu_paired_sam_equals_reference_on_100mbp_index_through_the_automaton(scale, monkeypatch):
+    monkeypatch.setenv("BT_BEST_NESTED", "0")
+    test_gpu_paired_sam_equals_reference_on_100mbp_index(scale)
