@@ -532,8 +532,8 @@ def main():
             lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 1)        # reset: count the timed steps only
         kernel_ms.clear()
         flush_ms.clear()
-        prof = (C.c_ulonglong * 48)()
-        has_prof = hasattr(lib, "bt_best_prof_read") and lib.bt_best_prof_read(prof, 48, 1) > 0      # reset: the timed steps only
+        prof = (C.c_ulonglong * 96)()
+        has_prof = hasattr(lib, "bt_best_prof_read") and lib.bt_best_prof_read(prof, 96, 1) > 0      # reset: the timed steps only
         t0 = time.perf_counter()
         for k in range(steps):
             step(k)
@@ -541,8 +541,9 @@ def main():
         wall = time.perf_counter() - t0
         if has_prof:
             # the profiling build of bt_best_kernel (make bestprof): wavefront cycles per section of the engine
-            nsec = lib.bt_best_prof_read(prof, 48, 0)
-            names = ["RUN", "BEGIN", "SETQ", "ADV", "LEAF", "STREAK", "CURTAIL", "SPLIT", "SORT", "CHASE", "REPORT", "REF", "END", "FRONT"]
+            nsec = lib.bt_best_prof_read(prof, 96, 0)
+            names = ["RUN", "BEGIN", "SETQ", "ADV", "LEAF", "STREAK", "CURTAIL", "SPLIT", "SORT", "CHASE", "REPORT", "REF", "END", "FRONT",
+                     "HOT", "HOT_STEP", "HOT_SEND", "HOT_CHASE", "COLD", "COLD_TAKE", "COLD_EXIT", "COLD_POST", "COLD_RUN", "COLD_PRE"]
             tot = max(1, prof[0])
             SECTIONS.clear()
             for i in range(min(nsec, len(names))):

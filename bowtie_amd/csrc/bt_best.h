@@ -72,9 +72,12 @@
  * and lanes per section, tallied by the first active lane into bf_prof[] (bt_best_kernels.hip).  Sections nest (a leaf's
  * advance contains the streak, the curtail and the split); a section entered by some of a wavefront's lanes while the
  * others wait counts what the wavefront spends on those lanes.  No-ops in the product build. */
-enum { BP_RUN = 0, BP_BEGIN, BP_SETQ, BP_ADV, BP_LEAF, BP_STREAK, BP_CURTAIL, BP_SPLIT, BP_SORT, BP_CHASE, BP_REPORT, BP_REF, BP_END, BP_FRONT, BP_N };   /* BP_N <= 16 */
+enum { BP_RUN = 0, BP_BEGIN, BP_SETQ, BP_ADV, BP_LEAF, BP_STREAK, BP_CURTAIL, BP_SPLIT, BP_SORT, BP_CHASE, BP_REPORT, BP_REF, BP_END, BP_FRONT,
+       /* the wavefront automaton's own: a hot round and its pieces, a cold sweep and its pieces */
+       BP_HOT, BP_HSTEP, BP_HSEND, BP_HCHASE, BP_COLD, BP_CTAKE, BP_CEXIT, BP_CPOST, BP_CRUN, BP_CPRE, BP_N };   /* BP_N <= BF_PROF_SLOTS */
+#define BF_PROF_SLOTS 32
 #if defined(BF_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long bf_prof[3 * 16];
+extern __device__ unsigned long long bf_prof[3 * BF_PROF_SLOTS];
 #define BF_PT0(v) const unsigned long long v = __builtin_readcyclecounter()
 #define BF_PADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
 	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) { atomicAdd(&bf_prof[3 * (k)], __builtin_readcyclecounter() - (v)); \
@@ -2384,10 +2387,12 @@ BF_FN void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 BF_FN uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 {
 	uint32_t did = 0;
+	BF_PT0(t_hot);
 	if (S.phase == BA_FRONT) { la_front(X, S.leaf); S.phase = BA_STEP; }
-	if (S.phase == BA_STEP) { did |= 1u; if (!la_step(X, S.leaf)) S.phase = BA_SEND; }
-	if (S.phase == BA_SEND && sendOk) { did |= 2u; S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT; }
-	if (S.phase == BA_CHASE) { did |= 4u; ch_advance_piece(X, S.ch); if (S.ch.tidx != BT_OFF_MASK || S.ch.done) S.phase = BA_RUN; }
+	if (S.phase == BA_STEP) { BF_PT0(t_s); did |= 1u; if (!la_step(X, S.leaf)) S.phase = BA_SEND; BF_PADD(BP_HSTEP, t_s); }
+	if (S.phase == BA_SEND && sendOk) { BF_PT0(t_s); did |= 2u; S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT; BF_PADD(BP_HSEND, t_s); }
+	if (S.phase == BA_CHASE) { BF_PT0(t_s); did |= 4u; ch_advance_piece(X, S.ch); if (S.ch.tidx != BT_OFF_MASK || S.ch.done) S.phase = BA_RUN; BF_PADD(BP_HCHASE, t_s); }
+	BF_PADD(BP_HOT, t_hot);
 	return did;
 }
 
@@ -2396,20 +2401,26 @@ BF_FN uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 template <class Take>
 BF_FN void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk, Take take)
 {
+	BF_PT0(t_cold);
 	if (S.phase == BA_END) { bf_auto_end(X, B, S); S.phase = BA_TAKE; }
 	if (S.phase == BA_TAKE && takeOk) {
+		BF_PT0(t_s);
 		const uint32_t rd = take();
 		if (rd == 0xffffffffu) S.phase = BA_IDLE;
 		else { bf_auto_begin(X, B, rd, S); S.phase = BA_RUN; }
+		BF_PADD(BP_CTAKE, t_s);
 	}
-	if (S.phase == BA_LEAF_EXIT) { la_exit(X, S.leaf); S.phase = BA_POST; }
-	if (S.phase == BA_POST) { adv_post(X, S.adv); S.phase = BA_RUN; }
-	if (S.phase == BA_RUN) bf_auto_run(X, B, S);
+	if (S.phase == BA_LEAF_EXIT) { BF_PT0(t_s); la_exit(X, S.leaf); S.phase = BA_POST; BF_PADD(BP_CEXIT, t_s); }
+	if (S.phase == BA_POST) { BF_PT0(t_s); adv_post(X, S.adv); S.phase = BA_RUN; BF_PADD(BP_CPOST, t_s); }
+	if (S.phase == BA_RUN) { BF_PT0(t_s); bf_auto_run(X, B, S); BF_PADD(BP_CRUN, t_s); }
 	if (S.phase == BA_PRE) {
+		BF_PT0(t_s);
 		if (!adv_pre(X, S.adv, S.drv)) S.phase = BA_RUN;             /* no second halves: the runner's turn goes on (next pass) */
 		else S.phase = S.adv.leaf ? BA_LEAF_ENTER : BA_POST;
+		BF_PADD(BP_CPRE, t_s);
 	}
 	if (S.phase == BA_LEAF_ENTER) S.phase = la_enter(X, S.leaf, S.adv.leaf) ? BA_FRONT : BA_POST;
+	BF_PADD(BP_COLD, t_cold);
 }
 
 #undef AW

@@ -13,7 +13,7 @@
  */
 #include <hip/hip_runtime.h>
 #if defined(BF_PROFILE)
-__device__ unsigned long long bf_prof[3 * 16];      /* bt_best.h: cycles, passes, lanes per section (BP_*) */
+__device__ unsigned long long bf_prof[3 * 32];      /* bt_best.h: cycles, passes, lanes per section (BP_*; BF_PROF_SLOTS) */
 #endif
 #include "bt_best.h"
 #include "bt_kernels.h"
@@ -105,6 +105,7 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 		if (w >= n) return 0xffffffffu;
 		return A.workList ? A.workList[w] : w;
 	};
+	BF_PT0(t_run);
 	for (;;) {
 		const bool hot = BA_IS_HOT(S.phase);
 		const unsigned long long hotM = __ballot(hot), coldM = __ballot(!hot && S.phase != BA_IDLE);
@@ -126,6 +127,7 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 		 * second pass right away (sweepTwice), which the wave model prices at more than their waiting costs */
 		if (A.sweepTwice && __ballot(BA_IS_PENDING(S.phase)) != 0) { if (BA_IS_PENDING(S.phase)) bf_auto_cold(X, BATCH, S, false, take); }
 	}
+	BF_PADD(BP_RUN, t_run);
 	BT_BEST_EPILOGUE
 }
 
@@ -146,10 +148,10 @@ extern "C" int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint
 extern "C" int bt_best_prof_read(unsigned long long* out, int cap, int reset)
 {
 #if defined(BF_PROFILE)
-	unsigned long long h[3 * 16] = {};
+	unsigned long long h[3 * BF_PROF_SLOTS] = {};
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bf_prof), sizeof(h)) != hipSuccess) return 0;
 	for (int i = 0; i < 3 * BP_N && i < cap; i++) out[i] = h[i];
-	if (reset) { unsigned long long z[3 * 16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bf_prof), z, sizeof(z)); }
+	if (reset) { unsigned long long z[3 * BF_PROF_SLOTS] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bf_prof), z, sizeof(z)); }
 	return BP_N;
 #else
 	(void)out; (void)cap; (void)reset;
