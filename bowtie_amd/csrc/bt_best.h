@@ -295,41 +295,9 @@ BF_INL uint32_t alt_cost(uint32_t info, uint32_t rdepth, uint32_t seedLen)
 	return ((rdepth + i < seedLen) ? (1u << 14) : 0u) | ((info >> 16) & 0xffu);
 }
 
-/* Branch::curtail (range_source.h:877-939) */
-BF_FN void br_curtail(BfLane& X, uint32_t b, uint32_t seedLen)
-{
-	const uint32_t alt = AW(b + BR_ALT), n = AW(b + BR_NALT), rdepth = br_rdepth(X, b);
-	uint32_t lowest = 0xffffu;
-	for (uint32_t k = 0; k < n; k++) {
-		const uint32_t info = AW(alt + k * BF_ALW + 8u);
-		if (info >> 28) continue;
-		const uint32_t c = alt_cost(info, rdepth, seedLen);
-		if (c < lowest) lowest = c;
-	}
-	uint32_t f = AW(b + BR_FLAGS);
-	if (lowest > 0 && lowest != 0xffffu) br_set_cost(X, b, br_cost(X, b) + lowest);
-	else if (lowest == 0xffffu) f |= BRF_EXHAUSTED;
-	AW(b + BR_FLAGS) = f | BRF_CURTAILED;
-	if (X.growing == b) X.growing = 0;
-}
-
 /* ---- CostCompare (range_source.h:1103-1142) and the heap ----------------------------------------
  * std::priority_queue<Branch*, vector, CostCompare> = libstdc++'s __push_heap / __adjust_heap
  * (bits/stl_heap.h); reproduced step for step because keys change while a branch is queued. */
-BF_FN bool bf_before(BfLane& X, uint32_t a, uint32_t b)        /* CostCompare()(a, b): true -> b before a */
-{
-	const uint32_t ca = br_cost(X, a), cb = br_cost(X, b);
-	if (ca != cb) return cb < ca;
-	const bool aUn = (AW(a + BR_FLAGS) & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0;
-	const bool bUn = (AW(b + BR_FLAGS) & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0;
-	if (bUn && !aUn) return false;
-	if (aUn && !bUn) return true;
-	const uint32_t ra = AW(a + BR_RDLEN), rb = AW(b + BR_RDLEN);
-	const uint32_t ta = ((ra & 0xffffu) + (ra >> 16)) & 0xffffu, tb = ((rb & 0xffffu) + (rb >> 16)) & 0xffffu;
-	if (ta != tb) return ta < tb;
-	return AW(b + BR_ID) < AW(a + BR_ID);
-}
-
 /* what CostCompare looks at, fetched in one go (the record's first two 16-byte pieces) instead of field by field as the
  * comparison proceeds */
 struct BfKey { uint32_t cost, un, depth, id; };
@@ -440,16 +408,8 @@ BF_FN void pm_free_id(BfLane& X, uint32_t d, uint32_t id)
 }
 
 /* PathManager::curtail (range_source.h:1435-1454) */
-BF_FN void pm_curtail(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen)
-{
-	const uint32_t orig = br_cost(X, br);
-	br_curtail(X, br, seedLen);
-	if (AW(br + BR_FLAGS) & BRF_EXHAUSTED) { pm_pop(X, d); pm_free_id(X, d, AW(br + BR_ID)); }
-	else if (br_cost(X, br) != orig) { const uint32_t p = pm_pop(X, d); pm_push(X, d, p); }
-}
-
-/* pm_curtail + br_curtail for the branch whose record leaf_advance_branch holds in registers (R == what the arena has):
- * only the alternatives' info words are fetched */
+/* PathManager::curtail (range_source.h:1402-1424) + Branch::curtail (:877-939) for the branch whose record la_send holds in
+ * registers (R == what the arena has): only the alternatives' info words are fetched */
 BF_FN void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen, const uint32_t* R)
 {
 	const uint32_t alt = R[BR_ALT], n = R[BR_NALT], rdepth = R[BR_RDLEN] & 0xffffu;
@@ -585,22 +545,6 @@ BF_FN bool pm_split_and_prep(BfLane& X, uint32_t d, uint32_t seedLen, uint32_t d
 /* ---- the leaf: EbwtRangeSourceDriver + EbwtRangeSource ------------------------------------------- */
 BF_INL const BfSpec& leaf_spec(BfLane& X, uint32_t d) { return X.P->specs[(AW(d + DR_KIND) >> 16) & 0xffu]; }
 
-/* the leaf's query character at offset i of its (possibly seed-edited) query: qry_ / qryBuf_
- * (ebwt_search_backtrack.h:1831-1861) */
-BF_FN uint32_t leaf_qry(BfLane& X, uint32_t d, const BfSpec& sp, uint32_t i)
-{
-	const BfRead& R = X.R[sp.mate];
-	uint32_t c = bf_base(R, sp.fw, !sp.mirror, i);
-	if (AW(d + LF_RSFLAGS) & 8u) {
-		const uint32_t n = AW(d + LF_SEED) >> 16, full = R.len;
-		for (uint32_t k = 0; k < n; k++) {
-			const uint32_t m = AW(d + LF_SEEDMM0 + k);
-			if (full - (m & 0xffffu) - 1u == i) c = m >> 16;
-		}
-	}
-	return c;
-}
-
 BF_INL uint32_t bf_cext(uint32_t cext, uint32_t sRight, uint32_t s, uint32_t len)
 {
 	return cext == BF_PIN_SEED ? s : cext == BF_PIN_HI_HALF ? sRight : cext == BF_PIN_BEGIN ? 0u : len;
@@ -715,7 +659,8 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 		if (r2 != r3) maxmms = 3;
 		if (qlen <= maxmms) { rsf |= 1u | 4u; go = false; }
 	}
-	/* leaf_qry with the seed's edits read once instead of at every character */
+	/* the leaf's query character at offset i of its (possibly seed-edited) query -- qry_ / qryBuf_
+	 * (ebwt_search_backtrack.h:1831-1861) -- with the seed's edits read once instead of at every character */
 	uint32_t sqN = 0, sqM[3] = {0, 0, 0};
 	if (valid) { sqN = AW(d + LF_SEED) >> 16; for (uint32_t k = 0; k < 3u; k++) sqM[k] = AW(d + LF_SEEDMM0 + k); }
 	auto qry = [&](uint32_t i) -> uint32_t {
@@ -755,7 +700,7 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 				const uint32_t lo = (sp.fw == ebwtFw) ? a : len - qlen, base16 = lo & ~15u;
 				const BtU4 v0 = bt_ld4((const void*)(R.seq + base16)), v1 = bt_ld4((const void*)(R.seq + base16 + (lo + ftabChars > base16 + 16u ? 16u : 0u)));
 				const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-				auto chr = [&](uint32_t i) -> uint32_t {               /* leaf_qry(i) for i in [a, qlen) */
+				auto chr = [&](uint32_t i) -> uint32_t {               /* the query character at i, for i in [a, qlen) */
 					const uint32_t sidx = ((sp.fw == ebwtFw) ? i : len - 1u - i) - base16;
 					uint32_t c = (w8[sidx >> 2] >> (8u * (sidx & 3u))) & 0xffu;
 					if (!sp.fw && c < 4u) c ^= 3u;
@@ -877,7 +822,7 @@ BF_FN bool la_step(BfLane& X, BfLeafSt& S)
 		if (depth < qlen) {
 			uint32_t c = S.havePf ? S.pfC : bf_base(RD, sp.fw, ebwtFw, cur);
 			if (S.seedEdits) {
-				const uint32_t full = RD.len;                          /* leaf_qry's overrides, from registers */
+				const uint32_t full = RD.len;                          /* the seed's edits override the read's characters (qryBuf_), from registers */
 				for (uint32_t k = 0; k < 3u; k++) if (k < S.seedN && full - (S.seedM[k] & 0xffffu) - 1u == cur) c = S.seedM[k] >> 16;
 			}
 			const uint32_t q = bt_mm_penalty(maq, bf_phred(S.havePf ? S.pfQ : bf_qualc(RD, sp.fw, ebwtFw, cur)));
