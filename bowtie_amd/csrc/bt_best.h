@@ -43,9 +43,13 @@
 #if defined(__HIPCC__)
 #define BF_FN static __host__ __device__
 #define BF_INL __host__ __device__ __forceinline__
+/* the automaton's own layer is inlined into its kernel's loop: as real functions its pieces take the lane's records by
+ * reference, and a record whose address is handed to a call lives in scratch memory for the whole kernel */
+#define BF_FNI static __host__ __device__ __attribute__((always_inline))
 #else
 #define BF_FN static
 #define BF_INL static inline
+#define BF_FNI static
 #endif
 /* PairedBWAlignerV1 (bf_run_pair_v1, the reference's default paired-end aligner): part of every build since round 3
  * (GPU-verified against the 120 reference outputs of tests/golden/pe_v1) */
@@ -410,7 +414,7 @@ BF_FN void pm_free_id(BfLane& X, uint32_t d, uint32_t id)
 /* PathManager::curtail (range_source.h:1435-1454) */
 /* PathManager::curtail (range_source.h:1402-1424) + Branch::curtail (:877-939) for the branch whose record la_send holds in
  * registers (R == what the arena has): only the alternatives' info words are fetched */
-BF_FN void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen, const uint32_t* R)
+BF_FNI void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen, const uint32_t* R)
 {
 	const uint32_t alt = R[BR_ALT], n = R[BR_NALT], rdepth = R[BR_RDLEN] & 0xffffu;
 	uint32_t lowest = 0xffffu;
@@ -759,7 +763,7 @@ struct BfLeafSt {
 };
 
 /* leaf_advance's prologue; false: the leaf is done, there is nothing to advance (its flags say so now) */
-BF_FN bool la_enter(BfLane& X, BfLeafSt& S, uint32_t d)
+BF_FNI bool la_enter(BfLane& X, BfLeafSt& S, uint32_t d)
 {
 	const uint32_t fl = AW(d + DR_FLAGS);
 	if ((fl & BF_F_DONE) || (AW(d + LF_HEAPSZ) & 0xffffu) == 0) { AW(d + DR_FLAGS) = fl | BF_F_DONE; return false; }
@@ -776,7 +780,7 @@ BF_FN bool la_enter(BfLane& X, BfLeafSt& S, uint32_t d)
 }
 
 /* the queue's front, its record in one go (four independent 16-byte loads, one wait) */
-BF_FN void la_front(BfLane& X, BfLeafSt& S)
+BF_FNI void la_front(BfLane& X, BfLeafSt& S)
 {
 	BF_PT0(t_front);
 	const uint32_t br = pm_front(X, S.d);
@@ -798,7 +802,7 @@ BF_FN void la_front(BfLane& X, BfLeafSt& S)
 }
 
 /* one step of the streak; true: the branch was simply extended and the next step goes on from the registers */
-BF_FN bool la_step(BfLane& X, BfLeafSt& S)
+BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 {
 	const BfSpec& sp = X.P->specs[S.spec];
 	const BtIndexDev& ix = X.ix[sp.mirror];
@@ -940,7 +944,7 @@ BF_FN bool la_step(BfLane& X, BfLeafSt& S)
 
 /* the streak has ended: the arena gets what its steps would have written one by one, before anything reads it; curtail,
  * splitAndPrep.  true: the leaf's advance goes on with the queue's new front (la_front), false: it is over (la_exit) */
-BF_FN bool la_send(BfLane& X, BfLeafSt& S)
+BF_FNI bool la_send(BfLane& X, BfLeafSt& S)
 {
 	const BfSpec& sp = X.P->specs[S.spec];
 	const uint32_t d = S.d, br = S.br;
@@ -964,7 +968,7 @@ BF_FN bool la_send(BfLane& X, BfLeafSt& S)
 }
 
 /* leaf_advance's epilogue: the range source's and the driver's flags and cost */
-BF_FN void la_exit(BfLane& X, BfLeafSt& S)
+BF_FNI void la_exit(BfLane& X, BfLeafSt& S)
 {
 	const uint32_t d = S.d;
 	const uint32_t rsf = (AW(d + LF_RSFLAGS) & ~2u) | (S.found ? 2u : 0u);
@@ -1385,7 +1389,7 @@ enum { BF_AFTER_NONE = 0, BF_AFTER_SEED_BRANCH, BF_AFTER_FULL_BRANCH, BF_AFTER_F
 
 /* the first halves, down to the leaf that is due (S.leaf, 0: none); false: the driver's advance ended here (a delayed range
  * handed out, nothing left to advance) and there are no second halves to go through */
-BF_FN bool adv_pre(BfLane& X, BfAdvSt& S, uint32_t d)
+BF_FNI bool adv_pre(BfLane& X, BfAdvSt& S, uint32_t d)
 {
 	S.d = d; S.leaf = 0; S.seed = 0; S.full = 0; S.old = 0; S.p2 = 0; S.precost1 = 0; S.after = BF_AFTER_NONE; S.p = 0; S.precost = 0;
 	/* cost_advance<0>, first half */
@@ -1449,7 +1453,7 @@ BF_FN bool adv_pre(BfLane& X, BfAdvSt& S, uint32_t d)
 	return true;
 }
 /* the second halves, innermost first */
-BF_FN void adv_post(BfLane& X, BfAdvSt& S)
+BF_FNI void adv_post(BfLane& X, BfAdvSt& S)
 {
 	uint32_t after = S.after;
 	if (after == BF_AFTER_FULL_CHILD) { cost_advance_post<1>(X, S.full, S.p2, S.precost1); after = BF_AFTER_FULL_BRANCH; }
@@ -1575,7 +1579,7 @@ BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uin
 }
 /* one row of the walk resolved, or one LF step of it: RangeChaser::advance (range_chaser.h:150-209) a piece at a time --
  * ch_advance below is this in a loop, the wavefront automaton takes a piece per round */
-BF_FN void ch_advance_piece(BfLane& X, BfChase& c)
+BF_FNI void ch_advance_piece(BfLane& X, BfChase& c)
 {
 	c.tidx = BT_OFF_MASK;
 	if (c.cDone) {
@@ -2216,7 +2220,7 @@ struct BfAuto {
 };
 
 /* bf_run_read / bf_run_pair down to their loops */
-BF_FN void bf_auto_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfAuto& S)
+BF_FNI void bf_auto_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfAuto& S)
 {
 	BF_PT0(t_begin);
 	S.live = 0; S.done = true; S.chase = false; S.attempts = 0; S.afterAdv = 0;
@@ -2240,7 +2244,7 @@ BF_FN void bf_auto_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfAuto& S)
 	}
 	BF_PADD(BP_BEGIN, t_begin);
 }
-BF_FN void bf_auto_end(BfLane& X, const BtBatchDev& B, BfAuto& S)
+BF_FNI void bf_auto_end(BfLane& X, const BtBatchDev& B, BfAuto& S)
 {
 	bf_read_end(X, B, S.kind == 1u ? 1u : 2u);
 	if (X.status & BT_STF_OVERFLOW) {
@@ -2251,7 +2255,7 @@ BF_FN void bf_auto_end(BfLane& X, const BtBatchDev& B, BfAuto& S)
 
 /* the turns of bf_run_read's / bf_run_pair's loop, up to the one that needs the driver advanced (-> BA_PRE; the turn goes
  * on behind the advance: afterAdv), a piece of the SA walk (-> BA_CHASE) or nothing any more (-> BA_END) */
-BF_FN void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
+BF_FNI void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 {
 	BfChase& ch = S.ch;
 	const uint32_t drv = S.drv;
@@ -2329,7 +2333,7 @@ BF_FN void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 
 /* one hot round of one lane; sendOk: streaks that have ended are finished this round (the wavefront's gate) */
 /* -> what the lane went through: 1 a step, 2 the end of a streak, 4 a piece of a walk (the host's wave model counts them) */
-BF_FN uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
+BF_FNI uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 {
 	uint32_t did = 0;
 	BF_PT0(t_hot);
@@ -2344,7 +2348,7 @@ BF_FN uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 /* one pass of the cold sweep for one lane; takeOk: lanes that wait for a read take one (take() -> its number, or
  * 0xffffffff when the batch has none left) */
 template <class Take>
-BF_FN void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk, Take take)
+BF_FNI void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk, Take take)
 {
 	BF_PT0(t_cold);
 	if (S.phase == BA_END) { bf_auto_end(X, B, S); S.phase = BA_TAKE; }
