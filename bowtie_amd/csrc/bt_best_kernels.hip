@@ -1,12 +1,16 @@
 /*
  * bt_best_kernels.hip -- gfx950 kernel of the best-first search path (--best, --strata, -M, -v 3).
  *
- *   bt_best_kernel : one lane = one read, run start to finish by the automaton of bt_best.h; lanes
- *                    pull reads from a global cursor until the batch drains.  Every lane owns an
- *                    arena of `arenaWords` 32-bit words in HBM for the read's branches, heaps and
- *                    driver records.  With a paired program a "read" is a pair: both mates' drivers
- *                    compete in one queue and the second mate is found by scanning the 2-bit
- *                    reference next to the first one's hit (PairedBWAlignerV2, aligner.h:1483-2051).
+ *   bt_best_kernel        : the wavefront automaton of bt_best.h -- one loop per wavefront over the engine's resumable
+ *                           pieces: hot rounds for the lanes that extend a branch or walk the suffix array, cold sweeps
+ *                           for the rest, reads taken lane by lane from a global cursor.  Picked for indexes that do not
+ *                           fit the Infinity Cache (bt_api.cpp).
+ *   bt_best_nested_kernel : one lane = one read (or pair), run start to finish call by call; reads handed out a wavefront
+ *                           at a time.  Small genomes, and PairedBWAlignerV1's runner always.
+ *   Every lane owns an arena of `arenaWords` 32-bit words in HBM for the read's branches, heaps and driver records.  With
+ *   a paired program a "read" is a pair: both mates' drivers compete in one queue and the second mate is found by scanning
+ *   the 2-bit reference next to the first one's hit (PairedBWAlignerV2, aligner.h:1483-2051).  A second, small launch of
+ *   either kernel (work list, 16 MB arenas, one lane per wavefront taking reads) searches again what outgrew its arena.
  *
  * Replaces (reference, CPU): the *Stateful worker loops of ebwt_search.cpp:1223/1509/1955/2609 for
  * unpaired reads (MixedMultiAligner::run + UnpairedAlignerV2, aligner.h:244-360, 381-599).

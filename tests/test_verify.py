@@ -133,3 +133,24 @@ def test_tampered_pairs_are_caught():
     assert r["bad_insert"] > 10
     t["n_hits"][int(al[1])] = 3
     assert V.verify_pairs(len1=50, len2=50, pol=mode, **t)["odd_count"] == 1
+
+
+@pytest.mark.parametrize("l1,l2,extra", [(50, 36, {}), (36, 50, {}), (50, 36, {"allow_contain": True}), (40, 40, {"min_ins": 200, "max_ins": 420})])
+def test_oracle_pairs_of_unequal_mates_verify_clean(l1, l2, extra):
+    """mates of different lengths (the containment rule depends on which mate is the shorter one), --allow-contain, and
+    -I / -X that actually cut: the oracle's pairs pass every rule"""
+    import copy
+    b1, b2 = T.pair_set("e_coli", "pe50")
+
+    def trimmed(b, L):
+        r = copy.copy(b)
+        r.seq, r.qual, r.len = b.seq.copy(), b.qual.copy(), np.minimum(b.len, L).astype(b.len.dtype)
+        r.seq[:, L:] = 4
+        return r
+    b1, b2 = trimmed(b1, l1), trimmed(b2, l2)
+    mode = dict(T.MODES["pe_n2_best_X500"], **extra)
+    per = T.oracle_pair_results("e_coli", b1, b2, mode)
+    t = pair_tensors("e_coli", b1, b2, per)
+    r = V.verify_pairs(len1=l1, len2=l2, pol=mode, **t)
+    assert r["checked"] == sum(1 for h, _, _ in per if len(h) >= 2) > 40
+    assert {k: v for k, v in r.items() if k != "checked"} == PAIR_RULES
