@@ -676,6 +676,10 @@ def main():
                          "traffic_note": (tr["source"] if tr else "no rocprofv3 PMC profile of this round's source of this kernel on this workload in profiles/traffic.json (round 3 measured 213 KB/read on big_n2_100, an upper bound: 1.9 x algorithmic)"),
                          "achieved_over_wall": abytes * args.steps / wall / 1e9,
                          "kernel": kname, "kernel_ms_avg": kavg, "kernel_ms_main_avg": kmain,
+                         # a step of the stateful path is two dispatches of the same kernel: the main launch and the second pass over
+                         # the reads that outgrew their arena (it returns at once when there are none) -- rocprofv3's per-kernel
+                         # average is over both, kernel_ms_avg is the step's span (HIP events around both)
+                         "dispatches_per_step": 2 if (paired or wl["pol"].get("best")) else 1,
                          "carry_over_launches": carry_age, "flush_ms_total": sum(flush_ms),
                          "reads_searched_again_last_step": sum(int(lib.bt_ctx_last_retried(o["al"]._h)) for o in pipes),
                          "algorithmic_bytes_per_launch": abytes,
