@@ -193,7 +193,7 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: fl
                 ts = int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3)) if m else None
                 return wall, ts
 
-            nA = 40_000 if paired else 200_000
+            nA = 200_000      # reads, or pairs: the sample whose SAM is diffed against the reference's (round 3: 40 000 pairs)
             bA, inA = make(nA, 4321)
             if diff_only:
                 # the parity leg alone: the reference's SAM for the sample against the product's
@@ -211,7 +211,7 @@ def cpu_baseline(base: str, wl: dict, text_np: np.ndarray, idx=None, seconds: fl
             wA, _ = run(cores, inA)
             nB = int(min(2_000_000 // unit if paired else 4_000_000, max(3 * nA, seconds * nA / max(wA, 0.5))))
             if paired:
-                nB = min(nB, 300_000)              # the numpy pair generator is a python loop
+                nB = min(nB, 500_000)              # the numpy pair generator is a python loop
             bB, inB = make(nB, 4322)
             sweep = {}
             for p in sorted({min(32, cores), min(64, cores), min(128, cores), cores}):
