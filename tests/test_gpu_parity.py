@@ -621,3 +621,19 @@ def test_gpu_automaton_large_batches(gidx, automaton):
 def test_gpu_automaton_arena_overflow_retry(gidx, monkeypatch):
     monkeypatch.setenv("BT_BEST_NESTED", "0")
     test_gpu_best_first_arena_overflow_retry(gidx, monkeypatch)
+
+
+def test_gpu_stream_stress_a_few_rounds():
+    """A gate on the streamed path (round 3's one-off wrong answer): the stress harness of round 4 --
+    the streamed test in a loop, carry-over 0 / 1 / 12 in turn, every batch's reads in an order of the round's own, so that
+    whatever a recycled staging area still holds is never the right answer -- for a few seconds, with the mismatch pool's
+    staging region poisoned: no round may differ from the oracle."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BT_STREAM_POISON="1", BT_MAX_BLOCKS="2")
+    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "scripts", "r4", "stream_stress.py"), "--seconds", "6", "--tag", "gate"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-800:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert d["rounds"] >= 2 and d["fails"] == 0, d
