@@ -1375,6 +1375,44 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 	return BT_OK;
 }
 
+extern "C" int bt_align_stream_tick(bt_ctx* c, uint32_t min_rounds)
+{
+	if (!c) return BT_ERR_ARG;
+	if (!c->carryPending || !c->pool) return BT_OK;              /* nothing is parked */
+	HIPCHK(hipSetDevice(c->idx->device));
+	/* the launch of ctx_flush_carry, except that it parks again: same grid, no fresh reads, a ring slot of its own whose
+	 * batch is empty (a slot is reused sixteen launches later; what used it has been complete for four by then) */
+	BtKernelArgs A;
+	memset(&A, 0, sizeof(A));
+	BtWarm warm;
+	fill_index_args(c, &A, &warm);
+	const uint32_t bid = c->launchSeq & (BT_BATCH_RING - 1u);
+	BatchView none;
+	memset(&none, 0, sizeof(none));
+	c->ring[bid] = none; c->ringRetry[bid] = false; c->ringMaxLen[bid] = 0;
+	BtCold cold;
+	fill_cold(c, &cold, none.B, bid);
+	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));                 /* this launch's parked counts */
+	A.H.seq = nullptr; A.H.qual = nullptr; A.H.stride = 0; A.H.n_reads = 0;
+	A.cold = c->d_cold; A.warm = c->d_warm;
+	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
+	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
+	A.counts = c->d_counts;
+	A.nextRead = c->d_cursor;
+	A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = 1; A.park = 1; A.maxAge = c->carryAge; A.parkedOf = c->d_carry;
+	A.parkMinRounds = min_rounds ? min_rounds : env_u32("BT_TICK_MIN_ROUNDS", 150000);
+	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	const uint32_t k = c->launchSeq & (BT_BATCH_RING - 1u);
+	HIPCHK(hipMemcpyAsync(c->hostParked + (size_t)k * BT_BATCH_RING, c->d_carry, BT_BATCH_RING * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipEventRecord(c->evLaunch[k], c->stream));
+	c->launchSeq++;
+	return BT_OK;
+}
+
 extern "C" void* bt_host_alloc(size_t bytes)
 {
 	void* p = nullptr;

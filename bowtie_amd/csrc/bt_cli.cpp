@@ -1368,6 +1368,23 @@ int main(int argc, char** argv)
 			const double tb = now_s();
 			if (j->last || abort_run.load()) {
 				g_tl.mark("search: end of input, finishing what is parked", j->seq);
+				/* the batches still in flight come out one by one: a tick lets what is parked run on for a while and says what
+				 * it completed, so the writer works through the oldest batches while the stragglers of the later ones still run
+				 * (a flush hands all of them over at once, when the last straggler of the last batch is done: 13 batches,
+				 * 3.9 s of formatting and writing that overlapped nothing in round 4's timeline).  After as many ticks as a
+				 * read may ride along, whatever is left is flushed. */
+				if (!abort_run.load() && !getenv("BT_CLI_NO_TICKS")) {
+					for (int tick = 0; tick < 14 && !fl.empty(); tick++) {
+						drain(0);
+						if (fl.empty()) break;
+						if (bt_align_stream_tick(cs, 0) != BT_OK) break;
+						g_tl.mark("search: tick", j->seq);
+						/* until the oldest batch comes out, or for as long as a tick may take */
+						const size_t before = fl.size();
+						const double t0 = now_s();
+						while (fl.size() == before && now_s() - t0 < 0.6) { drain(0); if (fl.size() == before) std::this_thread::sleep_for(std::chrono::microseconds(500)); }
+					}
+				}
 				drain(1);
 				busy_gpu[(size_t)g] += now_s() - tb;
 				const bool end = j->last;

@@ -236,6 +236,14 @@ int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_
  * threads. */
 int  bt_align_stream_submit(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, void* tag);
 int  bt_align_stream_collect(bt_ctx* ctx, void** tag, int flush);
+/* With carry-over: one more launch of the context's grid with no new reads.  What is parked runs on for at least
+ * `min_rounds` lock-step rounds (0: the library's default) or to its end, is parked again, and what it completes is known as
+ * after any launch -- bt_align_stream_collect(ctx, &tag, 0) then hands out the batches that are done.  For the end of the
+ * input: a few ticks let the oldest batches out one by one while the stragglers of the later ones still run, where a
+ * flush holds every batch back until the last straggler of the last one is done (the reference's threads finish their
+ * reads in whatever order they come, ebwt_search.cpp:1180-1230; its output queue does the re-ordering, hit.h:600-700).
+ * Asynchronous like a submit; a context without carry-over, or with nothing parked, is left alone. */
+int  bt_align_stream_tick(bt_ctx* ctx, uint32_t min_rounds);
 /* Page-locked host memory for the arrays of a bt_read_batch handed to bt_align_stream_submit: from such memory the
  * upload is a DMA the call does not wait for (from ordinary memory the runtime stages it and the call returns when it
  * is done).  NULL when there is none to be had; ordinary memory works everywhere.  (A reader thread's parse buffers:

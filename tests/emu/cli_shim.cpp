@@ -143,6 +143,7 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	c->done.push_back(tag);
 	return BT_OK;
 }
+extern "C" int bt_align_stream_tick(bt_ctx* c, uint32_t min_rounds) { (void)min_rounds; return c ? BT_OK : BT_ERR_ARG; }
 extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 {
 	(void)flush;
