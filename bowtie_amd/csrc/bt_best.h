@@ -45,7 +45,11 @@
 #define BF_INL __host__ __device__ __forceinline__
 /* the automaton's own layer is inlined into its kernel's loop: as real functions its pieces take the lane's records by
  * reference, and a record whose address is handed to a call lives in scratch memory for the whole kernel */
+#ifdef BF_NO_FNI      /* A/B build: the automaton's layer as real calls again (round 4's state before cc149e9) */
+#define BF_FNI static __host__ __device__
+#else
 #define BF_FNI static __host__ __device__ __attribute__((always_inline))
+#endif
 #else
 #define BF_FN static
 #define BF_INL static inline

@@ -216,7 +216,7 @@ enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_F
 /* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
  * cycles (s_memtime) per section, accumulated in LDS.  No-ops in the product build. */
 enum { PS_RESUME = 0, PS_SLOW, PS_WAIT, PS_RANK, PS_REFILL, PS_LOOP,
-       PS_FELL_OFF, PS_RESOLVE_DONE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_RESCAN, PS_SEARCH_END, PS_PHASE_NEXT, PS_SEARCH_BEGIN, PS_FTABSEQ_DONE, PS_FTAB_DONE, PS_BT_LOOP, PS_CANDSCAN, PS_BT_PICK, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_PASSES, PS_N };
+       PS_FELL_OFF, PS_RESOLVE_DONE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_RESCAN, PS_SEARCH_END, PS_PHASE_NEXT, PS_SEARCH_BEGIN, PS_FTABSEQ_DONE, PS_FTAB_DONE, PS_BT_LOOP, PS_CANDSCAN, PS_BT_PICK, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_PASSES, PS_SINGLE_LFEX, PS_SINGLE_RUNS, PS_N };
 #if defined(BT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define BT_PROF_T0(v) const unsigned long long v = __builtin_readcyclecounter()
 #define BT_PROF_PASS() do { const unsigned long long ex_ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + PS_PASSES], 1ull); } while (0)

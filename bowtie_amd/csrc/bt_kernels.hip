@@ -99,6 +99,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	const BtCold* cold = A.cold;
 	uint32_t nReads = A.H.n_reads;
 	if (EXT && A.orderCount) { const uint32_t v = *BT_GP(const uint32_t, A.orderCount); nReads = v < A.orderCap ? v : A.orderCap; }
+#ifdef BT_PROFILE
+	bool pf_prevSingle = false;
+#endif
 	uint32_t sc_iters = 0, sc_rounds = 0, sc_fetch = 0, sc_chase = 0, sc_lfex = 0, sc_lf2 = 0, sc_lf1 = 0, sc_same = 0;
 
 	if (EXT && A.pool && A.adopt) {
@@ -221,6 +224,16 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			sc_lf2 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_C2));
 			sc_lf1 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_LF1));
 			sc_same += (uint32_t)__builtin_popcountll(__ballot(isR && req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u));
+#ifdef BT_PROFILE
+			/* how much of the search runs on ranges that are one BWT row (round 5: the measurement behind locus mode) */
+			{
+				const bool sEx = isR && L.lfk == LFK_EX2 && (uint32_t)req.x == (uint32_t)req.a + 1u;
+				const bool sAny = sEx || (isR && L.lfk == LFK_LF1);
+				const unsigned long long bEx = __ballot(sEx), bRun = __ballot(sAny && !pf_prevSingle);
+				if ((threadIdx.x & 63u) == 0) { atomicAdd(&CNT[CN_N + PS_SINGLE_LFEX], (unsigned long long)__builtin_popcountll(bEx)); atomicAdd(&CNT[CN_N + PS_SINGLE_RUNS], (unsigned long long)__builtin_popcountll(bRun)); }
+				if (isR) pf_prevSingle = sAny;
+			}
+#endif
 		}
 		if (live) L.iters++;
 		if (EXT && A.pool && A.park) {
