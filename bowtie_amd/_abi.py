@@ -40,7 +40,8 @@ class HitBatchC(C.Structure):
 
 class OpCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters", "same_pair", "rescans", "cand_scans", "wave_rounds", "fetches")]
+                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters", "same_pair", "rescans", "cand_scans", "wave_rounds", "fetches",
+                 "loc_lfex", "loc_lf1", "loc_chase", "loc_records", "loc_windows")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -43,12 +43,16 @@
 #if defined(__HIPCC__)
 #define BF_FN static __host__ __device__
 #define BF_INL __host__ __device__ __forceinline__
-/* the automaton's own layer is inlined into its kernel's loop: as real functions its pieces take the lane's records by
- * reference, and a record whose address is handed to a call lives in scratch memory for the whole kernel */
-#ifdef BF_NO_FNI      /* A/B build: the automaton's layer as real calls again (round 4's state before cc149e9) */
-#define BF_FNI static __host__ __device__
-#else
+/* The automaton's own layer as real calls (the default) or inlined into its kernel's loop (-DBF_FNI_INLINE).  As real
+ * functions its pieces take the lane's records by reference, and a record whose address is handed to a call lives in scratch
+ * memory for the whole kernel; inlined, the loop is one 100 k-instruction body.  Measured both ways (profiles/r5/call1_SUMMARY.txt,
+ * profiles/r4/eleventh_call_inlined_layer_ecoli.txt): at hg19 scale, where the library picks the automaton, calls win
+ * (BASELINE config 5's share 10.09 against 9.57 M reads/s); on e_coli with the automaton forced, inlining does (29.1 against
+ * 23.7 M) -- but there the library picks the call-by-call kernel anyway. */
+#ifdef BF_FNI_INLINE
 #define BF_FNI static __host__ __device__ __attribute__((always_inline))
+#else
+#define BF_FNI static __host__ __device__
 #endif
 #else
 #define BF_FN static

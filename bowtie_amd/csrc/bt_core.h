@@ -75,13 +75,13 @@ enum {
 	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25 | ccValid<<26 (LDS copy only) */
 	FR_W3,       /* f2 | f3<<11                                                                  */
 	FR_W4,       /* altNum | eligibleNum<<12                                                     */
-	FR_W5,       /* cand                                                                         */
+	FR_W5,       /* cand | dcf<<11 | lmode<<22 | lt<<23 | lz<<25 (locus mode, below)                 */
 	FR_W6,       /* pi | pj<<11 | pel<<13                                                        */
 	FR_PTOP, FR_PBOT, FR_EBASE,
-	FR_MM,       /* mismatch chosen at this level: query offset | refc<<16                       */
-	FR_PAD
+	FR_ANCHOR,   /* locus mode: the frame's anchor (text offset of its row's suffix + depth)       */
+	FR_MM        /* mismatch chosen at this level: query offset | refc<<16                       */
 };
-#define BT_TOS_WORDS 10      /* FR_W0..FR_EBASE travel to the LDS top-of-stack copy              */
+#define BT_TOS_WORDS 11      /* FR_W0..FR_ANCHOR travel to the LDS top-of-stack copy             */
 #define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
 #define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
 
@@ -104,17 +104,17 @@ struct BtScratch {
 	                       smaller LDS allocation when the candidate caches are off) */
 	uint32_t  noCC;     /* 1: no LDS candidate caches (the 3-waves-per-SIMD build: LDS holds the read and
 	                       the top-of-stack record only); choosing a target then always fetches its ranges */
-	uint32_t  rlQual;   /* first quality word of `rl` = number of base words (14, or 13 for <= 104 bases) */
+	uint32_t  rlMax;    /* longest read this build's LDS copy holds (112, or 104 in the 3-waves-per-SIMD build) */
 	uint32_t* rl;       /* LDS copy of the lane's whole read (reads of <= BT_RL_MAXLEN bases; RL builds of the
-	                       automaton): word w at rl[w*tosStride]; [0,14) the bases, 4 bits each,
-	                       [14,42) the qualities, one byte each */
+	                       automaton): word w at rl[w*tosStride]; [0,7) the bases, TWO bits each (16 to a word:
+	                       what the text is packed as, so that a stretch of the read is compared with the text by
+	                       XOR), [7,7+rlMax/4) the qualities, one byte each, bit 7 = "this base is an N" */
 };
 #define BT_RL_MAXLEN 112u
-#define BT_RL_SEQ_WORDS 14u
-#define BT_RL_WORDS 42u
-#define BT_RL3_MAXLEN 104u       /* the 3-waves-per-SIMD build: 13 base words + 26 quality words */
-#define BT_RL3_SEQ_WORDS 13u
-#define BT_RL3_WORDS 39u
+#define BT_RL_SEQ_WORDS 7u
+#define BT_RL_WORDS 35u
+#define BT_RL3_MAXLEN 104u       /* the 3-waves-per-SIMD build: 7 base words + 26 quality words */
+#define BT_RL3_WORDS 33u
 
 /* ---- batch-level arguments --------------------------------------------------------------- */
 struct BtHitRec {            /* == bt_hit (include/bowtie_amd.h) */
@@ -151,6 +151,11 @@ struct BtWarm {
 	const uint32_t* ftab[2];
 	const uint32_t* offs[2];
 	uint32_t zOff[2], offMask[2], offRate[2], ftabChars[2], len[2];
+	/* the locus image (bt_rank.h), all NULL / 0 when it was not built or is switched off */
+	const BtU4*     loc[2];
+	const uint32_t* rtxt[2];
+	const uint16_t* walk[2];
+	uint32_t locOn, pad;
 };
 #define BT_BATCH_RING 16
 struct BtCold {
@@ -189,6 +194,7 @@ enum {
 	ST_IDLE = 0,
 	/* fast states */
 	ST_STEP_BEGIN, ST_STEP_LFDONE, ST_STEP_POST, ST_CHASE_CHECK, ST_CHASE_LFDONE, ST_WIN_DONE,
+	ST_LOC_REC, ST_LOC_TXT, ST_STEP_LOC,      /* locus mode: a row's locus record / a text window arrived; a step decided by text */
 	/* slow states */
 	ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FTABSEQ_DONE, ST_FTAB_DONE, ST_FRAME_ENTER, ST_BT_LOOP, ST_BT_PICK,
 	ST_CANDSCAN, ST_CANDSCAN_DONE, ST_CHILD_RET, ST_RESCAN, ST_RESCAN_DONE, ST_FRAME_RETURN,
@@ -201,7 +207,11 @@ enum { LFK_EX2 = 0, LFK_C2, LFK_LF1, LFK_CHASE };
 
 /* op counters (bt_op_counts order) */
 enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_FRAMES, CN_ITERS, CN_SAMEPAIR,
-       CN_RESCAN, CN_CANDSCAN, CN_WROUNDS, CN_FETCH, CN_N };
+       CN_RESCAN, CN_CANDSCAN, CN_WROUNDS, CN_FETCH,
+       /* locus mode: the reference's mapLFEx / mapLF1 / SA-walk steps that were decided by text comparison or by the dense
+        * suffix array instead of being gone through (they are part of bt_op_counts' lfex / lf1 / chase all the same), the locus
+        * records and the text windows fetched for it */
+       CN_TLFEX, CN_TLF1, CN_TCHASE, CN_LOCREC, CN_TXTWIN, CN_N };
 #if defined(__HIP_DEVICE_COMPILE__)
 /* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
 #define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)
@@ -255,10 +265,17 @@ struct BtLane {
 	uint32_t cand : 11, scanCb : 16;         /* scanCb: next chunk (8 records) of a running frame scan */
 	uint32_t ebase;
 	/* per-position temporaries that live across the wait + control */
-	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, ra_cont : 2;
+	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, ra_cont : 2,
+	         /* locus mode (RL builds, when the index has its locus image): the frame's range is one BWT row whose place in the
+	          * text is known -- `top` holds the ANCHOR (text offset of the row's suffix + depth: the base compared at depth
+	          * d is T[anchor - d - 1]) and bot = top + 1 (top: the range became empty) -- from depth `dcf` on.  The frame's
+	          * range-stack entries are its positions below dcf plus ONE for its last position (bt_ent) */
+	         lmode : 1, dcf : 11;
 	/* pending backtrack target */
 	uint32_t pi : 11, pj : 2, btham : 16;
-	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1, wpf : 1, cchunk : 8;   /* cchunk: the cached 16-byte chunk of the read (register-window build), 0xff = none */
+	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1, wpf : 1, cchunk : 8,   /* cchunk: the cached 16-byte chunk of the read (register-window build), 0xff = none */
+	         lt : 2, lz : 1,      /* locus mode: the text's base at the frame's last position (its one alternative there); lz: there is none (text start) */
+	         ra_l : 1;            /* the alignment being reported comes from locus mode: ra_top is an anchor, not a row */
 	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
@@ -300,19 +317,22 @@ BT_HD uint32_t bt_apply_muts(const BtLane& L, uint32_t i, uint32_t c)
 /* query char / quality at index i of the string setQuery selected (ebwt_search_backtrack.h:90-140),
  * with the seedling mutations applied (:1368-1382).  RL: from the lane's LDS copy of the read;
  * otherwise a direct (synchronous) global load, used on rare paths only. */
-BT_HD uint32_t bt_rl_base(const BtScratch& S, uint32_t j)
+/* the LDS copy: base j as a 2-bit code (an N reads as 0 here), its quality byte with the N flag in bit 7 */
+BT_HD uint32_t bt_rl_base2(const BtScratch& S, uint32_t j)
 {
-	return (S.rl[(j >> 3) * S.tosStride] >> ((j & 7u) * 4u)) & 0xfu;
+	return (S.rl[(j >> 4) * S.tosStride] >> ((j & 15u) * 2u)) & 3u;
 }
-BT_HD uint32_t bt_rl_qual(const BtScratch& S, uint32_t j)
+BT_HD uint32_t bt_rl_qbyte(const BtScratch& S, uint32_t j)
 {
-	return (S.rl[(S.rlQual + (j >> 2)) * S.tosStride] >> ((j & 3u) * 8u)) & 0xffu;
+	return (S.rl[(BT_RL_SEQ_WORDS + (j >> 2)) * S.tosStride] >> ((j & 3u) * 8u)) & 0xffu;
 }
 template <bool RL>
 BT_HD uint32_t bt_qry(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t c = RL ? bt_rl_base(S, j) : (uint32_t)BT_GP(const uint8_t, H.seq)[L.roff + j];
+	uint32_t c;
+	if (RL) { c = bt_rl_base2(S, j); if (L.hasN && (bt_rl_qbyte(S, j) & 0x80u)) c = 4u; }
+	else c = (uint32_t)BT_GP(const uint8_t, H.seq)[L.roff + j];
 	if (!L.readFw && c < 4u) c ^= 3u;
 	return bt_apply_muts(L, i, c);
 }
@@ -320,25 +340,25 @@ template <bool RL>
 BT_HD uint32_t bt_qual(const BtLane& L, const BtHot& H, const BtScratch& S, uint32_t i)
 {
 	uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t v = RL ? bt_rl_qual(S, j) : (uint32_t)BT_GP(const uint8_t, H.qual)[L.roff + j];
+	uint32_t v = RL ? (bt_rl_qbyte(S, j) & 0x7fu) : (uint32_t)BT_GP(const uint8_t, H.qual)[L.roff + j];
 	return v >= 33u ? v - 33u : 0u;
 }
 /* copy the lane's read into its LDS slot (RL): 16 bases + 16 qualities per step */
 BT_HD void bt_rl_store_chunk(const BtScratch& S, uint32_t base, const BtU4& sv, const BtU4& qv)
 {
 	const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
-	uint32_t p[4];
+	uint32_t p = 0;
 	BT_UNROLL
 	for (int k = 0; k < 4; k++)
-		p[k] = (w[k] & 0xfu) | ((w[k] >> 4) & 0xf0u) | ((w[k] >> 8) & 0xf00u) | ((w[k] >> 12) & 0xf000u);
+		p |= ((w[k] & 3u) | ((w[k] >> 6) & 0xcu) | ((w[k] >> 12) & 0x30u) | ((w[k] >> 18) & 0xc0u)) << (8 * k);
 	const uint32_t ts = S.tosStride;
-	/* the last chunk of a 104-base layout (13 + 26 words) is half a chunk: its upper half is padding */
-	const bool full = (base >> 3) + 1u < S.rlQual;
-	S.rl[((base >> 3) + 0u) * ts] = p[0] | (p[1] << 16);
-	if (full) S.rl[((base >> 3) + 1u) * ts] = p[2] | (p[3] << 16);
-	const uint32_t qb = S.rlQual + (base >> 2);
-	S.rl[(qb + 0u) * ts] = qv.x; S.rl[(qb + 1u) * ts] = qv.y;
-	if (full) { S.rl[(qb + 2u) * ts] = qv.z; S.rl[(qb + 3u) * ts] = qv.w; }
+	/* the last chunk of a 104-base layout (26 quality words) is half a chunk: its upper half is padding */
+	const bool full = base + 16u <= S.rlMax;
+	S.rl[(base >> 4) * ts] = p;
+	const uint32_t qb = BT_RL_SEQ_WORDS + (base >> 2);
+	/* an N (code 4) has bit 2 set: it goes to bit 7 of the base's quality byte (qualities are ASCII, below 128) */
+	S.rl[(qb + 0u) * ts] = (qv.x & 0x7f7f7f7fu) | ((w[0] & 0x04040404u) << 5); S.rl[(qb + 1u) * ts] = (qv.y & 0x7f7f7f7fu) | ((w[1] & 0x04040404u) << 5);
+	if (full) { S.rl[(qb + 2u) * ts] = (qv.z & 0x7f7f7f7fu) | ((w[2] & 0x04040404u) << 5); S.rl[(qb + 3u) * ts] = (qv.w & 0x7f7f7f7fu) | ((w[3] & 0x04040404u) << 5); }
 }
 BT_HD void bt_rl_load(const BtLane& L, const BtHot& H, const BtScratch& S)
 {
@@ -389,6 +409,19 @@ BT_HD uint32_t bt_off_code(uint32_t plen, uint32_t qs, uint32_t code)
 	       code == BT_OC_S3 ? (qs >> 1) : ((qs >> 1) + (qs & 1u));
 }
 
+/* Range-stack entry of position i of the current frame.  A frame in locus mode has entries for its positions below dcf
+ * (they were gone through in row space) and ONE more, for the position it stops at: the positions between are stretches
+ * that matched the text, which no scan and no backtrack ever looks at (a matching position has nothing to substitute). */
+BT_HD uint32_t bt_ent(const BtLane& L, uint32_t i)
+{
+	return L.ebase + ((L.lmode && i >= L.dcf ? (uint32_t)L.dcf : i) - L.depth);
+}
+/* ... and back: the position of the entry `t` places above the entry of position `from` */
+BT_HD uint32_t bt_ent_pos(const BtLane& L, uint32_t from, uint32_t t)
+{
+	return (L.lmode && from + t >= L.dcf) ? (uint32_t)L.d : from + t;
+}
+
 /* current position through the register window; false if the window has to be fetched first */
 BT_HD bool bt_window_get(const BtLane& L, uint32_t i, uint32_t* c_out, uint32_t* q_out)
 {
@@ -407,8 +440,9 @@ BT_HD bool bt_window_get(const BtLane& L, uint32_t i, uint32_t* c_out, uint32_t*
 BT_HD void bt_read_get(const BtLane& L, const BtScratch& S, uint32_t i, uint32_t* c_out, uint32_t* q_out)
 {
 	const uint32_t j = L.rev ? (L.plen - 1u - i) : i;
-	uint32_t c = bt_rl_base(S, j);
-	const uint32_t v = bt_rl_qual(S, j);
+	uint32_t c = bt_rl_base2(S, j);
+	uint32_t v = bt_rl_qbyte(S, j);
+	if (v & 0x80u) { c = 4u; v &= 0x7fu; }
 	if (!L.readFw && c < 4u) c ^= 3u;
 	*c_out = bt_apply_muts(L, i, c);
 	*q_out = v >= 33u ? v - 33u : 0u;
@@ -463,7 +497,7 @@ BT_HD void bt_lane_start(BtLane& L, const BtProgram& P, const BtHot& H, const Bt
 	L.cchunk = 0xffu;
 	L.iters = 0; L.tosValid = 0; L.ccValid = 0; L.bid = C.curBid;
 	L.state = ST_PHASE_NEXT;
-	if (RL && L.plen > S.rlQual * 8u) {
+	if (RL && L.plen > S.rlMax) {
 		/* longer than this build keeps in LDS (the caller's bt_ctx_set_max_read_len promise did not hold): not
 		 * searched, flagged */
 		L.plen = 0; L.status = BT_STF_OVERFLOW;
@@ -575,8 +609,8 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 }
 
 /* Begin reportAlignment (ebwt_search_backtrack.h:1455-1513) for `sd` mismatches on [top,bot). */
-#define BT_GOTO_RA(SD, TOP, BOT, COST, CONT) \
-	do { L.ra_sd = (SD); L.ra_top = (TOP); L.ra_bot = (BOT); L.ra_cost = (COST); L.ra_cont = (CONT); \
+#define BT_GOTO_RA(SD, TOP, BOT, COST, CONT, LOC) \
+	do { L.ra_sd = (SD); L.ra_top = (TOP); L.ra_bot = (BOT); L.ra_cost = (COST); L.ra_cont = (CONT); L.ra_l = (LOC) ? 1u : 0u; \
 	     L.state = ST_RA_BEGIN; } while (0)
 
 /* A frame scan (re-scan for the next eligible quality, or search for the deepest remaining target)
@@ -619,6 +653,101 @@ BT_HD void bt_candscan_piece(const BtU4& q, uint32_t t0, uint32_t span, uint32_t
 	}
 }
 
+
+/* ---- locus mode: the pieces ---------------------------------------------------------------------------------------------
+ * (RL builds.)  Reference behaviour replaced: the mapLF1 / one-row mapLFEx steps of GreedyDFSRangeSource::backtrack
+ * (ebwt_search_backtrack.h:544-566 with ebwt.h:2334-2380, 2494-2512) from the step at which the range is one row [top, top+1).
+ * That row's suffix starts at SA[top] in the joined text; extending it by a base c succeeds iff the text's base to the left is
+ * c, and the new row's suffix starts one to the left.  So with anchor = SA[top] + d the base met at depth d' >= d is
+ * T[anchor - d' - 1] (none if anchor == d': the '$' row, where mapLF1 gives OFF_MASK and mapLFEx four empty ranges), the
+ * mapLFEx quartet there is "the text's base has the one row, the other three are empty", and everything the reference does
+ * between two depths at which read and text differ -- elims that allow nothing, no alternatives, no eligibility changes --
+ * leaves no trace.  The automaton therefore jumps from event to event: the next depth at which read and text differ, the
+ * end of the read, the half-and-half boundaries. */
+BT_HD uint32_t bt_rev2(uint32_t x)                          /* the sixteen 2-bit groups of x in reverse order */
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t r = __builtin_bitreverse32(x);
+#else
+	uint32_t r = x;
+	r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1); r = ((r >> 2) & 0x33333333u) | ((r & 0x33333333u) << 2);
+	r = ((r >> 4) & 0x0f0f0f0fu) | ((r & 0x0f0f0f0fu) << 4); r = ((r >> 8) & 0x00ff00ffu) | ((r & 0x00ff00ffu) << 8);
+	r = (r >> 16) | (r << 16);
+#endif
+	return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+/* the query's characters at depths dd .. dd+15, two bits each, depth dd lowest (positions beyond the query hold garbage) */
+BT_HD uint32_t bt_loc_qword(const BtLane& L, const BtScratch& S, uint32_t dd)
+{
+	/* depth dd is query index qlen-1-dd, which is read position j = rev ? plen-qlen+dd : qlen-1-dd: ascending with the
+	 * depth in the one case, descending in the other (then the stretch is fetched from its low end and turned round) */
+	const int32_t jl = L.rev ? (int32_t)(L.plen - L.qlen + dd) : (int32_t)(L.qlen - 1u - dd) - 15;
+	const uint32_t ts = S.tosStride;
+	uint32_t seg;
+	if (jl >= 0) {
+		const uint32_t w = (uint32_t)jl >> 4, sh = 2u * ((uint32_t)jl & 15u);
+		const uint64_t two = (uint64_t)S.rl[w * ts] | ((uint64_t)S.rl[(w + 1u) * ts] << 32);
+		seg = (uint32_t)(two >> sh);
+	} else {
+		seg = S.rl[0] << (2u * (uint32_t)(-jl));             /* -jl = 1..15 */
+	}
+	if (!L.rev) seg = bt_rev2(seg);
+	if (!L.readFw) seg = ~seg;
+	if (L.nmuts) {
+		/* the seedling's substitutions (bt_apply_muts), by query index */
+		const uint32_t r0 = L.qlen - 1u - L.mutpos0 - dd, r1 = L.qlen - 1u - L.mutpos1 - dd, r2 = L.qlen - 1u - L.mutpos2 - dd;
+		if (r0 < 16u) seg = (seg & ~(3u << (2u * r0))) | ((uint32_t)L.mutnew0 << (2u * r0));
+		if (L.nmuts > 1 && r1 < 16u) seg = (seg & ~(3u << (2u * r1))) | ((uint32_t)L.mutnew1 << (2u * r1));
+		if (L.nmuts > 2 && r2 < 16u) seg = (seg & ~(3u << (2u * r2))) | ((uint32_t)L.mutnew2 << (2u * r2));
+	}
+	return seg;
+}
+/* How many of the depths [lo, hi) are alternatives as far as the qualities go (ham + penalty(q) <= qualThresh): what tells a
+ * mapLFEx step from a mapLF1 step in a stretch that is skipped.  Four quality bytes per LDS word. */
+BT_HD uint32_t bt_loc_count_alt(const BtLane& L, const BtScratch& S, uint32_t lo, uint32_t hi)
+{
+	if (hi <= lo) return 0;
+	if (!L.considerQuals) return hi - lo;
+	if (L.ham > L.qualThresh) return 0;
+	const uint32_t P = L.qualThresh - L.ham;
+	uint32_t qlim;
+	if (!L.maq) qlim = P > 93u ? 93u : P;
+	else qlim = P >= 30u ? 93u : P >= 20u ? 24u : P >= 10u ? 14u : 4u;
+	const uint32_t thr = (qlim + 33u) * 0x01010101u | 0x80808080u;       /* a byte v <= qlim + 33  <=>  bit 7 of (0x80 + qlim + 33 - v) */
+	const uint32_t jlo = L.rev ? L.plen - L.qlen + lo : L.qlen - hi, jhi = jlo + (hi - lo);
+	const uint32_t ts = S.tosStride;
+	uint32_t n = 0;
+	BT_NOUNROLL
+	for (uint32_t w = jlo >> 2; w <= (jhi - 1u) >> 2; w++) {
+		uint32_t m = (thr - (S.rl[(BT_RL_SEQ_WORDS + w) * ts] & 0x7f7f7f7fu)) & 0x80808080u;
+		if (w == jlo >> 2) m &= 0xffffffffu << (8u * (jlo & 3u));
+		if (w == (jhi - 1u) >> 2) m &= 0xffffffffu >> (8u * (3u - ((jhi - 1u) & 3u)));
+		n += (uint32_t)__builtin_popcount(m);
+	}
+	return n;
+}
+/* A window of the text in depth order: eight words (sixteen characters each) starting `sh` characters before depth w0; the
+ * first depth at or after d, and below lim, at which the query differs from it (0xffffffff: none), and the text's base there. */
+BT_HD uint32_t bt_loc_first_mm(const BtLane& L, const BtScratch& S, const uint32_t wt[9], uint32_t sh, uint32_t w0,
+                               uint32_t d, uint32_t lim, uint32_t* tOut)
+{
+	uint32_t fm = 0xffffffffu, tf = 0;
+	BT_UNROLL
+	for (int k = 6; k >= 0; k--) {                     /* the shallowest word last: its answer stays */
+		const uint32_t wb = w0 + 16u * (uint32_t)k;
+		if (wb < lim && wb + 16u > d) {
+			const uint32_t td = (uint32_t)((((uint64_t)wt[k + 1] << 32) | wt[k]) >> (2u * sh));
+			uint32_t x = bt_loc_qword(L, S, wb) ^ td;
+			x = (x | (x >> 1)) & 0x55555555u;
+			if (d > wb) x &= 0xffffffffu << (2u * (d - wb));
+			if (lim < wb + 16u) x &= 0xffffffffu >> (2u * (wb + 16u - lim));
+			if (x) { const uint32_t b = (uint32_t)__builtin_ctz(x); fm = wb + (b >> 1); tf = (td >> b) & 3u; }
+		}
+	}
+	*tOut = tf;
+	return fm;
+}
+
 /* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
 template <bool RL>
 BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
@@ -635,7 +764,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 		BT_PROF_PASS();
 		/* ---- ran off the 5' end of the query (:1086-1090) ------------------------------- */
 		if (ST_IS(ST_FELL_OFF)) { BT_PROF_T0(t_fell_off); do {
-			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL);
+			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL, L.lmode);
 			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
 		} while (0); BT_PROF_ADD(PS_FELL_OFF, t_fell_off); }
 
@@ -643,7 +772,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 		if (ST_IS(ST_RESOLVE_DONE)) { BT_PROF_T0(t_resolve_done); do {
 			const uint32_t zOff = WSEL(zOff);
 			uint32_t off;
-			if (L.crow == zOff) off = L.cjumps;
+			if (W.locOn) {
+				/* no walk: the alignment was found in locus mode (its text offset is known: anchor - qlen), or the row's
+				 * locus record has just arrived (word 0 = SA[row]).  The walk the reference does from here is tallied from
+				 * the table of walk lengths */
+				off = (RL && L.ra_l) ? L.crow - L.qlen : res.q[0].x;
+				BT_COUNT_N(CN_TCHASE, BT_GP(const uint16_t, WSEL(walk))[off]);
+			}
+			else if (L.crow == zOff) off = L.cjumps;
 			else off = bt_u4_word(res.q[0], (L.crow >> WSEL(offRate)) & 3u) + L.cjumps;
 			BT_COUNT(CN_OFFS);
 			/* joinedToTextOff (ebwt.h:2569-2629) */
@@ -681,7 +817,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			switch (L.ra_cont) {
 			case RC_STEP:
 				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
-				L.top = L.bot;                                   /* keep looking (:730-735) */
+				if (RL && L.lmode) L.bot = L.top; else L.top = L.bot;     /* keep looking (:730-735); in locus mode `top` is the anchor and stays */
 				if (L.altNum > 0) L.state = ST_BT_LOOP;
 				else { L.ret = 0; L.state = ST_FRAME_RETURN; }
 				break;
@@ -700,7 +836,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.state == ST_FRAME_FETCHED) {
 				w[0] = res.q[0].x; w[1] = res.q[0].y; w[2] = res.q[0].z; w[3] = res.q[0].w;
 				w[4] = res.q[1].x; w[5] = res.q[1].y; w[6] = res.q[1].z; w[7] = res.q[1].w;
-				w[8] = res.q[2].x; w[9] = res.q[2].y;
+				w[8] = res.q[2].x; w[9] = res.q[2].y; w[10] = res.q[2].z;
 			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
 				BT_UNROLL
@@ -726,10 +862,11 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
 			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
-			L.cand = w[FR_W5] & 0x7ffu;
+			v = w[FR_W5]; L.cand = v & 0x7ffu; L.dcf = (v >> 11) & 0x7ffu; L.lmode = (v >> 22) & 1u; L.lt = (v >> 23) & 3u; L.lz = (v >> 25) & 1u;
 			v = w[FR_W6]; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
 			L.pbttop = w[FR_PTOP]; L.pbtbot = w[FR_PBOT];
 			L.ebase = w[FR_EBASE];
+			if (L.lmode) { L.top = w[FR_ANCHOR]; L.bot = L.top; }      /* the anchor; a frame that has a child stands on an empty range */
 			L.state = ST_CHILD_RET;
 		} while (0); BT_PROF_ADD(PS_FRAME_RETURN, t_frame_return); }
 
@@ -740,7 +877,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; break;
 			}
 			{
-				const uint32_t e = L.ebase + (L.pi - L.depth);
+				const uint32_t e = bt_ent(L, L.pi);
 				const uint32_t el = L.pel | (1u << L.pj);           /* the mask travelled with the frame record */
 				META_MASK(e) = (uint8_t)el;
 				L.pel = el;
@@ -757,14 +894,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_COUNT(CN_RESCAN);
 				L.lowAltQual = 0xff; L.candValid = 0; L.ccValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
-				if (L.d >= kmin) { L.scanCb = (L.ebase + (L.d - L.depth)) >> 3; L.state = ST_RESCAN; break; }
+				if (L.d >= kmin) { L.scanCb = bt_ent(L, L.d) >> 3; L.state = ST_RESCAN; break; }
 			}
 			L.state = ST_BT_LOOP;
 		} while (0); BT_PROF_ADD(PS_CHILD_RET, t_child_ret); }
 
 		if (ST_IS(ST_RESCAN) || ST_IS(ST_RESCAN_DONE)) { BT_PROF_T0(t_rescan); do {
 			const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
-			const uint32_t e_lo = L.ebase + (kmin - L.depth), e_hi = L.ebase + (L.d - L.depth);
+			const uint32_t e_lo = bt_ent(L, kmin), e_hi = bt_ent(L, L.d);
 			const uint32_t c_lo = e_lo >> 3;
 			if (L.state == ST_RESCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_RESCAN_DONE; break; }
 			/* the batch (chunks lo..hi) arrived in res.q[0..]; same walk as the reference: deepest
@@ -792,7 +929,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				}
 				L.lowAltQual = a.low; L.eligibleNum = a.num;
 				if (a.cnd != 0xffffffffu) {
-					L.cand = kmin + a.cnd; L.candValid = 1; L.ccValid = 0;
+					L.cand = bt_ent_pos(L, kmin, a.cnd); L.candValid = 1; L.ccValid = 0;
 					L.elcint = (a.cel & 1u) == 0 ? 0u : (a.cel & 2u) == 0 ? 1u : (a.cel & 4u) == 0 ? 2u : 3u;
 					L.elignore = 0;
 				}
@@ -866,7 +1003,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
 		if (ST_IS(ST_SEARCH_BEGIN)) { BT_PROF_T0(t_search_begin); do {
-			L.bailed = 0; L.sd = 0;
+			L.bailed = 0; L.sd = 0; L.lmode = 0; L.dcf = 0;
 			uint32_t nsInFtab = 0;
 			const uint32_t ftabChars = WSEL(ftabChars);
 			if (L.hasN) {
@@ -943,7 +1080,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			BT_COUNT(CN_FTAB);
 			if (L.qlen == ftabChars && bot > top) {
 				if (L.reportPartials > 0) { L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER; }
-				else { L.top = top; L.bot = bot; BT_GOTO_RA(0, top, bot, L.iham, RC_ENTRY); }
+				else { L.top = top; L.bot = bot; BT_GOTO_RA(0, top, bot, L.iham, RC_ENTRY, 0); }
 			} else if (bot > top) {
 				L.depth = ftabChars; L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER;
 			} else { L.ret = 0; L.state = ST_SEARCH_END; }
@@ -955,19 +1092,20 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				/* the deepest position that still has a target of the eligible quality (the
 				 * `for(; i >= depth; i--)` walk of :767-812), batch by batch */
 				BT_COUNT(CN_CANDSCAN);
-				L.scanCb = (L.ebase + (L.d - L.depth)) >> 3;
+				L.scanCb = bt_ent(L, L.d) >> 3;
 				L.state = ST_CANDSCAN;
 				break;
 			}
 			L.state = ST_BT_PICK;
 			if (L.ccValid) break;                        /* its ranges are in LDS: pick right away */
+			if (L.lmode && L.cand >= L.dcf) break;       /* the frame's position in the text: one alternative, the text's base (lt) */
 			/* fetch the target position's four (top,bot) ranges and its (mask,quality) record */
-			const uint32_t e = L.ebase + (L.cand - L.depth);
+			const uint32_t e = bt_ent(L, L.cand);
 			BT_REQ_FETCH(&PT(e, 0), 2, &META(e & ~7u));
 		} while (0); BT_PROF_ADD(PS_BT_LOOP, t_bt_loop); }
 
 		if (ST_IS(ST_CANDSCAN) || ST_IS(ST_CANDSCAN_DONE)) { BT_PROF_T0(t_candscan); do {
-			const uint32_t e_lo = L.ebase, e_hi = L.ebase + (L.d - L.depth);
+			const uint32_t e_lo = L.ebase, e_hi = bt_ent(L, L.d);
 			const uint32_t c_lo = e_lo >> 3;
 			if (L.state == ST_CANDSCAN) { bt_scan_request(L, S, c_lo, req); L.state = ST_CANDSCAN_DONE; break; }
 			const uint32_t hi = L.scanCb, lo = hi >= c_lo + 3u ? hi - 3u : c_lo;
@@ -984,7 +1122,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				}
 			}
 			const bool found = cnd != 0xffffffffu;
-			if (found) { L.cand = L.depth + cnd; L.candValid = 1; L.ccValid = 0; }
+			if (found) { L.cand = bt_ent_pos(L, L.depth, cnd); L.candValid = 1; L.ccValid = 0; }
 			if (found) { L.state = ST_BT_LOOP; break; }
 			if (lo > c_lo) { L.scanCb = lo - 1u; L.state = ST_CANDSCAN; break; }
 			L.state = ST_ABORT;                                   /* cannot happen: altNum > 0 */
@@ -992,10 +1130,17 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 
 		if (ST_IS_NOREQ(ST_BT_PICK)) { BT_PROF_T0(t_bt_pick); do {
 			const uint32_t i = L.cand;
-			const uint32_t e = L.ebase + (i - L.depth);
+			const uint32_t e = bt_ent(L, i);
 			const uint32_t ts = S.tosStride;
 			uint32_t mv, tp[4], bp[4];
-			if (L.ccValid) {
+			const bool locTarget = L.lmode && i >= L.dcf;
+			if (locTarget && !L.ccValid) {
+				/* a position decided by the text has one alternative, the text's base there, on the one row that goes with it;
+				 * it is picked at most once (afterwards its mask is full), so its mask is the fresh one */
+				BT_UNROLL
+				for (uint32_t k = 0; k < 4u; k++) { tp[k] = 0; bp[k] = (k == L.lt) ? 1u : 0u; }
+				mv = (15u ^ (1u << L.lt)) | (bt_qual<RL>(L, H, S, L.qlen - i - 1u) << 8);
+			} else if (L.ccValid) {
 				BT_UNROLL
 				for (uint32_t k = 0; k < 4u; k++) { tp[k] = S.tos[k * ts]; bp[k] = S.tos[(4u + k) * ts]; }
 				mv = S.tos[8u * ts];
@@ -1030,7 +1175,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			} else {
 				j = L.elcint;                                     /* the only eligible target: no draw (:820-834) */
 			}
-			const uint32_t bttop = bt_sel4(j, tp[0], tp[1], tp[2], tp[3]);
+			/* a child of a position in the text stands on the same anchor, one position further */
+			const uint32_t bttop = locTarget ? L.top : bt_sel4(j, tp[0], tp[1], tp[2], tp[3]);
 			const uint32_t btbot = bttop + bt_sel4(j, sp[0], sp[1], sp[2], sp[3]);
 			const uint32_t btham = L.ham + bt_mm_penalty(L.maq, qi);
 			const uint32_t btcint = j;
@@ -1043,10 +1189,11 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			FRW(L.sd, FR_MM) = icur | (btcint << 16);
 			L.pi = i; L.pj = j; L.pbttop = bttop; L.pbtbot = btbot; L.btham = btham;
 			if (i + 1u == L.qlen) {
-				BT_GOTO_RA(L.sd + 1u, bttop, btbot, btham, RC_CHILD);
+				BT_GOTO_RA(L.sd + 1u, bttop, btbot, btham, RC_CHILD, locTarget);
 				break;
 			}
 			uint32_t newDepth = i + 1u, ntop = bttop, nbot = btbot;
+			bool childLoc = locTarget;
 			const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
 			const uint32_t ftabChars = WSEL(ftabChars);
 			if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < ftabChars && ftabChars <= L.d5) {
@@ -1065,6 +1212,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_COUNT(CN_FTAB);
 				if (ntop == nbot) { L.ret = 0; L.state = ST_CHILD_RET; break; }
 				newDepth = ftabChars;
+				childLoc = false;                             /* rows again */
 			}
 			/* push: save the parent (HBM record + LDS top-of-stack copy), enter the child */
 			if (L.sd + 1u >= S.a->frCap) { L.state = ST_ABORT; break; }
@@ -1075,13 +1223,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (L.ccValid << 26);
 				w[FR_W3] = L.f2 | (L.f3 << 11);
 				w[FR_W4] = L.altNum | (L.eligibleNum << 12);
-				w[FR_W5] = L.cand;
+				w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25);
 				w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
 				w[FR_PTOP] = L.pbttop; w[FR_PBOT] = L.pbtbot; w[FR_EBASE] = L.ebase;
+				w[FR_ANCHOR] = L.top;
 				uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
 				BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
 				bt_st4(fr, q0); bt_st4(fr + 4, q1);
-				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE];
+				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE]; FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
 				BT_UNROLL
 				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
 				if (L.ccValid) {
@@ -1090,7 +1239,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				}
 				L.tosFrame = L.sd; L.tosValid = 1;
 			}
-			L.ebase = L.ebase + (L.d - L.depth + 1u);
+			L.ebase = bt_ent(L, L.d) + 1u;
+			L.lmode = childLoc ? 1u : 0u; L.dcf = childLoc ? newDepth : 0u;
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
@@ -1129,7 +1279,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			uint32_t ri = L.ra_r + L.ra_i;
 			if (ri >= L.ra_bot) ri -= spread;
 			L.crow = ri; L.cjumps = 0;
-			L.state = ST_CHASE_CHECK;
+			L.state = (RL && L.ra_l) ? ST_RESOLVE_DONE : ST_CHASE_CHECK;       /* in locus mode "the row" is the anchor: nothing to walk */
 		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
 
 		/* ---- frame prologue (:363-455) -------------------------------------------------- */
@@ -1160,8 +1310,103 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
 	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
+	/* locus mode: the window of text this call's answer holds (0 none, 1 a locus record's 48 characters, 2 pieces of the
+	 * reversed text), the depth it starts at and the anchor it belongs to; whether the step just decided was a mismatch */
+	uint32_t wkind = 0, wd0 = 0, wanchor = 0;
+	bool locMiss = false;
 	for (;;) {
 		BT_PROF_T0(t_resume);
+		if (RL && (L.state == ST_LOC_REC || L.state == ST_LOC_TXT)) {
+			if (L.state == ST_LOC_REC) {
+				/* the row's locus record: from here on the frame stands on a place in the text, not on a row */
+				L.lmode = 1; L.dcf = L.d;
+				L.top = res.q[0].x + L.d; L.bot = L.top + 1u;
+				wkind = 1;
+			} else wkind = 2;
+			wd0 = L.d; wanchor = L.top;
+			L.state = ST_STEP_BEGIN;
+		}
+		if (RL && L.state == ST_STEP_BEGIN && L.lmode) {
+			/* ---- locus mode: the next event of the frame (see "locus mode: the pieces") ------------------------ */
+			const uint32_t d = L.d;
+			if (d >= L.qlen) L.state = ST_FELL_OFF;
+			else if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; }
+			else if (bt_ent(L, d) >= S.a->entCap) L.state = ST_ABORT;
+			else {
+				const uint32_t anchor = L.top, len = WSEL(len);
+				const uint32_t y0 = len - anchor + wd0;                 /* first character of a kind-2 window in the reversed text */
+				const uint32_t sh = wkind == 2 ? (y0 & 15u) : 0u;
+				const uint32_t ncov = wkind == 2 ? 128u - sh : BT_LOC_CTX;
+				if (wkind == 0 || wanchor != anchor || d < wd0 || d >= wd0 + ncov) {
+					/* no text at hand for this depth: fetch what is left of the read's length (two 16-byte pieces hold 128
+					 * characters; the address is a word's, not a piece's) */
+					const uint32_t y = len - anchor + d;
+					BT_REQ_FETCH(WSEL(rtxt) + (y >> 4), ((y & 15u) + (L.qlen - d) + 63u) >> 6, nullptr);
+					BT_COUNT(CN_TXTWIN);
+					L.state = ST_LOC_TXT;
+					BT_COUNT_HOST(CN_FETCH);
+					return;
+				}
+				uint32_t wt[9];
+				if (wkind == 1) { wt[0] = res.q[0].y; wt[1] = res.q[0].z; wt[2] = res.q[0].w; wt[3] = wt[4] = wt[5] = wt[6] = wt[7] = 0; }
+				else { wt[0] = res.q[0].x; wt[1] = res.q[0].y; wt[2] = res.q[0].z; wt[3] = res.q[0].w; wt[4] = res.q[1].x; wt[5] = res.q[1].y; wt[6] = res.q[1].z; wt[7] = res.q[1].w; }
+				wt[8] = 0;
+				/* the depths that can be compared: up to the end of the query, of the window, of the text (depth == anchor is
+				 * the '$' row: nothing to the left) */
+				uint32_t lim = L.qlen < wd0 + ncov ? (uint32_t)L.qlen : wd0 + ncov;
+				const bool textEnds = anchor < lim;
+				if (textEnds) lim = anchor;
+				uint32_t tf;
+				const uint32_t fm = bt_loc_first_mm(L, S, wt, sh, wd0, d, lim, &tf);
+				/* the event: the first mismatch; else a half-and-half boundary; else the text's or the read's end */
+				uint32_t dev = fm;
+				if (L.halfAndHalf) {
+					const uint32_t h[4] = {L.d5 - 1u, L.d5, L.d3 - 1u, L.d3};
+					BT_UNROLL
+					for (int k = 0; k < 4; k++) if (h[k] >= d && h[k] < lim && h[k] < dev) dev = h[k];
+				}
+				if (dev == 0xffffffffu) {
+					if (textEnds) dev = anchor;
+					else if (lim == L.qlen) dev = L.qlen - 1u;
+				}
+				/* what the reference goes through between here and there: one mapLFEx (both rows in one side pair) per
+				 * position that is an alternative, one mapLF1 per position that is not */
+				const uint32_t upto = dev == 0xffffffffu ? lim : dev;
+				{
+					const uint32_t lo = d > L.fu ? d : (uint32_t)L.fu;
+					const uint32_t nalt = bt_loc_count_alt(L, S, lo < upto ? lo : upto, upto);
+					BT_COUNT_N(CN_TLFEX, nalt); BT_COUNT_N(CN_TLF1, (upto - d) - nalt);
+				}
+				if (dev == 0xffffffffu) {
+					/* everything the window holds matches and the read goes on: the next window */
+					L.d = upto;
+					const uint32_t y = len - anchor + upto;
+					BT_REQ_FETCH(WSEL(rtxt) + (y >> 4), ((y & 15u) + (L.qlen - upto) + 63u) >> 6, nullptr);
+					BT_COUNT(CN_TXTWIN);
+					L.state = ST_LOC_TXT;
+					BT_COUNT_HOST(CN_FETCH);
+					return;
+				}
+				/* the step at the event, as STEP_BEGIN would set it up */
+				uint32_t c, q;
+				bt_read_get(L, S, L.qlen - dev - 1u, &c, &q);
+				L.c = c; L.q = q; L.d = dev;
+				const bool alt = (dev >= L.fu) && (!L.considerQuals || (L.ham + bt_mm_penalty(L.maq, q) <= L.qualThresh));
+				bool elig = false, over = false;
+				if (alt) {
+					if (L.considerQuals) {
+						if (q < L.lowAltQual) { elig = true; over = true; }
+						else if (q == L.lowAltQual) elig = true;
+					} else elig = true;
+				}
+				L.fl_alt = alt; L.fl_elig = elig; L.fl_over = over;
+				locMiss = dev == fm || (textEnds && dev == anchor);
+				L.lz = (textEnds && dev == anchor) ? 1u : 0u;
+				if (dev == fm) L.lt = tf;
+				if (alt) BT_COUNT(CN_TLFEX); else BT_COUNT(CN_TLF1);
+				L.state = ST_STEP_LOC;
+			}
+		}
 		/* ---- resume: the read window arrived ------------------------------------------------- */
 		if (!RL && L.state == ST_WIN_DONE) {
 			L.cs0 = res.q[0].x; L.cs1 = res.q[0].y; L.cs2 = res.q[0].z; L.cs3 = res.q[0].w;
@@ -1176,11 +1421,18 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			L.state = ST_CHASE_CHECK;
 		}
 		/* ---- resume: one query position (:456-739) ---------------------------------------- */
-		if (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST) {
+		if (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST || (RL && L.state == ST_STEP_LOC)) {
 			const uint32_t c = L.c, q = L.q, d = L.d, cur = L.qlen - d - 1u;
-			const uint32_t e = L.ebase + (d - L.depth);
+			const uint32_t e = bt_ent(L, d);
 			uint32_t ta[4], tb[4];
-			if (L.state == ST_STEP_LFDONE) {
+			if (RL && L.state == ST_STEP_LOC) {
+				/* decided by the text: the quartet of a one-row range -- the text's base has the one row that goes with it,
+				 * the other three ranges are empty (all four at the text's start); nothing is kept of it but the record */
+				const uint32_t t = locMiss ? (uint32_t)L.lt : c;
+				BT_UNROLL
+				for (uint32_t k = 0; k < 4u; k++) { ta[k] = 0; tb[k] = (k == t && !L.lz) ? 1u : 0u; }
+				L.bot = locMiss ? L.top : L.top + 1u;
+			} else if (L.state == ST_STEP_LFDONE) {
 				if (!RL && L.wpf) {
 					L.cs0 = res.q[3].x; L.cs1 = res.q[3].y; L.cs2 = res.q[3].z; L.cs3 = res.q[3].w;
 					L.cq0 = res.x.x; L.cq1 = res.x.y; L.cq2 = res.x.z; L.cq3 = res.x.w;
@@ -1263,7 +1515,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			}
 			if (frameFail) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else if (cur == 0 && L.bot > L.top && !invalidHH && !invalidExact && !reportedPartial)
-				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP);
+				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP, L.lmode);
 			else if ((L.top == L.bot || btDespite) && L.altNum > 0) L.state = ST_BT_LOOP;
 			else if (mustBacktrack || invalidHH || invalidExact || L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
@@ -1280,10 +1532,21 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 
 		/* ---- emit: next query position (:456-568) -------------------------------------------- */
 		if (L.state == ST_STEP_BEGIN) {
+			if (RL && L.lmode) continue;            /* a frame in locus mode: its next event, at the top of the loop */
 			const uint32_t d = L.d;
 			if (d >= L.qlen) { L.state = ST_FELL_OFF; continue; }
 			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; continue; }
 			if (L.ebase + (d - L.depth) >= S.a->entCap) { L.state = ST_ABORT; continue; }
+			if (RL && W.locOn && !L.hasN && L.top + 1u == L.bot) {
+				/* the range is one row: leave row space (its locus record: where the row's suffix is in the text, and the
+				 * 48 characters to the left of it).  Reads with an N stay in row space: an N never matches, which the packed
+				 * comparison does not know */
+				BT_REQ_FETCH(WSEL(loc) + L.top, 1, nullptr);
+				BT_COUNT(CN_LOCREC);
+				L.state = ST_LOC_REC;
+				BT_COUNT_HOST(CN_FETCH);
+				return;
+			}
 			uint32_t c, q;
 			if (RL) bt_read_get(L, S, L.qlen - d - 1u, &c, &q);
 			else if (!bt_window_get(L, L.qlen - d - 1u, &c, &q)) {
@@ -1335,6 +1598,14 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 		}
 		/* ---- emit: next SA-walk step, or the SA sample once the walk has arrived ---------------- */
 		if (L.state == ST_CHASE_CHECK) {
+			if (W.locOn) {
+				/* the dense suffix array: the row's locus record instead of the walk to a sampled row */
+				BT_REQ_FETCH(WSEL(loc) + L.crow, 1, nullptr);
+				BT_COUNT(CN_LOCREC);
+				L.state = ST_RESOLVE_DONE;
+				BT_COUNT_HOST(CN_FETCH);
+				return;
+			}
 			if ((L.crow & WSEL(offMask)) != L.crow && L.crow != WSEL(zOff)) {
 				BT_REQ_RANK1(L.crow); L.lfk = LFK_CHASE;
 				L.state = ST_CHASE_LFDONE; return;

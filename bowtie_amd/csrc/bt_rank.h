@@ -68,6 +68,19 @@ struct BtIndexDev {
 	uint32_t fchr[5];
 	const uint8_t*  blk;       /* the rank blocks: (len + 1) / 64 + 2 of them, 32 bytes each (see above)          */
 	uint32_t zBlk, zPos;       /* zOff / 64, zOff % 64                                                             */
+	/* ---- the locus image (round 5; optional: loc == NULL means it was not built and the search stays in row space) ----
+	 * Once a range is ONE BWT row the search is no longer a search: the row's suffix sits at one place of the text, and what
+	 * the reference's mapLF1 / single-row mapLFEx steps compute base by base from there on is a string comparison against
+	 * the text to the left of it.  HBM capacity (288 GB) buys that comparison:
+	 *   loc[row]  16 bytes: word 0 = SA[row] (offset of the row's suffix in the joined text); words 1..3 = the 48 text
+	 *             characters to the LEFT of it, two bits each, nearest first (depth order: character k = T[SA-1-k])
+	 *   rtxt      the joined text REVERSED, two bits per base, 16 per word: base y = T[len-1-y] -- reversed so that the
+	 *             characters further left of a position are at increasing addresses, like loc's words
+	 *   walk[p]   u16, by text offset p: the LF steps Ebwt::reportChaseOne's walk (ebwt.h:2727-2746) takes from the row
+	 *             whose suffix starts at p -- what the op counters tally for a hit that no longer walks (saturating) */
+	const BtU4*     loc;
+	const uint32_t* rtxt;
+	const uint16_t* walk;
 	uint32_t wide;             /* the index is a 64-bit (.ebwtl) build.  Its rows still fit 32 bits here, but the
 	                              reference binary that serves it is compiled with 64-bit offsets, and two things
 	                              a user can see follow the offset width: the row a hit is reported from is drawn
@@ -231,6 +244,55 @@ BT_HD void bt_blk_build_host(const BtIndexDev& ix, uint8_t* out)
 		}
 		w[4] = (uint32_t)p0; w[5] = (uint32_t)(p0 >> 32); w[6] = (uint32_t)p1; w[7] = (uint32_t)(p1 >> 32);
 		memcpy(out + b * BT_BLK_BYTES, w, BT_BLK_BYTES);
+	}
+}
+
+/* ---- the locus image, host build (the emulator's; the GPU loader does the same with kernels, bt_kernels.hip) --------------
+ * One pass over the text from its end: row 0 is the suffix "$" (SA = len); LF of the row of suffix p is the row of suffix
+ * p - 1 and the BWT character there is T[p-1].  rtxt: (len + 15) / 16 + 32 words (padding: a window fetch may run past
+ * either end), walk: len + 1 entries, loc: len + 1 records. */
+#define BT_LOC_CTX 48u
+#define BT_RTXT_PAD_WORDS 16u       /* words of padding before rtxt[0] and after its last word */
+BT_HD uint64_t bt_rtxt_words(uint32_t len) { return ((uint64_t)len + 15u) / 16u + 2u * BT_RTXT_PAD_WORDS; }
+BT_HD void bt_loc_build_host(const BtIndexDev& ix, BtU4* loc, uint32_t* rtxtAlloc, uint16_t* walk)
+{
+	uint32_t* rtxt = rtxtAlloc + BT_RTXT_PAD_WORDS;
+	memset(rtxtAlloc, 0, (size_t)bt_rtxt_words(ix.len) * 4u);
+	/* pass 1: rows in text order from the end; SA and the text.  Bowtie sorts the suffix "$" LAST (a suffix that is a prefix
+	 * of another is the greater one): row len is the suffix at offset len */
+	uint32_t row = ix.len;
+	for (uint32_t p = ix.len; ; p--) {
+		loc[row].x = p; loc[row].y = loc[row].z = loc[row].w = 0;
+		if (p == 0) break;                                  /* row == zOff */
+		uint32_t lf[4], L;
+		bt_rank4(ix, row, lf, &L);
+		const uint32_t y = ix.len - p;                      /* T[p-1] = base len-1-(p-1) of the reversed text */
+		rtxt[y >> 4] |= L << (2u * (y & 15u));
+		row = lf[L];
+	}
+	/* pass 2: the walk lengths by text offset -- 0 where the row is sampled (or is the '$' row), else one more than the
+	 * offset before it.  Needs the row of every offset: from loc's SA column, inverted on the fly */
+	{
+		/* rowOf[p] is only needed here: reuse walk[] in two steps -- first mark sampled offsets */
+		for (uint32_t r = 0; r <= ix.len; r++) {
+			const uint32_t p = loc[r].x;
+			walk[p] = ((r & ix.offMask) == r || r == ix.zOff) ? 0u : 1u;
+		}
+		uint32_t run = 0;
+		for (uint32_t p = 0; p <= ix.len; p++) {
+			if (walk[p] == 0u) run = 0; else run = run < 0xffffu ? run + 1u : run;
+			walk[p] = (uint16_t)run;
+		}
+	}
+	/* pass 3: every row's 48 characters of left context, from the reversed text */
+	for (uint32_t r = 0; r <= ix.len; r++) {
+		const uint32_t y0 = ix.len - loc[r].x, w = y0 >> 4, s = 2u * (y0 & 15u);
+		uint32_t c[3];
+		for (int k = 0; k < 3; k++) {
+			const uint64_t two = (uint64_t)rtxt[w + k] | ((uint64_t)rtxt[w + k + 1] << 32);
+			c[k] = (uint32_t)(two >> s);
+		}
+		loc[r].y = c[0]; loc[r].z = c[1]; loc[r].w = c[2];
 	}
 }
 

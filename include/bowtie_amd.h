@@ -156,6 +156,16 @@ typedef struct bt_op_counts {
 	                             lane_iters / wave_rounds = mean active lanes per round        */
 	uint64_t fetches;         /* rounds a lane spent on a non-rank request (read window, backtrack
 	                             target, frame record, record scan, ftab, SA sample)           */
+	/* Locus mode (round 5; csrc/bt_rank.h "the locus image"): once a range is one BWT row the steps above are decided by
+	 * comparing the read with the text, and a reported row's offset comes from a dense suffix array.  The reference's
+	 * steps that were decided that way are COUNTED IN lfex / lf1 / chase above all the same (and a one-row mapLFEx in
+	 * same_pair: its two rows are neighbours; one in 448 such pairs straddles two side pairs, which row space would
+	 * have known and the text does not); these say how many of them, and what was fetched instead. */
+	uint64_t loc_lfex;        /* mapLFEx steps on a one-row range decided by the text           */
+	uint64_t loc_lf1;         /* mapLF1 steps decided by the text                               */
+	uint64_t loc_chase;       /* SA-walk steps not walked (from the table of walk lengths)      */
+	uint64_t loc_records;     /* 16-byte locus records fetched (one per range that became one row, one per reported row) */
+	uint64_t loc_windows;     /* text windows fetched (32 bytes: the read's remaining length)   */
 } bt_op_counts;
 
 /* index geometry, for callers that need it (EbwtParams, ebwt.h:116-321) */

@@ -216,3 +216,15 @@ def result_digest(per_read) -> str:
 def hit_cap_for(kw) -> int:
     """Hit slots per read large enough that no golden case overflows (-a on the tandem repeat)."""
     return 1024 if kw.get("all_hits") else max(64, int(kw.get("khits", 1)))   # >= any -M value used
+
+
+def check_op_counts(oc, gc, what=""):
+    """The product's op counters against the oracle's (= the reference algorithm's): equal -- with one allowance.  A
+    mapLFEx on a one-row range that locus mode decided by the text is tallied as "both rows in one side pair" (they are
+    neighbours; the row itself is not known there), which is wrong for one such row in 448: same_pair may exceed the
+    oracle's by a small part of loc_lfex, never fall below it."""
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames"):
+        assert getattr(oc, f) == getattr(gc, f), (what, f, getattr(oc, f), getattr(gc, f))
+    extra = int(gc.same_pair) - int(oc.same_pair)
+    loc = int(getattr(gc, "loc_lfex", 0))
+    assert 0 <= extra <= max(2, loc // 40), (what, "same_pair", int(oc.same_pair), int(gc.same_pair), loc)

@@ -22,7 +22,7 @@
 #define EMU_POISON(p, n) ((void)0)
 #endif
 
-struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; std::vector<uint8_t> blk[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
+struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; std::vector<uint8_t> blk[2]; std::vector<BtU4> loc[2]; std::vector<uint32_t> rtxt[2]; std::vector<uint16_t> walk[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
 
 static void bind(EmuIndex* e, int m)
 {
@@ -33,6 +33,15 @@ static void bind(EmuIndex* e, int m)
 	e->blk[m].assign((size_t)bt_blk_count(e->d[m].len) * BT_BLK_BYTES, 0);
 	bt_blk_build_host(e->d[m], e->blk[m].data());
 	e->d[m].blk = e->blk[m].data();
+	/* the locus image (bt_rank.h), as the GPU loader derives it; EMU_LOCUS=0: an index without one (row space only) */
+	e->d[m].loc = nullptr; e->d[m].rtxt = nullptr; e->d[m].walk = nullptr;
+	if (!getenv("EMU_LOCUS") || atoi(getenv("EMU_LOCUS")) != 0) {
+		e->loc[m].assign((size_t)e->d[m].len + 1u, BtU4{0, 0, 0, 0});
+		e->rtxt[m].assign((size_t)bt_rtxt_words(e->d[m].len), 0u);
+		e->walk[m].assign((size_t)e->d[m].len + 1u, 0);
+		bt_loc_build_host(e->d[m], e->loc[m].data(), e->rtxt[m].data(), e->walk[m].data());
+		e->d[m].loc = e->loc[m].data(); e->d[m].rtxt = e->rtxt[m].data() + BT_RTXT_PAD_WORDS; e->d[m].walk = e->walk[m].data();
+	}
 }
 
 extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
@@ -90,8 +99,10 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		H.blk[m] = e->d[m].blk; H.zBlk[m] = e->d[m].zBlk; H.zPos[m] = e->d[m].zPos; W.zOff[m] = e->d[m].zOff;
 		W.offMask[m] = e->d[m].offMask; W.ftab[m] = e->d[m].ftab; W.offs[m] = e->d[m].offs; W.offRate[m] = e->d[m].offRate;
 		W.ftabChars[m] = e->d[m].ftabChars; W.len[m] = e->d[m].len;
+		W.loc[m] = e->d[m].loc; W.rtxt[m] = e->d[m].rtxt; W.walk[m] = e->d[m].walk;
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
 	}
+	W.locOn = (e->d[0].loc && (!e->mirror || e->d[1].loc) && !(getenv("EMU_LOCUS_OFF") && atoi(getenv("EMU_LOCUS_OFF")))) ? 1u : 0u;
 	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
 	entCap = (entCap + 7u) & ~7u;
 	std::vector<BtU4> frames4((size_t)nLanes * frCap * 4);
@@ -122,7 +133,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		scr[g].rl = rlbuf.data() + g;
 		scr[g].tosRec = scr[g].tos + (size_t)BT_CC_WORDS * nLanes;
 		scr[g].noCC = lite ? 1u : 0u;
-		scr[g].rlQual = lite ? BT_RL3_SEQ_WORDS : BT_RL_SEQ_WORDS;
+		scr[g].rlMax = lite ? BT_RL3_MAXLEN : BT_RL_MAXLEN;
 	}
 	uint32_t next = 0, live = nLanes;
 	/* EMU_PARK_EVERY=<n>: every lane is parked and adopted again (carry-over) in one round out of n, at random */
@@ -187,6 +198,10 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		counts->ftab = CNT[CN_FTAB]; counts->offs = CNT[CN_OFFS]; counts->rstarts = CNT[CN_RSTARTS];
 		counts->frames = CNT[CN_FRAMES]; counts->lane_iters = CNT[CN_ITERS]; counts->same_pair = CNT[CN_SAMEPAIR];
 		counts->rescans = CNT[CN_RESCAN]; counts->cand_scans = CNT[CN_CANDSCAN]; counts->fetches = CNT[CN_FETCH];
+		/* what locus mode decided by the text is part of the reference's op counts all the same (bt_op_counts) */
+		counts->loc_lfex = CNT[CN_TLFEX]; counts->loc_lf1 = CNT[CN_TLF1]; counts->loc_chase = CNT[CN_TCHASE];
+		counts->loc_records = CNT[CN_LOCREC]; counts->loc_windows = CNT[CN_TXTWIN];
+		counts->lfex += CNT[CN_TLFEX]; counts->same_pair += CNT[CN_TLFEX]; counts->lf1 += CNT[CN_TLF1]; counts->chase += CNT[CN_TCHASE];
 	}
 	return BT_OK;
 }

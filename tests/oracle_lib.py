@@ -22,7 +22,8 @@ from bowtie_amd._abi import Policy, make_policy   # noqa: E402  (bt_policy, incl
 
 class OpCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters", "same_pair", "rescans", "cand_scans", "wave_rounds", "fetches")]
+                ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "lane_iters", "same_pair", "rescans", "cand_scans", "wave_rounds", "fetches",
+                 "loc_lfex", "loc_lf1", "loc_chase", "loc_records", "loc_windows")]
 
 
 class OHit(C.Structure):

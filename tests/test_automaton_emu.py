@@ -63,8 +63,7 @@ def test_emu_vs_oracle_ragged(mode, emu):
     got = emu["multi"].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), counts=ec, pal_cap=16384,
                              n_lanes=64, ent_cap=12 * 160)
     T.compare_results(got, want, mode)
-    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
-        assert getattr(oc, f) == getattr(ec, f), f
+    T.check_op_counts(oc, ec)
 
 
 def test_emu_lane_count_independence(emu):
@@ -134,8 +133,7 @@ def test_emu_vs_oracle_ragged_read_in_lds(mode, emu):
     pol = A.make_policy(**kw)
     got = emu["multi"].align(pol, batch, hit_cap=T.hit_cap_for(kw), counts=ec, pal_cap=16384, n_lanes=64, ent_cap=12 * 128)
     T.compare_results(got, want, mode)
-    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
-        assert getattr(oc, f) == getattr(ec, f), f
+    T.check_op_counts(oc, ec)
     T.compare_results(emu["multi"].align(pol, batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, ent_cap=12 * 128, no_rl=True), want, mode)
 
 
@@ -176,8 +174,7 @@ def test_emu_best_first_vs_oracle_ragged(mode, emu):
     want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
     got = emu["multi"].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), counts=ec)
     T.compare_results(got, want, mode)
-    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
-        assert getattr(oc, f) == getattr(ec, f), f
+    T.check_op_counts(oc, ec)
 
 
 def test_emu_best_first_arena_overflow_is_flagged(emu):
@@ -228,8 +225,7 @@ def test_emu_paired_without_best_vs_oracle_counts(mode, emu):
     want = T.oracle_pair_results("multi", b1, b2, kw, cap=cap, counts=oc, v1=True)
     got = emu["multi"].align_pairs(A.make_policy(**dict(kw, pe_v1=True)), b1, b2, hit_cap=cap, counts=ec)
     T.compare_results(got, want, mode)
-    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
-        assert getattr(oc, f) == getattr(ec, f), f
+    T.check_op_counts(oc, ec)
 
 
 @pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500"])
@@ -241,8 +237,7 @@ def test_emu_paired_vs_oracle_counts(mode, emu):
     want = T.oracle_pair_results("multi", b1, b2, kw, cap=cap, counts=oc)
     got = emu["multi"].align_pairs(A.make_policy(**kw), b1, b2, hit_cap=cap, counts=ec)
     T.compare_results(got, want, mode)
-    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames", "same_pair"):
-        assert getattr(oc, f) == getattr(ec, f), f
+    T.check_op_counts(oc, ec)
 
 
 # ---- the automaton under MemorySanitizer ------------------------------------------------------
