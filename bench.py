@@ -59,7 +59,7 @@ def gather_ceiling(index_kind: str):
 # the round whose source a kernel's PMC profile must have been taken on to describe it still: bump a kernel's entry when its
 # source changes.  bt_search_kernel: round 3 (round 4 changed nothing in it: its device code differs from the measured one by
 # the size of the argument block only); the best-first kernels: round 4 (the automaton, the organised engine)
-KERNEL_ROUNDS = {"bt_search_kernel": 3, "bt_best_kernel": 4, "bt_best_nested_kernel": 4}
+KERNEL_ROUNDS = {"bt_search_kernel": 5, "bt_best_kernel": 4, "bt_best_nested_kernel": 4}      # bt_search_kernel: round 5 = locus mode
 
 
 def measured_traffic(kernel: str, workload: str):
@@ -476,6 +476,8 @@ def main():
                                        d["mm_pool"].data_ptr(), mm_cap, 0)
                 o["sets"].append(d)
             o["al"] = AL.Aligner(idx, pol, stream=st.cuda_stream)
+            if os.environ.get("BT_LOCUS_OFF") == "1":        # A/B: this measurement's launches stay in row space (--env-sweep "rowspace:BT_LOCUS_OFF=1")
+                lib.bt_ctx_set_locus(o["al"]._h, 0)
             if carry and lib.bt_ctx_set_carry(o["al"]._h, carry_age) != 0:
                 raise RuntimeError("bt_ctx_set_carry failed")
             lib.bt_ctx_set_max_read_len(o["al"]._h, L)         # synthetic reads: all of length L (rows are padded to 16)
@@ -683,7 +685,10 @@ def main():
                          "carry_over_launches": carry_age, "flush_ms_total": sum(flush_ms),
                          "reads_searched_again_last_step": sum(int(lib.bt_ctx_last_retried(o["al"]._h)) for o in pipes),
                          "algorithmic_bytes_per_launch": abytes,
-                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches")},
+                         "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches",
+                                                                          "loc_lfex", "loc_lf1", "loc_chase", "loc_records", "loc_windows")},
+                         "locus_mode": bool(lib.bt_ctx_get_locus(pipes[0]["al"]._h)),
+                         "locus_image_GB": lib.bt_index_locus_bytes(idx._h) / 1e9, "locus_image_build_s": lib.bt_index_locus_build_seconds(idx._h),
                          "lane_iters_per_read": per_launch["lane_iters"] / n,
                          "mean_active_lanes_per_round": per_launch["lane_iters"] / max(1.0, per_launch["wave_rounds"]),
                          "wave_rounds_per_launch": per_launch["wave_rounds"]},

@@ -33,6 +33,12 @@ struct bt_index {
 	/* the worst-case arenas of the best-first engine's second pass (reads that outgrew their own arena): one set per
 	 * index replica = per device, shared by every context on it -- the passes of different contexts take turns on it
 	 * through `retryFree` (recorded after a pass, waited for by the next one's stream) */
+	/* the locus image of the phase-program engine (bt_rank.h): derived on the device when the first context that can use
+	 * it is created (index_ensure_locus), kept for the index's lifetime.  0 not tried, 1 there, -1 not to be had */
+	mutable std::mutex locMu;
+	mutable int locState = 0;
+	mutable uint64_t loc_bytes = 0;
+	mutable double loc_build_s = 0;
 	mutable std::mutex retryMu;
 	mutable uint32_t* retryArenas = nullptr; mutable uint32_t retryArenaLanes = 0;
 	mutable hipEvent_t retryFree = nullptr;
@@ -58,6 +64,7 @@ struct bt_ctx {
 	uint32_t nLanes = 0, frCap = 0, entCap = 0, palCap = 0, maxLen = 0;
 	uint32_t cus = 0, blocksPerCU = 2;      /* nLanes covers the widest launch (3 blocks per CU) */
 	bool rl3 = true;                        /* the three-blocks-per-CU build may be used */
+	bool locus = false;                     /* the index has its locus image and this context's launches use it */
 	int occ = 2;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint16_t* meta = nullptr; uint64_t* pals = nullptr;
 	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [7] longest read, [8..10] second pass */
@@ -203,6 +210,92 @@ static uint32_t env_u32(const char* name, uint32_t dflt)
 	return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+/* The locus image (bt_rank.h: dense suffix array + 48 characters of left context per row, the reversed text, the table of
+ * walk lengths), derived from what bt_index_load put on the device: 18.25 bytes per base and index -- HBM capacity spent
+ * on the search's dependent chains.  Not built when the device has not that much to spare (the search then stays in row
+ * space, as in rounds 1-4) or BT_LOCUS=0 says so.  true: the index has it. */
+static bool index_ensure_locus(const bt_index* cidx)
+{
+	std::lock_guard<std::mutex> lk(cidx->locMu);
+	if (cidx->locState != 0) return cidx->locState > 0;
+	bt_index* idx = const_cast<bt_index*>(cidx);
+	idx->locState = -1;
+	if (env_u32("BT_LOCUS", 1) == 0) return false;
+	const int nidx = idx->has_mirror ? 2 : 1;
+	uint64_t need = 0;
+	for (int m = 0; m < nidx; m++)
+		need += ((uint64_t)idx->dev[m].len + 1u) * (sizeof(BtU4) + 2u) + bt_rtxt_words(idx->dev[m].len) * 4u;
+	size_t freeB = 0, totalB = 0;
+	if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return false;
+	/* leave room for what a run allocates afterwards (reads, results, scratch arenas): a quarter of the device or what the
+	 * image itself takes, whichever is less */
+	const uint64_t reserve = std::min<uint64_t>(totalB / 4u, need) + (256ull << 20);
+	if ((uint64_t)freeB < need + reserve) {
+		if (getenv("BT_VERBOSE")) fprintf(stderr, "bowtie_amd: no room for the locus image (%.1f GB, %.1f GB free): searching in row space\n", need / 1e9, freeB / 1e9);
+		return false;
+	}
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	(void)hipEventRecord(e0, nullptr);
+	std::vector<void*> mine;
+	bool ok = true;
+	for (int m = 0; m < nidx && ok; m++) {
+		BtIndexDev& d = idx->dev[m];
+		BtU4* loc = nullptr; uint32_t* rtxt = nullptr; uint16_t* walk = nullptr;
+		const uint64_t rows = (uint64_t)d.len + 1u, words = bt_rtxt_words(d.len);
+		ok = hipMalloc((void**)&loc, rows * sizeof(BtU4)) == hipSuccess;
+		if (ok) mine.push_back(loc);
+		ok = ok && hipMalloc((void**)&rtxt, words * 4u) == hipSuccess;
+		if (ok) mine.push_back(rtxt);
+		ok = ok && hipMalloc((void**)&walk, rows * 2u) == hipSuccess;
+		if (ok) mine.push_back(walk);
+		ok = ok && hipMemset(rtxt, 0, words * 4u) == hipSuccess;
+		ok = ok && bt_launch_loc_build(&d, loc, rtxt, walk, nullptr) == 0;
+		if (ok) { d.loc = loc; d.rtxt = rtxt + BT_RTXT_PAD_WORDS; d.walk = walk; }
+	}
+	(void)hipEventRecord(e1, nullptr);
+	ok = ok && hipDeviceSynchronize() == hipSuccess;
+	float ms = 0;
+	if (ok) (void)hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	if (!ok) {
+		(void)hipGetLastError();
+		for (void* p : mine) (void)hipFree(p);
+		for (int m = 0; m < nidx; m++) { idx->dev[m].loc = nullptr; idx->dev[m].rtxt = nullptr; idx->dev[m].walk = nullptr; }
+		return false;
+	}
+	for (void* p : mine) idx->allocs.push_back(p);
+	if (!idx->has_mirror) idx->dev[1] = idx->dev[0];
+	idx->loc_bytes = need; idx->loc_build_s = ms / 1e3;
+	idx->locState = 1;
+	if (getenv("BT_VERBOSE")) fprintf(stderr, "bowtie_amd: locus image %.2f GB, derived in %.2f s\n", need / 1e9, ms / 1e3);
+	return true;
+}
+/* A/B and diagnostics: a context's launches with (1) or without (0) locus mode; 1 has no effect on an index without the image */
+extern "C" int bt_ctx_set_locus(bt_ctx* c, int on)
+{
+	if (!c) return BT_ERR_ARG;
+	c->locus = on && !c->best && c->idx->locState > 0;
+	if (c->big) c->big->locus = c->locus;
+	return BT_OK;
+}
+extern "C" int bt_ctx_get_locus(const bt_ctx* c) { return c && c->locus ? 1 : 0; }
+/* tests: the image's three arrays of one index copied to host buffers (loc: (len+1) x 16 bytes, rtxt: (len+15)/16 words,
+ * walk: (len+1) x 2 bytes; NULL skips one) */
+extern "C" int bt_index_locus_copy(const bt_index* idx, int mirror, void* loc, void* rtxt, void* walk)
+{
+	if (!idx || idx->locState <= 0) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(idx->device));
+	const BtIndexDev& d = idx->dev[mirror ? 1 : 0];
+	const uint64_t rows = (uint64_t)d.len + 1u;
+	if (loc) HIPCHK(hipMemcpy(loc, d.loc, rows * sizeof(BtU4), hipMemcpyDeviceToHost));
+	if (rtxt) HIPCHK(hipMemcpy(rtxt, d.rtxt, (((uint64_t)d.len + 15u) / 16u) * 4u, hipMemcpyDeviceToHost));
+	if (walk) HIPCHK(hipMemcpy(walk, d.walk, rows * 2u, hipMemcpyDeviceToHost));
+	return BT_OK;
+}
+extern "C" uint64_t bt_index_locus_bytes(const bt_index* idx) { return idx ? idx->loc_bytes : 0; }
+extern "C" double bt_index_locus_build_seconds(const bt_index* idx) { return idx ? idx->loc_build_s : 0; }
+
 static void ctx_free_scratch(bt_ctx* c)
 {
 	if (c->frames) (void)hipFree(c->frames);
@@ -281,6 +374,8 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	for (int i = 0; !c->best && i < c->prog.nsteps; i++) need_mirror |= c->prog.steps[i].mirror != 0;
 	if (need_mirror && !idx->has_mirror) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(idx->device));
+	/* the phase-program engine leaves row space where a range is one row, if the index can have its locus image */
+	c->locus = !c->best && index_ensure_locus(idx);
 	if (stream) c->stream = (hipStream_t)stream;
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 	HIPCHK(hipEventCreate(&c->ev0));
@@ -529,7 +624,9 @@ static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
 		warm->zOff[m] = d.zOff; warm->offMask[m] = d.offMask; warm->ftab[m] = d.ftab; warm->offs[m] = d.offs;
 		warm->offRate[m] = d.offRate; warm->ftabChars[m] = d.ftabChars; warm->len[m] = d.len;
 		for (int k = 0; k < 5; k++) A->H.fchr[m][k] = d.fchr[k];
+		if (c->locus) { warm->loc[m] = d.loc; warm->rtxt[m] = d.rtxt; warm->walk[m] = d.walk; }
 	}
+	warm->locOn = c->locus ? 1u : 0u;
 }
 
 /* Second pass, on the stream, over the reads of `v` whose search outgrew the per-read scratch: collected from the
@@ -1082,6 +1179,9 @@ extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 	out->lfex = h[0]; out->lf2 = h[1]; out->lf1 = h[2]; out->chase = h[3]; out->ftab = h[4];
 	out->offs = h[5]; out->rstarts = h[6]; out->frames = h[7];
 	out->lane_iters = h[8]; out->same_pair = h[9]; out->rescans = h[10]; out->cand_scans = h[11]; out->wave_rounds = h[12]; out->fetches = h[13];
+	/* what locus mode decided by the text is part of the reference's op counts all the same (bt_op_counts) */
+	out->loc_lfex = h[CN_TLFEX]; out->loc_lf1 = h[CN_TLF1]; out->loc_chase = h[CN_TCHASE]; out->loc_records = h[CN_LOCREC]; out->loc_windows = h[CN_TXTWIN];
+	out->lfex += out->loc_lfex; out->same_pair += out->loc_lfex; out->lf1 += out->loc_lf1; out->chase += out->loc_chase;
 	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
 	return BT_OK;
 }

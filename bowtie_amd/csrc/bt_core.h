@@ -728,22 +728,31 @@ BT_HD uint32_t bt_loc_count_alt(const BtLane& L, const BtScratch& S, uint32_t lo
 }
 /* A window of the text in depth order: eight words (sixteen characters each) starting `sh` characters before depth w0; the
  * first depth at or after d, and below lim, at which the query differs from it (0xffffffff: none), and the text's base there. */
-BT_HD uint32_t bt_loc_first_mm(const BtLane& L, const BtScratch& S, const uint32_t wt[9], uint32_t sh, uint32_t w0,
+struct BtLocWin { uint32_t w0, w1, w2, w3, w4, w5, w6, w7; };          /* named words: nothing here is indexed at run time */
+BT_HD void bt_loc_mm_word(const BtLane& L, const BtScratch& S, uint32_t lo, uint32_t hi, uint32_t sh, uint32_t wb,
+                          uint32_t d, uint32_t lim, uint32_t& fm, uint32_t& tf)
+{
+	if (wb < lim && wb + 16u > d) {
+		const uint32_t td = (uint32_t)((((uint64_t)hi << 32) | lo) >> (2u * sh));
+		uint32_t x = bt_loc_qword(L, S, wb) ^ td;
+		x = (x | (x >> 1)) & 0x55555555u;
+		if (d > wb) x &= 0xffffffffu << (2u * (d - wb));
+		if (lim < wb + 16u) x &= 0xffffffffu >> (2u * (wb + 16u - lim));
+		if (x) { const uint32_t b = (uint32_t)__builtin_ctz(x); fm = wb + (b >> 1); tf = (td >> b) & 3u; }
+	}
+}
+BT_HD uint32_t bt_loc_first_mm(const BtLane& L, const BtScratch& S, const BtLocWin& t, uint32_t sh, uint32_t w0,
                                uint32_t d, uint32_t lim, uint32_t* tOut)
 {
 	uint32_t fm = 0xffffffffu, tf = 0;
-	BT_UNROLL
-	for (int k = 6; k >= 0; k--) {                     /* the shallowest word last: its answer stays */
-		const uint32_t wb = w0 + 16u * (uint32_t)k;
-		if (wb < lim && wb + 16u > d) {
-			const uint32_t td = (uint32_t)((((uint64_t)wt[k + 1] << 32) | wt[k]) >> (2u * sh));
-			uint32_t x = bt_loc_qword(L, S, wb) ^ td;
-			x = (x | (x >> 1)) & 0x55555555u;
-			if (d > wb) x &= 0xffffffffu << (2u * (d - wb));
-			if (lim < wb + 16u) x &= 0xffffffffu >> (2u * (wb + 16u - lim));
-			if (x) { const uint32_t b = (uint32_t)__builtin_ctz(x); fm = wb + (b >> 1); tf = (td >> b) & 3u; }
-		}
-	}
+	/* the shallowest word last: its answer stays */
+	bt_loc_mm_word(L, S, t.w6, t.w7, sh, w0 + 96u, d, lim, fm, tf);
+	bt_loc_mm_word(L, S, t.w5, t.w6, sh, w0 + 80u, d, lim, fm, tf);
+	bt_loc_mm_word(L, S, t.w4, t.w5, sh, w0 + 64u, d, lim, fm, tf);
+	bt_loc_mm_word(L, S, t.w3, t.w4, sh, w0 + 48u, d, lim, fm, tf);
+	bt_loc_mm_word(L, S, t.w2, t.w3, sh, w0 + 32u, d, lim, fm, tf);
+	bt_loc_mm_word(L, S, t.w1, t.w2, sh, w0 + 16u, d, lim, fm, tf);
+	bt_loc_mm_word(L, S, t.w0, t.w1, sh, w0, d, lim, fm, tf);
 	*tOut = tf;
 	return fm;
 }
@@ -1347,10 +1356,11 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 					BT_COUNT_HOST(CN_FETCH);
 					return;
 				}
-				uint32_t wt[9];
-				if (wkind == 1) { wt[0] = res.q[0].y; wt[1] = res.q[0].z; wt[2] = res.q[0].w; wt[3] = wt[4] = wt[5] = wt[6] = wt[7] = 0; }
-				else { wt[0] = res.q[0].x; wt[1] = res.q[0].y; wt[2] = res.q[0].z; wt[3] = res.q[0].w; wt[4] = res.q[1].x; wt[5] = res.q[1].y; wt[6] = res.q[1].z; wt[7] = res.q[1].w; }
-				wt[8] = 0;
+				const bool rec = wkind == 1;
+				BtLocWin wt;
+				wt.w0 = rec ? res.q[0].y : res.q[0].x; wt.w1 = rec ? res.q[0].z : res.q[0].y; wt.w2 = rec ? res.q[0].w : res.q[0].z;
+				wt.w3 = rec ? 0u : res.q[0].w; wt.w4 = rec ? 0u : res.q[1].x; wt.w5 = rec ? 0u : res.q[1].y;
+				wt.w6 = rec ? 0u : res.q[1].z; wt.w7 = rec ? 0u : res.q[1].w;
 				/* the depths that can be compared: up to the end of the query, of the window, of the text (depth == anchor is
 				 * the '$' row: nothing to the left) */
 				uint32_t lim = L.qlen < wd0 + ncov ? (uint32_t)L.qlen : wd0 + ncov;
@@ -1361,9 +1371,9 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				/* the event: the first mismatch; else a half-and-half boundary; else the text's or the read's end */
 				uint32_t dev = fm;
 				if (L.halfAndHalf) {
-					const uint32_t h[4] = {L.d5 - 1u, L.d5, L.d3 - 1u, L.d3};
-					BT_UNROLL
-					for (int k = 0; k < 4; k++) if (h[k] >= d && h[k] < lim && h[k] < dev) dev = h[k];
+#define BT_LOC_HH(v) do { const uint32_t h_ = (v); if (h_ >= d && h_ < lim && h_ < dev) dev = h_; } while (0)
+					BT_LOC_HH(L.d5 - 1u); BT_LOC_HH(L.d5); BT_LOC_HH(L.d3 - 1u); BT_LOC_HH(L.d3);
+#undef BT_LOC_HH
 				}
 				if (dev == 0xffffffffu) {
 					if (textEnds) dev = anchor;

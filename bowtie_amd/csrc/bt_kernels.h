@@ -86,6 +86,7 @@ int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, uint32_t iter
 int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
                          uint8_t* L, uint32_t sides, void* stream);
 int bt_launch_blk_build(const BtIndexDev* ix, uint8_t* out, uint32_t nBlocks, void* stream);
+int bt_launch_loc_build(const BtIndexDev* ix, BtU4* loc, uint32_t* rtxtAlloc, uint16_t* walk, void* stream);
 int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
                           uint32_t* joined, uint32_t* tidx, uint32_t* toff, void* stream);
 }

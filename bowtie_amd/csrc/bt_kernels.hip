@@ -50,6 +50,62 @@ extern "C" int bt_launch_blk_build(const BtIndexDev* ix, uint8_t* out, uint32_t 
 	return (int)hipGetLastError();
 }
 
+/* ---- the locus image (bt_rank.h), derived once per index at load (what bt_loc_build_host does on the host) ------------------
+ * pass 1, one lane per BWT row: walk to a sampled row as Ebwt::reportChaseOne does (ebwt.h:2727-2746) -> SA[row] into the
+ * row's record, the walk's length into walk[SA] (by text offset), and the row's own BWT character -- the text's base to the
+ * left of its suffix -- into the reversed text.  pass 2, one lane per row: the 48 characters to the left of the row's suffix,
+ * out of the reversed text, into the record. */
+__global__ __launch_bounds__(256) void bt_loc_sa_kernel(BtIndexDev ix, BtU4* loc, uint32_t* rtxt, uint16_t* walk)
+{
+	const uint64_t nRows = (uint64_t)ix.len + 1u;
+	for (uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r0 < nRows; r0 += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t row = (uint32_t)r0, j = 0, first = 0;
+		while ((row & ix.offMask) != row && row != ix.zOff) {
+			uint32_t lf[4], L;
+			bt_rank4(ix, row, lf, &L);
+			if (j == 0) first = L;
+			row = lf[L];
+			j++;
+		}
+		if (j == 0 && (uint32_t)r0 != ix.zOff) { uint32_t lf[4]; bt_rank4(ix, (uint32_t)r0, lf, &first); }
+		const uint32_t sa = (row == ix.zOff ? 0u : BT_GP(const uint32_t, ix.offs)[row >> ix.offRate]) + j;
+		BT_GP(uint32_t, loc)[r0 * 4u] = sa;
+		BT_GP(uint16_t, walk)[sa] = (uint16_t)(j < 0xffffu ? j : 0xffffu);
+		if (sa > 0) {
+			const uint32_t y = ix.len - sa;                 /* T[sa-1] is base len-1-(sa-1) of the reversed text */
+			atomicOr(rtxt + (y >> 4), first << (2u * (y & 15u)));
+		}
+	}
+}
+__global__ __launch_bounds__(256) void bt_loc_ctx_kernel(BtIndexDev ix, BtU4* loc, const uint32_t* rtxt)
+{
+	const uint64_t nRows = (uint64_t)ix.len + 1u;
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nRows; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t sa = BT_GP(const uint32_t, loc)[r * 4u];
+		const uint32_t y0 = ix.len - sa, w = y0 >> 4, s = 2u * (y0 & 15u);
+		uint32_t t[4], c[3];
+		BT_UNROLL
+		for (int k = 0; k < 4; k++) t[k] = BT_GP(const uint32_t, rtxt)[w + k];
+		BT_UNROLL
+		for (int k = 0; k < 3; k++) c[k] = (uint32_t)((((uint64_t)t[k + 1] << 32) | t[k]) >> s);
+		BtU4 v; v.x = sa; v.y = c[0]; v.z = c[1]; v.w = c[2];
+		bt_st4(loc + r, v);
+	}
+}
+/* loc: len + 1 records; rtxtAlloc: bt_rtxt_words(len) words, zeroed by the caller; walk: len + 1 entries */
+extern "C" int bt_launch_loc_build(const BtIndexDev* ix, BtU4* loc, uint32_t* rtxtAlloc, uint16_t* walk, void* stream)
+{
+	hipDeviceProp_t prop; int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+	const uint64_t nRows = (uint64_t)ix->len + 1u;
+	uint64_t nb = (nRows + 255u) / 256u;
+	const uint64_t cap = (uint64_t)prop.multiProcessorCount * 64u;
+	if (nb > cap) nb = cap;
+	hipLaunchKernelGGL(bt_loc_sa_kernel, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, *ix, loc, rtxtAlloc + BT_RTXT_PAD_WORDS, walk);
+	hipLaunchKernelGGL(bt_loc_ctx_kernel, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, *ix, loc, rtxtAlloc + BT_RTXT_PAD_WORDS);
+	return (int)hipGetLastError();
+}
+
 /* EXT = true compiles in carry-over (parking at the end of a launch, adoption at the start of the next) and the
  * pick-up list of the overflow second pass; a launch that needs neither uses the leaner EXT = false build. */
 /* LITE (with RL): the LDS diet that lets three blocks share a CU -- the read in 39 words (<= 104 bases) and
@@ -88,7 +144,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
 	S.noCC = LITE ? 1u : 0u;
-	S.rlQual = LITE ? BT_RL3_SEQ_WORDS : BT_RL_SEQ_WORDS;
+	S.rlMax = LITE ? BT_RL3_MAXLEN : BT_RL_MAXLEN;
 	S.rl = RLB + (RL ? threadIdx.x : 0u);
 
 	BtLane L = {};
@@ -168,8 +224,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			BtU4 qa[4] = {}, qx = {}, qw = {};
 			/* every address a lane can ask for is global memory (index, scratch arenas, ftab, SA sample,
 			 * reads): plain global loads, not FLAT ones (see BT_GP) */
-			if (nA > 0u) qa[0] = bt_ld4(pA);
-			if (nA > 1u) qa[1] = bt_ld4(pA + 16);
+			/* (a text window's address is a word's, not a 16-byte piece's: bt_ld4w) */
+			if (nA > 0u) qa[0] = bt_ld4w(pA);
+			if (nA > 1u) qa[1] = bt_ld4w(pA + 16);
 			if (nA > 2u) qa[2] = bt_ld4(pB);
 			if (nA > 3u) qa[3] = bt_ld4(pB + 16);
 			if (hasX) qx = bt_ld4(pX);

@@ -114,6 +114,19 @@ BT_HD BtU4 bt_ld4(const void* p)
 #endif
 	return r;
 }
+/* the same from an address that is only word-aligned (a window of the reversed text) */
+BT_HD BtU4 bt_ld4w(const void* p)
+{
+	BtU4 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef uint32_t bt_vec4w __attribute__((ext_vector_type(4), aligned(4)));
+	const bt_vec4w v = *BT_GP(const bt_vec4w, p);
+	r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+#else
+	memcpy(&r, p, 16);
+#endif
+	return r;
+}
 BT_HD void bt_st4(void* p, const BtU4& v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

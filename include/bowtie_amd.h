@@ -244,6 +244,17 @@ int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_
  * pass on the stream); run them through bt_align_batch.  `in`, `out` and the arrays they point at stay the caller's
  * and must live until the batch is collected.  What the reference does with a FASTQ reader feeding its worker
  * threads. */
+/* Locus mode (csrc/bt_rank.h "the locus image"): the phase-program engine replaces, from the step at which a
+ * range is one BWT row, the reference's row-by-row mapLF1 / mapLFEx steps (ebwt_search_backtrack.h:544-566, ebwt.h:2334-2380,
+ * 2494-2512) by comparisons with the text, and the SA walk of a reported row (Ebwt::reportChaseOne, ebwt.h:2693-2755) by a
+ * look-up in a dense suffix array -- same results, same op counts (bt_op_counts).  The image (18.25 bytes per base and
+ * index) is derived on the device when the first such context is created, if the device has the room and BT_LOCUS=0 does not
+ * forbid it.  bt_ctx_set_locus switches a context's launches between the two ways (A/B, diagnostics). */
+int      bt_ctx_set_locus(bt_ctx* ctx, int on);
+int      bt_ctx_get_locus(const bt_ctx* ctx);
+uint64_t bt_index_locus_bytes(const bt_index* idx);          /* 0: the index has no locus image */
+double   bt_index_locus_build_seconds(const bt_index* idx);
+int      bt_index_locus_copy(const bt_index* idx, int mirror, void* loc, void* rtxt, void* walk);   /* tests: the image's arrays to host buffers */
 int  bt_align_stream_submit(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, void* tag);
 int  bt_align_stream_collect(bt_ctx* ctx, void** tag, int flush);
 /* With carry-over: one more launch of the context's grid with no new reads.  What is parked runs on for at least

@@ -60,6 +60,15 @@ extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
 	return e;
 }
 extern "C" void emu_index_free(void* p) { delete (EmuIndex*)p; }
+/* the host-built locus image of one index (tests compare the GPU loader's with it) */
+extern "C" int emu_locus_arrays(void* p, int mirror, const void** loc, const void** rtxt, const void** walk, uint32_t* len)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	const int m = mirror ? 1 : 0;
+	if (!e->d[m].loc) return 1;
+	*loc = e->d[m].loc; *rtxt = e->d[m].rtxt; *walk = e->d[m].walk; *len = e->d[m].len;
+	return 0;
+}
 
 extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint32_t* L)
 {

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes():
     assert C.sizeof(A.HitC) == 24
     assert C.sizeof(A.Policy) == 88
-    assert C.sizeof(A.OpCounts) == 112
+    assert C.sizeof(A.OpCounts) == 152
 
 
 def test_policy_default_matches_reference_defaults():

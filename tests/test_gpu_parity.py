@@ -43,6 +43,59 @@ def test_probe_rank_blocks_equal_the_side_layout(index, gidx):
         assert (L_b[ok] == L_s[ok]).all(), (index, mirror)
 
 
+@pytest.mark.parametrize("index", ["e_coli", "multi"])
+def test_locus_image_equals_the_host_build(index, gidx):
+    """The locus image the loader derives on the GPU (bt_loc_sa_kernel / bt_loc_ctx_kernel: dense suffix array + 48 characters
+    of left context per row, the reversed 2-bit text, the table of walk lengths) against the host build of the same
+    (bt_loc_build_host, one sequential pass over the text), text index and mirror index, every row."""
+    import ctypes as C
+    import emu_lib as E
+    al = aligner(gidx, index, T.MODES["n2"])               # creating a phase-program context derives the image
+    L = AL.lib()
+    assert L.bt_ctx_get_locus(al._h) == 1 and L.bt_index_locus_bytes(gidx[index]._h) > 0
+    e = E.EmuAligner(os.path.join(T.G, index))
+    EL = E.lib()
+    EL.emu_locus_arrays.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(C.c_uint32)]
+    for mirror in (0, 1):
+        pl, pt, pw, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        assert EL.emu_locus_arrays(e.h, mirror, C.byref(pl), C.byref(pt), C.byref(pw), C.byref(n)) == 0
+        rows, words = n.value + 1, (n.value + 15) // 16
+        want_loc = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_uint32)), shape=(rows, 4))
+        want_txt = np.ctypeslib.as_array(C.cast(pt, C.POINTER(C.c_uint32)), shape=(words,))
+        want_walk = np.ctypeslib.as_array(C.cast(pw, C.POINTER(C.c_uint16)), shape=(rows,))
+        loc = np.zeros((rows, 4), dtype=np.uint32); txt = np.zeros(words, dtype=np.uint32); walk = np.zeros(rows, dtype=np.uint16)
+        assert L.bt_index_locus_copy(gidx[index]._h, mirror, loc.ctypes.data, txt.ctypes.data, walk.ctypes.data) == 0
+        assert (txt == want_txt).all(), (index, mirror, "text")
+        assert (walk == want_walk).all(), (index, mirror, "walk lengths")
+        assert (loc == want_loc).all(), (index, mirror, "records", np.nonzero((loc != want_loc).any(axis=1))[0][:5])
+
+
+@pytest.mark.parametrize("mode", ["v0", "v2", "n2", "n3", "n2_k3", "n1_a_m20", "n2_nomaq"])
+def test_locus_mode_on_and_off_agree(mode, gidx):
+    """One context, the same ragged reads with locus mode and in row space: the same hits, the same op counts (what the
+    text decided is tallied as the reference's steps), and far fewer lock-step rounds."""
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(77)
+    reads = []
+    for i in range(1200):
+        ln = int(rng.integers(4, 105))
+        b = synth_reads(text, 1, ln, mm_dist=(0, 1, 2, 3), seed=21000 + i, n_frac=0.1, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :ln].copy(), b.qual[0, :ln].tobytes()))
+    batch = pack_reads(reads)
+    al = aligner(gidx, "multi", kw)
+    L = AL.lib()
+    out = {}
+    for on in (1, 0):
+        assert L.bt_ctx_set_locus(al._h, on) == 0 and L.bt_ctx_get_locus(al._h) == on
+        c = A.OpCounts()
+        out[on] = (al.align(batch, hit_cap=T.hit_cap_for(kw), counts=c), c)
+    T.compare_results(out[1][0], out[0][0], mode + " locus mode against row space")
+    T.check_op_counts(out[0][1], out[1][1], mode)
+    assert out[0][1].loc_records == 0 and out[1][1].loc_records > 0
+    assert out[1][1].lane_iters < out[0][1].lane_iters
+
+
 def test_probe_rank_known_answers(gidx):
     with open(os.path.join(T.G, "rank_vectors.json")) as f:
         v = json.load(f)
