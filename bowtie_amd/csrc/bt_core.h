@@ -75,13 +75,13 @@ enum {
 	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25 | ccValid<<26 (LDS copy only) */
 	FR_W3,       /* f2 | f3<<11                                                                  */
 	FR_W4,       /* altNum | eligibleNum<<12                                                     */
-	FR_W5,       /* cand | dcf<<11 | lmode<<22 | lt<<23 | lz<<25 (locus mode, below)                 */
+	FR_W5,       /* cand | dcf<<11 | lmode<<22 | lt<<23 | lz<<25 | el<<26 (locus mode, below)        */
 	FR_W6,       /* pi | pj<<11 | pel<<13                                                        */
-	FR_PTOP, FR_PBOT, FR_EBASE,
+	FR_EBASE,
 	FR_ANCHOR,   /* locus mode: the frame's anchor (text offset of its row's suffix + depth)       */
 	FR_MM        /* mismatch chosen at this level: query offset | refc<<16                       */
 };
-#define BT_TOS_WORDS 11      /* FR_W0..FR_ANCHOR travel to the LDS top-of-stack copy             */
+#define BT_TOS_WORDS 9       /* FR_W0..FR_ANCHOR travel to the LDS top-of-stack copy             */
 #define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
 #define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
 
@@ -184,6 +184,10 @@ struct BtReq {
 	 *        x = address of an optional extra 16-byte piece -> res.x (0 = none) */
 	uint64_t a, x;
 	uint32_t wchunk;
+	/* not a request: what this call's locus-mode steps decided by the text instead of going through -- mapLFEx steps in the
+	 * high half, mapLF1 steps in the low half (each at most a read's length per call).  The caller adds them up (the kernel
+	 * per lane in a register, flushed now and then: an LDS atomic per step costs more than the step) */
+	uint32_t tally;
 };
 struct BtRes {
 	BtU4 q[4];              /* RANK: q[0] = LF(rowA, ACGT), q[1] = LF(rowB, ACGT), q[2].x = BWT char at rowA */
@@ -226,16 +230,18 @@ enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_F
 /* Section timers for the profiling build (-DBT_PROFILE, scripts/prof_sections.py): wavefront
  * cycles (s_memtime) per section, accumulated in LDS.  No-ops in the product build. */
 enum { PS_RESUME = 0, PS_SLOW, PS_WAIT, PS_RANK, PS_REFILL, PS_LOOP,
-       PS_FELL_OFF, PS_RESOLVE_DONE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_RESCAN, PS_SEARCH_END, PS_PHASE_NEXT, PS_SEARCH_BEGIN, PS_FTABSEQ_DONE, PS_FTAB_DONE, PS_BT_LOOP, PS_CANDSCAN, PS_BT_PICK, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_PASSES, PS_SINGLE_LFEX, PS_SINGLE_RUNS, PS_N };
+       PS_FELL_OFF, PS_RESOLVE_DONE, PS_RA_END, PS_FRAME_RETURN, PS_CHILD_RET, PS_RESCAN, PS_SEARCH_END, PS_PHASE_NEXT, PS_SEARCH_BEGIN, PS_FTABSEQ_DONE, PS_FTAB_DONE, PS_BT_LOOP, PS_CANDSCAN, PS_BT_PICK, PS_RA_BEGIN, PS_ROW_BEGIN, PS_FRAME_ENTER, PS_PASSES, PS_SINGLE_LFEX, PS_SINGLE_RUNS, PS_LOCUS, PS_LOC_MM, PS_LOC_TALLY, PS_LOCUS_PASSES, PS_RUN_ITERS, PS_N };
 #if defined(BT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define BT_PROF_T0(v) const unsigned long long v = __builtin_readcyclecounter()
 #define BT_PROF_PASS() do { const unsigned long long ex_ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + PS_PASSES], 1ull); } while (0)
+#define BT_PROF_TICK(k) do { const unsigned long long ex_ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + (k)], 1ull); } while (0)
 #define BT_PROF_ADD(k, v) do { const unsigned long long ex_ = __ballot(1); \
 	if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex_)) atomicAdd(&CNT[CN_N + (k)], __builtin_readcyclecounter() - (v)); } while (0)
 #else
 #define BT_PROF_T0(v)
 #define BT_PROF_ADD(k, v)
 #define BT_PROF_PASS()
+#define BT_PROF_TICK(k)
 #endif
 
 struct BtLane {
@@ -258,7 +264,8 @@ struct BtLane {
 	/* current frame (locals of backtrack(), ebwt_search_backtrack.h:363-455) */
 	uint32_t sd : 7, depth : 11, d : 11;
 	uint32_t top, bot;
-	uint32_t ham : 16, lowAltQual : 8;
+	uint32_t ham : 16, lowAltQual : 8,
+	         el : 6;                 /* locus mode: levels of the reference's recursion gone through without a frame of their own since the last real one (bt_loc_elide) */
 	uint32_t fu : 11, f1 : 11, elcint : 2, elignore : 1, candValid : 1;
 	uint32_t f2 : 11, f3 : 11;
 	uint32_t altNum : 12, eligibleNum : 12;
@@ -276,7 +283,6 @@ struct BtLane {
 	uint32_t pel : 4, tosFrame : 7, tosValid : 1, ccValid : 1, wpf : 1, cchunk : 8,   /* cchunk: the cached 16-byte chunk of the read (register-window build), 0xff = none */
 	         lt : 2, lz : 1,      /* locus mode: the text's base at the frame's last position (its one alternative there); lz: there is none (text start) */
 	         ra_l : 1;            /* the alignment being reported comes from locus mode: ra_top is an anchor, not a row */
-	uint32_t pbttop, pbtbot;
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
 	uint32_t ra_top, ra_bot, ra_r, ra_i;
@@ -728,31 +734,31 @@ BT_HD uint32_t bt_loc_count_alt(const BtLane& L, const BtScratch& S, uint32_t lo
 }
 /* A window of the text in depth order: eight words (sixteen characters each) starting `sh` characters before depth w0; the
  * first depth at or after d, and below lim, at which the query differs from it (0xffffffff: none), and the text's base there. */
-struct BtLocWin { uint32_t w0, w1, w2, w3, w4, w5, w6, w7; };          /* named words: nothing here is indexed at run time */
-BT_HD void bt_loc_mm_word(const BtLane& L, const BtScratch& S, uint32_t lo, uint32_t hi, uint32_t sh, uint32_t wb,
-                          uint32_t d, uint32_t lim, uint32_t& fm, uint32_t& tf)
+struct BtLocWin { uint32_t w0, w1, w2, w3, w4, w5, w6, w7; };          /* named words: registers are not indexed at run time */
+BT_HD uint32_t bt_loc_win_word(const BtLocWin& t, uint32_t k)
 {
-	if (wb < lim && wb + 16u > d) {
-		const uint32_t td = (uint32_t)((((uint64_t)hi << 32) | lo) >> (2u * sh));
-		uint32_t x = bt_loc_qword(L, S, wb) ^ td;
-		x = (x | (x >> 1)) & 0x55555555u;
-		if (d > wb) x &= 0xffffffffu << (2u * (d - wb));
-		if (lim < wb + 16u) x &= 0xffffffffu >> (2u * (wb + 16u - lim));
-		if (x) { const uint32_t b = (uint32_t)__builtin_ctz(x); fm = wb + (b >> 1); tf = (td >> b) & 3u; }
-	}
+	const uint32_t a = (k & 1u) ? t.w1 : t.w0, b = (k & 1u) ? t.w3 : t.w2, c = (k & 1u) ? t.w5 : t.w4, e = (k & 1u) ? t.w7 : t.w6;
+	const uint32_t lo = (k & 2u) ? b : a, hi = (k & 2u) ? e : c;
+	return k >= 8u ? 0u : ((k & 4u) ? hi : lo);
 }
+/* A window of the text in depth order -- words of sixteen characters, the first one starting `sh` characters before depth
+ * w0 --: the first depth at or after d, and below lim, at which the query differs from it (0xffffffff: none), and the
+ * text's base there.  Word by word from the shallow end, done at the first difference: a row that is not where the read
+ * comes from differs within a base or two. */
 BT_HD uint32_t bt_loc_first_mm(const BtLane& L, const BtScratch& S, const BtLocWin& t, uint32_t sh, uint32_t w0,
                                uint32_t d, uint32_t lim, uint32_t* tOut)
 {
 	uint32_t fm = 0xffffffffu, tf = 0;
-	/* the shallowest word last: its answer stays */
-	bt_loc_mm_word(L, S, t.w6, t.w7, sh, w0 + 96u, d, lim, fm, tf);
-	bt_loc_mm_word(L, S, t.w5, t.w6, sh, w0 + 80u, d, lim, fm, tf);
-	bt_loc_mm_word(L, S, t.w4, t.w5, sh, w0 + 64u, d, lim, fm, tf);
-	bt_loc_mm_word(L, S, t.w3, t.w4, sh, w0 + 48u, d, lim, fm, tf);
-	bt_loc_mm_word(L, S, t.w2, t.w3, sh, w0 + 32u, d, lim, fm, tf);
-	bt_loc_mm_word(L, S, t.w1, t.w2, sh, w0 + 16u, d, lim, fm, tf);
-	bt_loc_mm_word(L, S, t.w0, t.w1, sh, w0, d, lim, fm, tf);
+	BT_NOUNROLL
+	for (uint32_t k = (d - w0) >> 4; w0 + 16u * k < lim; k++) {
+		const uint32_t wb = w0 + 16u * k;
+		const uint32_t td = (uint32_t)((((uint64_t)bt_loc_win_word(t, k + 1u) << 32) | bt_loc_win_word(t, k)) >> (2u * sh));
+		uint32_t x = bt_loc_qword(L, S, wb) ^ td;
+		x = (x | (x >> 1)) & 0x55555555u;
+		if (d > wb) x &= 0xffffffffu << (2u * (d - wb));
+		if (lim < wb + 16u) x &= 0xffffffffu >> (2u * (wb + 16u - lim));
+		if (x) { const uint32_t b = (uint32_t)__builtin_ctz(x); fm = wb + (b >> 1); tf = (td >> b) & 3u; break; }
+	}
 	*tOut = tf;
 	return fm;
 }
@@ -838,14 +844,15 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 
 		/* ---- return from a frame: pop the parent's record (LDS copy, else one fetch) ---------- */
 		if (ST_IS(ST_FRAME_RETURN) || ST_IS(ST_FRAME_FETCHED)) { BT_PROF_T0(t_frame_return); do {
-			if (L.sd == 0) { L.state = ST_SEARCH_END; break; }
-			const uint32_t f = L.sd - 1u;
+			/* the levels gone through without a frame (bt_loc_elide) return with the frame they started from */
+			if (L.sd == L.el) { L.state = ST_SEARCH_END; break; }
+			const uint32_t f = L.sd - L.el - 1u;
 			uint32_t w[BT_TOS_WORDS];
 			bool fromTos = false;
 			if (L.state == ST_FRAME_FETCHED) {
 				w[0] = res.q[0].x; w[1] = res.q[0].y; w[2] = res.q[0].z; w[3] = res.q[0].w;
 				w[4] = res.q[1].x; w[5] = res.q[1].y; w[6] = res.q[1].z; w[7] = res.q[1].w;
-				w[8] = res.q[2].x; w[9] = res.q[2].y; w[10] = res.q[2].z;
+				w[8] = res.q[2].x;
 			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
 				BT_UNROLL
@@ -871,9 +878,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
 			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
-			v = w[FR_W5]; L.cand = v & 0x7ffu; L.dcf = (v >> 11) & 0x7ffu; L.lmode = (v >> 22) & 1u; L.lt = (v >> 23) & 3u; L.lz = (v >> 25) & 1u;
+			v = w[FR_W5]; L.cand = v & 0x7ffu; L.dcf = (v >> 11) & 0x7ffu; L.lmode = (v >> 22) & 1u; L.lt = (v >> 23) & 3u; L.lz = (v >> 25) & 1u; L.el = v >> 26;
 			v = w[FR_W6]; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
-			L.pbttop = w[FR_PTOP]; L.pbtbot = w[FR_PBOT];
 			L.ebase = w[FR_EBASE];
 			if (L.lmode) { L.top = w[FR_ANCHOR]; L.bot = L.top; }      /* the anchor; a frame that has a child stands on an empty range */
 			L.state = ST_CHILD_RET;
@@ -1012,7 +1018,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 
 		/* ---- backtrack() entry: tallyNs + ftab jump (:237-297, 1308-1362) -------------- */
 		if (ST_IS(ST_SEARCH_BEGIN)) { BT_PROF_T0(t_search_begin); do {
-			L.bailed = 0; L.sd = 0; L.lmode = 0; L.dcf = 0;
+			L.bailed = 0; L.sd = 0; L.lmode = 0; L.dcf = 0; L.el = 0;
 			uint32_t nsInFtab = 0;
 			const uint32_t ftabChars = WSEL(ftabChars);
 			if (L.hasN) {
@@ -1196,7 +1202,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			else if (i < L.f2) { n1 = L.f2; n2 = L.f3; }
 			else if (i < L.f3) { n2 = L.f3; }
 			FRW(L.sd, FR_MM) = icur | (btcint << 16);
-			L.pi = i; L.pj = j; L.pbttop = bttop; L.pbtbot = btbot; L.btham = btham;
+			L.pi = i; L.pj = j; L.btham = btham;
 			if (i + 1u == L.qlen) {
 				BT_GOTO_RA(L.sd + 1u, bttop, btbot, btham, RC_CHILD, locTarget);
 				break;
@@ -1232,14 +1238,14 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (L.ccValid << 26);
 				w[FR_W3] = L.f2 | (L.f3 << 11);
 				w[FR_W4] = L.altNum | (L.eligibleNum << 12);
-				w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25);
+				w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25) | (L.el << 26);
 				w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
-				w[FR_PTOP] = L.pbttop; w[FR_PBOT] = L.pbtbot; w[FR_EBASE] = L.ebase;
+				w[FR_EBASE] = L.ebase;
 				w[FR_ANCHOR] = L.top;
 				uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
 				BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
 				bt_st4(fr, q0); bt_st4(fr + 4, q1);
-				FRW(L.sd, FR_PBOT) = w[FR_PBOT]; FRW(L.sd, FR_EBASE) = w[FR_EBASE]; FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
+				FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
 				BT_UNROLL
 				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
 				if (L.ccValid) {
@@ -1249,7 +1255,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				L.tosFrame = L.sd; L.tosValid = 1;
 			}
 			L.ebase = bt_ent(L, L.d) + 1u;
-			L.lmode = childLoc ? 1u : 0u; L.dcf = childLoc ? newDepth : 0u;
+			L.lmode = childLoc ? 1u : 0u; L.dcf = childLoc ? newDepth : 0u; L.el = 0;
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
@@ -1310,6 +1316,52 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 	}
 }
 
+/* A frame that has stood on the text from its first position (dcf == depth) and has just met the text's other base has
+ * ONE alternative in all: that base, there.  What the reference does with it (:743-1064) is fixed: it takes it (with a draw
+ * that decides nothing when qualities are not considered, none otherwise: the single-eligible-target rule), recurses, and
+ * -- its only alternative spent -- returns what the child returns.  Such a frame needs no record: the lane becomes the
+ * child (the mismatch is written where a frame's is, the counters a frame entry moves are moved), and whatever comes back
+ * goes to the frame the chain of such levels started from (L.el counts them; ST_FRAME_RETURN skips them).  false: not such a
+ * case (the half-and-half re-jump through the ftab, the frame arena full) -- the caller goes the general way. */
+template <bool RL>
+BT_HD bool bt_loc_elide(BtLane& L, const BtProgram& P, const BtWarm& W, const BtScratch& S, unsigned long long* CNT)
+{
+	const uint32_t i = L.d, j = L.lt, icur = L.qlen - i - 1u;
+	if (L.el == 63u || L.sd + 1u >= S.a->frCap) return false;
+	const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
+	if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < WSEL(ftabChars) && WSEL(ftabChars) <= L.d5) return false;
+	if (L.eligibleNum > 1 || L.elignore) (void)bt_rnd_u32(L);        /* r % 1: the draw is made, its value decides nothing */
+	const uint32_t btham = L.ham + bt_mm_penalty(L.maq, L.q);
+	uint32_t nu = L.fu, n1 = L.f1, n2 = L.f2, n3 = L.f3;
+	if (i < L.f1)      { nu = L.f1; n1 = L.f2; n2 = L.f3; }
+	else if (i < L.f2) { n1 = L.f2; n2 = L.f3; }
+	else if (i < L.f3) { n2 = L.f3; }
+	FRW(L.sd, FR_MM) = icur | (j << 16);
+	if (i + 1u == L.qlen) {
+		/* the substitution is the read's last position: reported as the child's alignment; this frame then returns what
+		 * the report returns (RC_FELL: straight to ST_FRAME_RETURN) */
+		BT_GOTO_RA(L.sd + 1u, L.top, L.top + 1u, btham, RC_FELL, 1);
+		return true;
+	}
+	/* the child's frame, entered (:363-455) */
+	L.ebase = bt_ent(L, L.d) + 1u;
+	L.sd = L.sd + 1u; L.el = L.el + 1u;
+	L.depth = i + 1u; L.dcf = i + 1u; L.bot = L.top + 1u; L.ham = btham;
+	L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
+	BT_COUNT(CN_FRAMES);
+	if (L.halfAndHalf) {
+		const uint32_t maxBts = P.steps[L.step].maxBts;
+		if (maxBts > 0 && L.numBts == maxBts) { L.bailed = 1; L.ret = 0; L.state = ST_FRAME_RETURN; return true; }
+		L.numBts++;
+	}
+	L.altNum = 0; L.eligibleNum = 0;
+	L.elcint = 0; L.elignore = 1;
+	L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0;
+	L.d = L.depth;
+	L.state = ST_STEP_BEGIN;
+	return true;
+}
+
 /*
  * Advance one lane until it has a memory request for this round (req.kind != RQ_NONE) or has
  * finished its read (state ST_IDLE).  `res` is the answer to the lane's previous request.
@@ -1318,12 +1370,13 @@ template <bool RL>
 BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
                        const BtRes& res, BtReq& req, unsigned long long* CNT)
 {
-	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;
+	req.kind = RQ_NONE; req.n = 0; req.a = 0; req.x = 0; req.wchunk = 0xffffu;        /* (tally: the caller's to clear and to read) */
 	/* locus mode: the window of text this call's answer holds (0 none, 1 a locus record's 48 characters, 2 pieces of the
 	 * reversed text), the depth it starts at and the anchor it belongs to; whether the step just decided was a mismatch */
 	uint32_t wkind = 0, wd0 = 0, wanchor = 0;
 	bool locMiss = false;
 	for (;;) {
+		BT_PROF_TICK(PS_RUN_ITERS);
 		BT_PROF_T0(t_resume);
 		if (RL && (L.state == ST_LOC_REC || L.state == ST_LOC_TXT)) {
 			if (L.state == ST_LOC_REC) {
@@ -1337,6 +1390,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 		}
 		if (RL && L.state == ST_STEP_BEGIN && L.lmode) {
 			/* ---- locus mode: the next event of the frame (see "locus mode: the pieces") ------------------------ */
+			BT_PROF_T0(t_locus);
+			BT_PROF_TICK(PS_LOCUS_PASSES);
 			const uint32_t d = L.d;
 			if (d >= L.qlen) L.state = ST_FELL_OFF;
 			else if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; }
@@ -1351,7 +1406,6 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 					 * characters; the address is a word's, not a piece's) */
 					const uint32_t y = len - anchor + d;
 					BT_REQ_FETCH(WSEL(rtxt) + (y >> 4), ((y & 15u) + (L.qlen - d) + 63u) >> 6, nullptr);
-					BT_COUNT(CN_TXTWIN);
 					L.state = ST_LOC_TXT;
 					BT_COUNT_HOST(CN_FETCH);
 					return;
@@ -1367,7 +1421,9 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				const bool textEnds = anchor < lim;
 				if (textEnds) lim = anchor;
 				uint32_t tf;
+				BT_PROF_T0(t_mm);
 				const uint32_t fm = bt_loc_first_mm(L, S, wt, sh, wd0, d, lim, &tf);
+				BT_PROF_ADD(PS_LOC_MM, t_mm);
 				/* the event: the first mismatch; else a half-and-half boundary; else the text's or the read's end */
 				uint32_t dev = fm;
 				if (L.halfAndHalf) {
@@ -1383,16 +1439,17 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				 * position that is an alternative, one mapLF1 per position that is not */
 				const uint32_t upto = dev == 0xffffffffu ? lim : dev;
 				{
+					BT_PROF_T0(t_tally);
 					const uint32_t lo = d > L.fu ? d : (uint32_t)L.fu;
 					const uint32_t nalt = bt_loc_count_alt(L, S, lo < upto ? lo : upto, upto);
-					BT_COUNT_N(CN_TLFEX, nalt); BT_COUNT_N(CN_TLF1, (upto - d) - nalt);
+					req.tally += (nalt << 16) | ((upto - d) - nalt);
+					BT_PROF_ADD(PS_LOC_TALLY, t_tally);
 				}
 				if (dev == 0xffffffffu) {
 					/* everything the window holds matches and the read goes on: the next window */
 					L.d = upto;
 					const uint32_t y = len - anchor + upto;
 					BT_REQ_FETCH(WSEL(rtxt) + (y >> 4), ((y & 15u) + (L.qlen - upto) + 63u) >> 6, nullptr);
-					BT_COUNT(CN_TXTWIN);
 					L.state = ST_LOC_TXT;
 					BT_COUNT_HOST(CN_FETCH);
 					return;
@@ -1413,9 +1470,10 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				locMiss = dev == fm || (textEnds && dev == anchor);
 				L.lz = (textEnds && dev == anchor) ? 1u : 0u;
 				if (dev == fm) L.lt = tf;
-				if (alt) BT_COUNT(CN_TLFEX); else BT_COUNT(CN_TLF1);
+				req.tally += alt ? 0x10000u : 1u;
 				L.state = ST_STEP_LOC;
 			}
+			BT_PROF_ADD(PS_LOCUS, t_locus);
 		}
 		/* ---- resume: the read window arrived ------------------------------------------------- */
 		if (!RL && L.state == ST_WIN_DONE) {
@@ -1435,7 +1493,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			const uint32_t c = L.c, q = L.q, d = L.d, cur = L.qlen - d - 1u;
 			const uint32_t e = bt_ent(L, d);
 			uint32_t ta[4], tb[4];
-			if (RL && L.state == ST_STEP_LOC) {
+			const bool wasLoc = RL && L.state == ST_STEP_LOC;
+			if (wasLoc) {
 				/* decided by the text: the quartet of a one-row range -- the text's base has the one row that goes with it,
 				 * the other three ranges are empty (all four at the text's start); nothing is kept of it but the record */
 				const uint32_t t = locMiss ? (uint32_t)L.lt : c;
@@ -1526,7 +1585,9 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			if (frameFail) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else if (cur == 0 && L.bot > L.top && !invalidHH && !invalidExact && !reportedPartial)
 				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP, L.lmode);
-			else if ((L.top == L.bot || btDespite) && L.altNum > 0) L.state = ST_BT_LOOP;
+			else if ((L.top == L.bot || btDespite) && L.altNum > 0) {
+				if (!(RL && wasLoc && locMiss && L.dcf == L.depth && L.top == L.bot && bt_loc_elide<RL>(L, P, W, S, CNT))) L.state = ST_BT_LOOP;
+			}
 			else if (mustBacktrack || invalidHH || invalidExact || L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
 		}
@@ -1552,7 +1613,6 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				 * 48 characters to the left of it).  Reads with an N stay in row space: an N never matches, which the packed
 				 * comparison does not know */
 				BT_REQ_FETCH(WSEL(loc) + L.top, 1, nullptr);
-				BT_COUNT(CN_LOCREC);
 				L.state = ST_LOC_REC;
 				BT_COUNT_HOST(CN_FETCH);
 				return;
@@ -1611,7 +1671,6 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			if (W.locOn) {
 				/* the dense suffix array: the row's locus record instead of the walk to a sampled row */
 				BT_REQ_FETCH(WSEL(loc) + L.crow, 1, nullptr);
-				BT_COUNT(CN_LOCREC);
 				L.state = ST_RESOLVE_DONE;
 				BT_COUNT_HOST(CN_FETCH);
 				return;

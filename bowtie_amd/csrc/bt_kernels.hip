@@ -158,7 +158,8 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 #ifdef BT_PROFILE
 	bool pf_prevSingle = false;
 #endif
-	uint32_t sc_iters = 0, sc_rounds = 0, sc_fetch = 0, sc_chase = 0, sc_lfex = 0, sc_lf2 = 0, sc_lf1 = 0, sc_same = 0;
+	uint32_t sc_iters = 0, sc_rounds = 0, sc_fetch = 0, sc_chase = 0, sc_lfex = 0, sc_lf2 = 0, sc_lf1 = 0, sc_same = 0, sc_locrec = 0, sc_txtwin = 0;
+	uint32_t tl_acc = 0;       /* this lane's locus-mode tallies (BtReq::tally: mapLFEx | mapLF1 steps decided by the text), flushed before a half can overflow */
 
 	if (EXT && A.pool && A.adopt) {
 		/* carry-over: what lane g of the previous launch parked -- state and pending request; the scratch slot is g
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		BT_PROF_ADD(PS_RANK, t_rank);
 
 		/* ---- advance every lane to its next request, pulling new reads as old ones finish ------- */
+		req.tally = 0;
 		for (;;) {
 			if (L.state == ST_IDLE) {
 				if (drained) break;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
 		 * have run out of work simply carry an empty request */
+		tl_acc += req.tally;
 		const bool live = L.state != ST_IDLE;
 		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
 		if (__ballot(live) == 0) break;
@@ -281,6 +284,16 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			sc_lf2 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_C2));
 			sc_lf1 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_LF1));
 			sc_same += (uint32_t)__builtin_popcountll(__ballot(isR && req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u));
+			if (RL || WARM.locOn) {
+				const bool isF = req.kind == RQ_FETCH;
+				sc_locrec += (uint32_t)__builtin_popcountll(__ballot(isF && (L.state == ST_LOC_REC || (L.state == ST_RESOLVE_DONE && WARM.locOn))));
+				sc_txtwin += (uint32_t)__builtin_popcountll(__ballot(isF && L.state == ST_LOC_TXT));
+				/* a call adds at most a read's length to a half: flush long before 2^15 */
+				if ((sc_rounds & 63u) == 63u && __ballot((tl_acc & 0x60006000u) != 0) != 0) {
+					atomicAdd(&CNT[CN_TLFEX], (unsigned long long)(tl_acc >> 16)); atomicAdd(&CNT[CN_TLF1], (unsigned long long)(tl_acc & 0xffffu));
+					tl_acc = 0;
+				}
+			}
 #ifdef BT_PROFILE
 			/* how much of the search runs on ranges that are one BWT row (round 5: the measurement behind locus mode) */
 			{
@@ -318,7 +331,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		{ BtU4 v; v.x = A.launchSeq; v.y = 0; v.z = 0; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 15, v); }
 		atomicAdd(A.parkedOf + L.bid, 1u);
 	}
+	if (tl_acc) { atomicAdd(&CNT[CN_TLFEX], (unsigned long long)(tl_acc >> 16)); atomicAdd(&CNT[CN_TLF1], (unsigned long long)(tl_acc & 0xffffu)); }
 	if ((threadIdx.x & 63u) == 0) {
+		atomicAdd(&CNT[CN_LOCREC], (unsigned long long)sc_locrec); atomicAdd(&CNT[CN_TXTWIN], (unsigned long long)sc_txtwin);
 		atomicAdd(&CNT[CN_ITERS], (unsigned long long)sc_iters); atomicAdd(&CNT[CN_WROUNDS], (unsigned long long)sc_rounds);
 		atomicAdd(&CNT[CN_FETCH], (unsigned long long)sc_fetch); atomicAdd(&CNT[CN_CHASE], (unsigned long long)sc_chase);
 		atomicAdd(&CNT[CN_LFEX], (unsigned long long)sc_lfex); atomicAdd(&CNT[CN_LF2], (unsigned long long)sc_lf2);

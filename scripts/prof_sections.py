@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("BT_LIB", "libbowtie_amd_prof.so")
 import bench  # noqa
 from bowtie_amd import aligner as AL
-NAMES = ["RESUME", "SLOW", "WAIT(unused)", "FETCH+RANK", "REFILL", "LANE_RUN", "FELL_OFF", "RESOLVE_DONE", "RA_END", "FRAME_RETURN", "CHILD_RET", "RESCAN", "SEARCH_END", "PHASE_NEXT", "SEARCH_BEGIN", "FTABSEQ_DONE", "FTAB_DONE", "BT_LOOP", "CANDSCAN", "BT_PICK", "RA_BEGIN", "ROW_BEGIN", "FRAME_ENTER", "SLOW_PASSES(count)", "SINGLE_ROW_LFEX(count)", "SINGLE_ROW_RUNS(count)"]
+NAMES = ["RESUME", "SLOW", "WAIT(unused)", "FETCH+RANK", "REFILL", "LANE_RUN", "FELL_OFF", "RESOLVE_DONE", "RA_END", "FRAME_RETURN", "CHILD_RET", "RESCAN", "SEARCH_END", "PHASE_NEXT", "SEARCH_BEGIN", "FTABSEQ_DONE", "FTAB_DONE", "BT_LOOP", "CANDSCAN", "BT_PICK", "RA_BEGIN", "ROW_BEGIN", "FRAME_ENTER", "SLOW_PASSES(count)", "SINGLE_ROW_LFEX(count)", "SINGLE_ROW_RUNS(count)", "LOCUS", "LOCUS_FIRST_MM", "LOCUS_TALLY", "LOCUS_PASSES(count)", "RUN_ITERS(count)"]
 orig_counts = AL.lib().bt_ctx_counts
 def hook(h, cnt, reset):
     rc = orig_counts(h, cnt, reset)

@@ -153,6 +153,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 			if (drained[g]) continue;
 			BtLane& L = lanes[g];
 			BtReq req;
+			req.tally = 0;
 			for (;;) {
 				if (L.state == ST_IDLE) {
 					if (next >= in->n_reads) { drained[g] = 1; live--; break; }
@@ -161,7 +162,10 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 				bt_lane_run<RL>(L, P, H, W, cold, scr[g], res[g], req, CNT);
 				if (L.state != ST_IDLE) break;
 			}
+			CNT[CN_TLFEX] += req.tally >> 16; CNT[CN_TLF1] += req.tally & 0xffffu;      /* locus mode's steps decided by the text (also a finished read's) */
 			if (drained[g]) continue;
+			if (req.kind == RQ_FETCH && (L.state == ST_LOC_REC || (L.state == ST_RESOLVE_DONE && W.locOn))) BT_COUNT(CN_LOCREC);
+			if (req.kind == RQ_FETCH && L.state == ST_LOC_TXT) BT_COUNT(CN_TXTWIN);
 			BT_COUNT(CN_ITERS);
 			L.iters++;
 			if (parkEvery && (parkRng = parkRng * 1664525u + 1013904223u, (parkRng >> 8) % parkEvery == 0)) {

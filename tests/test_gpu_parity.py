@@ -260,7 +260,7 @@ def test_gpu_scratch_overflow_is_retried(gidx, monkeypatch):
     """A read whose backtracking outgrows its per-lane arenas is flagged by the kernel and re-run by
     bt_align_batch through a worst-case-sized context; with absurdly small arenas most reads take
     that road and the results must still equal the oracle's."""
-    monkeypatch.setenv("BT_ENTRY_CAP", "24")
+    monkeypatch.setenv("BT_ENTRY_CAP", "12")      # (24 until round 5: locus mode keeps one range-stack entry for a whole stretch that matches the text)
     monkeypatch.setenv("BT_FRAME_CAP", "3")
     monkeypatch.setenv("BT_PARTIAL_CAP", "4")
     for index, rname, mode in (("multi", "syn100", "n2"), ("multi", "syn50lowq", "n3"), ("e_coli", "syn76", "v2"),
@@ -345,7 +345,7 @@ def test_gpu_device_path_retries_overflowed_reads_on_the_stream(gidx, monkeypatc
     """bt_align_batch_device with absurdly small arenas: the reads that outgrow them are collected and searched again
     on the same stream (no host copy); what the caller reads back after the sync is complete and equals the oracle's."""
     monkeypatch.setenv("BT_DEVICE_RETRY", "1")                  # the default since round 3
-    monkeypatch.setenv("BT_ENTRY_CAP", "24")
+    monkeypatch.setenv("BT_ENTRY_CAP", "12")      # (24 until round 5: locus mode keeps one range-stack entry for a whole stretch that matches the text)
     monkeypatch.setenv("BT_FRAME_CAP", "3")
     monkeypatch.setenv("BT_PARTIAL_CAP", "4")
     for index, rname, mode in (("multi", "syn100", "n2"), ("multi", "syn50lowq", "n3"), ("e_coli", "syn76", "v2"), ("multi", "syn36", "n2_k3"),
