@@ -42,10 +42,28 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # passes, gfx950-corrected as MI355X_MICROARCH.md prescribes): bench.py cannot run the profiler on itself,
 # so the figures live in profiles/traffic.json keyed by (kernel template instance, workload) and are used
 # only when the kernel this run launched is the one that was profiled -- otherwise `traffic` is null.
-def gather_ceiling(index_kind: str):
+def gather_ceiling(index_kind: str, al=None, cus: int = 0):
     """Measured ceiling of the access pattern itself on this GPU: independent random rank queries over the index image
-    with nothing else going on (bt_bench_gather; round 3: the 32-byte rank blocks the kernels gather), best
-    configuration, priced at SURVEY 8(d)'s 128 bytes per query so that it compares with roofline.achieved."""
+    with nothing else going on (bt_bench_gather; the 32-byte rank blocks the kernels gather), best configuration,
+    priced at SURVEY 8(d)'s 128 bytes per query so that it compares with roofline.achieved.  Measured in this run when a
+    context is at hand (< 1 s), otherwise read from an earlier round's file."""
+    if al is not None and cus > 0:
+        try:
+            lib = AL.lib()
+            lib.bt_bench_gather.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+            best = None
+            for bpc in (2, 4, 8):
+                ms, gbs = C.c_float(), C.c_double()
+                nb, iters = cus * bpc, 2048
+                if lib.bt_bench_gather(al._h, 0, nb, iters, 0, C.byref(ms), C.byref(gbs)) != 0:
+                    raise RuntimeError("bt_bench_gather")
+                q = nb * 256.0 * iters / (ms.value * 1e-3)
+                if best is None or q > best[0]:
+                    best = (q, bpc)
+            return {"GBps": best[0] * 128.0 / 1e9, "Gqueries_per_s": best[0] / 1e9,
+                    "source": "measured in this run: bt_bench_gather, %d blocks of 256 lanes per CU, 2048 independent rank queries per lane" % best[1]}
+        except Exception as e:      # noqa: BLE001  -- the file of an earlier round stands in
+            log("[bench] gather ceiling not measured (%s): reading an earlier round's" % e)
     src = ("profiles/r3/gather_big.json" if index_kind == "big" else "profiles/r2/gather_ecoli.json")
     try:
         with open(os.path.join(ROOT, src)) as f:
@@ -90,6 +108,11 @@ WORKLOADS = {
                                 mm_dist=(0, 0, 1, 1, 2), reads=1_000_000),
     "big_pe_n1_best_50": dict(index="big", length=50, paired=True, pol=dict(mode="n", mms=1, best=True, max_ins=500),
                               mm_dist=(0, 0, 1, 1, 2), reads=12_500_000),
+    # the same pairs WITHOUT --best: the reference's default paired-end aligner, PairedBWAlignerV1 (aligner.h:606-1480)
+    "big_pe_n1_50_v1": dict(index="big", length=50, paired=True, pol=dict(mode="n", mms=1, max_ins=500, pe_v1=True),
+                            mm_dist=(0, 0, 1, 1, 2), reads=12_500_000),
+    "ecoli_pe_n1_50_v1": dict(index="ecoli", length=50, paired=True, pol=dict(mode="n", mms=1, max_ins=500, pe_v1=True),
+                              mm_dist=(0, 0, 1, 1, 2), reads=1_000_000),
 }
 
 
@@ -693,7 +716,16 @@ def main():
                          "mean_active_lanes_per_round": per_launch["lane_iters"] / max(1.0, per_launch["wave_rounds"]),
                          "wave_rounds_per_launch": per_launch["wave_rounds"]},
         }
-        gc = gather_ceiling(wl["index"]) if not args.genome else None
+        gc = None
+        if not paired and not wl["pol"].get("best"):
+            try:
+                gal = AL.Aligner(idx, pol)
+                gc = gather_ceiling(wl["index"], gal, torch.cuda.get_device_properties(dev).multi_processor_count)
+                gal.close()
+            except Exception:       # noqa: BLE001
+                gc = None
+        if gc is None and not args.genome:
+            gc = gather_ceiling(wl["index"])
         if gc:
             # the kernel's rank traffic (the 128-byte gathers) against what the memory system delivers for that
             # pattern alone; `frac` above stays against the 8 TB/s streaming peak
@@ -739,8 +771,10 @@ def main():
                 torch.cuda.empty_cache()
         also = args.also
         if also == "auto":
-            also = "big_v2_76,big_pe_n1_best_50" if (world == 1 and args.workload == "big_n2_100" and not args.reads and not args.genome
-                                                     and not args.no_cpu) else "none"
+            # every other BASELINE configuration (2: e_coli -v 0 36 bp; 3: -v 2 76 bp; 5's share: pairs --best) and the two other
+            # stateful modes people run: single-end --best, and pairs without --best (the reference's default paired aligner)
+            also = ("big_v2_76,big_pe_n1_best_50,ecoli_v0_36,big_n2_best_100:16000000,big_pe_n1_50_v1:6250000"
+                    if (world == 1 and args.workload == "big_n2_100" and not args.reads and not args.genome and not args.no_cpu) else "none")
         if also != "none" and world == 1:
             # BASELINE configs 3 and 5 in the same line: each in its own process (the index cache under /tmp is reused),
             # 2 timed steps, every hit re-verified where the workload allows it, a sample diffed against the reference
@@ -748,9 +782,11 @@ def main():
             del rb, rb2, M, pipes, last
             torch.cuda.empty_cache()
             out["config"]["other_workloads"] = {}
-            for name in [x for x in also.split(",") if x]:
+            for item in [x for x in also.split(",") if x]:
+                name, _, nreads = item.partition(":")           # "workload[:reads per step]"
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "2", "--warmup", "1",
-                                    "--cpu-diff-only", "--also", "none"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                                    "--cpu-diff-only", "--also", "none"] + (["--reads", nreads] if nreads else []),
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 try:
                     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
                     out["config"]["other_workloads"][name] = {

@@ -504,6 +504,15 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 			if (lanes < BT_BLOCK) lanes = BT_BLOCK;
 		}
 		c->arenaWords = words; c->arenaLanes = lanes;
+		/* fewer lanes than asked for is slower, not wrong -- but say so once (BT_VERBOSE), and ask again when the caller's
+		 * batches still want more and the device may have room by then: arenaAsked stands only as long as memory is short */
+		if (lanes < c->arenaAsked) {
+			if (getenv("BT_VERBOSE")) fprintf(stderr, "bowtie_amd: best-first arenas for %u lanes instead of %u (device memory: %.1f of %.1f GB free)\n",
+			                                  lanes, c->arenaAsked, freeB / 1e9, totB / 1e9);
+			size_t f2 = 0, t2 = 0;
+			if (hipMemGetInfo(&f2, &t2) == hipSuccess && (uint64_t)f2 / 100u * env_u32("BT_BEST_ARENA_FRAC", 45u) >= (uint64_t)c->arenaAsked * words * 4u)
+				c->arenaAsked = lanes;        /* there is room after all (another context went away): the next call may grow */
+		}
 	}
 	if (c->arenaLanes < lanes) lanes = c->arenaLanes;
 	BtBatchDev B;

@@ -860,7 +860,7 @@ int list_input(Options& O)
 				                                : "Error, fewer reads in file specified with -2 than in file specified with -1";
 				r = BT_ERR_READS;
 			}
-			if (r == BT_OK && tabbed) bt_io_split_tabbed(&b1, &b2, &bu, &order);
+			if (r == BT_OK && tabbed && !bt_io_split_tabbed(&b1, &b2, &bu, &order)) { err = "Error: internal: a --12 batch lost its pair flags"; r = BT_ERR_READS; }
 		}
 		if (r != BT_OK) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
 		if (b1.n == 0 && bu.n == 0) break;
@@ -931,7 +931,7 @@ int main(int argc, char** argv)
 				/* a --12 batch: the unpaired records leave for a job of their own */
 				std::unique_ptr<Job> u(new Job());
 				u->store.reset(new BtHostBatch());
-				bt_io_split_tabbed(j->store.get(), j->store2.get(), u->store.get(), &j->order);
+				if (!bt_io_split_tabbed(j->store.get(), j->store2.get(), u->store.get(), &j->order)) { err = "Error: internal: a --12 batch lost its pair flags"; r = BT_ERR_READS; }
 				j->rb = j->store->view(); j->rb2 = j->store2->view();
 				if (u->store->n) { u->rb = u->store->view(); j->unp = std::move(u); }
 				else j->order.clear();
@@ -1022,7 +1022,9 @@ int main(int argc, char** argv)
 		}
 		if (streamed) {
 			const char* cv = getenv("BT_CLI_CARRY");          /* diagnostics: launches a read may ride along (0 = none) */
-			if (bt_ctx_set_carry(ctxs[g], cv && *cv ? atoi(cv) : 12) != BT_OK) die("Error: bt_ctx_set_carry failed");
+			int cage = cv && *cv ? atoi(cv) : 12;
+			if (cage > 12) cage = 12;                         /* the searcher keeps at most 13 batches in flight: the oldest must be able to complete */
+			if (bt_ctx_set_carry(ctxs[g], cage) != BT_OK) die("Error: bt_ctx_set_carry failed");
 			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 		}
@@ -1045,7 +1047,10 @@ int main(int argc, char** argv)
 	const int G = (int)ctxs.size();
 	/* the searcher never waits for the writer: a batch's results are a few hundred MB of host memory, and a searcher held up
 	 * here stops feeding the GPU (round 4's timeline of a 64 M-read run: 1.8 s of every 10 with nothing enqueued) */
-	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 64);
+	/* the results queue: deep enough that the searcher does not wait for the writer while the in-flight batches come back in a
+	 * burst (up to BT_BATCH_RING - 2 = 14 of them), not so deep that a slow writer -- SAM formatting, a slow file system, the
+	 * --al/--un dumps -- lets batches of 150 MB and more pile up on the host without bound (round 4 had G + 64) */
+	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 16);
 	std::vector<double> busy_gpu((size_t)G, 0.0);
 	std::thread reader([&] {
 		uint64_t seq = 0;
@@ -1397,9 +1402,16 @@ int main(int argc, char** argv)
 			 * the launches it depends on are all enqueued -- not forced out: forcing (flush) stops the wavefronts from taking
 			 * new reads until the stragglers are done, which is what a 64 M-read run spent 2.8 s of its 18 on in round 4's
 			 * timeline. */
-			while (fl.size() >= 13 && !abort_run.load()) {
-				drain(0);
-				if (fl.size() >= 13) std::this_thread::sleep_for(std::chrono::microseconds(500));
+			{
+				const double tw = now_s();
+				while (fl.size() >= 13 && !abort_run.load()) {
+					drain(0);
+					if (fl.size() < 13) break;
+					/* the oldest batch completes by itself within the time its launches take; if it has not after a minute
+					 * something is wrong on the device: a flush waits for the stream and hands the error out */
+					if (now_s() - tw > 60.0) { drain(1); break; }
+					std::this_thread::sleep_for(std::chrono::microseconds(500));
+				}
 			}
 			g_tl.mark("search: taken", j->seq);
 			search_prepare(O, j.get());

@@ -265,7 +265,7 @@ struct BtLane {
 	uint32_t sd : 7, depth : 11, d : 11;
 	uint32_t top, bot;
 	uint32_t ham : 16, lowAltQual : 8,
-	         el : 6;                 /* locus mode: levels of the reference's recursion gone through without a frame of their own since the last real one (bt_loc_elide) */
+	         el : 6;                 /* locus mode: levels of the reference's recursion gone through without a frame of their own since the last real one (bt_loc_descend) */
 	uint32_t fu : 11, f1 : 11, elcint : 2, elignore : 1, candValid : 1;
 	uint32_t f2 : 11, f3 : 11;
 	uint32_t altNum : 12, eligibleNum : 12;
@@ -763,6 +763,34 @@ BT_HD uint32_t bt_loc_first_mm(const BtLane& L, const BtScratch& S, const BtLocW
 	return fm;
 }
 
+/* Save the current frame before a child is entered: its record in HBM (two 16-byte stores and a word) and the LDS
+ * top-of-stack copy, from which a child that fails pops it back without a fetch. */
+BT_HD void bt_frame_push(BtLane& L, const BtScratch& S)
+{
+	const uint32_t ts = S.tosStride;
+	uint32_t w[BT_TOS_WORDS];
+	w[FR_W0] = L.depth | (L.d << 11);
+	w[FR_W1] = L.ham | (L.lowAltQual << 16);
+	w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (L.ccValid << 26);
+	w[FR_W3] = L.f2 | (L.f3 << 11);
+	w[FR_W4] = L.altNum | (L.eligibleNum << 12);
+	w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25) | (L.el << 26);
+	w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
+	w[FR_EBASE] = L.ebase;
+	w[FR_ANCHOR] = L.top;
+	uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
+	BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
+	bt_st4(fr, q0); bt_st4(fr + 4, q1);
+	FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
+	BT_UNROLL
+	for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
+	if (L.ccValid) {
+		BT_UNROLL
+		for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts] = S.tos[k * ts];
+	}
+	L.tosFrame = L.sd; L.tosValid = 1;
+}
+
 /* ---- the slow states: everything that is not "next query position" / "next SA-walk step" ---- */
 template <bool RL>
 BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtWarm& W, const BtCold& C, const BtScratch& S,
@@ -782,6 +810,42 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.sd >= L.reportPartials) BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_FELL, L.lmode);
 			else { L.ret = 0; L.state = ST_FRAME_RETURN; }
 		} while (0); BT_PROF_ADD(PS_FELL_OFF, t_fell_off); }
+
+		/* ---- reportAlignment / reportFullAlignment (:1455-1565) -------------------------- */
+		if (ST_IS(ST_RA_BEGIN)) { BT_PROF_T0(t_ra_begin); do {
+			if (L.reportPartials) {
+				if (L.ra_sd > 0) bt_report_partial(L, S, L.ra_sd);
+				L.ret = 0; L.state = ST_RA_END; break;
+			}
+			uint32_t stratum = 0;
+			BT_NOUNROLL
+			for (uint32_t i = 0; i < L.ra_sd; i++)                      /* calcStratum (:1164-1177) */
+				if ((BT_FR_MM(i) & 0xffffu) >= (L.qlen - L.r3)) stratum++;
+			stratum += L.nmuts;
+			L.ra_stratum = stratum;
+			L.ra_cost = (L.ra_cost | (stratum << 14)) & 0xffffu;
+			if (L.ra_sd + L.nmuts == 0 && !L.reportExacts) { L.ret = 0; L.state = ST_RA_END; break; }
+			{
+				const uint32_t spread = L.ra_bot - L.ra_top;
+				uint32_t r = bt_rnd_u32(L);
+				if (C.ix[0].wide) {                                     /* nextU<TIndexOffU>() of the 64-bit build: random_source.h:56-62 */
+					const uint64_t r64 = ((uint64_t)r << 32) | bt_rnd_u32(L);
+					r = (uint32_t)(r64 % spread);
+				} else r %= spread;
+				L.ra_r = L.ra_top + r;
+				L.ra_i = 0;
+			}
+			L.state = ST_ROW_BEGIN;
+		} while (0); BT_PROF_ADD(PS_RA_BEGIN, t_ra_begin); }
+
+		if (ST_IS(ST_ROW_BEGIN)) { BT_PROF_T0(t_row_begin); do {
+			const uint32_t spread = L.ra_bot - L.ra_top;
+			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
+			uint32_t ri = L.ra_r + L.ra_i;
+			if (ri >= L.ra_bot) ri -= spread;
+			L.crow = ri; L.cjumps = 0;
+			L.state = (RL && L.ra_l) ? ST_RESOLVE_DONE : ST_CHASE_CHECK;       /* in locus mode "the row" is the anchor: nothing to walk */
+		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
 
 		/* ---- an SA walk reached a sampled row: offset -> (tidx,toff) -> sink (ebwt.h:2569-2746) ---- */
 		if (ST_IS(ST_RESOLVE_DONE)) { BT_PROF_T0(t_resolve_done); do {
@@ -844,7 +908,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 
 		/* ---- return from a frame: pop the parent's record (LDS copy, else one fetch) ---------- */
 		if (ST_IS(ST_FRAME_RETURN) || ST_IS(ST_FRAME_FETCHED)) { BT_PROF_T0(t_frame_return); do {
-			/* the levels gone through without a frame (bt_loc_elide) return with the frame they started from */
+			/* "child true => return true" (:972-974) all the way up: nothing of the frames in between is looked at again */
+			if (L.ret && L.state == ST_FRAME_RETURN) { L.sd = 0; L.el = 0; L.state = ST_SEARCH_END; break; }
+			/* the levels gone through without a frame (bt_loc_descend) return with the frame they started from */
 			if (L.sd == L.el) { L.state = ST_SEARCH_END; break; }
 			const uint32_t f = L.sd - L.el - 1u;
 			uint32_t w[BT_TOS_WORDS];
@@ -1231,71 +1297,13 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			/* push: save the parent (HBM record + LDS top-of-stack copy), enter the child */
 			if (L.sd + 1u >= S.a->frCap) { L.state = ST_ABORT; break; }
-			{
-				uint32_t w[BT_TOS_WORDS];
-				w[FR_W0] = L.depth | (L.d << 11);
-				w[FR_W1] = L.ham | (L.lowAltQual << 16);
-				w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (L.ccValid << 26);
-				w[FR_W3] = L.f2 | (L.f3 << 11);
-				w[FR_W4] = L.altNum | (L.eligibleNum << 12);
-				w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25) | (L.el << 26);
-				w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
-				w[FR_EBASE] = L.ebase;
-				w[FR_ANCHOR] = L.top;
-				uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
-				BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
-				bt_st4(fr, q0); bt_st4(fr + 4, q1);
-				FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
-				BT_UNROLL
-				for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
-				if (L.ccValid) {
-					BT_UNROLL
-					for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts] = S.tos[k * ts];
-				}
-				L.tosFrame = L.sd; L.tosValid = 1;
-			}
+			bt_frame_push(L, S);
 			L.ebase = bt_ent(L, L.d) + 1u;
 			L.lmode = childLoc ? 1u : 0u; L.dcf = childLoc ? newDepth : 0u; L.el = 0;
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
 			L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 			L.state = ST_FRAME_ENTER;
 		} while (0); BT_PROF_ADD(PS_BT_PICK, t_bt_pick); }
-
-		/* ---- reportAlignment / reportFullAlignment (:1455-1565) -------------------------- */
-		if (ST_IS(ST_RA_BEGIN)) { BT_PROF_T0(t_ra_begin); do {
-			if (L.reportPartials) {
-				if (L.ra_sd > 0) bt_report_partial(L, S, L.ra_sd);
-				L.ret = 0; L.state = ST_RA_END; break;
-			}
-			uint32_t stratum = 0;
-			BT_NOUNROLL
-			for (uint32_t i = 0; i < L.ra_sd; i++)                      /* calcStratum (:1164-1177) */
-				if ((BT_FR_MM(i) & 0xffffu) >= (L.qlen - L.r3)) stratum++;
-			stratum += L.nmuts;
-			L.ra_stratum = stratum;
-			L.ra_cost = (L.ra_cost | (stratum << 14)) & 0xffffu;
-			if (L.ra_sd + L.nmuts == 0 && !L.reportExacts) { L.ret = 0; L.state = ST_RA_END; break; }
-			{
-				const uint32_t spread = L.ra_bot - L.ra_top;
-				uint32_t r = bt_rnd_u32(L);
-				if (C.ix[0].wide) {                                     /* nextU<TIndexOffU>() of the 64-bit build: random_source.h:56-62 */
-					const uint64_t r64 = ((uint64_t)r << 32) | bt_rnd_u32(L);
-					r = (uint32_t)(r64 % spread);
-				} else r %= spread;
-				L.ra_r = L.ra_top + r;
-				L.ra_i = 0;
-			}
-			L.state = ST_ROW_BEGIN;
-		} while (0); BT_PROF_ADD(PS_RA_BEGIN, t_ra_begin); }
-
-		if (ST_IS(ST_ROW_BEGIN)) { BT_PROF_T0(t_row_begin); do {
-			const uint32_t spread = L.ra_bot - L.ra_top;
-			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
-			uint32_t ri = L.ra_r + L.ra_i;
-			if (ri >= L.ra_bot) ri -= spread;
-			L.crow = ri; L.cjumps = 0;
-			L.state = (RL && L.ra_l) ? ST_RESOLVE_DONE : ST_CHASE_CHECK;       /* in locus mode "the row" is the anchor: nothing to walk */
-		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
 
 		/* ---- frame prologue (:363-455) -------------------------------------------------- */
 		if (ST_IS(ST_FRAME_ENTER)) { BT_PROF_T0(t_frame_enter); do {
@@ -1316,18 +1324,23 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 	}
 }
 
-/* A frame that has stood on the text from its first position (dcf == depth) and has just met the text's other base has
- * ONE alternative in all: that base, there.  What the reference does with it (:743-1064) is fixed: it takes it (with a draw
- * that decides nothing when qualities are not considered, none otherwise: the single-eligible-target rule), recurses, and
- * -- its only alternative spent -- returns what the child returns.  Such a frame needs no record: the lane becomes the
- * child (the mismatch is written where a frame's is, the counters a frame entry moves are moved), and whatever comes back
- * goes to the frame the chain of such levels started from (L.el counts them; ST_FRAME_RETURN skips them).  false: not such a
- * case (the half-and-half re-jump through the ftab, the frame arena full) -- the caller goes the general way. */
+/* A frame in locus mode has just met the text's other base at its last position, as an alternative of the eligible
+ * quality.  That position is the deepest of the frame, so it is the target the reference takes next (:767-834) -- with a
+ * draw that decides nothing (r % 1) unless it is the single eligible target, in which case there is none -- and its child
+ * stands on the same anchor, one position further.  Taking it needs nothing from memory, so it is done here, where the
+ * step was decided, and not by the sweep's target choice:
+ *   - a frame that has stood on the text from its first position (dcf == depth) has this ONE alternative in all; its only
+ *     alternative spent, it returns what the child returns.  Such a frame needs no record: the lane becomes the child, and
+ *     whatever comes back goes to the frame the chain of such levels started from (L.el counts them; ST_FRAME_RETURN skips
+ *     them);
+ *   - a frame with positions in row space as well is saved like any frame that gets a child (bt_frame_push).
+ * false: not done here (the half-and-half re-jump through the ftab, the frame arena full) -- the caller goes the general way. */
 template <bool RL>
-BT_HD bool bt_loc_elide(BtLane& L, const BtProgram& P, const BtWarm& W, const BtScratch& S, unsigned long long* CNT)
+BT_HD bool bt_loc_descend(BtLane& L, const BtProgram& P, const BtWarm& W, const BtScratch& S, unsigned long long* CNT)
 {
 	const uint32_t i = L.d, j = L.lt, icur = L.qlen - i - 1u;
-	if (L.el == 63u || L.sd + 1u >= S.a->frCap) return false;
+	const bool pure = L.dcf == L.depth;
+	if ((pure && L.el == 63u) || L.sd + 1u >= S.a->frCap) return false;
 	const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
 	if (L.halfAndHalf && !rootNoFtab && L.r2 == L.r3 && i + 1u < WSEL(ftabChars) && WSEL(ftabChars) <= L.d5) return false;
 	if (L.eligibleNum > 1 || L.elignore) (void)bt_rnd_u32(L);        /* r % 1: the draw is made, its value decides nothing */
@@ -1337,15 +1350,18 @@ BT_HD bool bt_loc_elide(BtLane& L, const BtProgram& P, const BtWarm& W, const Bt
 	else if (i < L.f2) { n1 = L.f2; n2 = L.f3; }
 	else if (i < L.f3) { n2 = L.f3; }
 	FRW(L.sd, FR_MM) = icur | (j << 16);
+	L.pel = 15u ^ (1u << j); L.pi = i; L.pj = j;
 	if (i + 1u == L.qlen) {
-		/* the substitution is the read's last position: reported as the child's alignment; this frame then returns what
-		 * the report returns (RC_FELL: straight to ST_FRAME_RETURN) */
-		BT_GOTO_RA(L.sd + 1u, L.top, L.top + 1u, btham, RC_FELL, 1);
+		/* the substitution is the read's last position: reported as the child's alignment.  A frame with nothing else to
+		 * try then returns what the report returns (RC_FELL: straight to ST_FRAME_RETURN) */
+		BT_GOTO_RA(L.sd + 1u, L.top, L.top + 1u, btham, pure ? RC_FELL : RC_CHILD, 1);
 		return true;
 	}
+	if (pure) L.el = L.el + 1u;
+	else { bt_frame_push(L, S); L.el = 0; }
 	/* the child's frame, entered (:363-455) */
 	L.ebase = bt_ent(L, L.d) + 1u;
-	L.sd = L.sd + 1u; L.el = L.el + 1u;
+	L.sd = L.sd + 1u;
 	L.depth = i + 1u; L.dcf = i + 1u; L.bot = L.top + 1u; L.ham = btham;
 	L.fu = nu; L.f1 = n1; L.f2 = n2; L.f3 = n3;
 	BT_COUNT(CN_FRAMES);
@@ -1375,7 +1391,12 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 	 * reversed text), the depth it starts at and the anchor it belongs to; whether the step just decided was a mismatch */
 	uint32_t wkind = 0, wd0 = 0, wanchor = 0;
 	bool locMiss = false;
-	for (;;) {
+	/* ONE pass per call -- arrivals, the step they decide, the slow-state sweep, the next request -- and where a lane could go
+	 * on without memory (a position that needs no rank, the read's end, a check that fails) it waits for the next round's
+	 * pass instead of going round again: a wavefront pays for every trip round this code with all its lanes, the trips it
+	 * makes in a round are its slowest lane's, and a lane that waits a round costs nobody anything (scripts/pass_model.py:
+	 * 1.3 trips per wavefront and round in row space, 3 in locus mode, for 1.01-1.07 per lane). */
+	{
 		BT_PROF_TICK(PS_RUN_ITERS);
 		BT_PROF_T0(t_resume);
 		if (RL && (L.state == ST_LOC_REC || L.state == ST_LOC_TXT)) {
@@ -1586,7 +1607,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			else if (cur == 0 && L.bot > L.top && !invalidHH && !invalidExact && !reportedPartial)
 				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP, L.lmode);
 			else if ((L.top == L.bot || btDespite) && L.altNum > 0) {
-				if (!(RL && wasLoc && locMiss && L.dcf == L.depth && L.top == L.bot && bt_loc_elide<RL>(L, P, W, S, CNT))) L.state = ST_BT_LOOP;
+				if (!(RL && wasLoc && locMiss && L.fl_elig && !L.lz && L.top == L.bot && bt_loc_descend<RL>(L, P, W, S, CNT))) L.state = ST_BT_LOOP;
 			}
 			else if (mustBacktrack || invalidHH || invalidExact || L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
@@ -1603,11 +1624,23 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 
 		/* ---- emit: next query position (:456-568) -------------------------------------------- */
 		if (L.state == ST_STEP_BEGIN) {
-			if (RL && L.lmode) continue;            /* a frame in locus mode: its next event, at the top of the loop */
+			if (RL && L.lmode) {
+				/* a frame in locus mode that goes on (a child just entered, a boundary passed): its next event is found when
+				 * the text for it arrives -- one window per call.  Going round this loop again with the window at hand would
+				 * save the lane a round and cost its wavefront a trip through everything (scripts/pass_model.py: the
+				 * wavefront's trips per round are its slowest lane's) */
+				const uint32_t d = L.d;
+				if (d >= L.qlen) { L.state = ST_FELL_OFF; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
+				const uint32_t y = WSEL(len) - L.top + d;
+				BT_REQ_FETCH(WSEL(rtxt) + (y >> 4), ((y & 15u) + (L.qlen - d) + 63u) >> 6, nullptr);
+				L.state = ST_LOC_TXT;
+				BT_COUNT_HOST(CN_FETCH);
+				return;
+			}
 			const uint32_t d = L.d;
-			if (d >= L.qlen) { L.state = ST_FELL_OFF; continue; }
-			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; continue; }
-			if (L.ebase + (d - L.depth) >= S.a->entCap) { L.state = ST_ABORT; continue; }
+			if (d >= L.qlen) { L.state = ST_FELL_OFF; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
+			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
+			if (L.ebase + (d - L.depth) >= S.a->entCap) { L.state = ST_ABORT; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
 			if (RL && W.locOn && !L.hasN && L.top + 1u == L.bot) {
 				/* the range is one row: leave row space (its locus record: where the row's suffix is in the text, and the
 				 * 48 characters to the left of it).  Reads with an N stay in row space: an N never matches, which the packed
@@ -1647,7 +1680,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				{ BtU4 v; v.x = f1; v.y = f2; v.z = f3; v.w = f4; bt_st4(PB4(e), v); }
 				if (c < 4u) { L.top = bt_sel4(c, f0, f1, f2, f3); L.bot = bt_sel4(c, f1, f2, f3, f4); }
 				L.state = ST_STEP_POST;
-				continue;
+				return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */
 			} else if (alt || c < 4u) {
 				if (alt) { BT_REQ_RANK2(rtop, rbot); L.lfk = LFK_EX2; }
 				else if (L.top + 1u == L.bot) { BT_REQ_RANK1(L.top); L.lfk = LFK_LF1; }
@@ -1663,7 +1696,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			} else {
 				/* non-alternative N: the range is already (1,1); only the bookkeeping remains */
 				L.state = ST_STEP_POST;
-				continue;
+				return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */
 			}
 		}
 		/* ---- emit: next SA-walk step, or the SA sample once the walk has arrived ---------------- */
@@ -1686,7 +1719,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				BT_COUNT_HOST(CN_FETCH);
 				return;
 			}
-			continue;
+			return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */
 		}
 		if (L.state == ST_IDLE) return;
 	}

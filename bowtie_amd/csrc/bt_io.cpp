@@ -86,15 +86,12 @@ static void compact_batch(BtHostBatch* b, const std::vector<uint32_t>& keep)
 	else if (b->n_paired > b->n) b->n_paired = b->n;
 }
 
-void bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order)
+bool bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order)
 {
 	order->assign(a->n, 1);
 	unp->n = 0; unp->n_paired = 0; unp->paired.clear();
-	if (!a->paired.empty() && a->paired.size() != a->n) {       /* the column did not follow its batch: never guess which records were pairs */
-		fprintf(stderr, "bt_io_split_tabbed: %zu pair flags for %u records\n", a->paired.size(), a->n);
-		abort();
-	}
-	if (a->paired.empty() || a->n_paired == a->n) { a->paired.clear(); b->paired.clear(); return; }       /* pairs only */
+	if (!a->paired.empty() && a->paired.size() != a->n) return false;      /* the column did not follow its batch: never guess which records were pairs */
+	if (a->paired.empty() || a->n_paired == a->n) { a->paired.clear(); b->paired.clear(); return true; }       /* pairs only */
 	std::vector<uint32_t> kp, ku;
 	for (uint32_t i = 0; i < a->n; i++) { if (a->paired[i]) kp.push_back(i); else { ku.push_back(i); (*order)[i] = 0; } }
 	/* the unpaired reads: rows of `a` as they are (names and seeds were left alone by the mate-name fix) */
@@ -117,6 +114,7 @@ void bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::v
 	a->paired.clear(); b->paired.clear();
 	compact_batch(a, kp); compact_batch(b, kp);
 	a->n_paired = a->n; b->n_paired = b->n;
+	return true;
 }
 
 bool bt_io_intersect_pairs(BtHostBatch* a, BtHostBatch* b)

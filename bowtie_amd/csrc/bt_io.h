@@ -74,8 +74,9 @@ bool bt_io_intersect_pairs(BtHostBatch* a, BtHostBatch* b);
 /* A --12 file may hold pairs and unpaired reads (TabbedPatternSource, pat.cpp:977-1127: three fields or five).  a / b =
  * the batches of the two mate streams over that file (same records; an unpaired record's second end is empty).  Moves
  * the unpaired reads to `unp`, leaves the pairs in a / b, and says in `order` how the input interleaved them
- * (1 = the next pair, 0 = the next unpaired read). */
-void bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order);
+ * (1 = the next pair, 0 = the next unpaired read).  false: the batch is inconsistent with itself (its column of pair flags
+ * does not have one flag per record) and was left alone -- an internal error the caller reports as BT_ERR_READS. */
+bool bt_io_split_tabbed(BtHostBatch* a, BtHostBatch* b, BtHostBatch* unp, std::vector<uint8_t>* order);
 
 struct BtRefNames {
 	std::vector<std::string> names;

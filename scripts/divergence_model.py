@@ -33,7 +33,7 @@ def build_probe():
     old = "#define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE)"
     assert old in s
     s = s.replace(old, "#define ST_IS_NOREQ(x) (L.state == (x) && req.kind == RQ_NONE && (BT_VISIT(x), true))")
-    for pat in ["\t\tif (!RL && L.state == ST_WIN_DONE) {", "\t\tif (L.state == ST_CHASE_LFDONE) {", "\t\tif (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST) {",
+    for pat in ["\t\tif (!RL && L.state == ST_WIN_DONE) {", "\t\tif (L.state == ST_CHASE_LFDONE) {", "\t\tif (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST || (RL && L.state == ST_STEP_LOC)) {", "\t\tif (RL && L.state == ST_STEP_BEGIN && L.lmode) {",
                 "\t\tif (L.state == ST_STEP_BEGIN) {", "\t\tif (L.state == ST_CHASE_CHECK) {"]:
         assert pat in s, pat
         s = s.replace(pat, pat + " BT_VISIT(L.state);", 1)
@@ -48,10 +48,10 @@ def build_probe():
     assert old in e
     e = e.replace(old, "\tg_trace.clear();\n\twhile (live > 0) {\n\t\tconst size_t row = g_trace.size();\n\t\tg_trace.resize(row + nLanes, 0ull);\n"
                        "\t\tfor (uint32_t g = 0; g < nLanes; g++) {\n\t\t\tbt_visit_mask = &g_trace[row + g];\n\t\t\tif (drained[g]) continue;")
-    old = "\t\t\tif (drained[g]) continue;\n\t\t\tBT_COUNT(CN_ITERS);"
+    old = "\t\t\tif (drained[g]) continue;\n\t\t\tif (req.kind == RQ_FETCH && (L.state == ST_LOC_REC"
     assert old in e
     e = e.replace(old, "\t\t\tif (drained[g]) { g_trace[row + g] = 0; continue; }\n"
-                       "\t\t\tg_trace[row + g] |= ((unsigned long long)(req.kind == RQ_RANK && req.n == 2) << 62) | (1ull << 63);\n\t\t\tBT_COUNT(CN_ITERS);")
+                       "\t\t\tg_trace[row + g] |= ((unsigned long long)(req.kind == RQ_RANK && req.n == 2) << 62) | (1ull << 63);\n\t\t\tif (req.kind == RQ_FETCH && (L.state == ST_LOC_REC")
     e = e.replace("\tout->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;\n\tif (counts) {\n\t\tcounts->lfex = CNT[CN_LFEX];",
                   "\tbt_visit_mask = &g_dummy;\n\tout->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;\n\tif (counts) {\n\t\tcounts->lfex = CNT[CN_LFEX];", 1)
     open(W + "/emu/bt_emu.cpp", "w").write(e)

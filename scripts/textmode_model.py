@@ -29,12 +29,12 @@ def build_probe():
     e = open(os.path.join(ROOT, "tests/emu/bt_emu.cpp")).read()
     e = e.replace('#include "../../bowtie_amd/csrc/bt_host.h"', '#include "../bt_host.h"')
     e = e.replace("/* Same contract as bt_align_batch (host pointers); nLanes lock-step lanes. */",
-                  'struct Ev { uint32_t rd, code, anchor, d, sd, lane; };\nstatic std::vector<Ev> g_ev;\n'
+                  'struct Ev { uint32_t rd, code, anchor, d, sd, lane, fr; };\nstatic std::vector<Ev> g_ev;\n'
                   'extern "C" Ev* emu_events(size_t* n) { *n = g_ev.size(); return g_ev.data(); }\n'
                   'static uint32_t sa_of(const BtIndexDev& ix, uint32_t row) { uint32_t j = 0; while ((row & ix.offMask) != row && row != ix.zOff) { uint32_t lf[4], l; bt_rank4(ix, row, lf, &l); row = lf[l]; j++; } return (row == ix.zOff ? 0u : ix.offs[row >> ix.offRate]) + j; }\n')
     old = "\t\t\tif (req.kind == RQ_RANK) {\n\t\t\t\tif (L.lfk == LFK_CHASE) BT_COUNT(CN_CHASE);"
     assert old in e
-    e = e.replace(old, "\t\t\t{ Ev v; v.rd = L.rd; v.lane = g; v.d = L.d; v.sd = L.sd; v.anchor = 0xffffffffu;\n"
+    e = e.replace(old, "\t\t\t{ Ev v; v.rd = L.rd; v.lane = g; v.d = L.d; v.sd = L.sd; v.anchor = 0xffffffffu; v.fr = (L.lmode ? (uint32_t)L.dcf - L.depth : L.d - L.depth + 1u) | ((uint32_t)L.lmode << 16) | ((uint32_t)L.altNum << 20);\n"
                        "\t\t\t  if (req.kind == RQ_RANK) { const bool single = L.lfk == LFK_LF1 || L.lfk == LFK_CHASE || (req.n == 2 && (uint32_t)req.x == (uint32_t)req.a + 1u);\n"
                        "\t\t\t    v.code = (L.lfk == LFK_EX2 ? 1u : L.lfk == LFK_C2 ? 2u : L.lfk == LFK_LF1 ? 3u : 4u) | (single ? 8u : 0u) | ((uint32_t)L.mirror << 4);\n"
                        "\t\t\t    if (single && L.lfk != LFK_CHASE) v.anchor = sa_of(e->d[L.mirror], (uint32_t)req.a) + L.d; }\n"
@@ -74,7 +74,7 @@ def main():
     L = E.lib()
 
     class Ev(C.Structure):
-        _fields_ = [(k, C.c_uint32) for k in ("rd", "code", "anchor", "d", "sd", "lane")]
+        _fields_ = [(k, C.c_uint32) for k in ("rd", "code", "anchor", "d", "sd", "lane", "fr")]
     L.emu_events.restype = C.POINTER(Ev)
     L.emu_events.argtypes = [C.POINTER(C.c_size_t)]
     emu = E.EmuAligner(a.index)
@@ -83,7 +83,7 @@ def main():
     emu.align(pol, batch, n_lanes=256, lite=True, pal_cap=16384, counts=cnt)
     n = C.c_size_t()
     p = L.emu_events(C.byref(n))
-    ev = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, 6)).copy()
+    ev = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, 7)).copy()
     R = a.reads
     print("%d reads x %d bp, %s: %.1f lane-rounds per read" % (R, a.len, a.mode, len(ev) / R))
     code = ev[:, 1] & 7
@@ -98,8 +98,11 @@ def main():
     items = ["ST_IDLE"] + [x.strip() for x in re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S).replace("\n", " ").split(",") if x.strip()]
     fm = code == 5
     st = ev[fm, 1] >> 8
+    frl = ev[fm, 6] & 0xffff
+    alt = ev[fm, 6] >> 20
     for s in np.unique(st):
-        print("    fetch -> %-18s %6.1f per read" % (items[s], (st == s).sum() / R))
+        m2 = st == s
+        print("    fetch -> %-18s %6.1f per read; frame's row-space entries: mean %.1f, <=4: %.2f <=8: %.2f <=16: %.2f; altNum mean %.1f <=4: %.2f" % (items[s], m2.sum() / R, frl[m2].mean(), (frl[m2] <= 4).mean(), (frl[m2] <= 8).mean(), (frl[m2] <= 16).mean(), alt[m2].mean(), (alt[m2] <= 4).mean()))
     # per read: order events by (lane, time) -- events are appended round by round, lanes in order; a read stays on its lane
     order = np.lexsort((np.arange(len(ev)), ev[:, 0]))
     ev = ev[order]

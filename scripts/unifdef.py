@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Resolve preprocessor conditionals on a given set of macros and leave every other line alone (a small `unifdef`).
 
-  python scripts/unifdef.py -DBF_FAST_EXTEND=1 -DBF_REFILL=0 [-UBF_CHECK] file.h > file.resolved.h
+  python scripts/unifdef.py -DSOME_FORK=1 -DOTHER_FORK=0 [-UBF_CHECK] file.h > file.resolved.h      (round 4 used it with -DBF_FAST_EXTEND=1 -DBF_REFILL=0; those forks are gone)
 
 Used in round 4 to collapse the experiment forks of bt_best.h once the GPU had decided them.  A conditional whose
 expression mentions a macro that is not given stays as it is (its body is still processed); `#ifndef X / #define X v /
