@@ -682,7 +682,7 @@ def test_gpu_stream_stress_a_few_rounds():
     import subprocess
     import sys
     env = dict(os.environ, BT_STREAM_POISON="1", BT_MAX_BLOCKS="2")
-    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "scripts", "r4", "stream_stress.py"), "--seconds", "6", "--tag", "gate"],
+    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "scripts", "r4", "stream_stress.py"), "--seconds", "10", "--tag", "gate"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-800:]
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
