@@ -65,6 +65,9 @@ struct bt_ctx {
 	uint32_t cus = 0, blocksPerCU = 2;      /* nLanes covers the widest launch (3 blocks per CU) */
 	bool rl3 = true;                        /* the three-blocks-per-CU build may be used */
 	bool locus = false;                     /* the index has its locus image and this context's launches use it */
+	/* descriptors on their way to the device (ctx_h2d): a ring of page-locked slots, so that no asynchronous copy ever
+	 * reads memory that has gone out of scope */
+	uint8_t* hstage = nullptr; uint32_t hsNext = 0; hipEvent_t hsEv[64] = {}; bool hsUsed[64] = {};
 	int occ = 2;
 	uint32_t *frames = nullptr, *pairs = nullptr; uint16_t* meta = nullptr; uint64_t* pals = nullptr;
 	uint32_t* d_cursor = nullptr;      /* [0] read cursor, [1] mm_pool_used, [7] longest read, [8..10] second pass */
@@ -210,6 +213,33 @@ static uint32_t env_u32(const char* name, uint32_t dflt)
 	return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+/* A small host structure (a descriptor block, the cursors' initial values) to device memory, on the context's stream.
+ * hipMemcpyAsync from ordinary host memory is staged by the runtime -- usually before the call returns, but that is not a
+ * promise: under load (several processes on one GPU) the runtime may page-lock the caller's pages and read them when the
+ * stream gets there, and every such source in this file used to be a local variable.  Round 5's stress of the overflow
+ * second pass (scripts/r5/retry_stress.py, six processes side by side) caught a launch that had seen garbage descriptors:
+ * every read of its batch "outgrew" its arenas, and the second pass's mismatch lists came back empty -- the right hits with
+ * wrong mismatch entries, round 3's one-off symptom.  The source is now a slot of page-locked memory that
+ * belongs to the context and is not written again before the copy that reads it is done. */
+#define BT_HSTAGE_SLOTS 64
+#define BT_HSTAGE_SLOT_BYTES 4096
+static_assert(sizeof(BtCold) <= BT_HSTAGE_SLOT_BYTES && sizeof(BtWarm) <= BT_HSTAGE_SLOT_BYTES && sizeof(BtBatchDev) <= BT_HSTAGE_SLOT_BYTES, "a descriptor fits a staging slot");
+static int ctx_h2d(bt_ctx* c, void* dst, const void* src, size_t bytes)
+{
+	if (bytes > BT_HSTAGE_SLOT_BYTES) return BT_ERR_ARG;
+	if (!c->hstage) HIPCHK(hipHostMalloc((void**)&c->hstage, (size_t)BT_HSTAGE_SLOTS * BT_HSTAGE_SLOT_BYTES));
+	const uint32_t k = c->hsNext++ % BT_HSTAGE_SLOTS;
+	if (!c->hsEv[k]) HIPCHK(hipEventCreateWithFlags(&c->hsEv[k], hipEventDisableTiming));
+	if (c->hsUsed[k]) HIPCHK(hipEventSynchronize(c->hsEv[k]));       /* 64 copies ago: done long since */
+	uint8_t* slot = c->hstage + (size_t)k * BT_HSTAGE_SLOT_BYTES;
+	memcpy(slot, src, bytes);
+	HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipEventRecord(c->hsEv[k], c->stream));
+	c->hsUsed[k] = true;
+	return BT_OK;
+}
+#define BT_H2D(dst, src, bytes) do { const int rc_ = ctx_h2d(c, (dst), (src), (bytes)); if (rc_ != BT_OK) return rc_; } while (0)
+
 /* The locus image (bt_rank.h: dense suffix array + 48 characters of left context per row, the reversed text, the table of
  * walk lengths), derived from what bt_index_load put on the device: 18.25 bytes per base and index -- HBM capacity spent
  * on the search's dependent chains.  Not built when the device has not that much to spare (the search then stays in row
@@ -275,7 +305,12 @@ static bool index_ensure_locus(const bt_index* cidx)
 extern "C" int bt_ctx_set_locus(bt_ctx* c, int on)
 {
 	if (!c) return BT_ERR_ARG;
-	c->locus = on && !c->best && c->idx->locState > 0;
+	c->locus = on && c->idx->locState > 0;
+	if (c->best && c->d_ix) {
+		BtIndexDev dv[2] = {c->idx->dev[0], c->idx->dev[1]};
+		if (!c->locus) for (int m = 0; m < 2; m++) { dv[m].loc = nullptr; dv[m].rtxt = nullptr; dv[m].walk = nullptr; }
+		HIPCHK(hipMemcpy(c->d_ix, dv, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
+	}
 	if (c->big) c->big->locus = c->locus;
 	return BT_OK;
 }
@@ -374,8 +409,10 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	for (int i = 0; !c->best && i < c->prog.nsteps; i++) need_mirror |= c->prog.steps[i].mirror != 0;
 	if (need_mirror && !idx->has_mirror) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(idx->device));
-	/* the phase-program engine leaves row space where a range is one row, if the index can have its locus image */
-	c->locus = !c->best && index_ensure_locus(idx);
+	/* the phase-program engine leaves row space where a range is one row, if the index can have its locus image; the best-first
+	 * engine takes a reported row's offset from the image's dense suffix array instead of walking to a sampled row (bt_best.h:
+	 * ch_row_set; BT_BEST_LOCUS=0: it walks, as in rounds 2-4) */
+	c->locus = index_ensure_locus(idx) && (!c->best || env_u32("BT_BEST_LOCUS", 1) != 0);
 	if (stream) c->stream = (hipStream_t)stream;
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 	HIPCHK(hipEventCreate(&c->ev0));
@@ -409,7 +446,11 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 		HIPCHK(hipMalloc((void**)&c->d_ix, 2 * sizeof(BtIndexDev)));
 		HIPCHK(hipMalloc((void**)&c->d_batch, sizeof(BtBatchDev)));
 		HIPCHK(hipMemcpy(c->d_bprog, &c->bprog, sizeof(BfProgram), hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(c->d_ix, idx->dev, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
+		{
+			BtIndexDev dv[2] = {idx->dev[0], idx->dev[1]};
+			if (!c->locus) for (int m = 0; m < 2; m++) { dv[m].loc = nullptr; dv[m].rtxt = nullptr; dv[m].walk = nullptr; }
+			HIPCHK(hipMemcpy(c->d_ix, dv, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
+		}
 		/* blocks per CU = waves per SIMD the best-first kernel was compiled for (bt_best_kernels.hip, BT_BEST_MIN_BLOCKS);
 		 * BT_BEST_BLOCKS_PER_CU overrides it for A/B runs */
 		c->nLanes = c->cus * env_u32("BT_BEST_BLOCKS_PER_CU", bt_best_blocks_per_cu()) * BT_BLOCK;
@@ -429,6 +470,8 @@ extern "C" void bt_ctx_destroy(bt_ctx* c)
 	if (c->pool) (void)hipFree(c->pool);
 	if (c->d_carry) (void)hipFree(c->d_carry);
 	if (c->hostParked) (void)hipHostFree(c->hostParked);
+	if (c->hstage) (void)hipHostFree(c->hstage);
+	for (int i = 0; i < 64; i++) if (c->hsEv[i]) (void)hipEventDestroy(c->hsEv[i]);
 	for (int i = 0; i < BT_BATCH_RING; i++) if (c->evLaunch[i]) (void)hipEventDestroy(c->evLaunch[i]);
 	if (c->d_cold_prev) (void)hipFree(c->d_cold_prev);
 	if (c->evSpan) (void)hipEventDestroy(c->evSpan);
@@ -523,9 +566,9 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	B.mm_pool = out->mm_pool; B.mm_pool_cap = out->mm_pool ? out->mm_pool_cap : 0;
 	B.mm_pool_used = c->d_cursor + 1;
 	if (in2) { B.seq2 = in2->seq; B.qual2 = in2->qual; B.len2 = in2->len; B.seed2 = in2->seed; B.stride2 = in2->stride; }
-	HIPCHK(hipMemcpyAsync(c->d_batch, &B, sizeof(B), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_batch, &B, sizeof(B));
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cursor, init, sizeof(init));
 	BtBestArgs A;
 	A.prog = in2 ? c->d_bprog_pe : c->d_bprog; A.ix = c->d_ix; A.batch = c->d_batch;
 	A.ref = in2 ? c->idx->d_ref : nullptr;
@@ -690,10 +733,10 @@ static int ctx_flush_carry(bt_ctx* c)
 	const BatchView& lastB = c->ring[(c->launchSeq - 1u) & (BT_BATCH_RING - 1u)];
 	const uint32_t keep = env_u32("BT_FLUSH_KEEP_BATCH", 0);   /* diagnostics: 1 = the last batch stands in as the current one */
 	if (keep) cold.B = lastB.B;
-	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cold, &cold, sizeof(cold));
+	BT_H2D(c->d_warm, &warm, sizeof(warm));
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cursor, init, sizeof(init));
 	HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));
 	A.H.seq = nullptr; A.H.qual = nullptr; A.H.stride = 0; A.H.n_reads = 0;
 	if (keep) { A.H.seq = lastB.seq; A.H.qual = lastB.qual; A.H.stride = lastB.stride; }
@@ -713,7 +756,7 @@ static int ctx_flush_carry(bt_ctx* c)
 	for (int i = 0; i < BT_BATCH_RING; i++) if (c->ringRetry[i]) {
 		BtCold pc;
 		fill_cold(c, &pc, c->ring[i].B, (uint32_t)i);
-		HIPCHK(hipMemcpyAsync(c->d_cold_prev, &pc, sizeof(pc), hipMemcpyHostToDevice, c->stream));
+		BT_H2D(c->d_cold_prev, &pc, sizeof(pc));
 		const int rc = enqueue_retry(c, A, c->ring[i], c->d_cold_prev, c->ringMaxLen[i]);
 		if (rc != BT_OK) return rc;
 		c->ringRetry[i] = false;
@@ -787,11 +830,11 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	if (carry) { c->ring[bid] = cur; c->ringRetry[bid] = devRetry; c->ringMaxLen[bid] = maxLen; }
 	BtCold cold;
 	fill_cold(c, &cold, cur.B, bid);
-	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cold, &cold, sizeof(cold));
 	BtWarm warm;
 	fill_index_args(c, &A, &warm);
 	A.H.seq = in->seq; A.H.qual = in->qual; A.H.stride = in->stride; A.H.n_reads = in->n_reads;
-	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_warm, &warm, sizeof(warm));
 	A.cold = c->d_cold; A.warm = c->d_warm;
 	A.frames = c->frames; A.pairs = c->pairs; A.meta = c->meta; A.pals = c->pals;
 	A.nLanes = c->nLanes; A.nSlots = c->nSlots; A.frCap = c->frCap; A.entCap = c->entCap; A.palCap = c->palCap;
@@ -799,7 +842,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	A.counts = counts_dev ? counts_dev : c->d_counts;
 	/* [0] read cursor, [1] mismatch-pool cursor, [7] longest read, [8] reads to search again, [9] their cursor */
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cursor, init, sizeof(init));
 	if (carry) {
 		HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));                 /* this launch's parked counts */
 		if (!mmCursorDev) HIPCHK(hipMemsetAsync(c->d_carry + BT_BATCH_RING + bid, 0, 4, c->stream));   /* this batch's mismatch-pool cursor */
@@ -1501,10 +1544,10 @@ extern "C" int bt_align_stream_tick(bt_ctx* c, uint32_t min_rounds)
 	c->ring[bid] = none; c->ringRetry[bid] = false; c->ringMaxLen[bid] = 0;
 	BtCold cold;
 	fill_cold(c, &cold, none.B, bid);
-	HIPCHK(hipMemcpyAsync(c->d_cold, &cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemcpyAsync(c->d_warm, &warm, sizeof(warm), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cold, &cold, sizeof(cold));
+	BT_H2D(c->d_warm, &warm, sizeof(warm));
 	const uint32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(c->d_cursor, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	BT_H2D(c->d_cursor, init, sizeof(init));
 	HIPCHK(hipMemsetAsync(c->d_carry, 0, BT_BATCH_RING * 4, c->stream));                 /* this launch's parked counts */
 	A.H.seq = nullptr; A.H.qual = nullptr; A.H.stride = 0; A.H.n_reads = 0;
 	A.cold = c->d_cold; A.warm = c->d_warm;

@@ -1553,6 +1553,17 @@ BF_FN void ch_row_set(BfLane& X, BfChase& c, uint32_t row)
 {
 	const BtIndexDev& ix = X.ix[c.mirror];
 	c.cRow = row;
+	if (ix.loc) {
+		/* the index has its locus image (bt_rank.h): the row's offset from the dense suffix array, the walk RowChaser
+		 * would have made (row_chaser.h:69-123) tallied from the table of walk lengths -- it ends at the '$' row, where no
+		 * sample is read, exactly when it is as long as the offset */
+		const uint32_t sa = BT_GP(const uint32_t, ix.loc)[(uint64_t)row * 4u];
+		const uint32_t w = BT_GP(const uint16_t, ix.walk)[sa];
+		c.cOff = sa; c.cDone = 1; c.cJumps = w;
+		X.c_chase += w;
+		if (sa != w) X.c_offs++;
+		return;
+	}
 	if (row == ix.zOff) { c.cOff = 0; c.cDone = 1; return; }
 	if ((row & ix.offMask) == row) { c.cOff = BT_GP(const uint32_t, ix.offs)[row >> ix.offRate]; c.cDone = 1; X.c_offs++; return; }
 	c.cDone = 0; c.cJumps = 0; c.cOff = BT_OFF_MASK;
