@@ -999,6 +999,22 @@ int main(int argc, char** argv)
 	}
 	bt_index_info info;
 	bt_index_info_get(idx, &info);
+	if (!getenv("BT_LOCUS")) {
+		/* The locus image (include/bowtie_amd.h: locus mode) is derived on the GPU when the first context is created --
+		 * 3.9 s for a 2.86 Gbp genome -- and makes the search 1.2-1.7 times as fast; on that genome it pays from about a
+		 * hundred million reads on.  The input's size decides (a file of FASTQ is ~2.1 bytes per base; compressed, a fourth
+		 * of that); input of unknown size (standard input) gets the image.  BT_LOCUS=0 / 1 overrides. */
+		uint64_t bytes = 0; bool known = true;
+		for (const std::string* lst : {&O.reads, &O.mates1, &O.mates2, &O.tab12, &O.ileaved})
+			for (const std::string& f : split_commas(*lst)) {
+				struct stat st;
+				if (f == "-" || stat(f.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) { known = false; continue; }
+				const bool gz = f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0;
+				bytes += (uint64_t)st.st_size * (gz ? 4u : 1u);
+			}
+		if (known && O.rd.format != BT_FMT_CMDLINE && bytes < 8ull * info.len) setenv("BT_LOCUS", "0", 1);
+		else if (O.rd.format == BT_FMT_CMDLINE) setenv("BT_LOCUS", "0", 1);        /* -c: a handful of reads */
+	}
 	BtRefNames refs;
 	for (uint32_t i = 0; i < info.n_pat; i++) { const char* nm = bt_index_refname(idx, i); refs.names.emplace_back(nm ? nm : ""); refs.lens.push_back(bt_index_reflen(idx, i)); }
 	/* `--inflight` whole batches are searched side by side, each on its own context and stream.  --stream

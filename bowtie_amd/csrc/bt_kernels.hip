@@ -249,31 +249,31 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		}
 		BT_PROF_ADD(PS_RANK, t_rank);
 
-		/* ---- advance every lane to its next request; a lane that finished its read in the last round takes the next one ------
-		 * One pass per round for the whole wavefront (bt_lane_run does not loop either): a lane that finishes now stays
-		 * idle for the rest of this round -- starting its next read at once would take the wavefront through
-		 * bt_lane_start and the automaton a second time for the sake of one lane. */
+		/* ---- advance every lane to its next request, pulling new reads as old ones finish -------
+		 * (A lane that finishes takes its next read at once: leaving it idle until the next round's pass was measured in the
+		 * eighth and ninth GPU calls of round 5 -- 15.0-15.1 M reads/s against 15.3 M -- and dropped.) */
 		req.tally = 0;
-		if (L.state == ST_IDLE && !drained) {
-			const uint32_t w = atomicAdd(A.nextRead, 1u);
-			if (w >= nReads) drained = true;
-			else {
+		for (;;) {
+			if (L.state == ST_IDLE) {
+				if (drained) break;
+				const uint32_t w = atomicAdd(A.nextRead, 1u);
+				if (w >= nReads) { drained = true; break; }
 				BT_PROF_T0(t_refill);
 				bt_lane_start<RL>(L, PROG, A.H, *cold, S, (EXT && A.order) ? BT_GP(const uint32_t, A.order)[w] : w);
 				BT_PROF_ADD(PS_REFILL, t_refill);
 			}
-		}
-		if (L.state != ST_IDLE) {
 			BT_PROF_T0(t_loop);
 			bt_lane_run<RL>(L, PROG, A.H, WARM, *cold, S, res, req, CNT);
 			BT_PROF_ADD(PS_LOOP, t_loop);
+			if (L.state == ST_IDLE) continue;
+			break;
 		}
 		/* the wavefront leaves the loop as a whole (keeps the tallies below wave-uniform); lanes that
 		 * have run out of work simply carry an empty request */
 		tl_acc += req.tally;
 		const bool live = L.state != ST_IDLE;
 		if (!live) { req.kind = RQ_NONE; req.wchunk = 0xffffu; }
-		if (__ballot(live || !drained) == 0) break;            /* (an idle lane that has not seen the cursor dry takes a read next round) */
+		if (__ballot(live) == 0) break;
 		/* op counters: wave-uniform tallies in scalar registers (ballot + popcount), flushed once
 		 * per wavefront at the end */
 		{

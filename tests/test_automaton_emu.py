@@ -240,6 +240,34 @@ def test_emu_paired_vs_oracle_counts(mode, emu):
     T.check_op_counts(oc, ec)
 
 
+@pytest.mark.parametrize("mode,lite", [("n2", True), ("n2", False), ("v2", True), ("n3", True), ("n2_k3", False), ("n1_a_m20", True), ("n2_nomaq", True)])
+def test_emu_locus_mode_against_row_space(mode, lite, emu, monkeypatch):
+    """Locus mode (bt_core.h: once a range is one BWT row the frame stands on a place in the text; events instead of steps,
+    levels without frames, the dense suffix array for reported rows) against the same automaton kept in row space
+    (EMU_LOCUS_OFF=1): the same hits, the same op counts -- what the text decided is tallied as the reference's steps --
+    and fewer lock-step rounds (on a genome of a few kilobases, with reads of 4 to 112 bases, a fifth fewer; on the benchmark's
+    a third to a half: scripts/textmode_model.py)."""
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(4242)
+    reads = []
+    for i in range(400):
+        ln = int(rng.integers(4, 105 if lite else 113))
+        b = synth_reads(text, 1, ln, mm_dist=(0, 1, 2, 3), seed=31000 + i, n_frac=0.1, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :ln].copy(), b.qual[0, :ln].tobytes()))
+    batch = pack_reads(reads)
+    out = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("EMU_LOCUS_OFF", off)
+        c = A.OpCounts()
+        out[off] = (emu["multi"].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), counts=c, pal_cap=16384, n_lanes=64,
+                                       ent_cap=12 * 128, lite=lite), c)
+    T.compare_results(out["0"][0], out["1"][0], mode + ": locus mode against row space")
+    T.check_op_counts(out["1"][1], out["0"][1], mode)
+    assert out["1"][1].loc_records == 0 and out["0"][1].loc_records > 0
+    assert out["0"][1].lane_iters < out["1"][1].lane_iters, (out["0"][1].lane_iters, out["1"][1].lane_iters)
+
+
 # ---- the automaton under MemorySanitizer ------------------------------------------------------
 MSAN_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 

@@ -17,7 +17,12 @@ BIN = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
 def run(args, index, reads, extra=()):
     # BT_TEST_CLI_EXTRA: extra bowtie-amd options for every run (e.g. "--stream"); paired runs ignore --stream by themselves
     cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + os.environ.get("BT_TEST_CLI_EXTRA", "").split() + list(extra) + list(args) + ["-x", index] + ([reads] if reads else [])
-    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
+    # half of the cases with the locus image forced (BT_LOCUS=1: by itself the binary would not build it for inputs this small),
+    # half as the binary decides (row space): by the parity of the command line's length
+    env = dict(os.environ)
+    if "BT_LOCUS" not in env and len(" ".join(cmd)) % 2 == 0:
+        env["BT_LOCUS"] = "1"
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600, env=env)
 
 
 def with_dump_paths(case, tmp_path):

@@ -209,7 +209,9 @@ def test_simple_case_bowtie_amd(case, run, simple_index):
     # BT_TEST_CLI_EXTRA: extra bowtie-amd options for every case (e.g. "--stream" to put the suite through the
     # experimental streamed search)
     cmd = [BIN, "--wrapper", "basic-0", "-p", "1"] + os.environ.get("BT_TEST_CLI_EXTRA", "").split() + run["args"] + ["-x", base] + case["reads"]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600)
+    # BT_LOCUS=1: the binary builds the locus image whatever the input's size (by itself it would not for a handful of reads),
+    # so that these cases go through locus mode as the library-level GPU tests do
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=T.G, timeout=600, env=dict(os.environ, BT_LOCUS=os.environ.get("BT_LOCUS", "1")))
     assert (p.returncode != 0) == (run["returncode"] != 0), p.stderr.decode(errors="replace")
     if run["returncode"] == 0:
         assert p.stdout == expected(run)
