@@ -54,7 +54,11 @@ struct Options {
 	std::string quals, quals1, quals2;       /* -Q / --Q1 / --Q2 */
 	bool interleaved = false;
 	bool suppress_set = false, int_quals = false;
-	uint32_t batch_reads = 4u << 20;
+	/* reads per batch = per launch.  With carry-over a read may ride along for twelve launches; the heaviest reads need
+	 * ~5 s of them, so a launch must last long enough: at 4 M reads (0.34 s) every launch ended up waiting for the stragglers
+	 * of the batch twelve launches back -- 3.8 M reads/s GPU-side on 192 M reads, 5.3 M file to file at 8 M, 5.6 M at 16 M
+	 * (where parsing bounds it: profiles/r5/call12_cli_batch_SUMMARY.txt).  8 M keeps a batch at ~2.4 GB of host memory. */
+	uint32_t batch_reads = 8u << 20;
 	std::string cmdline;
 };
 
@@ -133,7 +137,7 @@ void usage(FILE* o)
 	    "  -p/--threads <int> number of host threads for parsing and formatting (default: all, up to 32);\n"
 	    "                     the output order is that of the input whatever the value\n"
 	    "  --device <list>    GPU(s) to run on, e.g. 0,1,2,3: index replicated, batches dealt out (default: 0)\n"
-	    "  --batch <int>      reads per GPU batch (default: 4194304)\n"
+	    "  --batch <int>      reads per GPU batch (default: 8388608)\n"
 	    "  --inflight <int>   batches searched concurrently, each on its own stream (default: 2)\n"
 	    "  --stream           the default for unpaired reads without --best: batches stream through one\n"
 	    "                     context per GPU, reads still running when a batch ends are carried into the next\n"
@@ -1065,8 +1069,8 @@ int main(int argc, char** argv)
 	 * here stops feeding the GPU (round 4's timeline of a 64 M-read run: 1.8 s of every 10 with nothing enqueued) */
 	/* the results queue: deep enough that the searcher does not wait for the writer while the in-flight batches come back in a
 	 * burst (up to BT_BATCH_RING - 2 = 14 of them), not so deep that a slow writer -- SAM formatting, a slow file system, the
-	 * --al/--un dumps -- lets batches of 150 MB and more pile up on the host without bound (round 4 had G + 64) */
-	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 16);
+	 * --al/--un dumps -- lets batches of gigabytes pile up on the host without bound (round 4 had G + 64) */
+	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 8);
 	std::vector<double> busy_gpu((size_t)G, 0.0);
 	std::thread reader([&] {
 		uint64_t seq = 0;
