@@ -779,6 +779,12 @@ def main():
             # BASELINE configs 3 and 5 in the same line: each in its own process (the index cache under /tmp is reused),
             # 2 timed steps, every hit re-verified where the workload allows it, a sample diffed against the reference
             import subprocess
+            # this process's contexts and index replica go first: the locus image alone is 104 GB at hg19 scale, and a child
+            # that finds the device that full searches without one (round 5's final call: config 5's share 10.1 M reads/s
+            # in this leg against 11.7 M on its own)
+            for o in pipes:
+                o["al"].close()
+            idx.close()
             del rb, rb2, M, pipes, last
             torch.cuda.empty_cache()
             out["config"]["other_workloads"] = {}
