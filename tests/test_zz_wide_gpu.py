@@ -1,7 +1,9 @@
 """libbowtie_amd_l.so / bowtie-amd-l on the GPU: the build with 64-bit BWT rows (the reference's bowtie-align-l),
 through the C ABI and through the binary, rows numbered on either side of 2^32 (tests/test_wide_rows_emu.py explains the bias).
-Runs last (the name): this library had its first GPU run after the round's budget was spent -- the CPU suite runs the same
-sources through the host build -- and a failure here must not hide the rest of the suite under -x."""
+Runs last (the name): this library was written after the round's measurements and has had 88 GPU-seconds (profiles/r5/
+wide_rows_gpu.txt: the checks below, run from tests/wide_gpu_check.py and scripts/r5/wide_gpu_smoke.sh; the sweep over the plain
+goldens did not finish inside them) -- the CPU suite runs the same sources through the host build -- and a failure here must
+not hide the rest of the suite under -x."""
 import hashlib
 import os
 import subprocess
