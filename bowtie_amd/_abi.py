@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, BT_ERR_OVERFLOW, BT_ERR_READS = range(8)
+BT_OK, BT_ERR_IO, BT_ERR_FORMAT, BT_ERR_ARG, BT_ERR_DEVICE, BT_ERR_READ_SHORT, BT_ERR_OVERFLOW, BT_ERR_READS, BT_ERR_ROWS64, BT_ERR_UNSUPPORTED = range(10)
 BT_FMT_FASTQ, BT_FMT_FASTA, BT_FMT_RAW, BT_FMT_CMDLINE, BT_FMT_FASTA_CONT, BT_FMT_TABBED = range(6)
 BT_QUAL_PHRED33, BT_QUAL_PHRED64, BT_QUAL_SOLEXA64 = range(3)
 BT_MODE_V, BT_MODE_N = 0, 1

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("BT_LIB", "libbowtie_amd.so"))
 EXPORTS = ["bt_policy_default", "bt_has_pe_v1", "bt_index_load", "bt_index_info_get", "bt_index_refname",
            "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_index_digest", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
            "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_align_stream_submit", "bt_align_stream_collect", "bt_align_stream_tick", "bt_host_alloc", "bt_host_free", "bt_ctx_sync", "bt_ctx_set_carry", "bt_ctx_set_max_read_len", "bt_ctx_span_ms", "bt_ctx_launch_ms", "bt_ctx_last_carried", "bt_ctx_last_kernel_ms", "bt_ctx_last_kernel_name", "bt_ctx_last_mm_used", "bt_ctx_last_retried", "bt_ctx_set_locus", "bt_ctx_get_locus", "bt_index_locus_bytes", "bt_index_locus_build_seconds", "bt_index_locus_copy",
-           "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_probe_rank", "bt_probe_chase", "bt_bench_gather",
+           "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_rows64", "bt_index_len64", "bt_probe_rank", "bt_probe_rank64", "bt_probe_chase", "bt_bench_gather",
            "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_paired_count", "bt_reads_error", "bt_reads_close", "bt_format_hits", "bt_format_pairs",
            "bt_format_sam_header", "bt_format_summary", "bt_text_free"]
 _lib = None
@@ -103,6 +103,9 @@ def lib() -> C.CDLL:
         L.bt_strerror.restype = C.c_char_p
         L.bt_version.restype = C.c_char_p
         L.bt_probe_rank.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.bt_probe_rank64.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.bt_index_len64.argtypes = [C.c_void_p]
+        L.bt_index_len64.restype = C.c_uint64
         L.bt_probe_chase.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
         L.bt_policy_default.argtypes = [C.POINTER(A.Policy)]
@@ -327,6 +330,16 @@ class Aligner:
         rc = lib().bt_probe_rank(self._h, int(mirror) | (2 if sides else 0), rows.ctypes.data, len(rows), lf.ctypes.data, L.ctypes.data)
         if rc != A.BT_OK:
             raise BowtieAmdError(rc, "bt_probe_rank")
+        return lf, L
+
+    def probe_rank64(self, rows: np.ndarray, mirror: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """the same from the rank blocks with rows as 64-bit numbers (either library; the only rank probe of libbowtie_amd_l.so)"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        lf = np.zeros((len(rows), 4), dtype=np.uint64)
+        L = np.zeros(len(rows), dtype=np.uint8)
+        rc = lib().bt_probe_rank64(self._h, int(mirror), rows.ctypes.data, len(rows), lf.ctypes.data, L.ctypes.data)
+        if rc != A.BT_OK:
+            raise BowtieAmdError(rc, "bt_probe_rank64")
         return lf, L
 
     def probe_chase(self, rows: np.ndarray, qlen: int, mirror: bool = False):

@@ -154,6 +154,19 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 		/* pad the ebwt image by one side pair so that the partner-counter load of the last side
 		 * never leaves the allocation; ftab / offs by one 16-byte piece (they are fetched in aligned
 		 * 16-byte pieces) */
+#if BT_WIDE
+		/* the wide build (64-bit rows, bt_rank.h): no side layout -- the loader made the rank blocks and their segment table
+		 * on the host (bt_host.cpp: build_blocks); rows numbered from a bias (tests, bt_host.h) shift the row-indexed arrays */
+		d.ebwt = nullptr;
+		if ((r2 = upload(ix, h.blk, &d.blk, 64)) || (r2 = upload(ix, h.segBase, &d.segBase, 8)) || (r2 = upload(ix, h.ftab, &d.ftab, 4)) ||
+		    (r2 = upload(ix, h.eftab, &d.eftab)) || (r2 = upload(ix, h.offs, &d.offs, 4)) ||
+		    (r2 = upload(ix, h.rstarts, &d.rstarts)) || (r2 = upload(ix, h.plen, &d.plen))) {
+			bt_index_free(ix); return r2;
+		}
+		bt_host_index_bias(h, &d);
+		ix->blk_bytes += h.blk.size();
+		std::vector<uint8_t>().swap(h.blk);
+#else
 		if ((r2 = upload(ix, h.ebwt, &d.ebwt, 128)) || (r2 = upload(ix, h.ftab, &d.ftab, 4)) ||
 		    (r2 = upload(ix, h.eftab, &d.eftab)) || (r2 = upload(ix, h.offs, &d.offs, 4)) ||
 		    (r2 = upload(ix, h.rstarts, &d.rstarts)) || (r2 = upload(ix, h.plen, &d.plen))) {
@@ -170,10 +183,11 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 			d.blk = blk;
 			ix->blk_bytes += nb * BT_BLK_BYTES;
 		}
-		ix->ebwt_bytes += h.ebwt.size(); ix->offs_bytes += h.offs.size() * 4ull;
+#endif
+		ix->ebwt_bytes += h.ebwt.size(); ix->offs_bytes += h.offs.size() * sizeof(bt_row);
 		std::vector<uint8_t>().swap(h.ebwt);
-		std::vector<uint32_t>().swap(h.offs);
-		std::vector<uint32_t>().swap(h.ftab);
+		std::vector<bt_row>().swap(h.offs);
+		std::vector<bt_row>().swap(h.ftab);
 	}
 	if (!need_mirror) ix->dev[1] = ix->dev[0];
 	*out = ix;
@@ -184,19 +198,21 @@ extern "C" void bt_index_info_get(const bt_index* idx, bt_index_info* info)
 {
 	memset(info, 0, sizeof(*info));
 	const BtIndexHost& h = idx->host[0];
-	info->len = h.len; info->n_pat = h.nPat; info->n_frag = h.nFrag; info->ftab_chars = (uint32_t)h.ftabChars;
-	info->off_rate = (uint32_t)h.offRate; info->z_off = h.zOff;
+	info->len = h.len > 0xffffffffull ? 0xffffffffu : (uint32_t)h.len; info->n_pat = h.nPat; info->n_frag = h.nFrag; info->ftab_chars = (uint32_t)h.ftabChars;
+	info->off_rate = (uint32_t)h.offRate; info->z_off = (uint32_t)h.zOff;
 	info->ebwt_bytes = idx->ebwt_bytes; info->offs_bytes = idx->offs_bytes;
 	info->has_mirror = idx->has_mirror ? 1 : 0;
 	info->variant = idx->variant | (h.swapped ? BT_INDEX_SWAPPED : 0);
 }
+extern "C" int bt_rows64(void) { return BT_WIDE ? 1 : 0; }
+extern "C" uint64_t bt_index_len64(const bt_index* idx) { return idx ? (uint64_t)idx->host[0].len : 0; }
 extern "C" const char* bt_index_refname(const bt_index* idx, uint32_t tidx)
 {
 	return tidx < idx->host[0].refnames.size() ? idx->host[0].refnames[tidx].c_str() : nullptr;
 }
 extern "C" uint32_t bt_index_reflen(const bt_index* idx, uint32_t tidx)
 {
-	return tidx < idx->host[0].plen.size() ? idx->host[0].plen[tidx] : 0;
+	return tidx < idx->host[0].plen.size() ? (uint32_t)idx->host[0].plen[tidx] : 0;
 }
 extern "C" void bt_index_free(bt_index* idx)
 {
@@ -250,6 +266,7 @@ static bool index_ensure_locus(const bt_index* cidx)
 	if (cidx->locState != 0) return cidx->locState > 0;
 	bt_index* idx = const_cast<bt_index*>(cidx);
 	idx->locState = -1;
+	if (BT_WIDE) return false;                   /* the wide build searches in row space (bt_rank.h, "the row type") */
 	if (env_u32("BT_LOCUS", 1) == 0) return false;
 	const int nidx = idx->has_mirror ? 2 : 1;
 	uint64_t need = 0;
@@ -378,7 +395,7 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 		c->palCap = (uint32_t)(pals > (1u << 22) ? (1u << 22) : pals);
 	}
 	HIPCHK(hipMalloc((void**)&c->frames, (size_t)c->nSlots * c->frCap * BT_FR_WORDS * 4u));
-	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nSlots * c->entCap * 32u));
+	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nSlots * c->entCap * 8u * sizeof(bt_row)));
 	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nSlots * c->entCap * 2u));
 	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nSlots * c->palCap * 8u));
 	return BT_OK;
@@ -677,6 +694,9 @@ static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
 		warm->offRate[m] = d.offRate; warm->ftabChars[m] = d.ftabChars; warm->len[m] = d.len;
 		for (int k = 0; k < 5; k++) A->H.fchr[m][k] = d.fchr[k];
 		if (c->locus) { warm->loc[m] = d.loc; warm->rtxt[m] = d.rtxt; warm->walk[m] = d.walk; }
+#if BT_WIDE
+		A->H.segBase[m] = d.segBase; A->H.segShift = d.segShift; warm->rowLim[m] = d.rowLim;
+#endif
 	}
 	warm->locOn = c->locus ? 1u : 0u;
 }
@@ -905,10 +925,10 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 				for (uint32_t g = 0; g < nd; g++) {
 					BtLane L; memcpy(&L, recs[g].w, sizeof(L));
 					fprintf(stderr, "[carry] pool[%u] stamp=%u%s rd=%u bid=%u state=%u step=%u kind=%u mirror=%u readFw=%u rev=%u qlen=%u plen=%u sd=%u depth=%u d=%u top=%u bot=%u iters=%u nhits=%u stored=%u status=%u req{kind=%u n=%u a=%llx x=%llx}\n",
-					        g, recs[g].w[60], recs[g].w[60] == c->launchSeq ? "(live)" : "(stale)", L.rd, (unsigned)L.bid, (unsigned)L.state, (unsigned)L.step, (unsigned)L.kind,
-					        (unsigned)L.mirror, (unsigned)L.readFw, (unsigned)L.rev, (unsigned)L.qlen, (unsigned)L.plen, (unsigned)L.sd, (unsigned)L.depth, (unsigned)L.d, L.top, L.bot,
-					        L.iters, L.nhits, (unsigned)L.stored, (unsigned)L.status, recs[g].w[52], recs[g].w[53],
-					        (unsigned long long)(((uint64_t)recs[g].w[57] << 32) | recs[g].w[56]), (unsigned long long)(((uint64_t)recs[g].w[59] << 32) | recs[g].w[58]));
+					        g, recs[g].w[BT_POOL_STAMP_WORD], recs[g].w[BT_POOL_STAMP_WORD] == c->launchSeq ? "(live)" : "(stale)", L.rd, (unsigned)L.bid, (unsigned)L.state, (unsigned)L.step, (unsigned)L.kind,
+					        (unsigned)L.mirror, (unsigned)L.readFw, (unsigned)L.rev, (unsigned)L.qlen, (unsigned)L.plen, (unsigned)L.sd, (unsigned)L.depth, (unsigned)L.d, (unsigned)L.top, (unsigned)L.bot,
+					        L.iters, L.nhits, (unsigned)L.stored, (unsigned)L.status, recs[g].w[4 * BT_POOL_REQ], recs[g].w[4 * BT_POOL_REQ + 1],
+					        (unsigned long long)(((uint64_t)recs[g].w[4 * BT_POOL_REQ + 5] << 32) | recs[g].w[4 * BT_POOL_REQ + 4]), (unsigned long long)(((uint64_t)recs[g].w[4 * BT_POOL_REQ + 7] << 32) | recs[g].w[4 * BT_POOL_REQ + 6]));
 				}
 		}
 	}
@@ -1574,6 +1594,30 @@ extern "C" void* bt_host_alloc(size_t bytes)
 extern "C" void bt_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 /* ---- probes ---------------------------------------------------------------------------------- */
+/* rows as 64-bit numbers in either build (the wide build's own probe; the 32-bit calls below answer BT_ERR_UNSUPPORTED there) */
+extern "C" int bt_probe_rank64(bt_ctx* c, int mirror, const uint64_t* rows, uint32_t n, uint64_t* lf, uint8_t* L)
+{
+	if (!c || !rows || !lf || !L || (mirror && !c->idx->has_mirror)) return BT_ERR_ARG;
+	if (n == 0) return BT_OK;
+	HIPCHK(hipSetDevice(c->idx->device));
+	std::vector<bt_row> hr(n), hl(4ull * n);
+	for (uint32_t i = 0; i < n; i++) hr[i] = (bt_row)rows[i];
+	bt_row *d_rows = nullptr, *d_lf = nullptr; uint8_t* d_L = nullptr;
+	HIPCHK(hipMalloc((void**)&d_rows, sizeof(bt_row) * (size_t)n)); HIPCHK(hipMalloc((void**)&d_lf, 4u * sizeof(bt_row) * (size_t)n)); HIPCHK(hipMalloc((void**)&d_L, n));
+	HIPCHK(hipMemcpy(d_rows, hr.data(), sizeof(bt_row) * (size_t)n, hipMemcpyHostToDevice));
+	int rc = bt_launch_probe_rank(&c->idx->dev[mirror ? 1 : 0], d_rows, n, d_lf, d_L, 0, c->stream);
+	if (rc == 0) rc = (int)hipStreamSynchronize(c->stream);
+	if (rc == 0) { (void)hipMemcpy(hl.data(), d_lf, 4u * sizeof(bt_row) * (size_t)n, hipMemcpyDeviceToHost); (void)hipMemcpy(L, d_L, n, hipMemcpyDeviceToHost); }
+	for (size_t i = 0; i < 4ull * n; i++) lf[i] = hl[i];
+	(void)hipFree(d_rows); (void)hipFree(d_lf); (void)hipFree(d_L);
+	return rc == 0 ? BT_OK : BT_ERR_DEVICE;
+}
+
+#if BT_WIDE
+extern "C" int bt_probe_rank(bt_ctx*, int, const uint32_t*, uint32_t, uint32_t*, uint8_t*) { return BT_ERR_UNSUPPORTED; }
+extern "C" int bt_probe_chase(bt_ctx*, int, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*) { return BT_ERR_UNSUPPORTED; }
+extern "C" int bt_bench_gather(bt_ctx*, int, uint32_t, uint32_t, int, float*, double*) { return BT_ERR_UNSUPPORTED; }
+#else
 extern "C" int bt_probe_rank(bt_ctx* c, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L)
 {
 	const uint32_t sides = (uint32_t)mirror & 2u;          /* bit 1: rank from the side layout (see the header) */
@@ -1633,6 +1677,7 @@ extern "C" int bt_bench_gather(bt_ctx* c, int mirror, uint32_t n_blocks, uint32_
 	*gbs_out = (double)n_blocks * 256.0 * iters * (sides ? 128.0 : 32.0) / (ms * 1e-3) / 1e9;
 	return BT_OK;
 }
+#endif /* BT_WIDE */
 
 extern "C" int bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64_t cap)
 {
@@ -1666,12 +1711,16 @@ extern "C" int bt_index_digest(const char* ebwt_base, int mirror, uint64_t out[8
 	};
 	out[0] = (uint64_t)variant | (h.swapped ? 16u : 0u);
 	out[1] = h.len;
+#if BT_WIDE
+	out[2] = fnv(h.blk.data(), h.blk.size());          /* (the wide build's image: rank blocks instead of sides, 8-byte entries) */
+#else
 	out[2] = fnv(h.ebwt.data(), h.ebwt.size());
-	out[3] = fnv(h.ftab.data(), 4 * h.ftab.size());
-	out[4] = fnv(h.eftab.data(), 4 * h.eftab.size());
-	out[5] = fnv(h.offs.data(), 4 * h.offs.size());
-	out[6] = fnv(h.rstarts.data(), 4 * h.rstarts.size(), fnv(h.plen.data(), 4 * h.plen.size()));
-	uint32_t tail[8] = {h.zOff, h.fchr[0], h.fchr[1], h.fchr[2], h.fchr[3], h.fchr[4], (uint32_t)h.offRate, (uint32_t)h.ftabChars};
+#endif
+	out[3] = fnv(h.ftab.data(), sizeof(bt_row) * h.ftab.size());
+	out[4] = fnv(h.eftab.data(), sizeof(bt_row) * h.eftab.size());
+	out[5] = fnv(h.offs.data(), sizeof(bt_row) * h.offs.size());
+	out[6] = fnv(h.rstarts.data(), sizeof(bt_row) * h.rstarts.size(), fnv(h.plen.data(), sizeof(bt_row) * h.plen.size()));
+	bt_row tail[8] = {h.zOff, h.fchr[0], h.fchr[1], h.fchr[2], h.fchr[3], h.fchr[4], (bt_row)h.offRate, (bt_row)h.ftabChars};
 	out[7] = fnv(tail, sizeof(tail));
 	return BT_OK;
 }
@@ -1687,7 +1736,9 @@ extern "C" const char* bt_strerror(int code)
 	case BT_ERR_READ_SHORT: return "read shorter than the alignment mode allows";
 	case BT_ERR_OVERFLOW: return "per-read scratch capacity exceeded";
 	case BT_ERR_READS: return "malformed read input";
+	case BT_ERR_ROWS64: return "the index has 2^32-1 rows or more: use the build with 64-bit rows (libbowtie_amd_l.so, bowtie-amd-l)";
+	case BT_ERR_UNSUPPORTED: return "not in this build (the build with 64-bit rows has neither --best nor paired-end alignment yet)";
 	default: return "unknown error";
 	}
 }
-extern "C" const char* bt_version(void) { return "bowtie_amd 0.1.0 (gfx950)"; }
+extern "C" const char* bt_version(void) { return BT_WIDE ? "bowtie_amd 0.1.0 (gfx950, 64-bit rows)" : "bowtie_amd 0.1.0 (gfx950)"; }

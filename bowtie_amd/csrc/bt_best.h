@@ -210,6 +210,9 @@ struct BfLane {                   /* per-lane registers / private memory */
 
 #define AW(o) (X.A[(o)])
 
+/* (the wide build -- 64-bit BWT rows, bt_rank.h "the row type" -- keeps the types above, so that the ABI layer compiles
+ * unchanged, and leaves the engine out: bt_ctx_create answers BT_ERR_UNSUPPORTED for --best and for pairs there) */
+#if !BT_WIDE
 BF_INL uint32_t bf_rnd(uint32_t& last)                       /* RandomSource::nextU32, random_source.h:45-54 */
 {
 	last = 1664525u * last + 1013904223u;
@@ -2392,4 +2395,5 @@ BF_FNI void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk,
 }
 
 #undef AW
+#endif /* !BT_WIDE */
 #endif /* BT_BEST_H_ */

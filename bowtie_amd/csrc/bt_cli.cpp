@@ -986,6 +986,19 @@ int main(int argc, char** argv)
 	}
 	/* ---- index into HBM (above) ---- */
 	prefetch.join();
+	if (rc == BT_ERR_ROWS64 && !bt_rows64()) {
+		/* 2^32-1 rows or more: the reference's wrapper starts bowtie-align-l for such an index (bowtie:52-81); here the
+		 * same sources built with 64-bit rows, next to this binary */
+		char self[PATH_MAX];
+		const ssize_t n = readlink("/proc/self/exe", self, sizeof(self) - 3);
+		if (n > 0) {
+			self[n] = 0;
+			strcat(self, "-l");
+			fflush(stdout); fflush(stderr);
+			execv(self, argv);
+		}
+		die("Error: index \"%s\" has 2^32-1 rows or more and the 64-bit-row build (bowtie-amd-l) could not be started", O.index.c_str());
+	}
 	if (rc != BT_OK) {
 		if (rc == BT_ERR_IO) die("Could not locate a Bowtie index corresponding to basename \"%s\"", O.index.c_str());
 		die("Error: could not load index \"%s\": %s", O.index.c_str(), bt_strerror(rc));

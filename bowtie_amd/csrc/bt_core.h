@@ -89,7 +89,7 @@ struct BtArena {
 	/* arena bases and capacities (wave-uniform).  On the GPU this lives in LDS, one copy per
 	 * workgroup: addresses are formed where they are used and nothing stays in registers. */
 	uint32_t* frames;   /* [slot][frame][12]                                                     */
-	uint32_t* pairs;    /* [slot][entry][8]: tops ACGT, bots ACGT                                */
+	uint32_t* pairs;    /* [slot][entry][8] rows (bt_row): tops ACGT, bots ACGT                  */
 	uint16_t* meta;     /* [slot][entry] eliminated-chars mask | Phred<<8                        */
 	uint64_t* pals;     /* [slot][palCap] seedlings                                              */
 	uint32_t  frCap, entCap, palCap, pad;
@@ -141,22 +141,36 @@ struct BtBatchDev {
 struct BtHot {
 	const uint8_t* blk[2];            /* the rank blocks (bt_rank.h) of the text index and of the mirror index */
 	uint32_t zBlk[2], zPos[2];
-	uint32_t fchr[2][5];
+	bt_row   fchr[2][5];
 	const uint8_t* seq; const uint8_t* qual;
 	uint32_t stride, n_reads;
+#if BT_WIDE
+	const uint64_t* segBase[2];       /* the wide build's rank blocks count from their segment's start (bt_rank.h) */
+	uint32_t segShift, padW;
+#endif
 };
 /* BtWarm: index geometry the automaton reads a few times per frame / SA walk.  On the GPU it sits
  * in LDS (one copy per workgroup) so that it occupies no scalar registers across the round loop. */
 struct BtWarm {
-	const uint32_t* ftab[2];
-	const uint32_t* offs[2];
-	uint32_t zOff[2], offMask[2], offRate[2], ftabChars[2], len[2];
+	const bt_row* ftab[2];
+	const bt_row* offs[2];
+	bt_row   zOff[2], offMask[2];
+	uint32_t offRate[2], ftabChars[2];
+	bt_row   len[2];
 	/* the locus image (bt_rank.h), all NULL / 0 when it was not built or is switched off */
 	const BtU4*     loc[2];
 	const uint32_t* rtxt[2];
 	const uint16_t* walk[2];
 	uint32_t locOn, pad;
+#if BT_WIDE
+	bt_row   rowLim[2];               /* the last BWT row (BtIndexDev::rowLim) */
+#endif
 };
+#if BT_WIDE
+#define BT_WROWLIM() WSEL(rowLim)
+#else
+#define BT_WROWLIM() WSEL(len)
+#endif
 #define BT_BATCH_RING 16
 struct BtCold {
 	BtProgram  P;
@@ -190,9 +204,33 @@ struct BtReq {
 	uint32_t tally;
 };
 struct BtRes {
-	BtU4 q[4];              /* RANK: q[0] = LF(rowA, ACGT), q[1] = LF(rowB, ACGT), q[2].x = BWT char at rowA */
+	BtU4 q[4];              /* RANK: q[0] = LF(rowA, ACGT), q[1] = LF(rowB, ACGT), q[2].x = BWT char at rowA
+	                           (wide build: a quartet is four 64-bit rows = two pieces -- q[0..1] = LF(rowA, ACGT),
+	                           q[2..3] = LF(rowB, ACGT), x.x = BWT char at rowA -- the layout of a fetched range-stack entry) */
 	BtU4 x;
 };
+/* the two quartets of a rank answer / of a fetched range-stack entry, and single rows out of fetched pieces */
+#if BT_WIDE
+#define BT_RES_ROWL(res) ((res).x.x)
+BT_HD bt_row bt_u4_row2(const BtU4& v, uint32_t k) { return (k & 1u) ? (((uint64_t)v.w << 32) | v.z) : (((uint64_t)v.y << 32) | v.x); }
+BT_HD void bt_res_quartets(const BtRes& res, bt_row ta[4], bt_row tb[4])
+{
+	ta[0] = bt_u4_row2(res.q[0], 0); ta[1] = bt_u4_row2(res.q[0], 1); ta[2] = bt_u4_row2(res.q[1], 0); ta[3] = bt_u4_row2(res.q[1], 1);
+	tb[0] = bt_u4_row2(res.q[2], 0); tb[1] = bt_u4_row2(res.q[2], 1); tb[2] = bt_u4_row2(res.q[3], 0); tb[3] = bt_u4_row2(res.q[3], 1);
+}
+/* row k of a table fetched as the 16-byte piece(s) that hold it */
+BT_HD bt_row bt_piece_row(const BtU4& v, uint32_t k) { return bt_u4_row2(v, k); }
+#else
+#define BT_RES_ROWL(res) ((res).q[2].x)
+BT_HD void bt_res_quartets(const BtRes& res, uint32_t ta[4], uint32_t tb[4])
+{
+	ta[0] = res.q[0].x; ta[1] = res.q[0].y; ta[2] = res.q[0].z; ta[3] = res.q[0].w;
+	tb[0] = res.q[1].x; tb[1] = res.q[1].y; tb[2] = res.q[1].z; tb[3] = res.q[1].w;
+}
+#endif
+#define BT_ENT_PIECES (2u * (uint32_t)sizeof(bt_row) / 4u)     /* 16-byte pieces of a range-stack entry: 2, wide 4 */
+/* the locus-mode paths of the RL builds: not in the wide build (bt_rank.h, "the row type") */
+#define BT_LOC(RL) ((RL) && !BT_WIDE)
 
 enum {
 	ST_IDLE = 0,
@@ -263,7 +301,7 @@ struct BtLane {
 	uint32_t rnd, numBts;
 	/* current frame (locals of backtrack(), ebwt_search_backtrack.h:363-455) */
 	uint32_t sd : 7, depth : 11, d : 11;
-	uint32_t top, bot;
+	bt_row   top, bot;
 	uint32_t ham : 16, lowAltQual : 8,
 	         el : 6;                 /* locus mode: levels of the reference's recursion gone through without a frame of their own since the last real one (bt_loc_descend) */
 	uint32_t fu : 11, f1 : 11, elcint : 2, elignore : 1, candValid : 1;
@@ -285,8 +323,9 @@ struct BtLane {
 	         ra_l : 1;            /* the alignment being reported comes from locus mode: ra_top is an anchor, not a row */
 	/* report */
 	uint32_t ra_sd : 7, ra_stratum : 7, ra_cost : 16;
-	uint32_t ra_top, ra_bot, ra_r, ra_i;
-	uint32_t crow, cjumps;
+	bt_row   ra_top, ra_bot, ra_r, ra_i;
+	bt_row   crow;
+	uint32_t cjumps;
 	uint32_t iters;
 	/* register window over the read: 16 bases + 16 quals around the current position */
 	uint32_t state;                  /* ST_*: in a word of its own -- every guard of the sweep tests it */
@@ -378,6 +417,19 @@ BT_HD uint32_t bt_sel4(uint32_t k, uint32_t w0, uint32_t w1, uint32_t w2, uint32
 	return (k & 2u) ? hi : lo;
 }
 BT_HD uint32_t bt_u4_word(const BtU4& v, uint32_t k) { return bt_sel4(k, v.x, v.y, v.z, v.w); }
+#if BT_WIDE
+BT_HD bt_row bt_selr4(uint32_t k, bt_row w0, bt_row w1, bt_row w2, bt_row w3)
+{
+	bt_row lo = (k & 1u) ? w1 : w0, hi = (k & 1u) ? w3 : w2;
+	return (k & 2u) ? hi : lo;
+}
+/* LF(rowA, character k) of a rank answer */
+BT_HD bt_row bt_res_lfa(const BtRes& res, uint32_t k) { return (k & 2u) ? bt_u4_row2(res.q[1], k) : bt_u4_row2(res.q[0], k); }
+#else
+#define bt_selr4 bt_sel4
+BT_HD uint32_t bt_piece_row(const BtU4& v, uint32_t k) { return bt_u4_word(v, k & 3u); }
+BT_HD uint32_t bt_res_lfa(const BtRes& res, uint32_t k) { return bt_u4_word(res.q[0], k); }
+#endif
 BT_HD uint32_t bt_u4_byte(const BtU4& v, uint32_t b) { return (bt_u4_word(v, (b >> 2) & 3u) >> ((b & 3u) * 8u)) & 0xffu; }
 /* the 16-bit record k (0..7) of a fetched chunk of the (mask,quality) array */
 BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
@@ -387,10 +439,26 @@ BT_HD uint32_t bt_u4_meta(const BtU4& v, uint32_t k)
 }
 
 #define FRW(f, w) BT_GP(uint32_t, S.a->frames)[((uint64_t)S.slot * S.a->frCap + (f)) * BT_FR_WORDS + (w)]
-#define PT(e, c) BT_GP(uint32_t, S.a->pairs)[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + (c)]
-#define PT4(e) (S.a->pairs + ((uint64_t)S.slot * S.a->entCap + (e)) * 8u)          /* address of tops[4] */
-#define PB4(e) (S.a->pairs + ((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u)     /* address of bots[4] */
-#define PB(e, c) BT_GP(uint32_t, S.a->pairs)[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u + (c)]
+#define BT_ENT_WORDS (8u * (uint32_t)sizeof(bt_row) / 4u)        /* 32-bit words of a range-stack entry: 8 rows */
+#define PT(e, c) BT_GP(bt_row, S.a->pairs)[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + (c)]
+#define PT4(e) (S.a->pairs + ((uint64_t)S.slot * S.a->entCap + (e)) * BT_ENT_WORDS)                       /* address of tops[4] */
+#define PB4(e) (S.a->pairs + ((uint64_t)S.slot * S.a->entCap + (e)) * BT_ENT_WORDS + BT_ENT_WORDS / 2u)   /* address of bots[4] */
+#define PB(e, c) BT_GP(bt_row, S.a->pairs)[((uint64_t)S.slot * S.a->entCap + (e)) * 8u + 4u + (c)]
+/* a quartet of rows to an entry's tops / bots; a rank answer's two quartets to an entry */
+#if BT_WIDE
+BT_HD void bt_store_quartet(uint32_t* dst, bt_row a, bt_row b, bt_row c, bt_row d)
+{
+	BtU4 v; v.x = (uint32_t)a; v.y = (uint32_t)(a >> 32); v.z = (uint32_t)b; v.w = (uint32_t)(b >> 32); bt_st4(dst, v);
+	v.x = (uint32_t)c; v.y = (uint32_t)(c >> 32); v.z = (uint32_t)d; v.w = (uint32_t)(d >> 32); bt_st4(dst + 4, v);
+}
+#define BT_STORE_ENTRY(e, res) do { uint32_t* pe_ = PT4(e); bt_st4(pe_, (res).q[0]); bt_st4(pe_ + 4, (res).q[1]); bt_st4(pe_ + 8, (res).q[2]); bt_st4(pe_ + 12, (res).q[3]); } while (0)
+#else
+BT_HD void bt_store_quartet(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+	BtU4 v; v.x = a; v.y = b; v.z = c; v.w = d; bt_st4(dst, v);
+}
+#define BT_STORE_ENTRY(e, res) do { bt_st4(PT4(e), (res).q[0]); bt_st4(PB4(e), (res).q[1]); } while (0)
+#endif
 #define META(e) BT_GP(uint16_t, S.a->meta)[(uint64_t)S.slot * S.a->entCap + (e)]
 #define META_MASK(e) BT_GP(uint8_t, S.a->meta + (uint64_t)S.slot * S.a->entCap + (e))[0]   /* low byte: the eliminated-set */
 #define PALS(k) BT_GP(uint64_t, S.a->pals)[(uint64_t)S.slot * S.a->palCap + (k)]
@@ -560,7 +628,7 @@ BT_HD bool bt_report_hit(BtLane& L, const BtProgram& P, uint32_t ixfw, const BtS
 	if (L.nhits > P.sinkMax) return true;
 	if (L.stored < B.hit_cap) {
 		BtHitRec h;
-		h.tidx = tidx; h.toff = toff; h.oms = L.ra_bot - L.ra_top - 1u;
+		h.tidx = tidx; h.toff = toff; h.oms = (uint32_t)(L.ra_bot - L.ra_top - 1u);
 		h.cost = (uint16_t)L.ra_cost; h.stratum = (uint8_t)L.ra_stratum; h.fw = (uint8_t)L.readFw;
 		h.pad[0] = h.pad[1] = 0;
 		const uint32_t nmm = L.ra_sd + L.nmuts;
@@ -777,7 +845,7 @@ BT_HD void bt_frame_push(BtLane& L, const BtScratch& S)
 	w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25) | (L.el << 26);
 	w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
 	w[FR_EBASE] = L.ebase;
-	w[FR_ANCHOR] = L.top;
+	w[FR_ANCHOR] = (uint32_t)L.top;
 	uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
 	BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
 	bt_st4(fr, q0); bt_st4(fr + 4, q1);
@@ -826,11 +894,11 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			L.ra_cost = (L.ra_cost | (stratum << 14)) & 0xffffu;
 			if (L.ra_sd + L.nmuts == 0 && !L.reportExacts) { L.ret = 0; L.state = ST_RA_END; break; }
 			{
-				const uint32_t spread = L.ra_bot - L.ra_top;
-				uint32_t r = bt_rnd_u32(L);
+				const bt_row spread = L.ra_bot - L.ra_top;
+				bt_row r = bt_rnd_u32(L);
 				if (C.ix[0].wide) {                                     /* nextU<TIndexOffU>() of the 64-bit build: random_source.h:56-62 */
 					const uint64_t r64 = ((uint64_t)r << 32) | bt_rnd_u32(L);
-					r = (uint32_t)(r64 % spread);
+					r = (bt_row)(r64 % spread);
 				} else r %= spread;
 				L.ra_r = L.ra_top + r;
 				L.ra_i = 0;
@@ -839,19 +907,19 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 		} while (0); BT_PROF_ADD(PS_RA_BEGIN, t_ra_begin); }
 
 		if (ST_IS(ST_ROW_BEGIN)) { BT_PROF_T0(t_row_begin); do {
-			const uint32_t spread = L.ra_bot - L.ra_top;
+			const bt_row spread = L.ra_bot - L.ra_top;
 			if (L.ra_i >= spread) { L.ret = 0; L.state = ST_RA_END; break; }
-			uint32_t ri = L.ra_r + L.ra_i;
+			bt_row ri = L.ra_r + L.ra_i;
 			if (ri >= L.ra_bot) ri -= spread;
 			L.crow = ri; L.cjumps = 0;
-			L.state = (RL && L.ra_l) ? ST_RESOLVE_DONE : ST_CHASE_CHECK;       /* in locus mode "the row" is the anchor: nothing to walk */
+			L.state = (BT_LOC(RL) && L.ra_l) ? ST_RESOLVE_DONE : ST_CHASE_CHECK;       /* in locus mode "the row" is the anchor: nothing to walk */
 		} while (0); BT_PROF_ADD(PS_ROW_BEGIN, t_row_begin); }
 
 		/* ---- an SA walk reached a sampled row: offset -> (tidx,toff) -> sink (ebwt.h:2569-2746) ---- */
 		if (ST_IS(ST_RESOLVE_DONE)) { BT_PROF_T0(t_resolve_done); do {
-			const uint32_t zOff = WSEL(zOff);
-			uint32_t off;
-			if (W.locOn) {
+			const bt_row zOff = WSEL(zOff);
+			bt_row off;
+			if (!BT_WIDE && W.locOn) {
 				/* no walk: the alignment was found in locus mode (its text offset is known: anchor - qlen), or the row's
 				 * locus record has just arrived (word 0 = SA[row]).  The walk the reference does from here is tallied from
 				 * the table of walk lengths */
@@ -859,26 +927,27 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_COUNT_N(CN_TCHASE, BT_GP(const uint16_t, WSEL(walk))[off]);
 			}
 			else if (L.crow == zOff) off = L.cjumps;
-			else off = bt_u4_word(res.q[0], (L.crow >> WSEL(offRate)) & 3u) + L.cjumps;
+			else off = bt_piece_row(res.q[0], (uint32_t)(L.crow >> WSEL(offRate))) + L.cjumps;
 			BT_COUNT(CN_OFFS);
 			/* joinedToTextOff (ebwt.h:2569-2629) */
-			const uint32_t* rstarts = IXSEL(rstarts);
-			const uint32_t nFrag = IXSEL(nFrag), len = WSEL(len), ixfw = L.mirror ? 0u : 1u;
+			const bt_row* rstarts = IXSEL(rstarts);
+			const uint32_t nFrag = IXSEL(nFrag), ixfw = L.mirror ? 0u : 1u;
+			const bt_row len = WSEL(len);
 			uint32_t lo = 0, hi = nFrag, tidx = 0, toff = 0, probes = 0;
 			bool hit = false;
 			BT_NOUNROLL
 			for (;;) {
 				const uint32_t elt = lo + ((hi - lo) >> 1);
-				const uint32_t lower = BT_GP(const uint32_t, rstarts)[elt * 3u];
-				const uint32_t upper = (elt == nFrag - 1u) ? len : BT_GP(const uint32_t, rstarts)[(elt + 1u) * 3u];
+				const bt_row lower = BT_GP(const bt_row, rstarts)[elt * 3u];
+				const bt_row upper = (elt == nFrag - 1u) ? len : BT_GP(const bt_row, rstarts)[(elt + 1u) * 3u];
 				probes++;
 				if (lower <= off) {
 					if (upper > off) {
 						if (off + L.qlen <= upper) {
-							uint32_t fragoff = off - lower;
+							bt_row fragoff = off - lower;
 							if (!ixfw) { fragoff = (upper - lower) - fragoff - 1u; fragoff -= (L.qlen - 1u); }
-							tidx = BT_GP(const uint32_t, rstarts)[elt * 3u + 1u];
-							toff = fragoff + BT_GP(const uint32_t, rstarts)[elt * 3u + 2u];
+							tidx = (uint32_t)BT_GP(const bt_row, rstarts)[elt * 3u + 1u];
+							toff = (uint32_t)(fragoff + BT_GP(const bt_row, rstarts)[elt * 3u + 2u]);
 							hit = true;
 						}
 						break;
@@ -896,7 +965,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			switch (L.ra_cont) {
 			case RC_STEP:
 				if (L.ret) { L.state = ST_FRAME_RETURN; break; }
-				if (RL && L.lmode) L.bot = L.top; else L.top = L.bot;     /* keep looking (:730-735); in locus mode `top` is the anchor and stays */
+				if (BT_LOC(RL) && L.lmode) L.bot = L.top; else L.top = L.bot;     /* keep looking (:730-735); in locus mode `top` is the anchor and stays */
 				if (L.altNum > 0) L.state = ST_BT_LOOP;
 				else { L.ret = 0; L.state = ST_FRAME_RETURN; }
 				break;
@@ -1113,9 +1182,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				uint32_t ftabOff = 0;
 				BT_NOUNROLL
 				for (uint32_t t = 0; t < ftabChars; t++) ftabOff |= bt_qry<RL>(L, H, S, L.qlen - 1u - t) << (2u * t);
-				const uint32_t* ftab = WSEL(ftab);
+				const bt_row* ftab = WSEL(ftab);
 				L.ra_r = ftabOff;           /* parked until the table entry arrives */
-				BT_REQ_FETCH(ftab + (ftabOff & ~3u), 1, ftab + ((ftabOff + 1u) & ~3u));
+				BT_REQ_FETCH(ftab + (ftabOff & ~(BT_PIECE_ROWS - 1u)), 1, ftab + ((ftabOff + 1u) & ~(BT_PIECE_ROWS - 1u)));
 				L.state = ST_FTAB_DONE;
 			} else if (nsInFtab == 0 && m >= ftabChars) {
 				/* calcFtabOff (:1348-1362) needs the last ftabChars characters of the query: fetch the
@@ -1144,20 +1213,21 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				c = bt_apply_muts(L, i, c);
 				ftabOff |= c << (2u * t);
 			}
-			const uint32_t* ftab = WSEL(ftab);
+			const bt_row* ftab = WSEL(ftab);
 			L.ra_r = ftabOff;           /* parked until the table entry arrives */
-			BT_REQ_FETCH(ftab + (ftabOff & ~3u), 1, ftab + ((ftabOff + 1u) & ~3u));
+			BT_REQ_FETCH(ftab + (ftabOff & ~(BT_PIECE_ROWS - 1u)), 1, ftab + ((ftabOff + 1u) & ~(BT_PIECE_ROWS - 1u)));
 			L.state = ST_FTAB_DONE;
 		} while (0); BT_PROF_ADD(PS_FTABSEQ_DONE, t_ftabseq_done); }
 
 		if (ST_IS_NOREQ(ST_FTAB_DONE)) { BT_PROF_T0(t_ftab_done); do {
-			const uint32_t ftabChars = WSEL(ftabChars), len = WSEL(len);
-			const uint32_t ftabOff = L.ra_r;
-			uint32_t top = bt_u4_word(res.q[0], ftabOff & 3u);
-			uint32_t bot = (((ftabOff + 1u) & ~3u) == (ftabOff & ~3u)) ? bt_u4_word(res.q[0], (ftabOff + 1u) & 3u)
-			                                                          : bt_u4_word(res.x, (ftabOff + 1u) & 3u);
-			if (top > len) { const uint32_t* eftab = IXSEL(eftab); top = BT_GP(const uint32_t, eftab)[(top ^ BT_OFF_MASK) * 2u + 1u]; }
-			if (bot > len) { const uint32_t* eftab = IXSEL(eftab); bot = BT_GP(const uint32_t, eftab)[(bot ^ BT_OFF_MASK) * 2u]; }
+			const uint32_t ftabChars = WSEL(ftabChars);
+			const bt_row len = BT_WROWLIM();
+			const uint32_t ftabOff = (uint32_t)L.ra_r;
+			bt_row top = bt_piece_row(res.q[0], ftabOff);
+			bt_row bot = (((ftabOff + 1u) & ~(BT_PIECE_ROWS - 1u)) == (ftabOff & ~(BT_PIECE_ROWS - 1u))) ? bt_piece_row(res.q[0], ftabOff + 1u)
+			                                                                                          : bt_piece_row(res.x, ftabOff + 1u);
+			if (top > len) { const bt_row* eftab = IXSEL(eftab); top = BT_GP(const bt_row, eftab)[(top ^ BT_OFF_MASK) * 2u + 1u]; }
+			if (bot > len) { const bt_row* eftab = IXSEL(eftab); bot = BT_GP(const bt_row, eftab)[(bot ^ BT_OFF_MASK) * 2u]; }
 			BT_COUNT(CN_FTAB);
 			if (L.qlen == ftabChars && bot > top) {
 				if (L.reportPartials > 0) { L.depth = 0; L.top = 0; L.bot = 0; L.state = ST_FRAME_ENTER; }
@@ -1182,7 +1252,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.lmode && L.cand >= L.dcf) break;       /* the frame's position in the text: one alternative, the text's base (lt) */
 			/* fetch the target position's four (top,bot) ranges and its (mask,quality) record */
 			const uint32_t e = bt_ent(L, L.cand);
-			BT_REQ_FETCH(&PT(e, 0), 2, &META(e & ~7u));
+			BT_REQ_FETCH(&PT(e, 0), BT_ENT_PIECES, &META(e & ~7u));
 		} while (0); BT_PROF_ADD(PS_BT_LOOP, t_bt_loop); }
 
 		if (ST_IS(ST_CANDSCAN) || ST_IS(ST_CANDSCAN_DONE)) { BT_PROF_T0(t_candscan); do {
@@ -1213,7 +1283,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			const uint32_t i = L.cand;
 			const uint32_t e = bt_ent(L, i);
 			const uint32_t ts = S.tosStride;
-			uint32_t mv, tp[4], bp[4];
+			uint32_t mv;
+			bt_row tp[4], bp[4];
 			const bool locTarget = L.lmode && i >= L.dcf;
 			if (locTarget && !L.ccValid) {
 				/* a position decided by the text has one alternative, the text's base there, on the one row that goes with it;
@@ -1226,39 +1297,38 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				for (uint32_t k = 0; k < 4u; k++) { tp[k] = S.tos[k * ts]; bp[k] = S.tos[(4u + k) * ts]; }
 				mv = S.tos[8u * ts];
 			} else {
-				tp[0] = res.q[0].x; tp[1] = res.q[0].y; tp[2] = res.q[0].z; tp[3] = res.q[0].w;
-				bp[0] = res.q[1].x; bp[1] = res.q[1].y; bp[2] = res.q[1].z; bp[3] = res.q[1].w;
+				bt_res_quartets(res, tp, bp);
 				mv = bt_u4_meta(res.x, e & 7u);
-				if (!S.noCC) {
+				if (!BT_WIDE && !S.noCC) {
 					BT_UNROLL
-					for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = tp[k]; S.tos[(4u + k) * ts] = bp[k]; }
+					for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = (uint32_t)tp[k]; S.tos[(4u + k) * ts] = (uint32_t)bp[k]; }
 					S.tos[8u * ts] = mv;
 					L.ccValid = 1;
 				}
 			}
 			const uint32_t el = mv & 15u, qi = mv >> 8;
-			const uint32_t sp[4] = {bp[0] - tp[0], bp[1] - tp[1], bp[2] - tp[2], bp[3] - tp[3]};
+			const bt_row sp[4] = {bp[0] - tp[0], bp[1] - tp[1], bp[2] - tp[2], bp[3] - tp[3]};
 			uint32_t j = 0;
 			if (L.eligibleNum > 1 || L.elignore) {
-				uint32_t posSz = 0;
+				bt_row posSz = 0;
 				BT_UNROLL
 				for (uint32_t l = 0; l < 4u; l++) if ((el & (1u << l)) == 0) posSz += sp[l];
 				if (posSz == 0) { L.state = ST_ABORT; break; }
-				uint32_t r = bt_rnd_u32(L) % posSz;
+				uint32_t r = (uint32_t)(bt_rnd_u32(L) % posSz);      /* (:788-795: a 32-bit draw and 32-bit spreads in the 64-bit build too) */
 				bool found = false;
 				BT_UNROLL
 				for (uint32_t l = 0; l < 4u; l++) {
 					if (!found && (el & (1u << l)) == 0) {
-						if (r < sp[l]) { j = l; found = true; }
-						else r -= sp[l];
+						if (r < (uint32_t)sp[l]) { j = l; found = true; }
+						else r -= (uint32_t)sp[l];
 					}
 				}
 			} else {
 				j = L.elcint;                                     /* the only eligible target: no draw (:820-834) */
 			}
 			/* a child of a position in the text stands on the same anchor, one position further */
-			const uint32_t bttop = locTarget ? L.top : bt_sel4(j, tp[0], tp[1], tp[2], tp[3]);
-			const uint32_t btbot = bttop + bt_sel4(j, sp[0], sp[1], sp[2], sp[3]);
+			const bt_row bttop = locTarget ? L.top : bt_selr4(j, tp[0], tp[1], tp[2], tp[3]);
+			const bt_row btbot = bttop + bt_selr4(j, sp[0], sp[1], sp[2], sp[3]);
 			const uint32_t btham = L.ham + bt_mm_penalty(L.maq, qi);
 			const uint32_t btcint = j;
 			L.pel = el;
@@ -1273,7 +1343,8 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_GOTO_RA(L.sd + 1u, bttop, btbot, btham, RC_CHILD, locTarget);
 				break;
 			}
-			uint32_t newDepth = i + 1u, ntop = bttop, nbot = btbot;
+			uint32_t newDepth = i + 1u;
+			bt_row ntop = bttop, nbot = btbot;
 			bool childLoc = locTarget;
 			const bool rootNoFtab = (L.sd == 0) && L.nsFtab0;
 			const uint32_t ftabChars = WSEL(ftabChars);
@@ -1286,10 +1357,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 					if (L.qlen - 1u - jj == icur) c = btcint;
 					ftabOff |= c << (2u * jj);
 				}
-				const uint32_t* ftab = WSEL(ftab); const uint32_t* eftab = IXSEL(eftab); const uint32_t len = WSEL(len);
-				ntop = BT_GP(const uint32_t, ftab)[ftabOff]; nbot = BT_GP(const uint32_t, ftab)[ftabOff + 1u];
-				if (ntop > len) ntop = BT_GP(const uint32_t, eftab)[(ntop ^ BT_OFF_MASK) * 2u + 1u];
-				if (nbot > len) nbot = BT_GP(const uint32_t, eftab)[(nbot ^ BT_OFF_MASK) * 2u];
+				const bt_row* ftab = WSEL(ftab); const bt_row* eftab = IXSEL(eftab); const bt_row len = BT_WROWLIM();
+				ntop = BT_GP(const bt_row, ftab)[ftabOff]; nbot = BT_GP(const bt_row, ftab)[ftabOff + 1u];
+				if (ntop > len) ntop = BT_GP(const bt_row, eftab)[(ntop ^ BT_OFF_MASK) * 2u + 1u];
+				if (nbot > len) nbot = BT_GP(const bt_row, eftab)[(nbot ^ BT_OFF_MASK) * 2u];
 				BT_COUNT(CN_FTAB);
 				if (ntop == nbot) { L.ret = 0; L.state = ST_CHILD_RET; break; }
 				newDepth = ftabChars;
@@ -1399,17 +1470,17 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 	{
 		BT_PROF_TICK(PS_RUN_ITERS);
 		BT_PROF_T0(t_resume);
-		if (RL && (L.state == ST_LOC_REC || L.state == ST_LOC_TXT)) {
+		if (BT_LOC(RL) && (L.state == ST_LOC_REC || L.state == ST_LOC_TXT)) {
 			if (L.state == ST_LOC_REC) {
 				/* the row's locus record: from here on the frame stands on a place in the text, not on a row */
 				L.lmode = 1; L.dcf = L.d;
 				L.top = res.q[0].x + L.d; L.bot = L.top + 1u;
 				wkind = 1;
 			} else wkind = 2;
-			wd0 = L.d; wanchor = L.top;
+			wd0 = L.d; wanchor = (uint32_t)L.top;
 			L.state = ST_STEP_BEGIN;
 		}
-		if (RL && L.state == ST_STEP_BEGIN && L.lmode) {
+		if (BT_LOC(RL) && L.state == ST_STEP_BEGIN && L.lmode) {
 			/* ---- locus mode: the next event of the frame (see "locus mode: the pieces") ------------------------ */
 			BT_PROF_T0(t_locus);
 			BT_PROF_TICK(PS_LOCUS_PASSES);
@@ -1418,7 +1489,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			else if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else if (bt_ent(L, d) >= S.a->entCap) L.state = ST_ABORT;
 			else {
-				const uint32_t anchor = L.top, len = WSEL(len);
+				const uint32_t anchor = (uint32_t)L.top, len = (uint32_t)WSEL(len);
 				const uint32_t y0 = len - anchor + wd0;                 /* first character of a kind-2 window in the reversed text */
 				const uint32_t sh = wkind == 2 ? (y0 & 15u) : 0u;
 				const uint32_t ncov = wkind == 2 ? 128u - sh : BT_LOC_CTX;
@@ -1505,16 +1576,16 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 		}
 		/* ---- resume: SA walk (reportChaseOne, ebwt.h:2727-2746) --------------------------- */
 		if (L.state == ST_CHASE_LFDONE) {
-			L.crow = bt_u4_word(res.q[0], res.q[2].x);                  /* mapLF(l) */
+			L.crow = bt_res_lfa(res, BT_RES_ROWL(res));                 /* mapLF(l) */
 			L.cjumps++;
 			L.state = ST_CHASE_CHECK;
 		}
 		/* ---- resume: one query position (:456-739) ---------------------------------------- */
-		if (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST || (RL && L.state == ST_STEP_LOC)) {
+		if (L.state == ST_STEP_LFDONE || L.state == ST_STEP_POST || (BT_LOC(RL) && L.state == ST_STEP_LOC)) {
 			const uint32_t c = L.c, q = L.q, d = L.d, cur = L.qlen - d - 1u;
 			const uint32_t e = bt_ent(L, d);
-			uint32_t ta[4], tb[4];
-			const bool wasLoc = RL && L.state == ST_STEP_LOC;
+			bt_row ta[4], tb[4];
+			const bool wasLoc = BT_LOC(RL) && L.state == ST_STEP_LOC;
 			if (wasLoc) {
 				/* decided by the text: the quartet of a one-row range -- the text's base has the one row that goes with it,
 				 * the other three ranges are empty (all four at the text's start); nothing is kept of it but the record */
@@ -1523,24 +1594,22 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				for (uint32_t k = 0; k < 4u; k++) { ta[k] = 0; tb[k] = (k == t && !L.lz) ? 1u : 0u; }
 				L.bot = locMiss ? L.top : L.top + 1u;
 			} else if (L.state == ST_STEP_LFDONE) {
-				if (!RL && L.wpf) {
+				if (!BT_WIDE && !RL && L.wpf) {
 					L.cs0 = res.q[3].x; L.cs1 = res.q[3].y; L.cs2 = res.q[3].z; L.cs3 = res.q[3].w;
 					L.cq0 = res.x.x; L.cq1 = res.x.y; L.cq2 = res.x.z; L.cq3 = res.x.w;
 					L.cchunk = L.scanCb; L.wpf = 0;
 				}
-				ta[0] = res.q[0].x; ta[1] = res.q[0].y; ta[2] = res.q[0].z; ta[3] = res.q[0].w;
-				tb[0] = res.q[1].x; tb[1] = res.q[1].y; tb[2] = res.q[1].z; tb[3] = res.q[1].w;
-				const uint32_t ac = bt_sel4(c & 3u, ta[0], ta[1], ta[2], ta[3]);
-				const uint32_t bc = bt_sel4(c & 3u, tb[0], tb[1], tb[2], tb[3]);
+				bt_res_quartets(res, ta, tb);
+				const bt_row ac = bt_selr4(c & 3u, ta[0], ta[1], ta[2], ta[3]);
+				const bt_row bc = bt_selr4(c & 3u, tb[0], tb[1], tb[2], tb[3]);
 				if (L.lfk == LFK_EX2) {
-					bt_st4(PT4(e), res.q[0]);
-					bt_st4(PB4(e), res.q[1]);
+					BT_STORE_ENTRY(e, res);
 					if (c < 4u) { L.top = ac; L.bot = bc; }
 				} else if (L.lfk == LFK_C2) {
 					L.top = ac; L.bot = bc;
 				} else {
 					/* mapLF1 (ebwt.h:2494-2512) */
-					if (res.q[2].x != c || L.top == WSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
+					if (BT_RES_ROWL(res) != c || L.top == WSEL(zOff)) { L.top = BT_OFF_MASK; L.bot = BT_OFF_MASK; }
 					else { L.top = ac; L.bot = ac + 1u; }
 				}
 			} else {
@@ -1568,11 +1637,11 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 					/* deepest eligible target so far; its ranges go to the LDS candidate slot so that
 					 * choosing it later costs no fetch */
 					L.cand = d; L.candValid = 1;
-					if (!S.noCC) {
+					if (!BT_WIDE && !S.noCC) {
 						L.ccValid = 1;
 						const uint32_t ts = S.tosStride;
 						BT_UNROLL
-						for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = ta[k]; S.tos[(4u + k) * ts] = tb[k]; }
+						for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = (uint32_t)ta[k]; S.tos[(4u + k) * ts] = (uint32_t)tb[k]; }
 						S.tos[8u * ts] = el | (q << 8);
 					}
 				}
@@ -1607,7 +1676,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			else if (cur == 0 && L.bot > L.top && !invalidHH && !invalidExact && !reportedPartial)
 				BT_GOTO_RA(L.sd, L.top, L.bot, L.ham, RC_STEP, L.lmode);
 			else if ((L.top == L.bot || btDespite) && L.altNum > 0) {
-				if (!(RL && wasLoc && locMiss && L.fl_elig && !L.lz && L.top == L.bot && bt_loc_descend<RL>(L, P, W, S, CNT))) L.state = ST_BT_LOOP;
+				if (!(BT_LOC(RL) && wasLoc && locMiss && L.fl_elig && !L.lz && L.top == L.bot && bt_loc_descend<RL>(L, P, W, S, CNT))) L.state = ST_BT_LOOP;
 			}
 			else if (mustBacktrack || invalidHH || invalidExact || L.top == L.bot) { L.ret = 0; L.state = ST_FRAME_RETURN; }
 			else { L.d = d + 1u; L.state = ST_STEP_BEGIN; }
@@ -1624,14 +1693,14 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 
 		/* ---- emit: next query position (:456-568) -------------------------------------------- */
 		if (L.state == ST_STEP_BEGIN) {
-			if (RL && L.lmode) {
+			if (BT_LOC(RL) && L.lmode) {
 				/* a frame in locus mode that goes on (a child just entered, a boundary passed): its next event is found when
 				 * the text for it arrives -- one window per call.  Going round this loop again with the window at hand would
 				 * save the lane a round and cost its wavefront a trip through everything (scripts/pass_model.py: the
 				 * wavefront's trips per round are its slowest lane's) */
 				const uint32_t d = L.d;
 				if (d >= L.qlen) { L.state = ST_FELL_OFF; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
-				const uint32_t y = WSEL(len) - L.top + d;
+				const uint32_t y = (uint32_t)(WSEL(len) - L.top) + d;
 				BT_REQ_FETCH(WSEL(rtxt) + (y >> 4), ((y & 15u) + (L.qlen - d) + 63u) >> 6, nullptr);
 				L.state = ST_LOC_TXT;
 				BT_COUNT_HOST(CN_FETCH);
@@ -1641,7 +1710,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			if (d >= L.qlen) { L.state = ST_FELL_OFF; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
 			if (L.halfAndHalf && !bt_hh_check_top(L, S, d)) { L.ret = 0; L.state = ST_FRAME_RETURN; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
 			if (L.ebase + (d - L.depth) >= S.a->entCap) { L.state = ST_ABORT; return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */ }
-			if (RL && W.locOn && !L.hasN && L.top + 1u == L.bot) {
+			if (BT_LOC(RL) && W.locOn && !L.hasN && L.top + 1u == L.bot) {
 				/* the range is one row: leave row space (its locus record: where the row's suffix is in the text, and the
 				 * 48 characters to the left of it).  Reads with an N stay in row space: an N never matches, which the packed
 				 * comparison does not know */
@@ -1670,15 +1739,15 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				} else elig = true;
 			}
 			L.fl_alt = alt; L.fl_elig = elig; L.fl_over = over;
-			const uint32_t rtop = L.top, rbot = L.bot;
+			const bt_row rtop = L.top, rbot = L.bot;
 			if (c == 4u && d > 0) { L.top = 1; L.bot = 1; }
 			if (rtop == 0 && rbot == 0) {
 				/* depth 0: the fchr quartet (:531-543) */
 				const uint32_t e = L.ebase + (d - L.depth);
-				const uint32_t f0 = HFCHR(0), f1 = HFCHR(1), f2 = HFCHR(2), f3 = HFCHR(3), f4 = HFCHR(4);
-				{ BtU4 v; v.x = f0; v.y = f1; v.z = f2; v.w = f3; bt_st4(PT4(e), v); }
-				{ BtU4 v; v.x = f1; v.y = f2; v.z = f3; v.w = f4; bt_st4(PB4(e), v); }
-				if (c < 4u) { L.top = bt_sel4(c, f0, f1, f2, f3); L.bot = bt_sel4(c, f1, f2, f3, f4); }
+				const bt_row f0 = HFCHR(0), f1 = HFCHR(1), f2 = HFCHR(2), f3 = HFCHR(3), f4 = HFCHR(4);
+				bt_store_quartet(PT4(e), f0, f1, f2, f3);
+				bt_store_quartet(PB4(e), f1, f2, f3, f4);
+				if (c < 4u) { L.top = bt_selr4(c, f0, f1, f2, f3); L.bot = bt_selr4(c, f1, f2, f3, f4); }
 				L.state = ST_STEP_POST;
 				return;        /* (the lane goes on in the next round's pass: see the note at the head of the loop) */
 			} else if (alt || c < 4u) {
@@ -1688,7 +1757,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				/* the next position (d+1) leaves the 16-base window: fetch the neighbouring chunk with
 				 * this round's rank request instead of spending a round on it */
 				L.wpf = 0;
-				if (!RL && d + 1u < L.qlen) {
+				if (!BT_WIDE && !RL && d + 1u < L.qlen) {
 					const uint32_t i2 = L.qlen - d - 2u, j2 = L.rev ? (L.plen - 1u - i2) : i2;
 					if ((j2 >> 4) != L.cchunk) { req.wchunk = j2 >> 4; L.scanCb = j2 >> 4; L.wpf = 1; }
 				}
@@ -1701,7 +1770,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 		}
 		/* ---- emit: next SA-walk step, or the SA sample once the walk has arrived ---------------- */
 		if (L.state == ST_CHASE_CHECK) {
-			if (W.locOn) {
+			if (!BT_WIDE && W.locOn) {
 				/* the dense suffix array: the row's locus record instead of the walk to a sampled row */
 				BT_REQ_FETCH(WSEL(loc) + L.crow, 1, nullptr);
 				L.state = ST_RESOLVE_DONE;
@@ -1714,8 +1783,8 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 			}
 			L.state = ST_RESOLVE_DONE;
 			if (L.crow != WSEL(zOff)) {
-				const uint32_t* offs = WSEL(offs);
-				BT_REQ_FETCH(offs + ((L.crow >> WSEL(offRate)) & ~3u), 1, nullptr);
+				const bt_row* offs = WSEL(offs);
+				BT_REQ_FETCH(offs + ((L.crow >> WSEL(offRate)) & ~(bt_row)(BT_PIECE_ROWS - 1u)), 1, nullptr);
 				BT_COUNT_HOST(CN_FETCH);
 				return;
 			}

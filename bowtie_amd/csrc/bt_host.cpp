@@ -3,7 +3,11 @@
  */
 #include "bt_host.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#if BT_WIDE
+#include <thread>
+#endif
 
 namespace {
 struct File {
@@ -43,13 +47,30 @@ struct Reader {
 		if (!f.rd(&v, 8)) ok = false;
 		return swap ? __builtin_bswap64(v) : v;
 	}
-	/* n offsets -> u32 (eftab references in ftab are ~k in the file's width: the low word is ~k) */
-	bool offs(std::vector<uint32_t>& out, uint64_t n, bool check) {
+	/* n offsets -> rows of this build's width.  Narrow build: eftab references in ftab are ~k in the file's width, the low
+	 * word is ~k.  Wide build from a 32-bit file: ~k of 32 bits becomes ~k of 64 (`codes`: the array is ftab) */
+	bool offs(std::vector<bt_row>& out, uint64_t n, bool check, bool codes = false, uint64_t lenForCodes = 0) {
 		out.resize((size_t)n);
 		if (!wide) {
+#if BT_WIDE
+			std::vector<uint32_t> buf((size_t)(n < (1u << 20) ? n : (1u << 20)));
+			for (uint64_t i = 0; i < n; ) {
+				const uint64_t m = n - i < buf.size() ? n - i : buf.size();
+				if (!f.rd(buf.data(), 4ull * m)) return ok = false;
+				for (uint64_t k = 0; k < m; k++) {
+					const uint32_t v = swap ? __builtin_bswap32(buf[(size_t)k]) : buf[(size_t)k];
+					out[(size_t)(i + k)] = (codes && v > lenForCodes) ? (0xffffffff00000000ull | v) : (uint64_t)v;
+				}
+				i += m;
+			}
+			(void)check;
+			return true;
+#else
+			(void)codes; (void)lenForCodes;
 			if (!f.rd(out.data(), 4ull * n)) return ok = false;
 			if (swap) for (auto& v : out) v = __builtin_bswap32(v);
 			return true;
+#endif
 		}
 		std::vector<uint64_t> buf((size_t)(n < (1u << 20) ? n : (1u << 20)));
 		for (uint64_t i = 0; i < n; ) {
@@ -57,8 +78,12 @@ struct Reader {
 			if (!f.rd(buf.data(), 8ull * m)) return ok = false;
 			for (uint64_t k = 0; k < m; k++) {
 				const uint64_t v = swap ? __builtin_bswap64(buf[(size_t)k]) : buf[(size_t)k];
+#if BT_WIDE
+				out[(size_t)(i + k)] = v;
+#else
 				if (check && (v >> 32) != 0 && (v >> 32) != 0xffffffffull) narrow = false;
 				out[(size_t)(i + k)] = (uint32_t)v;
+#endif
 			}
 			i += m;
 		}
@@ -78,6 +103,91 @@ struct SrcBwt {
 	}
 };
 
+#if BT_WIDE
+/* The wide build's rank blocks (bt_rank.h), straight from the file's BWT: rows 0 .. len, '$' (row zOff, stored as an A) not
+ * counted.  One pass over the BWT makes the bit planes and per-chunk counts (threads), a prefix sum over the chunks the
+ * segment table, a second pass over the blocks their counters, relative to their segment's start.  fchrB: fchr + rowBias. */
+void build_blocks(const SrcBwt& src, uint64_t len, uint64_t zOff, const bt_row fchrB[5], uint32_t segShift,
+                  std::vector<uint8_t>* blk, std::vector<uint64_t>* segBase)
+{
+	const uint64_t nb = bt_blk_count(len), nRows = len + 1u;
+	blk->assign((size_t)(nb * BT_BLK_BYTES), 0);
+	const uint32_t chunkShift = segShift < 14u ? segShift : 14u;          /* blocks per chunk: at most a segment */
+	const uint64_t nChunks = (nb + (1ull << chunkShift) - 1u) >> chunkShift;
+	std::vector<uint64_t> cc((size_t)nChunks * 4u, 0);                      /* symbol counts per chunk */
+	unsigned nt = std::thread::hardware_concurrency();
+	if (const char* e = getenv("BT_LOAD_THREADS")) nt = (unsigned)atoi(e);
+	if (nt < 1) nt = 1;
+	if (nt > 64) nt = 64;
+	if ((uint64_t)nt > nChunks) nt = (unsigned)nChunks;
+	auto planes = [&](unsigned t) {
+		for (uint64_t ch = t; ch < nChunks; ch += nt) {
+			uint64_t cnt[4] = {0, 0, 0, 0};
+			const uint64_t b0 = ch << chunkShift, b1 = (b0 + (1ull << chunkShift)) < nb ? b0 + (1ull << chunkShift) : nb;
+			for (uint64_t b = b0; b < b1; b++) {
+				uint64_t p0 = 0, p1 = 0;
+				for (uint32_t i = 0; i < BT_BLK_ROWS; i++) {
+					const uint64_t row = b * BT_BLK_ROWS + i;
+					if (row >= nRows) break;
+					const uint32_t c = src.sym(row);
+					p0 |= (uint64_t)(c & 1u) << i; p1 |= (uint64_t)(c >> 1) << i;
+					if (row != zOff) cnt[c]++;
+				}
+				uint32_t w[4] = {(uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32)};
+				memcpy(blk->data() + b * BT_BLK_BYTES + 16, w, 16);
+			}
+			for (int c = 0; c < 4; c++) cc[(size_t)ch * 4u + c] = cnt[c];
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		for (unsigned t = 1; t < nt; t++) th.emplace_back(planes, t);
+		planes(0);
+		for (auto& x : th) x.join();
+	}
+	/* chunk starts (absolute counts) and the segment table */
+	const uint64_t nSeg = ((nb - 1u) >> segShift) + 1u;
+	segBase->assign((size_t)nSeg * 4u, 0);
+	std::vector<uint64_t> start((size_t)nChunks * 4u, 0);
+	{
+		uint64_t run[4] = {0, 0, 0, 0};
+		for (uint64_t ch = 0; ch < nChunks; ch++) {
+			for (int c = 0; c < 4; c++) start[(size_t)ch * 4u + c] = run[c];
+			if (((ch << chunkShift) & ((1ull << segShift) - 1u)) == 0)
+				for (int c = 0; c < 4; c++) (*segBase)[(size_t)((ch << chunkShift) >> segShift) * 4u + c] = fchrB[c] + run[c];
+			for (int c = 0; c < 4; c++) run[c] += cc[(size_t)ch * 4u + c];
+		}
+	}
+	auto counters = [&](unsigned t) {
+		for (uint64_t ch = t; ch < nChunks; ch += nt) {
+			const uint64_t b0 = ch << chunkShift, b1 = (b0 + (1ull << chunkShift)) < nb ? b0 + (1ull << chunkShift) : nb;
+			const uint64_t seg = b0 >> segShift;
+			uint64_t run[4];
+			for (int c = 0; c < 4; c++) run[c] = fchrB[c] + start[(size_t)ch * 4u + c] - (*segBase)[(size_t)seg * 4u + c];
+			for (uint64_t b = b0; b < b1; b++) {
+				uint32_t w[4] = {(uint32_t)run[0], (uint32_t)run[1], (uint32_t)run[2], (uint32_t)run[3]};
+				memcpy(blk->data() + b * BT_BLK_BYTES, w, 16);
+				uint32_t pw[4];
+				memcpy(pw, blk->data() + b * BT_BLK_BYTES + 16, 16);
+				const uint64_t p0 = ((uint64_t)pw[1] << 32) | pw[0], p1 = ((uint64_t)pw[3] << 32) | pw[2];
+				const uint64_t first = b * BT_BLK_ROWS;
+				const uint32_t valid = first >= nRows ? 0u : (nRows - first >= BT_BLK_ROWS ? BT_BLK_ROWS : (uint32_t)(nRows - first));
+				const uint64_t m = valid >= 64u ? ~0ull : ((1ull << valid) - 1ull);
+				const uint64_t cT = (uint64_t)__builtin_popcountll(p0 & p1 & m), cLo = (uint64_t)__builtin_popcountll(p0 & m), cHi = (uint64_t)__builtin_popcountll(p1 & m);
+				uint64_t cA = valid - cLo - cHi + cT;
+				if (zOff >= first && zOff < first + valid) cA--;
+				run[0] += cA; run[1] += cLo - cT; run[2] += cHi - cT; run[3] += cT;
+			}
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		for (unsigned t = 1; t < nt; t++) th.emplace_back(counters, t);
+		counters(0);
+		for (auto& x : th) x.join();
+	}
+}
+#else
 void repack_sides(const SrcBwt& src, uint64_t srcRows, uint32_t zOff, uint32_t len, std::vector<uint8_t>* out)
 {
 	const uint32_t bwtSz = len / 4u + 1u;
@@ -103,6 +213,8 @@ void repack_sides(const SrcBwt& src, uint64_t srcRows, uint32_t zOff, uint32_t l
 		}
 	}
 }
+
+#endif /* BT_WIDE */
 
 const char* const kExt[4] = {"bt2", "ebwt", "bt2l", "ebwtl"};
 }  // namespace
@@ -144,20 +256,25 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 	if (bt2) h.linesPerSide = 1;                                       /* EbwtParams::init ebwt.h:149 */
 	if (h.lineRate != wantLine || h.linesPerSide != 1 || h.ftabChars < 1 || h.ftabChars > 15 ||
 	    h.offRate < 0 || h.offRate > 31) return BT_ERR_FORMAT;
-	if (len64 == 0 || len64 >= 0xffffffffull) return BT_ERR_FORMAT;    /* device rows are 32-bit */
-	h.len = (uint32_t)len64;
+#if BT_WIDE
+	if (len64 == 0 || len64 >= (1ull << 38)) return BT_ERR_FORMAT;     /* block numbers are 32-bit */
+#else
+	if (len64 == 0) return BT_ERR_FORMAT;
+	if (len64 >= 0xffffffffull) return BT_ERR_ROWS64;                  /* this build's rows are 32-bit: libbowtie_amd_l.so */
+#endif
+	h.len = (bt_row)len64;
 	h.wide = wide; h.bt2 = bt2; h.swapped = R.swap;
 	const uint32_t offSize = wide ? 8u : 4u;
 	const uint32_t srcSideSz = 1u << h.lineRate;
 	const uint32_t srcSideBwtSz = srcSideSz - (bt2 ? 4u : 2u) * offSize;
-	const uint32_t bwtLen = h.len + 1u;
-	const uint32_t bwtSz = h.len / 4u + 1u;
+	const uint64_t bwtLen = len64 + 1u;
+	const uint64_t bwtSz = len64 / 4u + 1u;
 	uint64_t srcTotLen;
 	if (bt2) srcTotLen = (uint64_t)((bwtSz + srcSideBwtSz - 1u) / srcSideBwtSz) * srcSideSz;
 	else     srcTotLen = (uint64_t)((bwtSz + 2u * srcSideBwtSz - 1u) / (2u * srcSideBwtSz)) * (2u * srcSideSz);
 	const uint32_t ftabLen = (1u << (2 * h.ftabChars)) + 1u;
 	const uint32_t eftabLen = 2u * (uint32_t)h.ftabChars;
-	const uint32_t offsLen = (uint32_t)(((uint64_t)bwtLen + (1ull << h.offRate) - 1ull) >> h.offRate);
+	const uint64_t offsLen = (bwtLen + (1ull << h.offRate) - 1ull) >> h.offRate;
 	const uint64_t nPat = R.off();
 	if (!R.ok) return BT_ERR_IO;
 	if (nPat == 0 || nPat > h.len) return BT_ERR_FORMAT;
@@ -169,7 +286,11 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 	h.nFrag = (uint32_t)nFrag;
 	if (!R.offs(h.rstarts, 3ull * nFrag, true)) return BT_ERR_IO;
 	std::vector<uint8_t> src;
+#if BT_WIDE
+	std::vector<uint8_t>& raw = src;
+#else
 	std::vector<uint8_t>& raw = (!wide && !bt2) ? h.ebwt : src;
+#endif
 	raw.resize((size_t)srcTotLen);
 	if (!f1.rd(raw.data(), (size_t)srcTotLen)) return BT_ERR_IO;
 	if (R.swap && !wide && !bt2) {
@@ -187,18 +308,39 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 	for (int i = 0; i < 5; i++) fchr[i] = R.off();
 	if (!R.ok) return BT_ERR_IO;
 	if (zOff > h.len || fchr[4] != h.len) return BT_ERR_FORMAT;
-	for (int i = 0; i < 5; i++) { if (fchr[i] > h.len || (i && fchr[i] < fchr[i - 1])) return BT_ERR_FORMAT; h.fchr[i] = (uint32_t)fchr[i]; }
-	h.zOff = (uint32_t)zOff;
-	if (!R.offs(h.ftab, ftabLen, false) || !R.offs(h.eftab, eftabLen, true)) return BT_ERR_IO;
+	for (int i = 0; i < 5; i++) { if (fchr[i] > h.len || (i && fchr[i] < fchr[i - 1])) return BT_ERR_FORMAT; h.fchr[i] = (bt_row)fchr[i]; }
+	h.zOff = (bt_row)zOff;
+	if (!R.offs(h.ftab, ftabLen, false, true, len64) || !R.offs(h.eftab, eftabLen, true)) return BT_ERR_IO;
 	if (!R.narrow) return BT_ERR_FORMAT;
+#if BT_WIDE
+	{
+		/* the test knobs (bt_host.h): rows numbered from a bias, small segments */
+		if (const char* e = getenv("BT_WIDE_SEG_SHIFT")) { const long v = atol(e); if (v >= 2 && v <= 25) h.segShift = (uint32_t)v; }
+		if (const char* e = getenv("BT_WIDE_ROW_BIAS")) {
+			const uint64_t b = strtoull(e, nullptr, 0);
+			if ((b & ((1ull << (h.segShift + 6u)) - 1u)) != 0 || (b & ((1ull << h.offRate) - 1u)) != 0 || b >= (1ull << 37)) return BT_ERR_ARG;
+			h.rowBias = b;
+		}
+		const uint64_t B = h.rowBias;
+		for (int i = 0; i < 5; i++) h.fchr[i] += B;
+		h.zOff += B;
+		for (auto& v : h.ftab) if (v <= len64) v += B;
+		for (auto& v : h.eftab) v += B;
+		SrcBwt sb{src.data(), srcSideSz, srcSideBwtSz, bt2};
+		build_blocks(sb, len64, zOff, h.fchr, h.segShift, &h.blk, &h.segBase);
+		std::vector<uint8_t>().swap(src);
+		h.lineRate = 6;
+	}
+#else
 	if (wide || bt2) {
 		SrcBwt sb{src.data(), srcSideSz, srcSideBwtSz, bt2};
 		repack_sides(sb, bwtLen, h.zOff, h.len, &h.ebwt);
 		h.lineRate = 6;
 	}
+#endif
 	/* fragments must tile the joined text in order (joinedToTextOff's binary search, ebwt.h:2569-2629) */
 	for (uint32_t i = 0; i < h.nFrag; i++) {
-		const uint32_t lo = h.rstarts[3 * i], up = i + 1 < h.nFrag ? h.rstarts[3 * i + 3] : h.len;
+		const bt_row lo = h.rstarts[3 * i], up = i + 1 < h.nFrag ? h.rstarts[3 * i + 3] : h.len;
 		if (lo >= up || up > h.len || h.rstarts[3 * i + 1] >= h.nPat) return BT_ERR_FORMAT;
 	}
 	/* reference names: '\n'-separated, '\0'-terminated (ebwt.h:3452-3531) */
@@ -217,15 +359,15 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 	if (!f2.rd(&one, 4)) return BT_ERR_IO;
 	if (one != (R.swap ? (1u << 24) : 1u)) return BT_ERR_FORMAT;
 	Reader R2{f2, R.swap, wide};
-	std::vector<uint32_t> offs;
+	std::vector<bt_row> offs;
 	if (!R2.offs(offs, offsLen, true)) return BT_ERR_IO;
 	if (!R2.narrow) return BT_ERR_FORMAT;
 	if (offrate_override > h.offRate && offrate_override < 32) {
 		const uint32_t diff = (uint32_t)(offrate_override - h.offRate);
-		uint32_t sampled = offsLen >> diff;
-		if ((offsLen & ~(0xffffffffu << diff)) != 0) sampled++;
-		h.offs.resize(sampled);
-		for (uint32_t i = 0, idx = 0; i < offsLen; i += (1u << diff)) h.offs[idx++] = offs[i];
+		uint64_t sampled = offsLen >> diff;
+		if ((offsLen & ~(~0ull << diff)) != 0) sampled++;
+		h.offs.resize((size_t)sampled);
+		for (uint64_t i = 0, idx = 0; i < offsLen; i += (1ull << diff)) h.offs[(size_t)idx++] = offs[(size_t)i];
 		h.offRate = offrate_override;
 	} else {
 		h.offs.swap(offs);
@@ -237,20 +379,36 @@ void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d)
 {
 	memset(d, 0, sizeof(*d));
 	d->len = h.len; d->zOff = h.zOff; d->ftabChars = (uint32_t)h.ftabChars;
-	d->offRate = (uint32_t)h.offRate; d->offMask = 0xffffffffu << h.offRate;
+	d->offRate = (uint32_t)h.offRate; d->offMask = (bt_row)BT_OFF_MASK << h.offRate;
 	d->nFrag = h.nFrag; d->nPat = h.nPat; d->fw = h.fw ? 1u : 0u; d->wide = h.wide ? 1u : 0u;
 	for (int i = 0; i < 5; i++) d->fchr[i] = h.fchr[i];
 	/* postReadInit (ebwt.h:1043-1059), restated as (side, storage-symbol) of '$' */
-	d->zSide = h.zOff / 224u;
-	const uint32_t co = h.zOff % 224u;
+	d->zSide = (uint32_t)(h.zOff / 224u);
+	const uint32_t co = (uint32_t)(h.zOff % 224u);
 	d->zSym = (d->zSide & 1u) ? co : (223u - co);
-	d->zBlk = h.zOff / BT_BLK_ROWS; d->zPos = h.zOff % BT_BLK_ROWS;
+	d->zBlk = (uint32_t)(h.zOff / BT_BLK_ROWS); d->zPos = (uint32_t)(h.zOff % BT_BLK_ROWS);
+#if BT_WIDE
+	d->segShift = h.segShift; d->rowLim = h.len + h.rowBias;
+#endif
 }
 
 void bt_host_restore_text(const BtIndexHost& h, uint8_t* out)
 {
 	BtIndexDev d;
 	bt_host_index_describe(h, &d);
+#if BT_WIDE
+	d.blk = h.blk.data(); d.segBase = h.segBase.data();
+	bt_host_index_bias(h, &d);
+	bt_row i = d.rowLim, jumps = 0;           /* the row of the suffix "$" (sorts last) */
+	while (i != h.zOff && jumps < h.len) {
+		bt_row lf[4]; uint32_t L;
+		bt_rank4(d, i, lf, &L);
+		out[h.len - 1u - jumps] = (uint8_t)L;
+		i = lf[L];
+		jumps++;
+	}
+}
+#else
 	std::vector<uint8_t> padded(h.ebwt);
 	padded.resize(padded.size() + 128);
 	d.ebwt = padded.data();
@@ -263,6 +421,7 @@ void bt_host_restore_text(const BtIndexHost& h, uint8_t* out)
 		jumps++;
 	}
 }
+#endif
 
 /* ---- phase programs ------------------------------------------------------------------------ */
 static BtStep mk(bool mirror, bool readFw, int kind, bool re, bool cq, bool hh, bool maq, int rp,
@@ -393,6 +552,11 @@ struct TreeBuilder {
 };
 }
 
+#if BT_WIDE
+int bt_host_compile_best(const bt_policy&, BfProgram*) { return BT_ERR_UNSUPPORTED; }
+int bt_host_compile_best_paired(const bt_policy&, BfProgram*) { return BT_ERR_UNSUPPORTED; }
+int bt_host_ref_load(const std::string&, const BtIndexHost&, BtRefHost*, int) { return BT_ERR_UNSUPPORTED; }
+#else
 /* the drivers of one (mate, strand) block, in the order the factories push them.  `paired` selects
  * the Paired*AlignerFactory variants, which differ from the unpaired ones in two places: the
  * nudgeLeft flags of -v 1 (aligner_1mm.h:295-408) and rev1Off of the -v 3 half-and-half driver
@@ -572,3 +736,4 @@ int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost*
 	if ((uint64_t)(t + 1) != nRefs) return BT_ERR_FORMAT;
 	return BT_OK;
 }
+#endif /* !BT_WIDE */

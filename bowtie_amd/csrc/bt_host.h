@@ -15,18 +15,42 @@
 /* One index (text or mirror) parsed into host memory.  Field order and geometry follow
  * Ebwt::readIntoMemory (ebwt.h:2926-3421) and EbwtParams::init (ebwt.h:138-184). */
 struct BtIndexHost {
-	uint32_t len = 0, nPat = 0, nFrag = 0, zOff = 0;
+	bt_row   len = 0, zOff = 0;
+	uint32_t nPat = 0, nFrag = 0;
 	int32_t  lineRate = 0, linesPerSide = 0, offRate = 0, ftabChars = 0, flags = 0;
-	uint32_t fchr[5] = {0, 0, 0, 0, 0};
+	bt_row   fchr[5] = {0, 0, 0, 0, 0};
 	bool     fw = true;
 	bool     wide = false;      /* came from a 64-bit (.ebwtl/.bt2l) build: see BtIndexDev::wide         */
 	bool     bt2 = false;       /* came in bowtie2-build's side layout                                  */
 	bool     swapped = false;   /* was written on a machine of the other byte order                      */
 	std::vector<uint8_t>  ebwt;
-	std::vector<uint32_t> plen, rstarts, ftab, eftab, offs;
+	std::vector<bt_row> plen, rstarts, ftab, eftab, offs;
 	std::vector<std::string> refnames;
 	uint64_t ebwtTotLen() const { return ebwt.size(); }
+#if BT_WIDE
+	/* The wide build (64-bit BWT rows; bt_rank.h, "the row type") keeps no side layout: its loader derives the rank blocks
+	 * and their segment table straight from the file's BWT, whatever the variant.
+	 * rowBias (tests; BT_WIDE_ROW_BIAS, a multiple of 2^(segShift+6) and of 2^offRate): every BWT row of the image is numbered
+	 * rowBias higher than in the files -- fchr, zOff, the ftab / eftab entries and the segment table carry it, and whoever
+	 * binds the arrays to a BtIndexDev shifts the pointers of the row-indexed ones back by it (bt_host_index_bias) -- so that
+	 * a genome of a few Mbp exercises row arithmetic above 2^32 (with BT_WIDE_SEG_SHIFT, blocks per segment log2, also the
+	 * segments).  Text offsets are not biased.  Results are those of the unbiased index. */
+	std::vector<uint8_t>  blk;
+	std::vector<uint64_t> segBase;
+	uint32_t segShift = BT_SEG_SHIFT_DEFAULT;
+	uint64_t rowBias = 0;
+#endif
 };
+#if BT_WIDE
+/* after the pointers of a BtIndexDev were set to the start of the arrays: account for h.rowBias */
+inline void bt_host_index_bias(const BtIndexHost& h, BtIndexDev* d)
+{
+	const uint64_t bb = h.rowBias / BT_BLK_ROWS;
+	d->blk = (const uint8_t*)((uintptr_t)d->blk - (uintptr_t)(bb * BT_BLK_BYTES));
+	d->segBase = (const uint64_t*)((uintptr_t)d->segBase - (uintptr_t)((bb >> h.segShift) * 32u));
+	d->offs = (const bt_row*)((uintptr_t)d->offs - (uintptr_t)((h.rowBias >> h.offRate) * sizeof(bt_row)));
+}
+#endif
 
 /* Returns BT_OK or BT_ERR_*.  offrate_override (>= index offRate) subsamples offs[] the way
  * -o does (ebwt.h:2988-3001, 3301-3327); -1 keeps the index's own rate. */
@@ -52,6 +76,7 @@ int bt_host_compile_program(const bt_policy& pol, BtProgram* prog);
 
 /* The same for the stateful best-first workers (pol.best): the driver tree of
  * Unpaired{Exact,1mm,23mm,Seed}AlignerFactory::create() as a BfProgram (bt_best.h). */
+/* (the wide build -- bt_rank.h, "the row type" -- answers BT_ERR_UNSUPPORTED to the next three) */
 int bt_host_compile_best(const bt_policy& pol, BfProgram* prog);
 /* ... and of Paired*AlignerFactory::create() with --best (PairedBWAlignerV2): both mates' drivers in
  * one cost-aware driver, doubled sink limits, the RefAligner parameters. */

@@ -16,8 +16,17 @@
  * launches as it takes up to `maxAge`; a read that old is no longer parked but finished by the launch it is in.
  * So the results of batch k are complete when launch k + maxAge is, or after the flush launch bt_ctx_sync
  * enqueues; which batches still have reads parked after a launch is in parkedOf[]. */
+#if BT_WIDE
+#define BT_POOL_WORDS 80     /* the wide build's lane state is up to 17 pieces */
+#define BT_POOL_REQ 17
+#else
 #define BT_POOL_WORDS 64
-struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };   /* [0..47] BtLane, [48] slot, [52..53] request kind/n, [56..59] request a/x */
+#define BT_POOL_REQ 13
+#endif
+/* in 16-byte pieces: [0, BT_POOL_REQ) BtLane, [BT_POOL_REQ] request kind / n / wchunk, [BT_POOL_REQ + 1] request a, x,
+ * [BT_POOL_REQ + 2] word 0: the stamp (narrow build: words [0..51], [52..54], [56..59], [60]) */
+struct BtPoolRec { uint32_t w[BT_POOL_WORDS]; };
+#define BT_POOL_STAMP_WORD (4 * (BT_POOL_REQ + 2))
 
 struct BtKernelArgs {
 	BtHot      H;                /* by value: scalar registers                                   */
@@ -83,11 +92,11 @@ uint32_t bt_best_blocks_per_cu(void);
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */
 int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, uint32_t iters, uint32_t dep, uint32_t* sink, void* stream);
-int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
+int bt_launch_probe_rank(const BtIndexDev* ix, const bt_row* rows, uint32_t n, bt_row* lf,
                          uint8_t* L, uint32_t sides, void* stream);
 int bt_launch_blk_build(const BtIndexDev* ix, uint8_t* out, uint32_t nBlocks, void* stream);
 int bt_launch_loc_build(const BtIndexDev* ix, BtU4* loc, uint32_t* rtxtAlloc, uint16_t* walk, void* stream);
-int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
-                          uint32_t* joined, uint32_t* tidx, uint32_t* toff, void* stream);
+int bt_launch_probe_chase(const BtIndexDev* ix, const bt_row* rows, uint32_t n, uint32_t qlen,
+                          bt_row* joined, uint32_t* tidx, uint32_t* toff, void* stream);
 }
 #endif

@@ -22,6 +22,7 @@
 /* ---- deriving the rank blocks from the index files' side layout (bt_rank.h), once per index at load -------------
  * one wavefront per block of 64 BWT rows: every lane reads its row's symbol, two ballots make the bit planes, lane 0
  * ranks the block's first row the old way for the four absolute counters */
+#if !BT_WIDE
 __device__ __forceinline__ uint32_t dev_rowL_sides(const BtIndexDev& ix, uint32_t row)
 {
 	const uint32_t sideNum = row / BT_SIDE_SYMS, charOff = row - sideNum * BT_SIDE_SYMS;
@@ -106,6 +107,13 @@ extern "C" int bt_launch_loc_build(const BtIndexDev* ix, BtU4* loc, uint32_t* rt
 	return (int)hipGetLastError();
 }
 
+#else
+/* the wide build: its loader derives the rank blocks on the host, straight from the file's BWT (bt_host.cpp), and it has no
+ * locus image */
+extern "C" int bt_launch_blk_build(const BtIndexDev*, uint8_t*, uint32_t, void*) { return -1; }
+extern "C" int bt_launch_loc_build(const BtIndexDev*, BtU4*, uint32_t*, uint16_t*, void*) { return -1; }
+#endif
+
 /* EXT = true compiles in carry-over (parking at the end of a launch, adoption at the start of the next) and the
  * pick-up list of the overflow second pass; a launch that needs neither uses the leaner EXT = false build. */
 /* LITE (with RL): the LDS diet that lets three blocks share a CU -- the read in 39 words (<= 104 bases) and
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	 * so it occupies no registers in them */
 	constexpr int LANE_PIECES = (int)((sizeof(BtLane) + 15) / 16), LANE_PIECES_RL = (int)((offsetof(BtLane, cs0) + 15) / 16);
 	constexpr int PIECES = RL ? LANE_PIECES_RL : LANE_PIECES;
-	static_assert(LANE_PIECES <= 13, "pool record layout: at most 13 pieces of lane state, then request and stamp");
+	static_assert(LANE_PIECES <= BT_POOL_REQ, "pool record layout: at most BT_POOL_REQ pieces of lane state, then request and stamp");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
 	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
 	S.noCC = LITE ? 1u : 0u;
@@ -165,15 +173,15 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		/* carry-over: what lane g of the previous launch parked -- state and pending request; the scratch slot is g
 		 * as ever, and the read goes back into LDS from its own batch's arrays */
 		const BtPoolRec* r = A.pool + g;
-		if (BT_GP(const uint32_t, r->w)[60] == A.launchSeq - 1u) {
+		if (BT_GP(const uint32_t, r->w)[BT_POOL_STAMP_WORD] == A.launchSeq - 1u) {
 			/* word by word into the lane state: a 16-byte-piece copy makes the compiler keep BtLane as twelve
 			 * 4-word vectors for the whole round loop, a different (and larger) kernel than the plain build */
 			uint32_t lw[4 * LANE_PIECES] = {};
 			BT_UNROLL
 			for (int k = 0; k < PIECES; k++) { const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * k); lw[4 * k] = v.x; lw[4 * k + 1] = v.y; lw[4 * k + 2] = v.z; lw[4 * k + 3] = v.w; }
 			__builtin_memcpy(&L, lw, RL ? offsetof(BtLane, cs0) : sizeof(L));
-			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 13); req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
-			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * 14); req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
+			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * BT_POOL_REQ); req.kind = v.x; req.n = v.y; req.wchunk = v.z; }
+			{ const BtU4 v = bt_ld4((const uint8_t*)r->w + 16 * (BT_POOL_REQ + 1)); req.a = ((uint64_t)v.y << 32) | v.x; req.x = ((uint64_t)v.w << 32) | v.z; }
 			L.tosValid = 0; L.ccValid = 0;
 			if (RL) {
 				const BtBatchDev* pb = &cold->ring[L.bid];
@@ -210,8 +218,13 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			const bool m = L.mirror != 0;
 			const uint8_t* blk = m ? A.H.blk[1] : A.H.blk[0];
 			const uint32_t zBlk = m ? A.H.zBlk[1] : A.H.zBlk[0], zPos = m ? A.H.zPos[1] : A.H.zPos[0];
+#if BT_WIDE
+			const bt_row rowA = req.a, rowB = req.x;
+			const uint64_t bA = rowA / BT_BLK_ROWS, bB = rowB / BT_BLK_ROWS;
+#else
 			const uint32_t rowA = (uint32_t)req.a, rowB = (uint32_t)req.x;
 			const uint32_t bA = rowA / BT_BLK_ROWS, bB = rowB / BT_BLK_ROWS;
+#endif
 			const bool hasB = isRank && req.n == 2;
 			/* pieces 0,1: rank row A's block, or the first two pieces of a fetch; pieces 2,3: row B's block, or the
 			 * fetch's third and fourth piece */
@@ -232,6 +245,35 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			if (nA > 3u) qa[3] = bt_ld4(pB + 16);
 			if (hasX) qx = bt_ld4(pX);
 			if (hasW) qw = bt_ld4(pW);
+#if BT_WIDE
+			if (isRank) {
+				/* the blocks' counters count from their segment's start: add the segment's absolute counts (a small table,
+				 * cache-resident) and lay the quartets out as a fetched range-stack entry's (BtRes) */
+				const uint64_t* seg = m ? A.H.segBase[1] : A.H.segBase[0];
+				uint32_t lf[4], la, dummy;
+				bt_rank4_blk(qa[0], qa[1], (uint32_t)(rowA % BT_BLK_ROWS), (uint32_t)bA == zBlk, zPos, lf, &la);
+				{
+					const uint64_t* sb = seg + (bA >> A.H.segShift) * 4u;
+					const BtU4 s0 = bt_ld4(sb), s1 = bt_ld4(sb + 2);
+					const uint64_t v0 = (((uint64_t)s0.y << 32) | s0.x) + lf[0], v1 = (((uint64_t)s0.w << 32) | s0.z) + lf[1];
+					const uint64_t v2 = (((uint64_t)s1.y << 32) | s1.x) + lf[2], v3 = (((uint64_t)s1.w << 32) | s1.z) + lf[3];
+					res.q[0].x = (uint32_t)v0; res.q[0].y = (uint32_t)(v0 >> 32); res.q[0].z = (uint32_t)v1; res.q[0].w = (uint32_t)(v1 >> 32);
+					res.q[1].x = (uint32_t)v2; res.q[1].y = (uint32_t)(v2 >> 32); res.q[1].z = (uint32_t)v3; res.q[1].w = (uint32_t)(v3 >> 32);
+				}
+				res.x = qx; res.x.x = la;
+				if (hasB) {
+					bt_rank4_blk(qa[2], qa[3], (uint32_t)(rowB % BT_BLK_ROWS), (uint32_t)bB == zBlk, zPos, lf, &dummy);
+					const uint64_t* sb = seg + (bB >> A.H.segShift) * 4u;
+					const BtU4 s0 = bt_ld4(sb), s1 = bt_ld4(sb + 2);
+					const uint64_t v0 = (((uint64_t)s0.y << 32) | s0.x) + lf[0], v1 = (((uint64_t)s0.w << 32) | s0.z) + lf[1];
+					const uint64_t v2 = (((uint64_t)s1.y << 32) | s1.x) + lf[2], v3 = (((uint64_t)s1.w << 32) | s1.z) + lf[3];
+					res.q[2].x = (uint32_t)v0; res.q[2].y = (uint32_t)(v0 >> 32); res.q[2].z = (uint32_t)v1; res.q[2].w = (uint32_t)(v1 >> 32);
+					res.q[3].x = (uint32_t)v2; res.q[3].y = (uint32_t)(v2 >> 32); res.q[3].z = (uint32_t)v3; res.q[3].w = (uint32_t)(v3 >> 32);
+				}
+			} else {
+				res.q[0] = qa[0]; res.q[1] = qa[1]; res.q[2] = qa[2]; res.q[3] = qa[3]; res.x = qx;
+			}
+#else
 			if (isRank) {
 				uint32_t lf[4], la;
 				bt_rank4_blk(qa[0], qa[1], rowA % BT_BLK_ROWS, bA == zBlk, zPos, lf, &la);
@@ -246,6 +288,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			} else {
 				res.q[0] = qa[0]; res.q[1] = qa[1]; res.q[2] = qa[2]; res.q[3] = qa[3]; res.x = qx;
 			}
+#endif
 		}
 		BT_PROF_ADD(PS_RANK, t_rank);
 
@@ -285,7 +328,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 			sc_lfex += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_EX2));
 			sc_lf2 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_C2));
 			sc_lf1 += (uint32_t)__builtin_popcountll(__ballot(isR && L.lfk == LFK_LF1));
-			sc_same += (uint32_t)__builtin_popcountll(__ballot(isR && req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u));
+			sc_same += (uint32_t)__builtin_popcountll(__ballot(isR && req.n == 2 && (bt_row)req.a / 448u == (bt_row)req.x / 448u));
 			if (RL || WARM.locOn) {
 				const bool isF = req.kind == RQ_FETCH;
 				sc_locrec += (uint32_t)__builtin_popcountll(__ballot(isF && (L.state == ST_LOC_REC || (L.state == ST_RESOLVE_DONE && WARM.locOn))));
@@ -328,9 +371,9 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 		__builtin_memcpy(lw, &L, RL ? offsetof(BtLane, cs0) : sizeof(L));
 		BT_UNROLL
 		for (int k = 0; k < PIECES; k++) { BtU4 v; v.x = lw[4 * k]; v.y = lw[4 * k + 1]; v.z = lw[4 * k + 2]; v.w = lw[4 * k + 3]; bt_st4((uint8_t*)r->w + 16 * k, v); }
-		{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 13, v); }
-		{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); bt_st4((uint8_t*)r->w + 16 * 14, v); }
-		{ BtU4 v; v.x = A.launchSeq; v.y = 0; v.z = 0; v.w = 0; bt_st4((uint8_t*)r->w + 16 * 15, v); }
+		{ BtU4 v; v.x = req.kind; v.y = req.n; v.z = req.wchunk; v.w = 0; bt_st4((uint8_t*)r->w + 16 * BT_POOL_REQ, v); }
+		{ BtU4 v; v.x = (uint32_t)req.a; v.y = (uint32_t)(req.a >> 32); v.z = (uint32_t)req.x; v.w = (uint32_t)(req.x >> 32); bt_st4((uint8_t*)r->w + 16 * (BT_POOL_REQ + 1), v); }
+		{ BtU4 v; v.x = A.launchSeq; v.y = 0; v.z = 0; v.w = 0; bt_st4((uint8_t*)r->w + 16 * (BT_POOL_REQ + 2), v); }
 		atomicAdd(A.parkedOf + L.bid, 1u);
 	}
 	if (tl_acc) { atomicAdd(&CNT[CN_TLFEX], (unsigned long long)(tl_acc >> 16)); atomicAdd(&CNT[CN_TLF1], (unsigned long long)(tl_acc & 0xffffu)); }
@@ -348,29 +391,33 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 
 
 /* sides != 0: rank from the index files' side layout instead of the rank blocks the search uses */
-__global__ void bt_probe_rank_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* Lout, uint32_t sides)
+__global__ void bt_probe_rank_kernel(BtIndexDev ix, const bt_row* rows, uint32_t n, bt_row* lf, uint8_t* Lout, uint32_t sides)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	uint32_t r[4], L;
+	bt_row r[4]; uint32_t L;
+#if BT_WIDE
+	bt_rank4(ix, rows[i], r, &L);
+#else
 	if (sides) bt_rank4_sides(ix, rows[i], r, &L); else bt_rank4(ix, rows[i], r, &L);
+#endif
 	lf[i * 4 + 0] = r[0]; lf[i * 4 + 1] = r[1]; lf[i * 4 + 2] = r[2]; lf[i * 4 + 3] = r[3];
 	Lout[i] = (uint8_t)L;
 }
 
-__global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
-                                      uint32_t* joined, uint32_t* tidx, uint32_t* toff)
+__global__ void bt_probe_chase_kernel(BtIndexDev ix, const bt_row* rows, uint32_t n, uint32_t qlen,
+                                      bt_row* joined, uint32_t* tidx, uint32_t* toff)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	uint32_t row = rows[i], jumps = 0;
+	bt_row row = rows[i]; uint32_t jumps = 0;
 	while ((row & ix.offMask) != row && row != ix.zOff) {
-		uint32_t r[4], L;
+		bt_row r[4]; uint32_t L;
 		bt_rank4(ix, row, r, &L);
 		row = r[L];
 		jumps++;
 	}
-	const uint32_t off = (row == ix.zOff) ? jumps : ix.offs[row >> ix.offRate] + jumps;
+	const bt_row off = (row == ix.zOff) ? jumps : ix.offs[row >> ix.offRate] + jumps;
 	joined[i] = off;
 	uint32_t t = 0xffffffffu, o = 0, probes = 0;
 	if (!bt_joined_to_text(ix, qlen, off, &t, &o, &probes)) { t = 0xffffffffu; o = 0; }
@@ -383,6 +430,9 @@ __global__ void bt_probe_chase_kernel(BtIndexDev ix, const uint32_t* rows, uint3
  * of the index files' layout (dep bit 1 set: 4 x 16-byte loads of the row's side + 8 counter bytes of the partner
  * side).  dep bit 0 makes each query's row depend on the previous result (an SA walk's dependency chain) instead of
  * being known up front. */
+#if BT_WIDE
+extern "C" int bt_launch_gather_bench(const BtIndexDev*, uint32_t, uint32_t, uint32_t, uint32_t*, void*) { return -1; }
+#else
 __global__ __launch_bounds__(256) void bt_gather_bench_kernel(BtIndexDev ix, uint32_t iters, uint32_t dep, uint32_t* sink)
 {
 	uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u, acc = 0;
@@ -401,6 +451,7 @@ extern "C" int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, ui
 	hipLaunchKernelGGL(bt_gather_bench_kernel, dim3(nBlocks), dim3(256), 0, (hipStream_t)stream, *ix, iters, dep, sink);
 	return (int)hipGetLastError();
 }
+#endif
 
 /* ---- launchers (called from bt_api.cpp, which is plain C++) ------------------------------- */
 /* occ = waves per SIMD the register allocator was told to fit (1..4): the same source compiled for
@@ -443,15 +494,15 @@ extern "C" int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, 
 	hipLaunchKernelGGL(bt_maxlen_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, len, n, out);
 	return (int)hipGetLastError();
 }
-extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t* lf,
+extern "C" int bt_launch_probe_rank(const BtIndexDev* ix, const bt_row* rows, uint32_t n, bt_row* lf,
                                     uint8_t* L, uint32_t sides, void* stream)
 {
 	hipLaunchKernelGGL(bt_probe_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
 	                   *ix, rows, n, lf, L, sides);
 	return (int)hipGetLastError();
 }
-extern "C" int bt_launch_probe_chase(const BtIndexDev* ix, const uint32_t* rows, uint32_t n, uint32_t qlen,
-                                     uint32_t* joined, uint32_t* tidx, uint32_t* toff, void* stream)
+extern "C" int bt_launch_probe_chase(const BtIndexDev* ix, const bt_row* rows, uint32_t n, uint32_t qlen,
+                                     bt_row* joined, uint32_t* tidx, uint32_t* toff, void* stream)
 {
 	hipLaunchKernelGGL(bt_probe_chase_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
 	                   *ix, rows, n, qlen, joined, tidx, toff);

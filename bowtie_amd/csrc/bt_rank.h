@@ -52,20 +52,48 @@
 
 struct alignas(16) BtU4 { uint32_t x, y, z, w; };
 
+/* ---- the row type ---------------------------------------------------------------------------------------------------
+ * The reference compiles its sources twice: bowtie-align-s with 32-bit offsets and, with -DBOWTIE_64BIT_INDEX, bowtie-align-l
+ * with TIndexOffU = uint64_t for indexes of 2^32 - 1 rows and more (btypes.h:4-28; the `bowtie` wrapper picks the binary,
+ * bowtie:52-81).  So does this tree: -DBT_WIDE=1 builds libbowtie_amd_l.so / bowtie-amd-l from the same sources with 64-bit
+ * BWT rows and text offsets.  What changes with the width:
+ *   - a row-valued table entry (ftab, eftab, offs, rstarts, plen, fchr) is 8 bytes, a 16-byte piece holds two of them;
+ *   - a range-stack entry (tops ACGT, bots ACGT) is 64 bytes = four pieces, and a rank answer's quartets take two pieces each
+ *     (BtRes, bt_core.h);
+ *   - a rank block keeps its 32 bytes: its four counters are relative to the start of the block's SEGMENT (2^segShift blocks,
+ *     2^31 rows by default), whose absolute counts sit in a small table (segBase);
+ *   - the wide build searches in row space only (no locus image: it would need a 64-bit form of its own) and leaves the
+ *     best-first engine and pairs to a later round (BT_ERR_UNSUPPORTED).                                                  */
+#ifndef BT_WIDE
+#define BT_WIDE 0
+#endif
+#if BT_WIDE
+typedef uint64_t bt_row;
+#define BT_OFF_MASK 0xffffffffffffffffull
+#define BT_PIECE_ROWS 2u       /* row-valued entries per 16-byte piece */
+#else
+typedef uint32_t bt_row;
 #define BT_OFF_MASK 0xffffffffu
+#define BT_PIECE_ROWS 4u
+#endif
+#define BT_SEG_SHIFT_DEFAULT 25u   /* blocks per segment, log2: 2^25 blocks of 64 rows = 2^31 rows */
 #define BT_SIDE_SYMS 224u
 
 /* device-visible image of one index (fw or mirror); all pointers are device pointers on the
  * GPU build, host pointers in the host unit-test build. */
 struct BtIndexDev {
-	const uint8_t*  ebwt;      /* numSidePairs * 128 bytes, reference byte layout            */
-	const uint32_t* ftab;
-	const uint32_t* eftab;
-	const uint32_t* offs;
-	const uint32_t* rstarts;   /* 3 * nFrag                                                  */
-	const uint32_t* plen;
-	uint32_t len, zOff, zSide, zSym, ftabChars, offRate, offMask, nFrag, fw, nPat;
-	uint32_t fchr[5];
+	const uint8_t*  ebwt;      /* numSidePairs * 128 bytes, reference byte layout (NULL in the wide build: its loader
+	                              derives the rank blocks straight from the file's BWT)                              */
+	const bt_row* ftab;
+	const bt_row* eftab;
+	const bt_row* offs;
+	const bt_row* rstarts;     /* 3 * nFrag                                                  */
+	const bt_row* plen;
+	bt_row   len, zOff;
+	uint32_t zSide, zSym, ftabChars, offRate;
+	bt_row   offMask;
+	uint32_t nFrag, fw, nPat;
+	bt_row   fchr[5];
 	const uint8_t*  blk;       /* the rank blocks: (len + 1) / 64 + 2 of them, 32 bytes each (see above)          */
 	uint32_t zBlk, zPos;       /* zOff / 64, zOff % 64                                                             */
 	/* ---- the locus image (round 5; optional: loc == NULL means it was not built and the search stays in row space) ----
@@ -86,7 +114,17 @@ struct BtIndexDev {
 	                              a user can see follow the offset width: the row a hit is reported from is drawn
 	                              with nextU<TIndexOffU>() (two draws, ebwt_search_backtrack.h:1538), and a
 	                              best-first Branch is 160 bytes, so 1638 of them fit a pool chunk (pool.h:32)   */
+#if BT_WIDE
+	const uint64_t* segBase;   /* [segment][4]: LF(first row of the segment, ACGT), absolute                              */
+	uint32_t segShift, padW;   /* blocks per segment, log2                                                                */
+	bt_row   rowLim;           /* the last BWT row (= len, unless the image's rows are offset: tests, bt_host.h)           */
+#endif
 };
+#if BT_WIDE
+#define BT_ROWLIM(ix) ((ix).rowLim)
+#else
+#define BT_ROWLIM(ix) ((ix).len)
+#endif
 
 /* ---- global-memory accessors ---------------------------------------------------------------
  * Pointers that reach the device code through LDS or through structures in memory are generic,
@@ -149,6 +187,7 @@ BT_HD void bt_count_word(uint64_t w, uint32_t bits, uint32_t& cC, uint32_t& cG, 
 	cC += (uint32_t)__builtin_popcountll(~hi & lo);
 }
 
+#if !BT_WIDE
 /* Rank from the 7 BWT words of the side holding `row` plus the pair's four counters.
  *   w[0..6] : the side's 56 BWT bytes as little-endian u64
  *   occ[4]  : occ_mid A,C,G,T of the side pair
@@ -205,11 +244,12 @@ BT_UNROLL
 	else              { occ[0] = (uint32_t)own; occ[1] = (uint32_t)(own >> 32); occ[2] = (uint32_t)oth; occ[3] = (uint32_t)(oth >> 32); }
 	bt_rank4_words(ix, sideNum, charOff, w, occ, lf, L);
 }
+#endif /* !BT_WIDE */
 
 /* ---- rank blocks ------------------------------------------------------------------------------------------------ */
 #define BT_BLK_BYTES 32u
 #define BT_BLK_ROWS 64u
-BT_HD uint64_t bt_blk_count(uint32_t len) { return (uint64_t)(len + 1u) / BT_BLK_ROWS + 2u; }
+BT_HD uint64_t bt_blk_count(bt_row len) { return ((uint64_t)len + 1u) / BT_BLK_ROWS + 2u; }
 /* LF(row, ACGT) and rowL from a rank block's eight words: o = occ[4], p = plane0 lo/hi, plane1 lo/hi; n = row % 64;
  * zHere: the block is the one holding the '$' row (which is stored as an A and must not count as one) */
 BT_HD void bt_rank4_blk(const BtU4& o, const BtU4& p, uint32_t n, bool zHere, uint32_t zPos, uint32_t lf[4], uint32_t* L)
@@ -223,7 +263,23 @@ BT_HD void bt_rank4_blk(const BtU4& o, const BtU4& p, uint32_t n, bool zHere, ui
 	lf[0] = o.x + cA; lf[1] = o.y + (cLo - cT); lf[2] = o.z + (cHi - cT); lf[3] = o.w + cT;
 	*L = ((uint32_t)(p0 >> n) & 1u) | (((uint32_t)(p1 >> n) & 1u) << 1);
 }
+#define BT_LOC_CTX 48u
+#define BT_RTXT_PAD_WORDS 16u       /* (the locus image, below) words of padding before rtxt[0] and after its last word */
+BT_HD uint64_t bt_rtxt_words(bt_row len) { return ((uint64_t)len + 15u) / 16u + 2u * BT_RTXT_PAD_WORDS; }
 /* the rank the search uses: one 32-byte block per BWT row queried */
+#if BT_WIDE
+/* the wide build's: the block's counters are relative to its segment's (see "the row type") */
+BT_HD void bt_rank4(const BtIndexDev& ix, bt_row row, bt_row lf[4], uint32_t* L)
+{
+	const uint64_t b = row / BT_BLK_ROWS;
+	const uint8_t* q = ix.blk + b * BT_BLK_BYTES;
+	const BtU4 o = bt_ld4(q), p = bt_ld4(q + 16);
+	uint32_t r[4];
+	bt_rank4_blk(o, p, (uint32_t)(row % BT_BLK_ROWS), (uint32_t)b == ix.zBlk, ix.zPos, r, L);
+	const uint64_t* sb = ix.segBase + (b >> ix.segShift) * 4u;
+	for (int c = 0; c < 4; c++) lf[c] = BT_GP(const uint64_t, sb)[c] + r[c];
+}
+#else
 BT_HD void bt_rank4(const BtIndexDev& ix, uint32_t row, uint32_t lf[4], uint32_t* L)
 {
 	const uint32_t b = row / BT_BLK_ROWS;
@@ -264,9 +320,6 @@ BT_HD void bt_blk_build_host(const BtIndexDev& ix, uint8_t* out)
  * One pass over the text from its end: row 0 is the suffix "$" (SA = len); LF of the row of suffix p is the row of suffix
  * p - 1 and the BWT character there is T[p-1].  rtxt: (len + 15) / 16 + 32 words (padding: a window fetch may run past
  * either end), walk: len + 1 entries, loc: len + 1 records. */
-#define BT_LOC_CTX 48u
-#define BT_RTXT_PAD_WORDS 16u       /* words of padding before rtxt[0] and after its last word */
-BT_HD uint64_t bt_rtxt_words(uint32_t len) { return ((uint64_t)len + 15u) / 16u + 2u * BT_RTXT_PAD_WORDS; }
 BT_HD void bt_loc_build_host(const BtIndexDev& ix, BtU4* loc, uint32_t* rtxtAlloc, uint16_t* walk)
 {
 	uint32_t* rtxt = rtxtAlloc + BT_RTXT_PAD_WORDS;
@@ -309,39 +362,41 @@ BT_HD void bt_loc_build_host(const BtIndexDev& ix, BtU4* loc, uint32_t* rtxtAllo
 	}
 }
 
+#endif /* BT_WIDE: the side-layout block build and the locus image are the narrow build's */
+
 /* ftabHi / ftabLo (ebwt.h:985-1034) */
-BT_HD uint32_t bt_ftab_hi(const BtIndexDev& ix, uint32_t i)
+BT_HD bt_row bt_ftab_hi(const BtIndexDev& ix, uint32_t i)
 {
-	uint32_t v = BT_GP(const uint32_t, ix.ftab)[i];
-	if (v <= ix.len) return v;
-	return BT_GP(const uint32_t, ix.eftab)[(v ^ BT_OFF_MASK) * 2u + 1u];
+	bt_row v = BT_GP(const bt_row, ix.ftab)[i];
+	if (v <= BT_ROWLIM(ix)) return v;
+	return BT_GP(const bt_row, ix.eftab)[(v ^ BT_OFF_MASK) * 2u + 1u];
 }
-BT_HD uint32_t bt_ftab_lo(const BtIndexDev& ix, uint32_t i)
+BT_HD bt_row bt_ftab_lo(const BtIndexDev& ix, uint32_t i)
 {
-	uint32_t v = BT_GP(const uint32_t, ix.ftab)[i];
-	if (v <= ix.len) return v;
-	return BT_GP(const uint32_t, ix.eftab)[(v ^ BT_OFF_MASK) * 2u];
+	bt_row v = BT_GP(const bt_row, ix.ftab)[i];
+	if (v <= BT_ROWLIM(ix)) return v;
+	return BT_GP(const bt_row, ix.eftab)[(v ^ BT_OFF_MASK) * 2u];
 }
 
 /* joinedToTextOff (ebwt.h:2569-2629): joined offset -> (tidx,toff); false if [off,off+qlen)
  * straddles a fragment boundary. */
-BT_HD bool bt_joined_to_text(const BtIndexDev& ix, uint32_t qlen, uint32_t off,
+BT_HD bool bt_joined_to_text(const BtIndexDev& ix, uint32_t qlen, bt_row off,
                              uint32_t* tidx, uint32_t* toff, uint32_t* probes)
 {
 	uint32_t top = 0, bot = ix.nFrag;
 	for (;;) {
 		uint32_t elt = top + ((bot - top) >> 1);
-		uint32_t lower = BT_GP(const uint32_t, ix.rstarts)[elt * 3u];
-		uint32_t upper = (elt == ix.nFrag - 1u) ? ix.len : BT_GP(const uint32_t, ix.rstarts)[(elt + 1u) * 3u];
+		bt_row lower = BT_GP(const bt_row, ix.rstarts)[elt * 3u];
+		bt_row upper = (elt == ix.nFrag - 1u) ? ix.len : BT_GP(const bt_row, ix.rstarts)[(elt + 1u) * 3u];
 		(*probes)++;
 		if (lower <= off) {
 			if (upper > off) {
 				if (off + qlen > upper) return false;
-				uint32_t fraglen = upper - lower;
-				uint32_t fragoff = off - lower;
+				bt_row fraglen = upper - lower;
+				bt_row fragoff = off - lower;
 				if (!ix.fw) { fragoff = fraglen - fragoff - 1u; fragoff -= (qlen - 1u); }
-				*tidx = BT_GP(const uint32_t, ix.rstarts)[elt * 3u + 1u];
-				*toff = fragoff + BT_GP(const uint32_t, ix.rstarts)[elt * 3u + 2u];
+				*tidx = (uint32_t)BT_GP(const bt_row, ix.rstarts)[elt * 3u + 1u];
+				*toff = (uint32_t)(fragoff + BT_GP(const bt_row, ix.rstarts)[elt * 3u + 2u]);
 				return true;
 			}
 			top = elt;

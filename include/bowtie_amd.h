@@ -50,6 +50,10 @@ extern "C" {
                                   reads of the batch are valid                                */
 #define BT_ERR_READS       7   /* malformed read input (the reference prints a message and
                                   exits 1; the message is in bt_reads_error())                */
+#define BT_ERR_ROWS64      8   /* the index has 2^32-1 BWT rows or more: it needs the build with 64-bit rows,
+                                  libbowtie_amd_l.so / bowtie-amd-l (the reference's bowtie-align-l, btypes.h:4-28) */
+#define BT_ERR_UNSUPPORTED 9   /* not in this build: the 64-bit-row build has the phase-program engine (-v / -n,
+                                  -k / -a / -m / -M) and neither --best nor pairs yet                             */
 
 /* ---- policy: exactly the knobs the reference workers read -------------------------------- */
 #define BT_MODE_V 0            /* end-to-end, -v <mms>   (ebwt_search.cpp:3249-3268)          */
@@ -180,8 +184,9 @@ typedef struct bt_index_info {
  * reference's order -- <base>.1.bt2, .1.ebwt, then the 64-bit builds .1.bt2l, .1.ebwtl (adjustEbwtBase
  * ebwt.cpp:36-48; the `bowtie` wrapper's choice of the -l binary, bowtie:52-81) -- in either byte
  * order, and converts what it finds to one in-memory layout.  64-bit builds load when the index has
- * fewer than 2^32-1 rows (BT_ERR_FORMAT otherwise), and keep the two behaviours of the 64-bit
- * binary that a user can see (see BtIndexDev::wide in csrc/bt_rank.h). */
+ * fewer than 2^32-1 rows (BT_ERR_ROWS64 otherwise: libbowtie_amd_l.so, the same sources compiled with
+ * 64-bit rows, holds those -- bt_rows64() tells the two libraries apart), and keep the two behaviours
+ * of the 64-bit binary that a user can see (see BtIndexDev::wide in csrc/bt_rank.h). */
 #define BT_INDEX_BT2      0
 #define BT_INDEX_EBWT     1
 #define BT_INDEX_BT2L     2
@@ -197,6 +202,10 @@ typedef struct bt_ctx   bt_ctx;     /* per-GPU stream, scratch, queues          
 int  bt_index_load(const char* ebwt_base, int need_mirror, int offrate_override, int device,
                    bt_index** out);
 void bt_index_info_get(const bt_index* idx, bt_index_info* info);
+/* 1 in the library built with 64-bit BWT rows (libbowtie_amd_l.so), 0 in libbowtie_amd.so; the text length of an
+ * index whatever its size (bt_index_info::len is 32 bits: 0xffffffff there if it does not fit) */
+int      bt_rows64(void);
+uint64_t bt_index_len64(const bt_index* idx);
 const char* bt_index_refname(const bt_index* idx, uint32_t tidx);   /* Ebwt::refnames()      */
 uint32_t    bt_index_reflen (const bt_index* idx, uint32_t tidx);   /* Ebwt::plen()          */
 void bt_index_free(bt_index* idx);
@@ -324,6 +333,9 @@ const char* bt_version(void);
  * bit 1: rank from the index files' 224-symbol side layout instead of the 32-byte rank blocks the search kernels
  * query (bt_rank.h) -- the two must agree.  Host pointers. */
 int bt_probe_rank(bt_ctx* ctx, int mirror, const uint32_t* rows, uint32_t n, uint32_t* lf, uint8_t* L);
+/* the same with rows as 64-bit numbers, from the rank blocks -- in either library; in libbowtie_amd_l.so (bt_rows64()) the
+ * three 32-bit probes around it answer BT_ERR_UNSUPPORTED */
+int bt_probe_rank64(bt_ctx* ctx, int mirror, const uint64_t* rows, uint32_t n, uint64_t* lf, uint8_t* L);
 /* rows[n] -> joined-text offset via the SA walk of reportChaseOne (ebwt.h:2727-2746) and
  * (tidx,toff) via joinedToTextOff (ebwt.h:2569) for a query of length qlen; tidx=0xffffffff when
  * the hit straddles a fragment boundary. */

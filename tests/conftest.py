@@ -31,6 +31,8 @@ def pytest_configure(config):
         oracle_lib.lib()
         emu_lib.lib()
         emu_lib.shim()
+        emu_lib.wide_lib()          # the same with 64-bit rows (libbowtie_amd_l.so's sources)
+        emu_lib.wide_shim()
 
 
 def _has_gpu() -> bool:

@@ -29,6 +29,14 @@ static void bind(EmuIndex* e, int m)
 	bt_host_index_describe(e->h[m], &e->d[m]);
 	e->d[m].ebwt = e->h[m].ebwt.data(); e->d[m].ftab = e->h[m].ftab.data(); e->d[m].eftab = e->h[m].eftab.data();
 	e->d[m].offs = e->h[m].offs.data(); e->d[m].rstarts = e->h[m].rstarts.data(); e->d[m].plen = e->h[m].plen.data();
+#if BT_WIDE
+	/* the wide build (64-bit rows): the loader made the rank blocks and their segment table; no locus image */
+	e->d[m].ebwt = nullptr;
+	e->d[m].blk = e->h[m].blk.data(); e->d[m].segBase = e->h[m].segBase.data();
+	e->d[m].loc = nullptr; e->d[m].rtxt = nullptr; e->d[m].walk = nullptr;
+	bt_host_index_bias(e->h[m], &e->d[m]);
+	return;
+#else
 	/* the rank blocks the search queries (bt_rank.h), derived from the sides as the GPU loader derives them */
 	e->blk[m].assign((size_t)bt_blk_count(e->d[m].len) * BT_BLK_BYTES, 0);
 	bt_blk_build_host(e->d[m], e->blk[m].data());
@@ -42,6 +50,7 @@ static void bind(EmuIndex* e, int m)
 		bt_loc_build_host(e->d[m], e->loc[m].data(), e->rtxt[m].data(), e->walk[m].data());
 		e->d[m].loc = e->loc[m].data(); e->d[m].rtxt = e->rtxt[m].data() + BT_RTXT_PAD_WORDS; e->d[m].walk = e->walk[m].data();
 	}
+#endif
 }
 
 extern "C" void* emu_index_load(const char* base, int need_mirror, int offrate)
@@ -66,10 +75,40 @@ extern "C" int emu_locus_arrays(void* p, int mirror, const void** loc, const voi
 	EmuIndex* e = (EmuIndex*)p;
 	const int m = mirror ? 1 : 0;
 	if (!e->d[m].loc) return 1;
-	*loc = e->d[m].loc; *rtxt = e->d[m].rtxt; *walk = e->d[m].walk; *len = e->d[m].len;
+	*loc = e->d[m].loc; *rtxt = e->d[m].rtxt; *walk = e->d[m].walk; *len = (uint32_t)e->d[m].len;
 	return 0;
 }
 
+/* rows as 64-bit numbers, whatever the build's row type */
+extern "C" void emu_rank4_64(void* p, int mirror, uint64_t row, uint64_t* lf, uint32_t* L)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	bt_row r[4];
+	bt_rank4(e->d[mirror ? 1 : 0], (bt_row)row, r, L);
+	for (int c = 0; c < 4; c++) lf[c] = r[c];
+}
+/* text length, the number the image's rows are offset by (wide build, BT_WIDE_ROW_BIAS), sizeof(bt_row) */
+extern "C" void emu_index_dims(void* p, uint64_t out[3])
+{
+	EmuIndex* e = (EmuIndex*)p;
+	out[0] = e->h[0].len;
+#if BT_WIDE
+	out[1] = e->h[0].rowBias;
+#else
+	out[1] = 0;
+#endif
+	out[2] = sizeof(bt_row);
+}
+/* sequence t of the index: its name into name[cap] (NUL-terminated), its length returned; -1 past the last one */
+extern "C" long long emu_index_ref(void* p, uint32_t t, char* name, uint32_t cap)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	const BtIndexHost& h = e->h[0];
+	if (t >= h.plen.size()) return -1;
+	snprintf(name, cap, "%s", t < h.refnames.size() ? h.refnames[t].c_str() : "");
+	return (long long)h.plen[t];
+}
+#if !BT_WIDE
 extern "C" void emu_rank4(void* p, int mirror, uint32_t row, uint32_t* lf, uint32_t* L)
 {
 	EmuIndex* e = (EmuIndex*)p;
@@ -81,6 +120,7 @@ extern "C" void emu_rank4_sides(void* p, int mirror, uint32_t row, uint32_t* lf,
 	EmuIndex* e = (EmuIndex*)p;
 	bt_rank4_sides(e->d[mirror ? 1 : 0], row, lf, L);
 }
+#endif
 
 /* Same contract as bt_align_batch (host pointers); nLanes lock-step lanes. */
 template <bool RL>
@@ -110,12 +150,15 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		W.ftabChars[m] = e->d[m].ftabChars; W.len[m] = e->d[m].len;
 		W.loc[m] = e->d[m].loc; W.rtxt[m] = e->d[m].rtxt; W.walk[m] = e->d[m].walk;
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
+#if BT_WIDE
+		H.segBase[m] = e->d[m].segBase; H.segShift = e->d[m].segShift; W.rowLim[m] = e->d[m].rowLim;
+#endif
 	}
 	W.locOn = (e->d[0].loc && (!e->mirror || e->d[1].loc) && !(getenv("EMU_LOCUS_OFF") && atoi(getenv("EMU_LOCUS_OFF")))) ? 1u : 0u;
 	H.seq = in->seq; H.qual = in->qual; H.stride = in->stride; H.n_reads = in->n_reads;
 	entCap = (entCap + 7u) & ~7u;
 	std::vector<BtU4> frames4((size_t)nLanes * frCap * 4);
-	std::vector<BtU4> pairs4((size_t)nLanes * entCap * 2);
+	std::vector<BtU4> pairs4((size_t)nLanes * entCap * BT_ENT_PIECES);
 	std::vector<uint16_t> meta((size_t)nLanes * entCap + 8);
 	std::vector<uint64_t> pals((size_t)nLanes * palCap);
 	std::vector<uint32_t> tos((size_t)nLanes * BT_LDS_WORDS);
@@ -141,7 +184,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
 		scr[g].rl = rlbuf.data() + g;
 		scr[g].tosRec = scr[g].tos + (size_t)BT_CC_WORDS * nLanes;
-		scr[g].noCC = lite ? 1u : 0u;
+		scr[g].noCC = (lite || BT_WIDE) ? 1u : 0u;      /* (the wide build has no candidate caches: a range-stack entry is 64 bytes) */
 		scr[g].rlMax = lite ? BT_RL3_MAXLEN : BT_RL_MAXLEN;
 	}
 	uint32_t next = 0, live = nLanes;
@@ -182,8 +225,21 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 				else if (L.lfk == LFK_EX2) BT_COUNT(CN_LFEX);
 				else if (L.lfk == LFK_C2) BT_COUNT(CN_LF2);
 				else BT_COUNT(CN_LF1);
-				if (req.n == 2 && (uint32_t)req.a / 448u == (uint32_t)req.x / 448u) BT_COUNT(CN_SAMEPAIR);
+				if (req.n == 2 && (bt_row)req.a / 448u == (bt_row)req.x / 448u) BT_COUNT(CN_SAMEPAIR);
 				const BtIndexDev& ix = e->d[L.mirror];
+#if BT_WIDE
+				{
+					/* as the kernel lays a rank answer out in the wide build (BtRes): quartets of 64-bit rows, two pieces each */
+					bt_row lf[4]; uint32_t la, dummy;
+					EMU_POISON(&res[g], sizeof(BtRes));
+					memset(&res[g].x, 0, 16);
+					bt_rank4(ix, (bt_row)req.a, lf, &la);
+					memcpy(&res[g].q[0], lf, 32);
+					res[g].x.x = la;
+					if (req.n == 2) { bt_rank4(ix, (bt_row)req.x, lf, &dummy); memcpy(&res[g].q[2], lf, 32); }
+					continue;
+				}
+#else
 				uint32_t lf[4], la, dummy;
 				EMU_POISON(&res[g].q[1], 16); EMU_POISON(&res[g].q[2], 16);     /* what the kernel's rank branch leaves unset */
 				memset(&res[g].q[3], 0, 16); memset(&res[g].x, 0, 16);
@@ -198,6 +254,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 					bt_rank4(ix, (uint32_t)req.x, lf, &dummy);
 					res[g].q[1].x = lf[0]; res[g].q[1].y = lf[1]; res[g].q[1].z = lf[2]; res[g].q[1].w = lf[3];
 				}
+#endif
 			} else {
 				memset(&res[g], 0, sizeof(BtRes));
 				for (uint32_t k = 0; k < req.n; k++) memcpy(&res[g].q[k], (const uint8_t*)(uintptr_t)req.a + 16 * k, 16);
@@ -220,6 +277,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 }
 
 
+#if !BT_WIDE
 /* bt_best_kernel's loop -- the wavefront automaton of bt_best.h -- for one "wavefront" of W lanes gone through side by side:
  * the same decisions as the kernel's (hot round or cold sweep, new reads, the gate of the ended streaks), its ballots
  * being counts over the lanes.  Checks what the loop has to get right on top of the pieces it calls: every read run
@@ -383,6 +441,8 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	return BT_OK;
 }
 
+#endif /* !BT_WIDE */
+
 /* rl_mode: 0 = as the kernel launcher decides (reads of <= BT_RL_MAXLEN bases keep their read in "LDS"),
  * 1 = force the register-window build of the automaton, 2 = the lite layout of the 3-waves build */
 extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
@@ -392,7 +452,11 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
 	/* the stateful best-first workers: entCap doubles as the arena size in words (0 = 4 M words) */
+#if BT_WIDE
+	if (pol->best) return BT_ERR_UNSUPPORTED;
+#else
 	if (pol->best) return emu_run_best(p, pol, in, out, counts, entCap >= 256u ? entCap : (1u << 22));
+#endif
 	/* rl_mode 2 = the 3-waves-per-SIMD layout: read in LDS (<= 104 bases), no candidate caches */
 	if (rl_mode == 2 && maxLen <= BT_RL3_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, true);
 	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, false);

@@ -35,8 +35,8 @@ extern "C" void bt_index_info_get(const bt_index* idx, bt_index_info* info)
 {
 	memset(info, 0, sizeof(*info));
 	const BtIndexHost& h = ((EmuIndex*)idx->emu)->h[0];
-	info->len = h.len; info->n_pat = h.nPat; info->n_frag = h.nFrag; info->ftab_chars = (uint32_t)h.ftabChars;
-	info->off_rate = (uint32_t)h.offRate; info->z_off = h.zOff;
+	info->len = h.len > 0xffffffffull ? 0xffffffffu : (uint32_t)h.len; info->n_pat = h.nPat; info->n_frag = h.nFrag; info->ftab_chars = (uint32_t)h.ftabChars;
+	info->off_rate = (uint32_t)h.offRate; info->z_off = (uint32_t)h.zOff;
 	info->has_mirror = idx->mirror ? 1 : 0;
 	info->variant = idx->variant | (h.swapped ? BT_INDEX_SWAPPED : 0);
 }
@@ -48,7 +48,7 @@ extern "C" const char* bt_index_refname(const bt_index* idx, uint32_t t)
 extern "C" uint32_t bt_index_reflen(const bt_index* idx, uint32_t t)
 {
 	const BtIndexHost& h = ((EmuIndex*)idx->emu)->h[0];
-	return t < h.plen.size() ? h.plen[t] : 0;
+	return t < h.plen.size() ? (uint32_t)h.plen[t] : 0;
 }
 extern "C" void bt_index_free(bt_index* idx) { if (idx) { emu_index_free(idx->emu); delete idx; } }
 extern "C" int bt_index_load_reference(bt_index* ix) { return ix ? BT_OK : BT_ERR_ARG; }       /* emu_align_pairs loads it on first use */
@@ -94,7 +94,7 @@ static int null_align(const bt_ctx* c, const bt_read_batch* in, bt_hit_batch* ou
 		if ((x >> 28 & 3u) == 3u || L == 0 || h.plen[t] <= L) continue;
 		bt_hit& H = out->hits[(size_t)i * out->hit_cap];
 		memset(&H, 0, sizeof(H));
-		H.tidx = t; H.toff = (x >> 7) % (h.plen[t] - L); H.fw = (uint8_t)(x >> 5 & 1u); H.nmm = (uint16_t)(x >> 3 & 3u) % 3u;
+		H.tidx = t; H.toff = (x >> 7) % ((uint32_t)h.plen[t] - L); H.fw = (uint8_t)(x >> 5 & 1u); H.nmm = (uint16_t)(x >> 3 & 3u) % 3u;
 		H.cost = (uint16_t)(H.nmm * 30u); H.stratum = (uint8_t)H.nmm;
 		if (H.nmm && out->mm_pool && pool + H.nmm <= out->mm_pool_cap) {
 			H.mm_off = pool;
@@ -125,10 +125,15 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 {
 	if (!c || !in1 || !in2 || !out) return BT_ERR_ARG;
 	if (in1->n_reads == 0) return BT_OK;
+#if BT_WIDE
+	(void)counts;
+	return BT_ERR_UNSUPPORTED;
+#else
 	std::lock_guard<std::mutex> lock(g_emu_mutex);
 	const int rc = emu_align_pairs(c->ix->emu, &c->pol, in1, in2, out, counts, 0);
 	if (rc != BT_OK) return rc;
 	return worst_status(out, in1->n_reads);
+#endif
 }
 extern "C" void* bt_host_alloc(size_t bytes) { return bytes ? aligned_alloc(256, (bytes + 255u) & ~(size_t)255u) : nullptr; }
 extern "C" void bt_host_free(void* p) { free(p); }

@@ -24,14 +24,56 @@ SRCS = [os.path.join(EMU_DIR, "bt_emu.cpp")] + [os.path.join(ROOT, "bowtie_amd",
 _lib = None
 
 
-def build():
-    tmp = LIB_PATH + ".tmp%d" % os.getpid()
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w"] + DEFS + ["-o", tmp, SRCS[0], SRCS[1]])
-    os.replace(tmp, LIB_PATH)
+def build(path=None, extra=()):
+    path = path or LIB_PATH
+    tmp = path + ".tmp%d" % os.getpid()
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-pthread"] + DEFS + list(extra) + ["-o", tmp, SRCS[0], SRCS[1]])
+    os.replace(tmp, path)
+
+
+# the same sources with 64-bit BWT rows (-DBT_WIDE=1; bowtie_amd/csrc/bt_rank.h "the row type"): what libbowtie_amd_l.so runs
+WIDE_LIB_PATH = os.path.join(EMU_DIR, "libbt_emu_l%s.so" % _SUFFIX)
+_wlib = None
+
+
+def _common_argtypes(L):
+    L.emu_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.emu_index_load.restype = C.c_void_p
+    L.emu_index_free.argtypes = [C.c_void_p]
+    L.emu_rank4_64.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.emu_index_dims.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.emu_index_ref.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.emu_index_ref.restype = C.c_longlong
+    L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
+                                  C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 5
+
+
+def wide_lib():
+    global _wlib
+    if _wlib is None:
+        if not os.path.exists(WIDE_LIB_PATH) or any(os.path.getmtime(WIDE_LIB_PATH) < os.path.getmtime(s) for s in SRCS):
+            build(WIDE_LIB_PATH, ["-DBT_WIDE=1"])
+        L = C.CDLL(WIDE_LIB_PATH)
+        _common_argtypes(L)
+        _wlib = L
+    return _wlib
 
 
 SHIM_PATH = os.path.join(EMU_DIR, "libcli_shim%s.so" % _SUFFIX)
 SHIM_SRCS = [os.path.join(EMU_DIR, "cli_shim.cpp"), os.path.join(EMU_DIR, "bt_emu.cpp")] + SRCS[1:]
+
+
+WIDE_SHIM_PATH = os.path.join(EMU_DIR, "libcli_shim_l%s.so" % _SUFFIX)
+
+
+def wide_shim():
+    """the same for the bowtie-amd-l binary (64-bit rows)"""
+    if not os.path.exists(WIDE_SHIM_PATH) or any(os.path.getmtime(WIDE_SHIM_PATH) < os.path.getmtime(s) for s in SHIM_SRCS):
+        tmp = WIDE_SHIM_PATH + ".tmp%d" % os.getpid()
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-pthread", "-DBT_WIDE=1"] + DEFS + ["-I" + os.path.join(ROOT, "include"), "-o", tmp,
+                               SHIM_SRCS[0], SHIM_SRCS[2]])
+        os.replace(tmp, WIDE_SHIM_PATH)
+    return WIDE_SHIM_PATH
 
 
 def shim():
@@ -52,12 +94,8 @@ def lib():
         if not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in SRCS):
             build()
         L = C.CDLL(LIB_PATH)
-        L.emu_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
-        L.emu_index_load.restype = C.c_void_p
-        L.emu_index_free.argtypes = [C.c_void_p]
+        _common_argtypes(L)
         L.emu_rank4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
-                                      C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 5
         L.emu_align_pairs.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC), C.POINTER(A.ReadBatchC),
                                       C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts), C.c_uint32]
         _lib = L
@@ -65,16 +103,51 @@ def lib():
 
 
 class EmuAligner:
-    def __init__(self, base: str, need_mirror=True, offrate=-1):
-        self.h = lib().emu_index_load(base.encode(), int(need_mirror), offrate)
+    def __init__(self, base: str, need_mirror=True, offrate=-1, wide=False, row_bias=None, seg_shift=None):
+        """wide: the build with 64-bit BWT rows; row_bias / seg_shift: its test knobs (bt_host.h) -- the image's rows numbered
+        from row_bias, 2^seg_shift rank blocks per segment"""
+        self.L = wide_lib() if wide else lib()
+        saved = {k: os.environ.get(k) for k in ("BT_WIDE_ROW_BIAS", "BT_WIDE_SEG_SHIFT")}
+        try:
+            for k, v in (("BT_WIDE_ROW_BIAS", row_bias), ("BT_WIDE_SEG_SHIFT", seg_shift)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = str(v)
+            self.h = self.L.emu_index_load(base.encode(), int(need_mirror), offrate)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if not self.h:
             raise IOError("emu: cannot load " + base)
 
     def rank4(self, row, mirror=False):
-        lf = (C.c_uint32 * 4)()
+        lf = (C.c_uint64 * 4)()
         L = C.c_uint32()
-        lib().emu_rank4(self.h, int(mirror), row, lf, C.byref(L))
+        self.L.emu_rank4_64(self.h, int(mirror), row, lf, C.byref(L))
         return list(lf), int(L.value)
+
+    def refs(self):
+        """([names], [lengths]) of the index's sequences"""
+        names, lens = [], []
+        buf = C.create_string_buffer(4096)
+        t = 0
+        while True:
+            n = self.L.emu_index_ref(self.h, t, buf, 4096)
+            if n < 0:
+                return names, lens
+            names.append(buf.value.decode())
+            lens.append(int(n))
+            t += 1
+
+    def dims(self):
+        """(text length, row bias, bytes per row)"""
+        d = (C.c_uint64 * 3)()
+        self.L.emu_index_dims(self.h, d)
+        return int(d[0]), int(d[1]), int(d[2])
 
     def align(self, pol: A.Policy, batch: ReadBatch, hit_cap=None, mm_per_hit=8, counts=None,
               n_lanes=64, fr_cap=64, ent_cap=None, pal_cap=1024, no_rl=False, lite=False):
@@ -92,7 +165,7 @@ class EmuAligner:
         rb = A.ReadBatchC(n, batch.stride, seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, seed.ctypes.data)
         hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data,
                          pool.ctypes.data, len(pool), 0)
-        rc = lib().emu_align_batch(self.h, C.byref(pol), C.byref(rb), C.byref(hb),
+        rc = self.L.emu_align_batch(self.h, C.byref(pol), C.byref(rb), C.byref(hb),
                                    C.byref(counts) if counts is not None else None,
                                    n_lanes, fr_cap, ent_cap, pal_cap, 2 if lite else int(no_rl))
         if rc != 0:
@@ -112,7 +185,7 @@ class EmuAligner:
         status = np.zeros(n, dtype=np.uint8)
         pool = np.zeros(max(1, n * hit_cap * mm_per_hit), dtype=np.uint16)
         hb = A.HitBatchC(hit_cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, pool.ctypes.data, len(pool), 0)
-        rc = lib().emu_align_pairs(self.h, C.byref(pol), C.byref(rb1), C.byref(rb2), C.byref(hb),
+        rc = self.L.emu_align_pairs(self.h, C.byref(pol), C.byref(rb1), C.byref(rb2), C.byref(hb),
                                    C.byref(counts) if counts is not None else None, arena_words)
         if rc != 0:
             raise RuntimeError("emu_align_pairs rc=%d" % rc)

@@ -28,6 +28,18 @@ def test_library_exports_every_declared_symbol():
     assert set(AL.EXPORTS) == set(names)
 
 
+def test_the_64_bit_row_library_exports_the_same_abi():
+    """libbowtie_amd_l.so: the same sources compiled with -DBT_WIDE=1 (the reference's bowtie-align-l), the same entry points"""
+    L = C.CDLL(os.path.join(os.path.dirname(AL.LIB_PATH), "libbowtie_amd_l.so"))
+    for n in declared_functions():
+        assert hasattr(L, n), "libbowtie_amd_l.so does not export " + n
+    assert L.bt_rows64() == 1 and AL.lib().bt_rows64() == 0
+    L.bt_version.restype = C.c_char_p
+    assert b"64-bit rows" in L.bt_version()
+    L.bt_strerror.restype = C.c_char_p
+    assert b"64-bit" in L.bt_strerror(A.BT_ERR_ROWS64) and b"--best" in L.bt_strerror(A.BT_ERR_UNSUPPORTED)
+
+
 def test_struct_sizes():
     assert C.sizeof(A.HitC) == 24
     assert C.sizeof(A.Policy) == 88

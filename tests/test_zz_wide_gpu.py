@@ -1,0 +1,87 @@
+"""libbowtie_amd_l.so / bowtie-amd-l on the GPU: the build with 64-bit BWT rows (the reference's bowtie-align-l),
+through the C ABI and through the binary, rows numbered on either side of 2^32 (tests/test_wide_rows_emu.py explains the bias).
+Runs last (the name): this library was written after the round's measurements and has had 88 GPU-seconds (profiles/r5/
+wide_rows_gpu.txt: the checks below, run from tests/wide_gpu_check.py and scripts/r5/wide_gpu_smoke.sh; the sweep over the plain
+goldens did not finish inside them) -- the CPU suite runs the same sources through the host build -- and a failure here must
+not hide the rest of the suite under -x."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+import common as T
+
+pytestmark = pytest.mark.gpu
+
+SEG_SHIFT = 4
+
+
+def _bias(name):
+    half = int(T.oracle_index(name).fw.len) // 2
+    g = 1 << (SEG_SHIFT + 6)
+    return (1 << 32) - (half // g) * g
+
+
+def _env(bias_of=None):
+    env = dict(os.environ, BT_LIB="libbowtie_amd_l.so")
+    env.pop("BT_WIDE_ROW_BIAS", None)
+    env.pop("BT_WIDE_SEG_SHIFT", None)
+    if bias_of:
+        env["BT_WIDE_ROW_BIAS"] = str(_bias(bias_of))
+        env["BT_WIDE_SEG_SHIFT"] = str(SEG_SHIFT)
+    return env
+
+
+def _run(args, env):
+    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "tests", "wide_gpu_check.py")] + args, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert p.returncode == 0 and b": ok, " in p.stdout, p.stdout.decode()[-4000:]
+
+
+@pytest.mark.parametrize("biased", [False, True], ids=["plain", "biased"])
+@pytest.mark.parametrize("name", ["e_coli", "multi"])
+def test_gpu_wide_rank_vs_oracle(name, biased):
+    _run(["rank", name], _env(name if biased else None))
+
+
+@pytest.mark.parametrize("biased", [False, True], ids=["plain", "biased"])
+def test_gpu_wide_matches_reference_sam(biased):
+    """the golden SAMs of the phase-program modes, e_coli and multi (the bias is multi's: any multiple of the segment size
+    does for e_coli too)"""
+    _run(["golden"], _env("multi" if biased else None))
+
+
+@pytest.mark.parametrize("biased", [False, True], ids=["plain", "biased"])
+def test_gpu_wide_on_large_index_matches_bowtie_align_l(biased):
+    _run(["family"], _env("multi" if biased else None))
+
+
+def test_gpu_wide_vs_oracle_ragged_with_op_counts():
+    _run(["ragged"], _env("multi"))
+
+
+def test_gpu_wide_second_pass():
+    _run(["second_pass"], _env("e_coli"))
+
+
+def test_gpu_wide_build_answers_unsupported_for_the_best_first_engine():
+    _run(["unsupported"], _env(None))
+
+
+def test_cli_l_on_large_index_is_byte_identical_to_bowtie_align_l(tmp_path):
+    """bowtie-amd-l -x multi_l (the streamed path, carry-over, ticks): the SAM of the binary, end to end, rows biased"""
+    import test_index_family as FAM
+    from bowtie_amd.synth import write_fastq
+    binp = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd-l")
+    fq = str(tmp_path / "r.fq")
+    env = _env("multi")
+    env.pop("BT_LIB")
+    for run in [r for r in FAM.fam()["runs"] if (r["reads"], r["mode"]) in (("syn36", "n2"), ("syn100", "v2"), ("syn50lowq", "n3_y"))]:
+        write_fastq(T.read_set("multi", run["reads"]), fq)
+        p = subprocess.run([binp, "-S", "--sam-nohead"] + run["args"] + ["-x", FAM.LARGE, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()
+        assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]
+    p = subprocess.run([binp, "-S", "--best", "-x", FAM.LARGE, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode != 0 and b"64-bit rows" in p.stderr, p.stderr.decode()
