@@ -1737,7 +1737,7 @@ extern "C" const char* bt_strerror(int code)
 	case BT_ERR_OVERFLOW: return "per-read scratch capacity exceeded";
 	case BT_ERR_READS: return "malformed read input";
 	case BT_ERR_ROWS64: return "the index has 2^32-1 rows or more: use the build with 64-bit rows (libbowtie_amd_l.so, bowtie-amd-l)";
-	case BT_ERR_UNSUPPORTED: return "not in this build (the build with 64-bit rows has neither --best nor paired-end alignment yet)";
+	case BT_ERR_UNSUPPORTED: return "not in this build (the build with 64-bit rows has bt_probe_rank64 instead of the 32-bit probes, and no gather benchmark)";
 	default: return "unknown error";
 	}
 }

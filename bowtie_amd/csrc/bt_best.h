@@ -147,7 +147,10 @@ struct BtRefDev {
 	uint32_t nRefs, pad;
 };
 
-/* ---- record layouts (word indices) ---------------------------------------------------------- */
+/* ---- record layouts (word indices) ----------------------------------------------------------
+ * A BWT row takes BF_RW 32-bit words of a record: one, or two (low word first) in the build with 64-bit rows (bt_rank.h,
+ * "the row type"); everything else is the same in both. */
+#define BF_RW ((uint32_t)sizeof(bt_row) / 4u)
 #define BF_DRW 32u
 enum {
 	DR_KIND = 0,       /* kind | fw<<8 | mate<<9 | spec<<16                                        */
@@ -157,7 +160,7 @@ enum {
 	LF_HEAP, LF_HEAPSZ /* sz | cap<<16 */, LF_BP /* bpCur | bpPool<<16 */, LF_BPLAST /* lastCur[0] | lastCur[1]<<16 */,
 	LF_PMCOST, LF_RND, LF_QLEN /* qlen | len<<16 */, LF_REV01, LF_REV23, LF_D53 /* depth5 | depth3<<16 */,
 	LF_RSFLAGS         /* 1 rs.done, 2 rs.foundRange, 4 skippingThisRead, 8 seedRange valid        */,
-	LF_CURTOP, LF_CURBOT, LF_CURCOST /* cost | numMms<<16 */, LF_CURBR /* branch whose edits the range carries */,
+	LF_CURTOP, LF_CURBOT = LF_CURTOP + BF_RW, LF_CURCOST = LF_CURBOT + BF_RW /* cost | numMms<<16 */, LF_CURBR /* branch whose edits the range carries */,
 	LF_SEED            /* seedRange: cost | n<<16 */, LF_SEEDMM0, LF_SEEDMM1, LF_SEEDMM2 /* mms | refc<<16 */,
 	/* cost-aware (CostAwareRangeSourceDriver) */
 	CA_RSS = 3, CA_NRSS /* n | cap<<16 */, CA_ACT, CA_NACT, CA_RND, CA_LAST, CA_DELAYED, CA_OPTS /* 1 strandFix, 2 patsrc set */,
@@ -168,17 +171,22 @@ enum {
 #define BF_F_DONE 1u
 #define BF_F_FOUND 2u
 
+#if BT_WIDE
+#define BF_BRW 20u     /* five 16-byte pieces: [id d01 d23 rdlen] [costham top] [bot flags] ... as the indices below fall */
+#else
 #define BF_BRW 16u
-enum { BR_ID = 0, BR_D01, BR_D23, BR_RDLEN /* rdepth | len<<16 */, BR_COSTHAM /* cost | ham<<16 */, BR_TOP, BR_BOT,
-       BR_FLAGS /* 1 curtailed 2 exhausted 4 delayedIncrease 8 ltop valid 16 lbot valid | delayedCost<<16 */,
-       BR_LTOP, BR_LBOT, BR_ALT, BR_NALT, BR_PARENT, BR_EDIT /* pos | refc<<10 | nedits<<16 */, BR_HILO /* hi | lo<<16 */ };
+#endif
+enum { BR_ID = 0, BR_D01, BR_D23, BR_RDLEN /* rdepth | len<<16 */, BR_COSTHAM /* cost | ham<<16 */, BR_TOP, BR_BOT = BR_TOP + BF_RW,
+       BR_FLAGS = BR_BOT + BF_RW /* 1 curtailed 2 exhausted 4 delayedIncrease 8 ltop valid 16 lbot valid | delayedCost<<16 */,
+       BR_LTOP, BR_LBOT = BR_LTOP + BF_RW, BR_ALT = BR_LBOT + BF_RW, BR_NALT, BR_PARENT, BR_EDIT /* pos | refc<<10 | nedits<<16 */, BR_HILO /* hi | lo<<16 */ };
 #define BRF_CURTAILED 1u
 #define BRF_EXHAUSTED 2u
 #define BRF_DELAYED 4u
 #define BRF_LTOP 8u
 #define BRF_LBOT 16u
 
-#define BF_ALW 10u     /* tops[4] bots[4] info pad; info = i | quallo<<16 | elim mask<<24 | eliminated<<28 */
+#define BF_ALW (8u * BF_RW + 2u)     /* tops[4] bots[4] info pad; info = i | quallo<<16 | elim mask<<24 | eliminated<<28 */
+#define BF_ALI (8u * BF_RW)          /* the info word's index in an alternative's record */
 #define BF_RESERVED 64u
 /* AllocOnlyPool<Branch>: 256 KB chunk / sizeof(Branch) (pool.h:32,198): 136 bytes in the 32-bit build, 160 in the
  * 64-bit one (BtIndexDev::wide) */
@@ -186,8 +194,14 @@ enum { BR_ID = 0, BR_D01, BR_D23, BR_RDLEN /* rdepth | len<<16 */, BR_COSTHAM /*
 #define BF_ADV_COST_CHANGES 2
 
 struct BfChase {                  /* RangeChaser + RowChaser state */
-	uint32_t mirror, qlen, top, bot, irow, row, tidx, toff, done, cDone, cRow, cJumps, cOff;
+	uint32_t mirror, qlen;
+	bt_row   top, bot, irow, row;
+	uint32_t tidx, toff, done, cDone;
+	bt_row   cRow;
+	uint32_t cJumps;
+	bt_row   cOff;                /* offset in the joined text */
 };
+#define BF_NONE32 0xffffffffu     /* "no sequence" in a chaser's tidx / toff (BT_OFF_MASK where rows are 32 bits) */
 
 struct BfRead { BF_G const uint8_t* seq; BF_G const uint8_t* qual; uint32_t len, seed; };
 
@@ -209,10 +223,19 @@ struct BfLane {                   /* per-lane registers / private memory */
 };
 
 #define AW(o) (X.A[(o)])
+/* a row in the arena (AR) / in a register copy of a record (RR) */
+#if BT_WIDE
+#define AR(o) ((bt_row)(uint32_t)AW(o) | ((bt_row)(uint32_t)AW((o) + 1u) << 32))
+#define AR_SET(o, v) do { const bt_row ar_v_ = (v); const uint32_t ar_o_ = (o); AW(ar_o_) = (uint32_t)ar_v_; AW(ar_o_ + 1u) = (uint32_t)(ar_v_ >> 32); } while (0)
+#define RR(R, i) ((bt_row)(R)[(i)] | ((bt_row)(R)[(i) + 1u] << 32))
+#define RR_SET(R, i, v) do { const bt_row rr_v_ = (v); (R)[(i)] = (uint32_t)rr_v_; (R)[(i) + 1u] = (uint32_t)(rr_v_ >> 32); } while (0)
+#else
+#define AR(o) AW(o)
+#define AR_SET(o, v) (AW(o) = (v))
+#define RR(R, i) ((R)[(i)])
+#define RR_SET(R, i, v) ((R)[(i)] = (v))
+#endif
 
-/* (the wide build -- 64-bit BWT rows, bt_rank.h "the row type" -- keeps the types above, so that the ABI layer compiles
- * unchanged, and leaves the engine out: bt_ctx_create answers BT_ERR_UNSUPPORTED for --best and for pairs there) */
-#if !BT_WIDE
 BF_INL uint32_t bf_rnd(uint32_t& last)                       /* RandomSource::nextU32, random_source.h:45-54 */
 {
 	last = 1664525u * last + 1013904223u;
@@ -263,21 +286,32 @@ BF_INL uint32_t br_nedits(BfLane& X, uint32_t b) { return AW(b + BR_EDIT) >> 16;
 /* Branch::prep and the locus part of Branch::init (range_source.h:559-566, 946-954) */
 BF_INL void br_prep(BfLane& X, uint32_t b)
 {
-	const uint32_t top = AW(b + BR_TOP), bot = AW(b + BR_BOT);
+	const bt_row top = AR(b + BR_TOP), bot = AR(b + BR_BOT);
 	uint32_t f = AW(b + BR_FLAGS);
-	if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; AW(b + BR_LTOP) = top; AW(b + BR_LBOT) = bot; }
-	else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; AW(b + BR_LTOP) = top; }
+	if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; AR_SET(b + BR_LTOP, top); AR_SET(b + BR_LBOT, bot); }
+	else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; AR_SET(b + BR_LTOP, top); }
 	AW(b + BR_FLAGS) = f;
 }
 
 /* Branch::init (range_source.h:527-604) */
 BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32_t rdepth, uint32_t len, uint32_t cost,
-                      uint32_t ham, uint32_t top, uint32_t bot, uint32_t parent, uint32_t edit, uint32_t hilo)
+                      uint32_t ham, bt_row top, bt_row bot, uint32_t parent, uint32_t edit, uint32_t hilo)
 {
 	/* branch records start on a 16-byte boundary: leaf_advance_branch reads one in four 16-byte pieces */
 	if (X.top & 3u) (void)bf_alloc(X, 4u - (X.top & 3u));
 	const uint32_t b = bf_alloc(X, BF_BRW);
 	/* the record in four 16-byte stores, prepped from the values at hand (br_prep reads back what was just stored) */
+#if BT_WIDE
+	{
+		/* the wide build's record (five pieces; rows are two words): word by word, prepped */
+		for (uint32_t k = 0; k < BF_BRW; k++) AW(b + k) = 0;
+		AW(b + BR_ID) = id; AW(b + BR_D01) = d01; AW(b + BR_D23) = d23;
+		AW(b + BR_RDLEN) = rdepth | (len << 16); AW(b + BR_COSTHAM) = (cost & 0xffffu) | (ham << 16);
+		AR_SET(b + BR_TOP, top); AR_SET(b + BR_BOT, bot);
+		AW(b + BR_PARENT) = parent; AW(b + BR_EDIT) = edit; AW(b + BR_HILO) = hilo;
+		br_prep(X, b);
+	}
+#else
 	{
 		uint32_t f = 0, lt = 0, lb = 0;
 		if (bot > top + 1u) { f = BRF_LTOP | BRF_LBOT; lt = top; lb = bot; }
@@ -289,14 +323,7 @@ BF_FN uint32_t br_new(BfLane& X, uint32_t id, uint32_t d01, uint32_t d23, uint32
 		q3.x = parent; q3.y = edit; q3.z = hilo; q3.w = 0;
 		bt_st4((void*)(X.A + b), q0); bt_st4((void*)(X.A + b + 4u), q1); bt_st4((void*)(X.A + b + 8u), q2); bt_st4((void*)(X.A + b + 12u), q3);
 	}
-	X.c_frames++;
-	return b;
-	AW(b + BR_ID) = id; AW(b + BR_D01) = d01; AW(b + BR_D23) = d23;
-	AW(b + BR_RDLEN) = rdepth | (len << 16); AW(b + BR_COSTHAM) = (cost & 0xffffu) | (ham << 16);
-	AW(b + BR_TOP) = top; AW(b + BR_BOT) = bot; AW(b + BR_FLAGS) = 0;
-	AW(b + BR_LTOP) = 0; AW(b + BR_LBOT) = 0; AW(b + BR_ALT) = 0; AW(b + BR_NALT) = 0;
-	AW(b + BR_PARENT) = parent; AW(b + BR_EDIT) = edit; AW(b + BR_HILO) = hilo;
-	br_prep(X, b);
+#endif
 	X.c_frames++;
 	return b;
 }
@@ -321,7 +348,11 @@ BF_INL BfKey bf_key(BfLane& X, uint32_t b)
 	const BtU4 q0 = bt_ld4((const void*)(X.A + b)), q1 = bt_ld4((const void*)(X.A + b + 4u));
 	BfKey k;
 	k.id = q0.x; k.depth = ((q0.w & 0xffffu) + (q0.w >> 16)) & 0xffffu;
+#if BT_WIDE
+	k.cost = q1.x & 0xffffu; k.un = ((uint32_t)AW(b + BR_FLAGS) & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0 ? 1u : 0u;
+#else
 	k.cost = q1.x & 0xffffu; k.un = (q1.w & (BRF_CURTAILED | BRF_EXHAUSTED)) != 0 ? 1u : 0u;
+#endif
 	return k;
 }
 BF_INL bool bf_before_k(const BfKey& a, const BfKey& b)        /* bf_before on fetched keys */
@@ -432,7 +463,7 @@ BF_FNI void pm_curtail_regs(BfLane& X, uint32_t d, uint32_t br, uint32_t seedLen
 	for (uint32_t k0 = 0; k0 < n; k0 += 8u) {
 		/* eight alternatives' info words in flight at a time (they sit ten words apart) */
 		uint32_t in8[8];
-		for (uint32_t j = 0; j < 8u; j++) in8[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
+		for (uint32_t j = 0; j < 8u; j++) in8[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + BF_ALI) : (1u << 28);
 		for (uint32_t j = 0; j < 8u; j++) {
 			const uint32_t info = in8[j];
 			if (info >> 28) continue;
@@ -462,12 +493,16 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 		const BtU4 r2 = bt_ld4((const void*)(X.A + b + 8u)), r3 = bt_ld4((const void*)(X.A + b + 12u));
 		P[0] = r0.x; P[1] = r0.y; P[2] = r0.z; P[3] = r0.w; P[4] = r1.x; P[5] = r1.y; P[6] = r1.z; P[7] = r1.w;
 		P[8] = r2.x; P[9] = r2.y; P[10] = r2.z; P[11] = r2.w; P[12] = r3.x; P[13] = r3.y; P[14] = r3.z; P[15] = r3.w;
+#if BT_WIDE
+		const BtU4 r4 = bt_ld4((const void*)(X.A + b + 16u));
+		P[16] = r4.x; P[17] = r4.y; P[18] = r4.z; P[19] = r4.w;
+#endif
 	}
 	const uint32_t alt = P[BR_ALT], n = P[BR_NALT], rdepth = P[BR_RDLEN] & 0xffffu;
 	uint32_t tied[3] = {0, 0, 0}, numTied = 0, numNotElim = 0, best = 0xffffu, next = 0xffffu;
 	for (uint32_t k0 = 0; k0 < n; k0 += 8u) {
 		uint32_t in8[8];
-		for (uint32_t j = 0; j < 8u; j++) in8[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + 8u) : (1u << 28);
+		for (uint32_t j = 0; j < 8u; j++) in8[j] = k0 + j < n ? (uint32_t)AW(alt + (k0 + j) * BF_ALW + BF_ALI) : (1u << 28);
 		for (uint32_t j = 0; j < 8u; j++) {
 			const uint32_t info = in8[j], k = k0 + j;
 			if (info >> 28) continue;
@@ -483,23 +518,30 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 	uint32_t r = 0;
 	if (numTied > 1u) r = PM_RND(X, d) % numTied;
 	const uint32_t rec = alt + tied[r] * BF_ALW;
+#if BT_WIDE
+	bt_row W[8];
+	for (uint32_t k = 0; k < 8u; k++) W[k] = AR(rec + k * BF_RW);
+	uint32_t info = AW(rec + BF_ALI);
+#else
 	uint32_t W[9];
 	for (uint32_t k = 0; k < 9u; k++) W[k] = AW(rec + k);
 	uint32_t info = W[8];
+#endif
 	const uint32_t pos = info & 0xffffu;
 	uint32_t mask = (info >> 24) & 0xfu;
 	const uint32_t num = 4u - (uint32_t)__builtin_popcount(mask);
 	uint32_t chr = 0, last = 0;
 	if (num > 1u) {
-		uint32_t tot = 0;
+		/* (range_source.h:341, 417: the total is a TIndexOffU, the dart a 32-bit draw modulo it) */
+		bt_row tot = 0;
 		for (uint32_t c = 0; c < 4u; c++) if (!((mask >> c) & 1u)) tot += W[4u + c] - W[c];
-		uint32_t dart = PM_RND(X, d) % tot;
+		uint32_t dart = (uint32_t)(PM_RND(X, d) % tot);
 		for (uint32_t c = 0; c < 4u; c++) {
 			if ((mask >> c) & 1u) continue;
-			const uint32_t w = W[4u + c] - W[c];
+			const bt_row w = W[4u + c] - W[c];
 			chr = c;
 			if (c == 3u || dart < w) break;
-			dart -= w;
+			dart -= (uint32_t)w;
 		}
 		mask |= 1u << chr;
 		info = (info & ~(0xfu << 24)) | (mask << 24);
@@ -508,8 +550,8 @@ BF_FN uint32_t br_split(BfLane& X, uint32_t d, uint32_t b, uint32_t seedLen, uin
 		chr = !(mask & 1u) ? 0u : !(mask & 2u) ? 1u : !(mask & 4u) ? 2u : 3u;
 		info |= 1u << 28;
 	}
-	AW(rec + 8u) = info;
-	const uint32_t top = W[chr], bot = W[4u + chr];
+	AW(rec + BF_ALI) = info;
+	const bt_row top = W[chr], bot = W[4u + chr];
 	const uint32_t depth = pos + rdepth;
 	const uint32_t d01 = P[BR_D01], d23 = P[BR_D23];
 	const uint32_t d0 = d01 & 0xffffu, d1 = d01 >> 16, d2 = d23 & 0xffffu, d3 = d23 >> 16;
@@ -725,10 +767,10 @@ BF_FN void leaf_set_query(BfLane& X, uint32_t d, uint32_t seedSrc)
 				off = chr(a);
 				for (uint32_t i = ftabChars - 1u; i > 0; i--) off = (off << 2) | chr(qlen - i);
 			}
-			const uint32_t top = bt_ftab_hi(ix, off), bot = bt_ftab_lo(ix, off + 1u);
+			const bt_row top = bt_ftab_hi(ix, off), bot = bt_ftab_lo(ix, off + 1u);
 			X.c_ftab++;
 			if (qlen == ftabChars && bot > top) {
-				AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
+				AR_SET(d + LF_CURTOP, top); AR_SET(d + LF_CURBOT, bot);
 				AW(d + LF_CURCOST) = icost | ((valid ? (AW(d + LF_SEED) >> 16) : 0u) << 16);
 				AW(d + LF_CURBR) = 0;
 				rsf |= 2u;
@@ -769,7 +811,8 @@ struct BfLeafSt {
 	uint32_t seedN, seedM[3];     /* the seed's edits the query carries (seedEdits): fixed while the leaf advances */
 	uint32_t br, R[BF_BRW];       /* the queue's front and its record */
 	uint32_t cost, nedits, rdepth;/* of that branch: fixed while it is extended */
-	uint32_t top, bot, pfC, pfQ;
+	bt_row   top, bot;
+	uint32_t pfC, pfQ;
 	bool seedEdits, found, curtail, extended, tbNew, dirty, havePf;
 };
 
@@ -801,6 +844,10 @@ BF_FNI void la_front(BfLane& X, BfLeafSt& S)
 		const BtU4 r2 = bt_ld4((const void*)(X.A + br + 8u)), r3 = bt_ld4((const void*)(X.A + br + 12u));
 		R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
 		R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
+#if BT_WIDE
+		const BtU4 r4 = bt_ld4((const void*)(X.A + br + 16u));
+		R[16] = r4.x; R[17] = r4.y; R[18] = r4.z; R[19] = r4.w;
+#endif
 	}
 	S.br = br;
 	S.cost = R[BR_COSTHAM] & 0xffffu;
@@ -826,7 +873,7 @@ BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 	const uint32_t blen = R[BR_RDLEN] >> 16;
 	const uint32_t depth = rdepth + blen;
 	uint32_t cur = 0;
-	uint32_t top = R[BR_TOP], bot = R[BR_BOT];
+	bt_row top = RR(R, BR_TOP), bot = RR(R, BR_BOT);
 	bool curtail = false, extended = false, tbNew = false;
 	bool hit = false;
 	/* hhCheckTop (:2444-2475) */
@@ -847,10 +894,10 @@ BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 			const uint32_t ham = R[BR_COSTHAM] >> 16;
 			const uint32_t d0 = R[BR_D01] & 0xffffu;
 			const bool alt = depth >= d0 && ham + q <= sp.qualLim;
-			uint32_t otop = top;
+			bt_row otop = top;
 			if (c == 4u && depth > 0) top = bot = 1;
 			const uint32_t fl = R[BR_FLAGS];
-			uint32_t tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
+			bt_row tops[4] = {0, 0, 0, 0}, bots[4] = {0, 0, 0, 0};
 			bool ranges = false;
 			/* which LF-mapping the step needs is decided first, the rows' rank blocks are fetched at ONE place in the code --
 			 * the lanes of a wavefront that are stepping, whatever their cases, wait for them once -- and the case is
@@ -871,8 +918,8 @@ BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 				if (c < 4u) lfCase = (top + 1u == bot) ? 3u : 4u;
 			}
 			if (lfCase) {
-				uint32_t la[4], lb[4] = {0, 0, 0, 0}, LA, LB;
-				const uint32_t ra = R[BR_LTOP], rb = R[BR_LBOT];
+				bt_row la[4], lb[4] = {0, 0, 0, 0}; uint32_t LA, LB;
+				const bt_row ra = RR(R, BR_LTOP), rb = RR(R, BR_LBOT);
 				const bool two = lfCase == 1u || lfCase == 4u;
 				bt_rank4(ix, ra, la, &LA);
 				if (two) bt_rank4(ix, rb, lb, &LB);
@@ -905,8 +952,8 @@ BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 					if (nalt == 0) { AW(br + BR_ALT) = rec; X.growing = br; }
 					else if (X.growing != br || rec != R[BR_ALT] + nalt * BF_ALW) X.ovf = 2;   /* contiguity broken: a bug */
 					if (!X.ovf) {
-						for (uint32_t k = 0; k < 4u; k++) { AW(rec + k) = tops[k]; AW(rec + 4u + k) = bots[k]; }
-						AW(rec + 8u) = blen | (q << 16) | (mask << 24);
+						for (uint32_t k = 0; k < 4u; k++) { AR_SET(rec + k * BF_RW, tops[k]); AR_SET(rec + (4u + k) * BF_RW, bots[k]); }
+						AW(rec + BF_ALI) = blen | (q << 16) | (mask << 24);
 						AW(br + BR_NALT) = nalt + 1u;
 						if (nalt == 0) R[BR_ALT] = rec;
 						R[BR_NALT] = nalt + 1u;
@@ -931,7 +978,7 @@ BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 		}
 		if (!hhOk) { curtail = true; hit = false; }
 		else if (hit && !invalidExact) {
-			AW(d + LF_CURTOP) = top; AW(d + LF_CURBOT) = bot;
+			AR_SET(d + LF_CURTOP, top); AR_SET(d + LF_CURBOT, bot);
 			AW(d + LF_CURCOST) = cost | ((nedits + (S.seedEdits ? S.seedN : 0u)) << 16);
 			AW(d + LF_CURBR) = br;
 			S.found = true;
@@ -943,9 +990,9 @@ BF_FNI bool la_step(BfLane& X, BfLeafSt& S)
 	if (!(extended && !X.ovf && (R[BR_FLAGS] & (BRF_DELAYED | BRF_CURTAILED)) == 0 && !(sp.useBtCnt != 0 && X.btCnt == 0))) return false;
 	/* splitAndPrep on an untouched queue whose front is this branch does one thing, prep: done on the registers */
 	uint32_t f = R[BR_FLAGS];
-	if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; R[BR_LTOP] = top; R[BR_LBOT] = bot; }
-	else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; R[BR_LTOP] = top; }
-	R[BR_FLAGS] = f; R[BR_TOP] = top; R[BR_BOT] = bot;
+	if (bot > top + 1u) { f |= BRF_LTOP | BRF_LBOT; RR_SET(R, BR_LTOP, top); RR_SET(R, BR_LBOT, bot); }
+	else if (bot > top) { f = (f | BRF_LTOP) & ~BRF_LBOT; RR_SET(R, BR_LTOP, top); }
+	R[BR_FLAGS] = f; RR_SET(R, BR_TOP, top); RR_SET(R, BR_BOT, bot);
 	S.dirty = true;
 #if defined(BF_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
 	if ((uint32_t)AW(PMW(LF_HEAP)) != br || X.pm[6] != br || PMW(LF_PMCOST) != cost) { fprintf(stderr, "BF_CHECK: the extended branch is not the queue's front\n"); abort(); }
@@ -960,9 +1007,9 @@ BF_FNI bool la_send(BfLane& X, BfLeafSt& S)
 	const BfSpec& sp = X.P->specs[S.spec];
 	const uint32_t d = S.d, br = S.br;
 	const uint32_t* R = S.R;
-	if (S.tbNew) { AW(br + BR_TOP) = S.top; AW(br + BR_BOT) = S.bot; }
-	else if (S.dirty) { AW(br + BR_TOP) = R[BR_TOP]; AW(br + BR_BOT) = R[BR_BOT]; }
-	if (S.dirty) { AW(br + BR_FLAGS) = R[BR_FLAGS]; AW(br + BR_LTOP) = R[BR_LTOP]; AW(br + BR_LBOT) = R[BR_LBOT]; }
+	if (S.tbNew) { AR_SET(br + BR_TOP, S.top); AR_SET(br + BR_BOT, S.bot); }
+	else if (S.dirty) { AR_SET(br + BR_TOP, RR(R, BR_TOP)); AR_SET(br + BR_BOT, RR(R, BR_BOT)); }
+	if (S.dirty) { AW(br + BR_FLAGS) = R[BR_FLAGS]; AR_SET(br + BR_LTOP, RR(R, BR_LTOP)); AR_SET(br + BR_LBOT, RR(R, BR_LBOT)); }
 	if (S.dirty || S.extended) AW(br + BR_RDLEN) = R[BR_RDLEN];
 	{ BF_PT0(t_curtail); if (S.curtail) pm_curtail_regs(X, d, br, S.depth3, R); BF_PADD(BP_CURTAIL, t_curtail); }
 	if (X.ovf) return false;
@@ -1199,7 +1246,7 @@ template <int LEVEL> BF_FN bool cost_found_first_range(BfLane& X, uint32_t d, ui
 				}
 				if (dr_found(X, p)) {
 					uint32_t del = child_range(X, p), lastR = r;
-					const uint32_t wd = AW(del + LF_CURBOT) - AW(del + LF_CURTOP), wl = AW(lastR + LF_CURBOT) - AW(lastR + LF_CURTOP);
+					const bt_row wd = AR(del + LF_CURBOT) - AR(del + LF_CURTOP), wl = AR(lastR + LF_CURBOT) - AR(lastR + LF_CURTOP);
 					const uint64_t tot = (uint64_t)wd + wl;
 					const uint32_t rq = (uint32_t)((uint64_t)bf_rnd_at(X, d + CA_RND) % tot);
 					if (rq < wd) { const uint32_t t = lastR; lastR = del; del = t; }
@@ -1552,50 +1599,50 @@ BF_FN void bf_build_tree_v1(BfLane& X, uint32_t tops[4])
 
 /* ---- RowChaser / RangeChaser (row_chaser.h:69-155, range_chaser.h:52-209; no range cache:
  * ebwt_search.cpp passes NULL caches) ------------------------------------------------------------- */
-BF_FN void ch_row_set(BfLane& X, BfChase& c, uint32_t row)
+BF_FN void ch_row_set(BfLane& X, BfChase& c, bt_row row)
 {
 	const BtIndexDev& ix = X.ix[c.mirror];
 	c.cRow = row;
-	if (ix.loc) {
+	if (!BT_WIDE && ix.loc) {
 		/* the index has its locus image (bt_rank.h): the row's offset from the dense suffix array, the walk RowChaser
 		 * would have made (row_chaser.h:69-123) tallied from the table of walk lengths -- it ends at the '$' row, where no
 		 * sample is read, exactly when it is as long as the offset */
 		const uint32_t sa = BT_GP(const uint32_t, ix.loc)[(uint64_t)row * 4u];
-		const uint32_t w = BT_GP(const uint16_t, ix.walk)[sa];
+		const uint32_t w = BT_GP(const uint16_t, ix.walk)[sa];     /* (32-bit rows only: the wide build has no locus image) */
 		c.cOff = sa; c.cDone = 1; c.cJumps = w;
 		X.c_chase += w;
 		if (sa != w) X.c_offs++;
 		return;
 	}
 	if (row == ix.zOff) { c.cOff = 0; c.cDone = 1; return; }
-	if ((row & ix.offMask) == row) { c.cOff = BT_GP(const uint32_t, ix.offs)[row >> ix.offRate]; c.cDone = 1; X.c_offs++; return; }
+	if ((row & ix.offMask) == row) { c.cOff = BT_GP(const bt_row, ix.offs)[row >> ix.offRate]; c.cDone = 1; X.c_offs++; return; }
 	c.cDone = 0; c.cJumps = 0; c.cOff = BT_OFF_MASK;
 }
 BF_FN void ch_row_off(BfLane& X, BfChase& c)
 {
-	uint32_t tidx = BT_OFF_MASK, toff = BT_OFF_MASK;
-	if (!bt_joined_to_text(X.ix[c.mirror], c.qlen, c.cOff, &tidx, &toff, &X.c_rst)) tidx = BT_OFF_MASK;
+	uint32_t tidx = BF_NONE32, toff = BF_NONE32;
+	if (!bt_joined_to_text(X.ix[c.mirror], c.qlen, c.cOff, &tidx, &toff, &X.c_rst)) tidx = BF_NONE32;
 	c.tidx = tidx; c.toff = toff;
 }
-BF_FN void ch_set_row(BfLane& X, BfChase& c, uint32_t row)
+BF_FN void ch_set_row(BfLane& X, BfChase& c, bt_row row)
 {
 	c.row = row;
 	for (;;) {
 		ch_row_set(X, c, c.row);
 		if (!c.cDone) break;
 		ch_row_off(X, c);
-		if (c.tidx != BT_OFF_MASK) return;
+		if (c.tidx != BF_NONE32) return;
 		c.row++;
 		if (c.row == c.bot) c.row = c.top;
 		if (c.row == c.irow) { c.done = 1; return; }
 	}
 }
-BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uint32_t mirror, uint32_t qlen)
+BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, bt_row top, bt_row bot, uint32_t mirror, uint32_t qlen)
 {
 	BF_PT0(t_chase);
 	c.mirror = mirror; c.qlen = qlen; c.top = top; c.bot = bot;
 	c.irow = top + (bf_rnd(X.alRnd) % (bot - top));
-	c.done = 0; c.tidx = BT_OFF_MASK;
+	c.done = 0; c.tidx = BF_NONE32;
 	ch_set_row(X, c, c.irow);
 	BF_PADD(BP_CHASE, t_chase);
 }
@@ -1603,7 +1650,7 @@ BF_FN void ch_set_top_bot(BfLane& X, BfChase& c, uint32_t top, uint32_t bot, uin
  * ch_advance below is this in a loop, the wavefront automaton takes a piece per round */
 BF_FNI void ch_advance_piece(BfLane& X, BfChase& c)
 {
-	c.tidx = BT_OFF_MASK;
+	c.tidx = BF_NONE32;
 	if (c.cDone) {
 		c.row++;
 		if (c.row == c.bot) c.row = c.top;
@@ -1612,12 +1659,12 @@ BF_FNI void ch_advance_piece(BfLane& X, BfChase& c)
 	} else {
 		/* RowChaser::advance: one LF step */
 		const BtIndexDev& ix = X.ix[c.mirror];
-		uint32_t lf[4], L;
+		bt_row lf[4]; uint32_t L;
 		bt_rank4(ix, c.cRow, lf, &L);
 		c.cRow = lf[L];
 		c.cJumps++; X.c_chase++;
 		if (c.cRow == ix.zOff) { c.cOff = c.cJumps; c.cDone = 1; }
-		else if ((c.cRow & ix.offMask) == c.cRow) { c.cOff = BT_GP(const uint32_t, ix.offs)[c.cRow >> ix.offRate] + c.cJumps; c.cDone = 1; X.c_offs++; }
+		else if ((c.cRow & ix.offMask) == c.cRow) { c.cOff = BT_GP(const bt_row, ix.offs)[c.cRow >> ix.offRate] + c.cJumps; c.cDone = 1; X.c_offs++; }
 		if (c.cDone) ch_row_off(X, c);
 	}
 }
@@ -1781,8 +1828,8 @@ BF_FN void bf_read_end(BfLane& X, const BtBatchDev& B, uint32_t mult)
 }
 BF_INL void bf_chase_init(BfChase& ch)
 {
-	ch.mirror = 0; ch.qlen = 0; ch.top = ch.bot = ch.irow = ch.row = 0; ch.tidx = BT_OFF_MASK; ch.toff = 0;
-	ch.done = 0; ch.cDone = 1; ch.cRow = ch.cJumps = ch.cOff = 0;
+	ch.mirror = 0; ch.qlen = 0; ch.top = ch.bot = ch.irow = ch.row = 0; ch.tidx = BF_NONE32; ch.toff = 0;
+	ch.done = 0; ch.cDone = 1; ch.cRow = 0; ch.cJumps = 0; ch.cOff = 0;
 }
 
 /* ---- one read: UnpairedAlignerV2::setQuery + advance() until done (aligner.h:434-567) ---------- */
@@ -1801,12 +1848,12 @@ BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 		BF_PADD(BP_BEGIN, t_begin);
 		while (!done && !X.ovf) {
 			if (chase) {
-				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
-				if (ch.tidx != BT_OFF_MASK) {
+				if (ch.tidx == BF_NONE32 && !ch.done) { ch_advance(X, ch); continue; }
+				if (ch.tidx != BF_NONE32) {
 					const uint32_t leaf = AW(drv + CA_LAST);
-					done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+					done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, (uint32_t)(AR(leaf + LF_CURBOT) - AR(leaf + LF_CURTOP) - 1u),
 					                      !leaf_spec(X, leaf).mirror);
-					ch.tidx = BT_OFF_MASK;
+					ch.tidx = BF_NONE32;
 				} else {
 					chase = false;
 					dr_set(X, drv, BF_F_FOUND, false);
@@ -1817,11 +1864,11 @@ BF_FN void bf_run_read(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				if (dr_found(X, drv)) {
 					const uint32_t leaf = AW(drv + CA_LAST);
 					const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
-					ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
-					if (ch.tidx != BT_OFF_MASK) {
-						done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+					ch_set_top_bot(X, ch, AR(leaf + LF_CURTOP), AR(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
+					if (ch.tidx != BF_NONE32) {
+						done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, (uint32_t)(AR(leaf + LF_CURBOT) - AR(leaf + LF_CURTOP) - 1u),
 						                      !leaf_spec(X, leaf).mirror);
-						ch.tidx = BT_OFF_MASK;
+						ch.tidx = BF_NONE32;
 					}
 					if (!ch.done && !bf_irrelevant(X, cost)) chase = true;
 					else dr_set(X, drv, BF_F_FOUND, false);
@@ -2034,7 +2081,7 @@ BF_FN bool bf_resolve_in_ref_body(BfLane& X, const BtBatchDev& B, uint32_t leaf,
 	if (end - begin < qlen || end < begin) return false;
 	uint32_t result = 0, nmm = 0, stratum = 0;
 	if (!bf_ref_find_one(X, tidx, M, fw ? 1u : 0u, begin, end, pairFw ? pairsFw : pairsRc, toff, mmBuf, &result, &nmm, &stratum)) return false;
-	const uint32_t oms = AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u;     /* both mates carry the anchor's range */
+	const uint32_t oms = (uint32_t)(AR(leaf + LF_CURBOT) - AR(leaf + LF_CURTOP) - 1u);     /* both mates carry the anchor's range */
 	const uint32_t omate = amate1 ? 1u : 0u;
 	/* the found mate: fw-index coordinates (ebwtFw = true), cost = stratum << 14 (aligner.h:1973) */
 	auto emit_found = [&](uint32_t mateNo) {
@@ -2074,12 +2121,12 @@ BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 		BF_PADD(BP_BEGIN, t_begin);
 		while (!done && !X.ovf) {
 			if (chase) {
-				if (ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
-				if (ch.tidx != BT_OFF_MASK) {
+				if (ch.tidx == BF_NONE32 && !ch.done) { ch_advance(X, ch); continue; }
+				if (ch.tidx != BF_NONE32) {
 					/* resolveOutstanding (aligner.h:1849-1871) */
 					const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, pairsFw, pairsRc, mmBuf);
 					if (++attempts > X.P->pairTries || ret) done = true;
-					ch.tidx = BT_OFF_MASK;
+					ch.tidx = BF_NONE32;
 				} else {
 					chase = false;
 					done = dr_done(X, drv);
@@ -2094,7 +2141,7 @@ BF_FN void bf_run_pair(BfLane& X, const BtBatchDev& B, uint32_t rd)
 						dr_set(X, drv, BF_F_FOUND, false);
 						const uint32_t leaf = AW(drv + CA_LAST);
 						const BfSpec& sp = leaf_spec(X, leaf);
-						ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
+						ch_set_top_bot(X, ch, AR(leaf + LF_CURTOP), AR(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
 					}
 				} else done = true;
 			}
@@ -2141,12 +2188,12 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 #define V1_DONE(d)  ((d) == 0u || dr_done(X, (d)))
 		auto chase_range_of = [&](uint32_t top, uint32_t qlen) {
 			const uint32_t leaf = AW(top + CA_LAST);
-			ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, qlen);
+			ch_set_top_bot(X, ch, AR(leaf + LF_CURTOP), AR(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, qlen);
 		};
 		while (!done && !X.ovf) {
 			if (doneFw && doneFwFirst) { o = 1; doneFwFirst = false; attempts = 0; }
 			BfV1Orient& Q = O[o];
-			if ((Q.chaseL || Q.chaseR) && ch.tidx == BT_OFF_MASK && !ch.done) { ch_advance(X, ch); continue; }
+			if ((Q.chaseL || Q.chaseR) && ch.tidx == BF_NONE32 && !ch.done) { ch_advance(X, ch); continue; }
 			bool& donePair = (o == 0) ? doneFw : done;
 			bool returned = false;
 			if (Q.chaseL || Q.chaseR) {
@@ -2155,12 +2202,12 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				bool& chaseMe = sideL ? Q.chaseL : Q.chaseR;
 				bool& chaseOther = sideL ? Q.chaseR : Q.chaseL;
 				bool& delayedOther = sideL ? Q.delayedR : Q.delayedL;
-				if (ch.tidx != BT_OFF_MASK) {
+				if (ch.tidx != BF_NONE32) {
 					if (!done) {
 						done = bf_resolve_in_ref(X, B, AW(drMe + CA_LAST), ch.tidx, ch.toff, pairsFw, pairsRc, mmBuf);
 						if (++attempts > P.pairTries) { donePair = true; returned = true; }
 					}
-					if (!returned) ch.tidx = BT_OFF_MASK;                       /* rchase_->reset() */
+					if (!returned) ch.tidx = BF_NONE32;                       /* rchase_->reset() */
 				} else {
 					chaseMe = false;
 					dr_set(X, drMe, BF_F_FOUND, false);
@@ -2187,7 +2234,7 @@ BF_FN void bf_run_pair_v1(BfLane& X, const BtBatchDev& B, uint32_t rd)
 				if (!dr_found(X, drMe)) BF_ADVANCE_TOP(X, drMe);
 				if (dr_found(X, drMe)) {
 					const uint32_t leaf = AW(drMe + CA_LAST);
-					szMe += AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP);
+					szMe += (uint32_t)(AR(leaf + LF_CURBOT) - AR(leaf + LF_CURTOP));        /* (aligner.h:1216, 1398: a 32-bit tally in the 64-bit build too) */
 					if (szOther == 0 && szMe > 3u) delayedMe = true;                     /* dontReconcile_: aligner.h:1233 */
 					else {
 						if (szMe > symCeil && szOther > symCeil) { donePair = true; continue; }
@@ -2287,12 +2334,12 @@ BF_FNI void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 		for (;;) {
 			if (S.done || X.ovf) { S.phase = BA_END; return; }
 			if (S.chase) {
-				if (ch.tidx == BT_OFF_MASK && !ch.done) { S.phase = BA_CHASE; return; }
-				if (ch.tidx != BT_OFF_MASK) {
+				if (ch.tidx == BF_NONE32 && !ch.done) { S.phase = BA_CHASE; return; }
+				if (ch.tidx != BF_NONE32) {
 					const uint32_t leaf = AW(drv + CA_LAST);
-					S.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+					S.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, (uint32_t)(AR(leaf + LF_CURBOT) - AR(leaf + LF_CURTOP) - 1u),
 					                        !leaf_spec(X, leaf).mirror);
-					ch.tidx = BT_OFF_MASK;
+					ch.tidx = BF_NONE32;
 				} else {
 					S.chase = false;
 					dr_set(X, drv, BF_F_FOUND, false);
@@ -2303,11 +2350,11 @@ BF_FNI void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 				if (dr_found(X, drv)) {
 					const uint32_t leaf = AW(drv + CA_LAST);
 					const uint32_t cost = AW(leaf + LF_CURCOST) & 0xffffu;
-					ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
-					if (ch.tidx != BT_OFF_MASK) {
-						S.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, AW(leaf + LF_CURBOT) - AW(leaf + LF_CURTOP) - 1u,
+					ch_set_top_bot(X, ch, AR(leaf + LF_CURTOP), AR(leaf + LF_CURBOT), leaf_spec(X, leaf).mirror, X.R[0].len);
+					if (ch.tidx != BF_NONE32) {
+						S.done = bf_report_leaf(X, B, leaf, ch.tidx, ch.toff, 0, (uint32_t)(AR(leaf + LF_CURBOT) - AR(leaf + LF_CURTOP) - 1u),
 						                        !leaf_spec(X, leaf).mirror);
-						ch.tidx = BT_OFF_MASK;
+						ch.tidx = BF_NONE32;
 					}
 					if (!ch.done && !bf_irrelevant(X, cost)) S.chase = true;
 					else dr_set(X, drv, BF_F_FOUND, false);
@@ -2326,12 +2373,12 @@ BF_FNI void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 		if (!tail) {
 			if (S.done || X.ovf) { S.phase = BA_END; return; }
 			if (S.chase) {
-				if (ch.tidx == BT_OFF_MASK && !ch.done) { S.phase = BA_CHASE; return; }
-				if (ch.tidx != BT_OFF_MASK) {
+				if (ch.tidx == BF_NONE32 && !ch.done) { S.phase = BA_CHASE; return; }
+				if (ch.tidx != BF_NONE32) {
 					/* resolveOutstanding (aligner.h:1849-1871) */
 					const bool ret = bf_resolve_in_ref(X, B, AW(drv + CA_LAST), ch.tidx, ch.toff, S.pairsFw, S.pairsRc, S.mmBuf);
 					if (++S.attempts > X.P->pairTries || ret) S.done = true;
-					ch.tidx = BT_OFF_MASK;
+					ch.tidx = BF_NONE32;
 				} else {
 					S.chase = false;
 					S.done = dr_done(X, drv);
@@ -2348,7 +2395,7 @@ BF_FNI void bf_auto_run(BfLane& X, const BtBatchDev& B, BfAuto& S)
 			dr_set(X, drv, BF_F_FOUND, false);
 			const uint32_t leaf = AW(drv + CA_LAST);
 			const BfSpec& sp = leaf_spec(X, leaf);
-			ch_set_top_bot(X, ch, AW(leaf + LF_CURTOP), AW(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
+			ch_set_top_bot(X, ch, AR(leaf + LF_CURTOP), AR(leaf + LF_CURBOT), sp.mirror, X.R[sp.mate].len);
 		}
 	}
 }
@@ -2362,7 +2409,7 @@ BF_FNI uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 	if (S.phase == BA_FRONT) { la_front(X, S.leaf); S.phase = BA_STEP; }
 	if (S.phase == BA_STEP) { BF_PT0(t_s); did |= 1u; if (!la_step(X, S.leaf)) S.phase = BA_SEND; BF_PADD(BP_HSTEP, t_s); }
 	if (S.phase == BA_SEND && sendOk) { BF_PT0(t_s); did |= 2u; S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT; BF_PADD(BP_HSEND, t_s); }
-	if (S.phase == BA_CHASE) { BF_PT0(t_s); did |= 4u; ch_advance_piece(X, S.ch); if (S.ch.tidx != BT_OFF_MASK || S.ch.done) S.phase = BA_RUN; BF_PADD(BP_HCHASE, t_s); }
+	if (S.phase == BA_CHASE) { BF_PT0(t_s); did |= 4u; ch_advance_piece(X, S.ch); if (S.ch.tidx != BF_NONE32 || S.ch.done) S.phase = BA_RUN; BF_PADD(BP_HCHASE, t_s); }
 	BF_PADD(BP_HOT, t_hot);
 	return did;
 }
@@ -2395,5 +2442,4 @@ BF_FNI void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk,
 }
 
 #undef AW
-#endif /* !BT_WIDE */
 #endif /* BT_BEST_H_ */

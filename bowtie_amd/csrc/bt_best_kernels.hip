@@ -65,7 +65,6 @@ __device__ unsigned long long bf_prof[3 * 32];      /* bt_best.h: cycles, passes
 		atomicAdd(&A.counts[CN_SAMEPAIR], (unsigned long long)X.c_same); \
 	}
 
-#if !BT_WIDE
 /* every lane its read from start to finish, reads handed out a wavefront at a time: PairedBWAlignerV1's runner, and the
  * others' for comparison (BT_BEST_NESTED=1) */
 __global__ BT_BEST_BOUNDS void bt_best_nested_kernel(BtBestArgs A)
@@ -136,8 +135,6 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 	BT_BEST_EPILOGUE
 }
 
-#endif /* !BT_WIDE */
-
 /* indices of the reads whose status carries `flag`, at most `cap` of them (*count keeps counting) */
 __global__ void bt_collect_flagged_kernel(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, uint32_t cap)
 {
@@ -174,12 +171,7 @@ extern "C" uint32_t bt_best_blocks_per_cu(void)
 
 extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)
 {
-#if BT_WIDE
-	(void)a; (void)nBlocks; (void)stream;
-	return -1;                /* no best-first engine in the wide build (bt_best.h) */
-#else
 	if (a->nested) hipLaunchKernelGGL(bt_best_nested_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
 	else hipLaunchKernelGGL(bt_best_kernel, dim3(nBlocks), dim3(BT_BLOCK), 0, (hipStream_t)stream, *a);
 	return (int)hipGetLastError();
-#endif
 }

@@ -552,11 +552,6 @@ struct TreeBuilder {
 };
 }
 
-#if BT_WIDE
-int bt_host_compile_best(const bt_policy&, BfProgram*) { return BT_ERR_UNSUPPORTED; }
-int bt_host_compile_best_paired(const bt_policy&, BfProgram*) { return BT_ERR_UNSUPPORTED; }
-int bt_host_ref_load(const std::string&, const BtIndexHost&, BtRefHost*, int) { return BT_ERR_UNSUPPORTED; }
-#else
 /* the drivers of one (mate, strand) block, in the order the factories push them.  `paired` selects
  * the Paired*AlignerFactory variants, which differ from the unpaired ones in two places: the
  * nudgeLeft flags of -v 1 (aligner_1mm.h:295-408) and rev1Off of the -v 3 half-and-half driver
@@ -736,4 +731,3 @@ int bt_host_ref_load(const std::string& base, const BtIndexHost& idx, BtRefHost*
 	if ((uint64_t)(t + 1) != nRefs) return BT_ERR_FORMAT;
 	return BT_OK;
 }
-#endif /* !BT_WIDE */

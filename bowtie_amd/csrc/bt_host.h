@@ -76,7 +76,6 @@ int bt_host_compile_program(const bt_policy& pol, BtProgram* prog);
 
 /* The same for the stateful best-first workers (pol.best): the driver tree of
  * Unpaired{Exact,1mm,23mm,Seed}AlignerFactory::create() as a BfProgram (bt_best.h). */
-/* (the wide build -- bt_rank.h, "the row type" -- answers BT_ERR_UNSUPPORTED to the next three) */
 int bt_host_compile_best(const bt_policy& pol, BfProgram* prog);
 /* ... and of Paired*AlignerFactory::create() with --best (PairedBWAlignerV2): both mates' drivers in
  * one cost-aware driver, doubled sink limits, the RefAligner parameters. */

@@ -62,8 +62,9 @@ struct alignas(16) BtU4 { uint32_t x, y, z, w; };
  *     (BtRes, bt_core.h);
  *   - a rank block keeps its 32 bytes: its four counters are relative to the start of the block's SEGMENT (2^segShift blocks,
  *     2^31 rows by default), whose absolute counts sit in a small table (segBase);
- *   - the wide build searches in row space only (no locus image: it would need a 64-bit form of its own) and leaves the
- *     best-first engine and pairs to a later round (BT_ERR_UNSUPPORTED).                                                  */
+ *   - a record of the best-first engine's arena (a branch, an alternative, a leaf's current range: bt_best.h) holds a row in
+ *     two 32-bit words;
+ *   - the wide build searches in row space only (no locus image: it would need a 64-bit form of its own).              */
 #ifndef BT_WIDE
 #define BT_WIDE 0
 #endif

@@ -52,8 +52,8 @@ extern "C" {
                                   exits 1; the message is in bt_reads_error())                */
 #define BT_ERR_ROWS64      8   /* the index has 2^32-1 BWT rows or more: it needs the build with 64-bit rows,
                                   libbowtie_amd_l.so / bowtie-amd-l (the reference's bowtie-align-l, btypes.h:4-28) */
-#define BT_ERR_UNSUPPORTED 9   /* not in this build: the 64-bit-row build has the phase-program engine (-v / -n,
-                                  -k / -a / -m / -M) and neither --best nor pairs yet                             */
+#define BT_ERR_UNSUPPORTED 9   /* not in this build: the 64-bit-row build has no 32-bit probes and no gather benchmark
+                                  (bt_probe_rank64 is its probe); both engines and pairs are in both builds       */
 
 /* ---- policy: exactly the knobs the reference workers read -------------------------------- */
 #define BT_MODE_V 0            /* end-to-end, -v <mms>   (ebwt_search.cpp:3249-3268)          */

@@ -277,7 +277,6 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 }
 
 
-#if !BT_WIDE
 /* bt_best_kernel's loop -- the wavefront automaton of bt_best.h -- for one "wavefront" of W lanes gone through side by side:
  * the same decisions as the kernel's (hot round or cold sweep, new reads, the gate of the ended streaks), its ballots
  * being counts over the lanes.  Checks what the loop has to get right on top of the pieces it calls: every read run
@@ -441,8 +440,6 @@ extern "C" int emu_align_pairs(void* p, const bt_policy* pol, const bt_read_batc
 	return BT_OK;
 }
 
-#endif /* !BT_WIDE */
-
 /* rl_mode: 0 = as the kernel launcher decides (reads of <= BT_RL_MAXLEN bases keep their read in "LDS"),
  * 1 = force the register-window build of the automaton, 2 = the lite layout of the 3-waves build */
 extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hit_batch* out,
@@ -452,11 +449,7 @@ extern "C" int emu_align_batch(void* p, const bt_policy* pol, const bt_read_batc
 	uint32_t maxLen = 0;
 	for (uint32_t i = 0; i < in->n_reads; i++) if (in->len[i] > maxLen) maxLen = in->len[i];
 	/* the stateful best-first workers: entCap doubles as the arena size in words (0 = 4 M words) */
-#if BT_WIDE
-	if (pol->best) return BT_ERR_UNSUPPORTED;
-#else
 	if (pol->best) return emu_run_best(p, pol, in, out, counts, entCap >= 256u ? entCap : (1u << 22));
-#endif
 	/* rl_mode 2 = the 3-waves-per-SIMD layout: read in LDS (<= 104 bases), no candidate caches */
 	if (rl_mode == 2 && maxLen <= BT_RL3_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, true);
 	if (rl_mode == 0 && maxLen <= BT_RL_MAXLEN) return emu_run<true>(p, pol, in, out, counts, nLanes, frCap, entCap, palCap, false);

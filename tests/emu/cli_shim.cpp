@@ -125,15 +125,10 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 {
 	if (!c || !in1 || !in2 || !out) return BT_ERR_ARG;
 	if (in1->n_reads == 0) return BT_OK;
-#if BT_WIDE
-	(void)counts;
-	return BT_ERR_UNSUPPORTED;
-#else
 	std::lock_guard<std::mutex> lock(g_emu_mutex);
 	const int rc = emu_align_pairs(c->ix->emu, &c->pol, in1, in2, out, counts, 0);
 	if (rc != BT_OK) return rc;
 	return worst_status(out, in1->n_reads);
-#endif
 }
 extern "C" void* bt_host_alloc(size_t bytes) { return bytes ? aligned_alloc(256, (bytes + 255u) & ~(size_t)255u) : nullptr; }
 extern "C" void bt_host_free(void* p) { free(p); }

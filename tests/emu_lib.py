@@ -46,6 +46,8 @@ def _common_argtypes(L):
     L.emu_index_ref.restype = C.c_longlong
     L.emu_align_batch.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC),
                                   C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts)] + [C.c_uint32] * 5
+    L.emu_align_pairs.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC), C.POINTER(A.ReadBatchC),
+                                  C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts), C.c_uint32]
 
 
 def wide_lib():
@@ -96,8 +98,6 @@ def lib():
         L = C.CDLL(LIB_PATH)
         _common_argtypes(L)
         L.emu_rank4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        L.emu_align_pairs.argtypes = [C.c_void_p, C.POINTER(A.Policy), C.POINTER(A.ReadBatchC), C.POINTER(A.ReadBatchC),
-                                      C.POINTER(A.HitBatchC), C.POINTER(A.OpCounts), C.c_uint32]
         _lib = L
     return _lib
 

@@ -37,7 +37,7 @@ def test_the_64_bit_row_library_exports_the_same_abi():
     L.bt_version.restype = C.c_char_p
     assert b"64-bit rows" in L.bt_version()
     L.bt_strerror.restype = C.c_char_p
-    assert b"64-bit" in L.bt_strerror(A.BT_ERR_ROWS64) and b"--best" in L.bt_strerror(A.BT_ERR_UNSUPPORTED)
+    assert b"64-bit" in L.bt_strerror(A.BT_ERR_ROWS64) and b"bt_probe_rank64" in L.bt_strerror(A.BT_ERR_UNSUPPORTED)
 
 
 def test_struct_sizes():

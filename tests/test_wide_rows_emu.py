@@ -1,6 +1,6 @@
 """64-bit BWT rows (the reference's bowtie-align-l, btypes.h:4-28), on the CPU: the host build of the per-read
-automaton compiled with -DBT_WIDE=1 -- the sources libbowtie_amd_l.so is built from -- against the oracle and against the
-unmodified reference's outputs.
+automatons (phase programs, best-first engine, pairs) compiled with -DBT_WIDE=1 -- the sources libbowtie_amd_l.so is built
+from -- against the oracle and against the unmodified reference's outputs.
 
 No index of 2^32 rows fits a test suite, so the wide build's loader can number an image's rows from a bias (bt_host.h:
 BT_WIDE_ROW_BIAS) and cut its rank blocks into small segments (BT_WIDE_SEG_SHIFT): a genome of a few Mbp then runs its whole
@@ -89,6 +89,57 @@ def test_wide_emu_matches_reference_sam(run, kind, wide):
     T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
 
 
+@pytest.mark.parametrize("kind", ["plain", "biased"])
+@pytest.mark.parametrize("run", T.paired_runs(), ids=lambda r: r["file"][:-7])
+def test_wide_emu_paired_matches_reference_sam(run, kind, wide):
+    """paired-end with --best (PairedBWAlignerV2 + the window scan on the 2-bit reference) in the wide build"""
+    b1, b2 = T.pair_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = wide[run["index"], kind].align_pairs(A.make_policy(**kw), b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    T.check_pairs_against_golden(run, res, b1, b2, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("kind", ["plain", "biased"])
+@pytest.mark.parametrize("run", T.paired_v1_runs(), ids=lambda r: r["file"][6:-7])
+def test_wide_emu_paired_without_best_matches_reference_sam(run, kind, wide):
+    """... and without --best (PairedBWAlignerV1, the reference's default paired aligner)"""
+    b1, b2 = T.pair_set(run["index"], run["reads"])
+    kw = dict(T.MODES[run["mode"]], pe_v1=True)
+    res = wide[run["index"], kind].align_pairs(A.make_policy(**kw), b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    T.check_pairs_against_golden(run, res, b1, b2, T.oracle_index(run["index"]).refnames)
+
+
+import test_automaton_emu as TA                         # noqa: E402
+
+
+@pytest.mark.parametrize("mode", TA.BEST_RAGGED)
+def test_wide_emu_best_first_vs_oracle_ragged(mode, wide):
+    """ragged 1..150-base reads with Ns and low qualities through the wide best-first engine on biased rows: hits and op
+    counts (same_pair apart: see below) equal the oracle's"""
+    kw = T.MODES[mode]
+    batch = TA.ragged_batch(300, 1, 151, 11)
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+    got = wide["multi", "biased"].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), counts=ec)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames"):
+        assert getattr(ec, f) == getattr(oc, f), (mode, f, getattr(ec, f), getattr(oc, f))
+
+
+@pytest.mark.parametrize("mode", ["pe_n1_best_X500", "pe_n2_best_X400_I250_k3", "pe_v3_best_X500", "pe_n1_a_strata_X500", "pev1_n2_X500", "pev1_n1_X500_a"])
+def test_wide_emu_paired_vs_oracle_counts(mode, wide):
+    kw = T.MODES[mode]
+    v1 = mode.startswith("pev1")
+    b1, b2 = T.pair_set("multi", "pe50")
+    oc, ec = OL.OpCounts(), A.OpCounts()
+    cap = 2048 if kw.get("all_hits") else None
+    want = T.oracle_pair_results("multi", b1, b2, kw, cap=cap, counts=oc, v1=v1)
+    got = wide["multi", "biased"].align_pairs(A.make_policy(**(dict(kw, pe_v1=True) if v1 else kw)), b1, b2, hit_cap=cap, counts=ec)
+    T.compare_results(got, want, mode)
+    for f in ("lfex", "lf2", "lf1", "chase", "ftab", "offs", "rstarts", "frames"):
+        assert getattr(ec, f) == getattr(oc, f), (mode, f, getattr(ec, f), getattr(oc, f))
+
+
 @pytest.mark.parametrize("no_rl", [False, True], ids=["read_in_lds", "register_window"])
 @pytest.mark.parametrize("mode", ["v0", "v1", "v2", "n2", "n3", "n2_k3", "n2_nomaq", "n1_a_m20"])
 def test_wide_emu_vs_oracle_ragged(mode, no_rl, wide):
@@ -114,7 +165,7 @@ def test_wide_emu_vs_oracle_ragged(mode, no_rl, wide):
 
 
 @pytest.mark.parametrize("bias", [False, True], ids=["plain", "biased"])
-@pytest.mark.parametrize("run", [r for r in FAM.fam()["runs"] if r["reads"] in ("syn36", "syn150", "syn50lowq") and _phase_program(r["mode"])],
+@pytest.mark.parametrize("run", [r for r in FAM.fam()["runs"] if r["reads"] in ("syn36", "syn150", "syn50lowq")],
                          ids=lambda r: os.path.basename(r["file"])[:-7])
 def test_wide_emu_on_large_index_matches_bowtie_align_l(run, bias):
     """a .ebwtl index (64-bit offsets on disk, the reference's bowtie-build-l) against bowtie-align-l's own output: the
@@ -128,10 +179,27 @@ def test_wide_emu_on_large_index_matches_bowtie_align_l(run, bias):
     FAM._check(run, FAM._render(run, res, batch, FAM.wide_oracle().refnames))
 
 
-def test_wide_build_leaves_the_best_first_engine_out(wide):
-    batch = T.read_set("multi", "syn36")
-    with pytest.raises(RuntimeError, match="rc=9"):
-        wide["multi", "plain"].align(A.make_policy(**T.MODES["n2_best"]), batch)
+@pytest.mark.parametrize("kind", ["plain", "biased"])
+@pytest.mark.parametrize("run", [r for r in RUNS if not _phase_program(r["mode"])], ids=lambda r: r["file"][:-7])
+def test_wide_emu_best_first_matches_reference_sam(run, kind, wide):
+    """the best-first engine (--best, --strata, -M, -v 3) with 64-bit rows: branch records, alternatives and the chaser hold
+    rows as two words"""
+    batch = T.read_set(run["index"], run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = wide[run["index"], kind].align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw))
+    T.check_against_golden(run, res, batch, T.oracle_index(run["index"]).refnames)
+
+
+@pytest.mark.parametrize("bias", [False, True], ids=["plain", "biased"])
+@pytest.mark.parametrize("run", FAM.fam()["paired_runs"], ids=lambda r: os.path.basename(r["file"])[:-7])
+def test_wide_emu_paired_on_large_index_matches_bowtie_align_l(run, bias):
+    ln = int(OL.OracleIndex(os.path.join(T.G, "multi"), wide=True).fw.len)
+    g = 1 << (SEG_SHIFT + 6)
+    emu = E.EmuAligner(FAM.LARGE, wide=True, row_bias=((1 << 32) - (ln // 2 // g) * g) if bias else None, seg_shift=SEG_SHIFT if bias else None)
+    b1, b2 = T.pair_set("multi", run["reads"])
+    kw = T.MODES[run["mode"]]
+    res = emu.align_pairs(A.make_policy(**kw), b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+    FAM._check(run, FAM._render_pairs(run, res, b1, b2, FAM.wide_oracle().refnames))
 
 
 def test_wide_loader_refuses_a_bias_that_does_not_fit_the_segments():
@@ -193,9 +261,13 @@ def test_wide_engine_against_bowtie_align_l(seed, tmp_path):
     emu = E.EmuAligner(base, wide=True, row_bias=bias, seg_shift=seg_shift)
     done = 0
     for _ in range(4):
-        pol_args = rng.choice([p for p in F.UNPAIRED_POLICIES if "--best" not in p and p != ["-v", "3"]])
-        rep = [x for x in rng.choice([r for r in F.REPORTS])]
+        pol_args = rng.choice(F.UNPAIRED_POLICIES)                      # both engines: the phase scripts and --best / --strata / -M / -v 3
+        rep = [x for x in rng.choice(F.REPORTS)]
+        if "-M" in pol_args or "-m" in pol_args or ("-k" in pol_args and "-k" in rep):
+            rep = [x for x in rep if x not in ("-m", "-k", "1", "2", "3")] if ("-M" in pol_args or "-m" in pol_args) else []
         args = pol_args + rep + F.out_options(rng) + ["--seed", str(rng.randrange(0, 5))]
+        if not F._args_ok(args):
+            continue
         ref = subprocess.run([ALIGN_L, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         if ref.returncode != 0:
             assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
@@ -205,10 +277,9 @@ def test_wide_engine_against_bowtie_align_l(seed, tmp_path):
         oi = type("Refs", (), {})()
         oi.refnames, oi.reflens = emu.refs()
         opts = H.out_opts(**out)
-        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), 1)
+        cap = 4096 if pol.get("all_hits") else max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
         p = A.make_policy(**pol)
-        assert not p.best
-        per = emu.align(p, b1, hit_cap=cap, lite=rng.random() < 0.5, no_rl=rng.random() < 0.3)
+        per = emu.align(p, b1, hit_cap=cap, lite=(not p.best and rng.random() < 0.5), no_rl=(not p.best and rng.random() < 0.3))
         hits, nh, st, pool = H.pack_hits(per, cap)
         got, tally = H.format_hits(b1, hits, nh, st, pool, cap, oi.refnames, oi.reflens, opts)
         got = F._header_for(ref.stdout, oi, opts, ex) + got
@@ -216,3 +287,82 @@ def test_wide_engine_against_bowtie_align_l(seed, tmp_path):
         assert H.summary(tally).strip().split("\n") == F._summary_of(ref.stderr), args
         done += 1
     assert done or True
+
+
+@pytest.mark.skipif(not os.path.exists(ALIGN_L), reason="needs the reference binaries (make -C oracle ref)")
+@pytest.mark.parametrize("best", [True, False], ids=["best", "v1"])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BT_FUZZ_OFFSET", "0")), int(os.environ.get("BT_FUZZ_OFFSET", "0")) + int(os.environ.get("BT_WIDE_FUZZ_SEEDS", "60")) // 2))
+def test_wide_paired_engine_against_bowtie_align_l(seed, best, tmp_path):
+    """tests/test_engine_fuzz.py's paired fuzz (PairedBWAlignerV2 with --best, PairedBWAlignerV1 without), the index by
+    bowtie-build-l (with its .3/.4.ebwtl), the answers by bowtie-align-l, the wide host build on biased rows"""
+    import random
+    import subprocess
+    import cli_cases as CC
+    import test_engine_fuzz as F
+    from bowtie_amd import hostio as H
+    rng = random.Random((30_000 if best else 40_000) + seed)
+    seqs = [s for s in F.make_genome(rng)]
+    seqs.append("".join(rng.choice("ACGT") for _ in range(rng.choice([60, 120, 250]))))
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        for i, sq in enumerate(seqs):
+            f.write(">%s\n%s\n" % ("s%d some description" % i if i % 2 == 0 else "t%d" % i, sq))
+    base = str(tmp_path / "g")
+    off = rng.choice([1, 3, 5])
+    b = subprocess.run([BUILD_L, "--ftabchars", str(rng.choice([1, 2, 4, 6])), "--offrate", str(off), "-q", fa, base], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if b.returncode != 0:
+        pytest.skip("bowtie-build-l refuses this genome")
+    m1, m2 = [], []
+    for i in range(rng.randrange(3, 10)):
+        g = rng.choice(seqs)
+        L1, L2 = rng.choice([5, 8, 12, 20]), rng.choice([5, 8, 12, 20])
+        Fr = rng.randrange(max(L1, L2), max(L1, L2) + 60)
+        if len(g) >= Fr and rng.random() < 0.85:
+            p0 = rng.randrange(0, len(g) - Fr + 1)
+            frag = g[p0:p0 + Fr].replace("N", "C")
+            a, bb = list(frag[:L1]), list(F._rc(frag[Fr - L2:]))
+            for sq in (a, bb):
+                for _ in range(rng.choice([0, 0, 1, 2])):
+                    sq[rng.randrange(len(sq))] = rng.choice("ACGT")
+            a, bb = "".join(a), "".join(bb)
+            if rng.random() < 0.3:
+                a, bb = bb, a
+        else:
+            a = "".join(rng.choice("ACGT") for _ in range(L1)); bb = "".join(rng.choice("ACGT") for _ in range(L2))
+        m1.append(("p%d" % i, a, "".join(rng.choice("!+5?IIII") for _ in a)))
+        m2.append(("p%d" % i, bb, "".join(rng.choice("!+5?IIII") for _ in bb)))
+    f1, f2 = str(tmp_path / "m_1.fq"), str(tmp_path / "m_2.fq")
+    F._write_fastq(f1, m1, 1)
+    F._write_fastq(f2, m2, 2)
+    seg_shift = rng.choice([2, 3, 5])
+    gran = 1 << max(seg_shift + 6, off)
+    bias = rng.choice([0, (1 << 32) - gran * rng.randrange(0, 3), (1 << 33) + gran * rng.randrange(0, 5), (1 << 36) - gran])
+    emu = E.EmuAligner(base, wide=True, row_bias=bias, seg_shift=seg_shift)
+    refs = type("Refs", (), {})()
+    refs.refnames, refs.reflens = emu.refs()
+    for _ in range(3):
+        args = rng.choice(F.PAIRED_POLICIES) + (["--best"] if best else []) + rng.choice(F.PAIRED_REPORTS) + \
+            rng.choice([["-X", "100"], ["-X", "60", "-I", "10"], ["-X", "250"]]) + rng.choice([[], [], ["-5", "1"], ["-3", "2"], ["-5", "2", "-3", "1"]]) + F.out_options(rng)
+        if not F._args_ok(args):
+            continue
+        if not best and "--strata" in args and "-M" not in args and args[:2] != ["-v", "3"]:
+            continue
+        ref = subprocess.run([ALIGN_L, "--wrapper", "basic-0", "-p", "1"] + args + ["-x", base, "-1", f1, "-2", f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if ref.returncode != 0:
+            assert ref.returncode > 0 and (b"is less than" in ref.stderr or b"at least" in ref.stderr), (args, ref.stderr[-300:])
+            continue
+        rd, pol, out, ex = CC.interpret(args)
+        b1, b2 = H.read_all(f1, mate=1, **rd), H.read_all(f2, mate=2, **rd)
+        o1 = rd.get("trim5", 0) if pol.get("mate1_fw", True) else rd.get("trim3", 0)
+        o2 = rd.get("trim3", 0) if pol.get("mate2_fw", False) else rd.get("trim5", 0)
+        pol = dict(pol, min_ins=max(0, max(0, pol.get("min_ins", 0) - o1) - o2), max_ins=max(0, max(0, pol.get("max_ins", 250) - o1) - o2))
+        opts = H.out_opts(**out)
+        cap = 4096 if pol.get("all_hits") else 2 * max(pol.get("khits", 1), pol.get("mhits", 1) if pol.get("sample_max") else 1)
+        if not best:
+            pol = dict(pol, pe_v1=True)
+        per = emu.align_pairs(A.make_policy(**pol), b1, b2, hit_cap=cap)
+        hits, nh, st, pool = H.pack_hits(per, cap)
+        got, tally = H.format_pairs(b1, b2, hits, nh, st, pool, cap, refs.refnames, refs.reflens, opts)
+        got = F._header_for(ref.stdout, refs, opts, ex) + got
+        assert got == ref.stdout, (seqs, args, bias, seg_shift)
+        assert H.summary(tally).strip().split("\n") == F._summary_of(ref.stderr), args

@@ -66,8 +66,9 @@ def test_gpu_wide_second_pass():
     _run(["second_pass"], _env("e_coli"))
 
 
-def test_gpu_wide_build_answers_unsupported_for_the_best_first_engine():
-    _run(["unsupported"], _env(None))
+def test_gpu_wide_best_first_and_pairs():
+    """(written after the last GPU second was spent: the host build of the same code passes tests/test_wide_rows_emu.py)"""
+    _run(["best"], _env("multi"))
 
 
 def test_cli_l_on_large_index_is_byte_identical_to_bowtie_align_l(tmp_path):
@@ -83,5 +84,28 @@ def test_cli_l_on_large_index_is_byte_identical_to_bowtie_align_l(tmp_path):
         p = subprocess.run([binp, "-S", "--sam-nohead"] + run["args"] + ["-x", FAM.LARGE, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert p.returncode == 0, p.stderr.decode()
         assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]
-    p = subprocess.run([binp, "-S", "--best", "-x", FAM.LARGE, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-    assert p.returncode != 0 and b"64-bit rows" in p.stderr, p.stderr.decode()
+
+
+def test_cli_l_best_first_and_pairs_are_byte_identical_to_bowtie_align_l(tmp_path):
+    """(the wide best-first engine: written after the last GPU second was spent; tests/test_wide_rows_emu.py runs this test
+    through the CPU shim)"""
+    import test_index_family as FAM
+    from bowtie_amd.synth import write_fastq
+    binp = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd-l")
+    fq = str(tmp_path / "r.fq")
+    env = _env("multi")
+    env.pop("BT_LIB")
+    for run in [r for r in FAM.fam()["runs"] if (r["reads"], r["mode"]) in (("syn36", "n2_best"), ("syn100", "v2_a_best_strata"))]:
+        write_fastq(T.read_set("multi", run["reads"]), fq)
+        p = subprocess.run([binp, "-S", "--sam-nohead"] + run["args"] + ["-x", FAM.LARGE, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()
+        assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]
+    # pairs (--best: PairedBWAlignerV2 and the window scan; the reference's 2-bit reference files .3/.4.ebwtl)
+    for run in FAM.fam()["paired_runs"][:2]:
+        b1, b2 = T.pair_set("multi", run["reads"])
+        f1, f2 = str(tmp_path / "m1.fq"), str(tmp_path / "m2.fq")
+        write_fastq(b1, f1)
+        write_fastq(b2, f2)
+        p = subprocess.run([binp, "-S", "--sam-nohead"] + run["args"] + ["-x", FAM.LARGE, "-1", f1, "-2", f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()
+        assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]

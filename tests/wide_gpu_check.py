@@ -112,16 +112,32 @@ def main():
         T.compare_results(got2, want, "wide n2 with the second pass")
         assert AL.lib().bt_ctx_last_retried(al2._h) > 0
         n_checked += 2
-    elif what == "unsupported":
-        idx = AL.Index(os.path.join(T.G, "multi"))
-        for mode in ("n2_best", "v3"):
-            try:
-                AL.Aligner(idx, A.make_policy(**T.MODES[mode]))
-            except AL.BowtieAmdError as e:
-                assert e.code == A.BT_ERR_UNSUPPORTED, e
-                n_checked += 1
-            else:
-                raise AssertionError("the wide build took " + mode)
+    elif what == "best":
+        # the best-first engine and pairs in the wide build: the .ebwtl goldens of bowtie-align-l (--best / --strata / -M / -v 3,
+        # paired with --best), the plain index's paired goldens without --best (PairedBWAlignerV1)
+        import test_index_family as FAM
+        idx = AL.Index(FAM.LARGE)
+        for run in FAM.fam()["runs"]:
+            if phase_program(run["mode"]):
+                continue
+            batch = T.read_set("multi", run["reads"])
+            kw = T.MODES[run["mode"]]
+            res = AL.Aligner(idx, A.make_policy(**kw)).align(batch, hit_cap=T.hit_cap_for(kw))
+            FAM._check(run, FAM._render(run, res, batch, idx.refnames))
+            n_checked += 1
+        for run in FAM.fam()["paired_runs"]:
+            b1, b2 = T.pair_set("multi", run["reads"])
+            kw = T.MODES[run["mode"]]
+            res = AL.Aligner(idx, A.make_policy(**kw)).align_pairs(b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+            FAM._check(run, FAM._render_pairs(run, res, b1, b2, idx.refnames))
+            n_checked += 1
+        plain = AL.Index(os.path.join(T.G, "multi"))
+        for run in T.paired_v1_runs("multi")[:6]:
+            b1, b2 = T.pair_set("multi", run["reads"])
+            kw = dict(T.MODES[run["mode"]], pe_v1=True)
+            res = AL.Aligner(plain, A.make_policy(**kw)).align_pairs(b1, b2, hit_cap=2048 if kw.get("all_hits") else None)
+            T.check_pairs_against_golden(run, res, b1, b2, plain.refnames)
+            n_checked += 1
     else:
         raise SystemExit("unknown check " + what)
     print("wide_gpu_check %s: ok, %d checks (row bias %d)" % (what, n_checked, bias))
