@@ -366,3 +366,24 @@ def test_wide_paired_engine_against_bowtie_align_l(seed, best, tmp_path):
         got = F._header_for(ref.stdout, refs, opts, ex) + got
         assert got == ref.stdout, (seqs, args, bias, seg_shift)
         assert H.summary(tally).strip().split("\n") == F._summary_of(ref.stderr), args
+
+
+@pytest.mark.skipif(not TA._msan_available(), reason="needs clang with the MemorySanitizer runtime")
+def test_wide_automaton_reads_nothing_uninitialised(tmp_path):
+    """tests/emu/emu_msan.cpp with -DBT_WIDE=1: LDS, the scratch arenas and what the kernel's rank branch leaves unset of a
+    round's answer (in the wide build: the second row's two pieces) poisoned; 40 reads with Ns on biased rows, three
+    policies, all three builds of the automaton"""
+    import subprocess
+    exe = str(tmp_path / "emu_msan_w")
+    subprocess.check_call([TA.MSAN_CLANG, "-fsanitize=memory", "-fsanitize-recover=memory", "-fno-omit-frame-pointer", "-g", "-O1", "-std=c++17", "-w",
+                           "-DBT_WIDE=1", "-pthread", "-o", exe, os.path.join(T.ROOT, "tests", "emu", "emu_msan.cpp"), os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_host.cpp")])
+    b = synth_reads(T.joined_text("multi"), 40, 60, mm_dist=(0, 1, 2, 3), seed=5, n_frac=0.1)
+    reads = ["".join("ACGTN"[c] for c in b.seq[i, :60]) for i in range(b.n)]
+    env = dict(os.environ, MSAN_OPTIONS="halt_on_error=0:exitcode=0", BT_WIDE_ROW_BIAS=str(_bias("multi")), BT_WIDE_SEG_SHIFT=str(SEG_SHIFT), BT_LOAD_THREADS="1")
+    for pol in (["n", "2", "0", "1"], ["v", "2", "1", "1"], ["n", "3", "0", "3"]):
+        for rl_mode in ("2", "0", "1"):
+            p = subprocess.run([exe, os.path.join(T.G, "multi")] + pol + ["64", rl_mode] + reads, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            frames0 = [ln for ln in p.stderr.decode(errors="replace").splitlines() if ln.lstrip().startswith("#0 ")]
+            mine = [ln for ln in frames0 if "File::File" not in ln and "operator new" not in ln]
+            assert not mine, "\n".join(mine[:5])
+            assert "rc 0" in p.stdout.decode()
