@@ -387,3 +387,14 @@ def test_wide_automaton_reads_nothing_uninitialised(tmp_path):
             mine = [ln for ln in frames0 if "File::File" not in ln and "operator new" not in ln]
             assert not mine, "\n".join(mine[:5])
             assert "rc 0" in p.stdout.decode()
+
+
+@pytest.mark.parametrize("what", [["best"], ["family"], ["rank", "multi"], ["ragged"]], ids=lambda w: w[0])
+def test_the_gpu_check_script_on_the_host_build(what):
+    """tests/wide_gpu_check.py -- what tests/test_zz_wide_gpu.py runs against libbowtie_amd_l.so -- with the binding stubbed by
+    the wide host build: the script's own logic, where there is no GPU"""
+    import subprocess
+    import sys
+    env = dict(os.environ, BT_WIDE_ROW_BIAS=str(_bias("multi")), BT_WIDE_SEG_SHIFT=str(SEG_SHIFT))
+    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "tests", "wide_gpu_check_dry.py")] + what, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b": ok, " in p.stdout, p.stdout.decode()[-3000:]
