@@ -25,7 +25,14 @@ extern "C" int bt_index_load(const char* base, int need_mirror, int offrate_over
 	if (variant < 0) return BT_ERR_IO;
 	void* e = nullptr;
 	try { e = emu_index_load(base, need_mirror, offrate_override); } catch (const std::exception&) { return BT_ERR_FORMAT; }
-	if (!e) return BT_ERR_FORMAT;
+	if (!e) {
+		/* the loader's own verdict (an index of 2^32-1 rows or more under the 32-bit build: BT_ERR_ROWS64, on which the binary
+		 * starts bowtie-amd-l) */
+		BtIndexHost probe;
+		int rc = BT_ERR_FORMAT;
+		try { rc = bt_host_index_load(base, true, offrate_override, &probe); } catch (const std::exception&) { rc = BT_ERR_FORMAT; }
+		return rc != BT_OK ? rc : BT_ERR_FORMAT;
+	}
 	bt_index* ix = new bt_index();
 	ix->emu = e; ix->mirror = need_mirror != 0; ix->variant = variant;
 	*out = ix;

@@ -398,3 +398,46 @@ def test_the_gpu_check_script_on_the_host_build(what):
     env = dict(os.environ, BT_WIDE_ROW_BIAS=str(_bias("multi")), BT_WIDE_SEG_SHIFT=str(SEG_SHIFT))
     p = subprocess.run([sys.executable, os.path.join(T.ROOT, "tests", "wide_gpu_check_dry.py")] + what, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0 and b": ok, " in p.stdout, p.stdout.decode()[-3000:]
+
+
+def _fake_huge_index(base, rows=(1 << 32) + 12345):
+    """the first bytes of a .ebwtl index that claims `rows` BWT rows: as far as a loader reads before it knows the size"""
+    import struct
+    for ext in ("", ".rev"):
+        with open(base + ext + ".1.ebwtl", "wb") as f:
+            f.write(struct.pack("<iQiiiii", 1, rows - 1, 7, 1, 5, 10, 0))
+        with open(base + ext + ".2.ebwtl", "wb") as f:
+            f.write(struct.pack("<i", 1))
+
+
+def test_the_32_bit_library_points_an_index_of_2_to_32_rows_to_the_64_bit_one(tmp_path):
+    """BT_ERR_ROWS64 from the 32-bit loader (host-only entry point: no GPU needed); the 64-bit library reads on (and finds
+    this file truncated)"""
+    import ctypes as C
+    from bowtie_amd import aligner as AL
+    base = str(tmp_path / "huge")
+    _fake_huge_index(base)
+    out = (C.c_uint64 * 8)()
+    assert AL.lib().bt_index_digest(base.encode(), 0, out) == A.BT_ERR_ROWS64
+    wide = C.CDLL(os.path.join(os.path.dirname(AL.LIB_PATH), "libbowtie_amd_l.so"))
+    wide.bt_index_digest.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]
+    assert wide.bt_index_digest(base.encode(), 0, out) in (A.BT_ERR_IO, A.BT_ERR_FORMAT)
+    # one row below the limit is the 32-bit build's own (and truncated here)
+    _fake_huge_index(base, rows=(1 << 32) - 1)
+    assert AL.lib().bt_index_digest(base.encode(), 0, out) in (A.BT_ERR_IO, A.BT_ERR_FORMAT)
+
+
+def test_bowtie_amd_starts_bowtie_amd_l_for_such_an_index(tmp_path):
+    """the reference's wrapper picks bowtie-align-l (bowtie:52-81); bowtie-amd execs bowtie-amd-l.  Under the 32-bit CPU shim both
+    binaries get BT_ERR_ROWS64 from the loader: the first starts the second, the second (whose library has 64-bit rows)
+    reports it -- seen from outside as the message of the second"""
+    import subprocess
+    base = str(tmp_path / "huge")
+    _fake_huge_index(base)
+    fq = str(tmp_path / "r.fq")
+    with open(fq, "w") as f:
+        f.write("@r0\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n")
+    env = dict(os.environ, LD_PRELOAD=E.shim())
+    p = subprocess.run([os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd"), "-x", base, fq], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0 and "could not be started" not in err and "2^32-1 rows" in err, err

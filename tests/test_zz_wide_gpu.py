@@ -109,3 +109,21 @@ def test_cli_l_best_first_and_pairs_are_byte_identical_to_bowtie_align_l(tmp_pat
         p = subprocess.run([binp, "-S", "--sam-nohead"] + run["args"] + ["-x", FAM.LARGE, "-1", f1, "-2", f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert p.returncode == 0, p.stderr.decode()
         assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]
+
+
+def test_bowtie_amd_starts_bowtie_amd_l_for_an_index_of_2_to_32_rows(tmp_path):
+    """the first bytes of a .ebwtl index that claims 2^32 + 12345 rows: libbowtie_amd.so answers BT_ERR_ROWS64, bowtie-amd starts
+    bowtie-amd-l, whose library reads on and finds the file truncated (the message is the second binary's)"""
+    import struct
+    base = str(tmp_path / "huge")
+    for ext in ("", ".rev"):
+        with open(base + ext + ".1.ebwtl", "wb") as f:
+            f.write(struct.pack("<iQiiiii", 1, (1 << 32) + 12344, 7, 1, 5, 10, 0))
+        with open(base + ext + ".2.ebwtl", "wb") as f:
+            f.write(struct.pack("<i", 1))
+    fq = str(tmp_path / "r.fq")
+    with open(fq, "w") as f:
+        f.write("@r0\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n")
+    p = subprocess.run([os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd"), "-x", base, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0 and "could not be started" not in err and "2^32-1 rows" not in err, err
