@@ -280,6 +280,11 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 	if (nPat == 0 || nPat > h.len) return BT_ERR_FORMAT;
 	h.nPat = (uint32_t)nPat;
 	if (!R.offs(h.plen, nPat, true)) return BT_ERR_IO;
+#if BT_WIDE
+	/* an alignment's offset within its sequence is 32 bits in bt_hit (and in the reference's Hit::h.second only because
+	 * TIndexOffU is 64 there): a single sequence of 2^32 bases or more is not held */
+	for (const bt_row v : h.plen) if (v >= 0xffffffffull) return BT_ERR_FORMAT;
+#endif
 	const uint64_t nFrag = R.off();
 	if (!R.ok) return BT_ERR_IO;
 	if (nFrag == 0 || nFrag > h.len) return BT_ERR_FORMAT;
