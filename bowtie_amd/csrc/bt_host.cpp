@@ -323,7 +323,8 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 		if (const char* e = getenv("BT_WIDE_SEG_SHIFT")) { const long v = atol(e); if (v >= 2 && v <= 25) h.segShift = (uint32_t)v; }
 		if (const char* e = getenv("BT_WIDE_ROW_BIAS")) {
 			const uint64_t b = strtoull(e, nullptr, 0);
-			if ((b & ((1ull << (h.segShift + 6u)) - 1u)) != 0 || (b & ((1ull << h.offRate) - 1u)) != 0 || b >= (1ull << 37)) return BT_ERR_ARG;
+			/* whole segments, whole 16-byte pieces of the SA sample (two entries), block numbers that stay 32 bits */
+			if ((b & ((1ull << (h.segShift + 6u)) - 1u)) != 0 || (b & ((2ull << h.offRate) - 1u)) != 0 || b >= (1ull << 37) || b + len64 >= (1ull << 38)) return BT_ERR_ARG;
 			h.rowBias = b;
 		}
 		const uint64_t B = h.rowBias;

@@ -30,7 +30,7 @@ struct BtIndexHost {
 #if BT_WIDE
 	/* The wide build (64-bit BWT rows; bt_rank.h, "the row type") keeps no side layout: its loader derives the rank blocks
 	 * and their segment table straight from the file's BWT, whatever the variant.
-	 * rowBias (tests; BT_WIDE_ROW_BIAS, a multiple of 2^(segShift+6) and of 2^offRate): every BWT row of the image is numbered
+	 * rowBias (tests; BT_WIDE_ROW_BIAS, a multiple of 2^(segShift+6) and of 2^(offRate+1)): every BWT row of the image is numbered
 	 * rowBias higher than in the files -- fchr, zOff, the ftab / eftab entries and the segment table carry it, and whoever
 	 * binds the arrays to a BtIndexDev shifts the pointers of the row-indexed ones back by it (bt_host_index_bias) -- so that
 	 * a genome of a few Mbp exercises row arithmetic above 2^32 (with BT_WIDE_SEG_SHIFT, blocks per segment log2, also the

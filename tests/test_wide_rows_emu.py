@@ -256,7 +256,7 @@ def test_wide_engine_against_bowtie_align_l(seed, tmp_path):
     fq = str(tmp_path / "r.fq")
     F._write_fastq(fq, reads)
     seg_shift = rng.choice([2, 3, 5])
-    gran = 1 << max(seg_shift + 6, off)
+    gran = 1 << max(seg_shift + 6, off + 1)
     bias = rng.choice([0, (1 << 32) - gran * rng.randrange(0, 3), (1 << 33) + gran * rng.randrange(0, 5), (1 << 36) - gran])
     emu = E.EmuAligner(base, wide=True, row_bias=bias, seg_shift=seg_shift)
     done = 0
@@ -335,7 +335,7 @@ def test_wide_paired_engine_against_bowtie_align_l(seed, best, tmp_path):
     F._write_fastq(f1, m1, 1)
     F._write_fastq(f2, m2, 2)
     seg_shift = rng.choice([2, 3, 5])
-    gran = 1 << max(seg_shift + 6, off)
+    gran = 1 << max(seg_shift + 6, off + 1)
     bias = rng.choice([0, (1 << 32) - gran * rng.randrange(0, 3), (1 << 33) + gran * rng.randrange(0, 5), (1 << 36) - gran])
     emu = E.EmuAligner(base, wide=True, row_bias=bias, seg_shift=seg_shift)
     refs = type("Refs", (), {})()
