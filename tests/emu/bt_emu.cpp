@@ -7,6 +7,7 @@
  * libbowtie_amd.so and nothing in the product loads it; GPU parity is tested separately
  * (tests/test_gpu_*.py) through the C ABI.
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -216,6 +217,18 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 				 * in LDS does not -- the top-of-stack record and candidate cache are invalid, the read is loaded again */
 				for (uint32_t k = 0; k < BT_LDS_WORDS; k++) tos[(size_t)k * nLanes + g] = 0xdeadbeefu;
 				for (uint32_t k = 0; k < BT_RL_WORDS; k++) rlbuf[(size_t)k * nLanes + g] = 0xdeadbeefu;
+				{
+					/* ... and the lane's state goes through the pool record's bytes as the kernel copies it: in builds that keep
+					 * the read in LDS only what lies before the register window (offsetof cs0), the rest starts from zero */
+					static_assert((sizeof(BtLane) + 15) / 16 <= 17, "a parked lane fits the pool record (bt_kernels.h: BT_POOL_REQ)");
+					uint8_t rec[sizeof(BtLane)];
+					const size_t keep = RL ? offsetof(BtLane, cs0) : sizeof(BtLane);
+					memcpy(rec, &L, keep);
+					BtLane fresh;
+					memset(&fresh, 0, sizeof(fresh));
+					memcpy(&fresh, rec, keep);
+					L = fresh;
+				}
 				L.tosValid = 0; L.ccValid = 0;
 				if (RL) for (uint32_t base = 0; base < L.plen; base += 16u)
 					bt_rl_store_chunk(scr[g], base, bt_ld4(in->seq + L.roff + base), bt_ld4(in->qual + L.roff + base));

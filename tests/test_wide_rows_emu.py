@@ -441,3 +441,31 @@ def test_bowtie_amd_starts_bowtie_amd_l_for_such_an_index(tmp_path):
     p = subprocess.run([os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd"), "-x", base, fq], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     err = p.stderr.decode(errors="replace")
     assert p.returncode != 0 and "could not be started" not in err and "2^32-1 rows" in err, err
+
+
+@pytest.mark.parametrize("wide_build", [False, True], ids=["rows32", "rows64"])
+def test_carry_over_round_trip_on_the_host_build(wide_build):
+    """EMU_PARK_EVERY (tests/emu/bt_emu.cpp): every lane is parked and adopted again in one round out of three, at random -- its
+    state through the pool record's bytes as the kernel copies it (only what lies before the register window in the builds that
+    keep the read in LDS), LDS lost, the read loaded again -- in both widths of the row type; results are the oracle's"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import common as T, emu_lib as E
+from bowtie_amd import _abi as A
+wide = %r
+e = E.EmuAligner(T.G + "/multi", wide=wide, row_bias=((1 << 32) - 29696) if wide else None, seg_shift=4 if wide else None)
+n = 0
+for mode in ("n2", "v2", "n3", "n2_k3", "n1_a_m20"):
+    kw = T.MODES[mode]
+    for reads, kwargs in (("syn100", {}), ("syn100", {"lite": True}), ("syn150", {"no_rl": True})):
+        batch = T.read_set("multi", reads)
+        got = e.align(A.make_policy(**kw), batch, hit_cap=T.hit_cap_for(kw), pal_cap=16384, n_lanes=37, **kwargs)
+        T.compare_results(got, T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw)), mode)
+        n += 1
+print("ok", n)
+''' % (T.ROOT, os.path.join(T.ROOT, "tests"), wide_build)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_PARK_EVERY="3"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b"ok 15" in p.stdout, p.stdout.decode()[-3000:]
