@@ -86,6 +86,22 @@ def test_cli_l_on_large_index_is_byte_identical_to_bowtie_align_l(tmp_path):
         assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]
 
 
+def test_cli_l_small_batches_carry_over(tmp_path):
+    """the same through batches of 64 reads: lanes parked at the end of a launch and adopted by the next (the wide build's pool
+    record is 20 pieces), ticks at the end of the input -- not among the checks of the round's last GPU seconds"""
+    import test_index_family as FAM
+    from bowtie_amd.synth import write_fastq
+    binp = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd-l")
+    fq = str(tmp_path / "r.fq")
+    env = _env("multi")
+    env.pop("BT_LIB")
+    for run in [r for r in FAM.fam()["runs"] if (r["reads"], r["mode"]) in (("syn100", "v2"), ("syn150", "n2"))]:
+        write_fastq(T.read_set("multi", run["reads"]), fq)
+        p = subprocess.run([binp, "-S", "--sam-nohead", "--batch", "64"] + run["args"] + ["-x", FAM.LARGE, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()
+        assert hashlib.md5(p.stdout).hexdigest() == run["md5"], run["file"]
+
+
 def test_cli_l_best_first_and_pairs_are_byte_identical_to_bowtie_align_l(tmp_path):
     """(the wide best-first engine: written after the last GPU second was spent; tests/test_wide_rows_emu.py runs this test
     through the CPU shim)"""
