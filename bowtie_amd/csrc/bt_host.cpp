@@ -29,10 +29,12 @@ struct File {
  *   <base>.1.bt2l   sideSz - 4*OFF_SIZE BWT bytes followed by the 4 counters [A][C][G][T] before the side
  *
  * each in either byte order (first word 1 or 1<<24, ebwt.h:2926-2937).  Whatever the file holds, the
- * image the kernels read is the first layout: the BWT symbols are re-dealt into 224-row sides and
- * the counters recomputed, offsets are narrowed to 32 bits (an index of 2^32-1 or more rows is
- * refused: device rows are u32).  What does not survive the conversion, and so is kept as a flag, is
- * the 64-bit build's arithmetic: h.wide (see BtIndexDev::wide).                                      */
+ * image the 32-bit build's kernels read is the first layout: the BWT symbols are re-dealt into 224-row
+ * sides and the counters recomputed, offsets are narrowed to 32 bits (an index of 2^32-1 or more rows
+ * is BT_ERR_ROWS64 there: its rows are u32).  What does not survive the conversion, and so is kept as a
+ * flag, is the 64-bit build's arithmetic: h.wide (see BtIndexDev::wide).  The build with 64-bit rows
+ * (-DBT_WIDE=1, bt_rank.h "the row type") keeps every offset 64 bits wide and derives its rank blocks
+ * straight from the file's BWT (build_blocks below).                                                 */
 namespace {
 struct Reader {
 	File& f; bool swap, wide, ok = true, narrow = true;
