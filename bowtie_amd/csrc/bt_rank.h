@@ -110,7 +110,8 @@ struct BtIndexDev {
 	const BtU4*     loc;
 	const uint32_t* rtxt;
 	const uint16_t* walk;
-	uint32_t wide;             /* the index is a 64-bit (.ebwtl) build.  Its rows still fit 32 bits here, but the
+	uint32_t wide;             /* the index FILES are a 64-bit (.ebwtl / .bt2l) build -- whatever this build's row type: the
+	                              32-bit build holds such an index too if it has fewer than 2^32 - 1 rows.  The
 	                              reference binary that serves it is compiled with 64-bit offsets, and two things
 	                              a user can see follow the offset width: the row a hit is reported from is drawn
 	                              with nextU<TIndexOffU>() (two draws, ebwt_search_backtrack.h:1538), and a
