@@ -46,6 +46,7 @@ struct Options {
 	std::vector<std::string> rg_fields;
 	int threads = 0, offrate = -1, inflight = 2;      /* threads 0 = pick from the host */
 	bool no_stream = false, stream = false;
+	bool large_index = false;                /* --large-index: the reference's wrapper then runs bowtie-align-l, which reads only the .ebwtl files (bowtie:64-65) */
 	std::vector<int> devices;                /* GPUs the batches are dealt to (default: 0) */
 	bool quiet = false, timing = false, sam_nohead = false, tryhard = false, maxbts_set = false, paired = false;
 	bool best_given = false;     /* --best itself: what clears the reference's useV1 (ebwt_search.cpp:776); -v 3 / -M only set `stateful` */
@@ -99,6 +100,7 @@ void usage(FILE* o)
 	    "  --solexa-quals     input quals are from GA Pipeline ver. < 1.3\n"
 	    "  --solexa1.3-quals  input quals are from GA Pipeline ver. >= 1.3\n"
 	    "  --integer-quals    qualities are given as space-separated integers (not ASCII)\n"
+	    "  --large-index      force usage of a 'large' index, even if a small one is present\n"
 	    "Alignment:\n"
 	    "  -v <int>           report end-to-end hits w/ <=v mismatches; ignore qualities (0-2)\n"
 	    "    or\n"
@@ -171,7 +173,7 @@ struct LongOpt { const char* name; int has_arg; int id; };
 enum {
 	O_SOLEXA = 256, O_PHRED64, O_PHRED33, O_SEED, O_MAXBTS, O_QUIET, O_REFIDX, O_FULLREF, O_NOMAQ, O_NOFW, O_NORC,
 	O_SAM_NOHEAD, O_SAM_NOSQ, O_SAM_RG, O_SAM_NOTRUNC, O_NO_UNAL, O_MAPQ, O_SUPPRESS, O_COST, O_SHOWSEED, O_VERSION,
-	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_STREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_TAB12, O_ILEAVED, O_QUALS1, O_QUALS2, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
+	O_USAGE, O_BEST, O_STRATA, O_FF, O_FR, O_RF, O_PAIRTRIES, O_ALLOW_CONTAIN, O_DEVICE, O_BATCH, O_INFLIGHT, O_NOSTREAM, O_STREAM, O_WRAPPER, O_AL, O_UN, O_MAX, O_INTQUALS, O_TAB12, O_ILEAVED, O_QUALS1, O_QUALS2, O_LARGE_INDEX, O_IGNORED, O_IGNORED_ARG, O_UNSUPPORTED, O_UNSUPPORTED_ARG
 };
 const LongOpt LONGS[] = {
 	{"all", 0, 'a'}, {"solexa-quals", 0, O_SOLEXA}, {"time", 0, 't'}, {"trim3", 1, '3'}, {"trim5", 1, '5'}, {"seed", 1, O_SEED},
@@ -188,7 +190,7 @@ const LongOpt LONGS[] = {
 	{"verbose", 0, O_IGNORED}, {"startverbose", 0, O_IGNORED}, {"sanity", 0, O_IGNORED}, {"reorder", 0, O_IGNORED},
 	{"thread-ceiling", 1, O_IGNORED_ARG}, {"thread-piddir", 1, O_IGNORED_ARG}, {"mm", 0, O_IGNORED}, {"shmem", 0, O_IGNORED},
 	{"mmsweep", 0, O_IGNORED}, {"prewidth", 1, O_IGNORED_ARG}, {"cachelim", 1, O_IGNORED_ARG}, {"cachesz", 1, O_IGNORED_ARG},
-	{"pause", 0, O_IGNORED}, {"stats", 0, O_IGNORED}, {"reportopps", 0, O_UNSUPPORTED}, {"mixthresh", 1, O_UNSUPPORTED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_UNSUPPORTED},
+	{"pause", 0, O_IGNORED}, {"stats", 0, O_IGNORED}, {"reportopps", 0, O_UNSUPPORTED}, {"mixthresh", 1, O_UNSUPPORTED_ARG}, {"stateful", 0, O_UNSUPPORTED}, {"large-index", 0, O_LARGE_INDEX},
 	/* the best-first engine and everything that needs it */
 	{"best", 0, O_BEST}, {"better", 0, O_UNSUPPORTED}, {"oldbest", 0, O_UNSUPPORTED}, {"strata", 0, O_STRATA},
 	{"minins", 1, 'I'}, {"maxins", 1, 'X'}, {"ff", 0, O_FF}, {"fr", 0, O_FR},
@@ -411,6 +413,7 @@ void parse_args(int argc, char** argv, Options* O)
 		case O_STREAM: O->stream = true; break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
 		case O_WRAPPER: break;
+		case O_LARGE_INDEX: O->large_index = true; break;
 		case O_INTQUALS: O->int_quals = true; break;
 		case O_AL: O->dump_al = val; break;
 		case O_UN: O->dump_un = val; break;
@@ -954,6 +957,23 @@ int main(int argc, char** argv)
 	};
 	/* the index is located before the first batch's thread starts: find_index() leaves through exit() when there is none,
 	 * and no thread of ours may be inside the reader then */
+	if (O.large_index) {
+		/* bowtie --large-index: "force usage of a 'large' index, even if a small one is present" -- the wrapper starts
+		 * bowtie-align-l, whose loader knows only <base>.*.ebwtl.  Here: the binary with 64-bit rows, its loader looking for
+		 * the 64-bit files first (BT_INDEX_PREFER_LARGE, bt_host.cpp) */
+		setenv("BT_INDEX_PREFER_LARGE", "1", 1);
+		if (!bt_rows64()) {
+			char self[PATH_MAX];
+			const ssize_t n = readlink("/proc/self/exe", self, sizeof(self) - 3);
+			if (n > 0) {
+				self[n] = 0;
+				strcat(self, "-l");
+				fflush(stdout); fflush(stderr);
+				execv(self, argv);
+			}
+			die("Error: --large-index needs the 64-bit-row build (bowtie-amd-l), which could not be started");
+		}
+	}
 	const std::string base = find_index(O.index);
 	if (O.devices.empty()) O.devices.push_back(0);
 	std::unique_ptr<Job> first_job(new Job());

@@ -225,9 +225,13 @@ const char* const kExt[4] = {"bt2", "ebwt", "bt2l", "ebwtl"};
  * and its wrapper picks the 64-bit binary only when there is no small index (bowtie:52-81). */
 int bt_host_index_variant(const std::string& base)
 {
-	for (int v = 0; v < 4; v++) {
-		File f(base + ".1." + kExt[v]);
-		if (f.f) return v;
+	/* BT_INDEX_PREFER_LARGE (set by bowtie-amd --large-index): the 64-bit files first, as bowtie-align-l knows only them */
+	static const int plain[4] = {0, 1, 2, 3}, large[4] = {2, 3, 0, 1};
+	const char* e = getenv("BT_INDEX_PREFER_LARGE");
+	const int* order = (e && *e && *e != '0') ? large : plain;
+	for (int k = 0; k < 4; k++) {
+		File f(base + ".1." + kExt[order[k]]);
+		if (f.f) return order[k];
 	}
 	return -1;
 }

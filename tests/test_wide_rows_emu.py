@@ -469,3 +469,34 @@ print("ok", n)
 ''' % (T.ROOT, os.path.join(T.ROOT, "tests"), wide_build)
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_PARK_EVERY="3"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0 and b"ok 15" in p.stdout, p.stdout.decode()[-3000:]
+
+
+def test_large_index_option_takes_the_ebwtl_files(tmp_path):
+    """bowtie --large-index (the wrapper then runs bowtie-align-l, bowtie:64-65): with both builds of an index under one base,
+    bowtie-amd answers as bowtie-align-s does on the .ebwt files, bowtie-amd --large-index starts bowtie-amd-l, whose loader
+    takes the .ebwtl files and answers as bowtie-align-l does (the two-draw choice of the reported row tells them apart).
+    Through the CPU shims."""
+    import hashlib
+    import shutil
+    import subprocess
+    from bowtie_amd.synth import write_fastq
+    base = str(tmp_path / "both")
+    for ext in ("1", "2", "3", "4", "rev.1", "rev.2"):
+        shutil.copy(os.path.join(T.G, "multi." + ext + ".ebwt"), base + "." + ext + ".ebwt")
+        shutil.copy(FAM.LARGE + "." + ext + ".ebwtl", base + "." + ext + ".ebwtl")
+    small = {(r["reads"], r["mode"]): r for r in T.golden_runs("multi")}
+    picked = [r for r in FAM.fam()["runs"] if not r["same_as_small"] and (r["reads"], r["mode"]) in small and _phase_program(r["mode"])][:2]
+    assert picked
+    fq = str(tmp_path / "r.fq")
+    binp = os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd")
+    for run in picked:
+        write_fastq(T.read_set("multi", run["reads"]), fq)
+        outs = {}
+        for tag, extra, shim in (("small", [], E.shim()), ("large", ["--large-index"], E.wide_shim())):
+            # (the exec'd bowtie-amd-l keeps the environment: it gets the wide shim from the start)
+            p = subprocess.run([binp, "-S", "--sam-nohead"] + extra + run["args"] + ["-x", base, fq], env=dict(os.environ, LD_PRELOAD=shim),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert p.returncode == 0, p.stderr.decode()
+            outs[tag] = hashlib.md5(p.stdout).hexdigest()
+        assert outs["large"] == run["md5"], run["file"]
+        assert outs["small"] != outs["large"]
