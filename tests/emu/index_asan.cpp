@@ -19,6 +19,6 @@ int main(int argc, char** argv)
 		try { rcm = bt_host_index_load(base + ".rev", false, -1, &mir); } catch (const std::exception&) { rcm = BT_ERR_FORMAT; }
 		try { rcr = bt_host_ref_load(base, fw, &ref); } catch (const std::exception&) { rcr = BT_ERR_FORMAT; }
 	}
-	printf("fw %d mirror %d ref %d len %u\n", rc, rcm, rcr, rc == BT_OK ? fw.len : 0u);
+	printf("fw %d mirror %d ref %d len %llu\n", rc, rcm, rcr, rc == BT_OK ? (unsigned long long)fw.len : 0ull);
 	return 0;
 }

@@ -500,3 +500,56 @@ def test_large_index_option_takes_the_ebwtl_files(tmp_path):
             outs[tag] = hashlib.md5(p.stdout).hexdigest()
         assert outs["large"] == run["md5"], run["file"]
         assert outs["small"] != outs["large"]
+
+
+def test_wide_loader_survives_damaged_index_files(tmp_path):
+    """tests/emu/index_asan.cpp with -DBT_WIDE=1: the wide loader (64-bit tables, rank blocks and segment table built in threads
+    from the file's BWT, the row bias) under AddressSanitizer + UBSan on 250 damaged copies of a bowtie-build-l index -- it may
+    load them or refuse them, not crash"""
+    import random
+    import subprocess
+    if not os.path.exists(BUILD_L):
+        pytest.skip("needs oracle/_ref/bowtie-build-l")
+    exe = str(tmp_path / "index_asan_w")
+    r = subprocess.run(["g++", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-std=c++17", "-w", "-pthread", "-DBT_WIDE=1",
+                        "-o", exe, os.path.join(T.ROOT, "tests", "emu", "index_asan.cpp"), os.path.join(T.ROOT, "bowtie_amd", "csrc", "bt_host.cpp")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        f.write(">a x\nAGCATCGATCAGTATCTGACCNNNGTTAGGCATTACGGATCCATGCAAGTCTTGACGTACGGTCAATGC\n>b\nACGTTGCAAC\n")
+    subprocess.run([BUILD_L, "--ftabchars", "3", "--offrate", "2", "-q", fa, str(tmp_path / "g")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    exts = ["1.ebwtl", "2.ebwtl", "3.ebwtl", "4.ebwtl", "rev.1.ebwtl", "rev.2.ebwtl"]
+    orig = {e: open(str(tmp_path / "g") + "." + e, "rb").read() for e in exts}
+    w = str(tmp_path / "w")
+    seen = set()
+    for seed in range(250):
+        rng = random.Random(seed)
+        for e in exts:
+            with open(w + "." + e, "wb") as f:
+                f.write(orig[e])
+        e = rng.choice(exts)
+        b = bytearray(orig[e])
+        kind = rng.choice(["flip", "trunc", "word", "zero", "grow"])
+        if kind == "flip":
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif kind == "trunc":
+            b = b[:rng.randrange(0, len(b) + 1)]
+        elif kind == "word" and len(b) >= 8:
+            i = rng.randrange(0, min(len(b) - 7, 120))
+            b[i:i + 8] = rng.choice([bytes([255]) * 8, bytes(8), (1 << 40).to_bytes(8, "little"), (0x7fffffff).to_bytes(8, "little")])
+        elif kind == "zero":
+            b = bytearray(len(b))
+        else:
+            b += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 50)))
+        with open(w + "." + e, "wb") as f:
+            f.write(b)
+        env = dict(os.environ, BT_LOAD_THREADS=str(rng.choice([1, 3])))
+        if rng.random() < 0.3:
+            env.update(BT_WIDE_SEG_SHIFT="2", BT_WIDE_ROW_BIAS=str(1 << 32))
+        p = subprocess.run([exe, w], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
+        assert p.returncode == 0 and b"ERROR" not in p.stderr and b"runtime error" not in p.stderr, (seed, e, kind, p.stderr.decode(errors="replace")[-800:])
+        seen.add(p.stdout.split(b" len")[0])
+    assert len(seen) >= 3
