@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <exception>
 #include <mutex>
 #include <string.h>
@@ -190,6 +191,9 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 		std::vector<bt_row>().swap(h.ftab);
 	}
 	if (!need_mirror) ix->dev[1] = ix->dev[0];
+	/* the uploads above ran on the null stream (fills included, and a fill returns before it has run): nothing of them is
+	 * pending when a context -- whose stream does not wait for the null stream -- is created on this index */
+	if (hipDeviceSynchronize() != hipSuccess) { bt_index_free(ix); return BT_ERR_DEVICE; }
 	*out = ix;
 	return BT_OK;
 }
@@ -221,6 +225,15 @@ extern "C" void bt_index_free(bt_index* idx)
 	if (idx->retryFree) { (void)hipEventSynchronize(idx->retryFree); (void)hipEventDestroy(idx->retryFree); }
 	if (idx->retryArenas) (void)hipFree(idx->retryArenas);
 	delete idx;
+}
+
+/* A host structure to device memory, complete when the call returns -- whatever stream reads it next (the contexts' streams
+ * are non-blocking: nothing orders them behind the null stream the copy is issued on) */
+static hipError_t h2d_now(void* dst, const void* src, size_t bytes)
+{
+	hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+	return e;
 }
 
 static uint32_t env_u32(const char* name, uint32_t dflt)
@@ -319,14 +332,19 @@ static bool index_ensure_locus(const bt_index* cidx)
 	return true;
 }
 /* A/B and diagnostics: a context's launches with (1) or without (0) locus mode; 1 has no effect on an index without the image */
+static int ctx_flush_carry(bt_ctx* c);
 extern "C" int bt_ctx_set_locus(bt_ctx* c, int on)
 {
 	if (!c) return BT_ERR_ARG;
+	/* reads in flight were parked in the mode they were searched in (a lane in locus mode stands on a text offset, not on a
+	 * row): they are finished first, and the stream is idle when the descriptors change */
+	if (c->carryPending) { const int rc = ctx_flush_carry(c); if (rc != BT_OK) return rc; }
+	if (c->stream) HIPCHK(hipStreamSynchronize(c->stream));
 	c->locus = on && c->idx->locState > 0;
 	if (c->best && c->d_ix) {
 		BtIndexDev dv[2] = {c->idx->dev[0], c->idx->dev[1]};
 		if (!c->locus) for (int m = 0; m < 2; m++) { dv[m].loc = nullptr; dv[m].rtxt = nullptr; dv[m].walk = nullptr; }
-		HIPCHK(hipMemcpy(c->d_ix, dv, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
+		HIPCHK(h2d_now(c->d_ix, dv, 2 * sizeof(BtIndexDev)));
 	}
 	if (c->big) c->big->locus = c->locus;
 	return BT_OK;
@@ -363,9 +381,9 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 {
 	if (carry && !c->pool) {
 		HIPCHK(hipMalloc((void**)&c->pool, (size_t)c->nLanes * sizeof(BtPoolRec)));
-		HIPCHK(hipMemset(c->pool, 0, (size_t)c->nLanes * sizeof(BtPoolRec)));
+		HIPCHK(hipMemsetAsync(c->pool, 0, (size_t)c->nLanes * sizeof(BtPoolRec), c->stream));      /* (on the context's stream: see ctx_init) */
 		HIPCHK(hipMalloc((void**)&c->d_carry, 32 * 4));
-		HIPCHK(hipMemset(c->d_carry, 0, 32 * 4));
+		HIPCHK(hipMemsetAsync(c->d_carry, 0, 32 * 4, c->stream));
 		HIPCHK(hipHostMalloc((void**)&c->hostParked, BT_BATCH_RING * BT_BATCH_RING * 4));
 		memset(c->hostParked, 0, BT_BATCH_RING * BT_BATCH_RING * 4);
 		for (int i = 0; i < BT_BATCH_RING; i++) HIPCHK(hipEventCreateWithFlags(&c->evLaunch[i], hipEventDisableTiming));
@@ -445,8 +463,14 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	 * +15..23 % over two blocks, profiles/README.md); BT_NO_RL3=1 keeps every launch at blocksPerCU */
 	c->rl3 = env_u32("BT_NO_RL3", 0) == 0 && c->occ == 2;
 	c->nLanes = c->cus * (c->rl3 && c->blocksPerCU < 3u ? 3u : c->blocksPerCU) * BT_BLOCK;
+	/* Everything a context's launches read or update is initialised ON THE CONTEXT'S STREAM, never on the null stream: that
+	 * stream is non-blocking (it does not wait for the null stream), and hipMemset returns before the fill has run.  Until
+	 * round 6 these were null-stream hipMemset calls; with several processes on one GPU such a fill could run late -- after
+	 * the context's first launch had started -- and zero the read and mismatch-pool cursors under a running kernel: pool
+	 * entries handed out twice, "the right hit with another read's mismatch list" (DESIGN.md 4.3;
+	 * tests/test_gpu_parity.py::test_gpu_fresh_context_is_ordered_on_its_own_stream holds the null stream busy to show it). */
 	HIPCHK(hipMalloc((void**)&c->d_cursor, 64));
-	HIPCHK(hipMemset(c->d_cursor, 0, 64));
+	HIPCHK(hipMemsetAsync(c->d_cursor, 0, 64, c->stream));
 	/* carry-over between the launches of this context (bt_kernels.h): asked for with bt_ctx_set_carry or BT_CARRY=1 */
 	c->carryAge = env_u32("BT_CARRY", 0);
 	if (c->carryAge > BT_BATCH_RING - 2) c->carryAge = BT_BATCH_RING - 2;
@@ -457,16 +481,16 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	HIPCHK(hipMalloc((void**)&c->d_cold, sizeof(BtCold)));
 	HIPCHK(hipMalloc((void**)&c->d_warm, sizeof(BtWarm)));
 	HIPCHK(hipMalloc((void**)&c->d_counts, (CN_N + PS_N) * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long)));
+	HIPCHK(hipMemsetAsync(c->d_counts, 0, (CN_N + PS_N) * sizeof(unsigned long long), c->stream));
 	if (c->best) {
 		HIPCHK(hipMalloc((void**)&c->d_bprog, sizeof(BfProgram)));
 		HIPCHK(hipMalloc((void**)&c->d_ix, 2 * sizeof(BtIndexDev)));
 		HIPCHK(hipMalloc((void**)&c->d_batch, sizeof(BtBatchDev)));
-		HIPCHK(hipMemcpy(c->d_bprog, &c->bprog, sizeof(BfProgram), hipMemcpyHostToDevice));
+		HIPCHK(h2d_now(c->d_bprog, &c->bprog, sizeof(BfProgram)));
 		{
 			BtIndexDev dv[2] = {idx->dev[0], idx->dev[1]};
 			if (!c->locus) for (int m = 0; m < 2; m++) { dv[m].loc = nullptr; dv[m].rtxt = nullptr; dv[m].walk = nullptr; }
-			HIPCHK(hipMemcpy(c->d_ix, dv, 2 * sizeof(BtIndexDev), hipMemcpyHostToDevice));
+			HIPCHK(h2d_now(c->d_ix, dv, 2 * sizeof(BtIndexDev)));
 		}
 		/* blocks per CU = waves per SIMD the best-first kernel was compiled for (bt_best_kernels.hip, BT_BEST_MIN_BLOCKS);
 		 * BT_BEST_BLOCKS_PER_CU overrides it for A/B runs */
@@ -1000,7 +1024,7 @@ extern "C" int bt_index_load_reference(bt_index* ix)
 	void* p = nullptr;
 	HIPCHK(hipMalloc(&p, sizeof(d)));
 	ix->allocs.push_back(p);
-	HIPCHK(hipMemcpy(p, &d, sizeof(d), hipMemcpyHostToDevice));
+	HIPCHK(h2d_now(p, &d, sizeof(d)));
 	ix->d_ref = (BtRefDev*)p;
 	ix->ref_bytes = (R.bits.size() + R.nmask.size()) * 4ull;
 	return BT_OK;
@@ -1017,7 +1041,7 @@ static int ctx_ensure_paired(bt_ctx* c)
 	if (P.needMirror && !c->idx->has_mirror) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
 	HIPCHK(hipMalloc((void**)&c->d_bprog_pe, sizeof(BfProgram)));
-	HIPCHK(hipMemcpy(c->d_bprog_pe, &P, sizeof(P), hipMemcpyHostToDevice));
+	HIPCHK(h2d_now(c->d_bprog_pe, &P, sizeof(P)));
 	c->have_pe = true;
 	return BT_OK;
 }
@@ -1034,6 +1058,43 @@ extern "C" int bt_align_pairs_device(bt_ctx* c, const bt_read_batch* in1, const 
 	    (in1->stride & 15u) || (in2->stride & 15u)) return BT_ERR_ARG;
 	HIPCHK(hipSetDevice(c->idx->device));
 	return run_best_device(c, in1, out, (unsigned long long*)counts_dev, in2);
+}
+
+
+/* What a batch's hit records and its mismatch-pool cursor must agree on, checked on the host before results are handed
+ * back: every stored hit's list lies inside the entries the kernel handed out, and (exact != 0: one pass, no read flagged
+ * BT_STF_MMPOOL) the lists add up to the cursor -- each entry handed out belongs to exactly one stored hit.  Small batches
+ * (and any batch under BT_CHECK=1) are also checked for overlap: the lists, put in order, tile [0, cursor).  A batch that
+ * fails comes back as BT_ERR_DEVICE with both numbers, not as plausible results (round 5's driver run: "the right hit
+ * with another read's mismatch list", status OK). */
+static int check_mm_pool(const bt_hit_batch* out, uint32_t n, uint32_t cursor, bool exact, const char* what)
+{
+	const uint32_t used = cursor < out->mm_pool_cap ? cursor : out->mm_pool_cap;
+	uint64_t sum = 0, outside = 0; bool mmpool = false;
+	const size_t slots = (size_t)n * out->hit_cap;
+	for (uint32_t i = 0; i < n; i++) mmpool |= (out->status[i] & BT_STF_MMPOOL) != 0;
+	for (size_t k = 0; k < slots; k++) {
+		const bt_hit& h = out->hits[k];
+		if (!h.nmm) continue;
+		sum += h.nmm;
+		if ((uint64_t)h.mm_off + h.nmm > used) outside++;
+	}
+	bool bad = outside != 0 || (exact && !mmpool && sum != cursor) || (!exact && sum > cursor);
+	uint64_t overlaps = 0;
+	static const bool checkAll = getenv("BT_CHECK") && atoi(getenv("BT_CHECK")) != 0;
+	if (!bad && (slots <= (1u << 20) || checkAll)) {
+		std::vector<uint64_t> r;
+		for (size_t k = 0; k < slots; k++) if (out->hits[k].nmm) r.push_back(((uint64_t)out->hits[k].mm_off << 16) | out->hits[k].nmm);
+		std::sort(r.begin(), r.end());
+		uint64_t end = 0;
+		for (uint64_t v : r) { if ((v >> 16) < end) overlaps++; end = (v >> 16) + (v & 0xffffu); }
+		bad = overlaps != 0;
+	}
+	if (!bad) return BT_OK;
+	fprintf(stderr, "bowtie_amd: %s: the hit records and the mismatch-pool cursor disagree: %llu entries in stored hits, cursor %u (capacity %u), "
+	                "%llu lists outside the entries handed out, %llu overlapping -- results withheld\n",
+	        what, (unsigned long long)sum, cursor, out->mm_pool_cap, (unsigned long long)outside, (unsigned long long)overlaps);
+	return BT_ERR_DEVICE;
 }
 
 extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read_batch* in2, bt_hit_batch* out,
@@ -1081,7 +1142,7 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 		din[m].seq = d + o_seq[m]; din[m].qual = d + o_qual[m];
 		din[m].len = (const uint16_t*)(d + o_len[m]); din[m].seed = (const uint32_t*)(d + o_seed[m]);
 	}
-	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_mm - o_hits, c->stream));
+	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_cur + 256 - o_hits, c->stream));      /* results, pool and all: what the kernel does not write is zero, not whatever the allocation held */
 	bt_hit_batch dout = *out;
 	dout.hits = (bt_hit*)(d + o_hits); dout.n_hits = (uint32_t*)(d + o_nh); dout.status = d + o_st;
 	dout.mm_pool = out->mm_pool_cap ? (uint16_t*)(d + o_mm) : nullptr;
@@ -1091,11 +1152,16 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out->n_hits, d + o_nh, 4ull * n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out->status, d + o_st, n, hipMemcpyDeviceToHost, c->stream));
-	if (out->mm_pool_cap)
-		HIPCHK(hipMemcpyAsync(out->mm_pool, d + o_mm, 2ull * out->mm_pool_cap, hipMemcpyDeviceToHost, c->stream));
 	rc = bt_ctx_sync(c);
 	if (rc != BT_OK) return rc;
 	out->mm_pool_used = c->last_mm_used < out->mm_pool_cap ? c->last_mm_used : out->mm_pool_cap;
+	/* the entries the kernels handed out, not the pool's capacity */
+	if (out->mm_pool_used) {
+		HIPCHK(hipMemcpyAsync(out->mm_pool, d + o_mm, 2ull * out->mm_pool_used, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	/* (the on-stream second pass appends to the same pool: a pair searched twice leaves its first lists behind) */
+	if ((rc = check_mm_pool(out, n, c->last_mm_used, c->last_dev_retried == 0, c->is_big ? "bt_align_pairs (second pass)" : "bt_align_pairs")) != BT_OK) return rc;
 	if (counts) { rc = bt_ctx_counts(c, counts, 0); if (rc != BT_OK) return rc; }
 	/* pairs that outgrew their arena: again through the twin context's 16 MB arenas */
 	std::vector<uint32_t> redo;
@@ -1254,7 +1320,7 @@ extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 	/* what locus mode decided by the text is part of the reference's op counts all the same (bt_op_counts) */
 	out->loc_lfex = h[CN_TLFEX]; out->loc_lf1 = h[CN_TLF1]; out->loc_chase = h[CN_TCHASE]; out->loc_records = h[CN_LOCREC]; out->loc_windows = h[CN_TXTWIN];
 	out->lfex += out->loc_lfex; out->same_pair += out->loc_lfex; out->lf1 += out->loc_lf1; out->chase += out->loc_chase;
-	if (reset) HIPCHK(hipMemset(c->d_counts, 0, sizeof(h)));
+	if (reset) HIPCHK(hipMemsetAsync(c->d_counts, 0, sizeof(h), c->stream));      /* ordered before the next launch's tallies */
 	return BT_OK;
 }
 
@@ -1289,7 +1355,7 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	HIPCHK(hipMemcpyAsync(d + o_qual, in->qual, (size_t)n * in->stride, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(d + o_len, in->len, 2ull * n, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(d + o_seed, in->seed, 4ull * n, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_mm - o_hits, c->stream));
+	HIPCHK(hipMemsetAsync(d + o_hits, 0, o_cur + 256 - o_hits, c->stream));      /* results, pool and all: what the kernel does not write is zero, not whatever the allocation held */
 	bt_read_batch din = *in;
 	din.seq = d + o_seq; din.qual = d + o_qual; din.len = (const uint16_t*)(d + o_len); din.seed = (const uint32_t*)(d + o_seed);
 	bt_hit_batch dout = *out;
@@ -1301,11 +1367,16 @@ extern "C" int bt_align_batch(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* 
 	HIPCHK(hipMemcpyAsync(out->hits, d + o_hits, (size_t)n * out->hit_cap * sizeof(bt_hit), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out->n_hits, d + o_nh, 4ull * n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out->status, d + o_st, n, hipMemcpyDeviceToHost, c->stream));
-	if (out->mm_pool_cap)
-		HIPCHK(hipMemcpyAsync(out->mm_pool, d + o_mm, 2ull * out->mm_pool_cap, hipMemcpyDeviceToHost, c->stream));
 	rc = bt_ctx_sync(c);
 	if (rc != BT_OK) return rc;
 	out->mm_pool_used = c->last_mm_used < out->mm_pool_cap ? c->last_mm_used : out->mm_pool_cap;
+	/* the entries the kernel handed out, not the pool's capacity */
+	if (out->mm_pool_used) {
+		HIPCHK(hipMemcpyAsync(out->mm_pool, d + o_mm, 2ull * out->mm_pool_used, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	/* (the best-first engine's on-stream second pass appends to the same pool: a read searched twice leaves its first lists behind) */
+	if ((rc = check_mm_pool(out, n, c->last_mm_used, c->last_dev_retried == 0, c->is_big ? "bt_align_batch (second pass)" : "bt_align_batch")) != BT_OK) return rc;
 	if (counts) { rc = bt_ctx_counts(c, counts, 0); if (rc != BT_OK) return rc; }
 	/* reads whose search outgrew the per-read scratch are run again, on the GPU, through a twin
 	 * context sized for the worst case (few lanes, huge per-lane arenas) */
@@ -1723,6 +1794,17 @@ extern "C" int bt_index_digest(const char* ebwt_base, int mirror, uint64_t out[8
 	bt_row tail[8] = {h.zOff, h.fchr[0], h.fchr[1], h.fchr[2], h.fchr[3], h.fchr[4], (bt_row)h.offRate, (bt_row)h.ftabChars};
 	out[7] = fnv(tail, sizeof(tail));
 	return BT_OK;
+}
+
+/* Host-side, a few bytes of <base>.1.<ext> read: 1 = the index has 2^32-1 rows or more (libbowtie_amd_l.so's job),
+ * 0 = it fits 32-bit rows, < 0 = BT_ERR_IO / BT_ERR_FORMAT. */
+extern "C" int bt_index_needs_rows64(const char* ebwt_base)
+{
+	if (!ebwt_base) return BT_ERR_ARG;
+	uint64_t len = 0;
+	const int rc = bt_host_index_header_len(ebwt_base, &len);
+	if (rc != BT_OK) return rc;
+	return len >= 0xffffffffull ? 1 : 0;
 }
 
 extern "C" const char* bt_strerror(int code)

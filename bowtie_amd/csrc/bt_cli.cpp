@@ -938,7 +938,7 @@ int main(int argc, char** argv)
 				/* a --12 batch: the unpaired records leave for a job of their own */
 				std::unique_ptr<Job> u(new Job());
 				u->store.reset(new BtHostBatch());
-				if (!bt_io_split_tabbed(j->store.get(), j->store2.get(), u->store.get(), &j->order)) { err = "Error: internal: a --12 batch lost its pair flags"; r = BT_ERR_READS; }
+				if (!bt_io_split_tabbed(j->store.get(), j->store2.get(), u->store.get(), &j->order)) { j->error = "Error: internal: a --12 batch lost its pair flags"; r = BT_ERR_READS; }
 				j->rb = j->store->view(); j->rb2 = j->store2->view();
 				if (u->store->n) { u->rb = u->store->view(); j->unp = std::move(u); }
 				else j->order.clear();
@@ -975,6 +975,20 @@ int main(int argc, char** argv)
 		}
 	}
 	const std::string base = find_index(O.index);
+	if (!bt_rows64() && bt_index_needs_rows64(base.c_str()) == 1) {
+		/* 2^32-1 rows or more: the reference's wrapper starts bowtie-align-l for such an index (bowtie:52-81); here the
+		 * same sources built with 64-bit rows, next to this binary.  Decided from the index's header NOW, before the first
+		 * batch's thread takes a single read from the input: what comes from a pipe cannot be read twice */
+		char self[PATH_MAX];
+		const ssize_t n = readlink("/proc/self/exe", self, sizeof(self) - 3);
+		if (n > 0) {
+			self[n] = 0;
+			strcat(self, "-l");
+			fflush(stdout); fflush(stderr);
+			execv(self, argv);
+		}
+		die("Error: index \"%s\" has 2^32-1 rows or more and the 64-bit-row build (bowtie-amd-l) could not be started", O.index.c_str());
+	}
 	if (O.devices.empty()) O.devices.push_back(0);
 	std::unique_ptr<Job> first_job(new Job());
 	int first_rc = BT_OK;
@@ -1005,24 +1019,18 @@ int main(int argc, char** argv)
 		for (size_t d = 0; d < ND; d++) if (rcs[d] != BT_OK) { rc = rcs[d]; break; }
 	}
 	/* ---- index into HBM (above) ---- */
-	prefetch.join();
-	if (rc == BT_ERR_ROWS64 && !bt_rows64()) {
-		/* 2^32-1 rows or more: the reference's wrapper starts bowtie-align-l for such an index (bowtie:52-81); here the
-		 * same sources built with 64-bit rows, next to this binary */
-		char self[PATH_MAX];
-		const ssize_t n = readlink("/proc/self/exe", self, sizeof(self) - 3);
-		if (n > 0) {
-			self[n] = 0;
-			strcat(self, "-l");
-			fflush(stdout); fflush(stderr);
-			execv(self, argv);
-		}
-		die("Error: index \"%s\" has 2^32-1 rows or more and the 64-bit-row build (bowtie-amd-l) could not be started", O.index.c_str());
-	}
 	if (rc != BT_OK) {
-		if (rc == BT_ERR_IO) die("Could not locate a Bowtie index corresponding to basename \"%s\"", O.index.c_str());
-		die("Error: could not load index \"%s\": %s", O.index.c_str(), bt_strerror(rc));
+		/* said at once -- not after a first batch has been waited for (reads on a pipe may be a long time coming).  The
+		 * reader's thread may be inside the input at this moment: the process leaves without running static destructors
+		 * under it (nothing has been written yet) */
+		/* (an index of 2^32-1 rows or more never gets here in the 32-bit build: see above, before the first read was taken) */
+		if (rc == BT_ERR_ROWS64) fprintf(stderr, "Error: index \"%s\" has 2^32-1 rows or more: it needs the 64-bit-row build (bowtie-amd-l)\n", O.index.c_str());
+		else if (rc == BT_ERR_IO) fprintf(stderr, "Could not locate a Bowtie index corresponding to basename \"%s\"\n", O.index.c_str());
+		else fprintf(stderr, "Error: could not load index \"%s\": %s\n", O.index.c_str(), bt_strerror(rc));
+		fflush(nullptr);
+		_exit(1);
 	}
+	prefetch.join();
 	bt_index* idx = idxs[0];
 	if (O.timing) print_timer("Time loading forward and mirror index: ", now_s() - t0);
 	g_tl.mark("index loaded", 0);

@@ -84,6 +84,10 @@ enum {
 #define BT_TOS_WORDS 9       /* FR_W0..FR_ANCHOR travel to the LDS top-of-stack copy             */
 #define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
 #define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
+#define BT_LITE_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS)            /* the 3-waves-per-SIMD build: candidate, top-of-stack */
+#ifndef BT_LITE_CC
+#define BT_LITE_CC 1         /* 0: round 5's 3-waves build, without the current frame's candidate cache (A/B) */
+#endif
 
 struct BtArena {
 	/* arena bases and capacities (wave-uniform).  On the GPU this lives in LDS, one copy per
@@ -102,8 +106,10 @@ struct BtScratch {
 	uint32_t  slot;
 	uint32_t* tosRec;   /* the top-of-stack record region of `tos` (tos + 9*tosStride, or the whole of a
 	                       smaller LDS allocation when the candidate caches are off) */
-	uint32_t  noCC;     /* 1: no LDS candidate caches (the 3-waves-per-SIMD build: LDS holds the read and
-	                       the top-of-stack record only); choosing a target then always fetches its ranges */
+	uint32_t  noCC;     /* 0: both LDS candidate caches (the current frame's and the top-of-stack frame's); 1: none
+	                       (choosing a target then always fetches its ranges); 2: the current frame's only -- the
+	                       3-waves-per-SIMD build since round 6 (BT_LITE_CC): a frame popped back has to fetch its
+	                       target's ranges again, a frame that fails where it stands does not */
 	uint32_t  rlMax;    /* longest read this build's LDS copy holds (112, or 104 in the 3-waves-per-SIMD build) */
 	uint32_t* rl;       /* LDS copy of the lane's whole read (reads of <= BT_RL_MAXLEN bases; RL builds of the
 	                       automaton): word w at rl[w*tosStride]; [0,7) the bases, TWO bits each (16 to a word:
@@ -839,7 +845,8 @@ BT_HD void bt_frame_push(BtLane& L, const BtScratch& S)
 	uint32_t w[BT_TOS_WORDS];
 	w[FR_W0] = L.depth | (L.d << 11);
 	w[FR_W1] = L.ham | (L.lowAltQual << 16);
-	w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (L.ccValid << 26);
+	const uint32_t ccSave = S.noCC == 2u ? 0u : (uint32_t)L.ccValid;     /* (no room for the saved frame's candidate: it is fetched again) */
+	w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (ccSave << 26);
 	w[FR_W3] = L.f2 | (L.f3 << 11);
 	w[FR_W4] = L.altNum | (L.eligibleNum << 12);
 	w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25) | (L.el << 26);
@@ -852,7 +859,7 @@ BT_HD void bt_frame_push(BtLane& L, const BtScratch& S)
 	FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
 	BT_UNROLL
 	for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
-	if (L.ccValid) {
+	if (ccSave) {
 		BT_UNROLL
 		for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts] = S.tos[k * ts];
 	}
@@ -1299,7 +1306,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			} else {
 				bt_res_quartets(res, tp, bp);
 				mv = bt_u4_meta(res.x, e & 7u);
-				if (!BT_WIDE && !S.noCC) {
+				if (!BT_WIDE && S.noCC != 1u) {
 					BT_UNROLL
 					for (uint32_t k = 0; k < 4u; k++) { S.tos[k * ts] = (uint32_t)tp[k]; S.tos[(4u + k) * ts] = (uint32_t)bp[k]; }
 					S.tos[8u * ts] = mv;
@@ -1637,7 +1644,7 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 					/* deepest eligible target so far; its ranges go to the LDS candidate slot so that
 					 * choosing it later costs no fetch */
 					L.cand = d; L.candValid = 1;
-					if (!BT_WIDE && !S.noCC) {
+					if (!BT_WIDE && S.noCC != 1u) {
 						L.ccValid = 1;
 						const uint32_t ts = S.tosStride;
 						BT_UNROLL

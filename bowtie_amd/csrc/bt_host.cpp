@@ -237,6 +237,23 @@ int bt_host_index_variant(const std::string& base)
 }
 const char* bt_host_index_ext(int variant) { return variant >= 0 && variant < 4 ? kExt[variant] : "ebwt"; }
 
+/* The text length in the header of <base>.1.<ext>, whichever variant the base names: a few bytes read, nothing loaded.
+ * (bowtie-amd decides with it which binary runs -- before a single read has been taken from the input; the reference's
+ * wrapper looks at the file names for the same decision, bowtie:52-81.) */
+int bt_host_index_header_len(const std::string& base, uint64_t* len64)
+{
+	const int variant = bt_host_index_variant(base);
+	if (variant < 0) return BT_ERR_IO;
+	File f1(base + ".1." + kExt[variant]);
+	if (!f1.f) return BT_ERR_IO;
+	uint32_t one = 0;
+	if (!f1.rd(&one, 4)) return BT_ERR_IO;
+	if (one != 1 && one != (1u << 24)) return BT_ERR_FORMAT;
+	Reader R{f1, one != 1, variant >= 2};
+	*len64 = R.off();
+	return R.ok ? BT_OK : BT_ERR_IO;
+}
+
 int bt_host_index_load(const std::string& base, bool fw, int offrate_override, BtIndexHost* out, int variant)
 {
 	BtIndexHost& h = *out;
@@ -325,9 +342,12 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
 	if (!R.narrow) return BT_ERR_FORMAT;
 #if BT_WIDE
 	{
-		/* the test knobs (bt_host.h): rows numbered from a bias, small segments */
-		if (const char* e = getenv("BT_WIDE_SEG_SHIFT")) { const long v = atol(e); if (v >= 2 && v <= 25) h.segShift = (uint32_t)v; }
-		if (const char* e = getenv("BT_WIDE_ROW_BIAS")) {
+		/* the test knobs (bt_host.h): rows numbered from a bias, small segments -- how rows beyond 2^32 are exercised on a
+		 * genome of a few Mbp.  Honoured only where BT_TEST_KNOBS=1 says this is a test (tests/conftest.py sets it) */
+		const char* tk = getenv("BT_TEST_KNOBS");
+		const bool knobs = tk && *tk && *tk != '0';
+		if (const char* e = knobs ? getenv("BT_WIDE_SEG_SHIFT") : nullptr) { const long v = atol(e); if (v >= 2 && v <= 25) h.segShift = (uint32_t)v; }
+		if (const char* e = knobs ? getenv("BT_WIDE_ROW_BIAS") : nullptr) {
 			const uint64_t b = strtoull(e, nullptr, 0);
 			/* whole segments, whole 16-byte pieces of the SA sample (two entries), block numbers that stay 32 bits */
 			if ((b & ((1ull << (h.segShift + 6u)) - 1u)) != 0 || (b & ((2ull << h.offRate) - 1u)) != 0 || b >= (1ull << 37) || b + len64 >= (1ull << 38)) return BT_ERR_ARG;

@@ -60,6 +60,8 @@ int bt_host_index_load(const std::string& base, bool fw, int offrate_override, B
  * order the reference looks for them; and its file extension. */
 int bt_host_index_variant(const std::string& base);
 const char* bt_host_index_ext(int variant);
+/* the text length the header of <base>.1.<ext> states (nothing else is read) */
+int bt_host_index_header_len(const std::string& base, uint64_t* len64);
 
 /* Fill the device-visible descriptor from host-side geometry (pointers are left to the caller). */
 void bt_host_index_describe(const BtIndexHost& h, BtIndexDev* d);

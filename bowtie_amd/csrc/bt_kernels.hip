@@ -123,7 +123,7 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 {
 	__shared__ uint32_t RLB[RL ? (LITE ? BT_RL3_WORDS : BT_RL_WORDS) * BT_BLOCK : 1];  /* RL: every lane's whole read */
 	__shared__ unsigned long long CNT[CN_N + PS_N];
-	__shared__ uint32_t TOS[(LITE ? BT_TOS_WORDS : BT_LDS_WORDS) * BT_BLOCK];   /* per lane: candidate, top-of-stack record, its candidate */
+	__shared__ uint32_t TOS[(LITE ? (BT_LITE_CC ? BT_LITE_LDS_WORDS : BT_TOS_WORDS) : BT_LDS_WORDS) * BT_BLOCK];   /* per lane: candidate, top-of-stack record, its candidate (LITE: not the last) */
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	__shared__ BtWarm WARM;                                    /* index geometry (see BtWarm) */
 	__shared__ BtArena ARENA;                                  /* scratch arena bases + capacities */
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	constexpr int PIECES = RL ? LANE_PIECES_RL : LANE_PIECES;
 	static_assert(LANE_PIECES <= BT_POOL_REQ, "pool record layout: at most BT_POOL_REQ pieces of lane state, then request and stamp");
 	S.tos = TOS + threadIdx.x; S.tosStride = BT_BLOCK;
-	S.tosRec = LITE ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
-	S.noCC = LITE ? 1u : 0u;
+	S.tosRec = (LITE && !BT_LITE_CC) ? S.tos : S.tos + BT_CC_WORDS * BT_BLOCK;
+	S.noCC = LITE ? (BT_LITE_CC ? 2u : 1u) : 0u;
 	S.rlMax = LITE ? BT_RL3_MAXLEN : BT_RL_MAXLEN;
 	S.rl = RLB + (RL ? threadIdx.x : 0u);
 

@@ -216,6 +216,10 @@ int  bt_index_restore_text(const char* ebwt_base, uint8_t* out, uint64_t cap);
  * length, out[2..7] = FNV-1a-64 digests of the loaded image's arrays (ebwt, ftab, eftab, offs,
  * plen+rstarts, zOff/fchr/offRate/ftabChars).  Equal digests = the same image, whatever the files. */
 int  bt_index_digest(const char* ebwt_base, int mirror, uint64_t out[8]);
+/* Host-side utility (no GPU), a few bytes of the header read: 1 = the index has 2^32-1 rows or more and needs the
+ * build with 64-bit rows, 0 = it does not, < 0 = BT_ERR_IO / BT_ERR_FORMAT.  Replaces: the file-name test by which
+ * the reference's wrapper picks bowtie-align-l (bowtie:52-81) -- decided before any read is taken from the input. */
+int  bt_index_needs_rows64(const char* ebwt_base);
 
 /* Replaces: the per-thread set-up at the top of each worker (sink, params, 1..9
  * GreedyDFSRangeSource objects; ebwt_search.cpp:1155, 2082-2134, 2413-2539).  One ctx per GPU,
@@ -228,7 +232,12 @@ void bt_ctx_destroy(bt_ctx* ctx);
  *   bt_align_batch         : host pointers in `in`/`out`; copies H2D, runs, copies D2H.
  *   bt_align_batch_device  : every pointer in `in`/`out` is a device pointer (reads already in
  *                            HBM, hits stay in HBM); asynchronous on the ctx stream.  `counts`
- *                            (optional, device pointer to bt_op_counts) is accumulated into. */
+ *                            (optional, device pointer to bt_op_counts) is accumulated into.
+ *                            Stream order is the caller's: a context's own stream (stream == NULL at
+ *                            bt_ctx_create) is NON-BLOCKING -- it does not wait for the null stream -- so
+ *                            whatever produced the arrays on another stream (a fill, a copy, a kernel)
+ *                            must be complete, or the caller's stream must be the one the context was
+ *                            created on. */
 int  bt_align_batch(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, bt_op_counts* counts);
 int  bt_align_batch_device(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out,
                            bt_op_counts* counts_dev);

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the loader's test knobs (bt_host.cpp: BT_WIDE_ROW_BIAS, BT_WIDE_SEG_SHIFT) are honoured only where this says "a test"
+os.environ.setdefault("BT_TEST_KNOBS", "1")
 
 
 @pytest.hookimpl(tryfirst=True)
@@ -33,6 +35,7 @@ def pytest_configure(config):
         emu_lib.shim()
         emu_lib.wide_lib()          # the same with 64-bit rows (libbowtie_amd_l.so's sources)
         emu_lib.wide_shim()
+        emu_lib.build_stall()       # tests/emu/gpu_stall.hip (GPU tests: a stream held busy)
 
 
 def _has_gpu() -> bool:

@@ -185,7 +185,7 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		scr[g].tos = tos.data() + g; scr[g].tosStride = nLanes;
 		scr[g].rl = rlbuf.data() + g;
 		scr[g].tosRec = scr[g].tos + (size_t)BT_CC_WORDS * nLanes;
-		scr[g].noCC = (lite || BT_WIDE) ? 1u : 0u;      /* (the wide build has no candidate caches: a range-stack entry is 64 bytes) */
+		scr[g].noCC = BT_WIDE ? 1u : (lite ? (BT_LITE_CC ? 2u : 1u) : 0u);      /* (the wide build has no candidate caches: a range-stack entry is 64 bytes) */
 		scr[g].rlMax = lite ? BT_RL3_MAXLEN : BT_RL_MAXLEN;
 	}
 	uint32_t next = 0, live = nLanes;

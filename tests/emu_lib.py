@@ -9,6 +9,8 @@ import subprocess
 
 import numpy as np
 
+os.environ.setdefault("BT_TEST_KNOBS", "1")      # the loader's test knobs (row bias, segment size) are for tests: this is one
+
 from bowtie_amd import _abi as A
 from bowtie_amd.aligner import unpack_hits
 from bowtie_amd.reads import ReadBatch
@@ -190,3 +192,29 @@ class EmuAligner:
         if rc != 0:
             raise RuntimeError("emu_align_pairs rc=%d" % rc)
         return unpack_pair_hits(n, hit_cap, hits, n_hits, status, pool, pol)
+
+
+# tests/emu/gpu_stall.hip: keeps a HIP stream busy for a stated time (GPU tests; compiled here with hipcc, which cross-compiles
+# gfx950 without a GPU, so that the .so travels to the GPU box with the snapshot)
+STALL_PATH = os.path.join(EMU_DIR, "libgpu_stall.so")
+STALL_SRC = os.path.join(EMU_DIR, "gpu_stall.hip")
+_stall = None
+
+
+def build_stall():
+    if not os.path.exists(STALL_PATH) or os.path.getmtime(STALL_PATH) < os.path.getmtime(STALL_SRC):
+        tmp = STALL_PATH + ".tmp%d" % os.getpid()
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-o", tmp, STALL_SRC])
+        os.replace(tmp, STALL_PATH)
+    return STALL_PATH
+
+
+def stall_lib():
+    global _stall
+    if _stall is None:
+        L = C.CDLL(build_stall())
+        L.gpu_stall.argtypes = [C.c_void_p, C.c_uint]
+        L.gpu_stall_probe.argtypes = [C.c_int, C.c_uint, C.c_size_t]
+        L.gpu_stall_probe.restype = C.c_longlong
+        _stall = L
+    return _stall

@@ -273,6 +273,36 @@ def test_gpu_scratch_overflow_is_retried(gidx, monkeypatch):
         T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "overflow-retry " + mode)
 
 
+def test_gpu_fresh_context_is_ordered_on_its_own_stream(gidx, monkeypatch):
+    """Round 6's finding: a context's cursors were zeroed by null-stream hipMemset calls, which return
+    before the fill has run -- and the context's stream, being non-blocking, does not wait for the null stream.  With several
+    processes on one GPU the fill could run late: after the first launch, before its mismatch-pool cursor was read (the first
+    pass then "handed out no entries" and the second pass's lists were written over the first's: the right hit with another
+    read's mismatch list), or under the twin context's first launch (the second pass's lists empty).
+    Here the null stream is held busy (tests/emu/gpu_stall.hip) while each context is created and runs its first batch, so
+    that anything still enqueued on it runs after the batch: on the parent of the fix this test fails every time
+    (scripts/r6/repro_null_stream.py runs it against that library), with the fix nothing of a context depends on the null
+    stream any more."""
+    import torch
+    import emu_lib
+    stall = emu_lib.stall_lib()
+    monkeypatch.setenv("BT_ENTRY_CAP", "12")
+    monkeypatch.setenv("BT_FRAME_CAP", "3")
+    monkeypatch.setenv("BT_PARTIAL_CAP", "4")
+    keep = [aligner(gidx, ix, T.MODES["n2"]) for ix in ("e_coli", "multi")]      # (the locus images exist: creating a context waits for nothing)
+    torch.cuda.synchronize()
+    for index, rname, mode in (("multi", "syn100", "n2"), ("e_coli", "syn76", "v2"), ("multi", "syn36", "n2_k3")):
+        batch = T.read_set(index, rname)
+        kw = T.MODES[mode]
+        assert stall.gpu_stall(None, 250) == 0              # the null stream is busy for a quarter of a second ...
+        al = aligner(gidx, index, kw)                       # ... while the context is created ...
+        keep.append(al)                                     # (destroying one frees device memory, which waits for the device)
+        got = al.align(batch, hit_cap=T.hit_cap_for(kw))    # ... and searches its first batch, second pass and all
+        assert al.last_retried > batch.n // 20, (mode, al.last_retried)
+        T.compare_results(got, T.oracle_results(index, batch, kw, cap=T.hit_cap_for(kw)), "busy null stream " + mode)
+        torch.cuda.synchronize()
+
+
 def test_gpu_hits_verify_against_text_large(gidx):
     """2 M reads through the device-pointer path (what bench.py times), then every reported hit
     re-derived from the text on the GPU (bowtie_amd/verify.py): windows, mismatch lists, policy, cost."""
@@ -294,6 +324,7 @@ def test_gpu_hits_verify_against_text_large(gidx):
         al = aligner(gidx, "e_coli", kw)
         rbc = A.ReadBatchC(n, rb["stride"], rb["seq"].data_ptr(), rb["qual"].data_ptr(), rb["len"].data_ptr(), rb["seed"].data_ptr())
         hbc = A.HitBatchC(1, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), pool.data_ptr(), n * 8, 0)
+        torch.cuda.synchronize()        # torch filled these arrays on ITS stream: the context's stream does not wait for that one
         assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
         assert AL.lib().bt_ctx_sync(al._h) == 0
         r = V.verify_hits(text_t, ln, rstarts, rb["seq"], rb["qual"], L, hits, n_hits, pool, kw)
@@ -319,6 +350,7 @@ def _device_align(al, batch, stride, hit_cap):
     pool = torch.zeros(n * hit_cap * 8, dtype=torch.int16, device=dev)
     rbc = A.ReadBatchC(n, stride, seq.data_ptr(), qual.data_ptr(), ln.data_ptr(), seed.data_ptr())
     hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), pool.data_ptr(), pool.numel(), 0)
+    torch.cuda.synchronize()            # torch filled these arrays on ITS stream: the context's stream does not wait for that one
     assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
     assert AL.lib().bt_ctx_sync(al._h) == 0
     pol = al.policy
@@ -382,6 +414,7 @@ def _device_align_many(al, batches, stride, hit_cap):
         rbc = A.ReadBatchC(n, stride, seq.data_ptr(), qual.data_ptr(), ln.data_ptr(), seed.data_ptr())
         hbc = A.HitBatchC(hit_cap, hits.data_ptr(), n_hits.data_ptr(), status.data_ptr(), pool.data_ptr(), pool.numel(), 0)
         keep.append((seq, qual, ln, seed, hits, n_hits, status, pool, rbc, hbc, n))
+        torch.cuda.synchronize()        # torch filled these arrays on ITS stream: the context's stream does not wait for that one
         assert AL.lib().bt_align_batch_device(al._h, C.byref(rbc), C.byref(hbc), None) == 0
     assert AL.lib().bt_ctx_sync(al._h) == 0
     pol = al.policy

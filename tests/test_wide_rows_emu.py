@@ -443,6 +443,28 @@ def test_bowtie_amd_starts_bowtie_amd_l_for_such_an_index(tmp_path):
     assert p.returncode != 0 and "could not be started" not in err and "2^32-1 rows" in err, err
 
 
+def test_bowtie_amd_picks_the_binary_before_it_takes_a_read_from_a_pipe(tmp_path):
+    """Reads on standard input, from a pipe whose writer has sent nothing yet: bowtie-amd must start bowtie-amd-l for an index
+    of 2^32 rows WITHOUT waiting for -- let alone consuming -- a first batch (what it has read from a pipe the second binary
+    never sees; the reference's wrapper decides from the file names before anything runs, bowtie:52-81).  Until round 6 the
+    first batch was parsed before the decision: this call then blocks on the silent pipe until the timeout."""
+    import subprocess
+    base = str(tmp_path / "huge")
+    _fake_huge_index(base)
+    env = dict(os.environ, LD_PRELOAD=E.shim())
+    p = subprocess.Popen([os.path.join(T.ROOT, "bowtie_amd", "bowtie-amd"), "-x", base, "-"], env=env, stdin=subprocess.PIPE,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        p.wait(timeout=60)                       # nothing is written to its stdin, which stays open
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.wait()
+        raise AssertionError("bowtie-amd waited for reads from the pipe before it chose the 64-bit-row binary")
+    err = p.stderr.read().decode(errors="replace")
+    p.stdin.close()
+    assert p.returncode != 0 and "could not be started" not in err and "2^32-1 rows" in err, err
+
+
 @pytest.mark.parametrize("wide_build", [False, True], ids=["rows32", "rows64"])
 def test_carry_over_round_trip_on_the_host_build(wide_build):
     """EMU_PARK_EVERY (tests/emu/bt_emu.cpp): every lane is parked and adopted again in one round out of three, at random -- its

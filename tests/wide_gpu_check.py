@@ -3,6 +3,7 @@ BT_LIB=libbowtie_amd_l.so (the binding holds one library per process) and, for t
 in the environment (BT_WIDE_ROW_BIAS, BT_WIDE_SEG_SHIFT: tests/test_wide_rows_emu.py has the story).  Everything goes through
 the C ABI; the oracle and the reference's golden outputs are the checkers.  usage: wide_gpu_check.py <what> [index]"""
 import os
+os.environ.setdefault("BT_TEST_KNOBS", "1")      # the loader honours BT_WIDE_ROW_BIAS / BT_WIDE_SEG_SHIFT only for tests
 import sys
 
 import numpy as np
