@@ -74,17 +74,35 @@ def gather_ceiling(index_kind: str, al=None, cus: int = 0):
         return None
 
 
-# the round whose source a kernel's PMC profile must have been taken on to describe it still: bump a kernel's entry when its
-# source changes.  bt_search_kernel: round 3 (round 4 changed nothing in it: its device code differs from the measured one by
-# the size of the argument block only); the best-first kernels: round 4 (the automaton, the organised engine)
-KERNEL_ROUNDS = {"bt_search_kernel": 5, "bt_best_kernel": 4, "bt_best_nested_kernel": 4}      # bt_search_kernel: round 5 = locus mode
+# A PMC profile describes a kernel only as long as the kernel's source is what was profiled: the template name survives source
+# changes, so an entry of profiles/traffic.json carries the SHA-256 (16 hex digits) of the source files its kernel is compiled
+# from, and is used only while they are unchanged (round 5's hand-kept round numbers went stale: VERDICT r5).  Otherwise
+# `traffic` is null.  `python bench.py --kernel-sha` prints the current digests.
+KERNEL_SOURCES = {
+    "bt_search_kernel": ("bt_rank.h", "bt_core.h", "bt_kernels.h", "bt_kernels.hip"),
+    "bt_best_kernel": ("bt_rank.h", "bt_best.h", "bt_kernels.h", "bt_best_kernels.hip"),
+    "bt_best_nested_kernel": ("bt_rank.h", "bt_best.h", "bt_kernels.h", "bt_best_kernels.hip"),
+}
+
+
+def kernel_source_sha16(kernel: str):
+    import hashlib
+    files = KERNEL_SOURCES.get(kernel.split("<")[0].split(" ")[0])
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "bowtie_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(kernel: str, workload: str):
     try:
+        sha = kernel_source_sha16(kernel)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for e in json.load(f)["entries"]:
-                if e["kernel"] == kernel and e["workload"] == workload and e.get("kernel_round") == KERNEL_ROUNDS.get(kernel.split("<")[0]):
+                if e["kernel"] == kernel and e["workload"] == workload and sha and e.get("source_sha16") == sha:
                     return e
     except (OSError, ValueError, KeyError):
         pass
@@ -392,7 +410,11 @@ def main():
     ap.add_argument("--dry-ranks", action="store_true",
                     help="no GPU work: start the ranks, reduce made-up per-rank hit counters the way the real run does, print the "
                          "line's skeleton (CPU test of the launch + reduce path)")
+    ap.add_argument("--kernel-sha", action="store_true", help="print the source digests profiles/traffic.json entries are keyed by, and exit")
     args = ap.parse_args()
+    if args.kernel_sha:
+        print(json.dumps({k: kernel_source_sha16(k) for k in KERNEL_SOURCES}))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own (the driver's command shape): start one rank per GPU ourselves, the way
@@ -737,6 +759,10 @@ def main():
             cb["value_counts"] = "reads processed per second; the reference's results are the product's (diff_mismatches), so the same fraction aligns"
             cb["aligned_reads_per_s"] = cb["value"] * aligned_all / max(1.0, reads_all)
             out["cpu_baseline"] = cb
+            # (`vs_baseline` stays null: BASELINE.md holds no published number for this metric.  This is the run's own ratio:
+            # reads processed per second here over the reference's at its best -p on this host's cores, same reads, same results)
+            if cb.get("value"):
+                out["vs_cpu_baseline"] = out["reads_processed_per_s"] / cb["value"]
             out["config"]["reads_diffed_vs_reference"] = cb.get("reads_diffed_vs_reference")
             out["config"]["diff_mismatches"] = cb.get("diff_mismatches")
         if args.env_sweep and world == 1:

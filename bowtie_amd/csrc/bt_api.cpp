@@ -100,6 +100,9 @@ struct bt_ctx {
 	uint32_t last_mm_used = 0;
 	uint32_t* iters_dev = nullptr;     /* optional per-read iteration counts (diagnostics) */
 	struct bt_stream* hs = nullptr;    /* bt_align_stream_*: staging slots of the batches in flight */
+	/* the environment's knobs (diagnostics, A/B, tests), read ONCE per context: a launch path that calls getenv a dozen times
+	 * is noise at 22 ms streamed launches (ctx_env) */
+	struct { const char* name; uint32_t value; } envc[64]; uint32_t nEnvc = 0;
 };
 
 template <class T> static int upload(bt_index* ix, const std::vector<T>& v, const T** out, size_t pad_elems = 0)
@@ -240,6 +243,15 @@ static uint32_t env_u32(const char* name, uint32_t dflt)
 {
 	const char* v = getenv(name);
 	return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
+/* env_u32 through the context's cache: the environment is looked at the first time a context asks for a knob */
+static uint32_t ctx_env(bt_ctx* c, const char* name, uint32_t dflt)
+{
+	for (uint32_t i = 0; i < c->nEnvc; i++) if (c->envc[i].name == name || strcmp(c->envc[i].name, name) == 0) return c->envc[i].value;
+	const uint32_t v = env_u32(name, dflt);
+	if (c->nEnvc < 64u) { c->envc[c->nEnvc].name = name; c->envc[c->nEnvc].value = v; c->nEnvc++; }
+	return v;
 }
 
 /* A small host structure (a descriptor block, the cursors' initial values) to device memory, on the context's stream.
@@ -557,7 +569,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	 * 16 K and 64 K words -- reads with hundreds of seed extenders, the slow ones -- and whatever outgrows its arena
 	 * lands in the second pass below, which has a thousand lanes instead of a quarter of a million: with 16 K-word
 	 * arenas that pass took minutes per million reads (profiles/r3/best_arena.txt) */
-	const uint32_t words = c->is_big ? (1u << 22) : env_u32("BT_BEST_ARENA_WORDS", 65536u);
+	const uint32_t words = c->is_big ? (1u << 22) : ctx_env(c, "BT_BEST_ARENA_WORDS", 65536u);
 	/* one arena per lane that the launch can use: a small batch does not fill the grid, and 64 KB x 393 216 lanes
 	 * (six blocks per CU) are 26 GB that a thousand-read batch has no use for */
 	uint32_t lanes = c->is_big ? (c->nLanes > 256u ? 256u : c->nLanes) : c->nLanes;
@@ -575,7 +587,7 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		 * the lanes rather than ending the run (a launch with fewer lanes is slower, not wrong) */
 		size_t freeB = 0, totB = 0;
 		if (hipMemGetInfo(&freeB, &totB) == hipSuccess) {
-			const uint64_t budget = (uint64_t)freeB / 100u * env_u32("BT_BEST_ARENA_FRAC", 45u);
+			const uint64_t budget = (uint64_t)freeB / 100u * ctx_env(c, "BT_BEST_ARENA_FRAC", 45u);
 			const uint64_t fit = budget / ((uint64_t)words * 4u) / BT_BLOCK * BT_BLOCK;
 			if (fit < lanes) lanes = fit < BT_BLOCK ? BT_BLOCK : (uint32_t)fit;
 		} else (void)hipGetLastError();
@@ -591,10 +603,10 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		/* fewer lanes than asked for is slower, not wrong -- but say so once (BT_VERBOSE), and ask again when the caller's
 		 * batches still want more and the device may have room by then: arenaAsked stands only as long as memory is short */
 		if (lanes < c->arenaAsked) {
-			if (getenv("BT_VERBOSE")) fprintf(stderr, "bowtie_amd: best-first arenas for %u lanes instead of %u (device memory: %.1f of %.1f GB free)\n",
+			if (ctx_env(c, "BT_VERBOSE", 0)) fprintf(stderr, "bowtie_amd: best-first arenas for %u lanes instead of %u (device memory: %.1f of %.1f GB free)\n",
 			                                  lanes, c->arenaAsked, freeB / 1e9, totB / 1e9);
 			size_t f2 = 0, t2 = 0;
-			if (hipMemGetInfo(&f2, &t2) == hipSuccess && (uint64_t)f2 / 100u * env_u32("BT_BEST_ARENA_FRAC", 45u) >= (uint64_t)c->arenaAsked * words * 4u)
+			if (hipMemGetInfo(&f2, &t2) == hipSuccess && (uint64_t)f2 / 100u * ctx_env(c, "BT_BEST_ARENA_FRAC", 45u) >= (uint64_t)c->arenaAsked * words * 4u)
 				c->arenaAsked = lanes;        /* there is room after all (another context went away): the next call may grow */
 		}
 	}
@@ -624,14 +636,14 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	 * e_coli, whose index sits in the L2 caches, 0.48x / 0.72x.  So: the automaton when the index does not fit the
 	 * Infinity Cache (256 MB; the rank blocks are half a byte per base), BT_BEST_NESTED=0/1 to say otherwise. */
 	{
-		const char* nv = getenv("BT_BEST_NESTED");
+		const uint32_t nv = ctx_env(c, "BT_BEST_NESTED", 2u);           /* 0 / 1 say which; unset: by the index's size */
 		const bool small = (uint64_t)c->idx->dev[0].len < (512ull << 20);
-		A.nested = (in2 && c->pol.pe_v1) || (nv && *nv ? atoi(nv) != 0 : small) ? 1u : 0u;
+		A.nested = (in2 && c->pol.pe_v1) || (nv != 2u ? nv != 0u : small) ? 1u : 0u;
 	}
 	/* the gates' defaults: scripts/best_wave_model.py's pick, then the GPU A/B of profiles/r4/ */
-	A.coldMin = env_u32("BT_BEST_COLD_MIN", 16); A.takeMin = env_u32("BT_BEST_TAKE_MIN", 16);
-	A.sendPeriod = env_u32("BT_BEST_SEND_PERIOD", 4); A.sendMin = env_u32("BT_BEST_SEND_MIN", 24);
-	A.sweepTwice = env_u32("BT_BEST_SWEEP_TWICE", 0);
+	A.coldMin = ctx_env(c, "BT_BEST_COLD_MIN", 16); A.takeMin = ctx_env(c, "BT_BEST_TAKE_MIN", 16);
+	A.sendPeriod = ctx_env(c, "BT_BEST_SEND_PERIOD", 4); A.sendMin = ctx_env(c, "BT_BEST_SEND_MIN", 24);
+	A.sweepTwice = ctx_env(c, "BT_BEST_SWEEP_TWICE", 0);
 	/* per-launch HIP events, as on the phase-program path (bt_ctx_span_ms / bt_ctx_launch_ms) */
 	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }
 	hipEvent_t* ring = c->evRing[c->spanLaunches & 15u];
@@ -640,13 +652,13 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	snprintf(c->last_kernel, sizeof(c->last_kernel), A.nested ? "bt_best_nested_kernel" : "bt_best_kernel");
 	if (bt_launch_best(&A, nBlocks, c->stream) != 0) return BT_ERR_DEVICE;
-	if (!c->is_big && env_u32("BT_BEST_DEVICE_RETRY", 1)) {
+	if (!c->is_big && ctx_env(c, "BT_BEST_DEVICE_RETRY", 1)) {
 		/* reads that outgrew their arena: collected and searched again on the stream, 1024 lanes with 16 MB
 		 * arenas each -- the caller of the device-pointer entry points sees finished results only.  (256 lanes were
 		 * tried to save memory: on the hg19-scale index enough reads come here that the pass then takes several
 		 * times as long as the main launch, profiles/r3/.) */
 		const uint32_t bigWords = 1u << 22;
-		uint32_t bigLanes = env_u32("BT_BEST_RETRY_LANES", in->n_reads >= (1u << 18) ? 1024u : 256u);
+		uint32_t bigLanes = ctx_env(c, "BT_BEST_RETRY_LANES", in->n_reads >= (1u << 18) ? 1024u : 256u);
 		const int rrc = ctx_ensure_retry_list(c, in->n_reads);
 		if (rrc != BT_OK) return rrc;
 		if (bt_launch_collect_flagged(out->status, in->n_reads, BT_STF_OVERFLOW, c->retryList, c->d_cursor + 2, c->retryCap, c->stream) != 0) return BT_ERR_DEVICE;
@@ -680,11 +692,11 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		 * eighth_call_second_pass.txt, ninth_call_second_pass_stride.txt; step = main launch + this pass): 64 to a
 		 * wavefront 4.2 s per step (call by call: 5.5 s), every 16th lane 2.8 s (call by call: 2.5 s), one per wavefront
 		 * 2.45 s = 10.2 M reads/s against 5.9 M. */
-		uint32_t stride = env_u32("BT_BEST_RETRY_STRIDE", 64);
+		uint32_t stride = ctx_env(c, "BT_BEST_RETRY_STRIDE", 64);
 		if (stride < 1u) stride = 1u;
 		if (stride > 64u) stride = 64u;
 		A2.laneStride = stride;
-		A2.nested = env_u32("BT_BEST_RETRY_NESTED", 0) ? 1u : A.nested;
+		A2.nested = ctx_env(c, "BT_BEST_RETRY_NESTED", 0) ? 1u : A.nested;
 		if (bt_launch_best(&A2, bigLanes / BT_BLOCK * stride, c->stream) != 0) return BT_ERR_DEVICE;
 		HIPCHK(hipEventRecord(ix->retryFree, c->stream));
 	}
@@ -743,7 +755,7 @@ static int enqueue_retry(bt_ctx* c, const BtKernelArgs& A0, const BatchView& v, 
 	R.nextRead = c->d_cursor + 9;
 	R.order = c->retryList; R.orderCount = c->d_cursor + 8; R.orderCap = c->retryCap;
 	R.pool = nullptr; R.adopt = 0; R.park = 0; R.parkedOf = nullptr;
-	if (bt_launch_search(&R, b->nLanes / BT_BLOCK, c->occ, maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0) ? 1 : 0, c->stream) != 0)
+	if (bt_launch_search(&R, b->nLanes / BT_BLOCK, c->occ, (maxLen <= BT_RL_MAXLEN && !ctx_env(c, "BT_NO_RL", 0) ? 1 : 0) | (ctx_env(c, "BT_FORCE_EXT", 0) ? BT_RL_FORCE_EXT : 0), c->stream) != 0)
 		return BT_ERR_DEVICE;
 	return BT_OK;
 }
@@ -775,7 +787,7 @@ static int ctx_flush_carry(bt_ctx* c)
 	memset(&none, 0, sizeof(none));
 	fill_cold(c, &cold, none, bid);
 	const BatchView& lastB = c->ring[(c->launchSeq - 1u) & (BT_BATCH_RING - 1u)];
-	const uint32_t keep = env_u32("BT_FLUSH_KEEP_BATCH", 0);   /* diagnostics: 1 = the last batch stands in as the current one */
+	const uint32_t keep = ctx_env(c, "BT_FLUSH_KEEP_BATCH", 0);   /* diagnostics: 1 = the last batch stands in as the current one */
 	if (keep) cold.B = lastB.B;
 	BT_H2D(c->d_cold, &cold, sizeof(cold));
 	BT_H2D(c->d_warm, &warm, sizeof(warm));
@@ -791,9 +803,9 @@ static int ctx_flush_carry(bt_ctx* c)
 	A.nextRead = c->d_cursor;
 	A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = 1; A.park = 0; A.maxAge = 0; A.parkedOf = c->d_carry;
 	HIPCHK(hipEventRecord(c->evFlush[0], c->stream));
-	const bool dbg = env_u32("BT_CARRY_DEBUG", 0) != 0;       /* diagnostics: name and fence every carry launch */
+	const bool dbg = ctx_env(c, "BT_CARRY_DEBUG", 0) != 0;       /* diagnostics: name and fence every carry launch */
 	if (dbg) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] flush launch seq=%u blocks=%u rl=%d ...\n", c->launchSeq, c->carryBlocks, c->carryRl); }
-	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl | (ctx_env(c, "BT_FORCE_EXT", 0) ? BT_RL_FORCE_EXT : 0), c->stream) != 0) return BT_ERR_DEVICE;
 	if (dbg) { const int e = (int)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] flush launch done rc=%d\n", e); }
 	c->launchSeq++;
 	c->carryPending = false;
@@ -827,7 +839,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
 	/* short reads (all of today's sequencers' single-end lengths up to 112) keep the whole read in LDS */
-	int rl = (maxLen <= BT_RL_MAXLEN && !env_u32("BT_NO_RL", 0)) ? 1 : 0;
+	int rl = (maxLen <= BT_RL_MAXLEN && !ctx_env(c, "BT_NO_RL", 0)) ? 1 : 0;
 	bool both = false;                /* longest read known on the device only: enqueue both builds, gated */
 	if (rl && c->rl3) {
 		/* only the row stride is known here: one small reduction over len[] settles it, on the stream (below) */
@@ -839,7 +851,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	const bool carry = c->carry && async && !c->is_big && rl != 0 && !both && counts_dev == nullptr;
 	uint32_t gridBlocks = c->cus * (rl == 2 ? 3u : c->blocksPerCU);
 	{
-		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);   /* tests: a small grid makes small batches drain */
+		const uint32_t lim = ctx_env(c, "BT_MAX_BLOCKS", 0);   /* tests: a small grid makes small batches drain */
 		if (lim && lim < gridBlocks) gridBlocks = lim;
 	}
 	if (c->carryPending && (!carry || rl != c->carryRl || gridBlocks != c->carryBlocks || maxLen > c->maxLen)) {
@@ -851,7 +863,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 	 * Off by default (BT_DEVICE_RETRY=1 turns it on): the second pass runs the EXT instances of the kernel, whose fault on
 	 * two inputs of the simple_tests suite was fixed too late in round 2 for the whole GPU suite to run through them
 	 * (DESIGN.md 4.4). */
-	const bool devRetry = async && retry_on_stream && !c->is_big && env_u32("BT_DEVICE_RETRY", 1);
+	const bool devRetry = async && retry_on_stream && !c->is_big && ctx_env(c, "BT_DEVICE_RETRY", 1);
 	if (devRetry) {
 		if ((rc = ctx_ensure_big(c, maxLen, c->stream)) != BT_OK) return rc;
 		if ((rc = ctx_ensure_scratch(c->big, maxLen, false)) != BT_OK) return rc;
@@ -892,7 +904,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		if (!mmCursorDev) HIPCHK(hipMemsetAsync(c->d_carry + BT_BATCH_RING + bid, 0, 4, c->stream));   /* this batch's mismatch-pool cursor */
 		A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = adopt ? 1u : 0u; A.park = 1u;
 		A.maxAge = c->carryAge; A.parkedOf = c->d_carry;
-		A.parkMinRounds = env_u32("BT_PARK_MIN_ROUNDS", 0);
+		A.parkMinRounds = ctx_env(c, "BT_PARK_MIN_ROUNDS", 0);
 	}
 	if (mmCursorDev) HIPCHK(hipMemsetAsync(mmCursorDev, 0, 4, c->stream));
 	if (both && bt_launch_maxlen(in->len, in->n_reads, c->d_cursor + 7, c->stream) != 0) return BT_ERR_DEVICE;
@@ -913,18 +925,18 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 #endif
 	auto launch_main = [&](int rlv) -> int {
 		uint32_t maxBlocks = c->cus * (rlv == 2 ? 3u : c->blocksPerCU);
-		const uint32_t lim = env_u32("BT_MAX_BLOCKS", 0);
+		const uint32_t lim = ctx_env(c, "BT_MAX_BLOCKS", 0);
 		if (lim && lim < maxBlocks) maxBlocks = lim;
 		uint32_t nBlocks = (in->n_reads + BT_BLOCK - 1) / BT_BLOCK;
 		if (carry || nBlocks > maxBlocks) nBlocks = maxBlocks;     /* carry-over: always the whole grid */
 		{
 			/* the template instance bt_launch_search picks (bt_kernels.hip) */
-			const bool ext = A.pool || A.order;
+			const bool ext = A.pool || A.order || ctx_env(c, "BT_FORCE_EXT", 0);
 			const int o = rlv == 2 ? 3 : (rlv ? (c->occ == 1 ? 1 : 2) : (c->occ < 1 ? 1 : (c->occ > 4 ? 4 : c->occ)));
 			snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<%d,%s,%s,%s>", o, ext ? "true" : "false",
 			         rlv ? "true" : "false", rlv == 2 ? "true" : "false");
 		}
-		return bt_launch_search(&A, nBlocks, c->occ, rlv, c->stream) != 0 ? BT_ERR_DEVICE : BT_OK;
+		return bt_launch_search(&A, nBlocks, c->occ, rlv | (ctx_env(c, "BT_FORCE_EXT", 0) ? BT_RL_FORCE_EXT : 0), c->stream) != 0 ? BT_ERR_DEVICE : BT_OK;
 	};
 	if (both) {
 		/* the batch's longest read is on the device only (c->d_cursor[7], reduced above): both builds are
@@ -937,7 +949,7 @@ static int run_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out, uin
 		snprintf(c->last_kernel, sizeof(c->last_kernel), "bt_search_kernel<3|2,*,true,*> (gated)");
 	} else {
 		A.gate = nullptr;
-		const bool dbg = carry && env_u32("BT_CARRY_DEBUG", 0) != 0;
+		const bool dbg = carry && ctx_env(c, "BT_CARRY_DEBUG", 0) != 0;
 		if (dbg) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[carry] main launch seq=%u bid=%u adopt=%d n_reads=%u blocks=%u rl=%d maxAge=%u ...\n", c->launchSeq, bid, (int)adopt, in->n_reads, gridBlocks, rl, c->carryAge); }
 		if ((rc = launch_main(rl)) != BT_OK) return rc;
 		if (dbg) {
@@ -1527,7 +1539,7 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	/* diagnostics: BT_STREAM_POISON=1 fills the mismatch pool's staging region with 0xff, so that an entry the
 	 * host reads without the kernel having written it is recognisable (position 0x3ff, base 3) instead of looking like another
 	 * read's entry left over from whoever had the memory before */
-	if (env_u32("BT_STREAM_POISON", 0) && out->mm_pool_cap) HIPCHK(hipMemsetAsync(d + o_mm, 0xff, 2ull * out->mm_pool_cap, cs));
+	if (ctx_env(c, "BT_STREAM_POISON", 0) && out->mm_pool_cap) HIPCHK(hipMemsetAsync(d + o_mm, 0xff, 2ull * out->mm_pool_cap, cs));
 	HIPCHK(hipEventRecord(s.up, cs));
 	HIPCHK(hipStreamWaitEvent(c->stream, s.up, 0));
 	bt_read_batch din = *in;
@@ -1542,7 +1554,7 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	 * may be enqueued before this batch's results have been copied */
 	/* BT_STREAM_OLD_CURSOR=1 (diagnostics): the cursors rounds 2-3 used -- the ring's for a carried batch, the
 	 * context's otherwise */
-	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false, env_u32("BT_STREAM_OLD_CURSOR", 0) ? nullptr : (uint32_t*)(d + o_cur));
+	const int rc = run_device(c, &din, &dout, maxLen, nullptr, false, true, false, ctx_env(c, "BT_STREAM_OLD_CURSOR", 0) ? nullptr : (uint32_t*)(d + o_cur));
 	if (rc != BT_OK) return rc;
 	s.in = in; s.out = out; s.tag = tag; s.n = n; s.o_hits = o_hits; s.o_nh = o_nh; s.o_st = o_st; s.o_mm = o_mm;
 	s.mmCursor = c->lastMmCursor; s.state = 1;
@@ -1575,7 +1587,7 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 				if (hipEventQuery(c->evLaunch[k]) == hipSuccess) { complete = c->hostParked[(size_t)k * BT_BATCH_RING + s.bid] == 0; break; }
 			}
 			if (!complete) return BT_OK;
-			const int r2 = stream_copy_back(c, s, env_u32("BT_STREAM_ORDERED", 0) != 0);
+			const int r2 = stream_copy_back(c, s, ctx_env(c, "BT_STREAM_ORDERED", 0) != 0);
 			if (r2 != BT_OK) return r2;
 		} else {
 			if (!flush) return BT_ERR_ARG;                          /* cannot happen: uncarried batches are copied back at submit */
@@ -1586,7 +1598,7 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 	} else if (!flush && hipEventQuery(s.done) != hipSuccess) return BT_OK;
 	HIPCHK(hipEventSynchronize(s.done));
 	s.out->mm_pool_used = s.mm_used < s.out->mm_pool_cap ? s.mm_used : s.out->mm_pool_cap;
-	if (env_u32("BT_STREAM_RECHECK", 0)) {
+	if (ctx_env(c, "BT_STREAM_RECHECK", 0)) {
 		/* diagnostics: with the device idle, what the staging area holds now against what the copy stream
 		 * delivered -- a difference means the copy ran before the batch's last writes were there */
 		HIPCHK(hipDeviceSynchronize());
@@ -1610,7 +1622,7 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 		uint32_t cur = 0;
 		if (hipMemcpy(&cur, s.mmCursor, 4, hipMemcpyDeviceToHost) == hipSuccess && s.carried && cur != s.mm_used)
 			fprintf(stderr, "[stream-recheck] tag %p: mm cursor %u now, %u delivered\n", s.tag, cur, s.mm_used);
-		if (bad > 0 && env_u32("BT_STREAM_RECHECK", 0) > 1) return BT_ERR_DEVICE;
+		if (bad > 0 && ctx_env(c, "BT_STREAM_RECHECK", 0) > 1) return BT_ERR_DEVICE;
 	}
 	*tag = s.tag;
 	s.state = 0;
@@ -1647,8 +1659,8 @@ extern "C" int bt_align_stream_tick(bt_ctx* c, uint32_t min_rounds)
 	A.counts = c->d_counts;
 	A.nextRead = c->d_cursor;
 	A.pool = c->pool; A.launchSeq = c->launchSeq; A.adopt = 1; A.park = 1; A.maxAge = c->carryAge; A.parkedOf = c->d_carry;
-	A.parkMinRounds = min_rounds ? min_rounds : env_u32("BT_TICK_MIN_ROUNDS", 150000);
-	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl, c->stream) != 0) return BT_ERR_DEVICE;
+	A.parkMinRounds = min_rounds ? min_rounds : ctx_env(c, "BT_TICK_MIN_ROUNDS", 150000);
+	if (bt_launch_search(&A, c->carryBlocks, c->occ, c->carryRl | (ctx_env(c, "BT_FORCE_EXT", 0) ? BT_RL_FORCE_EXT : 0), c->stream) != 0) return BT_ERR_DEVICE;
 	const uint32_t k = c->launchSeq & (BT_BATCH_RING - 1u);
 	HIPCHK(hipMemcpyAsync(c->hostParked + (size_t)k * BT_BATCH_RING, c->d_carry, BT_BATCH_RING * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipEventRecord(c->evLaunch[k], c->stream));

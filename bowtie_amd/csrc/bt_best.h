@@ -2285,8 +2285,14 @@ struct BfAuto {
 	uint32_t c0[9];               /* the lane's op counters when the read began (a read that overflows is not tallied) */
 	BfChase ch;
 	BfAdvSt adv;
-	BfLeafSt leaf;
+	/* The leaf being extended (la_enter .. la_exit: the queue's front and its 16-word branch record, the range, the seed's
+	 * edits) is what the hot rounds read and write; the kernel gives every lane a place for it in LDS (bt_best_kernels.hip:
+	 * lane-strided, an odd number of words apart, so that a wavefront's accesses to one member fall into different banks) --
+	 * until round 6 it sat in scratch memory with the rest of the record.  (The host build points it at ordinary memory.) */
+	BfLeafSt* leafp;
 };
+/* words from one lane's BfLeafSt to the next in LDS: the struct's size rounded up to an odd number of words */
+#define BF_LEAF_STRIDE ((((uint32_t)sizeof(BfLeafSt) + 3u) / 4u) | 1u)
 
 /* bf_run_read / bf_run_pair down to their loops */
 BF_FNI void bf_auto_begin(BfLane& X, const BtBatchDev& B, uint32_t rd, BfAuto& S)
@@ -2406,9 +2412,9 @@ BF_FNI uint32_t bf_auto_hot(BfLane& X, BfAuto& S, bool sendOk)
 {
 	uint32_t did = 0;
 	BF_PT0(t_hot);
-	if (S.phase == BA_FRONT) { la_front(X, S.leaf); S.phase = BA_STEP; }
-	if (S.phase == BA_STEP) { BF_PT0(t_s); did |= 1u; if (!la_step(X, S.leaf)) S.phase = BA_SEND; BF_PADD(BP_HSTEP, t_s); }
-	if (S.phase == BA_SEND && sendOk) { BF_PT0(t_s); did |= 2u; S.phase = la_send(X, S.leaf) ? BA_FRONT : BA_LEAF_EXIT; BF_PADD(BP_HSEND, t_s); }
+	if (S.phase == BA_FRONT) { la_front(X, *S.leafp); S.phase = BA_STEP; }
+	if (S.phase == BA_STEP) { BF_PT0(t_s); did |= 1u; if (!la_step(X, *S.leafp)) S.phase = BA_SEND; BF_PADD(BP_HSTEP, t_s); }
+	if (S.phase == BA_SEND && sendOk) { BF_PT0(t_s); did |= 2u; S.phase = la_send(X, *S.leafp) ? BA_FRONT : BA_LEAF_EXIT; BF_PADD(BP_HSEND, t_s); }
 	if (S.phase == BA_CHASE) { BF_PT0(t_s); did |= 4u; ch_advance_piece(X, S.ch); if (S.ch.tidx != BF_NONE32 || S.ch.done) S.phase = BA_RUN; BF_PADD(BP_HCHASE, t_s); }
 	BF_PADD(BP_HOT, t_hot);
 	return did;
@@ -2428,7 +2434,7 @@ BF_FNI void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk,
 		else { bf_auto_begin(X, B, rd, S); S.phase = BA_RUN; }
 		BF_PADD(BP_CTAKE, t_s);
 	}
-	if (S.phase == BA_LEAF_EXIT) { BF_PT0(t_s); la_exit(X, S.leaf); S.phase = BA_POST; BF_PADD(BP_CEXIT, t_s); }
+	if (S.phase == BA_LEAF_EXIT) { BF_PT0(t_s); la_exit(X, *S.leafp); S.phase = BA_POST; BF_PADD(BP_CEXIT, t_s); }
 	if (S.phase == BA_POST) { BF_PT0(t_s); adv_post(X, S.adv); S.phase = BA_RUN; BF_PADD(BP_CPOST, t_s); }
 	if (S.phase == BA_RUN) { BF_PT0(t_s); bf_auto_run(X, B, S); BF_PADD(BP_CRUN, t_s); }
 	if (S.phase == BA_PRE) {
@@ -2437,7 +2443,7 @@ BF_FNI void bf_auto_cold(BfLane& X, const BtBatchDev& B, BfAuto& S, bool takeOk,
 		else S.phase = S.adv.leaf ? BA_LEAF_ENTER : BA_POST;
 		BF_PADD(BP_CPRE, t_s);
 	}
-	if (S.phase == BA_LEAF_ENTER) S.phase = la_enter(X, S.leaf, S.adv.leaf) ? BA_FRONT : BA_POST;
+	if (S.phase == BA_LEAF_ENTER) S.phase = la_enter(X, *S.leafp, S.adv.leaf) ? BA_FRONT : BA_POST;
 	BF_PADD(BP_COLD, t_cold);
 }
 

@@ -34,6 +34,11 @@ __device__ unsigned long long bf_prof[3 * 32];      /* bt_best.h: cycles, passes
 #define BT_BEST_MIN_BLOCKS 4
 #endif
 #define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
+#ifndef BT_BEST_LEAF_LDS
+/* 0: round 5's kernel, the leaf's state in scratch memory with the rest (A/B; and the build with 64-bit rows, whose leaf
+ * record is 43 words: four blocks of those do not fit a CU's LDS) */
+#define BT_BEST_LEAF_LDS (BT_WIDE ? 0 : 1)
+#endif
 /* what both kernels begin with: the batch's descriptors into LDS, the lane's record */
 #define BT_BEST_PROLOGUE \
 	__shared__ BfProgram PROG; \
@@ -99,6 +104,14 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 	BT_BEST_PROLOGUE;
 	BfAuto S;
 	__builtin_memset(&S, 0, sizeof(S));
+#if BT_BEST_LEAF_LDS
+	/* the leaf's state in LDS (bt_best.h: BfAuto::leafp), 37 words per lane: with four blocks on a CU, 148 of its 160 KB */
+	__shared__ uint32_t LEAF[BT_BLOCK * BF_LEAF_STRIDE];
+	S.leafp = (BfLeafSt*)(LEAF + threadIdx.x * BF_LEAF_STRIDE);
+#else
+	BfLeafSt leafHere;
+	S.leafp = &leafHere;
+#endif
 	S.phase = laneOn ? BA_TAKE : BA_IDLE;
 	S.kind = paired ? 2u : 1u;
 	const uint32_t coldMin = A.coldMin ? A.coldMin : 1u, takeMin = A.takeMin ? A.takeMin : 1u;

@@ -13,10 +13,13 @@
 #include "bt_io.h"
 
 #include <ctype.h>
+#include <fcntl.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <thread>
@@ -157,6 +160,19 @@ struct BtWindow {
 	void resize(size_t m) { char* q = (char*)realloc(p, m ? m : 1); if (!q) throw std::bad_alloc(); p = q; n = m; }
 };
 
+/* offsets, appended in bulk by several threads (no zero-fill on growth) */
+struct BtOffsets {
+	size_t* p = nullptr; size_t n = 0, cap = 0;
+	BtOffsets() {}
+	~BtOffsets() { free(p); }
+	BtOffsets(const BtOffsets&) = delete;
+	BtOffsets& operator=(const BtOffsets&) = delete;
+	void reserve(size_t m) { if (m > cap) { const size_t c = m + m / 4 + 1024; size_t* q = (size_t*)realloc(p, c * sizeof(size_t)); if (!q) throw std::bad_alloc(); p = q; cap = c; } }
+	size_t size() const { return n; }
+	size_t& operator[](size_t i) { return p[i]; }
+	void resize(size_t m) { reserve(m); n = m; }
+};
+
 struct BtReadStream {
 	bt_read_opts o;
 	std::vector<std::string> items;       /* file names, or the -c sequences                     */
@@ -173,11 +189,26 @@ struct BtReadStream {
 	bool open_failed = false;             /* the files left could not be opened: the run fails (CFilePatternSource::open
 	                                         throws, pat.cpp:296-357) once the reads before them are out            */
 	std::string raw;                      /* the batch's record texts                            */
+	/* the FASTQ bulk path (next_fastq): an uncompressed regular file is read straight from its descriptor -- several threads,
+	 * one pread each, into the window -- instead of through zlib's copy; and the window's newlines are indexed, by the same
+	 * threads, as the data arrives: the light parse (four newlines to a record) then walks the index instead of calling
+	 * memchr four times per record (the input stage was one thread's scan, 10-11 M reads/s whatever -p said) */
+	int rawfd = -1; uint64_t rawoff = 0;
+	BtOffsets nl;                         /* offsets into the window of the '\n's in [.., idx_end), ascending */
+	size_t nl_cur = 0, idx_end = 0;
+	int io_threads = 1;
+	double avg_rec = 256.0;               /* bytes per record of the last batch: how far ahead of a batch's need to read */
 	/* -F: the sliding window over the FASTA text (FastaContinuousPatternSource's members) */
 	size_t c_eat = 0, c_bufcur = 0; bool c_begin = true; uint64_t c_cur = 0, c_last = 0;
 	char c_buf[1024]; std::string c_prefix;
 	std::vector<BtRec> recs;
 };
+
+static void st_close_file(BtReadStream* s)
+{
+	if (s->f) { gzclose(s->f); s->f = nullptr; }
+	if (s->rawfd >= 0) { close(s->rawfd); s->rawfd = -1; }
+}
 
 static int st_fill(BtReadStream* s)
 {
@@ -206,7 +237,7 @@ static inline int st_peek(BtReadStream* s)
 
 static bool st_open_next(BtReadStream* s, std::string* err, bool keep_window = false)
 {
-	if (s->f) { gzclose(s->f); s->f = nullptr; }
+	st_close_file(s);
 	if (s->item >= s->items.size()) return false;
 	const std::string& fn = s->items[s->item++];
 	/* a name starting with \x01: a file the caller has already taken out of the run and said so (bowtie-amd: its -Q
@@ -225,6 +256,16 @@ static bool st_open_next(BtReadStream* s, std::string* err, bool keep_window = f
 		return st_open_next(s, err, keep_window);
 	}
 	gzbuffer(s->f, 1u << 20);
+	s->rawoff = 0;
+	if (fn != "-" && s->o.format == BT_FMT_FASTQ && !getenv("BT_IO_NO_RAW")) {
+		/* a regular file that is not gzip's: the bulk path reads it from a descriptor of its own (fq_more) */
+		const int fd = open(fn.c_str(), O_RDONLY | O_CLOEXEC);
+		if (fd >= 0) {
+			struct stat sb; unsigned char m[2] = {0, 0};
+			const bool plain = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && !(pread(fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b);
+			if (plain) s->rawfd = fd; else close(fd);
+		}
+	}
 	s->file_first = true; s->feof = false; s->file_recs = 0;
 	if (!keep_window) s->pos = s->end = 0;
 	return true;
@@ -250,7 +291,7 @@ BtReadStream* bt_io_open(const char* spec, const bt_read_opts& opts, std::string
 void bt_io_close(BtReadStream* s)
 {
 	if (!s) return;
-	if (s->f) gzclose(s->f);
+	st_close_file(s);
 	delete s;
 }
 
@@ -721,29 +762,154 @@ static uint32_t rand_seed(const uint8_t* seq, const uint8_t* qual, size_t len, c
 struct FqRec { size_t off; uint32_t e[4]; uint64_t rdid; };   /* e[k]: offset of line k's '\n' from off */
 
 static double io_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-static double g_io_fill_s = 0;        /* BT_IO_PROFILE: time inside gzread */
+static double g_io_fill_s = 0;        /* BT_IO_PROFILE: time inside gzread / pread */
+static double g_io_index_s = 0;       /* BT_IO_PROFILE: time indexing the window's newlines */
 
-static bool fq_more(BtReadStream* s)
+/* the '\n's of window[lo, hi): counted, or their offsets written to out[0..) in order (-> how many) */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static size_t nl_scan_avx2(const char* w, size_t lo, size_t hi, size_t* out)
+{
+	const __m256i nlv = _mm256_set1_epi8('\n');
+	size_t i = lo, n = 0;
+	for (; i + 64 <= hi; i += 64) {
+		const __m256i a = _mm256_loadu_si256((const __m256i*)(w + i)), b = _mm256_loadu_si256((const __m256i*)(w + i + 32));
+		uint64_t m = (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, nlv)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, nlv)) << 32);
+		if (!out) { n += (size_t)__builtin_popcountll(m); continue; }
+		while (m) { out[n++] = i + (size_t)__builtin_ctzll(m); m &= m - 1; }
+	}
+	for (; i < hi; i++) if (w[i] == '\n') { if (out) out[n] = i; n++; }
+	return n;
+}
+#endif
+static size_t nl_scan(const char* w, size_t lo, size_t hi, size_t* out)
+{
+#if defined(__x86_64__)
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	if (avx2) return nl_scan_avx2(w, lo, hi, out);
+#endif
+	const char* p = w + lo; const char* e = w + hi;
+	size_t n = 0;
+	while (p < e) {
+		const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+		if (!q) break;
+		if (out) out[n] = (size_t)(q - w);
+		n++;
+		p = q + 1;
+	}
+	return n;
+}
+/* tests: BT_IO_FILL_BYTES / BT_IO_SLICE_BYTES shrink a fill of the window and a thread's share of it, so that files of a few
+ * KB cross every boundary the 64 MB / 8 MB / 2 MB defaults put in the way of files of many GB */
+static size_t io_knob(const char* name, size_t dflt)
+{
+	const char* e = getenv(name);
+	const size_t v = e && *e ? (size_t)strtoull(e, nullptr, 10) : 0;
+	return v ? v : dflt;
+}
+/* extend the newline index over window[idx_end, end): the io threads take a slice each -- count, then write in place */
+static void nl_index_more(BtReadStream* s)
+{
+	const size_t lo = s->idx_end, hi = s->end;
+	if (hi <= lo) return;
+	const double t0 = io_now();
+	const char* w = s->buf.data();
+	const size_t span = hi - lo;
+	static const size_t sliceMin = io_knob("BT_IO_SLICE_BYTES", 2u << 20);
+	int T = s->io_threads < 1 ? 1 : s->io_threads;
+	if (span < 2u * sliceMin) T = 1;
+	else if ((size_t)T > span / sliceMin) T = (int)(span / sliceMin);
+	std::vector<size_t> cnt((size_t)T + 1, 0);
+	auto slice = [&](int t, size_t* a, size_t* b) { *a = lo + span * (size_t)t / (size_t)T; *b = lo + span * (size_t)(t + 1) / (size_t)T; };
+	auto run = [&](bool write) {
+		auto job = [&](int t) {
+			size_t a, b; slice(t, &a, &b);
+			if (!write) cnt[(size_t)t + 1] = nl_scan(w, a, b, nullptr);
+			else (void)nl_scan(w, a, b, s->nl.p + s->nl.n + cnt[(size_t)t]);
+		};
+		if (T == 1) job(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(job, t); for (auto& x : th) x.join(); }
+	};
+	run(false);
+	for (int t = 0; t < T; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+	s->nl.reserve(s->nl.n + cnt[(size_t)T]);
+	run(true);
+	s->nl.n += cnt[(size_t)T];
+	s->idx_end = hi;
+	g_io_index_s += io_now() - t0;
+}
+/* the next '\n' at or after window offset p, or (size_t)-1 when the window holds none (what memchr said before) */
+static inline size_t nl_next(BtReadStream* s, size_t p)
+{
+	while (s->nl_cur < s->nl.size() && s->nl[s->nl_cur] < p) s->nl_cur++;
+	return s->nl_cur < s->nl.size() ? s->nl[s->nl_cur] : (size_t)-1;
+}
+
+/* more of the file into the window (and into the newline index); `want` = bytes the batch still expects to need */
+static bool fq_more(BtReadStream* s, size_t want = 0)
 {
 	if (s->feof || !s->f) return false;
-	if (s->buf.size() - s->end < (16u << 20)) s->buf.resize(s->buf.size() + s->buf.size() / 2 + (32u << 20));
-	size_t room = s->buf.size() - s->end;
-	/* no further ahead than this: what a batch leaves over is moved to the front of the window by the next one */
-	if (room > (64u << 20)) room = 64u << 20;
+	/* no further ahead than the batch needs (what a batch leaves over is moved to the front of the window by the next one),
+	 * in pieces large enough for several threads to share */
+	static const size_t fillMin = io_knob("BT_IO_FILL_BYTES", 64u << 20), sliceMin = io_knob("BT_IO_SLICE_BYTES", 2u << 20) * 4u;
+	size_t room = want + fillMin / 16u;
+	if (room < fillMin) room = fillMin;
+	if (room > (1u << 30)) room = 1u << 30;
+	if (s->buf.size() - s->end < room) s->buf.resize(s->end + room + (s->buf.size() < (256u << 20) ? (32u << 20) : s->buf.size() / 8u));
 	const double t0 = io_now();
-	const int got = gzread(s->f, s->buf.data() + s->end, (unsigned)room);
+	size_t got = 0;
+	if (s->rawfd >= 0) {
+		/* pread by several threads, a slice each; a short slice is the end of the file */
+		int T = s->io_threads < 1 ? 1 : (s->io_threads > 16 ? 16 : s->io_threads);
+		if ((size_t)T > room / sliceMin) T = (int)(room / sliceMin);
+		if (T < 1) T = 1;
+		std::vector<size_t> g((size_t)T, 0);
+		char* dst = s->buf.data() + s->end;
+		auto rd = [&](int t) {
+			const size_t a = room * (size_t)t / (size_t)T, b = room * (size_t)(t + 1) / (size_t)T;
+			size_t done = 0;
+			while (a + done < b) {
+				const ssize_t k = pread(s->rawfd, dst + a + done, b - a - done, (off_t)(s->rawoff + a + done));
+				if (k <= 0) break;
+				done += (size_t)k;
+			}
+			g[(size_t)t] = done;
+		};
+		if (T == 1) rd(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(rd, t); for (auto& x : th) x.join(); }
+		for (int t = 0; t < T; t++) {
+			const size_t a = room * (size_t)t / (size_t)T, b = room * (size_t)(t + 1) / (size_t)T;
+			got += g[(size_t)t];
+			if (g[(size_t)t] < b - a) break;               /* the file ended inside this slice: what lies beyond was not read */
+		}
+		s->rawoff += got;
+	} else {
+		const int k = gzread(s->f, s->buf.data() + s->end, (unsigned)(room > (64u << 20) ? (64u << 20) : (fillMin < (64u << 20) ? fillMin : room)));
+		got = k > 0 ? (size_t)k : 0;
+	}
 	g_io_fill_s += io_now() - t0;
-	if (got <= 0) { s->feof = true; return false; }
-	s->end += (size_t)got;
+	if (got == 0) { s->feof = true; return false; }
+	s->end += got;
+	nl_index_more(s);
 	return true;
 }
 
 static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBatch* batch, std::string* err)
 {
 	static const bool prof = getenv("BT_IO_PROFILE") != nullptr;
-	const double tp0 = prof ? io_now() : 0; const double fill0 = g_io_fill_s;
-	/* the window keeps only what the previous batch did not use */
-	if (s->pos > 0) { memmove(s->buf.data(), s->buf.data() + s->pos, s->end - s->pos); s->end -= s->pos; s->pos = 0; }
+	const double tp0 = prof ? io_now() : 0; const double fill0 = g_io_fill_s, index0 = g_io_index_s;
+	s->io_threads = threads;
+	/* the window keeps only what the previous batch did not use; the newline index moves with it */
+	if (s->pos > 0) {
+		const size_t by = s->pos;
+		memmove(s->buf.data(), s->buf.data() + by, s->end - by); s->end -= by; s->pos = 0;
+		size_t k = 0;
+		while (s->nl_cur < s->nl.size() && s->nl[s->nl_cur] < by) s->nl_cur++;
+		for (size_t i = s->nl_cur; i < s->nl.size(); i++) s->nl[k++] = s->nl[i] - by;
+		s->nl.resize(k); s->nl_cur = 0;
+		s->idx_end = s->idx_end > by ? s->idx_end - by : 0;
+	}
+	if (s->idx_end < s->end) nl_index_more(s);        /* (a window another path of the reader filled) */
 	std::vector<FqRec> recs;
 	recs.reserve(max_reads < (1u << 22) ? max_reads : (1u << 22));
 	uint32_t maxline = 1;
@@ -757,7 +923,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		if (s->file_first) {
 			for (;;) {
 				while (s->pos < s->end && (s->buf[s->pos] == '\r' || s->buf[s->pos] == '\n')) s->pos++;
-				if (s->pos < s->end || !fq_more(s)) break;
+				if (s->pos < s->end || !fq_more(s, (size_t)((double)(max_reads - recs.size()) * s->avg_rec))) break;
 			}
 			if (s->pos >= s->end || s->buf[s->pos] != '@') { *err = "Error: reads file does not look like a FASTQ file"; return BT_ERR_READS; }
 			s->file_first = false;
@@ -765,10 +931,9 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		FqRec r; r.off = s->pos; r.rdid = s->rdid;
 		size_t p = s->pos; int k = 0; bool partial = false;
 		while (k < 4) {
-			const char* b = s->buf.data();
-			const char* nl = p < s->end ? (const char*)memchr(b + p, '\n', s->end - p) : nullptr;
-			if (nl) { r.e[k++] = (uint32_t)((size_t)(nl - b) - r.off); p = (size_t)(nl - b) + 1; continue; }
-			if (fq_more(s)) continue;
+			const size_t nl = nl_next(s, p);
+			if (nl != (size_t)-1) { r.e[k++] = (uint32_t)(nl - r.off); p = nl + 1; continue; }
+			if (fq_more(s, (size_t)((double)(max_reads - recs.size()) * s->avg_rec))) continue;
 			/* end of file: it stands in for the fourth newline only */
 			if (k == 3) { r.e[3] = (uint32_t)(s->end - r.off); k = 4; p = s->end; }
 			else partial = true;
@@ -782,7 +947,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 				s->rdid--;
 				if (s->rdid >= s->o.skip && !recs.empty() && recs.back().rdid == s->rdid) recs.pop_back();
 			}
-			s->pos = s->end; gzclose(s->f); s->f = nullptr; continue;
+			s->pos = s->end; st_close_file(s); continue;
 		}
 		s->pos = p;
 		if (s->rdid >= s->o.skip) {
@@ -791,23 +956,24 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 			if (l2 > maxline) maxline = l2;
 		}
 		s->rdid++; s->file_recs++;
-		if (s->pos >= s->end && s->feof) { gzclose(s->f); s->f = nullptr; }
+		if (s->pos >= s->end && s->feof) st_close_file(s);
 	}
 	if ((at_limit || (recs.size() == max_reads && !s->done)) && s->f && s->file_recs % 16u != 0) {
 		/* the batch is full (or -u is reached: the reference's reader is a batch ahead of that): look (without consuming)
 		 * whether the file ends inside the next record, because that would take this batch's last record with it */
 		size_t p = s->pos; int k = 0;
+		const size_t cur0 = s->nl_cur;
 		while (k < 3) {
-			const char* b = s->buf.data();
-			const char* nl = p < s->end ? (const char*)memchr(b + p, '\n', s->end - p) : nullptr;
-			if (nl) { k++; p = (size_t)(nl - b) + 1; continue; }
+			const size_t nl = nl_next(s, p);
+			if (nl != (size_t)-1) { k++; p = nl + 1; continue; }
 			if (fq_more(s)) continue;
 			break;
 		}
+		s->nl_cur = cur0;                                  /* a look ahead: nothing consumed */
 		if (k > 0 && k < 3 && s->feof) {
 			s->rdid--;
 			if (!recs.empty() && recs.back().rdid == s->rdid) recs.pop_back();
-			s->pos = s->end; gzclose(s->f); s->f = nullptr;
+			s->pos = s->end; st_close_file(s);
 		}
 	}
 	const size_t n = recs.size();
@@ -817,6 +983,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		return BT_OK;
 	}
 	const double tp1 = prof ? io_now() : 0;
+	if (s->pos > recs.front().off) s->avg_rec = (double)(s->pos - recs.front().off) / (double)n + 1.0;
 	if (maxline > 1040u) maxline = 1040u;
 	const uint32_t stride = (maxline + 15u) & ~15u;
 	batch->reset((uint32_t)n, stride);
@@ -946,8 +1113,8 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		}
 	}
 	batch->first_rdid = batch->rdid[0];
-	if (prof) fprintf(stderr, "[io] fastq batch of %zu: window+scan %.3f s (of which reading the file %.3f), buffers %.3f, records on %d threads %.3f, names %.3f\n",
-	                  n, tp1 - tp0, g_io_fill_s - fill0, tp2 - tp1, T, tp3 - tp2, io_now() - tp3);
+	if (prof) fprintf(stderr, "[io] fastq batch of %zu: window+scan %.3f s (of which reading the file %.3f, indexing its newlines %.3f), buffers %.3f, records on %d threads %.3f, names %.3f\n",
+	                  n, tp1 - tp0, g_io_fill_s - fill0, g_io_index_s - index0, tp2 - tp1, T, tp3 - tp2, io_now() - tp3);
 	return BT_OK;
 }
 
@@ -1048,7 +1215,7 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 			}
 			rc = 0;
 		}
-		if (rc == 0) { gzclose(s->f); s->f = nullptr; continue; }
+		if (rc == 0) { st_close_file(s); continue; }
 		if (s->rdid >= s->o.skip) s->recs.push_back({off, (uint32_t)(s->raw.size() - off), s->rdid});
 		else s->raw.resize(off);                    /* skipped reads are never parsed */
 		s->rdid++; s->file_recs++;

@@ -462,7 +462,8 @@ extern "C" int bt_launch_gather_bench(const BtIndexDev* ix, uint32_t nBlocks, ui
 extern "C" int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
-	const bool ext = a->pool || a->order || getenv("BT_FORCE_EXT") != nullptr;   /* BT_FORCE_EXT: diagnostics */
+	const bool ext = a->pool || a->order || (rl & BT_RL_FORCE_EXT) != 0;   /* (diagnostics: BT_FORCE_EXT, read by the context) */
+	rl &= ~BT_RL_FORCE_EXT;
 #define BT_LAUNCH(O, R, T) do { if (ext) hipLaunchKernelGGL((bt_search_kernel<O, true, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); \
                                 else hipLaunchKernelGGL((bt_search_kernel<O, false, R, T>), dim3(nBlocks), dim3(BT_BLOCK), 0, st, *a); } while (0)
 	if (rl == 2) {

@@ -300,7 +300,8 @@ static void emu_best_wave(std::vector<BfLane>& XS, const BtBatchDev& B, uint32_t
 	const size_t W = XS.size();
 	const bool sweepTwice = getenv("BT_BEST_SWEEP_TWICE") && atoi(getenv("BT_BEST_SWEEP_TWICE")) != 0;
 	std::vector<BfAuto> S(W);
-	for (auto& a : S) { memset(&a, 0, sizeof(a)); a.phase = BA_TAKE; a.kind = kind; }
+	std::vector<BfLeafSt> leafs(W);       /* (the kernel keeps these in LDS: BfAuto::leafp) */
+	for (size_t l = 0; l < W; l++) { BfAuto& a = S[l]; memset(&a, 0, sizeof(a)); memset(&leafs[l], 0, sizeof(BfLeafSt)); a.leafp = &leafs[l]; a.phase = BA_TAKE; a.kind = kind; }
 	uint32_t next = 0, round = 0, sweeps = 0;
 	/* the wave model's tallies (BT_EMU_VERBOSE): rounds and lanes per piece */
 	unsigned long long stepR = 0, stepL = 0, sendR = 0, sendL = 0, chaseR = 0, chaseL = 0, sweepL = 0, sweep2 = 0, sweep2L = 0, takeS = 0, takeL = 0, idleL = 0;

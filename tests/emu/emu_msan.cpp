@@ -11,9 +11,6 @@
 #define EMU_MSAN 1
 #include "bt_emu.cpp"
 #include <stdlib.h>
-#include <string>
-#include <fstream>
-#include <sstream>
 
 int main(int argc, char** argv)
 {
@@ -27,30 +24,39 @@ int main(int argc, char** argv)
 	pol.mode = argv[2][0] == 'v' ? BT_MODE_V : BT_MODE_N;
 	pol.mms = atoi(argv[3]); pol.all_hits = atoi(argv[4]); pol.khits = (uint32_t)atoi(argv[5]);
 	const uint32_t lanes = (uint32_t)atoi(argv[6]), rl_mode = (uint32_t)atoi(argv[7]);
-	std::vector<std::string> rs, qs;
+	/* (plain C strings: libstdc++'s own is not instrumented, and MemorySanitizer reports what it cannot see into) */
+	std::vector<char*> rs, qs;
+	auto add = [&](const char* r, const char* q) {
+		const size_t l = strlen(r);
+		char* rc = (char*)malloc(l + 1); memcpy(rc, r, l + 1);
+		char* qc = (char*)malloc(l + 1);
+		for (size_t k = 0; k < l; k++) qc[k] = (q && k < strlen(q)) ? q[k] : 'I';
+		qc[l] = 0;
+		rs.push_back(rc); qs.push_back(qc);
+	};
 	for (int a = 8; a < argc; a++) {
 		if (argv[a][0] == '@') {
-			std::ifstream f(argv[a] + 1);
-			std::string line;
-			while (std::getline(f, line)) {
-				std::istringstream is(line);
-				std::string r, q;
-				if (!(is >> r)) continue;
-				if (!(is >> q)) q = std::string(r.size(), 'I');
-				rs.push_back(r); qs.push_back(q);
+			FILE* f = fopen(argv[a] + 1, "r");
+			if (!f) { fprintf(stderr, "cannot open %s\n", argv[a] + 1); return 2; }
+			static char line[8192], r[4096], q[4096];
+			while (fgets(line, sizeof(line), f)) {
+				r[0] = q[0] = 0;
+				const int k = sscanf(line, "%4095s %4095s", r, q);
+				if (k >= 1) add(r, k >= 2 ? q : nullptr);
 			}
-		} else { rs.push_back(argv[a]); qs.push_back(std::string(strlen(argv[a]), 'I')); }
+			fclose(f);
+		} else add(argv[a], nullptr);
 	}
 	const uint32_t n = (uint32_t)rs.size();
 	uint32_t maxLen = 0;
-	for (uint32_t i = 0; i < n; i++) { const uint32_t l = (uint32_t)rs[i].size(); if (l > maxLen) maxLen = l; }
+	for (uint32_t i = 0; i < n; i++) { const uint32_t l = (uint32_t)strlen(rs[i]); if (l > maxLen) maxLen = l; }
 	const uint32_t stride = (maxLen + 15u) & ~15u;
 	/* the rows' padding is undefined on the device too (the caller only writes len bytes) */
 	uint8_t* seq = (uint8_t*)malloc((size_t)n * stride + 64); uint8_t* qual = (uint8_t*)malloc((size_t)n * stride + 64);
 	std::vector<uint16_t> len(n); std::vector<uint32_t> seed(n);
 	for (uint32_t i = 0; i < n; i++) {
-		const char* r = rs[i].c_str();
-		len[i] = (uint16_t)rs[i].size(); seed[i] = 12345u + i;
+		const char* r = rs[i];
+		len[i] = (uint16_t)strlen(rs[i]); seed[i] = 12345u + i;
 		for (uint32_t k = 0; k < len[i]; k++) {
 			const char c = r[k];
 			seq[(size_t)i * stride + k] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;

@@ -174,6 +174,66 @@ def test_fast_fastq_path_equals_step_by_step_parser(tmp_path, seed):
         assert isinstance(fast, list) and len(fast) > 50
 
 
+_READER_DIGEST = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+from bowtie_amd import hostio as H
+spec, threads, batch = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+h = hashlib.sha256()
+n = 0
+try:
+    for b in H.read_batches(spec, max_reads=batch, threads=threads, seed=7):
+        for i in range(b.n):
+            h.update(b.seq[i, :b.len[i]].tobytes() + b"|" + b.qual[i, :b.len[i]].tobytes() + b"|" + b.names[i] + b"|%%d;" %% int(b.seed[i]))
+        n += b.n
+    print("ok", n, h.hexdigest())
+except H.ReadInputError as e:
+    print("error", n, str(e).replace(chr(10), " / "))
+"""
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_bulk_reader_is_the_same_whatever_the_fill_and_slice_sizes(tmp_path, seed):
+    """The bulk FASTQ path reads an uncompressed file with several threads (a pread each) into the window and indexes the
+    window's newlines with several threads; the light parse walks that index.  With the fills and the threads' slices
+    shrunk to a few hundred bytes (BT_IO_FILL_BYTES / BT_IO_SLICE_BYTES: a record then straddles fills, slices, or both)
+    the reads, names, seeds -- or the error -- are what the zlib path (BT_IO_NO_RAW=1, one thread's memchr until round 6)
+    and the compressed copy of the files give; two files in one run, the first cut off inside a record."""
+    import gzip
+    import subprocess
+    import sys
+    rng = np.random.default_rng(100 + seed)
+    recs = _messy_fastq(rng, 900)
+    recs = [r for r in recs if b"-" not in r.split(b"\n")[1]]
+    if seed == 1:
+        recs[700] = b"@bad\nACGT\n+\nIIIIII\n"                              # more qualities than bases: the error must be the same
+    a, b = tmp_path / "a.fq", tmp_path / "b.fq"
+    a.write_bytes((b"\n\r\n" if seed == 2 else b"") + b"".join(recs[:500]) + (b"@cut\nACGT" if seed == 0 else b""))
+    b.write_bytes(b"".join(recs[500:]).rstrip(b"\r\n") if seed == 2 else b"".join(recs[500:]))
+    for f in (a, b):
+        with gzip.open(str(f) + ".gz", "wb") as g:
+            g.write(f.read_bytes())
+    spec, spec_gz = "%s,%s" % (a, b), "%s.gz,%s.gz" % (a, b)
+    code = _READER_DIGEST % T.ROOT
+
+    def run(spec, threads, batch, **env):
+        e = dict(os.environ)
+        e.update({k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, "-c", code, spec, str(threads), str(batch)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        return p.stdout.decode().strip()
+    want = run(spec, 1, 97, BT_IO_NO_RAW=1)
+    assert want.startswith("error" if seed == 1 else "ok")
+    for threads, batch, env in ((4, 97, {}), (4, 97, dict(BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64)), (3, 1000, dict(BT_IO_FILL_BYTES=1500, BT_IO_SLICE_BYTES=100)),
+                                (8, 5000, dict(BT_IO_FILL_BYTES=4096, BT_IO_SLICE_BYTES=16)), (4, 97, dict(BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64))):
+        got = run(spec, threads, batch, **env)
+        if batch == 97 or want.startswith("ok"):
+            assert got == want, (threads, batch, env)
+        else:
+            assert got.split(" ", 2)[2] == want.split(" ", 2)[2], (threads, batch, env)       # the same error, whatever the batch it falls into
+    assert run(spec_gz, 4, 97, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64) == want
+
+
 def test_file_ending_inside_a_record_follows_the_reference(tmp_path):
     """Checked against the unmodified binary: with reads a, b and a cut-off third record the reference
     aligns only `a` -- its light parser gives up the record before a truncated one unless that record
