@@ -1598,6 +1598,8 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 	} else if (!flush && hipEventQuery(s.done) != hipSuccess) return BT_OK;
 	HIPCHK(hipEventSynchronize(s.done));
 	s.out->mm_pool_used = s.mm_used < s.out->mm_pool_cap ? s.mm_used : s.out->mm_pool_cap;
+	/* the batch's hit records against its own pool cursor (one pass, one cursor, whatever launches its reads rode along with) */
+	{ const int rcm = check_mm_pool(s.out, s.n, s.mm_used, true, "bt_align_stream_collect"); if (rcm != BT_OK) return rcm; }
 	if (ctx_env(c, "BT_STREAM_RECHECK", 0)) {
 		/* diagnostics: with the device idle, what the staging area holds now against what the copy stream
 		 * delivered -- a difference means the copy ran before the batch's last writes were there */
@@ -1835,4 +1837,4 @@ extern "C" const char* bt_strerror(int code)
 	default: return "unknown error";
 	}
 }
-extern "C" const char* bt_version(void) { return BT_WIDE ? "bowtie_amd 0.1.0 (gfx950, 64-bit rows)" : "bowtie_amd 0.1.0 (gfx950)"; }
+extern "C" const char* bt_version(void) { return BT_WIDE ? "bowtie_amd 0.2.0 (gfx950, 64-bit rows)" : "bowtie_amd 0.2.0 (gfx950)"; }

@@ -1066,7 +1066,13 @@ int main(int argc, char** argv)
 	 * (opt-in: unpaired, phase-program engine) instead keeps one context per GPU fed through
 	 * bt_align_stream_* with the reads a batch leaves running carried into the next ones (bt_ctx_set_carry). */
 	const bool streamed = !O.paired && !O.pol.best && !O.no_stream;      /* --stream is the default (round 3: GPU-verified) */
-	std::vector<bt_ctx*> ctxs((size_t)(streamed ? 1 : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */
+	/* streamed: BT_CLI_STREAMS contexts per GPU, each fed its own run of batches with its own carry-over chain -- a launch
+	 * ends with a stretch in which a few wavefronts finish what has been carried long enough, and launches of one context
+	 * follow each other on one stream: with a second context the other's launch fills the machine meanwhile (round 6's
+	 * timeline of a 192 M-read run: one batch per 0.7-1.1 s GPU-side where the kernel needs 0.54 s) */
+	int n_streams = 1;
+	if (const char* sv = getenv("BT_CLI_STREAMS")) { n_streams = atoi(sv); if (n_streams < 1) n_streams = 1; if (n_streams > 4) n_streams = 4; }
+	std::vector<bt_ctx*> ctxs((size_t)(streamed ? n_streams : O.inflight) * ND, nullptr);          /* searcher g works on GPU g % ND */
 	std::vector<bt_ctx*> redo_ctxs(streamed ? ctxs.size() : 0, nullptr);
 	/* --12 input: the file's unpaired records run the stateful unpaired aligner (ebwt_search.cpp:3001-3002,
 	 * MixedMultiAligner) -- the best-first engine without the pair machinery, on a context of its own */
@@ -1074,6 +1080,7 @@ int main(int argc, char** argv)
 	OU.paired = false; OU.pol.pe_v1 = 0; OU.pol.best = 1;
 	if (!O.maxbts_set) OU.pol.max_bts = 800;
 	std::vector<bt_ctx*> unp_ctxs(O.rd.format == BT_FMT_TABBED && O.paired ? ctxs.size() : 0, nullptr);
+	size_t fl_lim = 13;                                       /* batches a streamed searcher keeps in flight */
 	for (size_t g = 0; g < ctxs.size(); g++) {
 		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
@@ -1083,8 +1090,10 @@ int main(int argc, char** argv)
 		}
 		if (streamed) {
 			const char* cv = getenv("BT_CLI_CARRY");          /* diagnostics: launches a read may ride along (0 = none) */
-			int cage = cv && *cv ? atoi(cv) : 12;
+			int cage = cv && *cv ? atoi(cv) : 12 / n_streams;  /* (a context sees every n-th batch: the same time to ride along) */
 			if (cage > 12) cage = 12;                         /* the searcher keeps at most 13 batches in flight: the oldest must be able to complete */
+			if (cage < 1) cage = 1;
+			if (n_streams > 1) fl_lim = (size_t)cage + 2u;      /* (one context: round 5's thirteen) */
 			if (bt_ctx_set_carry(ctxs[g], cage) != BT_OK) die("Error: bt_ctx_set_carry failed");
 			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
@@ -1465,9 +1474,9 @@ int main(int argc, char** argv)
 			 * timeline. */
 			{
 				const double tw = now_s();
-				while (fl.size() >= 13 && !abort_run.load()) {
+				while (fl.size() >= fl_lim && !abort_run.load()) {
 					drain(0);
-					if (fl.size() < 13) break;
+					if (fl.size() < fl_lim) break;
 					/* the oldest batch completes by itself within the time its launches take; if it has not after a minute
 					 * something is wrong on the device: a flush waits for the stream and hands the error out */
 					if (now_s() - tw > 60.0) { drain(1); break; }

@@ -73,18 +73,23 @@ enum {
 	FR_W0 = 0,   /* depth | d<<11                                                                */
 	FR_W1,       /* ham | lowAltQual<<16                                                         */
 	FR_W2,       /* fu | f1<<11 | elcint<<22 | elignore<<24 | candValid<<25 | ccValid<<26 (LDS copy only) */
-	FR_W3,       /* f2 | f3<<11                                                                  */
-	FR_W4,       /* altNum | eligibleNum<<12                                                     */
+	FR_W3,       /* f2 | f3<<11 | cel1<<22 | cel2<<26                                            */
+	FR_W4,       /* altNum | eligibleNum<<12 | low2<<24                                          */
 	FR_W5,       /* cand | dcf<<11 | lmode<<22 | lt<<23 | lz<<25 | el<<26 (locus mode, below)        */
 	FR_W6,       /* pi | pj<<11 | pel<<13                                                        */
 	FR_EBASE,
 	FR_ANCHOR,   /* locus mode: the frame's anchor (text offset of its row's suffix + depth)       */
-	FR_MM        /* mismatch chosen at this level: query offset | refc<<16                       */
+	FR_MM,       /* mismatch chosen at this level: query offset | refc<<16                       */
+	FR_L2        /* the second quality level: cand2 | num2<<11 | l2v<<23 (low2 rides in FR_W4, cel1 / cel2 in FR_W3) */
 };
-#define BT_TOS_WORDS 9       /* FR_W0..FR_ANCHOR travel to the LDS top-of-stack copy             */
+#define BT_TOS_L2 9          /* FR_L2's place in the LDS top-of-stack copy */
+#define BT_TOS_WORDS 10      /* FR_W0..FR_ANCHOR and FR_L2 travel to the LDS top-of-stack copy (FR_L2 as its word 9) */
 #define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
 #define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
 #define BT_LITE_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS)            /* the 3-waves-per-SIMD build: candidate, top-of-stack */
+#ifndef BT_L2_TALLY
+#define BT_L2_TALLY 1        /* 0: no second quality level is tallied (BtLane::low2): every re-scan walks the frame's records (A/B) */
+#endif
 #ifndef BT_LITE_CC
 #define BT_LITE_CC 1         /* 0: round 5's 3-waves build, without the current frame's candidate cache (A/B) */
 #endif
@@ -311,9 +316,17 @@ struct BtLane {
 	uint32_t ham : 16, lowAltQual : 8,
 	         el : 6;                 /* locus mode: levels of the reference's recursion gone through without a frame of their own since the last real one (bt_loc_descend) */
 	uint32_t fu : 11, f1 : 11, elcint : 2, elignore : 1, candValid : 1;
-	uint32_t f2 : 11, f3 : 11;
-	uint32_t altNum : 12, eligibleNum : 12;
+	uint32_t f2 : 11, f3 : 11,
+	         cel1 : 4, cel2 : 4;     /* eliminated-sets of the deepest position of the eligible quality / of the second level (below) */
+	uint32_t altNum : 12, eligibleNum : 12,
+	         low2 : 8;               /* the SECOND-lowest quality among the frame's alternatives (round 6), with ... */
 	uint32_t cand : 11, scanCb : 16;         /* scanCb: next chunk (8 records) of a running frame scan */
+	/* ... its untried substitutions, its deepest position, and whether the three are known.  While a frame steps forward it
+	 * tallies TWO quality levels instead of one: when the lowest is used up, the re-scan of the frame's records
+	 * (ebwt_search_backtrack.h:1004-1058: next-lowest quality, its count, its deepest position) is then already known --
+	 * nothing touched those records since -- and costs neither its fetch rounds nor its walk (43 re-scans per read at hg19
+	 * scale, 9 % of the wavefronts' time in round 5's section profile).  The level after that is found by the scan as before. */
+	uint32_t cand2 : 11, num2 : 12, l2v : 1;
 	uint32_t ebase;
 	/* per-position temporaries that live across the wait + control */
 	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, ra_cont : 2,
@@ -839,7 +852,7 @@ BT_HD uint32_t bt_loc_first_mm(const BtLane& L, const BtScratch& S, const BtLocW
 
 /* Save the current frame before a child is entered: its record in HBM (two 16-byte stores and a word) and the LDS
  * top-of-stack copy, from which a child that fails pops it back without a fetch. */
-BT_HD void bt_frame_push(BtLane& L, const BtScratch& S)
+BT_HD void bt_frame_push(BtLane& L, const BtScratch& S, uint32_t mm)
 {
 	const uint32_t ts = S.tosStride;
 	uint32_t w[BT_TOS_WORDS];
@@ -847,16 +860,17 @@ BT_HD void bt_frame_push(BtLane& L, const BtScratch& S)
 	w[FR_W1] = L.ham | (L.lowAltQual << 16);
 	const uint32_t ccSave = S.noCC == 2u ? 0u : (uint32_t)L.ccValid;     /* (no room for the saved frame's candidate: it is fetched again) */
 	w[FR_W2] = L.fu | (L.f1 << 11) | (L.elcint << 22) | (L.elignore << 24) | (L.candValid << 25) | (ccSave << 26);
-	w[FR_W3] = L.f2 | (L.f3 << 11);
-	w[FR_W4] = L.altNum | (L.eligibleNum << 12);
+	w[FR_W3] = L.f2 | (L.f3 << 11) | (L.cel1 << 22) | (L.cel2 << 26);
+	w[FR_W4] = L.altNum | (L.eligibleNum << 12) | (L.low2 << 24);
 	w[FR_W5] = L.cand | (L.dcf << 11) | (L.lmode << 22) | (L.lt << 23) | (L.lz << 25) | (L.el << 26);
 	w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
 	w[FR_EBASE] = L.ebase;
 	w[FR_ANCHOR] = (uint32_t)L.top;
+	w[BT_TOS_L2] = L.cand2 | (L.num2 << 11) | (L.l2v << 23);
 	uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
-	BtU4 q0, q1; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
-	bt_st4(fr, q0); bt_st4(fr + 4, q1);
-	FRW(L.sd, FR_ANCHOR) = w[FR_ANCHOR];
+	BtU4 q0, q1, q2; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
+	q2.x = w[FR_ANCHOR]; q2.y = mm; q2.z = w[BT_TOS_L2]; q2.w = 0;          /* FR_ANCHOR, FR_MM (again: the caller wrote it), FR_L2 */
+	bt_st4(fr, q0); bt_st4(fr + 4, q1); bt_st4(fr + 8, q2);
 	BT_UNROLL
 	for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
 	if (ccSave) {
@@ -994,7 +1008,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.state == ST_FRAME_FETCHED) {
 				w[0] = res.q[0].x; w[1] = res.q[0].y; w[2] = res.q[0].z; w[3] = res.q[0].w;
 				w[4] = res.q[1].x; w[5] = res.q[1].y; w[6] = res.q[1].z; w[7] = res.q[1].w;
-				w[8] = res.q[2].x;
+				w[8] = res.q[2].x; w[BT_TOS_L2] = res.q[2].z;
 			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
 				BT_UNROLL
@@ -1018,8 +1032,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_UNROLL
 				for (uint32_t k = 0; k < BT_CC_WORDS; k++) S.tos[k * ts] = S.tos[(BT_CC_WORDS + BT_TOS_WORDS + k) * ts];
 			}
-			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu;
-			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu;
+			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu; L.cel1 = (v >> 22) & 15u; L.cel2 = (v >> 26) & 15u;
+			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu; L.low2 = v >> 24;
+			v = w[BT_TOS_L2]; L.cand2 = v & 0x7ffu; L.num2 = (v >> 11) & 0xfffu; L.l2v = (v >> 23) & 1u;
 			v = w[FR_W5]; L.cand = v & 0x7ffu; L.dcf = (v >> 11) & 0x7ffu; L.lmode = (v >> 22) & 1u; L.lt = (v >> 23) & 3u; L.lz = (v >> 25) & 1u; L.el = v >> 26;
 			v = w[FR_W6]; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
 			L.ebase = w[FR_EBASE];
@@ -1051,6 +1066,17 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_COUNT(CN_RESCAN);
 				L.lowAltQual = 0xff; L.candValid = 0; L.ccValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
+#if defined(BT_L2_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+				{ extern unsigned long long g_l2_hit, g_l2_miss, g_l2_none; if (L.d >= kmin) { if (L.l2v) g_l2_hit++; else g_l2_miss++; } else g_l2_none++; }
+#endif
+				if (BT_L2_TALLY && L.d >= kmin && L.l2v) {
+					/* the next level was tallied while the frame stepped forward (BtLane::low2): what the scan would find */
+					L.lowAltQual = L.low2; L.eligibleNum = L.num2; L.cand = L.cand2; L.candValid = 1;
+					const uint32_t ce = L.cel2;
+					L.elcint = (ce & 1u) == 0 ? 0u : (ce & 2u) == 0 ? 1u : (ce & 4u) == 0 ? 2u : 3u;
+					L.elignore = 0; L.l2v = 0;
+					L.state = ST_BT_LOOP; break;
+				}
 				if (L.d >= kmin) { L.scanCb = bt_ent(L, L.d) >> 3; L.state = ST_RESCAN; break; }
 			}
 			L.state = ST_BT_LOOP;
@@ -1375,7 +1401,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			/* push: save the parent (HBM record + LDS top-of-stack copy), enter the child */
 			if (L.sd + 1u >= S.a->frCap) { L.state = ST_ABORT; break; }
-			bt_frame_push(L, S);
+			bt_frame_push(L, S, icur | (btcint << 16));
 			L.ebase = bt_ent(L, L.d) + 1u;
 			L.lmode = childLoc ? 1u : 0u; L.dcf = childLoc ? newDepth : 0u; L.el = 0;
 			L.sd = L.sd + 1u; L.depth = newDepth; L.top = ntop; L.bot = nbot; L.ham = btham;
@@ -1393,7 +1419,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			L.altNum = 0; L.eligibleNum = 0;
 			L.elcint = 0; L.elignore = 1;
-			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0;
+			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0; L.l2v = 0; L.low2 = 0xff; L.cel1 = 0; L.cel2 = 0;
 			L.d = L.depth;
 			L.state = ST_STEP_BEGIN;
 		} while (0); BT_PROF_ADD(PS_FRAME_ENTER, t_frame_enter); }
@@ -1436,7 +1462,7 @@ BT_HD bool bt_loc_descend(BtLane& L, const BtProgram& P, const BtWarm& W, const 
 		return true;
 	}
 	if (pure) L.el = L.el + 1u;
-	else { bt_frame_push(L, S); L.el = 0; }
+	else { bt_frame_push(L, S, icur | (j << 16)); L.el = 0; }
 	/* the child's frame, entered (:363-455) */
 	L.ebase = bt_ent(L, L.d) + 1u;
 	L.sd = L.sd + 1u;
@@ -1450,7 +1476,7 @@ BT_HD bool bt_loc_descend(BtLane& L, const BtProgram& P, const BtWarm& W, const 
 	}
 	L.altNum = 0; L.eligibleNum = 0;
 	L.elcint = 0; L.elignore = 1;
-	L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0;
+	L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0; L.l2v = 0; L.low2 = 0xff; L.cel1 = 0; L.cel2 = 0;
 	L.d = L.depth;
 	L.state = ST_STEP_BEGIN;
 	return true;
@@ -1634,7 +1660,17 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				el = ~nz & 15u;
 				const uint32_t na = (uint32_t)__builtin_popcount(nz);
 				L.altNum = L.altNum + na;
+				if (BT_L2_TALLY && !L.fl_elig && nz != 0 && L.considerQuals) {
+					/* an alternative of a quality above the eligible one: the second level's tallies (BtLane::low2) */
+					if (!L.l2v || q < L.low2) { L.low2 = q; L.num2 = na; L.cand2 = d; L.cel2 = el; L.l2v = 1; }
+					else if (q == L.low2) { L.num2 = L.num2 + na; L.cand2 = d; L.cel2 = el; }
+				}
 				if (L.fl_elig && nz != 0) {
+					if (BT_L2_TALLY && L.fl_over && L.eligibleNum > 0 && L.considerQuals) {
+						/* a lower quality takes over: what was the eligible level is the second one from here on */
+						L.low2 = L.lowAltQual; L.num2 = L.eligibleNum; L.cand2 = L.cand; L.cel2 = L.cel1; L.l2v = 1;
+					}
+					L.cel1 = el;
 					if (L.fl_over) {
 						L.lowAltQual = q; L.eligibleNum = 0;
 						L.elcint = (nz & 1u) ? 0u : (nz & 2u) ? 1u : (nz & 4u) ? 2u : 3u;

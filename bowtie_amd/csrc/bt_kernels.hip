@@ -78,6 +78,13 @@ __global__ __launch_bounds__(256) void bt_loc_sa_kernel(BtIndexDev ix, BtU4* loc
 		}
 	}
 }
+/* pass 1 again, a chain at a time (round 6; bt_rank.h: bt_loc_chain): one lane per sampled row */
+__global__ __launch_bounds__(256) void bt_loc_chain_kernel(BtIndexDev ix, BtU4* loc, uint32_t* rtxt, uint16_t* walk)
+{
+	const uint64_t nChains = bt_loc_chain_count(ix);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nChains; i += (uint64_t)gridDim.x * blockDim.x)
+		bt_loc_chain(ix, i, loc, rtxt, walk);
+}
 __global__ __launch_bounds__(256) void bt_loc_ctx_kernel(BtIndexDev ix, BtU4* loc, const uint32_t* rtxt)
 {
 	const uint64_t nRows = (uint64_t)ix.len + 1u;
@@ -102,7 +109,15 @@ extern "C" int bt_launch_loc_build(const BtIndexDev* ix, BtU4* loc, uint32_t* rt
 	uint64_t nb = (nRows + 255u) / 256u;
 	const uint64_t cap = (uint64_t)prop.multiProcessorCount * 64u;
 	if (nb > cap) nb = cap;
-	hipLaunchKernelGGL(bt_loc_sa_kernel, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, *ix, loc, rtxtAlloc + BT_RTXT_PAD_WORDS, walk);
+	/* BT_LOC_BUILD=rows: round 5's pass 1 (a walk per row) instead of a chain per sampled row */
+	const char* how = getenv("BT_LOC_BUILD");
+	if (how && !strcmp(how, "rows")) hipLaunchKernelGGL(bt_loc_sa_kernel, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, *ix, loc, rtxtAlloc + BT_RTXT_PAD_WORDS, walk);
+	else {
+		const uint64_t nChains = bt_loc_chain_count(*ix);
+		uint64_t ncb = (nChains + 255u) / 256u;
+		if (ncb > cap) ncb = cap;
+		hipLaunchKernelGGL(bt_loc_chain_kernel, dim3((uint32_t)ncb), dim3(256), 0, (hipStream_t)stream, *ix, loc, rtxtAlloc + BT_RTXT_PAD_WORDS, walk);
+	}
 	hipLaunchKernelGGL(bt_loc_ctx_kernel, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, *ix, loc, rtxtAlloc + BT_RTXT_PAD_WORDS);
 	return (int)hipGetLastError();
 }

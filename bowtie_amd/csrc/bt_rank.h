@@ -364,6 +364,47 @@ BT_HD void bt_loc_build_host(const BtIndexDev& ix, BtU4* loc, uint32_t* rtxtAllo
 	}
 }
 
+/* The image's pass 1 a CHAIN at a time (round 6; what the GPU loader runs, bt_kernels.hip: bt_loc_chain_kernel).  LF of the row
+ * of text offset p is the row of offset p - 1, so from a sampled row S (SA[S] = s, the index's sample) the walk
+ * S -> LF(S) -> ... visits the rows of offsets s, s - 1, s - 2, ... and ends where the next sampled row (or the '$' row,
+ * offset 0) begins: every row lies on exactly one such chain -- the rows above the last sampled offset on one more, headed by
+ * row `len` (the suffix at offset len) -- and the image costs one rank per ROW instead of one walk per row (2^offRate / 2
+ * ranks: 15.5 at offRate 5, round 5's bt_loc_sa_kernel).  A row's walk length -- the reference's LF steps from it to a
+ * sampled row, kept by text offset -- is its distance to the END of its chain: known once the chain has been gone through,
+ * and written then (a contiguous stretch of walk[]).  rtxt must be zeroed beforehand. */
+BT_HD uint64_t bt_loc_chain_count(const BtIndexDev& ix)
+{
+	return ((uint64_t)ix.len >> ix.offRate) + 1u + (((ix.len & ix.offMask) == ix.len) ? 0u : 1u);
+}
+BT_HD void bt_loc_chain(const BtIndexDev& ix, uint64_t i, BtU4* loc, uint32_t* rtxt, uint16_t* walk)
+{
+	const uint64_t nSampled = ((uint64_t)ix.len >> ix.offRate) + 1u;
+	const bool head = i < nSampled;                                   /* the chain's first row is a sampled one */
+	uint32_t row = head ? (uint32_t)(i << ix.offRate) : ix.len;
+	const uint32_t s = !head ? ix.len : (row == ix.zOff ? 0u : BT_GP(const uint32_t, ix.offs)[row >> ix.offRate]);
+	uint32_t k = 0;
+	for (;;) {
+		BT_GP(uint32_t, loc)[(uint64_t)row * 4u] = s - k;
+		if (row == ix.zOff) break;                                   /* offset 0: nothing to the left, no LF; the chain's last row */
+		uint32_t lf[4], L;
+		bt_rank4(ix, row, lf, &L);
+		const uint32_t y = ix.len - (s - k);                         /* T[sa-1] is base len-1-(sa-1) of the reversed text */
+#if defined(__HIP_DEVICE_COMPILE__)
+		atomicOr(rtxt + (y >> 4), L << (2u * (y & 15u)));
+#else
+		rtxt[y >> 4] |= L << (2u * (y & 15u));
+#endif
+		row = lf[L];
+		k++;
+		if ((row & ix.offMask) == row) break;                        /* the next chain's first row: its own lane's */
+	}
+	/* k = the distance from the chain's first row to its end (the next sampled row, or the '$' row): a row's walk length
+	 * is its distance to that end -- 0 for a sampled first row */
+	if (head) BT_GP(uint16_t, walk)[s] = 0;
+	for (uint32_t j = head ? 1u : 0u; j < k; j++) { const uint32_t d = k - j; BT_GP(uint16_t, walk)[s - j] = (uint16_t)(d < 0xffffu ? d : 0xffffu); }
+	if (row == ix.zOff) BT_GP(uint16_t, walk)[0] = 0;
+}
+
 #endif /* BT_WIDE: the side-layout block build and the locus image are the narrow build's */
 
 /* ftabHi / ftabLo (ebwt.h:985-1034) */

@@ -23,6 +23,10 @@
 #define EMU_POISON(p, n) ((void)0)
 #endif
 
+#ifdef BT_L2_DEBUG
+unsigned long long g_l2_hit = 0, g_l2_miss = 0, g_l2_none = 0;
+extern "C" void emu_l2_stats(unsigned long long* o) { o[0] = g_l2_hit; o[1] = g_l2_miss; o[2] = g_l2_none; }
+#endif
 struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; std::vector<uint8_t> blk[2]; std::vector<BtU4> loc[2]; std::vector<uint32_t> rtxt[2]; std::vector<uint16_t> walk[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
 
 static void bind(EmuIndex* e, int m)
@@ -79,6 +83,27 @@ extern "C" int emu_locus_arrays(void* p, int mirror, const void** loc, const voi
 	*loc = e->d[m].loc; *rtxt = e->d[m].rtxt; *walk = e->d[m].walk; *len = (uint32_t)e->d[m].len;
 	return 0;
 }
+
+#if !BT_WIDE
+/* the image's pass 1 as the GPU loader runs it (bt_rank.h: bt_loc_chain, a chain per sampled row) against the host build's
+ * one walk over the text: 0 = the SA column, the reversed text and the walk lengths are the same, else which differs */
+extern "C" int emu_locus_chains_check(void* p, int mirror)
+{
+	EmuIndex* e = (EmuIndex*)p;
+	const int m = mirror ? 1 : 0;
+	const BtIndexDev& ix = e->d[m];
+	if (!ix.loc) return -1;
+	std::vector<BtU4> loc((size_t)ix.len + 1u, BtU4{0xdeadbeefu, 0, 0, 0});
+	std::vector<uint32_t> rtxt((size_t)bt_rtxt_words(ix.len), 0u);
+	std::vector<uint16_t> walk((size_t)ix.len + 1u, 0xbeef);
+	const uint64_t n = bt_loc_chain_count(ix);
+	for (uint64_t i = 0; i < n; i++) bt_loc_chain(ix, i, loc.data(), rtxt.data() + BT_RTXT_PAD_WORDS, walk.data());
+	for (size_t r = 0; r <= ix.len; r++) if (loc[r].x != e->loc[m][r].x) return 1;
+	if (memcmp(rtxt.data(), e->rtxt[m].data(), rtxt.size() * 4u) != 0) return 2;
+	if (memcmp(walk.data(), e->walk[m].data(), walk.size() * 2u) != 0) return 3;
+	return 0;
+}
+#endif
 
 /* rows as 64-bit numbers, whatever the build's row type */
 extern "C" void emu_rank4_64(void* p, int mirror, uint64_t row, uint64_t* lf, uint32_t* L)

@@ -131,3 +131,29 @@ def test_synthetic_genome_index_is_searchable(tmp_path):
     batch = synth_reads(text, 200, 50, mm_dist=(0,), seed=3, n_frac=0.0)
     res = R.oracle_search(oi, OL.make_policy("v", 0), batch)
     assert sum(1 for h, _, _ in res if h) >= 190         # reads straddling a fragment boundary are rejected
+
+
+def test_locus_image_chain_by_chain_equals_the_one_walk_over_the_text(tmp_path):
+    """The GPU loader derives the locus image's suffix array, reversed text and walk lengths a CHAIN at a time since round 6
+    (bt_rank.h: bt_loc_chain -- from every sampled row down to the next one; round 5 walked from every row to a sampled one:
+    2^offRate / 2 ranks per row instead of one).  The same function on the host against bt_loc_build_host's single walk over
+    the text, on genomes of 1 .. 300 bases and every sampling rate 0 .. 6: the '$' row sampled or not, the last row sampled
+    or not, chains of length one."""
+    import ctypes as C
+    import emu_lib as E
+    from bowtie_amd import ebwt_build as EB
+    rng = np.random.default_rng(12)
+    n_checked = 0
+    for L in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 200, 255, 256, 300]:
+        for off_rate in (0, 1, 2, 3, 5, 6):
+            seq = rng.integers(0, 4, size=L).astype(np.uint8)
+            if L > 20 and off_rate == 2:
+                seq[L // 2:L // 2 + 3] = 4                                   # two fragments
+            base = str(tmp_path / ("g%d_%d" % (L, off_rate)))
+            EB.build_index([seq], ["s"], base, off_rate=off_rate, ftab_chars=min(3, max(1, L // 4)) if L < 12 else 4)
+            e = E.EmuAligner(base)
+            e.L.emu_locus_chains_check.argtypes = [C.c_void_p, C.c_int]
+            for mirror in (0, 1):
+                assert e.L.emu_locus_chains_check(e.h, mirror) == 0, (L, off_rate, mirror)
+                n_checked += 1
+    assert n_checked > 500
