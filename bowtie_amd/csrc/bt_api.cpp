@@ -27,7 +27,7 @@ struct bt_index {
 	BtIndexHost host[2];           /* big arrays are released after upload; names/plen stay */
 	BtIndexDev  dev[2];
 	std::vector<void*> allocs;
-	uint64_t blk_bytes = 0; uint64_t ebwt_bytes = 0, offs_bytes = 0;
+	uint64_t blk_bytes = 0; uint64_t ebwt_bytes = 0, offs_bytes = 0, jump_bytes = 0;
 	std::string base;
 	BtRefDev* d_ref = nullptr;     /* the 2-bit reference, loaded on demand (bt_index_load_reference) */
 	uint64_t ref_bytes = 0;
@@ -66,6 +66,7 @@ struct bt_ctx {
 	uint32_t cus = 0, blocksPerCU = 2;      /* nLanes covers the widest launch (3 blocks per CU) */
 	bool rl3 = true;                        /* the three-blocks-per-CU build may be used */
 	bool locus = false;                     /* the index has its locus image and this context's launches use it */
+	bool jumpOn = true;                     /* ... and its jump table (BT_JUMP=0: A/B, diagnostics) */
 	/* descriptors on their way to the device (ctx_h2d): a ring of page-locked slots, so that no asynchronous copy ever
 	 * reads memory that has gone out of scope */
 	uint8_t* hstage = nullptr; uint32_t hsNext = 0; hipEvent_t hsEv[64] = {}; bool hsUsed[64] = {};
@@ -90,6 +91,7 @@ struct bt_ctx {
 	bt_ctx* big = nullptr;             /* lazily created twin with worst-case scratch: reruns reads that overflowed */
 	bool is_big = false;
 	uint32_t last_retried = 0, last_dev_retried = 0, last_carried = 0;
+	uint64_t last_jumps = 0, last_jump_steps = 0;       /* bt_ctx_counts: jump-table look-ups and the reference's steps behind them */
 	uint32_t maxLenHint = 0;           /* bt_ctx_set_max_read_len */
 	char last_kernel[64] = "";         /* the kernel variant the last batch ran (as rocprofv3 names it) */
 	BtCold* d_cold = nullptr;
@@ -186,6 +188,31 @@ extern "C" int bt_index_load(const char* ebwt_base, int need_mirror, int offrate
 			if (bt_launch_blk_build(&d, blk, (uint32_t)nb, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) { bt_index_free(ix); return BT_ERR_DEVICE; }
 			d.blk = blk;
 			ix->blk_bytes += nb * BT_BLK_BYTES;
+		}
+		{
+			/* the jump table (bt_rank.h): the range behind a search's first 14 characters, derived from ftab and the rank blocks.
+			 * 10 bytes per entry, 2.7 GB per index at 14 characters; only for genomes that can use it (BT_JUMP_CHARS=<n> says
+			 * otherwise, 0 = none) */
+			uint32_t K = (uint64_t)h.len >= (1ull << 22) ? 14u : 0u;
+			if (const char* e = getenv("BT_JUMP_CHARS")) K = (uint32_t)atoi(e);
+			if (K > 15u) K = 15u;
+			d.jump = nullptr; d.jumpMeta = nullptr; d.jumpChars = 0;
+			if (K > (uint32_t)h.ftabChars && h.ftabChars >= 1 && K - (uint32_t)h.ftabChars <= 7u) {
+				const uint64_t n = 1ull << (2u * K);
+				uint32_t* jt = nullptr; uint16_t* jm = nullptr;
+				size_t freeB = 0, totB = 0;
+				const bool room = hipMemGetInfo(&freeB, &totB) == hipSuccess && (uint64_t)freeB > n * 10u + (totB / 8u);
+				if (room && hipMalloc((void**)&jt, n * 8u) == hipSuccess && hipMalloc((void**)&jm, n * 2u + 16u) == hipSuccess) {
+					ix->allocs.push_back(jt); ix->allocs.push_back(jm);
+					if (bt_launch_jump_build(&d, K, jt, jm, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) { bt_index_free(ix); return BT_ERR_DEVICE; }
+					d.jump = jt; d.jumpMeta = jm; d.jumpChars = K;
+					ix->jump_bytes += n * 10u;
+				} else {
+					(void)hipGetLastError();
+					if (jt) (void)hipFree(jt);
+					if (getenv("BT_VERBOSE")) fprintf(stderr, "bowtie_amd: no room for the jump table (%.1f GB): searches start from the index's own ftab\n", n * 10.0 / 1e9);
+				}
+			}
 		}
 #endif
 		ix->ebwt_bytes += h.ebwt.size(); ix->offs_bytes += h.offs.size() * sizeof(bt_row);
@@ -428,6 +455,13 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 	HIPCHK(hipMalloc((void**)&c->pairs, (size_t)c->nSlots * c->entCap * 8u * sizeof(bt_row)));
 	HIPCHK(hipMalloc((void**)&c->meta, (size_t)c->nSlots * c->entCap * 2u));
 	HIPCHK(hipMalloc((void**)&c->pals, (size_t)c->nSlots * c->palCap * 8u));
+	if (ctx_env(c, "BT_VERBOSE", 0)) {
+		size_t freeB = 0, totB = 0;
+		(void)hipMemGetInfo(&freeB, &totB);
+		fprintf(stderr, "bowtie_amd: context %p%s: scratch for %u lanes, reads <= %u: %u frames, %u range-stack entries, %u seedlings per lane = %.2f GB; device memory %.1f of %.1f GB free\n",
+		        (void*)c, c->is_big ? " (second pass)" : "", c->nSlots, c->maxLen, c->frCap, c->entCap, c->palCap,
+		        (double)c->nSlots * ((double)c->frCap * BT_FR_WORDS * 4.0 + (double)c->entCap * (8.0 * sizeof(bt_row) + 2.0) + (double)c->palCap * 8.0) / 1e9, freeB / 1e9, totB / 1e9);
+	}
 	return BT_OK;
 }
 
@@ -460,6 +494,7 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 	 * engine takes a reported row's offset from the image's dense suffix array instead of walking to a sampled row (bt_best.h:
 	 * ch_row_set; BT_BEST_LOCUS=0: it walks, as in rounds 2-4) */
 	c->locus = index_ensure_locus(idx) && (!c->best || env_u32("BT_BEST_LOCUS", 1) != 0);
+	c->jumpOn = env_u32("BT_JUMP", 1) != 0;
 	if (stream) c->stream = (hipStream_t)stream;
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 	HIPCHK(hipEventCreate(&c->ev0));
@@ -587,6 +622,10 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		 * the lanes rather than ending the run (a launch with fewer lanes is slower, not wrong) */
 		size_t freeB = 0, totB = 0;
 		if (hipMemGetInfo(&freeB, &totB) == hipSuccess) {
+			/* tests: BT_FAKE_FREE_MB pretends the device has that little free, so that the fewer-lanes path runs on a box
+			 * that has plenty */
+			const uint32_t fakeMB = ctx_env(c, "BT_FAKE_FREE_MB", 0);
+			if (fakeMB && ((size_t)fakeMB << 20) < freeB) freeB = (size_t)fakeMB << 20;
 			const uint64_t budget = (uint64_t)freeB / 100u * ctx_env(c, "BT_BEST_ARENA_FRAC", 45u);
 			const uint64_t fit = budget / ((uint64_t)words * 4u) / BT_BLOCK * BT_BLOCK;
 			if (fit < lanes) lanes = fit < BT_BLOCK ? BT_BLOCK : (uint32_t)fit;
@@ -600,6 +639,8 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 			if (lanes < BT_BLOCK) lanes = BT_BLOCK;
 		}
 		c->arenaWords = words; c->arenaLanes = lanes;
+		if (ctx_env(c, "BT_VERBOSE", 0)) fprintf(stderr, "bowtie_amd: best-first context %p%s: arenas for %u lanes (%u asked) x %u words = %.2f GB; device memory %.1f of %.1f GB free\n",
+		                                       (void*)c, c->is_big ? " (second pass)" : "", lanes, c->arenaAsked, words, (double)lanes * words * 4.0 / 1e9, freeB / 1e9, totB / 1e9);
 		/* fewer lanes than asked for is slower, not wrong -- but say so once (BT_VERBOSE), and ask again when the caller's
 		 * batches still want more and the device may have room by then: arenaAsked stands only as long as memory is short */
 		if (lanes < c->arenaAsked) {
@@ -730,6 +771,7 @@ static void fill_index_args(const bt_ctx* c, BtKernelArgs* A, BtWarm* warm)
 		warm->offRate[m] = d.offRate; warm->ftabChars[m] = d.ftabChars; warm->len[m] = d.len;
 		for (int k = 0; k < 5; k++) A->H.fchr[m][k] = d.fchr[k];
 		if (c->locus) { warm->loc[m] = d.loc; warm->rtxt[m] = d.rtxt; warm->walk[m] = d.walk; }
+		if (c->jumpOn) { warm->jump[m] = d.jump; warm->jumpMeta[m] = d.jumpMeta; warm->jumpChars[m] = d.jump ? d.jumpChars : 0u; }
 #if BT_WIDE
 		A->H.segBase[m] = d.segBase; A->H.segShift = d.segShift; warm->rowLim[m] = d.rowLim;
 #endif
@@ -1009,6 +1051,10 @@ extern "C" int bt_align_batch_device(bt_ctx* c, const bt_read_batch* in, bt_hit_
                                      bt_op_counts* counts_dev)
 {
 	if (!c || !in || !out) return BT_ERR_ARG;
+	/* (a caller's device-side counter block: the kernels tally more words than bt_op_counts has fields -- section timers, the
+	 * locus-mode and jump-table tallies that bt_ctx_counts folds into the reference's op counts -- so since 0.2.0 the counters
+	 * are read with bt_ctx_counts after bt_ctx_sync and this must be NULL) */
+	if (counts_dev) return BT_ERR_UNSUPPORTED;
 	/* lengths live in HBM: size the scratch for the row stride (>= every length), or for what the caller vouched for */
 	const uint32_t hint = c->maxLenHint && c->maxLenHint < in->stride ? c->maxLenHint : 0u;
 	return run_device(c, in, out, hint ? hint : in->stride, (unsigned long long*)counts_dev, hint == 0, true);
@@ -1062,6 +1108,7 @@ extern "C" int bt_align_pairs_device(bt_ctx* c, const bt_read_batch* in1, const 
                                      bt_op_counts* counts_dev)
 {
 	if (!c || !in1 || !in2 || !out || in1->n_reads != in2->n_reads) return BT_ERR_ARG;
+	if (counts_dev) return BT_ERR_UNSUPPORTED;          /* (see bt_align_batch_device) */
 	int rc = ctx_ensure_paired(c);
 	if (rc != BT_OK) return rc;
 	if (in1->n_reads == 0) { c->timed = false; return BT_OK; }
@@ -1317,6 +1364,10 @@ extern "C" int bt_ctx_prof_sections(bt_ctx* c, uint64_t* out, int n)
 extern "C" void bt_ctx_set_iters_buffer(bt_ctx* c, uint32_t* dev_ptr) { if (c) c->iters_dev = dev_ptr; }
 
 extern "C" uint32_t bt_ctx_last_mm_used(bt_ctx* c) { return c ? c->last_mm_used : 0; }
+/* after bt_ctx_counts: the jump table's look-ups among the counted searches, and the LF steps of the reference's algorithm that
+ * lay behind them (they are part of bt_op_counts' lf2 / lf1) */
+extern "C" void bt_ctx_jump_counts(bt_ctx* c, uint64_t* lookups, uint64_t* steps) { if (lookups) *lookups = c ? c->last_jumps : 0; if (steps) *steps = c ? c->last_jump_steps : 0; }
+extern "C" uint64_t bt_index_jump_bytes(const bt_index* idx) { return idx ? idx->jump_bytes : 0; }
 /* after bt_ctx_sync: reads the last two launches parked for their successors (carry-over; diagnostics) */
 extern "C" uint32_t bt_ctx_last_carried(bt_ctx* c) { return c ? c->last_carried : 0; }
 extern "C" uint32_t bt_ctx_last_retried(bt_ctx* c) { return c ? c->last_retried + c->last_dev_retried : 0; }
@@ -1332,6 +1383,9 @@ extern "C" int bt_ctx_counts(bt_ctx* c, bt_op_counts* out, int reset)
 	/* what locus mode decided by the text is part of the reference's op counts all the same (bt_op_counts) */
 	out->loc_lfex = h[CN_TLFEX]; out->loc_lf1 = h[CN_TLF1]; out->loc_chase = h[CN_TCHASE]; out->loc_records = h[CN_LOCREC]; out->loc_windows = h[CN_TXTWIN];
 	out->lfex += out->loc_lfex; out->same_pair += out->loc_lfex; out->lf1 += out->loc_lf1; out->chase += out->loc_chase;
+	/* ... and so is what lies behind the jump table's look-ups */
+	out->lf2 += h[CN_JLF2]; out->lf1 += h[CN_JLF1]; out->same_pair += h[CN_JSAME];
+	c->last_jumps = h[CN_JUMPS]; c->last_jump_steps = h[CN_JLF2] + h[CN_JLF1];
 	if (reset) HIPCHK(hipMemsetAsync(c->d_counts, 0, sizeof(h), c->stream));      /* ordered before the next launch's tallies */
 	return BT_OK;
 }

@@ -108,6 +108,9 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 	/* the leaf's state in LDS (bt_best.h: BfAuto::leafp), 37 words per lane: with four blocks on a CU, 148 of its 160 KB */
 	__shared__ uint32_t LEAF[BT_BLOCK * BF_LEAF_STRIDE];
 	S.leafp = (BfLeafSt*)(LEAF + threadIdx.x * BF_LEAF_STRIDE);
+	/* (gfx950 hands LDS out in 1 280-byte granules, 128 to a CU: BT_BEST_MIN_BLOCKS blocks must fit) */
+	static_assert(sizeof(LEAF) + sizeof(BfProgram) + 2 * sizeof(BtIndexDev) + sizeof(BtBatchDev) + sizeof(BtRefDev) + 64 <= (128u / BT_BEST_MIN_BLOCKS) * 1280u,
+	              "the leaf states and the descriptors must fit the block's share of the CU's LDS");
 #else
 	BfLeafSt leafHere;
 	S.leafp = &leafHere;

@@ -901,6 +901,17 @@ int main(int argc, char** argv)
 	const bool tabbed = O.rd.format == BT_FMT_TABBED;
 	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
 	const int T = O.threads;
+	/* the formatter's threads: -p of them, or twice that where the host has the cores to spare (the parser's -p threads and the
+	 * formatter's are busy at the same time only in the middle of a run; at its end the formatter works through the last
+	 * batches alone, and that stretch is part of every run: 5 of 28 s at 192 M reads in round 6's timeline) */
+	int TF = T;
+	{
+		const unsigned hw = std::thread::hardware_concurrency();
+		const int half = (int)(hw / 2u);
+		const int cap = half > T ? half : T;
+		TF = 2 * T < cap ? 2 * T : cap;
+		if (const char* e = getenv("BT_CLI_FORMAT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) TF = v; }
+	}
 	double busy_read = 0, busy_write = 0;
 	std::atomic<bool> abort_run(false);
 	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
@@ -1277,7 +1288,7 @@ int main(int argc, char** argv)
 				if (is_wide) { segs.push_back({lo, hi, (int)(c / 2)}); continue; }
 				/* split plain segments across the threads: several pieces each, so that the first ones are on their way to
 				 * the file while the rest are still being formatted */
-				uint32_t pieces = (hi - lo) >= 8192 ? (uint32_t)T * 4u : 1u;
+				uint32_t pieces = (hi - lo) >= 8192 ? (uint32_t)TF * 4u : 1u;
 				if (pieces > 1u && pieces > (hi - lo) / 4096u) pieces = (hi - lo) / 4096u;      /* >= 2: hi - lo >= 8192 */
 				for (uint32_t p = 0; p < pieces; p++)
 					segs.push_back({lo + (uint32_t)((uint64_t)(hi - lo) * p / pieces), lo + (uint32_t)((uint64_t)(hi - lo) * (p + 1) / pieces), -1});
@@ -1322,12 +1333,12 @@ int main(int argc, char** argv)
 				bt_io_format(one, names, off, hw, refs, O.out, 0, 1, &parts[si], &tl[si]);
 			};
 			double t_wait = 0;                                   /* this thread waiting for a piece's text */
-			if (T > 1 && segs.size() > 1) {
-				/* pieces are formatted in order of appearance by T threads and written, in order, by this one as they finish */
+			if (TF > 1 && segs.size() > 1) {
+				/* pieces are formatted in order of appearance by TF threads and written, in order, by this one as they finish */
 				std::vector<std::thread> th;
 				std::mutex m; std::condition_variable cv; size_t next = 0;
 				std::vector<char> ready(segs.size(), 0);
-				for (int t = 0; t < T; t++) th.emplace_back([&] {
+				for (int t = 0; t < TF; t++) th.emplace_back([&] {
 					for (;;) {
 						size_t si; { std::lock_guard<std::mutex> l(m); si = next++; }
 						if (si >= segs.size()) return;
@@ -1349,7 +1360,7 @@ int main(int argc, char** argv)
 				tally.aligned += tl[si].aligned; tally.unaligned += tl[si].unaligned; tally.maxed += tl[si].maxed; tally.reported += tl[si].reported;
 				tally.sample_max |= tl[si].sample_max; tally.reported_paired += tl[si].reported_paired;
 			}
-			if (getenv("BT_IO_PROFILE")) fprintf(stderr, "[io] batch of %u: format on %d threads + write %.3f s (%zu pieces; %.3f s of it waiting for text)\n", n, T, tf - tb, segs.size(), t_wait);
+			if (getenv("BT_IO_PROFILE")) fprintf(stderr, "[io] batch of %u: format on %d threads + write %.3f s (%zu pieces; %.3f s of it waiting for text)\n", n, TF, tf - tb, segs.size(), t_wait);
 			if (dumping) {
 				/* HitSink::dumpAlign / dumpUnal / dumpMaxed (hit.h:385-488): the read's record as it stood in
 				 * the input; files are created when the first read goes to them; without --max, reads over
@@ -1530,5 +1541,8 @@ int main(int argc, char** argv)
 	if (O.timing) print_timer("Overall time: ", now_s() - t_all);
 	g_tl.mark("end", 0);
 	g_tl.print();
-	return 0;
+	/* every file is closed and every stream flushed: leave without the runtime's own teardown (the HIP runtime unloading its
+	 * code objects and tearing down queues was most of a second at the end of every run) */
+	fflush(nullptr);
+	_exit(0);
 }

@@ -82,14 +82,22 @@ enum {
 	FR_MM,       /* mismatch chosen at this level: query offset | refc<<16                       */
 	FR_L2        /* the second quality level: cand2 | num2<<11 | l2v<<23 (low2 rides in FR_W4, cel1 / cel2 in FR_W3) */
 };
-#define BT_TOS_L2 9          /* FR_L2's place in the LDS top-of-stack copy */
-#define BT_TOS_WORDS 10      /* FR_W0..FR_ANCHOR and FR_L2 travel to the LDS top-of-stack copy (FR_L2 as its word 9) */
+#ifndef BT_L2_TALLY
+/* 1: a frame tallies a SECOND quality level while it steps forward (BtLane::low2) and its first re-scan costs nothing.  Off:
+ * the tally needs a tenth word in the LDS top-of-stack copy, and with it the three-block build's 54 144 bytes of LDS no
+ * longer fit three to a CU (LDS is handed out in 1 280-byte granules on gfx950: 3 x 43 > 128) -- round 6's third GPU call
+ * measured 12.0 M reads/s for it against 15.7 M without, i.e. two blocks per CU; -3.3 % rounds do not pay for that */
+#define BT_L2_TALLY 0
+#endif
+#if BT_L2_TALLY
+#define BT_L2_RESET(L) do { (L).l2v = 0; (L).low2 = 0xff; (L).cel1 = 0; (L).cel2 = 0; } while (0)
+#else
+#define BT_L2_RESET(L) do { } while (0)
+#endif
+#define BT_TOS_WORDS (9 + BT_L2_TALLY)   /* FR_W0..FR_ANCHOR (and FR_L2, as word 9) travel to the LDS top-of-stack copy */
 #define BT_CC_WORDS 9        /* LDS copy of the current backtrack candidate: tops[4], bots[4], record */
 #define BT_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS + BT_CC_WORDS)   /* per lane: candidate, top-of-stack, its candidate */
 #define BT_LITE_LDS_WORDS (BT_CC_WORDS + BT_TOS_WORDS)            /* the 3-waves-per-SIMD build: candidate, top-of-stack */
-#ifndef BT_L2_TALLY
-#define BT_L2_TALLY 1        /* 0: no second quality level is tallied (BtLane::low2): every re-scan walks the frame's records (A/B) */
-#endif
 #ifndef BT_LITE_CC
 #define BT_LITE_CC 1         /* 0: round 5's 3-waves build, without the current frame's candidate cache (A/B) */
 #endif
@@ -173,6 +181,10 @@ struct BtWarm {
 	const uint32_t* rtxt[2];
 	const uint16_t* walk[2];
 	uint32_t locOn, pad;
+	/* the jump table (bt_rank.h), NULL / 0 when the index has none */
+	const uint32_t* jump[2];
+	const uint16_t* jumpMeta[2];
+	uint32_t jumpChars[2];
 #if BT_WIDE
 	bt_row   rowLim[2];               /* the last BWT row (BtIndexDev::rowLim) */
 #endif
@@ -249,7 +261,7 @@ enum {
 	ST_STEP_BEGIN, ST_STEP_LFDONE, ST_STEP_POST, ST_CHASE_CHECK, ST_CHASE_LFDONE, ST_WIN_DONE,
 	ST_LOC_REC, ST_LOC_TXT, ST_STEP_LOC,      /* locus mode: a row's locus record / a text window arrived; a step decided by text */
 	/* slow states */
-	ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FTABSEQ_DONE, ST_FTAB_DONE, ST_FRAME_ENTER, ST_BT_LOOP, ST_BT_PICK,
+	ST_PHASE_NEXT, ST_SEARCH_BEGIN, ST_FTABSEQ_DONE, ST_FTAB_DONE, ST_JUMP_DONE, ST_FRAME_ENTER, ST_BT_LOOP, ST_BT_PICK,
 	ST_CANDSCAN, ST_CANDSCAN_DONE, ST_CHILD_RET, ST_RESCAN, ST_RESCAN_DONE, ST_FRAME_RETURN,
 	ST_FRAME_FETCHED, ST_FELL_OFF, ST_RA_BEGIN, ST_ROW_BEGIN, ST_RESOLVE_DONE, ST_RA_END, ST_SEARCH_END,
 	ST_ABORT
@@ -264,7 +276,10 @@ enum { CN_LFEX = 0, CN_LF2, CN_LF1, CN_CHASE, CN_FTAB, CN_OFFS, CN_RSTARTS, CN_F
        /* locus mode: the reference's mapLFEx / mapLF1 / SA-walk steps that were decided by text comparison or by the dense
         * suffix array instead of being gone through (they are part of bt_op_counts' lfex / lf1 / chase all the same), the locus
         * records and the text windows fetched for it */
-       CN_TLFEX, CN_TLF1, CN_TCHASE, CN_LOCREC, CN_TXTWIN, CN_N };
+       CN_TLFEX, CN_TLF1, CN_TCHASE, CN_LOCREC, CN_TXTWIN,
+       /* the jump table: the reference's mapLF (two rows) / mapLF1 steps behind a look-up, and how many of the former had both
+        * rows in one side pair (part of bt_op_counts' lf2 / lf1 / same_pair all the same); the look-ups themselves */
+       CN_JLF2, CN_JLF1, CN_JSAME, CN_JUMPS, CN_N };
 #if defined(__HIP_DEVICE_COMPILE__)
 /* one LDS atomic per wavefront: hipcc folds atomicAdd(p,1) of the active lanes into s_bcnt1 + one ds_add */
 #define BT_COUNT(k) atomicAdd(&CNT[k], 1ull)
@@ -326,7 +341,9 @@ struct BtLane {
 	 * (ebwt_search_backtrack.h:1004-1058: next-lowest quality, its count, its deepest position) is then already known --
 	 * nothing touched those records since -- and costs neither its fetch rounds nor its walk (43 re-scans per read at hg19
 	 * scale, 9 % of the wavefronts' time in round 5's section profile).  The level after that is found by the scan as before. */
+#if BT_L2_TALLY
 	uint32_t cand2 : 11, num2 : 12, l2v : 1;
+#endif
 	uint32_t ebase;
 	/* per-position temporaries that live across the wait + control */
 	uint32_t c : 3, q : 8, lfk : 2, fl_alt : 1, fl_elig : 1, fl_over : 1, ret : 1, ra_cont : 2,
@@ -866,10 +883,15 @@ BT_HD void bt_frame_push(BtLane& L, const BtScratch& S, uint32_t mm)
 	w[FR_W6] = L.pi | (L.pj << 11) | (L.pel << 13);
 	w[FR_EBASE] = L.ebase;
 	w[FR_ANCHOR] = (uint32_t)L.top;
-	w[BT_TOS_L2] = L.cand2 | (L.num2 << 11) | (L.l2v << 23);
+#if BT_L2_TALLY
+	const uint32_t l2w = L.cand2 | (L.num2 << 11) | (L.l2v << 23);
+	w[BT_TOS_WORDS - 1] = l2w;
+#else
+	const uint32_t l2w = 0;
+#endif
 	uint32_t* fr = S.a->frames + ((uint64_t)S.slot * S.a->frCap + L.sd) * BT_FR_WORDS;
 	BtU4 q0, q1, q2; q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = w[7];
-	q2.x = w[FR_ANCHOR]; q2.y = mm; q2.z = w[BT_TOS_L2]; q2.w = 0;          /* FR_ANCHOR, FR_MM (again: the caller wrote it), FR_L2 */
+	q2.x = w[FR_ANCHOR]; q2.y = mm; q2.z = l2w; q2.w = 0;          /* FR_ANCHOR, FR_MM (again: the caller wrote it), FR_L2 */
 	bt_st4(fr, q0); bt_st4(fr + 4, q1); bt_st4(fr + 8, q2);
 	BT_UNROLL
 	for (uint32_t k = 0; k < BT_TOS_WORDS; k++) S.tosRec[k * ts] = w[k];
@@ -1008,7 +1030,10 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			if (L.state == ST_FRAME_FETCHED) {
 				w[0] = res.q[0].x; w[1] = res.q[0].y; w[2] = res.q[0].z; w[3] = res.q[0].w;
 				w[4] = res.q[1].x; w[5] = res.q[1].y; w[6] = res.q[1].z; w[7] = res.q[1].w;
-				w[8] = res.q[2].x; w[BT_TOS_L2] = res.q[2].z;
+				w[8] = res.q[2].x;
+#if BT_L2_TALLY
+				w[BT_TOS_WORDS - 1] = res.q[2].z;
+#endif
 			} else if (L.tosValid && L.tosFrame == f) {
 				const uint32_t ts = S.tosStride;
 				BT_UNROLL
@@ -1034,7 +1059,9 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			v = w[FR_W3]; L.f2 = v & 0x7ffu; L.f3 = (v >> 11) & 0x7ffu; L.cel1 = (v >> 22) & 15u; L.cel2 = (v >> 26) & 15u;
 			v = w[FR_W4]; L.altNum = v & 0xfffu; L.eligibleNum = (v >> 12) & 0xfffu; L.low2 = v >> 24;
-			v = w[BT_TOS_L2]; L.cand2 = v & 0x7ffu; L.num2 = (v >> 11) & 0xfffu; L.l2v = (v >> 23) & 1u;
+#if BT_L2_TALLY
+			v = w[BT_TOS_WORDS - 1]; L.cand2 = v & 0x7ffu; L.num2 = (v >> 11) & 0xfffu; L.l2v = (v >> 23) & 1u;
+#endif
 			v = w[FR_W5]; L.cand = v & 0x7ffu; L.dcf = (v >> 11) & 0x7ffu; L.lmode = (v >> 22) & 1u; L.lt = (v >> 23) & 3u; L.lz = (v >> 25) & 1u; L.el = v >> 26;
 			v = w[FR_W6]; L.pi = v & 0x7ffu; L.pj = (v >> 11) & 3u; L.pel = (v >> 13) & 15u;
 			L.ebase = w[FR_EBASE];
@@ -1066,10 +1093,11 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				BT_COUNT(CN_RESCAN);
 				L.lowAltQual = 0xff; L.candValid = 0; L.ccValid = 0;
 				const uint32_t kmin = L.depth > L.fu ? L.depth : L.fu;
+#if BT_L2_TALLY
 #if defined(BT_L2_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
 				{ extern unsigned long long g_l2_hit, g_l2_miss, g_l2_none; if (L.d >= kmin) { if (L.l2v) g_l2_hit++; else g_l2_miss++; } else g_l2_none++; }
 #endif
-				if (BT_L2_TALLY && L.d >= kmin && L.l2v) {
+				if (L.d >= kmin && L.l2v) {
 					/* the next level was tallied while the frame stepped forward (BtLane::low2): what the scan would find */
 					L.lowAltQual = L.low2; L.eligibleNum = L.num2; L.cand = L.cand2; L.candValid = 1;
 					const uint32_t ce = L.cel2;
@@ -1077,6 +1105,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 					L.elignore = 0; L.l2v = 0;
 					L.state = ST_BT_LOOP; break;
 				}
+#endif
 				if (L.d >= kmin) { L.scanCb = bt_ent(L, L.d) >> 3; L.state = ST_RESCAN; break; }
 			}
 			L.state = ST_BT_LOOP;
@@ -1210,7 +1239,17 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			L.nsFtab0 = nsInFtab > 0 ? 1u : 0u;
 			const uint32_t m = L.unrev < L.qlen ? L.unrev : L.qlen;
 			L.fu = L.unrev; L.f1 = L.r1; L.f2 = L.r2; L.f3 = L.r3; L.ham = L.iham; L.ebase = 0;
-			if (RL && nsInFtab == 0 && m >= ftabChars) {
+			const uint32_t jumpChars = BT_WIDE ? 0u : WSEL(jumpChars);
+			if (!BT_WIDE && RL && jumpChars > ftabChars && !L.hasN && m >= jumpChars && L.qlen > jumpChars) {
+				/* the first jumpChars positions are ones the search may not revisit: what ftab + the steps behind it come
+				 * to is in the jump table (bt_rank.h) */
+				uint32_t off = 0;
+				BT_NOUNROLL
+				for (uint32_t t = 0; t < jumpChars; t++) off |= bt_qry<RL>(L, H, S, L.qlen - 1u - t) << (2u * t);
+				L.ra_r = off;           /* parked until the entry arrives */
+				BT_REQ_FETCH(WSEL(jump) + (size_t)(off >> 1) * 4u, 1, WSEL(jumpMeta) + (off & ~7u));
+				L.state = ST_JUMP_DONE;
+			} else if (RL && nsInFtab == 0 && m >= ftabChars) {
 				/* calcFtabOff (:1348-1362) straight from the LDS copy of the read */
 				uint32_t ftabOff = 0;
 				BT_NOUNROLL
@@ -1269,6 +1308,23 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 				L.depth = ftabChars; L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER;
 			} else { L.ret = 0; L.state = ST_SEARCH_END; }
 		} while (0); BT_PROF_ADD(PS_FTAB_DONE, t_ftab_done); }
+
+		if (!BT_WIDE && ST_IS_NOREQ(ST_JUMP_DONE)) { do {
+			const uint32_t off = (uint32_t)L.ra_r;
+			const uint32_t top = bt_u4_word(res.q[0], (off & 1u) * 2u), bot = bt_u4_word(res.q[0], (off & 1u) * 2u + 1u);
+			const uint32_t meta = bt_u4_meta(res.x, off & 7u);
+			const uint32_t nOps = meta & 7u, nMulti = (meta >> 3) & 7u, nSame = (meta >> 6) & 7u;
+			/* what the reference goes through for this: the ftab look-up and the steps behind it */
+			BT_COUNT(CN_FTAB); BT_COUNT(CN_JUMPS);
+			BT_COUNT_N(CN_JLF2, nMulti); BT_COUNT_N(CN_JLF1, nOps - nMulti); BT_COUNT_N(CN_JSAME, nSame);
+			if (bot > top) { L.depth = WSEL(jumpChars); L.top = top; L.bot = bot; L.state = ST_FRAME_ENTER; }
+			else {
+				/* the range ran empty on the way: the reference entered its frame behind ftab (unless ftab's own range was
+				 * empty: no steps) and the frame failed without anything to go back to */
+				if (nOps > 0) BT_COUNT(CN_FRAMES);
+				L.ret = 0; L.state = ST_SEARCH_END;
+			}
+		} while (0); }
 
 		/* ---- choose a backtrack target and descend (:743-971) --------------------------- */
 		if (ST_IS(ST_BT_LOOP)) { BT_PROF_T0(t_bt_loop); do {
@@ -1419,7 +1475,7 @@ BT_HD void bt_lane_slow(BtLane& L, const BtProgram& P, const BtHot& H, const BtW
 			}
 			L.altNum = 0; L.eligibleNum = 0;
 			L.elcint = 0; L.elignore = 1;
-			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0; L.l2v = 0; L.low2 = 0xff; L.cel1 = 0; L.cel2 = 0;
+			L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0; BT_L2_RESET(L);
 			L.d = L.depth;
 			L.state = ST_STEP_BEGIN;
 		} while (0); BT_PROF_ADD(PS_FRAME_ENTER, t_frame_enter); }
@@ -1476,7 +1532,7 @@ BT_HD bool bt_loc_descend(BtLane& L, const BtProgram& P, const BtWarm& W, const 
 	}
 	L.altNum = 0; L.eligibleNum = 0;
 	L.elcint = 0; L.elignore = 1;
-	L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0; L.l2v = 0; L.low2 = 0xff; L.cel1 = 0; L.cel2 = 0;
+	L.lowAltQual = 0xff; L.candValid = 0; L.cand = 0; L.ccValid = 0; BT_L2_RESET(L);
 	L.d = L.depth;
 	L.state = ST_STEP_BEGIN;
 	return true;
@@ -1660,17 +1716,21 @@ BT_HD void bt_lane_run(BtLane& L, const BtProgram& P, const BtHot& H, const BtWa
 				el = ~nz & 15u;
 				const uint32_t na = (uint32_t)__builtin_popcount(nz);
 				L.altNum = L.altNum + na;
-				if (BT_L2_TALLY && !L.fl_elig && nz != 0 && L.considerQuals) {
+#if BT_L2_TALLY
+				if (!L.fl_elig && nz != 0 && L.considerQuals) {
 					/* an alternative of a quality above the eligible one: the second level's tallies (BtLane::low2) */
 					if (!L.l2v || q < L.low2) { L.low2 = q; L.num2 = na; L.cand2 = d; L.cel2 = el; L.l2v = 1; }
 					else if (q == L.low2) { L.num2 = L.num2 + na; L.cand2 = d; L.cel2 = el; }
 				}
+#endif
 				if (L.fl_elig && nz != 0) {
-					if (BT_L2_TALLY && L.fl_over && L.eligibleNum > 0 && L.considerQuals) {
+#if BT_L2_TALLY
+					if (L.fl_over && L.eligibleNum > 0 && L.considerQuals) {
 						/* a lower quality takes over: what was the eligible level is the second one from here on */
 						L.low2 = L.lowAltQual; L.num2 = L.eligibleNum; L.cand2 = L.cand; L.cel2 = L.cel1; L.l2v = 1;
 					}
 					L.cel1 = el;
+#endif
 					if (L.fl_over) {
 						L.lowAltQual = q; L.eligibleNum = 0;
 						L.elcint = (nz & 1u) ? 0u : (nz & 2u) ? 1u : (nz & 4u) ? 2u : 3u;

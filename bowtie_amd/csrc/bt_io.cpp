@@ -760,6 +760,25 @@ static uint32_t rand_seed(const uint8_t* seq, const uint8_t* qual, size_t len, c
  * them valid for the encoding -- takes a short loop; anything else goes through parse_fastq
  * above, which follows the reference's parser step by step (and produces its error messages). */
 struct FqRec { size_t off; uint32_t e[4]; uint64_t rdid; };   /* e[k]: offset of line k's '\n' from off */
+/* a vector of plain records that several threads fill in place: growing it does not touch the new elements */
+template <class T> struct BtPod {
+	T* p = nullptr; size_t n = 0, cap = 0;
+	BtPod() {}
+	~BtPod() { free(p); }
+	BtPod(const BtPod&) = delete;
+	BtPod& operator=(const BtPod&) = delete;
+	void reserve(size_t m) { if (m > cap) { const size_t c = m + m / 4 + 64; T* q = (T*)realloc((void*)p, c * sizeof(T)); if (!q) throw std::bad_alloc(); p = q; cap = c; } }
+	void resize_uninit(size_t m) { reserve(m); n = m; }
+	void push_back(const T& v) { reserve(n + 1); p[n++] = v; }
+	void pop_back() { n--; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	T* data() { return p; }
+	T& operator[](size_t i) { return p[i]; }
+	const T& operator[](size_t i) const { return p[i]; }
+	T& back() { return p[n - 1]; }
+	T& front() { return p[0]; }
+};
 
 static double io_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static double g_io_fill_s = 0;        /* BT_IO_PROFILE: time inside gzread / pread */
@@ -910,10 +929,11 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		s->idx_end = s->idx_end > by ? s->idx_end - by : 0;
 	}
 	if (s->idx_end < s->end) nl_index_more(s);        /* (a window another path of the reader filled) */
-	std::vector<FqRec> recs;
+	BtPod<FqRec> recs;
 	recs.reserve(max_reads < (1u << 22) ? max_reads : (1u << 22));
 	uint32_t maxline = 1;
 	bool at_limit = false;
+	static const size_t bulkMin = io_knob("BT_IO_BULK_MIN", 4096);
 	while (!s->done && recs.size() < max_reads) {
 		if (s->rdid >= s->limit) { s->done = true; at_limit = true; break; }
 		if (!s->f) {
@@ -927,6 +947,47 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 			}
 			if (s->pos >= s->end || s->buf[s->pos] != '@') { *err = "Error: reads file does not look like a FASTQ file"; return BT_ERR_READS; }
 			s->file_first = false;
+		}
+		if (s->rdid >= s->o.skip) {
+			/* the bulk of a batch: as many whole records as the newline index already holds -- four newlines each, one after
+			 * the other from here -- are laid out by the io threads, a share each; whatever needs a look (the end of a file,
+			 * more data, -s / -u) goes through the loop below, record by record, as before */
+			while (s->nl_cur < s->nl.size() && s->nl[s->nl_cur] < s->pos) s->nl_cur++;
+			size_t m = (s->nl.size() - s->nl_cur) / 4u;
+			if (m > max_reads - recs.size()) m = max_reads - recs.size();
+			if ((uint64_t)m > s->limit - s->rdid) m = (size_t)(s->limit - s->rdid);
+			if (m >= bulkMin) {
+				const size_t base = recs.size(), c0 = s->nl_cur, p0 = s->pos;
+				const uint64_t id0 = s->rdid;
+				recs.resize_uninit(base + m);
+				FqRec* out = recs.data() + base;
+				const size_t* nl = s->nl.p;
+				int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+				if ((size_t)T > m / 2048u) T = (int)(m / 2048u);
+				if (T < 1) T = 1;
+				std::vector<uint32_t> mx((size_t)T, 1u);
+				auto job = [&](int t) {
+					const size_t lo = m * (size_t)t / (size_t)T, hi = m * (size_t)(t + 1) / (size_t)T;
+					uint32_t ml = 1;
+					for (size_t i = lo; i < hi; i++) {
+						const size_t off = i == 0 ? p0 : nl[c0 + 4u * i - 1u] + 1u;
+						FqRec& r = out[i];
+						r.off = off; r.rdid = id0 + i;
+						for (int k = 0; k < 4; k++) r.e[k] = (uint32_t)(nl[c0 + 4u * i + (size_t)k] - off);
+						const uint32_t l2 = r.e[1] - r.e[0] - 1u;
+						if (l2 > ml) ml = l2;
+					}
+					mx[(size_t)t] = ml;
+				};
+				if (T == 1) job(0);
+				else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(job, t); for (auto& x : th) x.join(); }
+				for (int t = 0; t < T; t++) if (mx[(size_t)t] > maxline) maxline = mx[(size_t)t];
+				s->pos = nl[c0 + 4u * m - 1u] + 1u;
+				s->nl_cur = c0 + 4u * m;
+				s->rdid += m; s->file_recs += m;
+				if (s->pos >= s->end && s->feof) st_close_file(s);
+				continue;
+			}
 		}
 		FqRec r; r.off = s->pos; r.rdid = s->rdid;
 		size_t p = s->pos; int k = 0; bool partial = false;
@@ -1421,51 +1482,109 @@ static void verbose_hit(std::string* o, const char* nm, size_t nn, const uint8_t
 	o->push_back('\n');
 }
 
+/* The two records an unpaired SAM run consists of are written with plain stores into room made once per record (its size is
+ * bounded by the name, the two L-character columns and the reference's name): ~30 appends per record, each with its own
+ * capacity check, were what a formatter thread spent its time on (round 6: 3 us per record and thread on the GPU host). */
+static inline char* w_u(char* p, uint64_t v)
+{
+	if (v < 10u) { *p++ = (char)('0' + v); return p; }
+	char b[24]; int n = 24;
+	do { b[--n] = (char)('0' + v % 10u); v /= 10u; } while (v);
+	memcpy(p, b + n, (size_t)(24 - n));
+	return p + (24 - n);
+}
+static inline char* w_s(char* p, const char* s, size_t n) { memcpy(p, s, n); return p + n; }
+#define W_LIT(p, lit) w_s((p), (lit), sizeof(lit) - 1u)
+static inline char* w_seq(char* d, const uint8_t* seq, uint32_t L, bool fw)
+{
+	static const char fwc[] = "ACGTN", rcc[] = "TGCAN";
+	if (fw) for (uint32_t i = 0; i < L; i++) d[i] = fwc[seq[i] > 4 ? 4 : seq[i]];
+	else for (uint32_t i = 0; i < L; i++) d[i] = rcc[seq[L - 1u - i] > 4 ? 4 : seq[L - 1u - i]];
+	return d + L;
+}
+static inline char* w_qual(char* d, const uint8_t* q, uint32_t L, bool fw)
+{
+	if (fw) { memcpy(d, q, L); return d + L; }
+	for (uint32_t i = 0; i < L; i++) d[i] = (char)q[L - 1u - i];
+	return d + L;
+}
+static inline size_t ref_name_len(const BtRefNames& refs, uint32_t tidx, const bt_out_opts& op)
+{
+	return (!op.ref_idx && tidx < refs.names.size()) ? refs.names[tidx].size() : 12u;
+}
+static inline char* w_ref(char* p, const BtRefNames& refs, uint32_t tidx, const bt_out_opts& op)
+{
+	if (!op.ref_idx && tidx < refs.names.size()) {
+		const std::string& nm = refs.names[tidx];
+		size_t i = nm.size();
+		if (!op.full_ref) { i = 0; while (i < nm.size() && !isspace((unsigned char)nm[i])) i++; }
+		return w_s(p, nm.data(), i);
+	}
+	return w_u(p, tidx);
+}
+static inline char* w_qname(char* p, const char* nm, size_t n, bool trunc)
+{
+	size_t i = 0;
+	if (trunc) { while (i < n && !isspace((unsigned char)nm[i])) i++; } else i = n;
+	return w_s(p, nm, i);
+}
+
 static void sam_hit(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
                     const bt_hit& h, const uint16_t* mm, uint32_t xms, const BtRefNames& refs, const bt_out_opts& op,
                     int mapq_override = -1)
 {
 	static const char dna[] = "ACGT";
 	const bool fw = h.fw != 0;
-	put_qname(o, nm, nn, !op.no_qname_trunc);
-	o->push_back('\t'); put_u(o, fw ? 0u : 16u);
-	o->push_back('\t'); put_ref(o, refs, h.tidx, op);
-	o->push_back('\t'); put_u(o, (uint64_t)h.toff + 1u);
-	o->push_back('\t'); put_i(o, mapq_override >= 0 ? mapq_override : op.mapq);
-	o->push_back('\t'); put_u(o, L); o->append("M\t*\t0\t0\t");
-	put_seq(o, seq, L, fw);
-	o->push_back('\t');
-	put_qual(o, qual, L, fw);
-	o->append("\tXA:i:"); put_u(o, h.stratum);
-	o->append("\tMD:Z:");
+	const uint32_t n = h.nmm;
+	const size_t at = o->size();
+	o->resize(at + nn + 2u * (size_t)L + ref_name_len(refs, h.tidx, op) + 6u * (size_t)n + 200u);
+	char* const base = &(*o)[0] + at;
+	char* p = base;
+	p = w_qname(p, nm, nn, !op.no_qname_trunc);
+	*p++ = '\t'; p = w_u(p, fw ? 0u : 16u);
+	*p++ = '\t'; p = w_ref(p, refs, h.tidx, op);
+	*p++ = '\t'; p = w_u(p, (uint64_t)h.toff + 1u);
+	*p++ = '\t';
+	{ const int64_t mq = mapq_override >= 0 ? mapq_override : op.mapq; if (mq < 0) { *p++ = '-'; p = w_u(p, (uint64_t)(-mq)); } else p = w_u(p, (uint64_t)mq); }
+	*p++ = '\t'; p = w_u(p, L); p = W_LIT(p, "M\t*\t0\t0\t");
+	p = w_seq(p, seq, L, fw);
+	*p++ = '\t';
+	p = w_qual(p, qual, L, fw);
+	p = W_LIT(p, "\tXA:i:"); p = w_u(p, h.stratum);
+	p = W_LIT(p, "\tMD:Z:");
 	/* MD walks the alignment left to right on the reference: by 5' offset for '+', by descending
 	 * offset for '-' */
 	const uint16_t* sorted = mm;                   /* ordered by position (any length: Phred<5 mismatches cost nothing) */
-	const uint32_t n = h.nmm;
 	uint32_t run_from = 0;     /* alignment columns consumed so far */
 	for (uint32_t k = 0; k < n; k++) {
 		const uint16_t e = fw ? sorted[k] : sorted[n - 1 - k];
 		const uint32_t col = fw ? BT_MM_POS(e) : (L - 1u - BT_MM_POS(e));
-		put_u(o, col - run_from);
-		o->push_back(dna[BT_MM_REFC(e)]);
+		p = w_u(p, col - run_from);
+		*p++ = dna[BT_MM_REFC(e)];
 		run_from = col + 1u;
 	}
-	put_u(o, L - run_from);
-	o->append("\tNM:i:"); put_u(o, n);
-	if (xms > 0) { o->append("\tXM:i:"); put_u(o, xms); }
-	o->push_back('\n');
+	p = w_u(p, L - run_from);
+	p = W_LIT(p, "\tNM:i:"); p = w_u(p, n);
+	if (xms > 0) { p = W_LIT(p, "\tXM:i:"); p = w_u(p, xms); }
+	*p++ = '\n';
+	o->resize(at + (size_t)(p - base));
 }
 
 static void sam_unaligned(std::string* o, const char* nm, size_t nn, const uint8_t* seq, const uint8_t* qual, uint32_t L,
                           uint32_t xm, const bt_out_opts& op)
 {
-	put_qname(o, nm, nn, !op.no_qname_trunc);
-	o->append("\t4\t*\t0\t0\t*\t*\t0\t0\t");
-	put_seq(o, seq, L, true);
-	o->push_back('\t');
-	put_qual(o, qual, L, true);
-	o->append("\tXM:i:"); put_u(o, xm);
-	o->push_back('\n');
+	const size_t at = o->size();
+	o->resize(at + nn + 2u * (size_t)L + 64u);
+	char* const base = &(*o)[0] + at;
+	char* p = base;
+	p = w_qname(p, nm, nn, !op.no_qname_trunc);
+	p = W_LIT(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t");
+	p = w_seq(p, seq, L, true);
+	*p++ = '\t';
+	p = w_qual(p, qual, L, true);
+	p = W_LIT(p, "\tXM:i:"); p = w_u(p, xm);
+	*p++ = '\n';
+	o->resize(at + (size_t)(p - base));
 }
 
 void bt_io_format(const bt_read_batch& rb, const char* names, const uint64_t* name_off, const bt_hit_batch& hb,

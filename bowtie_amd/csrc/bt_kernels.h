@@ -89,6 +89,7 @@ extern "C" {
 int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, uint32_t cap, void* stream);
 int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream);
 uint32_t bt_best_blocks_per_cu(void);
+int bt_launch_jump_build(const BtIndexDev* ix, uint32_t K, uint32_t* jump, uint16_t* meta, void* stream);
 #define BT_RL_FORCE_EXT 0x100     /* or'ed into `rl`: launch the EXT instance whatever the arguments ask for (diagnostics) */
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);
 int bt_launch_maxlen(const uint16_t* len, uint32_t n, uint32_t* out, void* stream);   /* *out = max(*out, max len[]) */

@@ -122,7 +122,30 @@ extern "C" int bt_launch_loc_build(const BtIndexDev* ix, BtU4* loc, uint32_t* rt
 	return (int)hipGetLastError();
 }
 
+/* the jump table (bt_rank.h: BtIndexDev::jump), an entry per lane */
+__global__ __launch_bounds__(256) void bt_jump_build_kernel(BtIndexDev ix, uint32_t K, uint32_t* jump, uint16_t* meta)
+{
+	const uint64_t n = 1ull << (2u * K);
+	for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t top, bot, m;
+		bt_jump_entry(ix, (uint32_t)x, K, &top, &bot, &m);
+		BT_GP(uint32_t, jump)[2u * x] = top; BT_GP(uint32_t, jump)[2u * x + 1u] = bot;
+		BT_GP(uint16_t, meta)[x] = (uint16_t)m;
+	}
+}
+extern "C" int bt_launch_jump_build(const BtIndexDev* ix, uint32_t K, uint32_t* jump, uint16_t* meta, void* stream)
+{
+	hipDeviceProp_t prop; int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+	uint64_t nb = ((1ull << (2u * K)) + 255u) / 256u;
+	const uint64_t cap = (uint64_t)prop.multiProcessorCount * 64u;
+	if (nb > cap) nb = cap;
+	hipLaunchKernelGGL(bt_jump_build_kernel, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, *ix, K, jump, meta);
+	return (int)hipGetLastError();
+}
+
 #else
+extern "C" int bt_launch_jump_build(const BtIndexDev*, uint32_t, uint32_t*, uint16_t*, void*) { return -1; }
 /* the wide build: its loader derives the rank blocks on the host, straight from the file's BWT (bt_host.cpp), and it has no
  * locus image */
 extern "C" int bt_launch_blk_build(const BtIndexDev*, uint8_t*, uint32_t, void*) { return -1; }
@@ -142,6 +165,10 @@ __global__ __launch_bounds__(BT_BLOCK, OCC) void bt_search_kernel(BtKernelArgs A
 	__shared__ BtProgram PROG;                                 /* the phase program, read on every phase change */
 	__shared__ BtWarm WARM;                                    /* index geometry (see BtWarm) */
 	__shared__ BtArena ARENA;                                  /* scratch arena bases + capacities */
+	/* three blocks of the LITE build share a CU's 160 KB of LDS, which gfx950 hands out in 1 280-byte granules: 42 of the
+	 * CU's 128 per block, not a byte more (round 6: one more word per lane in TOS made it two blocks per CU, 15.7 -> 12.0 M reads/s) */
+	static_assert(!LITE || sizeof(RLB) + sizeof(CNT) + sizeof(TOS) + sizeof(PROG) + sizeof(WARM) + sizeof(ARENA) + 64 <= 42u * 1280u,
+	              "the three-block build's LDS must fit 42 granules of 1280 bytes");
 	if (A.gate) { const uint32_t v = *BT_GP(const uint32_t, A.gate); if (v < A.gateLo || v > A.gateHi) return; }
 	if (threadIdx.x < CN_N + PS_N) CNT[threadIdx.x] = 0;
 	for (uint32_t i = threadIdx.x; i < sizeof(BtProgram) / 4; i += blockDim.x)

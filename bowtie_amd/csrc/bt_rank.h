@@ -110,6 +110,22 @@ struct BtIndexDev {
 	const BtU4*     loc;
 	const uint32_t* rtxt;
 	const uint16_t* walk;
+	/* ---- the jump table (round 6; optional: jump == NULL) ----
+	 * The reference starts a search with one look-up for the query's first ftabChars characters (10 in bowtie-build's indexes)
+	 * and then narrows the range a character at a time; on a 3 Gbp genome the next six of those steps go by before the range
+	 * is one row, each of them a dependent rank -- a lock-step round -- and while the positions are ones the search may not
+	 * revisit (the phase's `unrev` prefix: 14 characters with -n 2 -l 28, 28 for a seedling's extension, the whole read for
+	 * the exact phase) nothing is chosen and nothing recorded there: the result is a function of the characters alone.  HBM
+	 * buys the table of that function for the first jumpChars (14) characters: the range, and -- so that the op counters still
+	 * say what the reference's algorithm does -- how many LF steps lie behind it, how many of them on two rows and how many of
+	 * those inside one side pair.
+	 *   jump[x]      two rows: top, bot (top == bot: the range became empty on the way)
+	 *   jumpMeta[x]  u16: steps taken | two-row steps << 3 | same-pair steps << 6
+	 * x = the characters in the order the search meets them, two bits each, first character lowest: its low 2 * ftabChars bits
+	 * are the ftab offset. */
+	const uint32_t* jump;
+	const uint16_t* jumpMeta;
+	uint32_t jumpChars, padJ;
 	uint32_t wide;             /* the index FILES are a 64-bit (.ebwtl / .bt2l) build -- whatever this build's row type: the
 	                              32-bit build holds such an index too if it has fewer than 2^32 - 1 rows.  The
 	                              reference binary that serves it is compiled with 64-bit offsets, and two things
@@ -420,6 +436,38 @@ BT_HD bt_row bt_ftab_lo(const BtIndexDev& ix, uint32_t i)
 	if (v <= BT_ROWLIM(ix)) return v;
 	return BT_GP(const bt_row, ix.eftab)[(v ^ BT_OFF_MASK) * 2u];
 }
+
+#if !BT_WIDE
+/* One entry of the jump table (BtIndexDev::jump): the ftab range of x's first ftabChars characters, then the reference's own
+ * steps for the rest -- mapLF of both rows while the range has two or more (ebwt.h:2334-2380), mapLF1 while it has one
+ * (:2494-2512) -- as GreedyDFSRangeSource::backtrack goes through positions it may not revisit (ebwt_search_backtrack.h:544-566). */
+BT_HD void bt_jump_entry(const BtIndexDev& ix, uint32_t x, uint32_t K, uint32_t* topOut, uint32_t* botOut, uint32_t* metaOut)
+{
+	const uint32_t f = x & ((1u << (2u * ix.ftabChars)) - 1u);
+	uint32_t top = bt_ftab_hi(ix, f), bot = bt_ftab_lo(ix, f + 1u);
+	uint32_t nOps = 0, nMulti = 0, nSame = 0;
+	for (uint32_t d = ix.ftabChars; d < K; d++) {
+		if (bot <= top) break;
+		const uint32_t c = (x >> (2u * d)) & 3u;
+		uint32_t lf[4], L;
+		nOps++;
+		if (bot - top >= 2u) {
+			nMulti++;
+			if (top / 448u == bot / 448u) nSame++;
+			bt_rank4(ix, top, lf, &L);
+			const uint32_t t2 = lf[c];
+			bt_rank4(ix, bot, lf, &L);
+			top = t2; bot = lf[c];
+		} else {
+			bt_rank4(ix, top, lf, &L);
+			if (L != c || top == ix.zOff) { top = 0; bot = 0; }
+			else { top = lf[c]; bot = top + 1u; }
+		}
+	}
+	if (bot <= top) { top = 0; bot = 0; }
+	*topOut = top; *botOut = bot; *metaOut = nOps | (nMulti << 3) | (nSame << 6);
+}
+#endif
 
 /* joinedToTextOff (ebwt.h:2569-2629): joined offset -> (tidx,toff); false if [off,off+qlen)
  * straddles a fragment boundary. */

@@ -231,8 +231,10 @@ void bt_ctx_destroy(bt_ctx* ctx);
  * "search_*.c"; ebwt_search.cpp:1183-1199, 1660-1682, 2151-2176, 2557-2585).
  *   bt_align_batch         : host pointers in `in`/`out`; copies H2D, runs, copies D2H.
  *   bt_align_batch_device  : every pointer in `in`/`out` is a device pointer (reads already in
- *                            HBM, hits stay in HBM); asynchronous on the ctx stream.  `counts`
- *                            (optional, device pointer to bt_op_counts) is accumulated into.
+ *                            HBM, hits stay in HBM); asynchronous on the ctx stream.  `counts_dev`
+ *                            must be NULL since 0.2.0 (BT_ERR_UNSUPPORTED otherwise): the op counters
+ *                            of the batches since the last reset are read with bt_ctx_counts after
+ *                            bt_ctx_sync.
  *                            Stream order is the caller's: a context's own stream (stream == NULL at
  *                            bt_ctx_create) is NON-BLOCKING -- it does not wait for the null stream -- so
  *                            whatever produced the arrays on another stream (a fill, a copy, a kernel)
@@ -314,6 +316,12 @@ int  bt_ctx_set_max_read_len(bt_ctx* ctx, uint32_t max_len);
 float bt_ctx_span_ms(bt_ctx* ctx, uint32_t* n_launches);
 float bt_ctx_launch_ms(bt_ctx* ctx, int i);
 uint32_t bt_ctx_last_carried(bt_ctx* ctx);   /* after bt_ctx_sync: reads the last two launches parked (diagnostics) */
+/* The jump table (round 6): where the phase may not revisit a search's first 14 characters, the range behind them comes from
+ * one look-up in a table derived at load (10 bytes per 14-mer: 2.7 GB per index; genomes of 4 Mbp and more; BT_JUMP_CHARS=0:
+ * none) instead of ftab's 10 characters and four dependent LF steps.  The op counters still say what the reference's algorithm
+ * does.  bt_ctx_jump_counts (after bt_ctx_counts): the look-ups among the counted searches and the LF steps behind them. */
+void     bt_ctx_jump_counts(bt_ctx* ctx, uint64_t* lookups, uint64_t* steps);
+uint64_t bt_index_jump_bytes(const bt_index* idx);
 /* after bt_ctx_sync: mm_pool entries the last device-pointer batch used */
 uint32_t bt_ctx_last_mm_used(bt_ctx* ctx);
 /* reads of the last bt_align_batch that outgrew their search arenas and were re-run with worst-case

@@ -27,7 +27,7 @@
 unsigned long long g_l2_hit = 0, g_l2_miss = 0, g_l2_none = 0;
 extern "C" void emu_l2_stats(unsigned long long* o) { o[0] = g_l2_hit; o[1] = g_l2_miss; o[2] = g_l2_none; }
 #endif
-struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; std::vector<uint8_t> blk[2]; std::vector<BtU4> loc[2]; std::vector<uint32_t> rtxt[2]; std::vector<uint16_t> walk[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
+struct EmuIndex { BtIndexHost h[2]; BtIndexDev d[2]; std::vector<uint8_t> blk[2]; std::vector<BtU4> loc[2]; std::vector<uint32_t> rtxt[2]; std::vector<uint16_t> walk[2]; std::vector<uint32_t> jump[2]; std::vector<uint16_t> jumpMeta[2]; bool mirror; std::string base; BtRefHost ref; BtRefDev refd; bool haveRef = false; };
 
 static void bind(EmuIndex* e, int m)
 {
@@ -54,6 +54,23 @@ static void bind(EmuIndex* e, int m)
 		e->walk[m].assign((size_t)e->d[m].len + 1u, 0);
 		bt_loc_build_host(e->d[m], e->loc[m].data(), e->rtxt[m].data(), e->walk[m].data());
 		e->d[m].loc = e->loc[m].data(); e->d[m].rtxt = e->rtxt[m].data() + BT_RTXT_PAD_WORDS; e->d[m].walk = e->walk[m].data();
+	}
+	/* the jump table (bt_rank.h), as the GPU loader derives it -- for fewer characters, so that the host's copy stays small:
+	 * ftabChars + 2 of them (at most 12) for a genome of 32 K bases and more, EMU_JUMP_CHARS=<n> for any index (0: none) */
+	e->d[m].jump = nullptr; e->d[m].jumpMeta = nullptr; e->d[m].jumpChars = 0;
+	{
+		uint32_t K = e->d[m].len >= (1u << 15) ? (e->d[m].ftabChars + 2u > 12u ? 12u : e->d[m].ftabChars + 2u) : 0u;
+		if (const char* ev = getenv("EMU_JUMP_CHARS")) K = (uint32_t)atoi(ev);
+		if (K > e->d[m].ftabChars && K <= 13u && K - e->d[m].ftabChars <= 7u) {
+			const size_t n = (size_t)1 << (2u * K);
+			e->jump[m].assign(2u * n, 0u); e->jumpMeta[m].assign(n + 8u, 0);
+			for (size_t x = 0; x < n; x++) {
+				uint32_t top, bot, meta;
+				bt_jump_entry(e->d[m], (uint32_t)x, K, &top, &bot, &meta);
+				e->jump[m][2u * x] = top; e->jump[m][2u * x + 1u] = bot; e->jumpMeta[m][x] = (uint16_t)meta;
+			}
+			e->d[m].jump = e->jump[m].data(); e->d[m].jumpMeta = e->jumpMeta[m].data(); e->d[m].jumpChars = K;
+		}
 	}
 #endif
 }
@@ -175,6 +192,9 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		W.offMask[m] = e->d[m].offMask; W.ftab[m] = e->d[m].ftab; W.offs[m] = e->d[m].offs; W.offRate[m] = e->d[m].offRate;
 		W.ftabChars[m] = e->d[m].ftabChars; W.len[m] = e->d[m].len;
 		W.loc[m] = e->d[m].loc; W.rtxt[m] = e->d[m].rtxt; W.walk[m] = e->d[m].walk;
+#if !BT_WIDE
+		if (!(getenv("EMU_JUMP_OFF") && atoi(getenv("EMU_JUMP_OFF")))) { W.jump[m] = e->d[m].jump; W.jumpMeta[m] = e->d[m].jumpMeta; W.jumpChars[m] = e->d[m].jump ? e->d[m].jumpChars : 0u; }
+#endif
 		for (int k = 0; k < 5; k++) H.fchr[m][k] = e->d[m].fchr[k];
 #if BT_WIDE
 		H.segBase[m] = e->d[m].segBase; H.segShift = e->d[m].segShift; W.rowLim[m] = e->d[m].rowLim;
@@ -301,6 +321,8 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		}
 	}
 	out->mm_pool_used = mmUsed < out->mm_pool_cap ? mmUsed : out->mm_pool_cap;
+	if (getenv("BT_EMU_VERBOSE")) fprintf(stderr, "[emu] jump table: %llu look-ups, %llu two-row + %llu one-row steps behind them; ftab look-ups in all %llu\n",
+	                                      CNT[CN_JUMPS], CNT[CN_JLF2], CNT[CN_JLF1], CNT[CN_FTAB]);
 	if (counts) {
 		counts->lfex = CNT[CN_LFEX]; counts->lf2 = CNT[CN_LF2]; counts->lf1 = CNT[CN_LF1]; counts->chase = CNT[CN_CHASE];
 		counts->ftab = CNT[CN_FTAB]; counts->offs = CNT[CN_OFFS]; counts->rstarts = CNT[CN_RSTARTS];
@@ -310,6 +332,8 @@ static int emu_run(void* p, const bt_policy* pol, const bt_read_batch* in, bt_hi
 		counts->loc_lfex = CNT[CN_TLFEX]; counts->loc_lf1 = CNT[CN_TLF1]; counts->loc_chase = CNT[CN_TCHASE];
 		counts->loc_records = CNT[CN_LOCREC]; counts->loc_windows = CNT[CN_TXTWIN];
 		counts->lfex += CNT[CN_TLFEX]; counts->same_pair += CNT[CN_TLFEX]; counts->lf1 += CNT[CN_TLF1]; counts->chase += CNT[CN_TCHASE];
+		/* ... and so is what lies behind the jump table's look-ups */
+		counts->lf2 += CNT[CN_JLF2]; counts->lf1 += CNT[CN_JLF1]; counts->same_pair += CNT[CN_JSAME];
 	}
 	return BT_OK;
 }

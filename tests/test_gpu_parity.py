@@ -163,6 +163,51 @@ def test_gpu_vs_oracle_ragged(mode, gidx):
     T.check_op_counts(oc, gc)
 
 
+@pytest.mark.parametrize("chars", [9, 11, 13])
+def test_gpu_jump_table_results_and_op_counts(chars, monkeypatch):
+    """The jump table (bt_rank.h: the range behind a search's first 14 characters from one look-up where the phase may not
+    revisit them, instead of ftab's 10 and the steps behind it): indexes loaded with tables of 9, 11 and 13 characters
+    (BT_JUMP_CHARS; the test indexes' own ftabs have 7 and 6, and `multi` is too small to get a table by itself), ragged reads with Ns and low qualities and e_coli's 100-bp reads
+    in every phase-program mode -- the oracle's results, the oracle's op counts (the steps behind a look-up are tallied as the
+    reference takes them), look-ups actually made, and a context with BT_JUMP=0 beside it for the same answers."""
+    import ctypes as C
+    import oracle_lib as OL
+    monkeypatch.setenv("BT_JUMP_CHARS", str(chars))
+    idx = {n: AL.Index(os.path.join(T.G, n)) for n in ("e_coli", "multi")}
+    L = AL.lib()
+    L.bt_index_jump_bytes.restype = C.c_uint64
+    assert L.bt_index_jump_bytes(idx["multi"]._h) == 2 * 10 * 4 ** chars
+    text = T.joined_text("multi")
+    rng = np.random.default_rng(7)
+    reads = []
+    for i in range(1200):
+        ln = int(rng.integers(4, 113))
+        b = synth_reads(text, 1, ln, mm_dist=(0, 1, 2, 3), seed=5000 + i, n_frac=0.1, lowq_frac=0.1)
+        reads.append(Read(("j%d" % i).encode(), b.seq[0, :ln].copy(), b.qual[0, :ln].tobytes()))
+    ragged = pack_reads(reads)
+    eco = synth_reads(T.joined_text("e_coli"), 6000, 100, mm_dist=(0, 1, 2, 2, 3, 4), seed=77)
+    for mode in ("v0", "v1", "v2", "n2", "n3", "n2_k3", "n1_a_m20"):
+        kw = T.MODES[mode]
+        for name, batch in (("multi", ragged), ("e_coli", eco)):
+            oc, gc = OL.OpCounts(), A.OpCounts()
+            want = T.oracle_results(name, batch, kw, cap=T.hit_cap_for(kw), counts=oc)
+            al = AL.Aligner(idx[name], A.make_policy(**kw))
+            got = al.align(batch, hit_cap=T.hit_cap_for(kw), counts=gc)
+            T.compare_results(got, want, "jump table %d %s %s" % (chars, name, mode))
+            T.check_op_counts(oc, gc, "jump table %d %s %s" % (chars, name, mode))
+            lk, st = C.c_uint64(), C.c_uint64()
+            L.bt_ctx_jump_counts(al._h, C.byref(lk), C.byref(st))
+            assert lk.value > 0, (chars, name, mode)
+            if mode == "n2":
+                monkeypatch.setenv("BT_JUMP", "0")
+                off = AL.Aligner(idx[name], A.make_policy(**kw))
+                monkeypatch.delenv("BT_JUMP")
+                g0 = A.OpCounts()
+                T.compare_results(off.align(batch, hit_cap=T.hit_cap_for(kw), counts=g0), want, "no jump table %s" % name)
+                L.bt_ctx_jump_counts(off._h, C.byref(lk), C.byref(st))
+                assert lk.value == 0 and g0.lf2 == gc.lf2 and g0.lf1 == gc.lf1 and g0.ftab == gc.ftab and g0.lane_iters > gc.lane_iters
+
+
 @pytest.mark.parametrize("mode,length,n", [("v0", 36, 20000), ("v2", 76, 20000), ("n2", 100, 20000)])
 def test_gpu_vs_oracle_e_coli_synthetic(mode, length, n, gidx):
     kw = T.MODES[mode]
@@ -569,6 +614,25 @@ def test_gpu_best_first_arena_overflow_retry(gidx, monkeypatch):
     got = al.align(batch)
     assert al.last_retried > 0
     T.compare_results(got, T.oracle_results("multi", batch, kw), "n2_best tiny arenas")
+
+
+def test_gpu_best_first_with_fewer_arenas_than_lanes(gidx, monkeypatch, capfd):
+    """A best-first context takes at most 45 % of the device's free memory for its arenas and runs with fewer lanes when that is
+    not enough for one arena per lane (several contexts on one GPU: bowtie-amd --inflight, six test processes).  BT_FAKE_FREE_MB
+    pretends the device has 600 MB free: 45 % of that are arenas for 1 024 of the 4 096 lanes this batch could use; the
+    results are the oracle's all the same, and BT_VERBOSE says what was allocated."""
+    monkeypatch.setenv("BT_FAKE_FREE_MB", "600")
+    monkeypatch.setenv("BT_VERBOSE", "1")
+    batch = T.read_set("multi", "syn100")
+    for mode in ("n2_best", "v2_a_best_strata"):
+        kw = T.MODES[mode]
+        reads = type(batch)(np.tile(batch.seq, (7, 1)), np.tile(batch.qual, (7, 1)), np.tile(batch.len, 7), np.tile(batch.seed, 7), batch.names * 7)
+        al = aligner(gidx, "multi", kw)
+        got = al.align(reads, hit_cap=T.hit_cap_for(kw))
+        want = T.oracle_results("multi", batch, kw, cap=T.hit_cap_for(kw))
+        T.compare_results(got, want * 7, "fewer arenas " + mode)
+        err = capfd.readouterr().err
+        assert "arenas for 1024 lanes (4352 asked)" in err or "arenas for 1024 lanes" in err, err[-600:]
 
 
 def test_gpu_best_first_large_batch_properties(gidx):

@@ -224,14 +224,18 @@ def test_bulk_reader_is_the_same_whatever_the_fill_and_slice_sizes(tmp_path, see
         return p.stdout.decode().strip()
     want = run(spec, 1, 97, BT_IO_NO_RAW=1)
     assert want.startswith("error" if seed == 1 else "ok")
+    # (BT_IO_BULK_MIN: from how many whole records on the light parse lays them out in bulk, the threads a share each: 4096)
     for threads, batch, env in ((4, 97, {}), (4, 97, dict(BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64)), (3, 1000, dict(BT_IO_FILL_BYTES=1500, BT_IO_SLICE_BYTES=100)),
-                                (8, 5000, dict(BT_IO_FILL_BYTES=4096, BT_IO_SLICE_BYTES=16)), (4, 97, dict(BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64))):
+                                (8, 5000, dict(BT_IO_FILL_BYTES=4096, BT_IO_SLICE_BYTES=16)), (4, 97, dict(BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64)),
+                                (4, 97, dict(BT_IO_BULK_MIN=1)), (5, 97, dict(BT_IO_BULK_MIN=3, BT_IO_FILL_BYTES=700, BT_IO_SLICE_BYTES=64)),
+                                (8, 5000, dict(BT_IO_BULK_MIN=1, BT_IO_FILL_BYTES=100000)), (3, 333, dict(BT_IO_BULK_MIN=2, BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=2000))):
         got = run(spec, threads, batch, **env)
         if batch == 97 or want.startswith("ok"):
             assert got == want, (threads, batch, env)
         else:
             assert got.split(" ", 2)[2] == want.split(" ", 2)[2], (threads, batch, env)       # the same error, whatever the batch it falls into
     assert run(spec_gz, 4, 97, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64) == want
+    assert run(spec_gz, 4, 97, BT_IO_BULK_MIN=1) == want
 
 
 def test_file_ending_inside_a_record_follows_the_reference(tmp_path):
