@@ -603,6 +603,11 @@ def main():
             lib.bt_ctx_counts(o["al"]._h, C.byref(cnt), 0)
             for kk, v in cnt.as_dict().items():
                 c[kk] = c.get(kk, 0) + v
+            if hasattr(lib, "bt_ctx_jump_counts"):
+                lk, stp = C.c_uint64(), C.c_uint64()
+                lib.bt_ctx_jump_counts(o["al"]._h, C.byref(lk), C.byref(stp))
+                c["jump_lookups"] = c.get("jump_lookups", 0) + lk.value
+                c["jump_steps"] = c.get("jump_steps", 0) + stp.value
         return dict(wall=wall, c=c, kernel_ms=kernel_ms, flush_ms=flush_ms, last=last, pipes=pipes, carry_age=carry_age)
 
     log("[bench] %d x %d-bp reads in HBM in %.1fs" % (n, L, time.perf_counter() - t0))
@@ -733,6 +738,10 @@ def main():
                          "ops_per_read": {k: per_launch[k] / n for k in ("lfex", "lf2", "lf1", "chase", "frames", "rescans", "cand_scans", "fetches",
                                                                           "loc_lfex", "loc_lf1", "loc_chase", "loc_records", "loc_windows")},
                          "locus_mode": bool(lib.bt_ctx_get_locus(pipes[0]["al"]._h)),
+                         # the jump table (csrc/bt_rank.h): look-ups per read among the searches, and the LF steps of the reference's
+                         # algorithm that lay behind them (counted in ops_per_read's lf2 / lf1 all the same)
+                         "jump_table_GB": (lib.bt_index_jump_bytes(idx._h) / 1e9) if hasattr(lib, "bt_index_jump_bytes") else 0.0,
+                         "jump_lookups_per_read": per_launch.get("jump_lookups", 0) / n, "jump_steps_per_read": per_launch.get("jump_steps", 0) / n,
                          "locus_image_GB": lib.bt_index_locus_bytes(idx._h) / 1e9, "locus_image_build_s": lib.bt_index_locus_build_seconds(idx._h),
                          "lane_iters_per_read": per_launch["lane_iters"] / n,
                          "mean_active_lanes_per_round": per_launch["lane_iters"] / max(1.0, per_launch["wave_rounds"]),

@@ -80,6 +80,11 @@ def lib() -> C.CDLL:
         L.bt_ctx_get_locus.argtypes = [C.c_void_p]
         L.bt_index_locus_bytes.argtypes = [C.c_void_p]
         L.bt_index_locus_bytes.restype = C.c_uint64
+        if hasattr(L, "bt_index_jump_bytes"):          # (a library of an earlier round loaded with BT_LIB has none)
+            L.bt_index_jump_bytes.restype = C.c_uint64
+            L.bt_index_jump_bytes.argtypes = [C.c_void_p]
+            L.bt_ctx_jump_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            L.bt_ctx_jump_counts.restype = None
         L.bt_index_locus_build_seconds.argtypes = [C.c_void_p]
         L.bt_index_locus_build_seconds.restype = C.c_double
         L.bt_index_locus_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -541,7 +541,14 @@ static int ctx_init(bt_ctx* c, const bt_index* idx, const bt_policy* pol, void* 
 		}
 		/* blocks per CU = waves per SIMD the best-first kernel was compiled for (bt_best_kernels.hip, BT_BEST_MIN_BLOCKS);
 		 * BT_BEST_BLOCKS_PER_CU overrides it for A/B runs */
-		c->nLanes = c->cus * env_u32("BT_BEST_BLOCKS_PER_CU", bt_best_blocks_per_cu()) * BT_BLOCK;
+		{
+			/* which of the two kernels this context's launches will run (run_best_device): the call-by-call one for small
+			 * indexes and for PairedBWAlignerV1, the wavefront automaton otherwise */
+			const uint32_t nv = env_u32("BT_BEST_NESTED", 2u);
+			const bool small = (uint64_t)idx->dev[0].len < (512ull << 20);
+			const bool nested = pol->pe_v1 != 0 || (nv != 2u ? nv != 0u : small);
+			c->nLanes = c->cus * env_u32("BT_BEST_BLOCKS_PER_CU", bt_best_blocks_per_cu(nested ? 1 : 0)) * BT_BLOCK;
+		}
 	}
 	return BT_OK;
 }

@@ -28,12 +28,19 @@ __device__ unsigned long long bf_prof[3 * 32];      /* bt_best.h: cycles, passes
  * 6.78 M reads/s single-end / paired, 3 waves 5.15 / 12.26, 4 waves 5.94 / 13.22, 6 waves (80 registers, the rest
  * spilled to scratch, which is coalesced and cached) 6.20 / 13.90, 8 waves 5.62 / 14.16.  -DBT_BEST_MIN_BLOCKS=<n>
  * builds another (make bestsweep). */
-/* Default: four.  Six is a few per cent faster on e_coli, but every lane owns an arena (bt_api.cpp: 256 KB since the
- * hg19-scale measurement of profiles/r3/best_arena.txt), and four blocks per CU keep that at 67 GB per context. */
+/* Default: four for the call-by-call kernel.  Six is a few per cent faster on e_coli, but every lane owns an arena (bt_api.cpp:
+ * 256 KB since the hg19-scale measurement of profiles/r3/best_arena.txt), and four blocks per CU keep that at 67 GB per context.
+ * The wavefront automaton (the kernel of the indexes that do not fit the caches) runs THREE blocks per CU since round 6: with
+ * the leaf's state in LDS, 168 registers instead of 128 are worth more than the fourth wave (profiles/r6/call4_*: config 5's
+ * share 12.15 -> 12.43 M reads/s, --best single-end 2.39 -> 2.49 M), and its arenas are 51 GB instead of 67. */
 #ifndef BT_BEST_MIN_BLOCKS
 #define BT_BEST_MIN_BLOCKS 4
 #endif
+#ifndef BT_BEST_AUTO_BLOCKS
+#define BT_BEST_AUTO_BLOCKS 3
+#endif
 #define BT_BEST_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_MIN_BLOCKS)
+#define BT_BEST_AUTO_BOUNDS __launch_bounds__(BT_BLOCK, BT_BEST_AUTO_BLOCKS)
 #ifndef BT_BEST_LEAF_LDS
 /* 0: round 5's kernel, the leaf's state in scratch memory with the rest (A/B; and the build with 64-bit rows, whose leaf
  * record is 43 words: four blocks of those do not fit a CU's LDS) */
@@ -99,7 +106,7 @@ __global__ BT_BEST_BOUNDS void bt_best_nested_kernel(BtBestArgs A)
 
 /* the wavefront automaton (bt_best.h): one loop per wavefront, hot rounds for the lanes that extend a branch or walk the
  * suffix array, a cold sweep for the rest when enough of them wait for one; a lane takes its next read in the sweep */
-__global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
+__global__ BT_BEST_AUTO_BOUNDS void bt_best_kernel(BtBestArgs A)
 {
 	BT_BEST_PROLOGUE;
 	BfAuto S;
@@ -108,8 +115,8 @@ __global__ BT_BEST_BOUNDS void bt_best_kernel(BtBestArgs A)
 	/* the leaf's state in LDS (bt_best.h: BfAuto::leafp), 37 words per lane: with four blocks on a CU, 148 of its 160 KB */
 	__shared__ uint32_t LEAF[BT_BLOCK * BF_LEAF_STRIDE];
 	S.leafp = (BfLeafSt*)(LEAF + threadIdx.x * BF_LEAF_STRIDE);
-	/* (gfx950 hands LDS out in 1 280-byte granules, 128 to a CU: BT_BEST_MIN_BLOCKS blocks must fit) */
-	static_assert(sizeof(LEAF) + sizeof(BfProgram) + 2 * sizeof(BtIndexDev) + sizeof(BtBatchDev) + sizeof(BtRefDev) + 64 <= (128u / BT_BEST_MIN_BLOCKS) * 1280u,
+	/* (gfx950 hands LDS out in 1 280-byte granules, 128 to a CU: BT_BEST_AUTO_BLOCKS blocks must fit) */
+	static_assert(sizeof(LEAF) + sizeof(BfProgram) + 2 * sizeof(BtIndexDev) + sizeof(BtBatchDev) + sizeof(BtRefDev) + 64 <= (128u / BT_BEST_AUTO_BLOCKS) * 1280u,
 	              "the leaf states and the descriptors must fit the block's share of the CU's LDS");
 #else
 	BfLeafSt leafHere;
@@ -180,9 +187,9 @@ extern "C" int bt_best_prof_read(unsigned long long* out, int cap, int reset)
 }
 
 /* blocks per CU the kernel's register budget allows (= waves per SIMD: 256-lane blocks, 4 SIMDs) */
-extern "C" uint32_t bt_best_blocks_per_cu(void)
+extern "C" uint32_t bt_best_blocks_per_cu(int nested)
 {
-	return BT_BEST_MIN_BLOCKS;
+	return nested ? BT_BEST_MIN_BLOCKS : BT_BEST_AUTO_BLOCKS;
 }
 
 extern "C" int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream)

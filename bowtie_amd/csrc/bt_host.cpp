@@ -225,8 +225,9 @@ const char* const kExt[4] = {"bt2", "ebwt", "bt2l", "ebwtl"};
  * and its wrapper picks the 64-bit binary only when there is no small index (bowtie:52-81). */
 int bt_host_index_variant(const std::string& base)
 {
-	/* BT_INDEX_PREFER_LARGE (set by bowtie-amd --large-index): the 64-bit files first, as bowtie-align-l knows only them */
-	static const int plain[4] = {0, 1, 2, 3}, large[4] = {2, 3, 0, 1};
+	/* BT_INDEX_PREFER_LARGE (set by bowtie-amd --large-index): the 64-bit files ONLY, as bowtie-align-l -- the binary the
+	 * reference's wrapper then runs (bowtie:64-65) -- knows no others: a base that has only .ebwt / .bt2 files is "not found" */
+	static const int plain[4] = {0, 1, 2, 3}, large[4] = {2, 3, 2, 3};
 	const char* e = getenv("BT_INDEX_PREFER_LARGE");
 	const int* order = (e && *e && *e != '0') ? large : plain;
 	for (int k = 0; k < 4; k++) {

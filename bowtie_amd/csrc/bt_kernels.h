@@ -88,7 +88,7 @@ extern "C" {
 /* ids of the reads whose status has `flag` set -> list[0 .. *count) (order unspecified) */
 int bt_launch_collect_flagged(const uint8_t* status, uint32_t n, uint32_t flag, uint32_t* list, uint32_t* count, uint32_t cap, void* stream);
 int bt_launch_best(const BtBestArgs* a, uint32_t nBlocks, void* stream);
-uint32_t bt_best_blocks_per_cu(void);
+uint32_t bt_best_blocks_per_cu(int nested);      /* blocks per CU the call-by-call kernel (1) / the wavefront automaton (0) was built for */
 int bt_launch_jump_build(const BtIndexDev* ix, uint32_t K, uint32_t* jump, uint16_t* meta, void* stream);
 #define BT_RL_FORCE_EXT 0x100     /* or'ed into `rl`: launch the EXT instance whatever the arguments ask for (diagnostics) */
 int bt_launch_search(const BtKernelArgs* a, uint32_t nBlocks, int occ, int rl, void* stream);

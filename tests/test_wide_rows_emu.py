@@ -522,6 +522,13 @@ def test_large_index_option_takes_the_ebwtl_files(tmp_path):
             outs[tag] = hashlib.md5(p.stdout).hexdigest()
         assert outs["large"] == run["md5"], run["file"]
         assert outs["small"] != outs["large"]
+    # a base with no 64-bit files: bowtie-align-l -- what --large-index makes the reference's wrapper run -- does not find it
+    only_small = str(tmp_path / "small")
+    for ext in ("1", "2", "3", "4", "rev.1", "rev.2"):
+        shutil.copy(os.path.join(T.G, "multi." + ext + ".ebwt"), only_small + "." + ext + ".ebwt")
+    p = subprocess.run([binp, "-S", "--large-index", "-x", only_small, fq], env=dict(os.environ, LD_PRELOAD=E.wide_shim()),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"Could not locate a Bowtie index" in p.stderr, p.stderr.decode()
 
 
 def test_wide_loader_survives_damaged_index_files(tmp_path):
