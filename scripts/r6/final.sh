@@ -101,6 +101,12 @@ except Exception as e:
     print("   (no line: %s)" % e)
 PY
 cd $R
+# gpurun copies back at most 64 MiB: keep the stats, drop the raw traces and counter dumps
+for d in $O/trace_default $O/pmc_*/; do
+	[ -d "$d" ] || continue
+	find "$d" -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_default.csv \; 2>/dev/null
+	rm -rf "$d"
+done
 # ---- the binary ----
 BT_CLI_TIMELINE=0 timeout 900 python scripts/cli_bench.py --index big --reads 64000000 --no-ref --extra "--batch 8388608" > $O/cli_64m.json 2> $O/cli_64m.err
 python - "$O/cli_64m.json" >> $S <<'PY'
