@@ -688,9 +688,13 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 		const bool small = (uint64_t)c->idx->dev[0].len < (512ull << 20);
 		A.nested = (in2 && c->pol.pe_v1) || (nv != 2u ? nv != 0u : small) ? 1u : 0u;
 	}
-	/* the gates' defaults: scripts/best_wave_model.py's pick, then the GPU A/B of profiles/r4/ */
-	A.coldMin = ctx_env(c, "BT_BEST_COLD_MIN", 16); A.takeMin = ctx_env(c, "BT_BEST_TAKE_MIN", 16);
-	A.sendPeriod = ctx_env(c, "BT_BEST_SEND_PERIOD", 4); A.sendMin = ctx_env(c, "BT_BEST_SEND_MIN", 24);
+	/* the gates' defaults: scripts/best_wave_model.py's pick, then the GPU A/B of profiles/r4/; set again in round 6 for three
+	 * blocks per CU with the leaf in LDS (profiles/r6/call6_*, call7_*: a sweep of each gate at hg19 scale).  Pairs want their
+	 * cold sweeps rarer -- a pair's cold work (the driver's advance between two leaves, the mate's window scan) is long, and a
+	 * sweep for 16 lanes keeps 48 hot ones waiting: 32 is +7 % -- single reads do not (-9 %); both want streaks' ends gathered
+	 * longer (every 8th round or 40 lanes) */
+	A.coldMin = ctx_env(c, "BT_BEST_COLD_MIN", in2 ? 32u : 16u); A.takeMin = ctx_env(c, "BT_BEST_TAKE_MIN", 16);
+	A.sendPeriod = ctx_env(c, "BT_BEST_SEND_PERIOD", 8); A.sendMin = ctx_env(c, "BT_BEST_SEND_MIN", 40);
 	A.sweepTwice = ctx_env(c, "BT_BEST_SWEEP_TWICE", 0);
 	/* per-launch HIP events, as on the phase-program path (bt_ctx_span_ms / bt_ctx_launch_ms) */
 	if (!c->spanOpen) { HIPCHK(hipEventRecord(c->evSpan, c->stream)); c->spanOpen = true; c->spanLaunches = 0; c->flushTimed = false; }

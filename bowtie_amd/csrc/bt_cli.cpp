@@ -58,8 +58,12 @@ struct Options {
 	/* reads per batch = per launch.  With carry-over a read may ride along for twelve launches; the heaviest reads need
 	 * ~5 s of them, so a launch must last long enough: at 4 M reads (0.34 s) every launch ended up waiting for the stragglers
 	 * of the batch twelve launches back -- 3.8 M reads/s GPU-side on 192 M reads, 5.3 M file to file at 8 M, 5.6 M at 16 M
-	 * (where parsing bounds it: profiles/r5/call12_cli_batch_SUMMARY.txt).  8 M keeps a batch at ~2.4 GB of host memory. */
+	 * (where parsing bounds it: profiles/r5/call12_cli_batch_SUMMARY.txt).  8 M keeps a batch at ~2.4 GB of host memory.
+	 * Round 6 (the reader no longer bounds anything): 192 M reads in 28.8-30.0 s at 8 M, 25.5 s at 12 M, 27.1 s at 16 M per batch
+	 * (profiles/r6/call6_*) -- a streamed run on a host with the memory for it (thirteen batches in flight: 45 GB) takes 12 M
+	 * unless --batch says otherwise */
 	uint32_t batch_reads = 8u << 20;
+	bool batch_set = false;
 	std::string cmdline;
 };
 
@@ -408,7 +412,7 @@ void parse_args(int argc, char** argv, Options* O)
 			if (O->devices.empty()) die("Error: bad --device list: %s", val);
 			break;
 		}
-		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); break;
+		case O_BATCH: O->batch_reads = (uint32_t)parse_int(val, 1, "--batch arg must be at least 1"); O->batch_set = true; break;
 		case O_NOSTREAM: O->no_stream = true; break;
 		case O_STREAM: O->stream = true; break;
 		case O_INFLIGHT: O->inflight = (int)parse_int(val, 1, "--inflight arg must be at least 1"); if (O->inflight > 4) O->inflight = 4; break;
@@ -919,6 +923,11 @@ int main(int argc, char** argv)
 	struct ResultBufs { std::vector<bt_hit> hits; std::vector<uint32_t> n_hits; std::vector<uint8_t> status; std::vector<uint16_t> mm_pool; };
 	Chan<std::unique_ptr<ResultBufs>> spare_res(8);
 	const bool will_stream = !O.paired && !O.pol.best && !O.no_stream;      /* what `streamed` below says once the index is there */
+	if (will_stream && !O.batch_set) {
+		/* (see Options::batch_reads) */
+		const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+		if (pages > 0 && psz > 0 && (double)pages * (double)psz >= 256e9) O.batch_reads = 12u << 20;
+	}
 	/* one batch from the input into a job: returns BT_OK or the error it left in j->error */
 	auto read_job = [&](Job* j) -> int {
 		if (!spare.try_take(&j->store)) j->store.reset(new BtHostBatch());
