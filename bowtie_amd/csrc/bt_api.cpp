@@ -611,7 +611,9 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	 * 16 K and 64 K words -- reads with hundreds of seed extenders, the slow ones -- and whatever outgrows its arena
 	 * lands in the second pass below, which has a thousand lanes instead of a quarter of a million: with 16 K-word
 	 * arenas that pass took minutes per million reads (profiles/r3/best_arena.txt) */
-	const uint32_t words = c->is_big ? (1u << 22) : ctx_env(c, "BT_BEST_ARENA_WORDS", 65536u);
+	/* (pairs: 32 K words.  Their searches are short -- 50-bp mates, -n 1 -- and half the arena is +4.5 % on config 5's share
+	 * (profiles/r6/call7_*: the second pass takes the few more pairs that outgrow it); single-end -n 2 --best loses 18 % to it) */
+	const uint32_t words = c->is_big ? (1u << 22) : ctx_env(c, "BT_BEST_ARENA_WORDS", in2 ? 32768u : 65536u);
 	/* one arena per lane that the launch can use: a small batch does not fill the grid, and 64 KB x 393 216 lanes
 	 * (six blocks per CU) are 26 GB that a thousand-read batch has no use for */
 	uint32_t lanes = c->is_big ? (c->nLanes > 256u ? 256u : c->nLanes) : c->nLanes;
@@ -691,9 +693,10 @@ static int run_best_device(bt_ctx* c, const bt_read_batch* in, bt_hit_batch* out
 	/* the gates' defaults: scripts/best_wave_model.py's pick, then the GPU A/B of profiles/r4/; set again in round 6 for three
 	 * blocks per CU with the leaf in LDS (profiles/r6/call6_*, call7_*: a sweep of each gate at hg19 scale).  Pairs want their
 	 * cold sweeps rarer -- a pair's cold work (the driver's advance between two leaves, the mate's window scan) is long, and a
-	 * sweep for 16 lanes keeps 48 hot ones waiting: 32 is +7 % -- single reads do not (-9 %); both want streaks' ends gathered
+	 * sweep for 16 lanes keeps 48 hot ones waiting: 32 is +7 %, 40-48 another 1 % -- single reads do not (-9 %); pairs take
+	 * their next read when 24 lanes wait for one (+2.4 %), single reads when 8 do (+4 %); both want streaks' ends gathered
 	 * longer (every 8th round or 40 lanes) */
-	A.coldMin = ctx_env(c, "BT_BEST_COLD_MIN", in2 ? 32u : 16u); A.takeMin = ctx_env(c, "BT_BEST_TAKE_MIN", 16);
+	A.coldMin = ctx_env(c, "BT_BEST_COLD_MIN", in2 ? 40u : 16u); A.takeMin = ctx_env(c, "BT_BEST_TAKE_MIN", in2 ? 24u : 8u);
 	A.sendPeriod = ctx_env(c, "BT_BEST_SEND_PERIOD", 8); A.sendMin = ctx_env(c, "BT_BEST_SEND_MIN", 40);
 	A.sweepTwice = ctx_env(c, "BT_BEST_SWEEP_TWICE", 0);
 	/* per-launch HIP events, as on the phase-program path (bt_ctx_span_ms / bt_ctx_launch_ms) */
