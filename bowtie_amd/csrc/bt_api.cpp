@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/bowtie_amd.h"
 #include "bt_host.h"
@@ -1146,12 +1147,24 @@ static int check_mm_pool(const bt_hit_batch* out, uint32_t n, uint32_t cursor, b
 	uint64_t sum = 0, outside = 0; bool mmpool = false;
 	const size_t slots = (size_t)n * out->hit_cap;
 	for (uint32_t i = 0; i < n; i++) mmpool |= (out->status[i] & BT_STF_MMPOOL) != 0;
-	for (size_t k = 0; k < slots; k++) {
-		const bt_hit& h = out->hits[k];
-		if (!h.nmm) continue;
-		sum += h.nmm;
-		if ((uint64_t)h.mm_off + h.nmm > used) outside++;
-	}
+	auto scan = [&](size_t lo, size_t hi, uint64_t* s, uint64_t* o) {
+		uint64_t ss = 0, oo = 0;
+		for (size_t k = lo; k < hi; k++) {
+			const bt_hit& h = out->hits[k];
+			if (!h.nmm) continue;
+			ss += h.nmm;
+			if ((uint64_t)h.mm_off + h.nmm > used) oo++;
+		}
+		*s = ss; *o = oo;
+	};
+	if (slots >= ((size_t)1u << 22)) {
+		/* a batch of millions of reads: the pass over its hit records is on the thread that feeds the GPU */
+		constexpr int T = 8;
+		uint64_t ps[T], po[T];
+		std::thread th[T];
+		for (int t = 0; t < T; t++) th[t] = std::thread(scan, slots * (size_t)t / T, slots * (size_t)(t + 1) / T, &ps[t], &po[t]);
+		for (int t = 0; t < T; t++) { th[t].join(); sum += ps[t]; outside += po[t]; }
+	} else scan(0, slots, &sum, &outside);
 	bool bad = outside != 0 || (exact && !mmpool && sum != cursor) || (!exact && sum > cursor);
 	uint64_t overlaps = 0;
 	static const bool checkAll = getenv("BT_CHECK") && atoi(getenv("BT_CHECK")) != 0;

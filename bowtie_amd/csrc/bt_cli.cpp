@@ -33,9 +33,119 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 
+#include <new>
+#include <unordered_set>
+#include <sys/mman.h>
+
 #include "bt_io.h"
 
+/* ---- where the large blocks come from ---------------------------------------------------------------------------------
+ * A run over 192 M reads has thirteen batches of 12 M reads in flight: 65 GB of parsed reads, names, result arrays and SAM
+ * text, nearly all of it touched once.  Out of the C library's allocator that is 16 M page faults on the parser's and the
+ * formatter's threads, a third of a second of munmap() whenever a batch is let go, and seconds of the same inside exit().
+ * Blocks of 4 MB and more are therefore mapped here, aligned to 2 MB and marked for transparent huge pages (a fault and an
+ * unmap per 2 MB instead of per 4 KB; where the host has them switched off the mapping is an ordinary one).
+ * BT_CLI_HUGEPAGES=0: everything from malloc() as before.  These replace the global operator new / delete of the program
+ * (the library's C++ allocations included; its malloc()s are not touched). */
+namespace bigmem {
+constexpr size_t kHuge = (size_t)2u << 20, kMin = (size_t)4u << 20, kHdr = 64;
+constexpr uint64_t kMagic0 = 0x62742d616d642d62ull, kMagic1 = 0x69672d626c6f636bull;
+struct Hdr { uint64_t m0, base, len, m1; };
+static int g_on = -1;
+static size_t g_min = kMin;
+/* (BT_CLI_BIG_MIN, bytes: the tests' way of putting small runs through these blocks) */
+static bool on()
+{
+	if (g_on < 0) {
+		const char* m = getenv("BT_CLI_BIG_MIN");
+		if (m && atol(m) >= 4096) g_min = (size_t)atol(m);
+		const char* e = getenv("BT_CLI_HUGEPAGES");
+		g_on = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+	}
+	return g_on == 1;
+}
+static void* map_block(size_t n)
+{
+	const size_t use = (n + kHdr + kHuge - 1) & ~(kHuge - 1), len = use + kHuge;
+	if (use < n) return nullptr;
+	void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (m == MAP_FAILED) return nullptr;
+	const uintptr_t lo = (uintptr_t)m, a = (lo + kHuge - 1) & ~(uintptr_t)(kHuge - 1), end = lo + len;
+	if (a > lo) munmap(m, a - lo);
+	if (end > a + use) munmap((void*)(a + use), end - (a + use));
+#ifdef MADV_HUGEPAGE
+	(void)madvise((void*)a, use, MADV_HUGEPAGE);
+#endif
+	Hdr* h = (Hdr*)a;
+	h->m0 = kMagic0; h->base = (uint64_t)a; h->len = (uint64_t)use; h->m1 = kMagic1;
+	return (void*)(a + kHdr);
+}
+/* true: p was one of ours and is gone.  A pointer that sits 64 bytes past a 2 MB boundary and is not ours came from
+ * malloc(): the 64 bytes before it are heap, readable, and do not hold both magic words and their own address. */
+static bool unmap_block(void* p)
+{
+	if (((uintptr_t)p & (kHuge - 1)) != kHdr) return false;
+	Hdr* h = (Hdr*)((uintptr_t)p - kHdr);
+	if (h->m0 != kMagic0 || h->m1 != kMagic1 || h->base != (uint64_t)(uintptr_t)h) return false;
+	munmap((void*)h, (size_t)h->len);
+	return true;
+}
+}  /* namespace bigmem */
+
+void* operator new(size_t n)
+{
+	if (n >= 4096 && bigmem::on() && n >= bigmem::g_min) { void* p = bigmem::map_block(n); if (p) return p; }
+	for (;;) {
+		void* p = malloc(n ? n : 1);
+		if (p) return p;
+		std::new_handler h = std::get_new_handler();
+		if (!h) throw std::bad_alloc();
+		h();
+	}
+}
+void operator delete(void* p) noexcept { if (p && !bigmem::unmap_block(p)) free(p); }
+void operator delete(void* p, size_t) noexcept { if (p && !bigmem::unmap_block(p)) free(p); }
+
 namespace {
+
+/* read batches (bt_io_set_allocator): the same blocks */
+void* big_alloc(size_t bytes) { try { return ::operator new(bytes); } catch (...) { return nullptr; } }
+void big_free(void* p) { ::operator delete(p); }
+
+/* A batch's result arrays live in page-locked memory from the library (bt_host_alloc): the copies back from the device are
+ * DMAs at the link's rate then, not the runtime's staged copies into pageable memory -- 0.19 s per batch of 12 M reads, and
+ * two seconds at the end of a run, when the eleven batches still in flight come back at once.  BT_CLI_PINNED_RESULTS=0:
+ * pageable memory as before.  Small arrays (tests, the last batch of a file) are not worth a page-locking call. */
+int g_pin_results = -1;
+std::mutex g_pin_m;
+std::unordered_set<void*> g_pinned;
+template <typename T> struct PinAlloc {
+	using value_type = T;
+	PinAlloc() = default;
+	template <typename U> PinAlloc(const PinAlloc<U>&) {}
+	T* allocate(size_t n)
+	{
+		const size_t bytes = n * sizeof(T);
+		if (g_pin_results < 0) { const char* e = getenv("BT_CLI_PINNED_RESULTS"); g_pin_results = e ? (atoi(e) != 0 ? 1 : 0) : 1; }
+		if (g_pin_results == 1 && bytes >= ((size_t)1u << 20)) {
+			void* p = bt_host_alloc(bytes);
+			if (p) { std::lock_guard<std::mutex> l(g_pin_m); g_pinned.insert(p); return (T*)p; }
+		}
+		return (T*)::operator new(bytes);
+	}
+	void deallocate(T* p, size_t)
+	{
+		{
+			std::unique_lock<std::mutex> l(g_pin_m);
+			auto it = g_pinned.find((void*)p);
+			if (it != g_pinned.end()) { g_pinned.erase(it); l.unlock(); bt_host_free((void*)p); return; }
+		}
+		::operator delete((void*)p);
+	}
+	template <typename U> bool operator==(const PinAlloc<U>&) const { return true; }
+	template <typename U> bool operator!=(const PinAlloc<U>&) const { return false; }
+};
+template <typename T> using PinVec = std::vector<T, PinAlloc<T>>;
 
 struct Options {
 	bt_policy pol;
@@ -582,10 +692,10 @@ struct Job {
 	bt_read_batch rb2;                       /* paired-end: the second mates */
 	std::unique_ptr<BtHostBatch> store2;
 	uint32_t hit_cap = 1;
-	std::vector<bt_hit> hits;
-	std::vector<uint32_t> n_hits;
-	std::vector<uint8_t> status;
-	std::vector<uint16_t> mm_pool;
+	PinVec<bt_hit> hits;
+	PinVec<uint32_t> n_hits;
+	PinVec<uint8_t> status;
+	PinVec<uint16_t> mm_pool;
 	uint32_t mm_used = 0;
 	bool prepared = false;                   /* search_prepare has sized the four arrays for this batch */
 	bt_hit_batch hb;                         /* view into the four arrays above (what the search fills) */
@@ -901,6 +1011,7 @@ int main(int argc, char** argv)
 	/* BT_CLI_PINNED=1: read batches live in page-locked memory from the library, so that bt_align_stream_submit's uploads
 	 * are DMAs beside the running search (not the default until it has been measured on the GPU) */
 	if (getenv("BT_CLI_PINNED") && atoi(getenv("BT_CLI_PINNED")) != 0) bt_io_set_allocator(bt_host_alloc, bt_host_free);          /* see `pinned` below */
+	else if (bigmem::on()) bt_io_set_allocator(big_alloc, big_free);
 	open_read_streams(O, &rs, &rs2);
 	const bool tabbed = O.rd.format == BT_FMT_TABBED;
 	const bool dumping = !O.dump_al.empty() || !O.dump_un.empty() || !O.dump_max.empty();
@@ -920,8 +1031,31 @@ int main(int argc, char** argv)
 	std::atomic<bool> abort_run(false);
 	Chan<std::unique_ptr<BtHostBatch>> spare(8);              /* read batches on their way back to the reader */
 	/* ... and result arrays: a batch's four arrays (some 150 MB for 4 M reads) keep their memory from batch to batch */
-	struct ResultBufs { std::vector<bt_hit> hits; std::vector<uint32_t> n_hits; std::vector<uint8_t> status; std::vector<uint16_t> mm_pool; };
+	struct ResultBufs { PinVec<bt_hit> hits; PinVec<uint32_t> n_hits; PinVec<uint8_t> status; PinVec<uint16_t> mm_pool; };
 	Chan<std::unique_ptr<ResultBufs>> spare_res(8);
+	/* What neither channel has room for is let go on a thread of its own: unmapping a batch's 5 GB took the writer a third of
+	 * a second per batch at the end of a run, where it is the only stage still working (round 6's timeline).  Once the input is
+	 * exhausted nothing is kept back for the reader any more. */
+	struct Trash { std::unique_ptr<Job> j; std::unique_ptr<ResultBufs> r; std::unique_ptr<BtHostBatch> s; };
+	Chan<std::unique_ptr<Trash>> to_reap(64);
+	std::atomic<bool> input_done(false);
+	auto reap = [&] {
+		for (;;) {
+			std::unique_ptr<Trash> t = to_reap.take();
+			if (!t) return;
+			t.reset();
+			if (input_done.load()) {
+				std::unique_ptr<BtHostBatch> b; std::unique_ptr<ResultBufs> r;
+				while (spare.try_take(&b)) b.reset();
+				while (spare_res.try_take(&r)) r.reset();
+			}
+		}
+	};
+	auto let_go = [&](std::unique_ptr<Job>& j, std::unique_ptr<ResultBufs>& r, std::unique_ptr<BtHostBatch>& st) {
+		std::unique_ptr<Trash> t(new Trash());
+		t->j = std::move(j); t->r = std::move(r); t->s = std::move(st);
+		to_reap.put(std::move(t));
+	};
 	const bool will_stream = !O.paired && !O.pol.best && !O.no_stream;      /* what `streamed` below says once the index is there */
 	if (will_stream && !O.batch_set) {
 		/* (see Options::batch_reads) */
@@ -1114,6 +1248,9 @@ int main(int argc, char** argv)
 			if (cage > 12) cage = 12;                         /* the searcher keeps at most 13 batches in flight: the oldest must be able to complete */
 			if (cage < 1) cage = 1;
 			if (n_streams > 1) fl_lim = (size_t)cage + 2u;      /* (one context: round 5's thirteen) */
+			/* BT_CLI_INFLIGHT (diagnostics): at cage + 1 the batch behind the oldest one's last launch is submitted only when
+			 * that launch has ended; at cage + 2 (the library's limit is 14) it is enqueued behind it */
+			if (const char* fv = getenv("BT_CLI_INFLIGHT")) { const int v = atoi(fv); if (v >= 2 && v <= 14) fl_lim = (size_t)v; }
 			if (bt_ctx_set_carry(ctxs[g], cage) != BT_OK) die("Error: bt_ctx_set_carry failed");
 			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
@@ -1142,6 +1279,7 @@ int main(int argc, char** argv)
 	 * --al/--un dumps -- lets batches of gigabytes pile up on the host without bound (round 4 had G + 64) */
 	Chan<std::unique_ptr<Job>> to_gpu(2), to_out((size_t)G + 8);
 	std::vector<double> busy_gpu((size_t)G, 0.0);
+	std::thread reaper(reap);
 	std::thread reader([&] {
 		uint64_t seq = 0;
 		for (;;) {
@@ -1153,6 +1291,7 @@ int main(int argc, char** argv)
 			if (r != BT_OK || (j->rb.n_reads == 0 && !j->unp)) {
 				/* the end (or an input error, reported in its place in the order): one marker per searcher */
 				j->last = true;
+				input_done.store(true);
 				const uint64_t sq = j->seq;
 				to_gpu.put(std::move(j));
 				for (int g = 1; g < G; g++) { std::unique_ptr<Job> e(new Job()); e->last = true; e->seq = sq + (uint64_t)g; to_gpu.put(std::move(e)); }
@@ -1261,7 +1400,12 @@ int main(int argc, char** argv)
 				fwrite(text.data(), 1, text.size(), fout);
 				busy_write += now_s() - tb;
 				j->wide.clear();
-				spare.try_put(j->store);
+				{
+					std::unique_ptr<ResultBufs> none;
+					std::unique_ptr<BtHostBatch> st = std::move(j->store);
+					if (!input_done.load() && spare.try_put(st)) st.reset();
+					let_go(j, none, st);
+				}
 				continue;
 			}
 			const uint32_t n = j->rb.n_reads;
@@ -1406,12 +1550,18 @@ int main(int argc, char** argv)
 			busy_write += now_s() - tb;
 			g_tl.mark("write: done", j->seq);
 			j->wide.clear();
-			if (will_stream) {
-				std::unique_ptr<ResultBufs> rbuf(new ResultBufs());
-				rbuf->hits.swap(j->hits); rbuf->n_hits.swap(j->n_hits); rbuf->status.swap(j->status); rbuf->mm_pool.swap(j->mm_pool);
-				spare_res.try_put(rbuf);
+			{
+				const bool keep = !input_done.load();
+				std::unique_ptr<ResultBufs> rbuf;
+				if (will_stream && keep) {
+					rbuf.reset(new ResultBufs());
+					rbuf->hits.swap(j->hits); rbuf->n_hits.swap(j->n_hits); rbuf->status.swap(j->status); rbuf->mm_pool.swap(j->mm_pool);
+					if (spare_res.try_put(rbuf)) rbuf.reset();
+				}
+				std::unique_ptr<BtHostBatch> st = std::move(j->store);
+				if (keep && spare.try_put(st)) st.reset();
+				let_go(j, rbuf, st);
 			}
-			spare.try_put(j->store);
 		}
 	});
 
@@ -1522,6 +1672,7 @@ int main(int argc, char** argv)
 	for (auto& x : searchers) x.join();
 	reader.join();
 	writer.join();
+	to_reap.put(std::unique_ptr<Trash>());
 	if (O.timing) {
 		print_timer("Time searching: ", now_s() - t_search);
 		double bg = 0; for (double v : busy_gpu) bg += v;
@@ -1545,6 +1696,8 @@ int main(int argc, char** argv)
 	g_tl.mark("teardown: contexts destroyed", 0);
 	for (bt_index* x : idxs) bt_index_free(x);
 	g_tl.mark("teardown: index freed", 0);
+	reaper.join();
+	g_tl.mark("teardown: the last batches' memory let go", 0);
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }
 	if (O.timing) print_timer("Overall time: ", now_s() - t_all);

@@ -69,3 +69,10 @@ def test_formatter_pieces_reach_the_file_in_order(shim, tmp_path):
             assert p.returncode == 0, p.stderr.decode(errors="replace")
             outs.append(b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")))
         assert len(outs[0]) > n * L and outs[0] == outs[1] == outs[2]
+        # where the large blocks come from (bt_cli.cpp `bigmem`, the page-locked result arrays) changes no byte of the text:
+        # everything from 64 KB up out of the mapped blocks, and nothing at all
+        for knobs in (dict(BT_CLI_BIG_MIN="65536"), dict(BT_CLI_HUGEPAGES="0", BT_CLI_PINNED_RESULTS="0")):
+            p = subprocess.run([binary, "-p", "3", "--batch", "9000"] + fmt + ["-x", base, str(fq)], env=dict(env, **knobs),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert p.returncode == 0, p.stderr.decode(errors="replace")
+            assert b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")) == outs[0], knobs
