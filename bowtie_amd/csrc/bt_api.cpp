@@ -80,8 +80,8 @@ struct bt_ctx {
 	uint32_t carryAge = 1;                 /* launches a read may be carried through (bt_ctx_set_carry) */
 	int carryRl = 0; uint32_t carryBlocks = 0;   /* build and grid of the launches whose lanes the records belong to */
 	BtPoolRec* pool = nullptr;             /* [nLanes]: lane g's parked read */
-	uint32_t launchSeq = 1;                /* number of the next carry launch; its batch sits in ring[launchSeq % 16] */
-	uint32_t* d_carry = nullptr;           /* [0..15] reads parked by the last launch per ring slot, [16..31] the ring batches' mismatch-pool cursors */
+	uint32_t launchSeq = 1;                /* number of the next carry launch; its batch sits in ring[launchSeq % BT_BATCH_RING] */
+	uint32_t* d_carry = nullptr;           /* [0..RING) reads parked by the last launch per ring slot, [RING..2 RING) the ring batches' mismatch-pool cursors */
 	BatchView ring[BT_BATCH_RING]; bool ringRetry[BT_BATCH_RING] = {}; uint32_t ringMaxLen[BT_BATCH_RING] = {};
 	uint32_t* hostParked = nullptr;        /* pinned [16 launches][16 ring slots]: parkedOf after each launch */
 	hipEvent_t evLaunch[BT_BATCH_RING] = {};
@@ -291,7 +291,7 @@ static uint32_t ctx_env(bt_ctx* c, const char* name, uint32_t dflt)
  * wrong mismatch entries, round 3's one-off symptom.  The source is now a slot of page-locked memory that
  * belongs to the context and is not written again before the copy that reads it is done. */
 #define BT_HSTAGE_SLOTS 64
-#define BT_HSTAGE_SLOT_BYTES 4096
+#define BT_HSTAGE_SLOT_BYTES 16384
 static_assert(sizeof(BtCold) <= BT_HSTAGE_SLOT_BYTES && sizeof(BtWarm) <= BT_HSTAGE_SLOT_BYTES && sizeof(BtBatchDev) <= BT_HSTAGE_SLOT_BYTES, "a descriptor fits a staging slot");
 static int ctx_h2d(bt_ctx* c, void* dst, const void* src, size_t bytes)
 {
@@ -422,8 +422,8 @@ static int ctx_ensure_scratch(bt_ctx* c, uint32_t maxLen, bool carry)
 	if (carry && !c->pool) {
 		HIPCHK(hipMalloc((void**)&c->pool, (size_t)c->nLanes * sizeof(BtPoolRec)));
 		HIPCHK(hipMemsetAsync(c->pool, 0, (size_t)c->nLanes * sizeof(BtPoolRec), c->stream));      /* (on the context's stream: see ctx_init) */
-		HIPCHK(hipMalloc((void**)&c->d_carry, 32 * 4));
-		HIPCHK(hipMemsetAsync(c->d_carry, 0, 32 * 4, c->stream));
+		HIPCHK(hipMalloc((void**)&c->d_carry, 2 * BT_BATCH_RING * 4));
+		HIPCHK(hipMemsetAsync(c->d_carry, 0, 2 * BT_BATCH_RING * 4, c->stream));
 		HIPCHK(hipHostMalloc((void**)&c->hostParked, BT_BATCH_RING * BT_BATCH_RING * 4));
 		memset(c->hostParked, 0, BT_BATCH_RING * BT_BATCH_RING * 4);
 		for (int i = 0; i < BT_BATCH_RING; i++) HIPCHK(hipEventCreateWithFlags(&c->evLaunch[i], hipEventDisableTiming));
@@ -1719,7 +1719,8 @@ extern "C" int bt_align_stream_tick(bt_ctx* c, uint32_t min_rounds)
 	if (!c->carryPending || !c->pool) return BT_OK;              /* nothing is parked */
 	HIPCHK(hipSetDevice(c->idx->device));
 	/* the launch of ctx_flush_carry, except that it parks again: same grid, no fresh reads, a ring slot of its own whose
-	 * batch is empty (a slot is reused sixteen launches later; what used it has been complete for four by then) */
+	 * batch is empty (a slot is reused BT_BATCH_RING launches later; what used it has been complete for two at least by then:
+	 * nothing is carried through more than BT_BATCH_RING - 2 launches) */
 	BtKernelArgs A;
 	memset(&A, 0, sizeof(A));
 	BtWarm warm;

@@ -1071,10 +1071,14 @@ int main(int argc, char** argv)
 		to_reap.put(std::move(t));
 	};
 	const bool will_stream = !O.paired && !O.pol.best && !O.no_stream;      /* what `streamed` below says once the index is there */
+	bool big_host = false;                                     /* 256 GB of memory and more */
+	{
+		const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+		big_host = pages > 0 && psz > 0 && (double)pages * (double)psz >= 256e9;
+	}
 	if (will_stream && !O.batch_set) {
 		/* (see Options::batch_reads) */
-		const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
-		if (pages > 0 && psz > 0 && (double)pages * (double)psz >= 256e9) O.batch_reads = 12u << 20;
+		if (big_host) O.batch_reads = 12u << 20;
 	}
 	/* one batch from the input into a job: returns BT_OK or the error it left in j->error */
 	auto read_job = [&](Job* j) -> int {
@@ -1249,6 +1253,7 @@ int main(int argc, char** argv)
 	if (!O.maxbts_set) OU.pol.max_bts = 800;
 	std::vector<bt_ctx*> unp_ctxs(O.rd.format == BT_FMT_TABBED && O.paired ? ctxs.size() : 0, nullptr);
 	size_t fl_lim = 13;                                       /* batches a streamed searcher keeps in flight */
+	int n_ticks = 14;                                         /* at the end of the input: as many as a read may ride along, and two */
 	for (size_t g = 0; g < ctxs.size(); g++) {
 		rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &ctxs[g]);
 		if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
@@ -1257,14 +1262,22 @@ int main(int argc, char** argv)
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
 		}
 		if (streamed) {
-			const char* cv = getenv("BT_CLI_CARRY");          /* diagnostics: launches a read may ride along (0 = none) */
-			int cage = cv && *cv ? atoi(cv) : 12 / n_streams;  /* (a context sees every n-th batch: the same time to ride along) */
-			if (cage > 12) cage = 12;                         /* the searcher keeps at most 13 batches in flight: the oldest must be able to complete */
+			/* How long a read may ride along, and how many batches are in flight for it.  A batch is complete when its hardest
+			 * read is: at 12 M reads per batch that is fourteen or fifteen launches later (some ten seconds of sharing a
+			 * wavefront with 63 others).  With twelve launches to ride (the library's limit until round 6: a ring of 16 batches)
+			 * every launch from the thirteenth on closed with ~0.5 s of the machine waiting for the batch twelve back
+			 * (profiles/r6/call9_cli_192m_timeline.txt).  On a host with the memory for it (a batch in flight is 5 GB there, and
+			 * 2.2 GB of HBM) reads ride up to 22 launches and 24 batches may be in flight -- few runs get there: batches leave
+			 * as they complete; elsewhere round 5's 12 and 13.  BT_CLI_CARRY / BT_CLI_INFLIGHT set them (diagnostics). */
+			const char* cv = getenv("BT_CLI_CARRY");
+			int cage = cv && *cv ? atoi(cv) : (big_host && n_streams == 1 ? 22 : 12 / n_streams);  /* (of n contexts each sees every n-th batch: the same time to ride along) */
+			if (cage > 60) cage = 60;
 			if (cage < 1) cage = 1;
-			if (n_streams > 1) fl_lim = (size_t)cage + 2u;      /* (one context: round 5's thirteen) */
-			/* BT_CLI_INFLIGHT (diagnostics): at cage + 1 the batch behind the oldest one's last launch is submitted only when
-			 * that launch has ended; at cage + 2 (the library's limit is 14) it is enqueued behind it */
-			if (const char* fv = getenv("BT_CLI_INFLIGHT")) { const int v = atoi(fv); if (v >= 2 && v <= 14) fl_lim = (size_t)v; }
+			fl_lim = (size_t)cage + (big_host || n_streams > 1 ? 2u : 1u);
+			/* at cage + 1 the batch behind the oldest one's last launch is submitted only when that launch has ended; at cage + 2
+			 * it is enqueued behind it.  Fewer than cage + 1 would wait for a batch that cannot complete yet. */
+			if (const char* fv = getenv("BT_CLI_INFLIGHT")) { const int v = atoi(fv); if (v >= cage + 1 && v <= 62) fl_lim = (size_t)v; }
+			n_ticks = cage + 2;
 			if (bt_ctx_set_carry(ctxs[g], cage) != BT_OK) die("Error: bt_ctx_set_carry failed");
 			rc = bt_ctx_create(idxs[g % ND], &O.pol, nullptr, &redo_ctxs[g]);
 			if (rc != BT_OK) die("Error: bad alignment options: %s", bt_strerror(rc));
@@ -1633,7 +1646,7 @@ int main(int argc, char** argv)
 				 * 3.9 s of formatting and writing that overlapped nothing in round 4's timeline).  After as many ticks as a
 				 * read may ride along, whatever is left is flushed. */
 				if (!abort_run.load() && !getenv("BT_CLI_NO_TICKS")) {
-					for (int tick = 0; tick < 14 && !fl.empty(); tick++) {
+					for (int tick = 0; tick < n_ticks && !fl.empty(); tick++) {
 						drain(0);
 						if (fl.empty()) break;
 						if (bt_align_stream_tick(cs, 0) != BT_OK) break;

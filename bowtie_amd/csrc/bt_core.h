@@ -194,7 +194,10 @@ struct BtWarm {
 #else
 #define BT_WROWLIM() WSEL(len)
 #endif
-#define BT_BATCH_RING 16
+/* batches whose reads may be in flight at once (carry-over): a read rides along for at most BT_BATCH_RING - 2 launches.  16 until
+ * round 6: at twelve launches of 12 M reads the hardest reads of a batch were not done, and every launch from the thirteenth on
+ * ended with half a second of the machine waiting for them */
+#define BT_BATCH_RING 64
 struct BtCold {
 	BtProgram  P;
 	BtIndexDev ix[2];            /* [0] index of the text, [1] mirror index */
@@ -320,7 +323,7 @@ struct BtLane {
 	/* searcher (GreedyDFSRangeSource members) */
 	uint32_t qlen : 11, mirror : 1, readFw : 1, rev : 1, reportExacts : 1, considerQuals : 1, halfAndHalf : 1,
 	         maq : 1, reportPartials : 2, bailed : 1, nsFtab0 : 1;
-	uint32_t d5 : 11, d3 : 11, bid : 4;          /* bid: the read's batch is C.ring[bid] */
+	uint32_t d5 : 11, d3 : 11, bid : 6;          /* bid: the read's batch is C.ring[bid] (BT_BATCH_RING <= 64) */
 	uint32_t unrev : 11, r1 : 11;
 	uint32_t r2 : 11, r3 : 11;
 	uint32_t qualThresh;

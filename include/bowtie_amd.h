@@ -260,7 +260,7 @@ int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_
  * bt_align_stream_collect hands back the oldest submitted batch if it is complete -- its bt_hit_batch filled,
  * `*tag` = the value given at submit -- and `*tag = NULL` otherwise (not complete yet, or nothing in flight): the
  * call does not wait unless flush != 0, which finishes whatever is still being searched (end of input).  At most
- * 14 batches may be in flight.  Reads that outgrow the search scratch come back flagged BT_ST_OVERFLOW (no second
+ * 62 batches may be in flight (BT_BATCH_RING - 2; 14 in rounds 2-5).  Reads that outgrow the search scratch come back flagged BT_ST_OVERFLOW (no second
  * pass on the stream); run them through bt_align_batch.  `in`, `out` and the arrays they point at stay the caller's
  * and must live until the batch is collected.  What the reference does with a FASTQ reader feeding its worker
  * threads. */
@@ -295,7 +295,7 @@ int  bt_ctx_sync(bt_ctx* ctx);
 /* Carry-over between the batches of a context (what the reference's worker threads get for free: a thread that
  * finishes its read takes the next one, whatever "batch" it came from -- ebwt_search.cpp:1180-1230's GET_READ loop).
  * launches = 0 (default): every bt_align_batch_device call runs its batch to the last read before the next one
- * starts.  launches = n (1..14): when a batch's reads have all been handed out, the searches still running are
+ * starts.  launches = n (1..62; 1..14 in rounds 2-5): when a batch's reads have all been handed out, the searches still running are
  * parked and the following call on this context resumes them alongside its own reads -- a read may ride along for
  * up to n launches, after which the launch it is in finishes it -- so the minority of reads that backtrack for a
  * long time never leave the GPU idle.  The contract changes accordingly: the results of a batch are complete when

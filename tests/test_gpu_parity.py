@@ -490,9 +490,12 @@ def test_gpu_carry_over_between_batches(mode, gidx, monkeypatch):
         T.compare_results(g, T.oracle_results("multi", b, kw, cap=cap), "carry-over %s %s" % (mode, r))
 
 
-def test_gpu_carry_over_many_small_launches_equal_one_big(gidx, monkeypatch):
+@pytest.mark.parametrize("per,age", [(1000, 12), (250, 60)], ids=["40x1000_age12", "160x250_age60"])
+def test_gpu_carry_over_many_small_launches_equal_one_big(per, age, gidx, monkeypatch):
     """Size-independent property: 40 k reads as one batch without carry-over and as 40 carried batches of 1 k (512
-    lanes: every launch parks what it was doing, long reads ride through several) give the same per-read results."""
+    lanes: every launch parks what it was doing, long reads ride through several) give the same per-read results.  The
+    second case goes round the ring of batches (BT_BATCH_RING = 64, bt_core.h) two and a half times, with reads allowed to ride
+    through 60 launches."""
     monkeypatch.setenv("BT_MAX_BLOCKS", "2")
     kw = T.MODES["n2"]
     text = T.joined_text("e_coli")
@@ -500,10 +503,10 @@ def test_gpu_carry_over_many_small_launches_equal_one_big(gidx, monkeypatch):
     al = aligner(gidx, "e_coli", kw)
     whole = _device_align(al, big, 80, 1)
     al2 = aligner(gidx, "e_coli", kw)
-    assert AL.lib().bt_ctx_set_carry(al2._h, 12) == 0          # a read may ride along for twelve launches
+    assert AL.lib().bt_ctx_set_carry(al2._h, age) == 0         # a read may ride along for that many launches
     from bowtie_amd.reads import ReadBatch
-    parts = [ReadBatch(big.seq[i:i + 1000], big.qual[i:i + 1000], big.len[i:i + 1000], big.seed[i:i + 1000], big.names[i:i + 1000])
-             for i in range(0, 40000, 1000)]
+    parts = [ReadBatch(big.seq[i:i + per], big.qual[i:i + per], big.len[i:i + per], big.seed[i:i + per], big.names[i:i + per])
+             for i in range(0, 40000, per)]
     got = _device_align_many(al2, parts, 80, 1)
     assert AL.lib().bt_ctx_last_carried(al2._h) > 0
     assert T.result_digest([x for g in got for x in g]) == T.result_digest(whole)
@@ -569,6 +572,55 @@ def test_gpu_host_batches_streamed(carry, gidx, monkeypatch):
             overlaps = [(a, b) for a, b in zip(offs, offs[1:]) if a[0] + a[1] > b[0]][:6]
             raise AssertionError("%s\n%d reads differ: %s ...\nmismatch-list regions that overlap in the pool: %s\nmm_pool_used %d\n%s" %
                                  (e, len(bad), bad[:40], overlaps, int(j["hb"].mm_pool_used), "\n".join(info)))
+
+
+def test_gpu_stream_forty_batches_in_flight(gidx, monkeypatch):
+    """bt_align_stream_submit with more batches in flight than rounds 2-5 had ring slots for (16): 40 host batches of 500
+    reads handed over without waiting for any (512 lanes, reads ride along for up to 38 launches), collected as they
+    complete and flushed at the end -- in order, each read's result the one the whole set gives as one batch."""
+    import ctypes as C
+    monkeypatch.setenv("BT_MAX_BLOCKS", "2")
+    kw = T.MODES["n2"]
+    cap = 1
+    text = T.joined_text("e_coli")
+    big = synth_reads(text, 20000, 76, mm_dist=(0, 1, 2, 2, 3, 4), seed=777)
+    whole = aligner(gidx, "e_coli", kw).align(big, hit_cap=cap)
+    al = aligner(gidx, "e_coli", kw)
+    L = AL.lib()
+    assert L.bt_ctx_set_carry(al._h, 38) == 0
+    from bowtie_amd.reads import ReadBatch
+    jobs = []
+    for i in range(0, 20000, 500):
+        b = ReadBatch(big.seq[i:i + 500].copy(), big.qual[i:i + 500].copy(), big.len[i:i + 500].copy(), big.seed[i:i + 500].copy(), big.names[i:i + 500])
+        k, rb = AL.pack_batch(b)
+        hits = np.zeros(b.n * cap, dtype=A.HIT_DTYPE)
+        n_hits = np.zeros(b.n, dtype=np.uint32)
+        status = np.zeros(b.n, dtype=np.uint8)
+        pool = np.zeros(b.n * cap * 8, dtype=np.uint16)
+        hb = A.HitBatchC(cap, hits.ctypes.data, n_hits.ctypes.data, status.ctypes.data, pool.ctypes.data, len(pool), 0)
+        jobs.append(dict(b=b, keep=k, rb=rb, hits=hits, n_hits=n_hits, status=status, pool=pool, hb=hb))
+    done, tag, most = [], C.c_void_p(), 0
+    for i, j in enumerate(jobs):
+        assert L.bt_align_stream_submit(al._h, C.byref(j["rb"]), C.byref(j["hb"]), C.c_void_p(i + 1)) == 0
+        most = max(most, i + 1 - len(done))
+        if i >= 24 and i % 8 == 7:                           # late, and now and then: whatever is complete by now, oldest first
+            while True:
+                assert L.bt_align_stream_collect(al._h, C.byref(tag), 0) == 0
+                if tag.value is None:
+                    break
+                done.append(tag.value)
+    while True:
+        assert L.bt_align_stream_collect(al._h, C.byref(tag), 1) == 0
+        if tag.value is None:
+            break
+        done.append(tag.value)
+    assert done == list(range(1, len(jobs) + 1))
+    assert most > 16, most                                   # the point of the test
+    pol = al.policy
+    got = []
+    for j in jobs:
+        got += AL.unpack_hits(j["b"].n, cap, j["hits"], j["n_hits"], j["status"], j["pool"], int(pol.khits), int(pol.mhits), bool(pol.all_hits))
+    assert T.result_digest(got) == T.result_digest(whole)
 
 
 # ---- the best-first engine (--best, --strata, -M, -v 3): bt_best_kernel ---------------------------
