@@ -10,6 +10,7 @@
  * Output follows VerboseHitSink::append (hit.cpp:73-301), SAMHitSink::append / reportUnOrMax /
  * appendHeaders (sam.cpp:20-257) and HitSink::finish (hit.h:270-346).
  */
+#include <sys/mman.h>
 #include "bt_io.h"
 
 #include <ctype.h>
@@ -146,6 +147,22 @@ bt_read_batch BtHostBatch::view() const
 /* ---- the stream -------------------------------------------------------------------------- */
 struct BtRec { size_t off; uint32_t len; uint64_t rdid; };
 
+/* The reader's own large blocks (the file window: a batch's raw text, 2.9 GB for 12 M reads; the newline index) are asked to be
+ * backed by transparent huge pages where the host offers them on request: a fault and an unmap per 2 MB instead of per 4 KB
+ * (round 6, GPU call 9: 16 GB first touched by 64 threads in 0.17 s instead of 1.6 s, unmapped in 0.7 s instead of 1.6 s).
+ * BT_IO_HUGEPAGES=0: not asked for. */
+static void advise_huge(void* p, size_t bytes)
+{
+#ifdef MADV_HUGEPAGE
+	static const bool on = !(getenv("BT_IO_HUGEPAGES") && atoi(getenv("BT_IO_HUGEPAGES")) == 0);
+	if (!on || !p || bytes < ((size_t)4u << 20)) return;
+	const uintptr_t a = ((uintptr_t)p + 4095u) & ~(uintptr_t)4095u, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095u;
+	if (e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
+#else
+	(void)p; (void)bytes;
+#endif
+}
+
 /* the file window: grows without being zero-filled (realloc moves big blocks by remapping, not by copying) */
 struct BtWindow {
 	char* p = nullptr; size_t n = 0;
@@ -157,7 +174,7 @@ struct BtWindow {
 	const char* data() const { return p; }
 	size_t size() const { return n; }
 	char& operator[](size_t i) { return p[i]; }
-	void resize(size_t m) { char* q = (char*)realloc(p, m ? m : 1); if (!q) throw std::bad_alloc(); p = q; n = m; }
+	void resize(size_t m) { char* q = (char*)realloc(p, m ? m : 1); if (!q) throw std::bad_alloc(); if (q != p || m > n) advise_huge(q, m); p = q; n = m; }
 };
 
 /* offsets, appended in bulk by several threads (no zero-fill on growth) */
@@ -167,7 +184,7 @@ struct BtOffsets {
 	~BtOffsets() { free(p); }
 	BtOffsets(const BtOffsets&) = delete;
 	BtOffsets& operator=(const BtOffsets&) = delete;
-	void reserve(size_t m) { if (m > cap) { const size_t c = m + m / 4 + 1024; size_t* q = (size_t*)realloc(p, c * sizeof(size_t)); if (!q) throw std::bad_alloc(); p = q; cap = c; } }
+	void reserve(size_t m) { if (m > cap) { const size_t c = m + m / 4 + 1024; size_t* q = (size_t*)realloc(p, c * sizeof(size_t)); if (!q) throw std::bad_alloc(); advise_huge(q, c * sizeof(size_t)); p = q; cap = c; } }
 	size_t size() const { return n; }
 	size_t& operator[](size_t i) { return p[i]; }
 	void resize(size_t m) { reserve(m); n = m; }
@@ -767,7 +784,7 @@ template <class T> struct BtPod {
 	~BtPod() { free(p); }
 	BtPod(const BtPod&) = delete;
 	BtPod& operator=(const BtPod&) = delete;
-	void reserve(size_t m) { if (m > cap) { const size_t c = m + m / 4 + 64; T* q = (T*)realloc((void*)p, c * sizeof(T)); if (!q) throw std::bad_alloc(); p = q; cap = c; } }
+	void reserve(size_t m) { if (m > cap) { const size_t c = m + m / 4 + 64; T* q = (T*)realloc((void*)p, c * sizeof(T)); if (!q) throw std::bad_alloc(); advise_huge(q, c * sizeof(T)); p = q; cap = c; } }
 	void resize_uninit(size_t m) { reserve(m); n = m; }
 	void push_back(const T& v) { reserve(n + 1); p[n++] = v; }
 	void pop_back() { n--; }
