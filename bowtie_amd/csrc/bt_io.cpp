@@ -150,11 +150,13 @@ struct BtRec { size_t off; uint32_t len; uint64_t rdid; };
 /* The reader's own large blocks (the file window: a batch's raw text, 2.9 GB for 12 M reads; the newline index) are asked to be
  * backed by transparent huge pages where the host offers them on request: a fault and an unmap per 2 MB instead of per 4 KB
  * (round 6, GPU call 9: 16 GB first touched by 64 threads in 0.17 s instead of 1.6 s, unmapped in 0.7 s instead of 1.6 s).
- * BT_IO_HUGEPAGES=0: not asked for. */
+ * Only with BT_IO_HUGEPAGES=1: measured in the binary (GPU call 11) it costs more than it saves -- the window grows fill by fill,
+ * every growth is an mremap() and a madvise() under the address space's write lock, and the threads loading the index beside it
+ * fault under the read lock: the first batch was submitted 0.66 s later (1.96 s instead of 1.30 s) for 0.05 s per batch saved. */
 static void advise_huge(void* p, size_t bytes)
 {
 #ifdef MADV_HUGEPAGE
-	static const bool on = !(getenv("BT_IO_HUGEPAGES") && atoi(getenv("BT_IO_HUGEPAGES")) == 0);
+	static const bool on = getenv("BT_IO_HUGEPAGES") && atoi(getenv("BT_IO_HUGEPAGES")) != 0;
 	if (!on || !p || bytes < ((size_t)4u << 20)) return;
 	const uintptr_t a = ((uintptr_t)p + 4095u) & ~(uintptr_t)4095u, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095u;
 	if (e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
