@@ -1755,6 +1755,8 @@ int main(int argc, char** argv)
 	if (!fatal.empty()) { fprintf(stderr, "%s\n", fatal.c_str()); return 1; }
 	if (!O.quiet) { std::string s; bt_io_summary(tally, &s); fputs(s.c_str(), stderr); }
 	if (O.timing) print_timer("Overall time: ", now_s() - t_all);
+	/* the reapers unmap side by side what the process's exit would unmap alone (they no longer hand page-locked arrays back) */
+	if (!full_teardown) { for (auto& x : reapers) x.join(); g_tl.mark("teardown: the last batches' memory let go", 0); }
 	g_tl.mark("end", 0);
 	g_tl.print();
 	/* every file is closed and every stream flushed: leave without the runtime's own teardown (the HIP runtime unloading its
