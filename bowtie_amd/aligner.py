@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("BT_LIB", "libbowtie_amd.so"))
 EXPORTS = ["bt_policy_default", "bt_has_pe_v1", "bt_index_load", "bt_index_info_get", "bt_index_refname",
            "bt_index_reflen", "bt_index_free", "bt_index_restore_text", "bt_index_digest", "bt_index_needs_rows64", "bt_ctx_create", "bt_ctx_destroy", "bt_align_batch",
-           "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_align_stream_submit", "bt_align_stream_collect", "bt_align_stream_tick", "bt_host_alloc", "bt_host_free", "bt_ctx_sync", "bt_ctx_set_carry", "bt_ctx_set_max_read_len", "bt_ctx_span_ms", "bt_ctx_launch_ms", "bt_ctx_last_carried", "bt_ctx_last_kernel_ms", "bt_ctx_last_kernel_name", "bt_ctx_last_mm_used", "bt_ctx_jump_counts", "bt_index_jump_bytes", "bt_ctx_last_retried", "bt_ctx_set_locus", "bt_ctx_get_locus", "bt_index_locus_bytes", "bt_index_locus_build_seconds", "bt_index_locus_copy",
+           "bt_align_batch_device", "bt_index_load_reference", "bt_align_pairs", "bt_align_pairs_device", "bt_align_stream_submit", "bt_align_stream_room", "bt_align_stream_collect", "bt_align_stream_tick", "bt_host_alloc", "bt_host_free", "bt_ctx_sync", "bt_ctx_set_carry", "bt_ctx_set_max_read_len", "bt_ctx_span_ms", "bt_ctx_launch_ms", "bt_ctx_last_carried", "bt_ctx_last_kernel_ms", "bt_ctx_last_kernel_name", "bt_ctx_last_mm_used", "bt_ctx_jump_counts", "bt_index_jump_bytes", "bt_ctx_last_retried", "bt_ctx_set_locus", "bt_ctx_get_locus", "bt_index_locus_bytes", "bt_index_locus_build_seconds", "bt_index_locus_copy",
            "bt_ctx_counts", "bt_ctx_set_iters_buffer", "bt_ctx_prof_sections", "bt_strerror", "bt_version", "bt_rows64", "bt_index_len64", "bt_probe_rank", "bt_probe_rank64", "bt_probe_chase", "bt_bench_gather",
            "bt_reads_open", "bt_reads_next", "bt_reads_raw", "bt_reads_paired_count", "bt_reads_error", "bt_reads_close", "bt_format_hits", "bt_format_pairs",
            "bt_format_sam_header", "bt_format_summary", "bt_text_free"]
@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         L.bt_host_alloc.restype = C.c_void_p
         L.bt_host_free.argtypes = [C.c_void_p]
         L.bt_host_free.restype = None
+        L.bt_align_stream_room.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.bt_index_info_get.argtypes = [C.c_void_p, C.POINTER(A.IndexInfo)]
         L.bt_index_info_get.restype = None
         L.bt_index_refname.argtypes = [C.c_void_p, C.c_uint32]

@@ -1752,6 +1752,27 @@ extern "C" int bt_align_stream_tick(bt_ctx* c, uint32_t min_rounds)
 	return BT_OK;
 }
 
+/* How many batches of this shape the stream may hold in flight as far as the device's memory goes: a batch in flight has a
+ * staging area in HBM (reads in, results out: the layout of bt_align_stream_submit), and a caller that lets two dozen of them
+ * ride (bowtie-amd on a large host) must not find out at the twentieth that the device is full -- a large -k makes the area
+ * several times the reads' size.  Half of what is free now, plus the areas this context already has and is not using. */
+extern "C" int bt_align_stream_room(bt_ctx* c, const bt_read_batch* in, const bt_hit_batch* out, uint32_t* batches)
+{
+	if (!c || !in || !out || !batches || in->n_reads == 0 || out->hit_cap == 0) return BT_ERR_ARG;
+	HIPCHK(hipSetDevice(c->idx->device));
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t n = in->n_reads;
+	const size_t area = 2u * al(n * in->stride) + al(2ull * n) + al(4ull * n) + al(n * out->hit_cap * sizeof(bt_hit)) + al(4ull * n) + al(n) +
+	                    al(2ull * out->mm_pool_cap) + 256u;
+	size_t freeB = 0, totB = 0;
+	if (hipMemGetInfo(&freeB, &totB) != hipSuccess) { (void)hipGetLastError(); return BT_ERR_DEVICE; }
+	{ const size_t v = (size_t)ctx_env(c, "BT_FAKE_FREE_MB", 0) << 20; if (v && v < freeB) freeB = v; }   /* (tests) */
+	uint64_t fit = (uint64_t)(freeB / 2u) / area;
+	if (c->hs) for (auto* x : c->hs->slots) if (x->state == 0 && x->bytes >= area) fit++;
+	*batches = fit > 0xffffffffull ? 0xffffffffu : (uint32_t)fit;
+	return BT_OK;
+}
+
 extern "C" void* bt_host_alloc(size_t bytes)
 {
 	void* p = nullptr;

@@ -1636,6 +1636,9 @@ int main(int argc, char** argv)
 		bt_ctx* cs = ctxs[(size_t)g];
 		bt_ctx* cr = redo_ctxs[(size_t)g];
 		std::deque<std::unique_ptr<Job>> fl;                   /* in flight, oldest first */
+		size_t my_fl = fl_lim;                                 /* this searcher's own: its device may have less room than asked for */
+		int my_ticks = n_ticks;
+		bool sized = false;
 		auto drain = [&](int flush) {
 			while (!fl.empty()) {
 				void* tag = nullptr;
@@ -1666,7 +1669,7 @@ int main(int argc, char** argv)
 				 * 3.9 s of formatting and writing that overlapped nothing in round 4's timeline).  After as many ticks as a
 				 * read may ride along, whatever is left is flushed. */
 				if (!abort_run.load() && !getenv("BT_CLI_NO_TICKS")) {
-					for (int tick = 0; tick < n_ticks && !fl.empty(); tick++) {
+					for (int tick = 0; tick < my_ticks && !fl.empty(); tick++) {
 						drain(0);
 						if (fl.empty()) break;
 						if (bt_align_stream_tick(cs, 0) != BT_OK) break;
@@ -1691,9 +1694,9 @@ int main(int argc, char** argv)
 			 * timeline. */
 			{
 				const double tw = now_s();
-				while (fl.size() >= fl_lim && !abort_run.load()) {
+				while (fl.size() >= my_fl && !abort_run.load()) {
 					drain(0);
-					if (fl.size() < fl_lim) break;
+					if (fl.size() < my_fl) break;
 					/* the oldest batch completes by itself within the time its launches take; if it has not after a minute
 					 * something is wrong on the device: a flush waits for the stream and hands the error out */
 					if (now_s() - tw > 60.0) { drain(1); break; }
@@ -1703,6 +1706,19 @@ int main(int argc, char** argv)
 			g_tl.mark("search: taken", j->seq);
 			search_prepare(O, j.get());
 			g_tl.mark("search: result arrays ready", j->seq);
+			if (!sized) {
+				/* the first batch says how large a batch in flight is on the device (-k and -a make its result slots several
+				 * times the reads' size): no more of them ride than half the free HBM holds, and reads ride two launches fewer */
+				sized = true;
+				uint32_t room = 0;
+				if (bt_align_stream_room(cs, &j->rb, &j->hb, &room) == BT_OK && (size_t)room < my_fl) {
+					my_fl = room < 3u ? 3u : (size_t)room;
+					const int cage = (int)my_fl - 2;
+					if (bt_ctx_set_carry(cs, cage) != BT_OK) { j->error = "Error: bt_ctx_set_carry failed"; }
+					my_ticks = cage + 2;
+					if (O.timing) fprintf(stderr, "The device has room for %u batches of this size in flight: reads ride %d launches, %zu batches in flight\n", room, cage, my_fl);
+				}
+			}
 			const int rc = bt_align_stream_submit(cs, &j->rb, &j->hb, j.get());
 			g_tl.mark("search: submitted (uploaded, launch enqueued)", j->seq);
 			if (rc != BT_OK) {

@@ -276,6 +276,10 @@ uint64_t bt_index_locus_bytes(const bt_index* idx);          /* 0: the index has
 double   bt_index_locus_build_seconds(const bt_index* idx);
 int      bt_index_locus_copy(const bt_index* idx, int mirror, void* loc, void* rtxt, void* walk);   /* tests: the image's arrays to host buffers */
 int  bt_align_stream_submit(bt_ctx* ctx, const bt_read_batch* in, bt_hit_batch* out, void* tag);
+/* *batches = how many batches of this shape (reads, stride, hit_cap, mm_pool_cap) the device has room for in flight: half of
+ * its free memory now, in staging areas of that size, plus the context's idle ones.  For a caller that chooses how many
+ * batches to let ride (the reference's equivalent is the number of worker threads: each holds one read at a time). */
+int  bt_align_stream_room(bt_ctx* ctx, const bt_read_batch* in, const bt_hit_batch* out, uint32_t* batches);
 int  bt_align_stream_collect(bt_ctx* ctx, void** tag, int flush);
 /* With carry-over: one more launch of the context's grid with no new reads.  What is parked runs on for at least
  * `min_rounds` lock-step rounds (0: the library's default) or to its end, is parked again, and what it completes is known as

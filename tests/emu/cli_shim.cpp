@@ -139,6 +139,13 @@ extern "C" int bt_align_pairs(bt_ctx* c, const bt_read_batch* in1, const bt_read
 }
 extern "C" void* bt_host_alloc(size_t bytes) { return bytes ? aligned_alloc(256, (bytes + 255u) & ~(size_t)255u) : nullptr; }
 extern "C" void bt_host_free(void* p) { free(p); }
+/* no device: room for whatever the binary wants in flight (SHIM_STREAM_ROOM: as if the device had room for that many) */
+extern "C" int bt_align_stream_room(bt_ctx*, const bt_read_batch*, const bt_hit_batch*, uint32_t* batches)
+{
+	const char* e = getenv("SHIM_STREAM_ROOM");
+	*batches = e ? (uint32_t)atoi(e) : 1000u;
+	return BT_OK;
+}
 /* --stream: the asynchronous entry points, answered synchronously -- a submitted batch is searched at once and is the next
  * one collected; reads come back flagged rather than as an error code, as from the library's stream */
 extern "C" int bt_ctx_set_carry(bt_ctx* c, int launches) { return c && launches >= 0 && launches <= 14 ? BT_OK : BT_ERR_ARG; }

@@ -71,7 +71,10 @@ def test_formatter_pieces_reach_the_file_in_order(shim, tmp_path):
         assert len(outs[0]) > n * L and outs[0] == outs[1] == outs[2]
         # where the large blocks come from (bt_cli.cpp `bigmem`, the page-locked result arrays) changes no byte of the text:
         # everything from 64 KB up out of the mapped blocks, and nothing at all
-        for knobs in (dict(BT_CLI_BIG_MIN="65536"), dict(BT_CLI_HUGEPAGES="0", BT_CLI_PINNED_RESULTS="0")):
+        # ... nor does a device with room for four batches in flight only (bt_align_stream_room: reads then ride two launches),
+        # nor taking everything down by hand at the end
+        for knobs in (dict(BT_CLI_BIG_MIN="65536"), dict(BT_CLI_HUGEPAGES="0", BT_CLI_PINNED_RESULTS="0"), dict(SHIM_STREAM_ROOM="4"),
+                      dict(SHIM_STREAM_ROOM="1", BT_CLI_TEARDOWN="1")):
             p = subprocess.run([binary, "-p", "3", "--batch", "9000"] + fmt + ["-x", base, str(fq)], env=dict(env, **knobs),
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             assert p.returncode == 0, p.stderr.decode(errors="replace")

@@ -574,6 +574,27 @@ def test_gpu_host_batches_streamed(carry, gidx, monkeypatch):
                                  (e, len(bad), bad[:40], overlaps, int(j["hb"].mm_pool_used), "\n".join(info)))
 
 
+def test_gpu_stream_room_counts_staging_areas(gidx, monkeypatch):
+    """bt_align_stream_room: how many batches of a shape may ride as far as the device's memory goes -- half of what is free, in
+    staging areas laid out as bt_align_stream_submit lays them out.  BT_FAKE_FREE_MB pretends the device has 100 MB free."""
+    import ctypes as C
+    monkeypatch.setenv("BT_FAKE_FREE_MB", "100")
+    al = aligner(gidx, "e_coli", T.MODES["n2_k3"])
+    L = AL.lib()
+    n, stride, cap = 10000, 112, 8
+    pool = n * cap * 6 + 1024
+    rb = A.ReadBatchC(n, stride, 0, 0, 0, 0)
+    hb = A.HitBatchC(cap, 0, 0, 0, 0, pool, 0)
+    room = C.c_uint32(0)
+    assert L.bt_align_stream_room(al._h, C.byref(rb), C.byref(hb), C.byref(room)) == 0
+    r256 = lambda x: (x + 255) & ~255
+    area = 2 * r256(n * stride) + r256(2 * n) + r256(4 * n) + r256(n * cap * 24) + r256(4 * n) + r256(n) + r256(2 * pool) + 256
+    assert room.value == (50 << 20) // area and 5 < room.value < 20, (room.value, area)
+    assert L.bt_align_stream_room(al._h, C.byref(rb), C.byref(hb), None) != 0          # BT_ERR_ARG
+    hb0 = A.HitBatchC(0, 0, 0, 0, 0, pool, 0)
+    assert L.bt_align_stream_room(al._h, C.byref(rb), C.byref(hb0), C.byref(room)) != 0
+
+
 def test_gpu_stream_forty_batches_in_flight(gidx, monkeypatch):
     """bt_align_stream_submit with more batches in flight than rounds 2-5 had ring slots for (16): 40 host batches of 500
     reads handed over without waiting for any (512 lanes, reads ride along for up to 38 launches), collected as they
