@@ -15,6 +15,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -112,10 +113,11 @@ namespace {
 void* big_alloc(size_t bytes) { try { return ::operator new(bytes); } catch (...) { return nullptr; } }
 void big_free(void* p) { ::operator delete(p); }
 
-/* A batch's result arrays live in page-locked memory from the library (bt_host_alloc): the copies back from the device are
- * DMAs at the link's rate then, not the runtime's staged copies into pageable memory -- 0.19 s per batch of 12 M reads, and
- * two seconds at the end of a run, when the eleven batches still in flight come back at once.  BT_CLI_PINNED_RESULTS=0:
- * pageable memory as before.  Small arrays (tests, the last batch of a file) are not worth a page-locking call. */
+/* BT_CLI_PINNED_RESULTS=1: a batch's result arrays live in page-locked memory from the library (bt_host_alloc), so that the
+ * copies back from the device are DMAs, not the runtime's staged copies into pageable memory.  Measured (GPU calls 9-12) it
+ * changes nothing that can be seen -- the batches at the end of a run come back 0.2 s apart because that is how they complete,
+ * not because of the copies -- while page-locking 0.5 GB per batch costs the reader's thread its time and 8 GB of such memory
+ * is half a second of the process's exit: off by default.  Small arrays are never worth a page-locking call. */
 int g_pin_results = -1;
 std::mutex g_pin_m;
 std::unordered_set<void*> g_pinned;
@@ -130,7 +132,7 @@ template <typename T> struct PinAlloc {
 	T* allocate(size_t n)
 	{
 		const size_t bytes = n * sizeof(T);
-		if (g_pin_results < 0) { const char* e = getenv("BT_CLI_PINNED_RESULTS"); g_pin_results = e ? (atoi(e) != 0 ? 1 : 0) : 1; }
+		if (g_pin_results < 0) { const char* e = getenv("BT_CLI_PINNED_RESULTS"); g_pin_results = e && atoi(e) != 0 ? 1 : 0; }
 		if (g_pin_results == 1 && bytes >= ((size_t)1u << 20)) {
 			void* p = bt_host_alloc(bytes);
 			if (p) { std::lock_guard<std::mutex> l(g_pin_m); g_pinned.insert(p); return (T*)p; }
@@ -703,6 +705,44 @@ void print_timer(const char* msg, double secs)
 	fprintf(stderr, "%s%02ld:%02ld:%02ld\n", msg, s / 3600, (s / 60) % 60, s % 60);
 }
 
+/* The formatter's threads, started once.  Until round 6's call 13 the writer started its threads anew for every batch: on the GPU
+ * box's host (256 hardware threads) starting and joining a thread is ~0.8 ms -- its stack is mapped, and unmapped again with a
+ * TLB shoot-down across the machine -- so that 128 threads were 0.1 s per batch before any of them formatted a read
+ * (scripts/r6/fmt_probe.cpp: 12.6 M reads in 0.039 s on 32 fresh threads, 0.102 s on 128, 0.199 s on 256). */
+class WorkPool {
+public:
+	explicit WorkPool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); }); }
+	~WorkPool() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_work_.notify_all(); for (auto& t : th_) t.join(); }
+	/* fn(i) for i in [0, count), handed out in order to whichever thread is free; returns at once.  wait() before the next start(). */
+	void start(size_t count, std::function<void(size_t)> fn)
+	{
+		std::lock_guard<std::mutex> l(m_);
+		fn_ = std::move(fn); count_ = count; next_.store(0); active_ = th_.size(); gen_++;
+		cv_work_.notify_all();
+	}
+	void wait() { std::unique_lock<std::mutex> l(m_); cv_done_.wait(l, [&] { return active_ == 0; }); }
+private:
+	void loop()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			std::unique_lock<std::mutex> l(m_);
+			cv_work_.wait(l, [&] { return stop_ || gen_ != seen; });
+			if (stop_) return;
+			seen = gen_;
+			l.unlock();
+			for (;;) { const size_t i = next_.fetch_add(1); if (i >= count_) break; fn_(i); }
+			l.lock();
+			if (--active_ == 0) cv_done_.notify_all();
+		}
+	}
+	std::mutex m_; std::condition_variable cv_work_, cv_done_;
+	std::vector<std::thread> th_;
+	std::function<void(size_t)> fn_;
+	std::atomic<size_t> next_{0};
+	size_t count_ = 0, active_ = 0; uint64_t gen_ = 0; bool stop_ = false;
+};
+
 /* ---- one batch travelling through the stages ------------------------------------------------ */
 struct Job {
 	bt_read_batch rb;                        /* view into `store` */
@@ -1054,7 +1094,7 @@ int main(int argc, char** argv)
 	/* What neither channel has room for is let go on a thread of its own: unmapping a batch's 5 GB took the writer a third of
 	 * a second per batch at the end of a run, where it is the only stage still working (round 6's timeline).  Once the input is
 	 * exhausted nothing is kept back for the reader any more. */
-	struct Trash { std::unique_ptr<Job> j; std::unique_ptr<ResultBufs> r; std::unique_ptr<BtHostBatch> s; };
+	struct Trash { std::unique_ptr<Job> j; std::unique_ptr<ResultBufs> r; std::unique_ptr<BtHostBatch> s; std::vector<std::string> text; };
 	Chan<std::unique_ptr<Trash>> to_reap(64);
 	std::atomic<bool> input_done(false);
 	const bool full_teardown = getenv("BT_CLI_TEARDOWN") && atoi(getenv("BT_CLI_TEARDOWN")) != 0;
@@ -1331,6 +1371,9 @@ int main(int argc, char** argv)
 				const uint64_t sq = j->seq;
 				to_gpu.put(std::move(j));
 				for (int g = 1; g < G; g++) { std::unique_ptr<Job> e(new Job()); e->last = true; e->seq = sq + (uint64_t)g; to_gpu.put(std::move(e)); }
+				/* the input is through: its window (a batch's raw text: 2.9 GB) goes now, beside the search of the last batches */
+				bt_io_close(rs); rs = nullptr;
+				if (rs2) { bt_io_close(rs2); rs2 = nullptr; }
 				return;
 			}
 			const uint64_t sq = j->seq;
@@ -1345,8 +1388,10 @@ int main(int argc, char** argv)
 	FILE *f_al = nullptr, *f_un = nullptr, *f_max = nullptr;
 	FILE *f_al2 = nullptr, *f_un2 = nullptr, *f_max2 = nullptr;      /* pairs: the second mates' files */
 	std::thread writer([&] {
-		std::vector<std::unique_ptr<Job>> held;              /* finished out of turn */
 		std::vector<std::string> parts;                      /* formatted text, one buffer per piece of a batch */
+		std::unique_ptr<WorkPool> pool;                      /* the formatter's threads */
+		auto write_batches = [&] {
+		std::vector<std::unique_ptr<Job>> held;              /* finished out of turn */
 		uint64_t next_seq = 0; int lasts = 0;
 		for (;;) {
 			std::unique_ptr<Job> j;
@@ -1535,17 +1580,13 @@ int main(int argc, char** argv)
 			double t_wait = 0;                                   /* this thread waiting for a piece's text */
 			if (TF > 1 && segs.size() > 1) {
 				/* pieces are formatted in order of appearance by TF threads and written, in order, by this one as they finish */
-				std::vector<std::thread> th;
-				std::mutex m; std::condition_variable cv; size_t next = 0;
+				std::mutex m; std::condition_variable cv;
 				std::vector<char> ready(segs.size(), 0);
-				for (int t = 0; t < TF; t++) th.emplace_back([&] {
-					for (;;) {
-						size_t si; { std::lock_guard<std::mutex> l(m); si = next++; }
-						if (si >= segs.size()) return;
-						run(si);
-						{ std::lock_guard<std::mutex> l(m); ready[si] = 1; }
-						cv.notify_all();
-					}
+				if (!pool) pool.reset(new WorkPool(TF));
+				pool->start(segs.size(), [&](size_t si) {
+					run(si);
+					{ std::lock_guard<std::mutex> l(m); ready[si] = 1; }
+					cv.notify_all();
 				});
 				for (size_t si = 0; si < segs.size(); si++) {
 					const double tw = now_s();
@@ -1553,7 +1594,7 @@ int main(int argc, char** argv)
 					t_wait += now_s() - tw;
 					put_text(fout, parts[si].data(), parts[si].size());
 				}
-				for (auto& x : th) x.join();
+				pool->wait();
 			} else for (size_t si = 0; si < segs.size(); si++) { run(si); put_text(fout, parts[si].data(), parts[si].size()); }
 			const double tf = now_s();
 			for (size_t si = 0; si < segs.size(); si++) {
@@ -1610,6 +1651,12 @@ int main(int argc, char** argv)
 				let_go(j, rbuf, st);
 			}
 		}
+		};
+		write_batches();
+		if (!full_teardown) (void)pool.release();            /* its threads go with the process: joining 128 of them is 0.1 s */
+		else pool.reset();
+		/* the text buffers (2.5 GB for batches of 12 M reads) are unmapped beside the closing of the files, not before it */
+		if (!parts.empty()) { std::unique_ptr<Trash> t(new Trash()); t->text.swap(parts); to_reap.put(std::move(t)); }
 	});
 
 	/* ---- stage 2: the GPU.  Each searcher owns a context (its own stream and scratch); with two, one
@@ -1756,7 +1803,7 @@ int main(int argc, char** argv)
 	 * of it the runtime's lock passing between this thread and the reapers.  A run that failed, or one asked to
 	 * (BT_CLI_TEARDOWN=1: leak checks), takes everything down in order. */
 	if (full_teardown || !fatal.empty()) {
-		bt_io_close(rs);
+		if (rs) bt_io_close(rs);
 		if (rs2) bt_io_close(rs2);
 		g_tl.mark("teardown: inputs closed", 0);
 		for (bt_ctx* c : ctxs) bt_ctx_destroy(c);

@@ -24,6 +24,10 @@
 #include <zlib.h>
 
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <functional>
 
 /* ---- batch storage ----------------------------------------------------------------------- */
 static void* default_alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255u) & ~(size_t)255u); }
@@ -163,6 +167,64 @@ static void advise_huge(void* p, size_t bytes)
 #else
 	(void)p; (void)bytes;
 #endif
+}
+
+/* f(0) .. f(T - 1) side by side, on threads that are started once and kept.  Until round 6's call 13 every phase of the reader
+ * started T threads of its own and joined them: on the GPU box's host (256 hardware threads) that is ~0.8 ms per thread -- a
+ * stack mapped and unmapped again, with a TLB shoot-down across the machine -- 0.05 s per phase at -p 64, five phases per
+ * batch.  One job at a time: a second caller (another stream read from another thread), or a process that forked after the
+ * pool was made, starts threads of its own as before.  BT_IO_POOL=0: always. */
+namespace {
+struct IoPool {
+	std::mutex job_m;
+	std::mutex m; std::condition_variable cv_work, cv_done;
+	std::vector<std::thread> th;
+	bool stop = false;
+	uint64_t gen = 0; int count = 0; std::atomic<int> next{0}; size_t active = 0;
+	const std::function<void(int)>* fn = nullptr;
+	const pid_t pid = getpid();
+	void loop(uint64_t seen)
+	{
+		for (;;) {
+			std::unique_lock<std::mutex> l(m);
+			cv_work.wait(l, [&] { return stop || gen != seen; });
+			if (stop) return;
+			seen = gen;
+			l.unlock();
+			for (;;) { const int i = next.fetch_add(1); if (i >= count) break; (*fn)(i); }
+			l.lock();
+			if (--active == 0) cv_done.notify_all();
+		}
+	}
+	void run(int T, const std::function<void(int)>& f)
+	{
+		{
+			std::lock_guard<std::mutex> l(m);
+			while ((int)th.size() < T - 1) { const uint64_t g = gen; th.emplace_back([this, g] { loop(g); }); }
+			fn = &f; count = T; next.store(0); active = th.size(); gen++;
+		}
+		cv_work.notify_all();
+		for (;;) { const int i = next.fetch_add(1); if (i >= T) break; f(i); }      /* the caller takes its share */
+		std::unique_lock<std::mutex> l(m);
+		cv_done.wait(l, [&] { return active == 0; });
+	}
+};
+}
+static void par_for(int T, const std::function<void(int)>& f)
+{
+	if (T <= 1) { f(0); return; }
+	static const bool use_pool = !(getenv("BT_IO_POOL") && atoi(getenv("BT_IO_POOL")) == 0);
+	if (use_pool) {
+		static IoPool* const pool = new IoPool();      /* never taken down: its idle threads go with the process, whichever way it leaves */
+		if (getpid() == pool->pid && pool->job_m.try_lock()) {
+			std::lock_guard<std::mutex> g(pool->job_m, std::adopt_lock);
+			pool->run(T, f);
+			return;
+		}
+	}
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++) th.emplace_back(f, t);
+	for (auto& x : th) x.join();
 }
 
 /* the file window: grows without being zero-filled (realloc moves big blocks by remapping, not by copying) */
@@ -866,7 +928,7 @@ static void nl_index_more(BtReadStream* s)
 			else (void)nl_scan(w, a, b, s->nl.p + s->nl.n + cnt[(size_t)t]);
 		};
 		if (T == 1) job(0);
-		else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(job, t); for (auto& x : th) x.join(); }
+		else par_for(T, job);
 	};
 	run(false);
 	for (int t = 0; t < T; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
@@ -914,7 +976,7 @@ static bool fq_more(BtReadStream* s, size_t want = 0)
 			g[(size_t)t] = done;
 		};
 		if (T == 1) rd(0);
-		else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(rd, t); for (auto& x : th) x.join(); }
+		else par_for(T, rd);
 		for (int t = 0; t < T; t++) {
 			const size_t a = room * (size_t)t / (size_t)T, b = room * (size_t)(t + 1) / (size_t)T;
 			got += g[(size_t)t];
@@ -999,7 +1061,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 					mx[(size_t)t] = ml;
 				};
 				if (T == 1) job(0);
-				else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(job, t); for (auto& x : th) x.join(); }
+				else par_for(T, job);
 				for (int t = 0; t < T; t++) if (mx[(size_t)t] > maxline) maxline = mx[(size_t)t];
 				s->pos = nl[c0 + 4u * m - 1u] + 1u;
 				s->nl_cur = c0 + 4u * m;
@@ -1140,11 +1202,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		}
 	};
 	if (T == 1 || n < 4096) { for (int t = 0; t < T; t++) { work(t); if (err_at[(size_t)t] != (size_t)-1) break; } }
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; t++) th.emplace_back(work, t);
-		for (auto& x : th) x.join();
-	}
+	else par_for(T, work);
 	size_t first_err = (size_t)-1; int et = -1;
 	for (int t = 0; t < T; t++) if (err_at[(size_t)t] < first_err) { first_err = err_at[(size_t)t]; et = t; }
 	if (et >= 0) { *err = errs[(size_t)et]; batch->n = 0; return BT_ERR_READS; }
@@ -1172,11 +1230,7 @@ static int next_fastq(BtReadStream* s, uint32_t max_reads, int threads, BtHostBa
 		}
 	};
 	if (T == 1 || n < 4096) { for (int t = 0; t < T; t++) copy_names(t); }
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; t++) th.emplace_back(copy_names, t);
-		for (auto& x : th) x.join();
-	}
+	else par_for(T, copy_names);
 	batch->raw_off.clear(); batch->raw.clear();
 	if (o.flags & BT_READ_KEEP_RAW) {
 		/* the records themselves, for --al/--un/--max: what the reference keeps as readOrigBuf (a final
@@ -1335,11 +1389,7 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 		}
 	};
 	if (T == 1 || nrec < 4096) { for (int t = 0; t < T; t++) work(t); }
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; t++) th.emplace_back(work, t);
-		for (auto& x : th) x.join();
-	}
+	else par_for(T, work);
 	size_t first_err = (size_t)-1; int et = -1;
 	for (int t = 0; t < T; t++) if (err_at[(size_t)t] < first_err) { first_err = err_at[(size_t)t]; et = t; }
 	if (et >= 0) { *err = errs[(size_t)et]; return BT_ERR_READS; }
@@ -1404,11 +1454,7 @@ static int io_next_impl(BtReadStream* s, uint32_t max_reads, int threads, BtHost
 		}
 	};
 	if (T == 1 || n < 4096) { for (int t = 0; t < T; t++) pack(t); }
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; t++) th.emplace_back(pack, t);
-		for (auto& x : th) x.join();
-	}
+	else par_for(T, pack);
 	batch->first_rdid = n ? batch->rdid[0] : 0;
 	return BT_OK;
 }

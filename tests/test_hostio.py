@@ -228,7 +228,9 @@ def test_bulk_reader_is_the_same_whatever_the_fill_and_slice_sizes(tmp_path, see
     for threads, batch, env in ((4, 97, {}), (4, 97, dict(BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64)), (3, 1000, dict(BT_IO_FILL_BYTES=1500, BT_IO_SLICE_BYTES=100)),
                                 (8, 5000, dict(BT_IO_FILL_BYTES=4096, BT_IO_SLICE_BYTES=16)), (4, 97, dict(BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64)),
                                 (4, 97, dict(BT_IO_BULK_MIN=1)), (5, 97, dict(BT_IO_BULK_MIN=3, BT_IO_FILL_BYTES=700, BT_IO_SLICE_BYTES=64)),
-                                (8, 5000, dict(BT_IO_BULK_MIN=1, BT_IO_FILL_BYTES=100000)), (3, 333, dict(BT_IO_BULK_MIN=2, BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=2000))):
+                                (8, 5000, dict(BT_IO_BULK_MIN=1, BT_IO_FILL_BYTES=100000)), (3, 333, dict(BT_IO_BULK_MIN=2, BT_IO_NO_RAW=1, BT_IO_FILL_BYTES=2000)),
+                                # BT_IO_POOL=0: every phase on threads of its own, as until round 6 (the default keeps them: par_for in bt_io.cpp)
+                                (4, 97, dict(BT_IO_POOL=0, BT_IO_BULK_MIN=1)), (5, 1000, dict(BT_IO_POOL=0, BT_IO_FILL_BYTES=1500, BT_IO_SLICE_BYTES=100))):
         got = run(spec, threads, batch, **env)
         if batch == 97 or want.startswith("ok"):
             assert got == want, (threads, batch, env)
@@ -236,6 +238,31 @@ def test_bulk_reader_is_the_same_whatever_the_fill_and_slice_sizes(tmp_path, see
             assert got.split(" ", 2)[2] == want.split(" ", 2)[2], (threads, batch, env)       # the same error, whatever the batch it falls into
     assert run(spec_gz, 4, 97, BT_IO_FILL_BYTES=300, BT_IO_SLICE_BYTES=64) == want
     assert run(spec_gz, 4, 97, BT_IO_BULK_MIN=1) == want
+
+
+def test_two_streams_parsed_at_once_from_two_threads(tmp_path):
+    """The reader's phases run on a pool of threads that is kept (par_for, bt_io.cpp) and does one job at a time: a second stream
+    parsed from another thread at the same moment starts threads of its own.  Both get what one alone gets."""
+    import threading
+    from bowtie_amd import hostio as H
+    rng = np.random.default_rng(77)
+    files, want = [], []
+    for k in range(2):
+        f = tmp_path / ("s%d.fq" % k)
+        f.write_bytes(b"".join(r for r in _messy_fastq(rng, 12000) if b"-" not in r.split(b"\n")[1]))
+        files.append(str(f))
+        want.append([(b.n, b.seq.tobytes(), b.qual.tobytes(), b.len.tobytes(), list(b.names)) for b in H.read_batches(str(f), max_reads=5000, threads=1)])
+    for _ in range(3):
+        got = [None, None]
+
+        def work(k):
+            got[k] = [(b.n, b.seq.tobytes(), b.qual.tobytes(), b.len.tobytes(), list(b.names)) for b in H.read_batches(files[k], max_reads=5000, threads=4)]
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert got[0] == want[0] and got[1] == want[1]
 
 
 def test_file_ending_inside_a_record_follows_the_reference(tmp_path):
