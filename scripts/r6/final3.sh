@@ -1,12 +1,10 @@
 #!/bin/bash
 # Third final GPU call of round 6 (the tree left on main after bt_align_stream_room, the thread pools of the reader and the formatter, page-locked results off; nothing
 # but documents is written after it): what the driver runs at the round's end, then the profiles the bench line cites.
-#  1. python -m pytest tests -x -q -m gpu (the driver's command), then the whole suite twice more six-wide without -x; smoke()
+#  1. python -m pytest tests -x -q -m gpu (the driver's command); smoke()
 #  2. python bench.py (the default command: CPU baseline, --also auto)
-#  3. rocprofv3 --kernel-trace --stats of the default workload (2 steps)
-#  4. PMC: FETCH_SIZE / WRITE_SIZE of bt_search_kernel at 64 M reads per launch and of bt_best_kernel on config 5's share
-#     (profiles/traffic.json), SQ issue / wait counters of the final search kernel (16 M reads, carry-over 12: as round 5's)
-#  5. bowtie-amd 192 M reads file -> /dev/null at 8 M and at 16 M reads per batch
+#  3. rocprofv3 --kernel-trace --stats of the default workload (2 steps)   (no PMC: the kernels' sources are final2's)
+#  4. bowtie-amd 192 M reads file -> /dev/null: the defaults three times ten seconds apart, once right behind, two switches
 #   gpurun --timeout 2400 -- 'bash scripts/r6/final3.sh'
 export TMPDIR=/tmp
 R=$PWD
