@@ -1583,7 +1583,16 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	HIPCHK(hipSetDevice(c->idx->device));
 	if (!c->hs) {
 		c->hs = new bt_stream();
-		HIPCHK(hipStreamCreateWithFlags(&c->hs->copy, hipStreamNonBlocking));
+		/* The copy stream must not share a hardware queue with a stream that launches: the runtime deals its streams onto a few
+		 * queues (four by default) and a queue runs its packets in order, so a copy dealt onto the searching stream's queue
+		 * waits for the launch that is running -- 0.75 s per collected batch in the middle of a long run, with the next
+		 * submission waiting behind it (round 6, GPU call 14: a 640 M-read run stalled 2-3 s every few batches).  Streams of
+		 * another priority come from another set of queues.  BT_COPY_STREAM_PRIORITY=0: an ordinary stream as until then. */
+		int prLeast = 0, prGreatest = 0;
+		if (ctx_env(c, "BT_COPY_STREAM_PRIORITY", 1) && hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest) == hipSuccess && prGreatest != prLeast) {
+			if (hipStreamCreateWithPriority(&c->hs->copy, hipStreamNonBlocking, prGreatest) != hipSuccess) { (void)hipGetLastError(); c->hs->copy = nullptr; }
+		} else (void)hipGetLastError();
+		if (!c->hs->copy) HIPCHK(hipStreamCreateWithFlags(&c->hs->copy, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&c->hs->searched, hipEventDisableTiming));
 	}
 	bt_stream& S = *c->hs;
