@@ -1583,16 +1583,7 @@ extern "C" int bt_align_stream_submit(bt_ctx* c, const bt_read_batch* in, bt_hit
 	HIPCHK(hipSetDevice(c->idx->device));
 	if (!c->hs) {
 		c->hs = new bt_stream();
-		/* The copy stream must not share a hardware queue with a stream that launches: the runtime deals its streams onto a few
-		 * queues (four by default) and a queue runs its packets in order, so a copy dealt onto the searching stream's queue
-		 * waits for the launch that is running -- 0.75 s per collected batch in the middle of a long run, with the next
-		 * submission waiting behind it (round 6, GPU call 14: a 640 M-read run stalled 2-3 s every few batches).  Streams of
-		 * another priority come from another set of queues.  BT_COPY_STREAM_PRIORITY=0: an ordinary stream as until then. */
-		int prLeast = 0, prGreatest = 0;
-		if (ctx_env(c, "BT_COPY_STREAM_PRIORITY", 1) && hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest) == hipSuccess && prGreatest != prLeast) {
-			if (hipStreamCreateWithPriority(&c->hs->copy, hipStreamNonBlocking, prGreatest) != hipSuccess) { (void)hipGetLastError(); c->hs->copy = nullptr; }
-		} else (void)hipGetLastError();
-		if (!c->hs->copy) HIPCHK(hipStreamCreateWithFlags(&c->hs->copy, hipStreamNonBlocking));
+		HIPCHK(hipStreamCreateWithFlags(&c->hs->copy, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&c->hs->searched, hipEventDisableTiming));
 	}
 	bt_stream& S = *c->hs;
@@ -1679,6 +1670,12 @@ extern "C" int bt_align_stream_collect(bt_ctx* c, void** tag, int flush)
 			if (!complete) return BT_OK;
 			const int r2 = stream_copy_back(c, s, ctx_env(c, "BT_STREAM_ORDERED", 0) != 0);
 			if (r2 != BT_OK) return r2;
+			/* The copies are enqueued; they run when the launch that is searching lets them (on this device a copy does not
+			 * start beside the persistent kernel: it waits for the launch's end, whatever stream, priority or memory it uses --
+			 * round 6, GPU calls 14-16).  Waiting for them here kept the caller from submitting for that long, 0.75 s per
+			 * collected batch, and the stream ran dry every few batches of a long run: ask again later instead (the caller
+			 * polls; the batch is in state "copying" and the next call looks at its event only). */
+			if (!ctx_env(c, "BT_STREAM_COLLECT_WAITS", 0) && hipEventQuery(s.done) != hipSuccess) { (void)hipGetLastError(); return BT_OK; }
 		} else {
 			if (!flush) return BT_ERR_ARG;                          /* cannot happen: uncarried batches are copied back at submit */
 			const int rc = ctx_flush_carry(c);
