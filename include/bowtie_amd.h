@@ -263,7 +263,9 @@ int  bt_align_pairs_device(bt_ctx* ctx, const bt_read_batch* in1, const bt_read_
  * 62 batches may be in flight (BT_BATCH_RING - 2; 14 in rounds 2-5).  Reads that outgrow the search scratch come back flagged BT_ST_OVERFLOW (no second
  * pass on the stream); run them through bt_align_batch.  `in`, `out` and the arrays they point at stay the caller's
  * and must live until the batch is collected.  What the reference does with a FASTQ reader feeding its worker
- * threads. */
+ * threads.  (Measured on MI355X, round 6: a copy does not start while a launch's persistent kernel holds the device's
+ * registers -- uploads and results move in the gaps between launches, some 0.05 s of a 0.77 s cadence at 12 M reads per
+ * batch -- which is why a collect with flush == 0 never waits for them: poll.) */
 /* Locus mode (csrc/bt_rank.h "the locus image"): the phase-program engine replaces, from the step at which a
  * range is one BWT row, the reference's row-by-row mapLF1 / mapLFEx steps (ebwt_search_backtrack.h:544-566, ebwt.h:2334-2380,
  * 2494-2512) by comparisons with the text, and the SA walk of a reported row (Ebwt::reportChaseOne, ebwt.h:2693-2755) by a
